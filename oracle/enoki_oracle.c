@@ -1,0 +1,694 @@
+/*
+ * oracle/enoki_oracle.c -- TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C CPU restatement of the reference's scalar/AVX2 `DynamicArray<Packet<T,8>>`
+ * path for the north-star hot path.  It is the *checker* for
+ * the HIP kernels: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg may load it.  The product (libenoki-hip.so and everything above it) never links,
+ * imports or calls anything in this directory.
+ *
+ * Parity pinning: every function here is compared bit-for-bit (integer / mask / index /
+ * IEEE ops and sin/cos/exp/log) or within the documented class bounds (rcp, rsqrt,
+ * order-dependent reductions) against oracle/_ref/libenoki_ref.so -- the UNMODIFIED
+ * reference headers compiled with the pinned flags -- by tests/test_oracle_vs_ref.py,
+ * and against the committed fixtures in tests/golden/ (generated from that same build by
+ * tests/golden/make_golden.py).
+ *
+ * Build: gcc -std=c11 -O2 -mavx2 -mfma -ffp-contract=off -fno-math-errno (oracle/Makefile).
+ * -ffp-contract=off matters: only the explicit fmaf() calls below are fused, mirroring the
+ * explicit enoki::fmadd() calls of the reference.
+ *
+ * All file:line citations are relative to /root/reference.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#define PKT 8 /* Packet<float,8>: BASELINE.json config 1 */
+
+/* type codes shared with include/enoki_hip.h */
+enum { T_BOOL = 0, T_I32 = 1, T_U32 = 2, T_I64 = 3, T_U64 = 4, T_F32 = 5, T_F64 = 6 };
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+static inline float u2f(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint64_t d2u(double f) { uint64_t u; memcpy(&u, &f, 8); return u; }
+static inline double u2d(uint64_t u) { double f; memcpy(&f, &u, 8); return f; }
+
+/* ------------------------------------------------------------------------------------ */
+/*  f32 building blocks, AVX2 packet semantics                                            */
+/* ------------------------------------------------------------------------------------ */
+
+/* include/enoki/array_avx.h min_/max_ issue _mm256_min_ps(b, a) / _mm256_max_ps(b, a) (operands
+   swapped), i.e. (b < a) ? b : a -- the FIRST enoki operand wins when the compare is unordered. */
+static inline float min_ps(float a, float b) { return b < a ? b : a; }
+static inline float max_ps(float a, float b) { return b > a ? b : a; }
+
+/* cvttps2dq: truncation; NaN / out of range -> 0x80000000 ("integer indefinite") */
+static inline int32_t cvtt_f32_i32(float a) {
+    if (!(a > -2147483904.0f && a < 2147483648.0f)) return INT32_MIN;
+    return (int32_t) a;
+}
+
+/* detail::sincos_approx<Sin, Cos>, include/enoki/array_math.h:261-367 (float branch) */
+static void sincos_f32(float x, float *s_out, float *c_out) {
+    float xa = fabsf(x);                                         /* :297 */
+    int32_t j = cvtt_f32_i32(xa * 1.2732395447351626862f);       /* :300 IntArray j(xa * 4/pi) */
+    j = (int32_t) (((uint32_t) j + 1u) & ~1u);                   /* :303 */
+    float y = (float) j;                                         /* :306 */
+
+    uint32_t sign_sin = ((uint32_t) j << 29) ^ f2u(x);           /* :313 sl<29>(j) ^ x */
+    uint32_t sign_cos = (~((uint32_t) j - 2u)) << 29;            /* :316 */
+
+    /* :320-323 -- operators, not fmadd: four separately rounded mul/sub with contraction off */
+    float t = xa - y * 0.78515625f;
+    t = t - y * 2.4187564849853515625e-4f;
+    t = t - y * 3.77489497744594108e-8f;
+    y = t;
+
+    float z = y * y;                                             /* :330 */
+    if (xa == INFINITY) z = u2f(f2u(z) | 0xffffffffu);           /* :331 z |= eq(xa, inf) */
+
+    /* poly2 (array_math.h:25-29): fmadd(x2, c2, fmadd(x, c1, c0)) with x2 = x*x */
+    float z2 = z * z;
+    float s = fmaf(z2, -1.9515295891e-4f, fmaf(z, 8.3321608736e-3f, -1.6666654611e-1f)) * z;   /* :334 */
+    float c = fmaf(z2, 2.443315711809948e-5f, fmaf(z, -1.388731625493765e-3f, 4.166664568298827e-2f)) * z; /* :338 */
+
+    s = fmaf(s, y, y);                                           /* :357 */
+    c = fmaf(c, z, fmaf(z, -0.5f, 1.0f));                        /* :358 */
+
+    int polymask = (j & 2) == 0;                                 /* :360 */
+    if (s_out) *s_out = u2f(f2u(polymask ? s : c) ^ (sign_sin & 0x80000000u)); /* :363 mulsign */
+    if (c_out) *c_out = u2f(f2u(polymask ? c : s) ^ (sign_cos & 0x80000000u)); /* :366 */
+}
+
+/* exp, include/enoki/array_math.h:711-776 (float branch) */
+static float exp_f32(float x) {
+    int overflow = x > 88.3762588501f, underflow = x < -88.3762588501f;   /* :727-731 */
+    float n = floorf(fmaf(1.4426950408889634073599f, x, 0.5f));             /* :738 */
+    float xr = x;
+    xr = fmaf(-n, 0.693359375f, xr);                                         /* :742 fnmadd */
+    xr = fmaf(-n, -2.12194440e-4f, xr);                                      /* :743 */
+    /* poly5 (array_math.h:49-55) */
+    float x2 = xr * xr, x4 = x2 * x2;
+    float z = fmaf(x2, fmaf(xr, 8.3334519073e-3f, 4.1665795894e-2f),
+                   fmaf(x4, fmaf(xr, 1.9875691500e-4f, 1.3981999507e-3f),
+                        fmaf(xr, 1.6666665459e-1f, 5.0000001201e-1f)));      /* :752-754 */
+    z = fmaf(z, xr * xr, xr + 1.0f);                                         /* :755 */
+    /* ldexp (:677-680): z * reinterpret(sl<23>(int(n) + 0x7f)) */
+    int32_t ni = cvtt_f32_i32(n);
+    float scale = u2f(((uint32_t) ni + 0x7fu) << 23);
+    float r = z * scale;
+    return overflow ? INFINITY : (underflow ? 0.0f : r);                     /* :774-775 */
+}
+
+/* log, include/enoki/array_math.h:778-898 (float branch, !has_avx512f) */
+static float log_f32(float x) {
+    int valid = x >= 0.0f;                                                   /* :797 */
+    /* frexp(x) (:682-709) -- note the reference calls frexp on x, not on max(x, limit) (:811) */
+    uint32_t xi = f2u(x);
+    uint32_t exponent_bits = xi & 0x7f800000u;
+    int is_normal = (x != 0.0f) && (exponent_bits != 0x7f800000u);
+    int32_t exponent_i = (int32_t) (exponent_bits >> 23) - 0x7f;
+    uint32_t mantissa = (xi & ~0x7f800000u) | f2u(0.5f);
+    float xm = u2f(is_normal ? mantissa : xi);
+    float e = (float) (is_normal ? exponent_i : 0);
+
+    int ge = xm >= 0.70710678118654752440f;                                  /* :815 */
+    if (ge) e += 1.0f;                                                       /* :818 */
+
+    xm += (ge ? 0.0f : xm) - 1.0f;                                           /* :822 xm += (xm & ~mask) - 1 */
+
+    float z = xm * xm;                                                       /* :824 */
+    /* poly8 (array_math.h:75-82) */
+    float x2 = z, x4 = x2 * x2, x8 = x4 * x4;
+    float y = fmaf(x4, fmaf(x2, fmaf(xm, -1.1514610310e-1f, 1.1676998740e-1f),
+                              fmaf(xm, -1.2420140846e-1f, 1.4249322787e-1f)),
+                   fmaf(x2, fmaf(xm, -1.6668057665e-1f, 2.0000714765e-1f),
+                        fmaf(xm, -2.4999993993e-1f, 3.3333331174e-1f) + 7.0376836292e-2f * x8)); /* :825-829 */
+    y *= xm * z;                                                             /* :832 */
+    y = fmaf(e, -2.12194440e-4f, y);                                         /* :834 */
+    z = fmaf(z, -0.5f, xm + y);                                              /* :835 */
+    float r = fmaf(e, 0.693359375f, z);                                      /* :836 */
+
+    if (x == INFINITY) r = INFINITY;                                         /* :894 */
+    if (x == 0.0f) r = -INFINITY;                                            /* :895 */
+    return valid ? r : u2f(f2u(r) | 0xffffffffu);                            /* :897 r | ~valid_mask */
+}
+
+/* ------------------------------------------------------------------------------------ */
+/*  generic dispatch helpers                                                              */
+/* ------------------------------------------------------------------------------------ */
+
+static int is(const char *a, const char *b) { return strcmp(a, b) == 0; }
+
+static inline uint32_t lzcnt32(uint32_t v) { return v ? (uint32_t) __builtin_clz(v) : 32u; }
+static inline uint32_t tzcnt32(uint32_t v) { return v ? (uint32_t) __builtin_ctz(v) : 32u; }
+static inline uint64_t lzcnt64(uint64_t v) { return v ? (uint64_t) __builtin_clzll(v) : 64u; }
+static inline uint64_t tzcnt64(uint64_t v) { return v ? (uint64_t) __builtin_ctzll(v) : 64u; }
+
+/* ------------------------------------------------------------------------------------ */
+/*  unary                                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+static int unary_f32(const char *op, const float *a, float *o, size_t n) {
+#define LOOP(expr) do { for (size_t i = 0; i < n; ++i) { float x = a[i]; (void) x; o[i] = (expr); } return 0; } while (0)
+    if (is(op, "neg"))   LOOP(u2f(f2u(x) ^ 0x80000000u));          /* array_avx.h neg_: xor sign bit */
+    if (is(op, "abs"))   LOOP(u2f(f2u(x) & 0x7fffffffu));
+    if (is(op, "sqrt"))  LOOP(sqrtf(x));
+    if (is(op, "rcp"))   LOOP(1.0f / x);    /* class C: reference uses rcpps + 1 NR step (array_avx.h:324-357) */
+    if (is(op, "rsqrt")) LOOP(1.0f / sqrtf(x)); /* class C (array_avx.h:359-395) */
+    if (is(op, "floor")) LOOP(floorf(x));
+    if (is(op, "ceil"))  LOOP(ceilf(x));
+    if (is(op, "round")) LOOP(rintf(x));    /* nearest-even, array_router.h:254 */
+    if (is(op, "trunc")) LOOP(truncf(x));
+    if (is(op, "exp"))   LOOP(exp_f32(x));
+    if (is(op, "log"))   LOOP(log_f32(x));
+    if (is(op, "sign"))  LOOP(u2f((f2u(x) & 0x80000000u) | f2u(1.0f))); /* array_router.h:371 */
+#undef LOOP
+    if (is(op, "sin")) { for (size_t i = 0; i < n; ++i) sincos_f32(a[i], &o[i], NULL); return 0; }
+    if (is(op, "cos")) { for (size_t i = 0; i < n; ++i) sincos_f32(a[i], NULL, &o[i]); return 0; }
+    return -1;
+}
+
+static int unary_f64(const char *op, const double *a, double *o, size_t n) {
+#define LOOP(expr) do { for (size_t i = 0; i < n; ++i) { double x = a[i]; o[i] = (expr); } return 0; } while (0)
+    if (is(op, "neg"))   LOOP(u2d(d2u(x) ^ 0x8000000000000000ull));
+    if (is(op, "abs"))   LOOP(u2d(d2u(x) & 0x7fffffffffffffffull));
+    if (is(op, "sqrt"))  LOOP(sqrt(x));
+    if (is(op, "floor")) LOOP(floor(x));
+    if (is(op, "ceil"))  LOOP(ceil(x));
+    if (is(op, "round")) LOOP(rint(x));
+    if (is(op, "trunc")) LOOP(trunc(x));
+#undef LOOP
+    return -1;
+}
+
+#define DEF_UNARY_INT(NAME, T, UT, BITS, LZ, TZ, POP)                                         \
+    static int NAME(const char *op, const T *a, T *o, size_t n) {                             \
+        for (size_t i = 0; i < n; ++i) {                                                      \
+            UT x = (UT) a[i];                                                                 \
+            if      (is(op, "neg"))    o[i] = (T) (0 - x);                                    \
+            else if (is(op, "not"))    o[i] = (T) ~x;                                         \
+            else if (is(op, "abs"))    o[i] = (T) (((T) x < 0) ? (0 - x) : x);                \
+            else if (is(op, "popcnt")) o[i] = (T) POP(x);                                     \
+            else if (is(op, "lzcnt"))  o[i] = (T) LZ(x);                                      \
+            else if (is(op, "tzcnt"))  o[i] = (T) TZ(x);                                      \
+            else return -1;                                                                   \
+        }                                                                                     \
+        return 0;                                                                             \
+    }
+DEF_UNARY_INT(unary_i32, int32_t, uint32_t, 32, lzcnt32, tzcnt32, __builtin_popcount)
+DEF_UNARY_INT(unary_u32, uint32_t, uint32_t, 32, lzcnt32, tzcnt32, __builtin_popcount)
+DEF_UNARY_INT(unary_i64, int64_t, uint64_t, 64, lzcnt64, tzcnt64, __builtin_popcountll)
+DEF_UNARY_INT(unary_u64, uint64_t, uint64_t, 64, lzcnt64, tzcnt64, __builtin_popcountll)
+
+int orc_unary(int type, const char *op, const void *a, void *out, size_t n) {
+    switch (type) {
+        case T_I32: return unary_i32(op, (const int32_t *) a, (int32_t *) out, n);
+        case T_U32: return unary_u32(op, (const uint32_t *) a, (uint32_t *) out, n);
+        case T_I64: return unary_i64(op, (const int64_t *) a, (int64_t *) out, n);
+        case T_U64: return unary_u64(op, (const uint64_t *) a, (uint64_t *) out, n);
+        case T_F32: return unary_f32(op, (const float *) a, (float *) out, n);
+        case T_F64: return unary_f64(op, (const double *) a, (double *) out, n);
+    }
+    return -2;
+}
+
+int orc_sincos(int type, const void *a_, void *s_, void *c_, size_t n) {
+    if (type != T_F32) return -2;
+    const float *a = (const float *) a_;
+    float *s = (float *) s_, *c = (float *) c_;
+    for (size_t i = 0; i < n; ++i) sincos_f32(a[i], &s[i], &c[i]);
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/*  binary / ternary                                                                      */
+/* ------------------------------------------------------------------------------------ */
+
+/* safe_mul / safe_fmadd: CPU branch of src/autodiff/autodiff.cpp:1191-1221 */
+static inline float safe_mul_f32(float w, float g) { return (w == 0.0f || g == 0.0f) ? 0.0f : w * g; }
+static inline float safe_fmadd_f32(float w, float g, float acc) {
+    return (w == 0.0f || g == 0.0f) ? acc : fmaf(w, g, acc);
+}
+
+static int binary_f32(const char *op, const float *a, const float *b, float *o, size_t n) {
+#define LOOP(expr) do { for (size_t i = 0; i < n; ++i) { float x = a[i], y = b[i]; o[i] = (expr); } return 0; } while (0)
+    if (is(op, "add")) LOOP(x + y);
+    if (is(op, "sub")) LOOP(x - y);
+    if (is(op, "mul")) LOOP(x * y);
+    if (is(op, "div")) LOOP(x / y);
+    if (is(op, "min")) LOOP(min_ps(x, y));
+    if (is(op, "max")) LOOP(max_ps(x, y));
+    if (is(op, "safe_mul")) LOOP(safe_mul_f32(x, y));
+#undef LOOP
+    return -1;
+}
+
+static int binary_f64(const char *op, const double *a, const double *b, double *o, size_t n) {
+#define LOOP(expr) do { for (size_t i = 0; i < n; ++i) { double x = a[i], y = b[i]; o[i] = (expr); } return 0; } while (0)
+    if (is(op, "add")) LOOP(x + y);
+    if (is(op, "sub")) LOOP(x - y);
+    if (is(op, "mul")) LOOP(x * y);
+    if (is(op, "div")) LOOP(x / y);
+    if (is(op, "min")) LOOP(y < x ? y : x);
+    if (is(op, "max")) LOOP(y > x ? y : x);
+#undef LOOP
+    return -1;
+}
+
+/* Integer semantics of the AVX2 packets:
+   - add/sub/mul wrap (two's complement);  div/mod are C truncating division (scalar loops in the reference);
+   - variable shifts (vpsllvd/vpsrlvd/vpsravd, array_avx2.h sl_/sr_): count >= BITS gives 0 (or sign fill for
+     arithmetic right shift) rather than wrapping the count;
+   - mulhi: high half of the full product (array_fallbacks.h mulhi_scalar). */
+#define DEF_BINARY_INT(NAME, T, UT, WT, BITS, SIGNED)                                          \
+    static int NAME(const char *op, const T *a, const T *b, T *o, size_t n) {                  \
+        for (size_t i = 0; i < n; ++i) {                                                       \
+            T x = a[i], y = b[i];                                                              \
+            UT ux = (UT) x, uy = (UT) y;                                                       \
+            if      (is(op, "add")) o[i] = (T) (ux + uy);                                      \
+            else if (is(op, "sub")) o[i] = (T) (ux - uy);                                      \
+            else if (is(op, "mul")) o[i] = (T) (ux * uy);                                      \
+            else if (is(op, "div")) o[i] = (T) (x / y);                                        \
+            else if (is(op, "mod")) o[i] = (T) (x % y);                                        \
+            else if (is(op, "min")) o[i] = x < y ? x : y;                                      \
+            else if (is(op, "max")) o[i] = x > y ? x : y;                                      \
+            else if (is(op, "and")) o[i] = (T) (ux & uy);                                      \
+            else if (is(op, "or"))  o[i] = (T) (ux | uy);                                      \
+            else if (is(op, "xor")) o[i] = (T) (ux ^ uy);                                      \
+            else if (is(op, "mulhi")) o[i] = (T) (((WT) x * (WT) y) >> BITS);                  \
+            else if (is(op, "sl"))  o[i] = (T) (uy >= BITS ? 0 : (UT) (ux << uy));             \
+            else if (is(op, "sr")) {                                                           \
+                if (SIGNED) o[i] = (T) (uy >= BITS ? (x < 0 ? (T) -1 : (T) 0) : (T) (x >> uy)); \
+                else        o[i] = (T) (uy >= BITS ? 0 : (UT) (ux >> uy));                     \
+            }                                                                                  \
+            else return -1;                                                                    \
+        }                                                                                      \
+        return 0;                                                                              \
+    }
+DEF_BINARY_INT(binary_i32, int32_t, uint32_t, int64_t, 32, 1)
+DEF_BINARY_INT(binary_u32, uint32_t, uint32_t, uint64_t, 32, 0)
+DEF_BINARY_INT(binary_i64, int64_t, uint64_t, __int128, 64, 1)
+DEF_BINARY_INT(binary_u64, uint64_t, uint64_t, unsigned __int128, 64, 0)
+
+int orc_binary(int type, const char *op, const void *a, const void *b, void *out, size_t n) {
+    switch (type) {
+        case T_I32: return binary_i32(op, (const int32_t *) a, (const int32_t *) b, (int32_t *) out, n);
+        case T_U32: return binary_u32(op, (const uint32_t *) a, (const uint32_t *) b, (uint32_t *) out, n);
+        case T_I64: return binary_i64(op, (const int64_t *) a, (const int64_t *) b, (int64_t *) out, n);
+        case T_U64: return binary_u64(op, (const uint64_t *) a, (const uint64_t *) b, (uint64_t *) out, n);
+        case T_F32: return binary_f32(op, (const float *) a, (const float *) b, (float *) out, n);
+        case T_F64: return binary_f64(op, (const double *) a, (const double *) b, (double *) out, n);
+    }
+    return -2;
+}
+
+int orc_ternary(int type, const char *op, const void *a_, const void *b_, const void *c_, void *out, size_t n) {
+    if (type == T_F32) {
+        const float *a = (const float *) a_, *b = (const float *) b_, *c = (const float *) c_;
+        float *o = (float *) out;
+        for (size_t i = 0; i < n; ++i) {
+            /* array_avx.h fmadd_/fmsub_/fnmadd_/fnmsub_: vfmadd/vfmsub/vfnmadd/vfnmsub, single rounding */
+            if      (is(op, "fmadd"))  o[i] = fmaf(a[i], b[i], c[i]);
+            else if (is(op, "fmsub"))  o[i] = fmaf(a[i], b[i], -c[i]);
+            else if (is(op, "fnmadd")) o[i] = fmaf(-a[i], b[i], c[i]);
+            else if (is(op, "fnmsub")) o[i] = fmaf(-a[i], b[i], -c[i]);
+            else if (is(op, "safe_fmadd")) o[i] = safe_fmadd_f32(a[i], b[i], c[i]);
+            else return -1;
+        }
+        return 0;
+    } else if (type == T_F64) {
+        const double *a = (const double *) a_, *b = (const double *) b_, *c = (const double *) c_;
+        double *o = (double *) out;
+        for (size_t i = 0; i < n; ++i) {
+            if      (is(op, "fmadd"))  o[i] = fma(a[i], b[i], c[i]);
+            else if (is(op, "fmsub"))  o[i] = fma(a[i], b[i], -c[i]);
+            else if (is(op, "fnmadd")) o[i] = fma(-a[i], b[i], c[i]);
+            else if (is(op, "fnmsub")) o[i] = fma(-a[i], b[i], -c[i]);
+            else return -1;
+        }
+        return 0;
+    } else if (type == T_I32 || type == T_U32) {
+        /* integer fmadd = mul.lo + add (array_generic fallbacks) */
+        const uint32_t *a = (const uint32_t *) a_, *b = (const uint32_t *) b_, *c = (const uint32_t *) c_;
+        uint32_t *o = (uint32_t *) out;
+        for (size_t i = 0; i < n; ++i) {
+            if      (is(op, "fmadd"))  o[i] = a[i] * b[i] + c[i];
+            else if (is(op, "fmsub"))  o[i] = a[i] * b[i] - c[i];
+            else if (is(op, "fnmadd")) o[i] = c[i] - a[i] * b[i];
+            else if (is(op, "fnmsub")) o[i] = 0u - a[i] * b[i] - c[i];
+            else return -1;
+        }
+        return 0;
+    }
+    return -2;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/*  compare / select / cast                                                               */
+/* ------------------------------------------------------------------------------------ */
+
+#define DEF_COMPARE(NAME, T)                                                                  \
+    static int NAME(const char *op, const T *a, const T *b, uint8_t *o, size_t n) {           \
+        for (size_t i = 0; i < n; ++i) {                                                      \
+            T x = a[i], y = b[i];                                                             \
+            if      (is(op, "eq"))  o[i] = x == y;                                            \
+            else if (is(op, "neq")) o[i] = x != y;   /* unordered-true, _CMP_NEQ_UQ */        \
+            else if (is(op, "lt"))  o[i] = x < y;                                             \
+            else if (is(op, "le"))  o[i] = x <= y;                                            \
+            else if (is(op, "gt"))  o[i] = x > y;                                             \
+            else if (is(op, "ge"))  o[i] = x >= y;                                            \
+            else return -1;                                                                   \
+        }                                                                                     \
+        return 0;                                                                             \
+    }
+DEF_COMPARE(compare_i32, int32_t) DEF_COMPARE(compare_u32, uint32_t)
+DEF_COMPARE(compare_i64, int64_t) DEF_COMPARE(compare_u64, uint64_t)
+DEF_COMPARE(compare_f32, float)   DEF_COMPARE(compare_f64, double)
+
+int orc_compare(int type, const char *op, const void *a, const void *b, uint8_t *out, size_t n) {
+    switch (type) {
+        case T_I32: return compare_i32(op, (const int32_t *) a, (const int32_t *) b, out, n);
+        case T_U32: return compare_u32(op, (const uint32_t *) a, (const uint32_t *) b, out, n);
+        case T_I64: return compare_i64(op, (const int64_t *) a, (const int64_t *) b, out, n);
+        case T_U64: return compare_u64(op, (const uint64_t *) a, (const uint64_t *) b, out, n);
+        case T_F32: return compare_f32(op, (const float *) a, (const float *) b, out, n);
+        case T_F64: return compare_f64(op, (const double *) a, (const double *) b, out, n);
+    }
+    return -2;
+}
+
+static size_t type_size(int type) {
+    switch (type) {
+        case T_BOOL: return 1;
+        case T_I32: case T_U32: case T_F32: return 4;
+        case T_I64: case T_U64: case T_F64: return 8;
+    }
+    return 0;
+}
+
+/* select_: blendv on raw bits (array_avx.h select_) */
+int orc_select(int type, const uint8_t *m, const void *t, const void *f, void *out, size_t n) {
+    size_t sz = type_size(type);
+    if (!sz) return -2;
+    for (size_t i = 0; i < n; ++i)
+        memcpy((char *) out + i * sz, (const char *) (m[i] ? t : f) + i * sz, sz);
+    return 0;
+}
+
+/* Conversions between array types (array_avx.h / array_avx2.h converting constructors; scalar
+   loops for the 64-bit integer cases).  f32->i32 is cvttps2dq (indefinite = INT_MIN);
+   everything else matches C casts on in-range inputs, which is all the tests feed. */
+int orc_cast(int src, int dst, const void *a, void *out, size_t n) {
+#define CAST_LOOP(ST, DT, EXPR) do { const ST *s = (const ST *) a; DT *d = (DT *) out;       \
+        for (size_t i = 0; i < n; ++i) { ST x = s[i]; d[i] = (DT) (EXPR); } return 0; } while (0)
+#define ROW(SC, ST)                                                                           \
+    if (src == SC) {                                                                          \
+        switch (dst) {                                                                        \
+            case T_I32: if (SC == T_F32) CAST_LOOP(ST, int32_t, cvtt_f32_i32((float) x));    \
+                        CAST_LOOP(ST, int32_t, x);                                            \
+            case T_U32: CAST_LOOP(ST, uint32_t, x);                                           \
+            case T_I64: CAST_LOOP(ST, int64_t, x);                                            \
+            case T_U64: CAST_LOOP(ST, uint64_t, x);                                           \
+            case T_F32: CAST_LOOP(ST, float, x);                                              \
+            case T_F64: CAST_LOOP(ST, double, x);                                             \
+        }                                                                                     \
+    }
+    ROW(T_I32, int32_t) ROW(T_U32, uint32_t) ROW(T_I64, int64_t)
+    ROW(T_U64, uint64_t) ROW(T_F32, float) ROW(T_F64, double)
+#undef ROW
+#undef CAST_LOOP
+    return -2;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/*  gather / scatter / scatter_add  (include/enoki/dynamic.h:478-534)                     */
+/* ------------------------------------------------------------------------------------ */
+
+static int64_t load_index(int itype, const void *idx, size_t i) {
+    switch (itype) {
+        case T_I32: return ((const int32_t *) idx)[i];
+        case T_U32: return ((const uint32_t *) idx)[i];
+        case T_I64: return ((const int64_t *) idx)[i];
+        case T_U64: return (int64_t) ((const uint64_t *) idx)[i];
+    }
+    return 0;
+}
+
+/* out[i] = mask[i] ? base[idx[i]] : 0   (array_router.h:1075-1079 scalar case) */
+int orc_gather(int type, int itype, const void *base, size_t src_size, const void *idx,
+               const uint8_t *mask, void *out, size_t n) {
+    size_t sz = type_size(type);
+    (void) src_size;
+    if (!sz) return -2;
+    for (size_t i = 0; i < n; ++i) {
+        if (mask[i]) memcpy((char *) out + i * sz, (const char *) base + load_index(itype, idx, i) * (int64_t) sz, sz);
+        else         memset((char *) out + i * sz, 0, sz);
+    }
+    return 0;
+}
+
+/* scatter: element order, last writer wins (dynamic.h:498-515 -> per-packet scatter in lane order).
+   scatter_add: sequential read-modify-write in element order (dynamic.h:517-534 ->
+   transform, array_static.h:982-991). */
+int orc_scatter(int type, int itype, int add, void *base, const void *val, const void *idx,
+                const uint8_t *mask, size_t n) {
+    size_t sz = type_size(type);
+    if (!sz) return -2;
+    for (size_t i = 0; i < n; ++i) {
+        if (!mask[i]) continue;
+        char *dst = (char *) base + load_index(itype, idx, i) * (int64_t) sz;
+        const char *src = (const char *) val + i * sz;
+        if (!add) { memcpy(dst, src, sz); continue; }
+        switch (type) {
+            case T_F32: { float d, s; memcpy(&d, dst, 4); memcpy(&s, src, 4); d += s; memcpy(dst, &d, 4); break; }
+            case T_F64: { double d, s; memcpy(&d, dst, 8); memcpy(&s, src, 8); d += s; memcpy(dst, &d, 8); break; }
+            case T_I32: case T_U32: { uint32_t d, s; memcpy(&d, dst, 4); memcpy(&s, src, 4); d += s; memcpy(dst, &d, 4); break; }
+            case T_I64: case T_U64: { uint64_t d, s; memcpy(&d, dst, 8); memcpy(&s, src, 8); d += s; memcpy(dst, &d, 8); break; }
+            default: return -2;
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/*  horizontal reductions (include/enoki/dynamic.h:632-752)                               */
+/* ------------------------------------------------------------------------------------ */
+
+/* DynamicArray::hsum_: lane-wise accumulation over full packets, masked add of the last
+   (partial) packet, then the AVX in-packet tree: (lo + hi) [array_avx.h:404] followed by the
+   SSE tree of the 4-lane half (array_sse42.h hsum_: (v + movehdup(v)), then + movehl). */
+static float hreduce_f32(const float *a, size_t n, int op /* 0 sum, 1 prod, 2 min, 3 max */) {
+    if (n == 0) {
+        /* dynamic.h:633, 651, 669, 687 -- note hmax of an empty array is numeric_limits::min() */
+        switch (op) { case 0: return 0.0f; case 1: return 1.0f; case 2: return 3.402823466e+38f; default: return 1.175494351e-38f; }
+    }
+    if (n == 1) return a[0];
+    float lane[PKT];
+    for (int l = 0; l < PKT; ++l) lane[l] = (op == 0) ? 0.0f : (op == 1 ? 1.0f : a[0]);
+    size_t packets = (n + PKT - 1) / PKT;
+    for (size_t p = 0; p + 1 < packets; ++p) {
+        for (int l = 0; l < PKT; ++l) {
+            float v = a[p * PKT + l];
+            switch (op) {
+                case 0: lane[l] += v; break;
+                case 1: lane[l] *= v; break;
+                case 2: lane[l] = min_ps(lane[l], v); break;
+                default: lane[l] = max_ps(lane[l], v); break;
+            }
+        }
+    }
+    size_t last = (n - 1) % PKT;
+    for (size_t l = 0; l <= last; ++l) {
+        float v = a[(packets - 1) * PKT + l];
+        switch (op) {
+            case 0: lane[l] += v; break;
+            case 1: lane[l] *= v; break;
+            case 2: lane[l] = min_ps(lane[l], v); break;
+            default: lane[l] = max_ps(lane[l], v); break;
+        }
+    }
+    float h[4];
+    for (int l = 0; l < 4; ++l) {
+        switch (op) {
+            case 0: h[l] = lane[l] + lane[l + 4]; break;
+            case 1: h[l] = lane[l] * lane[l + 4]; break;
+            case 2: h[l] = min_ps(lane[l], lane[l + 4]); break;
+            default: h[l] = max_ps(lane[l], lane[l + 4]); break;
+        }
+    }
+    /* SSE tree: t = h + movehdup(h)  -> t0 = h0 (+) h1, t2 = h2 (+) h3;  r = t0 (+) t2 */
+    switch (op) {
+        case 0: return (h[0] + h[1]) + (h[2] + h[3]);
+        case 1: return (h[0] * h[1]) * (h[2] * h[3]);
+        case 2: return min_ps(min_ps(h[0], h[1]), min_ps(h[2], h[3]));
+        default: return max_ps(max_ps(h[0], h[1]), max_ps(h[2], h[3]));
+    }
+}
+
+#define DEF_REDUCE_INT(NAME, T, UT, TMAX, TMIN)                                               \
+    static T NAME(const T *a, size_t n, int op) {                                             \
+        if (n == 0) { switch (op) { case 0: return 0; case 1: return 1; case 2: return TMAX; default: return TMIN; } } \
+        T r = (op == 0) ? 0 : (op == 1 ? 1 : a[0]);                                           \
+        for (size_t i = 0; i < n; ++i) {                                                      \
+            switch (op) {                                                                     \
+                case 0: r = (T) ((UT) r + (UT) a[i]); break;                                  \
+                case 1: r = (T) ((UT) r * (UT) a[i]); break;                                  \
+                case 2: r = a[i] < r ? a[i] : r; break;                                       \
+                default: r = a[i] > r ? a[i] : r; break;                                      \
+            }                                                                                 \
+        }                                                                                     \
+        return r;                                                                             \
+    }
+DEF_REDUCE_INT(hreduce_i32, int32_t, uint32_t, INT32_MAX, INT32_MIN)
+DEF_REDUCE_INT(hreduce_u32, uint32_t, uint32_t, UINT32_MAX, 0)
+DEF_REDUCE_INT(hreduce_i64, int64_t, uint64_t, INT64_MAX, INT64_MIN)
+DEF_REDUCE_INT(hreduce_u64, uint64_t, uint64_t, UINT64_MAX, 0)
+
+int orc_reduce(int type, const char *op_, const void *a, void *out, size_t n) {
+    int op = is(op_, "hsum") ? 0 : is(op_, "hprod") ? 1 : is(op_, "hmin") ? 2 : is(op_, "hmax") ? 3 : -1;
+    if (op < 0) return -1;
+    switch (type) {
+        case T_F32: *(float *) out = hreduce_f32((const float *) a, n, op); return 0;
+        case T_I32: *(int32_t *) out = hreduce_i32((const int32_t *) a, n, op); return 0;
+        case T_U32: *(uint32_t *) out = hreduce_u32((const uint32_t *) a, n, op); return 0;
+        case T_I64: *(int64_t *) out = hreduce_i64((const int64_t *) a, n, op); return 0;
+        case T_U64: *(uint64_t *) out = hreduce_u64((const uint64_t *) a, n, op); return 0;
+    }
+    return -2;
+}
+
+/* all_/any_/count_ (dynamic.h:704-752): empty -> any false, all true, count 0 */
+int orc_mask_reduce(const char *op, const uint8_t *m, uint64_t *out, size_t n) {
+    uint64_t cnt = 0;
+    for (size_t i = 0; i < n; ++i) cnt += m[i] ? 1 : 0;
+    if      (is(op, "all"))   *out = cnt == n;
+    else if (is(op, "any"))   *out = cnt != 0;
+    else if (is(op, "count")) *out = cnt;
+    else return -1;
+    return 0;
+}
+
+/* arange / linspace (dynamic.h:909-938).  The CPU DynamicArray builds the first packet with the static
+   linspace (array_static.h:1119-1141: lane * step' + min with step' = (hi - min) / 7, mul and add rounded
+   separately) and then advances packet by packet with `value_p += shift` (shift = step * 8), i.e. the error
+   accumulates with the packet index.  (The reference's GPU type uses fmadd(index, step, min) instead,
+   cuda.h:655-663 -- that closed form is what the HIP kernel implements; see tests for the tolerance.) */
+int orc_arange_f32(float *out, size_t n) {
+    float v[PKT];
+    for (int l = 0; l < PKT; ++l) v[l] = (float) l;
+    for (size_t p = 0; p * PKT < n; ++p)
+        for (int l = 0; l < PKT; ++l) { if (p * PKT + l < n) out[p * PKT + l] = v[l]; v[l] += (float) PKT; }
+    return 0;
+}
+int orc_arange_u32(uint32_t *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = (uint32_t) i; return 0; }
+int orc_linspace_f32(float lo, float hi, float *out, size_t n) {
+    float step = (hi - lo) / (float) (n - 1);
+    float last = lo + step * (float) (PKT - 1);
+    float pstep = (last - lo) / (float) (PKT - 1);
+    float shift = step * (float) PKT;
+    float v[PKT];
+    for (int l = 0; l < PKT; ++l) { float t = (float) l * pstep; v[l] = t + lo; }
+    for (size_t p = 0; p * PKT < n; ++p)
+        for (int l = 0; l < PKT; ++l) { if (p * PKT + l < n) out[p * PKT + l] = v[l]; v[l] += shift; }
+    return 0;
+}
+int orc_reverse_f32(const float *a, float *out, size_t n) { for (size_t i = 0; i < n; ++i) out[i] = a[n - 1 - i]; return 0; }
+int orc_psum_f32(const float *a, float *out, size_t n) {
+    if (n) out[0] = a[0];
+    for (size_t i = 1; i < n; ++i) out[i] = out[i - 1] + a[i];
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/*  BASELINE.json configs                                                                 */
+/* ------------------------------------------------------------------------------------ */
+
+static double now_s(void) {
+    struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double) ts.tv_sec + 1e-9 * (double) ts.tv_nsec;
+}
+
+/* cfg1: hsum(fmadd(a, x, b)), tests/dynamic.cpp-style packet loops */
+float orc_cfg1(const float *a, const float *x, const float *b, size_t n, double *seconds) {
+    float *u = (float *) malloc(n * sizeof(float));
+    double t0 = now_s();
+    for (size_t i = 0; i < n; ++i) u[i] = fmaf(a[i], x[i], b[i]);
+    float y = hreduce_f32(u, n, 0);
+    if (seconds) *seconds = now_s() - t0;
+    free(u);
+    return y;
+}
+
+/* cfg2: hsum(sin(exp(fmadd(a, x, b)))) -- one array pass per op like the reference */
+float orc_cfg2(const float *a, const float *x, const float *b, size_t n, double *seconds) {
+    float *u = (float *) malloc(n * sizeof(float));
+    double t0 = now_s();
+    for (size_t i = 0; i < n; ++i) u[i] = fmaf(a[i], x[i], b[i]);
+    for (size_t i = 0; i < n; ++i) u[i] = exp_f32(u[i]);
+    for (size_t i = 0; i < n; ++i) sincos_f32(u[i], &u[i], NULL);
+    float y = hreduce_f32(u, n, 0);
+    if (seconds) *seconds = now_s() - t0;
+    free(u);
+    return y;
+}
+
+/* cfg3a: y = hsum(sin(fmadd(a, x, b))); backward(y) with a, b leaves (size n) and x plain.
+ *
+ * Restates what the reference tape does for exactly this graph:
+ *   forward  DiffArray::fmadd_ (autodiff.h:274-286): u = fmadd(a,x,b), edges a<-w=x, b<-w=1
+ *            DiffArray::sin_   (autodiff.h:491-501): (s,c) = sincos(u), edge u<-w=c
+ *            DiffArray::hsum_  (autodiff.h:1052-1062): y = hsum(s), edge s<-w=1
+ *   backward Tape::backward (autodiff.cpp:838-910), nodes in descending index order:
+ *            g_s = safe_mul(1, 1)               (:873-874; scalar, broadcast by set_slices :851-861)
+ *            g_u = safe_mul(c, g_s)
+ *            g_a = safe_mul(x, g_u);  g_b = safe_mul(1, g_u)
+ */
+float orc_cfg3a(const float *a, const float *x, const float *b, size_t n,
+                float *grad_a, float *grad_b, double *seconds) {
+    float *s = (float *) malloc(n * sizeof(float)), *c = (float *) malloc(n * sizeof(float));
+    float *gu = (float *) malloc(n * sizeof(float));
+    double t0 = now_s();
+    for (size_t i = 0; i < n; ++i) s[i] = fmaf(a[i], x[i], b[i]);
+    for (size_t i = 0; i < n; ++i) sincos_f32(s[i], &s[i], &c[i]);
+    float y = hreduce_f32(s, n, 0);
+    float gs = safe_mul_f32(1.0f, 1.0f);
+    for (size_t i = 0; i < n; ++i) gu[i] = safe_mul_f32(c[i], gs);
+    for (size_t i = 0; i < n; ++i) grad_a[i] = safe_mul_f32(x[i], gu[i]);
+    for (size_t i = 0; i < n; ++i) grad_b[i] = safe_mul_f32(1.0f, gu[i]);
+    if (seconds) *seconds = now_s() - t0;
+    free(s); free(c); free(gu);
+    return y;
+}
+
+/* cfg3b: a = gather(A, idx), b = gather(B, idx) (A, B leaves of size k), rest as cfg3a;
+ *   backward additionally runs Gather::backward (autodiff.cpp:384-398): grad_A = zero(k);
+ *   scatter_add(grad_A, g_a, idx) -- sequential in element order on the CPU path. */
+float orc_cfg3b(const float *A, const float *B, size_t k, const float *x, const uint32_t *idx,
+                size_t n, float *grad_A, float *grad_B, double *seconds) {
+    float *s = (float *) malloc(n * sizeof(float)), *c = (float *) malloc(n * sizeof(float));
+    float *gu = (float *) malloc(n * sizeof(float)), *ga = (float *) malloc(n * sizeof(float));
+    float *av = (float *) malloc(n * sizeof(float)), *bv = (float *) malloc(n * sizeof(float));
+    double t0 = now_s();
+    for (size_t i = 0; i < n; ++i) av[i] = A[idx[i]];
+    for (size_t i = 0; i < n; ++i) bv[i] = B[idx[i]];
+    for (size_t i = 0; i < n; ++i) s[i] = fmaf(av[i], x[i], bv[i]);
+    for (size_t i = 0; i < n; ++i) sincos_f32(s[i], &s[i], &c[i]);
+    float y = hreduce_f32(s, n, 0);
+    float gs = safe_mul_f32(1.0f, 1.0f);
+    for (size_t i = 0; i < n; ++i) gu[i] = safe_mul_f32(c[i], gs);
+    /* node order: fmadd's edges are (a <- x), (b <- 1); both gather nodes have a higher index than the
+       leaves, and b's gather node (created second) is processed first in descending order. */
+    for (size_t i = 0; i < n; ++i) ga[i] = safe_mul_f32(x[i], gu[i]);
+    for (size_t i = 0; i < n; ++i) gu[i] = safe_mul_f32(1.0f, gu[i]);
+    memset(grad_B, 0, k * sizeof(float));
+    for (size_t i = 0; i < n; ++i) grad_B[idx[i]] += gu[i];
+    memset(grad_A, 0, k * sizeof(float));
+    for (size_t i = 0; i < n; ++i) grad_A[idx[i]] += ga[i];
+    if (seconds) *seconds = now_s() - t0;
+    free(s); free(c); free(gu); free(ga); free(av); free(bv);
+    return y;
+}

@@ -1,0 +1,566 @@
+/*
+ * oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY (never linked into the product).
+ *
+ * Thin extern "C" driver around the *unmodified reference headers* that live
+ * under /root/reference/include (they are #included where they lie, never
+ * copied).  Built by oracle/Makefile into oracle/_ref/libenoki_ref.so with the
+ * pinned oracle flags:
+ *
+ *   -O2 -mavx2 -mfma -mf16c -mbmi -mbmi2 -mlzcnt -ffp-contract=off -fno-math-errno
+ *
+ * which selects the reference's AVX2 `Packet<float,8>` code path with
+ * contraction disabled, i.e. only the explicit fmadd() calls fuse.
+ *
+ * Every entry point takes plain host pointers, runs the op through
+ * enoki::DynamicArray<Packet<T,8>> (include/enoki/dynamic.h) or through
+ * DiffArray<DynamicArray<Packet<float>>> + Tape (include/enoki/autodiff.h,
+ * src/autodiff/autodiff.cpp, compiled into the same .so) and writes the
+ * result back to a host pointer.  Used to (a) pin oracle/enoki_oracle.c,
+ * (b) generate tests/golden/ fixtures, (c) serve as the "reference" CPU
+ * baseline in bench.py.
+ */
+#include <enoki/array.h>
+#include <enoki/dynamic.h>
+#include <enoki/autodiff.h>
+
+#include <chrono>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace enoki;
+
+namespace {
+
+template <typename T> using Pk  = Packet<T, 8>;
+template <typename T> using Dyn = DynamicArray<Pk<T>>;
+
+using FloatX  = DynamicArray<Packet<float>>;    // default width: 8 under -mavx2
+using UInt32X = DynamicArray<Packet<uint32_t>>;
+using FloatD  = DiffArray<FloatX>;
+using UInt32D = DiffArray<UInt32X>;
+
+template <typename T> Dyn<T> load(const T *p, size_t n) {
+    Dyn<T> r = Dyn<T>::copy(p, n);
+    return r;
+}
+
+template <typename A> void store(const A &a, scalar_t<A> *out, size_t n) {
+    if (a.size() == 1 && n != 1) {
+        for (size_t i = 0; i < n; ++i) out[i] = a.coeff(0);
+    } else {
+        memcpy(out, a.data(), n * sizeof(scalar_t<A>));
+    }
+}
+
+/* masks cross the boundary as u8 (0/1) */
+template <typename T> mask_t<Dyn<T>> load_mask(const uint8_t *m, size_t n) {
+    std::vector<uint32_t> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = m[i] ? 1u : 0u;
+    Dyn<uint32_t> v = Dyn<uint32_t>::copy(tmp.data(), n);
+    return mask_t<Dyn<T>>(neq(v, 0u));
+}
+
+template <typename M> void store_mask(const M &m, uint8_t *out, size_t n) {
+    Dyn<uint32_t> v = select(mask_t<Dyn<uint32_t>>(m), Dyn<uint32_t>(1u), Dyn<uint32_t>(0u));
+    if (v.size() == 1 && n != 1) {
+        for (size_t i = 0; i < n; ++i) out[i] = (uint8_t) v.coeff(0);
+    } else {
+        for (size_t i = 0; i < n; ++i) out[i] = (uint8_t) v.coeff(i);
+    }
+}
+
+bool is(const char *a, const char *b) { return strcmp(a, b) == 0; }
+
+template <typename T> int unary_float(const char *op, const T *a_, T *out, size_t n) {
+    Dyn<T> a = load(a_, n), r;
+    if      (is(op, "neg"))   r = -a;
+    else if (is(op, "abs"))   r = abs(a);
+    else if (is(op, "sqrt"))  r = sqrt(a);
+    else if (is(op, "rcp"))   r = rcp(a);
+    else if (is(op, "rsqrt")) r = rsqrt(a);
+    else if (is(op, "floor")) r = floor(a);
+    else if (is(op, "ceil"))  r = ceil(a);
+    else if (is(op, "round")) r = round(a);
+    else if (is(op, "trunc")) r = trunc(a);
+    else if (is(op, "sin"))   r = sin(a);
+    else if (is(op, "cos"))   r = cos(a);
+    else if (is(op, "exp"))   r = exp(a);
+    else if (is(op, "log"))   r = log(a);
+    else if (is(op, "tan"))   r = tan(a);
+    else if (is(op, "asin"))  r = asin(a);
+    else if (is(op, "acos"))  r = acos(a);
+    else if (is(op, "atan"))  r = atan(a);
+    else if (is(op, "sinh"))  r = sinh(a);
+    else if (is(op, "cosh"))  r = cosh(a);
+    else if (is(op, "tanh"))  r = tanh(a);
+    else if (is(op, "sign"))  r = sign(a);
+    else return -1;
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T> int unary_int(const char *op, const T *a_, T *out, size_t n) {
+    Dyn<T> a = load(a_, n), r;
+    if      (is(op, "neg"))    r = -a;
+    else if (is(op, "not"))    r = ~a;
+    else if (is(op, "abs"))    r = abs(a);
+    else if (is(op, "popcnt")) r = popcnt(a);
+    else if (is(op, "lzcnt"))  r = lzcnt(a);
+    else if (is(op, "tzcnt"))  r = tzcnt(a);
+    else return -1;
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T> int binary_float(const char *op, const T *a_, const T *b_, T *out, size_t n) {
+    Dyn<T> a = load(a_, n), b = load(b_, n), r;
+    if      (is(op, "add")) r = a + b;
+    else if (is(op, "sub")) r = a - b;
+    else if (is(op, "mul")) r = a * b;
+    else if (is(op, "div")) r = a / b;
+    else if (is(op, "min")) r = min(a, b);
+    else if (is(op, "max")) r = max(a, b);
+    else if (is(op, "atan2")) r = atan2(a, b);
+    else if (is(op, "safe_mul")) {
+        /* restates the CPU branch of safe_mul, src/autodiff/autodiff.cpp:1191-1205 */
+        Dyn<T> t = a * b, z = T(0);
+        r = select(eq(a, z) || eq(b, z), z, t);
+    }
+    else return -1;
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T> int binary_int(const char *op, const T *a_, const T *b_, T *out, size_t n) {
+    Dyn<T> a = load(a_, n), b = load(b_, n), r;
+    if      (is(op, "add"))   r = a + b;
+    else if (is(op, "sub"))   r = a - b;
+    else if (is(op, "mul"))   r = a * b;
+    else if (is(op, "div"))   r = a / b;
+    else if (is(op, "mod"))   r = a % b;
+    else if (is(op, "min"))   r = min(a, b);
+    else if (is(op, "max"))   r = max(a, b);
+    else if (is(op, "mulhi")) r = mulhi(a, b);
+    else if (is(op, "and"))   r = a & b;
+    else if (is(op, "or"))    r = a | b;
+    else if (is(op, "xor"))   r = a ^ b;
+    else if (is(op, "sl"))    r = a << b;
+    else if (is(op, "sr"))    r = a >> b;
+    else return -1;
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T> int ternary_any(const char *op, const T *a_, const T *b_, const T *c_, T *out, size_t n) {
+    Dyn<T> a = load(a_, n), b = load(b_, n), c = load(c_, n), r;
+    if      (is(op, "fmadd"))  r = fmadd(a, b, c);
+    else if (is(op, "fmsub"))  r = fmsub(a, b, c);
+    else if (is(op, "fnmadd")) r = fnmadd(a, b, c);
+    else if (is(op, "fnmsub")) r = fnmsub(a, b, c);
+    else if (is(op, "safe_fmadd")) {
+        /* CPU branch of safe_fmadd, src/autodiff/autodiff.cpp:1207-1221 */
+        Dyn<T> t = fmadd(a, b, c), z = T(0);
+        r = select(eq(a, z) || eq(b, z), c, t);
+    }
+    else return -1;
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T> int compare_any(const char *op, const T *a_, const T *b_, uint8_t *out, size_t n) {
+    Dyn<T> a = load(a_, n), b = load(b_, n);
+    mask_t<Dyn<T>> m;
+    if      (is(op, "eq"))  m = eq(a, b);
+    else if (is(op, "neq")) m = neq(a, b);
+    else if (is(op, "lt"))  m = a < b;
+    else if (is(op, "le"))  m = a <= b;
+    else if (is(op, "gt"))  m = a > b;
+    else if (is(op, "ge"))  m = a >= b;
+    else return -1;
+    store_mask(m, out, n);
+    return 0;
+}
+
+template <typename T> int select_any(const uint8_t *m_, const T *t_, const T *f_, T *out, size_t n) {
+    auto m = load_mask<T>(m_, n);
+    Dyn<T> r = select(m, load(t_, n), load(f_, n));
+    store(r, out, n);
+    return 0;
+}
+
+template <typename S, typename D> int cast_any(const S *a_, D *out, size_t n) {
+    Dyn<D> r = Dyn<D>(load(a_, n));
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T, typename I>
+int gather_any(const T *base, size_t /*src_size*/, const I *idx_, const uint8_t *mask_, T *out, size_t n) {
+    Dyn<I> idx = load(idx_, n);
+    auto m = load_mask<T>(mask_, n);
+    Dyn<T> r = gather<Dyn<T>>((const void *) base, idx, m);
+    store(r, out, n);
+    return 0;
+}
+
+template <typename T, typename I>
+int scatter_any(int add, T *base, const T *val_, const I *idx_, const uint8_t *mask_, size_t n) {
+    Dyn<I> idx = load(idx_, n);
+    Dyn<T> val = load(val_, n);
+    auto m = load_mask<T>(mask_, n);
+    if (add) scatter_add((void *) base, val, idx, m);
+    else     scatter((void *) base, val, idx, m);
+    return 0;
+}
+
+template <typename T> int reduce_any(const char *op, const T *a_, T *out, size_t n) {
+    Dyn<T> a = n ? load(a_, n) : Dyn<T>();
+    if      (is(op, "hsum"))  *out = hsum(a);
+    else if (is(op, "hprod")) *out = hprod(a);
+    else if (is(op, "hmax"))  *out = hmax(a);
+    else if (is(op, "hmin"))  *out = hmin(a);
+    else return -1;
+    return 0;
+}
+
+double now() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+} // namespace
+
+
+extern "C" {
+
+/* type codes shared with include/enoki_hip.h: 1=i32 2=u32 3=i64 4=u64 5=f32 6=f64 */
+
+int ref_packet_width() { return (int) Packet<float>::Size; }
+
+int ref_unary(int type, const char *op, const void *a, void *out, size_t n) {
+    switch (type) {
+        case 1: return unary_int<int32_t>(op, (const int32_t *) a, (int32_t *) out, n);
+        case 2: return unary_int<uint32_t>(op, (const uint32_t *) a, (uint32_t *) out, n);
+        case 3: return unary_int<int64_t>(op, (const int64_t *) a, (int64_t *) out, n);
+        case 4: return unary_int<uint64_t>(op, (const uint64_t *) a, (uint64_t *) out, n);
+        case 5: return unary_float<float>(op, (const float *) a, (float *) out, n);
+        case 6: return unary_float<double>(op, (const double *) a, (double *) out, n);
+    }
+    return -2;
+}
+
+int ref_binary(int type, const char *op, const void *a, const void *b, void *out, size_t n) {
+    switch (type) {
+        case 1: return binary_int<int32_t>(op, (const int32_t *) a, (const int32_t *) b, (int32_t *) out, n);
+        case 2: return binary_int<uint32_t>(op, (const uint32_t *) a, (const uint32_t *) b, (uint32_t *) out, n);
+        case 3: return binary_int<int64_t>(op, (const int64_t *) a, (const int64_t *) b, (int64_t *) out, n);
+        case 4: return binary_int<uint64_t>(op, (const uint64_t *) a, (const uint64_t *) b, (uint64_t *) out, n);
+        case 5: return binary_float<float>(op, (const float *) a, (const float *) b, (float *) out, n);
+        case 6: return binary_float<double>(op, (const double *) a, (const double *) b, (double *) out, n);
+    }
+    return -2;
+}
+
+int ref_ternary(int type, const char *op, const void *a, const void *b, const void *c, void *out, size_t n) {
+    switch (type) {
+        case 1: return ternary_any<int32_t>(op, (const int32_t *) a, (const int32_t *) b, (const int32_t *) c, (int32_t *) out, n);
+        case 2: return ternary_any<uint32_t>(op, (const uint32_t *) a, (const uint32_t *) b, (const uint32_t *) c, (uint32_t *) out, n);
+        case 5: return ternary_any<float>(op, (const float *) a, (const float *) b, (const float *) c, (float *) out, n);
+        case 6: return ternary_any<double>(op, (const double *) a, (const double *) b, (const double *) c, (double *) out, n);
+    }
+    return -2;
+}
+
+int ref_sincos(int type, const void *a_, void *s_, void *c_, size_t n) {
+    if (type == 5) {
+        auto [s, c] = sincos(load((const float *) a_, n));
+        store(s, (float *) s_, n); store(c, (float *) c_, n);
+        return 0;
+    } else if (type == 6) {
+        auto [s, c] = sincos(load((const double *) a_, n));
+        store(s, (double *) s_, n); store(c, (double *) c_, n);
+        return 0;
+    }
+    return -2;
+}
+
+int ref_compare(int type, const char *op, const void *a, const void *b, uint8_t *out, size_t n) {
+    switch (type) {
+        case 1: return compare_any<int32_t>(op, (const int32_t *) a, (const int32_t *) b, out, n);
+        case 2: return compare_any<uint32_t>(op, (const uint32_t *) a, (const uint32_t *) b, out, n);
+        case 3: return compare_any<int64_t>(op, (const int64_t *) a, (const int64_t *) b, out, n);
+        case 4: return compare_any<uint64_t>(op, (const uint64_t *) a, (const uint64_t *) b, out, n);
+        case 5: return compare_any<float>(op, (const float *) a, (const float *) b, out, n);
+        case 6: return compare_any<double>(op, (const double *) a, (const double *) b, out, n);
+    }
+    return -2;
+}
+
+int ref_select(int type, const uint8_t *m, const void *t, const void *f, void *out, size_t n) {
+    switch (type) {
+        case 1: return select_any<int32_t>(m, (const int32_t *) t, (const int32_t *) f, (int32_t *) out, n);
+        case 2: return select_any<uint32_t>(m, (const uint32_t *) t, (const uint32_t *) f, (uint32_t *) out, n);
+        case 3: return select_any<int64_t>(m, (const int64_t *) t, (const int64_t *) f, (int64_t *) out, n);
+        case 4: return select_any<uint64_t>(m, (const uint64_t *) t, (const uint64_t *) f, (uint64_t *) out, n);
+        case 5: return select_any<float>(m, (const float *) t, (const float *) f, (float *) out, n);
+        case 6: return select_any<double>(m, (const double *) t, (const double *) f, (double *) out, n);
+    }
+    return -2;
+}
+
+int ref_cast(int src, int dst, const void *a, void *out, size_t n) {
+#define CAST_ROW(S, st)                                                                   \
+    if (src == S) {                                                                       \
+        switch (dst) {                                                                    \
+            case 1: return cast_any<st, int32_t>((const st *) a, (int32_t *) out, n);     \
+            case 2: return cast_any<st, uint32_t>((const st *) a, (uint32_t *) out, n);   \
+            case 3: return cast_any<st, int64_t>((const st *) a, (int64_t *) out, n);     \
+            case 4: return cast_any<st, uint64_t>((const st *) a, (uint64_t *) out, n);   \
+            case 5: return cast_any<st, float>((const st *) a, (float *) out, n);         \
+            case 6: return cast_any<st, double>((const st *) a, (double *) out, n);       \
+        }                                                                                 \
+    }
+    CAST_ROW(1, int32_t) CAST_ROW(2, uint32_t) CAST_ROW(3, int64_t)
+    CAST_ROW(4, uint64_t) CAST_ROW(5, float) CAST_ROW(6, double)
+#undef CAST_ROW
+    return -2;
+}
+
+/* index type: 1=i32 2=u32 3=i64 4=u64; value type 1..6 (4- and 8-byte values) */
+int ref_gather(int type, int itype, const void *base, size_t src_size, const void *idx,
+               const uint8_t *mask, void *out, size_t n) {
+#define G(T, I) return gather_any<T, I>((const T *) base, src_size, (const I *) idx, mask, (T *) out, n)
+    if (type == 5 && itype == 2) G(float, uint32_t);
+    if (type == 5 && itype == 1) G(float, int32_t);
+    if (type == 1 && itype == 2) G(int32_t, uint32_t);
+    if (type == 1 && itype == 1) G(int32_t, int32_t);
+    if (type == 2 && itype == 2) G(uint32_t, uint32_t);
+    if (type == 2 && itype == 1) G(uint32_t, int32_t);
+    if (type == 6 && itype == 4) G(double, uint64_t);
+    if (type == 6 && itype == 3) G(double, int64_t);
+    if (type == 3 && itype == 3) G(int64_t, int64_t);
+    if (type == 4 && itype == 4) G(uint64_t, uint64_t);
+#undef G
+    return -2;
+}
+
+int ref_scatter(int type, int itype, int add, void *base, const void *val, const void *idx,
+                const uint8_t *mask, size_t n) {
+#define S(T, I) return scatter_any<T, I>(add, (T *) base, (const T *) val, (const I *) idx, mask, n)
+    if (type == 5 && itype == 2) S(float, uint32_t);
+    if (type == 5 && itype == 1) S(float, int32_t);
+    if (type == 1 && itype == 2) S(int32_t, uint32_t);
+    if (type == 1 && itype == 1) S(int32_t, int32_t);
+    if (type == 2 && itype == 2) S(uint32_t, uint32_t);
+    if (type == 2 && itype == 1) S(uint32_t, int32_t);
+    if (type == 6 && itype == 4) S(double, uint64_t);
+    if (type == 6 && itype == 3) S(double, int64_t);
+    if (type == 3 && itype == 3) S(int64_t, int64_t);
+    if (type == 4 && itype == 4) S(uint64_t, uint64_t);
+#undef S
+    return -2;
+}
+
+int ref_reduce(int type, const char *op, const void *a, void *out, size_t n) {
+    switch (type) {
+        case 1: return reduce_any<int32_t>(op, (const int32_t *) a, (int32_t *) out, n);
+        case 2: return reduce_any<uint32_t>(op, (const uint32_t *) a, (uint32_t *) out, n);
+        case 3: return reduce_any<int64_t>(op, (const int64_t *) a, (int64_t *) out, n);
+        case 4: return reduce_any<uint64_t>(op, (const uint64_t *) a, (uint64_t *) out, n);
+        case 5: return reduce_any<float>(op, (const float *) a, (float *) out, n);
+        case 6: return reduce_any<double>(op, (const double *) a, (double *) out, n);
+    }
+    return -2;
+}
+
+/* mask reductions: op = all | any | count ; result as uint64 */
+int ref_mask_reduce(const char *op, const uint8_t *m_, uint64_t *out, size_t n) {
+    if (n == 0) {
+        mask_t<Dyn<float>> m;
+        if      (is(op, "all"))   *out = all(m);
+        else if (is(op, "any"))   *out = any(m);
+        else if (is(op, "count")) *out = count(m);
+        else return -1;
+        return 0;
+    }
+    auto m = load_mask<float>(m_, n);
+    if      (is(op, "all"))   *out = all(m);
+    else if (is(op, "any"))   *out = any(m);
+    else if (is(op, "count")) *out = count(m);
+    else return -1;
+    return 0;
+}
+
+int ref_arange_f32(float *out, size_t n) { store(arange<Dyn<float>>(n), out, n); return 0; }
+int ref_arange_u32(uint32_t *out, size_t n) { store(arange<Dyn<uint32_t>>(n), out, n); return 0; }
+int ref_linspace_f32(float lo, float hi, float *out, size_t n) { store(linspace<Dyn<float>>(lo, hi, n), out, n); return 0; }
+int ref_reverse_f32(const float *a, float *out, size_t n) { store(reverse(load(a, n)), out, n); return 0; }
+int ref_psum_f32(const float *a, float *out, size_t n) { store(psum(load(a, n)), out, n); return 0; }
+
+/* ------------------------------------------------------------------ */
+/* BASELINE.json configs, run through the reference's own types.       */
+/* Each returns the elapsed seconds of the timed region in *seconds.   */
+/* ------------------------------------------------------------------ */
+
+/* cfg1: hsum(fmadd(a, x, b)) on DynamicArray<Packet<float,8>>  (tests/dynamic.cpp style) */
+float ref_cfg1(const float *a_, const float *x_, const float *b_, size_t n, double *seconds) {
+    Dyn<float> a = load(a_, n), x = load(x_, n), b = load(b_, n);
+    double t0 = now();
+    float y = hsum(fmadd(a, x, b));
+    if (seconds) *seconds = now() - t0;
+    return y;
+}
+
+/* cfg2: hsum(sin(exp(fmadd(a, x, b)))) */
+float ref_cfg2(const float *a_, const float *x_, const float *b_, size_t n, double *seconds) {
+    Dyn<float> a = load(a_, n), x = load(x_, n), b = load(b_, n);
+    double t0 = now();
+    float y = hsum(sin(exp(fmadd(a, x, b))));
+    if (seconds) *seconds = now() - t0;
+    return y;
+}
+
+/* cfg3a: y = hsum(sin(fmadd(a, x, b))); backward(y); a, b leaves of size n, x plain. */
+float ref_cfg3a(const float *a_, const float *x_, const float *b_, size_t n,
+                float *grad_a, float *grad_b, double *seconds) {
+    FloatD::set_log_level_(0);
+    FloatD a = FloatX::copy(a_, n), x = FloatX::copy(x_, n), b = FloatX::copy(b_, n);
+    set_requires_gradient(a);
+    set_requires_gradient(b);
+    double t0 = now();
+    FloatD y = hsum(sin(fmadd(a, x, b)));
+    backward(y);
+    if (seconds) *seconds = now() - t0;
+    if (grad_a) store(gradient(a), grad_a, n);
+    if (grad_b) store(gradient(b), grad_b, n);
+    return y.value_().coeff(0);
+}
+
+/* cfg3b: a = gather(A, idx), b = gather(B, idx) with A, B leaves of size K;
+          y = hsum(sin(fmadd(a, x, b))); backward(y) -> grads land in K-arrays via scatter_add. */
+float ref_cfg3b(const float *A_, const float *B_, size_t k, const float *x_, const uint32_t *idx_,
+                size_t n, float *grad_A, float *grad_B, double *seconds) {
+    FloatD::set_log_level_(0);
+    FloatD A = FloatX::copy(A_, k), B = FloatX::copy(B_, k), x = FloatX::copy(x_, n);
+    UInt32D idx = UInt32X::copy(idx_, n);
+    set_requires_gradient(A);
+    set_requires_gradient(B);
+    double t0 = now();
+    FloatD a = gather<FloatD>(A, idx), b = gather<FloatD>(B, idx);
+    FloatD y = hsum(sin(fmadd(a, x, b)));
+    backward(y);
+    if (seconds) *seconds = now() - t0;
+    if (grad_A) store(gradient(A), grad_A, k);
+    if (grad_B) store(gradient(B), grad_B, k);
+    return y.value_().coeff(0);
+}
+
+/* Generic little tape programs used by the tape parity tests: see tests/test_tape_parity.py.
+   prog: a sequence of (opcode, arg0, arg1, arg2) int32 quadruples acting on a register file of
+   FloatD values.  Registers [0, n_in) are preloaded from `inputs` (each of length sizes[i]) and
+   flagged as leaves when leaf[i] != 0.  The last register written is the output; mode 0 =
+   backward, 1 = forward (seeded from leaf `fwd_leaf`).  Gradients of all leaves (backward) or
+   of the output (forward) are written to grads[i] (backward) / grads[0] (forward). */
+enum {
+    P_ADD = 0, P_SUB, P_MUL, P_DIV, P_FMADD, P_NEG, P_ABS, P_SQRT, P_RCP, P_RSQRT, P_SIN, P_COS,
+    P_EXP, P_LOG, P_HSUM, P_HPROD, P_MIN, P_MAX, P_GATHER, P_SCATTER_ADD, P_SCATTER, P_SELECT_GT0,
+    P_MULC, P_ADDC, P_TANH, P_TAN, P_ATAN2, P_FMSUB, P_FNMADD, P_FNMSUB, P_SINH, P_COSH, P_ASIN,
+    P_ACOS, P_ATAN, P_PSUM, P_REVERSE
+};
+
+int ref_tape_program(const int32_t *prog, size_t n_ops, const float *const *inputs,
+                     const uint64_t *sizes, const uint8_t *leaf, size_t n_in,
+                     const uint32_t *const *index_inputs, const uint64_t *index_sizes, size_t n_idx,
+                     int mode, int fwd_leaf, int simplify,
+                     float *out_value, uint64_t *out_size, float *const *grads) {
+    FloatD::set_log_level_(0);
+    std::vector<FloatD> reg(n_in + n_ops);
+    std::vector<UInt32D> ireg(n_idx);
+    for (size_t i = 0; i < n_in; ++i) {
+        reg[i] = FloatX::copy(inputs[i], sizes[i]);
+        if (leaf[i]) set_requires_gradient(reg[i]);
+    }
+    for (size_t i = 0; i < n_idx; ++i)
+        ireg[i] = UInt32X::copy(index_inputs[i], index_sizes[i]);
+
+    size_t last = n_in ? n_in - 1 : 0;
+    for (size_t k = 0; k < n_ops; ++k) {
+        const int32_t *p = prog + 4 * k;
+        size_t d = n_in + k;
+        auto R = [&](int32_t i) -> FloatD & { return reg[(size_t) i]; };
+        float cst; memcpy(&cst, &p[2], sizeof(float));
+        switch (p[0]) {
+            case P_ADD:    reg[d] = R(p[1]) + R(p[2]); break;
+            case P_SUB:    reg[d] = R(p[1]) - R(p[2]); break;
+            case P_MUL:    reg[d] = R(p[1]) * R(p[2]); break;
+            case P_DIV:    reg[d] = R(p[1]) / R(p[2]); break;
+            case P_FMADD:  reg[d] = fmadd(R(p[1]), R(p[2]), R(p[3])); break;
+            case P_FMSUB:  reg[d] = fmsub(R(p[1]), R(p[2]), R(p[3])); break;
+            case P_FNMADD: reg[d] = fnmadd(R(p[1]), R(p[2]), R(p[3])); break;
+            case P_FNMSUB: reg[d] = fnmsub(R(p[1]), R(p[2]), R(p[3])); break;
+            case P_NEG:    reg[d] = -R(p[1]); break;
+            case P_ABS:    reg[d] = abs(R(p[1])); break;
+            case P_SQRT:   reg[d] = sqrt(R(p[1])); break;
+            case P_RCP:    reg[d] = rcp(R(p[1])); break;
+            case P_RSQRT:  reg[d] = rsqrt(R(p[1])); break;
+            case P_SIN:    reg[d] = sin(R(p[1])); break;
+            case P_COS:    reg[d] = cos(R(p[1])); break;
+            case P_TAN:    reg[d] = tan(R(p[1])); break;
+            case P_SINH:   reg[d] = sinh(R(p[1])); break;
+            case P_COSH:   reg[d] = cosh(R(p[1])); break;
+            case P_TANH:   reg[d] = tanh(R(p[1])); break;
+            case P_ASIN:   reg[d] = asin(R(p[1])); break;
+            case P_ACOS:   reg[d] = acos(R(p[1])); break;
+            case P_ATAN:   reg[d] = atan(R(p[1])); break;
+            case P_ATAN2:  reg[d] = atan2(R(p[1]), R(p[2])); break;
+            case P_EXP:    reg[d] = exp(R(p[1])); break;
+            case P_LOG:    reg[d] = log(R(p[1])); break;
+            case P_HSUM:   reg[d] = hsum(R(p[1])); break;
+            case P_HPROD:  reg[d] = hprod(R(p[1])); break;
+            case P_PSUM:   reg[d] = psum(R(p[1])); break;
+            case P_REVERSE:reg[d] = reverse(R(p[1])); break;
+            case P_MIN:    reg[d] = min(R(p[1]), R(p[2])); break;
+            case P_MAX:    reg[d] = max(R(p[1]), R(p[2])); break;
+            case P_MULC:   reg[d] = R(p[1]) * cst; break;
+            case P_ADDC:   reg[d] = R(p[1]) + cst; break;
+            case P_SELECT_GT0: reg[d] = select(R(p[1]) > 0.f, R(p[2]), R(p[3])); break;
+            case P_GATHER: reg[d] = gather<FloatD>(R(p[1]), ireg[(size_t) p[2]]); break;
+            case P_SCATTER_ADD: /* target p[1] (modified in place), value p[2], index p[3] */
+                scatter_add(R(p[1]), R(p[2]), ireg[(size_t) p[3]]);
+                reg[d] = R(p[1]);
+                break;
+            case P_SCATTER:
+                scatter(R(p[1]), R(p[2]), ireg[(size_t) p[3]]);
+                reg[d] = R(p[1]);
+                break;
+            default: return -1;
+        }
+        last = d;
+    }
+
+    FloatD &y = reg[last];
+    *out_size = y.size();
+    store(y.value_(), out_value, y.size());
+    if (simplify) FloatD::simplify_graph_();
+
+    if (mode == 0) {
+        backward(y);
+        for (size_t i = 0; i < n_in; ++i) {
+            if (!leaf[i]) continue;
+            const FloatX &g = gradient(reg[i]);
+            if (g.size() == 0) {            /* leaf not reached: reference leaves grad empty */
+                for (size_t j = 0; j < sizes[i]; ++j) grads[i][j] = 0.f;
+            } else {
+                store(g, grads[i], sizes[i]);
+            }
+        }
+    } else {
+        forward(reg[(size_t) fwd_leaf]);
+        const FloatX &g = gradient(y);
+        store(g, grads[0], y.size());
+    }
+    return 0;
+}
+
+} // extern "C"

@@ -1,0 +1,172 @@
+"""ctypes loaders for the two CPU checkers (TEST INFRASTRUCTURE ONLY).
+
+* ``port()``  -> oracle/libenoki_oracle.so   (plain-C restatement, oracle/enoki_oracle.c)
+* ``ref()``   -> oracle/_ref/libenoki_ref.so (the unmodified reference headers, oracle/ref_driver.cpp)
+
+Both expose the same calling convention (op names as C strings, type codes as in
+include/enoki_hip.h), with the prefix ``orc_`` resp. ``ref_``; :class:`Checker` hides the prefix.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+T_BOOL, T_I32, T_U32, T_I64, T_U64, T_F32, T_F64 = range(7)
+NP2T = {np.dtype(np.int32): T_I32, np.dtype(np.uint32): T_U32, np.dtype(np.int64): T_I64,
+        np.dtype(np.uint64): T_U64, np.dtype(np.float32): T_F32, np.dtype(np.float64): T_F64,
+        np.dtype(np.uint8): T_BOOL, np.dtype(np.bool_): T_BOOL}
+T2NP = {T_BOOL: np.uint8, T_I32: np.int32, T_U32: np.uint32, T_I64: np.int64, T_U64: np.uint64,
+        T_F32: np.float32, T_F64: np.float64}
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Checker:
+    def __init__(self, lib, prefix, kind):
+        self.lib, self.prefix, self.kind = lib, prefix, kind
+        for name in ("cfg1", "cfg2", "cfg3a", "cfg3b"):
+            getattr(lib, prefix + name).restype = ctypes.c_float
+
+    def _f(self, name):
+        return getattr(self.lib, self.prefix + name)
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise NotImplementedError(f"{self.kind}: {what} -> rc={rc}")
+
+    def unary(self, op, a):
+        a = np.ascontiguousarray(a); out = np.empty_like(a)
+        self._chk(self._f("unary")(NP2T[a.dtype], op.encode(), _p(a), _p(out), ctypes.c_size_t(a.size)), op)
+        return out
+
+    def sincos(self, a):
+        a = np.ascontiguousarray(a); s = np.empty_like(a); c = np.empty_like(a)
+        self._chk(self._f("sincos")(NP2T[a.dtype], _p(a), _p(s), _p(c), ctypes.c_size_t(a.size)), "sincos")
+        return s, c
+
+    def binary(self, op, a, b):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b, dtype=a.dtype); out = np.empty_like(a)
+        self._chk(self._f("binary")(NP2T[a.dtype], op.encode(), _p(a), _p(b), _p(out), ctypes.c_size_t(a.size)), op)
+        return out
+
+    def ternary(self, op, a, b, c):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b, dtype=a.dtype)
+        c = np.ascontiguousarray(c, dtype=a.dtype); out = np.empty_like(a)
+        self._chk(self._f("ternary")(NP2T[a.dtype], op.encode(), _p(a), _p(b), _p(c), _p(out),
+                                     ctypes.c_size_t(a.size)), op)
+        return out
+
+    def compare(self, op, a, b):
+        a = np.ascontiguousarray(a); b = np.ascontiguousarray(b, dtype=a.dtype)
+        out = np.empty(a.size, np.uint8)
+        self._chk(self._f("compare")(NP2T[a.dtype], op.encode(), _p(a), _p(b), _p(out), ctypes.c_size_t(a.size)), op)
+        return out
+
+    def select(self, m, t, f):
+        m = np.ascontiguousarray(m, dtype=np.uint8); t = np.ascontiguousarray(t)
+        f = np.ascontiguousarray(f, dtype=t.dtype); out = np.empty_like(t)
+        self._chk(self._f("select")(NP2T[t.dtype], _p(m), _p(t), _p(f), _p(out), ctypes.c_size_t(t.size)), "select")
+        return out
+
+    def cast(self, a, dst_dtype):
+        a = np.ascontiguousarray(a); out = np.empty(a.size, dst_dtype)
+        self._chk(self._f("cast")(NP2T[a.dtype], NP2T[np.dtype(dst_dtype)], _p(a), _p(out),
+                                  ctypes.c_size_t(a.size)), "cast")
+        return out
+
+    def gather(self, src, idx, mask):
+        src = np.ascontiguousarray(src); idx = np.ascontiguousarray(idx)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8); out = np.empty(idx.size, src.dtype)
+        self._chk(self._f("gather")(NP2T[src.dtype], NP2T[idx.dtype], _p(src), ctypes.c_size_t(src.size),
+                                    _p(idx), _p(mask), _p(out), ctypes.c_size_t(idx.size)), "gather")
+        return out
+
+    def scatter(self, target, val, idx, mask, add=False):
+        """returns the modified copy of ``target``"""
+        target = np.array(target, copy=True); val = np.ascontiguousarray(val, dtype=target.dtype)
+        idx = np.ascontiguousarray(idx); mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._chk(self._f("scatter")(NP2T[target.dtype], NP2T[idx.dtype], int(add), _p(target), _p(val),
+                                     _p(idx), _p(mask), ctypes.c_size_t(idx.size)), "scatter")
+        return target
+
+    def reduce(self, op, a):
+        a = np.ascontiguousarray(a); out = np.empty(1, a.dtype)
+        self._chk(self._f("reduce")(NP2T[a.dtype], op.encode(), _p(a), _p(out), ctypes.c_size_t(a.size)), op)
+        return out[0]
+
+    def mask_reduce(self, op, m):
+        m = np.ascontiguousarray(m, dtype=np.uint8); out = ctypes.c_uint64()
+        self._chk(self._f("mask_reduce")(op.encode(), _p(m), ctypes.byref(out), ctypes.c_size_t(m.size)), op)
+        return out.value
+
+    def linspace(self, lo, hi, n):
+        out = np.empty(n, np.float32)
+        self._f("linspace_f32")(ctypes.c_float(lo), ctypes.c_float(hi), _p(out), ctypes.c_size_t(n))
+        return out
+
+    def psum(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float32); out = np.empty_like(a)
+        self._f("psum_f32")(_p(a), _p(out), ctypes.c_size_t(a.size))
+        return out
+
+    # ---- BASELINE.json configs -------------------------------------------------------------
+    def cfg1(self, a, x, b):
+        sec = ctypes.c_double()
+        y = self._f("cfg1")(_p(a), _p(x), _p(b), ctypes.c_size_t(a.size), ctypes.byref(sec))
+        return y, sec.value
+
+    def cfg2(self, a, x, b):
+        sec = ctypes.c_double()
+        y = self._f("cfg2")(_p(a), _p(x), _p(b), ctypes.c_size_t(a.size), ctypes.byref(sec))
+        return y, sec.value
+
+    def cfg3a(self, a, x, b):
+        ga = np.empty_like(a); gb = np.empty_like(a); sec = ctypes.c_double()
+        y = self._f("cfg3a")(_p(a), _p(x), _p(b), ctypes.c_size_t(a.size), _p(ga), _p(gb), ctypes.byref(sec))
+        return y, ga, gb, sec.value
+
+    def cfg3b(self, A, B, x, idx):
+        gA = np.empty_like(A); gB = np.empty_like(B); sec = ctypes.c_double()
+        y = self._f("cfg3b")(_p(A), _p(B), ctypes.c_size_t(A.size), _p(x), _p(idx), ctypes.c_size_t(x.size),
+                             _p(gA), _p(gB), ctypes.byref(sec))
+        return y, gA, gB, sec.value
+
+
+def _build(target):
+    subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
+
+
+_cache = {}
+
+
+def port(build=True):
+    """our C restatement; always buildable (gcc only)"""
+    if "port" not in _cache:
+        path = os.path.join(ORACLE_DIR, "libenoki_oracle.so")
+        if build and (not os.path.exists(path) or
+                      os.path.getmtime(path) < os.path.getmtime(os.path.join(ORACLE_DIR, "enoki_oracle.c"))):
+            _build("port")
+        _cache["port"] = Checker(ctypes.CDLL(path), "orc_", "port")
+    return _cache["port"]
+
+
+def ref_available():
+    return os.path.exists(os.path.join(ORACLE_DIR, "_ref", "libenoki_ref.so")) or os.path.isdir("/root/reference")
+
+
+def ref():
+    """the real reference build; exists where /root/reference was available at build time"""
+    if "ref" not in _cache:
+        path = os.path.join(ORACLE_DIR, "_ref", "libenoki_ref.so")
+        if not os.path.exists(path):
+            if not os.path.isdir("/root/reference"):
+                raise FileNotFoundError(path)
+            _build("ref")
+        _cache["ref"] = Checker(ctypes.CDLL(path), "ref_", "reference")
+    return _cache["ref"]
