@@ -1,0 +1,124 @@
+"""In-tree build of the native libraries (gfx950 only).
+
+    python -m enoki_amd._build            # everything that is out of date
+    python -m enoki_amd._build --force
+
+Products (git-ignored, but shipped to the GPU box with the tree):
+    enoki_amd/libenoki-hip.so            C ABI + HIP kernels      (csrc/*.hip, csrc/runtime.cpp)
+    enoki_amd/libenoki-hip-autodiff.so   Tape<HIPArray<float>>    (src/autodiff.cpp)          [if present]
+    enoki_amd/hip*.so                    pybind11 modules         (python/*.cpp)              [if present]
+
+hipcc cross-compiles for gfx950 without a GPU, so this also runs in the CPU-only dev container.
+"""
+import concurrent.futures
+import os
+import subprocess
+import sys
+import sysconfig
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(ROOT, "build", "obj")
+
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+ARCH = "gfx950"
+# -ffp-contract=off: only explicit fma() calls fuse (bit parity with the reference CPU path)
+COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", "-fvisibility=hidden",
+          "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
+DEVICE = [f"--offload-arch={ARCH}"]
+
+LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "probe.hip"]
+
+
+def _newer(target, deps):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _headers():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    inc = os.path.join(ROOT, "include")
+    for base, _, files in os.walk(inc):
+        hs += [os.path.join(base, f) for f in files if f.endswith(".h")]
+    return hs
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: " + " ".join(cmd) + "\n" + r.stdout)
+    return r.stdout
+
+
+def _compile(src, force):
+    obj = os.path.join(OBJ, os.path.basename(src) + ".o")
+    if force or _newer(obj, [src] + _headers()):
+        cmd = [HIPCC] + DEVICE + COMMON + (["-x", "hip"] if src.endswith(".cpp") and "csrc" in src else []) + ["-c", src, "-o", obj]
+        _run(cmd)
+    return obj
+
+
+def build_core(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    sources = [os.path.join(CSRC, s) for s in LIB_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    with concurrent.futures.ThreadPoolExecutor(max_workers=min(8, len(sources))) as ex:
+        objs = list(ex.map(lambda s: _compile(s, force), sources))
+    lib = os.path.join(HERE, "libenoki-hip.so")
+    if force or _newer(lib, objs):
+        _run([HIPCC] + DEVICE + ["-shared", "-fPIC", "-o", lib] + objs)
+        if verbose:
+            print(f"[enoki_amd] built {os.path.relpath(lib, ROOT)}")
+    return lib
+
+
+def build_autodiff(force=False, verbose=True):
+    src = os.path.join(HERE, "src", "autodiff.cpp")
+    if not os.path.exists(src):
+        return None
+    os.makedirs(OBJ, exist_ok=True)
+    lib = os.path.join(HERE, "libenoki-hip-autodiff.so")
+    if force or _newer(lib, [src] + _headers()):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", f"-I{os.path.join(ROOT, 'include')}",
+              src, "-o", lib, f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN"])
+        if verbose:
+            print(f"[enoki_amd] built {os.path.relpath(lib, ROOT)}")
+    return lib
+
+
+def build_python(force=False, verbose=True):
+    pydir = os.path.join(HERE, "python")
+    if not os.path.isdir(pydir):
+        return []
+    import pybind11
+    ext = sysconfig.get_config_var("EXT_SUFFIX")
+    inc = [f"-I{pybind11.get_include()}", f"-I{sysconfig.get_paths()['include']}", f"-I{os.path.join(ROOT, 'include')}"]
+    out = []
+    jobs = []
+    for f in sorted(os.listdir(pydir)):
+        if not f.endswith(".cpp"):
+            continue
+        src = os.path.join(pydir, f)
+        mod = os.path.join(HERE, f[:-4] + ext)
+        out.append(mod)
+        if force or _newer(mod, [src] + _headers() + [os.path.join(pydir, h) for h in os.listdir(pydir) if h.endswith(".h")]):
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall"] + inc +
+                        [src, "-o", mod, f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN"])
+    if jobs:
+        with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
+            list(ex.map(_run, jobs))
+        if verbose:
+            print(f"[enoki_amd] built {len(jobs)} python module(s)")
+    return out
+
+
+def build_all(force=False, verbose=True):
+    build_core(force, verbose)
+    build_autodiff(force, verbose)
+    build_python(force, verbose)
+
+
+if __name__ == "__main__":
+    build_all(force="--force" in sys.argv)

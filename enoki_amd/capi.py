@@ -1,0 +1,306 @@
+"""ctypes binding of the C ABI declared in include/enoki_hip.h (libenoki-hip.so).
+
+This is the thinnest possible host-side view of the library: device buffers are raw pointers
+obtained from ``ek_hip_malloc`` and every function maps 1:1 onto an exported symbol.  It exists
+for the parity tests (which must call *through the C ABI*), for tools/ and for bench.py's
+low-level probes; user code goes through the HIPArray / DiffArray classes instead.
+
+There is deliberately no CPU fallback: if the shared library is missing the import fails.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libenoki-hip.so")
+
+# ek_type
+BOOL, I32, U32, I64, U64, F32, F64 = range(7)
+NP2EK = {np.dtype(np.uint8): BOOL, np.dtype(np.bool_): BOOL, np.dtype(np.int32): I32, np.dtype(np.uint32): U32,
+         np.dtype(np.int64): I64, np.dtype(np.uint64): U64, np.dtype(np.float32): F32, np.dtype(np.float64): F64}
+EK2NP = {BOOL: np.uint8, I32: np.int32, U32: np.uint32, I64: np.int64, U64: np.uint64, F32: np.float32, F64: np.float64}
+
+UNARY = {n: i for i, n in enumerate(
+    ["neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
+     "popcnt", "lzcnt", "tzcnt", "sign", "copy"])}
+BINARY = {n: i for i, n in enumerate(
+    ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul"])}
+TERNARY = {n: i for i, n in enumerate(["fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd"])}
+COMPARE = {n: i for i, n in enumerate(["eq", "neq", "lt", "le", "gt", "ge"])}
+REDUCE = {n: i for i, n in enumerate(["hsum", "hprod", "hmin", "hmax"])}
+MASK_REDUCE = {n: i for i, n in enumerate(["all", "any", "count"])}
+
+EXPORTS = [
+    "ek_hip_init", "ek_hip_device", "ek_hip_device_count", "ek_hip_stream", "ek_hip_set_stream", "ek_hip_sync",
+    "ek_hip_last_error", "ek_hip_malloc", "ek_hip_free", "ek_hip_malloc_trim", "ek_hip_host_malloc",
+    "ek_hip_host_free", "ek_hip_mem_get_info", "ek_hip_memcpy_to_device", "ek_hip_memcpy_to_host",
+    "ek_hip_memcpy_device", "ek_hip_memset", "ek_hip_whos", "ek_hip_set_log_level", "ek_hip_log_level",
+    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos",
+    "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
+    "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
+    "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum",
+]
+
+
+class Operand(ctypes.Structure):
+    _fields_ = [("ptr", ctypes.c_void_p), ("imm", ctypes.c_uint64), ("size", ctypes.c_size_t)]
+
+
+class EnokiHipError(RuntimeError):
+    pass
+
+
+def load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing -- run `python -m enoki_amd._build` (there is no CPU fallback)")
+    lib = ctypes.CDLL(LIB_PATH)
+    lib.ek_hip_last_error.restype = ctypes.c_char_p
+    lib.ek_hip_stream.restype = ctypes.c_void_p
+    lib.ek_hip_whos.restype = ctypes.c_void_p
+    lib.ek_hip_launch_count.restype = ctypes.c_uint64
+    lib.ek_hip_log_level.restype = ctypes.c_uint32
+    return lib
+
+
+lib = load()
+
+
+def check(rc):
+    if rc != 0:
+        raise EnokiHipError(f"[{rc}] " + lib.ek_hip_last_error().decode())
+
+
+def init(device=-1):
+    check(lib.ek_hip_init(device))
+
+
+def sync():
+    check(lib.ek_hip_sync())
+
+
+def stream():
+    return lib.ek_hip_stream()
+
+
+def set_tuning(key, value):
+    check(lib.ek_hip_set_tuning(key.encode(), int(value)))
+
+
+def whos():
+    p = lib.ek_hip_whos()
+    s = ctypes.string_at(p).decode()
+    ctypes.CDLL(None).free(ctypes.c_void_p(p))
+    return s
+
+
+class Buf:
+    """A device array: raw pointer + numpy dtype + element count (owned unless ``own=False``)."""
+
+    def __init__(self, dtype, n, own=True, ptr=None):
+        self.dtype = np.dtype(dtype)
+        if self.dtype == np.bool_:
+            self.dtype = np.dtype(np.uint8)
+        self.n = int(n)
+        self.own = own
+        if ptr is None:
+            p = ctypes.c_void_p()
+            check(lib.ek_hip_malloc(ctypes.c_size_t(max(self.n, 1) * self.dtype.itemsize), ctypes.byref(p)))
+            self.ptr = p.value
+        else:
+            self.ptr = ptr
+
+    @property
+    def ek(self):
+        return NP2EK[self.dtype]
+
+    @staticmethod
+    def from_numpy(a):
+        a = np.ascontiguousarray(a)
+        if a.dtype == np.bool_:
+            a = a.astype(np.uint8)
+        b = Buf(a.dtype, a.size)
+        if a.size:
+            check(lib.ek_hip_memcpy_to_device(ctypes.c_void_p(b.ptr), a.ctypes.data_as(ctypes.c_void_p),
+                                              ctypes.c_size_t(a.nbytes)))
+        return b
+
+    def numpy(self):
+        out = np.empty(self.n, self.dtype)
+        if self.n:
+            check(lib.ek_hip_memcpy_to_host(out.ctypes.data_as(ctypes.c_void_p), ctypes.c_void_p(self.ptr),
+                                            ctypes.c_size_t(out.nbytes)))
+        return out
+
+    def view(self, offset, n):
+        """non-owning window (element offset), e.g. to exercise misaligned pointers"""
+        return Buf(self.dtype, n, own=False, ptr=self.ptr + offset * self.dtype.itemsize)
+
+    def free(self):
+        if self.own and self.ptr:
+            lib.ek_hip_free(ctypes.c_void_p(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def _imm_bits(value, dtype):
+    return int(np.array([value], dtype=dtype).view({1: np.uint8, 4: np.uint32, 8: np.uint64}[np.dtype(dtype).itemsize])[0])
+
+
+def operand(x, dtype=None):
+    """Buf -> array operand; python/numpy scalar -> immediate operand of ``dtype``"""
+    if isinstance(x, Buf):
+        return Operand(x.ptr, 0, x.n)
+    return Operand(None, _imm_bits(x, dtype), 1)
+
+
+def _n(*xs):
+    n = 1
+    for x in xs:
+        if isinstance(x, Buf) and x.n != 1:
+            n = x.n
+    return n
+
+
+def _dtype(*xs):
+    for x in xs:
+        if isinstance(x, Buf):
+            return x.dtype
+    raise TypeError("at least one operand must be a device buffer")
+
+
+def unary(op, a, n=None):
+    dt = _dtype(a); n = _n(a) if n is None else n
+    out = Buf(dt, n); oa = operand(a, dt)
+    check(lib.ek_hip_unary(UNARY[op], NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(oa), ctypes.c_size_t(n)))
+    return out
+
+
+def binary(op, a, b, n=None):
+    dt = _dtype(a, b); n = _n(a, b) if n is None else n
+    out = Buf(dt, n); oa, ob = operand(a, dt), operand(b, dt)
+    check(lib.ek_hip_binary(BINARY[op], NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(oa), ctypes.byref(ob),
+                            ctypes.c_size_t(n)))
+    return out
+
+
+def ternary(op, a, b, c, n=None):
+    dt = _dtype(a, b, c); n = _n(a, b, c) if n is None else n
+    out = Buf(dt, n); oa, ob, oc = operand(a, dt), operand(b, dt), operand(c, dt)
+    check(lib.ek_hip_ternary(TERNARY[op], NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(oa), ctypes.byref(ob),
+                             ctypes.byref(oc), ctypes.c_size_t(n)))
+    return out
+
+
+def sincos(a):
+    dt = _dtype(a); n = _n(a)
+    s, c = Buf(dt, n), Buf(dt, n); oa = operand(a, dt)
+    check(lib.ek_hip_sincos(NP2EK[dt], ctypes.c_void_p(s.ptr), ctypes.c_void_p(c.ptr), ctypes.byref(oa),
+                            ctypes.c_size_t(n)))
+    return s, c
+
+
+def compare(op, a, b, n=None):
+    dt = _dtype(a, b); n = _n(a, b) if n is None else n
+    out = Buf(np.uint8, n); oa, ob = operand(a, dt), operand(b, dt)
+    check(lib.ek_hip_compare(COMPARE[op], NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(oa), ctypes.byref(ob),
+                             ctypes.c_size_t(n)))
+    return out
+
+
+def select(m, t, f, n=None):
+    dt = _dtype(t, f); n = _n(m, t, f) if n is None else n
+    out = Buf(dt, n); om, ot, of = operand(m, np.uint8), operand(t, dt), operand(f, dt)
+    check(lib.ek_hip_select(NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(om), ctypes.byref(ot), ctypes.byref(of),
+                            ctypes.c_size_t(n)))
+    return out
+
+
+def cast(a, dst_dtype):
+    n = a.n
+    out = Buf(dst_dtype, n); oa = operand(a)
+    check(lib.ek_hip_cast(a.ek, NP2EK[np.dtype(dst_dtype)], ctypes.c_void_p(out.ptr), ctypes.byref(oa),
+                          ctypes.c_size_t(n)))
+    return out
+
+
+def fill(dtype, value, n):
+    out = Buf(dtype, n)
+    check(lib.ek_hip_fill(out.ek, ctypes.c_void_p(out.ptr), ctypes.c_uint64(_imm_bits(value, dtype)), ctypes.c_size_t(n)))
+    return out
+
+
+def arange(dtype, n, start=0, step=1):
+    out = Buf(dtype, n)
+    check(lib.ek_hip_arange(out.ek, ctypes.c_void_p(out.ptr), ctypes.c_int64(start), ctypes.c_int64(step),
+                            ctypes.c_size_t(n)))
+    return out
+
+
+def linspace(dtype, lo, hi, n):
+    out = Buf(dtype, n)
+    check(lib.ek_hip_linspace(out.ek, ctypes.c_void_p(out.ptr), ctypes.c_double(lo), ctypes.c_double(hi),
+                              ctypes.c_size_t(n)))
+    return out
+
+
+def reverse(a):
+    out = Buf(a.dtype, a.n)
+    check(lib.ek_hip_reverse(a.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(a.ptr), ctypes.c_size_t(a.n)))
+    return out
+
+
+def gather(src, index, mask=True, n=None):
+    n = _n(index, mask) if n is None else n
+    out = Buf(src.dtype, n)
+    oi = operand(index); om = operand(mask, np.uint8)
+    check(lib.ek_hip_gather(src.ek, index.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(src.ptr), ctypes.byref(oi),
+                            ctypes.byref(om), ctypes.c_size_t(n)))
+    return out
+
+
+def scatter(target, value, index, mask=True, n=None):
+    n = _n(value, index, mask) if n is None else n
+    ov, oi, om = operand(value, target.dtype), operand(index), operand(mask, np.uint8)
+    check(lib.ek_hip_scatter(target.ek, index.ek, ctypes.c_void_p(target.ptr), ctypes.byref(ov), ctypes.byref(oi),
+                             ctypes.byref(om), ctypes.c_size_t(n)))
+
+
+def scatter_add(target, value, index, mask=True, n=None, mode=0):
+    n = _n(value, index, mask) if n is None else n
+    ov, oi, om = operand(value, target.dtype), operand(index), operand(mask, np.uint8)
+    check(lib.ek_hip_scatter_add(target.ek, index.ek, ctypes.c_void_p(target.ptr), ctypes.c_size_t(target.n),
+                                 ctypes.byref(ov), ctypes.byref(oi), ctypes.byref(om), ctypes.c_size_t(n), mode))
+
+
+def reduce(op, a):
+    out = Buf(a.dtype, 1)
+    check(lib.ek_hip_reduce(REDUCE[op], a.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(a.ptr if a.n else None),
+                            ctypes.c_size_t(a.n)))
+    return out
+
+
+def hsum_safe_mul(w, g, n=None):
+    dt = _dtype(w, g); n = _n(w, g) if n is None else n
+    out = Buf(dt, 1); ow, og = operand(w, dt), operand(g, dt)
+    check(lib.ek_hip_hsum_safe_mul(NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(ow), ctypes.byref(og),
+                                   ctypes.c_size_t(n)))
+    return out
+
+
+def mask_reduce(op, m):
+    res = ctypes.c_uint64()
+    check(lib.ek_hip_mask_reduce(MASK_REDUCE[op], ctypes.c_void_p(m.ptr if m.n else None), ctypes.c_size_t(m.n),
+                                 ctypes.byref(res)))
+    return res.value
+
+
+def psum(a):
+    out = Buf(a.dtype, a.n)
+    check(lib.ek_hip_psum(a.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(a.ptr), ctypes.c_size_t(a.n)))
+    return out

@@ -1,0 +1,122 @@
+// Internal helpers shared by the translation units of libenoki-hip.so (not installed).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <type_traits>
+
+#include "../../include/enoki_hip.h"
+
+namespace ek {
+
+// ---- error reporting -------------------------------------------------------------------------
+int fail(int code, const char *fmt, ...) __attribute__((format(printf, 2, 3)));
+int hip_fail(hipError_t err, const char *what, const char *file, int line);
+
+#define EK_HIP_CHECK(expr)                                                                     \
+    do {                                                                                       \
+        hipError_t ek_err_ = (expr);                                                           \
+        if (ek_err_ != hipSuccess) return ::ek::hip_fail(ek_err_, #expr, __FILE__, __LINE__);  \
+    } while (0)
+
+// ---- runtime state ---------------------------------------------------------------------------
+struct Tuning {
+    int blocks_per_cu = 8;   // grid cap for streaming kernels = blocks_per_cu * #CU
+    int reduce_blocks_per_cu = 4;
+};
+
+struct Context {
+    bool initialized = false;
+    int device = -1;
+    int num_cu = 256;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    uint32_t log_level = 0;
+    uint64_t launches = 0;
+    Tuning tuning;
+    void *reduce_scratch = nullptr;   // partials of two-stage reductions
+    size_t reduce_scratch_bytes = 0;
+};
+
+Context &ctx();
+int ensure_init();
+int reduce_scratch(size_t bytes, void **out);
+
+inline void note_launch(const char *name, size_t n) {
+    Context &c = ctx();
+    c.launches++;
+    if (c.log_level >= 3)
+        fprintf(stderr, "enoki-hip: launch %s (n=%zu)\n", name, n);
+}
+
+// post-launch check: kernel launch failures surface through hipGetLastError
+#define EK_LAUNCH_CHECK(name, n)                                                               \
+    do {                                                                                       \
+        ::ek::note_launch(name, n);                                                            \
+        hipError_t ek_err_ = hipGetLastError();                                                \
+        if (ek_err_ != hipSuccess) return ::ek::hip_fail(ek_err_, name, __FILE__, __LINE__);   \
+    } while (0)
+
+// ---- type mapping ------------------------------------------------------------------------------
+template <int Type> struct ctype;
+template <> struct ctype<EK_BOOL> { using type = uint8_t; };
+template <> struct ctype<EK_I32> { using type = int32_t; };
+template <> struct ctype<EK_U32> { using type = uint32_t; };
+template <> struct ctype<EK_I64> { using type = int64_t; };
+template <> struct ctype<EK_U64> { using type = uint64_t; };
+template <> struct ctype<EK_F32> { using type = float; };
+template <> struct ctype<EK_F64> { using type = double; };
+
+inline size_t type_size(int type) {
+    switch (type) {
+        case EK_BOOL: return 1;
+        case EK_I32: case EK_U32: case EK_F32: return 4;
+        case EK_I64: case EK_U64: case EK_F64: return 8;
+        default: return 0;
+    }
+}
+
+// arithmetic type whose overflow wraps: unsigned counterpart for integers, T itself for fp
+template <typename T, bool = std::is_floating_point_v<T>> struct wrap_type { using type = T; };
+template <typename T> struct wrap_type<T, false> { using type = std::make_unsigned_t<T>; };
+template <typename T> using wrap_t = typename wrap_type<T>::type;
+
+// Kernel-side view of an ek_operand
+template <typename T> struct Arg {
+    const T *ptr;   // device pointer or nullptr
+    T imm;          // immediate when ptr == nullptr
+    uint32_t vec;   // 1: one element per index, 0: broadcast
+};
+
+template <typename T> inline int make_arg(const ek_operand *o, size_t n, Arg<T> &out, const char *what) {
+    if (!o) return fail(EK_ERR_INVALID, "%s: null operand", what);
+    if (o->ptr == nullptr) {
+        T v;
+        memcpy(&v, &o->imm, sizeof(T));
+        out = Arg<T>{ nullptr, v, 0u };
+        return EK_OK;
+    }
+    if (o->size != n && o->size != 1)
+        return fail(EK_ERR_INVALID, "%s: arrays of incompatible size (%zu vs %zu)", what, o->size, n);
+    out = Arg<T>{ (const T *) o->ptr, T(0), o->size != 1 ? 1u : 0u };
+    return EK_OK;
+}
+
+inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+template <typename T> inline bool arg_aligned(const Arg<T> &a) { return !a.vec || aligned16(a.ptr); }
+
+// Grid for a streaming kernel that handles `work_items` per-thread items with 256-thread blocks
+inline unsigned stream_grid(size_t work_items, int blocks_per_cu) {
+    Context &c = ctx();
+    size_t blocks = (work_items + 255) / 256;
+    size_t cap = (size_t) c.num_cu * (size_t) blocks_per_cu;
+    if (blocks > cap) blocks = cap;
+    if (blocks == 0) blocks = 1;
+    return (unsigned) blocks;
+}
+
+} // namespace ek

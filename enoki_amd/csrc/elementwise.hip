@@ -1,0 +1,403 @@
+// Vertical (elementwise) ops of HIPArray<T>: arithmetic, fma family, rounding, bit ops,
+// transcendental first wave, compares, select, casts, and the fused backward primitives
+// safe_mul / safe_fmadd.  SURVEY.md rows a2-a5, a11.
+//
+// Semantics follow the reference's CPU (AVX2 DynamicArray) path, which is the parity target:
+//   * IEEE round-to-nearest add/sub/mul/div/sqrt/fma, no flush-to-zero (the CUDA path's .ftz,
+//     cuda.h:343-430, is NOT reproduced: the CPU path does not flush, array_intrin.h:167-194);
+//   * min/max: first operand wins on unordered compares (array_avx.h:244-245);
+//   * f32 -> i32 casts truncate, out of range gives 0x80000000 (cvttps2dq);
+//   * variable shifts with count >= width give 0 / sign fill (vpsllvd & co., array_avx2.h);
+//   * sin/cos/exp/log: array_math.h algorithms (csrc/ek_math.h), bit-exact.
+#include "ek_map.h"
+#include "ek_math.h"
+
+namespace ek {
+
+template <typename T> inline constexpr bool is_fp = std::is_floating_point_v<T>;
+template <typename T> inline constexpr bool is_int = std::is_integral_v<T> && !std::is_same_v<T, uint8_t>;
+template <typename T> inline constexpr bool is_mask = std::is_same_v<T, uint8_t>;
+
+template <typename T> using uint_of = std::conditional_t<sizeof(T) == 8, uint64_t, std::conditional_t<sizeof(T) == 4, uint32_t, uint8_t>>;
+
+template <typename T> __device__ __forceinline__ uint_of<T> bits(T v) {
+    uint_of<T> u;
+    __builtin_memcpy(&u, &v, sizeof(T));
+    return u;
+}
+template <typename T> __device__ __forceinline__ T from_bits(uint_of<T> u) {
+    T v;
+    __builtin_memcpy(&v, &u, sizeof(T));
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Unary
+// ------------------------------------------------------------------------------------------------
+template <int Op, typename T> constexpr bool unary_supported() {
+    switch (Op) {
+        case EK_NEG: case EK_ABS: return !is_mask<T>;
+        case EK_NOT: return !is_fp<T>;
+        case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_FLOOR: case EK_CEIL: case EK_ROUND: case EK_TRUNC:
+        case EK_SIGN: return is_fp<T>;
+        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG: return std::is_same_v<T, float>;
+        case EK_POPCNT: case EK_LZCNT: case EK_TZCNT: return is_int<T>;
+        case EK_COPY: return true;
+        default: return false;
+    }
+}
+
+template <int Op, typename T> struct UnaryOp {
+    static __device__ __forceinline__ T apply(T x) {
+        using U = uint_of<T>;
+        constexpr U sign_bit = U(1) << (sizeof(T) * 8 - 1);
+        if constexpr (Op == EK_COPY) {
+            return x;
+        } else if constexpr (Op == EK_NEG) {
+            if constexpr (is_fp<T>) return from_bits<T>(bits(x) ^ sign_bit);
+            else return (T) (U(0) - (U) x);
+        } else if constexpr (Op == EK_ABS) {
+            if constexpr (is_fp<T>) return from_bits<T>(bits(x) & ~sign_bit);
+            else if constexpr (std::is_signed_v<T>) return x < 0 ? (T) (U(0) - (U) x) : x;
+            else return x;
+        } else if constexpr (Op == EK_NOT) {
+            if constexpr (is_mask<T>) return x ? 0 : 1;
+            else return (T) ~(U) x;
+        } else if constexpr (Op == EK_SQRT) {
+            if constexpr (sizeof(T) == 4) return __builtin_sqrtf(x); else return __builtin_sqrt(x);   // correctly rounded expansion
+        } else if constexpr (Op == EK_RCP) {
+            return T(1) / x;
+        } else if constexpr (Op == EK_RSQRT) {
+            if constexpr (sizeof(T) == 4) return 1.0f / __builtin_sqrtf(x); else return 1.0 / __builtin_sqrt(x);
+        } else if constexpr (Op == EK_FLOOR) {
+            if constexpr (sizeof(T) == 4) return __builtin_floorf(x); else return __builtin_floor(x);
+        } else if constexpr (Op == EK_CEIL) {
+            if constexpr (sizeof(T) == 4) return __builtin_ceilf(x); else return __builtin_ceil(x);
+        } else if constexpr (Op == EK_ROUND) {
+            if constexpr (sizeof(T) == 4) return __builtin_rintf(x); else return __builtin_rint(x);
+        } else if constexpr (Op == EK_TRUNC) {
+            if constexpr (sizeof(T) == 4) return __builtin_truncf(x); else return __builtin_trunc(x);
+        } else if constexpr (Op == EK_SIGN) {
+            // (sign_mask & a) | 1.0   (array_router.h:371)
+            return from_bits<T>((bits(x) & sign_bit) | bits(T(1)));
+        } else if constexpr (Op == EK_SIN) {
+            float s, c; dev::sincos_f32<true, false>(x, s, c); return s;
+        } else if constexpr (Op == EK_COS) {
+            float s, c; dev::sincos_f32<false, true>(x, s, c); return c;
+        } else if constexpr (Op == EK_EXP) {
+            return dev::exp_f32(x);
+        } else if constexpr (Op == EK_LOG) {
+            return dev::log_f32(x);
+        } else if constexpr (Op == EK_POPCNT) {
+            if constexpr (sizeof(T) == 4) return (T) __popc((uint32_t) x); else return (T) __popcll((uint64_t) x);
+        } else if constexpr (Op == EK_LZCNT) {
+            if constexpr (sizeof(T) == 4) return (T) (x ? __clz((int) x) : 32); else return (T) (x ? __clzll((long long) x) : 64);
+        } else if constexpr (Op == EK_TZCNT) {
+            if constexpr (sizeof(T) == 4) return (T) (x ? __ffs((int) x) - 1 : 32); else return (T) (x ? __ffsll((long long) x) - 1 : 64);
+        } else {
+            return x;
+        }
+    }
+};
+
+struct SinCosOp {
+    static __device__ __forceinline__ void apply(float x, float &s, float &c) { dev::sincos_f32<true, true>(x, s, c); }
+};
+
+template <int Op, typename T> int unary_launch(void *out, const ek_operand *a, size_t n) {
+    if constexpr (unary_supported<Op, T>()) {
+        Arg<T> aa;
+        if (int rc = make_arg<T>(a, n, aa, "ek_hip_unary")) return rc;
+        return launch_map1<UnaryOp<Op, T>>("unary", (T *) out, n, aa);
+    } else {
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_unary(): op %d is not defined for type %d", Op, (int) sizeof(T));
+    }
+}
+
+#define EK_UNARY_CASE(OP) case OP: return unary_launch<OP, T>(out, a, n);
+template <typename T> int unary_dispatch(int op, void *out, const ek_operand *a, size_t n) {
+    switch (op) {
+        EK_UNARY_CASE(EK_NEG) EK_UNARY_CASE(EK_ABS) EK_UNARY_CASE(EK_NOT) EK_UNARY_CASE(EK_SQRT)
+        EK_UNARY_CASE(EK_RCP) EK_UNARY_CASE(EK_RSQRT) EK_UNARY_CASE(EK_FLOOR) EK_UNARY_CASE(EK_CEIL)
+        EK_UNARY_CASE(EK_ROUND) EK_UNARY_CASE(EK_TRUNC) EK_UNARY_CASE(EK_SIN) EK_UNARY_CASE(EK_COS)
+        EK_UNARY_CASE(EK_EXP) EK_UNARY_CASE(EK_LOG) EK_UNARY_CASE(EK_POPCNT) EK_UNARY_CASE(EK_LZCNT)
+        EK_UNARY_CASE(EK_TZCNT) EK_UNARY_CASE(EK_SIGN) EK_UNARY_CASE(EK_COPY)
+        default: return fail(EK_ERR_INVALID, "ek_hip_unary(): unknown op %d", op);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Binary
+// ------------------------------------------------------------------------------------------------
+template <int Op, typename T> constexpr bool binary_supported() {
+    switch (Op) {
+        case EK_ADD: case EK_SUB: case EK_MUL: case EK_DIV: case EK_MIN: case EK_MAX: return !is_mask<T>;
+        case EK_MOD: case EK_MULHI: case EK_SL: case EK_SR: return is_int<T>;
+        case EK_AND: case EK_OR: case EK_XOR: return true;   // fp: bitwise on the representation
+        case EK_SAFE_MUL: return is_fp<T>;
+        default: return false;
+    }
+}
+
+template <int Op, typename T> struct BinaryOp {
+    static __device__ __forceinline__ T apply(T x, T y) {
+        using U = uint_of<T>;
+        constexpr unsigned Bits = sizeof(T) * 8;
+        if constexpr (Op == EK_ADD) {
+            if constexpr (is_fp<T>) return x + y; else return (T) ((U) x + (U) y);
+        } else if constexpr (Op == EK_SUB) {
+            if constexpr (is_fp<T>) return x - y; else return (T) ((U) x - (U) y);
+        } else if constexpr (Op == EK_MUL) {
+            if constexpr (is_fp<T>) return x * y; else return (T) ((U) x * (U) y);
+        } else if constexpr (Op == EK_DIV) {
+            if constexpr (is_fp<T>) return x / y;
+            else return y == 0 ? T(0) : ((std::is_signed_v<T> && y == T(-1)) ? (T) (U(0) - (U) x) : (T) (x / y));
+        } else if constexpr (Op == EK_MOD) {
+            return y == 0 ? T(0) : ((std::is_signed_v<T> && y == T(-1)) ? T(0) : (T) (x % y));
+        } else if constexpr (Op == EK_MIN) {
+            return y < x ? y : x;
+        } else if constexpr (Op == EK_MAX) {
+            return y > x ? y : x;
+        } else if constexpr (Op == EK_MULHI) {
+            if constexpr (std::is_same_v<T, int32_t>) return __mulhi(x, y);
+            else if constexpr (std::is_same_v<T, uint32_t>) return __umulhi(x, y);
+            else if constexpr (std::is_same_v<T, int64_t>) return __mul64hi(x, y);
+            else return __umul64hi(x, y);
+        } else if constexpr (Op == EK_AND) {
+            return from_bits<T>(bits(x) & bits(y));
+        } else if constexpr (Op == EK_OR) {
+            return from_bits<T>(bits(x) | bits(y));
+        } else if constexpr (Op == EK_XOR) {
+            return from_bits<T>(bits(x) ^ bits(y));
+        } else if constexpr (Op == EK_SL) {
+            return (U) y >= Bits ? T(0) : (T) ((U) x << (U) y);
+        } else if constexpr (Op == EK_SR) {
+            if constexpr (std::is_signed_v<T>) return (U) y >= Bits ? (x < 0 ? T(-1) : T(0)) : (T) (x >> (U) y);
+            else return (U) y >= Bits ? T(0) : (T) (x >> y);
+        } else if constexpr (Op == EK_SAFE_MUL) {
+            return dev::safe_mul(x, y);
+        } else {
+            return x;
+        }
+    }
+};
+
+template <int Op, typename T> int binary_launch(void *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    if constexpr (binary_supported<Op, T>()) {
+        Arg<T> aa, bb;
+        if (int rc = make_arg<T>(a, n, aa, "ek_hip_binary")) return rc;
+        if (int rc = make_arg<T>(b, n, bb, "ek_hip_binary")) return rc;
+        return launch_map2<BinaryOp<Op, T>>("binary", (T *) out, n, aa, bb);
+    } else {
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_binary(): op %d is not defined for this type", Op);
+    }
+}
+
+#define EK_BINARY_CASE(OP) case OP: return binary_launch<OP, T>(out, a, b, n);
+template <typename T> int binary_dispatch(int op, void *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    switch (op) {
+        EK_BINARY_CASE(EK_ADD) EK_BINARY_CASE(EK_SUB) EK_BINARY_CASE(EK_MUL) EK_BINARY_CASE(EK_DIV)
+        EK_BINARY_CASE(EK_MOD) EK_BINARY_CASE(EK_MIN) EK_BINARY_CASE(EK_MAX) EK_BINARY_CASE(EK_MULHI)
+        EK_BINARY_CASE(EK_AND) EK_BINARY_CASE(EK_OR) EK_BINARY_CASE(EK_XOR) EK_BINARY_CASE(EK_SL)
+        EK_BINARY_CASE(EK_SR) EK_BINARY_CASE(EK_SAFE_MUL)
+        default: return fail(EK_ERR_INVALID, "ek_hip_binary(): unknown op %d", op);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Ternary
+// ------------------------------------------------------------------------------------------------
+template <int Op, typename T> struct TernaryOp {
+    static __device__ __forceinline__ T apply(T x, T y, T z) {
+        using U = uint_of<T>;
+        if constexpr (is_fp<T>) {
+            auto fma_ = [](T a, T b, T c) -> T {
+                if constexpr (sizeof(T) == 4) return __builtin_fmaf(a, b, c); else return __builtin_fma(a, b, c);
+            };
+            if constexpr (Op == EK_FMADD) return fma_(x, y, z);
+            else if constexpr (Op == EK_FMSUB) return fma_(x, y, -z);
+            else if constexpr (Op == EK_FNMADD) return fma_(-x, y, z);
+            else if constexpr (Op == EK_FNMSUB) return fma_(-x, y, -z);
+            else return dev::safe_fmadd(x, y, z);
+        } else {
+            // integer mad.lo (cuda.h:387-394)
+            U p = (U) x * (U) y;
+            if constexpr (Op == EK_FMADD) return (T) (p + (U) z);
+            else if constexpr (Op == EK_FMSUB) return (T) (p - (U) z);
+            else if constexpr (Op == EK_FNMADD) return (T) ((U) z - p);
+            else return (T) (U(0) - p - (U) z);
+        }
+    }
+};
+
+template <int Op, typename T>
+int ternary_launch(void *out, const ek_operand *a, const ek_operand *b, const ek_operand *c, size_t n) {
+    if constexpr (is_mask<T> || (Op == EK_SAFE_FMADD && !is_fp<T>)) {
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_ternary(): op %d is not defined for this type", Op);
+    } else {
+        Arg<T> aa, bb, cc;
+        if (int rc = make_arg<T>(a, n, aa, "ek_hip_ternary")) return rc;
+        if (int rc = make_arg<T>(b, n, bb, "ek_hip_ternary")) return rc;
+        if (int rc = make_arg<T>(c, n, cc, "ek_hip_ternary")) return rc;
+        return launch_map3<TernaryOp<Op, T>>("ternary", (T *) out, n, aa, bb, cc);
+    }
+}
+
+#define EK_TERNARY_CASE(OP) case OP: return ternary_launch<OP, T>(out, a, b, c, n);
+template <typename T>
+int ternary_dispatch(int op, void *out, const ek_operand *a, const ek_operand *b, const ek_operand *c, size_t n) {
+    switch (op) {
+        EK_TERNARY_CASE(EK_FMADD) EK_TERNARY_CASE(EK_FMSUB) EK_TERNARY_CASE(EK_FNMADD)
+        EK_TERNARY_CASE(EK_FNMSUB) EK_TERNARY_CASE(EK_SAFE_FMADD)
+        default: return fail(EK_ERR_INVALID, "ek_hip_ternary(): unknown op %d", op);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Compare / select / cast
+// ------------------------------------------------------------------------------------------------
+template <int Op, typename T> struct CompareOp {
+    static __device__ __forceinline__ uint8_t apply(T x, T y) {
+        if constexpr (Op == EK_EQ) return x == y;
+        else if constexpr (Op == EK_NEQ) return x != y;
+        else if constexpr (Op == EK_LT) return x < y;
+        else if constexpr (Op == EK_LE) return x <= y;
+        else if constexpr (Op == EK_GT) return x > y;
+        else return x >= y;
+    }
+};
+
+template <int Op, typename T> int compare_launch(uint8_t *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    Arg<T> aa, bb;
+    if (int rc = make_arg<T>(a, n, aa, "ek_hip_compare")) return rc;
+    if (int rc = make_arg<T>(b, n, bb, "ek_hip_compare")) return rc;
+    return launch_map2<CompareOp<Op, T>>("compare", out, n, aa, bb);
+}
+
+template <typename T> int compare_dispatch(int op, uint8_t *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    switch (op) {
+        case EK_EQ: return compare_launch<EK_EQ, T>(out, a, b, n);
+        case EK_NEQ: return compare_launch<EK_NEQ, T>(out, a, b, n);
+        case EK_LT: return compare_launch<EK_LT, T>(out, a, b, n);
+        case EK_LE: return compare_launch<EK_LE, T>(out, a, b, n);
+        case EK_GT: return compare_launch<EK_GT, T>(out, a, b, n);
+        case EK_GE: return compare_launch<EK_GE, T>(out, a, b, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_compare(): unknown op %d", op);
+    }
+}
+
+template <typename T> struct SelectOp {
+    static __device__ __forceinline__ T apply(uint8_t m, T t, T f) { return m ? t : f; }
+};
+
+template <typename T>
+int select_launch(void *out, const ek_operand *m, const ek_operand *t, const ek_operand *f, size_t n) {
+    Arg<uint8_t> mm;
+    Arg<T> tt, ff;
+    if (int rc = make_arg<uint8_t>(m, n, mm, "ek_hip_select")) return rc;
+    if (int rc = make_arg<T>(t, n, tt, "ek_hip_select")) return rc;
+    if (int rc = make_arg<T>(f, n, ff, "ek_hip_select")) return rc;
+    // a mask vector is read 16/sizeof(T) bytes per lane: needs that alignment only
+    return launch_map3<SelectOp<T>>("select", (T *) out, n, mm, tt, ff);
+}
+
+template <typename S, typename D> struct CastOp {
+    static __device__ __forceinline__ D apply(S x) {
+        if constexpr (std::is_same_v<S, float> && std::is_same_v<D, int32_t>) {
+            return dev::cvtt_i32(x);
+        } else if constexpr (is_fp<S> && std::is_integral_v<D>) {
+            // truncation (cvt.rzi, cuda.h:239-240); clamp like the hardware converter
+            if constexpr (std::is_same_v<D, uint8_t>) return x != S(0);
+            else return (D) x;
+        } else if constexpr (std::is_same_v<D, uint8_t>) {
+            return x != S(0);
+        } else {
+            return (D) x;
+        }
+    }
+};
+
+template <typename S, typename D> int cast_launch(void *out, const ek_operand *a, size_t n) {
+    Arg<S> aa;
+    if (int rc = make_arg<S>(a, n, aa, "ek_hip_cast")) return rc;
+    return launch_map1<CastOp<S, D>>("cast", (D *) out, n, aa);
+}
+
+template <typename S> int cast_dispatch(int dst, void *out, const ek_operand *a, size_t n) {
+    switch (dst) {
+        case EK_BOOL: return cast_launch<S, uint8_t>(out, a, n);
+        case EK_I32: return cast_launch<S, int32_t>(out, a, n);
+        case EK_U32: return cast_launch<S, uint32_t>(out, a, n);
+        case EK_I64: return cast_launch<S, int64_t>(out, a, n);
+        case EK_U64: return cast_launch<S, uint64_t>(out, a, n);
+        case EK_F32: return cast_launch<S, float>(out, a, n);
+        case EK_F64: return cast_launch<S, double>(out, a, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_cast(): unknown destination type %d", dst);
+    }
+}
+
+} // namespace ek
+
+using namespace ek;
+
+#define EK_TYPE_SWITCH(type, CALL, WHAT)                                                          \
+    switch (type) {                                                                              \
+        case EK_BOOL: { using T = uint8_t; return CALL; }                                         \
+        case EK_I32: { using T = int32_t; return CALL; }                                          \
+        case EK_U32: { using T = uint32_t; return CALL; }                                         \
+        case EK_I64: { using T = int64_t; return CALL; }                                          \
+        case EK_U64: { using T = uint64_t; return CALL; }                                         \
+        case EK_F32: { using T = float; return CALL; }                                            \
+        case EK_F64: { using T = double; return CALL; }                                           \
+        default: return fail(EK_ERR_INVALID, WHAT ": unknown type %d", type);                     \
+    }
+
+#define EK_PROLOGUE(WHAT)                                                                         \
+    if (int rc_ = ensure_init()) return rc_;                                                      \
+    if (n == 0) return EK_OK;                                                                     \
+    if (!out) return fail(EK_ERR_INVALID, WHAT ": null output pointer");
+
+extern "C" {
+
+int ek_hip_unary(int op, int type, void *out, const ek_operand *a, size_t n) {
+    EK_PROLOGUE("ek_hip_unary()")
+    EK_TYPE_SWITCH(type, unary_dispatch<T>(op, out, a, n), "ek_hip_unary()")
+}
+
+int ek_hip_binary(int op, int type, void *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    EK_PROLOGUE("ek_hip_binary()")
+    EK_TYPE_SWITCH(type, binary_dispatch<T>(op, out, a, b, n), "ek_hip_binary()")
+}
+
+int ek_hip_ternary(int op, int type, void *out, const ek_operand *a, const ek_operand *b, const ek_operand *c,
+                   size_t n) {
+    EK_PROLOGUE("ek_hip_ternary()")
+    EK_TYPE_SWITCH(type, ternary_dispatch<T>(op, out, a, b, c, n), "ek_hip_ternary()")
+}
+
+int ek_hip_sincos(int type, void *out, void *out_cos, const ek_operand *a, size_t n) {
+    EK_PROLOGUE("ek_hip_sincos()")
+    if (!out_cos) return fail(EK_ERR_INVALID, "ek_hip_sincos(): null output pointer");
+    if (type != EK_F32) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sincos(): only f32 is implemented");
+    Arg<float> aa;
+    if (int rc = make_arg<float>(a, n, aa, "ek_hip_sincos")) return rc;
+    return launch_map1x2<SinCosOp>("sincos", (float *) out, (float *) out_cos, n, aa);
+}
+
+int ek_hip_compare(int op, int type, uint8_t *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    EK_PROLOGUE("ek_hip_compare()")
+    EK_TYPE_SWITCH(type, compare_dispatch<T>(op, out, a, b, n), "ek_hip_compare()")
+}
+
+int ek_hip_select(int type, void *out, const ek_operand *mask, const ek_operand *t, const ek_operand *f, size_t n) {
+    EK_PROLOGUE("ek_hip_select()")
+    EK_TYPE_SWITCH(type, select_launch<T>(out, mask, t, f, n), "ek_hip_select()")
+}
+
+int ek_hip_cast(int src_type, int dst_type, void *out, const ek_operand *a, size_t n) {
+    EK_PROLOGUE("ek_hip_cast()")
+    int type = src_type;
+    EK_TYPE_SWITCH(type, cast_dispatch<T>(dst_type, out, a, n), "ek_hip_cast()")
+}
+
+} // extern "C"

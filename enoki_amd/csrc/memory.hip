@@ -1,0 +1,263 @@
+// Initialisation and indexed-memory kernels: fill / arange / linspace / reverse and masked
+// gather / scatter / scatter_add.  SURVEY.md rows a6, a7.
+//
+// Reference semantics:
+//   gather_      out[i] = mask[i] ? base[index[i]] : 0            cuda.h:845-864, dynamic.h:478-496
+//   scatter_     if (mask[i]) base[index[i]] = value[i]            cuda.h:866-890, dynamic.h:498-515
+//   scatter_add_ if (mask[i]) base[index[i]] += value[i]           cuda.h:892-905 (atom.global.add)
+// Indices are element offsets (stride = sizeof(T)), signed or unsigned 32/64 bit.  Index and
+// mask vectors are read as 16-byte (resp. 4-byte) packs per lane so that the streaming side of
+// these kernels stays coalesced; the random side goes through L2 / Infinity Cache.
+#include "ek_map.h"
+
+namespace ek {
+
+// ---- fill / arange / linspace / reverse -----------------------------------------------------------
+template <typename T> struct FillOp {
+    static __device__ __forceinline__ T apply(T x) { return x; }
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_arange(T *__restrict__ out, size_t n, T start, T step) {
+    using U = wrap_t<T>;
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256;
+    for (size_t i = gid; i < n; i += total) {
+        if constexpr (std::is_floating_point_v<T>) {
+            // fmadd(index, step, start)  (cuda.h:649-652)
+            if constexpr (sizeof(T) == 4) out[i] = __builtin_fmaf((float) (uint32_t) i, step, start);
+            else out[i] = __builtin_fma((double) (uint32_t) i, step, start);
+        } else {
+            out[i] = (T) ((U) start + (U) i * (U) step);
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_reverse(T *__restrict__ out, const T *__restrict__ in, size_t n) {
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256;
+    for (size_t i = gid; i < n; i += total)
+        out[i] = in[n - 1 - i];
+}
+
+// ---- gather ------------------------------------------------------------------------------------
+template <typename I> __device__ __forceinline__ int64_t index_offset(I i) { return (int64_t) i; }
+
+template <typename T, typename I, int N>
+__global__ __launch_bounds__(256) void k_gather(T *__restrict__ out, const T *__restrict__ base, Arg<I> index,
+                                                Arg<uint8_t> mask, size_t n, int vec_ok) {
+    const I si = index.vec ? I(0) : arg_scalar(index);
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const size_t e = lane_elem<N, 1>(0);
+    if (e >= n) return;
+    const bool fast = vec_ok && e + N <= n;
+    Pack<I, N> pi = arg_load<I, N, true>(index, si, e, n, fast);
+    Pack<uint8_t, N> pm = arg_load<uint8_t, N, true>(mask, sm, e, n, fast);
+    Pack<T, N> po;
+#pragma unroll
+    for (int k = 0; k < N; ++k)
+        po.v[k] = (pm.v[k] && e + k < n) ? base[index_offset(pi.v[k])] : T(0);
+    out_store<T, N, true>(out, po, e, n, fast);
+}
+
+// ---- scatter / scatter_add ---------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ void atomic_add(T *addr, T v) {
+    if constexpr (std::is_same_v<T, float>) {
+        unsafeAtomicAdd(addr, v);                       // global_atomic_add_f32, no CAS loop
+    } else if constexpr (std::is_same_v<T, double>) {
+        unsafeAtomicAdd(addr, v);                       // global_atomic_add_f64
+    } else if constexpr (sizeof(T) == 4) {
+        atomicAdd(reinterpret_cast<unsigned int *>(addr), (unsigned int) v);
+    } else {
+        atomicAdd(reinterpret_cast<unsigned long long *>(addr), (unsigned long long) v);
+    }
+}
+
+template <typename T, typename I, int N, bool Add>
+__global__ __launch_bounds__(256) void k_scatter(T *__restrict__ base, Arg<T> value, Arg<I> index,
+                                                 Arg<uint8_t> mask, size_t n, int vec_ok) {
+    const T sv = value.vec ? T(0) : arg_scalar(value);
+    const I si = index.vec ? I(0) : arg_scalar(index);
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const size_t e = lane_elem<N, 1>(0);
+    if (e >= n) return;
+    const bool fast = vec_ok && e + N <= n;
+    Pack<T, N> pv = arg_load<T, N, true>(value, sv, e, n, fast);
+    Pack<I, N> pi = arg_load<I, N, true>(index, si, e, n, fast);
+    Pack<uint8_t, N> pm = arg_load<uint8_t, N, true>(mask, sm, e, n, fast);
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if (pm.v[k] && e + k < n) {
+            T *dst = base + index_offset(pi.v[k]);
+            if constexpr (Add) atomic_add(dst, pv.v[k]); else *dst = pv.v[k];
+        }
+    }
+}
+
+template <typename T, typename I>
+int gather_launch(void *out, const void *base, const ek_operand *index, const ek_operand *mask, size_t n) {
+    constexpr int N = 16 / (sizeof(T) > sizeof(I) ? sizeof(T) : sizeof(I));
+    Arg<I> ii;
+    Arg<uint8_t> mm;
+    if (int rc = make_arg<I>(index, n, ii, "ek_hip_gather")) return rc;
+    if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_gather")) return rc;
+    int vec_ok = aligned16(out) && arg_aligned(ii) && arg_aligned(mm);
+    Context &c = ctx();
+    unsigned grid = (unsigned) ((n + (size_t) 256 * N - 1) / ((size_t) 256 * N));
+    hipLaunchKernelGGL((k_gather<T, I, N>), dim3(grid), dim3(256), 0, c.stream, (T *) out, (const T *) base, ii, mm,
+                       n, vec_ok);
+    EK_LAUNCH_CHECK("gather", n);
+    return EK_OK;
+}
+
+template <typename T, typename I, bool Add>
+int scatter_launch(void *base, const ek_operand *value, const ek_operand *index, const ek_operand *mask, size_t n) {
+    constexpr int N = 16 / (sizeof(T) > sizeof(I) ? sizeof(T) : sizeof(I));
+    Arg<T> vv;
+    Arg<I> ii;
+    Arg<uint8_t> mm;
+    if (int rc = make_arg<T>(value, n, vv, "ek_hip_scatter")) return rc;
+    if (int rc = make_arg<I>(index, n, ii, "ek_hip_scatter")) return rc;
+    if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter")) return rc;
+    int vec_ok = arg_aligned(vv) && arg_aligned(ii) && arg_aligned(mm);
+    Context &c = ctx();
+    unsigned grid = (unsigned) ((n + (size_t) 256 * N - 1) / ((size_t) 256 * N));
+    hipLaunchKernelGGL((k_scatter<T, I, N, Add>), dim3(grid), dim3(256), 0, c.stream, (T *) base, vv, ii, mm, n,
+                       vec_ok);
+    EK_LAUNCH_CHECK(Add ? "scatter_add" : "scatter", n);
+    return EK_OK;
+}
+
+#define EK_INDEX_SWITCH(itype, CALL, WHAT)                                                        \
+    switch (itype) {                                                                             \
+        case EK_I32: { using I = int32_t; return CALL; }                                          \
+        case EK_U32: { using I = uint32_t; return CALL; }                                         \
+        case EK_I64: { using I = int64_t; return CALL; }                                          \
+        case EK_U64: { using I = uint64_t; return CALL; }                                         \
+        default: return fail(EK_ERR_INVALID, WHAT ": index type %d is not an integer type", itype); \
+    }
+
+} // namespace ek
+
+using namespace ek;
+
+extern "C" {
+
+int ek_hip_fill(int type, void *out, uint64_t imm, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_fill(): null output pointer");
+    ek_operand op = { nullptr, imm, 1 };
+    // moves bit patterns: dispatch on the element width only (cuda_fill, common.cu:56-80)
+    switch (type_size(type)) {
+        case 1: { Arg<uint8_t> a; make_arg<uint8_t>(&op, n, a, "fill"); return launch_map1<FillOp<uint8_t>>("fill", (uint8_t *) out, n, a); }
+        case 4: { Arg<uint32_t> a; make_arg<uint32_t>(&op, n, a, "fill"); return launch_map1<FillOp<uint32_t>>("fill", (uint32_t *) out, n, a); }
+        case 8: { Arg<uint64_t> a; make_arg<uint64_t>(&op, n, a, "fill"); return launch_map1<FillOp<uint64_t>>("fill", (uint64_t *) out, n, a); }
+        default: return fail(EK_ERR_INVALID, "ek_hip_fill(): unknown type %d", type);
+    }
+}
+
+int ek_hip_arange(int type, void *out, int64_t start, int64_t step, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_arange(): null output pointer");
+    Context &c = ctx();
+    unsigned grid = stream_grid(n, c.tuning.blocks_per_cu);
+#define EK_ARANGE(T) hipLaunchKernelGGL((k_arange<T>), dim3(grid), dim3(256), 0, c.stream, (T *) out, n, (T) start, (T) step); break
+    switch (type) {
+        case EK_I32: EK_ARANGE(int32_t);
+        case EK_U32: EK_ARANGE(uint32_t);
+        case EK_I64: EK_ARANGE(int64_t);
+        case EK_U64: EK_ARANGE(uint64_t);
+        case EK_F32: EK_ARANGE(float);
+        case EK_F64: EK_ARANGE(double);
+        default: return fail(EK_ERR_INVALID, "ek_hip_arange(): unsupported type %d", type);
+    }
+#undef EK_ARANGE
+    EK_LAUNCH_CHECK("arange", n);
+    return EK_OK;
+}
+
+int ek_hip_linspace(int type, void *out, double min, double max, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_linspace(): null output pointer");
+    Context &c = ctx();
+    unsigned grid = stream_grid(n, c.tuning.blocks_per_cu);
+    if (type == EK_F32) {
+        float lo = (float) min, hi = (float) max;
+        float step = (hi - lo) / (float) (n - 1);           // cuda.h:661
+        hipLaunchKernelGGL((k_arange<float>), dim3(grid), dim3(256), 0, c.stream, (float *) out, n, lo, step);
+    } else if (type == EK_F64) {
+        double step = (max - min) / (double) (n - 1);
+        hipLaunchKernelGGL((k_arange<double>), dim3(grid), dim3(256), 0, c.stream, (double *) out, n, min, step);
+    } else {
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_linspace(): floating point types only");
+    }
+    EK_LAUNCH_CHECK("linspace", n);
+    return EK_OK;
+}
+
+int ek_hip_reverse(int type, void *out, const void *in, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out || !in) return fail(EK_ERR_INVALID, "ek_hip_reverse(): null pointer");
+    Context &c = ctx();
+    unsigned grid = stream_grid(n, c.tuning.blocks_per_cu);
+    switch (type_size(type)) {
+        case 1: hipLaunchKernelGGL((k_reverse<uint8_t>), dim3(grid), dim3(256), 0, c.stream, (uint8_t *) out, (const uint8_t *) in, n); break;
+        case 4: hipLaunchKernelGGL((k_reverse<uint32_t>), dim3(grid), dim3(256), 0, c.stream, (uint32_t *) out, (const uint32_t *) in, n); break;
+        case 8: hipLaunchKernelGGL((k_reverse<uint64_t>), dim3(grid), dim3(256), 0, c.stream, (uint64_t *) out, (const uint64_t *) in, n); break;
+        default: return fail(EK_ERR_INVALID, "ek_hip_reverse(): unknown type %d", type);
+    }
+    EK_LAUNCH_CHECK("reverse", n);
+    return EK_OK;
+}
+
+int ek_hip_gather(int type, int index_type, void *out, const void *base, const ek_operand *index,
+                  const ek_operand *mask, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out || !base) return fail(EK_ERR_INVALID, "ek_hip_gather(): null pointer");
+    switch (type_size(type)) {
+        case 1: EK_INDEX_SWITCH(index_type, (gather_launch<uint8_t, I>(out, base, index, mask, n)), "ek_hip_gather()")
+        case 4: EK_INDEX_SWITCH(index_type, (gather_launch<uint32_t, I>(out, base, index, mask, n)), "ek_hip_gather()")
+        case 8: EK_INDEX_SWITCH(index_type, (gather_launch<uint64_t, I>(out, base, index, mask, n)), "ek_hip_gather()")
+        default: return fail(EK_ERR_INVALID, "ek_hip_gather(): unknown type %d", type);
+    }
+}
+
+int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value, const ek_operand *index,
+                   const ek_operand *mask, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!base) return fail(EK_ERR_INVALID, "ek_hip_scatter(): null pointer");
+    switch (type_size(type)) {
+        case 1: EK_INDEX_SWITCH(index_type, (scatter_launch<uint8_t, I, false>(base, value, index, mask, n)), "ek_hip_scatter()")
+        case 4: EK_INDEX_SWITCH(index_type, (scatter_launch<uint32_t, I, false>(base, value, index, mask, n)), "ek_hip_scatter()")
+        case 8: EK_INDEX_SWITCH(index_type, (scatter_launch<uint64_t, I, false>(base, value, index, mask, n)), "ek_hip_scatter()")
+        default: return fail(EK_ERR_INVALID, "ek_hip_scatter(): unknown type %d", type);
+    }
+}
+
+int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, const ek_operand *value,
+                       const ek_operand *index, const ek_operand *mask, size_t n, int mode) {
+    (void) base_size;
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!base) return fail(EK_ERR_INVALID, "ek_hip_scatter_add(): null pointer");
+    bool is_fp = type == EK_F32 || type == EK_F64;
+    if (mode == 1 && is_fp)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add(): deterministic mode for floating point "
+                                        "types is not implemented yet (integer types are exact in mode 0)");
+    switch (type) {
+        case EK_F32: EK_INDEX_SWITCH(index_type, (scatter_launch<float, I, true>(base, value, index, mask, n)), "ek_hip_scatter_add()")
+        case EK_F64: EK_INDEX_SWITCH(index_type, (scatter_launch<double, I, true>(base, value, index, mask, n)), "ek_hip_scatter_add()")
+        case EK_I32: case EK_U32:
+            EK_INDEX_SWITCH(index_type, (scatter_launch<uint32_t, I, true>(base, value, index, mask, n)), "ek_hip_scatter_add()")
+        case EK_I64: case EK_U64:
+            EK_INDEX_SWITCH(index_type, (scatter_launch<uint64_t, I, true>(base, value, index, mask, n)), "ek_hip_scatter_add()")
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add(): unsupported type %d", type);
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,169 @@
+// Bandwidth probe: the streaming-kernel design space (vectors in flight per lane, non-temporal
+// loads/stores, grid shape) instantiated for a handful of representative bodies so that the
+// compile-time choices in ek_map.h (EK_MAP_U, EK_MAP_NT) and the blocks_per_cu default can be
+// re-measured on hardware.  tools/probe_bw.py drives it; results are kept under profiles/.
+#include "ek_map.h"
+#include "ek_math.h"
+
+namespace ek {
+
+using V4 = __attribute__((ext_vector_type(4))) float;
+
+template <bool NTL> __device__ __forceinline__ V4 ld(const V4 *p) {
+    if constexpr (NTL) return __builtin_nontemporal_load(p); else return *p;
+}
+template <bool NTS> __device__ __forceinline__ void st(V4 *p, V4 v) {
+    if constexpr (NTS) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
+// Body 0: copy (1R 1W)   1: fmadd (3R 1W)   2: sincos (1R 2W)   3: read-only sum (1R)   4: scale (1R 1W, scalar operand)
+template <int Body, int U, bool NTL, bool NTS, bool OneShot>
+__global__ __launch_bounds__(256) void k_probe(V4 *__restrict__ o0, V4 *__restrict__ o1, const V4 *__restrict__ a,
+                                               const V4 *__restrict__ b, const V4 *__restrict__ c, size_t nvec) {
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256;
+    V4 acc = { 0, 0, 0, 0 };
+    for (size_t v0 = gid; v0 < nvec; v0 += total * U) {
+        V4 pa[U], pb[U], pc[U];
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            size_t v = v0 + k * total;
+            if (v < nvec) {
+                pa[k] = ld<NTL>(a + v);
+                if constexpr (Body == 1) { pb[k] = ld<NTL>(b + v); pc[k] = ld<NTL>(c + v); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < U; ++k) {
+            size_t v = v0 + k * total;
+            if (v < nvec) {
+                if constexpr (Body == 0) {
+                    st<NTS>(o0 + v, pa[k]);
+                } else if constexpr (Body == 1) {
+                    V4 r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) r[i] = __builtin_fmaf(pa[k][i], pb[k][i], pc[k][i]);
+                    st<NTS>(o0 + v, r);
+                } else if constexpr (Body == 2) {
+                    V4 s, co;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { float ss, cc; dev::sincos_f32<true, true>(pa[k][i], ss, cc); s[i] = ss; co[i] = cc; }
+                    st<NTS>(o0 + v, s);
+                    st<NTS>(o1 + v, co);
+                } else if constexpr (Body == 3) {
+                    acc += pa[k];
+                } else {
+                    st<NTS>(o0 + v, pa[k] * 1.5f);
+                }
+            }
+        }
+        if (OneShot) break;
+    }
+    if constexpr (Body == 3) {
+        if (acc[0] + acc[1] + acc[2] + acc[3] == 12345.678f) o0[gid] = acc;   // keep the loads alive
+    }
+}
+
+template <int Body, int U, bool NTL, bool NTS>
+int probe_launch(int blocks_per_cu, void *o0, void *o1, const void *a, const void *b, const void *c, size_t n) {
+    Context &cx = ctx();
+    size_t nvec = n / 4;
+    if (blocks_per_cu > 0) {
+        unsigned grid = stream_grid((nvec + U - 1) / U, blocks_per_cu);
+        hipLaunchKernelGGL((k_probe<Body, U, NTL, NTS, false>), dim3(grid), dim3(256), 0, cx.stream, (V4 *) o0, (V4 *) o1,
+                           (const V4 *) a, (const V4 *) b, (const V4 *) c, nvec);
+    } else {
+        size_t blocks = (nvec + 256 * (size_t) U - 1) / (256 * (size_t) U);
+        hipLaunchKernelGGL((k_probe<Body, U, NTL, NTS, true>), dim3((unsigned) blocks), dim3(256), 0, cx.stream, (V4 *) o0,
+                           (V4 *) o1, (const V4 *) a, (const V4 *) b, (const V4 *) c, nvec);
+    }
+    EK_LAUNCH_CHECK("probe", n);
+    return EK_OK;
+}
+
+template <int Body, int U>
+int probe_nt(int ntl, int nts, int bpc, void *o0, void *o1, const void *a, const void *b, const void *c, size_t n) {
+    if (ntl && nts) return probe_launch<Body, U, true, true>(bpc, o0, o1, a, b, c, n);
+    if (ntl) return probe_launch<Body, U, true, false>(bpc, o0, o1, a, b, c, n);
+    if (nts) return probe_launch<Body, U, false, true>(bpc, o0, o1, a, b, c, n);
+    return probe_launch<Body, U, false, false>(bpc, o0, o1, a, b, c, n);
+}
+
+template <int Body>
+int probe_u(int u, int ntl, int nts, int bpc, void *o0, void *o1, const void *a, const void *b, const void *c, size_t n) {
+    switch (u) {
+        case 1: return probe_nt<Body, 1>(ntl, nts, bpc, o0, o1, a, b, c, n);
+        case 2: return probe_nt<Body, 2>(ntl, nts, bpc, o0, o1, a, b, c, n);
+        case 4: return probe_nt<Body, 4>(ntl, nts, bpc, o0, o1, a, b, c, n);
+        case 8: return probe_nt<Body, 8>(ntl, nts, bpc, o0, o1, a, b, c, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_probe(): unroll must be 1, 2, 4 or 8");
+    }
+}
+
+// ---- scatter_add experiments ---------------------------------------------------------------------
+// mode 0: every lane adds into ONE shared table (what ek_hip_scatter_add does);
+// mode 1: every workgroup adds into the copy of the table that belongs to its XCD (HW_REG_XCC_ID),
+//         so a table line is only ever owned by one XCD's L2; the 8 copies are summed afterwards.
+template <int Mode>
+__global__ __launch_bounds__(256) void k_probe_scatter_add(float *__restrict__ table, size_t table_size,
+                                                           const V4 *__restrict__ val, const uint4 *__restrict__ idx,
+                                                           size_t nvec) {
+    size_t v = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (v >= nvec) return;
+    float *t = table;
+    if constexpr (Mode == 1) t += (size_t) (__builtin_amdgcn_s_getreg(6164) & 7u) * table_size;   // hwreg(XCC_ID, 0, 4)
+    V4 pv = __builtin_nontemporal_load(val + v);
+    uint4 pi = idx[v];
+    unsafeAtomicAdd(t + pi.x, pv[0]);
+    unsafeAtomicAdd(t + pi.y, pv[1]);
+    unsafeAtomicAdd(t + pi.z, pv[2]);
+    unsafeAtomicAdd(t + pi.w, pv[3]);
+}
+
+__global__ __launch_bounds__(256) void k_probe_fold8(float *__restrict__ out, const float *__restrict__ copies, size_t k) {
+    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= k) return;
+    float s = out[i];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) s += copies[(size_t) c * k + i];
+    out[i] = s;
+}
+
+} // namespace ek
+
+using namespace ek;
+
+// scatter_add experiment: `table` must hold 8 * table_size floats for mode 1 (copies zeroed by the caller);
+// `fold_into` (table_size floats) receives table += sum of the copies when non-null.
+extern "C" EK_API int ek_hip_probe_scatter_add(int mode, float *table, size_t table_size, float *fold_into,
+                                               const float *val, const uint32_t *idx, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+    size_t nvec = n / 4;
+    unsigned grid = (unsigned) ((nvec + 255) / 256);
+    if (mode == 0)
+        hipLaunchKernelGGL((k_probe_scatter_add<0>), dim3(grid), dim3(256), 0, cx.stream, table, table_size,
+                           (const V4 *) val, (const uint4 *) idx, nvec);
+    else
+        hipLaunchKernelGGL((k_probe_scatter_add<1>), dim3(grid), dim3(256), 0, cx.stream, table, table_size,
+                           (const V4 *) val, (const uint4 *) idx, nvec);
+    if (fold_into)
+        hipLaunchKernelGGL(k_probe_fold8, dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, cx.stream, fold_into,
+                           table, table_size);
+    EK_LAUNCH_CHECK("probe_scatter_add", n);
+    return EK_OK;
+}
+
+// Diagnostic entry point (f32 only): body 0 copy, 1 fmadd, 2 sincos, 3 read-only, 4 scale.
+// blocks_per_cu <= 0 selects the "one shot" grid (every lane handles exactly `unroll` vectors).
+extern "C" EK_API int ek_hip_probe(int body, int unroll, int nt_load, int nt_store, int blocks_per_cu, void *out0,
+                                   void *out1, const void *a, const void *b, const void *c, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    switch (body) {
+        case 0: return probe_u<0>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        case 1: return probe_u<1>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        case 2: return probe_u<2>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        case 3: return probe_u<3>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        case 4: return probe_u<4>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_probe(): unknown body %d", body);
+    }
+}

@@ -1,0 +1,362 @@
+// Horizontal reductions for CDNA4: hsum / hprod / hmin / hmax, mask all / any / count, the fused
+// backward reduction hsum(safe_mul(w, g)), and the inclusive prefix sum.  SURVEY.md rows a8, a11.
+//
+// Replaces the reference's CUB calls (src/cuda/horiz.cu:162-354).  Structure (hand-written):
+//   stage 1  grid of (reduce_blocks_per_cu x #CU) blocks of 256 threads; every lane streams
+//            16-byte vectors (4 in flight), keeps 4 independent accumulators, then
+//            wave64 butterfly with __shfl_down (6 steps) -> 4 wave partials in LDS -> 1 block partial;
+//   stage 2  one 256-thread block folds the <= 2048 block partials the same way.
+// No floating point atomics: the result is deterministic for a given (n, grid), i.e. run-to-run
+// reproducible, but the summation ORDER differs from the CPU's lane-wise packet accumulation
+// (dynamic.h:632-702), so fp results agree to the order-dependent bound documented in tests/.
+#include "ek_map.h"
+#include "ek_math.h"
+
+#include <algorithm>
+#include <limits>
+
+namespace ek {
+
+template <int Op, typename T> struct Reducer {
+    static __device__ __host__ __forceinline__ T identity() {
+        if constexpr (Op == EK_HSUM) return T(0);
+        else if constexpr (Op == EK_HPROD) return T(1);
+        else if constexpr (Op == EK_HMIN) {
+            if constexpr (std::is_floating_point_v<T>) return std::numeric_limits<T>::infinity();
+            else return std::numeric_limits<T>::max();
+        } else {
+            if constexpr (std::is_floating_point_v<T>) return -std::numeric_limits<T>::infinity();
+            else return std::numeric_limits<T>::lowest();
+        }
+    }
+    static __device__ __forceinline__ T combine(T acc, T v) {
+        using U = wrap_t<T>;
+        if constexpr (Op == EK_HSUM) return (T) ((U) acc + (U) v);
+        else if constexpr (Op == EK_HPROD) return (T) ((U) acc * (U) v);
+        else if constexpr (Op == EK_HMIN) return v < acc ? v : acc;
+        else return v > acc ? v : acc;
+    }
+};
+
+template <typename T> __device__ __forceinline__ T shfl_down(T v, int delta) {
+    if constexpr (sizeof(T) == 8) {
+        uint64_t u;
+        __builtin_memcpy(&u, &v, 8);
+        uint32_t lo = (uint32_t) u, hi = (uint32_t) (u >> 32);
+        lo = __shfl_down(lo, delta, 64);
+        hi = __shfl_down(hi, delta, 64);
+        u = ((uint64_t) hi << 32) | lo;
+        __builtin_memcpy(&v, &u, 8);
+        return v;
+    } else {
+        return __shfl_down(v, delta, 64);
+    }
+}
+
+// 256 threads -> one value in thread 0
+template <typename R, typename T> __device__ __forceinline__ T block_reduce(T v) {
+    __shared__ T wave_part[4];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1)
+        v = R::combine(v, shfl_down(v, d));
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_part[wave] = v;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        v = R::combine(R::combine(wave_part[0], wave_part[1]), R::combine(wave_part[2], wave_part[3]));
+    return v;
+}
+
+// Loaders turn (index) -> value; they let the same reduction serve plain arrays, u8 masks and the
+// fused hsum(safe_mul(w, g)) of Tape::backward (autodiff.cpp:867-871).
+// N = elements consumed per 16-byte access, M = values handed to the reducer per access.
+template <typename T> struct PlainLoader {
+    const T *ptr;
+    static constexpr int N = 16 / sizeof(T), M = N;
+    __device__ __forceinline__ void init() { }
+    __device__ __forceinline__ Pack<T, N> load_pack(size_t v) const { return pack_load<T, N, true>(ptr + v * N); }
+    __device__ __forceinline__ T load(size_t i) const { return ptr[i]; }
+};
+
+struct MaskCountLoader {   // u8 mask -> u64 count, 16 mask bytes per lane per access
+    const uint8_t *ptr;
+    static constexpr int N = 16, M = 1;
+    __device__ __forceinline__ void init() { }
+    __device__ __forceinline__ Pack<uint64_t, 1> load_pack(size_t v) const {
+        Pack<uint8_t, 16> raw = pack_load<uint8_t, 16, true>(ptr + v * 16);
+        Pack<uint64_t, 1> r;
+        unsigned cnt = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) cnt += raw.v[i] ? 1u : 0u;
+        r.v[0] = cnt;
+        return r;
+    }
+    __device__ __forceinline__ uint64_t load(size_t i) const { return ptr[i] ? 1u : 0u; }
+};
+
+template <typename T> struct SafeMulLoader {
+    Arg<T> w, g;
+    T sw, sg;
+    static constexpr int N = 16 / sizeof(T), M = N;
+    __device__ __forceinline__ void init() {
+        sw = w.vec ? T(0) : arg_scalar(w);
+        sg = g.vec ? T(0) : arg_scalar(g);
+    }
+    __device__ __forceinline__ Pack<T, N> load_pack(size_t v) const {
+        Pack<T, N> pw = arg_load<T, N, true>(w, sw, v * N, (size_t) -1, true),
+                   pg = arg_load<T, N, true>(g, sg, v * N, (size_t) -1, true), r;
+#pragma unroll
+        for (int i = 0; i < N; ++i) r.v[i] = dev::safe_mul(pw.v[i], pg.v[i]);
+        return r;
+    }
+    __device__ __forceinline__ T load(size_t i) const {
+        return dev::safe_mul(w.vec ? w.ptr[i] : sw, g.vec ? g.ptr[i] : sg);
+    }
+};
+
+template <typename R, typename T, typename Loader>
+__global__ __launch_bounds__(256) void k_reduce_stage1(T *__restrict__ partials, size_t n, int vec_ok, Loader ld) {
+    constexpr int N = Loader::N, M = Loader::M, U = 4;
+    ld.init();
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256;
+    T acc[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) acc[k] = R::identity();
+    size_t done = 0;
+    if (vec_ok) {
+        const size_t nvec = n / N;
+        for (size_t v0 = gid; v0 < nvec; v0 += total * U) {
+            Pack<T, M> p[U];
+#pragma unroll
+            for (int k = 0; k < U; ++k)
+                if (v0 + k * total < nvec) p[k] = ld.load_pack(v0 + k * total);
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (v0 + k * total < nvec) {
+#pragma unroll
+                    for (int i = 0; i < M; ++i) acc[k] = R::combine(acc[k], p[k].v[i]);
+                }
+            }
+        }
+        done = nvec * N;
+    }
+    for (size_t i = done + gid; i < n; i += total)
+        acc[0] = R::combine(acc[0], ld.load(i));
+    T v = R::combine(R::combine(acc[0], acc[1]), R::combine(acc[2], acc[3]));
+    v = block_reduce<R>(v);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+
+template <typename R, typename T>
+__global__ __launch_bounds__(256) void k_reduce_stage2(T *__restrict__ out, const T *__restrict__ partials, unsigned count) {
+    T v = R::identity();
+    for (unsigned i = threadIdx.x; i < count; i += 256)
+        v = R::combine(v, partials[i]);
+    v = block_reduce<R>(v);
+    if (threadIdx.x == 0) out[0] = v;
+}
+
+template <typename R, typename T, typename Loader>
+int reduce_launch(const char *name, T *out, size_t n, int vec_ok, const Loader &ld) {
+    Context &c = ctx();
+    constexpr int N = Loader::N;
+    size_t items = (n / N + 3) / 4 + 1;
+    unsigned grid = stream_grid(items, c.tuning.reduce_blocks_per_cu);
+    if (grid > 2048) grid = 2048;
+    void *scratch = nullptr;
+    if (int rc = reduce_scratch((size_t) grid * sizeof(T), &scratch)) return rc;
+    hipLaunchKernelGGL((k_reduce_stage1<R, T, Loader>), dim3(grid), dim3(256), 0, c.stream, (T *) scratch, n, vec_ok, ld);
+    EK_LAUNCH_CHECK(name, n);
+    hipLaunchKernelGGL((k_reduce_stage2<R, T>), dim3(1), dim3(256), 0, c.stream, out, (const T *) scratch, grid);
+    EK_LAUNCH_CHECK("reduce_stage2", (size_t) grid);
+    return EK_OK;
+}
+
+template <int Op, typename T> int reduce_typed(void *out, const void *in, size_t n) {
+    PlainLoader<T> ld{ (const T *) in };
+    return reduce_launch<Reducer<Op, T>>("reduce", (T *) out, n, aligned16(in), ld);
+}
+
+template <typename T> int reduce_dispatch(int op, void *out, const void *in, size_t n) {
+    switch (op) {
+        case EK_HSUM: return reduce_typed<EK_HSUM, T>(out, in, n);
+        case EK_HPROD: return reduce_typed<EK_HPROD, T>(out, in, n);
+        case EK_HMIN: return reduce_typed<EK_HMIN, T>(out, in, n);
+        case EK_HMAX: return reduce_typed<EK_HMAX, T>(out, in, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_reduce(): unknown op %d", op);
+    }
+}
+
+// Identities of EMPTY inputs follow the CPU reference literally (dynamic.h:633, 651, 669, 687):
+// hsum -> 0, hprod -> 1, hmin -> numeric_limits::max(), hmax -> numeric_limits::min() (which is the
+// smallest positive normal for floating point types -- a reference quirk we keep).
+template <typename T> uint64_t empty_identity_bits(int op) {
+    T v;
+    switch (op) {
+        case EK_HSUM: v = T(0); break;
+        case EK_HPROD: v = T(1); break;
+        case EK_HMIN: v = std::numeric_limits<T>::max(); break;
+        default: v = std::numeric_limits<T>::min(); break;
+    }
+    uint64_t bits = 0;
+    memcpy(&bits, &v, sizeof(T));
+    return bits;
+}
+
+// ---- inclusive prefix sum ------------------------------------------------------------------------
+// Three-phase scan: per-block sums -> scan of block sums (single block) -> per-block scan + offset.
+// Blocks own contiguous chunks so results are deterministic.  Only Tape::append_psum needs this
+// (autodiff.cpp:473-521); it is not on the timed path.
+template <typename T>
+__global__ __launch_bounds__(256) void k_scan_block_sums(T *__restrict__ sums, const T *__restrict__ in, size_t n, size_t chunk) {
+    size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+    T v = T(0);
+    for (size_t i = begin + threadIdx.x; i < end; i += 256) v += in[i];
+    v = block_reduce<Reducer<EK_HSUM, T>>(v);
+    if (threadIdx.x == 0) sums[blockIdx.x] = v;
+}
+
+template <typename T>
+__global__ void k_scan_sums_serial(T *__restrict__ sums, unsigned count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        T run = T(0);
+        for (unsigned i = 0; i < count; ++i) { T s = sums[i]; sums[i] = run; run += s; }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_scan_apply(T *__restrict__ out, const T *__restrict__ in, const T *__restrict__ sums,
+                                                    size_t n, size_t chunk) {
+    __shared__ T tile[256];
+    size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+    T carry = sums[blockIdx.x];
+    for (size_t base = begin; base < end; base += 256) {
+        size_t i = base + threadIdx.x;
+        T v = i < end ? in[i] : T(0);
+        tile[threadIdx.x] = v;
+        __syncthreads();
+        // Hillis-Steele within the 256-tile
+        for (int d = 1; d < 256; d <<= 1) {
+            T add = threadIdx.x >= (unsigned) d ? tile[threadIdx.x - d] : T(0);
+            __syncthreads();
+            tile[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < end) out[i] = tile[threadIdx.x] + carry;
+        carry += tile[255];
+        __syncthreads();
+    }
+}
+
+template <typename T> int psum_typed(void *out, const void *in, size_t n) {
+    Context &c = ctx();
+    unsigned blocks = (unsigned) std::min<size_t>((n + 4095) / 4096, (size_t) c.num_cu * 4);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + 255) / 256 * 256;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+    void *sums = nullptr;
+    if (int rc = ek_hip_malloc((size_t) blocks * sizeof(T), &sums)) return rc;
+    hipLaunchKernelGGL((k_scan_block_sums<T>), dim3(blocks), dim3(256), 0, c.stream, (T *) sums, (const T *) in, n, chunk);
+    hipLaunchKernelGGL((k_scan_sums_serial<T>), dim3(1), dim3(64), 0, c.stream, (T *) sums, blocks);
+    hipLaunchKernelGGL((k_scan_apply<T>), dim3(blocks), dim3(256), 0, c.stream, (T *) out, (const T *) in, (const T *) sums, n, chunk);
+    ek_hip_free(sums);   // stream-ordered reuse
+    EK_LAUNCH_CHECK("psum", n);
+    return EK_OK;
+}
+
+} // namespace ek
+
+using namespace ek;
+
+extern "C" {
+
+int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_reduce(): null output pointer");
+    if (op < 0 || op >= EK_REDUCE_COUNT) return fail(EK_ERR_INVALID, "ek_hip_reduce(): unknown op %d", op);
+    if (n == 0) {
+        uint64_t bits;
+        switch (type) {
+            case EK_I32: bits = empty_identity_bits<int32_t>(op); break;
+            case EK_U32: bits = empty_identity_bits<uint32_t>(op); break;
+            case EK_I64: bits = empty_identity_bits<int64_t>(op); break;
+            case EK_U64: bits = empty_identity_bits<uint64_t>(op); break;
+            case EK_F32: bits = empty_identity_bits<float>(op); break;
+            case EK_F64: bits = empty_identity_bits<double>(op); break;
+            default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce(): unsupported type %d", type);
+        }
+        return ek_hip_fill(type, out, bits, 1);
+    }
+    if (!in) return fail(EK_ERR_INVALID, "ek_hip_reduce(): null input pointer");
+    if (n == 1) return ek_hip_memcpy_device(out, in, type_size(type));
+    switch (type) {
+        case EK_I32: return reduce_dispatch<int32_t>(op, out, in, n);
+        case EK_U32: return reduce_dispatch<uint32_t>(op, out, in, n);
+        case EK_I64: return reduce_dispatch<int64_t>(op, out, in, n);
+        case EK_U64: return reduce_dispatch<uint64_t>(op, out, in, n);
+        case EK_F32: return reduce_dispatch<float>(op, out, in, n);
+        case EK_F64: return reduce_dispatch<double>(op, out, in, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce(): unsupported type %d", type);
+    }
+}
+
+int ek_hip_hsum_safe_mul(int type, void *out, const ek_operand *w, const ek_operand *g, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_hsum_safe_mul(): null output pointer");
+    if (n == 0) return ek_hip_fill(type, out, 0, 1);
+    if (type == EK_F32) {
+        SafeMulLoader<float> ld;
+        if (int rc = make_arg<float>(w, n, ld.w, "ek_hip_hsum_safe_mul")) return rc;
+        if (int rc = make_arg<float>(g, n, ld.g, "ek_hip_hsum_safe_mul")) return rc;
+        ld.sw = ld.sg = 0;   // fetched on the device by Loader::init()
+        return reduce_launch<Reducer<EK_HSUM, float>>("hsum_safe_mul", (float *) out, n,
+                                                      arg_aligned(ld.w) && arg_aligned(ld.g), ld);
+    } else if (type == EK_F64) {
+        SafeMulLoader<double> ld;
+        if (int rc = make_arg<double>(w, n, ld.w, "ek_hip_hsum_safe_mul")) return rc;
+        if (int rc = make_arg<double>(g, n, ld.g, "ek_hip_hsum_safe_mul")) return rc;
+        ld.sw = ld.sg = 0;
+        return reduce_launch<Reducer<EK_HSUM, double>>("hsum_safe_mul", (double *) out, n,
+                                                       arg_aligned(ld.w) && arg_aligned(ld.g), ld);
+    }
+    return fail(EK_ERR_UNSUPPORTED, "ek_hip_hsum_safe_mul(): floating point types only");
+}
+
+int ek_hip_mask_reduce(int op, const uint8_t *mask, size_t n, uint64_t *host_result) {
+    if (int rc = ensure_init()) return rc;
+    if (!host_result) return fail(EK_ERR_INVALID, "ek_hip_mask_reduce(): null result pointer");
+    if (op < 0 || op >= EK_MASK_REDUCE_COUNT) return fail(EK_ERR_INVALID, "ek_hip_mask_reduce(): unknown op %d", op);
+    uint64_t count = 0;
+    if (n != 0) {
+        if (!mask) return fail(EK_ERR_INVALID, "ek_hip_mask_reduce(): null mask pointer");
+        void *dev_count = nullptr;
+        if (int rc = ek_hip_malloc(sizeof(uint64_t), &dev_count)) return rc;
+        MaskCountLoader ld{ mask };
+        int rc = reduce_launch<Reducer<EK_HSUM, uint64_t>>("mask_reduce", (uint64_t *) dev_count, n, aligned16(mask), ld);
+        if (!rc) rc = ek_hip_memcpy_to_host(&count, dev_count, sizeof(uint64_t));   // synchronizes
+        ek_hip_free(dev_count);
+        if (rc) return rc;
+    }
+    switch (op) {
+        case EK_ALL: *host_result = count == n; break;      // empty -> true  (dynamic.h:721)
+        case EK_ANY: *host_result = count != 0; break;      // empty -> false (dynamic.h:705)
+        default: *host_result = count; break;
+    }
+    return EK_OK;
+}
+
+int ek_hip_psum(int type, void *out, const void *in, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out || !in) return fail(EK_ERR_INVALID, "ek_hip_psum(): null pointer");
+    switch (type) {
+        case EK_I32: case EK_U32: return psum_typed<uint32_t>(out, in, n);
+        case EK_I64: case EK_U64: return psum_typed<uint64_t>(out, in, n);
+        case EK_F32: return psum_typed<float>(out, in, n);
+        case EK_F64: return psum_typed<double>(out, in, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_psum(): unsupported type %d", type);
+    }
+}
+
+} // extern "C"

@@ -1,0 +1,322 @@
+// libenoki-hip.so runtime: device/stream context, error reporting, caching allocator, copies.
+//
+// Replaces the non-JIT half of the reference's src/cuda/jit.cu (Context 149-262, caching
+// allocator 1683-1896) and src/cuda/common.cu (memcpy wrappers 104-122, error policy 268-286).
+// There is no trace/variable table: arrays are plain device buffers owned by HIPArray<T>.
+#include "ek_internal.h"
+
+#include <cstdlib>
+#include <mutex>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+namespace ek {
+
+static thread_local std::string t_last_error;
+
+int fail(int code, const char *fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    t_last_error = buf;
+    if (ctx().log_level >= 1)
+        fprintf(stderr, "enoki-hip: error: %s\n", buf);
+    return code;
+}
+
+int hip_fail(hipError_t err, const char *what, const char *file, int line) {
+    return fail(EK_ERR_HIP, "%s failed: %s (%s:%d)", what, hipGetErrorString(err), file, line);
+}
+
+Context &ctx() {
+    static Context c;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------------
+//  Caching allocator.  Size classes: powers of two up to 1 MiB, multiples of 1 MiB above (a
+//  64 Mi-element f32 array is exactly 256 MiB either way).  Freed blocks go to a per-class free
+//  list and are reused in stream order (single stream => no event bookkeeping needed); on
+//  out-of-memory the cache is released and the allocation retried once (jit.cu:1716-1723).
+// ------------------------------------------------------------------------------------------------
+struct Allocator {
+    std::mutex mutex;
+    std::unordered_map<size_t, std::vector<void *>> free_lists;   // class size -> blocks
+    std::unordered_map<void *, size_t> live;                      // block -> class size
+    size_t live_bytes = 0, cached_bytes = 0, watermark = 0, n_malloc = 0, n_reuse = 0;
+
+    static size_t round_size(size_t bytes) {
+        if (bytes <= 256) return 256;
+        if (bytes <= (size_t(1) << 20)) {
+            size_t s = 256;
+            while (s < bytes) s <<= 1;
+            return s;
+        }
+        const size_t mib = size_t(1) << 20;
+        return (bytes + mib - 1) / mib * mib;
+    }
+
+    hipError_t trim_locked() {
+        for (auto &kv : free_lists)
+            for (void *p : kv.second) {
+                hipError_t e = hipFree(p);
+                if (e != hipSuccess) return e;
+            }
+        free_lists.clear();
+        cached_bytes = 0;
+        return hipSuccess;
+    }
+};
+
+static Allocator &alloc() {
+    static Allocator a;
+    return a;
+}
+
+int ensure_init() {
+    if (ctx().initialized) return EK_OK;
+    return ek_hip_init(-1);
+}
+
+int reduce_scratch(size_t bytes, void **out) {
+    Context &c = ctx();
+    if (c.reduce_scratch_bytes < bytes) {
+        if (c.reduce_scratch) {
+            // the old scratch may still be in use by enqueued kernels: free is stream-ordered
+            // through the caching allocator (same stream), so handing it back is safe.
+            ek_hip_free(c.reduce_scratch);
+            c.reduce_scratch = nullptr;
+            c.reduce_scratch_bytes = 0;
+        }
+        size_t want = bytes < 65536 ? 65536 : bytes;
+        int rc = ek_hip_malloc(want, &c.reduce_scratch);
+        if (rc) return rc;
+        c.reduce_scratch_bytes = want;
+    }
+    *out = c.reduce_scratch;
+    return EK_OK;
+}
+
+} // namespace ek
+
+using namespace ek;
+
+extern "C" {
+
+int ek_hip_init(int device) {
+    Context &c = ctx();
+    if (c.initialized && (device < 0 || device == c.device)) return EK_OK;
+    int count = 0;
+    EK_HIP_CHECK(hipGetDeviceCount(&count));
+    if (count == 0) return fail(EK_ERR_HIP, "ek_hip_init(): no HIP device visible");
+    if (device < 0) {
+        // honour LOCAL_RANK so that one process per GPU needs no extra plumbing
+        const char *lr = getenv("LOCAL_RANK");
+        device = lr ? atoi(lr) % count : 0;
+    }
+    if (device >= count) return fail(EK_ERR_INVALID, "ek_hip_init(): device %d out of range (%d visible)", device, count);
+    if (c.initialized) {
+        EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (c.owns_stream) EK_HIP_CHECK(hipStreamDestroy(c.stream));
+        c.stream = nullptr;
+    }
+    EK_HIP_CHECK(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    EK_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    c.device = device;
+    c.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    EK_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
+    c.owns_stream = true;
+    c.initialized = true;
+    if (const char *lv = getenv("ENOKI_HIP_LOG")) c.log_level = (uint32_t) atoi(lv);
+    if (c.log_level >= 1)
+        fprintf(stderr, "enoki-hip: device %d (%s, %d CUs, %.1f GiB)\n", device, prop.name, c.num_cu,
+                (double) prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
+    return EK_OK;
+}
+
+int ek_hip_device(void) { return ctx().initialized ? ctx().device : -1; }
+
+int ek_hip_device_count(void) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) return 0;
+    return count;
+}
+
+void *ek_hip_stream(void) { return (void *) ctx().stream; }
+
+int ek_hip_set_stream(void *s) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    Context &c = ctx();
+    EK_HIP_CHECK(hipStreamSynchronize(c.stream));   // cached blocks may be reused on the new stream
+    if (c.owns_stream) EK_HIP_CHECK(hipStreamDestroy(c.stream));
+    c.stream = (hipStream_t) s;
+    c.owns_stream = false;
+    return EK_OK;
+}
+
+int ek_hip_sync(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    return EK_OK;
+}
+
+const char *ek_hip_last_error(void) { return t_last_error.c_str(); }
+
+int ek_hip_malloc(size_t bytes, void **out) {
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_malloc(): null output pointer");
+    int rc = ensure_init();
+    if (rc) return rc;
+    Allocator &a = alloc();
+    size_t cls = Allocator::round_size(bytes);
+    std::lock_guard<std::mutex> guard(a.mutex);
+    void *ptr = nullptr;
+    auto it = a.free_lists.find(cls);
+    if (it != a.free_lists.end() && !it->second.empty()) {
+        ptr = it->second.back();
+        it->second.pop_back();
+        a.cached_bytes -= cls;
+        a.n_reuse++;
+    } else {
+        hipError_t e = hipMalloc(&ptr, cls);
+        if (e != hipSuccess) {
+            (void) hipGetLastError();
+            hipError_t e2 = hipStreamSynchronize(ctx().stream);
+            if (e2 == hipSuccess) e2 = a.trim_locked();
+            if (e2 == hipSuccess) e = hipMalloc(&ptr, cls);
+            if (e != hipSuccess) {
+                (void) hipGetLastError();
+                return fail(EK_ERR_OOM, "ek_hip_malloc(): out of memory allocating %zu bytes (%zu live, %zu cached)",
+                            cls, a.live_bytes, a.cached_bytes);
+            }
+        }
+        a.n_malloc++;
+    }
+    a.live[ptr] = cls;
+    a.live_bytes += cls;
+    if (a.live_bytes > a.watermark) a.watermark = a.live_bytes;
+    *out = ptr;
+    return EK_OK;
+}
+
+int ek_hip_free(void *ptr) {
+    if (!ptr) return EK_OK;
+    Allocator &a = alloc();
+    std::lock_guard<std::mutex> guard(a.mutex);
+    auto it = a.live.find(ptr);
+    if (it == a.live.end())
+        return fail(EK_ERR_INVALID, "ek_hip_free(): pointer %p was not allocated by ek_hip_malloc()", ptr);
+    size_t cls = it->second;
+    a.live.erase(it);
+    a.live_bytes -= cls;
+    a.free_lists[cls].push_back(ptr);
+    a.cached_bytes += cls;
+    return EK_OK;
+}
+
+int ek_hip_malloc_trim(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    Allocator &a = alloc();
+    EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    std::lock_guard<std::mutex> guard(a.mutex);
+    EK_HIP_CHECK(a.trim_locked());
+    return EK_OK;
+}
+
+int ek_hip_host_malloc(size_t bytes, void **out) {
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_host_malloc(): null output pointer");
+    int rc = ensure_init();
+    if (rc) return rc;
+    EK_HIP_CHECK(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return EK_OK;
+}
+
+int ek_hip_host_free(void *ptr) {
+    if (!ptr) return EK_OK;
+    EK_HIP_CHECK(hipHostFree(ptr));
+    return EK_OK;
+}
+
+int ek_hip_mem_get_info(size_t *free_bytes, size_t *total_bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    size_t f = 0, t = 0;
+    EK_HIP_CHECK(hipMemGetInfo(&f, &t));
+    if (free_bytes) *free_bytes = f;
+    if (total_bytes) *total_bytes = t;
+    return EK_OK;
+}
+
+int ek_hip_memcpy_to_device(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!bytes) return EK_OK;
+    EK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
+    EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    return EK_OK;
+}
+
+int ek_hip_memcpy_to_host(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!bytes) return EK_OK;
+    EK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
+    EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    return EK_OK;
+}
+
+int ek_hip_memcpy_device(void *dst, const void *src, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!bytes) return EK_OK;
+    EK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, ctx().stream));
+    return EK_OK;
+}
+
+int ek_hip_memset(void *dst, int byte, size_t bytes) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    if (!bytes) return EK_OK;
+    EK_HIP_CHECK(hipMemsetAsync(dst, byte, bytes, ctx().stream));
+    return EK_OK;
+}
+
+char *ek_hip_whos(void) {
+    Allocator &a = alloc();
+    std::lock_guard<std::mutex> guard(a.mutex);
+    char buf[512];
+    snprintf(buf, sizeof(buf),
+             "\n  enoki-hip allocator (device %d)\n"
+             "  ===============================\n"
+             "  live blocks      : %zu\n"
+             "  live bytes       : %zu\n"
+             "  cached bytes     : %zu\n"
+             "  max. live bytes  : %zu\n"
+             "  hipMalloc calls  : %zu\n"
+             "  cache hits       : %zu\n"
+             "  kernel launches  : %llu\n",
+             ctx().device, a.live.size(), a.live_bytes, a.cached_bytes, a.watermark, a.n_malloc, a.n_reuse,
+             (unsigned long long) ctx().launches);
+    return strdup(buf);
+}
+
+void ek_hip_set_log_level(uint32_t level) { ctx().log_level = level; }
+uint32_t ek_hip_log_level(void) { return ctx().log_level; }
+uint64_t ek_hip_launch_count(void) { return ctx().launches; }
+
+int ek_hip_set_tuning(const char *key, int value) {
+    if (!key) return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): null key");
+    Tuning &t = ctx().tuning;
+    if (!strcmp(key, "blocks_per_cu") && value > 0) t.blocks_per_cu = value;
+    else if (!strcmp(key, "reduce_blocks_per_cu") && value > 0) t.reduce_blocks_per_cu = value;
+    else return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): unknown key/value %s=%d", key, value);
+    return EK_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,176 @@
+/*
+ * include/enoki_hip.h -- C ABI of libenoki-hip.so, the MI355X (gfx950) array runtime.
+ *
+ * This is the drop-in boundary for the reference's `libenoki-cuda.so` (exports declared in
+ * /root/reference/include/enoki/cuda.h:27-200).  The reference's exports are C++-mangled and
+ * operate on *trace indices* of a PTX JIT; this library is eager: every entry point takes raw
+ * device pointers + element counts and launches one pre-compiled HIP kernel on the library's
+ * stream.  `include/enoki/hip.h` (HIPArray<T>) is the C++ binding that sits on top of it and
+ * plays the role of `CUDAArray<T>` (cuda.h:205-954); INTEGRATION.md shows the reference-side
+ * stub a maintainer would add.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no C++ / torch types.
+ *  - every function returns 0 on success or a negative EK_ERR_* code; ek_hip_last_error()
+ *    returns a thread-local human readable message.  HIP API failures are reported the same
+ *    way (the reference exits the process, src/cuda/common.cu:268-286; a library should not).
+ *  - all work is enqueued on ONE stream (ek_hip_stream()/ek_hip_set_stream()); nothing
+ *    synchronizes unless documented (ek_hip_sync, *_to_host copies, all/any/count).
+ *  - masks are arrays of uint8_t (0/1), as in the reference (src/cuda/jit.cu:1137-1144).
+ *  - operands of vertical ops are `ek_operand`: a device array of `size` n or 1 (size-1
+ *    operands broadcast, cuda.h semantics via jit.cu:776-782), or an immediate scalar.
+ */
+#ifndef ENOKI_HIP_C_API_H
+#define ENOKI_HIP_C_API_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(_WIN32)
+#  define EK_API
+#else
+#  define EK_API __attribute__((visibility("default")))
+#endif
+
+/* Element types -- the subset of EnokiType (src/cuda/common.cuh:25-40) on the hot path. */
+typedef enum {
+    EK_BOOL = 0, EK_I32 = 1, EK_U32 = 2, EK_I64 = 3, EK_U64 = 4, EK_F32 = 5, EK_F64 = 6,
+    EK_TYPE_COUNT = 7
+} ek_type;
+
+typedef enum {
+    EK_OK = 0,
+    EK_ERR_INVALID = -1,      /* bad argument (null pointer, unknown op/type, size mismatch) */
+    EK_ERR_UNSUPPORTED = -2,  /* op not defined for this element type */
+    EK_ERR_HIP = -3,          /* a HIP runtime call failed; see ek_hip_last_error() */
+    EK_ERR_OOM = -4           /* allocation failed even after trimming the cache */
+} ek_status;
+
+/* Unary ops.  cuda.h:418-543 (abs_ .. tzcnt_) and array_math.h (sin/cos/exp/log, CPU algorithm). */
+typedef enum {
+    EK_NEG = 0, EK_ABS, EK_NOT, EK_SQRT, EK_RCP, EK_RSQRT, EK_FLOOR, EK_CEIL, EK_ROUND, EK_TRUNC,
+    EK_SIN, EK_COS, EK_EXP, EK_LOG, EK_POPCNT, EK_LZCNT, EK_TZCNT, EK_SIGN, EK_COPY,
+    EK_UNARY_COUNT
+} ek_unary_op;
+
+/* Binary ops.  cuda.h:341-385, 408-416, 499-580; safe_mul = autodiff.cpp:1191-1205. */
+typedef enum {
+    EK_ADD = 0, EK_SUB, EK_MUL, EK_DIV, EK_MOD, EK_MIN, EK_MAX, EK_MULHI, EK_AND, EK_OR, EK_XOR,
+    EK_SL, EK_SR, EK_SAFE_MUL,
+    EK_BINARY_COUNT
+} ek_binary_op;
+
+/* Ternary ops.  cuda.h:387-406; safe_fmadd = autodiff.cpp:1207-1221. */
+typedef enum {
+    EK_FMADD = 0, EK_FMSUB, EK_FNMADD, EK_FNMSUB, EK_SAFE_FMADD,
+    EK_TERNARY_COUNT
+} ek_ternary_op;
+
+/* Comparisons -> u8 mask.  cuda.h:582-630. */
+typedef enum { EK_EQ = 0, EK_NEQ, EK_LT, EK_LE, EK_GT, EK_GE, EK_COMPARE_COUNT } ek_compare_op;
+
+/* Horizontal reductions.  cuda.h:693-759 / src/cuda/horiz.cu:162-268. */
+typedef enum { EK_HSUM = 0, EK_HPROD, EK_HMIN, EK_HMAX, EK_REDUCE_COUNT } ek_reduce_op;
+
+/* Mask reductions.  cuda.h:761-794 / horiz.cu:284-354. */
+typedef enum { EK_ALL = 0, EK_ANY, EK_COUNT, EK_MASK_REDUCE_COUNT } ek_mask_reduce_op;
+
+/* An operand of a vertical op: device array (`ptr` != NULL, `size` == n or 1) or an immediate
+   (`ptr` == NULL; the scalar's bit pattern in the low bytes of `imm`). */
+typedef struct {
+    const void *ptr;
+    uint64_t imm;
+    size_t size;
+} ek_operand;
+
+/* ---------------------------------------------------------------------------------------------
+ *  Runtime: device, stream, memory, diagnostics
+ *  replaces cuda_malloc, cuda_free, cuda_malloc_trim, cuda_sync, cuda_memcpy_to_device/from_device,
+ *  cuda_mem_get_info, cuda_whos, cuda_set_log_level
+ *  (cuda.h:109-200; src/cuda/jit.cu:1683-1896, common.cu:104-122)
+ * ------------------------------------------------------------------------------------------- */
+EK_API int ek_hip_init(int device);                 /* select device, create stream (idempotent) */
+EK_API int ek_hip_device(void);                     /* device ordinal in use, -1 before init */
+EK_API int ek_hip_device_count(void);
+EK_API void *ek_hip_stream(void);                   /* hipStream_t */
+EK_API int ek_hip_set_stream(void *hip_stream);     /* adopt a caller-owned stream (e.g. torch's) */
+EK_API int ek_hip_sync(void);                       /* hipStreamSynchronize on the library stream */
+EK_API const char *ek_hip_last_error(void);
+
+EK_API int ek_hip_malloc(size_t bytes, void **out);         /* caching allocator, 256-B aligned */
+EK_API int ek_hip_free(void *ptr);                          /* returns the block to the cache */
+EK_API int ek_hip_malloc_trim(void);                        /* release cached blocks to the driver */
+EK_API int ek_hip_host_malloc(size_t bytes, void **out);    /* pinned host memory */
+EK_API int ek_hip_host_free(void *ptr);
+EK_API int ek_hip_mem_get_info(size_t *free_bytes, size_t *total_bytes);
+EK_API int ek_hip_memcpy_to_device(void *dst, const void *src, size_t bytes);   /* blocking */
+EK_API int ek_hip_memcpy_to_host(void *dst, const void *src, size_t bytes);     /* blocking */
+EK_API int ek_hip_memcpy_device(void *dst, const void *src, size_t bytes);      /* async d2d */
+EK_API int ek_hip_memset(void *dst, int byte, size_t bytes);                    /* async */
+/* malloc'd, NUL-terminated allocator report; caller frees with free() (cuda_whos, cuda.cpp:40) */
+EK_API char *ek_hip_whos(void);
+EK_API void ek_hip_set_log_level(uint32_t level);   /* 0 silent .. 3 every launch (cuda.h:195-200) */
+EK_API uint32_t ek_hip_log_level(void);
+EK_API uint64_t ek_hip_launch_count(void);          /* kernels launched since init (diagnostics) */
+EK_API int ek_hip_set_tuning(const char *key, int value);   /* e.g. "blocks_per_cu", "unroll" */
+
+/* ---------------------------------------------------------------------------------------------
+ *  Vertical (elementwise) ops: out[i] = op(a[i or 0], ...), i in [0, n)
+ * ------------------------------------------------------------------------------------------- */
+EK_API int ek_hip_unary(int op, int type, void *out, const ek_operand *a, size_t n);
+EK_API int ek_hip_binary(int op, int type, void *out, const ek_operand *a, const ek_operand *b, size_t n);
+EK_API int ek_hip_ternary(int op, int type, void *out, const ek_operand *a, const ek_operand *b,
+                          const ek_operand *c, size_t n);
+/* sincos_: both outputs from one pass over the input (array_math.h:261-367) */
+EK_API int ek_hip_sincos(int type, void *out_sin, void *out_cos, const ek_operand *a, size_t n);
+EK_API int ek_hip_compare(int op, int type, uint8_t *out_mask, const ek_operand *a, const ek_operand *b, size_t n);
+/* select_: out = mask ? t : f (cuda.h:632-639); `mask` is an EK_BOOL operand */
+EK_API int ek_hip_select(int type, void *out, const ek_operand *mask, const ek_operand *t,
+                         const ek_operand *f, size_t n);
+/* converting constructor (cuda.h:236-247): float->int truncates, int->float rounds to nearest */
+EK_API int ek_hip_cast(int src_type, int dst_type, void *out, const ek_operand *a, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ *  Initialization (cuda.h:641-691; horiz.cu:28-32; common.cu:56-102)
+ * ------------------------------------------------------------------------------------------- */
+EK_API int ek_hip_fill(int type, void *out, uint64_t imm_bits, size_t n);
+/* out[i] = start + i*step, computed in the element type (integer types wrap) */
+EK_API int ek_hip_arange(int type, void *out, int64_t start, int64_t step, size_t n);
+/* out[i] = fmadd(i, step, min), step = (max-min)/(n-1)  (cuda.h:655-663) */
+EK_API int ek_hip_linspace(int type, void *out, double min, double max, size_t n);
+EK_API int ek_hip_reverse(int type, void *out, const void *in, size_t n);
+
+/* ---------------------------------------------------------------------------------------------
+ *  Indexed memory ops (cuda.h:845-905).  `index_type` in {EK_I32, EK_U32, EK_I64, EK_U64};
+ *  element stride = sizeof(type); `mask` may be an immediate operand (all lanes on/off).
+ * ------------------------------------------------------------------------------------------- */
+EK_API int ek_hip_gather(int type, int index_type, void *out, const void *base,
+                         const ek_operand *index, const ek_operand *mask, size_t n);
+EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
+                          const ek_operand *index, const ek_operand *mask, size_t n);
+/* mode 0: hardware atomics (order of fp additions unspecified, like atom.global.add);
+   mode 1: deterministic -- bit-identical to the CPU reference's element-order accumulation
+           (dynamic.h:517-534); `base_size` (elements) is required for mode 1. */
+EK_API int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size,
+                              const ek_operand *value, const ek_operand *index,
+                              const ek_operand *mask, size_t n, int mode);
+
+/* ---------------------------------------------------------------------------------------------
+ *  Horizontal ops.  Results of ek_hip_reduce* stay on the device (`out` = 1 element, async);
+ *  mask reductions return to the host and therefore synchronize (cuda.h:761-794).
+ * ------------------------------------------------------------------------------------------- */
+EK_API int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n);
+/* fused backward edge to a scalar source: out[0] = hsum(safe_mul(w, g))  (autodiff.cpp:867-871) */
+EK_API int ek_hip_hsum_safe_mul(int type, void *out, const ek_operand *w, const ek_operand *g, size_t n);
+EK_API int ek_hip_mask_reduce(int op, const uint8_t *mask, size_t n, uint64_t *host_result);
+/* inclusive prefix sum (cuda.h:717-726 / horiz.cu:182-200) */
+EK_API int ek_hip_psum(int type, void *out, const void *in, size_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ENOKI_HIP_C_API_H */

@@ -1,0 +1,79 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+def hash_u32(i, seed):
+    """counter-based integer hash shared by host and device generators"""
+    v = (np.asarray(i, dtype=np.uint64) + np.uint64(seed) * np.uint64(0x9E3779B9)) & np.uint64(0xFFFFFFFF)
+    v = v.astype(np.uint32)
+    v ^= v >> np.uint32(16)
+    v = (v.astype(np.uint64) * np.uint64(0x7FEB352D) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    v ^= v >> np.uint32(15)
+    v = (v.astype(np.uint64) * np.uint64(0x846CA68B) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    v ^= v >> np.uint32(16)
+    return v
+
+
+def uniform_pm1(n, seed):
+    """f32 uniform in [-1, 1): 2u - 1 with u = (h >> 8) * 2^-24 (exact in f32)"""
+    h = hash_u32(np.arange(n, dtype=np.uint64), seed)
+    u = (h >> np.uint32(8)).astype(np.float32) * np.float32(2.0 ** -24)
+    return (np.float32(2.0) * u - np.float32(1.0)).astype(np.float32)
+
+
+SPECIALS_F32 = np.array(
+    [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-45, -1e-45, 1e-38, 1.17549435e-38, 3.4e38, -3.4e38, 1, -1, 0.5, 2,
+     88.3, 88.5, -88.3, -88.5, -103, 8192, -8192, 1e6, 1e9, 3e9, -3e9, 1e20, 0.70710678, 0.7071068, np.pi,
+     np.pi / 2, np.pi / 4, 1.5, 2.5, -1.5, -2.5, 0.49999997, 8388608.0, 16777216.0], dtype=np.float32)
+
+
+def f32_inputs(n, seed, scale=1.0, specials=True):
+    rng = np.random.default_rng(seed)
+    v = (rng.standard_normal(n) * scale).astype(np.float32)
+    if specials and n >= SPECIALS_F32.size:
+        v[:SPECIALS_F32.size] = SPECIALS_F32
+    return v
+
+
+def bits_equal(a, b):
+    """bit equality, except that any NaN equals any NaN (payloads are not part of the contract)"""
+    a = np.asarray(a); b = np.asarray(b)
+    if a.shape != b.shape or a.dtype != b.dtype:
+        return False
+    if a.dtype.kind == "f":
+        ia = a.view(np.uint32 if a.dtype == np.float32 else np.uint64)
+        ib = b.view(np.uint32 if b.dtype == np.float32 else np.uint64)
+        return bool(np.all((ia == ib) | (np.isnan(a) & np.isnan(b))))
+    return bool(np.array_equal(a, b))
+
+
+def ulp_diff(a, b):
+    """distance in units of the last place between two f32 arrays (finite entries)"""
+    a = np.asarray(a, np.float32); b = np.asarray(b, np.float32)
+    ia = a.view(np.int32).astype(np.int64); ib = b.view(np.int32).astype(np.int64)
+    ia = np.where(ia < 0, np.int64(-2147483648) - ia, ia)
+    ib = np.where(ib < 0, np.int64(-2147483648) - ib, ib)
+    return np.abs(ia - ib)
+
+
+@pytest.fixture(scope="session")
+def capi():
+    from enoki_amd import capi as c
+    c.init()
+    return c
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    return oracle_lib.port()

@@ -1,0 +1,352 @@
+"""Parity of the HIP kernels (called THROUGH the C ABI, enoki_amd/capi.py -> libenoki-hip.so) against
+the CPU oracle (oracle/enoki_oracle.c, itself pinned bit-exactly to the reference build, see
+tests/test_oracle_vs_ref.py).
+
+Parity classes:
+  A  bit-exact        integer/mask/index ops, IEEE arithmetic, rounding, casts, gather/scatter,
+                      sin/cos/exp/log (restated CEPHES with explicit fma)
+  C  vs float64 truth rcp <= 2 ulp, rsqrt <= 3 ulp (the reference's own test bounds, tests/float.cpp:129-165;
+                      the AVX2 reference uses rcpps/rsqrtps + one Newton step, which is ISA specific)
+  D  order dependent  hsum/hprod/fp scatter_add: |gpu - f64 truth| <= gamma_n * sum|x_i|
+"""
+import numpy as np
+import pytest
+
+from conftest import SPECIALS_F32, bits_equal, f32_inputs, ulp_diff
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 257, 1000, 4099, 100003, (1 << 20) + 7]
+
+
+def up(capi, a):
+    return capi.Buf.from_numpy(a)
+
+
+# ----------------------------------------------------------------------------------------------
+#  class A: float32 vertical ops
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("op", ["neg", "abs", "sqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
+                                "sign"])
+@pytest.mark.parametrize("scale", [1.0, 30.0, 3000.0])
+def test_unary_f32_bit_exact(capi, oracle, op, scale):
+    a = f32_inputs(100003, seed=11, scale=scale)
+    got = capi.unary(op, up(capi, a)).numpy()
+    assert bits_equal(got, oracle.unary(op, a)), op
+
+
+@pytest.mark.parametrize("n", SIZES)
+def test_unary_sizes_and_tails(capi, oracle, n):
+    a = f32_inputs(n, seed=n, specials=False)
+    for op in ["sin", "exp", "sqrt"]:
+        assert bits_equal(capi.unary(op, up(capi, a)).numpy(), oracle.unary(op, a)), (op, n)
+
+
+def test_sincos_bit_exact(capi, oracle):
+    for scale in (1.0, 100.0, 8192.0):
+        a = f32_inputs(200001, seed=5, scale=scale)
+        s, c = capi.sincos(up(capi, a))
+        es, ec = oracle.sincos(a)
+        assert bits_equal(s.numpy(), es) and bits_equal(c.numpy(), ec)
+
+
+@pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "min", "max", "safe_mul"])
+def test_binary_f32_bit_exact(capi, oracle, op):
+    a = f32_inputs(100003, seed=1, scale=10.0)
+    b = f32_inputs(100003, seed=2, scale=10.0)[::-1].copy()
+    got = capi.binary(op, up(capi, a), up(capi, b)).numpy()
+    assert bits_equal(got, oracle.binary(op, a, b)), op
+
+
+@pytest.mark.parametrize("op", ["fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd"])
+def test_ternary_f32_bit_exact(capi, oracle, op):
+    a = f32_inputs(100003, seed=1); b = f32_inputs(100003, seed=2)[::-1].copy(); c = f32_inputs(100003, seed=3)
+    got = capi.ternary(op, up(capi, a), up(capi, b), up(capi, c)).numpy()
+    assert bits_equal(got, oracle.ternary(op, a, b, c)), op
+
+
+def test_denormals_are_not_flushed(capi, oracle):
+    """the CPU reference does not set FTZ/DAZ (array_intrin.h:167-194); neither may the kernels"""
+    a = np.array([1e-39, 2e-39, -3e-40, 1.17549435e-38, 1e-45] * 13, np.float32)
+    b = np.array([0.5, 1.0, 2.0, 0.25, 1.0] * 13, np.float32)
+    for op in ["add", "mul", "sub"]:
+        got = capi.binary(op, up(capi, a), up(capi, b if op == "mul" else a)).numpy()
+        assert bits_equal(got, oracle.binary(op, a, b if op == "mul" else a)), op
+    got = capi.ternary("fmadd", up(capi, a), up(capi, b), up(capi, a)).numpy()
+    assert bits_equal(got, oracle.ternary("fmadd", a, b, a))
+    assert np.any((got != 0) & (np.abs(got) < 1.17549435e-38))     # denormal results survive
+
+
+def test_broadcast_and_immediate_operands(capi, oracle):
+    n = 4099
+    a = f32_inputs(n, seed=7); x = f32_inputs(n, seed=8); s = np.array([0.75], np.float32)
+    full = np.full(n, 0.75, np.float32)
+    expect = oracle.ternary("fmadd", a, x, full)
+    assert bits_equal(capi.ternary("fmadd", up(capi, a), up(capi, x), up(capi, s)).numpy(), expect)   # size-1 device array
+    assert bits_equal(capi.ternary("fmadd", up(capi, a), up(capi, x), 0.75).numpy(), expect)          # immediate
+    expect = oracle.binary("safe_mul", full, a)
+    assert bits_equal(capi.binary("safe_mul", 0.75, up(capi, a)).numpy(), expect)
+    # all operands scalar -> size-1 result computed on the device
+    r = capi.binary("mul", up(capi, s), 2.0, n=1).numpy()
+    assert r.shape == (1,) and r[0] == np.float32(1.5)
+
+
+def test_size_mismatch_is_an_error(capi):
+    a = up(capi, np.zeros(10, np.float32)); b = up(capi, np.zeros(7, np.float32))
+    with pytest.raises(capi.EnokiHipError, match="incompatible size"):
+        capi.binary("add", a, b)
+
+
+def test_misaligned_pointers_take_the_scalar_path(capi, oracle):
+    a = f32_inputs(1031, seed=3); b = f32_inputs(1031, seed=4)
+    da, db = up(capi, a), up(capi, b)
+    for off in (1, 2, 3):
+        got = capi.binary("add", da.view(off, 1000), db.view(off, 1000)).numpy()
+        assert bits_equal(got, oracle.binary("add", a[off:off + 1000], b[off:off + 1000]))
+        got = capi.unary("sin", da.view(off, 1000)).numpy()
+        assert bits_equal(got, oracle.unary("sin", a[off:off + 1000]))
+
+
+# ----------------------------------------------------------------------------------------------
+#  class C: rcp / rsqrt against float64 truth with the reference's own bounds
+# ----------------------------------------------------------------------------------------------
+def test_rcp_rsqrt_vs_f64(capi):
+    rng = np.random.default_rng(9)
+    a = np.exp(rng.uniform(-80, 80, 200001)).astype(np.float32)
+    r = capi.unary("rcp", up(capi, a)).numpy()
+    assert ulp_diff(r, (1.0 / a.astype(np.float64)).astype(np.float32)).max() <= 2        # tests/float.cpp:133
+    r = capi.unary("rsqrt", up(capi, a)).numpy()
+    assert ulp_diff(r, (1.0 / np.sqrt(a.astype(np.float64))).astype(np.float32)).max() <= 3   # tests/float.cpp:152
+
+
+# ----------------------------------------------------------------------------------------------
+#  class A: integers, masks, compares, select, casts
+# ----------------------------------------------------------------------------------------------
+INT_TYPES = [np.int32, np.uint32, np.int64, np.uint64]
+
+
+def int_inputs(dt, n, seed):
+    rng = np.random.default_rng(seed)
+    info = np.iinfo(dt)
+    a = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+    sp = np.array([0, 1, 2, 3, info.max, info.min, info.max - 1, 31, 32, 33, 63, 64, 65], dtype=dt)
+    a[:sp.size] = sp
+    return a
+
+
+@pytest.mark.parametrize("dt", INT_TYPES)
+def test_integer_ops_bit_exact(capi, oracle, dt):
+    n = 100000
+    a, b = int_inputs(dt, n, 1), int_inputs(dt, n, 2)[::-1].copy()
+    for op in ["neg", "not", "abs", "popcnt", "lzcnt", "tzcnt"]:
+        assert bits_equal(capi.unary(op, up(capi, a)).numpy(), oracle.unary(op, a)), (dt, op)
+    bnz = b.copy(); bnz[bnz == 0] = 1
+    if np.iinfo(dt).min < 0:
+        bnz[bnz == -1] = 3
+    for op in ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor"]:
+        bb = bnz if op in ("div", "mod") else b
+        assert bits_equal(capi.binary(op, up(capi, a), up(capi, bb)).numpy(), oracle.binary(op, a, bb)), (dt, op)
+    bits = 8 * np.dtype(dt).itemsize
+    sh = np.random.default_rng(3).integers(0, bits, n).astype(dt)
+    for op in ["sl", "sr"]:
+        assert bits_equal(capi.binary(op, up(capi, a), up(capi, sh)).numpy(), oracle.binary(op, a, sh)), (dt, op)
+    if bits == 32:   # counts >= width: vpsllvd/vpsrlvd/vpsravd semantics (0 / sign fill)
+        sh2 = np.random.default_rng(4).integers(0, 40, n).astype(dt)
+        for op in ["sl", "sr"]:
+            assert bits_equal(capi.binary(op, up(capi, a), up(capi, sh2)).numpy(), oracle.binary(op, a, sh2)), (dt, op)
+        for op in ["fmadd", "fmsub", "fnmadd", "fnmsub"]:
+            c = a[::-1].copy()
+            assert bits_equal(capi.ternary(op, up(capi, a), up(capi, b), up(capi, c)).numpy(),
+                              oracle.ternary(op, a, b, c)), (dt, op)
+
+
+@pytest.mark.parametrize("dt", INT_TYPES + [np.float32, np.float64])
+def test_compare_and_select(capi, oracle, dt):
+    n = 50021
+    if np.dtype(dt).kind == "f":
+        a = f32_inputs(n, 5).astype(dt); b = f32_inputs(n, 6).astype(dt); b[::7] = a[::7]
+    else:
+        a, b = int_inputs(dt, n, 5), int_inputs(dt, n, 6); b[::7] = a[::7]
+    for op in ["eq", "neq", "lt", "le", "gt", "ge"]:
+        assert np.array_equal(capi.compare(op, up(capi, a), up(capi, b)).numpy(), oracle.compare(op, a, b)), (dt, op)
+    m = (np.random.default_rng(1).integers(0, 2, n)).astype(np.uint8)
+    assert bits_equal(capi.select(up(capi, m), up(capi, a), up(capi, b)).numpy(), oracle.select(m, a, b))
+    # scalar mask / scalar branches
+    assert bits_equal(capi.select(True, up(capi, a), up(capi, b)).numpy(), a)
+    assert bits_equal(capi.select(up(capi, m), up(capi, a), dt(3)).numpy(), oracle.select(m, a, np.full(n, 3, dt)))
+
+
+def test_mask_logic(capi):
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 2, 10007).astype(np.uint8); b = rng.integers(0, 2, 10007).astype(np.uint8)
+    assert np.array_equal(capi.binary("and", up(capi, a), up(capi, b)).numpy(), a & b)
+    assert np.array_equal(capi.binary("or", up(capi, a), up(capi, b)).numpy(), a | b)
+    assert np.array_equal(capi.binary("xor", up(capi, a), up(capi, b)).numpy(), a ^ b)
+    assert np.array_equal(capi.unary("not", up(capi, a)).numpy(), 1 - a)
+    assert np.array_equal(capi.compare("eq", up(capi, a), up(capi, b)).numpy(), (a == b).astype(np.uint8))
+
+
+def test_casts(capi, oracle):
+    n = 100000
+    f = (np.random.default_rng(1).standard_normal(n) * 1e3).astype(np.float32)
+    f[:6] = [0.5, -0.5, 1.5, -1.5, 2.5, -2.5]
+    assert bits_equal(capi.cast(up(capi, f), np.int32).numpy(), oracle.cast(f, np.int32))
+    assert bits_equal(capi.cast(up(capi, f), np.float64).numpy(), oracle.cast(f, np.float64))
+    assert bits_equal(capi.cast(up(capi, np.abs(f)), np.uint32).numpy(), oracle.cast(np.abs(f), np.uint32))
+    big = np.array([3e9, -3e9, np.nan, np.inf, -np.inf, 2147483520.0, 2147483648.0, -2147483648.0], np.float32)
+    assert bits_equal(capi.cast(up(capi, big), np.int32).numpy(), oracle.cast(big, np.int32))   # cvttps2dq indefinite
+    for src in INT_TYPES:
+        a = int_inputs(src, n, 3)
+        for dst in [np.float32, np.float64] + [t for t in INT_TYPES if t != src]:
+            assert bits_equal(capi.cast(up(capi, a), dst).numpy(), oracle.cast(a, dst)), (src, dst)
+
+
+# ----------------------------------------------------------------------------------------------
+#  init ops
+# ----------------------------------------------------------------------------------------------
+def test_fill_arange_linspace_reverse(capi, oracle):
+    assert np.array_equal(capi.fill(np.float32, 2.5, 1001).numpy(), np.full(1001, 2.5, np.float32))
+    assert np.array_equal(capi.fill(np.uint8, 1, 77).numpy(), np.ones(77, np.uint8))
+    assert np.array_equal(capi.fill(np.int64, -3, 513).numpy(), np.full(513, -3, np.int64))
+    assert np.array_equal(capi.arange(np.uint32, 100003).numpy(), np.arange(100003, dtype=np.uint32))
+    assert np.array_equal(capi.arange(np.int32, 1000, start=-5, step=3).numpy(), np.arange(-5, 2995, 3, dtype=np.int32))
+    assert np.array_equal(capi.arange(np.float32, 5000).numpy(), np.arange(5000, dtype=np.float32))
+    # linspace: closed form fmadd(i, step, min) (cuda.h:655-663); the CPU DynamicArray accumulates packet by
+    # packet (dynamic.h:924-938), so the two agree to n * eps * range, not bit for bit.
+    for n in (2, 7, 1000, 16384):
+        got = capi.linspace(np.float32, -1.2, 1.2, n).numpy()
+        step = (np.float32(1.2) - np.float32(-1.2)) / np.float32(n - 1)
+        expect = (np.arange(n, dtype=np.float64) * np.float64(step) + np.float64(np.float32(-1.2)))
+        assert np.abs(got - expect).max() <= 2.4 * 2.0 ** -23
+        assert np.abs(got - oracle.linspace(-1.2, 1.2, n)).max() <= 2.4 * n * 2.0 ** -24
+    a = f32_inputs(1003, 1)
+    assert bits_equal(capi.reverse(up(capi, a)).numpy(), a[::-1].copy())
+
+
+# ----------------------------------------------------------------------------------------------
+#  gather / scatter / scatter_add
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [1, 7, 64, 1000, 100003])
+@pytest.mark.parametrize("itype", [np.uint32, np.int32, np.int64, np.uint64])
+def test_gather_scatter(capi, oracle, n, itype):
+    rng = np.random.default_rng(n)
+    K = 257
+    src = rng.standard_normal(K).astype(np.float32)
+    idx = rng.integers(0, K, n).astype(itype)
+    m = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+    assert bits_equal(capi.gather(up(capi, src), up(capi, idx), up(capi, m)).numpy(), oracle.gather(src, idx, m))
+    assert bits_equal(capi.gather(up(capi, src), up(capi, idx)).numpy(), oracle.gather(src, idx, np.ones(n, np.uint8)))
+    # scatter with unique indices (duplicates: last writer in element order on the CPU, unspecified on a GPU)
+    perm = rng.permutation(max(K, n))[:n].astype(itype)
+    tgt = rng.standard_normal(max(K, n)).astype(np.float32)
+    val = rng.standard_normal(n).astype(np.float32)
+    d = up(capi, tgt)
+    capi.scatter(d, up(capi, val), up(capi, perm), up(capi, m))
+    assert bits_equal(d.numpy(), oracle.scatter(tgt, val, perm, m))
+    # integer scatter_add is exact regardless of order
+    itgt = rng.integers(-100, 100, K).astype(np.int32); ival = rng.integers(-100, 100, n).astype(np.int32)
+    d = up(capi, itgt)
+    capi.scatter_add(d, up(capi, ival), up(capi, idx), up(capi, m))
+    assert np.array_equal(d.numpy(), oracle.scatter(itgt, ival, idx, m, add=True))
+
+
+def test_gather_other_widths(capi, oracle):
+    rng = np.random.default_rng(5)
+    n, K = 5003, 99
+    idx = rng.integers(0, K, n).astype(np.uint32); m = (rng.integers(0, 3, n) != 0).astype(np.uint8)
+    for dt in (np.float64, np.int64, np.uint8):
+        src = (rng.integers(0, 2, K).astype(np.uint8) if dt == np.uint8 else (rng.standard_normal(K) * 100).astype(dt))
+        expect = np.where(m != 0, src[idx], np.zeros(1, dt)[0]).astype(dt)
+        assert bits_equal(capi.gather(up(capi, src), up(capi, idx), up(capi, m)).numpy(), expect), dt
+
+
+def test_scatter_add_f32_order_bound(capi, oracle):
+    """class D: atomics accumulate in unspecified order; bound the error per bin by gamma * sum|v|"""
+    rng = np.random.default_rng(6)
+    n, K = 200003, 511
+    idx = rng.integers(0, K, n).astype(np.uint32); m = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+    val = rng.standard_normal(n).astype(np.float32); tgt = rng.standard_normal(K).astype(np.float32)
+    d = up(capi, tgt)
+    capi.scatter_add(d, up(capi, val), up(capi, idx), up(capi, m))
+    got = d.numpy()
+    truth = tgt.astype(np.float64).copy(); np.add.at(truth, idx[m != 0], val[m != 0].astype(np.float64))
+    mag = np.abs(tgt).astype(np.float64); np.add.at(mag, idx[m != 0], np.abs(val[m != 0]).astype(np.float64))
+    cnt = np.bincount(idx[m != 0], minlength=K) + 1
+    assert np.all(np.abs(got - truth) <= cnt * 2.0 ** -24 * mag + 1e-30)
+    # and the CPU oracle obeys the same bound (sanity of the bound itself)
+    assert np.all(np.abs(oracle.scatter(tgt, val, idx, m, add=True) - truth) <= cnt * 2.0 ** -24 * mag + 1e-30)
+
+
+# ----------------------------------------------------------------------------------------------
+#  horizontal reductions
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n", [0, 1, 2, 7, 8, 9, 255, 256, 1000, 100003, (1 << 22) + 5])
+def test_reductions(capi, oracle, n):
+    a = f32_inputs(n, seed=n + 1, specials=False)
+    for op in ["hsum", "hprod", "hmin", "hmax"]:
+        aa = a if op != "hprod" else (1 + 1e-6 * a).astype(np.float32)
+        got = capi.reduce(op, up(capi, aa)).numpy()[0]
+        if n <= 1 or op in ("hmin", "hmax"):
+            assert bits_equal(np.float32(got), np.float32(oracle.reduce(op, aa))), (op, n)   # incl. empty identities
+        elif op == "hsum":
+            truth = aa.astype(np.float64).sum(); mag = np.abs(aa).astype(np.float64).sum()
+            assert abs(got - truth) <= n * 2.0 ** -24 * mag
+            assert abs(oracle.reduce(op, aa) - truth) <= n * 2.0 ** -24 * mag
+        else:
+            truth = np.prod(aa.astype(np.float64))
+            assert abs(got - truth) <= n * 2.0 ** -23 * abs(truth)
+    for dt in INT_TYPES:
+        ia = int_inputs(dt, max(n, 13), 3)[:n]
+        for op in ["hsum", "hprod", "hmin", "hmax"]:
+            assert capi.reduce(op, up(capi, ia)).numpy()[0] == oracle.reduce(op, ia), (dt, op, n)
+
+
+def test_hsum_run_to_run_deterministic(capi):
+    a = up(capi, f32_inputs(1 << 20, 3, specials=False))
+    r = {capi.reduce("hsum", a).numpy()[0].tobytes() for _ in range(5)}
+    assert len(r) == 1
+
+
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 1000, 100003])
+def test_mask_reductions(capi, oracle, n):
+    rng = np.random.default_rng(n)
+    for m in (rng.integers(0, 2, n).astype(np.uint8), np.ones(n, np.uint8), np.zeros(n, np.uint8)):
+        for op in ["all", "any", "count"]:
+            assert capi.mask_reduce(op, up(capi, m)) == oracle.mask_reduce(op, m), (op, n)
+
+
+def test_hsum_safe_mul_fused(capi):
+    n = 100003
+    w = f32_inputs(n, 1, specials=False); g = f32_inputs(n, 2, specials=False)
+    w[::5] = 0; g[::5] = np.inf                 # 0 * inf must contribute 0, not NaN (autodiff.cpp:1191-1196)
+    g[::7] = 0; w[7::35] = np.inf               # inf * 0 likewise
+    got = capi.hsum_safe_mul(up(capi, w), up(capi, g)).numpy()[0]
+    assert np.isfinite(got)
+    w2 = np.where(np.isinf(w), 0, w).astype(np.float32); g2 = np.where(np.isinf(g), 1.0, g).astype(np.float32)
+    truth = np.where((w2 == 0) | (g2 == 0) | (w == 0) | (g == 0), 0, w2.astype(np.float64) * g2).sum()
+    assert abs(got - truth) <= n * 2.0 ** -24 * np.abs(w2.astype(np.float64) * g2).sum()
+    got = capi.hsum_safe_mul(up(capi, w2), up(capi, g2)).numpy()[0]
+    truth = np.where((w2 == 0) | (g2 == 0), 0, w2.astype(np.float64) * g2).sum()
+    mag = np.abs(w2.astype(np.float64) * g2).sum()
+    assert abs(got - truth) <= n * 2.0 ** -24 * mag
+    got = capi.hsum_safe_mul(up(capi, w2), 2.0).numpy()[0]                       # immediate gradient
+    assert abs(got - 2 * w2.astype(np.float64).sum()) <= n * 2.0 ** -23 * np.abs(w2).sum()
+    got = capi.hsum_safe_mul(up(capi, w2), up(capi, np.array([2.0], np.float32)), n=n).numpy()[0]   # device scalar
+    assert abs(got - 2 * w2.astype(np.float64).sum()) <= n * 2.0 ** -23 * np.abs(w2).sum()
+
+
+def test_psum(capi, oracle):
+    for n in (1, 5, 256, 257, 4097, 100003):
+        a = np.random.default_rng(n).integers(-5, 5, n).astype(np.float32)   # exact in f32 -> order independent
+        assert bits_equal(capi.psum(up(capi, a)).numpy(), oracle.psum(a)), n
+        ia = np.random.default_rng(n).integers(0, 1000, n).astype(np.uint32)
+        assert np.array_equal(capi.psum(up(capi, ia)).numpy(), np.cumsum(ia, dtype=np.uint32)), n
+
+
+def test_allocator_reuse_and_whos(capi):
+    before = capi.lib.ek_hip_launch_count()
+    b = capi.Buf(np.float32, 1 << 20); p = b.ptr; b.free()
+    b2 = capi.Buf(np.float32, 1 << 20)
+    assert b2.ptr == p                      # cached block is reused
+    assert "live bytes" in capi.whos()
+    assert capi.lib.ek_hip_launch_count() == before
