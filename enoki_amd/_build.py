@@ -114,10 +114,34 @@ def build_python(force=False, verbose=True):
     return out
 
 
+def build_checkers(force=False, verbose=True):
+    """Test infrastructure: the C oracle, the reference-built oracle (only where /root/reference exists) and
+    the register-machine harnesses of tests/cpp.  Building the checkers is not using them."""
+    oracle = os.path.join(ROOT, "oracle")
+    _run(["make", "-C", oracle, "port"])
+    if os.path.isdir("/root/reference"):
+        _run(["make", "-C", oracle, "ref"])
+    tcpp = os.path.join(ROOT, "tests", "cpp")
+    inc = f"-I{os.path.join(ROOT, 'include')}"
+    host = os.path.join(tcpp, "libtape_host.so")
+    deps = _headers() + [os.path.join(tcpp, "tape_program.h"), os.path.join(HERE, "src", "autodiff_impl.h"),
+                         os.path.join(oracle, "host_array.h")]
+    if force or _newer(host, [os.path.join(tcpp, "tape_host.cpp")] + deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "tape_host.cpp"), "-o", host,
+              f"-L{oracle}", "-lenoki_oracle", "-Wl,-rpath,$ORIGIN/../../oracle"])
+    hip = os.path.join(tcpp, "libtape_hip.so")
+    if force or _newer(hip, [os.path.join(tcpp, "tape_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + deps):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "tape_hip.cpp"), "-o", hip,
+              f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+    if verbose:
+        print("[enoki_amd] checkers up to date (oracle/, tests/cpp/)")
+
+
 def build_all(force=False, verbose=True):
     build_core(force, verbose)
     build_autodiff(force, verbose)
     build_python(force, verbose)
+    build_checkers(force, verbose)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,360 @@
+/*
+    enoki/array.h -- the slice of the Enoki free-function vocabulary that the HIP hot path needs
+
+    This header is written from scratch for the MI355X backend.  It provides what the reference
+    spreads over array_traits.h / array_router.h / array_struct.h, restricted to the device hot
+    path: type traits (is_array_v, scalar_t, mask_t, expr_t, ...), operator
+    and function routing `enoki::op(x)` -> `x.op_()`, gather/scatter with array targets, and a
+    small static `Array<Value, N>` for SoA structures such as `Array<HIPArray<float>, 3>`.
+
+    Routing rule (cf. the reference's ENOKI_ROUTE_* macros, array_router.h:23-149): both operands
+    are converted to the "expression type" -- the operand with the larger `Rank` (nesting depth,
+    then differentiability) -- and the member `op_()` of that type is called.
+*/
+#pragma once
+
+#include <array>
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+#include <tuple>
+#include <type_traits>
+#include <utility>
+
+namespace enoki {
+
+// ---------------------------------------------------------------------------------------------
+//  Traits
+// ---------------------------------------------------------------------------------------------
+
+/// Every array type derives from this empty tag
+struct ArrayTag { };
+
+template <bool B> using enable_if_t = std::enable_if_t<B, int>;
+
+template <typename T> constexpr bool is_array_v = std::is_base_of_v<ArrayTag, std::decay_t<T>>;
+
+namespace detail {
+    struct reinterpret_flag { };
+
+    template <typename T, typename = int> struct scalar { using type = std::decay_t<T>; };
+    template <typename T> struct scalar<T, enable_if_t<is_array_v<T>>> { using type = typename std::decay_t<T>::Scalar; };
+
+    template <typename T, typename = int> struct value { using type = std::decay_t<T>; };
+    template <typename T> struct value<T, enable_if_t<is_array_v<T>>> { using type = typename std::decay_t<T>::Value; };
+
+    template <typename T, typename = int> struct mask { using type = bool; };
+    template <typename T> struct mask<T, enable_if_t<is_array_v<T>>> { using type = typename std::decay_t<T>::MaskType; };
+
+    template <typename T, typename = int> struct rank { static constexpr size_t value = 0; };
+    template <typename T> struct rank<T, enable_if_t<is_array_v<T>>> { static constexpr size_t value = std::decay_t<T>::Rank; };
+
+    template <typename T, typename = int> struct depth { static constexpr size_t value = 0; };
+    template <typename T> struct depth<T, enable_if_t<is_array_v<T>>> { static constexpr size_t value = std::decay_t<T>::Depth; };
+
+    template <typename T, typename S, typename = int> struct replace_scalar { using type = S; };
+    template <typename T, typename S> struct replace_scalar<T, S, enable_if_t<is_array_v<T>>> {
+        using type = typename std::decay_t<T>::template ReplaceScalar<S>;
+    };
+
+    template <typename T, typename = int> struct is_mask_impl : std::is_same<std::decay_t<T>, bool> { };
+    template <typename T> struct is_mask_impl<T, enable_if_t<is_array_v<T>>> : std::bool_constant<std::decay_t<T>::IsMask> { };
+
+    template <typename T, typename = int> struct is_diff_impl : std::false_type { };
+    template <typename T> struct is_diff_impl<T, enable_if_t<is_array_v<T>>> : std::bool_constant<std::decay_t<T>::IsDiff> { };
+
+    template <typename T, typename = int> struct is_dynamic_impl : std::false_type { };
+    template <typename T> struct is_dynamic_impl<T, enable_if_t<is_array_v<T>>> : std::bool_constant<std::decay_t<T>::IsDynamic> { };
+
+    template <typename T, typename = int> struct is_device_impl : std::false_type { };
+    template <typename T> struct is_device_impl<T, enable_if_t<is_array_v<T>>> : std::bool_constant<std::decay_t<T>::IsDevice> { };
+
+    template <typename...> constexpr bool false_v = false;
+}
+
+template <typename T> using scalar_t = typename detail::scalar<T>::type;
+template <typename T> using value_t = typename detail::value<T>::type;
+template <typename T> using mask_t = typename detail::mask<T>::type;
+template <typename T, typename S> using replace_scalar_t = typename detail::replace_scalar<T, S>::type;
+template <typename T> constexpr size_t array_depth_v = detail::depth<T>::value;
+template <typename T> constexpr bool is_mask_v = detail::is_mask_impl<T>::value;
+template <typename T> constexpr bool is_diff_array_v = detail::is_diff_impl<T>::value;
+template <typename T> constexpr bool is_dynamic_v = detail::is_dynamic_impl<T>::value;
+/// true for arrays whose storage lives in GPU memory (the role of the reference's is_cuda_array_v)
+template <typename T> constexpr bool is_device_array_v = detail::is_device_impl<T>::value;
+template <typename T> constexpr bool is_hip_array_v = is_device_array_v<T>;
+
+template <typename T> using int32_array_t  = replace_scalar_t<T, int32_t>;
+template <typename T> using uint32_array_t = replace_scalar_t<T, uint32_t>;
+template <typename T> using int64_array_t  = replace_scalar_t<T, int64_t>;
+template <typename T> using uint64_array_t = replace_scalar_t<T, uint64_t>;
+template <typename T> using float32_array_t = replace_scalar_t<T, float>;
+template <typename T> using float64_array_t = replace_scalar_t<T, double>;
+template <typename T> using int_array_t = replace_scalar_t<T,
+    std::conditional_t<sizeof(scalar_t<T>) == 8, int64_t, std::conditional_t<sizeof(scalar_t<T>) == 4, int32_t, int8_t>>>;
+template <typename T> using uint_array_t = replace_scalar_t<T,
+    std::conditional_t<sizeof(scalar_t<T>) == 8, uint64_t, std::conditional_t<sizeof(scalar_t<T>) == 4, uint32_t, uint8_t>>>;
+
+namespace detail {
+    template <typename T1, typename T2> struct expr2 {
+        using D1 = std::decay_t<T1>;
+        using D2 = std::decay_t<T2>;
+        using type = std::conditional_t<(rank<D1>::value >= rank<D2>::value), D1, D2>;
+    };
+}
+
+/// Type of an expression that combines values of type T1 and T2 (the higher-ranked operand)
+template <typename T1, typename T2 = T1> using expr_t = typename detail::expr2<T1, T2>::type;
+
+namespace detail {
+    /// Pass through when the type already matches, convert otherwise
+    template <typename E, typename T> inline decltype(auto) as(const T &v) {
+        if constexpr (std::is_same_v<E, std::decay_t<T>>)
+            return (const E &) v;
+        else
+            return E(v);
+    }
+}
+
+template <typename T> constexpr bool is_arithmetic_scalar_v = std::is_arithmetic_v<std::decay_t<T>>;
+
+template <typename T1, typename T2>
+using enable_if_array_any_t = enable_if_t<(is_array_v<T1> || is_array_v<T2>) &&
+                                          (is_array_v<T1> || is_arithmetic_scalar_v<T1>) &&
+                                          (is_array_v<T2> || is_arithmetic_scalar_v<T2>)>;
+
+// ---------------------------------------------------------------------------------------------
+//  Operator / function routing
+// ---------------------------------------------------------------------------------------------
+
+#define ENOKI_HIP_ROUTE_UNARY(name, member)                                                       \
+    template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto name(const T &a) {          \
+        return a.member##_();                                                                     \
+    }
+
+#define ENOKI_HIP_ROUTE_BINARY(name, member)                                                      \
+    template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0>                        \
+    inline auto name(const T1 &a1, const T2 &a2) {                                                \
+        using E = expr_t<T1, T2>;                                                                 \
+        return detail::as<E>(a1).member##_(detail::as<E>(a2));                                    \
+    }
+
+#define ENOKI_HIP_ROUTE_TERNARY(name, member)                                                     \
+    template <typename T1, typename T2, typename T3,                                              \
+              enable_if_t<is_array_v<T1> || is_array_v<T2> || is_array_v<T3>> = 0>                \
+    inline auto name(const T1 &a1, const T2 &a2, const T3 &a3) {                                  \
+        using E = expr_t<expr_t<T1, T2>, T3>;                                                     \
+        return detail::as<E>(a1).member##_(detail::as<E>(a2), detail::as<E>(a3));                 \
+    }
+
+ENOKI_HIP_ROUTE_UNARY(operator-, neg)
+ENOKI_HIP_ROUTE_UNARY(operator~, not)
+ENOKI_HIP_ROUTE_UNARY(operator!, not)
+
+ENOKI_HIP_ROUTE_BINARY(operator+, add)
+ENOKI_HIP_ROUTE_BINARY(operator-, sub)
+ENOKI_HIP_ROUTE_BINARY(operator*, mul)
+ENOKI_HIP_ROUTE_BINARY(operator/, div)
+ENOKI_HIP_ROUTE_BINARY(operator%, mod)
+ENOKI_HIP_ROUTE_BINARY(operator<<, sl)
+ENOKI_HIP_ROUTE_BINARY(operator>>, sr)
+ENOKI_HIP_ROUTE_BINARY(operator<, lt)
+ENOKI_HIP_ROUTE_BINARY(operator<=, le)
+ENOKI_HIP_ROUTE_BINARY(operator>, gt)
+ENOKI_HIP_ROUTE_BINARY(operator>=, ge)
+ENOKI_HIP_ROUTE_BINARY(eq, eq)
+ENOKI_HIP_ROUTE_BINARY(neq, neq)
+ENOKI_HIP_ROUTE_BINARY(min, min)
+ENOKI_HIP_ROUTE_BINARY(max, max)
+ENOKI_HIP_ROUTE_BINARY(mulhi, mulhi)
+
+ENOKI_HIP_ROUTE_TERNARY(fmadd, fmadd)
+ENOKI_HIP_ROUTE_TERNARY(fmsub, fmsub)
+ENOKI_HIP_ROUTE_TERNARY(fnmadd, fnmadd)
+ENOKI_HIP_ROUTE_TERNARY(fnmsub, fnmsub)
+
+ENOKI_HIP_ROUTE_UNARY(abs, abs)
+ENOKI_HIP_ROUTE_UNARY(sqrt, sqrt)
+ENOKI_HIP_ROUTE_UNARY(rcp, rcp)
+ENOKI_HIP_ROUTE_UNARY(rsqrt, rsqrt)
+ENOKI_HIP_ROUTE_UNARY(floor, floor)
+ENOKI_HIP_ROUTE_UNARY(ceil, ceil)
+ENOKI_HIP_ROUTE_UNARY(round, round)
+ENOKI_HIP_ROUTE_UNARY(trunc, trunc)
+ENOKI_HIP_ROUTE_UNARY(sin, sin)
+ENOKI_HIP_ROUTE_UNARY(cos, cos)
+ENOKI_HIP_ROUTE_UNARY(sincos, sincos)
+ENOKI_HIP_ROUTE_UNARY(exp, exp)
+ENOKI_HIP_ROUTE_UNARY(log, log)
+ENOKI_HIP_ROUTE_UNARY(popcnt, popcnt)
+ENOKI_HIP_ROUTE_UNARY(lzcnt, lzcnt)
+ENOKI_HIP_ROUTE_UNARY(tzcnt, tzcnt)
+ENOKI_HIP_ROUTE_UNARY(sign, sign)
+ENOKI_HIP_ROUTE_UNARY(hsum, hsum)
+ENOKI_HIP_ROUTE_UNARY(hprod, hprod)
+ENOKI_HIP_ROUTE_UNARY(hmin, hmin)
+ENOKI_HIP_ROUTE_UNARY(hmax, hmax)
+ENOKI_HIP_ROUTE_UNARY(psum, psum)
+ENOKI_HIP_ROUTE_UNARY(reverse, reverse)
+ENOKI_HIP_ROUTE_UNARY(all, all)
+ENOKI_HIP_ROUTE_UNARY(any, any)
+ENOKI_HIP_ROUTE_UNARY(count, count)
+
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline bool none(const T &a) { return !any(a); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sqr(const T &a) { return a * a; }
+
+// Scalar fallbacks so that templated code also accepts plain arithmetic types
+inline float  fmadd(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
+inline double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T sqr(T a) { return a * a; }
+template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T rcp(T a) { return T(1) / a; }
+template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T hsum(T a) { return a; }
+template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline bool eq(T a, T b) { return a == b; }
+template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline bool neq(T a, T b) { return a != b; }
+template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T select(bool m, T t, T f) { return m ? t : f; }
+inline bool all(bool b) { return b; }
+inline bool any(bool b) { return b; }
+inline bool none(bool b) { return !b; }
+
+/// Bit-level operators: mask & mask, int & int, and value & mask (keeps the value where the mask
+/// is set and zero elsewhere -- `and_(mask)` of the backend, cuda.h:559-571)
+#define ENOKI_HIP_ROUTE_BITOP(name, member)                                                       \
+    template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0>                        \
+    inline auto name(const T1 &a1, const T2 &a2) {                                                \
+        if constexpr (is_mask_v<T2> && !is_mask_v<T1>) {                                          \
+            using M = mask_t<T1>;                                                                 \
+            return a1.member##_(detail::as<M>(a2));                                               \
+        } else {                                                                                  \
+            using E = expr_t<T1, T2>;                                                             \
+            return detail::as<E>(a1).member##_(detail::as<E>(a2));                                \
+        }                                                                                         \
+    }
+
+ENOKI_HIP_ROUTE_BITOP(operator&, and)
+ENOKI_HIP_ROUTE_BITOP(operator&&, and)
+ENOKI_HIP_ROUTE_BITOP(operator|, or)
+ENOKI_HIP_ROUTE_BITOP(operator||, or)
+ENOKI_HIP_ROUTE_BITOP(operator^, xor)
+
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0>
+inline auto andnot(const T1 &a1, const T2 &a2) { return a1 & !a2; }
+
+#define ENOKI_HIP_ROUTE_COMPOUND(op)                                                              \
+    template <typename T1, typename T2, enable_if_t<is_array_v<T1>> = 0>                          \
+    inline T1 &operator op##=(T1 &a1, const T2 &a2) {                                             \
+        a1 = a1 op a2;                                                                            \
+        return a1;                                                                                \
+    }
+
+ENOKI_HIP_ROUTE_COMPOUND(+)
+ENOKI_HIP_ROUTE_COMPOUND(-)
+ENOKI_HIP_ROUTE_COMPOUND(*)
+ENOKI_HIP_ROUTE_COMPOUND(/)
+ENOKI_HIP_ROUTE_COMPOUND(&)
+ENOKI_HIP_ROUTE_COMPOUND(|)
+ENOKI_HIP_ROUTE_COMPOUND(^)
+ENOKI_HIP_ROUTE_COMPOUND(<<)
+ENOKI_HIP_ROUTE_COMPOUND(>>)
+
+/// select(mask, t, f): the value operands decide the expression type (array_router.h:480-492)
+template <typename M, typename T1, typename T2,
+          enable_if_t<is_array_v<M> || is_array_v<T1> || is_array_v<T2>> = 0>
+inline auto select(const M &m, const T1 &t, const T2 &f) {
+    using E = expr_t<T1, T2>;
+    if constexpr (!is_array_v<E>) {
+        // scalar branches, array mask: lift the branches to the value type that matches the mask
+        using E2 = typename std::decay_t<M>::template ReplaceMaskValue<E>;
+        return E2::select_(m, E2(t), E2(f));
+    } else {
+        return E::select_(detail::as<mask_t<E>>(m), detail::as<E>(t), detail::as<E>(f));
+    }
+}
+
+/// mulsign(a, b) = a * sign(b), via sign-bit xor like the CPU packets (array_router.h:447)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T mulsign(const T &a, const T &b) {
+    return a * sign(b);
+}
+
+// ---------------------------------------------------------------------------------------------
+//  Initialization, shape
+// ---------------------------------------------------------------------------------------------
+
+template <typename T> inline T zero(size_t size = 1) {
+    if constexpr (is_array_v<T>) return T::zero_(size); else return T(0);
+}
+template <typename T> inline T empty(size_t size = 1) {
+    if constexpr (is_array_v<T>) return T::empty_(size); else return T();
+}
+template <typename T> inline T full(const scalar_t<T> &value, size_t size = 1) {
+    if constexpr (is_array_v<T>) return T::full_(value, size); else return T(value);
+}
+template <typename T> inline T arange(size_t size) { return T::arange_(0, (ptrdiff_t) size, 1); }
+template <typename T> inline T arange(ptrdiff_t start, ptrdiff_t stop, ptrdiff_t step = 1) {
+    return T::arange_(start, stop, step);
+}
+template <typename T> inline T linspace(scalar_t<T> min, scalar_t<T> max, size_t size) {
+    return T::linspace_(min, max, size);
+}
+
+/// Number of "slices" (dynamic entries) of an array; 1 for scalars
+template <typename T> inline size_t slices(const T &a) {
+    if constexpr (is_array_v<T>) return a.slices_(); else return 1;
+}
+
+/// Broadcast a size-1 dynamic array to `size` entries / resize
+template <typename T> inline void set_slices(T &a, size_t size) {
+    if constexpr (is_array_v<T>) a.set_slices_(size);
+}
+
+template <typename Target, typename Source> inline Target reinterpret_array(const Source &src) {
+    if constexpr (std::is_same_v<Target, Source>) {
+        return src;
+    } else if constexpr (is_array_v<Target>) {
+        return Target(src, detail::reinterpret_flag());
+    } else {
+        static_assert(sizeof(Target) == sizeof(Source));
+        Target t;
+        memcpy(&t, &src, sizeof(Target));
+        return t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+//  Gather / scatter with an array as source / target (array_struct.h:9-123)
+// ---------------------------------------------------------------------------------------------
+
+/// gather<Array>(source, index, mask): result[i] = mask[i] ? source[index[i]] : 0
+template <typename Array, size_t Stride = 0, bool Packed = true, bool IsPermute = false, typename Source,
+          typename Index, typename Mask = mask_t<Index>,
+          enable_if_t<is_array_v<Source> && is_dynamic_v<Source>> = 0>
+inline Array gather(const Source &source, const Index &index, const Mask &mask = true) {
+    return Array::template gather_array_<IsPermute>(source, index, detail::as<mask_t<Index>>(mask));
+}
+
+template <size_t Stride = 0, bool Packed = true, bool IsPermute = false, typename Target, typename Value,
+          typename Index, typename Mask = mask_t<Index>,
+          enable_if_t<is_array_v<Target> && is_dynamic_v<Target>> = 0>
+inline void scatter(Target &target, const Value &value, const Index &index, const Mask &mask = true) {
+    Target::template scatter_array_<IsPermute>(target, detail::as<Target>(value), index,
+                                               detail::as<mask_t<Index>>(mask));
+}
+
+template <size_t Stride = 0, bool Packed = true, bool IsPermute = false, typename Target, typename Value,
+          typename Index, typename Mask = mask_t<Index>,
+          enable_if_t<is_array_v<Target> && is_dynamic_v<Target>> = 0>
+inline void scatter_add(Target &target, const Value &value, const Index &index, const Mask &mask = true) {
+    Target::template scatter_add_array_<IsPermute>(target, detail::as<Target>(value), index,
+                                                   detail::as<mask_t<Index>>(mask));
+}
+
+// ---------------------------------------------------------------------------------------------
+//  Autodiff helpers that are no-ops for non-differentiable types (autodiff.h:1414-1500)
+// ---------------------------------------------------------------------------------------------
+
+template <typename T> inline decltype(auto) detach(const T &a) {
+    if constexpr (is_diff_array_v<T>) return a.value_(); else return (const T &) a;
+}
+
+} // namespace enoki

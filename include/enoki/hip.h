@@ -1,0 +1,604 @@
+/*
+    enoki/hip.h -- HIPArray<Value>: a 1-D array resident in MI355X memory
+
+    Plays the role of the reference's CUDAArray<Value> (include/enoki/cuda.h:205-954) and keeps its
+    member concept (`add_`, `fmadd_`, `select_`, `gather_<Stride>`, `hsum_`, `map`, `copy`, ...), but
+    NOT its mechanism: there is no trace, no JIT and no variable table.  A HIPArray owns a
+    reference-counted device buffer; every operation launches one pre-compiled HIP kernel from
+    libenoki-hip.so (include/enoki_hip.h) on the library stream and returns a new array.
+
+      * copies share the buffer (refcount), like cuda.h:224-226;
+      * arrays of size 1 created from host values are *immediates*: they live in the handle and
+        are passed to kernels as arguments, so `a * 2.f` never materialises a broadcast;
+      * arrays of size 1 produced on the device (hsum, ...) stay on the device -- nothing here
+        synchronises except coeff()/operator[], all_/any_/count_ and the *_to_host copies;
+      * size mismatches throw std::runtime_error("arrays of incompatible size"), jit.cu:776-782.
+*/
+#pragma once
+
+#include <enoki/array.h>
+#include <enoki_hip.h>
+
+#include <initializer_list>
+#include <vector>
+
+namespace enoki {
+
+namespace detail {
+    [[noreturn]] inline void hip_raise(const char *what) {
+        throw std::runtime_error(std::string(what) + ": " + ek_hip_last_error());
+    }
+    inline void hip_check(int rc, const char *what) {
+        if (rc != EK_OK) hip_raise(what);
+    }
+
+    /// Reference-counted device allocation
+    struct HIPBuffer {
+        void *ptr = nullptr;
+        size_t size = 0;          // elements
+        uint32_t ref_count = 1;
+        bool owned = true;        // false for map()ped memory that the caller keeps
+
+        ~HIPBuffer() {
+            if (owned && ptr) ek_hip_free(ptr);
+        }
+    };
+
+    template <typename T> struct hip_type;
+    template <> struct hip_type<bool>     { static constexpr int value = EK_BOOL; };
+    template <> struct hip_type<int32_t>  { static constexpr int value = EK_I32; };
+    template <> struct hip_type<uint32_t> { static constexpr int value = EK_U32; };
+    template <> struct hip_type<int64_t>  { static constexpr int value = EK_I64; };
+    template <> struct hip_type<uint64_t> { static constexpr int value = EK_U64; };
+    template <> struct hip_type<float>    { static constexpr int value = EK_F32; };
+    template <> struct hip_type<double>   { static constexpr int value = EK_F64; };
+}
+
+template <typename Value_> struct HIPArray : ArrayTag {
+    static_assert(std::is_arithmetic_v<Value_>, "HIPArray: arithmetic element types only");
+    template <typename T> friend struct HIPArray;
+
+    using Value = Value_;
+    using Scalar = Value_;
+    using ArrayType = HIPArray;
+    using MaskType = HIPArray<bool>;
+    template <typename T> using ReplaceValue = HIPArray<T>;
+    template <typename T> using ReplaceScalar = HIPArray<T>;
+    template <typename T> using ReplaceMaskValue = HIPArray<T>;
+
+    static constexpr int Type = detail::hip_type<Value>::value;
+    static constexpr size_t Depth = 1;
+    static constexpr size_t Rank = 2;
+    static constexpr bool IsMask = std::is_same_v<Value, bool>;
+    static constexpr bool IsDiff = false;
+    static constexpr bool IsDynamic = true;
+    static constexpr bool IsDevice = true;
+    static constexpr bool IsCUDA = false;
+    static constexpr bool IsFloat = std::is_floating_point_v<Value>;
+    static constexpr bool IsInt = std::is_integral_v<Value> && !IsMask;
+
+    // -----------------------------------------------------------------------------------------
+    //  Construction, assignment
+    // -----------------------------------------------------------------------------------------
+
+    HIPArray() = default;
+
+    ~HIPArray() { release(); }
+
+    HIPArray(const HIPArray &a) : m_buf(a.m_buf), m_imm(a.m_imm), m_is_imm(a.m_is_imm) {
+        if (m_buf) m_buf->ref_count++;
+    }
+
+    HIPArray(HIPArray &&a) noexcept : m_buf(a.m_buf), m_imm(a.m_imm), m_is_imm(a.m_is_imm) {
+        a.m_buf = nullptr;
+        a.m_is_imm = false;
+    }
+
+    /// Broadcast a host scalar (an immediate: no device memory is touched)
+    HIPArray(Value value) : m_imm(value), m_is_imm(true) { }
+
+    template <typename T, enable_if_t<std::is_arithmetic_v<T> && !std::is_same_v<T, Value>> = 0>
+    HIPArray(T value) : m_imm((Value) value), m_is_imm(true) { }
+
+    /// Element list -> device (cuda.h:319-323)
+    template <typename... Args, enable_if_t<(sizeof...(Args) > 1) && (std::is_arithmetic_v<Args> && ...)> = 0>
+    HIPArray(Args... args) {
+        Value data[] = { (Value) args... };
+        *this = copy(data, sizeof...(Args));
+    }
+
+    /// Converting constructor (cuda.h:236-247): float->int truncates, int->float rounds to nearest
+    template <typename T, enable_if_t<!std::is_same_v<T, Value>> = 0>
+    HIPArray(const HIPArray<T> &v) {
+        if (v.m_is_imm) {
+            m_imm = (Value) v.m_imm;
+            m_is_imm = true;
+        } else if (v.m_buf) {
+            size_t n = v.size();
+            allocate(n);
+            ek_operand oa = v.operand();
+            detail::hip_check(ek_hip_cast(HIPArray<T>::Type, Type, m_buf->ptr, &oa, n), "HIPArray(cast)");
+        }
+    }
+
+    /// Reinterpreting constructor (cuda.h:249-258): shares the buffer
+    template <typename T, enable_if_t<!std::is_same_v<T, Value>> = 0>
+    HIPArray(const HIPArray<T> &v, detail::reinterpret_flag) {
+        static_assert(sizeof(T) == sizeof(Value), "reinterpret_array(): element sizes must match");
+        if (v.m_is_imm) {
+            memcpy(&m_imm, &v.m_imm, sizeof(Value));
+            m_is_imm = true;
+        } else if (v.m_buf) {
+            m_buf = v.m_buf;
+            m_buf->ref_count++;
+        }
+    }
+
+    HIPArray(const HIPArray &v, detail::reinterpret_flag) : HIPArray(v) { }
+
+    HIPArray &operator=(const HIPArray &a) {
+        if (a.m_buf) a.m_buf->ref_count++;
+        release();
+        m_buf = a.m_buf;
+        m_imm = a.m_imm;
+        m_is_imm = a.m_is_imm;
+        return *this;
+    }
+
+    HIPArray &operator=(HIPArray &&a) noexcept {
+        std::swap(m_buf, a.m_buf);
+        std::swap(m_imm, a.m_imm);
+        std::swap(m_is_imm, a.m_is_imm);
+        return *this;
+    }
+
+    // -----------------------------------------------------------------------------------------
+    //  Vertical operations
+    // -----------------------------------------------------------------------------------------
+
+    HIPArray add_(const HIPArray &v) const { return binary(EK_ADD, v, "add_"); }
+    HIPArray sub_(const HIPArray &v) const { return binary(EK_SUB, v, "sub_"); }
+    HIPArray mul_(const HIPArray &v) const { return binary(EK_MUL, v, "mul_"); }
+    HIPArray div_(const HIPArray &v) const { return binary(EK_DIV, v, "div_"); }
+    HIPArray mod_(const HIPArray &v) const { return binary(EK_MOD, v, "mod_"); }
+    HIPArray mulhi_(const HIPArray &v) const { return binary(EK_MULHI, v, "mulhi_"); }
+    HIPArray min_(const HIPArray &v) const { return binary(EK_MIN, v, "min_"); }
+    HIPArray max_(const HIPArray &v) const { return binary(EK_MAX, v, "max_"); }
+    HIPArray xor_(const HIPArray &v) const { return binary(EK_XOR, v, "xor_"); }
+    HIPArray sl_(const HIPArray &v) const { return binary(EK_SL, v, "sl_"); }
+    HIPArray sr_(const HIPArray &v) const { return binary(EK_SR, v, "sr_"); }
+    HIPArray sl_(size_t k) const { return sl_(HIPArray((Value) k)); }
+    HIPArray sr_(size_t k) const { return sr_(HIPArray((Value) k)); }
+    template <size_t Imm> HIPArray sl_() const { return sl_(Imm); }
+    template <size_t Imm> HIPArray sr_() const { return sr_(Imm); }
+
+    HIPArray fmadd_(const HIPArray &b, const HIPArray &c) const { return ternary(EK_FMADD, b, c, "fmadd_"); }
+    HIPArray fmsub_(const HIPArray &b, const HIPArray &c) const { return ternary(EK_FMSUB, b, c, "fmsub_"); }
+    HIPArray fnmadd_(const HIPArray &b, const HIPArray &c) const { return ternary(EK_FNMADD, b, c, "fnmadd_"); }
+    HIPArray fnmsub_(const HIPArray &b, const HIPArray &c) const { return ternary(EK_FNMSUB, b, c, "fnmsub_"); }
+
+    HIPArray neg_() const { return unary(EK_NEG, "neg_"); }
+    HIPArray abs_() const { return unary(EK_ABS, "abs_"); }
+    HIPArray not_() const { return unary(EK_NOT, "not_"); }
+    HIPArray sqrt_() const { return unary(EK_SQRT, "sqrt_"); }
+    HIPArray rcp_() const { return unary(EK_RCP, "rcp_"); }
+    HIPArray rsqrt_() const { return unary(EK_RSQRT, "rsqrt_"); }
+    HIPArray floor_() const { return unary(EK_FLOOR, "floor_"); }
+    HIPArray ceil_() const { return unary(EK_CEIL, "ceil_"); }
+    HIPArray round_() const { return unary(EK_ROUND, "round_"); }
+    HIPArray trunc_() const { return unary(EK_TRUNC, "trunc_"); }
+    HIPArray sin_() const { return unary(EK_SIN, "sin_"); }
+    HIPArray cos_() const { return unary(EK_COS, "cos_"); }
+    HIPArray exp_() const { return unary(EK_EXP, "exp_"); }
+    HIPArray log_() const { return unary(EK_LOG, "log_"); }
+    HIPArray popcnt_() const { return unary(EK_POPCNT, "popcnt_"); }
+    HIPArray lzcnt_() const { return unary(EK_LZCNT, "lzcnt_"); }
+    HIPArray tzcnt_() const { return unary(EK_TZCNT, "tzcnt_"); }
+    HIPArray sign_() const { return unary(EK_SIGN, "sign_"); }
+
+    template <typename T> T floor2int_() const { return T(floor_()); }
+    template <typename T> T ceil2int_() const { return T(ceil_()); }
+
+    /// Both results from one pass over the input
+    std::pair<HIPArray, HIPArray> sincos_() const {
+        require_valid("sincos_");
+        size_t n = size();
+        HIPArray s = empty_(n), c = empty_(n);
+        ek_operand oa = operand();
+        detail::hip_check(ek_hip_sincos(Type, s.m_buf->ptr, c.m_buf->ptr, &oa, n), "sincos_");
+        return { std::move(s), std::move(c) };
+    }
+
+    /// and_/or_ with an operand of the same type are bit operations; with a mask they select
+    /// (cuda.h:545-575)
+    HIPArray and_(const HIPArray &v) const { return binary(EK_AND, v, "and_"); }
+    HIPArray or_(const HIPArray &v) const { return binary(EK_OR, v, "or_"); }
+
+    template <typename T = Value, enable_if_t<!std::is_same_v<T, bool>> = 0>
+    HIPArray and_(const MaskType &m) const { return select_(m, *this, HIPArray(Value(0))); }
+
+    template <typename T = Value, enable_if_t<!std::is_same_v<T, bool>> = 0>
+    HIPArray or_(const MaskType &m) const {
+        using UInt = scalar_t<uint_array_t<HIPArray>>;
+        UInt ones = (UInt) -1;
+        Value all_ones;
+        memcpy(&all_ones, &ones, sizeof(Value));
+        return select_(m, HIPArray(all_ones), *this);
+    }
+
+    template <typename T> HIPArray andnot_(const HIPArray<T> &v) const { return and_(v.not_()); }
+
+    MaskType eq_(const HIPArray &v) const { return compare(EK_EQ, v, "eq_"); }
+    MaskType neq_(const HIPArray &v) const { return compare(EK_NEQ, v, "neq_"); }
+    MaskType lt_(const HIPArray &v) const { return compare(EK_LT, v, "lt_"); }
+    MaskType le_(const HIPArray &v) const { return compare(EK_LE, v, "le_"); }
+    MaskType gt_(const HIPArray &v) const { return compare(EK_GT, v, "gt_"); }
+    MaskType ge_(const HIPArray &v) const { return compare(EK_GE, v, "ge_"); }
+
+    static HIPArray select_(const MaskType &m, const HIPArray &t, const HIPArray &f) {
+        m.require_valid("select_"); t.require_valid("select_"); f.require_valid("select_");
+        size_t n = broadcast_size(broadcast_size(m.size(), t.size()), f.size());
+        HIPArray r = empty_(n);
+        ek_operand om = m.operand(), ot = t.operand(), of = f.operand();
+        detail::hip_check(ek_hip_select(Type, r.m_buf->ptr, &om, &ot, &of, n), "select_");
+        return r;
+    }
+
+    // -----------------------------------------------------------------------------------------
+    //  Fused primitives of the reverse/forward sweeps (src/autodiff/autodiff.cpp:1191-1221)
+    // -----------------------------------------------------------------------------------------
+
+    /// (w == 0 || g == 0) ? 0 : w * g
+    static HIPArray safe_mul_(const HIPArray &w, const HIPArray &g) { return w.binary(EK_SAFE_MUL, g, "safe_mul"); }
+
+    /// (w == 0 || g == 0) ? acc : fma(w, g, acc)
+    static HIPArray safe_fmadd_(const HIPArray &w, const HIPArray &g, const HIPArray &acc) {
+        return w.ternary(EK_SAFE_FMADD, g, acc, "safe_fmadd");
+    }
+
+    /// hsum(safe_mul(w, g)) in one pass
+    static HIPArray hsum_safe_mul_(const HIPArray &w, const HIPArray &g) {
+        w.require_valid("hsum_safe_mul"); g.require_valid("hsum_safe_mul");
+        size_t n = broadcast_size(w.size(), g.size());
+        HIPArray r = empty_(1);
+        ek_operand ow = w.operand(), og = g.operand();
+        detail::hip_check(ek_hip_hsum_safe_mul(Type, r.m_buf->ptr, &ow, &og, n), "hsum_safe_mul");
+        return r;
+    }
+
+    // -----------------------------------------------------------------------------------------
+    //  Initialization
+    // -----------------------------------------------------------------------------------------
+
+    static HIPArray empty_(size_t size) {
+        HIPArray r;
+        r.allocate(size);
+        return r;
+    }
+
+    static HIPArray zero_(size_t size) {
+        if (size == 1) return HIPArray(Value(0));
+        HIPArray r = empty_(size);
+        if (size) detail::hip_check(ek_hip_memset(r.m_buf->ptr, 0, size * sizeof(Value)), "zero_");
+        return r;
+    }
+
+    static HIPArray full_(const Value &value, size_t size) {
+        if (size == 1) return HIPArray(value);
+        HIPArray r = empty_(size);
+        detail::hip_check(ek_hip_fill(Type, r.m_buf->ptr, imm_bits(value), size), "full_");
+        return r;
+    }
+
+    static HIPArray arange_(ptrdiff_t start, ptrdiff_t stop, ptrdiff_t step) {
+        size_t size = size_t((stop - start + step - (step > 0 ? 1 : -1)) / step);
+        HIPArray r = empty_(size);
+        detail::hip_check(ek_hip_arange(Type, r.m_buf->ptr, (int64_t) start, (int64_t) step, size), "arange_");
+        return r;
+    }
+
+    static HIPArray linspace_(Value min, Value max, size_t size) {
+        HIPArray r = empty_(size);
+        detail::hip_check(ek_hip_linspace(Type, r.m_buf->ptr, (double) min, (double) max, size), "linspace_");
+        return r;
+    }
+
+    /// Wrap existing device memory (cuda.h:796-798); `dealloc`: pointer came from ek_hip_malloc
+    static HIPArray map(void *ptr, size_t size, bool dealloc = false) {
+        HIPArray r;
+        r.m_buf = new detail::HIPBuffer();
+        r.m_buf->ptr = ptr;
+        r.m_buf->size = size;
+        r.m_buf->owned = dealloc;
+        return r;
+    }
+
+    /// Copy host memory to a new device array (cuda.h:800-802)
+    static HIPArray copy(const void *ptr, size_t size) {
+        HIPArray r = empty_(size);
+        if (size)
+            detail::hip_check(ek_hip_memcpy_to_device(r.m_buf->ptr, ptr, size * sizeof(Value)), "copy");
+        return r;
+    }
+
+    // -----------------------------------------------------------------------------------------
+    //  Indexed memory operations (cuda.h:845-905)
+    // -----------------------------------------------------------------------------------------
+
+    template <size_t Stride, typename Index>
+    static HIPArray gather_(const void *ptr, const Index &index, const MaskType &mask) {
+        static_assert(Stride == sizeof(Value) || Stride == 0, "HIPArray::gather_(): element stride only");
+        index.require_valid("gather_"); mask.require_valid("gather_");
+        size_t n = broadcast_size(index.size(), mask.size());
+        HIPArray r = empty_(n);
+        ek_operand oi = index.operand(), om = mask.operand();
+        detail::hip_check(ek_hip_gather(Type, Index::Type, r.m_buf->ptr, ptr, &oi, &om, n), "gather_");
+        return r;
+    }
+
+    template <size_t Stride, typename Index>
+    void scatter_(void *ptr, const Index &index, const MaskType &mask) const {
+        static_assert(Stride == sizeof(Value) || Stride == 0, "HIPArray::scatter_(): element stride only");
+        require_valid("scatter_"); index.require_valid("scatter_"); mask.require_valid("scatter_");
+        size_t n = broadcast_size(broadcast_size(size(), index.size()), mask.size());
+        ek_operand ov = operand(), oi = index.operand(), om = mask.operand();
+        detail::hip_check(ek_hip_scatter(Type, Index::Type, ptr, &ov, &oi, &om, n), "scatter_");
+    }
+
+    template <size_t Stride, typename Index>
+    void scatter_add_(void *ptr, const Index &index, const MaskType &mask, size_t target_size = 0) const {
+        static_assert(Stride == sizeof(Value) || Stride == 0, "HIPArray::scatter_add_(): element stride only");
+        require_valid("scatter_add_"); index.require_valid("scatter_add_"); mask.require_valid("scatter_add_");
+        size_t n = broadcast_size(broadcast_size(size(), index.size()), mask.size());
+        ek_operand ov = operand(), oi = index.operand(), om = mask.operand();
+        detail::hip_check(ek_hip_scatter_add(Type, Index::Type, ptr, target_size, &ov, &oi, &om, n, 0), "scatter_add_");
+    }
+
+    /// gather/scatter with an array as source/target (array_struct.h:9-123); a source of size 1 is
+    /// a broadcast (array_struct.h:19-22)
+    template <bool IsPermute, typename Index>
+    static HIPArray gather_array_(const HIPArray &source, const Index &index, const MaskType &mask) {
+        if (source.size() <= 1) return source & mask;
+        return gather_<sizeof(Value)>(source.data(), detach(index), mask);
+    }
+
+    template <bool IsPermute, typename Index>
+    static void scatter_array_(HIPArray &target, const HIPArray &value, const Index &index, const MaskType &mask) {
+        target.make_unique();
+        value.template scatter_<sizeof(Value)>(target.data(), detach(index), mask);
+    }
+
+    template <bool IsPermute, typename Index>
+    static void scatter_add_array_(HIPArray &target, const HIPArray &value, const Index &index, const MaskType &mask) {
+        target.make_unique();
+        value.template scatter_add_<sizeof(Value)>(target.data(), detach(index), mask, target.size());
+    }
+
+    // -----------------------------------------------------------------------------------------
+    //  Horizontal operations (cuda.h:693-794)
+    // -----------------------------------------------------------------------------------------
+
+    HIPArray hsum_() const { return reduce(EK_HSUM, "hsum_"); }
+    HIPArray hprod_() const { return reduce(EK_HPROD, "hprod_"); }
+    HIPArray hmin_() const { return reduce(EK_HMIN, "hmin_"); }
+    HIPArray hmax_() const { return reduce(EK_HMAX, "hmax_"); }
+
+    bool all_() const { return mask_reduce(EK_ALL, "all_") != 0; }
+    bool any_() const { return mask_reduce(EK_ANY, "any_") != 0; }
+    size_t count_() const { return (size_t) mask_reduce(EK_COUNT, "count_"); }
+
+    HIPArray reverse_() const {
+        size_t n = size();
+        if (n <= 1) return *this;
+        HIPArray r = empty_(n);
+        detail::hip_check(ek_hip_reverse(Type, r.m_buf->ptr, m_buf->ptr, n), "reverse_");
+        return r;
+    }
+
+    HIPArray psum_() const {
+        size_t n = size();
+        if (n <= 1) return *this;
+        HIPArray r = empty_(n);
+        detail::hip_check(ek_hip_psum(Type, r.m_buf->ptr, m_buf->ptr, n), "psum_");
+        return r;
+    }
+
+    // -----------------------------------------------------------------------------------------
+    //  Storage access
+    // -----------------------------------------------------------------------------------------
+
+    size_t size() const { return m_is_imm ? 1 : (m_buf ? m_buf->size : 0); }
+    size_t slices_() const { return size(); }
+    bool empty() const { return size() == 0; }
+    bool valid() const { return m_is_imm || m_buf != nullptr; }
+    bool is_immediate() const { return m_is_imm; }
+
+    /// Device pointer; an immediate is materialised on first use
+    const Value *data() const { materialize(); return m_buf ? (const Value *) m_buf->ptr : nullptr; }
+    Value *data() { materialize(); return m_buf ? (Value *) m_buf->ptr : nullptr; }
+
+    /// Broadcast a size-1 array / set the size of an empty array (CUDAArray::resize, cuda.h:935-937)
+    void resize(size_t size) { set_slices_(size); }
+
+    void set_slices_(size_t new_size) {
+        size_t cur = size();
+        if (cur == new_size) return;
+        if (cur == 0) {
+            release();
+            allocate(new_size);
+        } else if (cur == 1) {
+            HIPArray r = empty_(new_size);
+            ek_operand oa = operand();
+            detail::hip_check(ek_hip_unary(EK_COPY, Type, r.m_buf->ptr, &oa, new_size), "set_slices");
+            *this = std::move(r);
+        } else {
+            throw std::runtime_error("HIPArray::resize(): only arrays of size 0 or 1 can be resized (have " +
+                                     std::to_string(cur) + ", requested " + std::to_string(new_size) + ")");
+        }
+    }
+
+    /// Fetch one element (synchronises; cuda.h:939-943)
+    Value coeff(size_t i) const {
+        if (m_is_imm) return m_imm;
+        if (!m_buf || i >= m_buf->size)
+            throw std::runtime_error("HIPArray::coeff(): index " + std::to_string(i) + " out of range");
+        std::conditional_t<IsMask, uint8_t, Value> v;
+        detail::hip_check(ek_hip_memcpy_to_host(&v, (const uint8_t *) m_buf->ptr + i * sizeof(Value), sizeof(Value)), "coeff");
+        return (Value) v;
+    }
+    Value operator[](size_t i) const { return coeff(i); }
+
+    /// Copy everything to the host (synchronises)
+    std::vector<std::conditional_t<IsMask, uint8_t, Value>> to_host() const {
+        std::vector<std::conditional_t<IsMask, uint8_t, Value>> out(size());
+        if (m_is_imm) out[0] = m_imm;
+        else if (!out.empty())
+            detail::hip_check(ek_hip_memcpy_to_host(out.data(), m_buf->ptr, out.size() * sizeof(Value)), "to_host");
+        return out;
+    }
+
+    /// No-ops of the eager backend that keep templated code written for the JIT backend compiling
+    HIPArray &eval() { return *this; }
+    const HIPArray &eval() const { return *this; }
+    HIPArray &managed() { return *this; }
+    const HIPArray &managed() const { return *this; }
+
+    ek_operand operand() const {
+        ek_operand o;
+        if (m_is_imm) {
+            o.ptr = nullptr;
+            o.imm = imm_bits(m_imm);
+            o.size = 1;
+        } else {
+            o.ptr = m_buf ? m_buf->ptr : nullptr;
+            o.imm = 0;
+            o.size = m_buf ? m_buf->size : 0;
+        }
+        return o;
+    }
+
+    void require_valid(const char *what) const {
+        if (!valid())
+            throw std::runtime_error(std::string("HIPArray::") + what + "(): operand is uninitialized");
+    }
+
+    /// Writers (scatter targets) must not alias other handles
+    void make_unique() {
+        materialize();
+        if (m_buf && m_buf->ref_count > 1) {
+            HIPArray r = empty_(m_buf->size);
+            detail::hip_check(ek_hip_memcpy_device(r.m_buf->ptr, m_buf->ptr, m_buf->size * sizeof(Value)), "make_unique");
+            *this = std::move(r);
+        }
+    }
+
+    static size_t broadcast_size(size_t a, size_t b) {
+        if (a == b || b == 1) return a;
+        if (a == 1) return b;
+        throw std::runtime_error("HIPArray: arrays of incompatible size (" + std::to_string(a) + " and " +
+                                 std::to_string(b) + ")");
+    }
+
+private:
+    static uint64_t imm_bits(Value v) {
+        uint64_t bits = 0;
+        if constexpr (IsMask) bits = v ? 1 : 0;
+        else memcpy(&bits, &v, sizeof(Value));
+        return bits;
+    }
+
+    void allocate(size_t size) {
+        m_buf = new detail::HIPBuffer();
+        m_buf->size = size;
+        m_is_imm = false;
+        if (ek_hip_malloc((size ? size : 1) * sizeof(Value), &m_buf->ptr) != EK_OK) {
+            delete m_buf;
+            m_buf = nullptr;
+            detail::hip_raise("HIPArray::allocate");
+        }
+    }
+
+    void release() {
+        if (m_buf && --m_buf->ref_count == 0) delete m_buf;
+        m_buf = nullptr;
+    }
+
+    void materialize() const {
+        if (!m_is_imm) return;
+        HIPArray *self = const_cast<HIPArray *>(this);
+        Value v = m_imm;
+        self->allocate(1);
+        detail::hip_check(ek_hip_fill(Type, self->m_buf->ptr, imm_bits(v), 1), "materialize");
+    }
+
+    HIPArray unary(int op, const char *what) const {
+        require_valid(what);
+        size_t n = size();
+        HIPArray r = empty_(n);
+        ek_operand oa = operand();
+        detail::hip_check(ek_hip_unary(op, Type, r.m_buf->ptr, &oa, n), what);
+        return r;
+    }
+
+    HIPArray binary(int op, const HIPArray &b, const char *what) const {
+        require_valid(what); b.require_valid(what);
+        size_t n = broadcast_size(size(), b.size());
+        HIPArray r = empty_(n);
+        ek_operand oa = operand(), ob = b.operand();
+        detail::hip_check(ek_hip_binary(op, Type, r.m_buf->ptr, &oa, &ob, n), what);
+        return r;
+    }
+
+    HIPArray ternary(int op, const HIPArray &b, const HIPArray &c, const char *what) const {
+        require_valid(what); b.require_valid(what); c.require_valid(what);
+        size_t n = broadcast_size(broadcast_size(size(), b.size()), c.size());
+        HIPArray r = empty_(n);
+        ek_operand oa = operand(), ob = b.operand(), oc = c.operand();
+        detail::hip_check(ek_hip_ternary(op, Type, r.m_buf->ptr, &oa, &ob, &oc, n), what);
+        return r;
+    }
+
+    MaskType compare(int op, const HIPArray &b, const char *what) const {
+        require_valid(what); b.require_valid(what);
+        size_t n = broadcast_size(size(), b.size());
+        MaskType r = MaskType::empty_(n);
+        ek_operand oa = operand(), ob = b.operand();
+        detail::hip_check(ek_hip_compare(op, Type, (uint8_t *) r.data(), &oa, &ob, n), what);
+        return r;
+    }
+
+    HIPArray reduce(int op, const char *what) const {
+        size_t n = size();
+        if (n == 1) return *this;
+        HIPArray r = empty_(1);
+        detail::hip_check(ek_hip_reduce(op, Type, r.m_buf->ptr, m_buf ? m_buf->ptr : nullptr, n), what);
+        return r;
+    }
+
+    uint64_t mask_reduce(int op, const char *what) const {
+        static_assert(IsMask, "all_/any_/count_ require a mask array");
+        if (m_is_imm) return m_imm ? 1 : 0;
+        uint64_t result = 0;
+        detail::hip_check(ek_hip_mask_reduce(op, m_buf ? (const uint8_t *) m_buf->ptr : nullptr, size(), &result), what);
+        return result;
+    }
+
+    detail::HIPBuffer *m_buf = nullptr;
+    Value m_imm = Value(0);
+    bool m_is_imm = false;
+};
+
+/// Runtime helpers mirroring cuda_eval / cuda_sync / cuda_whos / cuda_malloc_trim (cuda.h:109-200)
+inline void hip_eval() { }
+inline void hip_sync() { detail::hip_check(ek_hip_sync(), "hip_sync"); }
+inline void hip_malloc_trim() { detail::hip_check(ek_hip_malloc_trim(), "hip_malloc_trim"); }
+inline std::string hip_whos() {
+    char *w = ek_hip_whos();
+    std::string s(w ? w : "");
+    free(w);
+    return s;
+}
+
+template <typename T> inline void set_label(const HIPArray<T> &, const char *) { }
+
+} // namespace enoki

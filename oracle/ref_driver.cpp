@@ -478,7 +478,10 @@ int ref_tape_program(const int32_t *prog, size_t n_ops, const float *const *inpu
     std::vector<FloatD> reg(n_in + n_ops);
     std::vector<UInt32D> ireg(n_idx);
     for (size_t i = 0; i < n_in; ++i) {
-        reg[i] = FloatX::copy(inputs[i], sizes[i]);
+        /* a size-1 DynamicArray must be built from a scalar: copy(ptr, 1) leaves lanes 1..7 of packet 0
+           undefined, and broadcasting reads the whole packet (dynamic.h:303-320) */
+        if (sizes[i] == 1) reg[i] = FloatX(inputs[i][0]);
+        else               reg[i] = FloatX::copy(inputs[i], sizes[i]);
         if (leaf[i]) set_requires_gradient(reg[i]);
     }
     for (size_t i = 0; i < n_idx; ++i)

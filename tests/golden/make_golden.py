@@ -1,0 +1,82 @@
+"""Generate tests/golden/ from the UNMODIFIED reference build (oracle/_ref/libenoki_ref.so).
+
+Run in the dev container (where /root/reference exists):   python tests/golden/make_golden.py
+The fixtures are what the GPU box (which has no /root/reference) falls back to when oracle/_ref did not
+travel; they also pin oracle/enoki_oracle.c independently of the live comparison in test_oracle_vs_ref.py.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(HERE))
+import oracle_lib  # noqa: E402
+import tape_lib  # noqa: E402
+from conftest import SPECIALS_F32, f32_inputs, uniform_pm1, hash_u32  # noqa: E402
+
+R = oracle_lib.ref()
+
+# ---- tape programs --------------------------------------------------------------------------------
+for name, prog in tape_lib.suite().items():
+    v, g = tape_lib.run(tape_lib.ref_fn(), prog)
+    out = {"value": v, "n_grads": np.array(len(g))}
+    for i, gi in enumerate(g):
+        if gi is not None:
+            out[f"g{i}"] = gi
+    np.savez_compressed(os.path.join(HERE, f"tape_{name}.npz"), **out)
+
+# ---- elementwise ops on a fixed input set (incl. specials) -------------------------------------------
+n = 4096
+a = f32_inputs(n, seed=101, scale=20.0); b = f32_inputs(n, seed=102, scale=20.0)[::-1].copy(); c = f32_inputs(n, seed=103)
+ops = {"in_a": a, "in_b": b, "in_c": c}
+for op in ["neg", "abs", "sqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log", "sign"]:
+    ops[f"unary_{op}"] = R.unary(op, a)
+s, co = R.sincos(a); ops["sincos_s"], ops["sincos_c"] = s, co
+for op in ["add", "sub", "mul", "div", "min", "max", "safe_mul"]:
+    ops[f"binary_{op}"] = R.binary(op, a, b)
+for op in ["fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd"]:
+    ops[f"ternary_{op}"] = R.ternary(op, a, b, c)
+for op in ["eq", "neq", "lt", "le", "gt", "ge"]:
+    ops[f"compare_{op}"] = R.compare(op, a, b)
+np.savez_compressed(os.path.join(HERE, "elementwise_f32.npz"), **ops)
+
+# ---- integer ops -----------------------------------------------------------------------------------
+rng = np.random.default_rng(7)
+iops = {}
+for dt in (np.int32, np.uint32):
+    info = np.iinfo(dt)
+    x = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True); y = rng.integers(info.min, info.max, n, dtype=dt, endpoint=True)
+    sh = rng.integers(0, 40, n).astype(dt)
+    t = dt.__name__
+    iops[f"{t}_x"], iops[f"{t}_y"], iops[f"{t}_sh"] = x, y, sh
+    for op in ["neg", "not", "abs", "popcnt", "lzcnt", "tzcnt"]:
+        iops[f"{t}_unary_{op}"] = R.unary(op, x)
+    for op in ["add", "sub", "mul", "min", "max", "mulhi", "and", "or", "xor"]:
+        iops[f"{t}_binary_{op}"] = R.binary(op, x, y)
+    for op in ["sl", "sr"]:
+        iops[f"{t}_binary_{op}"] = R.binary(op, x, sh)
+np.savez_compressed(os.path.join(HERE, "integer.npz"), **iops)
+
+# ---- gather / scatter / reductions / configs ---------------------------------------------------------
+K, n2 = 257, 5003
+src = rng.standard_normal(K).astype(np.float32); idx = rng.integers(0, K, n2).astype(np.uint32)
+m = (rng.integers(0, 4, n2) != 0).astype(np.uint8); val = rng.standard_normal(n2).astype(np.float32)
+mem = {"src": src, "idx": idx, "mask": m, "val": val,
+       "gather": R.gather(src, idx, m), "scatter_add": R.scatter(src, val, idx, m, add=True)}
+for nn in (0, 1, 7, 8, 9, 1000):
+    for op in ("hsum", "hprod", "hmin", "hmax"):
+        mem[f"{op}_{nn}"] = np.array([R.reduce(op, (1 + 0.01 * val[:nn]).astype(np.float32) if op == "hprod" else val[:nn])], np.float32)
+np.savez_compressed(os.path.join(HERE, "memory_reduce.npz"), **mem)
+
+cfg = {}
+for nn in (1000, 65536):
+    A = uniform_pm1(nn, 1); X = uniform_pm1(nn, 2); B = uniform_pm1(nn, 3)
+    Kc = 1024
+    TA = uniform_pm1(Kc, 6); TB = uniform_pm1(Kc, 7); I = (hash_u32(np.arange(nn, dtype=np.uint64), 4) % np.uint32(Kc)).astype(np.uint32)
+    cfg[f"cfg1_{nn}"] = np.array([R.cfg1(A, X, B)[0]], np.float32)
+    cfg[f"cfg2_{nn}"] = np.array([R.cfg2(A, X, B)[0]], np.float32)
+    y, ga, gb, _ = R.cfg3a(A, X, B); cfg[f"cfg3a_{nn}_y"] = np.array([y], np.float32); cfg[f"cfg3a_{nn}_ga"] = ga; cfg[f"cfg3a_{nn}_gb"] = gb
+    y, gA, gB, _ = R.cfg3b(TA, TB, X, I); cfg[f"cfg3b_{nn}_y"] = np.array([y], np.float32); cfg[f"cfg3b_{nn}_gA"] = gA; cfg[f"cfg3b_{nn}_gB"] = gB
+np.savez_compressed(os.path.join(HERE, "configs.npz"), **cfg)
+print("golden fixtures written to", HERE)

@@ -1,0 +1,166 @@
+"""Register-machine programs over DiffArray values and runners for the three tape implementations
+(reference build, product tape over the CPU oracle array, product tape over HIPArray).  See
+tests/cpp/tape_program.h for the encoding."""
+import ctypes
+import os
+import struct
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+OPS = ["add", "sub", "mul", "div", "fmadd", "neg", "abs", "sqrt", "rcp", "rsqrt", "sin", "cos", "exp", "log", "hsum",
+       "hprod", "min", "max", "gather", "scatter_add", "scatter", "select_gt0", "mulc", "addc", "tanh", "tan",
+       "atan2", "fmsub", "fnmadd", "fnmsub", "sinh", "cosh", "asin", "acos", "atan", "psum", "reverse"]
+OPCODE = {n: i for i, n in enumerate(OPS)}
+
+
+def _f2i(x):
+    return struct.unpack("<i", struct.pack("<f", float(x)))[0]
+
+
+class Program:
+    """inputs: list of (np.float32 array, is_leaf); index_inputs: list of np.uint32 arrays;
+    ops: list of tuples (name, a, b, c) -- register numbers; for mulc/addc b is a float constant;
+    for gather b is an index-input number; for scatter(_add) c is an index-input number."""
+
+    def __init__(self, inputs, ops, index_inputs=(), mode="backward", fwd_leaf=0, simplify=False):
+        self.inputs = [(np.ascontiguousarray(a, np.float32), bool(l)) for a, l in inputs]
+        self.index_inputs = [np.ascontiguousarray(i, np.uint32) for i in index_inputs]
+        self.ops, self.mode, self.fwd_leaf, self.simplify = list(ops), mode, fwd_leaf, simplify
+
+    def encode(self):
+        prog = []
+        for op in self.ops:
+            name, args = op[0], list(op[1:]) + [0] * (4 - len(op))
+            if name in ("mulc", "addc"):
+                args[1] = _f2i(args[1])
+            prog += [OPCODE[name]] + [int(a) for a in args[:3]]
+        return np.array(prog, np.int32)
+
+    def out_size_bound(self):
+        return max([a.size for a, _ in self.inputs] + [i.size for i in self.index_inputs] + [1])
+
+
+def run(fn, program):
+    """fn: the C entry point (ref_tape_program / host_tape_program / hip_tape_program).
+    Returns (value array, [grad per input or None])"""
+    p = program
+    prog = p.encode()
+    n_in, n_idx = len(p.inputs), len(p.index_inputs)
+    in_ptrs = (ctypes.c_void_p * max(n_in, 1))(*[a.ctypes.data for a, _ in p.inputs])
+    sizes = np.array([a.size for a, _ in p.inputs], np.uint64)
+    leaf = np.array([1 if l else 0 for _, l in p.inputs], np.uint8)
+    idx_ptrs = (ctypes.c_void_p * max(n_idx, 1))(*[i.ctypes.data for i in p.index_inputs])
+    idx_sizes = np.array([i.size for i in p.index_inputs] + [0], np.uint64)
+    out = np.zeros(p.out_size_bound(), np.float32)
+    out_size = ctypes.c_uint64()
+    if p.mode == "backward":
+        grads = [np.zeros(a.size, np.float32) for a, _ in p.inputs]
+    else:
+        grads = [np.zeros(p.out_size_bound(), np.float32)]
+    g_ptrs = (ctypes.c_void_p * max(len(grads), 1))(*[g.ctypes.data for g in grads])
+    rc = fn(prog.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(p.ops)), in_ptrs,
+            sizes.ctypes.data_as(ctypes.c_void_p), leaf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_in),
+            idx_ptrs, idx_sizes.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n_idx),
+            0 if p.mode == "backward" else 1, int(p.fwd_leaf), int(p.simplify),
+            out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(out_size), g_ptrs)
+    if rc != 0:
+        raise RuntimeError(f"tape program failed with rc={rc}")
+    n = out_size.value
+    if p.mode == "backward":
+        return out[:n].copy(), [g if l else None for g, (_, l) in zip(grads, p.inputs)]
+    return out[:n].copy(), [grads[0][:n].copy()]
+
+
+_libs = {}
+
+
+def ref_fn():
+    if "ref" not in _libs:
+        _libs["ref"] = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libenoki_ref.so"))
+    return _libs["ref"].ref_tape_program
+
+
+def host_lib():
+    if "host" not in _libs:
+        _libs["host"] = ctypes.CDLL(os.path.join(HERE, "cpp", "libtape_host.so"))
+        _libs["host"].host_tape_live_nodes.restype = ctypes.c_size_t
+    return _libs["host"]
+
+
+def hip_lib():
+    if "hip" not in _libs:
+        _libs["hip"] = ctypes.CDLL(os.path.join(HERE, "cpp", "libtape_hip.so"))
+        _libs["hip"].hip_tape_live_nodes.restype = ctypes.c_size_t
+    return _libs["hip"]
+
+
+# ---------------------------------------------------------------------------------------------------
+#  Program suite: every differentiable primitive of the first wave, broadcasting, duplicates,
+#  gather / scatter / scatter_add specials, forward mode, graph simplification.
+# ---------------------------------------------------------------------------------------------------
+def suite(n=1000, k=37, seed=0):
+    rng = np.random.default_rng(seed)
+    a = rng.uniform(-1, 1, n).astype(np.float32); x = rng.uniform(-1, 1, n).astype(np.float32)
+    b = rng.uniform(-1, 1, n).astype(np.float32)
+    pos = rng.uniform(0.5, 2, n).astype(np.float32)
+    A = rng.uniform(-1, 1, k).astype(np.float32); B = rng.uniform(-1, 1, k).astype(np.float32)
+    idx = rng.integers(0, k, n).astype(np.uint32)
+    perm = rng.permutation(n).astype(np.uint32)
+    s = np.array([0.75], np.float32)
+    P = {}
+    # BASELINE config 3a / 3b
+    P["cfg3a"] = Program([(a, 1), (x, 0), (b, 1)], [("fmadd", 0, 1, 2), ("sin", 3), ("hsum", 4)])
+    P["cfg3b"] = Program([(A, 1), (B, 1), (x, 0)], [("gather", 0, 0), ("gather", 1, 0), ("fmadd", 3, 2, 4), ("sin", 5),
+                                                     ("hsum", 6)], index_inputs=[idx])
+    P["cfg2_grad"] = Program([(a, 1), (x, 1), (b, 1)], [("fmadd", 0, 1, 2), ("exp", 3), ("sin", 4), ("hsum", 5)])
+    # arithmetic
+    P["arith"] = Program([(a, 1), (x, 1), (pos, 1)], [("mul", 0, 1), ("add", 3, 2), ("sub", 4, 0), ("neg", 5), ("abs", 6),
+                                                      ("mulc", 7, 1.5), ("addc", 8, -0.25), ("hsum", 9)])
+    P["square_dup_edge"] = Program([(a, 1)], [("mul", 0, 0), ("hsum", 1)])          # x*x: merged edge weights
+    P["sqrt_log"] = Program([(pos, 1)], [("sqrt", 0), ("log", 1), ("hsum", 2)])
+    P["cos_exp"] = Program([(a, 1)], [("cos", 0), ("exp", 1), ("hsum", 2)])
+    P["minmax_select"] = Program([(a, 1), (x, 1)], [("min", 0, 1), ("max", 0, 1), ("select_gt0", 0, 2, 3), ("hsum", 4)])
+    P["fm_family"] = Program([(a, 1), (x, 1), (b, 1)], [("fmsub", 0, 1, 2), ("fnmadd", 0, 1, 3), ("fnmsub", 4, 1, 2),
+                                                        ("hsum", 5)])
+    P["hprod"] = Program([((1 + 0.001 * a[:64]).astype(np.float32), 1)], [("hprod", 0)])
+    # broadcasting: scalar leaf combined with a vector (gradient reduces with hsum)
+    P["scalar_leaf"] = Program([(s, 1), (a, 1)], [("mul", 0, 1), ("sin", 2), ("hsum", 3)])
+    P["scalar_chain"] = Program([(s, 1), (a, 0)], [("fmadd", 1, 0, 0), ("mul", 2, 2), ("hsum", 3)])
+    P["vector_output"] = Program([(a, 1), (x, 1)], [("mul", 0, 1), ("sin", 2)])      # seed = ones over a vector
+    # specials
+    P["gather_only"] = Program([(A, 1)], [("gather", 0, 0), ("mulc", 1, 2.0), ("hsum", 2)], index_inputs=[idx])
+    P["permute_gather"] = Program([(a, 1)], [("gather", 0, 0), ("mul", 1, 1), ("hsum", 2)], index_inputs=[perm])
+    P["scatter_add"] = Program([(np.zeros(k, np.float32), 0), (a, 1)],
+                               [("scatter_add", 0, 1, 0), ("mul", 2, 2), ("hsum", 3)], index_inputs=[idx])
+    P["scatter_add_leaf_target"] = Program([(B, 1), (a, 1)], [("scatter_add", 0, 1, 0), ("sin", 2), ("hsum", 3)],
+                                           index_inputs=[idx])
+    # (a scatter into a LEAF target segfaults inside the reference build itself -- scatter_combine weight path,
+    #  autodiff.cpp:588-592 -- so the plain scatter is exercised with a non-differentiable target)
+    P["scatter_perm"] = Program([(np.zeros(n, np.float32), 0), (a, 1)], [("scatter", 0, 1, 0), ("mul", 2, 2), ("hsum", 3)],
+                                index_inputs=[perm])
+    P["reverse_psum"] = Program([(np.round(a * 8).astype(np.float32), 1), (x, 0)],
+                                [("psum", 0), ("reverse", 2), ("mul", 3, 1), ("hsum", 4)])
+    # forward mode
+    P["fwd_cfg3a"] = Program([(a, 1), (x, 0), (b, 1)], [("fmadd", 0, 1, 2), ("sin", 3), ("hsum", 4)], mode="forward",
+                             fwd_leaf=0)
+    P["fwd_vector"] = Program([(a, 1), (x, 1)], [("mul", 0, 1), ("exp", 2), ("add", 3, 0)], mode="forward", fwd_leaf=0)
+    P["fwd_gather"] = Program([(A, 1)], [("gather", 0, 0), ("sin", 1)], index_inputs=[idx], mode="forward", fwd_leaf=0)
+    # graph simplification (explicit, like tests/autodiff.cpp:39-47)
+    P["simplify_chain"] = Program([(a, 1), (x, 1)], [("mul", 0, 1), ("sin", 2), ("mulc", 3, 3.0), ("exp", 4), ("hsum", 5)],
+                                  simplify=True)
+    # class C inside weights: rcp / div / rsqrt use IEEE division on the GPU and in the oracle, rcpps+NR in the
+    # AVX2 reference -> compared with a tolerance only
+    P["div_rcp_rsqrt"] = Program([(a, 1), (pos, 1)], [("div", 0, 1), ("rcp", 1), ("rsqrt", 1), ("add", 2, 3),
+                                                      ("add", 5, 4), ("hsum", 6)])
+    return P
+
+
+TOLERANT = {"div_rcp_rsqrt"}          # not bit-comparable against the AVX2 reference build (class C)
+ORDER_DEPENDENT_ON_GPU = {            # contain hsum / hprod / fp scatter_add: GPU summation order differs (class D)
+    "cfg3a", "cfg3b", "cfg2_grad", "arith", "square_dup_edge", "sqrt_log", "cos_exp", "minmax_select", "fm_family",
+    "hprod", "scalar_leaf", "scalar_chain", "gather_only", "permute_gather", "scatter_add", "scatter_add_leaf_target",
+    "scatter_perm", "reverse_psum", "fwd_cfg3a", "simplify_chain", "div_rcp_rsqrt",
+}

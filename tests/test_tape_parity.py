@@ -1,0 +1,106 @@
+"""Tape / DiffArray parity.
+
+CPU (not gpu):  product Tape<T> + DiffArray<T> instantiated over the oracle array type (tests/cpp/tape_host.cpp)
+                vs the UNMODIFIED reference build (oracle/_ref) -- bit-for-bit on every program except the ones whose
+                edge weights go through rcp/rsqrt (class C: the AVX2 reference uses rcpps + Newton).  This pins the
+                host logic of the tape: graph bookkeeping, sweep order, refcounting, specials, simplification.
+GPU  (gpu):     product Tape over HIPArray<float> (tests/cpp/tape_hip.cpp -> libenoki-hip-autodiff.so -> C ABI)
+                vs the reference build when it travelled with the tree, else vs the committed fixtures in
+                tests/golden/tape_*.npz (generated from the reference build by tests/golden/make_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+
+import tape_lib as tl
+from conftest import bits_equal
+
+HAVE_REF = os.path.exists(os.path.join(tl.ROOT, "oracle", "_ref", "libenoki_ref.so"))
+GOLDEN = os.path.join(tl.HERE, "golden")
+NAMES = sorted(tl.suite().keys())
+
+
+def reference_result(name, prog):
+    """reference outputs for a suite program: live from oracle/_ref when present, else the golden fixture"""
+    if HAVE_REF:
+        return tl.run(tl.ref_fn(), prog)
+    z = np.load(os.path.join(GOLDEN, f"tape_{name}.npz"))
+    grads = [z[f"g{i}"] if f"g{i}" in z else None for i in range(int(z["n_grads"]))]
+    return z["value"], grads
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref was not built (needs /root/reference)")
+@pytest.mark.parametrize("name", NAMES)
+def test_host_tape_matches_reference_build(name):
+    prog = tl.suite()[name]
+    rv, rg = tl.run(tl.ref_fn(), prog)
+    hv, hg = tl.run(tl.host_lib().host_tape_program, prog)
+    assert tl.host_lib().host_tape_live_nodes() == 0, "tape leaked nodes"
+    if name in tl.TOLERANT or name == "sqrt_log":
+        assert bits_equal(rv, hv)
+        for a, b in zip(rg, hg):
+            if a is not None:
+                assert np.allclose(a, b, rtol=2e-6, atol=1e-6)
+    else:
+        assert bits_equal(rv, hv), name
+        for a, b in zip(rg, hg):
+            assert (a is None and b is None) or bits_equal(a, b), name
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_golden_fixtures_match_host_tape(name):
+    """the committed fixtures (made from the reference build) agree with the product tape on the oracle arrays"""
+    prog = tl.suite()[name]
+    z = np.load(os.path.join(GOLDEN, f"tape_{name}.npz"))
+    hv, hg = tl.run(tl.host_lib().host_tape_program, prog)
+    exact = not (name in tl.TOLERANT or name == "sqrt_log")
+    assert bits_equal(z["value"], hv)
+    for i, g in enumerate(hg):
+        if g is None:
+            continue
+        assert bits_equal(z[f"g{i}"], g) if exact else np.allclose(z[f"g{i}"], g, rtol=2e-6, atol=1e-6)
+
+
+def _order_bound(prog, n_terms_hint=None):
+    n = max(a.size for a, _ in prog.inputs)
+    return n * 2.0 ** -23
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", NAMES)
+def test_hip_tape_matches_reference(name):
+    prog = tl.suite()[name]
+    rv, rg = reference_result(name, prog)
+    gv, gg = tl.run(tl.hip_lib().hip_tape_program, prog)
+    assert tl.hip_lib().hip_tape_live_nodes() == 0, "tape leaked nodes"
+    assert gv.shape == rv.shape
+    if name not in tl.ORDER_DEPENDENT_ON_GPU:
+        # purely vertical programs: bit-exact against the reference
+        assert bits_equal(rv, gv), name
+        for a, b in zip(rg, gg):
+            assert (a is None and b is None) or bits_equal(a, b), name
+        return
+    # programs containing horizontal reductions / fp scatter_add: the primal reduction and every gradient that
+    # passed through a reduction depend on summation order (class D).  Bound: n * 2^-23 relative to the sum of
+    # magnitudes, evaluated per output.
+    scale = max(float(np.abs(rv).max()), 1.0)
+    n = max(a.size for a, _ in prog.inputs)
+    assert np.all(np.abs(gv - rv) <= n * 2.0 ** -23 * max(scale, float(np.sum(np.abs(prog.inputs[0][0]))))), name
+    for a, b in zip(rg, gg):
+        if a is None:
+            continue
+        tol = n * 2.0 ** -22 * max(float(np.abs(a).max()), 1.0)
+        assert np.all(np.abs(a - b) <= tol), (name, float(np.abs(a - b).max()), tol)
+
+
+@pytest.mark.gpu
+def test_hip_cfg3a_gradients_bit_exact_elementwise():
+    """cfg3a: the gradients are purely elementwise given the seed -> bit-exact even though y = hsum(..) is not"""
+    prog = tl.suite(n=100003)["cfg3a"]
+    rv, rg = reference_result("cfg3a_big", prog) if HAVE_REF else (None, None)
+    if not HAVE_REF:
+        pytest.skip("needs the reference build for n = 100003")
+    gv, gg = tl.run(tl.hip_lib().hip_tape_program, prog)
+    assert bits_equal(rg[0], gg[0]) and bits_equal(rg[2], gg[2])
+    assert abs(float(gv[0]) - float(rv[0])) <= 100003 * 2.0 ** -23 * 100003
