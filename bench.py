@@ -1,0 +1,215 @@
+#!/usr/bin/env python
+"""bench.py -- the north-star measurement: Gelem/s and %HBM-roofline of a 64 Mi-element DiffArray
+forward + backward() on MI355X (BASELINE.json: metric / configs[2]).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg3b|cfg3a|cfg2] [--n 67108864]
+
+One "step" = one pass of the hot path over one batch of synthetic input that is already resident in HBM:
+
+  cfg3b (default, BASELINE configs[2] "with scatter_add grads"):
+        A, B leaves of size K = 1 Mi (replicated); idx = hash mod K; x plain, size N
+        a = gather(A, idx); b = gather(B, idx); y = hsum(sin(fmadd(a, x, b))); backward(y)
+        -> grad_A, grad_B (K) via scatter_add
+  cfg3a a, b leaves of size N: y = hsum(sin(fmadd(a, x, b))); backward(y)
+  cfg2  plain HIPArray: y = hsum(sin(exp(fmadd(a, x, b))))
+
+Multi-GPU (one process per GPU, launched by torch.distributed.run): the N-element arrays are index-range
+sharded (STRONG scaling: N total is fixed), the K-element tables are replicated; per step ONE RCCL all-reduce
+finishes y and the table gradients (enoki_amd/dist.py).
+
+The JSON line carries, besides the contract fields, `roofline` for the dominant kernel (live per-launch timing
+with HIP events on the library stream, ek_hip_profile_*) and `cpu_baseline` (the reference build oracle/_ref, or
+the C restatement when it is absent, timed on ONE host core -- the reference has no threading).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_TBS = 8.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+K_TABLE = 1 << 20
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2"])
+    ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-steps", type=int, default=5)
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import enoki_amd.hip as ekc
+    import enoki_amd.hip_autodiff as ek
+    from enoki_amd import dist as ekd, synth
+
+    rank, local_rank, world = ekd.init()
+    if world != args.gpus and rank == 0:
+        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    ek.hip_init(local_rank)
+    ekd.adopt_torch_stream(ek)          # kernels + RCCL on one stream order
+    dev = torch.device("cuda", local_rank)
+
+    N = args.n
+    begin, end = ekd.shard_range(N, rank, world)
+    n = end - begin
+
+    # ---- synthetic inputs, generated on the device (seeds as in SURVEY.md 8d) ----------------------
+    x = synth.uniform_pm1(begin, n, 2)
+    if args.workload == "cfg3b":
+        A0 = synth.uniform_pm1(0, K_TABLE, 6); B0 = synth.uniform_pm1(0, K_TABLE, 7)
+        idx = ek.UInt32(synth.index_mod(begin, n, 4, K_TABLE))
+        xd = ek.Float32(x)
+        packer = ekd.Packer([1, K_TABLE, K_TABLE], dev) if world > 1 else None
+    else:
+        a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
+        xd = ek.Float32(x)
+        packer = ekd.Packer([1], dev) if world > 1 else None
+    ek.hip_sync()
+
+    out = {}
+
+    def step():
+        if args.workload == "cfg3b":
+            A = ek.Float32(A0); B = ek.Float32(B0)
+            ek.set_requires_gradient(A); ek.set_requires_gradient(B)
+            a = ek.gather(A, idx); b = ek.gather(B, idx)
+            y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
+            ek.backward(y)
+            gA = ek.gradient(A); gB = ek.gradient(B)
+            if packer:
+                packer.pack([ekd.as_tensor(ek.detach(y)), ekd.as_tensor(gA), ekd.as_tensor(gB)])
+                packer.all_reduce()
+            out["y"], out["gA"], out["gB"] = y, gA, gB
+        elif args.workload == "cfg3a":
+            a = ek.Float32(a0); b = ek.Float32(b0)
+            ek.set_requires_gradient(a); ek.set_requires_gradient(b)
+            y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
+            ek.backward(y)
+            if packer:
+                packer.pack([ekd.as_tensor(ek.detach(y))])
+                packer.all_reduce()
+            out["y"], out["ga"], out["gb"] = y, ek.gradient(a), ek.gradient(b)
+        else:
+            y = ekc.hsum(ekc.sin(ekc.exp(ekc.fmadd(a0, x, b0))))
+            if packer:
+                packer.pack([ekd.as_tensor(y)])
+                packer.all_reduce()
+            out["y"] = y
+
+    for _ in range(args.warmup):
+        step()
+    ekd.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize(); ekd.barrier()
+    elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
+    ms_per_step = elapsed / args.steps * 1e3
+    gelem_s = N / (ms_per_step * 1e-3) / 1e9
+
+    # ---- per-kernel timing of the same step (HIP events on the library stream) ----------------------
+    ek.hip_profile_begin()
+    for _ in range(args.profile_steps):
+        step()
+    prof = json.loads(ek.hip_profile_end())
+    torch.cuda.synchronize()
+    kernels = []
+    for k in prof:
+        if k["launches"] == 0 or k["elements"] // k["launches"] < 1024:
+            continue        # scalar bookkeeping launches (size-1 arrays) are not bandwidth kernels
+        avg_ms = k["total_ms"] / k["launches"]
+        bpl = k["bytes"] / k["launches"]
+        kernels.append({"kernel": k["kernel"], "launches_per_step": k["launches"] / args.profile_steps,
+                        "avg_ms": round(avg_ms, 5), "bytes_per_launch": int(bpl),
+                        "tb_s": round(bpl / avg_ms / 1e9, 4) if avg_ms > 0 else None,
+                        "share_ms_per_step": round(k["total_ms"] / args.profile_steps, 5)})
+    kernels.sort(key=lambda k: -k["share_ms_per_step"])
+    dom = kernels[0] if kernels else None
+    total_bytes_step = sum(k["bytes"] for k in prof) / args.profile_steps
+    roofline = None
+    if dom:
+        achieved = dom["bytes_per_launch"] / dom["avg_ms"] / 1e6      # GB/s
+        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
+                    "traffic": None,
+                    "whole_step": {"algorithmic_bytes": int(total_bytes_step),
+                                   "bytes_per_elt": round(total_bytes_step / n, 2),
+                                   "achieved_GBs": round(total_bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
+                                   "frac": round(total_bytes_step / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000), 4)},
+                    "kernels": kernels}
+
+    # ---- CPU baseline: the reference's own code path on ONE host core (rank 0, N = 1 GPU only) -------
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, N)
+
+    if rank == 0:
+        y_val = float(ek.detach(out["y"]).numpy()[0]) if args.workload != "cfg2" else float(out["y"].numpy()[0])
+        if packer:
+            y_val = float(packer.slot(0).item())
+        line = {
+            "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
+            "value": round(gelem_s, 3), "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: " + {
+                "cfg3b": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)), a=gather(A,idx), b=gather(B,idx), K=1Mi; backward() with scatter_add grads",
+                "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves",
+                "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))"}[args.workload],
+                "elements_total": N, "elements_per_gpu": n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
+                "sharding": f"index-range x{world}", "collectives_per_step": 1 if world > 1 else 0},
+            "result_y": y_val,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+
+
+def cpu_baseline(workload, N):
+    """Time the reference's CPU path (oracle/_ref = the unmodified reference headers; falls back to the C
+    restatement) on a bounded sample: the SAME workload at N elements, repeated until ~10 s of CPU work."""
+    import oracle_lib as ol
+    from conftest import hash_u32, uniform_pm1
+    try:
+        chk, kind = ol.ref(), "reference"
+    except Exception:
+        chk, kind = ol.port(), "port"
+    n = min(N, 1 << 26)
+    x = uniform_pm1(n, 2)
+    runs, t_total, t_best = 0, 0.0, None
+    if workload == "cfg3b":
+        A, B = uniform_pm1(K_TABLE, 6), uniform_pm1(K_TABLE, 7)
+        idx = (hash_u32(np.arange(n, dtype=np.uint64), 4) % np.uint32(K_TABLE)).astype(np.uint32)
+        fn = lambda: chk.cfg3b(A, B, x, idx)[-1]
+    elif workload == "cfg3a":
+        a, b = uniform_pm1(n, 1), uniform_pm1(n, 3)
+        fn = lambda: chk.cfg3a(a, x, b)[-1]
+    else:
+        a, b = uniform_pm1(n, 1), uniform_pm1(n, 3)
+        fn = lambda: chk.cfg2(a, x, b)[-1]
+    while runs < 2 or (t_total < 10.0 and runs < 8):
+        t = fn()
+        runs += 1; t_total += t
+        t_best = t if t_best is None else min(t_best, t)
+    return {"value": round(n / t_best / 1e9, 5), "unit": "Gelem/s", "cores": 1, "kind": kind,
+            "sample": f"{workload} at n={n} elements, best of {runs} runs ({t_total:.1f} s of CPU work), "
+                      f"timed region = forward + backward() inside the checker, single thread",
+            "nproc": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -27,6 +27,7 @@ int hip_fail(hipError_t err, const char *what, const char *file, int line);
 struct Tuning {
     int blocks_per_cu = 8;   // grid cap for streaming kernels = blocks_per_cu * #CU
     int reduce_blocks_per_cu = 4;
+    int scatter_add_binned = 1;   // 1: LDS-binned scatter_add for large inputs, 0: global atomics only
 };
 
 struct Context {
@@ -40,23 +41,28 @@ struct Context {
     Tuning tuning;
     void *reduce_scratch = nullptr;   // partials of two-stage reductions
     size_t reduce_scratch_bytes = 0;
+    bool profiling = false;           // ek_hip_profile_begin(): one event after every launch
 };
 
 Context &ctx();
 int ensure_init();
 int reduce_scratch(size_t bytes, void **out);
 
-inline void note_launch(const char *name, size_t n) {
+void profile_mark(const char *name, size_t n, size_t bytes);
+
+/// `bytes`: ALGORITHMIC bytes of this launch (distinct input bytes + output bytes), see DESIGN.md
+inline void note_launch(const char *name, size_t n, size_t bytes) {
     Context &c = ctx();
     c.launches++;
     if (c.log_level >= 3)
-        fprintf(stderr, "enoki-hip: launch %s (n=%zu)\n", name, n);
+        fprintf(stderr, "enoki-hip: launch %s (n=%zu, %zu bytes)\n", name, n, bytes);
+    if (c.profiling) profile_mark(name, n, bytes);
 }
 
 // post-launch check: kernel launch failures surface through hipGetLastError
-#define EK_LAUNCH_CHECK(name, n)                                                               \
+#define EK_LAUNCH_CHECK(name, n, bytes)                                                        \
     do {                                                                                       \
-        ::ek::note_launch(name, n);                                                            \
+        ::ek::note_launch(name, n, bytes);                                                     \
         hipError_t ek_err_ = hipGetLastError();                                                \
         if (ek_err_ != hipSuccess) return ::ek::hip_fail(ek_err_, name, __FILE__, __LINE__);   \
     } while (0)
@@ -108,6 +114,8 @@ template <typename T> inline int make_arg(const ek_operand *o, size_t n, Arg<T> 
 
 inline bool aligned16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 template <typename T> inline bool arg_aligned(const Arg<T> &a) { return !a.vec || aligned16(a.ptr); }
+/// bytes this operand contributes per launch of n elements (broadcast operands are free)
+template <typename T> inline size_t arg_bytes(const Arg<T> &a, size_t n) { return a.vec ? n * sizeof(T) : 0; }
 
 // Grid for a streaming kernel that handles `work_items` per-thread items with 256-thread blocks
 inline unsigned stream_grid(size_t work_items, int blocks_per_cu) {
@@ -118,5 +126,11 @@ inline unsigned stream_grid(size_t work_items, int blocks_per_cu) {
     if (blocks == 0) blocks = 1;
     return (unsigned) blocks;
 }
+
+// LDS-binned scatter_add (scatter_binned.hip)
+bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array);
+template <typename T, typename I>
+int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
+                       size_t n);
 
 } // namespace ek

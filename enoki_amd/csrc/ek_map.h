@@ -227,7 +227,7 @@ int launch_map1(const char *name, TO *out, size_t n, const Arg<TA> &a) {
     constexpr int N = 16 / max_size<TO, TA>::value;
     int vec_ok = aligned16(out) && arg_aligned(a);
     EK_MAP_LAUNCH(k_map1, F EK_COMMA TO EK_COMMA TA, N, n, out, n, vec_ok, a);
-    EK_LAUNCH_CHECK(name, n);
+    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n));
     return EK_OK;
 }
 
@@ -236,7 +236,7 @@ int launch_map1x2(const char *name, TO *out0, TO *out1, size_t n, const Arg<TA> 
     constexpr int N = 16 / max_size<TO, TA>::value;
     int vec_ok = aligned16(out0) && aligned16(out1) && arg_aligned(a);
     EK_MAP_LAUNCH(k_map1x2, F EK_COMMA TO EK_COMMA TA, N, n, out0, out1, n, vec_ok, a);
-    EK_LAUNCH_CHECK(name, n);
+    EK_LAUNCH_CHECK(name, n, 2 * n * sizeof(TO) + arg_bytes(a, n));
     return EK_OK;
 }
 
@@ -245,7 +245,7 @@ int launch_map2(const char *name, TO *out, size_t n, const Arg<TA> &a, const Arg
     constexpr int N = 16 / max_size<TO, TA, TB>::value;
     int vec_ok = aligned16(out) && arg_aligned(a) && arg_aligned(b);
     EK_MAP_LAUNCH(k_map2, F EK_COMMA TO EK_COMMA TA EK_COMMA TB, N, n, out, n, vec_ok, a, b);
-    EK_LAUNCH_CHECK(name, n);
+    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + arg_bytes(b, n));
     return EK_OK;
 }
 
@@ -254,7 +254,7 @@ int launch_map3(const char *name, TO *out, size_t n, const Arg<TA> &a, const Arg
     constexpr int N = 16 / max_size<TO, TA, TB, TC>::value;
     int vec_ok = aligned16(out) && arg_aligned(a) && arg_aligned(b) && arg_aligned(c);
     EK_MAP_LAUNCH(k_map3, F EK_COMMA TO EK_COMMA TA EK_COMMA TB EK_COMMA TC, N, n, out, n, vec_ok, a, b, c);
-    EK_LAUNCH_CHECK(name, n);
+    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + arg_bytes(b, n) + arg_bytes(c, n));
     return EK_OK;
 }
 

@@ -14,6 +14,14 @@
 
 namespace ek {
 
+// kernel names reported by ek_hip_profile_end() / ENOKI_HIP_LOG=3
+static const char *const unary_names[EK_UNARY_COUNT] = {
+    "neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
+    "popcnt", "lzcnt", "tzcnt", "sign", "copy" };
+static const char *const binary_names[EK_BINARY_COUNT] = {
+    "add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul" };
+static const char *const ternary_names[EK_TERNARY_COUNT] = { "fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd" };
+
 template <typename T> inline constexpr bool is_fp = std::is_floating_point_v<T>;
 template <typename T> inline constexpr bool is_int = std::is_integral_v<T> && !std::is_same_v<T, uint8_t>;
 template <typename T> inline constexpr bool is_mask = std::is_same_v<T, uint8_t>;
@@ -108,7 +116,7 @@ template <int Op, typename T> int unary_launch(void *out, const ek_operand *a, s
     if constexpr (unary_supported<Op, T>()) {
         Arg<T> aa;
         if (int rc = make_arg<T>(a, n, aa, "ek_hip_unary")) return rc;
-        return launch_map1<UnaryOp<Op, T>>("unary", (T *) out, n, aa);
+        return launch_map1<UnaryOp<Op, T>>(unary_names[Op], (T *) out, n, aa);
     } else {
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_unary(): op %d is not defined for type %d", Op, (int) sizeof(T));
     }
@@ -187,7 +195,7 @@ template <int Op, typename T> int binary_launch(void *out, const ek_operand *a, 
         Arg<T> aa, bb;
         if (int rc = make_arg<T>(a, n, aa, "ek_hip_binary")) return rc;
         if (int rc = make_arg<T>(b, n, bb, "ek_hip_binary")) return rc;
-        return launch_map2<BinaryOp<Op, T>>("binary", (T *) out, n, aa, bb);
+        return launch_map2<BinaryOp<Op, T>>(binary_names[Op], (T *) out, n, aa, bb);
     } else {
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_binary(): op %d is not defined for this type", Op);
     }
@@ -239,7 +247,7 @@ int ternary_launch(void *out, const ek_operand *a, const ek_operand *b, const ek
         if (int rc = make_arg<T>(a, n, aa, "ek_hip_ternary")) return rc;
         if (int rc = make_arg<T>(b, n, bb, "ek_hip_ternary")) return rc;
         if (int rc = make_arg<T>(c, n, cc, "ek_hip_ternary")) return rc;
-        return launch_map3<TernaryOp<Op, T>>("ternary", (T *) out, n, aa, bb, cc);
+        return launch_map3<TernaryOp<Op, T>>(ternary_names[Op], (T *) out, n, aa, bb, cc);
     }
 }
 

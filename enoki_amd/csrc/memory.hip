@@ -105,7 +105,9 @@ int gather_launch(void *out, const void *base, const ek_operand *index, const ek
     unsigned grid = (unsigned) ((n + (size_t) 256 * N - 1) / ((size_t) 256 * N));
     hipLaunchKernelGGL((k_gather<T, I, N>), dim3(grid), dim3(256), 0, c.stream, (T *) out, (const T *) base, ii, mm,
                        n, vec_ok);
-    EK_LAUNCH_CHECK("gather", n);
+    // algorithmic bytes: index + mask + output + one table element per lane (SURVEY.md 8d counts the
+    // table read as sizeof(T) per element even when the table is cache resident)
+    EK_LAUNCH_CHECK("gather", n, arg_bytes(ii, n) + arg_bytes(mm, n) + 2 * n * sizeof(T));
     return EK_OK;
 }
 
@@ -123,7 +125,7 @@ int scatter_launch(void *base, const ek_operand *value, const ek_operand *index,
     unsigned grid = (unsigned) ((n + (size_t) 256 * N - 1) / ((size_t) 256 * N));
     hipLaunchKernelGGL((k_scatter<T, I, N, Add>), dim3(grid), dim3(256), 0, c.stream, (T *) base, vv, ii, mm, n,
                        vec_ok);
-    EK_LAUNCH_CHECK(Add ? "scatter_add" : "scatter", n);
+    EK_LAUNCH_CHECK(Add ? "scatter_add" : "scatter", n, arg_bytes(vv, n) + arg_bytes(ii, n) + arg_bytes(mm, n));
     return EK_OK;
 }
 
@@ -173,7 +175,7 @@ int ek_hip_arange(int type, void *out, int64_t start, int64_t step, size_t n) {
         default: return fail(EK_ERR_INVALID, "ek_hip_arange(): unsupported type %d", type);
     }
 #undef EK_ARANGE
-    EK_LAUNCH_CHECK("arange", n);
+    EK_LAUNCH_CHECK("arange", n, n * type_size(type));
     return EK_OK;
 }
 
@@ -193,7 +195,7 @@ int ek_hip_linspace(int type, void *out, double min, double max, size_t n) {
     } else {
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_linspace(): floating point types only");
     }
-    EK_LAUNCH_CHECK("linspace", n);
+    EK_LAUNCH_CHECK("linspace", n, n * type_size(type));
     return EK_OK;
 }
 
@@ -209,7 +211,7 @@ int ek_hip_reverse(int type, void *out, const void *in, size_t n) {
         case 8: hipLaunchKernelGGL((k_reverse<uint64_t>), dim3(grid), dim3(256), 0, c.stream, (uint64_t *) out, (const uint64_t *) in, n); break;
         default: return fail(EK_ERR_INVALID, "ek_hip_reverse(): unknown type %d", type);
     }
-    EK_LAUNCH_CHECK("reverse", n);
+    EK_LAUNCH_CHECK("reverse", n, 2 * n * type_size(type));
     return EK_OK;
 }
 
@@ -241,7 +243,6 @@ int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value
 
 int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, const ek_operand *value,
                        const ek_operand *index, const ek_operand *mask, size_t n, int mode) {
-    (void) base_size;
     if (int rc = ensure_init()) return rc;
     if (n == 0) return EK_OK;
     if (!base) return fail(EK_ERR_INVALID, "ek_hip_scatter_add(): null pointer");
@@ -249,6 +250,24 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
     if (mode == 1 && is_fp)
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add(): deterministic mode for floating point "
                                         "types is not implemented yet (integer types are exact in mode 0)");
+    // large inputs into tables that fit 256 LDS buckets: partition + ds_add instead of global atomics
+    if (mode == 0 && ctx().tuning.scatter_add_binned && index && mask && value &&
+        scatter_add_binned_applicable(base_size, n, index->ptr != nullptr && index->size == n) &&
+        (index_type == EK_U32 || index_type == EK_I32) && (type == EK_F32 || type == EK_I32 || type == EK_U32)) {
+        Arg<uint8_t> mm;
+        if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add")) return rc;
+        if (type == EK_F32) {
+            Arg<float> vv;
+            if (int rc = make_arg<float>(value, n, vv, "ek_hip_scatter_add")) return rc;
+            if (index_type == EK_U32) { Arg<uint32_t> ii; if (int rc = make_arg<uint32_t>(index, n, ii, "ek_hip_scatter_add")) return rc; return scatter_add_binned<float, uint32_t>((float *) base, base_size, vv, ii, mm, n); }
+            else                      { Arg<int32_t> ii;  if (int rc = make_arg<int32_t>(index, n, ii, "ek_hip_scatter_add")) return rc;  return scatter_add_binned<float, int32_t>((float *) base, base_size, vv, ii, mm, n); }
+        } else {
+            Arg<uint32_t> vv;
+            if (int rc = make_arg<uint32_t>(value, n, vv, "ek_hip_scatter_add")) return rc;
+            if (index_type == EK_U32) { Arg<uint32_t> ii; if (int rc = make_arg<uint32_t>(index, n, ii, "ek_hip_scatter_add")) return rc; return scatter_add_binned<uint32_t, uint32_t>((uint32_t *) base, base_size, vv, ii, mm, n); }
+            else                      { Arg<int32_t> ii;  if (int rc = make_arg<int32_t>(index, n, ii, "ek_hip_scatter_add")) return rc;  return scatter_add_binned<uint32_t, int32_t>((uint32_t *) base, base_size, vv, ii, mm, n); }
+        }
+    }
     switch (type) {
         case EK_F32: EK_INDEX_SWITCH(index_type, (scatter_launch<float, I, true>(base, value, index, mask, n)), "ek_hip_scatter_add()")
         case EK_F64: EK_INDEX_SWITCH(index_type, (scatter_launch<double, I, true>(base, value, index, mask, n)), "ek_hip_scatter_add()")

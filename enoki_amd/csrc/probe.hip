@@ -76,7 +76,7 @@ int probe_launch(int blocks_per_cu, void *o0, void *o1, const void *a, const voi
         hipLaunchKernelGGL((k_probe<Body, U, NTL, NTS, true>), dim3((unsigned) blocks), dim3(256), 0, cx.stream, (V4 *) o0,
                            (V4 *) o1, (const V4 *) a, (const V4 *) b, (const V4 *) c, nvec);
     }
-    EK_LAUNCH_CHECK("probe", n);
+    EK_LAUNCH_CHECK("probe", n, 0);
     return EK_OK;
 }
 
@@ -149,7 +149,7 @@ extern "C" EK_API int ek_hip_probe_scatter_add(int mode, float *table, size_t ta
     if (fold_into)
         hipLaunchKernelGGL(k_probe_fold8, dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, cx.stream, fold_into,
                            table, table_size);
-    EK_LAUNCH_CHECK("probe_scatter_add", n);
+    EK_LAUNCH_CHECK("probe_scatter_add", n, 8 * n);
     return EK_OK;
 }
 

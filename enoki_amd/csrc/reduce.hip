@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_reduce_stage2(T *__restrict__ out, cons
 }
 
 template <typename R, typename T, typename Loader>
-int reduce_launch(const char *name, T *out, size_t n, int vec_ok, const Loader &ld) {
+int reduce_launch(const char *name, T *out, size_t n, int vec_ok, const Loader &ld, size_t bytes) {
     Context &c = ctx();
     constexpr int N = Loader::N;
     size_t items = (n / N + 3) / 4 + 1;
@@ -166,15 +166,16 @@ int reduce_launch(const char *name, T *out, size_t n, int vec_ok, const Loader &
     void *scratch = nullptr;
     if (int rc = reduce_scratch((size_t) grid * sizeof(T), &scratch)) return rc;
     hipLaunchKernelGGL((k_reduce_stage1<R, T, Loader>), dim3(grid), dim3(256), 0, c.stream, (T *) scratch, n, vec_ok, ld);
-    EK_LAUNCH_CHECK(name, n);
+    EK_LAUNCH_CHECK(name, n, bytes);
     hipLaunchKernelGGL((k_reduce_stage2<R, T>), dim3(1), dim3(256), 0, c.stream, out, (const T *) scratch, grid);
-    EK_LAUNCH_CHECK("reduce_stage2", (size_t) grid);
+    EK_LAUNCH_CHECK("reduce_stage2", (size_t) grid, (size_t) grid * sizeof(T) + sizeof(T));
     return EK_OK;
 }
 
 template <int Op, typename T> int reduce_typed(void *out, const void *in, size_t n) {
     PlainLoader<T> ld{ (const T *) in };
-    return reduce_launch<Reducer<Op, T>>("reduce", (T *) out, n, aligned16(in), ld);
+    return reduce_launch<Reducer<Op, T>>(Op == EK_HSUM ? "hsum" : Op == EK_HPROD ? "hprod" : Op == EK_HMIN ? "hmin" : "hmax",
+                                         (T *) out, n, aligned16(in), ld, n * sizeof(T));
 }
 
 template <typename T> int reduce_dispatch(int op, void *out, const void *in, size_t n) {
@@ -261,7 +262,7 @@ template <typename T> int psum_typed(void *out, const void *in, size_t n) {
     hipLaunchKernelGGL((k_scan_sums_serial<T>), dim3(1), dim3(64), 0, c.stream, (T *) sums, blocks);
     hipLaunchKernelGGL((k_scan_apply<T>), dim3(blocks), dim3(256), 0, c.stream, (T *) out, (const T *) in, (const T *) sums, n, chunk);
     ek_hip_free(sums);   // stream-ordered reuse
-    EK_LAUNCH_CHECK("psum", n);
+    EK_LAUNCH_CHECK("psum", n, 3 * n * sizeof(T));
     return EK_OK;
 }
 
@@ -311,14 +312,16 @@ int ek_hip_hsum_safe_mul(int type, void *out, const ek_operand *w, const ek_oper
         if (int rc = make_arg<float>(g, n, ld.g, "ek_hip_hsum_safe_mul")) return rc;
         ld.sw = ld.sg = 0;   // fetched on the device by Loader::init()
         return reduce_launch<Reducer<EK_HSUM, float>>("hsum_safe_mul", (float *) out, n,
-                                                      arg_aligned(ld.w) && arg_aligned(ld.g), ld);
+                                                      arg_aligned(ld.w) && arg_aligned(ld.g), ld,
+                                                      arg_bytes(ld.w, n) + arg_bytes(ld.g, n));
     } else if (type == EK_F64) {
         SafeMulLoader<double> ld;
         if (int rc = make_arg<double>(w, n, ld.w, "ek_hip_hsum_safe_mul")) return rc;
         if (int rc = make_arg<double>(g, n, ld.g, "ek_hip_hsum_safe_mul")) return rc;
         ld.sw = ld.sg = 0;
         return reduce_launch<Reducer<EK_HSUM, double>>("hsum_safe_mul", (double *) out, n,
-                                                       arg_aligned(ld.w) && arg_aligned(ld.g), ld);
+                                                       arg_aligned(ld.w) && arg_aligned(ld.g), ld,
+                                                       arg_bytes(ld.w, n) + arg_bytes(ld.g, n));
     }
     return fail(EK_ERR_UNSUPPORTED, "ek_hip_hsum_safe_mul(): floating point types only");
 }
@@ -333,7 +336,7 @@ int ek_hip_mask_reduce(int op, const uint8_t *mask, size_t n, uint64_t *host_res
         void *dev_count = nullptr;
         if (int rc = ek_hip_malloc(sizeof(uint64_t), &dev_count)) return rc;
         MaskCountLoader ld{ mask };
-        int rc = reduce_launch<Reducer<EK_HSUM, uint64_t>>("mask_reduce", (uint64_t *) dev_count, n, aligned16(mask), ld);
+        int rc = reduce_launch<Reducer<EK_HSUM, uint64_t>>("mask_reduce", (uint64_t *) dev_count, n, aligned16(mask), ld, n);
         if (!rc) rc = ek_hip_memcpy_to_host(&count, dev_count, sizeof(uint64_t));   // synchronizes
         ek_hip_free(dev_count);
         if (rc) return rc;

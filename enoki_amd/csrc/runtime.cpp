@@ -100,6 +100,34 @@ int reduce_scratch(size_t bytes, void **out) {
     return EK_OK;
 }
 
+// ------------------------------------------------------------------------------------------------
+//  Launch profiling: one hipEvent after every kernel launch; the time between consecutive events is
+//  attributed to the later launch (launches are back to back on one stream, so this is the kernel's
+//  duration plus the inter-kernel gap).  Used by bench.py for the `roofline` object.
+// ------------------------------------------------------------------------------------------------
+struct ProfileRecord { const char *name; size_t n, bytes; hipEvent_t event; };
+static std::vector<ProfileRecord> g_profile;
+static std::vector<hipEvent_t> g_event_pool;
+static hipEvent_t g_profile_start = nullptr;
+
+static hipEvent_t pool_event() {
+    if (!g_event_pool.empty()) {
+        hipEvent_t e = g_event_pool.back();
+        g_event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void) hipEventCreate(&e);
+    return e;
+}
+
+void profile_mark(const char *name, size_t n, size_t bytes) {
+    hipEvent_t e = pool_event();
+    if (!e) return;
+    (void) hipEventRecord(e, ctx().stream);
+    g_profile.push_back(ProfileRecord{ name, n, bytes, e });
+}
+
 } // namespace ek
 
 using namespace ek;
@@ -310,11 +338,56 @@ void ek_hip_set_log_level(uint32_t level) { ctx().log_level = level; }
 uint32_t ek_hip_log_level(void) { return ctx().log_level; }
 uint64_t ek_hip_launch_count(void) { return ctx().launches; }
 
+int ek_hip_profile_begin(void) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    Context &c = ctx();
+    for (auto &r : g_profile) g_event_pool.push_back(r.event);
+    g_profile.clear();
+    if (!g_profile_start) EK_HIP_CHECK(hipEventCreate(&g_profile_start));
+    EK_HIP_CHECK(hipEventRecord(g_profile_start, c.stream));
+    c.profiling = true;
+    return EK_OK;
+}
+
+char *ek_hip_profile_end(void) {
+    Context &c = ctx();
+    c.profiling = false;
+    if (c.initialized) (void) hipStreamSynchronize(c.stream);
+    struct Agg { size_t launches = 0, bytes = 0, n = 0; double ms = 0; };
+    std::vector<std::pair<std::string, Agg>> aggs;
+    hipEvent_t prev = g_profile_start;
+    for (auto &r : g_profile) {
+        float ms = 0.f;
+        if (prev && r.event) (void) hipEventElapsedTime(&ms, prev, r.event);
+        prev = r.event;
+        Agg *a = nullptr;
+        // launches of the same kernel over different sizes / operand shapes are different roofline points
+        std::string key = std::string(r.name) + "/" + std::to_string(r.n) + "/" + std::to_string(r.bytes);
+        for (auto &kv : aggs) if (kv.first == key) { a = &kv.second; break; }
+        if (!a) { aggs.emplace_back(key, Agg()); a = &aggs.back().second; }
+        a->launches++; a->bytes += r.bytes; a->n += r.n; a->ms += ms;
+    }
+    for (auto &r : g_profile) g_event_pool.push_back(r.event);
+    g_profile.clear();
+    std::string out = "[";
+    char buf[512];
+    for (size_t i = 0; i < aggs.size(); ++i) {
+        const Agg &a = aggs[i].second;
+        snprintf(buf, sizeof(buf), "%s{\"kernel\": \"%s\", \"launches\": %zu, \"total_ms\": %.6f, \"bytes\": %zu, \"elements\": %zu}",
+                 i ? ", " : "", aggs[i].first.substr(0, aggs[i].first.find('/')).c_str(), a.launches, a.ms, a.bytes, a.n);
+        out += buf;
+    }
+    out += "]";
+    return strdup(out.c_str());
+}
+
 int ek_hip_set_tuning(const char *key, int value) {
     if (!key) return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): null key");
     Tuning &t = ctx().tuning;
     if (!strcmp(key, "blocks_per_cu") && value > 0) t.blocks_per_cu = value;
     else if (!strcmp(key, "reduce_blocks_per_cu") && value > 0) t.reduce_blocks_per_cu = value;
+    else if (!strcmp(key, "scatter_add_binned") && (value == 0 || value == 1)) t.scatter_add_binned = value;
     else return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): unknown key/value %s=%d", key, value);
     return EK_OK;
 }

@@ -1,0 +1,102 @@
+"""Index-range sharding of 1-D arrays across the GPUs of one node.
+
+Partition: rank r of P owns elements [r*N/P, (r+1)*N/P) of EVERY size-N array, so all vertical ops, compares,
+selects and casts are local.  Size-1 arrays and small gather tables (size K) are replicated.  The only exchange
+steps of the hot path are
+    * horizontal reductions: local block reduction, then an all-reduce of ONE element;
+    * gradients of replicated tables: local scatter_add into a K-buffer, then an all-reduce of K elements.
+Both run as RCCL all-reduces over xGMI through torch.distributed (backend "nccl" IS RCCL on ROCm); `gloo` is
+used by the CPU tests.  To keep the number of collectives per backward() at ONE, callers pack every pending
+reduction into a flat buffer with `Packer`.
+
+torch is plumbing only: tensors are zero-copy views of the device arrays (``__cuda_array_interface__``), and the
+library stream is switched to torch's current stream so that kernels and collectives are ordered by the stream.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(n, rank, world):
+    """[begin, end) of the index range owned by `rank`"""
+    return (rank * n) // world, ((rank + 1) * n) // world
+
+
+def env_rank_world():
+    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+
+
+def init(backend=None):
+    """Initialise the process group (no-op for a single process).  Returns (rank, local_rank, world)."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def adopt_torch_stream(ek_module):
+    """run the library's kernels on torch's current stream so collectives and kernels are stream ordered"""
+    ek_module.hip_set_stream(torch.cuda.current_stream().cuda_stream)
+
+
+def as_tensor(array):
+    """zero-copy torch view of a device array (HIPArray / DiffArray python object)"""
+    return torch.as_tensor(array, device="cuda")
+
+
+def all_reduce_(tensor, op="sum"):
+    """in-place all-reduce; identity for a single process"""
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        rop = {"sum": dist.ReduceOp.SUM, "prod": dist.ReduceOp.PRODUCT, "max": dist.ReduceOp.MAX,
+               "min": dist.ReduceOp.MIN}[op]
+        dist.all_reduce(tensor, op=rop)
+    return tensor
+
+
+class Packer:
+    """Flat staging buffer: several pending sum-reductions (scalars and K-vectors) -> ONE all-reduce.
+
+    xGMI is point-to-point, so a ring all-reduce pays per-link latency per collective: batching the
+    1-element hsum results with the K-element gradient buffers keeps backward() at a single collective."""
+
+    def __init__(self, sizes, device, dtype=torch.float32):
+        self.sizes = list(sizes)
+        self.offsets = [0]
+        for s in self.sizes:
+            self.offsets.append(self.offsets[-1] + s)
+        self.flat = torch.empty(self.offsets[-1], device=device, dtype=dtype)
+
+    def slot(self, i):
+        return self.flat[self.offsets[i]:self.offsets[i + 1]]
+
+    def pack(self, tensors):
+        for i, t in enumerate(tensors):
+            self.slot(i).copy_(t.reshape(-1), non_blocking=True)
+
+    def all_reduce(self):
+        all_reduce_(self.flat, "sum")
+        return [self.slot(i) for i in range(len(self.sizes))]
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value):
+    """max of a python float over all ranks (CPU side channel: works with nccl and gloo)"""
+    if not (dist.is_initialized() and dist.get_world_size() > 1):
+        return value
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

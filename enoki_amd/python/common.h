@@ -1,0 +1,241 @@
+/*
+    python/common.h -- generic pybind11 binder for 1-D device arrays
+
+    Mirrors the surface of the reference's `bind<Array>()` (src/python/common.h:338-998) for the types on
+    the hot path: each array class gets constructors (scalar, numpy, copy), arithmetic / comparison
+    operators, zero/empty/full/arange/linspace, numpy()/torch interop, and the module gets the free
+    functions (fmadd, sin, ..., gather, scatter, scatter_add, hsum, ..., select, backward, gradient, ...)
+    overloaded per array type -- so `import enoki_amd.hip_autodiff as ek; ek.hsum(ek.sin(ek.fmadd(a, x, b)))`
+    reads like the reference's `enoki.cuda_autodiff`.
+*/
+#pragma once
+
+#include <pybind11/numpy.h>
+#include <pybind11/operators.h>
+#include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
+
+#include <enoki/hip.h>
+#include <enoki/autodiff.h>
+
+#include <sstream>
+
+namespace py = pybind11;
+using namespace py::literals;
+using namespace enoki;
+
+template <typename Array> std::string array_repr(const Array &a) {
+    const auto &v = detach(a);
+    auto host = v.to_host();
+    std::ostringstream oss;
+    oss << "[";
+    size_t n = host.size(), shown = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (n > 20 && i == 5) { oss << ".. " << (n - 10) << " skipped .., "; i = n - 6; continue; }
+        oss << (is_mask_v<Array> ? (double) (host[i] != 0) : (double) host[i]);
+        if (i + 1 < n) oss << ", ";
+        ++shown;
+    }
+    oss << "]";
+    return oss.str();
+}
+
+/// Bind one 1-D array type.  `Mask` / `UInt32` / `Int32` are the sibling types of the same module.
+template <typename Array> py::class_<Array> bind_array(py::module_ &m, const char *name) {
+    using Scalar = scalar_t<Array>;
+    using Plain = std::decay_t<decltype(detach(std::declval<const Array &>()))>;     // HIPArray<Scalar>
+    using Store = std::conditional_t<std::is_same_v<Scalar, bool>, uint8_t, Scalar>;
+    using Mask = mask_t<Array>;
+    constexpr bool IsMask = is_mask_v<Array>;
+    constexpr bool IsFloat = std::is_floating_point_v<Scalar>;
+    constexpr bool IsInt = std::is_integral_v<Scalar> && !IsMask;
+    constexpr bool IsDiff = is_diff_array_v<Array>;
+
+    py::class_<Array> cl(m, name);
+    cl.def(py::init<>())
+      .def(py::init<const Array &>())
+      .def(py::init<Scalar>())
+      .def(py::init([](py::array_t<Store, py::array::c_style | py::array::forcecast> a) {
+          return Array(Plain::copy(a.data(), (size_t) a.size()));
+      }))
+      .def("__len__", [](const Array &a) { return a.size(); })
+      .def("__repr__", [](const Array &a) { return array_repr(a); })
+      .def("__getitem__", [](const Array &a, size_t i) {
+          if (i >= a.size()) throw py::index_error();
+          return a.coeff(i);
+      })
+      .def("size", [](const Array &a) { return a.size(); })
+      .def("eval", [](Array &a) -> Array & { return a.eval(); }, py::return_value_policy::reference)
+      .def("managed", [](Array &a) -> Array & { return a.managed(); }, py::return_value_policy::reference)
+      .def("numpy", [](const Array &a) {
+          auto host = detach(a).to_host();
+          py::array_t<Store> out((py::ssize_t) host.size());
+          if (!host.empty()) memcpy(out.mutable_data(), host.data(), host.size() * sizeof(Store));
+          return out;
+      })
+      .def("data_ptr", [](Array &a) { return (uintptr_t) a.data(); }, "raw device pointer")
+      .def_property_readonly("__cuda_array_interface__", [](Array &a) {
+          // consumed by torch.as_tensor(obj, device='cuda') on ROCm builds: zero-copy view
+          py::dict d;
+          char typestr[4] = { '<', IsFloat ? 'f' : (IsMask ? 'b' : (std::is_unsigned_v<Scalar> ? 'u' : 'i')),
+                              char('0' + sizeof(Store)), 0 };
+          d["shape"] = py::make_tuple(a.size());
+          d["typestr"] = std::string(typestr);
+          d["data"] = py::make_tuple((uintptr_t) a.data(), false);
+          d["version"] = 2;
+          return d;
+      })
+      .def_static("map", [](uintptr_t ptr, size_t size) { return Array(Plain::map((void *) ptr, size, false)); },
+                  "ptr"_a, "size"_a, "wrap device memory owned by the caller (e.g. tensor.data_ptr())")
+      .def_static("zero", [](size_t size) { return zero<Array>(size); }, "size"_a = 1)
+      .def_static("empty", [](size_t size) { return empty<Array>(size); }, "size"_a = 1)
+      .def_static("full", [](Scalar value, size_t size) { return full<Array>(value, size); }, "value"_a, "size"_a = 1);
+
+    m.def("slices", [](const Array &a) { return slices(a); });
+    m.def("set_slices", [](Array &a, size_t n) { set_slices(a, n); });
+    m.def("detach", [](const Array &a) { return Plain(detach(a)); });
+
+    cl.def("__eq__", [](const Array &a, const Array &b) { return eq(a, b); })
+      .def("__ne__", [](const Array &a, const Array &b) { return neq(a, b); });
+    m.def("eq", [](const Array &a, const Array &b) { return eq(a, b); });
+    m.def("neq", [](const Array &a, const Array &b) { return neq(a, b); });
+    m.def("select", [](const Mask &mk, const Array &t, const Array &f) { return select(mk, t, f); });
+
+    if constexpr (IsMask) {
+        cl.def("__and__", [](const Array &a, const Array &b) { return Array(a & b); })
+          .def("__or__", [](const Array &a, const Array &b) { return Array(a | b); })
+          .def("__xor__", [](const Array &a, const Array &b) { return Array(a ^ b); })
+          .def("__invert__", [](const Array &a) { return Array(!a); });
+        m.def("all", [](const Array &a) { return all(a); });
+        m.def("any", [](const Array &a) { return any(a); });
+        m.def("none", [](const Array &a) { return none(a); });
+        m.def("count", [](const Array &a) { return count(a); });
+    } else {
+        cl.def_static("arange", [](size_t size) { return arange<Array>(size); }, "size"_a)
+          .def(py::self + py::self).def(py::self - py::self).def(py::self * py::self)
+          .def(Scalar() + py::self).def(Scalar() - py::self).def(Scalar() * py::self)
+          .def(py::self + Scalar()).def(py::self - Scalar()).def(py::self * Scalar())
+          .def(-py::self)
+          .def("__lt__", [](const Array &a, const Array &b) { return a < b; })
+          .def("__le__", [](const Array &a, const Array &b) { return a <= b; })
+          .def("__gt__", [](const Array &a, const Array &b) { return a > b; })
+          .def("__ge__", [](const Array &a, const Array &b) { return a >= b; })
+          .def("__and__", [](const Array &a, const Mask &mk) { return Array(a & mk); });
+        m.def("abs", [](const Array &a) { return abs(a); });
+        m.def("min", [](const Array &a, const Array &b) { return min(a, b); });
+        m.def("max", [](const Array &a, const Array &b) { return max(a, b); });
+        m.def("sqr", [](const Array &a) { return sqr(a); });
+        m.def("fmadd", [](const Array &a, const Array &b, const Array &c) { return fmadd(a, b, c); });
+        m.def("fmsub", [](const Array &a, const Array &b, const Array &c) { return fmsub(a, b, c); });
+        m.def("fnmadd", [](const Array &a, const Array &b, const Array &c) { return fnmadd(a, b, c); });
+        m.def("fnmsub", [](const Array &a, const Array &b, const Array &c) { return fnmsub(a, b, c); });
+        m.def("hsum", [](const Array &a) { return hsum(a); });
+        m.def("hprod", [](const Array &a) { return hprod(a); });
+        m.def("hmin", [](const Array &a) { return hmin(a); });
+        m.def("hmax", [](const Array &a) { return hmax(a); });
+        m.def("psum", [](const Array &a) { return psum(a); });
+        m.def("reverse", [](const Array &a) { return reverse(a); });
+    }
+
+    if constexpr (IsFloat) {
+        cl.def_static("linspace", [](Scalar lo, Scalar hi, size_t size) { return linspace<Array>(lo, hi, size); },
+                      "min"_a, "max"_a, "size"_a)
+          .def(py::self / py::self).def(Scalar() / py::self).def(py::self / Scalar());
+        cl.def("__truediv__", [](const Array &a, const Array &b) { return a / b; });
+        m.def("sqrt", [](const Array &a) { return sqrt(a); });
+        m.def("rcp", [](const Array &a) { return rcp(a); });
+        m.def("rsqrt", [](const Array &a) { return rsqrt(a); });
+        m.def("floor", [](const Array &a) { return floor(a); });
+        m.def("ceil", [](const Array &a) { return ceil(a); });
+        m.def("round", [](const Array &a) { return round(a); });
+        m.def("trunc", [](const Array &a) { return trunc(a); });
+        m.def("sign", [](const Array &a) { return sign(a); });
+        if constexpr (std::is_same_v<Scalar, float>) {
+            m.def("sin", [](const Array &a) { return sin(a); });
+            m.def("cos", [](const Array &a) { return cos(a); });
+            m.def("sincos", [](const Array &a) { return sincos(a); });
+            m.def("exp", [](const Array &a) { return exp(a); });
+            m.def("log", [](const Array &a) { return log(a); });
+        }
+    }
+
+    if constexpr (IsInt) {
+        cl.def("__floordiv__", [](const Array &a, const Array &b) { return a / b; })
+          .def("__mod__", [](const Array &a, const Array &b) { return a % b; })
+          .def("__and__", [](const Array &a, const Array &b) { return Array(a & b); })
+          .def("__or__", [](const Array &a, const Array &b) { return Array(a | b); })
+          .def("__xor__", [](const Array &a, const Array &b) { return Array(a ^ b); })
+          .def("__invert__", [](const Array &a) { return Array(~a); })
+          .def("__lshift__", [](const Array &a, const Array &b) { return a << b; })
+          .def("__rshift__", [](const Array &a, const Array &b) { return a >> b; });
+        m.def("popcnt", [](const Array &a) { return popcnt(a); });
+        m.def("lzcnt", [](const Array &a) { return lzcnt(a); });
+        m.def("tzcnt", [](const Array &a) { return tzcnt(a); });
+        m.def("mulhi", [](const Array &a, const Array &b) { return mulhi(a, b); });
+    }
+
+    if constexpr (IsDiff && IsFloat) {
+        m.def("requires_gradient", [](const Array &a) { return requires_gradient(a); });
+        m.def("set_requires_gradient", [](Array &a, bool value) { set_requires_gradient(a, value); }, "array"_a,
+              "value"_a = true);
+        m.def("gradient", [](const Array &a) { return Plain(gradient(a)); });
+        m.def("gradient_index", [](const Array &a) { return gradient_index(a); });
+        m.def("set_gradient", [](Array &a, const Plain &g, bool backward) { a.set_gradient_(g, backward); }, "array"_a,
+              "gradient"_a, "backward"_a = true);
+        m.def("backward", [](const Array &a, bool free_graph) { backward(a, free_graph); }, "array"_a,
+              "free_graph"_a = true);
+        m.def("forward", [](const Array &a, bool free_graph) { forward(a, free_graph); }, "array"_a,
+              "free_graph"_a = true);
+        m.def("reattach", [](Array &a, const Array &b) { reattach(a, b); });
+        m.def("graphviz", [](const Array &a) { return graphviz(a); });
+        m.def("set_label", [](const Array &a, const char *label) { set_label(a, label); });
+        cl.def_static("backward", [](bool free_graph) { Array::backward_static_(free_graph); }, "free_graph"_a = true)
+          .def_static("forward", [](bool free_graph) { Array::forward_static_(free_graph); }, "free_graph"_a = true)
+          .def_static("whos", []() { return Array::whos_(); })
+          .def_static("simplify_graph", []() { Array::simplify_graph_(); })
+          .def_static("set_log_level", [](uint32_t level) { Array::set_log_level_(level); })
+          .def_static("push_prefix", [](const char *label) { Array::push_prefix_(label); })
+          .def_static("pop_prefix", []() { Array::pop_prefix_(); });
+    }
+    return cl;
+}
+
+/// gather / scatter / scatter_add for a (value type, index type) pair
+template <typename Array, typename Index> void bind_memory(py::module_ &m) {
+    using Mask = mask_t<Array>;
+    m.def("gather", [](const Array &source, const Index &index, const Mask &mask) {
+        return gather<Array>(source, index, mask);
+    }, "source"_a, "index"_a, "mask"_a = Mask(true));
+    m.def("scatter", [](Array &target, const Array &source, const Index &index, const Mask &mask) {
+        scatter(target, source, index, mask);
+    }, "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
+    m.def("scatter_add", [](Array &target, const Array &source, const Index &index, const Mask &mask) {
+        scatter_add(target, source, index, mask);
+    }, "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
+}
+
+/// Conversions between the array classes of one module (Float32(UInt32) etc.)
+template <typename Dst, typename Src> void bind_cast(py::class_<Dst> &cl) {
+    cl.def(py::init([](const Src &s) { return Dst(s); }));
+}
+
+inline void bind_runtime(py::module_ &m) {
+    m.def("hip_eval", []() { hip_eval(); }, "no-op: the backend is eager (kept for cuda_eval() call sites)");
+    m.def("hip_sync", []() { py::gil_scoped_release r; hip_sync(); });
+    m.def("hip_whos", []() { return hip_whos(); });
+    m.def("hip_malloc_trim", []() { hip_malloc_trim(); });
+    m.def("hip_set_log_level", [](uint32_t l) { ek_hip_set_log_level(l); });
+    m.def("hip_init", [](int device) { detail::hip_check(ek_hip_init(device), "hip_init"); }, "device"_a = -1);
+    m.def("hip_device", []() { return ek_hip_device(); });
+    m.def("hip_stream", []() { return (uintptr_t) ek_hip_stream(); });
+    m.def("hip_set_stream", [](uintptr_t s) { detail::hip_check(ek_hip_set_stream((void *) s), "hip_set_stream"); });
+    m.def("hip_launch_count", []() { return ek_hip_launch_count(); });
+    m.def("hip_profile_begin", []() { detail::hip_check(ek_hip_profile_begin(), "hip_profile_begin"); });
+    m.def("hip_profile_end", []() {
+        char *r = ek_hip_profile_end();
+        std::string s(r ? r : "[]");
+        free(r);
+        return s;
+    }, "JSON list of {kernel, launches, total_ms, bytes, elements} since hip_profile_begin()");
+    m.def("hip_set_tuning", [](const char *k, int v) { detail::hip_check(ek_hip_set_tuning(k, v), "hip_set_tuning"); });
+}

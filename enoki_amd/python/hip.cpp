@@ -1,0 +1,36 @@
+// enoki_amd.hip -- non-differentiable device arrays (the analogue of the reference's enoki.cuda module,
+// src/python/cuda.cpp:14-53 + cuda_1d.cpp:4-107)
+#include "common.h"
+
+using FloatC = HIPArray<float>;
+using DoubleC = HIPArray<double>;
+using Int32C = HIPArray<int32_t>;
+using UInt32C = HIPArray<uint32_t>;
+using Int64C = HIPArray<int64_t>;
+using UInt64C = HIPArray<uint64_t>;
+using MaskC = HIPArray<bool>;
+
+PYBIND11_MODULE(hip, m) {
+    m.doc() = "MI355X-native Enoki arrays (eager HIP kernels, no JIT)";
+    bind_runtime(m);
+    auto mask = bind_array<MaskC>(m, "Mask");
+    auto f32 = bind_array<FloatC>(m, "Float32");
+    auto f64 = bind_array<DoubleC>(m, "Float64");
+    auto i32 = bind_array<Int32C>(m, "Int32");
+    auto u32 = bind_array<UInt32C>(m, "UInt32");
+    auto i64 = bind_array<Int64C>(m, "Int64");
+    auto u64 = bind_array<UInt64C>(m, "UInt64");
+    m.attr("Float") = m.attr("Float32");
+
+    bind_cast<FloatC, Int32C>(f32); bind_cast<FloatC, UInt32C>(f32); bind_cast<FloatC, DoubleC>(f32);
+    bind_cast<FloatC, Int64C>(f32); bind_cast<FloatC, UInt64C>(f32);
+    bind_cast<DoubleC, FloatC>(f64); bind_cast<DoubleC, Int32C>(f64); bind_cast<DoubleC, UInt32C>(f64);
+    bind_cast<Int32C, FloatC>(i32); bind_cast<Int32C, UInt32C>(i32); bind_cast<Int32C, Int64C>(i32);
+    bind_cast<UInt32C, FloatC>(u32); bind_cast<UInt32C, Int32C>(u32); bind_cast<UInt32C, UInt64C>(u32);
+    bind_cast<Int64C, Int32C>(i64); bind_cast<Int64C, FloatC>(i64); bind_cast<Int64C, UInt64C>(i64);
+    bind_cast<UInt64C, UInt32C>(u64); bind_cast<UInt64C, FloatC>(u64); bind_cast<UInt64C, Int64C>(u64);
+
+    bind_memory<FloatC, UInt32C>(m); bind_memory<FloatC, Int32C>(m);
+    bind_memory<Int32C, UInt32C>(m); bind_memory<UInt32C, UInt32C>(m);
+    bind_memory<DoubleC, UInt32C>(m);
+}

@@ -1,0 +1,31 @@
+// enoki_amd.hip_autodiff -- differentiable device arrays (the analogue of enoki.cuda_autodiff,
+// src/python/cuda_autodiff.cpp:13-31 + cuda_autodiff_1d.cpp:4-156)
+#include "common.h"
+
+using FloatC = HIPArray<float>;
+using FloatD = DiffArray<HIPArray<float>>;
+using Int32D = DiffArray<HIPArray<int32_t>>;
+using UInt32D = DiffArray<HIPArray<uint32_t>>;
+using MaskD = DiffArray<HIPArray<bool>>;
+
+PYBIND11_MODULE(hip_autodiff, m) {
+    m.doc() = "MI355X-native differentiable Enoki arrays (tape-based reverse/forward mode)";
+    py::module_::import("enoki_amd.hip");      // plain array classes (gradient(), detach() return them)
+    bind_runtime(m);
+    auto mask = bind_array<MaskD>(m, "Mask");
+    auto f32 = bind_array<FloatD>(m, "Float32");
+    auto i32 = bind_array<Int32D>(m, "Int32");
+    auto u32 = bind_array<UInt32D>(m, "UInt32");
+    m.attr("Float") = m.attr("Float32");
+
+    f32.def(py::init([](const FloatC &v) { return FloatD(v); }));
+    u32.def(py::init([](const HIPArray<uint32_t> &v) { return UInt32D(v); }));
+    i32.def(py::init([](const HIPArray<int32_t> &v) { return Int32D(v); }));
+    mask.def(py::init([](const HIPArray<bool> &v) { return MaskD(v); }));
+    bind_cast<FloatD, Int32D>(f32); bind_cast<FloatD, UInt32D>(f32);
+    bind_cast<Int32D, FloatD>(i32); bind_cast<Int32D, UInt32D>(i32);
+    bind_cast<UInt32D, FloatD>(u32); bind_cast<UInt32D, Int32D>(u32);
+
+    bind_memory<FloatD, UInt32D>(m); bind_memory<FloatD, Int32D>(m);
+    bind_memory<UInt32D, UInt32D>(m); bind_memory<Int32D, UInt32D>(m);
+}

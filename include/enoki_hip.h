@@ -116,7 +116,13 @@ EK_API char *ek_hip_whos(void);
 EK_API void ek_hip_set_log_level(uint32_t level);   /* 0 silent .. 3 every launch (cuda.h:195-200) */
 EK_API uint32_t ek_hip_log_level(void);
 EK_API uint64_t ek_hip_launch_count(void);          /* kernels launched since init (diagnostics) */
-EK_API int ek_hip_set_tuning(const char *key, int value);   /* e.g. "blocks_per_cu", "unroll" */
+EK_API int ek_hip_set_tuning(const char *key, int value);   /* "blocks_per_cu", "reduce_blocks_per_cu" */
+/* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
+   launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of
+   {"kernel", "launches", "total_ms", "bytes", "elements"}; `bytes` are the ALGORITHMIC bytes of the
+   launches (distinct operand bytes + output bytes; broadcast operands count 0). */
+EK_API int ek_hip_profile_begin(void);
+EK_API char *ek_hip_profile_end(void);
 
 /* ---------------------------------------------------------------------------------------------
  *  Vertical (elementwise) ops: out[i] = op(a[i or 0], ...), i in [0, n)

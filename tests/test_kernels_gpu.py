@@ -350,3 +350,47 @@ def test_allocator_reuse_and_whos(capi):
     assert b2.ptr == p                      # cached block is reused
     assert "live bytes" in capi.whos()
     assert capi.lib.ek_hip_launch_count() == before
+
+
+# ----------------------------------------------------------------------------------------------
+#  LDS-binned scatter_add (csrc/scatter_binned.hip): large inputs
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K", [31, 16384, 16385, 100000, 1 << 20, (1 << 22) - 5])
+@pytest.mark.parametrize("masked", [False, True])
+def test_scatter_add_binned_int_exact(capi, K, masked):
+    """integer adds are order independent -> the binned path must reproduce np.add.at exactly"""
+    n = (1 << 20) + 1237
+    rng = np.random.default_rng(K)
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    val = rng.integers(-1000, 1000, n).astype(np.int32)
+    m = (rng.integers(0, 4, n) != 0).astype(np.uint8) if masked else np.ones(n, np.uint8)
+    tgt = rng.integers(-5, 5, K).astype(np.int32)
+    d = up(capi, tgt)
+    capi.scatter_add(d, up(capi, val), up(capi, idx), up(capi, m) if masked else True)
+    expect = tgt.copy(); np.add.at(expect, idx[m != 0], val[m != 0])
+    assert np.array_equal(d.numpy(), expect)
+    # the two implementations agree with each other
+    capi.set_tuning("scatter_add_binned", 0)
+    d2 = up(capi, tgt)
+    capi.scatter_add(d2, up(capi, val), up(capi, idx), up(capi, m) if masked else True)
+    capi.set_tuning("scatter_add_binned", 1)
+    assert np.array_equal(d2.numpy(), expect)
+
+
+@pytest.mark.parametrize("K", [1000, 1 << 20])
+def test_scatter_add_binned_f32(capi, K):
+    n = (1 << 21) + 5
+    rng = np.random.default_rng(K + 1)
+    idx = rng.integers(0, K, n).astype(np.int32)
+    val = rng.standard_normal(n).astype(np.float32)
+    tgt = rng.standard_normal(K).astype(np.float32)
+    d = up(capi, tgt)
+    capi.scatter_add(d, up(capi, val), up(capi, idx))
+    truth = tgt.astype(np.float64); np.add.at(truth, idx, val.astype(np.float64))
+    mag = np.abs(tgt).astype(np.float64); np.add.at(mag, idx, np.abs(val).astype(np.float64))
+    cnt = np.bincount(idx, minlength=K) + 1
+    assert np.all(np.abs(d.numpy() - truth) <= cnt * 2.0 ** -24 * mag + 1e-30)
+    # scalar value operand (broadcast gradient)
+    d = up(capi, np.zeros(K, np.float32))
+    capi.scatter_add(d, 0.5, up(capi, idx), n=n)
+    assert np.array_equal(d.numpy(), (np.bincount(idx, minlength=K) * 0.5).astype(np.float32))
