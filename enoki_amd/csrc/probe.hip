@@ -128,9 +128,50 @@ __global__ __launch_bounds__(256) void k_probe_fold8(float *__restrict__ out, co
     out[i] = s;
 }
 
+// ---- LDS atomic throughput -------------------------------------------------------------------------
+// variant 0: ds_add_f32 random bins   1: ds_add_u32 random bins   2: plain ds read-modify-write (racy, bound only)
+// 3: ds_add_f32, lane-private bins (no conflicts)   4: ds_add_rtn_u32 random (returning)
+template <int Variant>
+__global__ __launch_bounds__(512) void k_probe_lds_atomic(float *__restrict__ sink, int iters, int bins_log2) {
+    extern __shared__ __align__(16) unsigned char raw[];
+    float *accf = reinterpret_cast<float *>(raw);
+    unsigned *accu = reinterpret_cast<unsigned *>(raw);
+    const unsigned bins = 1u << bins_log2;
+    for (unsigned j = threadIdx.x; j < bins; j += 512) accf[j] = 0.f;
+    __syncthreads();
+    unsigned h = blockIdx.x * 512u + threadIdx.x + 1u;
+    unsigned ret = 0;
+    for (int it = 0; it < iters; ++it) {
+        h ^= h >> 16; h *= 0x7feb352du; h ^= h >> 15; h *= 0x846ca68bu; h ^= h >> 16;
+        unsigned b = h & (bins - 1);
+        if constexpr (Variant == 0) atomicAdd(&accf[b], 1.0f);
+        else if constexpr (Variant == 1) atomicAdd(&accu[b], 1u);
+        else if constexpr (Variant == 2) accf[b] = accf[b] + 1.0f;
+        else if constexpr (Variant == 3) atomicAdd(&accf[(threadIdx.x + (unsigned) it * 512u) & (bins - 1)], 1.0f);
+        else ret += atomicAdd(&accu[b], 1u);
+    }
+    __syncthreads();
+    if (accf[threadIdx.x] == 12345.678f || ret == 0xdeadbeefu) sink[threadIdx.x] = accf[threadIdx.x];
+}
+
 } // namespace ek
 
 using namespace ek;
+
+extern "C" EK_API int ek_hip_probe_lds_atomic(int variant, int blocks, int iters, int bins_log2, float *sink) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+    size_t lds = (size_t) 4 << bins_log2;
+    switch (variant) {
+        case 0: hipLaunchKernelGGL((k_probe_lds_atomic<0>), dim3(blocks), dim3(512), lds, cx.stream, sink, iters, bins_log2); break;
+        case 1: hipLaunchKernelGGL((k_probe_lds_atomic<1>), dim3(blocks), dim3(512), lds, cx.stream, sink, iters, bins_log2); break;
+        case 2: hipLaunchKernelGGL((k_probe_lds_atomic<2>), dim3(blocks), dim3(512), lds, cx.stream, sink, iters, bins_log2); break;
+        case 3: hipLaunchKernelGGL((k_probe_lds_atomic<3>), dim3(blocks), dim3(512), lds, cx.stream, sink, iters, bins_log2); break;
+        default: hipLaunchKernelGGL((k_probe_lds_atomic<4>), dim3(blocks), dim3(512), lds, cx.stream, sink, iters, bins_log2); break;
+    }
+    EK_LAUNCH_CHECK("probe_lds_atomic", (size_t) blocks * 512 * iters, 0);
+    return EK_OK;
+}
 
 // scatter_add experiment: `table` must hold 8 * table_size floats for mode 1 (copies zeroed by the caller);
 // `fold_into` (table_size floats) receives table += sum of the copies when non-null.

@@ -6,18 +6,19 @@
 // 160 KiB LDS, on the other hand, holds 16 Ki f32 bins (64 KiB, two workgroups per CU) and executes
 // ds_add_f32 at LDS speed.  So the adjoint of gather is restructured as
 //
-//   1. count     every workgroup owns a contiguous chunk of the n elements and histograms its
-//                indices by BUCKET (= index >> 14) in LDS                       reads  4 B/elt
-//   2. scan      exclusive scan of the (bucket-major, workgroup-minor) counts   tiny
-//   3. partition each workgroup re-reads its chunk and appends (index & 16383, value) to its slice of
-//                the bucket's pair list (LDS cursors)                           reads 8, writes 8 B/elt
-//   4. accumulate S workgroups per bucket stream the bucket's pairs and ds_add them into a
-//                zeroed LDS table, then write their partial table               reads  8 B/elt
-//   5. fold      target[k] += sum_s partial[s][k]                               (S + 2) * 4 B per bin
+//   1. count      every workgroup owns a contiguous chunk of the n elements and histograms its
+//                 indices by BUCKET (= index >> 14) in LDS                        reads  4 B/elt
+//   2. scan       per-bucket exclusive scan over the workgroups' counts + scan of the bucket totals
+//   3. partition  each workgroup re-reads its chunk in tiles of 4096 elements, sorts a tile by bucket
+//                 in LDS (so that a bucket's elements leave the CU as one coalesced run) and appends
+//                 (index, value) to the bucket's pair list                        reads 8, writes 8 B/elt
+//   4. accumulate S workgroups per bucket stream the bucket's pairs and ds_add them into a zeroed LDS
+//                 table, then write their partial table                           reads  8 B/elt
+//   5. fold       target[k] += sum_s partial[s][k]                                (S + 2) * 4 B per bin
 //
-// = 28 B/elt of coalesced streaming traffic and no global atomics.  Tables of <= 16 Ki bins skip
-// steps 1-3.  The result is the same set of additions as the atomic version in a different
-// (unspecified) order -- parity class D, like the reference's own GPU path.
+// = 28 B/elt of streaming traffic and no global atomics.  Tables of <= 16 Ki bins skip steps 1-3.
+// The result is the same set of additions as the atomic version in a different (unspecified) order
+// -- parity class D, like the reference's own GPU path.
 #include "ek_map.h"
 
 #include <algorithm>
@@ -28,6 +29,8 @@ constexpr int kBinShift = 14;
 constexpr int kBins = 1 << kBinShift;      // bins per bucket (64 KiB of f32 / i32 in LDS)
 constexpr int kMaxBuckets = 256;
 constexpr int kThreads = 512;
+constexpr int kPerThread = 8;
+constexpr int kTile = kThreads * kPerThread;   // elements sorted per LDS pass of the partition
 
 template <typename I> __device__ __forceinline__ uint32_t index_u32(I i) { return (uint32_t) i; }
 
@@ -40,76 +43,196 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(uint32_t *__restrict__ c
     __syncthreads();
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
-    for (size_t i = begin + threadIdx.x; i < end; i += kThreads) {
-        if (mask.vec ? mask.ptr[i] : sm)
-            atomicAdd(&hist[index_u32(index[i]) >> kBinShift], 1u);
+    for (size_t base = begin; base < end; base += kTile) {
+        uint32_t ix[kPerThread];
+        bool on[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            size_t i = base + (size_t) k * kThreads + threadIdx.x;
+            on[k] = i < end && (mask.vec ? mask.ptr[i] : sm);
+            ix[k] = i < end ? index_u32(index[i]) : 0u;
+        }
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k)
+            if (on[k]) atomicAdd(&hist[ix[k] >> kBinShift], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += kThreads)
         counts[(size_t) b * gridDim.x + blockIdx.x] = hist[b];
 }
 
-// ---- 2. scan (single workgroup; the array has n_buckets * n_blocks <= 256 * 2048 entries) -----------
-__global__ __launch_bounds__(1024) void k_bin_scan(uint32_t *__restrict__ counts, size_t count, uint32_t *__restrict__ total) {
+// ---- 2. scan ---------------------------------------------------------------------------------------
+// counts is [n_buckets][n_blocks]; workgroup b turns row b into its exclusive prefix and emits the row total
+__global__ __launch_bounds__(1024) void k_bin_scan_rows(uint32_t *__restrict__ counts, uint32_t *__restrict__ row_total,
+                                                        unsigned n_blocks) {
     __shared__ uint32_t part[1024];
-    const size_t per = (count + 1023) / 1024;
-    const size_t begin = threadIdx.x * per, end = begin + per < count ? begin + per : count;
-    uint32_t s = 0;
-    for (size_t i = begin; i < end; ++i) s += counts[i];
-    part[threadIdx.x] = s;
+    uint32_t *row = counts + (size_t) blockIdx.x * n_blocks;
+    uint32_t carry = 0;
+    for (unsigned base = 0; base < n_blocks; base += 1024) {
+        unsigned i = base + threadIdx.x;
+        uint32_t v = i < n_blocks ? row[i] : 0u;
+        part[threadIdx.x] = v;
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            uint32_t add = threadIdx.x >= (unsigned) d ? part[threadIdx.x - d] : 0u;
+            __syncthreads();
+            part[threadIdx.x] += add;
+            __syncthreads();
+        }
+        if (i < n_blocks) row[i] = carry + part[threadIdx.x] - v;
+        carry += part[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
+}
+
+// bucket_base[b] = sum of row totals of buckets < b; bucket_base[n_buckets] = grand total
+__global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__ bucket_base,
+                                                          const uint32_t *__restrict__ row_total, int n_buckets) {
+    __shared__ uint32_t part[256];
+    uint32_t v = (int) threadIdx.x < n_buckets ? row_total[threadIdx.x] : 0u;
+    part[threadIdx.x] = v;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    for (int d = 1; d < 256; d <<= 1) {
         uint32_t add = threadIdx.x >= (unsigned) d ? part[threadIdx.x - d] : 0u;
         __syncthreads();
         part[threadIdx.x] += add;
         __syncthreads();
     }
-    uint32_t run = threadIdx.x ? part[threadIdx.x - 1] : 0u;
-    for (size_t i = begin; i < end; ++i) {
-        uint32_t c = counts[i];
-        counts[i] = run;
-        run += c;
-    }
-    if (threadIdx.x == 1023) *total = part[1023];
+    if ((int) threadIdx.x < n_buckets) bucket_base[threadIdx.x] = part[threadIdx.x] - v;
+    if (threadIdx.x == 255) bucket_base[n_buckets] = part[255];
 }
 
 // ---- 3. partition ----------------------------------------------------------------------------------
 template <typename T, typename I>
-__global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict__ pair_bin, T *__restrict__ pair_val,
-                                                            const uint32_t *__restrict__ offsets, Arg<T> value,
+__global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict__ pair_idx, T *__restrict__ pair_val,
+                                                            const uint32_t *__restrict__ offsets,
+                                                            const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                             const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
                                                             size_t chunk, int n_buckets) {
-    __shared__ uint32_t cursor[kMaxBuckets];
-    for (int b = threadIdx.x; b < n_buckets; b += kThreads)
-        cursor[b] = offsets[(size_t) b * gridDim.x + blockIdx.x];
+    __shared__ uint32_t cursor[kMaxBuckets];       // next free global slot of this workgroup per bucket
+    __shared__ uint32_t tile_hist[kMaxBuckets];    // elements of the current tile per bucket
+    __shared__ uint32_t tile_off[kMaxBuckets];     // exclusive prefix of tile_hist
+    __shared__ uint32_t stage_idx[kTile];
+    __shared__ T stage_val[kTile];
+
+    for (int b = threadIdx.x; b < kMaxBuckets; b += kThreads) {
+        cursor[b] = b < n_buckets ? bucket_base[b] + offsets[(size_t) b * gridDim.x + blockIdx.x] : 0u;
+        tile_hist[b] = 0;
+    }
     __syncthreads();
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const T sv = value.vec ? T(0) : arg_scalar(value);
     const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
-    for (size_t i = begin + threadIdx.x; i < end; i += kThreads) {
-        if (mask.vec ? mask.ptr[i] : sm) {
-            uint32_t ix = index_u32(index[i]);
-            uint32_t pos = atomicAdd(&cursor[ix >> kBinShift], 1u);
-            pair_bin[pos] = ix & (kBins - 1);
-            pair_val[pos] = value.vec ? value.ptr[i] : sv;
+
+    for (size_t base = begin; base < end; base += kTile) {
+        uint32_t ix[kPerThread], rank[kPerThread];
+        T val[kPerThread];
+        bool on[kPerThread];
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            size_t i = base + (size_t) k * kThreads + threadIdx.x;
+            on[k] = i < end && (mask.vec ? mask.ptr[i] : sm);
+            ix[k] = i < end ? index_u32(index[i]) : 0u;
+            val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
         }
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k)
+            rank[k] = on[k] ? atomicAdd(&tile_hist[ix[k] >> kBinShift], 1u) : 0u;
+        __syncthreads();
+        // exclusive scan of the tile histogram (256 entries) by ONE wave: 4 entries per lane + shuffle scan
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            uint32_t h0 = tile_hist[4 * l], h1 = tile_hist[4 * l + 1], h2 = tile_hist[4 * l + 2], h3 = tile_hist[4 * l + 3];
+            uint32_t sum = h0 + h1 + h2 + h3, incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t up = __shfl_up(incl, d, 64);
+                if (l >= d) incl += up;
+            }
+            uint32_t excl = incl - sum;
+            tile_off[4 * l] = excl;
+            tile_off[4 * l + 1] = excl + h0;
+            tile_off[4 * l + 2] = excl + h0 + h1;
+            tile_off[4 * l + 3] = excl + h0 + h1 + h2;
+        }
+        __syncthreads();
+        const uint32_t tile_count = tile_off[kMaxBuckets - 1] + tile_hist[kMaxBuckets - 1];
+        // bucket-sorted staging
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            if (on[k]) {
+                uint32_t p = tile_off[ix[k] >> kBinShift] + rank[k];
+                stage_idx[p] = ix[k];
+                stage_val[p] = val[k];
+            }
+        }
+        __syncthreads();
+        // coalesced runs: consecutive staged elements of one bucket go to consecutive global slots
+        for (uint32_t j = threadIdx.x; j < tile_count; j += kThreads) {
+            uint32_t key = stage_idx[j], b = key >> kBinShift;
+            uint32_t g = cursor[b] + (j - tile_off[b]);
+            pair_idx[g] = key;
+            pair_val[g] = stage_val[j];
+        }
+        __syncthreads();
+        if (threadIdx.x < kMaxBuckets) {
+            cursor[threadIdx.x] += tile_hist[threadIdx.x];
+            tile_hist[threadIdx.x] = 0;
+        }
+        __syncthreads();
     }
 }
 
 // ---- 4. accumulate ---------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ void lds_add(T *addr, T v) {
-    if constexpr (std::is_same_v<T, float>) atomicAdd(addr, v);                 // ds_add_f32
-    else atomicAdd(reinterpret_cast<unsigned int *>(addr), (unsigned int) v);   // ds_add_u32
+// LDS accumulation.  Integer ds_add_u32 runs at ~10 cycles per wave instruction, but ds_add_f32 is
+// microcoded on gfx950: ~194 cycles per wave instruction, conflicts or not (profiles/probe_lds_r01.txt),
+// which would cap 64 Mi float adds at 0.33 ms.  Floats therefore take a per-bin EXCHANGE LOCK built
+// from the fast integer path:
+//     old = ds_wrxchg_rtn_b32(bin, LOCKED)      claim the bin (LOCKED = a NaN payload we never store)
+//     if (old == LOCKED) retry                   someone else holds it for the next few cycles
+//     ds_write_b32(bin, old + v)                 plain store releases it
+// A wave executes these in lockstep, so of the lanes that collide on one bin exactly one wins per
+// iteration and the holder never waits for a spinner -> always progresses.  With random bins almost
+// every lane succeeds on the first try: ~2 LDS instructions per element instead of a 194-cycle atomic.
+constexpr uint32_t kLockedBits = 0xFFC00001u;
+
+template <bool UseLock, typename T> __device__ __forceinline__ void lds_add(T *addr, T v, bool active) {
+    if constexpr (std::is_same_v<T, float>) {
+        if constexpr (UseLock) {
+            // The loop condition is WAVE-UNIFORM (__any): every lane stays inside until the whole wave is
+            // done, so a winner's releasing store is issued in the iteration in which it won.  (With a
+            // per-lane `while (pending)` the compiler may sink the store behind the loop exit, where the
+            // winner waits for reconvergence with the very lanes that spin on its lock -- a deadlock.)
+            unsigned *p = reinterpret_cast<unsigned *>(addr);
+            bool pending = active;
+            while (__any(pending)) {
+                if (pending) {
+                    unsigned old = atomicExch(p, kLockedBits);
+                    if (old != kLockedBits) {
+                        float sum = __uint_as_float(old) + v;
+                        unsigned bits = __float_as_uint(sum);
+                        if (bits == kLockedBits) bits = 0x7FC00000u;     // never publish the lock pattern
+                        __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        pending = false;
+                    }
+                }
+            }
+        } else {
+            if (active) atomicAdd(addr, v);                                          // ds_add_f32
+        }
+    } else {
+        if (active) atomicAdd(reinterpret_cast<unsigned int *>(addr), (unsigned int) v);   // ds_add_u32
+    }
 }
 
-// Pairs come either from the partition (Direct = false: bucket b owns pairs [bucket_begin[b], bucket_begin[b+1]))
+// Pairs come either from the partition (Direct = false: bucket b owns [bucket_base[b], bucket_base[b+1]))
 // or straight from the operands when the whole table fits one bucket (Direct = true).
-template <typename T, typename I, bool Direct>
+template <typename T, typename I, bool Direct, bool UseLock>
 __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ partials, size_t table_size,
-                                                             const uint32_t *__restrict__ pair_bin,
+                                                             const uint32_t *__restrict__ pair_idx,
                                                              const T *__restrict__ pair_val,
-                                                             const uint32_t *__restrict__ offsets, size_t offsets_stride,
-                                                             const uint32_t *__restrict__ total, Arg<T> value,
+                                                             const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                              const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
                                                              int slices) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -118,23 +241,40 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
     for (int j = threadIdx.x; j < kBins; j += kThreads) acc[j] = T(0);
     __syncthreads();
 
+    size_t begin, end;
     if constexpr (Direct) {
-        const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
-        const T sv = value.vec ? T(0) : arg_scalar(value);
         const size_t per = (n + slices - 1) / slices;
-        const size_t begin = (size_t) slice * per, end = begin + per < n ? begin + per : n;
-        for (size_t i = begin + threadIdx.x; i < end; i += kThreads)
-            if (mask.vec ? mask.ptr[i] : sm)
-                lds_add(&acc[index_u32(index[i]) & (kBins - 1)], value.vec ? value.ptr[i] : sv);
+        begin = (size_t) slice * per;
+        end = begin + per < n ? begin + per : n;
     } else {
-        const int n_buckets = gridDim.x / slices;
-        const size_t lo = offsets[(size_t) bucket * offsets_stride];
-        const size_t hi = bucket + 1 < n_buckets ? (size_t) offsets[(size_t) (bucket + 1) * offsets_stride] : (size_t) *total;
-        const size_t cnt = hi - lo, per = ((cnt + slices - 1) / slices + 3) & ~size_t(3);
-        size_t begin = lo + (size_t) slice * per, end = begin + per < hi ? begin + per : hi;
+        const size_t lo = bucket_base[bucket], hi = bucket_base[bucket + 1];
+        const size_t per = (hi - lo + slices - 1) / slices;
+        begin = lo + (size_t) slice * per;
+        end = begin + per < hi ? begin + per : hi;
         if (begin > hi) begin = hi;
-        for (size_t i = begin + threadIdx.x; i < end; i += kThreads)
-            lds_add(&acc[pair_bin[i]], pair_val[i]);
+    }
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const T sv = value.vec ? T(0) : arg_scalar(value);
+    for (size_t base = begin; base < end; base += (size_t) 4 * kThreads) {
+        uint32_t ix[4];
+        T val[4];
+        bool on[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            size_t i = base + (size_t) k * kThreads + threadIdx.x;
+            on[k] = i < end;
+            if constexpr (Direct) {
+                on[k] = on[k] && (mask.vec ? mask.ptr[i] : sm);
+                ix[k] = i < end ? index_u32(index[i]) : 0u;
+                val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
+            } else {
+                ix[k] = i < end ? pair_idx[i] : 0u;
+                val[k] = i < end ? pair_val[i] : T(0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            lds_add<UseLock>(&acc[ix[k] & (kBins - 1)], val[k], on[k]);
     }
     __syncthreads();
 
@@ -174,9 +314,14 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
         int slices = std::max(1, std::min(2 * c.num_cu, (int) (n / 65536)));
         Scratch partials;
         if (int rc = partials.alloc((size_t) slices * table_size * sizeof(T))) return rc;
-        hipLaunchKernelGGL((k_bin_accumulate<T, I, true>), dim3(slices), dim3(kThreads), lds_bytes, c.stream,
-                           (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, (size_t) 0, nullptr, value,
-                           index.ptr, mask, n, slices);
+        // tiny tables: many lanes of a wave collide on one bin, where the (conflict-insensitive) ds_add_f32
+        // beats the exchange lock; from ~1 Ki bins on collisions inside a wave are rare
+        if (table_size > 1024)
+            hipLaunchKernelGGL((k_bin_accumulate<T, I, true, true>), dim3(slices), dim3(kThreads), lds_bytes, c.stream,
+                               (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices);
+        else
+            hipLaunchKernelGGL((k_bin_accumulate<T, I, true, false>), dim3(slices), dim3(kThreads), lds_bytes, c.stream,
+                               (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices);
         EK_LAUNCH_CHECK("scatter_add_lds", n, algo_bytes);
         hipLaunchKernelGGL((k_bin_fold<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
                            (const T *) partials.ptr, table_size, slices);
@@ -184,35 +329,39 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
         return EK_OK;
     }
 
-    // chunked passes over the input: enough workgroups to fill the chip, chunks of >= 32 Ki elements
-    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + 32767) / 32768);
+    // chunked passes over the input: a few workgroups per CU, chunks are multiples of the tile
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
     if (blocks == 0) blocks = 1;
     size_t chunk = (n + blocks - 1) / blocks;
-    chunk = (chunk + 1023) / 1024 * 1024;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
     blocks = (unsigned) ((n + chunk - 1) / chunk);
 
     const size_t count_entries = (size_t) n_buckets * blocks;
-    Scratch counts, pairs_bin, pairs_val, partials;
-    if (int rc = counts.alloc((count_entries + 1) * sizeof(uint32_t))) return rc;
-    if (int rc = pairs_bin.alloc(n * sizeof(uint32_t))) return rc;
+    Scratch counts, pairs_idx, pairs_val, partials;
+    // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1]
+    if (int rc = counts.alloc((count_entries + 2 * kMaxBuckets + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = pairs_idx.alloc(n * sizeof(uint32_t))) return rc;
     if (int rc = pairs_val.alloc(n * sizeof(T))) return rc;
-    uint32_t *total = (uint32_t *) counts.ptr + count_entries;
+    uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
+    uint32_t *bucket_base = row_total + kMaxBuckets;
 
     hipLaunchKernelGGL((k_bin_count<I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, index.ptr,
                        mask, n, chunk, n_buckets);
     EK_LAUNCH_CHECK("scatter_add_count", n, arg_bytes(index, n) + arg_bytes(mask, n));
-    hipLaunchKernelGGL(k_bin_scan, dim3(1), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, count_entries, total);
+    hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_buckets), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
+    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (const uint32_t *) row_total,
+                       n_buckets);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
-    hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) pairs_bin.ptr,
-                       (T *) pairs_val.ptr, (const uint32_t *) counts.ptr, value, index.ptr, mask, n, chunk, n_buckets);
+    hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) pairs_idx.ptr,
+                       (T *) pairs_val.ptr, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, value, index.ptr,
+                       mask, n, chunk, n_buckets);
     EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint32_t) + sizeof(T)));
 
     int slices = std::max(1, (4 * c.num_cu + n_buckets - 1) / n_buckets);
     if (int rc = partials.alloc((size_t) slices * table_size * sizeof(T))) return rc;
-    hipLaunchKernelGGL((k_bin_accumulate<T, I, false>), dim3((unsigned) (n_buckets * slices)), dim3(kThreads), lds_bytes,
-                       c.stream, (T *) partials.ptr, table_size, (const uint32_t *) pairs_bin.ptr,
-                       (const T *) pairs_val.ptr, (const uint32_t *) counts.ptr, (size_t) blocks, (const uint32_t *) total,
-                       value, index.ptr, mask, n, slices);
+    hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3((unsigned) (n_buckets * slices)), dim3(kThreads), lds_bytes,
+                       c.stream, (T *) partials.ptr, table_size, (const uint32_t *) pairs_idx.ptr,
+                       (const T *) pairs_val.ptr, (const uint32_t *) bucket_base, value, index.ptr, mask, n, slices);
     EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint32_t) + sizeof(T)) + (size_t) slices * table_size * sizeof(T));
     hipLaunchKernelGGL((k_bin_fold<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
                        (const T *) partials.ptr, table_size, slices);
