@@ -74,11 +74,11 @@ def main():
         A0 = synth.uniform_pm1(0, K_TABLE, 6); B0 = synth.uniform_pm1(0, K_TABLE, 7)
         idx = ek.UInt32(synth.index_mod(begin, n, 4, K_TABLE))
         xd = ek.Float32(x)
-        packer = ekd.Packer([1, K_TABLE, K_TABLE], dev) if world > 1 else None
+        packer = ekd.Packer([1, K_TABLE, K_TABLE], dev) if ekd.active() else None
     else:
         a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
         xd = ek.Float32(x)
-        packer = ekd.Packer([1], dev) if world > 1 else None
+        packer = ekd.Packer([1], dev) if ekd.active() else None
     ek.hip_sync()
 
     out = {}
@@ -172,7 +172,7 @@ def main():
                 "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves",
                 "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))"}[args.workload],
                 "elements_total": N, "elements_per_gpu": n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
-                "sharding": f"index-range x{world}", "collectives_per_step": 1 if world > 1 else 0},
+                "sharding": f"index-range x{world}", "collectives_per_step": 1 if packer else 0},
             "result_y": y_val,
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -30,7 +30,9 @@ def env_rank_world():
 def init(backend=None):
     """Initialise the process group (no-op for a single process).  Returns (rank, local_rank, world)."""
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # under a launcher (RANK set) the group is created even for one rank, so that a 1-GPU torchrun run
+    # exercises exactly the code path of the multi-GPU runs
+    if (world > 1 or "RANK" in os.environ) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -55,7 +57,7 @@ def as_tensor(array):
 
 def all_reduce_(tensor, op="sum"):
     """in-place all-reduce; identity for a single process"""
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         rop = {"sum": dist.ReduceOp.SUM, "prod": dist.ReduceOp.PRODUCT, "max": dist.ReduceOp.MAX,
                "min": dist.ReduceOp.MIN}[op]
         dist.all_reduce(tensor, op=rop)
@@ -87,14 +89,19 @@ class Packer:
         return [self.slot(i) for i in range(len(self.sizes))]
 
 
+def active():
+    """True when collectives are live (a process group exists)"""
+    return dist.is_initialized()
+
+
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_initialized():
         dist.barrier()
 
 
 def max_over_ranks(value):
     """max of a python float over all ranks (CPU side channel: works with nccl and gloo)"""
-    if not (dist.is_initialized() and dist.get_world_size() > 1):
+    if not dist.is_initialized():
         return value
     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=dev)
