@@ -117,6 +117,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+    if packer:
+        packer.wait_all()                 # every step's all-reduce has completed inside the timed region
     torch.cuda.synchronize(); ekd.barrier()
     elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
     ms_per_step = elapsed / args.steps * 1e3
@@ -127,6 +129,8 @@ def main():
     for _ in range(args.profile_steps):
         step()
     prof = json.loads(ek.hip_profile_end())
+    if packer:
+        packer.wait_all()
     torch.cuda.synchronize()
     kernels = []
     for k in prof:

@@ -65,28 +65,49 @@ def all_reduce_(tensor, op="sum"):
 
 
 class Packer:
-    """Flat staging buffer: several pending sum-reductions (scalars and K-vectors) -> ONE all-reduce.
+    """Flat staging buffers: several pending sum-reductions (scalars and K-vectors) -> ONE all-reduce.
 
     xGMI is point-to-point, so a ring all-reduce pays per-link latency per collective: batching the
-    1-element hsum results with the K-element gradient buffers keeps backward() at a single collective."""
+    1-element hsum results with the K-element gradient buffers keeps backward() at a single collective.
+    The collective is issued asynchronously (RCCL's own stream, ordered after the compute stream at issue
+    time) and `depth` staging buffers rotate, so the all-reduce of step i overlaps the kernels of step i+1;
+    a buffer is only waited for when it comes up for reuse (or in `wait_all`)."""
 
-    def __init__(self, sizes, device, dtype=torch.float32):
+    def __init__(self, sizes, device, dtype=torch.float32, depth=2):
         self.sizes = list(sizes)
         self.offsets = [0]
         for s in self.sizes:
             self.offsets.append(self.offsets[-1] + s)
-        self.flat = torch.empty(self.offsets[-1], device=device, dtype=dtype)
+        self.bufs = [torch.empty(self.offsets[-1], device=device, dtype=dtype) for _ in range(depth)]
+        self.work = [None] * depth
+        self.cur = 0
+        self.flat = self.bufs[0]
 
-    def slot(self, i):
-        return self.flat[self.offsets[i]:self.offsets[i + 1]]
+    def slot(self, i, buf=None):
+        flat = self.flat if buf is None else buf
+        return flat[self.offsets[i]:self.offsets[i + 1]]
 
     def pack(self, tensors):
+        self.cur = (self.cur + 1) % len(self.bufs)
+        if self.work[self.cur] is not None:        # the buffer's previous collective must have finished
+            self.work[self.cur].wait()
+            self.work[self.cur] = None
+        self.flat = self.bufs[self.cur]
         for i, t in enumerate(tensors):
             self.slot(i).copy_(t.reshape(-1), non_blocking=True)
 
-    def all_reduce(self):
-        all_reduce_(self.flat, "sum")
+    def all_reduce(self, async_op=True):
+        """start the all-reduce of the buffer filled by the last pack(); returns its slots (valid after wait)"""
+        if dist.is_initialized():
+            w = dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, async_op=async_op)
+            self.work[self.cur] = w if async_op else None
         return [self.slot(i) for i in range(len(self.sizes))]
+
+    def wait_all(self):
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
 
 
 def active():

@@ -13,6 +13,7 @@
 */
 #pragma once
 
+#include <algorithm>
 #include <array>
 #include <cstddef>
 #include <cstdint>
@@ -348,6 +349,191 @@ inline void scatter_add(Target &target, const Value &value, const Index &index, 
     Target::template scatter_add_array_<IsPermute>(target, detail::as<Target>(value), index,
                                                    detail::as<mask_t<Index>>(mask));
 }
+
+// ---------------------------------------------------------------------------------------------
+//  Static arrays: Array<Value, N> -- N components stored side by side (SoA when Value is itself a
+//  dynamic array, e.g. Array<HIPArray<float>, 3> = three independent device arrays).  Every
+//  operation is applied component by component through the free functions above, so it costs N
+//  kernel launches on the device backend.  Component order of horizontal operations follows the
+//  reference's generic static array: hsum = ((c0 + c1) + c2) ..., dot = fmadd(a2, b2, fmadd(a1, b1,
+//  a0 * b0)) (array_static.h:948-960).
+// ---------------------------------------------------------------------------------------------
+template <typename Value_, size_t Size_> struct Array : ArrayTag {
+    using Value = Value_;
+    using Scalar = scalar_t<Value_>;
+    using ArrayType = Array;
+    using MaskType = Array<mask_t<Value_>, Size_>;
+    template <typename T> using ReplaceScalar = Array<replace_scalar_t<Value_, T>, Size_>;
+    template <typename T> using ReplaceValue = Array<T, Size_>;
+    template <typename T> using ReplaceMaskValue = Array<replace_scalar_t<Value_, T>, Size_>;
+
+    static constexpr size_t Size = Size_;
+    static constexpr size_t Depth = array_depth_v<Value_> + 1;
+    static constexpr size_t Rank = detail::rank<Value_>::value + 4;
+    static constexpr bool IsMask = is_mask_v<Value_>;
+    static constexpr bool IsDiff = is_diff_array_v<Value_>;
+    static constexpr bool IsDynamic = is_dynamic_v<Value_>;
+    static constexpr bool IsDevice = is_device_array_v<Value_>;
+
+    Array() = default;
+
+    /// Broadcast a scalar or an inner array to all components
+    template <typename T, enable_if_t<std::is_arithmetic_v<T> || std::is_same_v<std::decay_t<T>, Value_>> = 0>
+    Array(const T &v) { for (size_t i = 0; i < Size; ++i) m_data[i] = Value(v); }
+
+    /// One initializer per component
+    template <typename... Args, enable_if_t<sizeof...(Args) == Size_ && (Size_ > 1) &&
+                                            (std::is_constructible_v<Value_, const Args &> && ...)> = 0>
+    Array(const Args &... args) : m_data{ Value(args)... } { }
+
+    /// Component-wise conversion
+    template <typename V2, enable_if_t<!std::is_same_v<V2, Value_>> = 0>
+    Array(const Array<V2, Size_> &a) { for (size_t i = 0; i < Size; ++i) m_data[i] = Value(a.coeff(i)); }
+
+    template <typename V2> Array(const Array<V2, Size_> &a, detail::reinterpret_flag) {
+        for (size_t i = 0; i < Size; ++i) m_data[i] = reinterpret_array<Value>(a.coeff(i));
+    }
+
+    Value &coeff(size_t i) { return m_data[i]; }
+    const Value &coeff(size_t i) const { return m_data[i]; }
+    Value &operator[](size_t i) { return m_data[i]; }
+    const Value &operator[](size_t i) const { return m_data[i]; }
+    Value &x() { return m_data[0]; }
+    const Value &x() const { return m_data[0]; }
+    Value &y() { static_assert(Size >= 2); return m_data[1]; }
+    const Value &y() const { static_assert(Size >= 2); return m_data[1]; }
+    Value &z() { static_assert(Size >= 3); return m_data[2]; }
+    const Value &z() const { static_assert(Size >= 3); return m_data[2]; }
+    Value &w() { static_assert(Size >= 4); return m_data[3]; }
+    const Value &w() const { static_assert(Size >= 4); return m_data[3]; }
+    static constexpr size_t size() { return Size; }
+
+#define ENOKI_HIP_STATIC_UNARY(name, func)                                                        \
+    Array name##_() const { Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = func(m_data[i]); return r; }
+#define ENOKI_HIP_STATIC_BINARY(name, expr)                                                       \
+    Array name##_(const Array &o) const {                                                         \
+        Array r;                                                                                  \
+        for (size_t i = 0; i < Size; ++i) { const Value &a = m_data[i], &b = o.m_data[i]; r.m_data[i] = expr; } \
+        return r;                                                                                 \
+    }
+#define ENOKI_HIP_STATIC_COMPARE(name, expr)                                                      \
+    MaskType name##_(const Array &o) const {                                                      \
+        MaskType r;                                                                               \
+        for (size_t i = 0; i < Size; ++i) { const Value &a = m_data[i], &b = o.m_data[i]; r.coeff(i) = expr; } \
+        return r;                                                                                 \
+    }
+
+    ENOKI_HIP_STATIC_UNARY(neg, operator-) ENOKI_HIP_STATIC_UNARY(not, operator~) ENOKI_HIP_STATIC_UNARY(abs, enoki::abs)
+    ENOKI_HIP_STATIC_UNARY(sqrt, enoki::sqrt) ENOKI_HIP_STATIC_UNARY(rcp, enoki::rcp) ENOKI_HIP_STATIC_UNARY(rsqrt, enoki::rsqrt)
+    ENOKI_HIP_STATIC_UNARY(floor, enoki::floor) ENOKI_HIP_STATIC_UNARY(ceil, enoki::ceil)
+    ENOKI_HIP_STATIC_UNARY(round, enoki::round) ENOKI_HIP_STATIC_UNARY(trunc, enoki::trunc)
+    ENOKI_HIP_STATIC_UNARY(sin, enoki::sin) ENOKI_HIP_STATIC_UNARY(cos, enoki::cos) ENOKI_HIP_STATIC_UNARY(exp, enoki::exp)
+    ENOKI_HIP_STATIC_UNARY(log, enoki::log) ENOKI_HIP_STATIC_UNARY(sign, enoki::sign)
+    ENOKI_HIP_STATIC_BINARY(add, a + b) ENOKI_HIP_STATIC_BINARY(sub, a - b) ENOKI_HIP_STATIC_BINARY(mul, a * b)
+    ENOKI_HIP_STATIC_BINARY(div, a / b) ENOKI_HIP_STATIC_BINARY(mod, a % b) ENOKI_HIP_STATIC_BINARY(min, enoki::min(a, b))
+    ENOKI_HIP_STATIC_BINARY(max, enoki::max(a, b)) ENOKI_HIP_STATIC_BINARY(and, a & b) ENOKI_HIP_STATIC_BINARY(or, a | b)
+    ENOKI_HIP_STATIC_BINARY(xor, a ^ b) ENOKI_HIP_STATIC_BINARY(sl, a << b) ENOKI_HIP_STATIC_BINARY(sr, a >> b)
+    ENOKI_HIP_STATIC_COMPARE(eq, enoki::eq(a, b)) ENOKI_HIP_STATIC_COMPARE(neq, enoki::neq(a, b))
+    ENOKI_HIP_STATIC_COMPARE(lt, a < b) ENOKI_HIP_STATIC_COMPARE(le, a <= b)
+    ENOKI_HIP_STATIC_COMPARE(gt, a > b) ENOKI_HIP_STATIC_COMPARE(ge, a >= b)
+#undef ENOKI_HIP_STATIC_UNARY
+#undef ENOKI_HIP_STATIC_BINARY
+#undef ENOKI_HIP_STATIC_COMPARE
+
+    Array fmadd_(const Array &b, const Array &c) const {
+        Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = enoki::fmadd(m_data[i], b.m_data[i], c.m_data[i]); return r;
+    }
+    Array fmsub_(const Array &b, const Array &c) const {
+        Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = enoki::fmsub(m_data[i], b.m_data[i], c.m_data[i]); return r;
+    }
+    Array fnmadd_(const Array &b, const Array &c) const {
+        Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = enoki::fnmadd(m_data[i], b.m_data[i], c.m_data[i]); return r;
+    }
+    Array fnmsub_(const Array &b, const Array &c) const {
+        Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = enoki::fnmsub(m_data[i], b.m_data[i], c.m_data[i]); return r;
+    }
+
+    template <typename T = Value_, enable_if_t<!is_mask_v<T>> = 0> Array and_(const MaskType &m) const {
+        Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = m_data[i] & m.coeff(i); return r;
+    }
+    template <typename T = Value_, enable_if_t<!is_mask_v<T>> = 0> Array or_(const MaskType &m) const {
+        Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = m_data[i] | m.coeff(i); return r;
+    }
+
+    static Array select_(const MaskType &m, const Array &t, const Array &f) {
+        Array r;
+        for (size_t i = 0; i < Size; ++i) r.m_data[i] = enoki::select(m.coeff(i), t.m_data[i], f.m_data[i]);
+        return r;
+    }
+
+    /// Horizontal operations run over the COMPONENTS (array_static.h hsum_/hprod_/dot_)
+    Value hsum_() const { Value r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = r + m_data[i]; return r; }
+    Value hprod_() const { Value r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = r * m_data[i]; return r; }
+    Value hmin_() const { Value r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = enoki::min(r, m_data[i]); return r; }
+    Value hmax_() const { Value r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = enoki::max(r, m_data[i]); return r; }
+    Value dot_(const Array &o) const {
+        Value r = m_data[0] * o.m_data[0];
+        for (size_t i = 1; i < Size; ++i) r = enoki::fmadd(m_data[i], o.m_data[i], r);
+        return r;
+    }
+    auto all_() const { auto r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = r & m_data[i]; return r; }
+    auto any_() const { auto r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = r | m_data[i]; return r; }
+
+    /// Dynamic (slice) interface when the components are dynamic arrays
+    size_t slices_() const { size_t n = 0; for (size_t i = 0; i < Size; ++i) n = std::max(n, slices(m_data[i])); return n; }
+    void set_slices_(size_t n) { for (size_t i = 0; i < Size; ++i) set_slices(m_data[i], n); }
+
+    static Array zero_(size_t n = 1) { Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = zero<Value>(n); return r; }
+    static Array empty_(size_t n = 1) { Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = empty<Value>(n); return r; }
+    static Array full_(const Scalar &v, size_t n = 1) { Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = full<Value>(v, n); return r; }
+
+    /// Component-wise gather/scatter of SoA structures (struct_support, array_struct.h:432-465)
+    template <bool IsPermute, typename Index, typename Mask>
+    static Array gather_array_(const Array &source, const Index &index, const Mask &mask) {
+        Array r;
+        for (size_t i = 0; i < Size; ++i) r.m_data[i] = gather<Value, 0, true, IsPermute>(source.m_data[i], index, mask);
+        return r;
+    }
+    template <bool IsPermute, typename Index, typename Mask>
+    static void scatter_array_(Array &target, const Array &value, const Index &index, const Mask &mask) {
+        for (size_t i = 0; i < Size; ++i) scatter<0, true, IsPermute>(target.m_data[i], value.m_data[i], index, mask);
+    }
+    template <bool IsPermute, typename Index, typename Mask>
+    static void scatter_add_array_(Array &target, const Array &value, const Index &index, const Mask &mask) {
+        for (size_t i = 0; i < Size; ++i) scatter_add<0, true, IsPermute>(target.m_data[i], value.m_data[i], index, mask);
+    }
+
+private:
+    Value m_data[Size_];
+};
+
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto dot(const T &a, const T &b) { return a.dot_(b); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto squared_norm(const T &a) { return a.dot_(a); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto norm(const T &a) { return sqrt(a.dot_(a)); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T normalize(const T &a) { return a * rsqrt(squared_norm(a)); }
+template <typename V> inline Array<V, 3> cross(const Array<V, 3> &a, const Array<V, 3> &b) {
+    return Array<V, 3>(fmsub(a.y(), b.z(), a.z() * b.y()), fmsub(a.z(), b.x(), a.x() * b.z()),
+                       fmsub(a.x(), b.y(), a.y() * b.x()));
+}
+
+/// meshgrid for dynamic device arrays (array_utils.h:23-48): x varies fastest
+template <typename T, enable_if_t<is_array_v<T> && is_dynamic_v<T> && array_depth_v<T> == 1> = 0>
+inline Array<T, 2> meshgrid(const T &x, const T &y) {
+    using UInt32 = uint32_array_t<T>;
+    uint32_t nx = (uint32_t) slices(x), n = nx * (uint32_t) slices(y);
+    UInt32 index = arange<UInt32>(n), yi = index / UInt32(nx), xi = index - yi * UInt32(nx);
+    return Array<T, 2>(gather<T>(x, xi), gather<T>(y, yi));
+}
+
+/// Structure-of-arrays helpers for user types, mirroring ENOKI_STRUCT (array_macro.h:216-359): member-wise
+/// constructors so that `Ray<Vector3fC>(o, d)` works for any vector type
+#define ENOKI_STRUCT(Struct, ...)                                                                 \
+    Struct() = default;                                                                           \
+    Struct(const Struct &) = default;                                                             \
+    Struct(Struct &&) = default;                                                                  \
+    Struct &operator=(const Struct &) = default;                                                  \
+    Struct &operator=(Struct &&) = default;
+#define ENOKI_STRUCT_SUPPORT(Struct, ...)
 
 // ---------------------------------------------------------------------------------------------
 //  Autodiff helpers that are no-ops for non-differentiable types (autodiff.h:1414-1500)

@@ -692,3 +692,36 @@ float orc_cfg3b(const float *A, const float *B, size_t k, const float *x, const 
     free(s); free(c); free(gu); free(ga); free(av); free(bv);
     return y;
 }
+
+/* cfg4: masked gather -> ray/sphere intersection -> shading -> masked scatter -> hit count.
+ * Arithmetic order of the user-level kernels (tests/sphere.cpp:58-83) on Array<Packet, 3>:
+ *   dot(u, v) = fmadd(u2, v2, fmadd(u1, v1, u0*v0))                     (array_static.h:948-960)
+ *   a = dot(d,d); b = 2*dot(o,d); c = dot(o,o) - 1; discrim = b*b - (4*a)*c   (operators: separate roundings)
+ *   t = (-b + sqrt(discrim)) / (2*a); pos = o + t*d; hit = discrim >= 0; pos = select(hit, pos, 0)
+ *   shade = 0.2 + max(dot(pos, (-1,-1,2)), 0) * 90 */
+static inline float dot3(const float *u, const float *v) { return fmaf(u[2], v[2], fmaf(u[1], v[1], u[0] * v[0])); }
+
+int orc_cfg4(const float *gx, const float *gy, const uint32_t *perm, const uint8_t *mask, size_t n, float *image,
+             uint64_t *hit_count) {
+    uint64_t hits = 0;
+    float *shade = (float *) malloc(n * sizeof(float));
+    uint8_t *hit = (uint8_t *) malloc(n);
+    for (size_t i = 0; i < n; ++i) {
+        float px = mask[i] ? gx[perm[i]] : 0.0f, py = mask[i] ? gy[perm[i]] : 0.0f;
+        float o[3] = { px, py, -1.0f }, d[3] = { 0.0f, 0.0f, 1.0f };
+        float a = dot3(d, d), b = 2.0f * dot3(o, d), c = dot3(o, o) - 1.0f;
+        float t4 = 4.0f * a;
+        float discrim = b * b - t4 * c;
+        float t = (-b + sqrtf(discrim)) / (2.0f * a);
+        int h = discrim >= 0.0f;
+        float pos[3], lightdir[3] = { -1.0f, -1.0f, 2.0f };
+        for (int k = 0; k < 3; ++k) { float td = t * d[k]; pos[k] = h ? o[k] + td : 0.0f; }
+        shade[i] = 0.2f + max_ps(dot3(pos, lightdir), 0.0f) * 90.0f;
+        hit[i] = (uint8_t) (h && mask[i]);
+    }
+    for (size_t i = 0; i < n; ++i)
+        if (hit[i]) { image[perm[i]] = shade[i]; hits++; }
+    *hit_count = hits;
+    free(shade); free(hit);
+    return 0;
+}

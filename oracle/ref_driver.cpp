@@ -566,4 +566,63 @@ int ref_tape_program(const int32_t *prog, size_t n_ops, const float *const *inpu
     return 0;
 }
 
+
+/* ------------------------------------------------------------------ */
+/* BASELINE config 4: masked gather/scatter ray-sphere intersection.    */
+/* The three kernels are the user-level program of tests/sphere.cpp     */
+/* (make_rays 58-64, intersect_rays 67-78, shade_hits 81-83) written    */
+/* against the reference's own Array<FloatX, N> types; the surrounding  */
+/* gather / scatter / count follow SURVEY.md 8d (cfg4).                 */
+/* ------------------------------------------------------------------ */
+} // extern "C" (templates below)
+
+namespace {
+using Vector2fX = Array<FloatX, 2>;
+using Vector3fX = Array<FloatX, 3>;
+using MaskX = mask_t<FloatX>;
+
+template <typename Vector3> struct RayT {
+    Vector3 o, d;
+    Vector3 operator()(const value_t<Vector3> &t) const { return o + t * d; }
+};
+
+template <typename Vector2> auto sphere_make_rays(const Vector2 &p) {
+    using Vector3 = Array<value_t<Vector2>, 3>;
+    return RayT<Vector3>{ Vector3(p.x(), p.y(), -1.f), Vector3(0.f, 0.f, 1.f) };
+}
+
+template <typename Ray, typename Mask> auto sphere_intersect(const Ray &r, Mask &hit) {
+    auto a = dot(r.d, r.d);
+    auto b = 2.f * dot(r.o, r.d);
+    auto c = dot(r.o, r.o) - 1.f;
+    auto discrim = b * b - 4.f * a * c;
+    auto t = (-b + sqrt(discrim)) / (2.f * a);
+    hit = discrim >= 0.f;
+    return select(hit, r(t), 0.f);
+}
+
+template <typename Vector3> auto sphere_shade(const Vector3 &n) {
+    return 0.2f + max(dot(n, Vector3(-1.f, -1.f, 2.f)), 0.f) * 90.f;
+}
+} // namespace
+
+extern "C" {
+
+int ref_cfg4(const float *gx, const float *gy, const uint32_t *perm_, const uint8_t *mask_, size_t n,
+             float *image /* n, pre-initialised by the caller */, uint64_t *hit_count) {
+    Vector2fX p(FloatX::copy(gx, n), FloatX::copy(gy, n));
+    UInt32X perm = UInt32X::copy(perm_, n);
+    MaskX mask = MaskX(load_mask<float>(mask_, n));
+    Vector2fX pp = gather<Vector2fX>(p, perm, mask);
+    MaskX hit;
+    auto pos = sphere_intersect(sphere_make_rays(pp), hit);
+    FloatX shade = sphere_shade(pos);
+    hit = hit & mask;
+    FloatX img = FloatX::copy(image, n);
+    scatter(img, shade, perm, hit);
+    store(img, image, n);
+    *hit_count = count(hit);
+    return 0;
+}
+
 } // extern "C"

@@ -80,3 +80,9 @@ for nn in (1000, 65536):
     y, gA, gB, _ = R.cfg3b(TA, TB, X, I); cfg[f"cfg3b_{nn}_y"] = np.array([y], np.float32); cfg[f"cfg3b_{nn}_gA"] = gA; cfg[f"cfg3b_{nn}_gB"] = gB
 np.savez_compressed(os.path.join(HERE, "configs.npz"), **cfg)
 print("golden fixtures written to", HERE)
+
+# ---- BASELINE config 4 (ray-sphere, masked gather/scatter) -------------------------------------------
+from test_sphere_gpu import scene, run  # noqa: E402
+gx, gy, perm, mask = scene(64, seed=1)
+img, h = run(R.lib.ref_cfg4, gx, gy, perm, mask)
+np.savez_compressed(os.path.join(HERE, "cfg4.npz"), gx=gx, gy=gy, perm=perm, mask=mask, image=img, hits=np.array(h))

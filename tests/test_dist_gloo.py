@@ -35,7 +35,8 @@ y, gA, gB, _ = P.cfg3b(A, B, np.ascontiguousarray(x), np.ascontiguousarray(idx))
 
 packer = ekd.Packer([1, K, K], "cpu")
 packer.pack([torch.tensor([y], dtype=torch.float32), torch.from_numpy(gA), torch.from_numpy(gB)])
-ty, tgA, tgB = packer.all_reduce()                     # ONE collective
+ty, tgA, tgB = packer.all_reduce()                     # ONE collective, asynchronous
+packer.wait_all()
 t = ekd.max_over_ranks(float(rank + 1))
 ekd.barrier()
 if rank == 0:

@@ -1,0 +1,77 @@
+"""BASELINE config 4: masked gather / scatter ray-sphere intersection (tests/sphere.cpp, tests/ray.h) on
+Array<HIPArray<float>, 3>.  Every op on this path is class A (mul/add/fma/sqrt/div/select/max, gather, scatter with a
+permutation, count), so the image must be BIT-EXACT against the reference build and the hit count equal."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+HAVE_REF = os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "libenoki_ref.so"))
+
+
+def scene(res, seed=0, shard=None):
+    n = res * res
+    lin = ol.port().linspace(-1.2, 1.2, res) if False else None
+    step = (np.float32(1.2) - np.float32(-1.2)) / np.float32(res - 1)
+    lin = (np.arange(res, dtype=np.float32) * step + np.float32(-1.2)).astype(np.float32)   # fmadd(i, step, min) below
+    lin = np.array([np.float32(np.float64(i) * np.float64(step) + np.float64(np.float32(-1.2))) for i in range(res)], np.float32)
+    gx, gy = np.tile(lin, res), np.repeat(lin, res)
+    rng = np.random.default_rng(seed)
+    perm = rng.permutation(n).astype(np.uint32)
+    mask = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+    return gx, gy, perm, mask
+
+
+def run(fn, gx, gy, perm, mask):
+    n = gx.size
+    img = np.full(n, -1.0, np.float32)
+    hc = ctypes.c_uint64()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = fn(p(gx), p(gy), p(perm), p(mask), ctypes.c_size_t(n), p(img), ctypes.byref(hc))
+    assert rc == 0
+    return img, hc.value
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref was not built")
+@pytest.mark.parametrize("res", [8, 64, 257])
+def test_oracle_cfg4_matches_reference_build(res):
+    args = scene(res)
+    ri, rh = run(ol.ref().lib.ref_cfg4, *args)
+    pi, ph = run(ol.port().lib.orc_cfg4, *args)
+    assert rh == ph and np.array_equal(ri.view(np.uint32), pi.view(np.uint32))
+
+
+def test_oracle_cfg4_matches_golden():
+    z = np.load(os.path.join(HERE, "golden", "cfg4.npz"))
+    pi, ph = run(ol.port().lib.orc_cfg4, z["gx"], z["gy"], z["perm"], z["mask"])
+    assert ph == int(z["hits"]) and np.array_equal(pi.view(np.uint32), z["image"].view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("res", [8, 64, 257, 1024])
+def test_hip_cfg4_bit_exact(res):
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libsphere_hip.so"))
+    args = scene(res, seed=res)
+    gi, gh = run(lib.hip_cfg4, *args)
+    pi, ph = run(ol.port().lib.orc_cfg4, *args)           # oracle (pinned to the reference build above)
+    assert gh == ph
+    assert np.array_equal(gi.view(np.uint32), pi.view(np.uint32))
+    if HAVE_REF:
+        ri, rh = run(ol.ref().lib.ref_cfg4, *args)
+        assert rh == gh and np.array_equal(ri.view(np.uint32), gi.view(np.uint32))
+    assert gh > 0 and gi.max() > 100
+
+
+@pytest.mark.gpu
+def test_hip_meshgrid_linspace_grid():
+    """the pixel grid built by the product's own linspace + meshgrid (closed form fmadd(i, step, min))"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libsphere_hip.so"))
+    res = 300
+    gx = np.zeros(res * res, np.float32); gy = np.zeros(res * res, np.float32)
+    assert lib.hip_sphere_grid(ctypes.c_size_t(res), gx.ctypes.data_as(ctypes.c_void_p), gy.ctypes.data_as(ctypes.c_void_p)) == 0
+    egx, egy, _, _ = scene(res)
+    assert np.array_equal(gx.view(np.uint32), egx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), egy.view(np.uint32))
