@@ -13,9 +13,13 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
   cfg3a a, b leaves of size N: y = hsum(sin(fmadd(a, x, b))); backward(y)
   cfg2  plain HIPArray: y = hsum(sin(exp(fmadd(a, x, b))))
 
+`value` is the headline workload (cfg3b unless --workload says otherwise).  On one GPU the other two GPU
+configurations of BASELINE.md section 4 are measured in the same run and reported under "also" (same timing
+method), because the three have separate pass lines.
+
 Multi-GPU (one process per GPU, launched by torch.distributed.run): the N-element arrays are index-range
-sharded (STRONG scaling: N total is fixed), the K-element tables are replicated; per step ONE RCCL all-reduce
-finishes y and the table gradients (enoki_amd/dist.py).
+sharded (STRONG scaling: N total is fixed), the K-element tables are replicated; per step ONE asynchronous
+RCCL all-reduce finishes y and the table gradients (enoki_amd/dist.py) and overlaps the next step's kernels.
 
 The JSON line carries, besides the contract fields, `roofline` for the dominant kernel (live per-launch timing
 with HIP events on the library stream, ek_hip_profile_*) and `cpu_baseline` (the reference build oracle/_ref, or
@@ -35,6 +39,15 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_TBS = 8.0           # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 K_TABLE = 1 << 20
+DESCRIPTION = {
+    "cfg3b": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)), a=gather(A,idx), b=gather(B,idx), K=1Mi; backward() with scatter_add grads",
+    "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves of size N",
+    "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))",
+}
+# kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
+PMC_SYMBOL = {"gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
+              "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",
+              "safe_mul": "k_map2<BinaryOp<13", "hsum": "k_reduce_stage1", "sin": "k_map1<UnaryOp<10", "exp": "k_map1<UnaryOp<12"}
 
 
 def parse():
@@ -45,142 +58,156 @@ def parse():
     ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2"])
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5)
     return ap.parse_args()
 
 
-def main():
-    args = parse()
-    import torch
-    import enoki_amd.hip as ekc
-    import enoki_amd.hip_autodiff as ek
-    from enoki_amd import dist as ekd, synth
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes,
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/rocprof_summary.py), or None"""
+    path = os.path.join(ROOT, "profiles", "rocprof_pmc_r01.txt")
+    sym = PMC_SYMBOL.get(kernel)
+    if not sym or not os.path.exists(path):
+        return None
+    best = None
+    for line in open(path):
+        if line.startswith(sym):
+            f = line.split()
+            try:
+                grid, rd, wr = int(f[-4]), float(f[-2]), float(f[-1])
+            except ValueError:
+                continue
+            if best is None or grid > best[0]:
+                best = (grid, (rd + wr) * 1e6)
+    return int(best[1]) if best else None
 
-    rank, local_rank, world = ekd.init()
-    if world != args.gpus and rank == 0:
-        print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
-    ek.hip_init(local_rank)
-    ekd.adopt_torch_stream(ek)          # kernels + RCCL on one stream order
-    dev = torch.device("cuda", local_rank)
 
-    N = args.n
-    begin, end = ekd.shard_range(N, rank, world)
-    n = end - begin
+class Bench:
+    def __init__(self, args):
+        import torch
+        import enoki_amd.hip as ekc
+        import enoki_amd.hip_autodiff as ek
+        from enoki_amd import dist as ekd, synth
+        self.torch, self.ekc, self.ek, self.ekd, self.synth, self.args = torch, ekc, ek, ekd, synth, args
+        self.rank, self.local_rank, self.world = ekd.init()
+        if self.world != args.gpus and self.rank == 0:
+            print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={self.world}", file=sys.stderr)
+        torch.cuda.set_device(self.local_rank)          # torch's HIP runtime initialises first
+        ek.hip_init(self.local_rank)
+        ekd.adopt_torch_stream(ek)                        # kernels + RCCL ordered by one stream
+        self.dev = torch.device("cuda", self.local_rank)
+        self.N = args.n
+        self.begin, self.end = ekd.shard_range(self.N, self.rank, self.world)
+        self.n = self.end - self.begin
 
-    # ---- synthetic inputs, generated on the device (seeds as in SURVEY.md 8d) ----------------------
-    x = synth.uniform_pm1(begin, n, 2)
-    if args.workload == "cfg3b":
-        A0 = synth.uniform_pm1(0, K_TABLE, 6); B0 = synth.uniform_pm1(0, K_TABLE, 7)
-        idx = ek.UInt32(synth.index_mod(begin, n, 4, K_TABLE))
-        xd = ek.Float32(x)
-        packer = ekd.Packer([1, K_TABLE, K_TABLE], dev) if ekd.active() else None
-    else:
-        a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
-        xd = ek.Float32(x)
-        packer = ekd.Packer([1], dev) if ekd.active() else None
-    ek.hip_sync()
+    def make_step(self, workload):
+        """returns (step_fn, packer, out_dict); inputs are generated on the device (seeds of SURVEY.md 8d)"""
+        ek, ekc, ekd, synth = self.ek, self.ekc, self.ekd, self.synth
+        n, begin = self.n, self.begin
+        x = synth.uniform_pm1(begin, n, 2)
+        out = {}
+        if workload == "cfg3b":
+            A0 = synth.uniform_pm1(0, K_TABLE, 6); B0 = synth.uniform_pm1(0, K_TABLE, 7)
+            idx = ek.UInt32(synth.index_mod(begin, n, 4, K_TABLE))
+            xd = ek.Float32(x)
+            packer = ekd.Packer([1, K_TABLE, K_TABLE], self.dev) if ekd.active() else None
 
-    out = {}
+            def step():
+                A = ek.Float32(A0); B = ek.Float32(B0)
+                ek.set_requires_gradient(A); ek.set_requires_gradient(B)
+                a = ek.gather(A, idx); b = ek.gather(B, idx)
+                y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
+                ek.backward(y)
+                gA = ek.gradient(A); gB = ek.gradient(B)
+                if packer:
+                    packer.pack([ekd.as_tensor(ek.detach(y)), ekd.as_tensor(gA), ekd.as_tensor(gB)])
+                    packer.all_reduce()
+                out["y"] = ek.detach(y)
+        elif workload == "cfg3a":
+            a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
+            xd = ek.Float32(x)
+            packer = ekd.Packer([1], self.dev) if ekd.active() else None
 
-    def step():
-        if args.workload == "cfg3b":
-            A = ek.Float32(A0); B = ek.Float32(B0)
-            ek.set_requires_gradient(A); ek.set_requires_gradient(B)
-            a = ek.gather(A, idx); b = ek.gather(B, idx)
-            y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
-            ek.backward(y)
-            gA = ek.gradient(A); gB = ek.gradient(B)
-            if packer:
-                packer.pack([ekd.as_tensor(ek.detach(y)), ekd.as_tensor(gA), ekd.as_tensor(gB)])
-                packer.all_reduce()
-            out["y"], out["gA"], out["gB"] = y, gA, gB
-        elif args.workload == "cfg3a":
-            a = ek.Float32(a0); b = ek.Float32(b0)
-            ek.set_requires_gradient(a); ek.set_requires_gradient(b)
-            y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
-            ek.backward(y)
-            if packer:
-                packer.pack([ekd.as_tensor(ek.detach(y))])
-                packer.all_reduce()
-            out["y"], out["ga"], out["gb"] = y, ek.gradient(a), ek.gradient(b)
+            def step():
+                a = ek.Float32(a0); b = ek.Float32(b0)
+                ek.set_requires_gradient(a); ek.set_requires_gradient(b)
+                y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
+                ek.backward(y)
+                out["ga"], out["gb"] = ek.gradient(a), ek.gradient(b)
+                if packer:
+                    packer.pack([ekd.as_tensor(ek.detach(y))])
+                    packer.all_reduce()
+                out["y"] = ek.detach(y)
         else:
-            y = ekc.hsum(ekc.sin(ekc.exp(ekc.fmadd(a0, x, b0))))
-            if packer:
-                packer.pack([ekd.as_tensor(y)])
-                packer.all_reduce()
-            out["y"] = y
+            a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
+            packer = ekd.Packer([1], self.dev) if ekd.active() else None
 
-    for _ in range(args.warmup):
-        step()
-    ekd.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    if packer:
-        packer.wait_all()                 # every step's all-reduce has completed inside the timed region
-    torch.cuda.synchronize(); ekd.barrier()
-    elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
-    ms_per_step = elapsed / args.steps * 1e3
-    gelem_s = N / (ms_per_step * 1e-3) / 1e9
+            def step():
+                y = ekc.hsum(ekc.sin(ekc.exp(ekc.fmadd(a0, x, b0))))
+                if packer:
+                    packer.pack([ekd.as_tensor(y)])
+                    packer.all_reduce()
+                out["y"] = y
+        ek.hip_sync()
+        return step, packer, out
 
-    # ---- per-kernel timing of the same step (HIP events on the library stream) ----------------------
-    ek.hip_profile_begin()
-    for _ in range(args.profile_steps):
-        step()
-    prof = json.loads(ek.hip_profile_end())
-    if packer:
-        packer.wait_all()
-    torch.cuda.synchronize()
-    kernels = []
-    for k in prof:
-        if k["launches"] == 0 or k["elements"] // k["launches"] < 1024:
-            continue        # scalar bookkeeping launches (size-1 arrays) are not bandwidth kernels
-        avg_ms = k["total_ms"] / k["launches"]
-        bpl = k["bytes"] / k["launches"]
-        kernels.append({"kernel": k["kernel"], "launches_per_step": k["launches"] / args.profile_steps,
-                        "avg_ms": round(avg_ms, 5), "bytes_per_launch": int(bpl),
-                        "tb_s": round(bpl / avg_ms / 1e9, 4) if avg_ms > 0 else None,
-                        "share_ms_per_step": round(k["total_ms"] / args.profile_steps, 5)})
-    kernels.sort(key=lambda k: -k["share_ms_per_step"])
-    dom = kernels[0] if kernels else None
-    total_bytes_step = sum(k["bytes"] for k in prof) / args.profile_steps
-    roofline = None
-    if dom:
-        achieved = dom["bytes_per_launch"] / dom["avg_ms"] / 1e6      # GB/s
-        roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
-                    "traffic": None,
-                    "whole_step": {"algorithmic_bytes": int(total_bytes_step),
-                                   "bytes_per_elt": round(total_bytes_step / n, 2),
-                                   "achieved_GBs": round(total_bytes_step / (ms_per_step * 1e-3) / 1e9, 1),
-                                   "frac": round(total_bytes_step / (ms_per_step * 1e-3) / 1e9 / (HBM_PEAK_TBS * 1000), 4)},
-                    "kernels": kernels}
+    def run(self, workload, steps, warmup, profile_steps):
+        torch, ek, ekd = self.torch, self.ek, self.ekd
+        step, packer, out = self.make_step(workload)
+        for _ in range(warmup):
+            step()
+        if packer:
+            packer.wait_all()
+        ekd.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        if packer:
+            packer.wait_all()             # every step's all-reduce completes inside the timed region
+        torch.cuda.synchronize(); ekd.barrier()
+        elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
+        ms_per_step = elapsed / steps * 1e3
+        gelem_s = self.N / (ms_per_step * 1e-3) / 1e9
 
-    # ---- CPU baseline: the reference's own code path on ONE host core (rank 0, N = 1 GPU only) -------
-    cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu = cpu_baseline(args.workload, N)
-
-    if rank == 0:
-        y_val = float(ek.detach(out["y"]).numpy()[0]) if args.workload != "cfg2" else float(out["y"].numpy()[0])
+        # per-kernel timing of the same step: one HIP event per launch on the library stream
+        ek.hip_profile_begin()
+        for _ in range(profile_steps):
+            step()
+        prof = json.loads(ek.hip_profile_end())
+        if packer:
+            packer.wait_all()
+        torch.cuda.synchronize()
+        kernels = []
+        for k in prof:
+            if k["launches"] == 0 or k["elements"] // k["launches"] < 1024:
+                continue        # scalar bookkeeping launches (size-1 arrays) are not bandwidth kernels
+            avg_ms = k["total_ms"] / k["launches"]
+            bpl = k["bytes"] / k["launches"]
+            kernels.append({"kernel": k["kernel"], "launches_per_step": k["launches"] / profile_steps,
+                            "avg_ms": round(avg_ms, 5), "bytes_per_launch": int(bpl),
+                            "tb_s": round(bpl / avg_ms / 1e9, 4) if avg_ms > 0 else None,
+                            "share_ms_per_step": round(k["total_ms"] / profile_steps, 5)})
+        kernels.sort(key=lambda k: -k["share_ms_per_step"])
+        total_bytes_step = sum(k["bytes"] for k in prof) / profile_steps
+        roofline = None
+        if kernels:
+            dom = kernels[0]
+            achieved = dom["bytes_per_launch"] / dom["avg_ms"] / 1e6      # GB/s
+            whole = total_bytes_step / (ms_per_step * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
+                        "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
+                        "traffic": pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else None,
+                        "traffic_source": "profiles/rocprof_pmc_r01.txt (separate rocprofv3 --pmc passes, same command)",
+                        "whole_step": {"algorithmic_bytes": int(total_bytes_step),
+                                       "bytes_per_elt": round(total_bytes_step / max(self.n, 1), 2),
+                                       "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
+                        "kernels": kernels}
+        y_val = float(out["y"].numpy()[0])
         if packer:
             y_val = float(packer.slot(0).item())
-        line = {
-            "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
-            "value": round(gelem_s, 3), "unit": "Gelem/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: " + {
-                "cfg3b": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)), a=gather(A,idx), b=gather(B,idx), K=1Mi; backward() with scatter_add grads",
-                "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves",
-                "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))"}[args.workload],
-                "elements_total": N, "elements_per_gpu": n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
-                "sharding": f"index-range x{world}", "collectives_per_step": 1 if packer else 0},
-            "result_y": y_val,
-            "roofline": roofline, "cpu_baseline": cpu,
-        }
-        print(json.dumps(line))
+        return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "result_y": y_val,
+                "roofline": roofline, "collectives_per_step": 1 if packer else 0}
 
 
 def cpu_baseline(workload, N):
@@ -213,6 +240,42 @@ def cpu_baseline(workload, N):
             "sample": f"{workload} at n={n} elements, best of {runs} runs ({t_total:.1f} s of CPU work), "
                       f"timed region = forward + backward() inside the checker, single thread",
             "nproc": os.cpu_count()}
+
+
+def main():
+    args = parse()
+    b = Bench(args)
+    main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
+    also = {}
+    if b.world == 1 and not args.no_also:
+        for w in ("cfg3a", "cfg2", "cfg3b"):
+            if w != args.workload:
+                r = b.run(w, max(5, args.steps // 2), 2, 3)
+                also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
+                           "whole_step_frac_of_hbm_peak": r["roofline"]["whole_step"]["frac"] if r["roofline"] else None,
+                           "bytes_per_elt": r["roofline"]["whole_step"]["bytes_per_elt"] if r["roofline"] else None,
+                           "dominant_kernel": r["roofline"]["kernel"] if r["roofline"] else None,
+                           "dominant_kernel_frac": r["roofline"]["frac"] if r["roofline"] else None,
+                           "workload": DESCRIPTION[w]}
+    cpu = None
+    if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args.workload, b.N)
+    if b.rank == 0:
+        line = {
+            "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
+            "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}", "elements_total": b.N,
+                       "elements_per_gpu": b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
+                       "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"]},
+            "result_y": main_res["result_y"], "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,
+        }
+        print(json.dumps(line))
+    if b.ekd.active():
+        import torch.distributed as dist
+        b.ekd.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

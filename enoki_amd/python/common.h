@@ -219,6 +219,77 @@ template <typename Dst, typename Src> void bind_cast(py::class_<Dst> &cl) {
     cl.def(py::init([](const Src &s) { return Dst(s); }));
 }
 
+/// Static vectors of device arrays: Vector2f / Vector3f / Vector4f (cuda_2d.cpp ... cuda_4d.cpp in the reference)
+template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::module_ &m, const char *name) {
+    using Vec = Array<Value, N>;
+    using Scalar = scalar_t<Value>;
+    using Mask = mask_t<Value>;
+    using UInt32 = uint32_array_t<Value>;
+    py::class_<Vec> cl(m, name);
+    cl.def(py::init<>())
+      .def(py::init<const Vec &>())
+      .def(py::init<Scalar>())
+      .def(py::init<const Value &>())
+      .def("__len__", [](const Vec &) { return N; })
+      .def("__getitem__", [](const Vec &v, size_t i) { if (i >= N) throw py::index_error(); return v.coeff(i); })
+      .def("__setitem__", [](Vec &v, size_t i, const Value &x) { if (i >= N) throw py::index_error(); v.coeff(i) = x; })
+      .def("__repr__", [](const Vec &v) {
+          std::string s = "[";
+          for (size_t i = 0; i < N; ++i) s += array_repr(v.coeff(i)) + (i + 1 < N ? ",\n " : "]");
+          return s;
+      })
+      .def(py::self + py::self).def(py::self - py::self).def(py::self * py::self).def(py::self / py::self)
+      .def(-py::self)
+      .def("__mul__", [](const Vec &a, const Value &b) { return Vec(a * b); })
+      .def("__rmul__", [](const Vec &a, const Value &b) { return Vec(a * b); })
+      .def("__truediv__", [](const Vec &a, const Value &b) { return Vec(a / b); })
+      .def("__mul__", [](const Vec &a, Scalar b) { return Vec(a * b); })
+      .def("__rmul__", [](const Vec &a, Scalar b) { return Vec(a * b); })
+      .def("__add__", [](const Vec &a, Scalar b) { return Vec(a + b); })
+      .def("__sub__", [](const Vec &a, Scalar b) { return Vec(a - b); });
+    if constexpr (N == 2) cl.def(py::init<const Value &, const Value &>());
+    if constexpr (N == 3) cl.def(py::init<const Value &, const Value &, const Value &>());
+    if constexpr (N == 4) cl.def(py::init<const Value &, const Value &, const Value &, const Value &>());
+    cl.def_property("x", [](const Vec &v) { return v.x(); }, [](Vec &v, const Value &x) { v.x() = x; });
+    if constexpr (N >= 2) cl.def_property("y", [](const Vec &v) { return v.y(); }, [](Vec &v, const Value &x) { v.y() = x; });
+    if constexpr (N >= 3) cl.def_property("z", [](const Vec &v) { return v.z(); }, [](Vec &v, const Value &x) { v.z() = x; });
+    if constexpr (N >= 4) cl.def_property("w", [](const Vec &v) { return v.w(); }, [](Vec &v, const Value &x) { v.w() = x; });
+
+    m.def("dot", [](const Vec &a, const Vec &b) { return dot(a, b); });
+    m.def("squared_norm", [](const Vec &a) { return squared_norm(a); });
+    m.def("norm", [](const Vec &a) { return norm(a); });
+    m.def("normalize", [](const Vec &a) { return normalize(a); });
+    m.def("hsum", [](const Vec &a) { return hsum(a); });
+    m.def("hprod", [](const Vec &a) { return hprod(a); });
+    m.def("hmin", [](const Vec &a) { return hmin(a); });
+    m.def("hmax", [](const Vec &a) { return hmax(a); });
+    m.def("abs", [](const Vec &a) { return abs(a); });
+    m.def("sqrt", [](const Vec &a) { return sqrt(a); });
+    m.def("min", [](const Vec &a, const Vec &b) { return min(a, b); });
+    m.def("max", [](const Vec &a, const Vec &b) { return max(a, b); });
+    m.def("fmadd", [](const Vec &a, const Vec &b, const Vec &c) { return fmadd(a, b, c); });
+    m.def("select", [](const Mask &mk, const Vec &t, const Vec &f) { return select(mk, t, f); });
+    m.def("slices", [](const Vec &a) { return slices(a); });
+    m.def("gather", [](const Vec &source, const UInt32 &index, const Mask &mask) { return gather<Vec>(source, index, mask); },
+          "source"_a, "index"_a, "mask"_a = Mask(true));
+    m.def("scatter", [](Vec &target, const Vec &source, const UInt32 &index, const Mask &mask) { scatter(target, source, index, mask); },
+          "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
+    m.def("scatter_add", [](Vec &target, const Vec &source, const UInt32 &index, const Mask &mask) { scatter_add(target, source, index, mask); },
+          "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
+    if constexpr (N == 3) m.def("cross", [](const Vec &a, const Vec &b) { return cross(a, b); });
+    if constexpr (is_diff_array_v<Value>) {
+        m.def("set_requires_gradient", [](Vec &a, bool value) { for (size_t i = 0; i < N; ++i) set_requires_gradient(a.coeff(i), value); },
+              "array"_a, "value"_a = true);
+        m.def("gradient", [](const Vec &a) {
+            using Plain = std::decay_t<decltype(detach(std::declval<const Value &>()))>;
+            Array<Plain, N> g;
+            for (size_t i = 0; i < N; ++i) g.coeff(i) = gradient(a.coeff(i));
+            return g;
+        });
+    }
+    return cl;
+}
+
 inline void bind_runtime(py::module_ &m) {
     m.def("hip_eval", []() { hip_eval(); }, "no-op: the backend is eager (kept for cuda_eval() call sites)");
     m.def("hip_sync", []() { py::gil_scoped_release r; hip_sync(); });

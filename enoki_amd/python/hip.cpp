@@ -21,6 +21,10 @@ PYBIND11_MODULE(hip, m) {
     auto i64 = bind_array<Int64C>(m, "Int64");
     auto u64 = bind_array<UInt64C>(m, "UInt64");
     m.attr("Float") = m.attr("Float32");
+    bind_vector<FloatC, 2>(m, "Vector2f");
+    bind_vector<FloatC, 3>(m, "Vector3f");
+    bind_vector<FloatC, 4>(m, "Vector4f");
+    m.def("meshgrid", [](const FloatC &x, const FloatC &y) { return meshgrid(x, y); });
 
     bind_cast<FloatC, Int32C>(f32); bind_cast<FloatC, UInt32C>(f32); bind_cast<FloatC, DoubleC>(f32);
     bind_cast<FloatC, Int64C>(f32); bind_cast<FloatC, UInt64C>(f32);

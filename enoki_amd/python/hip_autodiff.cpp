@@ -17,6 +17,9 @@ PYBIND11_MODULE(hip_autodiff, m) {
     auto i32 = bind_array<Int32D>(m, "Int32");
     auto u32 = bind_array<UInt32D>(m, "UInt32");
     m.attr("Float") = m.attr("Float32");
+    bind_vector<FloatD, 2>(m, "Vector2f");
+    bind_vector<FloatD, 3>(m, "Vector3f");
+    bind_vector<FloatD, 4>(m, "Vector4f");
 
     f32.def(py::init([](const FloatC &v) { return FloatD(v); }));
     u32.def(py::init([](const HIPArray<uint32_t> &v) { return UInt32D(v); }));

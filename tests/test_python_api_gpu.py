@@ -129,3 +129,31 @@ def test_scatter_add_gradient_and_torch_interop(ek, ekc):
     w = ekc.Float32.map(src.data_ptr(), 16)
     torch.cuda.synchronize()
     assert np.array_equal((w + ekc.Float32(1.0)).numpy(), np.arange(16, dtype=np.float32) + 1)
+
+
+def test_vector3f_ray_sphere_in_python(ekc):
+    """tests/sphere.cpp written against the Python surface (Vector2f/Vector3f of device arrays)"""
+    import ctypes
+    import oracle_lib as ol
+    res = 64
+    grid = ekc.meshgrid(ekc.Float32.linspace(-1.2, 1.2, res), ekc.Float32.linspace(-1.2, 1.2, res))
+    F = ekc.Float32
+    o = ekc.Vector3f(grid.x, grid.y, F(-1.0)); d = ekc.Vector3f(F(0.0), F(0.0), F(1.0))
+    a = ekc.dot(d, d); b = ekc.dot(o, d) * 2.0; c = ekc.dot(o, o) - 1.0
+    discrim = b * b - a * 4.0 * c
+    t = (-b + ekc.sqrt(discrim)) / (a * 2.0)
+    hit = discrim >= F(0.0)
+    pos = ekc.select(hit, o + d * t, ekc.Vector3f(0.0))
+    shade = ekc.max(ekc.dot(pos, ekc.Vector3f(F(-1.0), F(-1.0), F(2.0))), F(0.0)) * 90.0 + 0.2
+    # checker: the C oracle with an identity permutation and a full mask
+    n = res * res
+    gx, gy = grid.x.numpy(), grid.y.numpy()
+    img = np.zeros(n, np.float32); hc = ctypes.c_uint64()
+    perm = np.arange(n, dtype=np.uint32); mask = np.ones(n, np.uint8)
+    p = lambda arr: arr.ctypes.data_as(ctypes.c_void_p)
+    ol.port().lib.orc_cfg4(p(gx), p(gy), p(perm), p(mask), ctypes.c_size_t(n), p(img), ctypes.byref(hc))
+    got = np.where(hit.numpy() != 0, shade.numpy(), 0).astype(np.float32)
+    assert ekc.count(hit) == hc.value
+    assert bits_equal(got, img)
+    v = ekc.Vector3f(F(3.0), F(0.0), F(4.0))
+    assert ekc.norm(v)[0] == 5.0 and len(v) == 3 and ekc.cross(ekc.Vector3f(F(1.0), F(0.0), F(0.0)), ekc.Vector3f(F(0.0), F(1.0), F(0.0))).z[0] == 1.0
