@@ -15,16 +15,14 @@
 
 #include "ek_internal.h"
 
-#ifndef EK_MAP_U
-#  define EK_MAP_U 1          // 16-byte vectors per lane per array
-#endif
-#ifndef EK_MAP_NTL
-#  define EK_MAP_NTL true     // non-temporal loads
-#endif
-#ifndef EK_MAP_NTS
-#  define EK_MAP_NTS true     // non-temporal stores
-#endif
-
+// Cache policy, measured two ways on the MI355X (profiles/):
+//   * single kernels re-reading the same buffers (tools/probe_bw.py --sweep) prefer plain loads for
+//     one-input bodies -- but that is the 256 MiB Infinity Cache serving repeats of the same array;
+//   * the same kernels chained as a producer -> consumer PIPELINE like the real tape
+//     (tools/probe_pipeline.py, cfg3a emulation) are fastest with non-temporal loads AND stores and one
+//     vector per lane everywhere: 0.6035 ms / 83.4 % of 8 TB/s, vs 0.628 ms for the per-kernel optimum,
+//     0.664 ms for plain loads + nt stores and 0.681 ms without nt.
+// The pipeline is what the backend executes, so: U = 1, nt loads, nt stores.
 namespace ek {
 
 template <typename T, int N> struct alignas(sizeof(T) * N) Pack { T v[N]; };
@@ -210,15 +208,19 @@ __global__ __launch_bounds__(256) void k_map3(TO *__restrict__ out, size_t n, in
 }
 
 // ---- host-side launchers -----------------------------------------------------------------------
-template <int N> inline unsigned oneshot_grid(size_t n) {
-    size_t per_block = (size_t) 256 * EK_MAP_U * N;
+template <int N, int U> inline unsigned oneshot_grid(size_t n) {
+    size_t per_block = (size_t) 256 * U * N;
     size_t blocks = (n + per_block - 1) / per_block;
     return (unsigned) (blocks ? blocks : 1);
 }
 
-#define EK_MAP_LAUNCH(KERNEL, TYPES, N_, n_, ...)                                                 \
-    hipLaunchKernelGGL((KERNEL<TYPES, EK_MAP_U, EK_MAP_NTL, EK_MAP_NTS>), dim3(oneshot_grid<N_>(n_)), \
-                       dim3(256), 0, ctx().stream, __VA_ARGS__)
+/// Functors may declare `static constexpr bool heavy = true` (transcendental bodies)
+template <typename F, typename = void> struct is_heavy : std::false_type { };
+template <typename F> struct is_heavy<F, std::void_t<decltype(F::heavy)>> : std::bool_constant<F::heavy> { };
+
+#define EK_MAP_LAUNCH(KERNEL, TYPES, N_, U_, NTL_, NTS_, n_, ...)                                 \
+    hipLaunchKernelGGL((KERNEL<TYPES, U_, NTL_, NTS_>), dim3(oneshot_grid<N_, U_>(n_)), dim3(256), 0, \
+                       ctx().stream, __VA_ARGS__)
 
 #define EK_COMMA ,
 
@@ -226,7 +228,7 @@ template <typename F, typename TO, typename TA>
 int launch_map1(const char *name, TO *out, size_t n, const Arg<TA> &a) {
     constexpr int N = 16 / max_size<TO, TA>::value;
     int vec_ok = aligned16(out) && arg_aligned(a);
-    EK_MAP_LAUNCH(k_map1, F EK_COMMA TO EK_COMMA TA, N, n, out, n, vec_ok, a);
+    EK_MAP_LAUNCH(k_map1, F EK_COMMA TO EK_COMMA TA, N, 1, true, true, n, out, n, vec_ok, a);
     EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n));
     return EK_OK;
 }
@@ -235,7 +237,7 @@ template <typename F, typename TO, typename TA>
 int launch_map1x2(const char *name, TO *out0, TO *out1, size_t n, const Arg<TA> &a) {
     constexpr int N = 16 / max_size<TO, TA>::value;
     int vec_ok = aligned16(out0) && aligned16(out1) && arg_aligned(a);
-    EK_MAP_LAUNCH(k_map1x2, F EK_COMMA TO EK_COMMA TA, N, n, out0, out1, n, vec_ok, a);
+    EK_MAP_LAUNCH(k_map1x2, F EK_COMMA TO EK_COMMA TA, N, 1, true, true, n, out0, out1, n, vec_ok, a);
     EK_LAUNCH_CHECK(name, n, 2 * n * sizeof(TO) + arg_bytes(a, n));
     return EK_OK;
 }
@@ -244,7 +246,7 @@ template <typename F, typename TO, typename TA, typename TB>
 int launch_map2(const char *name, TO *out, size_t n, const Arg<TA> &a, const Arg<TB> &b) {
     constexpr int N = 16 / max_size<TO, TA, TB>::value;
     int vec_ok = aligned16(out) && arg_aligned(a) && arg_aligned(b);
-    EK_MAP_LAUNCH(k_map2, F EK_COMMA TO EK_COMMA TA EK_COMMA TB, N, n, out, n, vec_ok, a, b);
+    EK_MAP_LAUNCH(k_map2, F EK_COMMA TO EK_COMMA TA EK_COMMA TB, N, 1, true, true, n, out, n, vec_ok, a, b);
     EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + arg_bytes(b, n));
     return EK_OK;
 }
@@ -253,7 +255,7 @@ template <typename F, typename TO, typename TA, typename TB, typename TC>
 int launch_map3(const char *name, TO *out, size_t n, const Arg<TA> &a, const Arg<TB> &b, const Arg<TC> &c) {
     constexpr int N = 16 / max_size<TO, TA, TB, TC>::value;
     int vec_ok = aligned16(out) && arg_aligned(a) && arg_aligned(b) && arg_aligned(c);
-    EK_MAP_LAUNCH(k_map3, F EK_COMMA TO EK_COMMA TA EK_COMMA TB EK_COMMA TC, N, n, out, n, vec_ok, a, b, c);
+    EK_MAP_LAUNCH(k_map3, F EK_COMMA TO EK_COMMA TA EK_COMMA TB EK_COMMA TC, N, 1, true, true, n, out, n, vec_ok, a, b, c);
     EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + arg_bytes(b, n) + arg_bytes(c, n));
     return EK_OK;
 }

@@ -56,6 +56,7 @@ template <int Op, typename T> constexpr bool unary_supported() {
 }
 
 template <int Op, typename T> struct UnaryOp {
+    static constexpr bool heavy = Op == EK_SIN || Op == EK_COS || Op == EK_EXP || Op == EK_LOG;
     static __device__ __forceinline__ T apply(T x) {
         using U = uint_of<T>;
         constexpr U sign_bit = U(1) << (sizeof(T) * 8 - 1);

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void k_probe(V4 *__restrict__ o0, V4 *__restri
             if (v < nvec) {
                 pa[k] = ld<NTL>(a + v);
                 if constexpr (Body == 1) { pb[k] = ld<NTL>(b + v); pc[k] = ld<NTL>(c + v); }
+                if constexpr (Body == 5) { pb[k] = ld<NTL>(b + v); }
             }
         }
 #pragma unroll
@@ -49,6 +50,13 @@ __global__ __launch_bounds__(256) void k_probe(V4 *__restrict__ o0, V4 *__restri
                     for (int i = 0; i < 4; ++i) { float ss, cc; dev::sincos_f32<true, true>(pa[k][i], ss, cc); s[i] = ss; co[i] = cc; }
                     st<NTS>(o0 + v, s);
                     st<NTS>(o1 + v, co);
+                } else if constexpr (Body == 5) {           // 2 inputs, 1 output (safe_mul(x, g))
+                    st<NTS>(o0 + v, pa[k] * pb[k]);
+                } else if constexpr (Body == 6) {           // 1 input, 1 output, transcendental (sin)
+                    V4 r;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) { float ss, cc; dev::sincos_f32<true, false>(pa[k][i], ss, cc); r[i] = ss; }
+                    st<NTS>(o0 + v, r);
                 } else if constexpr (Body == 3) {
                     acc += pa[k];
                 } else {
@@ -205,6 +213,8 @@ extern "C" EK_API int ek_hip_probe(int body, int unroll, int nt_load, int nt_sto
         case 2: return probe_u<2>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
         case 3: return probe_u<3>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
         case 4: return probe_u<4>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        case 5: return probe_u<5>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
+        case 6: return probe_u<6>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
         default: return fail(EK_ERR_INVALID, "ek_hip_probe(): unknown body %d", body);
     }
 }

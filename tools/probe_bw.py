@@ -28,8 +28,8 @@ rng = np.random.default_rng(0)
 host = rng.uniform(-1, 1, n).astype(np.float32)
 a = capi.Buf.from_numpy(host); b = capi.Buf.from_numpy(host[::-1].copy()); c = capi.Buf.from_numpy(host)
 o0 = capi.Buf(np.float32, n); o1 = capi.Buf(np.float32, n)
-bytes_per_elt = {0: 8, 1: 16, 2: 12, 3: 4, 4: 8}
-names = {0: "copy", 1: "fmadd", 2: "sincos", 3: "read", 4: "scale"}
+bytes_per_elt = {0: 8, 1: 16, 2: 12, 3: 4, 4: 8, 5: 12, 6: 8}
+names = {0: "copy", 1: "fmadd", 2: "sincos", 3: "read", 4: "scale", 5: "mul2", 6: "sin"}
 P = ctypes.c_void_p
 
 
@@ -46,8 +46,8 @@ print(f"# n = {n} f32 elements ({n * 4 / 2**20:.0f} MiB per array); TB/s of ALGO
 
 if args.sweep:
     fns = {}
-    for body in [0, 1, 2, 3, 4]:
-        for u, (ntl, nts), bpc in itertools.product([1, 2, 4], [(0, 0), (0, 1), (1, 0), (1, 1)], [0, 8, 32]):
+    for body in [0, 1, 2, 3, 4, 5, 6]:
+        for u, (ntl, nts), bpc in itertools.product([1, 2, 4], [(0, 0), (0, 1), (1, 0), (1, 1)], [0]):
             def f(body=body, u=u, ntl=ntl, nts=nts, bpc=bpc):
                 capi.check(capi.lib.ek_hip_probe(body, u, ntl, nts, bpc, P(o0.ptr), P(o1.ptr), P(a.ptr), P(b.ptr),
                                                  P(c.ptr), ctypes.c_size_t(n)))
