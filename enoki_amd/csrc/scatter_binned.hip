@@ -34,31 +34,67 @@ constexpr int kTile = kThreads * kPerThread;   // elements sorted per LDS pass o
 
 template <typename I> __device__ __forceinline__ uint32_t index_u32(I i) { return (uint32_t) i; }
 
+// Loads one tile (kTile elements) of indices / mask bits / values into registers.  Fast path: the lane
+// owns two runs of 4 consecutive elements (16-byte loads); fallback: strided scalar loads.
+template <bool WithValue, typename I, typename T>
+__device__ __forceinline__ void load_tile(const I *__restrict__ index, const Arg<uint8_t> &mask, uint8_t sm,
+                                          const Arg<T> &value, T sv, size_t base, size_t end, int vec_ok,
+                                          uint32_t (&ix)[kPerThread], bool (&on)[kPerThread], T *val) {
+    static_assert(kPerThread == 8 && sizeof(I) == 4);
+    if (vec_ok && base + kTile <= end) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const size_t e = base + (size_t) h * (kTile / 2) + (size_t) threadIdx.x * 4;
+            Pack<I, 4> pi = pack_load<I, 4, true>(index + e);
+            Pack<uint8_t, 4> pm;
+            if (mask.vec) pm = pack_load<uint8_t, 4, true>(mask.ptr + e);
+            Pack<T, 4> pv;
+            if constexpr (WithValue) { if (value.vec) pv = pack_load<T, 4, true>(value.ptr + e); }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ix[h * 4 + j] = index_u32(pi.v[j]);
+                on[h * 4 + j] = mask.vec ? pm.v[j] != 0 : sm != 0;
+                if constexpr (WithValue) val[h * 4 + j] = value.vec ? pv.v[j] : sv;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            size_t i = base + (size_t) k * kThreads + threadIdx.x;
+            on[k] = i < end && (mask.vec ? mask.ptr[i] != 0 : sm != 0);
+            ix[k] = i < end ? index_u32(index[i]) : 0u;
+            if constexpr (WithValue) val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
+        }
+    }
+}
+
 // ---- 1. count ------------------------------------------------------------------------------------
 template <typename I>
 __global__ __launch_bounds__(kThreads) void k_bin_count(uint32_t *__restrict__ counts, const I *__restrict__ index,
-                                                        Arg<uint8_t> mask, size_t n, size_t chunk, int n_buckets) {
+                                                        Arg<uint8_t> mask, size_t n, size_t chunk, int n_buckets,
+                                                        int rep_shift, int vec_ok) {
+    // Each bucket owns 2^rep_shift counters; a lane uses counter (lane mod 2^rep_shift).  With 64 buckets and
+    // 64 lanes several lanes of a wave hit the same LDS address and serialise; replication spreads them.
     __shared__ uint32_t hist[kMaxBuckets];
-    for (int b = threadIdx.x; b < n_buckets; b += kThreads) hist[b] = 0;
+    const uint32_t rep = threadIdx.x & ((1u << rep_shift) - 1u);
+    for (int b = threadIdx.x; b < kMaxBuckets; b += kThreads) hist[b] = 0;
     __syncthreads();
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
     for (size_t base = begin; base < end; base += kTile) {
         uint32_t ix[kPerThread];
         bool on[kPerThread];
-#pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            size_t i = base + (size_t) k * kThreads + threadIdx.x;
-            on[k] = i < end && (mask.vec ? mask.ptr[i] : sm);
-            ix[k] = i < end ? index_u32(index[i]) : 0u;
-        }
+        load_tile<false>(index, mask, sm, Arg<uint32_t>{ nullptr, 0u, 0u }, 0u, base, end, vec_ok, ix, on, (uint32_t *) nullptr);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
-            if (on[k]) atomicAdd(&hist[ix[k] >> kBinShift], 1u);
+            if (on[k]) atomicAdd(&hist[((ix[k] >> kBinShift) << rep_shift) | rep], 1u);
     }
     __syncthreads();
-    for (int b = threadIdx.x; b < n_buckets; b += kThreads)
-        counts[(size_t) b * gridDim.x + blockIdx.x] = hist[b];
+    for (int b = threadIdx.x; b < n_buckets; b += kThreads) {
+        uint32_t c = 0;
+        for (int r = 0; r < (1 << rep_shift); ++r) c += hist[(b << rep_shift) + r];
+        counts[(size_t) b * gridDim.x + blockIdx.x] = c;
+    }
 }
 
 // ---- 2. scan ---------------------------------------------------------------------------------------
@@ -109,10 +145,11 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict
                                                             const uint32_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                             const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
-                                                            size_t chunk, int n_buckets) {
+                                                            size_t chunk, int n_buckets, int rep_shift, int vec_ok) {
     __shared__ uint32_t cursor[kMaxBuckets];       // next free global slot of this workgroup per bucket
-    __shared__ uint32_t tile_hist[kMaxBuckets];    // elements of the current tile per bucket
+    __shared__ uint32_t tile_hist[kMaxBuckets];    // elements of the current tile per (bucket, replica) slot
     __shared__ uint32_t tile_off[kMaxBuckets];     // exclusive prefix of tile_hist
+    const uint32_t rep = threadIdx.x & ((1u << rep_shift) - 1u);
     __shared__ uint32_t stage_idx[kTile];
     __shared__ T stage_val[kTile];
 
@@ -129,16 +166,10 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict
         uint32_t ix[kPerThread], rank[kPerThread];
         T val[kPerThread];
         bool on[kPerThread];
-#pragma unroll
-        for (int k = 0; k < kPerThread; ++k) {
-            size_t i = base + (size_t) k * kThreads + threadIdx.x;
-            on[k] = i < end && (mask.vec ? mask.ptr[i] : sm);
-            ix[k] = i < end ? index_u32(index[i]) : 0u;
-            val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
-        }
+        load_tile<true>(index, mask, sm, value, sv, base, end, vec_ok, ix, on, val);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
-            rank[k] = on[k] ? atomicAdd(&tile_hist[ix[k] >> kBinShift], 1u) : 0u;
+            rank[k] = on[k] ? atomicAdd(&tile_hist[((ix[k] >> kBinShift) << rep_shift) | rep], 1u) : 0u;
         __syncthreads();
         // exclusive scan of the tile histogram (256 entries) by ONE wave: 4 entries per lane + shuffle scan
         if (threadIdx.x < 64) {
@@ -162,7 +193,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             if (on[k]) {
-                uint32_t p = tile_off[ix[k] >> kBinShift] + rank[k];
+                uint32_t p = tile_off[((ix[k] >> kBinShift) << rep_shift) | rep] + rank[k];
                 stage_idx[p] = ix[k];
                 stage_val[p] = val[k];
             }
@@ -171,15 +202,17 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict
         // coalesced runs: consecutive staged elements of one bucket go to consecutive global slots
         for (uint32_t j = threadIdx.x; j < tile_count; j += kThreads) {
             uint32_t key = stage_idx[j], b = key >> kBinShift;
-            uint32_t g = cursor[b] + (j - tile_off[b]);
+            uint32_t g = cursor[b] + (j - tile_off[b << rep_shift]);
             pair_idx[g] = key;
             pair_val[g] = stage_val[j];
         }
         __syncthreads();
-        if (threadIdx.x < kMaxBuckets) {
-            cursor[threadIdx.x] += tile_hist[threadIdx.x];
-            tile_hist[threadIdx.x] = 0;
+        if ((int) threadIdx.x < n_buckets) {
+            const uint32_t first = threadIdx.x << rep_shift, next = (threadIdx.x + 1) << rep_shift;
+            cursor[threadIdx.x] += (next < kMaxBuckets ? tile_off[next] : tile_count) - tile_off[first];
         }
+        __syncthreads();
+        if (threadIdx.x < kMaxBuckets) tile_hist[threadIdx.x] = 0;
         __syncthreads();
     }
 }
@@ -255,12 +288,13 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
     }
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const T sv = value.vec ? T(0) : arg_scalar(value);
-    for (size_t base = begin; base < end; base += (size_t) 4 * kThreads) {
-        uint32_t ix[4];
-        T val[4];
-        bool on[4];
+    constexpr int kAcc = 8;      // loads in flight per lane
+    for (size_t base = begin; base < end; base += (size_t) kAcc * kThreads) {
+        uint32_t ix[kAcc];
+        T val[kAcc];
+        bool on[kAcc];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < kAcc; ++k) {
             size_t i = base + (size_t) k * kThreads + threadIdx.x;
             on[k] = i < end;
             if constexpr (Direct) {
@@ -268,12 +302,12 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
                 ix[k] = i < end ? index_u32(index[i]) : 0u;
                 val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
             } else {
-                ix[k] = i < end ? pair_idx[i] : 0u;
-                val[k] = i < end ? pair_val[i] : T(0);
+                ix[k] = i < end ? __builtin_nontemporal_load(pair_idx + i) : 0u;
+                val[k] = i < end ? __builtin_nontemporal_load(pair_val + i) : T(0);
             }
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
+        for (int k = 0; k < kAcc; ++k)
             lds_add<UseLock>(&acc[ix[k] & (kBins - 1)], val[k], on[k]);
     }
     __syncthreads();
@@ -336,6 +370,9 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     chunk = (chunk + kTile - 1) / kTile * kTile;
     blocks = (unsigned) ((n + chunk - 1) / chunk);
 
+    const int vec_ok = arg_aligned(index) && arg_aligned(mask) && arg_aligned(value);
+    int rep_shift = 0;
+    while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
     const size_t count_entries = (size_t) n_buckets * blocks;
     Scratch counts, pairs_idx, pairs_val, partials;
     // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1]
@@ -346,7 +383,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     uint32_t *bucket_base = row_total + kMaxBuckets;
 
     hipLaunchKernelGGL((k_bin_count<I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, index.ptr,
-                       mask, n, chunk, n_buckets);
+                       mask, n, chunk, n_buckets, rep_shift, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_count", n, arg_bytes(index, n) + arg_bytes(mask, n));
     hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_buckets), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
     hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (const uint32_t *) row_total,
@@ -354,7 +391,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
     hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) pairs_idx.ptr,
                        (T *) pairs_val.ptr, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, value, index.ptr,
-                       mask, n, chunk, n_buckets);
+                       mask, n, chunk, n_buckets, 0, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint32_t) + sizeof(T)));
 
     int slices = std::max(1, (4 * c.num_cu + n_buckets - 1) / n_buckets);
