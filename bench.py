@@ -60,6 +60,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5)
+    ap.add_argument("--deterministic", action="store_true", help="bit-reproducible fp scatter_add (sorted path)")
     return ap.parse_args()
 
 
@@ -96,6 +97,8 @@ class Bench:
         torch.cuda.set_device(self.local_rank)          # torch's HIP runtime initialises first
         ek.hip_init(self.local_rank)
         ekd.adopt_torch_stream(ek)                        # kernels + RCCL ordered by one stream
+        if args.deterministic:
+            ek.hip_set_tuning("deterministic", 1)
         self.dev = torch.device("cuda", self.local_rank)
         self.N = args.n
         self.begin, self.end = ekd.shard_range(self.N, self.rank, self.world)

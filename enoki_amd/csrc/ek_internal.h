@@ -28,6 +28,7 @@ struct Tuning {
     int blocks_per_cu = 8;   // grid cap for streaming kernels = blocks_per_cu * #CU
     int reduce_blocks_per_cu = 4;
     int scatter_add_binned = 1;   // 1: LDS-binned scatter_add for large inputs, 0: global atomics only
+    int deterministic = 0;        // 1: fp scatter_add always takes the bit-reproducible sorted path (ENOKI_HIP_DETERMINISTIC)
 };
 
 struct Context {
@@ -131,6 +132,11 @@ inline unsigned stream_grid(size_t work_items, int blocks_per_cu) {
 bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array);
 template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
+                       size_t n);
+
+// deterministic scatter_add: stable radix sort by index + sequential per-bin sums (scatter_binned.hip)
+template <typename T, typename I>
+int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n);
 
 } // namespace ek

@@ -247,9 +247,26 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
     if (n == 0) return EK_OK;
     if (!base) return fail(EK_ERR_INVALID, "ek_hip_scatter_add(): null pointer");
     bool is_fp = type == EK_F32 || type == EK_F64;
-    if (mode == 1 && is_fp)
-        return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add(): deterministic mode for floating point "
-                                        "types is not implemented yet (integer types are exact in mode 0)");
+    if (mode == 0 && ctx().tuning.deterministic) mode = 1;
+    if (mode == 1 && is_fp) {
+        // deterministic: bit-identical to the CPU reference's element-order accumulation
+        if (!index || !mask || !value || index->ptr == nullptr || index->size != n || base_size == 0 ||
+            (index_type != EK_U32 && index_type != EK_I32) || n >= ((size_t) 1 << 32))
+            return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add(): deterministic mode needs a 32-bit index ARRAY of size n "
+                                            "and the target size (base_size)");
+        Arg<uint8_t> mm;
+        if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add")) return rc;
+#define EK_SORTED_CALL(T, I)                                                                                          \
+        do {                                                                                                          \
+            Arg<T> vv; Arg<I> ii;                                                                                     \
+            if (int rc = make_arg<T>(value, n, vv, "ek_hip_scatter_add")) return rc;                                  \
+            if (int rc = make_arg<I>(index, n, ii, "ek_hip_scatter_add")) return rc;                                  \
+            return scatter_add_sorted<T, I>((T *) base, base_size, vv, ii, mm, n);                                    \
+        } while (0)
+        if (type == EK_F32) { if (index_type == EK_U32) EK_SORTED_CALL(float, uint32_t); else EK_SORTED_CALL(float, int32_t); }
+        else                { if (index_type == EK_U32) EK_SORTED_CALL(double, uint32_t); else EK_SORTED_CALL(double, int32_t); }
+#undef EK_SORTED_CALL
+    }
     // large inputs into tables that fit 256 LDS buckets: partition + ds_add instead of global atomics
     if (mode == 0 && ctx().tuning.scatter_add_binned && index && mask && value &&
         scatter_add_binned_applicable(base_size, n, index->ptr != nullptr && index->size == n) &&

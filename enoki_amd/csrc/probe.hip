@@ -136,6 +136,38 @@ __global__ __launch_bounds__(256) void k_probe_fold8(float *__restrict__ out, co
     out[i] = s;
 }
 
+// ---- gather experiments ---------------------------------------------------------------------------
+// E elements per lane (index loaded as one vector when E == 4), table load policy: 0 plain, 1 non-temporal,
+// 2 via __builtin_amdgcn_global_load with sc bits is not expressible in HIP -> only 0/1 here.
+template <int E, int Policy>
+__global__ __launch_bounds__(256) void k_probe_gather(float *__restrict__ out, const float *__restrict__ table,
+                                                      const uint32_t *__restrict__ idx, size_t n) {
+    size_t e = ((size_t) blockIdx.x * 256 + threadIdx.x) * E;
+    if (e + E > n) return;
+    uint32_t ix[E];
+    float v[E];
+    if constexpr (E == 4) {
+        using U4 = __attribute__((ext_vector_type(4))) uint32_t;
+        U4 p = __builtin_nontemporal_load(reinterpret_cast<const U4 *>(idx + e));
+        ix[0] = p[0]; ix[1] = p[1]; ix[2] = p[2]; ix[3] = p[3];
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) ix[k] = __builtin_nontemporal_load(idx + e + k);
+    }
+#pragma unroll
+    for (int k = 0; k < E; ++k) {
+        if constexpr (Policy == 1) v[k] = __builtin_nontemporal_load(table + ix[k]);
+        else v[k] = table[ix[k]];
+    }
+    if constexpr (E == 4) {
+        V4 r = { v[0], v[1], v[2], v[3] };
+        __builtin_nontemporal_store(r, reinterpret_cast<V4 *>(out + e));
+    } else {
+#pragma unroll
+        for (int k = 0; k < E; ++k) __builtin_nontemporal_store(v[k], out + e + k);
+    }
+}
+
 // ---- LDS atomic throughput -------------------------------------------------------------------------
 // variant 0: ds_add_f32 random bins   1: ds_add_u32 random bins   2: plain ds read-modify-write (racy, bound only)
 // 3: ds_add_f32, lane-private bins (no conflicts)   4: ds_add_rtn_u32 random (returning)
@@ -178,6 +210,18 @@ extern "C" EK_API int ek_hip_probe_lds_atomic(int variant, int blocks, int iters
         default: hipLaunchKernelGGL((k_probe_lds_atomic<4>), dim3(blocks), dim3(512), lds, cx.stream, sink, iters, bins_log2); break;
     }
     EK_LAUNCH_CHECK("probe_lds_atomic", (size_t) blocks * 512 * iters, 0);
+    return EK_OK;
+}
+
+extern "C" EK_API int ek_hip_probe_gather(int elems, int policy, float *out, const float *table, const uint32_t *idx, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+#define EK_PG(E, P) hipLaunchKernelGGL((k_probe_gather<E, P>), dim3((unsigned) ((n / E + 255) / 256)), dim3(256), 0, cx.stream, out, table, idx, n)
+    if (elems == 1 && policy == 0) EK_PG(1, 0); else if (elems == 1) EK_PG(1, 1);
+    else if (elems == 4 && policy == 0) EK_PG(4, 0); else if (elems == 4) EK_PG(4, 1);
+    else if (elems == 8 && policy == 0) EK_PG(8, 0); else EK_PG(8, 1);
+#undef EK_PG
+    EK_LAUNCH_CHECK("probe_gather", n, 12 * n);
     return EK_OK;
 }
 

@@ -31,9 +31,11 @@ int hip_fail(hipError_t err, const char *what, const char *file, int line) {
     return fail(EK_ERR_HIP, "%s failed: %s (%s:%d)", what, hipGetErrorString(err), file, line);
 }
 
+// Context and allocator are intentionally leaked: arrays owned by other shared objects (the global tape,
+// Python modules) may be released during static destruction, after this library's statics would be gone.
 Context &ctx() {
-    static Context c;
-    return c;
+    static Context *c = new Context();
+    return *c;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -72,8 +74,8 @@ struct Allocator {
 };
 
 static Allocator &alloc() {
-    static Allocator a;
-    return a;
+    static Allocator *a = new Allocator();
+    return *a;
 }
 
 int ensure_init() {
@@ -160,6 +162,7 @@ int ek_hip_init(int device) {
     c.owns_stream = true;
     c.initialized = true;
     if (const char *lv = getenv("ENOKI_HIP_LOG")) c.log_level = (uint32_t) atoi(lv);
+    if (const char *dv = getenv("ENOKI_HIP_DETERMINISTIC")) c.tuning.deterministic = atoi(dv) != 0;
     if (c.log_level >= 1)
         fprintf(stderr, "enoki-hip: device %d (%s, %d CUs, %.1f GiB)\n", device, prop.name, c.num_cu,
                 (double) prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
@@ -388,6 +391,7 @@ int ek_hip_set_tuning(const char *key, int value) {
     if (!strcmp(key, "blocks_per_cu") && value > 0) t.blocks_per_cu = value;
     else if (!strcmp(key, "reduce_blocks_per_cu") && value > 0) t.reduce_blocks_per_cu = value;
     else if (!strcmp(key, "scatter_add_binned") && (value == 0 || value == 1)) t.scatter_add_binned = value;
+    else if (!strcmp(key, "deterministic") && (value == 0 || value == 1)) t.deterministic = value;
     else return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): unknown key/value %s=%d", key, value);
     return EK_OK;
 }

@@ -418,3 +418,238 @@ EK_BINNED_INSTANCE(float, uint32_t) EK_BINNED_INSTANCE(float, int32_t)
 EK_BINNED_INSTANCE(uint32_t, uint32_t) EK_BINNED_INSTANCE(uint32_t, int32_t)
 
 } // namespace ek
+
+// =================================================================================================
+//  Deterministic scatter_add (mode 1): bit-identical to the CPU reference's element-order accumulation
+//  (dynamic.h:517-534 -> sequential transform, array_static.h:982-991).
+//
+//  A STABLE least-significant-digit radix sort of the (index, value) pairs by index (8 bits per pass,
+//  ceil(log2(table) / 8) passes) leaves every bin's contributions contiguous AND in element order; one
+//  lane per bin then adds its run sequentially, starting from the bin's current value -- the exact
+//  sequence of fp additions the CPU performs.  Stability comes from ranking with wave64 ballots instead
+//  of atomics: a tile is laid out so that (wave, item, lane) order is element order, lanes holding the
+//  same digit find each other with 8 ballots ("match any"), and per-wave digit counters in LDS are only
+//  ever touched by their own wave.
+// =================================================================================================
+namespace ek {
+
+constexpr int kRadixBits = 8, kRadix = 1 << kRadixBits;
+constexpr int kSortWaves = kThreads / 64;
+
+template <typename I>
+__global__ __launch_bounds__(kThreads) void k_radix_count(uint32_t *__restrict__ counts, const I *__restrict__ keys,
+                                                          Arg<uint8_t> mask, size_t n, size_t chunk, int shift) {
+    __shared__ uint32_t hist[kRadix];
+    for (int b = threadIdx.x; b < kRadix; b += kThreads) hist[b] = 0;
+    __syncthreads();
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+    for (size_t i = begin + threadIdx.x; i < end; i += kThreads)
+        if (mask.vec ? mask.ptr[i] : sm)
+            atomicAdd(&hist[(index_u32(keys[i]) >> shift) & (kRadix - 1)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < kRadix; b += kThreads)
+        counts[(size_t) b * gridDim.x + blockIdx.x] = hist[b];
+}
+
+template <typename T, typename I>
+__global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *__restrict__ out_keys, T *__restrict__ out_vals,
+                                                                     const I *__restrict__ keys, Arg<T> value,
+                                                                     Arg<uint8_t> mask, const uint32_t *__restrict__ offsets,
+                                                                     const uint32_t *__restrict__ bucket_base, size_t n,
+                                                                     size_t chunk, int shift) {
+    __shared__ uint32_t wave_count[kSortWaves][kRadix];   // per-wave digit counters, then exclusive over waves
+    __shared__ uint32_t total[kRadix], tile_off[kRadix], cursor[kRadix];
+    __shared__ uint32_t stage_key[kTile];
+    __shared__ T stage_val[kTile];
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt_mask = (1ull << lane) - 1ull;
+    for (int b = threadIdx.x; b < kRadix; b += kThreads)
+        cursor[b] = bucket_base[b] + offsets[(size_t) b * gridDim.x + blockIdx.x];
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const T sv = value.vec ? T(0) : arg_scalar(value);
+    const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+
+    for (size_t base = begin; base < end; base += kTile) {
+        for (int b = threadIdx.x; b < kSortWaves * kRadix; b += kThreads) (&wave_count[0][0])[b] = 0;
+        __syncthreads();
+
+        uint32_t key[kPerThread], rank[kPerThread];
+        T val[kPerThread];
+        bool on[kPerThread];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            // striped inside the wave: (wave, item, lane) order == element order
+            const size_t i = base + (size_t) wave * (kTile / kSortWaves) + (size_t) j * 64 + lane;
+            on[j] = i < end && (mask.vec ? mask.ptr[i] != 0 : sm != 0);
+            key[j] = i < end ? index_u32(keys[i]) : 0u;
+            val[j] = (value.vec && i < end) ? value.ptr[i] : sv;
+        }
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const uint32_t d = (key[j] >> shift) & (kRadix - 1);
+            unsigned long long peers = __ballot(on[j]);
+#pragma unroll
+            for (int bit = 0; bit < kRadixBits; ++bit) {
+                const bool set = (d >> bit) & 1u;
+                const unsigned long long m = __ballot(on[j] && set);
+                peers &= set ? m : ~m;
+            }
+            const uint32_t below = (uint32_t) __popcll(peers & lt_mask);
+            uint32_t old = 0;
+            if (on[j] && below == 0) {                       // leader of its digit group in this item
+                volatile uint32_t *slot = &wave_count[wave][d];
+                old = *slot;
+                *slot = old + (uint32_t) __popcll(peers);
+            }
+            const int leader = on[j] ? __ffsll((long long) peers) - 1 : lane;
+            old = __shfl(old, leader, 64);
+            rank[j] = old + below;
+            __builtin_amdgcn_wave_barrier();
+        }
+        __syncthreads();
+        // per digit: exclusive prefix over the waves, and the tile total
+        if (threadIdx.x < kRadix) {
+            uint32_t run = 0;
+            for (int w = 0; w < kSortWaves; ++w) {
+                uint32_t c = wave_count[w][threadIdx.x];
+                wave_count[w][threadIdx.x] = run;
+                run += c;
+            }
+            total[threadIdx.x] = run;
+        }
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const int l = threadIdx.x;
+            uint32_t h0 = total[4 * l], h1 = total[4 * l + 1], h2 = total[4 * l + 2], h3 = total[4 * l + 3];
+            uint32_t sum = h0 + h1 + h2 + h3, incl = sum;
+#pragma unroll
+            for (int dd = 1; dd < 64; dd <<= 1) {
+                uint32_t up = __shfl_up(incl, dd, 64);
+                if (l >= dd) incl += up;
+            }
+            uint32_t excl = incl - sum;
+            tile_off[4 * l] = excl; tile_off[4 * l + 1] = excl + h0;
+            tile_off[4 * l + 2] = excl + h0 + h1; tile_off[4 * l + 3] = excl + h0 + h1 + h2;
+        }
+        __syncthreads();
+        const uint32_t tile_count = tile_off[kRadix - 1] + total[kRadix - 1];
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            if (on[j]) {
+                const uint32_t d = (key[j] >> shift) & (kRadix - 1);
+                const uint32_t p = tile_off[d] + wave_count[wave][d] + rank[j];
+                stage_key[p] = key[j];
+                stage_val[p] = val[j];
+            }
+        }
+        __syncthreads();
+        for (uint32_t s = threadIdx.x; s < tile_count; s += kThreads) {
+            const uint32_t k = stage_key[s], d = (k >> shift) & (kRadix - 1);
+            const uint32_t g = cursor[d] + (s - tile_off[d]);
+            out_keys[g] = k;
+            out_vals[g] = stage_val[s];
+        }
+        __syncthreads();
+        if (threadIdx.x < kRadix) cursor[threadIdx.x] += total[threadIdx.x];
+        __syncthreads();
+    }
+}
+
+/// One lane per bin: locate the bin's run in the sorted keys and add it sequentially
+template <typename T>
+__global__ __launch_bounds__(256) void k_segment_sum(T *__restrict__ target, size_t table_size,
+                                                     const uint32_t *__restrict__ keys, const T *__restrict__ vals, size_t m) {
+    const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= table_size) return;
+    auto lower_bound = [&](uint64_t key) {
+        size_t lo = 0, hi = m;
+        while (lo < hi) {
+            size_t mid = (lo + hi) >> 1;
+            if ((uint64_t) keys[mid] < key) lo = mid + 1; else hi = mid;
+        }
+        return lo;
+    };
+    const size_t lo = lower_bound(k), hi = lower_bound(k + 1);
+    if (lo == hi) return;
+    T acc = target[k];
+    for (size_t i = lo; i < hi; ++i) acc += vals[i];
+    target[k] = acc;
+}
+
+template <typename T, typename I>
+int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
+                       size_t n) {
+    Context &c = ctx();
+    int bits = 1;
+    while (((size_t) 1 << bits) < table_size && bits < 32) ++bits;
+    const int passes = (bits + kRadixBits - 1) / kRadixBits;
+
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+    const size_t count_entries = (size_t) kRadix * blocks;
+
+    Scratch counts, keys_a, vals_a, keys_b, vals_b;
+    if (int rc = counts.alloc((count_entries + 2 * kRadix + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = keys_a.alloc(n * sizeof(uint32_t))) return rc;
+    if (int rc = vals_a.alloc(n * sizeof(T))) return rc;
+    if (passes > 1) {
+        if (int rc = keys_b.alloc(n * sizeof(uint32_t))) return rc;
+        if (int rc = vals_b.alloc(n * sizeof(T))) return rc;
+    }
+    uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
+    uint32_t *bucket_base = row_total + kRadix;
+
+    size_t m = n;                         // valid pairs after the first pass dropped the masked ones
+    const uint32_t *in_keys = nullptr;
+    const T *in_vals = nullptr;
+    for (int p = 0; p < passes; ++p) {
+        const int shift = p * kRadixBits;
+        uint32_t *out_keys = (uint32_t *) ((p & 1) ? keys_b.ptr : keys_a.ptr);
+        T *out_vals = (T *) ((p & 1) ? vals_b.ptr : vals_a.ptr);
+        if (p == 0) {
+            hipLaunchKernelGGL((k_radix_count<I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr,
+                               index.ptr, mask, n, chunk, shift);
+        } else {
+            Arg<uint8_t> all_on{ nullptr, 1, 0 };
+            hipLaunchKernelGGL((k_radix_count<uint32_t>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                               (uint32_t *) counts.ptr, in_keys, all_on, m, chunk, shift);
+        }
+        hipLaunchKernelGGL(k_bin_scan_rows, dim3(kRadix), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
+        hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (const uint32_t *) row_total, kRadix);
+        if (p == 0) {
+            hipLaunchKernelGGL((k_radix_partition_stable<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys,
+                               out_vals, index.ptr, value, mask, (const uint32_t *) counts.ptr,
+                               (const uint32_t *) bucket_base, n, chunk, shift);
+            uint32_t valid = 0;           // the only synchronisation of the deterministic path
+            EK_HIP_CHECK(hipMemcpyAsync(&valid, bucket_base + kRadix, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+            EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+            m = valid;
+        } else {
+            Arg<uint8_t> all_on{ nullptr, 1, 0 };
+            Arg<T> vals{ in_vals, T(0), 1 };
+            hipLaunchKernelGGL((k_radix_partition_stable<T, uint32_t>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys,
+                               out_vals, in_keys, vals, all_on, (const uint32_t *) counts.ptr,
+                               (const uint32_t *) bucket_base, m, chunk, shift);
+        }
+        EK_LAUNCH_CHECK("scatter_add_sort_pass", n, 0);
+        in_keys = out_keys;
+        in_vals = out_vals;
+        if (m == 0) return EK_OK;
+    }
+    hipLaunchKernelGGL((k_segment_sum<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
+                       table_size, in_keys, in_vals, m);
+    EK_LAUNCH_CHECK("scatter_add_segment_sum", table_size, m * (sizeof(uint32_t) + sizeof(T)));
+    return EK_OK;
+}
+
+#define EK_SORTED_INSTANCE(T, I)                                                                                      \
+    template int scatter_add_sorted<T, I>(T *, size_t, const Arg<T> &, const Arg<I> &, const Arg<uint8_t> &, size_t);
+EK_SORTED_INSTANCE(float, uint32_t) EK_SORTED_INSTANCE(float, int32_t)
+EK_SORTED_INSTANCE(double, uint32_t) EK_SORTED_INSTANCE(double, int32_t)
+
+} // namespace ek

@@ -116,7 +116,7 @@ EK_API char *ek_hip_whos(void);
 EK_API void ek_hip_set_log_level(uint32_t level);   /* 0 silent .. 3 every launch (cuda.h:195-200) */
 EK_API uint32_t ek_hip_log_level(void);
 EK_API uint64_t ek_hip_launch_count(void);          /* kernels launched since init (diagnostics) */
-EK_API int ek_hip_set_tuning(const char *key, int value);   /* "blocks_per_cu", "reduce_blocks_per_cu" */
+EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic" */
 /* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
    launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of
    {"kernel", "launches", "total_ms", "bytes", "elements"}; `bytes` are the ALGORITHMIC bytes of the
@@ -158,9 +158,11 @@ EK_API int ek_hip_gather(int type, int index_type, void *out, const void *base,
                          const ek_operand *index, const ek_operand *mask, size_t n);
 EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
                           const ek_operand *index, const ek_operand *mask, size_t n);
-/* mode 0: hardware atomics (order of fp additions unspecified, like atom.global.add);
-   mode 1: deterministic -- bit-identical to the CPU reference's element-order accumulation
-           (dynamic.h:517-534); `base_size` (elements) is required for mode 1. */
+/* mode 0: fastest -- LDS-binned accumulation for large inputs (needs `base_size`), hardware atomics otherwise;
+           the order of fp additions is unspecified, like the reference's atom.global.add;
+   mode 1: deterministic -- stable radix sort by index + sequential per-bin sums: bit-identical to the CPU
+           reference's element-order accumulation (dynamic.h:517-534).  Needs `base_size` and a 32-bit
+           index array; synchronizes once.  Integer types are exact in either mode. */
 EK_API int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size,
                               const ek_operand *value, const ek_operand *index,
                               const ek_operand *mask, size_t n, int mode);

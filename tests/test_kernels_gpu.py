@@ -394,3 +394,38 @@ def test_scatter_add_binned_f32(capi, K):
     d = up(capi, np.zeros(K, np.float32))
     capi.scatter_add(d, 0.5, up(capi, idx), n=n)
     assert np.array_equal(d.numpy(), (np.bincount(idx, minlength=K) * 0.5).astype(np.float32))
+
+
+# ----------------------------------------------------------------------------------------------
+#  deterministic scatter_add (mode 1): stable radix sort + sequential per-bin sums == CPU element order
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("K,n", [(7, 1000), (257, 5003), (4096, 100003), (70000, 300001), (1 << 20, (1 << 21) + 11)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_scatter_add_deterministic_bit_exact(capi, oracle, K, n, masked):
+    rng = np.random.default_rng(K + n)
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    val = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)).astype(np.float32)     # wide dynamic range
+    m = (rng.integers(0, 4, n) != 0).astype(np.uint8) if masked else np.ones(n, np.uint8)
+    tgt = rng.standard_normal(K).astype(np.float32)
+    d = up(capi, tgt)
+    capi.scatter_add(d, up(capi, val), up(capi, idx), up(capi, m) if masked else True, mode=1)
+    assert bits_equal(d.numpy(), oracle.scatter(tgt, val, idx, m, add=True))
+    # run-to-run identical as well
+    d2 = up(capi, tgt)
+    capi.scatter_add(d2, up(capi, val), up(capi, idx.astype(np.int32)), up(capi, m) if masked else True, mode=1)
+    assert bits_equal(d2.numpy(), d.numpy())
+
+
+def test_scatter_add_deterministic_switch(capi, oracle):
+    """the global switch (ENOKI_HIP_DETERMINISTIC / tuning) routes the default mode through the sorted path"""
+    rng = np.random.default_rng(5)
+    K, n = 1000, 200003
+    idx = rng.integers(0, K, n).astype(np.uint32); val = rng.standard_normal(n).astype(np.float32)
+    tgt = np.zeros(K, np.float32)
+    capi.set_tuning("deterministic", 1)
+    try:
+        d = up(capi, tgt)
+        capi.scatter_add(d, up(capi, val), up(capi, idx))
+        assert bits_equal(d.numpy(), oracle.scatter(tgt, val, idx, np.ones(n, np.uint8), add=True))
+    finally:
+        capi.set_tuning("deterministic", 0)

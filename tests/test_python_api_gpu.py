@@ -157,3 +157,22 @@ def test_vector3f_ray_sphere_in_python(ekc):
     assert bits_equal(got, img)
     v = ekc.Vector3f(F(3.0), F(0.0), F(4.0))
     assert ekc.norm(v)[0] == 5.0 and len(v) == 3 and ekc.cross(ekc.Vector3f(F(1.0), F(0.0), F(0.0)), ekc.Vector3f(F(0.0), F(1.0), F(0.0))).z[0] == 1.0
+
+
+@pytest.mark.parametrize("n", [1000, 65536])
+def test_cfg3b_deterministic_mode_is_bit_exact(ek, n):
+    """with the deterministic scatter_add the table gradients of cfg3b equal the reference build bit for bit
+    (only y, an hsum, stays order dependent)"""
+    z = np.load(os.path.join(GOLDEN, "configs.npz"))
+    K = 1024
+    A = ek.Float32(uniform_pm1(K, 6)); B = ek.Float32(uniform_pm1(K, 7)); x = ek.Float32(uniform_pm1(n, 2))
+    idx = ek.UInt32((hash_u32(np.arange(n, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32))
+    ek.hip_set_tuning("deterministic", 1)
+    try:
+        ek.set_requires_gradient(A); ek.set_requires_gradient(B)
+        y = ek.hsum(ek.sin(ek.fmadd(ek.gather(A, idx), x, ek.gather(B, idx))))
+        ek.backward(y)
+        assert bits_equal(ek.gradient(A).numpy(), z[f"cfg3b_{n}_gA"])
+        assert bits_equal(ek.gradient(B).numpy(), z[f"cfg3b_{n}_gB"])
+    finally:
+        ek.hip_set_tuning("deterministic", 0)
