@@ -134,6 +134,8 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("hmin", [](const Array &a) { return hmin(a); });
         m.def("hmax", [](const Array &a) { return hmax(a); });
         m.def("psum", [](const Array &a) { return psum(a); });
+        if constexpr (!IsDiff)
+            m.def("compress", [](const Array &a, const Mask &mk) { return compress(a, mk); });
         m.def("reverse", [](const Array &a) { return reverse(a); });
     }
 

@@ -204,6 +204,9 @@ ENOKI_HIP_ROUTE_UNARY(any, any)
 ENOKI_HIP_ROUTE_UNARY(count, count)
 
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline bool none(const T &a) { return !any(a); }
+template <typename T, typename M, enable_if_t<is_array_v<T>> = 0> inline T compress(const T &a, const M &mask) {
+    return a.compress_(detail::as<mask_t<T>>(mask));
+}
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sqr(const T &a) { return a * a; }
 
 // Scalar fallbacks so that templated code also accepts plain arithmetic types

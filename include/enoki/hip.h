@@ -54,6 +54,33 @@ namespace detail {
     template <> struct hip_type<double>   { static constexpr int value = EK_F64; };
 }
 
+namespace detail {
+    /// Ops on two host-known scalars are evaluated on the host (single IEEE operations: same bits as the
+    /// kernels); returns false for ops that need the device algorithms (transcendentals, ...).
+    template <typename V> inline bool host_binary(int op, V a, V b, V &out) {
+        if constexpr (std::is_floating_point_v<V>) {
+            switch (op) {
+                case EK_ADD: out = a + b; return true;
+                case EK_SUB: out = a - b; return true;
+                case EK_MUL: out = a * b; return true;
+                case EK_DIV: out = a / b; return true;
+                case EK_SAFE_MUL: out = (a == V(0) || b == V(0)) ? V(0) : a * b; return true;
+                default: return false;
+            }
+        } else if constexpr (std::is_integral_v<V> && !std::is_same_v<V, bool>) {
+            using U = std::make_unsigned_t<V>;
+            switch (op) {
+                case EK_ADD: out = (V) ((U) a + (U) b); return true;
+                case EK_SUB: out = (V) ((U) a - (U) b); return true;
+                case EK_MUL: out = (V) ((U) a * (U) b); return true;
+                default: return false;
+            }
+        } else {
+            return false;
+        }
+    }
+}
+
 template <typename Value_> struct HIPArray : ArrayTag {
     static_assert(std::is_arithmetic_v<Value_>, "HIPArray: arithmetic element types only");
     template <typename T> friend struct HIPArray;
@@ -387,6 +414,21 @@ template <typename Value_> struct HIPArray : ArrayTag {
     bool any_() const { return mask_reduce(EK_ANY, "any_") != 0; }
     size_t count_() const { return (size_t) mask_reduce(EK_COUNT, "count_"); }
 
+    /// Stream compaction (cuda.h:907-923 / horiz.cu:124-160): keeps the entries whose mask is set, in order.
+    /// Built from the library's own scan + scatter; reads the new size back (synchronises, like the reference).
+    HIPArray compress_(const MaskType &mask) const {
+        if (mask.size() == 0) return HIPArray();
+        if (mask.size() != size()) throw std::runtime_error("HIPArray::compress_(): size mismatch!");
+        if (size() == 1) return mask.coeff(0) ? *this : HIPArray();
+        using UInt32 = HIPArray<uint32_t>;
+        UInt32 ones = UInt32::select_(mask, UInt32(1u), UInt32(0u));
+        UInt32 pos = ones.psum_();                         // inclusive prefix sum: 1-based slot of kept entries
+        size_t kept = (size_t) pos.coeff(size() - 1);
+        HIPArray result = empty_(kept);
+        if (kept) scatter_<sizeof(Value)>(result.data(), pos.sub_(UInt32(1u)), mask);
+        return result;
+    }
+
     HIPArray reverse_() const {
         size_t n = size();
         if (n <= 1) return *this;
@@ -533,6 +575,12 @@ private:
 
     HIPArray unary(int op, const char *what) const {
         require_valid(what);
+        if constexpr (!IsMask) {
+            if (m_is_imm && op == EK_NEG) {
+                if constexpr (IsFloat) return HIPArray(Value(-m_imm));
+                else return HIPArray((Value) (std::make_unsigned_t<Value>(0) - (std::make_unsigned_t<Value>) m_imm));
+            }
+        }
         size_t n = size();
         HIPArray r = empty_(n);
         ek_operand oa = operand();
@@ -542,6 +590,10 @@ private:
 
     HIPArray binary(int op, const HIPArray &b, const char *what) const {
         require_valid(what); b.require_valid(what);
+        if (m_is_imm && b.m_is_imm) {
+            Value r;
+            if (detail::host_binary<Value>(op, m_imm, b.m_imm, r)) return HIPArray(r);
+        }
         size_t n = broadcast_size(size(), b.size());
         HIPArray r = empty_(n);
         ek_operand oa = operand(), ob = b.operand();

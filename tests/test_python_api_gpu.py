@@ -176,3 +176,17 @@ def test_cfg3b_deterministic_mode_is_bit_exact(ek, n):
         assert bits_equal(ek.gradient(B).numpy(), z[f"cfg3b_{n}_gB"])
     finally:
         ek.hip_set_tuning("deterministic", 0)
+
+
+def test_compress_and_immediate_fast_path(ekc):
+    rng = np.random.default_rng(3)
+    for n in (1, 5, 1000, 100003):
+        a = rng.standard_normal(n).astype(np.float32); m = rng.integers(0, 2, n).astype(bool)
+        got = ekc.compress(ekc.Float32(a), ekc.Mask(m.astype(np.uint8))).numpy()
+        assert bits_equal(got, a[m])
+    u = np.arange(1000, dtype=np.uint32)
+    assert np.array_equal(ekc.compress(ekc.UInt32(u), ekc.UInt32(u) % ekc.UInt32(3) == ekc.UInt32(0)).numpy(), u[u % 3 == 0])
+    # scalar (op) scalar is evaluated on the host: no kernel launch, same bits
+    before = ekc.hip_launch_count()
+    r = ekc.Float32(1.5) * ekc.Float32(2.0) + ekc.Float32(0.25) - ekc.Float32(1.0)
+    assert ekc.hip_launch_count() == before and r[0] == 2.25 and len(r) == 1
