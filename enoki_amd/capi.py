@@ -23,9 +23,11 @@ EK2NP = {BOOL: np.uint8, I32: np.int32, U32: np.uint32, I64: np.int64, U64: np.u
 
 UNARY = {n: i for i, n in enumerate(
     ["neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
-     "popcnt", "lzcnt", "tzcnt", "sign", "copy"])}
+     "popcnt", "lzcnt", "tzcnt", "sign", "copy", "tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh",
+     "acosh", "atanh", "cbrt"])}
 BINARY = {n: i for i, n in enumerate(
-    ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul"])}
+    ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
+     "atan2", "pow", "fmod", "ldexp"])}
 TERNARY = {n: i for i, n in enumerate(["fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd"])}
 COMPARE = {n: i for i, n in enumerate(["eq", "neq", "lt", "le", "gt", "ge"])}
 REDUCE = {n: i for i, n in enumerate(["hsum", "hprod", "hmin", "hmax"])}
@@ -36,7 +38,7 @@ EXPORTS = [
     "ek_hip_last_error", "ek_hip_malloc", "ek_hip_free", "ek_hip_malloc_trim", "ek_hip_host_malloc",
     "ek_hip_host_free", "ek_hip_mem_get_info", "ek_hip_memcpy_to_device", "ek_hip_memcpy_to_host",
     "ek_hip_memcpy_device", "ek_hip_memset", "ek_hip_whos", "ek_hip_set_log_level", "ek_hip_log_level",
-    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos",
+    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum",
@@ -209,6 +211,14 @@ def ternary(op, a, b, c, n=None):
     check(lib.ek_hip_ternary(TERNARY[op], NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(oa), ctypes.byref(ob),
                              ctypes.byref(oc), ctypes.c_size_t(n)))
     return out
+
+
+def sincosh(a):
+    dt = _dtype(a); n = _n(a)
+    s = Buf(dt, n); c = Buf(dt, n); oa = operand(a, dt)
+    check(lib.ek_hip_sincosh(NP2EK[dt], ctypes.c_void_p(s.ptr), ctypes.c_void_p(c.ptr), ctypes.byref(oa),
+                             ctypes.c_size_t(n)))
+    return s, c
 
 
 def sincos(a):

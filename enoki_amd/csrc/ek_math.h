@@ -115,6 +115,231 @@ __device__ __forceinline__ float log_f32(float x) {
     return valid ? r : u2f(0xffffffffu);
 }
 
+// ------------------------------------------------------------------------------------------------
+//  Second wave: tan/cot, asin/acos/atan/atan2, cbrt, pow, hyperbolic and
+//  inverse hyperbolic functions -- float branches of array_math.h.
+//
+//  Polynomials use the reference's Estrin groupings (array_math.h:25-105), one overload per
+//  degree; c[k] multiplies x^k.  Coefficients the reference writes as double literals and then
+//  narrows (`S(c)`) are written the same way here so that both sides round the literal once.
+//  Where the reference calls rcp() the AVX2 path uses rcpps + one Newton step
+//  (array_avx.h:324-357, machine dependent); the kernels divide exactly, so tan/cot/sinh/cosh/tanh
+//  are parity class C (few ulp), everything else in this block is bit-exact (class A).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float fma_(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+__device__ __forceinline__ float estrin(float x, float c0, float c1, float c2) {
+    float x2 = x * x;
+    return fma_(x2, c2, fma_(x, c1, c0));
+}
+__device__ __forceinline__ float estrin(float x, float c0, float c1, float c2, float c3) {
+    float x2 = x * x;
+    return fma_(x2, fma_(x, c3, c2), fma_(x, c1, c0));
+}
+__device__ __forceinline__ float estrin(float x, float c0, float c1, float c2, float c3, float c4) {
+    float x2 = x * x, x4 = x2 * x2;
+    return fma_(x2, fma_(x, c3, c2), fma_(x, c1, c0) + c4 * x4);
+}
+__device__ __forceinline__ float estrin(float x, float c0, float c1, float c2, float c3, float c4, float c5) {
+    float x2 = x * x, x4 = x2 * x2;
+    return fma_(x2, fma_(x, c3, c2), fma_(x4, fma_(x, c5, c4), fma_(x, c1, c0)));
+}
+__device__ __forceinline__ float estrin(float x, float c0, float c1, float c2, float c3, float c4, float c5,
+                                        float c6) {
+    float x2 = x * x, x4 = x2 * x2;
+    return fma_(x4, fma_(x2, c6, fma_(x, c5, c4)), fma_(x2, fma_(x, c3, c2), fma_(x, c1, c0)));
+}
+
+__device__ __forceinline__ float copysign_f32(float mag, float sgn) {       // array_router.h:397
+    return u2f((f2u(mag) & 0x7fffffffu) | (f2u(sgn) & 0x80000000u));
+}
+__device__ __forceinline__ float mulsign_f32(float v, float sgn) {          // array_router.h:449
+    return u2f(f2u(v) ^ (f2u(sgn) & 0x80000000u));
+}
+__device__ __forceinline__ float nan_mask_f32() { return u2f(0xffffffffu); }
+
+// frexp / ldexp by exponent-field surgery (array_math.h:677-709); zero, denormal-as-zero-exponent,
+// inf and NaN pass through frexp unchanged with exponent 0
+__device__ __forceinline__ float frexp_f32(float x, float &e_out) {
+    uint32_t xi = f2u(x), eb = xi & 0x7f800000u;
+    bool normal = (x != 0.0f) && (eb != 0x7f800000u);
+    e_out = (float) (normal ? (int32_t) (eb >> 23) - 0x7f : 0);
+    return u2f(normal ? ((xi & ~0x7f800000u) | 0x3f000000u) : xi);
+}
+__device__ __forceinline__ float ldexp_f32(float x, float e) {
+    return x * u2f(((uint32_t) cvtt_i32(e) + 0x7fu) << 23);
+}
+
+// tan / cot: detail::tancot_approx (array_math.h:369-442)
+template <bool Tan> __device__ __forceinline__ float tancot_f32(float x) {
+    float xa = __builtin_fabsf(x);
+    int32_t j = cvtt_i32(xa * (float) 1.2732395447351626862);
+    j = (int32_t) (((uint32_t) j + 1u) & ~1u);
+    float y = (float) j;
+
+    float t = xa - y * (float) 0.78515625;
+    t = t - y * (float) 2.4187564849853515625e-4;
+    t = t - y * (float) 3.77489497744594108e-8;
+    y = t;
+
+    float z = y * y;
+    if (xa == __builtin_inff()) z = nan_mask_f32();
+
+    float r = estrin(z, (float) 3.33331568548e-1, (float) 1.33387994085e-1, (float) 5.34112807005e-2,
+                     (float) 2.44301354525e-2, (float) 3.11992232697e-3, (float) 9.38540185543e-3);
+    r = fma_(r, z * y, y);
+
+    bool recip = Tan ? (j & 2) != 0 : (j & 2) == 0;
+    if (xa < (float) 1e-4) r = y;
+    if (recip) r = 1.0f / r;
+
+    uint32_t sign = ((uint32_t) j << 30) ^ f2u(x);
+    return u2f(f2u(r) ^ (sign & 0x80000000u));
+}
+
+// shared front end of asin / acos (array_math.h:489-506, :571-585); c0 differs in the last digits
+__device__ __forceinline__ float asin_core_f32(float x, float c0, bool &big) {
+    float xa = __builtin_fabsf(x), x2 = x * x;
+    big = xa > 0.5f;
+    float x1 = 0.5f * (1.0f - xa);
+    float x3 = big ? x1 : x2;
+    float x4 = big ? __builtin_sqrtf(x1) : xa;
+    float z1 = estrin(x3, c0, 7.4953002686e-2f, 4.5470025998e-2f, 2.4181311049e-2f, 4.2163199048e-2f);
+    return fma_(z1, x3 * x4, x4);
+}
+
+__device__ __forceinline__ float asin_f32(float x) {                        // array_math.h:474-553
+    bool big;
+    float z1 = asin_core_f32(x, 1.6666752422e-1f, big);
+    float r = big ? (float) 1.57079632679489661923 - (z1 + z1) : z1;
+    return copysign_f32(r, x);
+}
+
+__device__ __forceinline__ float acos_f32(float x) {                        // array_math.h:555-601
+    bool big;
+    float z1 = asin_core_f32(x, 1.666675242e-1f, big);
+    float z2 = z1 + z1;
+    if (x < 0.0f) z2 = (float) 3.14159265358979323846 - z2;
+    float z3 = (float) 1.57079632679489661923 - copysign_f32(z1, x);
+    return big ? z2 : z3;
+}
+
+// atan2(y, x): minimax fit in min/max form (array_math.h:603-664); min/max keep the x86
+// operand convention of BinaryOp (second operand returned on unordered compares)
+__device__ __forceinline__ float atan2_f32(float y, float x) {
+    float abs_x = __builtin_fabsf(x), abs_y = __builtin_fabsf(y);
+    float min_val = abs_x < abs_y ? abs_x : abs_y;      // min(abs_y, abs_x)
+    float max_val = abs_y > abs_x ? abs_y : abs_x;      // max(abs_x, abs_y)
+    float scale = 1.0f / max_val;
+    float scaled_min = min_val * scale;
+    float z = scaled_min * scaled_min;
+
+    float t = estrin(z, (float) 0.99999934166683966009, (float) -0.33326497518773606976,
+                     (float) 0.19881342388439013552, (float) -0.13486708938456973185,
+                     (float) 0.083863120428809689910, (float) -0.037006525670417265220,
+                     (float) 0.0078613793713198150252);
+    t = t * scaled_min;
+    if (abs_y > abs_x) t = (float) 1.57079632679489661923 - t;
+    if (x < 0.0f) t = (float) 3.14159265358979323846 - t;
+    float r = y < 0.0f ? u2f(f2u(t) ^ 0x80000000u) : t;
+    return max_val != 0.0f ? r : 0.0f;
+}
+
+// cbrt (array_math.h:900-954): polynomial seed on the frexp mantissa, exponent / 3 with a
+// cbrt(2), cbrt(4) fix-up, one Newton step
+__device__ __forceinline__ float cbrt_f32(float x) {
+    const float CBRT2 = (float) 1.25992104989487316477, CBRT4 = (float) 1.58740105196819947475,
+                THIRD = (float) (1.0 / 3.0);
+    float xa = __builtin_fabsf(x), xe;
+    float xm = frexp_f32(xa, xe);
+    xe += 1.0f;
+
+    float xea = __builtin_fabsf(xe), xea1 = __builtin_floorf(xea * THIRD), rem = fma_(-xea1, 3.0f, xea);
+
+    xm = estrin(xm, (float) 0.40238979564544752126924, (float) 1.1399983354717293273738,
+                (float) -0.95438224771509446525043, (float) 0.54664601366395524503440,
+                (float) -0.13466110473359520655053);
+
+    float f1 = xe >= 0.0f ? CBRT2 : 1.0f / CBRT2, f2 = xe >= 0.0f ? CBRT4 : 1.0f / CBRT4;
+    float f = rem == 1.0f ? f1 : f2;
+    if (rem != 0.0f) xm *= f;
+
+    float r = ldexp_f32(xm, mulsign_f32(xea1, xe));
+    r = mulsign_f32(r, x);
+    r -= (r - (x / (r * r))) * THIRD;
+    return __builtin_fabsf(x) < __builtin_inff() ? r : x;
+}
+
+__device__ __forceinline__ float pow_f32(float x, float y) { return exp_f32(log_f32(x) * y); }   // array_math.h:956-958
+
+__device__ __forceinline__ float fmod_f32(float x, float y) {               // array_math.h:1381-1383
+    return fma_(-__builtin_truncf(x / y), y, x);
+}
+
+// odd polynomial used by sinh / sincosh for |x| <= 1 (array_math.h:1028-1031)
+__device__ __forceinline__ float sinh_small_f32(float x) {
+    float x2 = x * x;
+    return fma_(estrin(x2, (float) 1.66667160211e-1, (float) 8.33028376239e-3, (float) 2.03721912945e-4), x2 * x, x);
+}
+
+__device__ __forceinline__ float sinh_f32(float x) {                        // array_math.h:997-1046
+    float e0 = exp_f32(x), e1 = 1.0f / e0;
+    return __builtin_fabsf(x) > 1.0f ? (e0 - e1) * 0.5f : sinh_small_f32(x);
+}
+
+__device__ __forceinline__ float cosh_f32(float x) {                        // array_math.h:1048-1065
+    float e0 = exp_f32(x), e1 = 1.0f / e0;
+    return (e0 + e1) * 0.5f;
+}
+
+__device__ __forceinline__ void sincosh_f32(float x, float &s, float &c) {  // array_math.h:1067-1127
+    float e0 = exp_f32(x), e1 = 1.0f / e0;
+    s = __builtin_fabsf(x) > 1.0f ? (e0 - e1) * 0.5f : sinh_small_f32(x);
+    c = 0.5f * (e0 + e1);
+}
+
+__device__ __forceinline__ float tanh_f32(float x) {                        // array_math.h:1129-1179
+    float x2 = x * x;
+    float r_small = estrin(x2, (float) -3.33332819422e-1, (float) 1.33314422036e-1, (float) -5.37397155531e-2,
+                           (float) 2.06390887954e-2, (float) -5.70498872745e-3);
+    r_small = fma_(r_small, x2 * x, x);
+    float e = exp_f32(x + x), e2 = 1.0f / (e + 1.0f);
+    float r_big = 1.0f - (e2 + e2);
+    return __builtin_fabsf(x) >= 0.625f ? r_big : r_small;
+}
+
+__device__ __forceinline__ float asinh_f32(float x) {                       // array_math.h:1185-1237
+    float x2 = x * x, xa = __builtin_fabsf(x);
+    bool big = xa >= (float) 0.51, huge = xa >= (float) 1e10;
+    float r_small = estrin(x2, (float) -1.6666288134e-1, (float) 7.4847586088e-2, (float) -4.2699340972e-2,
+                           (float) 2.0122003309e-2);
+    r_small = fma_(r_small, x2 * x, x);
+    float r_big = log_f32(xa + (huge ? 0.0f : __builtin_sqrtf(x2 + 1.0f)));
+    if (huge) r_big += (float) 0.693147180559945309417;
+    return big ? copysign_f32(r_big, x) : r_small;
+}
+
+__device__ __forceinline__ float acosh_f32(float x) {                       // array_math.h:1239-1293
+    float x1 = x - 1.0f;
+    bool big = x1 >= (float) 0.49, huge = x1 >= (float) 1e10;
+    float r_small = estrin(x1, (float) 1.4142135263e+0, (float) -1.1784741703e-1, (float) 2.6454905019e-2,
+                           (float) -7.5272886713e-3, (float) 1.7596881071e-3);
+    r_small *= __builtin_sqrtf(x1);
+    if (x1 < 0.0f) r_small = nan_mask_f32();
+    float r_big = log_f32(x + (huge ? 0.0f : __builtin_sqrtf(fma_(x, x, -1.0f))));
+    if (huge) r_big += (float) 0.693147180559945309417;
+    return big ? r_big : r_small;
+}
+
+__device__ __forceinline__ float atanh_f32(float x) {                       // array_math.h:1295-1348
+    float xa = __builtin_fabsf(x), x2 = x * x;
+    float r_small = estrin(x2, (float) 3.33337300303e-1, (float) 1.99782164500e-1, (float) 1.46691431730e-1,
+                           (float) 8.24370301058e-2, (float) 1.81740078349e-1);
+    r_small = fma_(r_small, x2 * x, x);
+    float r_big = log_f32((1.0f + xa) / (1.0f - xa)) * 0.5f;
+    return xa >= 0.5f ? copysign_f32(r_big, x) : r_small;
+}
+
 // safe_mul / safe_fmadd: CPU branch of src/autodiff/autodiff.cpp:1191-1221
 // (w == 0 || g == 0) ? 0 : w*g     resp.    (w == 0 || g == 0) ? acc : fma(w, g, acc)
 template <typename T> __device__ __forceinline__ T safe_mul(T w, T g) {

@@ -17,9 +17,11 @@ namespace ek {
 // kernel names reported by ek_hip_profile_end() / ENOKI_HIP_LOG=3
 static const char *const unary_names[EK_UNARY_COUNT] = {
     "neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
-    "popcnt", "lzcnt", "tzcnt", "sign", "copy" };
+    "popcnt", "lzcnt", "tzcnt", "sign", "copy", "tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh",
+    "acosh", "atanh", "cbrt" };
 static const char *const binary_names[EK_BINARY_COUNT] = {
-    "add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul" };
+    "add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
+    "atan2", "pow", "fmod", "ldexp" };
 static const char *const ternary_names[EK_TERNARY_COUNT] = { "fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd" };
 
 template <typename T> inline constexpr bool is_fp = std::is_floating_point_v<T>;
@@ -48,7 +50,9 @@ template <int Op, typename T> constexpr bool unary_supported() {
         case EK_NOT: return !is_fp<T>;
         case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_FLOOR: case EK_CEIL: case EK_ROUND: case EK_TRUNC:
         case EK_SIGN: return is_fp<T>;
-        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG: return std::is_same_v<T, float>;
+        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
+        case EK_TAN: case EK_COT: case EK_ASIN: case EK_ACOS: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_TANH:
+        case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return std::is_same_v<T, float>;
         case EK_POPCNT: case EK_LZCNT: case EK_TZCNT: return is_int<T>;
         case EK_COPY: return true;
         default: return false;
@@ -56,7 +60,6 @@ template <int Op, typename T> constexpr bool unary_supported() {
 }
 
 template <int Op, typename T> struct UnaryOp {
-    static constexpr bool heavy = Op == EK_SIN || Op == EK_COS || Op == EK_EXP || Op == EK_LOG;
     static __device__ __forceinline__ T apply(T x) {
         using U = uint_of<T>;
         constexpr U sign_bit = U(1) << (sizeof(T) * 8 - 1);
@@ -97,6 +100,30 @@ template <int Op, typename T> struct UnaryOp {
             return dev::exp_f32(x);
         } else if constexpr (Op == EK_LOG) {
             return dev::log_f32(x);
+        } else if constexpr (Op == EK_TAN) {
+            return dev::tancot_f32<true>(x);
+        } else if constexpr (Op == EK_COT) {
+            return dev::tancot_f32<false>(x);
+        } else if constexpr (Op == EK_ASIN) {
+            return dev::asin_f32(x);
+        } else if constexpr (Op == EK_ACOS) {
+            return dev::acos_f32(x);
+        } else if constexpr (Op == EK_ATAN) {
+            return dev::atan2_f32(x, 1.0f);     // array_math.h:666-668
+        } else if constexpr (Op == EK_SINH) {
+            return dev::sinh_f32(x);
+        } else if constexpr (Op == EK_COSH) {
+            return dev::cosh_f32(x);
+        } else if constexpr (Op == EK_TANH) {
+            return dev::tanh_f32(x);
+        } else if constexpr (Op == EK_ASINH) {
+            return dev::asinh_f32(x);
+        } else if constexpr (Op == EK_ACOSH) {
+            return dev::acosh_f32(x);
+        } else if constexpr (Op == EK_ATANH) {
+            return dev::atanh_f32(x);
+        } else if constexpr (Op == EK_CBRT) {
+            return dev::cbrt_f32(x);
         } else if constexpr (Op == EK_POPCNT) {
             if constexpr (sizeof(T) == 4) return (T) __popc((uint32_t) x); else return (T) __popcll((uint64_t) x);
         } else if constexpr (Op == EK_LZCNT) {
@@ -111,6 +138,10 @@ template <int Op, typename T> struct UnaryOp {
 
 struct SinCosOp {
     static __device__ __forceinline__ void apply(float x, float &s, float &c) { dev::sincos_f32<true, true>(x, s, c); }
+};
+
+struct SinCoshOp {
+    static __device__ __forceinline__ void apply(float x, float &s, float &c) { dev::sincosh_f32(x, s, c); }
 };
 
 template <int Op, typename T> int unary_launch(void *out, const ek_operand *a, size_t n) {
@@ -131,6 +162,9 @@ template <typename T> int unary_dispatch(int op, void *out, const ek_operand *a,
         EK_UNARY_CASE(EK_ROUND) EK_UNARY_CASE(EK_TRUNC) EK_UNARY_CASE(EK_SIN) EK_UNARY_CASE(EK_COS)
         EK_UNARY_CASE(EK_EXP) EK_UNARY_CASE(EK_LOG) EK_UNARY_CASE(EK_POPCNT) EK_UNARY_CASE(EK_LZCNT)
         EK_UNARY_CASE(EK_TZCNT) EK_UNARY_CASE(EK_SIGN) EK_UNARY_CASE(EK_COPY)
+        EK_UNARY_CASE(EK_TAN) EK_UNARY_CASE(EK_COT) EK_UNARY_CASE(EK_ASIN) EK_UNARY_CASE(EK_ACOS)
+        EK_UNARY_CASE(EK_ATAN) EK_UNARY_CASE(EK_SINH) EK_UNARY_CASE(EK_COSH) EK_UNARY_CASE(EK_TANH)
+        EK_UNARY_CASE(EK_ASINH) EK_UNARY_CASE(EK_ACOSH) EK_UNARY_CASE(EK_ATANH) EK_UNARY_CASE(EK_CBRT)
         default: return fail(EK_ERR_INVALID, "ek_hip_unary(): unknown op %d", op);
     }
 }
@@ -143,7 +177,8 @@ template <int Op, typename T> constexpr bool binary_supported() {
         case EK_ADD: case EK_SUB: case EK_MUL: case EK_DIV: case EK_MIN: case EK_MAX: return !is_mask<T>;
         case EK_MOD: case EK_MULHI: case EK_SL: case EK_SR: return is_int<T>;
         case EK_AND: case EK_OR: case EK_XOR: return true;   // fp: bitwise on the representation
-        case EK_SAFE_MUL: return is_fp<T>;
+        case EK_SAFE_MUL: case EK_FMOD: return is_fp<T>;
+        case EK_ATAN2: case EK_POW: case EK_LDEXP: return std::is_same_v<T, float>;
         default: return false;
     }
 }
@@ -185,6 +220,15 @@ template <int Op, typename T> struct BinaryOp {
             else return (U) y >= Bits ? T(0) : (T) (x >> y);
         } else if constexpr (Op == EK_SAFE_MUL) {
             return dev::safe_mul(x, y);
+        } else if constexpr (Op == EK_ATAN2) {
+            return dev::atan2_f32(x, y);
+        } else if constexpr (Op == EK_POW) {
+            return dev::pow_f32(x, y);
+        } else if constexpr (Op == EK_LDEXP) {
+            return dev::ldexp_f32(x, y);
+        } else if constexpr (Op == EK_FMOD) {
+            if constexpr (sizeof(T) == 4) return dev::fmod_f32(x, y);
+            else return __builtin_fma(-__builtin_trunc(x / y), y, x);
         } else {
             return x;
         }
@@ -208,7 +252,8 @@ template <typename T> int binary_dispatch(int op, void *out, const ek_operand *a
         EK_BINARY_CASE(EK_ADD) EK_BINARY_CASE(EK_SUB) EK_BINARY_CASE(EK_MUL) EK_BINARY_CASE(EK_DIV)
         EK_BINARY_CASE(EK_MOD) EK_BINARY_CASE(EK_MIN) EK_BINARY_CASE(EK_MAX) EK_BINARY_CASE(EK_MULHI)
         EK_BINARY_CASE(EK_AND) EK_BINARY_CASE(EK_OR) EK_BINARY_CASE(EK_XOR) EK_BINARY_CASE(EK_SL)
-        EK_BINARY_CASE(EK_SR) EK_BINARY_CASE(EK_SAFE_MUL)
+        EK_BINARY_CASE(EK_SR) EK_BINARY_CASE(EK_SAFE_MUL) EK_BINARY_CASE(EK_ATAN2) EK_BINARY_CASE(EK_POW)
+        EK_BINARY_CASE(EK_FMOD) EK_BINARY_CASE(EK_LDEXP)
         default: return fail(EK_ERR_INVALID, "ek_hip_binary(): unknown op %d", op);
     }
 }
@@ -391,6 +436,15 @@ int ek_hip_sincos(int type, void *out, void *out_cos, const ek_operand *a, size_
     Arg<float> aa;
     if (int rc = make_arg<float>(a, n, aa, "ek_hip_sincos")) return rc;
     return launch_map1x2<SinCosOp>("sincos", (float *) out, (float *) out_cos, n, aa);
+}
+
+int ek_hip_sincosh(int type, void *out, void *out_cosh, const ek_operand *a, size_t n) {
+    EK_PROLOGUE("ek_hip_sincosh()")
+    if (!out_cosh) return fail(EK_ERR_INVALID, "ek_hip_sincosh(): null output pointer");
+    if (type != EK_F32) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sincosh(): only f32 is implemented");
+    Arg<float> aa;
+    if (int rc = make_arg<float>(a, n, aa, "ek_hip_sincosh")) return rc;
+    return launch_map1x2<SinCoshOp>("sincosh", (float *) out, (float *) out_cosh, n, aa);
 }
 
 int ek_hip_compare(int op, int type, uint8_t *out, const ek_operand *a, const ek_operand *b, size_t n) {

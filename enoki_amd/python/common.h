@@ -158,6 +158,30 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
             m.def("sincos", [](const Array &a) { return sincos(a); });
             m.def("exp", [](const Array &a) { return exp(a); });
             m.def("log", [](const Array &a) { return log(a); });
+            m.def("tan", [](const Array &a) { return tan(a); });
+            m.def("cot", [](const Array &a) { return cot(a); });
+            m.def("csc", [](const Array &a) { return csc(a); });
+            m.def("sec", [](const Array &a) { return sec(a); });
+            m.def("asin", [](const Array &a) { return asin(a); });
+            m.def("acos", [](const Array &a) { return acos(a); });
+            m.def("atan", [](const Array &a) { return atan(a); });
+            m.def("atan2", [](const Array &y, const Array &x) { return atan2(y, x); }, "y"_a, "x"_a);
+            m.def("sinh", [](const Array &a) { return sinh(a); });
+            m.def("cosh", [](const Array &a) { return cosh(a); });
+            m.def("sincosh", [](const Array &a) { return sincosh(a); });
+            m.def("tanh", [](const Array &a) { return tanh(a); });
+            m.def("csch", [](const Array &a) { return csch(a); });
+            m.def("sech", [](const Array &a) { return sech(a); });
+            m.def("coth", [](const Array &a) { return coth(a); });
+            m.def("asinh", [](const Array &a) { return asinh(a); });
+            m.def("acosh", [](const Array &a) { return acosh(a); });
+            m.def("atanh", [](const Array &a) { return atanh(a); });
+            m.def("cbrt", [](const Array &a) { return cbrt(a); });
+            m.def("pow", [](const Array &a, const Array &b) { return pow(a, b); });
+            m.def("pow", [](const Array &a, int b) { return pow(a, b); });
+            m.def("fmod", [](const Array &a, const Array &b) { return fmod(a, b); });
+            m.def("lerp", [](const Array &a, const Array &b, const Array &t) { return lerp(a, b, t); });
+            m.def("clamp", [](const Array &v, const Array &lo, const Array &hi) { return clamp(v, lo, hi); });
         }
     }
 

@@ -189,6 +189,21 @@ ENOKI_HIP_ROUTE_UNARY(cos, cos)
 ENOKI_HIP_ROUTE_UNARY(sincos, sincos)
 ENOKI_HIP_ROUTE_UNARY(exp, exp)
 ENOKI_HIP_ROUTE_UNARY(log, log)
+ENOKI_HIP_ROUTE_UNARY(tan, tan)
+ENOKI_HIP_ROUTE_UNARY(cot, cot)
+ENOKI_HIP_ROUTE_UNARY(asin, asin)
+ENOKI_HIP_ROUTE_UNARY(acos, acos)
+ENOKI_HIP_ROUTE_UNARY(atan, atan)
+ENOKI_HIP_ROUTE_UNARY(sinh, sinh)
+ENOKI_HIP_ROUTE_UNARY(cosh, cosh)
+ENOKI_HIP_ROUTE_UNARY(sincosh, sincosh)
+ENOKI_HIP_ROUTE_UNARY(tanh, tanh)
+ENOKI_HIP_ROUTE_UNARY(asinh, asinh)
+ENOKI_HIP_ROUTE_UNARY(acosh, acosh)
+ENOKI_HIP_ROUTE_UNARY(atanh, atanh)
+ENOKI_HIP_ROUTE_UNARY(cbrt, cbrt)
+ENOKI_HIP_ROUTE_BINARY(atan2, atan2)
+ENOKI_HIP_ROUTE_BINARY(ldexp, ldexp)
 ENOKI_HIP_ROUTE_UNARY(popcnt, popcnt)
 ENOKI_HIP_ROUTE_UNARY(lzcnt, lzcnt)
 ENOKI_HIP_ROUTE_UNARY(tzcnt, tzcnt)
@@ -208,6 +223,62 @@ template <typename T, typename M, enable_if_t<is_array_v<T>> = 0> inline T compr
     return a.compress_(detail::as<mask_t<T>>(mask));
 }
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sqr(const T &a) { return a * a; }
+
+// Reciprocal trigonometric / hyperbolic functions (array_math.h:463-464, 1181-1183)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto csc(const T &a) { return rcp(sin(a)); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sec(const T &a) { return rcp(cos(a)); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto csch(const T &a) { return rcp(sinh(a)); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sech(const T &a) { return rcp(cosh(a)); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto coth(const T &a) { return rcp(tanh(a)); }
+
+namespace detail {
+    template <typename T, typename = void> struct has_pow : std::false_type { };
+    template <typename T> struct has_pow<T, std::void_t<decltype(std::declval<const T &>().pow_(std::declval<const T &>()))>>
+        : std::true_type { };
+    template <typename T, typename = void> struct has_fmod : std::false_type { };
+    template <typename T> struct has_fmod<T, std::void_t<decltype(std::declval<const T &>().fmod_(std::declval<const T &>()))>>
+        : std::true_type { };
+}
+
+/// pow(x, y) = exp(log(x) * y) (array_math.h:956-958): a fused kernel where the array type has one, the
+/// composition (which is what a DiffArray records on its tape) otherwise
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0,
+          enable_if_t<!std::is_integral_v<T2>> = 0>
+inline auto pow(const T1 &a1, const T2 &a2) {
+    using E = expr_t<T1, T2>;
+    if constexpr (detail::has_pow<E>::value)
+        return detail::as<E>(a1).pow_(detail::as<E>(a2));
+    else
+        return exp(log(detail::as<E>(a1)) * detail::as<E>(a2));
+}
+
+/// Integer powers by repeated squaring (array_math.h:960-973)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T pow(const T &x_, int y) {
+    int n = y < 0 ? -y : y;
+    T result(1.f), x(x_);
+    while (n > 0) {
+        if (n & 1) result = result * x;
+        x = x * x;
+        n /= 2;
+    }
+    return y >= 0 ? result : rcp(result);
+}
+
+/// fmod(x, y) = fnmadd(trunc(x / y), y, x) (array_math.h:1381-1383)
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0>
+inline auto fmod(const T1 &a1, const T2 &a2) {
+    using E = expr_t<T1, T2>;
+    if constexpr (detail::has_fmod<E>::value)
+        return detail::as<E>(a1).fmod_(detail::as<E>(a2));
+    else
+        return fnmadd(trunc(detail::as<E>(a1) / detail::as<E>(a2)), detail::as<E>(a2), detail::as<E>(a1));
+}
+
+/// lerp / clamp / hypot (array_math.h:1350-1379)
+template <typename T1, typename T2, typename T3, enable_if_t<is_array_v<T1> || is_array_v<T2> || is_array_v<T3>> = 0>
+inline auto lerp(const T1 &a, const T2 &b, const T3 &t) { return fmadd(b, t, fnmadd(a, t, a)); }
+template <typename T1, typename T2, typename T3, enable_if_t<is_array_v<T1> || is_array_v<T2> || is_array_v<T3>> = 0>
+inline auto clamp(const T1 &value, const T2 &lo, const T3 &hi) { return max(min(value, hi), lo); }
 
 // Scalar fallbacks so that templated code also accepts plain arithmetic types
 inline float  fmadd(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }

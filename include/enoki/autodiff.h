@@ -437,6 +437,76 @@ template <typename Type_> struct DiffArray : ArrayTag {
         return create(idx, log(m_value));
     }
 
+    // ---- second wave (reference autodiff.h:366-377, 532-732): value from the fused kernel, edge weight
+    //      from the same derivative expression the reference records -------------------------------------
+#define ENOKI_HIP_DIFF_UNARY(name, label, value_expr, weight_expr)                                   \
+    DiffArray name##_() const {                                                                      \
+        Type result = value_expr;                                                                    \
+        Index idx = 0;                                                                               \
+        if constexpr (Enabled) {                                                                     \
+            if (m_index) idx = tape()->append(label, slices(m_value), m_index, weight_expr);         \
+        }                                                                                            \
+        return create(idx, std::move(result));                                                       \
+    }
+
+    ENOKI_HIP_DIFF_UNARY(tan,   "tan",   tan(m_value),   sqr(sec(m_value)))
+    ENOKI_HIP_DIFF_UNARY(cot,   "cot",   cot(m_value),   -sqr(csc(m_value)))
+    ENOKI_HIP_DIFF_UNARY(csc,   "csc",   csc(m_value),   -result * cot(m_value))
+    ENOKI_HIP_DIFF_UNARY(sec,   "sec",   sec(m_value),   result * tan(m_value))
+    ENOKI_HIP_DIFF_UNARY(asin,  "asin",  asin(m_value),  rsqrt(Type(1) - sqr(m_value)))
+    ENOKI_HIP_DIFF_UNARY(acos,  "acos",  acos(m_value),  -rsqrt(Type(1) - sqr(m_value)))
+    ENOKI_HIP_DIFF_UNARY(atan,  "atan",  atan(m_value),  rcp(Type(1) + sqr(m_value)))
+    ENOKI_HIP_DIFF_UNARY(csch,  "csch",  csch(m_value),  -result * coth(m_value))
+    ENOKI_HIP_DIFF_UNARY(sech,  "sech",  sech(m_value),  -result * tanh(m_value))
+    ENOKI_HIP_DIFF_UNARY(tanh,  "tanh",  tanh(m_value),  sqr(sech(m_value)))
+    ENOKI_HIP_DIFF_UNARY(asinh, "asinh", asinh(m_value), rsqrt(Type(1) + sqr(m_value)))
+    ENOKI_HIP_DIFF_UNARY(acosh, "acosh", acosh(m_value), rsqrt(sqr(m_value) - Type(1)))
+    ENOKI_HIP_DIFF_UNARY(atanh, "atanh", atanh(m_value), rcp(Type(1) - sqr(m_value)))
+    ENOKI_HIP_DIFF_UNARY(cbrt,  "cbrt",  cbrt(m_value),  Type(1.f) / (Type(3) * sqr(result)))
+#undef ENOKI_HIP_DIFF_UNARY
+
+    DiffArray sinh_() const {
+        auto [s, c] = sincosh(m_value);
+        Index idx = 0;
+        if constexpr (Enabled) {
+            if (m_index) idx = tape()->append("sinh", slices(m_value), m_index, c);
+        }
+        return create(idx, std::move(s));
+    }
+
+    DiffArray cosh_() const {
+        auto [s, c] = sincosh(m_value);
+        Index idx = 0;
+        if constexpr (Enabled) {
+            if (m_index) idx = tape()->append("cosh", slices(m_value), m_index, s);
+        }
+        return create(idx, std::move(c));
+    }
+
+    std::pair<DiffArray, DiffArray> sincosh_() const {
+        auto [s, c] = sincosh(m_value);
+        Index idx_s = 0, idx_c = 0;
+        if constexpr (Enabled) {
+            if (m_index) {
+                idx_s = tape()->append("sinh", slices(m_value), m_index, c);
+                idx_c = tape()->append("cosh", slices(m_value), m_index, s);
+            }
+        }
+        return { create(idx_s, std::move(s)), create(idx_c, std::move(c)) };
+    }
+
+    /// atan2(y = *this, x) (autodiff.h:618-633)
+    DiffArray atan2_(const DiffArray &x) const {
+        Index idx = 0;
+        if constexpr (Enabled) {
+            if (m_index | x.m_index) {
+                Type il2 = rcp(sqr(m_value) + sqr(x.m_value));
+                idx = tape()->append("atan2", slices(il2), m_index, x.m_index, il2 * x.m_value, -il2 * m_value);
+            }
+        }
+        return create(idx, atan2(m_value, x.m_value));
+    }
+
     /// value & mask: gradient flows where the mask is set (autodiff.h:780-787)
     template <typename T = Type, enable_if_t<!is_mask_v<T>> = 0>
     DiffArray and_(const MaskType &m) const {

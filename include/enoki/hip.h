@@ -226,6 +226,33 @@ template <typename Value_> struct HIPArray : ArrayTag {
     template <typename T> T floor2int_() const { return T(floor_()); }
     template <typename T> T ceil2int_() const { return T(ceil_()); }
 
+    // second wave (array_math.h:466-1348): one fused kernel each, f32
+    HIPArray tan_() const { return unary(EK_TAN, "tan_"); }
+    HIPArray cot_() const { return unary(EK_COT, "cot_"); }
+    HIPArray asin_() const { return unary(EK_ASIN, "asin_"); }
+    HIPArray acos_() const { return unary(EK_ACOS, "acos_"); }
+    HIPArray atan_() const { return unary(EK_ATAN, "atan_"); }
+    HIPArray sinh_() const { return unary(EK_SINH, "sinh_"); }
+    HIPArray cosh_() const { return unary(EK_COSH, "cosh_"); }
+    HIPArray tanh_() const { return unary(EK_TANH, "tanh_"); }
+    HIPArray asinh_() const { return unary(EK_ASINH, "asinh_"); }
+    HIPArray acosh_() const { return unary(EK_ACOSH, "acosh_"); }
+    HIPArray atanh_() const { return unary(EK_ATANH, "atanh_"); }
+    HIPArray cbrt_() const { return unary(EK_CBRT, "cbrt_"); }
+    HIPArray atan2_(const HIPArray &x) const { return binary(EK_ATAN2, x, "atan2_"); }
+    HIPArray pow_(const HIPArray &y) const { return binary(EK_POW, y, "pow_"); }
+    HIPArray fmod_(const HIPArray &y) const { return binary(EK_FMOD, y, "fmod_"); }
+    HIPArray ldexp_(const HIPArray &e) const { return binary(EK_LDEXP, e, "ldexp_"); }
+
+    std::pair<HIPArray, HIPArray> sincosh_() const {
+        require_valid("sincosh_");
+        size_t n = size();
+        HIPArray s = empty_(n), c = empty_(n);
+        ek_operand oa = operand();
+        detail::hip_check(ek_hip_sincosh(Type, s.m_buf->ptr, c.m_buf->ptr, &oa, n), "sincosh_");
+        return { std::move(s), std::move(c) };
+    }
+
     /// Both results from one pass over the input
     std::pair<HIPArray, HIPArray> sincos_() const {
         require_valid("sincos_");

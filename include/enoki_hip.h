@@ -50,17 +50,22 @@ typedef enum {
     EK_ERR_OOM = -4           /* allocation failed even after trimming the cache */
 } ek_status;
 
-/* Unary ops.  cuda.h:418-543 (abs_ .. tzcnt_) and array_math.h (sin/cos/exp/log, CPU algorithm). */
+/* Unary ops.  cuda.h:418-543 (abs_ .. tzcnt_) and array_math.h (sin/cos/exp/log, CPU algorithm).
+ * EK_TAN .. EK_CBRT (f32 only): the "second wave" the reference composes generically from traced
+ * primitives (array_math.h:466-474, 555, 666, 900, 997-1348); here one fused kernel each. */
 typedef enum {
     EK_NEG = 0, EK_ABS, EK_NOT, EK_SQRT, EK_RCP, EK_RSQRT, EK_FLOOR, EK_CEIL, EK_ROUND, EK_TRUNC,
     EK_SIN, EK_COS, EK_EXP, EK_LOG, EK_POPCNT, EK_LZCNT, EK_TZCNT, EK_SIGN, EK_COPY,
+    EK_TAN, EK_COT, EK_ASIN, EK_ACOS, EK_ATAN, EK_SINH, EK_COSH, EK_TANH, EK_ASINH, EK_ACOSH, EK_ATANH,
+    EK_CBRT,
     EK_UNARY_COUNT
 } ek_unary_op;
 
-/* Binary ops.  cuda.h:341-385, 408-416, 499-580; safe_mul = autodiff.cpp:1191-1205. */
+/* Binary ops.  cuda.h:341-385, 408-416, 499-580; safe_mul = autodiff.cpp:1191-1205;
+ * atan2(y, x) / pow / fmod / ldexp = array_math.h:603-664, 956-958, 1381-1383, 677-680 (atan2, pow, ldexp: f32). */
 typedef enum {
     EK_ADD = 0, EK_SUB, EK_MUL, EK_DIV, EK_MOD, EK_MIN, EK_MAX, EK_MULHI, EK_AND, EK_OR, EK_XOR,
-    EK_SL, EK_SR, EK_SAFE_MUL,
+    EK_SL, EK_SR, EK_SAFE_MUL, EK_ATAN2, EK_POW, EK_FMOD, EK_LDEXP,
     EK_BINARY_COUNT
 } ek_binary_op;
 
@@ -133,6 +138,8 @@ EK_API int ek_hip_ternary(int op, int type, void *out, const ek_operand *a, cons
                           const ek_operand *c, size_t n);
 /* sincos_: both outputs from one pass over the input (array_math.h:261-367) */
 EK_API int ek_hip_sincos(int type, void *out_sin, void *out_cos, const ek_operand *a, size_t n);
+/* sincosh: sinh and cosh from one exp() (array_math.h:1067-1127), what DiffArray::sinh_/cosh_ call (autodiff.h:635-657) */
+EK_API int ek_hip_sincosh(int type, void *out_sinh, void *out_cosh, const ek_operand *a, size_t n);
 EK_API int ek_hip_compare(int op, int type, uint8_t *out_mask, const ek_operand *a, const ek_operand *b, size_t n);
 /* select_: out = mask ? t : f (cuda.h:632-639); `mask` is an EK_BOOL operand */
 EK_API int ek_hip_select(int type, void *out, const ek_operand *mask, const ek_operand *t,

@@ -138,6 +138,187 @@ static float log_f32(float x) {
 }
 
 /* ------------------------------------------------------------------------------------ */
+/*  Second-wave f32 functions (array_math.h:369-442, 466-668, 900-958, 997-1348, 1381)     */
+/*                                                                                        */
+/*  Estrin evaluation with the groupings of array_math.h:25-105; c[k] multiplies x^k and  */
+/*  is narrowed from the double literal like the reference's `S(c)`.  rcp() is spelled as */
+/*  an exact division (class C versus the reference's rcpps + Newton step).               */
+/* ------------------------------------------------------------------------------------ */
+static inline float P2(float x, const double *c) {                           /* :25-29 */
+    float x2 = x * x;
+    return fmaf(x2, (float) c[2], fmaf(x, (float) c[1], (float) c[0]));
+}
+static inline float P3(float x, const double *c) {                           /* :31-37 */
+    float x2 = x * x;
+    return fmaf(x2, fmaf(x, (float) c[3], (float) c[2]), fmaf(x, (float) c[1], (float) c[0]));
+}
+static inline float P4f(float x, const float *c) {                           /* :39-45 */
+    float x2 = x * x, x4 = x2 * x2;
+    return fmaf(x2, fmaf(x, c[3], c[2]), fmaf(x, c[1], c[0]) + c[4] * x4);
+}
+static inline float P4(float x, const double *c) {
+    float f[5] = { (float) c[0], (float) c[1], (float) c[2], (float) c[3], (float) c[4] };
+    return P4f(x, f);
+}
+static inline float P5(float x, const double *c) {                           /* :47-54 */
+    float x2 = x * x, x4 = x2 * x2;
+    return fmaf(x2, fmaf(x, (float) c[3], (float) c[2]),
+                fmaf(x4, fmaf(x, (float) c[5], (float) c[4]), fmaf(x, (float) c[1], (float) c[0])));
+}
+static inline float P6(float x, const double *c) {                           /* :56-63 */
+    float x2 = x * x, x4 = x2 * x2;
+    return fmaf(x4, fmaf(x2, (float) c[6], fmaf(x, (float) c[5], (float) c[4])),
+                fmaf(x2, fmaf(x, (float) c[3], (float) c[2]), fmaf(x, (float) c[1], (float) c[0])));
+}
+
+static inline float copysign_ps(float mag, float sgn) { return u2f((f2u(mag) & 0x7fffffffu) | (f2u(sgn) & 0x80000000u)); }
+static inline float mulsign_ps(float v, float sgn) { return u2f(f2u(v) ^ (f2u(sgn) & 0x80000000u)); }
+
+/* frexp :682-709, ldexp :677-680 */
+static inline float frexp_f32(float x, float *e) {
+    uint32_t xi = f2u(x), eb = xi & 0x7f800000u;
+    int normal = (x != 0.0f) && (eb != 0x7f800000u);
+    *e = (float) (normal ? (int32_t) (eb >> 23) - 0x7f : 0);
+    return u2f(normal ? ((xi & ~0x7f800000u) | 0x3f000000u) : xi);
+}
+static inline float ldexp_f32(float x, float e) {
+    return x * u2f(((uint32_t) cvtt_f32_i32(e) + 0x7fu) << 23);
+}
+
+static float tancot_f32(float x, int want_tan) {                             /* :369-442 */
+    static const double c[6] = { 3.33331568548e-1, 1.33387994085e-1, 5.34112807005e-2,
+                                 2.44301354525e-2, 3.11992232697e-3, 9.38540185543e-3 };
+    float xa = fabsf(x);                                                     /* :388 */
+    int32_t j = cvtt_f32_i32(xa * (float) 1.2732395447351626862);            /* :391 */
+    j = (int32_t) (((uint32_t) j + 1u) & ~1u);                               /* :394 */
+    float y = (float) j;                                                     /* :397 */
+    float t = xa - y * (float) 0.78515625;                                   /* :401-403 */
+    t = t - y * (float) 2.4187564849853515625e-4;
+    t = t - y * (float) 3.77489497744594108e-8;
+    y = t;
+    float z = y * y;                                                         /* :410 */
+    if (xa == INFINITY) z = u2f(0xffffffffu);                                /* :411 */
+    float r = P5(z, c);                                                      /* :415-420 */
+    r = fmaf(r, z * y, y);                                                   /* :432 */
+    int recip = want_tan ? (j & 2) != 0 : (j & 2) == 0;                      /* :434-435 */
+    if (xa < (float) 1e-4) r = y;                                            /* :436 */
+    if (recip) r = 1.0f / r;                                                 /* :437 rcp(), class C */
+    uint32_t sign = ((uint32_t) j << 30) ^ f2u(x);                           /* :439 */
+    return u2f(f2u(r) ^ (sign & 0x80000000u));                               /* :441 */
+}
+
+static float asin_acos_core(float x, float c0, int *big) {                   /* :489-506 / :571-585 */
+    float c[5] = { c0, 7.4953002686e-2f, 4.5470025998e-2f, 2.4181311049e-2f, 4.2163199048e-2f };
+    float xa = fabsf(x), x2 = x * x;
+    *big = xa > 0.5f;
+    float x1 = 0.5f * (1.0f - xa);
+    float x3 = *big ? x1 : x2, x4 = *big ? sqrtf(x1) : xa;
+    float z1 = P4f(x3, c);
+    return fmaf(z1, x3 * x4, x4);
+}
+
+static float asin_f32(float x) {                                             /* :474-553 */
+    int big;
+    float z1 = asin_acos_core(x, 1.6666752422e-1f, &big);
+    float r = big ? (float) M_PI_2 - (z1 + z1) : z1;                         /* :508 */
+    return copysign_ps(r, x);                                                /* :552 */
+}
+
+static float acos_f32(float x) {                                             /* :555-601 */
+    int big;
+    float z1 = asin_acos_core(x, 1.666675242e-1f, &big);
+    float z2 = z1 + z1;                                                      /* :586 */
+    if (x < 0.0f) z2 = (float) M_PI - z2;                                    /* :587 */
+    float z3 = (float) M_PI_2 - copysign_ps(z1, x);                          /* :589 */
+    return big ? z2 : z3;
+}
+
+static float atan2_f32(float y, float x) {                                   /* :603-664, called as atan2(y, x) */
+    static const double c[7] = { 0.99999934166683966009, -0.33326497518773606976, +0.19881342388439013552,
+                                 -0.13486708938456973185, +0.083863120428809689910, -0.037006525670417265220,
+                                 0.0078613793713198150252 };
+    float abs_x = fabsf(x), abs_y = fabsf(y);                                /* :619-620 */
+    float min_val = min_ps(abs_y, abs_x), max_val = max_ps(abs_x, abs_y);    /* :621-622 */
+    float scale = 1.0f / max_val, scaled_min = min_val * scale;              /* :623-624 */
+    float z = scaled_min * scaled_min;
+    float t = P6(z, c) * scaled_min;                                         /* :633-657 */
+    if (abs_y > abs_x) t = (float) M_PI_2 - t;                               /* :659 */
+    if (x < 0.0f) t = (float) M_PI - t;                                      /* :660 */
+    float r = y < 0.0f ? u2f(f2u(t) ^ 0x80000000u) : t;                      /* :661 */
+    return max_val != 0.0f ? r : 0.0f;                                       /* :662 */
+}
+
+static float cbrt_f32(float x) {                                             /* :900-954 */
+    static const double c[5] = { 0.40238979564544752126924, 1.1399983354717293273738, -0.95438224771509446525043,
+                                 0.54664601366395524503440, -0.13466110473359520655053 };
+    const float CBRT2 = (float) 1.25992104989487316477, CBRT4 = (float) 1.58740105196819947475,
+                THIRD = (float) (1.0 / 3.0);
+    float xa = fabsf(x), xe;
+    float xm = frexp_f32(xa, &xe);                                           /* :923 */
+    xe += 1.0f;
+    float xea = fabsf(xe), xea1 = floorf(xea * THIRD), rem = fmaf(-xea1, 3.0f, xea);   /* :926-928 */
+    xm = P4(xm, c);                                                          /* :932-936 */
+    float f1 = xe >= 0.0f ? CBRT2 : 1.0f / CBRT2, f2 = xe >= 0.0f ? CBRT4 : 1.0f / CBRT4;
+    float f = rem == 1.0f ? f1 : f2;                                         /* :938-940 */
+    if (rem != 0.0f) xm *= f;                                                /* :942 */
+    float r = ldexp_f32(xm, mulsign_ps(xea1, xe));                           /* :944 */
+    r = mulsign_ps(r, x);
+    r -= (r - (x / (r * r))) * THIRD;                                        /* :948 */
+    return fabsf(x) < INFINITY ? r : x;                                      /* :953 */
+}
+
+static float sinh_small_f32(float x) {                                       /* :1025-1031 */
+    static const double c[3] = { 1.66667160211e-1, 8.33028376239e-3, 2.03721912945e-4 };
+    float x2 = x * x;
+    return fmaf(P2(x2, c), x2 * x, x);
+}
+static float sinh_f32(float x) {                                             /* :997-1046 */
+    float e0 = exp_f32(x), e1 = 1.0f / e0;                                   /* rcp(), class C */
+    return fabsf(x) > 1.0f ? (e0 - e1) * 0.5f : sinh_small_f32(x);
+}
+static float cosh_f32(float x) {                                             /* :1048-1065 */
+    float e0 = exp_f32(x), e1 = 1.0f / e0;
+    return (e0 + e1) * 0.5f;
+}
+static float tanh_f32(float x) {                                             /* :1129-1179 */
+    static const double c[5] = { -3.33332819422e-1, 1.33314422036e-1, -5.37397155531e-2, 2.06390887954e-2,
+                                 -5.70498872745e-3 };
+    float x2 = x * x;
+    float r_small = fmaf(P4(x2, c), x2 * x, x);                              /* :1154-1169 */
+    float e = exp_f32(x + x), e2 = 1.0f / (e + 1.0f);                        /* :1173-1174 rcp(), class C */
+    float r_big = 1.0f - (e2 + e2);
+    return fabsf(x) >= 0.625f ? r_big : r_small;
+}
+static float asinh_f32(float x) {                                            /* :1185-1237 */
+    static const double c[4] = { -1.6666288134e-1, 7.4847586088e-2, -4.2699340972e-2, 2.0122003309e-2 };
+    float x2 = x * x, xa = fabsf(x);
+    int big = xa >= (float) 0.51, huge = xa >= (float) 1e10;                 /* :1206-1207 */
+    float r_small = fmaf(P3(x2, c), x2 * x, x);                              /* :1211-1227 */
+    float r_big = log_f32(xa + (huge ? 0.0f : sqrtf(x2 + 1.0f)));            /* :1231 */
+    if (huge) r_big += (float) M_LN2;                                        /* :1232 */
+    return big ? copysign_ps(r_big, x) : r_small;
+}
+static float acosh_f32(float x) {                                            /* :1239-1293 */
+    static const double c[5] = { 1.4142135263e+0, -1.1784741703e-1, 2.6454905019e-2, -7.5272886713e-3,
+                                 1.7596881071e-3 };
+    float x1 = x - 1.0f;
+    int big = x1 >= (float) 0.49, huge = x1 >= (float) 1e10;                 /* :1259-1260 */
+    float r_small = P4(x1, c) * sqrtf(x1);                                   /* :1264-1283 */
+    if (x1 < 0.0f) r_small = u2f(0xffffffffu);                               /* :1284 */
+    float r_big = log_f32(x + (huge ? 0.0f : sqrtf(fmaf(x, x, -1.0f))));     /* :1288 */
+    if (huge) r_big += (float) M_LN2;
+    return big ? r_big : r_small;
+}
+static float atanh_f32(float x) {                                            /* :1295-1348 */
+    static const double c[5] = { 3.33337300303e-1, 1.99782164500e-1, 1.46691431730e-1, 8.24370301058e-2,
+                                 1.81740078349e-1 };
+    float xa = fabsf(x), x2 = x * x;
+    float r_small = fmaf(P4(x2, c), x2 * x, x);                              /* :1321-1339 */
+    float r_big = log_f32((1.0f + xa) / (1.0f - xa)) * 0.5f;                 /* :1343 */
+    return xa >= 0.5f ? copysign_ps(r_big, x) : r_small;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /*  generic dispatch helpers                                                              */
 /* ------------------------------------------------------------------------------------ */
 
@@ -166,6 +347,18 @@ static int unary_f32(const char *op, const float *a, float *o, size_t n) {
     if (is(op, "exp"))   LOOP(exp_f32(x));
     if (is(op, "log"))   LOOP(log_f32(x));
     if (is(op, "sign"))  LOOP(u2f((f2u(x) & 0x80000000u) | f2u(1.0f))); /* array_router.h:371 */
+    if (is(op, "tan"))   LOOP(tancot_f32(x, 1));
+    if (is(op, "cot"))   LOOP(tancot_f32(x, 0));
+    if (is(op, "asin"))  LOOP(asin_f32(x));
+    if (is(op, "acos"))  LOOP(acos_f32(x));
+    if (is(op, "atan"))  LOOP(atan2_f32(x, 1.0f));                  /* array_math.h:666-668 */
+    if (is(op, "sinh"))  LOOP(sinh_f32(x));
+    if (is(op, "cosh"))  LOOP(cosh_f32(x));
+    if (is(op, "tanh"))  LOOP(tanh_f32(x));
+    if (is(op, "asinh")) LOOP(asinh_f32(x));
+    if (is(op, "acosh")) LOOP(acosh_f32(x));
+    if (is(op, "atanh")) LOOP(atanh_f32(x));
+    if (is(op, "cbrt"))  LOOP(cbrt_f32(x));
 #undef LOOP
     if (is(op, "sin")) { for (size_t i = 0; i < n; ++i) sincos_f32(a[i], &o[i], NULL); return 0; }
     if (is(op, "cos")) { for (size_t i = 0; i < n; ++i) sincos_f32(a[i], NULL, &o[i]); return 0; }
@@ -243,6 +436,10 @@ static int binary_f32(const char *op, const float *a, const float *b, float *o, 
     if (is(op, "min")) LOOP(min_ps(x, y));
     if (is(op, "max")) LOOP(max_ps(x, y));
     if (is(op, "safe_mul")) LOOP(safe_mul_f32(x, y));
+    if (is(op, "atan2")) LOOP(atan2_f32(x, y));
+    if (is(op, "pow"))   LOOP(exp_f32(log_f32(x) * y));             /* array_math.h:956-958 */
+    if (is(op, "fmod"))  LOOP(fmaf(-truncf(x / y), y, x));          /* array_math.h:1381-1383 */
+    if (is(op, "ldexp")) LOOP(ldexp_f32(x, y));                     /* array_math.h:677-680 */
 #undef LOOP
     return -1;
 }

@@ -107,8 +107,12 @@ template <typename Value_> struct HostArray : ArrayTag {
     HOST_UNARY(rsqrt, "rsqrt") HOST_UNARY(floor, "floor") HOST_UNARY(ceil, "ceil") HOST_UNARY(round, "round")
     HOST_UNARY(trunc, "trunc") HOST_UNARY(sin, "sin") HOST_UNARY(cos, "cos") HOST_UNARY(exp, "exp")
     HOST_UNARY(log, "log") HOST_UNARY(sign, "sign") HOST_UNARY(popcnt, "popcnt") HOST_UNARY(lzcnt, "lzcnt")
-    HOST_UNARY(tzcnt, "tzcnt")
+    HOST_UNARY(tzcnt, "tzcnt") HOST_UNARY(tan, "tan") HOST_UNARY(cot, "cot") HOST_UNARY(asin, "asin")
+    HOST_UNARY(acos, "acos") HOST_UNARY(atan, "atan") HOST_UNARY(sinh, "sinh") HOST_UNARY(cosh, "cosh")
+    HOST_UNARY(tanh, "tanh") HOST_UNARY(asinh, "asinh") HOST_UNARY(acosh, "acosh") HOST_UNARY(atanh, "atanh")
+    HOST_UNARY(cbrt, "cbrt")
 #undef HOST_UNARY
+    std::pair<HostArray, HostArray> sincosh_() const { return { sinh_(), cosh_() }; }
     HostArray not_() const {
         if constexpr (IsMask) { HostArray r = empty_(size()); for (size_t i = 0; i < size(); ++i) (*r.m_data)[i] = !(*m_data)[i]; return r; }
         else return unary("not");
@@ -116,7 +120,8 @@ template <typename Value_> struct HostArray : ArrayTag {
 #define HOST_BINARY(name, op) HostArray name##_(const HostArray &b) const { return binary(op, b); }
     HOST_BINARY(add, "add") HOST_BINARY(sub, "sub") HOST_BINARY(mul, "mul") HOST_BINARY(div, "div")
     HOST_BINARY(mod, "mod") HOST_BINARY(min, "min") HOST_BINARY(max, "max") HOST_BINARY(mulhi, "mulhi")
-    HOST_BINARY(xor, "xor") HOST_BINARY(sl, "sl") HOST_BINARY(sr, "sr")
+    HOST_BINARY(xor, "xor") HOST_BINARY(sl, "sl") HOST_BINARY(sr, "sr") HOST_BINARY(atan2, "atan2")
+    HOST_BINARY(ldexp, "ldexp")
 #undef HOST_BINARY
     HostArray and_(const HostArray &b) const { return bitop(b, 0); }
     HostArray or_(const HostArray &b) const { return bitop(b, 1); }

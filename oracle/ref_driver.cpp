@@ -95,6 +95,11 @@ template <typename T> int unary_float(const char *op, const T *a_, T *out, size_
     else if (is(op, "sinh"))  r = sinh(a);
     else if (is(op, "cosh"))  r = cosh(a);
     else if (is(op, "tanh"))  r = tanh(a);
+    else if (is(op, "cot"))   r = cot(a);
+    else if (is(op, "asinh")) r = asinh(a);
+    else if (is(op, "acosh")) r = acosh(a);
+    else if (is(op, "atanh")) r = atanh(a);
+    else if (is(op, "cbrt"))  r = cbrt(a);
     else if (is(op, "sign"))  r = sign(a);
     else return -1;
     store(r, out, n);
@@ -123,6 +128,9 @@ template <typename T> int binary_float(const char *op, const T *a_, const T *b_,
     else if (is(op, "min")) r = min(a, b);
     else if (is(op, "max")) r = max(a, b);
     else if (is(op, "atan2")) r = atan2(a, b);
+    else if (is(op, "pow"))   r = pow(a, b);
+    else if (is(op, "fmod"))  r = fmod(a, b);
+    else if (is(op, "ldexp")) r = ldexp(a, b);
     else if (is(op, "safe_mul")) {
         /* restates the CPU branch of safe_mul, src/autodiff/autodiff.cpp:1191-1205 */
         Dyn<T> t = a * b, z = T(0);
@@ -466,7 +474,7 @@ enum {
     P_ADD = 0, P_SUB, P_MUL, P_DIV, P_FMADD, P_NEG, P_ABS, P_SQRT, P_RCP, P_RSQRT, P_SIN, P_COS,
     P_EXP, P_LOG, P_HSUM, P_HPROD, P_MIN, P_MAX, P_GATHER, P_SCATTER_ADD, P_SCATTER, P_SELECT_GT0,
     P_MULC, P_ADDC, P_TANH, P_TAN, P_ATAN2, P_FMSUB, P_FNMADD, P_FNMSUB, P_SINH, P_COSH, P_ASIN,
-    P_ACOS, P_ATAN, P_PSUM, P_REVERSE
+    P_ACOS, P_ATAN, P_PSUM, P_REVERSE, P_ASINH, P_ACOSH, P_ATANH, P_CBRT, P_POW, P_COT
 };
 
 int ref_tape_program(const int32_t *prog, size_t n_ops, const float *const *inputs,
@@ -517,6 +525,12 @@ int ref_tape_program(const int32_t *prog, size_t n_ops, const float *const *inpu
             case P_ACOS:   reg[d] = acos(R(p[1])); break;
             case P_ATAN:   reg[d] = atan(R(p[1])); break;
             case P_ATAN2:  reg[d] = atan2(R(p[1]), R(p[2])); break;
+            case P_COT:    reg[d] = cot(R(p[1])); break;
+            case P_ASINH:  reg[d] = asinh(R(p[1])); break;
+            case P_ACOSH:  reg[d] = acosh(R(p[1])); break;
+            case P_ATANH:  reg[d] = atanh(R(p[1])); break;
+            case P_CBRT:   reg[d] = cbrt(R(p[1])); break;
+            case P_POW:    reg[d] = pow(R(p[1]), R(p[2])); break;
             case P_EXP:    reg[d] = exp(R(p[1])); break;
             case P_LOG:    reg[d] = log(R(p[1])); break;
             case P_HSUM:   reg[d] = hsum(R(p[1])); break;

@@ -15,7 +15,7 @@ enum {
     P_ADD = 0, P_SUB, P_MUL, P_DIV, P_FMADD, P_NEG, P_ABS, P_SQRT, P_RCP, P_RSQRT, P_SIN, P_COS,
     P_EXP, P_LOG, P_HSUM, P_HPROD, P_MIN, P_MAX, P_GATHER, P_SCATTER_ADD, P_SCATTER, P_SELECT_GT0,
     P_MULC, P_ADDC, P_TANH, P_TAN, P_ATAN2, P_FMSUB, P_FNMADD, P_FNMSUB, P_SINH, P_COSH, P_ASIN,
-    P_ACOS, P_ATAN, P_PSUM, P_REVERSE
+    P_ACOS, P_ATAN, P_PSUM, P_REVERSE, P_ASINH, P_ACOSH, P_ATANH, P_CBRT, P_POW, P_COT
 };
 
 /// FloatD / UInt32D: differentiable float array and its index array type; `to_host(array, dst, n)` copies out
@@ -78,7 +78,21 @@ int run_tape_program(const int32_t *prog, size_t n_ops, const float *const *inpu
                 scatter(R(p[1]), R(p[2]), ireg[(size_t) p[3]]);
                 reg[d] = R(p[1]);
                 break;
-            default: return -1;   // op not available on this backend (tan, tanh, ... second wave)
+            case P_TAN: reg[d] = tan(R(p[1])); break;
+            case P_COT: reg[d] = cot(R(p[1])); break;
+            case P_ASIN: reg[d] = asin(R(p[1])); break;
+            case P_ACOS: reg[d] = acos(R(p[1])); break;
+            case P_ATAN: reg[d] = atan(R(p[1])); break;
+            case P_ATAN2: reg[d] = atan2(R(p[1]), R(p[2])); break;
+            case P_SINH: reg[d] = sinh(R(p[1])); break;
+            case P_COSH: reg[d] = cosh(R(p[1])); break;
+            case P_TANH: reg[d] = tanh(R(p[1])); break;
+            case P_ASINH: reg[d] = asinh(R(p[1])); break;
+            case P_ACOSH: reg[d] = acosh(R(p[1])); break;
+            case P_ATANH: reg[d] = atanh(R(p[1])); break;
+            case P_CBRT: reg[d] = cbrt(R(p[1])); break;
+            case P_POW: reg[d] = pow(R(p[1]), R(p[2])); break;
+            default: return -1;
         }
         last = d;
     }

@@ -41,6 +41,20 @@ for op in ["eq", "neq", "lt", "le", "gt", "ge"]:
     ops[f"compare_{op}"] = R.compare(op, a, b)
 np.savez_compressed(os.path.join(HERE, "elementwise_f32.npz"), **ops)
 
+# ---- second-wave math (array_math.h tan .. atanh, cbrt, atan2, pow, fmod, ldexp) -----------------------
+ops2 = {"in_a": a, "in_b": b, "in_c": c}
+for op in ["tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "cbrt"]:
+    ops2[f"unary_{op}"] = R.unary(op, a)
+unit = uniform_pm1(n, seed=104) * np.float32(1.2)          # covers [-1, 1] and a little outside (NaN results)
+ops2["in_unit"] = unit
+for op in ["asin", "acos", "atanh"]:
+    ops2[f"unit_{op}"] = R.unary(op, unit)
+for op in ["atan2", "pow", "fmod"]:
+    ops2[f"binary_{op}"] = R.binary(op, a, b)
+ops2["in_e"] = np.trunc(b).astype(np.float32)
+ops2["ldexp"] = R.binary("ldexp", c, np.clip(ops2["in_e"], -100, 100))
+np.savez_compressed(os.path.join(HERE, "elementwise2_f32.npz"), **ops2)
+
 # ---- integer ops -----------------------------------------------------------------------------------
 rng = np.random.default_rng(7)
 iops = {}

@@ -12,7 +12,8 @@ ROOT = os.path.dirname(HERE)
 
 OPS = ["add", "sub", "mul", "div", "fmadd", "neg", "abs", "sqrt", "rcp", "rsqrt", "sin", "cos", "exp", "log", "hsum",
        "hprod", "min", "max", "gather", "scatter_add", "scatter", "select_gt0", "mulc", "addc", "tanh", "tan",
-       "atan2", "fmsub", "fnmadd", "fnmsub", "sinh", "cosh", "asin", "acos", "atan", "psum", "reverse"]
+       "atan2", "fmsub", "fnmadd", "fnmsub", "sinh", "cosh", "asin", "acos", "atan", "psum", "reverse", "asinh", "acosh",
+       "atanh", "cbrt", "pow", "cot"]
 OPCODE = {n: i for i, n in enumerate(OPS)}
 
 
@@ -155,12 +156,25 @@ def suite(n=1000, k=37, seed=0):
     # AVX2 reference -> compared with a tolerance only
     P["div_rcp_rsqrt"] = Program([(a, 1), (pos, 1)], [("div", 0, 1), ("rcp", 1), ("rsqrt", 1), ("add", 2, 3),
                                                       ("add", 5, 4), ("hsum", 6)])
+    # second wave (array_math.h tan .. cbrt).  Vector outputs (seed = ones): the GPU tape must agree bit for bit with
+    # the product tape over the CPU oracle; against the AVX2 reference only cbrt / pow are bit-comparable, every
+    # other derivative contains rcp() or rsqrt() (class C)
+    u = (0.9 * a).astype(np.float32); w = (0.9 * x).astype(np.float32)
+    P["sw_trig"] = Program([(u, 1), (w, 1)], [("tan", 0), ("asin", 1), ("acos", 0), ("atan", 1), ("atan2", 0, 1),
+                                              ("cot", 1), ("add", 2, 3), ("add", 8, 4), ("add", 9, 5), ("add", 10, 6),
+                                              ("add", 11, 7)])
+    P["sw_hyp"] = Program([(u, 1), (w, 1), (pos, 1)], [("sinh", 0), ("cosh", 1), ("tanh", 0), ("asinh", 1), ("addc", 2, 1.0),
+                                                       ("acosh", 7), ("atanh", 0), ("add", 3, 4), ("add", 10, 5),
+                                                       ("add", 11, 6), ("add", 12, 8), ("add", 13, 9)])
+    P["sw_cbrt_pow"] = Program([(a, 1), (pos, 1), (x, 1)], [("cbrt", 0), ("pow", 1, 2), ("mul", 3, 4)])
+    P["sw_sum"] = Program([(u, 1), (w, 1)], [("tanh", 0), ("atan2", 2, 1), ("asinh", 3), ("hsum", 4)])
     return P
 
 
-TOLERANT = {"div_rcp_rsqrt"}          # not bit-comparable against the AVX2 reference build (class C)
+TOLERANT = {"div_rcp_rsqrt", "sw_trig", "sw_hyp", "sw_sum", "sw_cbrt_pow"}   # sw_cbrt_pow: d pow / d base goes through log's rcp()
+CLASS_C_VALUES = {"sw_trig", "sw_hyp", "sw_sum"}   # the primal itself contains rcp() (tan, cot, sinh, cosh, tanh)          # not bit-comparable against the AVX2 reference build (class C)
 ORDER_DEPENDENT_ON_GPU = {            # contain hsum / hprod / fp scatter_add: GPU summation order differs (class D)
     "cfg3a", "cfg3b", "cfg2_grad", "arith", "square_dup_edge", "sqrt_log", "cos_exp", "minmax_select", "fm_family",
     "hprod", "scalar_leaf", "scalar_chain", "gather_only", "permute_gather", "scatter_add", "scatter_add_leaf_target",
-    "scatter_perm", "reverse_psum", "fwd_cfg3a", "simplify_chain", "div_rcp_rsqrt",
+    "scatter_perm", "reverse_psum", "fwd_cfg3a", "simplify_chain", "div_rcp_rsqrt", "sw_sum",
 }

@@ -35,6 +35,40 @@ def test_unary_f32_bit_exact(capi, oracle, op, scale):
     assert bits_equal(got, oracle.unary(op, a)), op
 
 
+@pytest.mark.parametrize("op", ["tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh",
+                                "cbrt"])
+@pytest.mark.parametrize("scale", [0.3, 1.0, 30.0, 3000.0])
+def test_second_wave_unary_bit_exact(capi, oracle, op, scale):
+    """array_math.h second wave as single fused kernels.  The oracle is bit-exact with the reference for the
+    functions without rcp() and spells rcp() as an exact division like the kernels do (class C vs the
+    reference, tests/test_oracle_vs_ref.py::test_second_wave_class_c), so kernel == oracle bit for bit."""
+    a = f32_inputs(100003, seed=31, scale=scale)
+    assert bits_equal(capi.unary(op, up(capi, a)).numpy(), oracle.unary(op, a)), op
+
+
+@pytest.mark.parametrize("op", ["atan2", "pow", "fmod", "ldexp"])
+def test_second_wave_binary_bit_exact(capi, oracle, op):
+    for scale in (1.0, 40.0):
+        a = f32_inputs(100003, seed=41, scale=scale)
+        b = f32_inputs(100003, seed=42, scale=scale)[::-1].copy()
+        if op == "ldexp":
+            b = np.clip(np.trunc(b), -100, 100).astype(np.float32)
+        assert bits_equal(capi.binary(op, up(capi, a), up(capi, b)).numpy(), oracle.binary(op, a, b)), op
+        assert bits_equal(capi.binary(op, up(capi, a), 1.5 if op != "ldexp" else 3.0).numpy(),
+                          oracle.binary(op, a, np.full_like(a, 1.5 if op != "ldexp" else 3.0))), op
+
+
+def test_second_wave_golden(capi):
+    """kernels against vectors produced by the unmodified reference build (tests/golden/make_golden.py)"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "elementwise2_f32.npz"))
+    a, b = z["in_a"], z["in_b"]
+    for op in ["asin", "acos", "atan", "asinh", "acosh", "atanh", "cbrt"]:
+        assert bits_equal(capi.unary(op, up(capi, a)).numpy(), z[f"unary_{op}"]), op
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(capi.binary(op, up(capi, a), up(capi, b)).numpy(), z[f"binary_{op}"]), op
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_unary_sizes_and_tails(capi, oracle, n):
     a = f32_inputs(n, seed=n, specials=False)

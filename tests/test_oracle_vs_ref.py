@@ -39,6 +39,41 @@ def test_f32_vertical_ops_bit_exact(scale):
         assert np.array_equal(P.compare(op, a, b), R.compare(op, a, b)), op
 
 
+CLASS_A2 = ["asin", "acos", "atan", "asinh", "acosh", "atanh", "cbrt"]   # no rcp() inside: bit-exact
+CLASS_C2 = {"tan": 8, "cot": 8, "sinh": 8, "cosh": 8, "tanh": 16}        # rcp() inside: ulp bound port vs reference
+
+
+@needs_ref
+@pytest.mark.parametrize("scale", [0.3, 1.0, 30.0, 3000.0])
+def test_second_wave_bit_exact(scale):
+    """array_math.h second wave.  Functions that do not call rcp() match the reference bit for bit."""
+    R = ol.ref()
+    a = f32_inputs(200003, 21, scale); b = f32_inputs(200003, 22, scale)[::-1].copy()
+    for op in CLASS_A2:
+        assert bits_equal(P.unary(op, a), R.unary(op, a)), op
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(P.binary(op, a, b), R.binary(op, a, b)), op
+    e = np.clip(np.trunc(b), -100, 100).astype(np.float32)
+    assert bits_equal(P.binary("ldexp", a, e), R.binary("ldexp", a, e))
+
+
+@needs_ref
+def test_second_wave_class_c():
+    """tan/cot/sinh/cosh/tanh contain rcp(): the AVX2 reference uses rcpps + one Newton step (array_avx.h:324-357,
+    ISA specific), the oracle an exact division -> a few ulp apart away from overflow / denormal results."""
+    R = ol.ref()
+    rng = np.random.default_rng(5)
+    for op, bound in CLASS_C2.items():
+        a = rng.uniform(-9, 9, 200000).astype(np.float32)
+        p, r = P.unary(op, a), R.unary(op, a)
+        ok = np.isfinite(r) & (np.abs(r) > 1e-30) & (np.abs(r) < 1e30)
+        assert ok.mean() > 0.99 and ulp_diff(p[ok], r[ok]).max() <= bound, op
+        truth = {"tan": np.tan, "cot": lambda x: 1 / np.tan(x), "sinh": np.sinh, "cosh": np.cosh, "tanh": np.tanh}[op](
+            a.astype(np.float64))
+        rel = np.abs(p.astype(np.float64) - truth) / np.maximum(np.abs(truth), 1e-30)
+        assert np.percentile(rel, 99.9) < 2e-6, op          # the algorithm's own accuracy (array_math.h:376-386)
+
+
 @needs_ref
 def test_rcp_rsqrt_class_c():
     """both the IEEE oracle and the AVX2 reference stay within the reference's own test bounds vs float64"""
@@ -163,6 +198,22 @@ def test_golden_elementwise():
             assert np.array_equal(P.compare(op, a, b), z[key]), key
     s, co = P.sincos(a)
     assert bits_equal(s, z["sincos_s"]) and bits_equal(co, z["sincos_c"])
+
+
+def test_golden_second_wave():
+    z = np.load(os.path.join(GOLDEN, "elementwise2_f32.npz"))
+    a, b = z["in_a"], z["in_b"]
+    for op in CLASS_A2:
+        assert bits_equal(P.unary(op, a), z[f"unary_{op}"]), op
+    for op in ["asin", "acos", "atanh"]:
+        assert bits_equal(P.unary(op, z["in_unit"]), z[f"unit_{op}"]), op
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(P.binary(op, a, b), z[f"binary_{op}"]), op
+    assert bits_equal(P.binary("ldexp", z["in_c"], np.clip(z["in_e"], -100, 100)), z["ldexp"])
+    for op, bound in CLASS_C2.items():
+        p, r = P.unary(op, a), z[f"unary_{op}"]
+        ok = np.isfinite(r) & np.isfinite(p) & (np.abs(r) > 1e-30) & (np.abs(r) < 1e30) & (np.abs(a) < 50)
+        assert ulp_diff(p[ok], r[ok]).max() <= bound, op
 
 
 def test_golden_integer():

@@ -190,3 +190,49 @@ def test_compress_and_immediate_fast_path(ekc):
     before = ekc.hip_launch_count()
     r = ekc.Float32(1.5) * ekc.Float32(2.0) + ekc.Float32(0.25) - ekc.Float32(1.0)
     assert ekc.hip_launch_count() == before and r[0] == 2.25 and len(r) == 1
+
+
+def test_second_wave_python_surface(ekc, ek):
+    """enoki.hip / enoki.hip_autodiff expose the second-wave functions; derivatives against float64 calculus"""
+    rng = np.random.default_rng(9)
+    a = rng.uniform(-0.9, 0.9, 4099).astype(np.float32); b = rng.uniform(0.5, 2, 4099).astype(np.float32)
+    A64 = a.astype(np.float64)
+    checks = {"tan": np.tan, "asin": np.arcsin, "acos": np.arccos, "atan": np.arctan, "sinh": np.sinh, "cosh": np.cosh,
+              "tanh": np.tanh, "asinh": np.arcsinh, "atanh": np.arctanh, "cbrt": np.cbrt}
+    for name, f in checks.items():
+        got = getattr(ekc, name)(ekc.Float32(a)).numpy()
+        assert np.allclose(got, f(A64), rtol=2e-6, atol=2e-7), name
+    assert np.allclose(ekc.acosh(ekc.Float32(b + 1)).numpy(), np.arccosh(b.astype(np.float64) + 1), rtol=2e-6)
+    assert np.allclose(ekc.atan2(ekc.Float32(a), ekc.Float32(b)).numpy(), np.arctan2(A64, b), rtol=3e-6, atol=3e-7)
+    assert np.allclose(ekc.pow(ekc.Float32(b), ekc.Float32(a)).numpy(), b.astype(np.float64) ** A64, rtol=3e-6)
+    assert np.allclose(ekc.pow(ekc.Float32(a), 3).numpy(), A64 ** 3, rtol=1e-6, atol=1e-9)
+    b73 = (b * np.float32(7.3)).astype(np.float32)
+    assert np.allclose(ekc.fmod(ekc.Float32(b73), ekc.Float32(b)).numpy(), np.fmod(b73.astype(np.float64), b), atol=1e-5)
+    s, c = ekc.sincosh(ekc.Float32(a))
+    assert np.allclose(s.numpy(), np.sinh(A64), rtol=2e-6, atol=2e-7) and np.allclose(c.numpy(), np.cosh(A64), rtol=2e-6)
+    assert np.allclose(ekc.sec(ekc.Float32(a)).numpy(), 1 / np.cos(A64), rtol=2e-6)
+    assert np.allclose(ekc.lerp(ekc.Float32(a), ekc.Float32(b), ekc.Float32(0.25)).numpy(), A64 * 0.75 + b * 0.25, rtol=1e-5, atol=1e-6)
+
+    derivs = {"tan": lambda x: 1 / np.cos(x) ** 2, "asin": lambda x: 1 / np.sqrt(1 - x * x),
+              "acos": lambda x: -1 / np.sqrt(1 - x * x), "atan": lambda x: 1 / (1 + x * x), "sinh": np.cosh, "cosh": np.sinh,
+              "tanh": lambda x: 1 / np.cosh(x) ** 2, "asinh": lambda x: 1 / np.sqrt(1 + x * x),
+              "atanh": lambda x: 1 / (1 - x * x), "sec": lambda x: np.tan(x) / np.cos(x),
+              "sech": lambda x: -np.tanh(x) / np.cosh(x)}
+    for name, df in derivs.items():
+        x = ek.Float32(a); ek.set_requires_gradient(x)
+        y = ek.hsum(getattr(ek, name)(x))
+        ek.backward(y)
+        assert np.allclose(ek.gradient(x).numpy(), df(A64), rtol=1e-5, atol=1e-6), name
+    # cbrt away from 0, atan2 w.r.t. both arguments, pow through exp(log(x) * y)
+    x = ek.Float32(b); ek.set_requires_gradient(x)
+    ek.backward(ek.hsum(ek.cbrt(x)))
+    assert np.allclose(ek.gradient(x).numpy(), 1 / (3 * np.cbrt(b.astype(np.float64)) ** 2), rtol=1e-5)
+    yy = ek.Float32(a); xx = ek.Float32(b); ek.set_requires_gradient(yy); ek.set_requires_gradient(xx)
+    ek.backward(ek.hsum(ek.atan2(yy, xx)))
+    den = A64 ** 2 + b.astype(np.float64) ** 2
+    assert np.allclose(ek.gradient(yy).numpy(), b / den, rtol=1e-5) and np.allclose(ek.gradient(xx).numpy(), -A64 / den, rtol=1e-5, atol=1e-7)
+    base = ek.Float32(b); ex = ek.Float32(a); ek.set_requires_gradient(base); ek.set_requires_gradient(ex)
+    ek.backward(ek.hsum(ek.pow(base, ex)))
+    B64 = b.astype(np.float64)
+    assert np.allclose(ek.gradient(base).numpy(), A64 * B64 ** (A64 - 1), rtol=2e-5, atol=1e-6)
+    assert np.allclose(ek.gradient(ex).numpy(), np.log(B64) * B64 ** A64, rtol=2e-5, atol=1e-6)
