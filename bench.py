@@ -43,7 +43,11 @@ DESCRIPTION = {
     "cfg3b": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)), a=gather(A,idx), b=gather(B,idx), K=1Mi; backward() with scatter_add grads",
     "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves of size N",
     "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))",
+    "cfg4": "ray-sphere (tests/sphere.cpp:58-83) on Array<HIPArray<float>,3>: masked gather of a 16384^2-style pixel "
+            "grid through a random permutation, make_rays/intersect_rays/shade_hits, masked scatter, count(hit); "
+            "32 Mi rays per GPU, unfused eager kernels",
 }
+N_RAYS_PER_GPU = 1 << 25
 # kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
 PMC_SYMBOL = {"gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
               "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",
@@ -55,7 +59,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2"])
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4"])
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
@@ -142,6 +146,42 @@ class Bench:
                     packer.pack([ekd.as_tensor(ek.detach(y))])
                     packer.all_reduce()
                 out["y"] = ek.detach(y)
+        elif workload == "cfg4":
+            torch = self.torch
+            nr = N_RAYS_PER_GPU                                    # weak: every rank traces its own 32 Mi rays
+            res = int(round(nr ** 0.5)); res -= res % 2
+            while nr % res:
+                res -= 1
+            lin_x = ekc.Float32.linspace(-1.2, 1.2, res); lin_y = ekc.Float32.linspace(-1.2, 1.2, nr // res)
+            grid = ekc.meshgrid(lin_x, lin_y)                      # sphere.cpp:130-131
+            g = torch.Generator(device=self.dev); g.manual_seed(1234 + self.rank)
+            perm_t = torch.randperm(nr, device=self.dev, generator=g).to(torch.int32)   # shard-local permutation
+            perm = ekc.UInt32.map(perm_t.data_ptr(), nr)
+            mask = (synth.hash_u32(self.rank * nr, nr, 5) & ekc.UInt32(3)) != ekc.UInt32(0)     # 75 % active
+            out["keep"] = (perm_t, perm, mask, grid)
+            packer = None
+            F, V3 = ekc.Float32, ekc.Vector3f
+            light = V3(F(-1.0), F(-1.0), F(2.0))
+
+            def step():
+                pp = ekc.gather(grid, perm, mask)
+                o = V3(pp.x, pp.y, F(-1.0)); d = V3(F(0.0), F(0.0), F(1.0))
+                a = ekc.dot(d, d)
+                b = F(2.0) * ekc.dot(o, d)
+                c = ekc.dot(o, o) - F(1.0)
+                discrim = b * b - F(4.0) * a * c
+                t = (-b + ekc.sqrt(discrim)) / (F(2.0) * a)
+                hit = discrim >= F(0.0)
+                pos = ekc.select(hit, o + d * t, V3(F(0.0), F(0.0), F(0.0)))
+                shade = F(0.2) + ekc.max(ekc.dot(pos, light), F(0.0)) * F(90.0)
+                hit = hit & mask
+                image = F.full(-1.0, nr)
+                ekc.scatter(image, shade, perm, hit)
+                cnt = torch.tensor([ekc.count(hit)], device=self.dev, dtype=torch.int64)
+                if ekd.active():
+                    ekd.all_reduce_(cnt)
+                out["y"] = ekc.Float32(float(cnt.item()))
+                out["image"] = image
         else:
             a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
             packer = ekd.Packer([1], self.dev) if ekd.active() else None
@@ -171,7 +211,8 @@ class Bench:
         torch.cuda.synchronize(); ekd.barrier()
         elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
         ms_per_step = elapsed / steps * 1e3
-        gelem_s = self.N / (ms_per_step * 1e-3) / 1e9
+        units = N_RAYS_PER_GPU * self.world if workload == "cfg4" else self.N
+        gelem_s = units / (ms_per_step * 1e-3) / 1e9
 
         # per-kernel timing of the same step: one HIP event per launch on the library stream
         ek.hip_profile_begin()
@@ -203,7 +244,7 @@ class Bench:
                         "traffic": pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else None,
                         "traffic_source": "profiles/rocprof_pmc_r01.txt (separate rocprofv3 --pmc passes, same command)",
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
-                                       "bytes_per_elt": round(total_bytes_step / max(self.n, 1), 2),
+                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload == "cfg4" else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
                         "kernels": kernels}
         y_val = float(out["y"].numpy()[0])
@@ -232,6 +273,23 @@ def cpu_baseline(workload, N):
     elif workload == "cfg3a":
         a, b = uniform_pm1(n, 1), uniform_pm1(n, 3)
         fn = lambda: chk.cfg3a(a, x, b)[-1]
+    elif workload == "cfg4":
+        import ctypes
+        n = 1 << 22                                   # bounded sample: 4 Mi rays of the same program
+        res = 2048
+        lin = np.linspace(-1.2, 1.2, res, dtype=np.float32)
+        gx, gy = np.tile(lin, res), np.repeat(lin, res)
+        perm = np.random.default_rng(0).permutation(n).astype(np.uint32)
+        mask = ((hash_u32(np.arange(n, dtype=np.uint64), 5) & np.uint32(3)) != 0).astype(np.uint8)
+        img = np.empty(n, np.float32); hc = ctypes.c_uint64()
+        cfg4 = chk.lib.ref_cfg4 if kind == "reference" else chk.lib.orc_cfg4
+        ptr = lambda v: v.ctypes.data_as(ctypes.c_void_p)
+
+        def fn():
+            img.fill(-1.0)
+            t0 = time.perf_counter()
+            cfg4(ptr(gx), ptr(gy), ptr(perm), ptr(mask), ctypes.c_size_t(n), ptr(img), ctypes.byref(hc))
+            return time.perf_counter() - t0
     else:
         a, b = uniform_pm1(n, 1), uniform_pm1(n, 3)
         fn = lambda: chk.cfg2(a, x, b)[-1]
@@ -251,7 +309,7 @@ def main():
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
     if b.world == 1 and not args.no_also:
-        for w in ("cfg3a", "cfg2", "cfg3b"):
+        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4"):
             if w != args.workload:
                 r = b.run(w, max(5, args.steps // 2), 2, 3)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],

@@ -28,7 +28,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", 
           "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
 DEVICE = [f"--offload-arch={ARCH}"]
 
-LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "probe.hip"]
+LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "probe.hip"]
 
 
 def _newer(target, deps):

@@ -247,7 +247,9 @@ int launch_map2(const char *name, TO *out, size_t n, const Arg<TA> &a, const Arg
     constexpr int N = 16 / max_size<TO, TA, TB>::value;
     int vec_ok = aligned16(out) && arg_aligned(a) && arg_aligned(b);
     EK_MAP_LAUNCH(k_map2, F EK_COMMA TO EK_COMMA TA EK_COMMA TB, N, 1, true, true, n, out, n, vec_ok, a, b);
-    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + arg_bytes(b, n));
+    // algorithmic bytes = DISTINCT input arrays + output (x * x reads x once)
+    const bool b_dup = b.vec && a.vec && (const void *) b.ptr == (const void *) a.ptr;
+    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + (b_dup ? 0 : arg_bytes(b, n)));
     return EK_OK;
 }
 
@@ -256,7 +258,11 @@ int launch_map3(const char *name, TO *out, size_t n, const Arg<TA> &a, const Arg
     constexpr int N = 16 / max_size<TO, TA, TB, TC>::value;
     int vec_ok = aligned16(out) && arg_aligned(a) && arg_aligned(b) && arg_aligned(c);
     EK_MAP_LAUNCH(k_map3, F EK_COMMA TO EK_COMMA TA EK_COMMA TB EK_COMMA TC, N, 1, true, true, n, out, n, vec_ok, a, b, c);
-    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + arg_bytes(b, n) + arg_bytes(c, n));
+    const bool b_dup = b.vec && a.vec && (const void *) b.ptr == (const void *) a.ptr;
+    const bool c_dup = c.vec && ((a.vec && (const void *) c.ptr == (const void *) a.ptr) ||
+                                 (b.vec && (const void *) c.ptr == (const void *) b.ptr));
+    EK_LAUNCH_CHECK(name, n, n * sizeof(TO) + arg_bytes(a, n) + (b_dup ? 0 : arg_bytes(b, n)) +
+                             (c_dup ? 0 : arg_bytes(c, n)));
     return EK_OK;
 }
 

@@ -1,6 +1,7 @@
 // enoki_amd.hip -- non-differentiable device arrays (the analogue of the reference's enoki.cuda module,
 // src/python/cuda.cpp:14-53 + cuda_1d.cpp:4-107)
 #include "common.h"
+#include <enoki/random.h>
 
 using FloatC = HIPArray<float>;
 using DoubleC = HIPArray<double>;
@@ -37,4 +38,32 @@ PYBIND11_MODULE(hip, m) {
     bind_memory<FloatC, UInt32C>(m); bind_memory<FloatC, Int32C>(m);
     bind_memory<Int32C, UInt32C>(m); bind_memory<UInt32C, UInt32C>(m);
     bind_memory<DoubleC, UInt32C>(m);
+
+    // PCG32 (src/python/random.h:9-80, cuda_pcg32.cpp)
+    using RNG = PCG32<FloatC>;
+    py::class_<RNG>(m, "PCG32")
+        .def(py::init<UInt64C, UInt64C>(), "initstate"_a = UInt64C(uint64_t(PCG32_DEFAULT_STATE)),
+             "initseq"_a = UInt64C(uint64_t(PCG32_DEFAULT_STREAM)))
+        .def("seed", &RNG::seed, "initstate"_a = UInt64C(uint64_t(PCG32_DEFAULT_STATE)),
+             "initseq"_a = UInt64C(uint64_t(PCG32_DEFAULT_STREAM)))
+        .def("__sub__", [](const RNG &a, const RNG &b) { return a - b; })
+        .def("__eq__", [](const RNG &a, const RNG &b) { return a == b; })
+        .def("__ne__", [](const RNG &a, const RNG &b) { return a != b; })
+        .def("advance", &RNG::advance, "delta"_a)
+        .def("next_uint32", [](RNG &r) { return r.next_uint32(); })
+        .def("next_uint32", [](RNG &r, const MaskC &mk) { return r.next_uint32(mk); }, "mask"_a)
+        .def("next_uint64", [](RNG &r) { return r.next_uint64(); })
+        .def("next_uint64", [](RNG &r, const MaskC &mk) { return r.next_uint64(mk); }, "mask"_a)
+        .def("next_uint32_bounded", [](RNG &r, uint32_t bound) { return r.next_uint32_bounded(bound); }, "bound"_a)
+        .def("next_uint32_bounded", [](RNG &r, uint32_t bound, const MaskC &mk) { return r.next_uint32_bounded(bound, mk); },
+             "bound"_a, "mask"_a)
+        .def("next_uint64_bounded", [](RNG &r, uint64_t bound) { return r.next_uint64_bounded(bound); }, "bound"_a)
+        .def("next_uint64_bounded", [](RNG &r, uint64_t bound, const MaskC &mk) { return r.next_uint64_bounded(bound, mk); },
+             "bound"_a, "mask"_a)
+        .def("next_float32", [](RNG &r) { return r.next_float32(); })
+        .def("next_float32", [](RNG &r, const MaskC &mk) { return r.next_float32(mk); }, "mask"_a)
+        .def("next_float64", [](RNG &r) { return r.next_float64(); })
+        .def("next_float64", [](RNG &r, const MaskC &mk) { return r.next_float64(mk); }, "mask"_a)
+        .def_readwrite("state", &RNG::state)
+        .def_readwrite("inc", &RNG::inc);
 }

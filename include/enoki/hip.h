@@ -526,6 +526,21 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return out;
     }
 
+    /// One PCG32 draw as a single fused kernel (enoki/random.h; reference random.h:68-133): advances
+    /// `state` where `mask` is set and returns the sample derived from the old state.  `kind` is an
+    /// ek_pcg32_kind that must match Value (u32 / f32 / u64 / f64).
+    static HIPArray pcg32_next_(int kind, HIPArray<uint64_t> &state, const HIPArray<uint64_t> &inc, const MaskType &mask) {
+        size_t n = broadcast_size(broadcast_size(state.size(), inc.size()), mask.size());
+        if (n == 0) throw std::runtime_error("pcg32_next_(): uninitialized generator");
+        HIPArray result = empty_(n);
+        HIPArray<uint64_t> next = HIPArray<uint64_t>::empty_(n);
+        ek_operand os = state.operand(), oi = inc.operand(), om = mask.operand();
+        detail::hip_check(ek_hip_pcg32_next(kind, result.m_buf->ptr, (uint64_t *) next.m_buf->ptr, &os, &oi, &om, n),
+                          "pcg32_next_");
+        state = std::move(next);
+        return result;
+    }
+
     /// No-ops of the eager backend that keep templated code written for the JIT backend compiling
     HIPArray &eval() { return *this; }
     const HIPArray &eval() const { return *this; }

@@ -185,6 +185,14 @@ EK_API int ek_hip_mask_reduce(int op, const uint8_t *mask, size_t n, uint64_t *h
 /* inclusive prefix sum (cuda.h:717-726 / horiz.cu:182-200) */
 EK_API int ek_hip_psum(int type, void *out, const void *in, size_t n);
 
+/* PCG32 draw (include/enoki/random.h:68-133): one fused kernel that advances `state` by `inc` where `mask`
+ * is set (state_out[i] = mask[i] ? state[i] * 0x5851f42d4c957f2d + inc[i] : state[i]) and writes the output
+ * function of the OLD state: u32[n], f32[n] in [0,1), f64[n] in [0,1), or u64[n] (two steps; the FIRST draw is the high
+ * word, which is what the pinned g++ reference build produces for random.h:87-89). */
+typedef enum { EK_PCG32_UINT32 = 0, EK_PCG32_FLOAT32, EK_PCG32_UINT64, EK_PCG32_FLOAT64 } ek_pcg32_kind;
+EK_API int ek_hip_pcg32_next(int kind, void *out, uint64_t *state_out, const ek_operand *state,
+                             const ek_operand *inc, const ek_operand *mask, size_t n);
+
 #ifdef __cplusplus
 }
 #endif

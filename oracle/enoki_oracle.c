@@ -922,3 +922,57 @@ int orc_cfg4(const float *gx, const float *gy, const uint32_t *perm, const uint8
     free(shade); free(hit);
     return 0;
 }
+
+/* ------------------------------------------------------------------------------------ */
+/*  PCG32 (include/enoki/random.h:38-330; O'Neill's XSH-RR 64/32), scalar per lane      */
+/*  Same script as oracle/ref_driver.cpp:ref_pcg32.                                     */
+/* ------------------------------------------------------------------------------------ */
+#define ORC_PCG32_MULT 0x5851f42d4c957f2dull
+
+static inline uint32_t pcg32_draw(uint64_t *state, uint64_t inc, int active) {   /* random.h:68-84 */
+    uint64_t old = *state;
+    if (active) *state = old * ORC_PCG32_MULT + inc;
+    uint32_t xorshifted = (uint32_t) (((old >> 18) ^ old) >> 27);
+    uint32_t rot = (uint32_t) (old >> 59);
+    return (xorshifted >> rot) | (xorshifted << ((0u - rot) & 31u));             /* ror */
+}
+
+int orc_pcg32(uint64_t initstate, const uint64_t *initseq, size_t n, int steps, const uint8_t *mask,
+              uint32_t *out_u32, float *out_f32, uint64_t *out_u64, double *out_f64, uint32_t bound,
+              uint32_t *out_bounded, int64_t delta, uint32_t *out_after, uint64_t *state_out) {
+    const uint32_t threshold = (~bound + 1u) % bound;                            /* random.h:176 */
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t state = 0, inc = (initseq[i] << 1) | 1u;                        /* seed(), random.h:62-68 */
+        pcg32_draw(&state, inc, 1);
+        state += initstate;
+        pcg32_draw(&state, inc, 1);
+
+        for (int s = 0; s < steps; ++s)
+            out_u32[(size_t) s * n + i] = pcg32_draw(&state, inc, mask[i] != 0);
+
+        out_f32[i] = u2f((pcg32_draw(&state, inc, 1) >> 9) | 0x3f800000u) - 1.0f;                 /* :112-114 */
+        /* :87-89 `UInt64(next_uint32()) | sl<32>(UInt64(next_uint32()))`: operand evaluation order is
+           unspecified in C++; the pinned g++ build evaluates the RIGHT operand first, so the first draw
+           lands in the HIGH word.  The oracle (and the kernel) follow the pinned build. */
+        uint64_t hi = pcg32_draw(&state, inc, 1), lo = pcg32_draw(&state, inc, 1);
+        out_u64[i] = lo | (hi << 32);
+        out_f64[i] = u2d(((uint64_t) pcg32_draw(&state, inc, 1) << 20) | 0x3ff0000000000000ull) - 1.0; /* :128-133 */
+
+        uint32_t r;                                                              /* :178-190, per-lane rejection */
+        do { r = pcg32_draw(&state, inc, 1); } while (r < threshold);
+        out_bounded[i] = r % bound;
+
+        uint64_t cur_mult = ORC_PCG32_MULT, cur_plus = inc, acc_mult = 1, acc_plus = 0, d = (uint64_t) delta;
+        while (d != 0) {                                                         /* advance(), :262-283 */
+            if (d & 1) { acc_mult *= cur_mult; acc_plus = acc_plus * cur_mult + cur_plus; }
+            cur_plus = (cur_mult + 1) * cur_plus;
+            cur_mult *= cur_mult;
+            d >>= 1;
+        }
+        state = acc_mult * state + acc_plus;
+
+        out_after[i] = pcg32_draw(&state, inc, 1);
+        state_out[i] = state;
+    }
+    return 0;
+}

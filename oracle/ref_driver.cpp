@@ -22,6 +22,7 @@
 #include <enoki/array.h>
 #include <enoki/dynamic.h>
 #include <enoki/autodiff.h>
+#include <enoki/random.h>
 
 #include <chrono>
 #include <cstdint>
@@ -636,6 +637,28 @@ int ref_cfg4(const float *gx, const float *gy, const uint32_t *perm_, const uint
     scatter(img, shade, perm, hit);
     store(img, image, n);
     *hit_count = count(hit);
+    return 0;
+}
+
+/* PCG32<FloatX> (include/enoki/random.h): a fixed script of draws.  out_u32: steps x n (masked draws),
+   then one draw each of float32 / uint64 / float64 / uint32_bounded(bound), advance(delta), one more uint32,
+   and the final state.  n must be a multiple of 8 (packet width; masked u64 lanes in the padding are unused). */
+int ref_pcg32(uint64_t initstate, const uint64_t *initseq, size_t n, int steps, const uint8_t *mask_,
+              uint32_t *out_u32, float *out_f32, uint64_t *out_u64, double *out_f64, uint32_t bound,
+              uint32_t *out_bounded, int64_t delta, uint32_t *out_after, uint64_t *state_out) {
+    using RNG = PCG32<FloatX>;
+    using UInt64X = RNG::UInt64;
+    RNG rng(UInt64X(initstate), UInt64X::copy(initseq, n));
+    auto mask = mask_t<UInt64X>(load_mask<uint64_t>(mask_, n));
+    for (int s = 0; s < steps; ++s)
+        store(rng.next_uint32(mask), out_u32 + (size_t) s * n, n);
+    store(rng.next_float32(), out_f32, n);
+    store(rng.next_uint64(), out_u64, n);
+    store(rng.next_float64(), out_f64, n);
+    store(rng.next_uint32_bounded(bound), out_bounded, n);
+    rng.advance(RNG::Int64(delta));
+    store(rng.next_uint32(), out_after, n);
+    store(rng.state, state_out, n);
     return 0;
 }
 

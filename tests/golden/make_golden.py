@@ -55,6 +55,12 @@ ops2["in_e"] = np.trunc(b).astype(np.float32)
 ops2["ldexp"] = R.binary("ldexp", c, np.clip(ops2["in_e"], -100, 100))
 np.savez_compressed(os.path.join(HERE, "elementwise2_f32.npz"), **ops2)
 
+# ---- PCG32 (include/enoki/random.h) draw script, see oracle/ref_driver.cpp:ref_pcg32 -------------------
+seq = (np.arange(1024, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xda3e39cb94b95bdb))
+pm = ((hash_u32(np.arange(1024, dtype=np.uint64), 5) & np.uint32(3)) != 0).astype(np.uint8)
+pc = R.pcg32(0x853c49e6748fea9b, seq, 4, pm, 1000003, -98765)
+np.savez_compressed(os.path.join(HERE, "pcg32.npz"), initseq=seq, mask=pm, **pc)
+
 # ---- integer ops -----------------------------------------------------------------------------------
 rng = np.random.default_rng(7)
 iops = {}

@@ -138,6 +138,18 @@ class Checker:
         return y, gA, gB, sec.value
 
 
+    def pcg32(self, initstate, initseq, steps, mask, bound, delta):
+        """the PCG32 draw script of oracle/ref_driver.cpp:ref_pcg32 -> dict of outputs"""
+        initseq = np.ascontiguousarray(initseq, np.uint64); mask = np.ascontiguousarray(mask, np.uint8); n = initseq.size
+        o = {"u32": np.empty((steps, n), np.uint32), "f32": np.empty(n, np.float32), "u64": np.empty(n, np.uint64),
+             "f64": np.empty(n, np.float64), "bounded": np.empty(n, np.uint32), "after": np.empty(n, np.uint32),
+             "state": np.empty(n, np.uint64)}
+        self._chk(self._f("pcg32")(ctypes.c_uint64(initstate), _p(initseq), ctypes.c_size_t(n), ctypes.c_int(steps), _p(mask),
+                                   _p(o["u32"]), _p(o["f32"]), _p(o["u64"]), _p(o["f64"]), ctypes.c_uint32(bound),
+                                   _p(o["bounded"]), ctypes.c_int64(delta), _p(o["after"]), _p(o["state"])), "pcg32")
+        return o
+
+
 def _build(target):
     subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
 
