@@ -340,6 +340,119 @@ __device__ __forceinline__ float atanh_f32(float x) {                       // a
     return xa >= 0.5f ? copysign_f32(r_big, x) : r_small;
 }
 
+// ------------------------------------------------------------------------------------------------
+//  float64 branches of sin/cos/sincos, exp, log (array_math.h:325-327, 342-354, 745-746, 761-771,
+//  838-887).  Same structure as the f32 functions above; integers are 64 bit, the int conversion
+//  follows cvttpd2qq / the scalar fallback of the AVX2 path (indefinite = 0x8000000000000000).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t d2u(double f) { return (uint64_t) __double_as_longlong(f); }
+__device__ __forceinline__ double u2d(uint64_t u) { return __longlong_as_double((long long) u); }
+__device__ __forceinline__ double fma_(double a, double b, double c) { return __builtin_fma(a, b, c); }
+
+__device__ __forceinline__ int64_t cvtt_i64(double a) {
+    return (a > -9223372036854777856.0 && a < 9223372036854775808.0) ? (int64_t) a : (int64_t) 0x8000000000000000ull;
+}
+
+__device__ __forceinline__ double estrin(double x, double c0, double c1, double c2) {
+    double x2 = x * x;
+    return fma_(x2, c2, fma_(x, c1, c0));
+}
+__device__ __forceinline__ double estrin(double x, double c0, double c1, double c2, double c3) {
+    double x2 = x * x;
+    return fma_(x2, fma_(x, c3, c2), fma_(x, c1, c0));
+}
+__device__ __forceinline__ double estrin(double x, double c0, double c1, double c2, double c3, double c4, double c5) {
+    double x2 = x * x, x4 = x2 * x2;
+    return fma_(x2, fma_(x, c3, c2), fma_(x4, fma_(x, c5, c4), fma_(x, c1, c0)));
+}
+
+template <bool Sin, bool Cos>
+__device__ __forceinline__ void sincos_f64(double x, double &s_out, double &c_out) {
+    double xa = __builtin_fabs(x);
+    int64_t j = cvtt_i64(xa * 1.2732395447351626862);
+    j = (int64_t) (((uint64_t) j + 1ull) & ~1ull);
+    double y = (double) j;
+
+    uint64_t sign_sin = ((uint64_t) j << 61) ^ d2u(x);
+    uint64_t sign_cos = (~((uint64_t) j - 2ull)) << 61;
+
+    double t = xa - y * 7.85398125648498535156e-1;
+    t = t - y * 3.77489470793079817668e-8;
+    t = t - y * 2.69515142907905952645e-15;
+    y = t;
+
+    double z = y * y;
+    if (xa == __builtin_inf()) z = u2d(~0ull);
+
+    double s = estrin(z, -1.66666666666666307295e-1, 8.33333333332211858878e-3, -1.98412698295895385996e-4,
+                      2.75573136213857245213e-6, -2.50507477628578072866e-8, 1.58962301576546568060e-10) * z;
+    double c = estrin(z, 4.16666666666665929218e-2, -1.38888888888730564116e-3, 2.48015872888517045348e-5,
+                      -2.75573141792967388112e-7, 2.08757008419747316778e-9, -1.13585365213876817300e-11) * z;
+
+    s = fma_(s, y, y);
+    c = fma_(c, z, fma_(z, -0.5, 1.0));
+
+    bool polymask = (j & 2) == 0;
+    const uint64_t sb = 0x8000000000000000ull;
+    if (Sin) s_out = u2d(d2u(polymask ? s : c) ^ (sign_sin & sb));
+    if (Cos) c_out = u2d(d2u(polymask ? c : s) ^ (sign_cos & sb));
+}
+
+__device__ __forceinline__ double exp_f64(double x) {
+    bool overflow = x > 7.0943613930310391424428e2, underflow = x < -7.0943613930310391424428e2;
+    double n = __builtin_floor(fma_(1.4426950408889634073599, x, 0.5));
+    double xr = x;
+    xr = fma_(-n, 6.93145751953125e-1, xr);
+    xr = fma_(-n, 1.42860682030941723212e-6, xr);
+    double z = xr * xr;
+    double p = estrin(z, 9.99999999999999999910e-1, 3.02994407707441961300e-2, 1.26177193074810590878e-4) * xr;
+    double q = estrin(z, 2.00000000000000000009e0, 2.27265548208155028766e-1, 2.52448340349684104192e-3,
+                      3.00198505138664455042e-6);
+    double pq = p / (q - p);
+    z = pq + pq + 1.0;
+    double r = z * u2d(((uint64_t) cvtt_i64(n) + 0x3ffull) << 52);
+    return overflow ? __builtin_inf() : (underflow ? 0.0 : r);
+}
+
+__device__ __forceinline__ double log_f64(double x) {
+    bool valid = x >= 0.0;
+    uint64_t xi = d2u(x), exponent_bits = xi & 0x7ff0000000000000ull;
+    bool is_normal = (x != 0.0) && (exponent_bits != 0x7ff0000000000000ull);
+    int64_t exponent_i = (int64_t) (exponent_bits >> 52) - 0x3ff;
+    uint64_t mantissa = (xi & ~0x7ff0000000000000ull) | 0x3fe0000000000000ull;
+    double xm = u2d(is_normal ? mantissa : xi);
+    double e = (double) (is_normal ? exponent_i : 0);
+
+    bool e_big = __builtin_fabs(e) > 2.0;              // evaluated before the sqrt(1/2) adjustment (:815)
+    bool ge = xm >= 0.70710678118654752440;
+    if (ge) e += 1.0;
+
+    // |e| > 2: log(x) = z + z^3 P(z)/Q(z), z = 2(x-1)/(x+1)   (:842-861)
+    double zb = xm - 0.5;
+    if (ge) zb -= 0.5;
+    double yb = 0.5 * (ge ? xm : zb) + 0.5;
+    double x2b = zb / yb;
+    double z2 = x2b * x2b;
+    double rb = x2b * (z2 * estrin(z2, -6.41409952958715622951e1, 1.63866645699558079767e1, -7.89580278884799154124e-1) /
+                       estrin(z2, -7.69691943550460008604e2, 3.12093766372244180303e2, -3.56722798256324312549e1, 1.0));
+    double r_big = fma_(-e, 2.121944400546905827679e-4, rb) + x2b;
+
+    // otherwise: log(1+x) = x - x^2/2 + x^3 P(x)/Q(x)          (:863-884)
+    double x2s = (ge ? xm : xm + xm) - 1.0;
+    double zs = x2s * x2s;
+    double ys = x2s * (zs * estrin(x2s, 7.70838733755885391666e0, 1.79368678507819816313e1, 1.44989225341610930846e1,
+                                   4.70579119878881725854e0, 4.97494994976747001425e-1, 1.01875663804580931796e-4) /
+                       estrin(x2s, 2.31251620126765340583e1, 7.11544750618563894466e1, 8.29875266912776603211e1,
+                              4.52279145837532221105e1, 1.12873587189167450590e1, 1.0));
+    ys = fma_(-e, 2.121944400546905827679e-4, ys);
+    double r_small = x2s + fma_(-0.5, zs, ys);
+
+    double r = fma_(e, 0.693359375, e_big ? r_big : r_small);
+    if (x == __builtin_inf()) r = __builtin_inf();
+    if (x == 0.0) r = -__builtin_inf();
+    return valid ? r : u2d(~0ull);
+}
+
 // safe_mul / safe_fmadd: CPU branch of src/autodiff/autodiff.cpp:1191-1221
 // (w == 0 || g == 0) ? 0 : w*g     resp.    (w == 0 || g == 0) ? acc : fma(w, g, acc)
 template <typename T> __device__ __forceinline__ T safe_mul(T w, T g) {

@@ -50,7 +50,7 @@ template <int Op, typename T> constexpr bool unary_supported() {
         case EK_NOT: return !is_fp<T>;
         case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_FLOOR: case EK_CEIL: case EK_ROUND: case EK_TRUNC:
         case EK_SIGN: return is_fp<T>;
-        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
+        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG: return is_fp<T>;
         case EK_TAN: case EK_COT: case EK_ASIN: case EK_ACOS: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_TANH:
         case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return std::is_same_v<T, float>;
         case EK_POPCNT: case EK_LZCNT: case EK_TZCNT: return is_int<T>;
@@ -93,13 +93,17 @@ template <int Op, typename T> struct UnaryOp {
             // (sign_mask & a) | 1.0   (array_router.h:371)
             return from_bits<T>((bits(x) & sign_bit) | bits(T(1)));
         } else if constexpr (Op == EK_SIN) {
-            float s, c; dev::sincos_f32<true, false>(x, s, c); return s;
+            T s, c;
+            if constexpr (sizeof(T) == 4) dev::sincos_f32<true, false>(x, s, c); else dev::sincos_f64<true, false>(x, s, c);
+            return s;
         } else if constexpr (Op == EK_COS) {
-            float s, c; dev::sincos_f32<false, true>(x, s, c); return c;
+            T s, c;
+            if constexpr (sizeof(T) == 4) dev::sincos_f32<false, true>(x, s, c); else dev::sincos_f64<false, true>(x, s, c);
+            return c;
         } else if constexpr (Op == EK_EXP) {
-            return dev::exp_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::exp_f32(x); else return dev::exp_f64(x);
         } else if constexpr (Op == EK_LOG) {
-            return dev::log_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::log_f32(x); else return dev::log_f64(x);
         } else if constexpr (Op == EK_TAN) {
             return dev::tancot_f32<true>(x);
         } else if constexpr (Op == EK_COT) {
@@ -138,6 +142,7 @@ template <int Op, typename T> struct UnaryOp {
 
 struct SinCosOp {
     static __device__ __forceinline__ void apply(float x, float &s, float &c) { dev::sincos_f32<true, true>(x, s, c); }
+    static __device__ __forceinline__ void apply(double x, double &s, double &c) { dev::sincos_f64<true, true>(x, s, c); }
 };
 
 struct SinCoshOp {
@@ -432,7 +437,12 @@ int ek_hip_ternary(int op, int type, void *out, const ek_operand *a, const ek_op
 int ek_hip_sincos(int type, void *out, void *out_cos, const ek_operand *a, size_t n) {
     EK_PROLOGUE("ek_hip_sincos()")
     if (!out_cos) return fail(EK_ERR_INVALID, "ek_hip_sincos(): null output pointer");
-    if (type != EK_F32) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sincos(): only f32 is implemented");
+    if (type == EK_F64) {
+        Arg<double> ad;
+        if (int rc = make_arg<double>(a, n, ad, "ek_hip_sincos")) return rc;
+        return launch_map1x2<SinCosOp>("sincos", (double *) out, (double *) out_cos, n, ad);
+    }
+    if (type != EK_F32) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sincos(): floating point types only");
     Arg<float> aa;
     if (int rc = make_arg<float>(a, n, aa, "ek_hip_sincos")) return rc;
     return launch_map1x2<SinCosOp>("sincos", (float *) out, (float *) out_cos, n, aa);

@@ -319,6 +319,99 @@ static float atanh_f32(float x) {                                            /* 
 }
 
 /* ------------------------------------------------------------------------------------ */
+/*  float64 branches of sincos / exp / log (array_math.h:325-327, 342-354, 745-771, 838-887) */
+/* ------------------------------------------------------------------------------------ */
+static inline int64_t cvtt_f64_i64(double a) {                /* cvttsd2si: out of range / NaN -> INT64_MIN */
+    if (!(a > -9223372036854777856.0 && a < 9223372036854775808.0)) return INT64_MIN;
+    return (int64_t) a;
+}
+static inline double D2(double x, const double *c) { double x2 = x * x; return fma(x2, c[2], fma(x, c[1], c[0])); }
+static inline double D3(double x, const double *c) {
+    double x2 = x * x;
+    return fma(x2, fma(x, c[3], c[2]), fma(x, c[1], c[0]));
+}
+static inline double D5(double x, const double *c) {
+    double x2 = x * x, x4 = x2 * x2;
+    return fma(x2, fma(x, c[3], c[2]), fma(x4, fma(x, c[5], c[4]), fma(x, c[1], c[0])));
+}
+
+static void sincos_f64(double x, double *s_out, double *c_out) {             /* :261-367, double branch */
+    static const double cs[6] = { -1.66666666666666307295e-1, 8.33333333332211858878e-3, -1.98412698295895385996e-4,
+                                  2.75573136213857245213e-6, -2.50507477628578072866e-8, 1.58962301576546568060e-10 };
+    static const double cc[6] = { 4.16666666666665929218e-2, -1.38888888888730564116e-3, 2.48015872888517045348e-5,
+                                  -2.75573141792967388112e-7, 2.08757008419747316778e-9, -1.13585365213876817300e-11 };
+    double xa = fabs(x);
+    int64_t j = cvtt_f64_i64(xa * 1.2732395447351626862);                    /* :301 */
+    j = (int64_t) (((uint64_t) j + 1ull) & ~1ull);                           /* :304 */
+    double y = (double) j;
+    uint64_t sign_sin = ((uint64_t) j << 61) ^ d2u(x);                       /* :314 */
+    uint64_t sign_cos = (~((uint64_t) j - 2ull)) << 61;                      /* :317 */
+    double t = xa - y * 7.85398125648498535156e-1;                           /* :325-327 */
+    t = t - y * 3.77489470793079817668e-8;
+    t = t - y * 2.69515142907905952645e-15;
+    y = t;
+    double z = y * y;
+    if (xa == INFINITY) z = u2d(~0ull);                                      /* :331 */
+    double s = D5(z, cs) * z, c = D5(z, cc) * z;                             /* :342-354 */
+    s = fma(s, y, y);                                                        /* :357 */
+    c = fma(c, z, fma(z, -0.5, 1.0));                                        /* :358 */
+    int polymask = (j & 2) == 0;
+    if (s_out) *s_out = u2d(d2u(polymask ? s : c) ^ (sign_sin & 0x8000000000000000ull));
+    if (c_out) *c_out = u2d(d2u(polymask ? c : s) ^ (sign_cos & 0x8000000000000000ull));
+}
+
+static double exp_f64(double x) {                                            /* :711-776, double branch */
+    static const double cp[3] = { 9.99999999999999999910e-1, 3.02994407707441961300e-2, 1.26177193074810590878e-4 };
+    static const double cq[4] = { 2.00000000000000000009e0, 2.27265548208155028766e-1, 2.52448340349684104192e-3,
+                                  3.00198505138664455042e-6 };
+    int overflow = x > 7.0943613930310391424428e2, underflow = x < -7.0943613930310391424428e2;
+    double n = floor(fma(1.4426950408889634073599, x, 0.5));                 /* :739 */
+    double xr = fma(-n, 6.93145751953125e-1, x);                             /* :745 */
+    xr = fma(-n, 1.42860682030941723212e-6, xr);                             /* :746 */
+    double z = xr * xr;
+    double p = D2(z, cp) * xr, q = D3(z, cq);                                /* :761-768 */
+    double pq = p / (q - p);
+    z = pq + pq + 1.0;                                                       /* :770-771 */
+    double r = z * u2d(((uint64_t) cvtt_f64_i64(n) + 0x3ffull) << 52);       /* ldexp :677-680 */
+    return overflow ? INFINITY : (underflow ? 0.0 : r);
+}
+
+static double log_f64(double x) {                                            /* :778-898, double branch */
+    static const double pb[3] = { -6.41409952958715622951e1, 1.63866645699558079767e1, -7.89580278884799154124e-1 };
+    static const double qb[4] = { -7.69691943550460008604e2, 3.12093766372244180303e2, -3.56722798256324312549e1, 1.0 };
+    static const double ps[6] = { 7.70838733755885391666e0, 1.79368678507819816313e1, 1.44989225341610930846e1,
+                                  4.70579119878881725854e0, 4.97494994976747001425e-1, 1.01875663804580931796e-4 };
+    static const double qs[6] = { 2.31251620126765340583e1, 7.11544750618563894466e1, 8.29875266912776603211e1,
+                                  4.52279145837532221105e1, 1.12873587189167450590e1, 1.0 };
+    int valid = x >= 0.0;
+    uint64_t xi = d2u(x), eb = xi & 0x7ff0000000000000ull;                   /* frexp :682-709 */
+    int normal = (x != 0.0) && (eb != 0x7ff0000000000000ull);
+    double xm = u2d(normal ? ((xi & ~0x7ff0000000000000ull) | 0x3fe0000000000000ull) : xi);
+    double e = (double) (normal ? (int64_t) (eb >> 52) - 0x3ff : 0);
+    int e_big = fabs(e) > 2.0;                                               /* :815 (before the adjustment) */
+    int ge = xm >= 0.70710678118654752440;
+    if (ge) e += 1.0;                                                        /* :819 */
+
+    double zb = xm - 0.5;                                                    /* :844-860 */
+    if (ge) zb -= 0.5;
+    double yb = 0.5 * (ge ? xm : zb) + 0.5;
+    double x2b = zb / yb, z2 = x2b * x2b;
+    double rb = x2b * (z2 * D2(z2, pb) / D3(z2, qb));
+    double r_big = fma(-e, 2.121944400546905827679e-4, rb) + x2b;
+
+    double x2s = (ge ? xm : xm + xm) - 1.0;                                  /* :865-883 */
+    double zs = x2s * x2s;
+    double ys = x2s * (zs * D5(x2s, ps) / D5(x2s, qs));
+    ys = fma(-e, 2.121944400546905827679e-4, ys);
+    double r_small = x2s + fma(-0.5, zs, ys);
+
+    double r = fma(e, 0.693359375, e_big ? r_big : r_small);                 /* :886-887 */
+    if (x == INFINITY) r = INFINITY;
+    if (x == 0.0) r = -INFINITY;
+    return valid ? r : u2d(~0ull);
+}
+
+/* ------------------------------------------------------------------------------------ */
 /*  generic dispatch helpers                                                              */
 /* ------------------------------------------------------------------------------------ */
 
@@ -374,7 +467,11 @@ static int unary_f64(const char *op, const double *a, double *o, size_t n) {
     if (is(op, "ceil"))  LOOP(ceil(x));
     if (is(op, "round")) LOOP(rint(x));
     if (is(op, "trunc")) LOOP(trunc(x));
+    if (is(op, "exp"))   LOOP(exp_f64(x));
+    if (is(op, "log"))   LOOP(log_f64(x));
 #undef LOOP
+    if (is(op, "sin")) { for (size_t i = 0; i < n; ++i) sincos_f64(a[i], &o[i], NULL); return 0; }
+    if (is(op, "cos")) { for (size_t i = 0; i < n; ++i) sincos_f64(a[i], NULL, &o[i]); return 0; }
     return -1;
 }
 
@@ -410,6 +507,12 @@ int orc_unary(int type, const char *op, const void *a, void *out, size_t n) {
 }
 
 int orc_sincos(int type, const void *a_, void *s_, void *c_, size_t n) {
+    if (type == T_F64) {
+        const double *ad = (const double *) a_;
+        double *sd = (double *) s_, *cd = (double *) c_;
+        for (size_t i = 0; i < n; ++i) sincos_f64(ad[i], &sd[i], &cd[i]);
+        return 0;
+    }
     if (type != T_F32) return -2;
     const float *a = (const float *) a_;
     float *s = (float *) s_, *c = (float *) c_;

@@ -54,6 +54,26 @@ def f32_inputs(n, seed, scale=1.0, specials=True):
     return v
 
 
+SPECIALS_F64 = np.array(
+    [0.0, -0.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 1e-310, 2.2250738585072014e-308, 1e308, -1e308, 1, -1, 0.5, 2,
+     709.4, 709.5, -709.4, -709.5, -745.2, 8192, -8192, 1e6, 1e9, 3e9, -3e9, 0.70710678118654752, 0.7071067811865476,
+     np.pi, np.pi / 2, np.pi / 4, 1.5, 2.5, -1.5, -2.5, 0.49999999999999994, 4503599627370496.0, 0.125, 8.0, 3.0],
+    dtype=np.float64)
+
+
+def f64_inputs(n, seed, scale=1.0, specials=True, limit=None):
+    """float64 test inputs; `limit` clamps magnitudes (the AVX2 reference build's f64 sin/cos are indeterminate
+    for |x| * 4/pi >= 2^32: its 64-bit integer packets convert through 32-bit lanes)"""
+    rng = np.random.default_rng(seed)
+    v = rng.standard_normal(n) * scale
+    if specials and n >= SPECIALS_F64.size:
+        v[:SPECIALS_F64.size] = SPECIALS_F64
+    if limit is not None:
+        big = np.abs(v) > limit
+        v[big & np.isfinite(v)] = limit
+    return v
+
+
 def bits_equal(a, b):
     """bit equality, except that any NaN equals any NaN (payloads are not part of the contract)"""
     a = np.asarray(a); b = np.asarray(b)

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import oracle_lib  # noqa: E402
 import tape_lib  # noqa: E402
-from conftest import SPECIALS_F32, f32_inputs, uniform_pm1, hash_u32  # noqa: E402
+from conftest import SPECIALS_F32, f32_inputs, f64_inputs, uniform_pm1, hash_u32  # noqa: E402
 
 R = oracle_lib.ref()
 
@@ -54,6 +54,13 @@ for op in ["atan2", "pow", "fmod"]:
 ops2["in_e"] = np.trunc(b).astype(np.float32)
 ops2["ldexp"] = R.binary("ldexp", c, np.clip(ops2["in_e"], -100, 100))
 np.savez_compressed(os.path.join(HERE, "elementwise2_f32.npz"), **ops2)
+
+# ---- float64 transcendentals (array_math.h double branches) ---------------------------------------------
+d = f64_inputs(n, seed=201, scale=20.0, limit=3e9); dpos = np.abs(f64_inputs(n, seed=202, scale=1e3))
+ops64 = {"in_d": d, "in_pos": dpos, "sin": R.unary("sin", d), "cos": R.unary("cos", d), "exp": R.unary("exp", d),
+         "log": R.unary("log", d), "log_pos": R.unary("log", dpos)}
+ops64["sincos_s"], ops64["sincos_c"] = R.sincos(d)
+np.savez_compressed(os.path.join(HERE, "elementwise_f64.npz"), **ops64)
 
 # ---- PCG32 (include/enoki/random.h) draw script, see oracle/ref_driver.cpp:ref_pcg32 -------------------
 seq = (np.arange(1024, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xda3e39cb94b95bdb))

@@ -12,7 +12,7 @@ Parity classes:
 import numpy as np
 import pytest
 
-from conftest import SPECIALS_F32, bits_equal, f32_inputs, ulp_diff
+from conftest import SPECIALS_F32, bits_equal, f32_inputs, f64_inputs, ulp_diff
 
 pytestmark = pytest.mark.gpu
 
@@ -67,6 +67,22 @@ def test_second_wave_golden(capi):
         assert bits_equal(capi.unary(op, up(capi, a)).numpy(), z[f"unary_{op}"]), op
     for op in ["atan2", "pow", "fmod"]:
         assert bits_equal(capi.binary(op, up(capi, a), up(capi, b)).numpy(), z[f"binary_{op}"]), op
+
+
+@pytest.mark.parametrize("scale", [1.0, 30.0, 3000.0, 1e6, 1e300])
+def test_f64_transcendentals_bit_exact(capi, oracle, scale):
+    """float64 sin/cos/sincos/exp/log: array_math.h double branches, bit-exact vs the oracle (itself bit-exact vs
+    the reference build wherever that build is determinate, tests/test_oracle_vs_ref.py)"""
+    a = f64_inputs(100003, seed=51, scale=scale)
+    for op in ["sin", "cos", "exp", "log"]:
+        assert bits_equal(capi.unary(op, up(capi, a)).numpy(), oracle.unary(op, a)), op
+    s, c = capi.sincos(up(capi, a))
+    es, ec = oracle.sincos(a)
+    assert bits_equal(s.numpy(), es) and bits_equal(c.numpy(), ec)
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "elementwise_f64.npz"))
+    for op in ["sin", "cos", "exp", "log"]:
+        assert bits_equal(capi.unary(op, up(capi, z["in_d"])).numpy(), z[op]), op
 
 
 @pytest.mark.parametrize("n", SIZES)

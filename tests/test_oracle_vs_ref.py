@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle_lib as ol
-from conftest import bits_equal, f32_inputs, ulp_diff, uniform_pm1, hash_u32
+from conftest import bits_equal, f32_inputs, f64_inputs, ulp_diff, uniform_pm1, hash_u32
 
 HAVE_REF = os.path.exists(os.path.join(ol.ORACLE_DIR, "_ref", "libenoki_ref.so"))
 needs_ref = pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref was not built (needs /root/reference)")
@@ -37,6 +37,24 @@ def test_f32_vertical_ops_bit_exact(scale):
         assert bits_equal(P.ternary(op, a, b, c), R.ternary(op, a, b, c)), op
     for op in ["eq", "neq", "lt", "le", "gt", "ge"]:
         assert np.array_equal(P.compare(op, a, b), R.compare(op, a, b)), op
+
+
+@needs_ref
+@pytest.mark.parametrize("scale", [1.0, 30.0, 3000.0, 1e6])
+def test_f64_transcendentals_bit_exact(scale):
+    """double branches of sin/cos/sincos/exp/log.  sin/cos only for |x| <= 3e9: beyond |x|*4/pi = 2^32 this reference
+    build returns indeterminate values (its int64 packets convert through 32-bit lanes without AVX512DQ)."""
+    R = ol.ref()
+    a = f64_inputs(200003, 31, scale, limit=3e9)
+    for op in ["sin", "cos", "exp", "log"]:
+        assert bits_equal(P.unary(op, a), R.unary(op, a)), op
+    ps, pc = P.sincos(a); rs, rc = R.sincos(a)
+    assert bits_equal(ps, rs) and bits_equal(pc, rc)
+    b = f64_inputs(200003, 32, 1e300)                  # exp / log have no such restriction
+    for op in ["exp", "log"]:
+        assert bits_equal(P.unary(op, b), R.unary(op, b)), op
+    x = np.abs(f64_inputs(100000, 33, 10.0, specials=False)) + 1e-3
+    assert np.abs(P.unary("log", x) - np.log(x)).max() < 2e-15 and np.abs(P.unary("sin", x) - np.sin(x)).max() < 3e-16
 
 
 CLASS_A2 = ["asin", "acos", "atan", "asinh", "acosh", "atanh", "cbrt"]   # no rcp() inside: bit-exact
@@ -214,6 +232,16 @@ def test_golden_second_wave():
         p, r = P.unary(op, a), z[f"unary_{op}"]
         ok = np.isfinite(r) & np.isfinite(p) & (np.abs(r) > 1e-30) & (np.abs(r) < 1e30) & (np.abs(a) < 50)
         assert ulp_diff(p[ok], r[ok]).max() <= bound, op
+
+
+def test_golden_f64():
+    z = np.load(os.path.join(GOLDEN, "elementwise_f64.npz"))
+    d = z["in_d"]
+    for op in ["sin", "cos", "exp", "log"]:
+        assert bits_equal(P.unary(op, d), z[op]), op
+    assert bits_equal(P.unary("log", z["in_pos"]), z["log_pos"])
+    s_, c_ = P.sincos(d)
+    assert bits_equal(s_, z["sincos_s"]) and bits_equal(c_, z["sincos_c"])
 
 
 def test_golden_integer():

@@ -236,3 +236,13 @@ def test_second_wave_python_surface(ekc, ek):
     B64 = b.astype(np.float64)
     assert np.allclose(ek.gradient(base).numpy(), A64 * B64 ** (A64 - 1), rtol=2e-5, atol=1e-6)
     assert np.allclose(ek.gradient(ex).numpy(), np.log(B64) * B64 ** A64, rtol=2e-5, atol=1e-6)
+
+
+def test_float64_transcendentals_python(ekc):
+    a = np.random.default_rng(4).uniform(-20, 20, 10007)
+    x = ekc.Float64(a)
+    assert np.abs(ekc.sin(x).numpy() - np.sin(a)).max() < 3e-16 and np.abs(ekc.cos(x).numpy() - np.cos(a)).max() < 3e-16
+    assert np.allclose(ekc.exp(x).numpy(), np.exp(a), rtol=1e-15, atol=0)
+    assert np.allclose(ekc.log(ekc.Float64(np.abs(a) + 1e-9)).numpy(), np.log(np.abs(a) + 1e-9), rtol=0, atol=1e-15)
+    s, c = ekc.sincos(x)
+    assert np.array_equal(s.numpy(), ekc.sin(x).numpy()) and np.array_equal(c.numpy(), ekc.cos(x).numpy())
