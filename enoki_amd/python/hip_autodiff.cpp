@@ -4,6 +4,8 @@
 
 using FloatC = HIPArray<float>;
 using FloatD = DiffArray<HIPArray<float>>;
+using DoubleC = HIPArray<double>;
+using DoubleD = DiffArray<HIPArray<double>>;
 using Int32D = DiffArray<HIPArray<int32_t>>;
 using UInt32D = DiffArray<HIPArray<uint32_t>>;
 using MaskD = DiffArray<HIPArray<bool>>;
@@ -14,6 +16,7 @@ PYBIND11_MODULE(hip_autodiff, m) {
     bind_runtime(m);
     auto mask = bind_array<MaskD>(m, "Mask");
     auto f32 = bind_array<FloatD>(m, "Float32");
+    auto f64 = bind_array<DoubleD>(m, "Float64");       // Tape<HIPArray<double>> (autodiff.cpp:1240 analogue)
     auto i32 = bind_array<Int32D>(m, "Int32");
     auto u32 = bind_array<UInt32D>(m, "UInt32");
     m.attr("Float") = m.attr("Float32");
@@ -22,6 +25,8 @@ PYBIND11_MODULE(hip_autodiff, m) {
     bind_vector<FloatD, 4>(m, "Vector4f");
 
     f32.def(py::init([](const FloatC &v) { return FloatD(v); }));
+    f64.def(py::init([](const DoubleC &v) { return DoubleD(v); }));
+    bind_cast<FloatD, DoubleD>(f32); bind_cast<DoubleD, FloatD>(f64);
     u32.def(py::init([](const HIPArray<uint32_t> &v) { return UInt32D(v); }));
     i32.def(py::init([](const HIPArray<int32_t> &v) { return Int32D(v); }));
     mask.def(py::init([](const HIPArray<bool> &v) { return MaskD(v); }));
@@ -31,4 +36,5 @@ PYBIND11_MODULE(hip_autodiff, m) {
 
     bind_memory<FloatD, UInt32D>(m); bind_memory<FloatD, Int32D>(m);
     bind_memory<UInt32D, UInt32D>(m); bind_memory<Int32D, UInt32D>(m);
+    bind_memory<DoubleD, UInt32D>(m);
 }

@@ -246,3 +246,24 @@ def test_float64_transcendentals_python(ekc):
     assert np.allclose(ekc.log(ekc.Float64(np.abs(a) + 1e-9)).numpy(), np.log(np.abs(a) + 1e-9), rtol=0, atol=1e-15)
     s, c = ekc.sincos(x)
     assert np.array_equal(s.numpy(), ekc.sin(x).numpy()) and np.array_equal(c.numpy(), ekc.cos(x).numpy())
+
+
+def test_float64_autodiff(ek, ekc):
+    """DiffArray<HIPArray<double>> / Tape<HIPArray<double>>: cfg3a and cfg3b shapes in float64 vs numpy float64"""
+    rng = np.random.default_rng(8); n, k = 50021, 257
+    a, x, b = (rng.uniform(-1, 1, n) for _ in range(3))
+    A = ek.Float64(ekc.Float64(a)); B = ek.Float64(ekc.Float64(b)); X = ek.Float64(ekc.Float64(x))
+    ek.set_requires_gradient(A); ek.set_requires_gradient(B)
+    y = ek.hsum(ek.sin(ek.fmadd(A, X, B)))
+    ek.backward(y)
+    u = a * x + b
+    assert abs(ek.detach(y).numpy()[0] - np.sin(u).sum()) < 1e-9
+    assert np.allclose(ek.gradient(A).numpy(), np.cos(u) * x, rtol=1e-13, atol=1e-15)
+    assert np.allclose(ek.gradient(B).numpy(), np.cos(u), rtol=1e-13, atol=1e-15)
+    # gather / scatter_add adjoints in float64 (global fp64 atomics)
+    T = rng.uniform(-1, 1, k); idx = rng.integers(0, k, n).astype(np.uint32)
+    Td = ek.Float64(ekc.Float64(T)); ek.set_requires_gradient(Td)
+    g = ek.gather(Td, ek.UInt32(ekc.UInt32(idx)))
+    ek.backward(ek.hsum(ek.exp(g) * X))
+    want = np.zeros(k); np.add.at(want, idx, np.exp(T[idx]) * x)
+    assert np.allclose(ek.gradient(Td).numpy(), want, rtol=1e-11, atol=1e-12)
