@@ -137,6 +137,10 @@ def build_checkers(force=False, verbose=True):
     if force or _newer(sphere, [os.path.join(tcpp, "sphere_hip.cpp"), os.path.join(HERE, "libenoki-hip.so")] + _headers()):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "sphere_hip.cpp"), "-o", sphere,
               f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+    call = os.path.join(tcpp, "libcall_hip.so")
+    if force or _newer(call, [os.path.join(tcpp, "call_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "call_hip.cpp"), "-o", call,
+              f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     if verbose:
         print("[enoki_amd] checkers up to date (oracle/, tests/cpp/)")
 

@@ -445,8 +445,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// Built from the library's own scan + scatter; reads the new size back (synchronises, like the reference).
     HIPArray compress_(const MaskType &mask) const {
         if (mask.size() == 0) return HIPArray();
+        if (size() == 1) return *this;                       // broadcast operand: returned as is (cuda.h:910-911)
         if (mask.size() != size()) throw std::runtime_error("HIPArray::compress_(): size mismatch!");
-        if (size() == 1) return mask.coeff(0) ? *this : HIPArray();
         using UInt32 = HIPArray<uint32_t>;
         UInt32 ones = UInt32::select_(mask, UInt32(1u), UInt32(0u));
         UInt32 pos = ones.psum_();                         // inclusive prefix sum: 1-based slot of kept entries

@@ -1,0 +1,118 @@
+// Vectorised virtual method calls on device pointer arrays (include/enoki/array_call.h), in the style of the
+// reference's tests/call.cpp and tests/autodiff.cpp:564-607 (test35_call): a small class hierarchy whose
+// methods take and return HIPArray / Array<HIPArray, 3> / DiffArray values.  Driven by tests/test_call_gpu.py,
+// which computes the expected lanes with the CPU oracle's elementwise ops.
+#include <enoki/array_call.h>
+#include <enoki/autodiff.h>
+
+using namespace enoki;
+using FloatC = HIPArray<float>;
+using UInt32C = HIPArray<uint32_t>;
+using MaskC = HIPArray<bool>;
+using Vector3fC = Array<FloatC, 3>;
+using FloatD = DiffArray<FloatC>;
+
+struct Shape {
+    virtual ~Shape() = default;
+    /// elementwise response; receives the lane mask as trailing argument
+    virtual FloatC eval(const FloatC &x, const MaskC &active) const = 0;
+    /// nested array argument and result, no mask parameter
+    virtual Vector3fC offset(const Vector3fC &p, const FloatC &t) const = 0;
+    /// returns a plain scalar: becomes one value per lane
+    virtual float id() const = 0;
+    /// void method with a side effect on the instance
+    virtual void touch(const FloatC &x, const MaskC &active) = 0;
+    /// differentiable argument / result
+    virtual FloatD eval_d(const FloatD &x) const = 0;
+    size_t lanes_seen = 0;
+    size_t active_seen = 0;
+};
+
+struct Sine : Shape {
+    float amp;
+    explicit Sine(float amp) : amp(amp) { }
+    FloatC eval(const FloatC &x, const MaskC &active) const override { return select(active, sin(x) * amp, -1.f); }
+    Vector3fC offset(const Vector3fC &p, const FloatC &t) const override { return p + Vector3fC(t, 0.f, amp); }
+    float id() const override { return 1.f; }
+    void touch(const FloatC &x, const MaskC &active) override { lanes_seen += x.size(); active_seen += count(active); }
+    FloatD eval_d(const FloatD &x) const override { return sin(x) * amp; }
+};
+
+struct Poly : Shape {
+    float c0, c1;
+    Poly(float c0, float c1) : c0(c0), c1(c1) { }
+    FloatC eval(const FloatC &x, const MaskC &active) const override { return select(active, fmadd(x, c1, c0), -2.f); }
+    Vector3fC offset(const Vector3fC &p, const FloatC &t) const override { return p * t; }
+    float id() const override { return 2.f; }
+    void touch(const FloatC &x, const MaskC &active) override { lanes_seen += x.size(); active_seen += count(active); }
+    FloatD eval_d(const FloatD &x) const override { return fmadd(x, c1, c0) * x; }
+};
+
+ENOKI_CALL_SUPPORT_BEGIN(Shape)
+ENOKI_CALL_SUPPORT_METHOD(eval)
+ENOKI_CALL_SUPPORT_METHOD(offset)
+ENOKI_CALL_SUPPORT_METHOD(id)
+ENOKI_CALL_SUPPORT_METHOD(touch)
+ENOKI_CALL_SUPPORT_METHOD(eval_d)
+ENOKI_CALL_SUPPORT_END(Shape)
+
+using ShapePtrC = HIPArray<Shape *>;
+
+static void to_host(const FloatC &a, float *dst, size_t n) {
+    auto h = a.to_host();
+    if (h.size() == 1 && n != 1) { for (size_t i = 0; i < n; ++i) dst[i] = h[0]; }
+    else memcpy(dst, h.data(), n * sizeof(float));
+}
+
+/// which[i]: 0 -> Sine(1.5), 1 -> Poly(0.25, -2), 2 -> Sine(-0.5), 255 -> nullptr.  Outputs are n floats each;
+/// part_* describe partition(): group count, per group the instance number and size, then all permutations.
+extern "C" __attribute__((visibility("default")))
+int hip_call_test(const uint8_t *which, const float *x_, const float *t_, const uint8_t *mask_, size_t n, float *out_eval,
+                  float *out_eval_masked, float *out_off /* 3n */, float *out_id, uint64_t *touch_stats /* 3 x 2 */,
+                  float *out_d, float *out_grad, uint32_t *part_groups /* 1 + 2*4 */, uint32_t *part_perm /* n */) {
+    try {
+        Sine s0(1.5f), s2(-0.5f);
+        Poly p1(0.25f, -2.f);
+        Shape *table[3] = { &s0, &p1, &s2 };
+        std::vector<Shape *> host(n);
+        for (size_t i = 0; i < n; ++i) host[i] = which[i] < 3 ? table[which[i]] : nullptr;
+        ShapePtrC shapes = ShapePtrC::copy(host.data(), n);
+        FloatC x = FloatC::copy(x_, n), t = FloatC::copy(t_, n);
+        MaskC mask = MaskC::copy(mask_, n);
+
+        to_host(shapes->eval(x), out_eval, n);
+        to_host(shapes->eval(x, mask), out_eval_masked, n);
+        Vector3fC off = shapes->offset(Vector3fC(x, t, 1.f), t);
+        for (int k = 0; k < 3; ++k) to_host(off.coeff(k), out_off + k * n, n);
+        to_host(shapes->id(), out_id, n);
+        shapes->touch(x, mask);
+        for (int k = 0; k < 3; ++k) { touch_stats[2 * k] = table[k]->lanes_seen; touch_stats[2 * k + 1] = table[k]->active_seen; }
+
+        FloatD xd(x);
+        set_requires_gradient(xd);
+        FloatD yd = shapes->eval_d(xd);
+        to_host(detach(yd), out_d, n);
+        backward(hsum(yd));
+        to_host(gradient(xd), out_grad, n);
+
+        const auto &groups = partition(shapes);
+        part_groups[0] = (uint32_t) groups.size();
+        size_t pos = 0;
+        for (size_t g = 0; g < groups.size() && g < 4; ++g) {
+            Shape *p = groups[g].first;
+            if (g > 0 && !((uintptr_t) p > (uintptr_t) groups[g - 1].first))
+                return -4;                       // groups must come in ascending pointer order (horiz.cu:49-57)
+            uint32_t number = 255;
+            for (uint32_t k = 0; k < 3; ++k) if (p == table[k]) number = k;
+            part_groups[1 + 2 * g] = number;
+            part_groups[2 + 2 * g] = (uint32_t) groups[g].second.size();
+            auto h = groups[g].second.to_host();
+            memcpy(part_perm + pos, h.data(), h.size() * sizeof(uint32_t));
+            pos += h.size();
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hip_call_test: %s\n", e.what());
+        return -3;
+    }
+}

@@ -1,0 +1,94 @@
+"""Vectorised virtual method calls on device pointer arrays (include/enoki/array_call.h; reference
+include/enoki/array_call.h:17-283, cuda.h:815-842, horiz.cu:35-122, tests/call.cpp, tests/autodiff.cpp:564-607).
+
+tests/cpp/call_hip.cpp holds a two-class hierarchy; every lane's expected value is recomputed here with the CPU
+oracle's elementwise ops (all class A), so the comparison is bit-exact; partition() is checked against numpy."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, hash_u32, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def run(which, x, t, mask):
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libcall_hip.so"))
+    n = x.size
+    o = {"eval": np.empty(n, np.float32), "eval_masked": np.empty(n, np.float32), "off": np.empty((3, n), np.float32),
+         "id": np.empty(n, np.float32), "touch": np.zeros(6, np.uint64), "d": np.empty(n, np.float32),
+         "grad": np.empty(n, np.float32), "groups": np.zeros(9, np.uint32), "perm": np.zeros(n, np.uint32)}
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.hip_call_test(p(which), p(x), p(t), p(mask), ctypes.c_size_t(n), p(o["eval"]), p(o["eval_masked"]), p(o["off"]),
+                           p(o["id"]), p(o["touch"]), p(o["d"]), p(o["grad"]), p(o["groups"]), p(o["perm"]))
+    assert rc == 0, rc
+    return o
+
+
+def expected(oracle, which, x, t, mask, single):
+    f32 = np.float32
+    sinx = oracle.unary("sin", x)
+    f = {0: sinx * f32(1.5), 1: oracle.ternary("fmadd", x, np.full_like(x, -2.0), np.full_like(x, 0.25)), 2: sinx * f32(-0.5)}
+    inactive = {0: f32(-1), 1: f32(-2), 2: f32(-1)}
+    ev = np.zeros_like(x); evm = np.zeros_like(x); off = np.zeros((3, x.size), f32); ident = np.zeros_like(x)
+    d = np.zeros_like(x)
+    for k in (0, 1, 2):
+        sel = which == k
+        ev[sel] = f[k][sel]
+        act = sel & ((mask != 0) | single)          # a single-instance array is called with mask = true (array_call.h:151-153)
+        evm[sel] = inactive[k]
+        evm[act] = f[k][act]
+        ident[sel] = 1.0 if k != 1 else 2.0
+        amp = {0: f32(1.5), 2: f32(-0.5)}.get(k)
+        if k == 1:
+            off[0][sel] = (x * t)[sel]; off[1][sel] = (t * t)[sel]; off[2][sel] = t[sel]
+            d[sel] = (f[1] * x)[sel]
+        else:
+            off[0][sel] = (x + t)[sel]; off[1][sel] = (t + f32(0))[sel]; off[2][sel] = f32(1) + amp
+            d[sel] = f[k][sel]
+    return ev, evm, off, ident, d
+
+
+@pytest.mark.parametrize("n", [5, 1000, 100003])
+def test_vectorised_calls_bit_exact(oracle, n):
+    which = (hash_u32(np.arange(n, dtype=np.uint64), 11) % np.uint32(4)).astype(np.uint8)
+    which[which == 3] = 255                                   # null pointers
+    x = uniform_pm1(n, 12) * np.float32(3); t = uniform_pm1(n, 13)
+    mask = ((hash_u32(np.arange(n, dtype=np.uint64), 5) & np.uint32(3)) != 0).astype(np.uint8)
+    o = run(which, x, t, mask)
+    ev, evm, off, ident, d = expected(oracle, which, x, t, mask, single=False)
+    assert bits_equal(o["eval"], ev) and bits_equal(o["eval_masked"], evm)
+    assert bits_equal(o["off"], off) and bits_equal(o["id"], ident) and bits_equal(o["d"], d)
+    # derivatives: cos(x) * amp resp. d/dx (c1 x + c0) x
+    cosx = np.cos(x.astype(np.float64))
+    g = np.where(which == 0, 1.5 * cosx, np.where(which == 2, -0.5 * cosx, np.where(which == 1, -4.0 * x + 0.25, 0.0)))
+    assert np.allclose(o["grad"], g, rtol=2e-6, atol=2e-6)
+    # side effects: every instance saw its own lanes once, and the mask restricted to them
+    for k in (0, 1, 2):
+        assert o["touch"][2 * k] == (which == k).sum() and o["touch"][2 * k + 1] == ((which == k) & (mask != 0)).sum()
+    # partition(): one group per distinct pointer (incl. null), ascending pointer order is asserted inside the library;
+    # lanes ascending within a group (stable), sizes = histogram
+    ng = int(o["groups"][0]); pos = 0
+    assert ng == len(np.unique(which))
+    seen = set()
+    for gidx in range(ng):
+        number, size = int(o["groups"][1 + 2 * gidx]), int(o["groups"][2 + 2 * gidx])
+        lanes = o["perm"][pos:pos + size]; pos += size
+        assert np.array_equal(lanes, np.flatnonzero(which == number).astype(np.uint32)), number
+        seen.add(number)
+    assert seen == set(np.unique(which).tolist()) and pos == n
+
+
+def test_single_instance_shortcut(oracle):
+    n = 4099
+    which = np.zeros(n, np.uint8)
+    x = uniform_pm1(n, 21) * np.float32(3); t = uniform_pm1(n, 22)
+    mask = (np.arange(n) % 2).astype(np.uint8)
+    o = run(which, x, t, mask)
+    ev, evm, off, ident, d = expected(oracle, which, x, t, mask, single=True)
+    assert bits_equal(o["eval"], ev) and bits_equal(o["eval_masked"], evm) and bits_equal(o["off"], off)
+    assert bits_equal(o["id"], ident) and bits_equal(o["d"], d)
+    assert int(o["groups"][0]) == 1 and int(o["groups"][2]) == n and o["touch"][0] == n
