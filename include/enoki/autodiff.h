@@ -25,6 +25,7 @@
 
 #include <enoki/array.h>
 
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -41,6 +42,24 @@ namespace detail {
     template <typename T>
     struct has_fused_safe_ops<T, std::void_t<decltype(T::safe_mul_(std::declval<const T &>(), std::declval<const T &>()))>>
         : std::true_type { };
+}
+
+namespace detail {
+    template <typename T, typename = void> struct has_literal_test : std::false_type { };
+    template <typename T>
+    struct has_literal_test<T, std::void_t<decltype(std::declval<const T &>().is_literal_(scalar_t<T>(1)))>> : std::true_type { };
+
+    /// Is `w` the host-known scalar 1?  Then safe_mul(w, g) is g itself up to the sign of zero entries
+    /// (safe_mul returns +0 where g == -0), and the sweep can share g's buffer instead of streaming a copy.
+    /// Backends without immediates answer false.  ENOKI_HIP_STRICT_SAFE_MUL=1 restores the literal evaluation.
+    template <typename T> inline bool is_unit_weight(const T &w) {
+        if constexpr (has_literal_test<T>::value) {
+            static const bool strict = [] { const char *e = getenv("ENOKI_HIP_STRICT_SAFE_MUL"); return e && *e == '1'; }();
+            return !strict && w.is_literal_(scalar_t<T>(1));
+        } else {
+            return false;
+        }
+    }
 }
 
 template <typename Value> inline Value safe_mul(const Value &w, const Value &g) {

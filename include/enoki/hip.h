@@ -479,6 +479,9 @@ template <typename Value_> struct HIPArray : ArrayTag {
     size_t size() const { return m_is_imm ? 1 : (m_buf ? m_buf->size : 0); }
     size_t slices_() const { return size(); }
     bool empty() const { return size() == 0; }
+
+    /// True when the array is a host-known scalar equal to `v` (lets callers skip `x * 1` style passes)
+    bool is_literal_(Value v) const { return m_is_imm && m_imm == v; }
     bool valid() const { return m_is_imm || m_buf != nullptr; }
     bool is_immediate() const { return m_is_imm; }
 
