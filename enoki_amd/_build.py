@@ -80,7 +80,7 @@ def build_autodiff(force=False, verbose=True):
         return None
     os.makedirs(OBJ, exist_ok=True)
     lib = os.path.join(HERE, "libenoki-hip-autodiff.so")
-    if force or _newer(lib, [src] + _headers()):
+    if force or _newer(lib, [src, os.path.join(HERE, "src", "autodiff_impl.h")] + _headers()):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", f"-I{os.path.join(ROOT, 'include')}",
               src, "-o", lib, f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN"])
         if verbose:

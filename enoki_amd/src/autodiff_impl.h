@@ -509,8 +509,11 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
                     Value contribution = hsum_safe_mul(edge.weight, target.grad);
                     Detail::accumulate(source.grad, contribution);
                 } else if (source.grad.empty()) {
-                    // unit weight (add/sub/fmadd addend/...): g * 1 -- share the buffer, no kernel
-                    source.grad = detail::is_unit_weight(edge.weight) ? target.grad : safe_mul(edge.weight, target.grad);
+                    // unit weight (add/sub/fmadd addend/...) or unit gradient (the seed of backward(), passed on
+                    // through hsum): w * 1 and 1 * g -- share the other operand's buffer, no kernel
+                    source.grad = detail::is_unit_weight(edge.weight) ? target.grad
+                                : detail::is_unit_weight(target.grad) ? edge.weight
+                                                                      : safe_mul(edge.weight, target.grad);
                 } else {
                     source.grad = safe_fmadd(edge.weight, target.grad, source.grad);
                 }
@@ -563,7 +566,9 @@ template <typename Value> void Tape<Value>::forward(bool free_graph) {
                     if (target.size == 1 && (edge->weight.size() != 1 || src.grad.size() != 1)) {
                         Detail::accumulate(target.grad, hsum_safe_mul(edge->weight, src.grad));
                     } else if (target.grad.empty()) {
-                        target.grad = detail::is_unit_weight(edge->weight) ? src.grad : safe_mul(edge->weight, src.grad);
+                        target.grad = detail::is_unit_weight(edge->weight) ? src.grad
+                                    : detail::is_unit_weight(src.grad)     ? edge->weight
+                                                                           : safe_mul(edge->weight, src.grad);
                     } else {
                         target.grad = safe_fmadd(edge->weight, src.grad, target.grad);
                     }
