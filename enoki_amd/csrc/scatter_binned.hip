@@ -9,7 +9,7 @@
 //   1. count      every workgroup owns a contiguous chunk of the n elements and histograms its
 //                 indices by BUCKET (= index >> 14) in LDS                        reads  4 B/elt
 //   2. scan       per-bucket exclusive scan over the workgroups' counts + scan of the bucket totals
-//   3. partition  each workgroup re-reads its chunk in tiles of 4096 elements, sorts a tile by bucket
+//   3. partition  each workgroup re-reads its chunk in tiles of 8192 elements, sorts a tile by bucket
 //                 in LDS (so that a bucket's elements leave the CU as one coalesced run) and appends
 //                 (index, value) to the bucket's pair list                        reads 8, writes 8 B/elt
 //   4. accumulate S workgroups per bucket stream the bucket's pairs and ds_add them into a zeroed LDS
@@ -29,7 +29,7 @@ constexpr int kBinShift = 14;
 constexpr int kBins = 1 << kBinShift;      // bins per bucket (64 KiB of f32 / i32 in LDS)
 constexpr int kMaxBuckets = 256;
 constexpr int kThreads = 512;
-constexpr int kPerThread = 8;
+constexpr int kPerThread = 16;
 constexpr int kTile = kThreads * kPerThread;   // elements sorted per LDS pass of the partition
 
 template <typename I> __device__ __forceinline__ uint32_t index_u32(I i) { return (uint32_t) i; }
@@ -40,11 +40,12 @@ template <bool WithValue, typename I, typename T>
 __device__ __forceinline__ void load_tile(const I *__restrict__ index, const Arg<uint8_t> &mask, uint8_t sm,
                                           const Arg<T> &value, T sv, size_t base, size_t end, int vec_ok,
                                           uint32_t (&ix)[kPerThread], bool (&on)[kPerThread], T *val) {
-    static_assert(kPerThread == 8 && sizeof(I) == 4);
+    static_assert(kPerThread % 4 == 0 && sizeof(I) == 4);
+    constexpr int kRuns = kPerThread / 4;
     if (vec_ok && base + kTile <= end) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const size_t e = base + (size_t) h * (kTile / 2) + (size_t) threadIdx.x * 4;
+        for (int h = 0; h < kRuns; ++h) {
+            const size_t e = base + (size_t) h * (kTile / kRuns) + (size_t) threadIdx.x * 4;
             Pack<I, 4> pi = pack_load<I, 4, true>(index + e);
             Pack<uint8_t, 4> pm;
             if (mask.vec) pm = pack_load<uint8_t, 4, true>(mask.ptr + e);
