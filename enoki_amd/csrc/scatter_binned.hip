@@ -395,7 +395,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
                        mask, n, chunk, n_buckets, 0, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint32_t) + sizeof(T)));
 
-    int slices = std::max(1, (4 * c.num_cu + n_buckets - 1) / n_buckets);
+    int slices = std::max(1, (2 * c.num_cu + n_buckets - 1) / n_buckets);
     if (int rc = partials.alloc((size_t) slices * table_size * sizeof(T))) return rc;
     hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3((unsigned) (n_buckets * slices)), dim3(kThreads), lds_bytes,
                        c.stream, (T *) partials.ptr, table_size, (const uint32_t *) pairs_idx.ptr,
