@@ -40,6 +40,22 @@ template <typename Array> std::string array_repr(const Array &a) {
     return oss.str();
 }
 
+/// Make work queued on torch's current stream and on the library stream visible to each other.  When the
+/// library has adopted torch's stream (enoki_amd.dist.adopt_torch_stream) nothing needs to happen.
+inline void sync_with_torch() {
+    py::object sys_modules = py::module_::import("sys").attr("modules");
+    if (!sys_modules.contains("torch"))
+        return;
+    py::object cuda = py::module_::import("torch").attr("cuda");
+    if (!cuda.attr("is_initialized")().cast<bool>())
+        return;
+    uintptr_t torch_stream = cuda.attr("current_stream")().attr("cuda_stream").cast<uintptr_t>();
+    if (torch_stream == (uintptr_t) ek_hip_stream())
+        return;
+    cuda.attr("current_stream")().attr("synchronize")();
+    detail::hip_check(ek_hip_sync(), "hip_sync");
+}
+
 /// Bind one 1-D array type.  `Mask` / `UInt32` / `Int32` are the sibling types of the same module.
 template <typename Array> py::class_<Array> bind_array(py::module_ &m, const char *name) {
     using Scalar = scalar_t<Array>;
@@ -58,6 +74,39 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
       .def(py::init([](py::array_t<Store, py::array::c_style | py::array::forcecast> a) {
           return Array(Plain::copy(a.data(), (size_t) a.size()));
       }))
+      .def(py::init([](py::object o) {
+          // any object with __cuda_array_interface__ (a torch ROCm tensor, cupy, another module's array): one
+          // device-to-device copy, no host round trip (the reference goes through a scatter, common.h:1067-1161)
+          if (py::hasattr(o, "requires_grad") && py::hasattr(o, "detach") && o.attr("requires_grad").cast<bool>())
+              o = o.attr("detach")();          // torch refuses to export tensors that require grad
+          if (py::hasattr(o, "is_contiguous") && !o.attr("is_contiguous")().cast<bool>())
+              o = o.attr("contiguous")();
+          if (!py::hasattr(o, "__cuda_array_interface__"))
+              throw py::type_error("expected a scalar, a numpy array or an object with __cuda_array_interface__");
+          py::dict d = o.attr("__cuda_array_interface__");
+          std::string typestr = d["typestr"].cast<std::string>();
+          char kind = IsFloat ? 'f' : (IsMask ? 'b' : (std::is_unsigned_v<Scalar> ? 'u' : 'i'));
+          bool ok = typestr.size() == 3 && typestr[1] == kind && typestr[2] == char('0' + sizeof(Store));
+          if (IsMask && typestr.size() == 3 && typestr[1] == 'u' && typestr[2] == '1') ok = true;
+          if (!ok) throw py::type_error("__cuda_array_interface__: element type " + typestr + " does not match this array type");
+          py::tuple shape = d["shape"];
+          if (shape.size() > 1) throw py::type_error("__cuda_array_interface__: expected a 0-d or 1-d array");
+          size_t n = shape.size() == 0 ? 1 : shape[0].cast<size_t>();
+          if (d.contains("strides") && !d["strides"].is_none() && shape.size() == 1 && n > 1 &&
+              py::tuple(d["strides"])[0].cast<size_t>() != sizeof(Store))
+              throw py::type_error("__cuda_array_interface__: array is not contiguous");
+          uintptr_t ptr = py::tuple(d["data"])[0].cast<uintptr_t>();
+          sync_with_torch();
+          Plain r = empty<Plain>(n);
+          if (n) detail::hip_check(ek_hip_memcpy_device(r.data(), (const void *) ptr, n * sizeof(Store)), "copy from device object");
+          return Array(r);
+      }))
+      .def("torch", [](Array &a) {
+          // zero-copy torch view (the tensor keeps this object alive); the reference's .torch() copies
+          sync_with_torch();
+          py::object torch = py::module_::import("torch");
+          return torch.attr("as_tensor")(py::cast(a, py::return_value_policy::reference), "device"_a = "cuda");
+      })
       .def("__len__", [](const Array &a) { return a.size(); })
       .def("__repr__", [](const Array &a) { return array_repr(a); })
       .def("__getitem__", [](const Array &a, size_t i) {

@@ -1,0 +1,94 @@
+"""torch-ROCm interop: the ROCm port of the reference's tests/python/test_pytorch.py.
+Arrays are built from device tensors with one device-to-device copy (no host round trip) and exported with
+`.torch()` as zero-copy views through __cuda_array_interface__; torch is plumbing here, not the compute path."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def ek():
+    import enoki_amd.hip_autodiff as m
+    m.hip_init(0)
+    return m
+
+
+@pytest.fixture(scope="module")
+def ekc():
+    import enoki_amd.hip as m
+    return m
+
+
+def make_atan2(ek, ekc):
+    class EnokiAtan2(torch.autograd.Function):
+        """the PyTorch function example of the reference documentation (tests/python/test_pytorch.py:6-31)"""
+
+        @staticmethod
+        def forward(ctx, arg1, arg2):
+            ctx.in1 = ek.Float32(arg1)
+            ctx.in2 = ek.Float32(arg2)
+            ek.set_requires_gradient(ctx.in1, arg1.requires_grad)
+            ek.set_requires_gradient(ctx.in2, arg2.requires_grad)
+            ctx.out = ek.atan2(ctx.in1, ctx.in2)
+            out_torch = ek.detach(ctx.out).torch().clone()
+            ek.hip_malloc_trim()
+            return out_torch.reshape(arg1.shape)
+
+        @staticmethod
+        def backward(ctx, grad_out):
+            ek.set_gradient(ctx.out, ekc.Float32(grad_out))
+            ek.Float32.backward()
+            result = (ek.gradient(ctx.in1).torch().clone().reshape(grad_out.shape) if ek.requires_gradient(ctx.in1) else None,
+                      ek.gradient(ctx.in2).torch().clone().reshape(grad_out.shape) if ek.requires_gradient(ctx.in2) else None)
+            del ctx.out, ctx.in1, ctx.in2
+            ek.hip_malloc_trim()
+            return result
+
+    return EnokiAtan2.apply
+
+
+def test01_set_gradient(ek, ekc):
+    a = ek.Float32.full(42, 10)
+    ek.set_requires_gradient(a)
+    with pytest.raises(TypeError):
+        ek.set_gradient(a, ek.Float32.full(-1, 10))          # gradients are plain (non-differentiable) arrays
+    grad = ekc.Float32.full(-1, 10)
+    ek.set_gradient(a, grad)
+    assert np.allclose(grad.numpy(), ek.gradient(a).numpy())
+    ek.Float32.backward()
+
+
+def test02_array_to_torch(ek, ekc):
+    a = ekc.Float32.full(42, 10)
+    t = a.torch()
+    assert isinstance(t, torch.Tensor) and t.is_cuda and t.shape == (10,)
+    t += 8
+    assert np.allclose(t.cpu().numpy(), 50)
+    assert np.allclose(a.numpy(), 50)                        # zero-copy: the tensor aliases the array
+    x = torch.linspace(0, 1, 1000, device="cuda")
+    assert np.array_equal(ekc.Float32(x).numpy(), x.cpu().numpy())              # device -> device construction
+    assert np.array_equal(ekc.Float32(x[::2]).numpy(), x[::2].cpu().numpy())    # non-contiguous input
+    with pytest.raises(TypeError):
+        ekc.Float32(x.double())
+
+
+def test03_pytorch_function(ek, ekc):
+    enoki_atan2 = make_atan2(ek, ekc)
+    y = torch.tensor(1.0, device="cuda", requires_grad=True)
+    x = torch.tensor(2.0, device="cuda", requires_grad=True)
+    o = enoki_atan2(y, x)
+    o.backward()
+    assert np.allclose(y.grad.cpu(), 0.4) and np.allclose(x.grad.cpu(), -0.2)
+
+
+def test04_pytorch_function_vector(ek, ekc):
+    enoki_atan2 = make_atan2(ek, ekc)
+    y = torch.linspace(-2, 2, 1001, device="cuda", requires_grad=True)
+    x = torch.linspace(3, 1, 1001, device="cuda", requires_grad=True)
+    o = enoki_atan2(y, x)
+    o.sum().backward()
+    den = (x * x + y * y).detach()
+    assert torch.allclose(o, torch.atan2(y, x).detach(), atol=2e-6)
+    assert torch.allclose(y.grad, x.detach() / den, rtol=1e-5) and torch.allclose(x.grad, -y.detach() / den, rtol=1e-5, atol=1e-7)
