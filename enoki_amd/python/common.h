@@ -77,18 +77,21 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
       .def(py::init([](py::object o) {
           // any object with __cuda_array_interface__ (a torch ROCm tensor, cupy, another module's array): one
           // device-to-device copy, no host round trip (the reference goes through a scatter, common.h:1067-1161)
+          if (py::isinstance<Plain>(o))
+              throw py::reference_cast_error();     // our own plain array: the sharing constructor handles it (no copy)
           if (py::hasattr(o, "requires_grad") && py::hasattr(o, "detach") && o.attr("requires_grad").cast<bool>())
               o = o.attr("detach")();          // torch refuses to export tensors that require grad
           if (py::hasattr(o, "is_contiguous") && !o.attr("is_contiguous")().cast<bool>())
               o = o.attr("contiguous")();
+          // "not mine": let pybind11 try the remaining overloads (the converting constructors registered later)
           if (!py::hasattr(o, "__cuda_array_interface__"))
-              throw py::type_error("expected a scalar, a numpy array or an object with __cuda_array_interface__");
+              throw py::reference_cast_error();
           py::dict d = o.attr("__cuda_array_interface__");
           std::string typestr = d["typestr"].cast<std::string>();
           char kind = IsFloat ? 'f' : (IsMask ? 'b' : (std::is_unsigned_v<Scalar> ? 'u' : 'i'));
           bool ok = typestr.size() == 3 && typestr[1] == kind && typestr[2] == char('0' + sizeof(Store));
           if (IsMask && typestr.size() == 3 && typestr[1] == 'u' && typestr[2] == '1') ok = true;
-          if (!ok) throw py::type_error("__cuda_array_interface__: element type " + typestr + " does not match this array type");
+          if (!ok) throw py::reference_cast_error();      // other element type: a converting constructor may take it
           py::tuple shape = d["shape"];
           if (shape.size() > 1) throw py::type_error("__cuda_array_interface__: expected a 0-d or 1-d array");
           size_t n = shape.size() == 0 ? 1 : shape[0].cast<size_t>();

@@ -92,3 +92,11 @@ def test04_pytorch_function_vector(ek, ekc):
     den = (x * x + y * y).detach()
     assert torch.allclose(o, torch.atan2(y, x).detach(), atol=2e-6)
     assert torch.allclose(y.grad, x.detach() / den, rtol=1e-5) and torch.allclose(x.grad, -y.detach() / den, rtol=1e-5, atol=1e-7)
+
+
+def test05_own_arrays_are_shared_not_copied(ek, ekc):
+    """the __cuda_array_interface__ constructor must not intercept our own arrays: DiffArray(plain) shares the buffer"""
+    a = ekc.Float32.arange(1000)
+    d = ek.Float32(a)
+    assert ek.detach(d).data_ptr() == a.data_ptr()
+    assert np.array_equal(ekc.Float32(ekc.UInt32.arange(10)).numpy(), np.arange(10, dtype=np.float32))   # converting ctor still reachable
