@@ -246,6 +246,8 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
           .def("__invert__", [](const Array &a) { return Array(~a); })
           .def("__lshift__", [](const Array &a, const Array &b) { return a << b; })
           .def("__rshift__", [](const Array &a, const Array &b) { return a >> b; });
+        m.def("rol", [](const Array &a, const Array &k) { return rol(a, k); });
+        m.def("ror", [](const Array &a, const Array &k) { return ror(a, k); });
         m.def("popcnt", [](const Array &a) { return popcnt(a); });
         m.def("lzcnt", [](const Array &a) { return lzcnt(a); });
         m.def("tzcnt", [](const Array &a) { return tzcnt(a); });

@@ -219,6 +219,9 @@ ENOKI_HIP_ROUTE_UNARY(any, any)
 ENOKI_HIP_ROUTE_UNARY(count, count)
 
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline bool none(const T &a) { return !any(a); }
+template <typename T, typename M, enable_if_t<is_array_v<T>> = 0> inline auto extract(const T &a, const M &mask) {
+    return a.extract_(detail::as<mask_t<T>>(mask));
+}
 template <typename T, typename M, enable_if_t<is_array_v<T>> = 0> inline T compress(const T &a, const M &mask) {
     return a.compress_(detail::as<mask_t<T>>(mask));
 }
@@ -315,6 +318,41 @@ ENOKI_HIP_ROUTE_BITOP(operator^, xor)
 
 template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0>
 inline auto andnot(const T1 &a1, const T2 &a2) { return a1 & !a2; }
+
+/// Logical (zero-filling) right shift, also for signed element types
+template <typename E> inline E sr_logical(const E &a, const E &k) {
+    using S = scalar_t<E>;
+    if constexpr (std::is_signed_v<S>) {
+        using U = typename E::template ReplaceValue<std::make_unsigned_t<S>>;
+        const detail::reinterpret_flag flag{};
+        return E(U(a, flag) >> U(k, flag), flag);
+    } else {
+        return a >> k;
+    }
+}
+
+/// Rotations of integer arrays (array_router.h rol/ror; cuda.h composes them from shifts as well).  Shift
+/// counts >= the bit width give 0 in this backend, so a rotation by 0 is the identity.
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0> inline auto rol(const T1 &a, const T2 &k) {
+    using E = expr_t<T1, T2>;
+    using S = scalar_t<E>;
+    const E bits = E(S(sizeof(S) * 8)), kk = detail::as<E>(k) & E(S(sizeof(S) * 8 - 1));
+    return (detail::as<E>(a) << kk) | sr_logical(detail::as<E>(a), bits - kk);
+}
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0> inline auto ror(const T1 &a, const T2 &k) {
+    using E = expr_t<T1, T2>;
+    using S = scalar_t<E>;
+    const E bits = E(S(sizeof(S) * 8)), kk = detail::as<E>(k) & E(S(sizeof(S) * 8 - 1));
+    return sr_logical(detail::as<E>(a), kk) | (detail::as<E>(a) << (bits - kk));
+}
+
+/// floor / ceil with conversion to an integer array type (cuda.h:485-497)
+template <typename Target, typename T, enable_if_t<is_array_v<T>> = 0> inline Target floor2int(const T &a) {
+    return a.template floor2int_<Target>();
+}
+template <typename Target, typename T, enable_if_t<is_array_v<T>> = 0> inline Target ceil2int(const T &a) {
+    return a.template ceil2int_<Target>();
+}
 
 #define ENOKI_HIP_ROUTE_COMPOUND(op)                                                              \
     template <typename T1, typename T2, enable_if_t<is_array_v<T1>> = 0>                          \

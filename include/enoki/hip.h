@@ -529,6 +529,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return out;
     }
 
+    /// First entry whose mask bit is set (array_router.h extract(); synchronises).  Undefined for an empty mask.
+    Value extract_(const MaskType &mask) const {
+        if (size() <= 1) return coeff(0);
+        using UInt32 = HIPArray<uint32_t>;
+        UInt32 lane = UInt32::arange_(0, (ptrdiff_t) size(), 1);
+        uint32_t first = UInt32::select_(mask, lane, UInt32(~0u)).hmin_().coeff(0);
+        if (first == ~0u) throw std::runtime_error("extract_(): the mask is empty");
+        return coeff(first);
+    }
+
     /// One PCG32 draw as a single fused kernel (enoki/random.h; reference random.h:68-133): advances
     /// `state` where `mask` is set and returns the sample derived from the old state.  `kind` is an
     /// ek_pcg32_kind that must match Value (u32 / f32 / u64 / f64).

@@ -267,3 +267,18 @@ def test_float64_autodiff(ek, ekc):
     ek.backward(ek.hsum(ek.exp(g) * X))
     want = np.zeros(k); np.add.at(want, idx, np.exp(T[idx]) * x)
     assert np.allclose(ek.gradient(Td).numpy(), want, rtol=1e-11, atol=1e-12)
+
+
+def test_rotations(ekc):
+    rng = np.random.default_rng(12)
+    for dt, cls in ((np.uint32, ekc.UInt32), (np.int32, ekc.Int32), (np.uint64, ekc.UInt64)):
+        bits = np.dtype(dt).itemsize * 8
+        info = np.iinfo(dt)
+        a = rng.integers(info.min, info.max, 5003, dtype=dt, endpoint=True)
+        k = rng.integers(0, bits, 5003).astype(dt)
+        u = a.view(np.uint32 if bits == 32 else np.uint64); ku = k.astype(u.dtype)
+        want_l = ((u << ku) | (u >> ((bits - ku) % bits))) if True else None
+        want_l = np.where(ku == 0, u, (u << ku) | (u >> (np.array(bits, u.dtype) - ku)))
+        want_r = np.where(ku == 0, u, (u >> ku) | (u << (np.array(bits, u.dtype) - ku)))
+        assert np.array_equal(ekc.rol(cls(a), cls(k)).numpy().view(u.dtype), want_l), dt
+        assert np.array_equal(ekc.ror(cls(a), cls(k)).numpy().view(u.dtype), want_r), dt
