@@ -505,8 +505,14 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
             if (!has_grad) {
                 /* nothing to propagate */
             } else if (!edge.is_special()) {
-                if (source.size == 1 && (edge.weight.size() != 1 || target.grad.size() != 1)) {
+                if (source.size == 1 && (edge.weight.size() != 1 || target.grad.size() != 1 || target.size != 1)) {
+                    // vector target feeding a scalar source: the contribution is a horizontal sum over the
+                    // target's entries.  The reference materialises size-1 gradients to the node size first
+                    // (autodiff.cpp:851-853); here they stay broadcast, so when weight AND gradient are both
+                    // broadcasts the sum of target.size equal terms is formed as a product.
                     Value contribution = hsum_safe_mul(edge.weight, target.grad);
+                    if (edge.weight.size() == 1 && target.grad.size() == 1 && target.size != 1)
+                        contribution = contribution * Value(scalar_t<Value>(target.size));
                     Detail::accumulate(source.grad, contribution);
                 } else if (source.grad.empty()) {
                     // unit weight (add/sub/fmadd addend/...) or unit gradient (the seed of backward(), passed on
@@ -563,8 +569,11 @@ template <typename Value> void Tape<Value>::forward(bool free_graph) {
             Node &src = d->node(source_idx);
             if (!src.grad.empty()) {
                 if (!edge->is_special()) {
-                    if (target.size == 1 && (edge->weight.size() != 1 || src.grad.size() != 1)) {
-                        Detail::accumulate(target.grad, hsum_safe_mul(edge->weight, src.grad));
+                    if (target.size == 1 && (edge->weight.size() != 1 || src.grad.size() != 1 || src.size != 1)) {
+                        Value contribution = hsum_safe_mul(edge->weight, src.grad);
+                        if (edge->weight.size() == 1 && src.grad.size() == 1 && src.size != 1)   // see backward()
+                            contribution = contribution * Value(scalar_t<Value>(src.size));
+                        Detail::accumulate(target.grad, contribution);
                     } else if (target.grad.empty()) {
                         target.grad = detail::is_unit_weight(edge->weight) ? src.grad
                                     : detail::is_unit_weight(src.grad)     ? edge->weight

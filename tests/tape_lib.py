@@ -156,6 +156,12 @@ def suite(n=1000, k=37, seed=0):
     # AVX2 reference -> compared with a tolerance only
     P["div_rcp_rsqrt"] = Program([(a, 1), (pos, 1)], [("div", 0, 1), ("rcp", 1), ("rsqrt", 1), ("add", 2, 3),
                                                       ("add", 5, 4), ("hsum", 6)])
+    # broadcast gradients reaching a scalar node (reference tests test05_hsum_1_fwd, test33_bcast): the sum over the
+    # vector node's entries must be formed even when weight and gradient are both size-1 broadcasts
+    P["bcast_scalar_leaf"] = Program([(s, 1), (a, 0)], [("add", 1, 0), ("hsum", 2)])
+    P["bcast_scalar_leaf_mul"] = Program([(s, 1), (a, 1)], [("add", 1, 0), ("mul", 2, 1), ("addc", 3, 1.0), ("hsum", 4)])
+    P["fwd_hsum_of_hsum"] = Program([(a, 1)], [("hsum", 0), ("mul", 1, 0), ("hsum", 2)], mode="forward", fwd_leaf=0)
+    P["fwd_scalar_to_vector"] = Program([(s, 1), (a, 0)], [("mul", 0, 1), ("hsum", 2)], mode="forward", fwd_leaf=0)
     # second wave (array_math.h tan .. cbrt).  Vector outputs (seed = ones): the GPU tape must agree bit for bit with
     # the product tape over the CPU oracle; against the AVX2 reference only cbrt / pow are bit-comparable, every
     # other derivative contains rcp() or rsqrt() (class C)
@@ -176,5 +182,6 @@ CLASS_C_VALUES = {"sw_trig", "sw_hyp", "sw_sum"}   # the primal itself contains 
 ORDER_DEPENDENT_ON_GPU = {            # contain hsum / hprod / fp scatter_add: GPU summation order differs (class D)
     "cfg3a", "cfg3b", "cfg2_grad", "arith", "square_dup_edge", "sqrt_log", "cos_exp", "minmax_select", "fm_family",
     "hprod", "scalar_leaf", "scalar_chain", "gather_only", "permute_gather", "scatter_add", "scatter_add_leaf_target",
-    "scatter_perm", "reverse_psum", "fwd_cfg3a", "simplify_chain", "div_rcp_rsqrt", "sw_sum",
+    "scatter_perm", "reverse_psum", "fwd_cfg3a", "simplify_chain", "div_rcp_rsqrt", "sw_sum", "bcast_scalar_leaf",
+    "bcast_scalar_leaf_mul", "fwd_hsum_of_hsum", "fwd_scalar_to_vector",
 }
