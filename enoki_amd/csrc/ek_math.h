@@ -453,6 +453,187 @@ __device__ __forceinline__ double log_f64(double x) {
     return valid ? r : u2d(~0ull);
 }
 
+// ------------------------------------------------------------------------------------------------
+//  float64 branches of the second wave (array_math.h:405-441, 509-551, 591-600, 640-663, 950-951,
+//  1033-1041, 1160-1166, 1216-1225, 1270-1280, 1327-1337).  Rational CEPHES approximations; rcp()
+//  appears in tan/cot/sinh/cosh/tanh only (class C), the rest is bit-exact.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double estrin(double x, double c0, double c1, double c2, double c3, double c4) {
+    double x2 = x * x, x4 = x2 * x2;
+    return fma_(x2, fma_(x, c3, c2), fma_(x, c1, c0) + c4 * x4);
+}
+__device__ __forceinline__ double estrin(double x, double c0, double c1, double c2, double c3, double c4, double c5,
+                                         double c6) {
+    double x2 = x * x, x4 = x2 * x2;
+    return fma_(x4, fma_(x2, c6, fma_(x, c5, c4)), fma_(x2, fma_(x, c3, c2), fma_(x, c1, c0)));
+}
+__device__ __forceinline__ double copysign_f64(double mag, double sgn) {
+    return u2d((d2u(mag) & 0x7fffffffffffffffull) | (d2u(sgn) & 0x8000000000000000ull));
+}
+__device__ __forceinline__ double mulsign_f64(double v, double sgn) {
+    return u2d(d2u(v) ^ (d2u(sgn) & 0x8000000000000000ull));
+}
+__device__ __forceinline__ double frexp_f64(double x, double &e_out) {
+    uint64_t xi = d2u(x), eb = xi & 0x7ff0000000000000ull;
+    bool normal = (x != 0.0) && (eb != 0x7ff0000000000000ull);
+    e_out = (double) (normal ? (int64_t) (eb >> 52) - 0x3ff : 0);
+    return u2d(normal ? ((xi & ~0x7ff0000000000000ull) | 0x3fe0000000000000ull) : xi);
+}
+__device__ __forceinline__ double ldexp_f64(double x, double e) {
+    return x * u2d(((uint64_t) cvtt_i64(e) + 0x3ffull) << 52);
+}
+
+template <bool Tan> __device__ __forceinline__ double tancot_f64(double x) {
+    double xa = __builtin_fabs(x);
+    int64_t j = cvtt_i64(xa * 1.2732395447351626862);
+    j = (int64_t) (((uint64_t) j + 1ull) & ~1ull);
+    double y = (double) j;
+    double t = xa - y * 7.85398125648498535156e-1;
+    t = t - y * 3.77489470793079817668e-8;
+    t = t - y * 2.69515142907905952645e-15;
+    y = t;
+    double z = y * y;
+    if (xa == __builtin_inf()) z = u2d(~0ull);
+    double r = estrin(z, -1.79565251976484877988e7, 1.15351664838587416140e6, -1.30936939181383777646e4) /
+               estrin(z, -5.38695755929454629881e7, 2.50083801823357915839e7, -1.32089234440210967447e6,
+                      1.36812963470692954678e4, 1.0);
+    r = fma_(r, z * y, y);
+    bool recip = Tan ? (j & 2) != 0 : (j & 2) == 0;
+    if (xa < 1e-4) r = y;
+    if (recip) r = 1.0 / r;
+    uint64_t sign = ((uint64_t) j << 62) ^ d2u(x);
+    return u2d(d2u(r) ^ (sign & 0x8000000000000000ull));
+}
+
+__device__ __forceinline__ double asin_f64(double x) {
+    double xa = __builtin_fabs(x), x2 = x * x;
+    bool big = xa > 0.625;
+    // |x| > 0.625: asin(1 - t) = pi/2 - sqrt(2 t) (1 + R(t))
+    double zz = 1.0 - xa;
+    double p = estrin(zz, 2.853665548261061424989e1, -2.556901049652824852289e1, 6.968710824104713396794e0,
+                      -5.634242780008963776856e-1, 2.967721961301243206100e-3) /
+               estrin(zz, 3.424398657913078477438e2, -3.838770957603691357202e2, 1.470656354026814941758e2,
+                      -2.194779531642920639778e1, 1.0) * zz;
+    zz = __builtin_sqrt(zz + zz);
+    double zb = 0.78539816339744830962 - zz;
+    double r_big = zb - fma_(zz, p, -6.123233995736765886130e-17) + 0.78539816339744830962;
+    // otherwise a rational in x^2
+    double zs = estrin(x2, -8.198089802484824371615e0, 1.956261983317594739197e1, -1.626247967210700244449e1,
+                       5.444622390564711410273e0, -6.019598008014123785661e-1, 4.253011369004428248960e-3) /
+                estrin(x2, -4.918853881490881290097e1, 1.395105614657485689735e2, -1.471791292232726029859e2,
+                       7.049610280856842141659e1, -1.474091372988853791896e1, 1.0) * x2;
+    zs = fma_(xa, zs, xa);
+    if (xa < 1e-8) zs = xa;
+    return copysign_f64(big ? r_big : zs, x);
+}
+
+__device__ __forceinline__ double acos_f64(double x) {
+    bool mask = x > 0.5;
+    double y = asin_f64(mask ? __builtin_sqrt(fma_(-0.5, x, 0.5)) : x);
+    return mask ? y + y : 0.78539816339744830962 - y + 6.123233995736765886130e-17 + 0.78539816339744830962;
+}
+
+__device__ __forceinline__ double atan2_f64(double y, double x) {
+    double abs_x = __builtin_fabs(x), abs_y = __builtin_fabs(y);
+    double min_val = abs_x < abs_y ? abs_x : abs_y, max_val = abs_y > abs_x ? abs_y : abs_x;
+    double scale = 1.0 / max_val, scaled_min = min_val * scale, z = scaled_min * scaled_min;
+    double t = estrin(z, 9.9999999999999999419e-1, 2.50554429737833465113e0, 2.28289058385464073556e0,
+                      9.20960512187107069075e-1, 1.59189681028889623410e-1, 9.35911604785115940726e-3,
+                      8.07005540507283419124e-5) /
+               estrin(z, 1.00000000000000000000e0, 2.83887763071166519407e0, 3.02918312742541450749e0,
+                      1.50576983803701596773e0, 3.49719171130492192607e-1, 3.29968942624402204199e-2,
+                      8.26619391703564168942e-4);
+    t = t * scaled_min;
+    if (abs_y > abs_x) t = 1.57079632679489661923 - t;
+    if (x < 0.0) t = 3.14159265358979323846 - t;
+    double r = y < 0.0 ? u2d(d2u(t) ^ 0x8000000000000000ull) : t;
+    return max_val != 0.0 ? r : 0.0;
+}
+
+__device__ __forceinline__ double cbrt_f64(double x) {
+    const double CBRT2 = 1.25992104989487316477, CBRT4 = 1.58740105196819947475, THIRD = 1.0 / 3.0;
+    double xa = __builtin_fabs(x), xe;
+    double xm = frexp_f64(xa, xe);
+    xe += 1.0;
+    double xea = __builtin_fabs(xe), xea1 = __builtin_floor(xea * THIRD), rem = fma_(-xea1, 3.0, xea);
+    xm = estrin(xm, 0.40238979564544752126924, 1.1399983354717293273738, -0.95438224771509446525043,
+                0.54664601366395524503440, -0.13466110473359520655053);
+    double f1 = xe >= 0.0 ? CBRT2 : 1.0 / CBRT2, f2 = xe >= 0.0 ? CBRT4 : 1.0 / CBRT4;
+    double f = rem == 1.0 ? f1 : f2;
+    if (rem != 0.0) xm *= f;
+    double r = ldexp_f64(xm, mulsign_f64(xea1, xe));
+    r = mulsign_f64(r, x);
+    r -= (r - (x / (r * r))) * THIRD;
+    r -= (r - (x / (r * r))) * THIRD;
+    return __builtin_fabs(x) < __builtin_inf() ? r : x;
+}
+
+__device__ __forceinline__ double sinh_small_f64(double x) {
+    double x2 = x * x;
+    return fma_(estrin(x2, -3.51754964808151394800e5, -1.15614435765005216044e4, -1.63725857525983828727e2,
+                       -7.89474443963537015605e-1) /
+                estrin(x2, -2.11052978884890840399e6, 3.61578279834431989373e4, -2.77711081420602794433e2, 1.0),
+                x2 * x, x);
+}
+__device__ __forceinline__ double sinh_f64(double x) {
+    double e0 = exp_f64(x), e1 = 1.0 / e0;
+    return __builtin_fabs(x) > 1.0 ? (e0 - e1) * 0.5 : sinh_small_f64(x);
+}
+__device__ __forceinline__ double cosh_f64(double x) {
+    double e0 = exp_f64(x), e1 = 1.0 / e0;
+    return (e0 + e1) * 0.5;
+}
+__device__ __forceinline__ void sincosh_f64(double x, double &s, double &c) {
+    double e0 = exp_f64(x), e1 = 1.0 / e0;
+    s = __builtin_fabs(x) > 1.0 ? (e0 - e1) * 0.5 : sinh_small_f64(x);
+    c = 0.5 * (e0 + e1);
+}
+__device__ __forceinline__ double tanh_f64(double x) {
+    double x2 = x * x;
+    double r_small = estrin(x2, -1.61468768441708447952e3, -9.92877231001918586564e1, -9.64399179425052238628e-1) /
+                     estrin(x2, 4.84406305325125486048e3, 2.23548839060100448583e3, 1.12811678491632931402e2, 1.0);
+    r_small = fma_(r_small, x2 * x, x);
+    double e = exp_f64(x + x), e2 = 1.0 / (e + 1.0);
+    double r_big = 1.0 - (e2 + e2);
+    return __builtin_fabs(x) >= 0.625 ? r_big : r_small;
+}
+__device__ __forceinline__ double asinh_f64(double x) {
+    double x2 = x * x, xa = __builtin_fabs(x);
+    bool big = xa >= 0.533, huge = xa >= 1e20;
+    double r_small = estrin(x2, -5.56682227230859640450e0, -9.09030533308377316566e0, -4.37390226194356683570e0,
+                            -5.91750212056387121207e-1, -4.33231683752342103572e-3) /
+                     estrin(x2, 3.34009336338516356383e1, 6.95722521337257608734e1, 4.86042483805291788324e1,
+                            1.28757002067426453537e1, 1.0);
+    r_small = fma_(r_small, x2 * x, x);
+    double r_big = log_f64(xa + (huge ? 0.0 : __builtin_sqrt(x2 + 1.0)));
+    if (huge) r_big += 0.693147180559945309417;
+    return big ? copysign_f64(r_big, x) : r_small;
+}
+__device__ __forceinline__ double acosh_f64(double x) {
+    double x1 = x - 1.0;
+    bool big = x1 >= 0.49, huge = x1 >= 1e10;
+    double r_small = estrin(x1, 1.10855947270161294369E5, 1.08102874834699867335E5, 3.43989375926195455866E4,
+                            3.94726656571334401102E3, 1.18801130533544501356E2) /
+                     estrin(x1, 7.83869920495893927727E4, 8.29725251988426222434E4, 2.97683430363289370382E4,
+                            4.15352677227719831579E3, 1.86145380837903397292E2, 1.0);
+    r_small *= __builtin_sqrt(x1);
+    if (x1 < 0.0) r_small = u2d(~0ull);
+    double r_big = log_f64(x + (huge ? 0.0 : __builtin_sqrt(fma_(x, x, -1.0))));
+    if (huge) r_big += 0.693147180559945309417;
+    return big ? r_big : r_small;
+}
+__device__ __forceinline__ double atanh_f64(double x) {
+    double xa = __builtin_fabs(x), x2 = x * x;
+    double r_small = estrin(x2, -3.09092539379866942570e1, 6.54566728676544377376e1, -4.61252884198732692637e1,
+                            1.20426861384072379242e1, -8.54074331929669305196e-1) /
+                     estrin(x2, -9.27277618139601130017e1, 2.52006675691344555838e2, -2.49839401325893582852e2,
+                            1.08938092147140262656e2, -1.95638849376911654834e1, 1.0);
+    r_small = fma_(r_small, x2 * x, x);
+    double r_big = log_f64((1.0 + xa) / (1.0 - xa)) * 0.5;
+    return xa >= 0.5 ? copysign_f64(r_big, x) : r_small;
+}
+__device__ __forceinline__ double pow_f64(double x, double y) { return exp_f64(log_f64(x) * y); }
+
 // safe_mul / safe_fmadd: CPU branch of src/autodiff/autodiff.cpp:1191-1221
 // (w == 0 || g == 0) ? 0 : w*g     resp.    (w == 0 || g == 0) ? acc : fma(w, g, acc)
 template <typename T> __device__ __forceinline__ T safe_mul(T w, T g) {

@@ -50,9 +50,9 @@ template <int Op, typename T> constexpr bool unary_supported() {
         case EK_NOT: return !is_fp<T>;
         case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_FLOOR: case EK_CEIL: case EK_ROUND: case EK_TRUNC:
         case EK_SIGN: return is_fp<T>;
-        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG: return is_fp<T>;
+        case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
         case EK_TAN: case EK_COT: case EK_ASIN: case EK_ACOS: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_TANH:
-        case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return std::is_same_v<T, float>;
+        case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return is_fp<T>;
         case EK_POPCNT: case EK_LZCNT: case EK_TZCNT: return is_int<T>;
         case EK_COPY: return true;
         default: return false;
@@ -105,29 +105,29 @@ template <int Op, typename T> struct UnaryOp {
         } else if constexpr (Op == EK_LOG) {
             if constexpr (sizeof(T) == 4) return dev::log_f32(x); else return dev::log_f64(x);
         } else if constexpr (Op == EK_TAN) {
-            return dev::tancot_f32<true>(x);
+            if constexpr (sizeof(T) == 4) return dev::tancot_f32<true>(x); else return dev::tancot_f64<true>(x);
         } else if constexpr (Op == EK_COT) {
-            return dev::tancot_f32<false>(x);
+            if constexpr (sizeof(T) == 4) return dev::tancot_f32<false>(x); else return dev::tancot_f64<false>(x);
         } else if constexpr (Op == EK_ASIN) {
-            return dev::asin_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::asin_f32(x); else return dev::asin_f64(x);
         } else if constexpr (Op == EK_ACOS) {
-            return dev::acos_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::acos_f32(x); else return dev::acos_f64(x);
         } else if constexpr (Op == EK_ATAN) {
-            return dev::atan2_f32(x, 1.0f);     // array_math.h:666-668
+            if constexpr (sizeof(T) == 4) return dev::atan2_f32(x, 1.0f); else return dev::atan2_f64(x, 1.0);   // array_math.h:666-668
         } else if constexpr (Op == EK_SINH) {
-            return dev::sinh_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::sinh_f32(x); else return dev::sinh_f64(x);
         } else if constexpr (Op == EK_COSH) {
-            return dev::cosh_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::cosh_f32(x); else return dev::cosh_f64(x);
         } else if constexpr (Op == EK_TANH) {
-            return dev::tanh_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::tanh_f32(x); else return dev::tanh_f64(x);
         } else if constexpr (Op == EK_ASINH) {
-            return dev::asinh_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::asinh_f32(x); else return dev::asinh_f64(x);
         } else if constexpr (Op == EK_ACOSH) {
-            return dev::acosh_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::acosh_f32(x); else return dev::acosh_f64(x);
         } else if constexpr (Op == EK_ATANH) {
-            return dev::atanh_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::atanh_f32(x); else return dev::atanh_f64(x);
         } else if constexpr (Op == EK_CBRT) {
-            return dev::cbrt_f32(x);
+            if constexpr (sizeof(T) == 4) return dev::cbrt_f32(x); else return dev::cbrt_f64(x);
         } else if constexpr (Op == EK_POPCNT) {
             if constexpr (sizeof(T) == 4) return (T) __popc((uint32_t) x); else return (T) __popcll((uint64_t) x);
         } else if constexpr (Op == EK_LZCNT) {
@@ -147,6 +147,7 @@ struct SinCosOp {
 
 struct SinCoshOp {
     static __device__ __forceinline__ void apply(float x, float &s, float &c) { dev::sincosh_f32(x, s, c); }
+    static __device__ __forceinline__ void apply(double x, double &s, double &c) { dev::sincosh_f64(x, s, c); }
 };
 
 template <int Op, typename T> int unary_launch(void *out, const ek_operand *a, size_t n) {
@@ -183,7 +184,7 @@ template <int Op, typename T> constexpr bool binary_supported() {
         case EK_MOD: case EK_MULHI: case EK_SL: case EK_SR: return is_int<T>;
         case EK_AND: case EK_OR: case EK_XOR: return true;   // fp: bitwise on the representation
         case EK_SAFE_MUL: case EK_FMOD: return is_fp<T>;
-        case EK_ATAN2: case EK_POW: case EK_LDEXP: return std::is_same_v<T, float>;
+        case EK_ATAN2: case EK_POW: case EK_LDEXP: return is_fp<T>;
         default: return false;
     }
 }
@@ -226,11 +227,11 @@ template <int Op, typename T> struct BinaryOp {
         } else if constexpr (Op == EK_SAFE_MUL) {
             return dev::safe_mul(x, y);
         } else if constexpr (Op == EK_ATAN2) {
-            return dev::atan2_f32(x, y);
+            if constexpr (sizeof(T) == 4) return dev::atan2_f32(x, y); else return dev::atan2_f64(x, y);
         } else if constexpr (Op == EK_POW) {
-            return dev::pow_f32(x, y);
+            if constexpr (sizeof(T) == 4) return dev::pow_f32(x, y); else return dev::pow_f64(x, y);
         } else if constexpr (Op == EK_LDEXP) {
-            return dev::ldexp_f32(x, y);
+            if constexpr (sizeof(T) == 4) return dev::ldexp_f32(x, y); else return dev::ldexp_f64(x, y);
         } else if constexpr (Op == EK_FMOD) {
             if constexpr (sizeof(T) == 4) return dev::fmod_f32(x, y);
             else return __builtin_fma(-__builtin_trunc(x / y), y, x);
@@ -451,7 +452,12 @@ int ek_hip_sincos(int type, void *out, void *out_cos, const ek_operand *a, size_
 int ek_hip_sincosh(int type, void *out, void *out_cosh, const ek_operand *a, size_t n) {
     EK_PROLOGUE("ek_hip_sincosh()")
     if (!out_cosh) return fail(EK_ERR_INVALID, "ek_hip_sincosh(): null output pointer");
-    if (type != EK_F32) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sincosh(): only f32 is implemented");
+    if (type == EK_F64) {
+        Arg<double> ad;
+        if (int rc = make_arg<double>(a, n, ad, "ek_hip_sincosh")) return rc;
+        return launch_map1x2<SinCoshOp>("sincosh", (double *) out, (double *) out_cosh, n, ad);
+    }
+    if (type != EK_F32) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sincosh(): floating point types only");
     Arg<float> aa;
     if (int rc = make_arg<float>(a, n, aa, "ek_hip_sincosh")) return rc;
     return launch_map1x2<SinCoshOp>("sincosh", (float *) out, (float *) out_cosh, n, aa);

@@ -209,7 +209,7 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("sincos", [](const Array &a) { return sincos(a); });
         m.def("exp", [](const Array &a) { return exp(a); });
         m.def("log", [](const Array &a) { return log(a); });
-        if constexpr (std::is_same_v<Scalar, float>) {
+        {
             m.def("tan", [](const Array &a) { return tan(a); });
             m.def("cot", [](const Array &a) { return cot(a); });
             m.def("csc", [](const Array &a) { return csc(a); });

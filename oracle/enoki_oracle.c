@@ -412,6 +412,171 @@ static double log_f64(double x) {                                            /* 
 }
 
 /* ------------------------------------------------------------------------------------ */
+/*  float64 branches of the second wave (array_math.h:405-441, 509-551, 591-600, 640-663, */
+/*  950-951, 1033-1041, 1160-1166, 1216-1225, 1270-1280, 1327-1337)                       */
+/* ------------------------------------------------------------------------------------ */
+static inline double D4(double x, const double *c) {
+    double x2 = x * x, x4 = x2 * x2;
+    return fma(x2, fma(x, c[3], c[2]), fma(x, c[1], c[0]) + c[4] * x4);
+}
+static inline double D6(double x, const double *c) {
+    double x2 = x * x, x4 = x2 * x2;
+    return fma(x4, fma(x2, c[6], fma(x, c[5], c[4])), fma(x2, fma(x, c[3], c[2]), fma(x, c[1], c[0])));
+}
+static inline double copysign_pd(double m, double s) { return u2d((d2u(m) & 0x7fffffffffffffffull) | (d2u(s) & 0x8000000000000000ull)); }
+static inline double mulsign_pd(double v, double s) { return u2d(d2u(v) ^ (d2u(s) & 0x8000000000000000ull)); }
+static inline double frexp_f64(double x, double *e) {
+    uint64_t xi = d2u(x), eb = xi & 0x7ff0000000000000ull;
+    int normal = (x != 0.0) && (eb != 0x7ff0000000000000ull);
+    *e = (double) (normal ? (int64_t) (eb >> 52) - 0x3ff : 0);
+    return u2d(normal ? ((xi & ~0x7ff0000000000000ull) | 0x3fe0000000000000ull) : xi);
+}
+static inline double ldexp_f64(double x, double e) { return x * u2d(((uint64_t) cvtt_f64_i64(e) + 0x3ffull) << 52); }
+
+static double tancot_f64(double x, int want_tan) {                           /* :369-442 */
+    static const double pn[3] = { -1.79565251976484877988e7, 1.15351664838587416140e6, -1.30936939181383777646e4 };
+    static const double pd[5] = { -5.38695755929454629881e7, 2.50083801823357915839e7, -1.32089234440210967447e6,
+                                  1.36812963470692954678e4, 1.0 };
+    double xa = fabs(x);
+    int64_t j = cvtt_f64_i64(xa * 1.2732395447351626862);
+    j = (int64_t) (((uint64_t) j + 1ull) & ~1ull);
+    double y = (double) j;
+    double t = xa - y * 7.85398125648498535156e-1;
+    t = t - y * 3.77489470793079817668e-8;
+    t = t - y * 2.69515142907905952645e-15;
+    y = t;
+    double z = y * y;
+    if (xa == INFINITY) z = u2d(~0ull);
+    double r = D2(z, pn) / D4(z, pd);                                        /* :422-429 */
+    r = fma(r, z * y, y);
+    int recip = want_tan ? (j & 2) != 0 : (j & 2) == 0;
+    if (xa < 1e-4) r = y;
+    if (recip) r = 1.0 / r;                                                  /* rcp(): class C */
+    uint64_t sign = ((uint64_t) j << 62) ^ d2u(x);
+    return u2d(d2u(r) ^ (sign & 0x8000000000000000ull));
+}
+
+static double asin_f64(double x) {                                           /* :509-552 */
+    static const double bn[5] = { 2.853665548261061424989e1, -2.556901049652824852289e1, 6.968710824104713396794e0,
+                                  -5.634242780008963776856e-1, 2.967721961301243206100e-3 };
+    static const double bd[5] = { 3.424398657913078477438e2, -3.838770957603691357202e2, 1.470656354026814941758e2,
+                                  -2.194779531642920639778e1, 1.0 };
+    static const double sn[6] = { -8.198089802484824371615e0, 1.956261983317594739197e1, -1.626247967210700244449e1,
+                                  5.444622390564711410273e0, -6.019598008014123785661e-1, 4.253011369004428248960e-3 };
+    static const double sd[6] = { -4.918853881490881290097e1, 1.395105614657485689735e2, -1.471791292232726029859e2,
+                                  7.049610280856842141659e1, -1.474091372988853791896e1, 1.0 };
+    const double pio4 = 0.78539816339744830962, more_bits = 6.123233995736765886130e-17;
+    double xa = fabs(x), x2 = x * x;
+    int big = xa > 0.625;
+    double zz = 1.0 - xa;
+    double p = D4(zz, bn) / D4(zz, bd) * zz;
+    zz = sqrt(zz + zz);
+    double z = pio4 - zz;
+    double r_big = z - fma(zz, p, -more_bits) + pio4;                        /* :531 */
+    double zs = D5(x2, sn) / D5(x2, sd) * x2;
+    zs = fma(xa, zs, xa);
+    if (xa < 1e-8) zs = xa;
+    return copysign_pd(big ? r_big : zs, x);
+}
+
+static double acos_f64(double x) {                                           /* :591-600 */
+    const double pio4 = 0.78539816339744830962, more_bits = 6.123233995736765886130e-17;
+    int mask = x > 0.5;
+    double y = asin_f64(mask ? sqrt(fma(-0.5, x, 0.5)) : x);
+    return mask ? y + y : pio4 - y + more_bits + pio4;
+}
+
+static double atan2_f64(double y, double x) {                                /* :603-664 */
+    static const double tn[7] = { 9.9999999999999999419e-1, 2.50554429737833465113e0, 2.28289058385464073556e0,
+                                  9.20960512187107069075e-1, 1.59189681028889623410e-1, 9.35911604785115940726e-3,
+                                  8.07005540507283419124e-5 };
+    static const double td[7] = { 1.00000000000000000000e0, 2.83887763071166519407e0, 3.02918312742541450749e0,
+                                  1.50576983803701596773e0, 3.49719171130492192607e-1, 3.29968942624402204199e-2,
+                                  8.26619391703564168942e-4 };
+    double abs_x = fabs(x), abs_y = fabs(y);
+    double min_val = abs_x < abs_y ? abs_x : abs_y, max_val = abs_y > abs_x ? abs_y : abs_x;
+    double scale = 1.0 / max_val, scaled_min = min_val * scale, z = scaled_min * scaled_min;
+    double t = D6(z, tn) / D6(z, td) * scaled_min;
+    if (abs_y > abs_x) t = M_PI_2 - t;
+    if (x < 0.0) t = M_PI - t;
+    double r = y < 0.0 ? u2d(d2u(t) ^ 0x8000000000000000ull) : t;
+    return max_val != 0.0 ? r : 0.0;
+}
+
+static double cbrt_f64(double x) {                                           /* :900-954 */
+    static const double c[5] = { 0.40238979564544752126924, 1.1399983354717293273738, -0.95438224771509446525043,
+                                 0.54664601366395524503440, -0.13466110473359520655053 };
+    const double CBRT2 = 1.25992104989487316477, CBRT4 = 1.58740105196819947475, THIRD = 1.0 / 3.0;
+    double xa = fabs(x), xe;
+    double xm = frexp_f64(xa, &xe);
+    xe += 1.0;
+    double xea = fabs(xe), xea1 = floor(xea * THIRD), rem = fma(-xea1, 3.0, xea);
+    xm = D4(xm, c);
+    double f1 = xe >= 0.0 ? CBRT2 : 1.0 / CBRT2, f2 = xe >= 0.0 ? CBRT4 : 1.0 / CBRT4;
+    double f = rem == 1.0 ? f1 : f2;
+    if (rem != 0.0) xm *= f;
+    double r = ldexp_f64(xm, mulsign_pd(xea1, xe));
+    r = mulsign_pd(r, x);
+    r -= (r - (x / (r * r))) * THIRD;
+    r -= (r - (x / (r * r))) * THIRD;                                        /* :950-951 */
+    return fabs(x) < INFINITY ? r : x;
+}
+
+static double sinh_small_f64(double x) {                                     /* :1033-1041 */
+    static const double n_[4] = { -3.51754964808151394800e5, -1.15614435765005216044e4, -1.63725857525983828727e2,
+                                  -7.89474443963537015605e-1 };
+    static const double d_[4] = { -2.11052978884890840399e6, 3.61578279834431989373e4, -2.77711081420602794433e2, 1.0 };
+    double x2 = x * x;
+    return fma(D3(x2, n_) / D3(x2, d_), x2 * x, x);
+}
+static double sinh_f64(double x) { double e0 = exp_f64(x), e1 = 1.0 / e0; return fabs(x) > 1.0 ? (e0 - e1) * 0.5 : sinh_small_f64(x); }
+static double cosh_f64(double x) { double e0 = exp_f64(x), e1 = 1.0 / e0; return (e0 + e1) * 0.5; }
+static double tanh_f64(double x) {                                           /* :1160-1178 */
+    static const double n_[3] = { -1.61468768441708447952e3, -9.92877231001918586564e1, -9.64399179425052238628e-1 };
+    static const double d_[4] = { 4.84406305325125486048e3, 2.23548839060100448583e3, 1.12811678491632931402e2, 1.0 };
+    double x2 = x * x;
+    double r_small = fma(D2(x2, n_) / D3(x2, d_), x2 * x, x);
+    double e = exp_f64(x + x), e2 = 1.0 / (e + 1.0);
+    double r_big = 1.0 - (e2 + e2);
+    return fabs(x) >= 0.625 ? r_big : r_small;
+}
+static double asinh_f64(double x) {                                          /* :1202-1236 */
+    static const double n_[5] = { -5.56682227230859640450e0, -9.09030533308377316566e0, -4.37390226194356683570e0,
+                                  -5.91750212056387121207e-1, -4.33231683752342103572e-3 };
+    static const double d_[5] = { 3.34009336338516356383e1, 6.95722521337257608734e1, 4.86042483805291788324e1,
+                                  1.28757002067426453537e1, 1.0 };
+    double x2 = x * x, xa = fabs(x);
+    int big = xa >= 0.533, huge = xa >= 1e20;
+    double r_small = fma(D4(x2, n_) / D4(x2, d_), x2 * x, x);
+    double r_big = log_f64(xa + (huge ? 0.0 : sqrt(x2 + 1.0)));
+    if (huge) r_big += M_LN2;
+    return big ? copysign_pd(r_big, x) : r_small;
+}
+static double acosh_f64(double x) {                                          /* :1256-1292 */
+    static const double n_[5] = { 1.10855947270161294369E5, 1.08102874834699867335E5, 3.43989375926195455866E4,
+                                  3.94726656571334401102E3, 1.18801130533544501356E2 };
+    static const double d_[6] = { 7.83869920495893927727E4, 8.29725251988426222434E4, 2.97683430363289370382E4,
+                                  4.15352677227719831579E3, 1.86145380837903397292E2, 1.0 };
+    double x1 = x - 1.0;
+    int big = x1 >= 0.49, huge = x1 >= 1e10;
+    double r_small = D4(x1, n_) / D5(x1, d_) * sqrt(x1);
+    if (x1 < 0.0) r_small = u2d(~0ull);
+    double r_big = log_f64(x + (huge ? 0.0 : sqrt(fma(x, x, -1.0))));
+    if (huge) r_big += M_LN2;
+    return big ? r_big : r_small;
+}
+static double atanh_f64(double x) {                                          /* :1313-1347 */
+    static const double n_[5] = { -3.09092539379866942570e1, 6.54566728676544377376e1, -4.61252884198732692637e1,
+                                  1.20426861384072379242e1, -8.54074331929669305196e-1 };
+    static const double d_[6] = { -9.27277618139601130017e1, 2.52006675691344555838e2, -2.49839401325893582852e2,
+                                  1.08938092147140262656e2, -1.95638849376911654834e1, 1.0 };
+    double xa = fabs(x), x2 = x * x;
+    double r_small = fma(D4(x2, n_) / D5(x2, d_), x2 * x, x);
+    double r_big = log_f64((1.0 + xa) / (1.0 - xa)) * 0.5;
+    return xa >= 0.5 ? copysign_pd(r_big, x) : r_small;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /*  generic dispatch helpers                                                              */
 /* ------------------------------------------------------------------------------------ */
 
@@ -469,6 +634,18 @@ static int unary_f64(const char *op, const double *a, double *o, size_t n) {
     if (is(op, "trunc")) LOOP(trunc(x));
     if (is(op, "exp"))   LOOP(exp_f64(x));
     if (is(op, "log"))   LOOP(log_f64(x));
+    if (is(op, "tan"))   LOOP(tancot_f64(x, 1));
+    if (is(op, "cot"))   LOOP(tancot_f64(x, 0));
+    if (is(op, "asin"))  LOOP(asin_f64(x));
+    if (is(op, "acos"))  LOOP(acos_f64(x));
+    if (is(op, "atan"))  LOOP(atan2_f64(x, 1.0));
+    if (is(op, "sinh"))  LOOP(sinh_f64(x));
+    if (is(op, "cosh"))  LOOP(cosh_f64(x));
+    if (is(op, "tanh"))  LOOP(tanh_f64(x));
+    if (is(op, "asinh")) LOOP(asinh_f64(x));
+    if (is(op, "acosh")) LOOP(acosh_f64(x));
+    if (is(op, "atanh")) LOOP(atanh_f64(x));
+    if (is(op, "cbrt"))  LOOP(cbrt_f64(x));
 #undef LOOP
     if (is(op, "sin")) { for (size_t i = 0; i < n; ++i) sincos_f64(a[i], &o[i], NULL); return 0; }
     if (is(op, "cos")) { for (size_t i = 0; i < n; ++i) sincos_f64(a[i], NULL, &o[i]); return 0; }
@@ -555,6 +732,11 @@ static int binary_f64(const char *op, const double *a, const double *b, double *
     if (is(op, "div")) LOOP(x / y);
     if (is(op, "min")) LOOP(y < x ? y : x);
     if (is(op, "max")) LOOP(y > x ? y : x);
+    if (is(op, "atan2")) LOOP(atan2_f64(x, y));
+    if (is(op, "pow"))   LOOP(exp_f64(log_f64(x) * y));
+    if (is(op, "fmod"))  LOOP(fma(-trunc(x / y), y, x));
+    if (is(op, "ldexp")) LOOP(ldexp_f64(x, y));
+    if (is(op, "safe_mul")) LOOP((x == 0.0 || y == 0.0) ? 0.0 : x * y);
 #undef LOOP
     return -1;
 }

@@ -60,6 +60,17 @@ d = f64_inputs(n, seed=201, scale=20.0, limit=3e9); dpos = np.abs(f64_inputs(n, 
 ops64 = {"in_d": d, "in_pos": dpos, "sin": R.unary("sin", d), "cos": R.unary("cos", d), "exp": R.unary("exp", d),
          "log": R.unary("log", d), "log_pos": R.unary("log", dpos)}
 ops64["sincos_s"], ops64["sincos_c"] = R.sincos(d)
+dunit = f64_inputs(n, seed=203, scale=0.6)
+ops64["in_unit"] = dunit
+for op in ["tan", "cot", "atan", "sinh", "cosh", "tanh", "asinh", "cbrt"]:
+    ops64[f"sw_{op}"] = R.unary(op, d)
+for op in ["asin", "acos", "atanh"]:
+    ops64[f"sw_{op}"] = R.unary(op, dunit)
+ops64["sw_acosh"] = R.unary("acosh", dpos)
+d2 = f64_inputs(n, seed=204, scale=20.0, limit=3e9)[::-1].copy()
+ops64["in_d2"] = d2
+for op in ["atan2", "pow", "fmod"]:
+    ops64[f"sw_{op}"] = R.binary(op, d, d2)
 np.savez_compressed(os.path.join(HERE, "elementwise_f64.npz"), **ops64)
 
 # ---- PCG32 (include/enoki/random.h) draw script, see oracle/ref_driver.cpp:ref_pcg32 -------------------

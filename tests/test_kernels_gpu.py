@@ -85,6 +85,26 @@ def test_f64_transcendentals_bit_exact(capi, oracle, scale):
         assert bits_equal(capi.unary(op, up(capi, z["in_d"])).numpy(), z[op]), op
 
 
+@pytest.mark.parametrize("scale", [0.3, 1.0, 30.0, 3000.0])
+def test_f64_second_wave_bit_exact(capi, oracle, scale):
+    """float64 tan .. cbrt, atan2, pow, fmod, ldexp, sincosh: bit-exact vs the oracle and vs vectors from the reference"""
+    a = f64_inputs(100003, seed=61, scale=scale, limit=3e9); b = f64_inputs(100003, seed=62, scale=scale, limit=3e9)[::-1].copy()
+    for op in ["tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "cbrt"]:
+        assert bits_equal(capi.unary(op, up(capi, a)).numpy(), oracle.unary(op, a)), op
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(capi.binary(op, up(capi, a), up(capi, b)).numpy(), oracle.binary(op, a, b)), op
+    e = np.clip(np.trunc(b), -500, 500)
+    assert bits_equal(capi.binary("ldexp", up(capi, a), up(capi, e)).numpy(), oracle.binary("ldexp", a, e))
+    s, c = capi.sincosh(up(capi, a))
+    assert bits_equal(s.numpy(), oracle.unary("sinh", a)) and bits_equal(c.numpy(), oracle.unary("cosh", a))
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "elementwise_f64.npz"))
+    for op in ["tan", "cot", "atan", "sinh", "cosh", "tanh", "asinh", "cbrt"]:
+        assert bits_equal(capi.unary(op, up(capi, z["in_d"])).numpy(), z[f"sw_{op}"]), op
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(capi.binary(op, up(capi, z["in_d"]), up(capi, z["in_d2"])).numpy(), z[f"sw_{op}"]), op
+
+
 @pytest.mark.parametrize("n", SIZES)
 def test_unary_sizes_and_tails(capi, oracle, n):
     a = f32_inputs(n, seed=n, specials=False)

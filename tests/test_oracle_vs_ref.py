@@ -57,6 +57,21 @@ def test_f64_transcendentals_bit_exact(scale):
     assert np.abs(P.unary("log", x) - np.log(x)).max() < 2e-15 and np.abs(P.unary("sin", x) - np.sin(x)).max() < 3e-16
 
 
+@needs_ref
+@pytest.mark.parametrize("scale", [0.3, 1.0, 30.0, 3000.0])
+def test_f64_second_wave_bit_exact(scale):
+    """double branches of tan .. cbrt, atan2, pow, fmod, ldexp: all bit-exact -- AVX2 has no rcppd, so even the
+    functions that call rcp() divide exactly in the reference build"""
+    R = ol.ref()
+    a = f64_inputs(100003, 41, scale, limit=3e9); b = f64_inputs(100003, 42, scale, limit=3e9)[::-1].copy()
+    for op in ["tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh", "acosh", "atanh", "cbrt"]:
+        assert bits_equal(P.unary(op, a), R.unary(op, a)), op
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(P.binary(op, a, b), R.binary(op, a, b)), op
+    e = np.clip(np.trunc(b), -500, 500)
+    assert bits_equal(P.binary("ldexp", a, e), R.binary("ldexp", a, e))
+
+
 CLASS_A2 = ["asin", "acos", "atan", "asinh", "acosh", "atanh", "cbrt"]   # no rcp() inside: bit-exact
 CLASS_C2 = {"tan": 8, "cot": 8, "sinh": 8, "cosh": 8, "tanh": 16}        # rcp() inside: ulp bound port vs reference
 
@@ -242,6 +257,13 @@ def test_golden_f64():
     assert bits_equal(P.unary("log", z["in_pos"]), z["log_pos"])
     s_, c_ = P.sincos(d)
     assert bits_equal(s_, z["sincos_s"]) and bits_equal(c_, z["sincos_c"])
+    for op in ["tan", "cot", "atan", "sinh", "cosh", "tanh", "asinh", "cbrt"]:
+        assert bits_equal(P.unary(op, d), z[f"sw_{op}"]), op
+    for op in ["asin", "acos", "atanh"]:
+        assert bits_equal(P.unary(op, z["in_unit"]), z[f"sw_{op}"]), op
+    assert bits_equal(P.unary("acosh", z["in_pos"]), z["sw_acosh"])
+    for op in ["atan2", "pow", "fmod"]:
+        assert bits_equal(P.binary(op, d, z["in_d2"]), z[f"sw_{op}"]), op
 
 
 def test_golden_integer():

@@ -282,3 +282,14 @@ def test_rotations(ekc):
         want_r = np.where(ku == 0, u, (u >> ku) | (u << (np.array(bits, u.dtype) - ku)))
         assert np.array_equal(ekc.rol(cls(a), cls(k)).numpy().view(u.dtype), want_l), dt
         assert np.array_equal(ekc.ror(cls(a), cls(k)).numpy().view(u.dtype), want_r), dt
+
+
+def test_float64_second_wave_and_autodiff(ek, ekc):
+    a = np.random.default_rng(14).uniform(-0.9, 0.9, 5003)
+    x = ekc.Float64(a)
+    for name, f in {"tan": np.tan, "asin": np.arcsin, "atan": np.arctan, "sinh": np.sinh, "tanh": np.tanh,
+                    "asinh": np.arcsinh, "atanh": np.arctanh, "cbrt": np.cbrt}.items():
+        assert np.allclose(getattr(ekc, name)(x).numpy(), f(a), rtol=1e-14, atol=1e-15), name
+    xd = ek.Float64(x); ek.set_requires_gradient(xd)
+    ek.backward(ek.hsum(ek.atan(xd) + ek.tanh(xd)))
+    assert np.allclose(ek.gradient(xd).numpy(), 1 / (1 + a * a) + 1 / np.cosh(a) ** 2, rtol=1e-13)
