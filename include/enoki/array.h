@@ -394,11 +394,31 @@ template <typename T, enable_if_t<is_array_v<T>> = 0> inline T mulsign(const T &
 //  Initialization, shape
 // ---------------------------------------------------------------------------------------------
 
+/// Structure-of-arrays support for user types; specialised by ENOKI_STRUCT_SUPPORT (see the end of this file)
+template <typename T, typename = int> struct struct_support { static constexpr bool Defined = false; };
+template <typename T> constexpr bool is_struct_v = struct_support<std::decay_t<T>>::Defined;
+
 template <typename T> inline T zero(size_t size = 1) {
-    if constexpr (is_array_v<T>) return T::zero_(size); else return T(0);
+    if constexpr (is_struct_v<T>) {
+        T r;
+        struct_support<T>::apply(r, [&](auto &f) { f = zero<std::decay_t<decltype(f)>>(size); });
+        return r;
+    } else if constexpr (is_array_v<T>) {
+        return T::zero_(size);
+    } else {
+        return T(0);
+    }
 }
 template <typename T> inline T empty(size_t size = 1) {
-    if constexpr (is_array_v<T>) return T::empty_(size); else return T();
+    if constexpr (is_struct_v<T>) {
+        T r;
+        struct_support<T>::apply(r, [&](auto &f) { f = empty<std::decay_t<decltype(f)>>(size); });
+        return r;
+    } else if constexpr (is_array_v<T>) {
+        return T::empty_(size);
+    } else {
+        return T();
+    }
 }
 template <typename T> inline T full(const scalar_t<T> &value, size_t size = 1) {
     if constexpr (is_array_v<T>) return T::full_(value, size); else return T(value);
@@ -413,12 +433,21 @@ template <typename T> inline T linspace(scalar_t<T> min, scalar_t<T> max, size_t
 
 /// Number of "slices" (dynamic entries) of an array; 1 for scalars
 template <typename T> inline size_t slices(const T &a) {
-    if constexpr (is_array_v<T>) return a.slices_(); else return 1;
+    if constexpr (is_struct_v<T>) {
+        size_t result = 0;
+        struct_support<T>::apply(a, [&](const auto &f) { size_t n = slices(f); if (n > result) result = n; });
+        return result;
+    } else if constexpr (is_array_v<T>) {
+        return a.slices_();
+    } else {
+        return 1;
+    }
 }
 
 /// Broadcast a size-1 dynamic array to `size` entries / resize
 template <typename T> inline void set_slices(T &a, size_t size) {
-    if constexpr (is_array_v<T>) a.set_slices_(size);
+    if constexpr (is_struct_v<T>) struct_support<T>::apply(a, [&](auto &f) { set_slices(f, size); });
+    else if constexpr (is_array_v<T>) a.set_slices_(size);
 }
 
 template <typename Target, typename Source> inline Target reinterpret_array(const Source &src) {
@@ -637,15 +666,136 @@ inline Array<T, 2> meshgrid(const T &x, const T &y) {
     return Array<T, 2>(gather<T>(x, xi), gather<T>(y, yi));
 }
 
-/// Structure-of-arrays helpers for user types, mirroring ENOKI_STRUCT (array_macro.h:216-359): member-wise
-/// constructors so that `Ray<Vector3fC>(o, d)` works for any vector type
+// ---- variadic field lists (up to 24 fields): statement-wise and comma-separated application of a macro ----
+#define ENOKI_HIP_FE_1(M, a) M(a)
+#define ENOKI_HIP_FE_2(M, a, ...) M(a) ENOKI_HIP_FE_1(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_3(M, a, ...) M(a) ENOKI_HIP_FE_2(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_4(M, a, ...) M(a) ENOKI_HIP_FE_3(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_5(M, a, ...) M(a) ENOKI_HIP_FE_4(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_6(M, a, ...) M(a) ENOKI_HIP_FE_5(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_7(M, a, ...) M(a) ENOKI_HIP_FE_6(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_8(M, a, ...) M(a) ENOKI_HIP_FE_7(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_9(M, a, ...) M(a) ENOKI_HIP_FE_8(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_10(M, a, ...) M(a) ENOKI_HIP_FE_9(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_11(M, a, ...) M(a) ENOKI_HIP_FE_10(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_12(M, a, ...) M(a) ENOKI_HIP_FE_11(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_13(M, a, ...) M(a) ENOKI_HIP_FE_12(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_14(M, a, ...) M(a) ENOKI_HIP_FE_13(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_15(M, a, ...) M(a) ENOKI_HIP_FE_14(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_16(M, a, ...) M(a) ENOKI_HIP_FE_15(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_17(M, a, ...) M(a) ENOKI_HIP_FE_16(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_18(M, a, ...) M(a) ENOKI_HIP_FE_17(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_19(M, a, ...) M(a) ENOKI_HIP_FE_18(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_20(M, a, ...) M(a) ENOKI_HIP_FE_19(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_21(M, a, ...) M(a) ENOKI_HIP_FE_20(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_22(M, a, ...) M(a) ENOKI_HIP_FE_21(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_23(M, a, ...) M(a) ENOKI_HIP_FE_22(M, __VA_ARGS__)
+#define ENOKI_HIP_FE_24(M, a, ...) M(a) ENOKI_HIP_FE_23(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_1(M, a) M(a)
+#define ENOKI_HIP_FEC_2(M, a, ...) M(a), ENOKI_HIP_FEC_1(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_3(M, a, ...) M(a), ENOKI_HIP_FEC_2(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_4(M, a, ...) M(a), ENOKI_HIP_FEC_3(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_5(M, a, ...) M(a), ENOKI_HIP_FEC_4(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_6(M, a, ...) M(a), ENOKI_HIP_FEC_5(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_7(M, a, ...) M(a), ENOKI_HIP_FEC_6(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_8(M, a, ...) M(a), ENOKI_HIP_FEC_7(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_9(M, a, ...) M(a), ENOKI_HIP_FEC_8(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_10(M, a, ...) M(a), ENOKI_HIP_FEC_9(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_11(M, a, ...) M(a), ENOKI_HIP_FEC_10(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_12(M, a, ...) M(a), ENOKI_HIP_FEC_11(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_13(M, a, ...) M(a), ENOKI_HIP_FEC_12(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_14(M, a, ...) M(a), ENOKI_HIP_FEC_13(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_15(M, a, ...) M(a), ENOKI_HIP_FEC_14(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_16(M, a, ...) M(a), ENOKI_HIP_FEC_15(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_17(M, a, ...) M(a), ENOKI_HIP_FEC_16(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_18(M, a, ...) M(a), ENOKI_HIP_FEC_17(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_19(M, a, ...) M(a), ENOKI_HIP_FEC_18(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_20(M, a, ...) M(a), ENOKI_HIP_FEC_19(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_21(M, a, ...) M(a), ENOKI_HIP_FEC_20(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_22(M, a, ...) M(a), ENOKI_HIP_FEC_21(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_23(M, a, ...) M(a), ENOKI_HIP_FEC_22(M, __VA_ARGS__)
+#define ENOKI_HIP_FEC_24(M, a, ...) M(a), ENOKI_HIP_FEC_23(M, __VA_ARGS__)
+#define ENOKI_HIP_PICK(_1, _2, _3, _4, _5, _6, _7, _8, _9, _10, _11, _12, _13, _14, _15, _16, _17, _18, _19, _20, _21, _22, _23, _24, NAME, ...) NAME
+#define ENOKI_HIP_FOR_EACH(M, ...) ENOKI_HIP_PICK(__VA_ARGS__, ENOKI_HIP_FE_24, ENOKI_HIP_FE_23, ENOKI_HIP_FE_22, ENOKI_HIP_FE_21, ENOKI_HIP_FE_20, ENOKI_HIP_FE_19, ENOKI_HIP_FE_18, ENOKI_HIP_FE_17, ENOKI_HIP_FE_16, ENOKI_HIP_FE_15, ENOKI_HIP_FE_14, ENOKI_HIP_FE_13, ENOKI_HIP_FE_12, ENOKI_HIP_FE_11, ENOKI_HIP_FE_10, ENOKI_HIP_FE_9, ENOKI_HIP_FE_8, ENOKI_HIP_FE_7, ENOKI_HIP_FE_6, ENOKI_HIP_FE_5, ENOKI_HIP_FE_4, ENOKI_HIP_FE_3, ENOKI_HIP_FE_2, ENOKI_HIP_FE_1)(M, __VA_ARGS__)
+#define ENOKI_HIP_FOR_EACH_COMMA(M, ...) ENOKI_HIP_PICK(__VA_ARGS__, ENOKI_HIP_FEC_24, ENOKI_HIP_FEC_23, ENOKI_HIP_FEC_22, ENOKI_HIP_FEC_21, ENOKI_HIP_FEC_20, ENOKI_HIP_FEC_19, ENOKI_HIP_FEC_18, ENOKI_HIP_FEC_17, ENOKI_HIP_FEC_16, ENOKI_HIP_FEC_15, ENOKI_HIP_FEC_14, ENOKI_HIP_FEC_13, ENOKI_HIP_FEC_12, ENOKI_HIP_FEC_11, ENOKI_HIP_FEC_10, ENOKI_HIP_FEC_9, ENOKI_HIP_FEC_8, ENOKI_HIP_FEC_7, ENOKI_HIP_FEC_6, ENOKI_HIP_FEC_5, ENOKI_HIP_FEC_4, ENOKI_HIP_FEC_3, ENOKI_HIP_FEC_2, ENOKI_HIP_FEC_1)(M, __VA_ARGS__)
+#define ENOKI_HIP_FIRST(a, ...) a
+#define ENOKI_HIP_CAT_(a, b) a##b
+#define ENOKI_HIP_CAT(a, b) ENOKI_HIP_CAT_(a, b)
+
+/// Structure-of-arrays support for user types (array_macro.h:216-359, array_struct.h:125-430): a class template whose
+/// fields are arrays declares them once with ENOKI_STRUCT (inside the class: field-wise and converting constructors /
+/// assignment) and ENOKI_STRUCT_SUPPORT (at global scope: lets zero / empty / slices / set_slices / gather / scatter /
+/// scatter_add / select operate on the whole structure field by field).
+#define ENOKI_HIP_S_TPL(f)      typename T_##f
+#define ENOKI_HIP_S_DECL(f)     T_##f &&f##_
+#define ENOKI_HIP_S_INIT(f)     f(std::forward<T_##f>(f##_))
+#define ENOKI_HIP_S_COPY(f)     f(value.f)
+#define ENOKI_HIP_S_ASSIGN(f)   f = value.f;
+#define ENOKI_HIP_S_VISIT1(f)   fn(v.f);
+#define ENOKI_HIP_S_VISIT2(f)   fn(v.f, w.f);
+#define ENOKI_HIP_S_VISIT3(f)   fn(v.f, w.f, u.f);
+
 #define ENOKI_STRUCT(Struct, ...)                                                                 \
     Struct() = default;                                                                           \
-    Struct(const Struct &) = default;                                                             \
-    Struct(Struct &&) = default;                                                                  \
-    Struct &operator=(const Struct &) = default;                                                  \
-    Struct &operator=(Struct &&) = default;
-#define ENOKI_STRUCT_SUPPORT(Struct, ...)
+    template <ENOKI_HIP_FOR_EACH_COMMA(ENOKI_HIP_S_TPL, __VA_ARGS__),                             \
+              std::enable_if_t<!std::is_base_of_v<Struct, std::decay_t<                           \
+                  ENOKI_HIP_CAT(T_, ENOKI_HIP_FIRST(__VA_ARGS__))>>, int> = 0>                    \
+    Struct(ENOKI_HIP_FOR_EACH_COMMA(ENOKI_HIP_S_DECL, __VA_ARGS__))                               \
+        : ENOKI_HIP_FOR_EACH_COMMA(ENOKI_HIP_S_INIT, __VA_ARGS__) { }                             \
+    template <typename... Args_> Struct(const Struct<Args_...> &value)                            \
+        : ENOKI_HIP_FOR_EACH_COMMA(ENOKI_HIP_S_COPY, __VA_ARGS__) { }                             \
+    template <typename... Args_> Struct &operator=(const Struct<Args_...> &value) {               \
+        ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_ASSIGN, __VA_ARGS__)                                       \
+        return *this;                                                                             \
+    }
+
+#define ENOKI_STRUCT_SUPPORT(Struct, ...)                                                         \
+    namespace enoki {                                                                             \
+    template <typename... Args_> struct struct_support<Struct<Args_...>> {                        \
+        static constexpr bool Defined = true;                                                     \
+        using Value = Struct<Args_...>;                                                           \
+        template <typename F> static void apply(Value &v, F &&fn) {                               \
+            ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_VISIT1, __VA_ARGS__)                                   \
+        }                                                                                         \
+        template <typename F> static void apply(const Value &v, F &&fn) {                         \
+            ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_VISIT1, __VA_ARGS__)                                   \
+        }                                                                                         \
+        template <typename V2, typename F> static void apply2(Value &v, const V2 &w, F &&fn) {    \
+            ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_VISIT2, __VA_ARGS__)                                   \
+        }                                                                                         \
+        template <typename V2, typename V3, typename F>                                           \
+        static void apply3(Value &v, const V2 &w, const V3 &u, F &&fn) {                          \
+            ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_VISIT3, __VA_ARGS__)                                   \
+        }                                                                                         \
+    };                                                                                            \
+    }
+
+
+// Field-wise versions of the array helpers for ENOKI_STRUCT types
+template <typename T, size_t Stride = 0, bool Packed = true, bool IsPermute = false, typename Index,
+          typename Mask = mask_t<Index>, enable_if_t<is_struct_v<T>> = 0>
+inline T gather(const T &source, const Index &index, const Mask &mask = true) {
+    T r;
+    struct_support<T>::apply2(r, source, [&](auto &dst, const auto &src) {
+        dst = gather<std::decay_t<decltype(dst)>, 0, true, IsPermute>(src, index, mask);
+    });
+    return r;
+}
+template <size_t Stride = 0, bool Packed = true, bool IsPermute = false, typename T, typename Index,
+          typename Mask = mask_t<Index>, enable_if_t<is_struct_v<T>> = 0>
+inline void scatter(T &target, const T &value, const Index &index, const Mask &mask = true) {
+    struct_support<T>::apply2(target, value, [&](auto &dst, const auto &src) { scatter<0, true, IsPermute>(dst, src, index, mask); });
+}
+template <size_t Stride = 0, bool Packed = true, bool IsPermute = false, typename T, typename Index,
+          typename Mask = mask_t<Index>, enable_if_t<is_struct_v<T>> = 0>
+inline void scatter_add(T &target, const T &value, const Index &index, const Mask &mask = true) {
+    struct_support<T>::apply2(target, value, [&](auto &dst, const auto &src) { scatter_add<0, true, IsPermute>(dst, src, index, mask); });
+}
+template <typename M, typename T, enable_if_t<is_struct_v<T>> = 0> inline T select(const M &mask, const T &t, const T &f) {
+    T r;
+    struct_support<T>::apply3(r, t, f, [&](auto &dst, const auto &a, const auto &b) { dst = select(mask, a, b); });
+    return r;
+}
 
 // ---------------------------------------------------------------------------------------------
 //  Autodiff helpers that are no-ops for non-differentiable types (autodiff.h:1414-1500)

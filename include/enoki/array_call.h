@@ -146,7 +146,7 @@ namespace detail {
 
     /// Arguments that are arrays travel through the group's permutation; scalars and size-1 arrays pass through
     template <typename T, typename Perm> inline auto gather_argument(const T &v, const Perm &perm) {
-        if constexpr (is_array_v<T>) {
+        if constexpr (is_array_v<T> || is_struct_v<T>) {      // arrays, nested arrays and ENOKI_STRUCT types
             if (slices(v) <= 1)
                 return T(v);
             return gather<T, 0, true, true>(v, perm);

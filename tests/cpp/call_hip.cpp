@@ -116,3 +116,67 @@ int hip_call_test(const uint8_t *which, const float *x_, const float *t_, const 
         return -3;
     }
 }
+
+// ---- ENOKI_STRUCT types as arguments / results of vectorised calls, and struct-wise gather / scatter / select -------
+template <typename Value_> struct Hit {
+    using Value = Value_;
+    using Vector3 = Array<Value_, 3>;
+    Vector3 p;
+    Value t;
+    mask_t<Value_> valid;
+    ENOKI_STRUCT(Hit, p, t, valid)
+};
+ENOKI_STRUCT_SUPPORT(Hit, p, t, valid)
+
+using HitC = Hit<FloatC>;
+
+struct Mover {
+    virtual ~Mover() = default;
+    virtual HitC advance(const HitC &h, const FloatC &dt) const = 0;
+};
+struct Forward : Mover {
+    HitC advance(const HitC &h, const FloatC &dt) const override { return HitC(h.p + Vector3fC(dt, 0.f, 0.f), h.t + dt, h.valid); }
+};
+struct Flip : Mover {
+    HitC advance(const HitC &h, const FloatC &dt) const override { return HitC(-h.p, h.t * dt, !h.valid); }
+};
+
+ENOKI_CALL_SUPPORT_BEGIN(Mover)
+ENOKI_CALL_SUPPORT_METHOD(advance)
+ENOKI_CALL_SUPPORT_END(Mover)
+
+/// outputs: px, py, pz, t (n floats each), valid (n bytes); then struct-wise gather(reverse permutation) -> gx, gt
+extern "C" __attribute__((visibility("default")))
+int hip_struct_test(const uint8_t *which, const float *x_, const float *dt_, size_t n, float *px, float *py, float *pz,
+                    float *t_out, uint8_t *valid_out, float *gx, float *gt, uint64_t *zero_slices) {
+    try {
+        Forward fwd; Flip flip;
+        Mover *table[2] = { &fwd, &flip };
+        std::vector<Mover *> host(n);
+        for (size_t i = 0; i < n; ++i) host[i] = which[i] < 2 ? table[which[i]] : nullptr;
+        HIPArray<Mover *> movers = HIPArray<Mover *>::copy(host.data(), n);
+        FloatC x = FloatC::copy(x_, n), dt = FloatC::copy(dt_, n);
+        HitC h(Vector3fC(x, x * 2.f, 1.f), x + 1.f, x > 0.f);
+        HitC r = movers->advance(h, dt);
+        to_host(r.p.x(), px, n); to_host(r.p.y(), py, n); to_host(r.p.z(), pz, n); to_host(r.t, t_out, n);
+        auto vm = r.valid.to_host();
+        for (size_t i = 0; i < n; ++i) valid_out[i] = vm.size() == 1 ? vm[0] : vm[i];
+
+        UInt32C rev = UInt32C(uint32_t(n - 1)) - arange<UInt32C>(n);
+        HitC g = gather<HitC>(r, rev);                        // struct-wise gather
+        to_host(g.p.x(), gx, n); to_host(g.t, gt, n);
+        HitC z = zero<HitC>(n);                               // struct-wise zero / slices / scatter / select
+        zero_slices[0] = slices(z);
+        scatter(z, g, rev);
+        HitC sel = select(x > 0.f, z, h);
+        zero_slices[1] = slices(sel);
+        auto a = sel.t.to_host(), b = r.t.to_host(), c = h.t.to_host();
+        auto xm = x.to_host();
+        for (size_t i = 0; i < n; ++i)
+            if (a[i] != (xm[i] > 0.f ? b[i] : c[i])) return -5;
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hip_struct_test: %s\n", e.what());
+        return -3;
+    }
+}

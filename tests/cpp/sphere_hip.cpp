@@ -15,7 +15,6 @@ template <typename Vector_> struct Ray {
     using Vector = Vector_;
     using Value = value_t<Vector>;
     Vector o, d;
-    Ray(const Vector &o, const Vector &d) : o(o), d(d) { }
     Vector operator()(const Value &t) const { return o + t * d; }
     ENOKI_STRUCT(Ray, o, d)
 };

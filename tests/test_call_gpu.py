@@ -92,3 +92,30 @@ def test_single_instance_shortcut(oracle):
     assert bits_equal(o["eval"], ev) and bits_equal(o["eval_masked"], evm) and bits_equal(o["off"], off)
     assert bits_equal(o["id"], ident) and bits_equal(o["d"], d)
     assert int(o["groups"][0]) == 1 and int(o["groups"][2]) == n and o["touch"][0] == n
+
+
+def test_struct_arguments_and_structwise_memory_ops():
+    """ENOKI_STRUCT / ENOKI_STRUCT_SUPPORT (array_macro.h:216-359): a struct of arrays as argument and result of a
+    vectorised call, plus struct-wise gather / scatter / zero / slices / select"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libcall_hip.so"))
+    n = 10007
+    which = (hash_u32(np.arange(n, dtype=np.uint64), 31) % np.uint32(3)).astype(np.uint8)
+    which[which == 2] = 255
+    x = uniform_pm1(n, 32) * np.float32(4); dt = uniform_pm1(n, 33)
+    f32 = np.float32
+    o = {k: np.empty(n, np.float32) for k in ("px", "py", "pz", "t", "gx", "gt")}
+    valid = np.empty(n, np.uint8); zs = np.zeros(2, np.uint64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.hip_struct_test(p(which), p(x), p(dt), ctypes.c_size_t(n), p(o["px"]), p(o["py"]), p(o["pz"]), p(o["t"]), p(valid),
+                             p(o["gx"]), p(o["gt"]), p(zs))
+    assert rc == 0, rc
+    fwd, flip = which == 0, which == 1
+    px = np.where(fwd, x + dt, np.where(flip, -x, f32(0))).astype(f32)
+    py = np.where(fwd, x * f32(2) + f32(0), np.where(flip, -(x * f32(2)), f32(0))).astype(f32)
+    pz = np.where(fwd, f32(1), np.where(flip, f32(-1), f32(0))).astype(f32)
+    t = np.where(fwd, (x + f32(1)) + dt, np.where(flip, (x + f32(1)) * dt, f32(0))).astype(f32)
+    v = np.where(fwd, x > 0, np.where(flip, ~(x > 0), False))
+    assert bits_equal(o["px"], px) and bits_equal(o["py"], py) and bits_equal(o["pz"], pz) and bits_equal(o["t"], t)
+    assert np.array_equal(valid != 0, v)
+    assert bits_equal(o["gx"], px[::-1].copy()) and bits_equal(o["gt"], t[::-1].copy())
+    assert zs[0] == n and zs[1] == n
