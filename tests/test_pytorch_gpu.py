@@ -100,3 +100,26 @@ def test05_own_arrays_are_shared_not_copied(ek, ekc):
     d = ek.Float32(a)
     assert ek.detach(d).data_ptr() == a.data_ptr()
     assert np.array_equal(ekc.Float32(ekc.UInt32.arange(10)).numpy(), np.arange(10, dtype=np.float32))   # converting ctor still reachable
+
+
+def test06_enoki_namespace():
+    """`import enoki as ek` with the reference's spelling (FloatC / FloatD aliases, type-dispatched free functions):
+    the documentation example of tests/python/test_pytorch.py runs unchanged up to the module name"""
+    import enoki as ek2
+    a = ek2.FloatD.full(42, 10)
+    ek2.set_requires_gradient(a)
+    with pytest.raises(TypeError):
+        ek2.set_gradient(a, ek2.FloatD.full(-1, 10))
+    ek2.set_gradient(a, ek2.FloatC.full(-1, 10))
+    ek2.FloatD.backward()
+    y = torch.tensor([1.0, 0.5], device="cuda"); x = torch.tensor([2.0, 3.0], device="cuda")
+    yd, xd = ek2.FloatD(y), ek2.FloatD(x)
+    ek2.set_requires_gradient(yd); ek2.set_requires_gradient(xd)
+    out = ek2.atan2(yd, xd)                                 # differentiable overload
+    ek2.backward(ek2.hsum(out))
+    den = (x * x + y * y).cpu().numpy()
+    assert np.allclose(ek2.gradient(yd).numpy(), x.cpu().numpy() / den, rtol=1e-5)
+    assert np.allclose(ek2.atan2(ek2.FloatC(y), ek2.FloatC(x)).numpy(), np.arctan2(y.cpu().numpy(), x.cpu().numpy()), rtol=2e-6)
+    import enoki.cuda_autodiff as m
+    assert m is ek2.hip_autodiff
+    ek2.cuda_malloc_trim()
