@@ -185,3 +185,40 @@ ORDER_DEPENDENT_ON_GPU = {            # contain hsum / hprod / fp scatter_add: G
     "scatter_perm", "reverse_psum", "fwd_cfg3a", "simplify_chain", "div_rcp_rsqrt", "sw_sum", "bcast_scalar_leaf",
     "bcast_scalar_leaf_mul", "fwd_hsum_of_hsum", "fwd_scalar_to_vector",
 }
+
+
+# ---------------------------------------------------------------------------------------------------
+#  Random purely-vertical programs (vector output, seed = ones): every op is class A, so the product tape must agree
+#  BIT FOR BIT with the reference build -- on the CPU oracle arrays and on the GPU.
+# ---------------------------------------------------------------------------------------------------
+def random_program(seed, n=257, n_ops=14, mode="backward"):
+    rng = np.random.default_rng(1000 + seed)
+    ins = [(rng.uniform(-1, 1, n).astype(np.float32), 1), (rng.uniform(-1, 1, n).astype(np.float32), 1),
+           (rng.uniform(-1, 1, n).astype(np.float32), int(rng.integers(0, 2))), (np.array([rng.uniform(0.5, 1.5)], np.float32), 1)]
+    n_in = len(ins)
+    ops = []
+    unary = ["neg", "abs", "sin", "cos", "exp", "mulc", "addc", "sqrt_safe"]
+    binary = ["add", "sub", "mul", "min", "max"]
+    ternary = ["fmadd", "fmsub", "fnmadd", "fnmsub", "select_gt0"]
+    for _ in range(n_ops):
+        n_reg = n_in + len(ops)
+        pick = lambda: int(rng.integers(0, n_reg))
+        kind = rng.integers(0, 3)
+        if kind == 0:
+            name = unary[int(rng.integers(0, len(unary)))]
+            if name == "mulc":
+                ops.append(("mulc", pick(), float(np.float32(rng.uniform(-2, 2)))))
+            elif name == "addc":
+                ops.append(("addc", pick(), float(np.float32(rng.uniform(-1, 1)))))
+            elif name == "sqrt_safe":                      # sqrt(|r| + 0.5): two helper ops + sqrt
+                ops.append(("abs", pick())); ops.append(("addc", n_in + len(ops) - 1, 0.5)); ops.append(("sqrt", n_in + len(ops) - 1))
+            else:
+                ops.append((name, pick()))
+        elif kind == 1:
+            ops.append((binary[int(rng.integers(0, len(binary)))], pick(), pick()))
+        else:
+            ops.append((ternary[int(rng.integers(0, len(ternary)))], pick(), pick(), pick()))
+    # tie the last registers together so that most of the graph is live, and keep the output a vector
+    last = n_in + len(ops) - 1
+    ops.append(("add", last, max(last - 1, 0))); ops.append(("add", n_in + len(ops) - 1, 0))
+    return Program(ins, ops, mode=mode, fwd_leaf=0)

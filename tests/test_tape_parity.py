@@ -119,3 +119,50 @@ def test_hip_cfg3a_gradients_bit_exact_elementwise():
     gv, gg = tl.run(tl.hip_lib().hip_tape_program, prog)
     assert bits_equal(rg[0], gg[0]) and bits_equal(rg[2], gg[2])
     assert abs(float(gv[0]) - float(rv[0])) <= 100003 * 2.0 ** -23 * 100003
+
+
+SEEDS = list(range(24))
+
+
+def same_grads(ref, got, prog):
+    """bit-exact for vector inputs; the scalar leaf's gradient is a horizontal sum (class D: order dependent)"""
+    for (arr, _), a, b in zip(prog.inputs, ref, got):
+        if a is None and b is None:
+            continue
+        if a is None or b is None:
+            return False
+        if prog.mode == "backward" and arr.size == 1:
+            if not np.allclose(a, b, rtol=1e-4, atol=1e-4):
+                return False
+        elif not bits_equal(a, b):
+            return False
+    return True
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref was not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_vertical_programs_host_tape_vs_reference(seed):
+    for mode in ("backward", "forward"):
+        prog = tl.random_program(seed, mode=mode)
+        rv, rg = tl.run(tl.ref_fn(), prog)
+        hv, hg = tl.run(tl.host_lib().host_tape_program, prog)
+        assert bits_equal(rv, hv), (seed, mode)
+        assert same_grads(rg, hg, prog) if mode == "backward" else bits_equal(rg[0], hg[0]), (seed, mode)
+    assert tl.host_lib().host_tape_live_nodes() == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed", SEEDS)
+def test_random_vertical_programs_hip_tape_bit_exact(seed):
+    """GPU tape vs the product tape on the CPU oracle arrays (itself bit-exact vs the reference build, test above) and,
+    when the reference build travelled with the tree, vs the reference directly"""
+    for mode in ("backward", "forward"):
+        prog = tl.random_program(seed, n=4099, mode=mode)
+        gv, gg = tl.run(tl.hip_lib().hip_tape_program, prog)
+        hv, hg = tl.run(tl.host_lib().host_tape_program, prog)
+        assert bits_equal(hv, gv), (seed, mode)
+        assert same_grads(hg, gg, prog) if mode == "backward" else bits_equal(hg[0], gg[0]), (seed, mode)
+        if HAVE_REF:
+            rv, rg = tl.run(tl.ref_fn(), prog)
+            assert bits_equal(rv, gv)
+            assert same_grads(rg, gg, prog) if mode == "backward" else bits_equal(rg[0], gg[0]), (seed, mode)
