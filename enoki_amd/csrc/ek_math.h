@@ -283,8 +283,11 @@ __device__ __forceinline__ float sinh_small_f32(float x) {
 }
 
 __device__ __forceinline__ float sinh_f32(float x) {                        // array_math.h:997-1046
-    float e0 = exp_f32(x), e1 = 1.0f / e0;
-    return __builtin_fabsf(x) > 1.0f ? (e0 - e1) * 0.5f : sinh_small_f32(x);
+    const bool big = __builtin_fabsf(x) > 1.0f;
+    float r_big = 0.0f, r_small = 0.0f;
+    if (__any(big)) { float e0 = exp_f32(x), e1 = 1.0f / e0; r_big = (e0 - e1) * 0.5f; }     // wave-uniform early outs, like
+    if (!__all(big)) r_small = sinh_small_f32(x);                                             // any_nested() at :1017-1024
+    return big ? r_big : r_small;
 }
 
 __device__ __forceinline__ float cosh_f32(float x) {                        // array_math.h:1048-1065
@@ -299,45 +302,65 @@ __device__ __forceinline__ void sincosh_f32(float x, float &s, float &c) {  // a
 }
 
 __device__ __forceinline__ float tanh_f32(float x) {                        // array_math.h:1129-1179
-    float x2 = x * x;
-    float r_small = estrin(x2, (float) -3.33332819422e-1, (float) 1.33314422036e-1, (float) -5.37397155531e-2,
-                           (float) 2.06390887954e-2, (float) -5.70498872745e-3);
-    r_small = fma_(r_small, x2 * x, x);
-    float e = exp_f32(x + x), e2 = 1.0f / (e + 1.0f);
-    float r_big = 1.0f - (e2 + e2);
-    return __builtin_fabsf(x) >= 0.625f ? r_big : r_small;
+    const bool big = __builtin_fabsf(x) >= 0.625f;
+    float r_small = 0.0f, r_big = 0.0f;
+    if (!__all(big)) {
+        float x2 = x * x;
+        r_small = estrin(x2, (float) -3.33332819422e-1, (float) 1.33314422036e-1, (float) -5.37397155531e-2,
+                         (float) 2.06390887954e-2, (float) -5.70498872745e-3);
+        r_small = fma_(r_small, x2 * x, x);
+    }
+    if (__any(big)) {
+        float e = exp_f32(x + x), e2 = 1.0f / (e + 1.0f);
+        r_big = 1.0f - (e2 + e2);
+    }
+    return big ? r_big : r_small;
 }
 
 __device__ __forceinline__ float asinh_f32(float x) {                       // array_math.h:1185-1237
     float x2 = x * x, xa = __builtin_fabsf(x);
     bool big = xa >= (float) 0.51, huge = xa >= (float) 1e10;
-    float r_small = estrin(x2, (float) -1.6666288134e-1, (float) 7.4847586088e-2, (float) -4.2699340972e-2,
-                           (float) 2.0122003309e-2);
-    r_small = fma_(r_small, x2 * x, x);
-    float r_big = log_f32(xa + (huge ? 0.0f : __builtin_sqrtf(x2 + 1.0f)));
-    if (huge) r_big += (float) 0.693147180559945309417;
+    float r_small = 0.0f, r_big = 0.0f;
+    if (!__all(big)) {
+        r_small = estrin(x2, (float) -1.6666288134e-1, (float) 7.4847586088e-2, (float) -4.2699340972e-2,
+                         (float) 2.0122003309e-2);
+        r_small = fma_(r_small, x2 * x, x);
+    }
+    if (__any(big)) {
+        r_big = log_f32(xa + (huge ? 0.0f : __builtin_sqrtf(x2 + 1.0f)));
+        if (huge) r_big += (float) 0.693147180559945309417;
+    }
     return big ? copysign_f32(r_big, x) : r_small;
 }
 
 __device__ __forceinline__ float acosh_f32(float x) {                       // array_math.h:1239-1293
     float x1 = x - 1.0f;
     bool big = x1 >= (float) 0.49, huge = x1 >= (float) 1e10;
-    float r_small = estrin(x1, (float) 1.4142135263e+0, (float) -1.1784741703e-1, (float) 2.6454905019e-2,
-                           (float) -7.5272886713e-3, (float) 1.7596881071e-3);
-    r_small *= __builtin_sqrtf(x1);
-    if (x1 < 0.0f) r_small = nan_mask_f32();
-    float r_big = log_f32(x + (huge ? 0.0f : __builtin_sqrtf(fma_(x, x, -1.0f))));
-    if (huge) r_big += (float) 0.693147180559945309417;
+    float r_small = 0.0f, r_big = 0.0f;
+    if (!__all(big)) {
+        r_small = estrin(x1, (float) 1.4142135263e+0, (float) -1.1784741703e-1, (float) 2.6454905019e-2,
+                         (float) -7.5272886713e-3, (float) 1.7596881071e-3);
+        r_small *= __builtin_sqrtf(x1);
+        if (x1 < 0.0f) r_small = nan_mask_f32();
+    }
+    if (__any(big)) {
+        r_big = log_f32(x + (huge ? 0.0f : __builtin_sqrtf(fma_(x, x, -1.0f))));
+        if (huge) r_big += (float) 0.693147180559945309417;
+    }
     return big ? r_big : r_small;
 }
 
 __device__ __forceinline__ float atanh_f32(float x) {                       // array_math.h:1295-1348
     float xa = __builtin_fabsf(x), x2 = x * x;
-    float r_small = estrin(x2, (float) 3.33337300303e-1, (float) 1.99782164500e-1, (float) 1.46691431730e-1,
-                           (float) 8.24370301058e-2, (float) 1.81740078349e-1);
-    r_small = fma_(r_small, x2 * x, x);
-    float r_big = log_f32((1.0f + xa) / (1.0f - xa)) * 0.5f;
-    return xa >= 0.5f ? copysign_f32(r_big, x) : r_small;
+    const bool big = xa >= 0.5f;
+    float r_small = 0.0f, r_big = 0.0f;
+    if (!__all(big)) {
+        r_small = estrin(x2, (float) 3.33337300303e-1, (float) 1.99782164500e-1, (float) 1.46691431730e-1,
+                         (float) 8.24370301058e-2, (float) 1.81740078349e-1);
+        r_small = fma_(r_small, x2 * x, x);
+    }
+    if (__any(big)) r_big = log_f32((1.0f + xa) / (1.0f - xa)) * 0.5f;
+    return big ? copysign_f32(r_big, x) : r_small;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -427,25 +450,27 @@ __device__ __forceinline__ double log_f64(double x) {
     bool ge = xm >= 0.70710678118654752440;
     if (ge) e += 1.0;
 
-    // |e| > 2: log(x) = z + z^3 P(z)/Q(z), z = 2(x-1)/(x+1)   (:842-861)
-    double zb = xm - 0.5;
-    if (ge) zb -= 0.5;
-    double yb = 0.5 * (ge ? xm : zb) + 0.5;
-    double x2b = zb / yb;
-    double z2 = x2b * x2b;
-    double rb = x2b * (z2 * estrin(z2, -6.41409952958715622951e1, 1.63866645699558079767e1, -7.89580278884799154124e-1) /
-                       estrin(z2, -7.69691943550460008604e2, 3.12093766372244180303e2, -3.56722798256324312549e1, 1.0));
-    double r_big = fma_(-e, 2.121944400546905827679e-4, rb) + x2b;
-
-    // otherwise: log(1+x) = x - x^2/2 + x^3 P(x)/Q(x)          (:863-884)
-    double x2s = (ge ? xm : xm + xm) - 1.0;
-    double zs = x2s * x2s;
-    double ys = x2s * (zs * estrin(x2s, 7.70838733755885391666e0, 1.79368678507819816313e1, 1.44989225341610930846e1,
-                                   4.70579119878881725854e0, 4.97494994976747001425e-1, 1.01875663804580931796e-4) /
-                       estrin(x2s, 2.31251620126765340583e1, 7.11544750618563894466e1, 8.29875266912776603211e1,
-                              4.52279145837532221105e1, 1.12873587189167450590e1, 1.0));
-    ys = fma_(-e, 2.121944400546905827679e-4, ys);
-    double r_small = x2s + fma_(-0.5, zs, ys);
+    double r_big = 0.0, r_small = 0.0;
+    if (__any(e_big)) {       // |e| > 2: log(x) = z + z^3 P(z)/Q(z), z = 2(x-1)/(x+1)   (:842-861, any_nested early out)
+        double zb = xm - 0.5;
+        if (ge) zb -= 0.5;
+        double yb = 0.5 * (ge ? xm : zb) + 0.5;
+        double x2b = zb / yb;
+        double z2 = x2b * x2b;
+        double rb = x2b * (z2 * estrin(z2, -6.41409952958715622951e1, 1.63866645699558079767e1, -7.89580278884799154124e-1) /
+                           estrin(z2, -7.69691943550460008604e2, 3.12093766372244180303e2, -3.56722798256324312549e1, 1.0));
+        r_big = fma_(-e, 2.121944400546905827679e-4, rb) + x2b;
+    }
+    if (!__all(e_big)) {      // otherwise: log(1+x) = x - x^2/2 + x^3 P(x)/Q(x)          (:863-884)
+        double x2s = (ge ? xm : xm + xm) - 1.0;
+        double zs = x2s * x2s;
+        double ys = x2s * (zs * estrin(x2s, 7.70838733755885391666e0, 1.79368678507819816313e1, 1.44989225341610930846e1,
+                                       4.70579119878881725854e0, 4.97494994976747001425e-1, 1.01875663804580931796e-4) /
+                           estrin(x2s, 2.31251620126765340583e1, 7.11544750618563894466e1, 8.29875266912776603211e1,
+                                  4.52279145837532221105e1, 1.12873587189167450590e1, 1.0));
+        ys = fma_(-e, 2.121944400546905827679e-4, ys);
+        r_small = x2s + fma_(-0.5, zs, ys);
+    }
 
     double r = fma_(e, 0.693359375, e_big ? r_big : r_small);
     if (x == __builtin_inf()) r = __builtin_inf();
@@ -600,13 +625,18 @@ __device__ __forceinline__ double tanh_f64(double x) {
 __device__ __forceinline__ double asinh_f64(double x) {
     double x2 = x * x, xa = __builtin_fabs(x);
     bool big = xa >= 0.533, huge = xa >= 1e20;
-    double r_small = estrin(x2, -5.56682227230859640450e0, -9.09030533308377316566e0, -4.37390226194356683570e0,
-                            -5.91750212056387121207e-1, -4.33231683752342103572e-3) /
-                     estrin(x2, 3.34009336338516356383e1, 6.95722521337257608734e1, 4.86042483805291788324e1,
-                            1.28757002067426453537e1, 1.0);
-    r_small = fma_(r_small, x2 * x, x);
-    double r_big = log_f64(xa + (huge ? 0.0 : __builtin_sqrt(x2 + 1.0)));
-    if (huge) r_big += 0.693147180559945309417;
+    double r_small = 0.0, r_big = 0.0;
+    if (!__all(big)) {
+        r_small = estrin(x2, -5.56682227230859640450e0, -9.09030533308377316566e0, -4.37390226194356683570e0,
+                         -5.91750212056387121207e-1, -4.33231683752342103572e-3) /
+                  estrin(x2, 3.34009336338516356383e1, 6.95722521337257608734e1, 4.86042483805291788324e1,
+                         1.28757002067426453537e1, 1.0);
+        r_small = fma_(r_small, x2 * x, x);
+    }
+    if (__any(big)) {
+        r_big = log_f64(xa + (huge ? 0.0 : __builtin_sqrt(x2 + 1.0)));
+        if (huge) r_big += 0.693147180559945309417;
+    }
     return big ? copysign_f64(r_big, x) : r_small;
 }
 __device__ __forceinline__ double acosh_f64(double x) {
@@ -624,13 +654,17 @@ __device__ __forceinline__ double acosh_f64(double x) {
 }
 __device__ __forceinline__ double atanh_f64(double x) {
     double xa = __builtin_fabs(x), x2 = x * x;
-    double r_small = estrin(x2, -3.09092539379866942570e1, 6.54566728676544377376e1, -4.61252884198732692637e1,
-                            1.20426861384072379242e1, -8.54074331929669305196e-1) /
-                     estrin(x2, -9.27277618139601130017e1, 2.52006675691344555838e2, -2.49839401325893582852e2,
-                            1.08938092147140262656e2, -1.95638849376911654834e1, 1.0);
-    r_small = fma_(r_small, x2 * x, x);
-    double r_big = log_f64((1.0 + xa) / (1.0 - xa)) * 0.5;
-    return xa >= 0.5 ? copysign_f64(r_big, x) : r_small;
+    const bool big = xa >= 0.5;
+    double r_small = 0.0, r_big = 0.0;
+    if (!__all(big)) {
+        r_small = estrin(x2, -3.09092539379866942570e1, 6.54566728676544377376e1, -4.61252884198732692637e1,
+                         1.20426861384072379242e1, -8.54074331929669305196e-1) /
+                  estrin(x2, -9.27277618139601130017e1, 2.52006675691344555838e2, -2.49839401325893582852e2,
+                         1.08938092147140262656e2, -1.95638849376911654834e1, 1.0);
+        r_small = fma_(r_small, x2 * x, x);
+    }
+    if (__any(big)) r_big = log_f64((1.0 + xa) / (1.0 - xa)) * 0.5;
+    return big ? copysign_f64(r_big, x) : r_small;
 }
 __device__ __forceinline__ double pow_f64(double x, double y) { return exp_f64(log_f64(x) * y); }
 
