@@ -11,12 +11,12 @@
 //   2. scan       per-bucket exclusive scan over the workgroups' counts + scan of the bucket totals
 //   3. partition  each workgroup re-reads its chunk in tiles of 8192 elements, sorts a tile by bucket
 //                 in LDS (so that a bucket's elements leave the CU as one coalesced run) and appends
-//                 (index, value) to the bucket's pair list                        reads 8, writes 8 B/elt
+//                 (index within the bucket: 16 bit, value) to the bucket's pair list  reads 8, writes 6 B/elt
 //   4. accumulate S workgroups per bucket stream the bucket's pairs and ds_add them into a zeroed LDS
-//                 table, then write their partial table                           reads  8 B/elt
+//                 table, then write their partial table                           reads  6 B/elt
 //   5. fold       target[k] += sum_s partial[s][k]                                (S + 2) * 4 B per bin
 //
-// = 28 B/elt of streaming traffic and no global atomics.  Tables of <= 16 Ki bins skip steps 1-3.
+// = 24 B/elt of streaming traffic and no global atomics.  Tables of <= 16 Ki bins skip steps 1-3.
 // The result is the same set of additions as the atomic version in a different (unspecified) order
 // -- parity class D, like the reference's own GPU path.
 #include "ek_map.h"
@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__
 
 // ---- 3. partition ----------------------------------------------------------------------------------
 template <typename T, typename I>
-__global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict__ pair_idx, T *__restrict__ pair_val,
+__global__ __launch_bounds__(kThreads) void k_bin_partition(uint16_t *__restrict__ pair_idx, T *__restrict__ pair_val,
                                                             const uint32_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                             const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint32_t *__restrict
         for (uint32_t j = threadIdx.x; j < tile_count; j += kThreads) {
             uint32_t key = stage_idx[j], b = key >> kBinShift;
             uint32_t g = cursor[b] + (j - tile_off[b << rep_shift]);
-            pair_idx[g] = key;
+            pair_idx[g] = (uint16_t) (key & (kBins - 1));   // the bucket is implied by the position: 14 bits suffice
             pair_val[g] = stage_val[j];
         }
         __syncthreads();
@@ -264,7 +264,7 @@ template <bool UseLock, typename T> __device__ __forceinline__ void lds_add(T *a
 // or straight from the operands when the whole table fits one bucket (Direct = true).
 template <typename T, typename I, bool Direct, bool UseLock>
 __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ partials, size_t table_size,
-                                                             const uint32_t *__restrict__ pair_idx,
+                                                             const uint16_t *__restrict__ pair_idx,
                                                              const T *__restrict__ pair_val,
                                                              const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                              const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
@@ -303,7 +303,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
                 ix[k] = i < end ? index_u32(index[i]) : 0u;
                 val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
             } else {
-                ix[k] = i < end ? __builtin_nontemporal_load(pair_idx + i) : 0u;
+                ix[k] = i < end ? (uint32_t) __builtin_nontemporal_load(pair_idx + i) : 0u;
                 val[k] = i < end ? __builtin_nontemporal_load(pair_val + i) : T(0);
             }
         }
@@ -378,7 +378,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     Scratch counts, pairs_idx, pairs_val, partials;
     // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1]
     if (int rc = counts.alloc((count_entries + 2 * kMaxBuckets + 1) * sizeof(uint32_t))) return rc;
-    if (int rc = pairs_idx.alloc(n * sizeof(uint32_t))) return rc;
+    if (int rc = pairs_idx.alloc(n * sizeof(uint16_t))) return rc;
     if (int rc = pairs_val.alloc(n * sizeof(T))) return rc;
     uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
     uint32_t *bucket_base = row_total + kMaxBuckets;
@@ -390,17 +390,17 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (const uint32_t *) row_total,
                        n_buckets);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
-    hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) pairs_idx.ptr,
+    hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint16_t *) pairs_idx.ptr,
                        (T *) pairs_val.ptr, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, value, index.ptr,
                        mask, n, chunk, n_buckets, 0, vec_ok);
-    EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint32_t) + sizeof(T)));
+    EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint16_t) + sizeof(T)));
 
     int slices = std::max(1, (2 * c.num_cu + n_buckets - 1) / n_buckets);
     if (int rc = partials.alloc((size_t) slices * table_size * sizeof(T))) return rc;
     hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3((unsigned) (n_buckets * slices)), dim3(kThreads), lds_bytes,
-                       c.stream, (T *) partials.ptr, table_size, (const uint32_t *) pairs_idx.ptr,
+                       c.stream, (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr,
                        (const T *) pairs_val.ptr, (const uint32_t *) bucket_base, value, index.ptr, mask, n, slices);
-    EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint32_t) + sizeof(T)) + (size_t) slices * table_size * sizeof(T));
+    EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) slices * table_size * sizeof(T));
     hipLaunchKernelGGL((k_bin_fold<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
                        (const T *) partials.ptr, table_size, slices);
     EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) (slices + 2) * table_size * sizeof(T));
