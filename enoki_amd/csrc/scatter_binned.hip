@@ -123,9 +123,15 @@ __global__ __launch_bounds__(1024) void k_bin_scan_rows(uint32_t *__restrict__ c
     if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
 }
 
-// bucket_base[b] = sum of row totals of buckets < b; bucket_base[n_buckets] = grand total
-__global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__ bucket_base,
-                                                          const uint32_t *__restrict__ row_total, int n_buckets) {
+// bucket_base[b] = sum of row totals of buckets < b; bucket_base[n_buckets] = grand total.
+// piece_prefix[b] = number of accumulate work items ("pieces") of buckets < b.  Every bucket gets a share of the
+// `target_pieces` workgroups proportional to its population (at least one when it is not empty) and is cut into
+// that many equal pieces: with evenly spread indices all buckets get the same number of pieces, with skewed indices
+// the crowded buckets get most of them -- the accumulate phase stays balanced either way.
+// (target_pieces == 0: the caller does not need pieces.)
+__global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__ bucket_base, uint32_t *__restrict__ piece_prefix,
+                                                          const uint32_t *__restrict__ row_total, int n_buckets,
+                                                          uint32_t target_pieces) {
     __shared__ uint32_t part[256];
     uint32_t v = (int) threadIdx.x < n_buckets ? row_total[threadIdx.x] : 0u;
     part[threadIdx.x] = v;
@@ -136,8 +142,28 @@ __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__
         part[threadIdx.x] += add;
         __syncthreads();
     }
-    if ((int) threadIdx.x < n_buckets) bucket_base[threadIdx.x] = part[threadIdx.x] - v;
+    const uint32_t lo = part[threadIdx.x] - v, hi = part[threadIdx.x];
+    if ((int) threadIdx.x < n_buckets) bucket_base[threadIdx.x] = lo;
     if (threadIdx.x == 255) bucket_base[n_buckets] = part[255];
+    if (target_pieces == 0) return;
+    __syncthreads();
+    const uint64_t total = part[255], size = hi - lo;
+    uint32_t pieces = 0;
+    if ((int) threadIdx.x < n_buckets && size > 0) {
+        pieces = (uint32_t) ((size * target_pieces + total / 2) / total);
+        if (pieces == 0) pieces = 1;
+    }
+    __syncthreads();
+    part[threadIdx.x] = pieces;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        uint32_t add = threadIdx.x >= (unsigned) d ? part[threadIdx.x - d] : 0u;
+        __syncthreads();
+        part[threadIdx.x] += add;
+        __syncthreads();
+    }
+    if ((int) threadIdx.x < n_buckets) piece_prefix[threadIdx.x] = part[threadIdx.x] - pieces;
+    if (threadIdx.x == 255) piece_prefix[n_buckets] = part[255];
 }
 
 // ---- 3. partition ----------------------------------------------------------------------------------
@@ -240,17 +266,40 @@ template <bool UseLock, typename T> __device__ __forceinline__ void lds_add(T *a
             // winner waits for reconvergence with the very lanes that spin on its lock -- a deadlock.)
             unsigned *p = reinterpret_cast<unsigned *>(addr);
             bool pending = active;
-            while (__any(pending)) {
-                if (pending) {
-                    unsigned old = atomicExch(p, kLockedBits);
-                    if (old != kLockedBits) {
-                        float sum = __uint_as_float(old) + v;
-                        unsigned bits = __float_as_uint(sum);
-                        if (bits == kLockedBits) bits = 0x7FC00000u;     // never publish the lock pattern
-                        __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        pending = false;
-                    }
+            // (1) optimistic round: with well-spread bins nearly every lane wins here
+            if (pending) {
+                unsigned old = atomicExch(p, kLockedBits);
+                if (old != kLockedBits) {
+                    float sum = __uint_as_float(old) + v;
+                    unsigned bits = __float_as_uint(sum);
+                    if (bits == kLockedBits) bits = 0x7FC00000u;         // never publish the lock pattern
+                    __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pending = false;
                 }
+            }
+            // (2) losers collided inside the wave (or met another wave's lock).  Skewed index distributions would
+            // serialise here lane by lane, so the lanes that share the first loser's bin first combine their values
+            // with a wave reduction and ONE lane adds the total: the number of rounds is the number of distinct
+            // contended bins, not the number of colliding lanes.  Only that one lane ever spins, and never on a
+            // lock held inside its own wave, so it always gets through.
+            const unsigned key = (unsigned) (uintptr_t) addr;
+            const int lane = threadIdx.x & 63;
+            while (__any(pending)) {
+                const unsigned long long pend = __ballot(pending);
+                const int leader = __ffsll((long long) pend) - 1;
+                const unsigned leader_key = __shfl(key, leader);
+                const bool grouped = pending && key == leader_key;
+                float total = grouped ? v : 0.0f;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+                if (lane == leader) {
+                    unsigned old;
+                    do { old = atomicExch(p, kLockedBits); } while (old == kLockedBits);
+                    unsigned bits = __float_as_uint(__uint_as_float(old) + total);
+                    if (bits == kLockedBits) bits = 0x7FC00000u;
+                    __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                pending = pending && !grouped;
             }
         } else {
             if (active) atomicAdd(addr, v);                                          // ds_add_f32
@@ -268,25 +317,33 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
                                                              const T *__restrict__ pair_val,
                                                              const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                              const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
-                                                             int slices) {
+                                                             int slices, const uint32_t *__restrict__ piece_prefix) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T *acc = reinterpret_cast<T *>(lds_raw);
-    const int bucket = blockIdx.x / slices, slice = blockIdx.x % slices;
-    for (int j = threadIdx.x; j < kBins; j += kThreads) acc[j] = T(0);
-    __syncthreads();
-
     size_t begin, end;
     if constexpr (Direct) {
         const size_t per = (n + slices - 1) / slices;
-        begin = (size_t) slice * per;
+        begin = (size_t) blockIdx.x * per;
         end = begin + per < n ? begin + per : n;
     } else {
-        const size_t lo = bucket_base[bucket], hi = bucket_base[bucket + 1];
-        const size_t per = (hi - lo + slices - 1) / slices;
-        begin = lo + (size_t) slice * per;
+        // work item = piece number blockIdx.x (the grid is an upper bound on the number of pieces): find its bucket
+        // (piece_prefix is ascending, <= 257 entries; `slices` carries n_buckets here), then its range: the q-th of the
+        // bucket's equal pieces
+        __shared__ int s_bucket;
+        const int n_buckets = slices;
+        if (blockIdx.x >= piece_prefix[n_buckets]) return;
+        for (int b = threadIdx.x; b < n_buckets; b += kThreads)
+            if (piece_prefix[b] <= blockIdx.x && blockIdx.x < piece_prefix[b + 1]) s_bucket = b;
+        __syncthreads();
+        const int bucket = s_bucket;
+        const size_t lo = bucket_base[bucket], hi = bucket_base[bucket + 1], q = blockIdx.x - piece_prefix[bucket];
+        const size_t pieces = piece_prefix[bucket + 1] - piece_prefix[bucket], per = (hi - lo + pieces - 1) / pieces;
+        begin = lo + q * per < hi ? lo + q * per : hi;
         end = begin + per < hi ? begin + per : hi;
-        if (begin > hi) begin = hi;
     }
+    for (int j = threadIdx.x; j < kBins; j += kThreads) acc[j] = T(0);
+    __syncthreads();
+
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const T sv = value.vec ? T(0) : arg_scalar(value);
     constexpr int kAcc = 8;      // loads in flight per lane
@@ -313,8 +370,9 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
     }
     __syncthreads();
 
-    T *out = partials + (size_t) slice * table_size + (size_t) bucket * kBins;
-    const size_t valid = table_size - (size_t) bucket * kBins;
+    // Direct: one table-sized partial per slice; binned: one bucket-sized partial per piece
+    T *out = Direct ? partials + (size_t) blockIdx.x * table_size : partials + (size_t) blockIdx.x * kBins;
+    const size_t valid = Direct ? table_size : (size_t) kBins;
     for (int j = threadIdx.x; j < kBins; j += kThreads)
         if ((size_t) j < valid) out[j] = acc[j];
 }
@@ -328,6 +386,20 @@ __global__ __launch_bounds__(256) void k_bin_fold(T *__restrict__ target, const 
     using U = wrap_t<T>;
     T s = target[k];
     for (int j = 0; j < slices; ++j) s = (T) ((U) s + (U) partials[(size_t) j * table_size + k]);
+    target[k] = s;
+}
+
+// binned path: bin k of bucket b sums the partials of the bucket's pieces
+template <typename T>
+__global__ __launch_bounds__(256) void k_bin_fold_pieces(T *__restrict__ target, const T *__restrict__ partials,
+                                                         const uint32_t *__restrict__ piece_prefix, size_t table_size) {
+    size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= table_size) return;
+    using U = wrap_t<T>;
+    const uint32_t b = (uint32_t) (k >> kBinShift), local = (uint32_t) (k & (kBins - 1));
+    T s = target[k];
+    for (uint32_t p = piece_prefix[b]; p < piece_prefix[b + 1]; ++p)
+        s = (T) ((U) s + (U) partials[(size_t) p * kBins + local]);
     target[k] = s;
 }
 
@@ -353,10 +425,12 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
         // beats the exchange lock; from ~1 Ki bins on collisions inside a wave are rare
         if (table_size > 1024)
             hipLaunchKernelGGL((k_bin_accumulate<T, I, true, true>), dim3(slices), dim3(kThreads), lds_bytes, c.stream,
-                               (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices);
+                               (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices,
+                               nullptr);
         else
             hipLaunchKernelGGL((k_bin_accumulate<T, I, true, false>), dim3(slices), dim3(kThreads), lds_bytes, c.stream,
-                               (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices);
+                               (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices,
+                               nullptr);
         EK_LAUNCH_CHECK("scatter_add_lds", n, algo_bytes);
         hipLaunchKernelGGL((k_bin_fold<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
                            (const T *) partials.ptr, table_size, slices);
@@ -376,34 +450,37 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
     const size_t count_entries = (size_t) n_buckets * blocks;
     Scratch counts, pairs_idx, pairs_val, partials;
-    // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1]
-    if (int rc = counts.alloc((count_entries + 2 * kMaxBuckets + 1) * sizeof(uint32_t))) return rc;
+    // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1] | piece_prefix[kMaxBuckets + 1]
+    if (int rc = counts.alloc((count_entries + 3 * kMaxBuckets + 2) * sizeof(uint32_t))) return rc;
     if (int rc = pairs_idx.alloc(n * sizeof(uint16_t))) return rc;
     if (int rc = pairs_val.alloc(n * sizeof(T))) return rc;
     uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
     uint32_t *bucket_base = row_total + kMaxBuckets;
+    uint32_t *piece_prefix = bucket_base + kMaxBuckets + 1;
+    // accumulate work items: about two workgroups per CU (64 KiB of LDS each), shared out by bucket population
+    const uint32_t target_pieces = (uint32_t) std::max(2 * c.num_cu, n_buckets);
+    const unsigned max_pieces = target_pieces + (unsigned) n_buckets;       // rounding + "at least one" slack
 
     hipLaunchKernelGGL((k_bin_count<I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, index.ptr,
                        mask, n, chunk, n_buckets, rep_shift, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_count", n, arg_bytes(index, n) + arg_bytes(mask, n));
     hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_buckets), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
-    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (const uint32_t *) row_total,
-                       n_buckets);
+    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, piece_prefix,
+                       (const uint32_t *) row_total, n_buckets, target_pieces);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
     hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint16_t *) pairs_idx.ptr,
                        (T *) pairs_val.ptr, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, value, index.ptr,
                        mask, n, chunk, n_buckets, 0, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint16_t) + sizeof(T)));
 
-    int slices = std::max(1, (2 * c.num_cu + n_buckets - 1) / n_buckets);
-    if (int rc = partials.alloc((size_t) slices * table_size * sizeof(T))) return rc;
-    hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3((unsigned) (n_buckets * slices)), dim3(kThreads), lds_bytes,
-                       c.stream, (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr,
-                       (const T *) pairs_val.ptr, (const uint32_t *) bucket_base, value, index.ptr, mask, n, slices);
-    EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) slices * table_size * sizeof(T));
-    hipLaunchKernelGGL((k_bin_fold<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
-                       (const T *) partials.ptr, table_size, slices);
-    EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) (slices + 2) * table_size * sizeof(T));
+    if (int rc = partials.alloc((size_t) max_pieces * kBins * sizeof(T))) return rc;
+    hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3(max_pieces), dim3(kThreads), lds_bytes, c.stream,
+                       (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr, (const T *) pairs_val.ptr,
+                       (const uint32_t *) bucket_base, value, index.ptr, mask, n, n_buckets, (const uint32_t *) piece_prefix);
+    EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * kBins * sizeof(T));
+    hipLaunchKernelGGL((k_bin_fold_pieces<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
+                       (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size);
+    EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) max_pieces * kBins * sizeof(T) + 2 * table_size * sizeof(T));
     return EK_OK;
 }
 
@@ -621,7 +698,8 @@ int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Ar
                                (uint32_t *) counts.ptr, in_keys, all_on, m, chunk, shift);
         }
         hipLaunchKernelGGL(k_bin_scan_rows, dim3(kRadix), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
-        hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (const uint32_t *) row_total, kRadix);
+        hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr,
+                           (const uint32_t *) row_total, kRadix, 0u);
         if (p == 0) {
             hipLaunchKernelGGL((k_radix_partition_stable<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys,
                                out_vals, index.ptr, value, mask, (const uint32_t *) counts.ptr,
