@@ -79,16 +79,41 @@ __global__ __launch_bounds__(256) void k_scatter(T *__restrict__ base, Arg<T> va
     const I si = index.vec ? I(0) : arg_scalar(index);
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const size_t e = lane_elem<N, 1>(0);
-    if (e >= n) return;
+    if (!Add && e >= n) return;
+    // (scatter_add: lanes past the end stay in the wave -- they take part in the shuffles below with `on` = false;
+    //  arg_load bounds-checks every element on the non-vector path)
     const bool fast = vec_ok && e + N <= n;
     Pack<T, N> pv = arg_load<T, N, true>(value, sv, e, n, fast);
     Pack<I, N> pi = arg_load<I, N, true>(index, si, e, n, fast);
     Pack<uint8_t, N> pm = arg_load<uint8_t, N, true>(mask, sm, e, n, fast);
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        if (pm.v[k] && e + k < n) {
-            T *dst = base + index_offset(pi.v[k]);
-            if constexpr (Add) atomic_add(dst, pv.v[k]); else *dst = pv.v[k];
+        bool on = pm.v[k] && e + k < n;
+        if constexpr (Add) {
+            // Same-address device atomics retire at only ~0.08 G/s (profiles/probe_skew_r01.txt), so hot bins are
+            // pre-combined inside the wave: the lanes that share the first active lane's index reduce their values
+            // and issue ONE atomic; two rounds peel the two hottest bins of the instruction.  With well spread
+            // indices this costs a shuffle, a compare and a ballot per element.
+            const I my = pi.v[k];
+            const int lane = threadIdx.x & 63;
+            using U = wrap_t<T>;
+#pragma unroll
+            for (int round = 0; round < 2; ++round) {
+                const unsigned long long act = __ballot(on);
+                if (act == 0) break;
+                const int leader = __ffsll((long long) act) - 1;
+                const I hot = __shfl(my, leader);
+                const bool same = on && my == hot;
+                if (__popcll(__ballot(same)) < 2) break;         // the leader's bin is not shared: nothing to combine
+                U total = same ? (U) pv.v[k] : U(0);
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) total = (U) (total + (U) __shfl_xor(total, d));
+                if (lane == leader) atomic_add(base + index_offset(hot), (T) total);
+                on = on && !same;
+            }
+            if (on) atomic_add(base + index_offset(my), pv.v[k]);
+        } else {
+            if (on) base[index_offset(pi.v[k])] = pv.v[k];
         }
     }
 }

