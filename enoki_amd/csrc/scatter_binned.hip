@@ -720,12 +720,31 @@ __global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *_
     }
 }
 
-/// One lane per bin: locate the bin's run in the sorted keys and add it sequentially
+__device__ __forceinline__ float wave_read(float v, int lane) {
+    return __uint_as_float((unsigned) __builtin_amdgcn_readlane((int) __float_as_uint(v), lane));
+}
+__device__ __forceinline__ uint32_t wave_read(uint32_t v, int lane) { return (uint32_t) __builtin_amdgcn_readlane((int) v, lane); }
+__device__ __forceinline__ int32_t wave_read(int32_t v, int lane) { return __builtin_amdgcn_readlane(v, lane); }
+template <typename T, std::enable_if_t<sizeof(T) == 8, int> = 0> __device__ __forceinline__ T wave_read(T v, int lane) {
+    uint64_t bits;
+    __builtin_memcpy(&bits, &v, 8);
+    uint32_t lo = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) bits, lane),
+             hi = (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (bits >> 32), lane);
+    bits = (uint64_t) lo | ((uint64_t) hi << 32);
+    T r;
+    __builtin_memcpy(&r, &bits, 8);
+    return r;
+}
+
+/// One lane per bin: locate the bin's run in the sorted keys and add it sequentially -- the exact chain of additions
+/// of the CPU.  Runs longer than a wave (hot bins) are walked by the whole wave on behalf of their lane: 64 values are
+/// fetched with one coalesced load and folded in element order through readlane, ~16x faster than a single lane
+/// chasing its own loads (a serial chain cannot be parallelised without changing the rounding).
 template <typename T>
 __global__ __launch_bounds__(256) void k_segment_sum(T *__restrict__ target, size_t table_size,
                                                      const uint32_t *__restrict__ keys, const T *__restrict__ vals, size_t m) {
     const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
-    if (k >= table_size) return;
+    const bool valid = k < table_size;
     auto lower_bound = [&](uint64_t key) {
         size_t lo = 0, hi = m;
         while (lo < hi) {
@@ -734,11 +753,40 @@ __global__ __launch_bounds__(256) void k_segment_sum(T *__restrict__ target, siz
         }
         return lo;
     };
-    const size_t lo = lower_bound(k), hi = lower_bound(k + 1);
-    if (lo == hi) return;
-    T acc = target[k];
-    for (size_t i = lo; i < hi; ++i) acc += vals[i];
-    target[k] = acc;
+    size_t lo = 0, hi = 0;
+    if (valid) { lo = lower_bound(k); hi = lower_bound(k + 1); }
+    const bool has_run = hi > lo;
+    T acc = has_run ? target[k] : T(0);
+
+    // hot bins first, one at a time, cooperatively
+    const int lane = threadIdx.x & 63;
+    unsigned long long hot = __ballot(has_run && hi - lo > 64);
+    while (hot) {
+        const int owner = __ffsll((long long) hot) - 1;
+        hot &= hot - 1;
+        const size_t begin = __shfl(lo, owner), end = __shfl(hi, owner);
+        T sum = __shfl(acc, owner);
+        T next = begin + (size_t) lane < end ? vals[begin + (size_t) lane] : T(0);
+        for (size_t base = begin; base < end; base += 64) {
+            const T v = next;
+            const size_t ahead = base + 64 + (size_t) lane;            // prefetch the following 64 values
+            next = ahead < end ? vals[ahead] : T(0);
+            const int cnt = end - base < 64 ? (int) (end - base) : 64;
+            // element order; every lane carries the same sum.  v_readlane with a constant / uniform lane index
+            // (a generic shuffle would go through the LDS crossbar: ~100 cycles per element)
+            if (cnt == 64) {
+#pragma unroll
+                for (int j = 0; j < 64; ++j) sum += wave_read(v, j);
+            } else {
+                for (int j = 0; j < cnt; ++j) sum += wave_read(v, j);
+            }
+        }
+        if (lane == owner) { acc = sum; lo = hi; }                     // run consumed
+    }
+    if (has_run) {
+        for (size_t i = lo; i < hi; ++i) acc += vals[i];
+        target[k] = acc;
+    }
 }
 
 template <typename T, typename I>
