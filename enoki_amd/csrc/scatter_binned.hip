@@ -323,8 +323,8 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
     T *acc = reinterpret_cast<T *>(lds_raw);
     size_t begin, end;
     if constexpr (Direct) {
-        const size_t per = (n + slices - 1) / slices;
-        begin = (size_t) blockIdx.x * per;
+        const size_t per = ((n + slices - 1) / slices + 4095) / 4096 * 4096;     // multiple of the vector step
+        begin = (size_t) blockIdx.x * per < n ? (size_t) blockIdx.x * per : n;
         end = begin + per < n ? begin + per : n;
     } else {
         // work item = piece number blockIdx.x (the grid is an upper bound on the number of pieces): find its bucket
@@ -348,6 +348,61 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     const T sv = value.vec ? T(0) : arg_scalar(value);
     constexpr int kAcc = 8;      // loads in flight per lane
+    const bool plain = Direct && !mask.vec && sm != 0 && value.vec;
+    if constexpr (Direct) {
+        // fast path of the single-bucket case: no mask array, value array, 16-byte aligned operands -> every lane
+        // moves two 16-byte vectors of indices and of values per step (begin is a multiple of the step)
+        const bool aligned = ((reinterpret_cast<uintptr_t>(index) | reinterpret_cast<uintptr_t>(value.ptr)) & 15u) == 0;
+        if (plain && aligned) {
+            constexpr size_t kStep = (size_t) kAcc * kThreads;
+            size_t base = begin;
+            for (; base + kStep <= end; base += kStep) {
+                Pack<I, 4> pi[2];
+                Pack<T, 4> pv[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const size_t e = base + (size_t) h * (kStep / 2) + (size_t) threadIdx.x * 4;
+                    pi[h] = pack_load<I, 4, true>(index + e);
+                    pv[h] = pack_load<T, 4, true>(value.ptr + e);
+                }
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        lds_add<UseLock>(&acc[index_u32(pi[h].v[j]) & (kBins - 1)], pv[h].v[j], true);
+            }
+            begin = base;          // the generic loop below finishes the tail
+        }
+    } else {
+        // pair lists: a piece starts anywhere; up to 3 leading pairs go one per lane, then every lane moves two
+        // 4-element vectors (8 bytes of bucket-local indices, 16 bytes of values) per step
+        const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
+        {
+            const size_t i = begin + threadIdx.x;
+            const bool on = i < head_end;
+            const uint32_t ix = on ? (uint32_t) pair_idx[i] : 0u;
+            const T v = on ? pair_val[i] : T(0);
+            lds_add<UseLock>(&acc[ix & (kBins - 1)], v, on);
+        }
+        constexpr size_t kStep = (size_t) kAcc * kThreads;
+        size_t base = head_end;
+        for (; base + kStep <= end; base += kStep) {
+            Pack<uint16_t, 4> pi[2];
+            Pack<T, 4> pv[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const size_t e = base + (size_t) h * (kStep / 2) + (size_t) threadIdx.x * 4;
+                pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
+                pv[h] = pack_load<T, 4, true>(pair_val + e);
+            }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    lds_add<UseLock>(&acc[(uint32_t) pi[h].v[j] & (kBins - 1)], pv[h].v[j], true);
+        }
+        begin = base;
+    }
     for (size_t base = begin; base < end; base += (size_t) kAcc * kThreads) {
         uint32_t ix[kAcc];
         T val[kAcc];
@@ -357,9 +412,14 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
             size_t i = base + (size_t) k * kThreads + threadIdx.x;
             on[k] = i < end;
             if constexpr (Direct) {
-                on[k] = on[k] && (mask.vec ? mask.ptr[i] : sm);
-                ix[k] = i < end ? index_u32(index[i]) : 0u;
-                val[k] = (value.vec && i < end) ? value.ptr[i] : sv;
+                if (plain) {          // no mask array, value array: the common case without per-element operand tests
+                    ix[k] = i < end ? index_u32(__builtin_nontemporal_load(index + i)) : 0u;
+                    val[k] = i < end ? __builtin_nontemporal_load(value.ptr + i) : T(0);
+                } else {
+                    on[k] = on[k] && (mask.vec ? mask.ptr[i] : sm);
+                    ix[k] = i < end ? index_u32(__builtin_nontemporal_load(index + i)) : 0u;
+                    val[k] = (value.vec && i < end) ? __builtin_nontemporal_load(value.ptr + i) : sv;
+                }
             } else {
                 ix[k] = i < end ? (uint32_t) __builtin_nontemporal_load(pair_idx + i) : 0u;
                 val[k] = i < end ? __builtin_nontemporal_load(pair_val + i) : T(0);
@@ -388,6 +448,20 @@ __global__ __launch_bounds__(256) void k_bin_fold(T *__restrict__ target, const 
     T s = target[k];
     for (int j = 0; j < slices; ++j) s = (T) ((U) s + (U) partials[(size_t) j * table_size + k]);
     target[k] = s;
+}
+
+// first stage of a two-stage fold for small tables with many slices (a 16 Ki-bin table has only 64 workgroups
+// worth of bins): group g sums the slices s = g, g + groups, g + 2 groups, ... into out[g][k]
+template <typename T>
+__global__ __launch_bounds__(256) void k_bin_fold_groups(T *__restrict__ out, const T *__restrict__ partials, size_t table_size,
+                                                         int slices, int groups) {
+    size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (k >= table_size) return;
+    using U = wrap_t<T>;
+    const int g = blockIdx.y;
+    T s = T(0);
+    for (int j = g; j < slices; j += groups) s = (T) ((U) s + (U) partials[(size_t) j * table_size + k]);
+    out[(size_t) g * table_size + k] = s;
 }
 
 // binned path: bin k of bucket b sums the partials of the bucket's pieces
@@ -439,8 +513,20 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
                                (T *) partials.ptr, table_size, nullptr, nullptr, nullptr, value, index.ptr, mask, n, slices,
                                nullptr);
         EK_LAUNCH_CHECK("scatter_add_lds", n, algo_bytes);
-        hipLaunchKernelGGL((k_bin_fold<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
-                           (const T *) partials.ptr, table_size, slices);
+        const unsigned bin_blocks = (unsigned) ((table_size + 255) / 256);
+        if (slices > 32) {
+            // few bins, many slices: fold in two stages so that the first one has slices/2 x more workgroups
+            const int groups = 16;
+            Scratch grouped;
+            if (int rc = grouped.alloc((size_t) groups * table_size * sizeof(T))) return rc;
+            hipLaunchKernelGGL((k_bin_fold_groups<T>), dim3(bin_blocks, groups), dim3(256), 0, c.stream, (T *) grouped.ptr,
+                               (const T *) partials.ptr, table_size, slices, groups);
+            hipLaunchKernelGGL((k_bin_fold<T>), dim3(bin_blocks), dim3(256), 0, c.stream, base, (const T *) grouped.ptr,
+                               table_size, groups);
+        } else {
+            hipLaunchKernelGGL((k_bin_fold<T>), dim3(bin_blocks), dim3(256), 0, c.stream, base, (const T *) partials.ptr,
+                               table_size, slices);
+        }
         EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) (slices + 2) * table_size * sizeof(T));
         return EK_OK;
     }
