@@ -204,6 +204,15 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("round", [](const Array &a) { return round(a); });
         m.def("trunc", [](const Array &a) { return trunc(a); });
         m.def("sign", [](const Array &a) { return sign(a); });
+        m.def("isnan", [](const Array &a) { return isnan(a); });
+        m.def("isinf", [](const Array &a) { return isinf(a); });
+        m.def("isfinite", [](const Array &a) { return isfinite(a); });
+        m.def("safe_sqrt", [](const Array &a) { return safe_sqrt(a); });
+        m.def("safe_rsqrt", [](const Array &a) { return safe_rsqrt(a); });
+        m.def("safe_asin", [](const Array &a) { return safe_asin(a); });
+        m.def("safe_acos", [](const Array &a) { return safe_acos(a); });
+        m.def("hypot", [](const Array &a, const Array &b) { return hypot(a, b); });
+        m.def("copysign", [](const Array &a, const Array &b) { return copysign(a, b); });
         m.def("sin", [](const Array &a) { return sin(a); });
         m.def("cos", [](const Array &a) { return cos(a); });
         m.def("sincos", [](const Array &a) { return sincos(a); });

@@ -18,6 +18,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <limits>
 #include <stdexcept>
 #include <string>
 #include <tuple>
@@ -384,6 +385,32 @@ inline auto select(const M &m, const T1 &t, const T2 &f) {
         return E::select_(detail::as<mask_t<E>>(m), detail::as<E>(t), detail::as<E>(f));
     }
 }
+
+/// Classification and "safe" helpers (array_router.h:606-623, array_math.h:1362-1404)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto isnan(const T &a) { return neq(a, a); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto isinf(const T &a) {
+    return eq(abs(a), T(std::numeric_limits<scalar_t<T>>::infinity()));
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto isfinite(const T &a) {
+    return abs(a) < T(std::numeric_limits<scalar_t<T>>::infinity());
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T safe_sqrt(const T &a) { return sqrt(max(a, T(scalar_t<T>(0)))); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T safe_rsqrt(const T &a) { return rsqrt(max(a, T(scalar_t<T>(0)))); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T safe_asin(const T &a) {
+    return asin(min(T(scalar_t<T>(1)), max(T(scalar_t<T>(-1)), a)));
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T safe_acos(const T &a) {
+    return acos(min(T(scalar_t<T>(1)), max(T(scalar_t<T>(-1)), a)));
+}
+/// hypot without intermediate overflow / underflow (array_math.h:1362-1379)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T hypot(const T &a, const T &b) {
+    using S = scalar_t<T>;
+    const T inf = T(std::numeric_limits<S>::infinity());
+    T abs_a = abs(a), abs_b = abs(b), maxval = max(abs_a, abs_b), minval = min(abs_a, abs_b), ratio = minval / maxval;
+    return select((abs_a < inf) & (abs_b < inf) & (ratio < inf), maxval * sqrt(T(S(1)) + ratio * ratio), abs_a + abs_b);
+}
+/// copysign(a, b): magnitude of a, sign of b (array_router.h:376-398)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline T copysign(const T &a, const T &b) { return abs(a) * sign(b); }
 
 /// mulsign(a, b) = a * sign(b), via sign-bit xor like the CPU packets (array_router.h:447)
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline T mulsign(const T &a, const T &b) {

@@ -293,3 +293,24 @@ def test_float64_second_wave_and_autodiff(ek, ekc):
     xd = ek.Float64(x); ek.set_requires_gradient(xd)
     ek.backward(ek.hsum(ek.atan(xd) + ek.tanh(xd)))
     assert np.allclose(ek.gradient(xd).numpy(), 1 / (1 + a * a) + 1 / np.cosh(a) ** 2, rtol=1e-13)
+
+
+def test_classification_and_safe_helpers(ekc, ek):
+    a = np.array([0.0, -0.0, 1.5, -2.0, np.inf, -np.inf, np.nan, 1e-40, 3e38, -4.0], np.float32)
+    x = ekc.Float32(a)
+    assert np.array_equal(ekc.isnan(x).numpy() != 0, np.isnan(a)) and np.array_equal(ekc.isinf(x).numpy() != 0, np.isinf(a))
+    assert np.array_equal(ekc.isfinite(x).numpy() != 0, np.isfinite(a))
+    with np.errstate(invalid="ignore"):
+        assert np.allclose(ekc.safe_sqrt(x).numpy(), np.sqrt(np.maximum(a, 0)).astype(np.float32), equal_nan=True)
+    u = np.linspace(-1.5, 1.5, 1001).astype(np.float32)
+    assert np.allclose(ekc.safe_asin(ekc.Float32(u)).numpy(), np.arcsin(np.clip(u, -1, 1)), atol=3e-7)
+    assert np.allclose(ekc.safe_acos(ekc.Float32(u)).numpy(), np.arccos(np.clip(u, -1, 1)), atol=5e-7)
+    p = np.array([3.0, 1e30, 1e-30, 0.0, np.inf], np.float32); q = np.array([4.0, 1e30, 1e-30, 0.0, 1.0], np.float32)
+    h = ekc.hypot(ekc.Float32(p), ekc.Float32(q)).numpy()
+    assert np.allclose(h[:3], np.hypot(p[:3].astype(np.float64), q[:3]), rtol=1e-6) and h[4] == np.inf
+    assert np.array_equal(ekc.copysign(ekc.Float32(p[:3]), ekc.Float32(np.array([-1, 1, -0.0], np.float32))).numpy(),
+                          np.copysign(p[:3], np.array([-1, 1, -0.0], np.float32)))
+    xd = ek.Float32(ekc.Float32(np.array([3.0, 5.0], np.float32))); yd = ek.Float32(ekc.Float32(np.array([4.0, 12.0], np.float32)))
+    ek.set_requires_gradient(xd)
+    ek.backward(ek.hsum(ek.hypot(xd, yd)))
+    assert np.allclose(ek.gradient(xd).numpy(), [0.6, 5.0 / 13.0], rtol=1e-6)
