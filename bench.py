@@ -48,6 +48,11 @@ DESCRIPTION = {
             "32 Mi rays per GPU, unfused eager kernels",
 }
 N_RAYS_PER_GPU = 1 << 25
+N_PATHS_PER_GPU = 1 << 24
+DESCRIPTION["cfg5"] = ("synthetic 3-bounce path tracer inside a textured unit sphere (SURVEY 8d cfg5, not in the reference): "
+                       "PCG32 sampling, sphere intersection, (theta, phi) -> texel, differentiable gather of the albedo "
+                       "texture (K = 1 Mi), cosine-weighted bounce; loss = hsum(radiance); backward() scatter_adds the "
+                       "texture gradient; 16 Mi paths per GPU; report only")
 # kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
 PMC_SYMBOL = {"gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
               "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",
@@ -59,7 +64,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4"])
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg5"])
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
@@ -86,6 +91,59 @@ def pmc_traffic(kernel):
             if best is None or grid > best[0]:
                 best = (grid, (rd + wr) * 1e6)
     return int(best[1]) if best else None
+
+
+def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024):
+    """cfg5: `n` light paths inside the unit sphere whose inner surface carries the albedo texture `tex`
+    (differentiable, width x width texels over (phi, theta)).  Geometry and sampling use plain arrays (enoki.hip),
+    only the texture lookups are on the tape, so backward() is one scatter_add per bounce into grad(tex).
+    Sampling: PCG32 streams first_lane .. first_lane + n (enoki/random.h); sphere intersection as in the
+    reference's tests/sphere.cpp:67-78; concentric disk mapping as in tests/autodiff.cpp:468-491."""
+    import math
+    F, U32, U64, V3 = ekc.Float32, ekc.UInt32, ekc.UInt64, ekc.Vector3f
+    rng = ekc.PCG32(U64(seed), U64.arange(n) + U64(first_lane))
+    # primary directions: uniform on the sphere; origin: a fixed point inside
+    z = F(1.0) - F(2.0) * rng.next_float32()
+    r = ekc.sqrt(ekc.max(F(0.0), F(1.0) - z * z))
+    phi = F(2.0 * math.pi) * rng.next_float32()
+    s_, c_ = ekc.sincos(phi)
+    d = V3(r * c_, r * s_, z)
+    o = V3(F(0.1), F(0.2), F(-0.1))
+    throughput = ek.Float32(1.0)
+    radiance = ek.Float32(0.0)
+    for _ in range(bounces):
+        b = ekc.dot(o, d)
+        c = ekc.dot(o, o) - F(1.0)
+        t = ekc.sqrt(ekc.max(F(0.0), b * b - c)) - b                       # far root: we are inside the sphere
+        p = ekc.normalize(o + d * t)
+        theta = ekc.acos(ekc.clamp(p.z, F(-1.0), F(1.0)))
+        ph = ekc.atan2(p.y, p.x)
+        uu = ekc.fmadd(ph, F(0.5 / math.pi), F(0.5)); vv = theta * F(1.0 / math.pi)
+        ix = ekc.min(U32(uu * F(float(width))), U32(width - 1)); iy = ekc.min(U32(vv * F(float(width))), U32(width - 1))
+        texel = iy * U32(width) + ix
+        albedo = ek.gather(tex, ek.UInt32(texel))                          # the only differentiable operation
+        radiance = radiance + throughput * albedo * ek.Float32(0.1)        # the surface emits a little of its colour
+        throughput = throughput * albedo
+        # cosine-weighted bounce around the inward normal nrm = -p (concentric disk mapping)
+        nrm = p * F(-1.0)
+        r1 = F(2.0) * rng.next_float32() - F(1.0); r2 = F(2.0) * rng.next_float32() - F(1.0)
+        swap = ekc.abs(r1) < ekc.abs(r2)
+        rad = ekc.select(swap, r2, r1)
+        ratio = ekc.select(swap, r1, r2) / ekc.select(rad == F(0.0), F(1.0), rad)
+        ang = ekc.select(swap, F(0.5 * math.pi) - F(0.25 * math.pi) * ratio, F(0.25 * math.pi) * ratio)
+        sn, cs = ekc.sincos(ang)
+        dx = rad * cs; dy = rad * sn
+        dz = ekc.sqrt(ekc.max(F(0.0), F(1.0) - dx * dx - dy * dy))
+        # orthonormal frame around nrm (Duff et al. 2017)
+        sign = ekc.copysign(F(1.0), nrm.z)
+        a = F(-1.0) / (sign + nrm.z)
+        bb = nrm.x * nrm.y * a
+        sx = V3(F(1.0) + sign * nrm.x * nrm.x * a, sign * bb, F(-1.0) * sign * nrm.x)
+        ty = V3(bb, sign + nrm.y * nrm.y * a, F(-1.0) * nrm.y)
+        d = ekc.normalize(sx * dx + ty * dy + nrm * dz)
+        o = p + nrm * F(1e-3)
+    radiance = radiance + throughput                                        # leftover energy reaches a white environment
+    return ek.hsum(radiance)
 
 
 class Bench:
@@ -146,6 +204,22 @@ class Bench:
                     packer.pack([ekd.as_tensor(ek.detach(y))])
                     packer.all_reduce()
                 out["y"] = ek.detach(y)
+        elif workload == "cfg5":
+            n5 = N_PATHS_PER_GPU
+            tex0 = ekc.fmadd(synth.uniform_pm1(0, K_TABLE, 8), ekc.Float32(0.3), ekc.Float32(0.5))    # albedo in [0.2, 0.8)
+            packer = ekd.Packer([1, K_TABLE], self.dev) if ekd.active() else None
+
+            def step():
+                tex = ek.Float32(tex0)
+                ek.set_requires_gradient(tex)
+                loss = path_trace(ek, ekc, tex, n5, seed=0x853c49e6748fea9b + self.rank, first_lane=self.rank * n5)
+                ek.backward(loss)
+                g = ek.gradient(tex)
+                if packer:
+                    packer.pack([ekd.as_tensor(ek.detach(loss)), ekd.as_tensor(g)])
+                    packer.all_reduce()
+                out["y"] = ek.detach(loss)
+                out["grad"] = g
         elif workload == "cfg4":
             torch = self.torch
             nr = N_RAYS_PER_GPU                                    # weak: every rank traces its own 32 Mi rays
@@ -211,7 +285,7 @@ class Bench:
         torch.cuda.synchronize(); ekd.barrier()
         elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
         ms_per_step = elapsed / steps * 1e3
-        units = N_RAYS_PER_GPU * self.world if workload == "cfg4" else self.N
+        units = N_RAYS_PER_GPU * self.world if workload == "cfg4" else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
         gelem_s = units / (ms_per_step * 1e-3) / 1e9
 
         # per-kernel timing of the same step: one HIP event per launch on the library stream
@@ -244,7 +318,7 @@ class Bench:
                         "traffic": pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else None,
                         "traffic_source": "profiles/rocprof_pmc_r01.txt (separate rocprofv3 --pmc passes, same command)",
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
-                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload == "cfg4" else self.n, 1), 2),
+                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload == "cfg4" else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
                         "kernels": kernels}
         y_val = float(out["y"].numpy()[0])
@@ -351,7 +425,7 @@ def main():
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
     if b.world == 1 and not args.no_also:
-        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4"):
+        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4", "cfg5"):
             if w != args.workload:
                 r = b.run(w, max(5, args.steps // 2), 2, 3)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
