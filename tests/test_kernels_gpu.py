@@ -540,3 +540,13 @@ def test_scatter_add_tables_beyond_4mi_bins(capi, pattern, dt):
     capi.scatter_add(t, up(capi, vals), up(capi, idx), up(capi, mask))
     want = 1 + np.bincount(idx[mask != 0], weights=vals[mask != 0].astype(np.float64), minlength=K)
     assert np.array_equal(t.numpy().astype(np.int64), want.astype(np.int64))
+
+
+def test_out_of_memory_is_an_error_not_a_crash(capi):
+    """an allocation beyond the device capacity: the cache is released, the allocation retried once, then the call
+    fails with EK_ERR_OOM (the reference exits the process on a failed cudaMalloc, common.cu:268-286 / jit.cu:1716-1723)"""
+    small = capi.fill(np.float32, 1.0, 1 << 20)
+    with pytest.raises(RuntimeError) as e:
+        capi.Buf(np.float32, 1 << 38)                      # 1 TiB
+    assert "out of memory" in str(e.value)
+    assert float(capi.reduce("hsum", small).numpy()[0]) == float(1 << 20)      # the library keeps working
