@@ -169,7 +169,7 @@ namespace detail {
         using InstancePtr = typename Storage_::Value;
         using Mask = typename Storage_::MaskType;
 
-        call_support_base(const Storage &self) : self(self) { }
+        call_support_base(const Storage &storage) : self(storage) { }
         const Storage &self;
 
         /// func(instance, mask, args...) once per distinct non-null instance (array_call.h:124-193, device branch)
