@@ -12,7 +12,7 @@ Parity classes:
 import numpy as np
 import pytest
 
-from conftest import SPECIALS_F32, bits_equal, f32_inputs, f64_inputs, ulp_diff
+from conftest import bits_equal, f32_inputs, f64_inputs, ulp_diff
 
 pytestmark = pytest.mark.gpu
 

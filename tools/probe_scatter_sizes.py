@@ -2,8 +2,6 @@
 import os
 import sys
 
-import numpy as np
-
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from enoki_amd import capi, hiprt, synth  # noqa: E402
 import enoki_amd.hip as ek  # noqa: E402

@@ -1,4 +1,4 @@
-import sys, time, numpy as np
+import sys, numpy as np
 sys.path.insert(0, '/root/repo')
 from enoki_amd import capi, hiprt
 capi.init(); st = capi.stream()

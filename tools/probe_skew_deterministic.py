@@ -10,7 +10,6 @@ for name, idx in (("all_zero", np.zeros(n, np.uint32)), ("zipf", np.minimum(rng.
     t = capi.fill(np.float32, 0.0, K); v = capi.Buf.from_numpy(vals); i = capi.Buf.from_numpy(idx)
     ms = hiprt.time_region(st, lambda: capi.scatter_add(t, v, i, mode=1), iters=1, warmup=1)
     print(f"deterministic {name:10s} {ms:9.3f} ms per call  {n / ms / 1e6:8.3f} G adds/s", flush=True)
-import json
 for name, idx in (("all_zero", np.zeros(n, np.uint32)), ("zipf", np.minimum(rng.zipf(1.3, n) - 1, K - 1).astype(np.uint32))):
     t = capi.fill(np.float32, 0.0, K); v = capi.Buf.from_numpy(vals); i = capi.Buf.from_numpy(idx)
     capi.profile_begin()
