@@ -1,5 +1,5 @@
 import sys
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from enoki_amd import capi, synth
 import enoki_amd.hip as ek
 capi.init()

@@ -1,5 +1,5 @@
 import sys, numpy as np
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from enoki_amd import capi, hiprt
 capi.init(); st = capi.stream()
 n = 1 << 22; K = 1 << 20
