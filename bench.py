@@ -441,10 +441,13 @@ def main():
         line = {
             "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+            "scaling": "weak" if args.workload in ("cfg4", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}", "elements_total": b.N,
-                       "elements_per_gpu": b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
+            "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}",
+                       "elements_total": (N_RAYS_PER_GPU if args.workload == "cfg4" else N_PATHS_PER_GPU) * b.world
+                       if args.workload in ("cfg4", "cfg5") else b.N,
+                       "elements_per_gpu": N_RAYS_PER_GPU if args.workload == "cfg4" else N_PATHS_PER_GPU if args.workload == "cfg5" else b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
                        "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"]},
             "result_y": main_res["result_y"], "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,
         }
