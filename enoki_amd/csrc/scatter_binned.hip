@@ -103,22 +103,35 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(uint32_t *__restrict__ c
 // counts is [n_buckets][n_blocks]; workgroup b turns row b into its exclusive prefix and emits the row total
 __global__ __launch_bounds__(1024) void k_bin_scan_rows(uint32_t *__restrict__ counts, uint32_t *__restrict__ row_total,
                                                         unsigned n_blocks) {
-    __shared__ uint32_t part[1024];
+    // 1024 entries per step: wave64 shuffle scan, then a scan of the 16 wave totals (no 20-barrier Hillis-Steele)
+    __shared__ uint32_t wave_total[16];
+    __shared__ uint32_t step_total;
     uint32_t *row = counts + (size_t) blockIdx.x * n_blocks;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (unsigned base = 0; base < n_blocks; base += 1024) {
         unsigned i = base + threadIdx.x;
-        uint32_t v = i < n_blocks ? row[i] : 0u;
-        part[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            uint32_t add = threadIdx.x >= (unsigned) d ? part[threadIdx.x - d] : 0u;
-            __syncthreads();
-            part[threadIdx.x] += add;
-            __syncthreads();
+        uint32_t v = i < n_blocks ? row[i] : 0u, incl = v;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t up = __shfl_up(incl, d, 64);
+            if (lane >= d) incl += up;
         }
-        if (i < n_blocks) row[i] = carry + part[threadIdx.x] - v;
-        carry += part[1023];
+        if (lane == 63) wave_total[wave] = incl;
+        __syncthreads();
+        if (wave == 0) {
+            uint32_t w = lane < 16 ? wave_total[lane] : 0u, wi = w;
+#pragma unroll
+            for (int d = 1; d < 16; d <<= 1) {
+                uint32_t up = __shfl_up(wi, d, 64);
+                if (lane >= d) wi += up;
+            }
+            if (lane < 16) wave_total[lane] = wi - w;          // exclusive offset of every wave
+            if (lane == 15) step_total = wi;
+        }
+        __syncthreads();
+        if (i < n_blocks) row[i] = carry + wave_total[wave] + incl - v;
+        carry += step_total;
         __syncthreads();
     }
     if (threadIdx.x == 0) row_total[blockIdx.x] = carry;
