@@ -59,6 +59,62 @@ __global__ __launch_bounds__(256) void k_gather(T *__restrict__ out, const T *__
     out_store<T, N, true>(out, po, e, n, fast);
 }
 
+// Gather of a structure-of-arrays value (Array<HIPArray<T>, C> = C tables sharing one index array, array_struct.h:9-40):
+// the index and mask vectors are read once and every lane issues its C x N lookups back to back.
+template <typename T, int C> struct TablePtrs { const T *base[C]; T *out[C]; };
+
+template <typename T, typename I, int N, int C>
+__global__ __launch_bounds__(256) void k_gather_multi(TablePtrs<T, C> t, Arg<I> index, Arg<uint8_t> mask, size_t n, int vec_ok) {
+    const I si = index.vec ? I(0) : arg_scalar(index);
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const size_t e = lane_elem<N, 1>(0);
+    if (e >= n) return;
+    const bool fast = vec_ok && e + N <= n;
+    Pack<I, N> pi = arg_load<I, N, true>(index, si, e, n, fast);
+    Pack<uint8_t, N> pm = arg_load<uint8_t, N, true>(mask, sm, e, n, fast);
+    Pack<T, N> po[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            po[c].v[k] = (pm.v[k] && e + k < n) ? t.base[c][index_offset(pi.v[k])] : T(0);
+#pragma unroll
+    for (int c = 0; c < C; ++c) out_store<T, N, true>(t.out[c], po[c], e, n, fast);
+}
+
+template <typename T, typename I, int C>
+int gather_multi_launch(void *const *outs, const void *const *bases, const ek_operand *index, const ek_operand *mask, size_t n) {
+    constexpr int N = 16 / (sizeof(T) > sizeof(I) ? sizeof(T) : sizeof(I));
+    Arg<I> ii;
+    Arg<uint8_t> mm;
+    if (int rc = make_arg<I>(index, n, ii, "ek_hip_gather_multi")) return rc;
+    if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_gather_multi")) return rc;
+    TablePtrs<T, C> t;
+    int vec_ok = arg_aligned(ii) && arg_aligned(mm);
+    for (int c = 0; c < C; ++c) {
+        if (!outs[c] || !bases[c]) return fail(EK_ERR_INVALID, "ek_hip_gather_multi(): null pointer");
+        t.base[c] = (const T *) bases[c];
+        t.out[c] = (T *) outs[c];
+        vec_ok = vec_ok && aligned16(outs[c]);
+    }
+    Context &c = ctx();
+    unsigned grid = (unsigned) ((n + (size_t) 256 * N - 1) / ((size_t) 256 * N));
+    hipLaunchKernelGGL((k_gather_multi<T, I, N, C>), dim3(grid), dim3(256), 0, c.stream, t, ii, mm, n, vec_ok);
+    EK_LAUNCH_CHECK("gather", n, arg_bytes(ii, n) + arg_bytes(mm, n) + (size_t) C * 2 * n * sizeof(T));
+    return EK_OK;
+}
+
+template <typename T, typename I>
+int gather_multi_dispatch(int count, void *const *outs, const void *const *bases, const ek_operand *index, const ek_operand *mask,
+                          size_t n) {
+    switch (count) {
+        case 2: return gather_multi_launch<T, I, 2>(outs, bases, index, mask, n);
+        case 3: return gather_multi_launch<T, I, 3>(outs, bases, index, mask, n);
+        case 4: return gather_multi_launch<T, I, 4>(outs, bases, index, mask, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_gather_multi(): 2, 3 or 4 components expected, got %d", count);
+    }
+}
+
 // ---- scatter / scatter_add ---------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void atomic_add(T *addr, T v) {
     if constexpr (std::is_same_v<T, float>) {
@@ -250,6 +306,18 @@ int ek_hip_gather(int type, int index_type, void *out, const void *base, const e
         case 4: EK_INDEX_SWITCH(index_type, (gather_launch<uint32_t, I>(out, base, index, mask, n)), "ek_hip_gather()")
         case 8: EK_INDEX_SWITCH(index_type, (gather_launch<uint64_t, I>(out, base, index, mask, n)), "ek_hip_gather()")
         default: return fail(EK_ERR_INVALID, "ek_hip_gather(): unknown type %d", type);
+    }
+}
+
+int ek_hip_gather_multi(int type, int index_type, int count, void *const *outs, const void *const *bases,
+                        const ek_operand *index, const ek_operand *mask, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!outs || !bases) return fail(EK_ERR_INVALID, "ek_hip_gather_multi(): null pointer");
+    switch (type_size(type)) {
+        case 4: EK_INDEX_SWITCH(index_type, (gather_multi_dispatch<uint32_t, I>(count, outs, bases, index, mask, n)), "ek_hip_gather_multi()")
+        case 8: EK_INDEX_SWITCH(index_type, (gather_multi_dispatch<uint64_t, I>(count, outs, bases, index, mask, n)), "ek_hip_gather_multi()")
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_gather_multi(): 4- and 8-byte element types only");
     }
 }
 

@@ -421,6 +421,13 @@ template <typename T, enable_if_t<is_array_v<T>> = 0> inline T mulsign(const T &
 //  Initialization, shape
 // ---------------------------------------------------------------------------------------------
 
+namespace detail {
+    template <typename V, typename I, typename = void> struct has_gather_multi : std::false_type { };
+    template <typename V, typename I>
+    struct has_gather_multi<V, I, std::void_t<decltype(V::template gather_multi_<2>(
+        (const V *) nullptr, (V *) nullptr, std::declval<const I &>(), std::declval<const mask_t<V> &>()))>> : std::true_type { };
+}
+
 /// Structure-of-arrays support for user types; specialised by ENOKI_STRUCT_SUPPORT (see the end of this file)
 template <typename T, typename = int> struct struct_support { static constexpr bool Defined = false; };
 template <typename T> constexpr bool is_struct_v = struct_support<std::decay_t<T>>::Defined;
@@ -659,6 +666,11 @@ template <typename Value_, size_t Size_> struct Array : ArrayTag {
     template <bool IsPermute, typename Index, typename Mask>
     static Array gather_array_(const Array &source, const Index &index, const Mask &mask) {
         Array r;
+        if constexpr (detail::has_gather_multi<Value, Index>::value && !is_diff_array_v<Index>) {
+            // device components sharing one index array: one kernel instead of Size
+            if (Value::template gather_multi_<Size>(source.m_data, r.m_data, index, detail::as<mask_t<Value>>(mask)))
+                return r;
+        }
         for (size_t i = 0; i < Size; ++i) r.m_data[i] = gather<Value, 0, true, IsPermute>(source.m_data[i], index, mask);
         return r;
     }

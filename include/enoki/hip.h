@@ -416,6 +416,28 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return gather_<sizeof(Value)>(source.data(), detach(index), mask);
     }
 
+    /// N tables, one index / mask array: a single kernel that reads the indices once (Array<HIPArray, N> sources)
+    template <size_t N, typename Index>
+    static bool gather_multi_(const HIPArray *sources, HIPArray *results, const Index &index, const MaskType &mask) {
+        if constexpr (IsMask || (sizeof(Value) != 4 && sizeof(Value) != 8) || N < 2 || N > 4) {
+            return false;
+        } else {
+            for (size_t c = 0; c < N; ++c)
+                if (sources[c].size() <= 1) return false;          // broadcast components take the generic path
+            size_t n = broadcast_size(index.size(), mask.size());
+            void *outs[N];
+            const void *bases[N];
+            for (size_t c = 0; c < N; ++c) {
+                results[c] = empty_(n);
+                outs[c] = results[c].m_buf->ptr;
+                bases[c] = sources[c].data();
+            }
+            ek_operand oi = index.operand(), om = mask.operand();
+            detail::hip_check(ek_hip_gather_multi(Type, Index::Type, (int) N, outs, bases, &oi, &om, n), "gather_multi_");
+            return true;
+        }
+    }
+
     template <bool IsPermute, typename Index>
     static void scatter_array_(HIPArray &target, const HIPArray &value, const Index &index, const MaskType &mask) {
         target.make_unique();

@@ -163,6 +163,11 @@ EK_API int ek_hip_reverse(int type, void *out, const void *in, size_t n);
  * ------------------------------------------------------------------------------------------- */
 EK_API int ek_hip_gather(int type, int index_type, void *out, const void *base,
                          const ek_operand *index, const ek_operand *mask, size_t n);
+/* Gather of a structure-of-arrays value: `count` (2..4) tables of the same element type share ONE index / mask array
+ * (gather<Array<HIPArray<T>, N>>(...), array_struct.h:9-40 calls gather_ once per component).  outs[c][i] =
+ * mask[i] ? bases[c][index[i]] : 0.  4- and 8-byte element types. */
+EK_API int ek_hip_gather_multi(int type, int index_type, int count, void *const *outs, const void *const *bases,
+                               const ek_operand *index, const ek_operand *mask, size_t n);
 EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
                           const ek_operand *index, const ek_operand *mask, size_t n);
 /* mode 0: fastest -- LDS-binned accumulation for large inputs (needs `base_size`), hardware atomics otherwise;

@@ -314,3 +314,21 @@ def test_classification_and_safe_helpers(ekc, ek):
     ek.set_requires_gradient(xd)
     ek.backward(ek.hsum(ek.hypot(xd, yd)))
     assert np.allclose(ek.gradient(xd).numpy(), [0.6, 5.0 / 13.0], rtol=1e-6)
+
+
+def test_vector_gather_is_one_kernel(ekc):
+    """gather<Vector3f>: the three component tables share the index array -> one ek_hip_gather_multi launch"""
+    rng = np.random.default_rng(21)
+    n, k = 100003, 5000
+    comps = [rng.standard_normal(k).astype(np.float32) for _ in range(3)]
+    idx = rng.integers(0, k, n).astype(np.uint32); mask = rng.integers(0, 2, n).astype(np.uint8)
+    src = ekc.Vector3f(*[ekc.Float32(c) for c in comps])
+    before = ekc.hip_launch_count()
+    got = ekc.gather(src, ekc.UInt32(idx), ekc.Mask(mask))
+    assert ekc.hip_launch_count() - before == 1
+    for c, name in zip(comps, "xyz"):
+        assert bits_equal(getattr(got, name).numpy(), np.where(mask != 0, c[idx], np.float32(0)))
+    # a broadcast component falls back to the per-component path and still gives the right values
+    src2 = ekc.Vector3f(ekc.Float32(comps[0]), ekc.Float32(2.5), ekc.Float32(comps[2]))
+    got2 = ekc.gather(src2, ekc.UInt32(idx))
+    assert bits_equal(got2.x.numpy(), comps[0][idx]) and np.all(got2.y.numpy() == 2.5) and bits_equal(got2.z.numpy(), comps[2][idx])
