@@ -550,3 +550,35 @@ def test_out_of_memory_is_an_error_not_a_crash(capi):
         capi.Buf(np.float32, 1 << 38)                      # 1 TiB
     assert "out of memory" in str(e.value)
     assert float(capi.reduce("hsum", small).numpy()[0]) == float(1 << 20)      # the library keeps working
+
+
+@pytest.mark.parametrize("seed", range(24))
+def test_scatter_add_randomized_shapes(capi, seed):
+    """random (n, table size, mask density, index distribution, value type) through the size-dependent paths of
+    ek_hip_scatter_add (atomics / LDS direct / binned / two-level binned); small integer values make every path exact"""
+    rng = np.random.default_rng(100 + seed)
+    n = int(rng.choice([1, 7, 1000, (1 << 18) - 1, 1 << 18, (1 << 18) + 1, 300_007, 1 << 20, (1 << 21) + 12345]))
+    K = int(rng.choice([1, 2, 63, 1024, 1025, 16384, 16385, 100_000, (1 << 20) - 3, 1 << 22, (1 << 22) + 1, 5_000_011, 1 << 24]))
+    dt = [np.float32, np.uint32, np.int32][seed % 3]
+    kind = ["uniform", "clustered", "few", "ramp"][int(rng.integers(0, 4))]
+    if kind == "uniform":
+        idx = rng.integers(0, K, n)
+    elif kind == "clustered":
+        idx = np.clip(rng.normal(K * 0.7, max(K * 0.01, 1.0), n), 0, K - 1).astype(np.int64)
+    elif kind == "few":
+        idx = rng.choice(rng.integers(0, K, 5), n)
+    else:
+        idx = (np.arange(n) * 977) % K
+    idx = idx.astype(np.uint32)
+    density = float(rng.choice([0.0, 0.3, 1.0]))
+    mask = (rng.random(n) < density).astype(np.uint8)
+    vals = rng.integers(0, 3, n).astype(dt)
+    t = capi.fill(dt, 2, K)
+    use_mask = density < 1.0
+    if use_mask:
+        capi.scatter_add(t, up(capi, vals), up(capi, idx), up(capi, mask))
+    else:
+        capi.scatter_add(t, up(capi, vals), up(capi, idx))
+    sel = mask != 0 if use_mask else np.ones(n, bool)
+    want = 2 + np.bincount(idx[sel], weights=vals[sel].astype(np.float64), minlength=K)
+    assert np.array_equal(t.numpy().astype(np.int64), want.astype(np.int64)), (n, K, dt, kind, density)
