@@ -116,6 +116,8 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
           if (i >= a.size()) throw py::index_error();
           return a.coeff(i);
       })
+      .def("__setitem__", [](Array &a, const Mask &m, const Array &v) { masked(a, m) = v; },
+           "a[mask] = value: masked assignment (a select, array_base.h:144-157)")
       .def("size", [](const Array &a) { return a.size(); })
       .def("eval", [](Array &a) -> Array & { return a.eval(); }, py::return_value_policy::reference)
       .def("managed", [](Array &a) -> Array & { return a.managed(); }, py::return_value_policy::reference)
@@ -322,6 +324,7 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
       .def("__len__", [](const Vec &) { return N; })
       .def("__getitem__", [](const Vec &v, size_t i) { if (i >= N) throw py::index_error(); return v.coeff(i); })
       .def("__setitem__", [](Vec &v, size_t i, const Value &x) { if (i >= N) throw py::index_error(); v.coeff(i) = x; })
+      .def("__setitem__", [](Vec &v, const Mask &m, const Vec &x) { masked(v, m) = x; })
       .def("__repr__", [](const Vec &v) {
           std::string s = "[";
           for (size_t i = 0; i < N; ++i) s += array_repr(v.coeff(i)) + (i + 1 < N ? ",\n " : "]");

@@ -573,6 +573,7 @@ template <typename Value_, size_t Size_> struct Array : ArrayTag {
     const Value &coeff(size_t i) const { return m_data[i]; }
     Value &operator[](size_t i) { return m_data[i]; }
     const Value &operator[](size_t i) const { return m_data[i]; }
+    template <typename M, enable_if_t<is_mask_v<M>> = 0> auto operator[](const M &mask);
     Value &x() { return m_data[0]; }
     const Value &x() const { return m_data[0]; }
     Value &y() { static_assert(Size >= 2); return m_data[1]; }
@@ -835,6 +836,46 @@ template <typename M, typename T, enable_if_t<is_struct_v<T>> = 0> inline T sele
     struct_support<T>::apply3(r, t, f, [&](auto &dst, const auto &a, const auto &b) { dst = select(mask, a, b); });
     return r;
 }
+
+// ---------------------------------------------------------------------------------------------
+//  Masked assignment: masked(x, m) = v;  masked(x, m) += v;  x[m] = v   (array_masked.h, array_base.h:144-157 --
+//  on dynamic arrays every variant is a select)
+// ---------------------------------------------------------------------------------------------
+namespace detail {
+    template <typename T> struct MaskedArray {
+        using Mask = std::conditional_t<is_array_v<T> || is_struct_v<T>, mask_t<std::conditional_t<is_struct_v<T>, bool, T>>, bool>;
+        T &d;
+        Mask m;
+        template <typename V> void operator=(const V &v) { assign(T(v)); }
+        template <typename V> void operator+=(const V &v) { assign(d + T(v)); }
+        template <typename V> void operator-=(const V &v) { assign(d - T(v)); }
+        template <typename V> void operator*=(const V &v) { assign(d * T(v)); }
+        template <typename V> void operator/=(const V &v) { assign(d / T(v)); }
+        template <typename V> void operator|=(const V &v) { assign(d | T(v)); }
+        template <typename V> void operator&=(const V &v) { assign(d & T(v)); }
+        template <typename V> void operator^=(const V &v) { assign(d ^ T(v)); }
+    private:
+        void assign(const T &v) {
+            if constexpr (is_array_v<T> || is_struct_v<T>) d = select(m, v, d);
+            else if (m) d = v;
+        }
+    };
+    template <typename T, typename M> struct MaskedStruct {      // ENOKI_STRUCT types: field-wise select with any mask type
+        T &d;
+        M m;
+        void operator=(const T &v) { d = select(m, v, d); }
+    };
+}
+
+template <typename T, typename M, enable_if_t<!is_struct_v<T>> = 0> inline detail::MaskedArray<T> masked(T &value, const M &mask) {
+    return detail::MaskedArray<T>{ value, typename detail::MaskedArray<T>::Mask(mask) };
+}
+template <typename T, typename M, enable_if_t<is_struct_v<T>> = 0> inline detail::MaskedStruct<T, M> masked(T &value, const M &mask) {
+    return detail::MaskedStruct<T, M>{ value, mask };
+}
+
+template <typename Value_, size_t Size_> template <typename M, enable_if_t<is_mask_v<M>>>
+inline auto Array<Value_, Size_>::operator[](const M &mask) { return masked(*this, mask); }
 
 // ---------------------------------------------------------------------------------------------
 //  Autodiff helpers that are no-ops for non-differentiable types (autodiff.h:1414-1500)

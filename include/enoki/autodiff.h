@@ -692,6 +692,7 @@ template <typename Type_> struct DiffArray : ArrayTag {
     Scalar *data() { return m_value.data(); }
     Scalar coeff(size_t i) const { return m_value.coeff(i); }
     Scalar operator[](size_t i) const { return m_value.coeff(i); }
+    auto operator[](const MaskType &mask) { return masked(*this, mask); }
     DiffArray &eval() { m_value.eval(); return *this; }
     const DiffArray &eval() const { m_value.eval(); return *this; }
     DiffArray &managed() { m_value.managed(); return *this; }

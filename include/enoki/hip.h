@@ -541,6 +541,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return (Value) v;
     }
     Value operator[](size_t i) const { return coeff(i); }
+    /// x[mask] = value  (masked assignment proxy, array_base.h:144-157)
+    auto operator[](const MaskType &mask) { return masked(*this, mask); }
 
     /// Copy everything to the host (synchronises)
     std::vector<std::conditional_t<IsMask, uint8_t, Value>> to_host() const {

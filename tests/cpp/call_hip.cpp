@@ -180,3 +180,39 @@ int hip_struct_test(const uint8_t *which, const float *x_, const float *dt_, siz
         return -3;
     }
 }
+
+// ---- masked assignment: masked(x, m) = v, x[m] op= v on arrays, nested arrays, differentiable arrays and structs ----
+extern "C" __attribute__((visibility("default")))
+int hip_masked_test(const float *x_, size_t n, float *out_assign, float *out_add, float *out_vec_y, float *out_struct_t,
+                    float *out_grad) {
+    try {
+        FloatC x = FloatC::copy(x_, n);
+        MaskC m = x > 0.f;
+        FloatC a = x;
+        masked(a, m) = 5.f;                               // a = x > 0 ? 5 : x
+        to_host(a, out_assign, n);
+        FloatC b = x;
+        b[m] += x * 2.f;                                  // b = x > 0 ? 3x : x
+        b[!m] *= -1.f;                                    //     x <= 0: -x
+        to_host(b, out_add, n);
+        Vector3fC v(x, x + 1.f, 2.f);
+        masked(v, m) = Vector3fC(0.f, 7.f, 0.f);
+        to_host(v.y(), out_vec_y, n);                     // x > 0 ? 7 : x + 1
+        HitC h(v, x, m);
+        masked(h, !m) = HitC(v, x * 0.f - 3.f, m);        // x <= 0: t = -3
+        to_host(h.t, out_struct_t, n);
+        FloatD xd(x);
+        set_requires_gradient(xd);
+        FloatD yd = xd * xd;
+        yd[DiffArray<MaskC>(m)] = xd * 3.f;               // y = x > 0 ? 3x : x^2
+        backward(hsum(yd));
+        to_host(gradient(xd), out_grad, n);               // x > 0 ? 3 : 2x
+        float s = 1.f;
+        masked(s, true) = 4.f;
+        masked(s, false) = 9.f;
+        return s == 4.f ? 0 : -6;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hip_masked_test: %s\n", e.what());
+        return -3;
+    }
+}

@@ -119,3 +119,22 @@ def test_struct_arguments_and_structwise_memory_ops():
     assert np.array_equal(valid != 0, v)
     assert bits_equal(o["gx"], px[::-1].copy()) and bits_equal(o["gt"], t[::-1].copy())
     assert zs[0] == n and zs[1] == n
+
+
+def test_masked_assignment():
+    """masked(x, m) = v / x[m] op= v (array_masked.h; selects on dynamic arrays) for arrays, nested arrays, structs,
+    differentiable arrays and plain scalars"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libcall_hip.so"))
+    n = 10007
+    x = uniform_pm1(n, 41) * np.float32(2)
+    o = {k: np.empty(n, np.float32) for k in ("assign", "add", "vec_y", "struct_t", "grad")}
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    rc = lib.hip_masked_test(p(x), ctypes.c_size_t(n), p(o["assign"]), p(o["add"]), p(o["vec_y"]), p(o["struct_t"]), p(o["grad"]))
+    assert rc == 0, rc
+    f32 = np.float32
+    pos = x > 0
+    assert bits_equal(o["assign"], np.where(pos, f32(5), x))
+    assert bits_equal(o["add"], np.where(pos, x + x * f32(2), x * f32(-1)))
+    assert bits_equal(o["vec_y"], np.where(pos, f32(7), x + f32(1)))
+    assert bits_equal(o["struct_t"], np.where(pos, x, x * f32(0) - f32(3)))
+    assert np.allclose(o["grad"], np.where(pos, 3.0, 2.0 * x), rtol=1e-6)

@@ -332,3 +332,18 @@ def test_vector_gather_is_one_kernel(ekc):
     src2 = ekc.Vector3f(ekc.Float32(comps[0]), ekc.Float32(2.5), ekc.Float32(comps[2]))
     got2 = ekc.gather(src2, ekc.UInt32(idx))
     assert bits_equal(got2.x.numpy(), comps[0][idx]) and np.all(got2.y.numpy() == 2.5) and bits_equal(got2.z.numpy(), comps[2][idx])
+
+
+def test_masked_setitem(ekc, ek):
+    a = np.linspace(-1, 1, 1001).astype(np.float32)
+    x = ekc.Float32(a)
+    x[x > ekc.Float32(0.25)] = ekc.Float32(9.0)
+    assert np.array_equal(x.numpy(), np.where(a > 0.25, np.float32(9), a))
+    v = ekc.Vector3f(ekc.Float32(a), ekc.Float32(a), ekc.Float32(1.0))
+    v[ekc.Float32(a) < ekc.Float32(0.0)] = ekc.Vector3f(ekc.Float32(0.0), ekc.Float32(0.0), ekc.Float32(0.0))
+    assert np.array_equal(v.x.numpy(), np.where(a < 0, np.float32(0), a)) and np.array_equal(v.z.numpy(), np.where(a < 0, np.float32(0), np.float32(1)))
+    xd = ek.Float32(ekc.Float32(a)); ek.set_requires_gradient(xd)
+    y = xd * xd
+    y[xd > ek.Float32(0.0)] = xd * ek.Float32(3.0)
+    ek.backward(ek.hsum(y))
+    assert np.allclose(ek.gradient(xd).numpy(), np.where(a > 0, 3.0, 2.0 * a), rtol=1e-6)
