@@ -838,6 +838,22 @@ template <typename M, typename T, enable_if_t<is_struct_v<T>> = 0> inline T sele
 }
 
 // ---------------------------------------------------------------------------------------------
+//  Fully nested horizontal operations (array_router.h:1257-1330): reduce over every dimension down to a scalar
+// ---------------------------------------------------------------------------------------------
+template <typename T> inline bool all_nested(const T &a) {
+    if constexpr (std::is_same_v<T, bool>) return a; else return all_nested(all(a));
+}
+template <typename T> inline bool any_nested(const T &a) {
+    if constexpr (std::is_same_v<T, bool>) return a; else return any_nested(any(a));
+}
+template <typename T> inline bool none_nested(const T &a) { return !any_nested(a); }
+template <typename T> inline auto hsum_nested(const T &a) {
+    if constexpr (!is_array_v<T>) return a;
+    else if constexpr (std::decay_t<T>::Depth == 1) return hsum(a);
+    else return hsum_nested(hsum(a));
+}
+
+// ---------------------------------------------------------------------------------------------
 //  Masked assignment: masked(x, m) = v;  masked(x, m) += v;  x[m] = v   (array_masked.h, array_base.h:144-157 --
 //  on dynamic arrays every variant is a select)
 // ---------------------------------------------------------------------------------------------
