@@ -838,6 +838,41 @@ template <typename M, typename T, enable_if_t<is_struct_v<T>> = 0> inline T sele
 }
 
 // ---------------------------------------------------------------------------------------------
+//  Component shuffling of static arrays (array_router.h: head / tail / concat / shuffle)
+// ---------------------------------------------------------------------------------------------
+template <size_t K, typename V, size_t N> inline Array<V, K> head(const Array<V, N> &a) {
+    static_assert(K <= N, "head<K>(): K exceeds the array size");
+    Array<V, K> r;
+    for (size_t i = 0; i < K; ++i) r.coeff(i) = a.coeff(i);
+    return r;
+}
+template <size_t K, typename V, size_t N> inline Array<V, K> tail(const Array<V, N> &a) {
+    static_assert(K <= N, "tail<K>(): K exceeds the array size");
+    Array<V, K> r;
+    for (size_t i = 0; i < K; ++i) r.coeff(i) = a.coeff(N - K + i);
+    return r;
+}
+template <typename V, size_t N1, size_t N2> inline Array<V, N1 + N2> concat(const Array<V, N1> &a, const Array<V, N2> &b) {
+    Array<V, N1 + N2> r;
+    for (size_t i = 0; i < N1; ++i) r.coeff(i) = a.coeff(i);
+    for (size_t i = 0; i < N2; ++i) r.coeff(N1 + i) = b.coeff(i);
+    return r;
+}
+template <typename V, size_t N> inline Array<V, N + 1> concat(const Array<V, N> &a, const V &b) {
+    Array<V, N + 1> r;
+    for (size_t i = 0; i < N; ++i) r.coeff(i) = a.coeff(i);
+    r.coeff(N) = b;
+    return r;
+}
+template <size_t... Is, typename V, size_t N> inline Array<V, sizeof...(Is)> shuffle(const Array<V, N> &a) {
+    static_assert(((Is < N) && ...), "shuffle<...>(): index out of range");
+    Array<V, sizeof...(Is)> r;
+    size_t k = 0;
+    ((r.coeff(k++) = a.coeff(Is)), ...);
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------
 //  Fully nested horizontal operations (array_router.h:1257-1330): reduce over every dimension down to a scalar
 // ---------------------------------------------------------------------------------------------
 template <typename T> inline bool all_nested(const T &a) {
