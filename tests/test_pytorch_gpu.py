@@ -123,3 +123,16 @@ def test06_enoki_namespace():
     import enoki.cuda_autodiff as m
     assert m is ek2.hip_autodiff
     ek2.cuda_malloc_trim()
+
+
+def test07_readme_python_example():
+    import enoki as ek2
+    x = ek2.FloatD.linspace(0, 1, 1 << 12); ek2.set_requires_gradient(x)
+    y = ek2.hsum(ek2.atan2(x, ek2.FloatD(2.0)) * ek2.exp(x))
+    ek2.backward(y)
+    g = ek2.gradient(x)
+    xv = np.linspace(0, 1, 1 << 12)
+    want = np.exp(xv) * (np.arctan2(xv, 2.0) + 2.0 / (xv * xv + 4.0))
+    assert np.allclose(g.numpy(), want, rtol=1e-5) and np.allclose(g.torch().cpu().numpy(), g.numpy())
+    rng = ek2.PCG32C(ek2.UInt64C(42), ek2.UInt64C.arange(1 << 12)); u = rng.next_float32().numpy()
+    assert u.min() >= 0 and u.max() < 1
