@@ -127,6 +127,12 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
           if (!host.empty()) memcpy(out.mutable_data(), host.data(), host.size() * sizeof(Store));
           return out;
       })
+      .def("__array__", [](const Array &a, py::args, py::kwargs) {       // np.asarray(x): a host copy, like .numpy()
+          auto host = detach(a).to_host();
+          py::array_t<Store> out((py::ssize_t) host.size());
+          if (!host.empty()) memcpy(out.mutable_data(), host.data(), host.size() * sizeof(Store));
+          return out;
+      })
       .def("data_ptr", [](Array &a) { return (uintptr_t) a.data(); }, "raw device pointer")
       .def_property_readonly("__cuda_array_interface__", [](Array &a) {
           // consumed by torch.as_tensor(obj, device='cuda') on ROCm builds: zero-copy view

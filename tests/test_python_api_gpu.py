@@ -347,3 +347,10 @@ def test_masked_setitem(ekc, ek):
     y[xd > ek.Float32(0.0)] = xd * ek.Float32(3.0)
     ek.backward(ek.hsum(y))
     assert np.allclose(ek.gradient(xd).numpy(), np.where(a > 0, 3.0, 2.0 * a), rtol=1e-6)
+
+
+def test_numpy_array_protocol(ekc):
+    a = np.arange(10, dtype=np.float32)
+    x = ekc.Float32(a) * ekc.Float32(2.0)
+    assert np.array_equal(np.asarray(x), a * 2) and np.asarray(x).dtype == np.float32
+    assert np.array_equal(np.asarray(ekc.UInt32.arange(5)), np.arange(5, dtype=np.uint32))
