@@ -354,3 +354,11 @@ def test_numpy_array_protocol(ekc):
     x = ekc.Float32(a) * ekc.Float32(2.0)
     assert np.array_equal(np.asarray(x), a * 2) and np.asarray(x).dtype == np.float32
     assert np.array_equal(np.asarray(ekc.UInt32.arange(5)), np.arange(5, dtype=np.uint32))
+
+
+def test_converting_constructor_stays_on_the_device(ekc):
+    """Float32(UInt32 array) must be the cast kernel, not a host round trip through the numpy protocol"""
+    u = ekc.UInt32.arange(1 << 20)
+    before = ekc.hip_launch_count()
+    f = ekc.Float32(u)
+    assert ekc.hip_launch_count() - before == 1 and f[12345] == 12345.0
