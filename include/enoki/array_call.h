@@ -24,8 +24,8 @@
     lanes in ascending order within a group.  The partition is cached in the array (copies share it), like
     cuda.h:816-842.
 
-    Not provided: ENOKI_CALL_SUPPORT_GETTER (array_call.h:269-283) -- it gathers fields straight out of
-    the instances and therefore needs them in device-visible (managed) memory.
+    ENOKI_CALL_SUPPORT_GETTER (array_call.h:269-283) is provided for scalar data members: the reference gathers
+    the field out of managed instance memory on the device, here it is read on the host once per instance.
 */
 #pragma once
 
@@ -244,6 +244,29 @@ namespace detail {
             else                                                                                  \
                 return Base::dispatch(invoke, true, packed, std::make_index_sequence<sizeof...(Args)>()); \
         }
+
+/// `ptrs->name()`: per-lane value of a scalar data member of the instances (array_call.h:269-283).  The reference
+/// gathers the field straight out of managed instance memory; instances live in ordinary host memory here, so the
+/// field is read on the host once per distinct instance and scattered to that instance's lanes (null -> 0).
+#define ENOKI_CALL_SUPPORT_GETTER_TYPE(name, field, type)                                         \
+    HIPArray<type> name(Mask mask = Mask(true)) const {                                           \
+        using Return = HIPArray<type>;                                                            \
+        mask = mask.and_(self.neq_(Storage(nullptr)));                                            \
+        const auto &groups = self.partition_();                                                   \
+        if (groups.size() == 1 && groups[0].first != nullptr)                                     \
+            return Return::select_(mask, Return((type) groups[0].first->field), Return(type(0)));  \
+        Return result = zero<Return>(self.size());                                                \
+        for (const auto &[instance, permutation] : groups) {                                      \
+            if (instance == nullptr)                                                              \
+                continue;                                                                         \
+            scatter<0, true, true>(result, Return((type) instance->field), permutation,           \
+                                   detail::gather_argument(mask, permutation));                   \
+        }                                                                                         \
+        return result;                                                                            \
+    }
+
+#define ENOKI_CALL_SUPPORT_GETTER(name, field)                                                    \
+    ENOKI_CALL_SUPPORT_GETTER_TYPE(name, field, std::decay_t<decltype(std::declval<Class>().field)>)
 
 #define ENOKI_CALL_SUPPORT_END(Class_)                                                            \
         };                                                                                        \

@@ -26,6 +26,7 @@ struct Shape {
     virtual FloatD eval_d(const FloatD &x) const = 0;
     size_t lanes_seen = 0;
     size_t active_seen = 0;
+    double tag_value = 0.0;
 };
 
 struct Sine : Shape {
@@ -54,6 +55,8 @@ ENOKI_CALL_SUPPORT_METHOD(offset)
 ENOKI_CALL_SUPPORT_METHOD(id)
 ENOKI_CALL_SUPPORT_METHOD(touch)
 ENOKI_CALL_SUPPORT_METHOD(eval_d)
+ENOKI_CALL_SUPPORT_GETTER(lanes, lanes_seen)
+ENOKI_CALL_SUPPORT_GETTER_TYPE(tag, tag_value, float)
 ENOKI_CALL_SUPPORT_END(Shape)
 
 using ShapePtrC = HIPArray<Shape *>;
@@ -213,6 +216,31 @@ int hip_masked_test(const float *x_, size_t n, float *out_assign, float *out_add
         return s == 4.f ? 0 : -6;
     } catch (const std::exception &e) {
         fprintf(stderr, "hip_masked_test: %s\n", e.what());
+        return -3;
+    }
+}
+
+
+/// getters: per-lane value of a data member (float view of a double field, and a size_t counter)
+extern "C" __attribute__((visibility("default")))
+int hip_getter_test(const uint8_t *which, const uint8_t *mask_, size_t n, float *out_tag, float *out_tag_masked, uint64_t *out_lanes) {
+    try {
+        Sine s0(1.5f), s2(-0.5f);
+        Poly p1(0.25f, -2.f);
+        s0.tag_value = 10.5; p1.tag_value = -3.25; s2.tag_value = 7.0;
+        s0.lanes_seen = 11; p1.lanes_seen = 22; s2.lanes_seen = 33;
+        Shape *table[3] = { &s0, &p1, &s2 };
+        std::vector<Shape *> host(n);
+        for (size_t i = 0; i < n; ++i) host[i] = which[i] < 3 ? table[which[i]] : nullptr;
+        ShapePtrC shapes = ShapePtrC::copy(host.data(), n);
+        MaskC mask = MaskC::copy(mask_, n);
+        to_host(shapes->tag(), out_tag, n);
+        to_host(shapes->tag(mask), out_tag_masked, n);
+        auto lanes = shapes->lanes().to_host();
+        for (size_t i = 0; i < n; ++i) out_lanes[i] = lanes.size() == 1 ? lanes[0] : lanes[i];
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hip_getter_test: %s\n", e.what());
         return -3;
     }
 }

@@ -138,3 +138,18 @@ def test_masked_assignment():
     assert bits_equal(o["vec_y"], np.where(pos, f32(7), x + f32(1)))
     assert bits_equal(o["struct_t"], np.where(pos, x, x * f32(0) - f32(3)))
     assert np.allclose(o["grad"], np.where(pos, 3.0, 2.0 * x), rtol=1e-6)
+
+
+def test_call_support_getters():
+    """ENOKI_CALL_SUPPORT_GETTER: per-lane values of scalar data members (null pointer / masked lanes -> 0)"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libcall_hip.so"))
+    n = 5003
+    which = (hash_u32(np.arange(n, dtype=np.uint64), 51) % np.uint32(4)).astype(np.uint8)
+    which[which == 3] = 255
+    mask = (np.arange(n) % 3 != 0).astype(np.uint8)
+    tag = np.empty(n, np.float32); tagm = np.empty(n, np.float32); lanes = np.empty(n, np.uint64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.hip_getter_test(p(which), p(mask), ctypes.c_size_t(n), p(tag), p(tagm), p(lanes)) == 0
+    want = np.select([which == 0, which == 1, which == 2], [10.5, -3.25, 7.0], 0.0).astype(np.float32)
+    assert np.array_equal(tag, want) and np.array_equal(tagm, np.where(mask != 0, want, np.float32(0)))
+    assert np.array_equal(lanes, np.select([which == 0, which == 1, which == 2], [11, 22, 33], 0).astype(np.uint64))
