@@ -17,6 +17,7 @@
 
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
+#include <enoki/matrix.h>
 
 #include <sstream>
 
@@ -384,6 +385,58 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
             for (size_t i = 0; i < N; ++i) g.coeff(i) = gradient(a.coeff(i));
             return g;
         });
+    }
+    return cl;
+}
+
+/// Matrix<Value, N> (src/python/matrix.h of the reference): N x N entries in row-major order, products, transpose, ...
+template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py::module_ &m, const char *name) {
+    using Mat = Matrix<Value, N>;
+    using Vec = Array<Value, N>;
+    py::class_<Mat> cl(m, name);
+    cl.def(py::init<>())
+      .def(py::init<const Mat &>())
+      .def(py::init<const Value &>(), "diagonal matrix")
+      .def(py::init([](const std::vector<Value> &rows) {
+          if (rows.size() != N * N) throw py::value_error("expected N*N entries in row-major order");
+          Mat r;
+          for (size_t i = 0; i < N; ++i)
+              for (size_t j = 0; j < N; ++j)
+                  r(i, j) = rows[i * N + j];
+          return r;
+      }), "entries"_a, "N*N entries in row-major order")
+      .def_static("identity", [](size_t size) { return identity<Mat>(size); }, "size"_a = 1)
+      .def_static("from_cols", [](const std::vector<Vec> &cols) {
+          if (cols.size() != N) throw py::value_error("expected N columns");
+          Mat r;
+          for (size_t j = 0; j < N; ++j) r.col(j) = cols[j];
+          return r;
+      })
+      .def("__getitem__", [](const Mat &a, std::pair<size_t, size_t> ij) {
+          if (ij.first >= N || ij.second >= N) throw py::index_error();
+          return a(ij.first, ij.second);
+      })
+      .def("__setitem__", [](Mat &a, std::pair<size_t, size_t> ij, const Value &v) {
+          if (ij.first >= N || ij.second >= N) throw py::index_error();
+          a(ij.first, ij.second) = v;
+      })
+      .def("col", [](const Mat &a, size_t j) { if (j >= N) throw py::index_error(); return Vec(a.col(j)); })
+      .def("row", [](const Mat &a, size_t i) { if (i >= N) throw py::index_error(); return a.row(i); })
+      .def("__matmul__", [](const Mat &a, const Mat &b) { return Mat(a * b); })
+      .def("__matmul__", [](const Mat &a, const Vec &v) { return Vec(a * v); })
+      .def("__mul__", [](const Mat &a, const Mat &b) { return Mat(a * b); })
+      .def("__mul__", [](const Mat &a, const Vec &v) { return Vec(a * v); })
+      .def("__mul__", [](const Mat &a, const Value &s) { return Mat(a * s); })
+      .def("__rmul__", [](const Mat &a, const Value &s) { return Mat(s * a); })
+      .def("__add__", [](const Mat &a, const Mat &b) { return Mat(a + b); })
+      .def("__sub__", [](const Mat &a, const Mat &b) { return Mat(a - b); });
+    m.def("transpose", [](const Mat &a) { return Mat(transpose(a)); });
+    m.def("trace", [](const Mat &a) { return trace(a); });
+    m.def("frob", [](const Mat &a) { return frob(a); });
+    m.def("diag", [](const Mat &a) { return Vec(diag(a)); });
+    if constexpr (N == 2 || N == 3) {
+        m.def("det", [](const Mat &a) { return det(a); });
+        m.def("inverse", [](const Mat &a) { return Mat(inverse(a)); });
     }
     return cl;
 }

@@ -23,6 +23,9 @@ PYBIND11_MODULE(hip_autodiff, m) {
     bind_vector<FloatD, 2>(m, "Vector2f");
     bind_vector<FloatD, 3>(m, "Vector3f");
     bind_vector<FloatD, 4>(m, "Vector4f");
+    bind_matrix<FloatD, 2>(m, "Matrix2f");
+    bind_matrix<FloatD, 3>(m, "Matrix3f");
+    bind_matrix<FloatD, 4>(m, "Matrix4f");
 
     f32.def(py::init([](const FloatC &v) { return FloatD(v); }));
     f64.def(py::init([](const DoubleC &v) { return DoubleD(v); }));

@@ -1,0 +1,174 @@
+/*
+    enoki/matrix.h -- small square matrices over array types
+
+    Matrix<Value, N> is N columns of Array<Value, N> (column-major, like the reference's
+    include/enoki/matrix.h:20-150), so Matrix<HIPArray<float>, 4> is a structure of 16 device arrays and
+    `m * v` transforms as many vectors as the arrays have entries.  Products use the reference's
+    operation order -- per result column `c0 * s0`, then `fmadd(c_i, s_i, sum)` (matrix.h:152-180) -- so the
+    results are bit-identical to the CPU path for the same inputs.
+
+    Provided: element access m(i, j), column access, zero / identity / diag, matrix * matrix, matrix * vector,
+    matrix * scalar, transpose, trace, frob, det and inverse for N = 2, 3 (matrix.h:262-318; they contain one
+    rcp(), parity class C).  The 4 x 4 inverse / determinant (SIMD shuffle formulation, matrix.h:320-415) and the
+    polar decomposition are not provided.
+*/
+#pragma once
+
+#include <enoki/array.h>
+
+namespace enoki {
+
+template <typename Value_, size_t Size_> struct Matrix : Array<Array<Value_, Size_>, Size_> {
+    using Entry = Value_;
+    using Column = Array<Value_, Size_>;
+    using Base = Array<Column, Size_>;
+    static constexpr size_t Size = Size_;
+    static constexpr bool IsMatrix = true;
+
+    Matrix() = default;
+    Matrix(const Base &b) : Base(b) { }
+
+    /// Diagonal matrix with `v` on the diagonal (matrix.h:53-59)
+    Matrix(const Entry &v) {
+        for (size_t j = 0; j < Size; ++j)
+            for (size_t i = 0; i < Size; ++i)
+                this->coeff(j).coeff(i) = i == j ? v : Entry(scalar_t<Entry>(0));
+    }
+
+    /// From N columns
+    template <typename... Cols, enable_if_t<sizeof...(Cols) == Size_ && (std::is_same_v<std::decay_t<Cols>, Column> && ...)> = 0>
+    Matrix(const Cols &... cols) {
+        size_t k = 0;
+        ((this->coeff(k++) = cols), ...);
+    }
+
+    /// From N * N entries in ROW-major order, as one writes a matrix down (matrix.h:107-115)
+    template <typename... Args, enable_if_t<sizeof...(Args) == Size_ * Size_ && (Size_ > 1)> = 0>
+    Matrix(const Args &... args) {
+        Entry entries[] = { Entry(args)... };
+        for (size_t i = 0; i < Size; ++i)
+            for (size_t j = 0; j < Size; ++j)
+                this->coeff(j).coeff(i) = entries[i * Size + j];
+    }
+
+    Entry &operator()(size_t i, size_t j) { return this->coeff(j).coeff(i); }
+    const Entry &operator()(size_t i, size_t j) const { return this->coeff(j).coeff(i); }
+    Column &col(size_t j) { return this->coeff(j); }
+    const Column &col(size_t j) const { return this->coeff(j); }
+    Column row(size_t i) const {
+        Column r;
+        for (size_t j = 0; j < Size; ++j) r.coeff(j) = (*this)(i, j);
+        return r;
+    }
+};
+
+template <typename T> constexpr bool is_matrix_v = false;
+template <typename V, size_t N> constexpr bool is_matrix_v<Matrix<V, N>> = true;
+
+template <typename M, enable_if_t<is_matrix_v<M>> = 0> inline M identity(size_t size = 1) {
+    using E = typename M::Entry;
+    M r;
+    for (size_t j = 0; j < M::Size; ++j)
+        for (size_t i = 0; i < M::Size; ++i)
+            r(i, j) = i == j ? full<E>(scalar_t<E>(1), size) : zero<E>(size);
+    return r;
+}
+
+template <typename M, enable_if_t<is_matrix_v<M>> = 0> inline M diag(const typename M::Column &v) {
+    M r;
+    for (size_t j = 0; j < M::Size; ++j)
+        for (size_t i = 0; i < M::Size; ++i)
+            r(i, j) = i == j ? v.coeff(i) : typename M::Entry(scalar_t<typename M::Entry>(0));
+    return r;
+}
+
+template <typename V, size_t N> inline Array<V, N> diag(const Matrix<V, N> &m) {
+    Array<V, N> r;
+    for (size_t i = 0; i < N; ++i) r.coeff(i) = m(i, i);
+    return r;
+}
+
+/// matrix * matrix (matrix.h:152-167)
+template <typename V, size_t N> inline Matrix<V, N> operator*(const Matrix<V, N> &a, const Matrix<V, N> &b) {
+    using Column = typename Matrix<V, N>::Column;
+    Matrix<V, N> r;
+    for (size_t j = 0; j < N; ++j) {
+        Column sum = a.col(0) * Column(b(0, j));
+        for (size_t i = 1; i < N; ++i) sum = fmadd(a.col(i), Column(b(i, j)), sum);
+        r.col(j) = sum;
+    }
+    return r;
+}
+
+/// matrix * vector (matrix.h:169-178)
+template <typename V, size_t N> inline Array<V, N> operator*(const Matrix<V, N> &m, const Array<V, N> &v) {
+    using Column = Array<V, N>;
+    Column sum = m.col(0) * Column(v.coeff(0));
+    for (size_t i = 1; i < N; ++i) sum = fmadd(m.col(i), Column(v.coeff(i)), sum);
+    return sum;
+}
+
+/// matrix * scalar entry, scalar * matrix (matrix.h:179-194)
+template <typename V, size_t N> inline Matrix<V, N> operator*(const Matrix<V, N> &m, const V &s) {
+    Matrix<V, N> r;
+    for (size_t j = 0; j < N; ++j) r.col(j) = m.col(j) * Array<V, N>(s);
+    return r;
+}
+template <typename V, size_t N> inline Matrix<V, N> operator*(const V &s, const Matrix<V, N> &m) {
+    Matrix<V, N> r;
+    for (size_t j = 0; j < N; ++j) r.col(j) = Array<V, N>(s) * m.col(j);
+    return r;
+}
+template <typename V, size_t N> inline Matrix<V, N> operator+(const Matrix<V, N> &a, const Matrix<V, N> &b) {
+    Matrix<V, N> r;
+    for (size_t j = 0; j < N; ++j) r.col(j) = a.col(j) + b.col(j);
+    return r;
+}
+template <typename V, size_t N> inline Matrix<V, N> operator-(const Matrix<V, N> &a, const Matrix<V, N> &b) {
+    Matrix<V, N> r;
+    for (size_t j = 0; j < N; ++j) r.col(j) = a.col(j) - b.col(j);
+    return r;
+}
+
+template <typename V, size_t N> inline Matrix<V, N> transpose(const Matrix<V, N> &m) {
+    Matrix<V, N> r;
+    for (size_t j = 0; j < N; ++j)
+        for (size_t i = 0; i < N; ++i)
+            r(i, j) = m(j, i);
+    return r;
+}
+
+/// Sum of the diagonal, in index order (matrix.h:205-211)
+template <typename V, size_t N> inline V trace(const Matrix<V, N> &m) {
+    V r = m(0, 0);
+    for (size_t i = 1; i < N; ++i) r = r + m(i, i);
+    return r;
+}
+
+/// Squared Frobenius norm (matrix.h:213-219)
+template <typename V, size_t N> inline V frob(const Matrix<V, N> &m) {
+    Array<V, N> r = m.col(0) * m.col(0);
+    for (size_t i = 1; i < N; ++i) r = fmadd(m.col(i), m.col(i), r);
+    return hsum(r);
+}
+
+template <typename V> inline V det(const Matrix<V, 2> &m) { return fmsub(m(0, 0), m(1, 1), m(0, 1) * m(1, 0)); }
+
+template <typename V> inline Matrix<V, 2> inverse(const Matrix<V, 2> &m) {
+    V inv_det = rcp(fmsub(m(0, 0), m(1, 1), m(0, 1) * m(1, 0)));
+    return Matrix<V, 2>(m(1, 1) * inv_det, -m(0, 1) * inv_det,
+                        -m(1, 0) * inv_det, m(0, 0) * inv_det);
+}
+
+template <typename V> inline V det(const Matrix<V, 3> &m) { return dot(m.col(0), cross(m.col(1), m.col(2))); }
+
+/// Rows of the inverse are cross products of the columns (matrix.h:286-311)
+template <typename V> inline Matrix<V, 3> inverse_transpose(const Matrix<V, 3> &m) {
+    using Vector = Array<V, 3>;
+    Vector row0 = cross(m.col(1), m.col(2)), row1 = cross(m.col(2), m.col(0)), row2 = cross(m.col(0), m.col(1));
+    Vector inv_det = Vector(rcp(dot(m.col(0), row0)));
+    return Matrix<V, 3>(Vector(row0 * inv_det), Vector(row1 * inv_det), Vector(row2 * inv_det));
+}
+template <typename V> inline Matrix<V, 3> inverse(const Matrix<V, 3> &m) { return transpose(inverse_transpose(m)); }
+
+} // namespace enoki

@@ -23,6 +23,7 @@
 #include <enoki/dynamic.h>
 #include <enoki/autodiff.h>
 #include <enoki/random.h>
+#include <enoki/matrix.h>
 
 #include <chrono>
 #include <cstdint>
@@ -663,3 +664,48 @@ int ref_pcg32(uint64_t initstate, const uint64_t *initseq, size_t n, int steps, 
 }
 
 } // extern "C"
+
+/* Matrix<FloatX, N> (include/enoki/matrix.h): entries are passed row-major, entry (i, j) = row i * N + j of an
+   (N*N, n) array.  Outputs: a * b, a * v, trace(a), frob(a), and for N = 2, 3 det(a) and inverse(a). */
+namespace {
+template <size_t N> int ref_matrix_impl(const float *a_, const float *b_, const float *v_, size_t n, float *mm, float *mv,
+                                        float *tr, float *fr, float *dt, float *inv) {
+    using M = Matrix<FloatX, N>;
+    using V = Array<FloatX, N>;
+    M a, b; V v;
+    for (size_t i = 0; i < N; ++i) {
+        for (size_t j = 0; j < N; ++j) {
+            a(i, j) = FloatX::copy(a_ + (i * N + j) * n, n);
+            b(i, j) = FloatX::copy(b_ + (i * N + j) * n, n);
+        }
+        v[i] = FloatX::copy(v_ + i * n, n);
+    }
+    M c = a * b;
+    V w = a * v;
+    for (size_t i = 0; i < N; ++i) {
+        for (size_t j = 0; j < N; ++j)
+            store(FloatX(c(i, j)), mm + (i * N + j) * n, n);
+        store(FloatX(w[i]), mv + i * n, n);
+    }
+    store(FloatX(trace(a)), tr, n);
+    store(FloatX(frob(a)), fr, n);
+    if constexpr (N <= 3) {
+        store(FloatX(det(a)), dt, n);
+        M ia = inverse(a);
+        for (size_t i = 0; i < N; ++i)
+            for (size_t j = 0; j < N; ++j)
+                store(FloatX(ia(i, j)), inv + (i * N + j) * n, n);
+    }
+    return 0;
+}
+} // namespace
+
+extern "C" int ref_matrix(int size, const float *a, const float *b, const float *v, size_t n, float *mm, float *mv,
+                          float *tr, float *fr, float *dt, float *inv) {
+    switch (size) {
+        case 2: return ref_matrix_impl<2>(a, b, v, n, mm, mv, tr, fr, dt, inv);
+        case 3: return ref_matrix_impl<3>(a, b, v, n, mm, mv, tr, fr, dt, inv);
+        case 4: return ref_matrix_impl<4>(a, b, v, n, mm, mv, tr, fr, dt, inv);
+    }
+    return -1;
+}

@@ -79,6 +79,19 @@ pm = ((hash_u32(np.arange(1024, dtype=np.uint64), 5) & np.uint32(3)) != 0).astyp
 pc = R.pcg32(0x853c49e6748fea9b, seq, 4, pm, 1000003, -98765)
 np.savez_compressed(os.path.join(HERE, "pcg32.npz"), initseq=seq, mask=pm, **pc)
 
+# ---- Matrix<FloatX, N> (include/enoki/matrix.h), see oracle/ref_driver.cpp:ref_matrix ---------------------
+mats = {}
+for N in (2, 3, 4):
+    a = uniform_pm1(N * N * 1024, 300 + N).reshape(N * N, 1024) * np.float32(2)
+    b = uniform_pm1(N * N * 1024, 310 + N).reshape(N * N, 1024)
+    v = uniform_pm1(N * 1024, 320 + N).reshape(N, 1024)
+    for i in range(N):                       # diagonally dominant -> well conditioned inverses
+        a[i * N + i] += np.float32(4)
+    for k, val in R.matrix(N, a, b, v).items():
+        mats[f"m{N}_{k}"] = val
+    mats[f"m{N}_a"], mats[f"m{N}_b"], mats[f"m{N}_v"] = a, b, v
+np.savez_compressed(os.path.join(HERE, "matrix.npz"), **mats)
+
 # ---- integer ops -----------------------------------------------------------------------------------
 rng = np.random.default_rng(7)
 iops = {}

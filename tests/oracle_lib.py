@@ -149,6 +149,16 @@ class Checker:
                                    _p(o["bounded"]), ctypes.c_int64(delta), _p(o["after"]), _p(o["state"])), "pcg32")
         return o
 
+    def matrix(self, size, a, b, v):
+        """Matrix<FloatX, size> script of oracle/ref_driver.cpp:ref_matrix; a, b: (size*size, n) row-major entries, v: (size, n)"""
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); v = np.ascontiguousarray(v, np.float32)
+        n = a.shape[1]
+        o = {"mm": np.empty_like(a), "mv": np.empty_like(v), "trace": np.empty(n, np.float32), "frob": np.empty(n, np.float32),
+             "det": np.zeros(n, np.float32), "inv": np.zeros_like(a)}
+        self._chk(self._f("matrix")(ctypes.c_int(size), _p(a), _p(b), _p(v), ctypes.c_size_t(n), _p(o["mm"]), _p(o["mv"]),
+                                    _p(o["trace"]), _p(o["frob"]), _p(o["det"]), _p(o["inv"])), "matrix")
+        return o
+
 
 def _build(target):
     subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
