@@ -38,7 +38,7 @@ EXPORTS = [
     "ek_hip_last_error", "ek_hip_malloc", "ek_hip_free", "ek_hip_malloc_trim", "ek_hip_host_malloc",
     "ek_hip_host_free", "ek_hip_mem_get_info", "ek_hip_memcpy_to_device", "ek_hip_memcpy_to_host",
     "ek_hip_memcpy_device", "ek_hip_memset", "ek_hip_whos", "ek_hip_set_log_level", "ek_hip_log_level",
-    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi",
+    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_scatter_add_multi",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum",
@@ -300,6 +300,23 @@ def scatter_add(target, value, index, mask=True, n=None, mode=0):
     ov, oi, om = operand(value, target.dtype), operand(index), operand(mask, np.uint8)
     check(lib.ek_hip_scatter_add(target.ek, index.ek, ctypes.c_void_p(target.ptr), ctypes.c_size_t(target.n),
                                  ctypes.byref(ov), ctypes.byref(oi), ctypes.byref(om), ctypes.c_size_t(n), mode))
+
+
+def scatter_add_multi(targets, values, index, mask=True, weights=None, n=None, mode=0):
+    """targets[c][index[i]] += (weights[c] * values[c])[i] for all c: ONE pass over the indices (ek_hip_scatter_add_multi)"""
+    count = len(targets)
+    dt = targets[0].dtype
+    n = _n(index, mask, *values) if n is None else n
+    ovs = [operand(v, dt) for v in values]
+    ows = [None if (weights is None or w is None) else operand(w, dt) for w in (weights or [None] * count)]
+    OpPtr = ctypes.POINTER(Operand)
+    bases = (ctypes.c_void_p * count)(*[t.ptr for t in targets])
+    vals = (OpPtr * count)(*[ctypes.pointer(o) for o in ovs])
+    wts = (OpPtr * count)(*[ctypes.pointer(o) if o is not None else OpPtr() for o in ows])
+    oi, om = operand(index), operand(mask, np.uint8)
+    check(lib.ek_hip_scatter_add_multi(targets[0].ek, index.ek, count, bases, ctypes.c_size_t(targets[0].n), vals,
+                                       wts if weights is not None else None, ctypes.byref(oi), ctypes.byref(om),
+                                       ctypes.c_size_t(n), mode))
 
 
 def reduce(op, a):

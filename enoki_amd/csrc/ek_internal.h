@@ -134,6 +134,11 @@ template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n);
 
+bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array);
+template <typename T, typename I, int C>
+int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);
+
 // deterministic scatter_add: stable radix sort by index + sequential per-bin sums (scatter_binned.hip)
 template <typename T, typename I>
 int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,

@@ -390,3 +390,95 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
 }
 
 } // extern "C"
+
+namespace {
+template <typename T, typename I, int C>
+int scatter_add_multi_fused(void *const *bases, size_t base_size, const ek_operand *const *values, const ek_operand *const *weights,
+                            const ek_operand *index, const ek_operand *mask, size_t n) {
+    Arg<T> vv[C], ww[C];
+    Arg<I> ii;
+    Arg<uint8_t> mm;
+    unsigned weighted = 0;
+    T *tables[C];
+    for (int c = 0; c < C; ++c) {
+        if (int rc = make_arg<T>(values[c], n, vv[c], "ek_hip_scatter_add_multi")) return rc;
+        ww[c] = Arg<T>{ nullptr, T(1), 0u };
+        if (weights && weights[c]) {
+            if (int rc = make_arg<T>(weights[c], n, ww[c], "ek_hip_scatter_add_multi")) return rc;
+            weighted |= 1u << c;
+        }
+        tables[c] = (T *) bases[c];
+    }
+    if (int rc = make_arg<I>(index, n, ii, "ek_hip_scatter_add_multi")) return rc;
+    if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add_multi")) return rc;
+    return scatter_add_binned_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n);
+}
+
+template <typename T, typename I>
+int scatter_add_multi_fused_count(int count, void *const *bases, size_t base_size, const ek_operand *const *values,
+                                  const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask, size_t n) {
+    switch (count) {
+        case 1: return scatter_add_multi_fused<T, I, 1>(bases, base_size, values, weights, index, mask, n);
+        case 2: return scatter_add_multi_fused<T, I, 2>(bases, base_size, values, weights, index, mask, n);
+        case 3: return scatter_add_multi_fused<T, I, 3>(bases, base_size, values, weights, index, mask, n);
+        default: {
+            // four streams would cost the partition kernel its second workgroup per CU (152 VGPRs): run 2 + 2
+            if (int rc = scatter_add_multi_fused<T, I, 2>(bases, base_size, values, weights, index, mask, n)) return rc;
+            return scatter_add_multi_fused<T, I, 2>(bases + 2, base_size, values + 2, weights ? weights + 2 : nullptr, index, mask, n);
+        }
+    }
+}
+} // namespace
+
+extern "C" {
+
+int ek_hip_scatter_add_multi(int type, int index_type, int count, void *const *bases, size_t base_size,
+                             const ek_operand *const *values, const ek_operand *const *weights, const ek_operand *index,
+                             const ek_operand *mask, size_t n, int mode) {
+    if (int rc = ensure_init()) return rc;
+    if (count < 1 || count > 4) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi(): 1 to 4 streams expected, got %d", count);
+    if (!bases || !values || !index || !mask) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi(): null pointer");
+    for (int c = 0; c < count; ++c) {
+        if (!bases[c] || !values[c]) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi(): null pointer");
+        for (int d = 0; d < c; ++d)
+            if (bases[d] == bases[c]) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi(): the tables must be distinct");
+    }
+    if (n == 0) return EK_OK;
+    if (mode == 0 && ctx().tuning.deterministic) mode = 1;
+    const bool fused = mode == 0 && ctx().tuning.scatter_add_binned && (type == EK_F32 || type == EK_I32 || type == EK_U32) &&
+                       (index_type == EK_U32 || index_type == EK_I32) &&
+                       scatter_add_binned_multi_applicable(base_size, n, index->ptr != nullptr && index->size == n);
+    if (fused) {
+        if (type == EK_F32) {
+            if (index_type == EK_U32) return scatter_add_multi_fused_count<float, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
+            return scatter_add_multi_fused_count<float, int32_t>(count, bases, base_size, values, weights, index, mask, n);
+        }
+        bool any_weight = false;
+        for (int c = 0; c < count; ++c) any_weight = any_weight || (weights && weights[c]);
+        if (!any_weight) {      // integer streams carry no gradients; the fused path takes them unweighted
+            if (index_type == EK_U32) return scatter_add_multi_fused_count<uint32_t, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
+            return scatter_add_multi_fused_count<uint32_t, int32_t>(count, bases, base_size, values, weights, index, mask, n);
+        }
+    }
+    // everything else: one scatter_add per stream, products materialised first
+    for (int c = 0; c < count; ++c) {
+        const ek_operand *v = values[c];
+        ek_operand product;
+        void *tmp = nullptr;
+        if (weights && weights[c]) {
+            if (type != EK_F32 && type != EK_F64) return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add_multi(): weights need a floating point type");
+            const size_t m = (values[c]->ptr && values[c]->size != 1) || (weights[c]->ptr && weights[c]->size != 1) ? n : 1;
+            if (int rc = ek_hip_malloc(m * type_size(type), &tmp)) return rc;
+            int rc = ek_hip_binary(EK_SAFE_MUL, type, tmp, weights[c], values[c], m);
+            if (rc) { ek_hip_free(tmp); return rc; }
+            product = ek_operand{ tmp, 0, m };
+            v = &product;
+        }
+        int rc = ek_hip_scatter_add(type, index_type, bases[c], base_size, v, index, mask, n, mode);
+        if (tmp) ek_hip_free(tmp);
+        if (rc) return rc;
+    }
+    return EK_OK;
+}
+
+} // extern "C"

@@ -20,6 +20,7 @@
 // The result is the same set of additions as the atomic version in a different (unspecified) order
 // -- parity class D, like the reference's own GPU path.
 #include "ek_map.h"
+#include "ek_math.h"
 
 #include <algorithm>
 #include <vector>
@@ -69,6 +70,41 @@ __device__ __forceinline__ void load_tile(const I *__restrict__ index, const Arg
         }
     }
 }
+
+// Same addressing as load_tile for one more operand array (further value streams and their weights)
+template <typename T>
+__device__ __forceinline__ void load_tile_operand(const Arg<T> &a, T s, size_t base, size_t end, int vec_ok, T (&val)[kPerThread]) {
+    constexpr int kRuns = kPerThread / 4;
+    if (!a.vec) {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) val[k] = s;
+    } else if (vec_ok && base + kTile <= end) {
+#pragma unroll
+        for (int h = 0; h < kRuns; ++h) {
+            const size_t e = base + (size_t) h * (kTile / kRuns) + (size_t) threadIdx.x * 4;
+            Pack<T, 4> pv = pack_load<T, 4, true>(a.ptr + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) val[h * 4 + j] = pv.v[j];
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < kPerThread; ++k) {
+            size_t i = base + (size_t) k * kThreads + threadIdx.x;
+            val[k] = i < end ? a.ptr[i] : s;
+        }
+    }
+}
+
+// Value streams of one partition pass: `count` tables receive contributions through ONE index / mask array
+// (the adjoints of gathers that share their index array).  Stream c scatters value[c], or -- when bit c of
+// `weighted` is set -- safe_mul(weight[c], value[c]): the tape's edge product w * g fused into the read, so the
+// product array is never materialised (autodiff.cpp:1191-1199 for the formula).
+template <typename T, int C> struct BinStreams {
+    Arg<T> value[C];
+    Arg<T> weight[C];
+    T *pair_val[C];
+    unsigned weighted;
+};
 
 // ---- 1. count ------------------------------------------------------------------------------------
 template <typename I, int Shift = kBinShift>
@@ -181,10 +217,10 @@ __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__
 }
 
 // ---- 3. partition ----------------------------------------------------------------------------------
-template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t>
-__global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__ pair_idx, T *__restrict__ pair_val,
+template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t, int C = 1>
+__global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__ pair_idx, BinStreams<T, C> st,
                                                             const uint32_t *__restrict__ offsets,
-                                                            const uint32_t *__restrict__ bucket_base, Arg<T> value,
+                                                            const uint32_t *__restrict__ bucket_base,
                                                             const I *__restrict__ index, Arg<uint8_t> mask, size_t n,
                                                             size_t chunk, int n_buckets, int rep_shift, int vec_ok) {
     __shared__ uint32_t cursor[kMaxBuckets];       // next free global slot of this workgroup per bucket
@@ -200,14 +236,31 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__
     }
     __syncthreads();
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
-    const T sv = value.vec ? T(0) : arg_scalar(value);
+    T sv[C], sw[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        sv[c] = st.value[c].vec ? T(0) : arg_scalar(st.value[c]);
+        sw[c] = (((st.weighted >> c) & 1u) && !st.weight[c].vec) ? arg_scalar(st.weight[c]) : T(1);
+    }
     const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+
+    // values of stream c for the current tile (times their weights)
+    auto load_stream = [&](int c, size_t base, T (&val)[kPerThread]) {
+        load_tile_operand(st.value[c], sv[c], base, end, vec_ok, val);
+        if ((st.weighted >> c) & 1u) {
+            T w[kPerThread];
+            load_tile_operand(st.weight[c], sw[c], base, end, vec_ok, w);
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k) val[k] = dev::safe_mul(w[k], val[k]);
+        }
+    };
 
     for (size_t base = begin; base < end; base += kTile) {
         uint32_t ix[kPerThread], rank[kPerThread];
         T val[kPerThread];
         bool on[kPerThread];
-        load_tile<true>(index, mask, sm, value, sv, base, end, vec_ok, ix, on, val);
+        load_tile<false>(index, mask, sm, Arg<T>{ nullptr, T(0), 0u }, T(0), base, end, vec_ok, ix, on, (T *) nullptr);
+        load_stream(0, base, val);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
             rank[k] = on[k] ? atomicAdd(&tile_hist[((ix[k] >> Shift) << rep_shift) | rep], 1u) : 0u;
@@ -230,22 +283,38 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__
         }
         __syncthreads();
         const uint32_t tile_count = tile_off[kMaxBuckets - 1] + tile_hist[kMaxBuckets - 1];
-        // bucket-sorted staging
+        // bucket-sorted staging (rank becomes the position inside the sorted tile)
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k) {
             if (on[k]) {
                 uint32_t p = tile_off[((ix[k] >> Shift) << rep_shift) | rep] + rank[k];
+                rank[k] = p;
                 stage_idx[p] = ix[k];
                 stage_val[p] = val[k];
             }
         }
+        if constexpr (C > 1) load_stream(1, base, val);      // in flight during the first output pass
         __syncthreads();
         // coalesced runs: consecutive staged elements of one bucket go to consecutive global slots
         for (uint32_t j = threadIdx.x; j < tile_count; j += kThreads) {
             uint32_t key = stage_idx[j], b = key >> Shift;
             uint32_t g = cursor[b] + (j - tile_off[b << rep_shift]);
             pair_idx[g] = (OutIdx) (key & ((1u << Shift) - 1u));   // the bucket is implied by the position
-            pair_val[g] = stage_val[j];
+            st.pair_val[0][g] = stage_val[j];
+        }
+        // further streams reuse the sorted positions: restage the values, same output addresses
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < kPerThread; ++k)
+                if (on[k]) stage_val[rank[k]] = val[k];
+            if (c + 1 < C) load_stream(c + 1, base, val);
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < tile_count; j += kThreads) {
+                uint32_t b = stage_idx[j] >> Shift;
+                st.pair_val[c][cursor[b] + (j - tile_off[b << rep_shift])] = stage_val[j];
+            }
         }
         __syncthreads();
         if ((int) threadIdx.x < n_buckets) {
@@ -500,6 +569,9 @@ struct Scratch {
 template <typename T, typename I>
 int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                              size_t n);
+template <typename T, typename I, int C>
+int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);
 
 template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
@@ -544,6 +616,21 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
         return EK_OK;
     }
 
+    const Arg<T> values[1] = { value }, weights[1] = { Arg<T>{ nullptr, T(1), 0u } };
+    T *bases[1] = { base };
+    return scatter_add_binned_multi<T, I, 1>(bases, table_size, values, weights, 0u, index, mask, n);
+}
+
+// `C` value streams through one index / mask array into `C` tables of the same size (2 .. 256 buckets): one count, one
+// scan, one partition pass that reads the indices once; accumulate + fold per stream.
+template <typename T, typename I, int C>
+int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n) {
+    Context &c = ctx();
+    const int n_buckets = (int) ((table_size + kBins - 1) / kBins);
+    const size_t lds_bytes = (size_t) kBins * sizeof(T);
+    if (n_buckets < 2 || n_buckets > kMaxBuckets) return fail(EK_ERR_INVALID, "scatter_add_binned_multi(): table size out of range");
+
     // chunked passes over the input: a few workgroups per CU, chunks are multiples of the tile
     unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
     if (blocks == 0) blocks = 1;
@@ -551,15 +638,27 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     chunk = (chunk + kTile - 1) / kTile * kTile;
     blocks = (unsigned) ((n + chunk - 1) / chunk);
 
-    const int vec_ok = arg_aligned(index) && arg_aligned(mask) && arg_aligned(value);
+    int vec_ok = arg_aligned(index) && arg_aligned(mask);
+    size_t stream_bytes = 0;
+    BinStreams<T, C> st;
+    st.weighted = weighted;
+    for (int s = 0; s < C; ++s) {
+        st.value[s] = values[s];
+        st.weight[s] = weights[s];
+        vec_ok = vec_ok && arg_aligned(values[s]) && (!((weighted >> s) & 1u) || arg_aligned(weights[s]));
+        stream_bytes += arg_bytes(values[s], n) + (((weighted >> s) & 1u) ? arg_bytes(weights[s], n) : 0);
+    }
     int rep_shift = 0;
     while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
     const size_t count_entries = (size_t) n_buckets * blocks;
-    Scratch counts, pairs_idx, pairs_val, partials;
+    Scratch counts, pairs_idx, pairs_val[C], partials;
     // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1] | piece_prefix[kMaxBuckets + 1]
     if (int rc = counts.alloc((count_entries + 3 * kMaxBuckets + 2) * sizeof(uint32_t))) return rc;
     if (int rc = pairs_idx.alloc(n * sizeof(uint16_t))) return rc;
-    if (int rc = pairs_val.alloc(n * sizeof(T))) return rc;
+    for (int s = 0; s < C; ++s) {
+        if (int rc = pairs_val[s].alloc(n * sizeof(T))) return rc;
+        st.pair_val[s] = (T *) pairs_val[s].ptr;
+    }
     uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
     uint32_t *bucket_base = row_total + kMaxBuckets;
     uint32_t *piece_prefix = bucket_base + kMaxBuckets + 1;
@@ -574,19 +673,23 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, piece_prefix,
                        (const uint32_t *) row_total, n_buckets, target_pieces);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
-    hipLaunchKernelGGL((k_bin_partition<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint16_t *) pairs_idx.ptr,
-                       (T *) pairs_val.ptr, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, value, index.ptr,
+    hipLaunchKernelGGL((k_bin_partition<T, I, kBinShift, uint16_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                       (uint16_t *) pairs_idx.ptr, st, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, index.ptr,
                        mask, n, chunk, n_buckets, 0, vec_ok);
-    EK_LAUNCH_CHECK("scatter_add_partition", n, algo_bytes + n * (sizeof(uint16_t) + sizeof(T)));
+    EK_LAUNCH_CHECK("scatter_add_partition", n, stream_bytes + arg_bytes(index, n) + arg_bytes(mask, n) +
+                                                n * (sizeof(uint16_t) + C * sizeof(T)));
 
     if (int rc = partials.alloc((size_t) max_pieces * kBins * sizeof(T))) return rc;
-    hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3(max_pieces), dim3(kThreads), lds_bytes, c.stream,
-                       (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr, (const T *) pairs_val.ptr,
-                       (const uint32_t *) bucket_base, value, index.ptr, mask, n, n_buckets, (const uint32_t *) piece_prefix);
-    EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * kBins * sizeof(T));
-    hipLaunchKernelGGL((k_bin_fold_pieces<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
-                       (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size);
-    EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) max_pieces * kBins * sizeof(T) + 2 * table_size * sizeof(T));
+    for (int s = 0; s < C; ++s) {
+        // (the partials buffer is reused: the launches of one stream are ordered on the stream)
+        hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3(max_pieces), dim3(kThreads), lds_bytes, c.stream,
+                           (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr, (const T *) pairs_val[s].ptr,
+                           (const uint32_t *) bucket_base, values[s], index.ptr, mask, n, n_buckets, (const uint32_t *) piece_prefix);
+        EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * kBins * sizeof(T));
+        hipLaunchKernelGGL((k_bin_fold_pieces<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, bases[s],
+                           (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size);
+        EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) max_pieces * kBins * sizeof(T) + 2 * table_size * sizeof(T));
+    }
     return EK_OK;
 }
 
@@ -637,9 +740,14 @@ int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, co
     hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr,
                        (const uint32_t *) row_total, n_super, 0u);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
-    hipLaunchKernelGGL((k_bin_partition<T, I, kSuperShift, uint32_t>), dim3(blocks), dim3(kThreads), 0, c.stream,
-                       (uint32_t *) pairs_idx.ptr, (T *) pairs_val.ptr, (const uint32_t *) counts.ptr,
-                       (const uint32_t *) bucket_base, value, index.ptr, mask, n, chunk, n_super, 0, vec_ok);
+    BinStreams<T, 1> st;
+    st.value[0] = value;
+    st.weight[0] = Arg<T>{ nullptr, T(1), 0u };
+    st.pair_val[0] = (T *) pairs_val.ptr;
+    st.weighted = 0u;
+    hipLaunchKernelGGL((k_bin_partition<T, I, kSuperShift, uint32_t, 1>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                       (uint32_t *) pairs_idx.ptr, st, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, index.ptr,
+                       mask, n, chunk, n_super, 0, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_partition", n, arg_bytes(value, n) + arg_bytes(index, n) + arg_bytes(mask, n) +
                                                 n * (sizeof(uint32_t) + sizeof(T)));
 
@@ -674,8 +782,19 @@ bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_ar
            table_size <= (size_t) kMaxBuckets * kSuperBins && n < ((size_t) 1 << 32);
 }
 
+bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array) {
+    return scatter_add_binned_applicable(table_size, n, index_is_array) && table_size > (size_t) kBins &&
+           table_size <= (size_t) kMaxBuckets * kBins;
+}
+
 #define EK_BINNED_INSTANCE(T, I)                                                                                      \
-    template int scatter_add_binned<T, I>(T *, size_t, const Arg<T> &, const Arg<I> &, const Arg<uint8_t> &, size_t);
+    template int scatter_add_binned<T, I>(T *, size_t, const Arg<T> &, const Arg<I> &, const Arg<uint8_t> &, size_t);  \
+    template int scatter_add_binned_multi<T, I, 1>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);                     \
+    template int scatter_add_binned_multi<T, I, 2>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);                     \
+    template int scatter_add_binned_multi<T, I, 3>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);
 EK_BINNED_INSTANCE(float, uint32_t) EK_BINNED_INSTANCE(float, int32_t)
 EK_BINNED_INSTANCE(uint32_t, uint32_t) EK_BINNED_INSTANCE(uint32_t, int32_t)
 

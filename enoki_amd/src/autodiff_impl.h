@@ -41,6 +41,15 @@ template <typename Value> struct Tape<Value>::Special {
     virtual void forward(Detail *, Index /* target */, const Edge &) const {
         throw std::runtime_error("Tape::Special::forward(): not implemented");
     }
+    /// The adjoint of a (non-permuting) gather as data -- index array, mask, size of the gathered-from array -- so that
+    /// backward() can batch the scatter_adds of gathers that share their index array and fuse pending edge products
+    /// into them.  false: not such a gather.
+    struct GatherAdjoint {
+        const Offset *offset = nullptr;
+        const Mask *mask = nullptr;
+        size_t size = 0;
+    };
+    virtual bool gather_adjoint(GatherAdjoint &) const { return false; }
     virtual ~Special() = default;
 };
 
@@ -60,6 +69,7 @@ template <typename Value> struct Tape<Value>::Edge {
 template <typename Value> struct Tape<Value>::Node {
     std::string label;
     Value grad;
+    Value grad_weight;                // non-empty: the gradient is the pending product safe_mul(grad_weight, grad)
     std::vector<Edge> edges;          // incoming: this node = f(edge.source ...)
     std::vector<Index> consumers;     // nodes that have an edge from this node
     uint32_t ref_ext = 0, ref_int = 0;
@@ -119,7 +129,7 @@ template <typename Value> struct Tape<Value>::Detail {
             visited[k] = true;
             scheduled.push_back(k);
             Node &n = node(k);
-            if (clear_grad) n.grad = Value();
+            if (clear_grad) { n.grad = Value(); n.grad_weight = Value(); }
             if (backward) {
                 for (const Edge &e : n.edges) stack.push_back(e.source);
             } else {
@@ -136,6 +146,90 @@ template <typename Value> struct Tape<Value>::Detail {
 
     static void accumulate(Value &dst, const Value &v) {
         if (dst.empty()) dst = v; else dst = dst + v;
+    }
+
+    // ---- deferred adjoints of gathers (backward sweep) ---------------------------------------------------------
+    // The adjoint of `t = gather(source, offset, mask)` is `grad(source)[offset] += grad(t)`.  The sweep does not run
+    // it on the spot: consecutive gather nodes that share their index array AND mask (e.g. a = gather(A, idx),
+    // b = gather(B, idx)) are collected and handed to the backend as ONE multi-table scatter_add, which reads and
+    // bins the indices once.  A gather node's gradient may also still be a pending edge product w * g (see
+    // Node::grad_weight); the backend multiplies while it reads instead of materialising the product array.
+    // Backends without scatter_add_multi_ execute the same adjoints one by one -- identical results.
+    struct PendingScatter {
+        Index source;
+        Value grad, weight;
+        Offset offset;
+        Mask mask;
+        size_t size;
+    };
+    std::vector<PendingScatter> pending;
+    static constexpr size_t MaxPending = 4;
+
+    static constexpr bool HasScatterAddMulti = detail::has_scatter_add_multi<Value, Offset>::value;
+
+    template <typename T> static bool same_storage(const T &a, const T &b) {
+        if constexpr (HasScatterAddMulti) return a.same_storage_(b);
+        else return false;
+    }
+
+    /// Does `n` compute nothing but a non-permuting gather?
+    static bool is_gather_node(const Node &n, typename Special::GatherAdjoint &ga) {
+        return n.edges.size() == 1 && n.edges[0].is_special() && n.edges[0].special->gather_adjoint(ga);
+    }
+
+    bool pending_targets(Index i) const {
+        for (const PendingScatter &p : pending)
+            if (p.source == i) return true;
+        return false;
+    }
+
+    void defer_gather_adjoint(Index source, const Value &grad, const Value &weight, const typename Special::GatherAdjoint &ga) {
+        if (!pending.empty()) {
+            const PendingScatter &first = pending[0];
+            if (pending.size() == MaxPending || first.size != ga.size || pending_targets(source) ||
+                !same_storage(first.offset, *ga.offset) || !same_storage(first.mask, *ga.mask))
+                flush_pending();
+        }
+        pending.push_back(PendingScatter{ source, grad, weight, *ga.offset, *ga.mask, ga.size });
+    }
+
+    void flush_pending() {
+        if (pending.empty()) return;
+        std::vector<PendingScatter> work;
+        work.swap(pending);
+        Value *targets[MaxPending];
+        const Value *values[MaxPending], *weights[MaxPending];
+        bool any_weight = false;
+        for (size_t c = 0; c < work.size(); ++c) {
+            PendingScatter &p = work[c];
+            Value &grad_source = node(p.source).grad;
+            if (grad_source.empty())
+                grad_source = zero<Value>(p.size);
+            else if (grad_source.size() == 1 && p.size != 1)
+                set_slices(grad_source, p.size);           // pending broadcast contribution
+            else if (grad_source.size() != p.size)
+                throw std::runtime_error("Internal error in Gather::backward()!");
+            targets[c] = &grad_source;
+            values[c] = &p.grad;
+            weights[c] = p.weight.empty() ? nullptr : &p.weight;
+            any_weight = any_weight || weights[c];
+        }
+        if constexpr (HasScatterAddMulti) {
+            if (work.size() > 1 || any_weight) {
+                Value::scatter_add_multi_(work.size(), targets, values, weights, work[0].offset, work[0].mask);
+                return;
+            }
+        }
+        for (size_t c = 0; c < work.size(); ++c)
+            scatter_add(*targets[c], weights[c] ? safe_mul(*weights[c], *values[c]) : *values[c], work[c].offset, work[c].mask);
+    }
+
+    /// Turn a pending edge product into an ordinary gradient array
+    static void materialize_grad(Node &n) {
+        if (!n.grad_weight.empty()) {
+            n.grad = safe_mul(n.grad_weight, n.grad);
+            n.grad_weight = Value();
+        }
     }
 };
 
@@ -287,6 +381,14 @@ template <typename Value> auto Tape<Value>::append_gather(const Offset &offset, 
             if (grad_source.size() != size && grad_source.size() != 1)
                 throw std::runtime_error("Internal error in Gather::forward()!");
             Detail::accumulate(grad_target, gather<Value>(grad_source, offset, mask));
+        }
+
+        bool gather_adjoint(typename Special::GatherAdjoint &out) const override {
+            if (permute) return false;
+            out.offset = &offset;
+            out.mask = &mask;
+            out.size = size;
+            return true;
         }
     };
 
@@ -482,6 +584,7 @@ template <typename Value> void Tape<Value>::forward(Index index, bool free_graph
 template <typename Value> void Tape<Value>::backward(bool free_graph) {
     std::vector<Index> order = d->scheduled;
     d->clear_schedule();
+    d->pending.clear();             // (left over only if an earlier sweep threw)
 
     if (free_graph)
         for (Index i : order) inc_ref_ext(i);
@@ -489,6 +592,12 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
     for (auto it = order.rbegin(); it != order.rend(); ++it) {
         Index target_idx = *it;
         Node &target = d->node(target_idx);
+
+        // gather nodes queue their adjoint (see Detail::PendingScatter); anything else first runs what is queued
+        typename Special::GatherAdjoint gather_adjoint;
+        const bool is_gather = Detail::is_gather_node(target, gather_adjoint);
+        if (!is_gather || d->pending_targets(target_idx)) d->flush_pending();
+        if (!is_gather) Detail::materialize_grad(target);
 
         if (target.grad.size() != target.size) {
             if (target.grad.size() > 1)
@@ -517,12 +626,26 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
                 } else if (source.grad.empty()) {
                     // unit weight (add/sub/fmadd addend/...) or unit gradient (the seed of backward(), passed on
                     // through hsum): w * 1 and 1 * g -- share the other operand's buffer, no kernel
-                    source.grad = detail::is_unit_weight(edge.weight) ? target.grad
-                                : detail::is_unit_weight(target.grad) ? edge.weight
-                                                                      : safe_mul(edge.weight, target.grad);
+                    typename Special::GatherAdjoint ga;
+                    if (detail::is_unit_weight(edge.weight)) {
+                        source.grad = target.grad;
+                    } else if (detail::is_unit_weight(target.grad)) {
+                        source.grad = edge.weight;
+                    } else if (Detail::HasScatterAddMulti && source.size > 1 && Detail::is_gather_node(source, ga) &&
+                               std::max(edge.weight.size(), target.grad.size()) == source.size) {
+                        // the product is only ever read by the gather's adjoint: leave it pending, the scatter_add
+                        // multiplies while it reads (a second contribution materialises it, see below)
+                        source.grad = target.grad;
+                        source.grad_weight = edge.weight;
+                    } else {
+                        source.grad = safe_mul(edge.weight, target.grad);
+                    }
                 } else {
+                    Detail::materialize_grad(source);
                     source.grad = safe_fmadd(edge.weight, target.grad, source.grad);
                 }
+            } else if (is_gather) {
+                d->defer_gather_adjoint(edge.source, target.grad, target.grad_weight, gather_adjoint);
             } else {
                 edge.special->backward(d, target_idx, edge);
             }
@@ -537,12 +660,17 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
             if (!t.edges.empty()) {
                 t.edges.clear();
                 t.grad = Value();
+                t.grad_weight = Value();
             }
             dec_ref_ext(target_idx);
         } else if (target.ref_int > 0 && !target.edges.empty()) {
             target.grad = Value();
+            target.grad_weight = Value();
+        } else {
+            Detail::materialize_grad(target);   // the gradient stays visible
         }
     }
+    d->flush_pending();
 
     if (d->log_level >= 1)
         std::cerr << "autodiff: backward(): processed " << order.size() << "/" << (d->next_index - d->sweep_base)

@@ -450,6 +450,49 @@ template <typename Value_> struct HIPArray : ArrayTag {
         value.template scatter_add_<sizeof(Value)>(target.data(), detach(index), mask, target.size());
     }
 
+    /// `count` scatter_adds through ONE index / mask array into `count` arrays of equal size; weights[c] (may be null) is
+    /// multiplied onto values[c] inside the kernel with safe_mul semantics.  Issued by Tape::backward() for gathers that
+    /// share their index array: the indices are read and binned once (ek_hip_scatter_add_multi).
+    template <typename Index>
+    static void scatter_add_multi_(size_t count, HIPArray *const *targets, const HIPArray *const *values,
+                                   const HIPArray *const *weights, const Index &index, const MaskType &mask) {
+        constexpr size_t kMax = 4;
+        if (count == 0 || count > kMax) throw std::runtime_error("HIPArray::scatter_add_multi_(): 1 to 4 streams expected");
+        index.require_valid("scatter_add_multi_"); mask.require_valid("scatter_add_multi_");
+        size_t n = broadcast_size(index.size(), mask.size());
+        void *bases[kMax];
+        ek_operand ov[kMax], ow[kMax];
+        const ek_operand *pv[kMax], *pw[kMax];
+        bool any_weight = false;
+        for (size_t c = 0; c < count; ++c) {
+            values[c]->require_valid("scatter_add_multi_");
+            if (targets[c]->size() != targets[0]->size())
+                throw std::runtime_error("HIPArray::scatter_add_multi_(): the targets must have the same size");
+            n = broadcast_size(n, values[c]->size());
+            ov[c] = values[c]->operand();
+            pv[c] = &ov[c];
+            pw[c] = nullptr;
+            if (weights && weights[c]) {
+                weights[c]->require_valid("scatter_add_multi_");
+                n = broadcast_size(n, weights[c]->size());
+                ow[c] = weights[c]->operand();
+                pw[c] = &ow[c];
+                any_weight = true;
+            }
+            targets[c]->make_unique();
+            bases[c] = targets[c]->data();
+        }
+        ek_operand oi = index.operand(), om = mask.operand();
+        detail::hip_check(ek_hip_scatter_add_multi(Type, Index::Type, (int) count, bases, targets[0]->size(), pv,
+                                                   any_weight ? pw : nullptr, &oi, &om, n, 0), "scatter_add_multi_");
+    }
+
+    /// Same device buffer (or the same host-known scalar)?  Lets the tape recognise gathers that share an index array.
+    bool same_storage_(const HIPArray &o) const {
+        if (m_is_imm || o.m_is_imm) return m_is_imm && o.m_is_imm && imm_bits(m_imm) == imm_bits(o.m_imm);
+        return m_buf && m_buf == o.m_buf;
+    }
+
     // -----------------------------------------------------------------------------------------
     //  Horizontal operations (cuda.h:693-794)
     // -----------------------------------------------------------------------------------------

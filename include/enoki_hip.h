@@ -178,6 +178,16 @@ EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand
 EK_API int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size,
                               const ek_operand *value, const ek_operand *index,
                               const ek_operand *mask, size_t n, int mode);
+/* `count` (1..4) scatter_adds through ONE index / mask array into `count` tables of `base_size` entries each:
+ *     bases[c][index[i]] += weights && weights[c] ? safe_mul(*weights[c], *values[c])[i] : (*values[c])[i]
+ * This is what Tape::backward() issues for gathers that share their index array (the adjoint of gather is
+ * scatter_add, autodiff.cpp:362-381); a weight is the pending edge product w * g of the sweep (autodiff.cpp:871-876,
+ * safe_mul 1191-1199), fused into the read instead of being materialised first.  The indices are read and binned
+ * once for all tables.  Same modes and accumulation-order caveats as ek_hip_scatter_add; inputs the fused path does
+ * not cover are executed as `count` separate scatter_adds (same results). */
+EK_API int ek_hip_scatter_add_multi(int type, int index_type, int count, void *const *bases, size_t base_size,
+                                    const ek_operand *const *values, const ek_operand *const *weights,
+                                    const ek_operand *index, const ek_operand *mask, size_t n, int mode);
 
 /* ---------------------------------------------------------------------------------------------
  *  Horizontal ops.  Results of ek_hip_reduce* stay on the device (`out` = 1 element, async);

@@ -26,6 +26,14 @@ for name, prog in tape_lib.suite().items():
             out[f"g{i}"] = gi
     np.savez_compressed(os.path.join(HERE, f"tape_{name}.npz"), **out)
 
+for name, prog in tape_lib.gather_suite().items():
+    v, g = tape_lib.run(tape_lib.ref_fn(), prog)
+    out = {"value": v, "n_grads": np.array(len(g))}
+    for i, gi in enumerate(g):
+        if gi is not None:
+            out[f"g{i}"] = gi
+    np.savez_compressed(os.path.join(HERE, f"tape_gather_{name}.npz"), **out)
+
 # ---- elementwise ops on a fixed input set (incl. specials) -------------------------------------------
 n = 4096
 a = f32_inputs(n, seed=101, scale=20.0); b = f32_inputs(n, seed=102, scale=20.0)[::-1].copy(); c = f32_inputs(n, seed=103)

@@ -177,6 +177,49 @@ def suite(n=1000, k=37, seed=0):
     return P
 
 
+def gather_suite(n=1000, k=37, seed=5):
+    """Gather adjoints: the backward sweep batches the scatter_adds of gathers that share their index array and fuses the
+    pending edge product into them (autodiff_impl.h: PendingScatter).  All data are small integers, so every product
+    and every sum is exact in float32 -> the results do not depend on the accumulation order and all implementations
+    (reference build, host tape, GPU tape on any of its scatter_add paths) must agree BIT FOR BIT."""
+    rng = np.random.default_rng(seed)
+    ints = lambda lo, hi, size: rng.integers(lo, hi + 1, size).astype(np.float32)
+    A, B, C = ints(-8, 8, k), ints(-8, 8, k), ints(-8, 8, k)
+    D = ints(-8, 8, k + 13)
+    x, w, v = ints(-4, 4, n), ints(-4, 4, n), ints(-4, 4, n)
+    i0 = rng.integers(0, k, n).astype(np.uint32); i1 = rng.integers(0, k, n).astype(np.uint32)
+    m = max(n // 3, 1)
+    j1 = rng.integers(0, k, m).astype(np.uint32); j2 = rng.integers(0, m, n).astype(np.uint32)
+    P = {}
+    # a = A[i0], b = B[i0]: u = a x + b, out = u u -> g_b = 2u (shared buffer), g_a = x * 2u (pending product)
+    P["shared_idx_weighted"] = Program([(A, 1), (B, 1), (x, 0)], [("gather", 0, 0), ("gather", 1, 0), ("fmadd", 3, 2, 4), ("mul", 5, 5)],
+                                       index_inputs=[i0])
+    # three tables, all weighted
+    P["three_tables"] = Program([(A, 1), (B, 1), (C, 1), (x, 0), (w, 0), (v, 0)],
+                                [("gather", 0, 0), ("gather", 1, 0), ("gather", 2, 0), ("mul", 6, 3), ("mul", 7, 4), ("mul", 8, 5),
+                                 ("add", 9, 10), ("add", 12, 11), ("mul", 13, 13)], index_inputs=[i0])
+    # the gather node is used twice -> the pending product is materialised by the second contribution
+    P["two_consumers"] = Program([(A, 1), (x, 0), (w, 0)], [("gather", 0, 0), ("mul", 3, 1), ("mul", 3, 2), ("add", 4, 5), ("mul", 6, 6)],
+                                 index_inputs=[i0])
+    # gather from a gathered array: the inner adjoint must have run before the outer node's gradient is read
+    P["gather_of_gather"] = Program([(A, 1), (x, 0)], [("gather", 0, 0), ("gather", 2, 1), ("mul", 3, 1), ("mul", 4, 4)],
+                                    index_inputs=[j1, j2])
+    # the same table through the same index array twice (two streams must not target one table)
+    P["same_table_twice"] = Program([(A, 1), (x, 0), (w, 0)], [("gather", 0, 0), ("gather", 0, 0), ("mul", 3, 1), ("mul", 4, 2), ("add", 5, 6)],
+                                    index_inputs=[i0])
+    # different index arrays / different table sizes: separate scatter_adds
+    P["different_indices"] = Program([(A, 1), (B, 1), (x, 0), (w, 0)], [("gather", 0, 0), ("gather", 1, 1), ("mul", 4, 2), ("mul", 5, 3), ("add", 6, 7)],
+                                     index_inputs=[i0, i1])
+    P["different_sizes"] = Program([(A, 1), (D, 1), (x, 0), (w, 0)], [("gather", 0, 0), ("gather", 1, 0), ("mul", 4, 2), ("mul", 5, 3), ("add", 6, 7)],
+                                   index_inputs=[i0])
+    # broadcast gradients (hsum seeds) through a shared index array
+    P["broadcast_grads"] = Program([(A, 1), (B, 1)], [("gather", 0, 0), ("gather", 1, 0), ("add", 2, 3), ("hsum", 4)], index_inputs=[i0])
+    # scalar weight times vector gradient
+    P["scalar_weight"] = Program([(A, 1), (B, 1), (x, 0)], [("gather", 0, 0), ("gather", 1, 0), ("mulc", 3, 3.0), ("mul", 4, 2), ("add", 5, 6), ("mul", 7, 7)],
+                                 index_inputs=[i0])
+    return P
+
+
 TOLERANT = {"div_rcp_rsqrt", "sw_trig", "sw_hyp", "sw_sum", "sw_cbrt_pow"}   # sw_cbrt_pow: d pow / d base goes through log's rcp()
 CLASS_C_VALUES = {"sw_trig", "sw_hyp", "sw_sum"}   # the primal itself contains rcp() (tan, cot, sinh, cosh, tanh)          # not bit-comparable against the AVX2 reference build (class C)
 ORDER_DEPENDENT_ON_GPU = {            # contain hsum / hprod / fp scatter_add: GPU summation order differs (class D)

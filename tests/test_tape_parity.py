@@ -166,3 +166,52 @@ def test_random_vertical_programs_hip_tape_bit_exact(seed):
             rv, rg = tl.run(tl.ref_fn(), prog)
             assert bits_equal(rv, gv)
             assert same_grads(rg, gg, prog) if mode == "backward" else bits_equal(rg[0], gg[0]), (seed, mode)
+
+
+# ---- gather adjoints: batched / fused scatter_adds ------------------------------------------------------------------
+GATHER_NAMES = sorted(tl.gather_suite().keys())
+
+
+def _all_equal(ref, got):
+    rv, rg = ref; gv, gg = got
+    if not bits_equal(rv, gv):
+        return False
+    return all((a is None and b is None) or (a is not None and b is not None and bits_equal(a, b)) for a, b in zip(rg, gg))
+
+
+@pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref was not built (needs /root/reference)")
+@pytest.mark.parametrize("name", GATHER_NAMES)
+def test_gather_adjoints_host_tape_vs_reference(name):
+    prog = tl.gather_suite()[name]
+    assert _all_equal(tl.run(tl.ref_fn(), prog), tl.run(tl.host_lib().host_tape_program, prog)), name
+    assert tl.host_lib().host_tape_live_nodes() == 0
+
+
+@pytest.mark.parametrize("name", GATHER_NAMES)
+def test_gather_adjoints_golden_vs_host_tape(name):
+    prog = tl.gather_suite()[name]
+    z = np.load(os.path.join(GOLDEN, f"tape_gather_{name}.npz"))
+    hv, hg = tl.run(tl.host_lib().host_tape_program, prog)
+    assert bits_equal(z["value"], hv)
+    for i, g in enumerate(hg):
+        assert g is None or bits_equal(z[f"g{i}"], g), (name, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", GATHER_NAMES)
+@pytest.mark.parametrize("n,k", [(1000, 37), ((1 << 19) + 3, 70001), ((1 << 18) + 1, 1 << 20)])
+def test_gather_adjoints_hip_tape_bit_exact(name, n, k):
+    """small: atomic path per stream; large: the fused multi-table binned path (exact integer-valued data, so the
+    accumulation order does not matter and the comparison with the CPU tape is bit for bit)"""
+    prog = tl.gather_suite(n=n, k=k)[name]
+    import gc
+    gc.collect()
+    live_before = tl.hip_lib().hip_tape_live_nodes()
+    got = tl.run(tl.hip_lib().hip_tape_program, prog)
+    assert tl.hip_lib().hip_tape_live_nodes() == live_before, "tape leaked nodes"
+    if n == 1000:
+        z = np.load(os.path.join(GOLDEN, f"tape_gather_{name}.npz"))
+        assert bits_equal(z["value"], got[0])
+        for i, g in enumerate(got[1]):
+            assert g is None or bits_equal(z[f"g{i}"], g), (name, i)
+    assert _all_equal(tl.run(tl.host_lib().host_tape_program, prog), got), name
