@@ -52,8 +52,27 @@ def pmc(dirs):
         print(f"{name:112s} {grid:10d} {max(fe[0], wr[0]):8d} {rd:10.1f} {wm:10.1f}")
 
 
+def raw(dirs):
+    """per-launch averages of whatever counters the passes collected (large grids only)"""
+    agg = {}
+    for d in dirs:
+        for f in dbs(d):
+            cur = sqlite3.connect(f).cursor()
+            for name, counter, value, grid in cur.execute("select kernel_name, counter_name, value, grid_size from counters_collection"):
+                if grid < 65536:
+                    continue
+                s = agg.setdefault(short(name), {}).setdefault(counter, [0, 0.0])
+                s[0] += 1; s[1] += value
+    for name, c in agg.items():
+        print(name)
+        for counter, (cnt, total) in sorted(c.items()):
+            print(f"    {counter:28s} launches {cnt:5d}  avg {total / max(cnt, 1):16.1f}")
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "kernels":
         kernels(sys.argv[2])
+    elif sys.argv[1] == "raw":
+        raw(sys.argv[2:])
     else:
         pmc(sys.argv[2:])
