@@ -11,6 +11,7 @@
 //   * sin/cos/exp/log: array_math.h algorithms (csrc/ek_math.h), bit-exact.
 #include "ek_map.h"
 #include "ek_math.h"
+#include "ek_special.h"
 
 namespace ek {
 
@@ -18,7 +19,7 @@ namespace ek {
 static const char *const unary_names[EK_UNARY_COUNT] = {
     "neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
     "popcnt", "lzcnt", "tzcnt", "sign", "copy", "tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh",
-    "acosh", "atanh", "cbrt" };
+    "acosh", "atanh", "cbrt", "erf", "erfc", "erfinv", "i0e", "dawson", "erfi", "lgamma", "tgamma" };
 static const char *const binary_names[EK_BINARY_COUNT] = {
     "add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
     "atan2", "pow", "fmod", "ldexp" };
@@ -53,6 +54,8 @@ template <int Op, typename T> constexpr bool unary_supported() {
         case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
         case EK_TAN: case EK_COT: case EK_ASIN: case EK_ACOS: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_TANH:
         case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return is_fp<T>;
+        case EK_ERF: case EK_ERFC: case EK_ERFINV: case EK_I0E: case EK_DAWSON: case EK_ERFI: case EK_LGAMMA: case EK_TGAMMA:
+            return is_fp<T>;
         case EK_POPCNT: case EK_LZCNT: case EK_TZCNT: return is_int<T>;
         case EK_COPY: return true;
         default: return false;
@@ -128,6 +131,22 @@ template <int Op, typename T> struct UnaryOp {
             if constexpr (sizeof(T) == 4) return dev::atanh_f32(x); else return dev::atanh_f64(x);
         } else if constexpr (Op == EK_CBRT) {
             if constexpr (sizeof(T) == 4) return dev::cbrt_f32(x); else return dev::cbrt_f64(x);
+        } else if constexpr (Op == EK_ERF) {
+            if constexpr (is_fp<T>) return dev::erf_t<T>(x); else return x;
+        } else if constexpr (Op == EK_ERFC) {
+            if constexpr (is_fp<T>) return dev::erfc_t<T>(x); else return x;
+        } else if constexpr (Op == EK_ERFINV) {
+            if constexpr (is_fp<T>) return dev::erfinv_t<T>(x); else return x;
+        } else if constexpr (Op == EK_I0E) {
+            if constexpr (is_fp<T>) return dev::i0e_t<T>(x); else return x;
+        } else if constexpr (Op == EK_DAWSON) {
+            if constexpr (is_fp<T>) return dev::dawson_t<T>(x); else return x;
+        } else if constexpr (Op == EK_ERFI) {
+            if constexpr (is_fp<T>) return dev::erfi_t<T>(x); else return x;
+        } else if constexpr (Op == EK_LGAMMA) {
+            if constexpr (is_fp<T>) return dev::lgamma_t<T>(x); else return x;
+        } else if constexpr (Op == EK_TGAMMA) {
+            if constexpr (is_fp<T>) return dev::tgamma_t<T>(x); else return x;
         } else if constexpr (Op == EK_POPCNT) {
             if constexpr (sizeof(T) == 4) return (T) __popc((uint32_t) x); else return (T) __popcll((uint64_t) x);
         } else if constexpr (Op == EK_LZCNT) {
@@ -171,6 +190,8 @@ template <typename T> int unary_dispatch(int op, void *out, const ek_operand *a,
         EK_UNARY_CASE(EK_TAN) EK_UNARY_CASE(EK_COT) EK_UNARY_CASE(EK_ASIN) EK_UNARY_CASE(EK_ACOS)
         EK_UNARY_CASE(EK_ATAN) EK_UNARY_CASE(EK_SINH) EK_UNARY_CASE(EK_COSH) EK_UNARY_CASE(EK_TANH)
         EK_UNARY_CASE(EK_ASINH) EK_UNARY_CASE(EK_ACOSH) EK_UNARY_CASE(EK_ATANH) EK_UNARY_CASE(EK_CBRT)
+        EK_UNARY_CASE(EK_ERF) EK_UNARY_CASE(EK_ERFC) EK_UNARY_CASE(EK_ERFINV) EK_UNARY_CASE(EK_I0E) EK_UNARY_CASE(EK_DAWSON)
+        EK_UNARY_CASE(EK_ERFI) EK_UNARY_CASE(EK_LGAMMA) EK_UNARY_CASE(EK_TGAMMA)
         default: return fail(EK_ERR_INVALID, "ek_hip_unary(): unknown op %d", op);
     }
 }

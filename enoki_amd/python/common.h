@@ -18,6 +18,7 @@
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
+#include <enoki/special.h>
 
 #include <sstream>
 
@@ -247,6 +248,14 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
             m.def("acosh", [](const Array &a) { return acosh(a); });
             m.def("atanh", [](const Array &a) { return atanh(a); });
             m.def("cbrt", [](const Array &a) { return cbrt(a); });
+            m.def("erf", [](const Array &a) { return erf(a); });
+            m.def("erfc", [](const Array &a) { return erfc(a); });
+            m.def("erfinv", [](const Array &a) { return erfinv(a); });
+            m.def("i0e", [](const Array &a) { return i0e(a); });
+            m.def("dawson", [](const Array &a) { return dawson(a); });
+            m.def("erfi", [](const Array &a) { return erfi(a); });
+            m.def("lgamma", [](const Array &a) { return lgamma(a); });
+            m.def("tgamma", [](const Array &a) { return tgamma(a); });
             m.def("pow", [](const Array &a, const Array &b) { return pow(a, b); });
             m.def("pow", [](const Array &a, int b) { return pow(a, b); });
             m.def("fmod", [](const Array &a, const Array &b) { return fmod(a, b); });

@@ -239,6 +239,15 @@ template <typename Value_> struct HIPArray : ArrayTag {
     HIPArray acosh_() const { return unary(EK_ACOSH, "acosh_"); }
     HIPArray atanh_() const { return unary(EK_ATANH, "atanh_"); }
     HIPArray cbrt_() const { return unary(EK_CBRT, "cbrt_"); }
+    // special functions (enoki/special.h; reference include/enoki/special.h:56-312), one fused kernel each
+    HIPArray erf_() const { return unary(EK_ERF, "erf_"); }
+    HIPArray erfc_() const { return unary(EK_ERFC, "erfc_"); }
+    HIPArray erfinv_() const { return unary(EK_ERFINV, "erfinv_"); }
+    HIPArray i0e_() const { return unary(EK_I0E, "i0e_"); }
+    HIPArray dawson_() const { return unary(EK_DAWSON, "dawson_"); }
+    HIPArray erfi_() const { return unary(EK_ERFI, "erfi_"); }
+    HIPArray lgamma_() const { return unary(EK_LGAMMA, "lgamma_"); }
+    HIPArray tgamma_() const { return unary(EK_TGAMMA, "tgamma_"); }
     HIPArray atan2_(const HIPArray &x) const { return binary(EK_ATAN2, x, "atan2_"); }
     HIPArray pow_(const HIPArray &y) const { return binary(EK_POW, y, "pow_"); }
     HIPArray fmod_(const HIPArray &y) const { return binary(EK_FMOD, y, "fmod_"); }

@@ -58,6 +58,7 @@ typedef enum {
     EK_SIN, EK_COS, EK_EXP, EK_LOG, EK_POPCNT, EK_LZCNT, EK_TZCNT, EK_SIGN, EK_COPY,
     EK_TAN, EK_COT, EK_ASIN, EK_ACOS, EK_ATAN, EK_SINH, EK_COSH, EK_TANH, EK_ASINH, EK_ACOSH, EK_ATANH,
     EK_CBRT,
+    EK_ERF, EK_ERFC, EK_ERFINV, EK_I0E, EK_DAWSON, EK_ERFI, EK_LGAMMA, EK_TGAMMA,   /* special.h:56-312, f32 and f64 */
     EK_UNARY_COUNT
 } ek_unary_op;
 

@@ -577,6 +577,146 @@ static double atanh_f64(double x) {                                          /* 
 }
 
 /* ------------------------------------------------------------------------------------ */
+/*  Special functions (include/enoki/special.h:22-312): erf, erfc, erfinv, i0e, dawson,   */
+/*  erfi, lgamma, tgamma.  Same operation order as the reference's composition; rcp() and */
+/*  rsqrt() are spelled as exact divisions (class C versus rcpps / rsqrtps + Newton in    */
+/*  float32, identical in float64 where the reference divides too).                       */
+/* ------------------------------------------------------------------------------------ */
+static inline float sin_only_f32(float x) { float s; sincos_f32(x, &s, NULL); return s; }
+static inline double sin_only_f64(double x) { double s; sincos_f64(x, &s, NULL); return s; }
+
+#define ORC_SPECIAL_GENERIC(T, SUF, FMA, EXP, LOG, SQRT, FABS, RINT, SIN)                                             \
+    static inline T S4##SUF(T x, const double *c) {                                      /* poly4, array_math.h:39-45 */ \
+        T x2 = x * x, x4 = x2 * x2;                                                                                   \
+        return FMA(x2, FMA(x, (T) c[3], (T) c[2]), FMA(x, (T) c[1], (T) c[0]) + (T) c[4] * x4);                        \
+    }                                                                                                                 \
+    static inline T S5##SUF(T x, const double *c) {                                      /* poly5, :47-54 */            \
+        T x2 = x * x, x4 = x2 * x2;                                                                                   \
+        return FMA(x2, FMA(x, (T) c[3], (T) c[2]), FMA(x4, FMA(x, (T) c[5], (T) c[4]), FMA(x, (T) c[1], (T) c[0])));    \
+    }                                                                                                                 \
+    static inline T S6##SUF(T x, const double *c) {                                      /* poly6, :56-63 */            \
+        T x2 = x * x, x4 = x2 * x2;                                                                                   \
+        return FMA(x4, FMA(x2, (T) c[6], FMA(x, (T) c[5], (T) c[4])),                                                  \
+                   FMA(x2, FMA(x, (T) c[3], (T) c[2]), FMA(x, (T) c[1], (T) c[0])));                                   \
+    }                                                                                                                 \
+    static inline T S7##SUF(T x, const double *c) {                                      /* poly7, :65-73 */            \
+        T x2 = x * x, x4 = x2 * x2;                                                                                   \
+        return FMA(x4, FMA(x2, FMA(x, (T) c[7], (T) c[6]), FMA(x, (T) c[5], (T) c[4])),                                \
+                   FMA(x2, FMA(x, (T) c[3], (T) c[2]), FMA(x, (T) c[1], (T) c[0])));                                   \
+    }                                                                                                                 \
+    static inline T S8##SUF(T x, const double *c) {                                      /* poly8, :75-83 */            \
+        T x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;                                                                     \
+        return FMA(x4, FMA(x2, FMA(x, (T) c[7], (T) c[6]), FMA(x, (T) c[5], (T) c[4])),                                \
+                   FMA(x2, FMA(x, (T) c[3], (T) c[2]), FMA(x, (T) c[1], (T) c[0]) + (T) c[8] * x8));                   \
+    }                                                                                                                 \
+    static T chbevl##SUF(T x, const double *c, int n) {                                  /* special.h:22-36 */          \
+        T b0 = (T) c[0], b1 = 0, b2 = 0;                                                                              \
+        for (int i = 0; i < n; ++i) { b2 = b1; b1 = b0; b0 = FMA(x, b1, -(b2 - (T) c[i])); }                           \
+        return (b0 - b2) * (T) 0.5;                                                                                   \
+    }                                                                                                                 \
+    static T i0e##SUF(T x_) {                                                            /* special.h:168-218 */        \
+        static const double A[] = { -1.30002500998624804212E-8, 6.04699502254191894932E-8, -2.67079385394061173391E-7, \
+            1.11738753912010371815E-6, -4.41673835845875056359E-6, 1.64484480707288970893E-5,                         \
+            -5.75419501008210370398E-5, 1.88502885095841655729E-4, -5.76375574538582365885E-4,                        \
+            1.63947561694133579842E-3, -4.32430999505057594430E-3, 1.05464603945949983183E-2,                         \
+            -2.37374148058994688156E-2, 4.93052842396707084878E-2, -9.49010970480476444210E-2,                        \
+            1.71620901522208775349E-1, -3.04682672343198398683E-1, 6.76795274409476084995E-1 };                       \
+        static const double B[] = { 3.39623202570838634515E-9, 2.26666899049817806459E-8, 2.04891858946906374183E-7,  \
+            2.89137052083475648297E-6, 6.88975834691682398426E-5, 3.36911647825569408990E-3,                          \
+            8.04490411014108831608E-1 };                                                                              \
+        T x = FABS(x_);                                                                                               \
+        if (x > (T) 8) return chbevl##SUF(FMA((T) 32, (T) 1 / x, -(T) 2), B, 7) * ((T) 1 / SQRT(x));                   \
+        return chbevl##SUF(FMA(x, (T) 0.5, -(T) 2), A, 18);                                                           \
+    }                                                                                                                 \
+    static T erfinv##SUF(T x) {                                                          /* special.h:222-246 */        \
+        static const double c1[] = { 1.50140941, 0.246640727, -0.00417768164, -0.00125372503, 0.00021858087,          \
+                                     -4.39150654e-06, -3.5233877e-06, 3.43273939e-07, 2.81022636e-08 };               \
+        static const double c2[] = { 2.83297682, 1.00167406, 0.00943887047, -0.0076224613, 0.00573950773,             \
+                                     -0.00367342844, 0.00134934322, 0.000100950558, -0.000200214257 };                \
+        T w = -LOG(((T) 1 - x) * ((T) 1 + x));                                                                        \
+        T w1 = w - (T) 2.5, w2 = SQRT(w) - (T) 3;                                                                     \
+        T p1 = S8##SUF(w1, c1), p2 = S8##SUF(w2, c2);                                                                 \
+        return (w < (T) 5 ? p1 : p2) * x;                                                                             \
+    }                                                                                                                 \
+    static T dawson##SUF(T x) {                                                          /* special.h:249-265 */        \
+        static const double cn[] = { 1.00000080272429, 9.18170212243285e-2, 4.25835373536124e-2, 6.0536496345054e-3,  \
+                                     9.88555033724111e-4, 3.64943550840577e-5, 1.55942290996993e-5 };                 \
+        static const double cd[] = { 1.0, 7.58517175815194e-1, 2.81364355593059e-1, 6.81783097841267e-2,              \
+                                     1.13586116798019e-2, 1.92020805811771e-3, 5.74217664074868e-5,                   \
+                                     3.11884331363595e-5 };                                                           \
+        T x2 = x * x;                                                                                                 \
+        return S6##SUF(x2, cn) / S7##SUF(x2, cd) * x;                                                                 \
+    }                                                                                                                 \
+    static T erfi##SUF(T x) { return (T) 1.12837916709551257390 * dawson##SUF(x) * EXP(x * x); }   /* :268-272 */      \
+    static T lgamma##SUF(T x_) {                                                         /* special.h:275-309 */        \
+        static const double coeff[7] = { 1.000000000190015, 76.18009172947146, -86.50532032941677, 24.01409824083091, \
+                                         -1.231739572450155, 0.1208650973866179e-2, -0.5395239384953e-5 };            \
+        const T pi = (T) 3.14159265358979323846;                                                                      \
+        int reflect = x_ < (T) 0.5;                                                                                   \
+        T x = reflect ? -x_ : x_ - (T) 1, b = x + (T) 5 + (T) 0.5, sum = 0;                                           \
+        for (int i = 6; i >= 1; --i) sum += (T) coeff[i] / (x + (T) i);                                               \
+        sum += (T) coeff[0];                                                                                          \
+        T result = (((T) 0.91893853320467274178 + LOG(sum)) - b) + LOG(b) * (x + (T) 0.5);                             \
+        if (reflect) {                                                                                                \
+            result = LOG(FABS(pi / SIN(pi * x_))) - result;                                                           \
+            if (x_ == RINT(x_)) result = (T) INFINITY;                                                                \
+        }                                                                                                             \
+        return result;                                                                                                \
+    }                                                                                                                 \
+    static T tgamma##SUF(T x) { return EXP(lgamma##SUF(x)); }                             /* special.h:312 */
+
+ORC_SPECIAL_GENERIC(float, _sf32, fmaf, exp_f32, log_f32, sqrtf, fabsf, rintf, sin_only_f32)
+ORC_SPECIAL_GENERIC(double, _sf64, fma, exp_f64, log_f64, sqrt, fabs, rint, sin_only_f64)
+
+/* erf / erfc: special.h:56-165; *_core = the function before the other one's fix-up (Recurse = false) */
+static float erf_core_f32(float x) {
+    static const double c[] = { 1.128379165726710e+0, -3.761262582423300e-1, 1.128358514861418e-1, -2.685381193529856e-2,
+                                5.188327685732524e-3, -8.010193625184903e-4, 7.853861353153693e-5 };
+    return S6_sf32(x * x, c) * x;
+}
+static float erfc_core_f32(float x) {
+    static const double cs[] = { 5.638259427386472e-1, -2.741127028184656e-1, 3.404879937665872e-1, -4.944515323274145e-1,
+                                 6.210004621745983e-1, -5.824733027278666e-1, 3.687424674597105e-1, -1.387039388740657e-1,
+                                 2.326819970068386e-2 };
+    static const double cl[] = { 5.641895067754075e-1, -2.820767439740514e-1, 4.218463358204948e-1, -1.015265279202700e+0,
+                                 2.921019019210786e+0, -7.495518717768503e+0, 1.297719955372516e+1, -1.047766399936249e+1 };
+    float xa = fabsf(x), z = exp_f32(-x * x), q = 1.0f / xa, y = q * q;
+    float r = z * q * (xa > 2.0f ? S7_sf32(y, cl) : S8_sf32(y, cs));
+    return x < 0.0f ? 2.0f - r : r;
+}
+static float erf_f32(float x) { return fabsf(x) > 1.0f ? 1.0f - erfc_core_f32(x) : erf_core_f32(x); }
+static float erfc_f32(float x) { return fabsf(x) < 1.0f ? 1.0f - erf_core_f32(x) : erfc_core_f32(x); }
+
+static double erf_core_f64(double x) {
+    static const double p[] = { 5.55923013010394962768e4, 7.00332514112805075473e3, 2.23200534594684319226e3,
+                                9.00260197203842689217e1, 9.60497373987051638749e0 };
+    static const double q[] = { 4.92673942608635921086e4, 2.26290000613890934246e4, 4.59432382970980127987e3,
+                                5.21357949780152679795e2, 3.35617141647503099647e1, 1.00000000000000000000e0 };
+    double z = x * x;
+    return S4_sf64(z, p) / S5_sf64(z, q) * x;
+}
+static double erfc_core_f64(double x) {
+    static const double ps[] = { 5.57535335369399327526e2, 1.02755188689515710272e3, 9.34528527171957607540e2,
+                                 5.26445194995477358631e2, 1.96520832956077098242e2, 4.86371970985681366614e1,
+                                 7.46321056442269912687e0, 5.64189564831068821977e-1, 2.46196981473530512524e-10 };
+    static const double qs[] = { 5.57535340817727675546e2, 1.65666309194161350182e3, 2.24633760818710981792e3,
+                                 1.82390916687909736289e3, 9.75708501743205489753e2, 3.54937778887819891062e2,
+                                 8.67072140885989742329e1, 1.32281951154744992508e1, 1.00000000000000000000e0 };
+    static const double pl[] = { 2.97886665372100240670e0, 7.40974269950448939160e0, 6.16021097993053585195e0,
+                                 5.01905042251180477414e0, 1.27536670759978104416e0, 5.64189583547755073984e-1 };
+    static const double ql[] = { 3.36907645100081516050e0, 9.60896809063285878198e0, 1.70814450747565897222e1,
+                                 1.20489539808096656605e1, 9.39603524938001434673e0, 2.26052863220117276590e0,
+                                 1.00000000000000000000e0 };
+    double xa = fabs(x), z = exp_f64(-x * x);
+    int large = xa > 8.0;
+    double r = (z * (large ? S5_sf64(xa, pl) : S8_sf64(xa, ps))) / (large ? S6_sf64(xa, ql) : S8_sf64(xa, qs));
+    if (!(z != 0.0)) r = 0.0;
+    return x < 0.0 ? 2.0 - r : r;
+}
+static double erf_f64(double x) { return fabs(x) > 1.0 ? 1.0 - erfc_core_f64(x) : erf_core_f64(x); }
+static double erfc_f64(double x) { return fabs(x) < 1.0 ? 1.0 - erf_core_f64(x) : erfc_core_f64(x); }
+
+/* ------------------------------------------------------------------------------------ */
 /*  generic dispatch helpers                                                              */
 /* ------------------------------------------------------------------------------------ */
 
@@ -617,6 +757,14 @@ static int unary_f32(const char *op, const float *a, float *o, size_t n) {
     if (is(op, "acosh")) LOOP(acosh_f32(x));
     if (is(op, "atanh")) LOOP(atanh_f32(x));
     if (is(op, "cbrt"))  LOOP(cbrt_f32(x));
+    if (is(op, "erf"))    LOOP(erf_f32(x));
+    if (is(op, "erfc"))   LOOP(erfc_f32(x));
+    if (is(op, "erfinv")) LOOP(erfinv_sf32(x));
+    if (is(op, "i0e"))    LOOP(i0e_sf32(x));
+    if (is(op, "dawson")) LOOP(dawson_sf32(x));
+    if (is(op, "erfi"))   LOOP(erfi_sf32(x));
+    if (is(op, "lgamma")) LOOP(lgamma_sf32(x));
+    if (is(op, "tgamma")) LOOP(tgamma_sf32(x));
 #undef LOOP
     if (is(op, "sin")) { for (size_t i = 0; i < n; ++i) sincos_f32(a[i], &o[i], NULL); return 0; }
     if (is(op, "cos")) { for (size_t i = 0; i < n; ++i) sincos_f32(a[i], NULL, &o[i]); return 0; }
@@ -646,6 +794,14 @@ static int unary_f64(const char *op, const double *a, double *o, size_t n) {
     if (is(op, "acosh")) LOOP(acosh_f64(x));
     if (is(op, "atanh")) LOOP(atanh_f64(x));
     if (is(op, "cbrt"))  LOOP(cbrt_f64(x));
+    if (is(op, "erf"))    LOOP(erf_f64(x));
+    if (is(op, "erfc"))   LOOP(erfc_f64(x));
+    if (is(op, "erfinv")) LOOP(erfinv_sf64(x));
+    if (is(op, "i0e"))    LOOP(i0e_sf64(x));
+    if (is(op, "dawson")) LOOP(dawson_sf64(x));
+    if (is(op, "erfi"))   LOOP(erfi_sf64(x));
+    if (is(op, "lgamma")) LOOP(lgamma_sf64(x));
+    if (is(op, "tgamma")) LOOP(tgamma_sf64(x));
 #undef LOOP
     if (is(op, "sin")) { for (size_t i = 0; i < n; ++i) sincos_f64(a[i], &o[i], NULL); return 0; }
     if (is(op, "cos")) { for (size_t i = 0; i < n; ++i) sincos_f64(a[i], NULL, &o[i]); return 0; }

@@ -24,6 +24,7 @@
 #include <enoki/autodiff.h>
 #include <enoki/random.h>
 #include <enoki/matrix.h>
+#include <enoki/special.h>
 
 #include <chrono>
 #include <cstdint>
@@ -102,6 +103,14 @@ template <typename T> int unary_float(const char *op, const T *a_, T *out, size_
     else if (is(op, "acosh")) r = acosh(a);
     else if (is(op, "atanh")) r = atanh(a);
     else if (is(op, "cbrt"))  r = cbrt(a);
+    else if (is(op, "erf"))    r = erf(a);
+    else if (is(op, "erfc"))   r = erfc(a);
+    else if (is(op, "erfinv")) r = erfinv(a);
+    else if (is(op, "i0e"))    r = i0e(a);
+    else if (is(op, "dawson")) r = dawson(a);
+    else if (is(op, "erfi"))   r = erfi(a);
+    else if (is(op, "lgamma")) r = lgamma(a);
+    else if (is(op, "tgamma")) r = tgamma(a);
     else if (is(op, "sign"))  r = sign(a);
     else return -1;
     store(r, out, n);

@@ -81,6 +81,20 @@ for op in ["atan2", "pow", "fmod"]:
     ops64[f"sw_{op}"] = R.binary(op, d, d2)
 np.savez_compressed(os.path.join(HERE, "elementwise_f64.npz"), **ops64)
 
+# ---- special functions (include/enoki/special.h:56-312) ------------------------------------------------
+sp = {}
+srng = np.random.default_rng(77)
+for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+    edge = np.array([0, -0.0, 1, -1, 0.5, -0.5, 2, -2, 8, -8, 9, 1e-30, np.inf, -np.inf, np.nan, 3, -3, 4, 5, -5, -2.5], dt)
+    wide = np.concatenate([srng.uniform(-12, 12, 4075).astype(dt), edge])
+    unit = np.concatenate([srng.uniform(-0.999, 0.999, 4092).astype(dt), np.array([0, -0.0, 1, -1], dt)])
+    sp[f"{tag}_wide"], sp[f"{tag}_unit"] = wide, unit
+    for op in ["erf", "erfc", "i0e", "dawson", "lgamma", "tgamma"]:
+        sp[f"{tag}_{op}"] = R.unary(op, wide)
+    for op in ["erfinv", "erfi"]:
+        sp[f"{tag}_{op}"] = R.unary(op, unit)
+np.savez_compressed(os.path.join(HERE, "special.npz"), **sp)
+
 # ---- PCG32 (include/enoki/random.h) draw script, see oracle/ref_driver.cpp:ref_pcg32 -------------------
 seq = (np.arange(1024, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xda3e39cb94b95bdb))
 pm = ((hash_u32(np.arange(1024, dtype=np.uint64), 5) & np.uint32(3)) != 0).astype(np.uint8)

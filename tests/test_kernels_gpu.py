@@ -505,8 +505,9 @@ def test_scatter_add_multi_weighted_f32(capi, K, n):
     capi.scatter_add_multi(d, [up(capi, g[0]), up(capi, g[1]), up(capi, g[2]), 0.75], up(capi, idx),
                            weights=[None, up(capi, w1), -1.5, up(capi, w3)], n=n)
     f32 = np.float32
-    prod = [g[0], np.where((w1 == 0) | (g[1] == 0), f32(0), w1 * g[1]).astype(f32), (f32(-1.5) * g[2]).astype(f32),
-            (w3 * f32(0.75)).astype(f32)]
+    with np.errstate(invalid="ignore"):
+        prod = [g[0], np.where((w1 == 0) | (g[1] == 0), f32(0), w1 * g[1]).astype(f32), (f32(-1.5) * g[2]).astype(f32),
+                (w3 * f32(0.75)).astype(f32)]
     cnt = np.bincount(idx, minlength=K) + 1
     for c in range(4):
         truth = tgts[c].astype(np.float64); np.add.at(truth, idx, prod[c].astype(np.float64))
