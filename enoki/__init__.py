@@ -21,7 +21,7 @@ for _name, _mod in (("hip", hip), ("hip_autodiff", hip_autodiff), ("cuda", hip),
 
 # type aliases: <Type>C = plain device array, <Type>D = differentiable device array
 _TYPES = ["Float32", "Float64", "Int32", "UInt32", "Int64", "UInt64", "Mask", "Vector2f", "Vector3f", "Vector4f",
-          "Matrix2f", "Matrix3f", "Matrix4f"]
+          "Matrix2f", "Matrix3f", "Matrix4f", "Complex2f"]
 _SHORT = {"Float32": "Float", "Mask": "Bool"}
 for _t in _TYPES:
     for _mod, _suffix in ((hip, "C"), (hip_autodiff, "D")):

@@ -19,6 +19,7 @@
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
 #include <enoki/special.h>
+#include <enoki/complex.h>
 
 #include <sstream>
 
@@ -447,6 +448,43 @@ template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py:
         m.def("det", [](const Mat &a) { return det(a); });
         m.def("inverse", [](const Mat &a) { return Mat(inverse(a)); });
     }
+    return cl;
+}
+
+/// Complex<Value> (src/python/complex.h of the reference)
+template <typename Value> py::class_<Complex<Value>> bind_complex(py::module_ &m, const char *name) {
+    using C = Complex<Value>;
+    py::class_<C> cl(m, name);
+    cl.def(py::init<>())
+      .def(py::init<const C &>())
+      .def(py::init<const Value &>(), "real"_a)
+      .def(py::init<const Value &, const Value &>(), "real"_a, "imag"_a)
+      .def_property("real", [](const C &z) { return real(z); }, [](C &z, const Value &v) { z.coeff(0) = v; })
+      .def_property("imag", [](const C &z) { return imag(z); }, [](C &z, const Value &v) { z.coeff(1) = v; })
+      .def("__getitem__", [](const C &z, size_t i) { if (i >= 2) throw py::index_error(); return z.coeff(i); })
+      .def("__len__", [](const C &) { return 2; })
+      .def("__add__", [](const C &a, const C &b) { return C(a + b); })
+      .def("__sub__", [](const C &a, const C &b) { return C(a - b); })
+      .def("__neg__", [](const C &a) { return C(-a); })
+      .def("__mul__", [](const C &a, const C &b) { return C(a * b); })
+      .def("__mul__", [](const C &a, const Value &b) { return C(a * b); })
+      .def("__rmul__", [](const C &a, const Value &b) { return C(b * a); })
+      .def("__truediv__", [](const C &a, const C &b) { return C(a / b); })
+      .def("__truediv__", [](const C &a, const Value &b) { return C(a / b); });
+    m.def("real", [](const C &z) { return real(z); });
+    m.def("imag", [](const C &z) { return imag(z); });
+    m.def("conj", [](const C &z) { return conj(z); });
+    m.def("squared_norm", [](const C &z) { return squared_norm(z); });
+    m.def("abs", [](const C &z) { return abs(z); });
+    m.def("arg", [](const C &z) { return arg(z); });
+    m.def("rcp", [](const C &z) { return rcp(z); });
+    m.def("exp", [](const C &z) { return exp(z); });
+    m.def("log", [](const C &z) { return log(z); });
+    m.def("sqrt", [](const C &z) { return sqrt(z); });
+    m.def("pow", [](const C &a, const C &b) { return pow(a, b); });
+    m.def("sin", [](const C &z) { return sin(z); });
+    m.def("cos", [](const C &z) { return cos(z); });
+    m.def("tan", [](const C &z) { return tan(z); });
     return cl;
 }
 

@@ -28,6 +28,7 @@ PYBIND11_MODULE(hip, m) {
     bind_matrix<FloatC, 2>(m, "Matrix2f");
     bind_matrix<FloatC, 3>(m, "Matrix3f");
     bind_matrix<FloatC, 4>(m, "Matrix4f");
+    bind_complex<FloatC>(m, "Complex2f");
     m.def("meshgrid", [](const FloatC &x, const FloatC &y) { return meshgrid(x, y); });
 
     bind_cast<FloatC, Int32C>(f32); bind_cast<FloatC, UInt32C>(f32); bind_cast<FloatC, DoubleC>(f32);

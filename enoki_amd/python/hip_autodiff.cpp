@@ -26,6 +26,7 @@ PYBIND11_MODULE(hip_autodiff, m) {
     bind_matrix<FloatD, 2>(m, "Matrix2f");
     bind_matrix<FloatD, 3>(m, "Matrix3f");
     bind_matrix<FloatD, 4>(m, "Matrix4f");
+    bind_complex<FloatD>(m, "Complex2f");
 
     f32.def(py::init([](const FloatC &v) { return FloatD(v); }));
     f64.def(py::init([](const DoubleC &v) { return DoubleD(v); }));

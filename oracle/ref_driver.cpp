@@ -25,6 +25,7 @@
 #include <enoki/random.h>
 #include <enoki/matrix.h>
 #include <enoki/special.h>
+#include <enoki/complex.h>
 
 #include <chrono>
 #include <cstdint>
@@ -717,4 +718,19 @@ extern "C" int ref_matrix(int size, const float *a, const float *b, const float 
         case 4: return ref_matrix_impl<4>(a, b, v, n, mm, mv, tr, fr, dt, inv);
     }
     return -1;
+}
+
+/* Complex<FloatX> (include/enoki/complex.h): a, b are (2, n) arrays {re, im}.  out is (10, 2, n):
+   a*b, a/b, exp(a), log(a), sqrt(a), pow(a, b), sin(a), cos(a), rcp(a), {abs(a), arg(a)} */
+extern "C" int ref_complex(const float *a_, const float *b_, size_t n, float *out) {
+    using C = Complex<FloatX>;
+    C a(FloatX::copy(a_, n), FloatX::copy(a_ + n, n)), b(FloatX::copy(b_, n), FloatX::copy(b_ + n, n));
+    C r[9] = { a * b, a / b, exp(a), log(a), sqrt(a), pow(a, b), sin(a), cos(a), rcp(a) };
+    for (int k = 0; k < 9; ++k) {
+        store(FloatX(real(r[k])), out + ((size_t) k * 2 + 0) * n, n);
+        store(FloatX(imag(r[k])), out + ((size_t) k * 2 + 1) * n, n);
+    }
+    store(FloatX(abs(a)), out + (size_t) 18 * n, n);
+    store(FloatX(arg(a)), out + (size_t) 19 * n, n);
+    return 0;
 }

@@ -95,6 +95,11 @@ for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
         sp[f"{tag}_{op}"] = R.unary(op, unit)
 np.savez_compressed(os.path.join(HERE, "special.npz"), **sp)
 
+# ---- Complex<FloatX> (include/enoki/complex.h), see oracle/ref_driver.cpp:ref_complex ------------------------
+ca = uniform_pm1(2 * 2048, 401).reshape(2, 2048) * np.float32(2.5)
+cb = uniform_pm1(2 * 2048, 402).reshape(2, 2048) * np.float32(1.5)
+np.savez_compressed(os.path.join(HERE, "complex.npz"), a=ca, b=cb, out=R.complex(ca, cb))
+
 # ---- PCG32 (include/enoki/random.h) draw script, see oracle/ref_driver.cpp:ref_pcg32 -------------------
 seq = (np.arange(1024, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(0xda3e39cb94b95bdb))
 pm = ((hash_u32(np.arange(1024, dtype=np.uint64), 5) & np.uint32(3)) != 0).astype(np.uint8)

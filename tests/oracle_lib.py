@@ -159,6 +159,13 @@ class Checker:
                                     _p(o["trace"]), _p(o["frob"]), _p(o["det"]), _p(o["inv"])), "matrix")
         return o
 
+    def complex(self, a, b):
+        """Complex<FloatX> script of oracle/ref_driver.cpp:ref_complex; a, b: (2, n) -> (10, 2, n)"""
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)
+        out = np.empty((10, 2, a.shape[1]), np.float32)
+        self._chk(self._f("complex")(_p(a), _p(b), ctypes.c_size_t(a.shape[1]), _p(out)), "complex")
+        return out
+
 
 def _build(target):
     subprocess.run(["make", "-C", ORACLE_DIR, target], check=True, stdout=subprocess.DEVNULL)
