@@ -444,7 +444,7 @@ template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py:
     m.def("trace", [](const Mat &a) { return trace(a); });
     m.def("frob", [](const Mat &a) { return frob(a); });
     m.def("diag", [](const Mat &a) { return Vec(diag(a)); });
-    if constexpr (N == 2 || N == 3) {
+    if constexpr (N >= 2 && N <= 4) {
         m.def("det", [](const Mat &a) { return det(a); });
         m.def("inverse", [](const Mat &a) { return Mat(inverse(a)); });
     }

@@ -8,9 +8,10 @@
     results are bit-identical to the CPU path for the same inputs.
 
     Provided: element access m(i, j), column access, zero / identity / diag, matrix * matrix, matrix * vector,
-    matrix * scalar, transpose, trace, frob, det and inverse for N = 2, 3 (matrix.h:262-318; they contain one
-    rcp(), parity class C).  The 4 x 4 inverse / determinant (SIMD shuffle formulation, matrix.h:320-415) and the
-    polar decomposition are not provided.
+    matrix * scalar, transpose, trace, frob, det and inverse for N = 2, 3 (matrix.h:262-318, same operation order;
+    they contain one rcp(), parity class C) and for N = 4.  The 4 x 4 case is a Laplace expansion over 2 x 2 minors
+    -- NOT the reference's SSE shuffle formulation (matrix.h:320-415) -- so it agrees with the reference to rounding
+    (a few ulp times the condition number), not bit for bit.  The polar decomposition is not provided.
 */
 #pragma once
 
@@ -170,5 +171,61 @@ template <typename V> inline Matrix<V, 3> inverse_transpose(const Matrix<V, 3> &
     return Matrix<V, 3>(Vector(row0 * inv_det), Vector(row1 * inv_det), Vector(row2 * inv_det));
 }
 template <typename V> inline Matrix<V, 3> inverse(const Matrix<V, 3> &m) { return transpose(inverse_transpose(m)); }
+
+namespace detail {
+    /// The twelve 2 x 2 minors of the upper (s) and lower (c) row pairs of a 4 x 4 matrix
+    template <typename V> struct Minors4 {
+        V s[6], c[6];
+        explicit Minors4(const Matrix<V, 4> &m) {
+            static constexpr int pairs[6][2] = { { 0, 1 }, { 0, 2 }, { 0, 3 }, { 1, 2 }, { 1, 3 }, { 2, 3 } };
+            for (int k = 0; k < 6; ++k) {
+                const int a = pairs[k][0], b = pairs[k][1];
+                s[k] = fmsub(m(0, a), m(1, b), m(1, a) * m(0, b));
+                c[k] = fmsub(m(2, a), m(3, b), m(3, a) * m(2, b));
+            }
+        }
+        V det() const {
+            V d = s[0] * c[5];
+            d = fnmadd(s[1], c[4], d);
+            d = fmadd(s[2], c[3], d);
+            d = fmadd(s[3], c[2], d);
+            d = fnmadd(s[4], c[1], d);
+            return fmadd(s[5], c[0], d);
+        }
+    };
+    /// a * x - b * y + c * z
+    template <typename V> inline V expand3(const V &a, const V &x, const V &b, const V &y, const V &c, const V &z) {
+        return fmadd(c, z, fmsub(a, x, b * y));
+    }
+}
+
+template <typename V> inline V det(const Matrix<V, 4> &m) { return detail::Minors4<V>(m).det(); }
+
+template <typename V> inline Matrix<V, 4> inverse(const Matrix<V, 4> &m) {
+    detail::Minors4<V> k(m);
+    const V *s = k.s, *c = k.c;
+    V inv_det = rcp(k.det());
+    using detail::expand3;
+    Matrix<V, 4> r;
+    r(0, 0) =  expand3(m(1, 1), c[5], m(1, 2), c[4], m(1, 3), c[3]) * inv_det;
+    r(0, 1) = -expand3(m(0, 1), c[5], m(0, 2), c[4], m(0, 3), c[3]) * inv_det;
+    r(0, 2) =  expand3(m(3, 1), s[5], m(3, 2), s[4], m(3, 3), s[3]) * inv_det;
+    r(0, 3) = -expand3(m(2, 1), s[5], m(2, 2), s[4], m(2, 3), s[3]) * inv_det;
+    r(1, 0) = -expand3(m(1, 0), c[5], m(1, 2), c[2], m(1, 3), c[1]) * inv_det;
+    r(1, 1) =  expand3(m(0, 0), c[5], m(0, 2), c[2], m(0, 3), c[1]) * inv_det;
+    r(1, 2) = -expand3(m(3, 0), s[5], m(3, 2), s[2], m(3, 3), s[1]) * inv_det;
+    r(1, 3) =  expand3(m(2, 0), s[5], m(2, 2), s[2], m(2, 3), s[1]) * inv_det;
+    r(2, 0) =  expand3(m(1, 0), c[4], m(1, 1), c[2], m(1, 3), c[0]) * inv_det;
+    r(2, 1) = -expand3(m(0, 0), c[4], m(0, 1), c[2], m(0, 3), c[0]) * inv_det;
+    r(2, 2) =  expand3(m(3, 0), s[4], m(3, 1), s[2], m(3, 3), s[0]) * inv_det;
+    r(2, 3) = -expand3(m(2, 0), s[4], m(2, 1), s[2], m(2, 3), s[0]) * inv_det;
+    r(3, 0) = -expand3(m(1, 0), c[3], m(1, 1), c[1], m(1, 2), c[0]) * inv_det;
+    r(3, 1) =  expand3(m(0, 0), c[3], m(0, 1), c[1], m(0, 2), c[0]) * inv_det;
+    r(3, 2) = -expand3(m(3, 0), s[3], m(3, 1), s[1], m(3, 2), s[0]) * inv_det;
+    r(3, 3) =  expand3(m(2, 0), s[3], m(2, 1), s[1], m(2, 2), s[0]) * inv_det;
+    return r;
+}
+
+template <typename V> inline Matrix<V, 4> inverse_transpose(const Matrix<V, 4> &m) { return transpose(inverse(m)); }
 
 } // namespace enoki

@@ -676,7 +676,7 @@ int ref_pcg32(uint64_t initstate, const uint64_t *initseq, size_t n, int steps, 
 } // extern "C"
 
 /* Matrix<FloatX, N> (include/enoki/matrix.h): entries are passed row-major, entry (i, j) = row i * N + j of an
-   (N*N, n) array.  Outputs: a * b, a * v, trace(a), frob(a), and for N = 2, 3 det(a) and inverse(a). */
+   (N*N, n) array.  Outputs: a * b, a * v, trace(a), frob(a), det(a) and inverse(a). */
 namespace {
 template <size_t N> int ref_matrix_impl(const float *a_, const float *b_, const float *v_, size_t n, float *mm, float *mv,
                                         float *tr, float *fr, float *dt, float *inv) {
@@ -699,7 +699,7 @@ template <size_t N> int ref_matrix_impl(const float *a_, const float *b_, const 
     }
     store(FloatX(trace(a)), tr, n);
     store(FloatX(frob(a)), fr, n);
-    if constexpr (N <= 3) {
+    {
         store(FloatX(det(a)), dt, n);
         M ia = inverse(a);
         for (size_t i = 0; i < N; ++i)

@@ -67,17 +67,22 @@ def test_matrix_ops_match_reference(mod, N):
     # frob: fmadd chain over the columns is exact, the horizontal sum over N entries runs in index order
     assert np.allclose(num(ek.frob(a)), g["frob"], rtol=1e-6)
     assert bits_equal(num(ek.diag(a)[N - 1]), g["a"][N * N - 1])
-    if N <= 3:
-        assert ulp_diff(num(ek.det(a)), g["det"]) <= 4
+    if N <= 4:
+        # N = 2, 3: the reference's operation order (one rcp -> class C); N = 4: Laplace expansion over 2 x 2 minors
+        # instead of the reference's shuffle formulation -> equal to rounding only
+        if N <= 3:
+            assert ulp_diff(num(ek.det(a)), g["det"]) <= 4
+        else:
+            assert np.allclose(num(ek.det(a)), g["det"], rtol=2e-5)
         ia = ek.inverse(a)
         for i in range(N):
             for j in range(N):
-                assert np.allclose(num(ia[i, j]), g["inv"][i * N + j], rtol=4e-6, atol=1e-7), (i, j)
+                assert np.allclose(num(ia[i, j]), g["inv"][i * N + j], rtol=4e-6 if N <= 3 else 1e-4, atol=1e-7 if N <= 3 else 2e-6), (i, j)
         # a * a^-1 = identity
         p = a @ ia
         for i in range(N):
             for j in range(N):
-                assert np.allclose(num(p[i, j]), 1.0 if i == j else 0.0, atol=2e-6)
+                assert np.allclose(num(p[i, j]), 1.0 if i == j else 0.0, atol=2e-6 if N <= 3 else 1e-5)
     ident = M.identity(5)
     assert np.array_equal(num(ident[0, 0]), np.ones(5, np.float32)) and np.array_equal(num(ident[0, N - 1]), np.zeros(5, np.float32))
     s = a * ek.Float32(2.0)
