@@ -1066,7 +1066,8 @@ int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Ar
                                out_vals, in_keys, vals, all_on, (const uint32_t *) counts.ptr,
                                (const uint32_t *) bucket_base, m, chunk, shift);
         }
-        EK_LAUNCH_CHECK("scatter_add_sort_pass", n, 0);
+        // per pass: the count reads the keys (4 B), the partition reads and writes (key, value) pairs
+        EK_LAUNCH_CHECK("scatter_add_sort_pass", n, m * (sizeof(uint32_t) + 2 * (sizeof(uint32_t) + sizeof(T))));
         in_keys = out_keys;
         in_vals = out_vals;
         if (m == 0) return EK_OK;

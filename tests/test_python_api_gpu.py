@@ -362,3 +362,30 @@ def test_converting_constructor_stays_on_the_device(ekc):
     before = ekc.hip_launch_count()
     f = ekc.Float32(u)
     assert ekc.hip_launch_count() - before == 1 and f[12345] == 12345.0
+
+
+def test_shared_index_gathers_backward_is_one_scatter_pipeline(ek):
+    """a = gather(A, idx, m), b = gather(B, idx, m): the backward sweep issues ONE multi-table scatter_add (one count, one
+    partition) with the edge product x * g fused in; masked lanes contribute nothing.  Integer-valued data -> exact."""
+    rng = np.random.default_rng(33)
+    n, k = (1 << 19) + 11, 1 << 17
+    A = rng.integers(-8, 9, k).astype(np.float32); B = rng.integers(-8, 9, k).astype(np.float32)
+    x = rng.integers(-4, 5, n).astype(np.float32)
+    idx = rng.integers(0, k, n).astype(np.uint32); m = (rng.integers(0, 4, n) != 0)
+    Ad, Bd = ek.Float32(A), ek.Float32(B)
+    ek.set_requires_gradient(Ad); ek.set_requires_gradient(Bd)
+    I, M = ek.UInt32(idx), ek.Mask(m.astype(np.uint8))
+    a = ek.gather(Ad, I, M); b = ek.gather(Bd, I, M)
+    u = ek.fmadd(a, ek.Float32(x), b)
+    y = u * u
+    ek.hip_profile_begin()
+    ek.backward(ek.hsum(y))
+    import json
+    prof = {r["kernel"]: r for r in json.loads(ek.hip_profile_end())}
+    assert prof["scatter_add_partition"]["launches"] == 1 and prof["scatter_add_count"]["launches"] == 1
+    assert prof["scatter_add_accumulate"]["launches"] == 2 and "safe_mul" not in prof
+    uu = np.where(m, A[idx] * x + B[idx], np.float32(0))
+    gA = np.zeros(k, np.float64); gB = np.zeros(k, np.float64)
+    np.add.at(gA, idx[m], (2 * uu * x)[m]); np.add.at(gB, idx[m], (2 * uu)[m])
+    assert np.array_equal(ek.gradient(Ad).numpy(), gA.astype(np.float32))
+    assert np.array_equal(ek.gradient(Bd).numpy(), gB.astype(np.float32))
