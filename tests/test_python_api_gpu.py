@@ -389,3 +389,21 @@ def test_shared_index_gathers_backward_is_one_scatter_pipeline(ek):
     np.add.at(gA, idx[m], (2 * uu * x)[m]); np.add.at(gB, idx[m], (2 * uu)[m])
     assert np.array_equal(ek.gradient(Ad).numpy(), gA.astype(np.float32))
     assert np.array_equal(ek.gradient(Bd).numpy(), gB.astype(np.float32))
+
+
+def test_shared_index_gathers_backward_float64(ek):
+    """float64 has no fused multi-table path: the queued adjoints run one by one with materialised products -- same values"""
+    rng = np.random.default_rng(34)
+    n, k = (1 << 18) + 7, 5000
+    A = rng.integers(-8, 9, k).astype(np.float64); B = rng.integers(-8, 9, k).astype(np.float64)
+    x = rng.integers(-4, 5, n).astype(np.float64)
+    idx = rng.integers(0, k, n).astype(np.uint32)
+    Ad, Bd = ek.Float64(A), ek.Float64(B)
+    ek.set_requires_gradient(Ad); ek.set_requires_gradient(Bd)
+    I = ek.UInt32(idx)
+    u = ek.fmadd(ek.gather(Ad, I), ek.Float64(x), ek.gather(Bd, I))
+    ek.backward(ek.hsum(u * u))
+    uu = A[idx] * x + B[idx]
+    gA = np.zeros(k); gB = np.zeros(k)
+    np.add.at(gA, idx, 2 * uu * x); np.add.at(gB, idx, 2 * uu)
+    assert np.array_equal(ek.gradient(Ad).numpy(), gA) and np.array_equal(ek.gradient(Bd).numpy(), gB)
