@@ -154,9 +154,15 @@ __global__ __launch_bounds__(256) void k_probe_gather(float *__restrict__ out, c
 #pragma unroll
         for (int k = 0; k < E; ++k) ix[k] = __builtin_nontemporal_load(idx + e + k);
     }
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rsrc;
+    if constexpr (Policy >= 3) rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(table), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
     for (int k = 0; k < E; ++k) {
         if constexpr (Policy == 1) v[k] = __builtin_nontemporal_load(table + ix[k]);
+        else if constexpr (Policy == 2) v[k] = __hip_atomic_load(table + ix[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1
+        else if constexpr (Policy == 3) v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, ix[k] * 4u, 0, 0));
+        else if constexpr (Policy == 4) v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, ix[k] * 4u, 0, 1));    // sc0
+        else if constexpr (Policy == 5) v[k] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, ix[k] * 4u, 0, 17));   // sc0 sc1
         else v[k] = table[ix[k]];
     }
     if constexpr (E == 4) {
@@ -218,7 +224,9 @@ extern "C" EK_API int ek_hip_probe_gather(int elems, int policy, float *out, con
     Context &cx = ctx();
 #define EK_PG(E, P) hipLaunchKernelGGL((k_probe_gather<E, P>), dim3((unsigned) ((n / E + 255) / 256)), dim3(256), 0, cx.stream, out, table, idx, n)
     if (elems == 1 && policy == 0) EK_PG(1, 0); else if (elems == 1) EK_PG(1, 1);
-    else if (elems == 4 && policy == 0) EK_PG(4, 0); else if (elems == 4) EK_PG(4, 1);
+    else if (elems == 4 && policy == 0) EK_PG(4, 0); else if (elems == 4 && policy == 1) EK_PG(4, 1);
+    else if (elems == 4 && policy == 2) EK_PG(4, 2); else if (elems == 4 && policy == 3) EK_PG(4, 3);
+    else if (elems == 4 && policy == 4) EK_PG(4, 4); else if (elems == 4 && policy == 5) EK_PG(4, 5);
     else if (elems == 8 && policy == 0) EK_PG(8, 0); else EK_PG(8, 1);
 #undef EK_PG
     EK_LAUNCH_CHECK("probe_gather", n, 12 * n);
