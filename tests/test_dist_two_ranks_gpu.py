@@ -1,0 +1,41 @@
+"""The sharded bench path end to end on a device: two ranks (processes) share the one GPU of the test box, collectives go
+through gloo (RCCL refuses two ranks on one device; on a multi-GPU node the same code runs with backend nccl = RCCL).
+Exercises enoki_amd/dist.py on device buffers: index-range shards, the packed asynchronous all-reduce of y and the two
+table gradients, max-over-ranks timing -- the all-reduced loss must equal the single-process loss up to summation order."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(workload, n, ranks, port):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--n", str(n),
+           "--workload", workload, "--no-cpu-baseline", "--no-also", "--profile-steps", "1"]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ENOKI_DIST_BACKEND="gloo")
+    if ranks == 1:
+        out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        return json.loads(out.stdout.strip().splitlines()[-1])
+    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(ranks)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(ranks)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0, se[-2000:]
+    line = [l for l in outs[0][0].strip().splitlines() if l.startswith("{")]
+    assert line and not any(l.startswith("{") for l in outs[1][0].splitlines()), "rank 0 alone prints the JSON line"
+    return json.loads(line[-1])
+
+
+@pytest.mark.parametrize("workload", ["cfg3b", "cfg3a"])
+def test_two_ranks_match_one(workload):
+    n = 1 << 22
+    one = run_bench(workload, n, 1, 29611)
+    two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613)
+    assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2 and two["config"]["collectives_per_step"] == 1
+    assert abs(one["result_y"] - two["result_y"]) <= n * 2.0 ** -23 * max(abs(one["result_y"]), 1.0) * 4
+    assert two["value"] > 0 and two["scaling"] == "strong"
