@@ -56,6 +56,39 @@ def __getattr__(name):
     return fn
 
 
+def cuda_eval():
+    """no-op: the backend is eager"""
+    hip.hip_eval()
+
+
+def cuda_sync():
+    hip.hip_sync()
+
+
+def cuda_whos():
+    return hip.hip_whos()
+
+
+def cuda_set_log_level(level):
+    hip.hip_set_log_level(level)
+
+
+def cuda_log_level():
+    return hip.hip_log_level()
+
+
+def cuda_mem_get_info():
+    return hip.hip_mem_get_info()
+
+
+def shape(a):
+    """(components..., entries) of an array, like the reference's ek.shape"""
+    try:
+        return (len(a), max(len(a[i]) for i in range(len(a)))) if hasattr(a, "x") else (len(a),)
+    except TypeError:
+        return (len(a),)
+
+
 def cuda_malloc_trim():
     """name used by scripts written for the reference"""
     hip.hip_malloc_trim()

@@ -173,6 +173,11 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("any", [](const Array &a) { return any(a); });
         m.def("none", [](const Array &a) { return none(a); });
         m.def("count", [](const Array &a) { return count(a); });
+        // flat arrays have one nesting level: the *_nested forms coincide with the plain ones (array_router.h:1331-1383)
+        m.def("all_nested", [](const Array &a) { return all(a); });
+        m.def("any_nested", [](const Array &a) { return any(a); });
+        m.def("none_nested", [](const Array &a) { return none(a); });
+        m.def("count_nested", [](const Array &a) { return count(a); });
     } else {
         cl.def_static("arange", [](size_t size) { return arange<Array>(size); }, "size"_a)
           .def(py::self + py::self).def(py::self - py::self).def(py::self * py::self)
@@ -196,6 +201,10 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("hprod", [](const Array &a) { return hprod(a); });
         m.def("hmin", [](const Array &a) { return hmin(a); });
         m.def("hmax", [](const Array &a) { return hmax(a); });
+        m.def("hsum_nested", [](const Array &a) { return hsum(a); });
+        m.def("hprod_nested", [](const Array &a) { return hprod(a); });
+        m.def("hmin_nested", [](const Array &a) { return hmin(a); });
+        m.def("hmax_nested", [](const Array &a) { return hmax(a); });
         m.def("psum", [](const Array &a) { return psum(a); });
         if constexpr (!IsDiff)
             m.def("compress", [](const Array &a, const Mask &mk) { return compress(a, mk); });
@@ -224,6 +233,17 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("safe_acos", [](const Array &a) { return safe_acos(a); });
         m.def("hypot", [](const Array &a, const Array &b) { return hypot(a, b); });
         m.def("copysign", [](const Array &a, const Array &b) { return copysign(a, b); });
+        m.def("copysign_neg", [](const Array &a, const Array &b) { return copysign(a, -b); });
+        m.def("mulsign", [](const Array &a, const Array &b) { return mulsign(a, b); });
+        m.def("mulsign_neg", [](const Array &a, const Array &b) { return mulsign(a, -b); });
+        m.def("hmean", [](const Array &a) { return hsum(a) * Array(Scalar(1) / Scalar(std::max<size_t>(slices(a), 1))); });
+        m.def("hmean_nested", [](const Array &a) { return hsum(a) * Array(Scalar(1) / Scalar(std::max<size_t>(slices(a), 1))); });
+        // |a - b| <= atol + rtol |b| everywhere (src/python/common.h allclose); NaNs compare unequal unless equal_nan
+        m.def("allclose", [](const Array &a, const Array &b, Scalar rtol, Scalar atol, bool equal_nan) {
+            auto ok = abs(detach(a) - detach(b)) <= fmadd(abs(detach(b)), std::decay_t<decltype(detach(b))>(rtol), std::decay_t<decltype(detach(b))>(atol));
+            if (equal_nan) ok = ok | (isnan(detach(a)) & isnan(detach(b)));
+            return all(ok);
+        }, "a"_a, "b"_a, "rtol"_a = Scalar(1e-5), "atol"_a = Scalar(1e-8), "equal_nan"_a = false);
         m.def("sin", [](const Array &a) { return sin(a); });
         m.def("cos", [](const Array &a) { return cos(a); });
         m.def("sincos", [](const Array &a) { return sincos(a); });
@@ -365,6 +385,11 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
     if constexpr (N >= 4) cl.def_property("w", [](const Vec &v) { return v.w(); }, [](Vec &v, const Value &x) { v.w() = x; });
 
     m.def("dot", [](const Vec &a, const Vec &b) { return dot(a, b); });
+    m.def("abs_dot", [](const Vec &a, const Vec &b) { return abs(dot(a, b)); });
+    m.def("hsum_nested", [](const Vec &a) { return hsum(hsum(a)); });
+    m.def("hprod_nested", [](const Vec &a) { return hprod(hprod(a)); });
+    m.def("hmin_nested", [](const Vec &a) { return hmin(hmin(a)); });
+    m.def("hmax_nested", [](const Vec &a) { return hmax(hmax(a)); });
     m.def("squared_norm", [](const Vec &a) { return squared_norm(a); });
     m.def("norm", [](const Vec &a) { return norm(a); });
     m.def("normalize", [](const Vec &a) { return normalize(a); });
@@ -447,6 +472,7 @@ template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py:
     if constexpr (N >= 2 && N <= 4) {
         m.def("det", [](const Mat &a) { return det(a); });
         m.def("inverse", [](const Mat &a) { return Mat(inverse(a)); });
+        m.def("inverse_transpose", [](const Mat &a) { return Mat(transpose(inverse(a))); });
     }
     return cl;
 }
@@ -494,6 +520,12 @@ inline void bind_runtime(py::module_ &m) {
     m.def("hip_whos", []() { return hip_whos(); });
     m.def("hip_malloc_trim", []() { hip_malloc_trim(); });
     m.def("hip_set_log_level", [](uint32_t l) { ek_hip_set_log_level(l); });
+    m.def("hip_log_level", []() { return ek_hip_log_level(); });
+    m.def("hip_mem_get_info", []() {
+        size_t free_bytes = 0, total_bytes = 0;
+        detail::hip_check(ek_hip_mem_get_info(&free_bytes, &total_bytes), "hip_mem_get_info");
+        return std::make_pair(free_bytes, total_bytes);
+    }, "(free, total) bytes of device memory (cuda_mem_get_info)");
     m.def("hip_init", [](int device) { detail::hip_check(ek_hip_init(device), "hip_init"); }, "device"_a = -1);
     m.def("hip_device", []() { return ek_hip_device(); });
     m.def("hip_stream", []() { return (uintptr_t) ek_hip_stream(); });

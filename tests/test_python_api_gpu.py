@@ -407,3 +407,26 @@ def test_shared_index_gathers_backward_float64(ek):
     gA = np.zeros(k); gB = np.zeros(k)
     np.add.at(gA, idx, 2 * uu * x); np.add.at(gB, idx, 2 * uu)
     assert np.array_equal(ek.gradient(Ad).numpy(), gA) and np.array_equal(ek.gradient(Bd).numpy(), gB)
+
+
+def test_reference_module_level_helpers(ekc, ek):
+    """the rest of the names src/python/*.cpp registers at module level: *_nested reductions, hmean, mulsign, copysign_neg,
+    abs_dot, allclose, inverse_transpose and the cuda_* runtime entry points (as `import enoki` aliases)"""
+    import enoki
+    a = np.linspace(-2, 3, 1001).astype(np.float32); b = np.cos(a).astype(np.float32)
+    for m in (ekc, ek):
+        A, B = m.Float32(a), m.Float32(b)
+        num = lambda x: (m.detach(x) if m is ek else x).numpy()
+        assert bits_equal(num(m.hsum_nested(A)), num(m.hsum(A))) and bits_equal(num(m.hmax_nested(A)), num(m.hmax(A)))
+        assert np.allclose(num(m.hmean(A)), a.mean(), rtol=1e-5)
+        assert bits_equal(num(m.mulsign(A, B)), np.where(np.signbit(b), -a, a)) and bits_equal(num(m.mulsign_neg(A, B)), np.where(np.signbit(b), a, -a))
+        assert bits_equal(num(m.copysign_neg(A, B)), np.copysign(a, -b))
+        assert m.allclose(A, A + m.Float32(1e-9)) and not m.allclose(A, A + m.Float32(1e-2))
+        assert m.all_nested(A > m.Float32(-3.0)) and m.count_nested(A > m.Float32(0.0)) == int((a > 0).sum())
+        v = m.Vector3f(A, B, m.Float32(1.0))
+        assert bits_equal(num(m.abs_dot(v, v)), np.abs(num(m.dot(v, v))))
+        assert np.allclose(num(m.hsum_nested(v)), a.sum() + b.sum() + 1001, rtol=1e-5)
+    assert enoki.cuda_mem_get_info()[1] > enoki.cuda_mem_get_info()[0] > 0
+    enoki.cuda_eval(); enoki.cuda_sync()
+    assert isinstance(enoki.cuda_whos(), str) and enoki.cuda_log_level() == 0
+    assert enoki.shape(ekc.Float32(a)) == (1001,) and enoki.shape(ekc.Vector3f(ekc.Float32(a), ekc.Float32(a), ekc.Float32(a))) == (3, 1001)
