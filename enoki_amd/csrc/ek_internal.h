@@ -144,4 +144,8 @@ template <typename T, typename I>
 int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n);
 
+template <typename T, typename I, int C>
+int scatter_add_sorted_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);
+
 } // namespace ek

@@ -392,7 +392,7 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
 } // extern "C"
 
 namespace {
-template <typename T, typename I, int C>
+template <typename T, typename I, int C, bool Sorted = false>
 int scatter_add_multi_fused(void *const *bases, size_t base_size, const ek_operand *const *values, const ek_operand *const *weights,
                             const ek_operand *index, const ek_operand *mask, size_t n) {
     Arg<T> vv[C], ww[C];
@@ -411,7 +411,22 @@ int scatter_add_multi_fused(void *const *bases, size_t base_size, const ek_opera
     }
     if (int rc = make_arg<I>(index, n, ii, "ek_hip_scatter_add_multi")) return rc;
     if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add_multi")) return rc;
-    return scatter_add_binned_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n);
+    if constexpr (Sorted) return scatter_add_sorted_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n);
+    else return scatter_add_binned_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n);
+}
+
+// deterministic mode: 2 or 3 streams per sort (one stream goes through ek_hip_scatter_add)
+template <typename T, typename I>
+int scatter_add_multi_sorted_count(int count, void *const *bases, size_t base_size, const ek_operand *const *values,
+                                   const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask, size_t n) {
+    switch (count) {
+        case 2: return scatter_add_multi_fused<T, I, 2, true>(bases, base_size, values, weights, index, mask, n);
+        case 3: return scatter_add_multi_fused<T, I, 3, true>(bases, base_size, values, weights, index, mask, n);
+        default: {
+            if (int rc = scatter_add_multi_fused<T, I, 2, true>(bases, base_size, values, weights, index, mask, n)) return rc;
+            return scatter_add_multi_fused<T, I, 2, true>(bases + 2, base_size, values + 2, weights ? weights + 2 : nullptr, index, mask, n);
+        }
+    }
 }
 
 template <typename T, typename I>
@@ -459,6 +474,16 @@ int ek_hip_scatter_add_multi(int type, int index_type, int count, void *const *b
             if (index_type == EK_U32) return scatter_add_multi_fused_count<uint32_t, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
             return scatter_add_multi_fused_count<uint32_t, int32_t>(count, bases, base_size, values, weights, index, mask, n);
         }
+    }
+    // deterministic mode with several fp streams: one stable sort of the keys carries all value streams
+    if (mode == 1 && count >= 2 && (type == EK_F32 || type == EK_F64) && (index_type == EK_U32 || index_type == EK_I32) &&
+        index->ptr != nullptr && index->size == n && base_size > 0 && n < ((size_t) 1 << 32)) {
+        if (type == EK_F32) {
+            if (index_type == EK_U32) return scatter_add_multi_sorted_count<float, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
+            return scatter_add_multi_sorted_count<float, int32_t>(count, bases, base_size, values, weights, index, mask, n);
+        }
+        if (index_type == EK_U32) return scatter_add_multi_sorted_count<double, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
+        return scatter_add_multi_sorted_count<double, int32_t>(count, bases, base_size, values, weights, index, mask, n);
     }
     // everything else: one scatter_add per stream, products materialised first
     for (int c = 0; c < count; ++c) {

@@ -833,9 +833,9 @@ __global__ __launch_bounds__(kThreads) void k_radix_count(uint32_t *__restrict__
         counts[(size_t) b * gridDim.x + blockIdx.x] = hist[b];
 }
 
-template <typename T, typename I>
-__global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *__restrict__ out_keys, T *__restrict__ out_vals,
-                                                                     const I *__restrict__ keys, Arg<T> value,
+template <typename T, typename I, int C = 1>
+__global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *__restrict__ out_keys, BinStreams<T, C> st,
+                                                                     const I *__restrict__ keys,
                                                                      Arg<uint8_t> mask, const uint32_t *__restrict__ offsets,
                                                                      const uint32_t *__restrict__ bucket_base, size_t n,
                                                                      size_t chunk, int shift) {
@@ -849,8 +849,24 @@ __global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *_
     for (int b = threadIdx.x; b < kRadix; b += kThreads)
         cursor[b] = bucket_base[b] + offsets[(size_t) b * gridDim.x + blockIdx.x];
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
-    const T sv = value.vec ? T(0) : arg_scalar(value);
+    T sv[C], sw[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        sv[c] = st.value[c].vec ? T(0) : arg_scalar(st.value[c]);
+        sw[c] = (((st.weighted >> c) & 1u) && !st.weight[c].vec) ? arg_scalar(st.weight[c]) : T(1);
+    }
     const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+
+    // values of stream c for the current tile, in the tile's (wave, item, lane) layout, times their weights
+    auto load_stream = [&](int c, size_t base, T (&val)[kPerThread]) {
+#pragma unroll
+        for (int j = 0; j < kPerThread; ++j) {
+            const size_t i = base + (size_t) wave * (kTile / kSortWaves) + (size_t) j * 64 + lane;
+            T v = (st.value[c].vec && i < end) ? st.value[c].ptr[i] : sv[c];
+            if ((st.weighted >> c) & 1u) v = dev::safe_mul((st.weight[c].vec && i < end) ? st.weight[c].ptr[i] : sw[c], v);
+            val[j] = v;
+        }
+    };
 
     for (size_t base = begin; base < end; base += kTile) {
         for (int b = threadIdx.x; b < kSortWaves * kRadix; b += kThreads) (&wave_count[0][0])[b] = 0;
@@ -865,8 +881,8 @@ __global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *_
             const size_t i = base + (size_t) wave * (kTile / kSortWaves) + (size_t) j * 64 + lane;
             on[j] = i < end && (mask.vec ? mask.ptr[i] != 0 : sm != 0);
             key[j] = i < end ? index_u32(keys[i]) : 0u;
-            val[j] = (value.vec && i < end) ? value.ptr[i] : sv;
         }
+        load_stream(0, base, val);
 #pragma unroll
         for (int j = 0; j < kPerThread; ++j) {
             const uint32_t d = (key[j] >> shift) & (kRadix - 1);
@@ -921,16 +937,31 @@ __global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *_
             if (on[j]) {
                 const uint32_t d = (key[j] >> shift) & (kRadix - 1);
                 const uint32_t p = tile_off[d] + wave_count[wave][d] + rank[j];
+                rank[j] = p;                       // position inside the sorted tile, reused by the other streams
                 stage_key[p] = key[j];
                 stage_val[p] = val[j];
             }
         }
+        if constexpr (C > 1) load_stream(1, base, val);
         __syncthreads();
         for (uint32_t s = threadIdx.x; s < tile_count; s += kThreads) {
             const uint32_t k = stage_key[s], d = (k >> shift) & (kRadix - 1);
             const uint32_t g = cursor[d] + (s - tile_off[d]);
             out_keys[g] = k;
-            out_vals[g] = stage_val[s];
+            st.pair_val[0][g] = stage_val[s];
+        }
+#pragma unroll
+        for (int c = 1; c < C; ++c) {
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < kPerThread; ++j)
+                if (on[j]) stage_val[rank[j]] = val[j];
+            if (c + 1 < C) load_stream(c + 1, base, val);
+            __syncthreads();
+            for (uint32_t s = threadIdx.x; s < tile_count; s += kThreads) {
+                const uint32_t d = (stage_key[s] >> shift) & (kRadix - 1);
+                st.pair_val[c][cursor[d] + (s - tile_off[d])] = stage_val[s];
+            }
         }
         __syncthreads();
         if (threadIdx.x < kRadix) cursor[threadIdx.x] += total[threadIdx.x];
@@ -958,21 +989,41 @@ template <typename T, std::enable_if_t<sizeof(T) == 8, int> = 0> __device__ __fo
 /// of the CPU.  Runs longer than a wave (hot bins) are walked by the whole wave on behalf of their lane: 64 values are
 /// fetched with one coalesced load and folded in element order through readlane, ~16x faster than a single lane
 /// chasing its own loads (a serial chain cannot be parallelised without changing the rounding).
+/// Run boundaries of the sorted keys: bin k owns [starts[k], ends[k]) (both zero-initialised: bins without elements keep
+/// an empty run).  One streaming pass over the keys instead of two binary searches per bin, shared by all value streams.
+__global__ __launch_bounds__(256) void k_segment_bounds(uint32_t *__restrict__ starts, uint32_t *__restrict__ ends,
+                                                        const uint32_t *__restrict__ keys, size_t m, size_t table_size) {
+    // four consecutive keys per lane (one 16-byte load; the scratch buffer is 16-byte aligned) plus the two neighbours
+    const size_t i0 = ((size_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i0 >= m) return;
+    uint32_t k[6];
+    if (i0 + 4 <= m) {
+        Pack<uint32_t, 4> p = pack_load<uint32_t, 4, false>(keys + i0);
+        k[1] = p.v[0]; k[2] = p.v[1]; k[3] = p.v[2]; k[4] = p.v[3];
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) k[1 + j] = i0 + j < m ? keys[i0 + j] : 0xffffffffu;
+    }
+    k[0] = i0 > 0 ? keys[i0 - 1] : 0xffffffffu;
+    k[5] = i0 + 4 < m ? keys[i0 + 4] : 0xffffffffu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const size_t i = i0 + j;
+        const uint32_t key = k[1 + j];
+        if (i >= m || key >= table_size) continue;   // out-of-range index: undefined in the reference, ignored here
+        if (i == 0 || k[j] != key) starts[key] = (uint32_t) i;
+        if (i + 1 == m || k[2 + j] != key) ends[key] = (uint32_t) (i + 1);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_segment_sum(T *__restrict__ target, size_t table_size,
-                                                     const uint32_t *__restrict__ keys, const T *__restrict__ vals, size_t m) {
+                                                     const uint32_t *__restrict__ starts, const uint32_t *__restrict__ ends,
+                                                     const T *__restrict__ vals) {
     const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
     const bool valid = k < table_size;
-    auto lower_bound = [&](uint64_t key) {
-        size_t lo = 0, hi = m;
-        while (lo < hi) {
-            size_t mid = (lo + hi) >> 1;
-            if ((uint64_t) keys[mid] < key) lo = mid + 1; else hi = mid;
-        }
-        return lo;
-    };
     size_t lo = 0, hi = 0;
-    if (valid) { lo = lower_bound(k); hi = lower_bound(k + 1); }
+    if (valid) { lo = starts[k]; hi = ends[k]; }
     const bool has_run = hi > lo;
     T acc = has_run ? target[k] : T(0);
 
@@ -1007,9 +1058,11 @@ __global__ __launch_bounds__(256) void k_segment_sum(T *__restrict__ target, siz
     }
 }
 
-template <typename T, typename I>
-int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
-                       size_t n) {
+// `C` value streams sorted by ONE key array: the keys are ranked, moved and re-read once per pass for all streams,
+// then every table sums its own sorted values in element order.
+template <typename T, typename I, int C>
+int scatter_add_sorted_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n) {
     Context &c = ctx();
     int bits = 1;
     while (((size_t) 1 << bits) < table_size && bits < 32) ++bits;
@@ -1022,24 +1075,32 @@ int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Ar
     blocks = (unsigned) ((n + chunk - 1) / chunk);
     const size_t count_entries = (size_t) kRadix * blocks;
 
-    Scratch counts, keys_a, vals_a, keys_b, vals_b;
+    Scratch counts, keys_a, keys_b, vals_a[C], vals_b[C];
     if (int rc = counts.alloc((count_entries + 2 * kRadix + 1) * sizeof(uint32_t))) return rc;
     if (int rc = keys_a.alloc(n * sizeof(uint32_t))) return rc;
-    if (int rc = vals_a.alloc(n * sizeof(T))) return rc;
-    if (passes > 1) {
+    if (passes > 1)
         if (int rc = keys_b.alloc(n * sizeof(uint32_t))) return rc;
-        if (int rc = vals_b.alloc(n * sizeof(T))) return rc;
+    for (int s = 0; s < C; ++s) {
+        if (int rc = vals_a[s].alloc(n * sizeof(T))) return rc;
+        if (passes > 1)
+            if (int rc = vals_b[s].alloc(n * sizeof(T))) return rc;
     }
     uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
     uint32_t *bucket_base = row_total + kRadix;
 
     size_t m = n;                         // valid pairs after the first pass dropped the masked ones
     const uint32_t *in_keys = nullptr;
-    const T *in_vals = nullptr;
+    const T *in_vals[C] = {};
     for (int p = 0; p < passes; ++p) {
         const int shift = p * kRadixBits;
         uint32_t *out_keys = (uint32_t *) ((p & 1) ? keys_b.ptr : keys_a.ptr);
-        T *out_vals = (T *) ((p & 1) ? vals_b.ptr : vals_a.ptr);
+        BinStreams<T, C> st;
+        st.weighted = p == 0 ? weighted : 0u;
+        for (int s = 0; s < C; ++s) {
+            st.pair_val[s] = (T *) ((p & 1) ? vals_b[s].ptr : vals_a[s].ptr);
+            st.value[s] = p == 0 ? values[s] : Arg<T>{ in_vals[s], T(0), 1u };
+            st.weight[s] = p == 0 ? weights[s] : Arg<T>{ nullptr, T(1), 0u };
+        }
         if (p == 0) {
             hipLaunchKernelGGL((k_radix_count<I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr,
                                index.ptr, mask, n, chunk, shift);
@@ -1052,34 +1113,52 @@ int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Ar
         hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr,
                            (const uint32_t *) row_total, kRadix, 0u);
         if (p == 0) {
-            hipLaunchKernelGGL((k_radix_partition_stable<T, I>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys,
-                               out_vals, index.ptr, value, mask, (const uint32_t *) counts.ptr,
-                               (const uint32_t *) bucket_base, n, chunk, shift);
+            hipLaunchKernelGGL((k_radix_partition_stable<T, I, C>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys, st,
+                               index.ptr, mask, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, n, chunk, shift);
             uint32_t valid = 0;           // the only synchronisation of the deterministic path
             EK_HIP_CHECK(hipMemcpyAsync(&valid, bucket_base + kRadix, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
             EK_HIP_CHECK(hipStreamSynchronize(c.stream));
             m = valid;
         } else {
             Arg<uint8_t> all_on{ nullptr, 1, 0 };
-            Arg<T> vals{ in_vals, T(0), 1 };
-            hipLaunchKernelGGL((k_radix_partition_stable<T, uint32_t>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys,
-                               out_vals, in_keys, vals, all_on, (const uint32_t *) counts.ptr,
-                               (const uint32_t *) bucket_base, m, chunk, shift);
+            hipLaunchKernelGGL((k_radix_partition_stable<T, uint32_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys, st,
+                               in_keys, all_on, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, m, chunk, shift);
         }
-        // per pass: the count reads the keys (4 B), the partition reads and writes (key, value) pairs
-        EK_LAUNCH_CHECK("scatter_add_sort_pass", n, m * (sizeof(uint32_t) + 2 * (sizeof(uint32_t) + sizeof(T))));
+        // per pass: the count reads the keys (4 B), the partition reads and writes the keys and C value streams
+        EK_LAUNCH_CHECK("scatter_add_sort_pass", n, m * (sizeof(uint32_t) + 2 * (sizeof(uint32_t) + C * sizeof(T))));
         in_keys = out_keys;
-        in_vals = out_vals;
+        for (int s = 0; s < C; ++s) in_vals[s] = st.pair_val[s];
         if (m == 0) return EK_OK;
     }
-    hipLaunchKernelGGL((k_segment_sum<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, base,
-                       table_size, in_keys, in_vals, m);
-    EK_LAUNCH_CHECK("scatter_add_segment_sum", table_size, m * (sizeof(uint32_t) + sizeof(T)));
+    Scratch bounds;
+    if (int rc = bounds.alloc(2 * table_size * sizeof(uint32_t))) return rc;
+    uint32_t *starts = (uint32_t *) bounds.ptr, *ends = starts + table_size;
+    EK_HIP_CHECK(hipMemsetAsync(bounds.ptr, 0, 2 * table_size * sizeof(uint32_t), c.stream));
+    hipLaunchKernelGGL(k_segment_bounds, dim3((unsigned) ((m + 1023) / 1024)), dim3(256), 0, c.stream, starts, ends, in_keys, m,
+                       table_size);
+    EK_LAUNCH_CHECK("scatter_add_segment_bounds", m, m * sizeof(uint32_t) + 2 * table_size * sizeof(uint32_t));
+    for (int s = 0; s < C; ++s) {
+        hipLaunchKernelGGL((k_segment_sum<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, bases[s],
+                           table_size, (const uint32_t *) starts, (const uint32_t *) ends, in_vals[s]);
+        EK_LAUNCH_CHECK("scatter_add_segment_sum", table_size, m * sizeof(T) + table_size * (2 * sizeof(uint32_t) + 2 * sizeof(T)));
+    }
     return EK_OK;
 }
 
+template <typename T, typename I>
+int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
+                       size_t n) {
+    const Arg<T> values[1] = { value }, weights[1] = { Arg<T>{ nullptr, T(1), 0u } };
+    T *bases[1] = { base };
+    return scatter_add_sorted_multi<T, I, 1>(bases, table_size, values, weights, 0u, index, mask, n);
+}
+
 #define EK_SORTED_INSTANCE(T, I)                                                                                      \
-    template int scatter_add_sorted<T, I>(T *, size_t, const Arg<T> &, const Arg<I> &, const Arg<uint8_t> &, size_t);
+    template int scatter_add_sorted<T, I>(T *, size_t, const Arg<T> &, const Arg<I> &, const Arg<uint8_t> &, size_t);  \
+    template int scatter_add_sorted_multi<T, I, 2>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);                     \
+    template int scatter_add_sorted_multi<T, I, 3>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);
 EK_SORTED_INSTANCE(float, uint32_t) EK_SORTED_INSTANCE(float, int32_t)
 EK_SORTED_INSTANCE(double, uint32_t) EK_SORTED_INSTANCE(double, int32_t)
 
