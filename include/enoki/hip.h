@@ -425,14 +425,27 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return gather_<sizeof(Value)>(source.data(), detach(index), mask);
     }
 
+    static constexpr size_t gather_multi_small_ = (size_t) 3 << 20, gather_multi_large_ = (size_t) 128 << 20;
+
     /// N tables, one index / mask array: a single kernel that reads the indices once (Array<HIPArray, N> sources)
     template <size_t N, typename Index>
     static bool gather_multi_(const HIPArray *sources, HIPArray *results, const Index &index, const MaskType &mask) {
         if constexpr (IsMask || (sizeof(Value) != 4 && sizeof(Value) != 8) || N < 2 || N > 4) {
             return false;
         } else {
-            for (size_t c = 0; c < N; ++c)
+            size_t table_bytes = 0;
+            for (size_t c = 0; c < N; ++c) {
                 if (sources[c].size() <= 1) return false;          // broadcast components take the generic path
+                table_bytes = std::max(table_bytes, sources[c].size() * sizeof(Value));
+            }
+            // One launch reads the indices once, but its working set is ALL tables: when one table fits the 4 MiB L2 of
+            // an XCD and the set does not, separate launches are up to 2x faster (profiles/probe_gather_multi_r01.txt)
+            static const int policy = [] {
+                const char *e = getenv("ENOKI_HIP_GATHER_MULTI");
+                return !e ? 0 : (e[0] == 'a' ? 1 : e[0] == 'n' ? 2 : 0);      // always / never / (default) by size
+            }();
+            if (policy == 2 || (policy == 0 && N * table_bytes > gather_multi_small_ && table_bytes < gather_multi_large_))
+                return false;
             size_t n = broadcast_size(index.size(), mask.size());
             void *outs[N];
             const void *bases[N];

@@ -328,6 +328,14 @@ def test_vector_gather_is_one_kernel(ekc):
     assert ekc.hip_launch_count() - before == 1
     for c, name in zip(comps, "xyz"):
         assert bits_equal(getattr(got, name).numpy(), np.where(mask != 0, c[idx], np.float32(0)))
+    # 4 MiB tables: each fits the L2 of an XCD, three do not -> one launch per component (profiles/probe_gather_multi_r01.txt)
+    big = [rng.standard_normal(1 << 20).astype(np.float32) for _ in range(3)]
+    bidx = rng.integers(0, 1 << 20, n).astype(np.uint32)
+    bsrc = ekc.Vector3f(*[ekc.Float32(c) for c in big])
+    before = ekc.hip_launch_count()
+    bgot = ekc.gather(bsrc, ekc.UInt32(bidx))
+    assert ekc.hip_launch_count() - before == 3
+    assert bits_equal(bgot.y.numpy(), big[1][bidx])
     # a broadcast component falls back to the per-component path and still gives the right values
     src2 = ekc.Vector3f(ekc.Float32(comps[0]), ekc.Float32(2.5), ekc.Float32(comps[2]))
     got2 = ekc.gather(src2, ekc.UInt32(idx))
