@@ -220,6 +220,60 @@ def gather_suite(n=1000, k=37, seed=5):
     return P
 
 
+def random_gather_program(seed, n=1000, k=37, n_ops=18):
+    """Random programs mixing table arithmetic (size k), gathers through a few shared index arrays and vector arithmetic
+    (size n), vector output.  Small integer data and a bounded number of multiplications keep every value, product and
+    sum exactly representable, so all tape implementations must agree bit for bit whatever the accumulation order;
+    interior (computed) tables are gathered from as well, which exercises the ordering of the deferred adjoints."""
+    rng = np.random.default_rng(5000 + seed)
+    ints = lambda lo, hi, size: rng.integers(lo, hi + 1, size).astype(np.float32)
+    n_tables, n_vecs, n_idx = 3, 2, 2
+    ins = [(ints(-3, 3, k), 1) for _ in range(n_tables)] + [(ints(-2, 2, n), int(rng.integers(0, 2))) for _ in range(n_vecs)]
+    idx = [rng.integers(0, k, n).astype(np.uint32) for _ in range(n_idx)]
+    kind = ["t"] * n_tables + ["v"] * n_vecs            # register kinds
+    depth = [0] * len(kind)                             # multiplications on the path: bounds the magnitudes
+    ops = []
+
+    def pick(kd, max_depth=10):
+        c = [r for r in range(len(kind)) if kind[r] == kd and depth[r] <= max_depth]
+        return int(c[int(rng.integers(0, len(c)))]) if c else None
+
+    def push(op, kd, d):
+        ops.append(op); kind.append(kd); depth.append(d)
+
+    for _ in range(n_ops):
+        r = rng.random()
+        if r < 0.35:                                    # gather from any table register through one of the index arrays
+            t = pick("t")
+            push(("gather", t, int(rng.integers(0, n_idx))), "v", depth[t])
+        elif r < 0.5:                                   # table arithmetic -> interior tables
+            a, b = pick("t", 0), pick("t", 0)
+            name = ["add", "sub", "mul"][int(rng.integers(0, 3))]
+            push((name, a, b), "t", max(depth[a], depth[b]) + (1 if name == "mul" else 0))
+        else:
+            name = ["add", "sub", "mul", "neg", "mulc", "fmadd"][int(rng.integers(0, 6))]
+            if name == "neg":
+                a = pick("v"); push(("neg", a), "v", depth[a])
+            elif name == "mulc":
+                a = pick("v"); push(("mulc", a, float(rng.integers(-2, 3))), "v", depth[a])
+            elif name in ("mul", "fmadd"):
+                a, b = pick("v", 0), pick("v", 0)
+                if name == "mul":
+                    push(("mul", a, b), "v", max(depth[a], depth[b]) + 1)
+                else:
+                    c = pick("v", 1); push(("fmadd", a, b, c), "v", max(depth[a], depth[b], depth[c]) + 1)
+            else:
+                a, b = pick("v"), pick("v"); push((name, a, b), "v", max(depth[a], depth[b]))
+    # make sure every table is used, and tie the last vector registers together (vector output, seed = ones)
+    for t in range(n_tables):
+        push(("gather", t, 0), "v", 0)
+    vec = [r for r in range(len(kind)) if kind[r] == "v"][-6:]
+    acc = vec[0]
+    for r in vec[1:]:
+        push(("add", acc, r), "v", max(depth[acc], depth[r])); acc = len(kind) - 1
+    return Program(ins, ops, index_inputs=idx)
+
+
 TOLERANT = {"div_rcp_rsqrt", "sw_trig", "sw_hyp", "sw_sum", "sw_cbrt_pow"}   # sw_cbrt_pow: d pow / d base goes through log's rcp()
 CLASS_C_VALUES = {"sw_trig", "sw_hyp", "sw_sum"}   # the primal itself contains rcp() (tan, cot, sinh, cosh, tanh)          # not bit-comparable against the AVX2 reference build (class C)
 ORDER_DEPENDENT_ON_GPU = {            # contain hsum / hprod / fp scatter_add: GPU summation order differs (class D)
