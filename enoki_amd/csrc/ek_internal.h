@@ -129,12 +129,12 @@ inline unsigned stream_grid(size_t work_items, int blocks_per_cu) {
 }
 
 // LDS-binned scatter_add (scatter_binned.hip)
-bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array);
+bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array, size_t elem_size = 4);
 template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n);
 
-bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array);
+bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array, size_t elem_size = 4);
 template <typename T, typename I, int C>
 int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
                              const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);

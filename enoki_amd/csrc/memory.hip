@@ -362,10 +362,20 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
     }
     // large inputs into tables that fit 256 LDS buckets: partition + ds_add instead of global atomics
     if (mode == 0 && ctx().tuning.scatter_add_binned && index && mask && value &&
-        scatter_add_binned_applicable(base_size, n, index->ptr != nullptr && index->size == n) &&
-        (index_type == EK_U32 || index_type == EK_I32) && (type == EK_F32 || type == EK_I32 || type == EK_U32)) {
+        scatter_add_binned_applicable(base_size, n, index->ptr != nullptr && index->size == n, type_size(type)) &&
+        (index_type == EK_U32 || index_type == EK_I32) && type != EK_BOOL) {
         Arg<uint8_t> mm;
         if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add")) return rc;
+#define EK_BINNED_CALL(T)                                                                                              \
+        do {                                                                                                          \
+            Arg<T> vv;                                                                                                \
+            if (int rc = make_arg<T>(value, n, vv, "ek_hip_scatter_add")) return rc;                                  \
+            if (index_type == EK_U32) { Arg<uint32_t> ii; if (int rc = make_arg<uint32_t>(index, n, ii, "ek_hip_scatter_add")) return rc; return scatter_add_binned<T, uint32_t>((T *) base, base_size, vv, ii, mm, n); } \
+            else                      { Arg<int32_t> ii;  if (int rc = make_arg<int32_t>(index, n, ii, "ek_hip_scatter_add")) return rc;  return scatter_add_binned<T, int32_t>((T *) base, base_size, vv, ii, mm, n); }  \
+        } while (0)
+        if (type == EK_F64) EK_BINNED_CALL(double);
+        if (type == EK_I64 || type == EK_U64) EK_BINNED_CALL(uint64_t);
+#undef EK_BINNED_CALL
         if (type == EK_F32) {
             Arg<float> vv;
             if (int rc = make_arg<float>(value, n, vv, "ek_hip_scatter_add")) return rc;
@@ -460,17 +470,25 @@ int ek_hip_scatter_add_multi(int type, int index_type, int count, void *const *b
     }
     if (n == 0) return EK_OK;
     if (mode == 0 && ctx().tuning.deterministic) mode = 1;
-    const bool fused = mode == 0 && ctx().tuning.scatter_add_binned && (type == EK_F32 || type == EK_I32 || type == EK_U32) &&
+    const bool fused = mode == 0 && ctx().tuning.scatter_add_binned && type != EK_BOOL &&
                        (index_type == EK_U32 || index_type == EK_I32) &&
-                       scatter_add_binned_multi_applicable(base_size, n, index->ptr != nullptr && index->size == n);
+                       scatter_add_binned_multi_applicable(base_size, n, index->ptr != nullptr && index->size == n, type_size(type));
     if (fused) {
         if (type == EK_F32) {
             if (index_type == EK_U32) return scatter_add_multi_fused_count<float, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
             return scatter_add_multi_fused_count<float, int32_t>(count, bases, base_size, values, weights, index, mask, n);
         }
+        if (type == EK_F64) {
+            if (index_type == EK_U32) return scatter_add_multi_fused_count<double, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
+            return scatter_add_multi_fused_count<double, int32_t>(count, bases, base_size, values, weights, index, mask, n);
+        }
         bool any_weight = false;
         for (int c = 0; c < count; ++c) any_weight = any_weight || (weights && weights[c]);
         if (!any_weight) {      // integer streams carry no gradients; the fused path takes them unweighted
+            if (type_size(type) == 8) {
+                if (index_type == EK_U32) return scatter_add_multi_fused_count<uint64_t, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
+                return scatter_add_multi_fused_count<uint64_t, int32_t>(count, bases, base_size, values, weights, index, mask, n);
+            }
             if (index_type == EK_U32) return scatter_add_multi_fused_count<uint32_t, uint32_t>(count, bases, base_size, values, weights, index, mask, n);
             return scatter_add_multi_fused_count<uint32_t, int32_t>(count, bases, base_size, values, weights, index, mask, n);
         }

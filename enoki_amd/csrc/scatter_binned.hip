@@ -29,6 +29,21 @@ namespace ek {
 
 constexpr int kBinShift = 14;
 constexpr int kBins = 1 << kBinShift;      // bins per bucket (64 KiB of f32 / i32 in LDS)
+// 8-byte element types get half as many bins per bucket: the LDS table stays at 64 KiB (two workgroups per CU)
+template <typename T> constexpr int bin_shift_of = sizeof(T) == 8 ? kBinShift - 1 : kBinShift;
+template <typename T> constexpr int bins_of = 1 << bin_shift_of<T>;
+
+// four consecutive elements: one 16-byte load for 4-byte types, two for 8-byte types
+template <typename T, bool NT> __device__ __forceinline__ void load4(const T *p, T (&out)[4]) {
+    if constexpr (sizeof(T) * 4 <= 16) {
+        Pack<T, 4> v = pack_load<T, 4, NT>(p);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = v.v[j];
+    } else {
+        Pack<T, 2> a = pack_load<T, 2, NT>(p), b = pack_load<T, 2, NT>(p + 2);
+        out[0] = a.v[0]; out[1] = a.v[1]; out[2] = b.v[0]; out[3] = b.v[1];
+    }
+}
 constexpr int kMaxBuckets = 256;
 constexpr int kThreads = 512;
 constexpr int kPerThread = 16;
@@ -51,13 +66,13 @@ __device__ __forceinline__ void load_tile(const I *__restrict__ index, const Arg
             Pack<I, 4> pi = pack_load<I, 4, true>(index + e);
             Pack<uint8_t, 4> pm;
             if (mask.vec) pm = pack_load<uint8_t, 4, true>(mask.ptr + e);
-            Pack<T, 4> pv;
-            if constexpr (WithValue) { if (value.vec) pv = pack_load<T, 4, true>(value.ptr + e); }
+            T pv[4] = {};
+            if constexpr (WithValue) { if (value.vec) load4<T, true>(value.ptr + e, pv); }
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 ix[h * 4 + j] = index_u32(pi.v[j]);
                 on[h * 4 + j] = mask.vec ? pm.v[j] != 0 : sm != 0;
-                if constexpr (WithValue) val[h * 4 + j] = value.vec ? pv.v[j] : sv;
+                if constexpr (WithValue) val[h * 4 + j] = value.vec ? pv[j] : sv;
             }
         }
     } else {
@@ -82,9 +97,10 @@ __device__ __forceinline__ void load_tile_operand(const Arg<T> &a, T s, size_t b
 #pragma unroll
         for (int h = 0; h < kRuns; ++h) {
             const size_t e = base + (size_t) h * (kTile / kRuns) + (size_t) threadIdx.x * 4;
-            Pack<T, 4> pv = pack_load<T, 4, true>(a.ptr + e);
+            T pv[4];
+            load4<T, true>(a.ptr + e, pv);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) val[h * 4 + j] = pv.v[j];
+            for (int j = 0; j < 4; ++j) val[h * 4 + j] = pv[j];
         }
     } else {
 #pragma unroll
@@ -339,6 +355,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__
 // iteration and the holder never waits for a spinner -> always progresses.  With random bins almost
 // every lane succeeds on the first try: ~2 LDS instructions per element instead of a 194-cycle atomic.
 constexpr uint32_t kLockedBits = 0xFFC00001u;
+constexpr unsigned long long kLockedBits64 = 0xFFF8000000000001ull;
 
 template <bool UseLock, typename T> __device__ __forceinline__ void lds_add(T *addr, T v, bool active) {
     if constexpr (std::is_same_v<T, float>) {
@@ -387,6 +404,44 @@ template <bool UseLock, typename T> __device__ __forceinline__ void lds_add(T *a
         } else {
             if (active) atomicAdd(addr, v);                                          // ds_add_f32
         }
+    } else if constexpr (std::is_same_v<T, double>) {
+        // the same exchange lock on 64-bit bins (ds_wrxchg_rtn_b64); tiny tables use ds_add_f64 directly
+        if constexpr (UseLock) {
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(addr);
+            bool pending = active;
+            if (pending) {
+                unsigned long long old = atomicExch(p, kLockedBits64);
+                if (old != kLockedBits64) {
+                    unsigned long long bits = (unsigned long long) __double_as_longlong(__longlong_as_double((long long) old) + v);
+                    if (bits == kLockedBits64) bits = 0x7FF8000000000000ull;
+                    __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pending = false;
+                }
+            }
+            const unsigned key = (unsigned) (uintptr_t) addr;
+            const int lane = threadIdx.x & 63;
+            while (__any(pending)) {
+                const unsigned long long pend = __ballot(pending);
+                const int leader = __ffsll((long long) pend) - 1;
+                const unsigned leader_key = __shfl(key, leader);
+                const bool grouped = pending && key == leader_key;
+                double total = grouped ? v : 0.0;
+#pragma unroll
+                for (int d = 32; d >= 1; d >>= 1) total += __shfl_xor(total, d);
+                if (lane == leader) {
+                    unsigned long long old;
+                    do { old = atomicExch(p, kLockedBits64); } while (old == kLockedBits64);
+                    unsigned long long bits = (unsigned long long) __double_as_longlong(__longlong_as_double((long long) old) + total);
+                    if (bits == kLockedBits64) bits = 0x7FF8000000000000ull;
+                    __hip_atomic_store(p, bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                }
+                pending = pending && !grouped;
+            }
+        } else {
+            if (active) atomicAdd(addr, v);                                          // ds_add_f64
+        }
+    } else if constexpr (sizeof(T) == 8) {
+        if (active) atomicAdd(reinterpret_cast<unsigned long long *>(addr), (unsigned long long) v);   // ds_add_u64
     } else {
         if (active) atomicAdd(reinterpret_cast<unsigned int *>(addr), (unsigned int) v);   // ds_add_u32
     }
@@ -403,6 +458,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
                                                              int slices, const uint32_t *__restrict__ piece_prefix) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T *acc = reinterpret_cast<T *>(lds_raw);
+    constexpr int Bins = bins_of<T>;
     size_t begin, end;
     if constexpr (Direct) {
         const size_t per = ((n + slices - 1) / slices + 4095) / 4096 * 4096;     // multiple of the vector step
@@ -424,7 +480,7 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
         begin = lo + q * per < hi ? lo + q * per : hi;
         end = begin + per < hi ? begin + per : hi;
     }
-    for (int j = threadIdx.x; j < kBins; j += kThreads) acc[j] = T(0);
+    for (int j = threadIdx.x; j < Bins; j += kThreads) acc[j] = T(0);
     __syncthreads();
 
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
@@ -440,18 +496,18 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
             size_t base = begin;
             for (; base + kStep <= end; base += kStep) {
                 Pack<I, 4> pi[2];
-                Pack<T, 4> pv[2];
+                T pv[2][4];
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
                     const size_t e = base + (size_t) h * (kStep / 2) + (size_t) threadIdx.x * 4;
                     pi[h] = pack_load<I, 4, true>(index + e);
-                    pv[h] = pack_load<T, 4, true>(value.ptr + e);
+                    load4<T, true>(value.ptr + e, pv[h]);
                 }
 #pragma unroll
                 for (int h = 0; h < 2; ++h)
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
-                        lds_add<UseLock>(&acc[index_u32(pi[h].v[j]) & (kBins - 1)], pv[h].v[j], true);
+                        lds_add<UseLock>(&acc[index_u32(pi[h].v[j]) & (Bins - 1)], pv[h][j], true);
             }
             begin = base;          // the generic loop below finishes the tail
         }
@@ -464,24 +520,24 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
             const bool on = i < head_end;
             const uint32_t ix = on ? (uint32_t) pair_idx[i] : 0u;
             const T v = on ? pair_val[i] : T(0);
-            lds_add<UseLock>(&acc[ix & (kBins - 1)], v, on);
+            lds_add<UseLock>(&acc[ix & (Bins - 1)], v, on);
         }
         constexpr size_t kStep = (size_t) kAcc * kThreads;
         size_t base = head_end;
         for (; base + kStep <= end; base += kStep) {
             Pack<uint16_t, 4> pi[2];
-            Pack<T, 4> pv[2];
+            T pv[2][4];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
                 const size_t e = base + (size_t) h * (kStep / 2) + (size_t) threadIdx.x * 4;
                 pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
-                pv[h] = pack_load<T, 4, true>(pair_val + e);
+                load4<T, true>(pair_val + e, pv[h]);
             }
 #pragma unroll
             for (int h = 0; h < 2; ++h)
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
-                    lds_add<UseLock>(&acc[(uint32_t) pi[h].v[j] & (kBins - 1)], pv[h].v[j], true);
+                    lds_add<UseLock>(&acc[(uint32_t) pi[h].v[j] & (Bins - 1)], pv[h][j], true);
         }
         begin = base;
     }
@@ -509,14 +565,14 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
         }
 #pragma unroll
         for (int k = 0; k < kAcc; ++k)
-            lds_add<UseLock>(&acc[ix[k] & (kBins - 1)], val[k], on[k]);
+            lds_add<UseLock>(&acc[ix[k] & (Bins - 1)], val[k], on[k]);
     }
     __syncthreads();
 
     // Direct: one table-sized partial per slice; binned: one bucket-sized partial per piece
-    T *out = Direct ? partials + (size_t) blockIdx.x * table_size : partials + (size_t) blockIdx.x * kBins;
-    const size_t valid = Direct ? table_size : (size_t) kBins;
-    for (int j = threadIdx.x; j < kBins; j += kThreads)
+    T *out = Direct ? partials + (size_t) blockIdx.x * table_size : partials + (size_t) blockIdx.x * Bins;
+    const size_t valid = Direct ? table_size : (size_t) Bins;
+    for (int j = threadIdx.x; j < Bins; j += kThreads)
         if ((size_t) j < valid) out[j] = acc[j];
 }
 
@@ -553,10 +609,10 @@ __global__ __launch_bounds__(256) void k_bin_fold_pieces(T *__restrict__ target,
     size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
     if (k >= table_size) return;
     using U = wrap_t<T>;
-    const uint32_t b = (uint32_t) (k >> kBinShift), local = (uint32_t) (k & (kBins - 1));
+    const uint32_t b = (uint32_t) (k >> bin_shift_of<T>), local = (uint32_t) (k & (bins_of<T> - 1));
     T s = target[k];
     for (uint32_t p = piece_prefix[b]; p < piece_prefix[b + 1]; ++p)
-        s = (T) ((U) s + (U) partials[(size_t) p * kBins + local]);
+        s = (T) ((U) s + (U) partials[(size_t) p * bins_of<T> + local]);
     target[k] = s;
 }
 
@@ -576,11 +632,12 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
 template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n) {
-    if (table_size > (size_t) kMaxBuckets * kBins)
+    constexpr int Bins = bins_of<T>;
+    if (table_size > (size_t) kMaxBuckets * Bins)
         return scatter_add_binned_large<T, I>(base, table_size, value, index, mask, n);
     Context &c = ctx();
-    const int n_buckets = (int) ((table_size + kBins - 1) / kBins);
-    const size_t lds_bytes = (size_t) kBins * sizeof(T);
+    const int n_buckets = (int) ((table_size + Bins - 1) / Bins);
+    const size_t lds_bytes = (size_t) Bins * sizeof(T);
     const size_t algo_bytes = arg_bytes(value, n) + arg_bytes(index, n) + arg_bytes(mask, n);
 
     if (n_buckets == 1) {
@@ -627,8 +684,9 @@ template <typename T, typename I, int C>
 int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
                              const Arg<I> &index, const Arg<uint8_t> &mask, size_t n) {
     Context &c = ctx();
-    const int n_buckets = (int) ((table_size + kBins - 1) / kBins);
-    const size_t lds_bytes = (size_t) kBins * sizeof(T);
+    constexpr int Bins = bins_of<T>, Shift = bin_shift_of<T>;
+    const int n_buckets = (int) ((table_size + Bins - 1) / Bins);
+    const size_t lds_bytes = (size_t) Bins * sizeof(T);
     if (n_buckets < 2 || n_buckets > kMaxBuckets) return fail(EK_ERR_INVALID, "scatter_add_binned_multi(): table size out of range");
 
     // chunked passes over the input: a few workgroups per CU, chunks are multiples of the tile
@@ -666,29 +724,29 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
     const uint32_t target_pieces = (uint32_t) std::max(2 * c.num_cu, n_buckets);
     const unsigned max_pieces = target_pieces + (unsigned) n_buckets;       // rounding + "at least one" slack
 
-    hipLaunchKernelGGL((k_bin_count<I>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, index.ptr,
+    hipLaunchKernelGGL((k_bin_count<I, Shift>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, index.ptr,
                        mask, n, chunk, n_buckets, rep_shift, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_count", n, arg_bytes(index, n) + arg_bytes(mask, n));
     hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_buckets), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
     hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, piece_prefix,
                        (const uint32_t *) row_total, n_buckets, target_pieces);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
-    hipLaunchKernelGGL((k_bin_partition<T, I, kBinShift, uint16_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream,
+    hipLaunchKernelGGL((k_bin_partition<T, I, Shift, uint16_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream,
                        (uint16_t *) pairs_idx.ptr, st, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, index.ptr,
                        mask, n, chunk, n_buckets, 0, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_partition", n, stream_bytes + arg_bytes(index, n) + arg_bytes(mask, n) +
                                                 n * (sizeof(uint16_t) + C * sizeof(T)));
 
-    if (int rc = partials.alloc((size_t) max_pieces * kBins * sizeof(T))) return rc;
+    if (int rc = partials.alloc((size_t) max_pieces * Bins * sizeof(T))) return rc;
     for (int s = 0; s < C; ++s) {
         // (the partials buffer is reused: the launches of one stream are ordered on the stream)
         hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3(max_pieces), dim3(kThreads), lds_bytes, c.stream,
                            (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr, (const T *) pairs_val[s].ptr,
                            (const uint32_t *) bucket_base, values[s], index.ptr, mask, n, n_buckets, (const uint32_t *) piece_prefix);
-        EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * kBins * sizeof(T));
+        EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * Bins * sizeof(T));
         hipLaunchKernelGGL((k_bin_fold_pieces<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, bases[s],
                            (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size);
-        EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) max_pieces * kBins * sizeof(T) + 2 * table_size * sizeof(T));
+        EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) max_pieces * Bins * sizeof(T) + 2 * table_size * sizeof(T));
     }
     return EK_OK;
 }
@@ -699,8 +757,7 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
 // slice is then an ordinary binned scatter_add on `base + slice * 4 Mi`.  The slice populations are read back once
 // (the only synchronisation).  Versus the global-atomic fallback this is ~5x faster on uniform indices and does not
 // collapse on skewed ones (same-address device atomics retire at 0.08 G/s).
-constexpr int kSuperShift = kBinShift + 8;                    // 2^22 bins per super-bucket
-constexpr size_t kSuperBins = (size_t) 1 << kSuperShift;
+template <typename T> constexpr int super_shift_of = bin_shift_of<T> + 8;       // 2^22 (2^21 for 8-byte types) bins per super-bucket
 
 template <typename T, int N> __global__ __launch_bounds__(256) void k_scatter_add_pairs(T *__restrict__ base, const T *__restrict__ val,
                                                                                        const uint32_t *__restrict__ idx, size_t n) {
@@ -708,7 +765,7 @@ template <typename T, int N> __global__ __launch_bounds__(256) void k_scatter_ad
     size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     using U = wrap_t<T>;
-    if constexpr (std::is_same_v<T, float>) unsafeAtomicAdd(base + idx[i], val[i]);
+    if constexpr (std::is_floating_point_v<T>) unsafeAtomicAdd(base + idx[i], val[i]);
     else atomicAdd(reinterpret_cast<U *>(base) + idx[i], (U) val[i]);
 }
 
@@ -716,6 +773,8 @@ template <typename T, typename I>
 int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                              size_t n) {
     Context &c = ctx();
+    constexpr int kSuperShift = super_shift_of<T>;
+    constexpr size_t kSuperBins = (size_t) 1 << kSuperShift;
     const int n_super = (int) ((table_size + kSuperBins - 1) / kSuperBins);
     unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
     if (blocks == 0) blocks = 1;
@@ -777,14 +836,16 @@ int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, co
 }
 
 // entry points used by ek_hip_scatter_add (memory.hip)
-bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array) {
+bool scatter_add_binned_applicable(size_t table_size, size_t n, bool index_is_array, size_t elem_size) {
+    const int shift = elem_size == 8 ? kBinShift - 1 : kBinShift;
     return index_is_array && table_size > 0 && n >= ((size_t) 1 << 18) &&
-           table_size <= (size_t) kMaxBuckets * kSuperBins && n < ((size_t) 1 << 32);
+           table_size <= ((size_t) kMaxBuckets << (shift + 8)) && n < ((size_t) 1 << 32);
 }
 
-bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array) {
-    return scatter_add_binned_applicable(table_size, n, index_is_array) && table_size > (size_t) kBins &&
-           table_size <= (size_t) kMaxBuckets * kBins;
+bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array, size_t elem_size) {
+    const int shift = elem_size == 8 ? kBinShift - 1 : kBinShift;
+    return scatter_add_binned_applicable(table_size, n, index_is_array, elem_size) && table_size > ((size_t) 1 << shift) &&
+           table_size <= ((size_t) kMaxBuckets << shift);
 }
 
 #define EK_BINNED_INSTANCE(T, I)                                                                                      \
@@ -797,6 +858,8 @@ bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index
                                                    const Arg<I> &, const Arg<uint8_t> &, size_t);
 EK_BINNED_INSTANCE(float, uint32_t) EK_BINNED_INSTANCE(float, int32_t)
 EK_BINNED_INSTANCE(uint32_t, uint32_t) EK_BINNED_INSTANCE(uint32_t, int32_t)
+EK_BINNED_INSTANCE(double, uint32_t) EK_BINNED_INSTANCE(double, int32_t)
+EK_BINNED_INSTANCE(uint64_t, uint32_t) EK_BINNED_INSTANCE(uint64_t, int32_t)
 
 } // namespace ek
 

@@ -523,6 +523,33 @@ def test_scatter_add_multi_weighted_f32(capi, K, n):
     assert np.array_equal(d1[1].numpy().view(np.uint32), d2[1].numpy().view(np.uint32))
 
 
+@pytest.mark.parametrize("K", [8193, 100000, (1 << 21) - 3, (1 << 21) + 9])
+def test_scatter_add_multi_64bit(capi, K):
+    """8-byte element types: 8 Ki bins per LDS bucket (64 KiB), exchange lock on 64-bit words; int64 streams exact, float64
+    streams with a fused weight within the rounding bound of an arbitrary-order accumulation"""
+    n = (1 << 19) + 977
+    rng = np.random.default_rng(K)
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    m = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+    iv = [rng.integers(-10**12, 10**12, n).astype(np.int64) for _ in range(2)]
+    it = [rng.integers(-5, 5, K).astype(np.int64) for _ in range(2)]
+    d = [up(capi, t) for t in it]
+    capi.scatter_add_multi(d, [up(capi, v) for v in iv], up(capi, idx), up(capi, m))
+    for c in range(2):
+        expect = it[c].copy(); np.add.at(expect, idx[m != 0], iv[c][m != 0])
+        assert np.array_equal(d[c].numpy(), expect), c
+    g = [rng.standard_normal(n) for _ in range(2)]; w = rng.standard_normal(n); w[::9] = 0.0
+    ft = [rng.standard_normal(K) for _ in range(2)]
+    d = [up(capi, t) for t in ft]
+    capi.scatter_add_multi(d, [up(capi, g[0]), up(capi, g[1])], up(capi, idx), weights=[None, up(capi, w)], n=n)
+    prod = [g[0], np.where((w == 0) | (g[1] == 0), 0.0, w * g[1])]
+    cnt = np.bincount(idx, minlength=K) + 1
+    for c in range(2):
+        truth = ft[c].astype(np.longdouble); np.add.at(truth, idx, prod[c].astype(np.longdouble))
+        mag = np.abs(ft[c]); np.add.at(mag, idx, np.abs(prod[c]))
+        assert np.all(np.abs(d[c].numpy() - truth.astype(np.float64)) <= cnt * 2.0 ** -52 * mag + 1e-300), c
+
+
 def test_scatter_add_multi_rejects_bad_arguments(capi):
     t = up(capi, np.zeros(100, np.float32)); v = up(capi, np.ones(10, np.float32)); i = up(capi, np.zeros(10, np.uint32))
     with pytest.raises(capi.EnokiHipError):
@@ -570,7 +597,7 @@ def test_scatter_add_deterministic_switch(capi, oracle):
 
 
 @pytest.mark.parametrize("pattern", ["all_same", "two_bins", "zipf", "one_bucket", "sorted"])
-@pytest.mark.parametrize("dt", [np.float32, np.uint32])
+@pytest.mark.parametrize("dt", [np.float32, np.uint32, np.float64, np.int64])
 def test_scatter_add_binned_skewed_indices(capi, pattern, dt):
     """heavily skewed index distributions (gradients of a few hot texels): colliding lanes are combined inside the wave
     and the accumulate work is shared out by bucket population, so the result is exact (small integer values) and the
@@ -594,7 +621,7 @@ def test_scatter_add_binned_skewed_indices(capi, pattern, dt):
 
 
 @pytest.mark.parametrize("pattern", ["uniform", "zipf", "all_same", "last_slice_only"])
-@pytest.mark.parametrize("dt", [np.float32, np.uint32])
+@pytest.mark.parametrize("dt", [np.float32, np.uint32, np.float64, np.uint64])
 def test_scatter_add_tables_beyond_4mi_bins(capi, pattern, dt):
     """tables larger than 256 LDS buckets: pairs are first split by 4 Mi-bin slice of the table, every populated slice is
     then an ordinary binned scatter_add (small slices: atomics); exact for small integer values"""
@@ -620,14 +647,14 @@ def test_out_of_memory_is_an_error_not_a_crash(capi):
     assert float(capi.reduce("hsum", small).numpy()[0]) == float(1 << 20)      # the library keeps working
 
 
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(48))
 def test_scatter_add_randomized_shapes(capi, seed):
     """random (n, table size, mask density, index distribution, value type) through the size-dependent paths of
     ek_hip_scatter_add (atomics / LDS direct / binned / two-level binned); small integer values make every path exact"""
     rng = np.random.default_rng(100 + seed)
     n = int(rng.choice([1, 7, 1000, (1 << 18) - 1, 1 << 18, (1 << 18) + 1, 300_007, 1 << 20, (1 << 21) + 12345]))
     K = int(rng.choice([1, 2, 63, 1024, 1025, 16384, 16385, 100_000, (1 << 20) - 3, 1 << 22, (1 << 22) + 1, 5_000_011, 1 << 24]))
-    dt = [np.float32, np.uint32, np.int32][seed % 3]
+    dt = [np.float32, np.uint32, np.int32, np.float64, np.int64, np.uint64][seed % 6]
     kind = ["uniform", "clustered", "few", "ramp"][int(rng.integers(0, 4))]
     if kind == "uniform":
         idx = rng.integers(0, K, n)
