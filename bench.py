@@ -421,6 +421,12 @@ def cpu_all_cores(workload, n, kind):
 
 def main():
     args = parse()
+    launched = "RANK" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if launched:
+        # A multi-process run must never sit in a collective forever (a rank that died, a rendezvous that never
+        # completes): after 15 minutes every rank dumps its python stack and exits non-zero instead of hanging.
+        import faulthandler
+        faulthandler.dump_traceback_later(900, exit=True)
     b = Bench(args)
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
@@ -451,11 +457,19 @@ def main():
                        "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"]},
             "result_y": main_res["result_y"], "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if b.ekd.active():
+        # the measurement is complete and printed: tear the group down, but do not let a stuck teardown hold the job
+        import faulthandler
+        import threading
         import torch.distributed as dist
+        faulthandler.cancel_dump_traceback_later()
+        killer = threading.Timer(120.0, lambda: os._exit(0))
+        killer.daemon = True
+        killer.start()
         b.ekd.barrier()
         dist.destroy_process_group()
+        killer.cancel()
 
 
 if __name__ == "__main__":
