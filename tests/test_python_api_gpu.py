@@ -438,3 +438,18 @@ def test_reference_module_level_helpers(ekc, ek):
     enoki.cuda_eval(); enoki.cuda_sync()
     assert isinstance(enoki.cuda_whos(), str) and enoki.cuda_log_level() == 0
     assert enoki.shape(ekc.Float32(a)) == (1001,) and enoki.shape(ekc.Vector3f(ekc.Float32(a), ekc.Float32(a), ekc.Float32(a))) == (3, 1001)
+
+
+def test_compat_package_covers_the_widened_types():
+    """`import enoki as ek`: <Type>C / <Type>D aliases for the matrix / complex classes, type-dispatched special functions"""
+    import enoki as ek2
+    x = np.linspace(-1.5, 1.5, 257).astype(np.float32)
+    for suffix, det in (("C", lambda v: v), ("D", ek2.detach)):
+        F = getattr(ek2, "Float" + suffix)
+        assert np.allclose(det(ek2.erf(F(x))).numpy(), [__import__("math").erf(float(v)) for v in x], atol=2e-6)
+        M = getattr(ek2, "Matrix4f" + suffix)
+        m = M.identity(3) * F(2.0)
+        assert np.allclose(det(ek2.det(m)).numpy(), 16.0) and np.allclose(det(ek2.inverse(m)[2, 2]).numpy(), 0.5)
+        C = getattr(ek2, "Complex2f" + suffix)
+        z = C(F(x), F(x * 0 + 1)) * C(F(x * 0), F(x * 0 + 1))             # (x + i) * i = -1 + x i
+        assert np.allclose(det(z.real).numpy(), -1.0) and np.allclose(det(z.imag).numpy(), x)
