@@ -260,9 +260,13 @@ __global__ __launch_bounds__(kThreads) void k_bin_partition(OutIdx *__restrict__
     }
     const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
 
-    // values of stream c for the current tile (times their weights)
+    // values of stream c for the current tile (times their weights).  `val` still holds the values of stream c - 1: when
+    // that stream was unweighted and reads the same array (g and w * g of one gradient g -- the usual pair), the array
+    // is not loaded a second time.
     auto load_stream = [&](int c, size_t base, T (&val)[kPerThread]) {
-        load_tile_operand(st.value[c], sv[c], base, end, vec_ok, val);
+        const bool reuse = c > 0 && st.value[c].vec && st.value[c].ptr == st.value[c > 0 ? c - 1 : 0].ptr &&
+                           !((st.weighted >> (c > 0 ? c - 1 : 0)) & 1u);
+        if (!reuse) load_tile_operand(st.value[c], sv[c], base, end, vec_ok, val);
         if ((st.weighted >> c) & 1u) {
             T w[kPerThread];
             load_tile_operand(st.weight[c], sw[c], base, end, vec_ok, w);
@@ -704,7 +708,8 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
         st.value[s] = values[s];
         st.weight[s] = weights[s];
         vec_ok = vec_ok && arg_aligned(values[s]) && (!((weighted >> s) & 1u) || arg_aligned(weights[s]));
-        stream_bytes += arg_bytes(values[s], n) + (((weighted >> s) & 1u) ? arg_bytes(weights[s], n) : 0);
+        const bool reused = s > 0 && values[s].vec && values[s].ptr == values[s - 1].ptr && !((weighted >> (s - 1)) & 1u);
+        stream_bytes += (reused ? 0 : arg_bytes(values[s], n)) + (((weighted >> s) & 1u) ? arg_bytes(weights[s], n) : 0);
     }
     int rep_shift = 0;
     while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
