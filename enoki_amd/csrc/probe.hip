@@ -219,6 +219,34 @@ extern "C" EK_API int ek_hip_probe_lds_atomic(int variant, int blocks, int iters
     return EK_OK;
 }
 
+// L2 blocking in time: one launch per table slice [lo, hi); lanes whose index falls outside skip (their output element is
+// written by another launch).  `out` is written with per-lane 4-byte stores.
+__global__ __launch_bounds__(256) void k_probe_gather_range(float *__restrict__ out, const float *__restrict__ table,
+                                                            const uint32_t *__restrict__ idx, size_t n, uint32_t lo, uint32_t hi) {
+    size_t e = ((size_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e + 4 > n) return;
+    using U4 = __attribute__((ext_vector_type(4))) uint32_t;
+    U4 p = __builtin_nontemporal_load(reinterpret_cast<const U4 *>(idx + e));
+    float v[4];
+    bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { in[k] = p[k] >= lo && p[k] < hi; v[k] = in[k] ? table[p[k]] : 0.0f; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (in[k]) out[e + k] = v[k];
+}
+
+extern "C" EK_API int ek_hip_probe_gather_sliced(int slices, float *out, const float *table, size_t table_size, const uint32_t *idx, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+    for (int s = 0; s < slices; ++s) {
+        uint32_t lo = (uint32_t) (table_size * (size_t) s / slices), hi = (uint32_t) (table_size * (size_t) (s + 1) / slices);
+        hipLaunchKernelGGL(k_probe_gather_range, dim3((unsigned) ((n / 4 + 255) / 256)), dim3(256), 0, cx.stream, out, table, idx, n, lo, hi);
+    }
+    EK_LAUNCH_CHECK("probe_gather_sliced", n, 12 * n);
+    return EK_OK;
+}
+
 extern "C" EK_API int ek_hip_probe_gather(int elems, int policy, float *out, const float *table, const uint32_t *idx, size_t n) {
     if (int rc = ensure_init()) return rc;
     Context &cx = ctx();
