@@ -38,7 +38,7 @@ EXPORTS = [
     "ek_hip_last_error", "ek_hip_malloc", "ek_hip_free", "ek_hip_malloc_trim", "ek_hip_host_malloc",
     "ek_hip_host_free", "ek_hip_mem_get_info", "ek_hip_memcpy_to_device", "ek_hip_memcpy_to_host",
     "ek_hip_memcpy_device", "ek_hip_memset", "ek_hip_whos", "ek_hip_set_log_level", "ek_hip_log_level",
-    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_scatter_add_multi",
+    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_scatter_add_multi", "ek_hip_concat",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum",

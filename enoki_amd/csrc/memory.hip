@@ -39,6 +39,21 @@ __global__ __launch_bounds__(256) void k_reverse(T *__restrict__ out, const T *_
         out[i] = in[n - 1 - i];
 }
 
+// ---- concat ------------------------------------------------------------------------------------
+constexpr int kConcatMax = 8;
+struct ConcatArgs { const void *src[kConcatMax]; size_t end[kConcatMax]; };
+
+template <typename T> __global__ __launch_bounds__(256) void k_concat(T *__restrict__ out, ConcatArgs a, size_t total) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const void *src = a.src[0];
+    size_t begin = 0;
+#pragma unroll
+    for (int k = 0; k < kConcatMax - 1; ++k)            // ends ascend: the last boundary at or below i wins
+        if (i >= a.end[k]) { src = a.src[k + 1]; begin = a.end[k]; }
+    out[i] = static_cast<const T *>(src)[i - begin];
+}
+
 // ---- gather ------------------------------------------------------------------------------------
 template <typename I> __device__ __forceinline__ int64_t index_offset(I i) { return (int64_t) i; }
 
@@ -293,6 +308,35 @@ int ek_hip_reverse(int type, void *out, const void *in, size_t n) {
         default: return fail(EK_ERR_INVALID, "ek_hip_reverse(): unknown type %d", type);
     }
     EK_LAUNCH_CHECK("reverse", n, 2 * n * type_size(type));
+    return EK_OK;
+}
+
+int ek_hip_concat(int type, void *out, int count, const void *const *srcs, const size_t *sizes) {
+    if (int rc = ensure_init()) return rc;
+    if (count < 1 || count > kConcatMax) return fail(EK_ERR_INVALID, "ek_hip_concat(): 1 to %d arrays expected, got %d", kConcatMax, count);
+    if (!out || !srcs || !sizes) return fail(EK_ERR_INVALID, "ek_hip_concat(): null pointer");
+    ConcatArgs a;
+    size_t total = 0;
+    for (int i = 0; i < kConcatMax; ++i) {
+        a.src[i] = nullptr;
+        a.end[i] = total;
+        if (i < count) {
+            if (sizes[i] && !srcs[i]) return fail(EK_ERR_INVALID, "ek_hip_concat(): null pointer");
+            a.src[i] = srcs[i];
+            total += sizes[i];
+            a.end[i] = total;
+        }
+    }
+    if (total == 0) return EK_OK;
+    Context &c = ctx();
+    unsigned grid = (unsigned) ((total + 255) / 256);
+    switch (type_size(type)) {
+        case 1: hipLaunchKernelGGL((k_concat<uint8_t>), dim3(grid), dim3(256), 0, c.stream, (uint8_t *) out, a, total); break;
+        case 4: hipLaunchKernelGGL((k_concat<uint32_t>), dim3(grid), dim3(256), 0, c.stream, (uint32_t *) out, a, total); break;
+        case 8: hipLaunchKernelGGL((k_concat<uint64_t>), dim3(grid), dim3(256), 0, c.stream, (uint64_t *) out, a, total); break;
+        default: return fail(EK_ERR_INVALID, "ek_hip_concat(): unknown type %d", type);
+    }
+    EK_LAUNCH_CHECK("concat", total, 2 * total * type_size(type));
     return EK_OK;
 }
 

@@ -94,6 +94,13 @@ class Packer:
             self.work[self.cur].wait()
             self.work[self.cur] = None
         self.flat = self.bufs[self.cur]
+        if self.flat.is_cuda and self.flat.dtype == torch.float32 and len(tensors) <= 8 and \
+                all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+            # one launch for all parts (ek_hip_concat) on the stream shared with torch, instead of one copy per part
+            from enoki_amd import hip as _ek
+            assert [t.numel() for t in tensors] == self.sizes
+            _ek.hip_concat_f32(self.flat.data_ptr(), [(t.data_ptr(), t.numel()) for t in tensors])
+            return
         for i, t in enumerate(tensors):
             self.slot(i).copy_(t.reshape(-1), non_blocking=True)
 

@@ -538,5 +538,11 @@ inline void bind_runtime(py::module_ &m) {
         free(r);
         return s;
     }, "JSON list of {kernel, launches, total_ms, bytes, elements} since hip_profile_begin()");
+    m.def("hip_concat_f32", [](uintptr_t out, const std::vector<std::pair<uintptr_t, size_t>> &parts) {
+        std::vector<const void *> srcs;
+        std::vector<size_t> sizes;
+        for (const auto &p : parts) { srcs.push_back((const void *) p.first); sizes.push_back(p.second); }
+        detail::hip_check(ek_hip_concat(EK_F32, (void *) out, (int) parts.size(), srcs.data(), sizes.data()), "hip_concat_f32");
+    }, "out"_a, "parts"_a, "out = parts[0] | parts[1] | ... ((device pointer, element count) pairs of float32 arrays), one launch");
     m.def("hip_set_tuning", [](const char *k, int v) { detail::hip_check(ek_hip_set_tuning(k, v), "hip_set_tuning"); });
 }

@@ -157,6 +157,9 @@ EK_API int ek_hip_arange(int type, void *out, int64_t start, int64_t step, size_
 /* out[i] = fmadd(i, step, min), step = (max-min)/(n-1)  (cuda.h:655-663) */
 EK_API int ek_hip_linspace(int type, void *out, double min, double max, size_t n);
 EK_API int ek_hip_reverse(int type, void *out, const void *in, size_t n);
+/* out = srcs[0] | srcs[1] | ... (sizes in elements, count <= 8) in ONE launch: the staging step of the packed all-reduce
+ * (scalar loss + K-element gradients -> one flat buffer), where three small copies would cost three launches */
+EK_API int ek_hip_concat(int type, void *out, int count, const void *const *srcs, const size_t *sizes);
 
 /* ---------------------------------------------------------------------------------------------
  *  Indexed memory ops (cuda.h:845-905).  `index_type` in {EK_I32, EK_U32, EK_I64, EK_U64};

@@ -677,3 +677,20 @@ def test_scatter_add_randomized_shapes(capi, seed):
     sel = mask != 0 if use_mask else np.ones(n, bool)
     want = 2 + np.bincount(idx[sel], weights=vals[sel].astype(np.float64), minlength=K)
     assert np.array_equal(t.numpy().astype(np.int64), want.astype(np.int64)), (n, K, dt, kind, density)
+
+
+def test_concat_single_launch(capi):
+    """ek_hip_concat: several arrays -> one flat buffer in one launch (staging of the packed all-reduce)"""
+    import ctypes
+    rng = np.random.default_rng(3)
+    parts = [rng.standard_normal(s).astype(np.float32) for s in (1, 1000, 0, 70001, 3)]
+    bufs = [up(capi, p) if p.size else None for p in parts]
+    out = capi.Buf(np.float32, sum(p.size for p in parts))
+    srcs = (ctypes.c_void_p * len(parts))(*[b.ptr if b is not None else None for b in bufs])
+    sizes = (ctypes.c_size_t * len(parts))(*[p.size for p in parts])
+    before = capi.lib.ek_hip_launch_count()
+    capi.check(capi.lib.ek_hip_concat(capi.NP2EK[np.dtype(np.float32)], ctypes.c_void_p(out.ptr), len(parts), srcs, sizes))
+    assert capi.lib.ek_hip_launch_count() - before == 1
+    assert np.array_equal(out.numpy(), np.concatenate(parts))
+    with pytest.raises(capi.EnokiHipError):
+        capi.check(capi.lib.ek_hip_concat(capi.NP2EK[np.dtype(np.float32)], ctypes.c_void_p(out.ptr), 9, srcs, sizes))
