@@ -428,6 +428,15 @@ namespace detail {
         (const V *) nullptr, (V *) nullptr, std::declval<const I &>(), std::declval<const mask_t<V> &>()))>> : std::true_type { };
 }
 
+namespace detail {
+    /// Backends that can run several scatter_adds through one index array in one pass (HIPArray::scatter_add_multi_)
+    template <typename T, typename I, typename = void> struct has_scatter_add_multi : std::false_type { };
+    template <typename T, typename I>
+    struct has_scatter_add_multi<T, I, std::void_t<decltype(T::scatter_add_multi_(
+        size_t(0), (T *const *) nullptr, (const T *const *) nullptr, (const T *const *) nullptr, std::declval<const I &>(),
+        std::declval<const mask_t<T> &>()))>> : std::true_type { };
+}
+
 /// Structure-of-arrays support for user types; specialised by ENOKI_STRUCT_SUPPORT (see the end of this file)
 template <typename T, typename = int> struct struct_support { static constexpr bool Defined = false; };
 template <typename T> constexpr bool is_struct_v = struct_support<std::decay_t<T>>::Defined;
@@ -681,6 +690,21 @@ template <typename Value_, size_t Size_> struct Array : ArrayTag {
     }
     template <bool IsPermute, typename Index, typename Mask>
     static void scatter_add_array_(Array &target, const Array &value, const Index &index, const Mask &mask) {
+        // the components share the index / mask array: one binning pass for all of them where the backend offers it
+        // (e.g. splatting RGB samples into three image planes)
+        if constexpr (detail::has_scatter_add_multi<Value, Index>::value && std::is_same_v<Mask, mask_t<Value>> &&
+                      Size >= 2 && Size <= 4) {
+            bool uniform = true;
+            for (size_t i = 0; i < Size; ++i)
+                uniform = uniform && target.m_data[i].size() == target.m_data[0].size() && target.m_data[i].size() > 1;
+            if (uniform) {
+                Value *targets[Size];
+                const Value *values[Size];
+                for (size_t i = 0; i < Size; ++i) { targets[i] = &target.m_data[i]; values[i] = &value.m_data[i]; }
+                Value::scatter_add_multi_(Size, targets, values, (const Value *const *) nullptr, index, mask);
+                return;
+            }
+        }
         for (size_t i = 0; i < Size; ++i) scatter_add<0, true, IsPermute>(target.m_data[i], value.m_data[i], index, mask);
     }
 

@@ -62,15 +62,6 @@ namespace detail {
     }
 }
 
-namespace detail {
-    /// Backends that can run several scatter_adds through one index array in one pass (HIPArray::scatter_add_multi_)
-    template <typename T, typename I, typename = void> struct has_scatter_add_multi : std::false_type { };
-    template <typename T, typename I>
-    struct has_scatter_add_multi<T, I, std::void_t<decltype(T::scatter_add_multi_(
-        size_t(0), (T *const *) nullptr, (const T *const *) nullptr, (const T *const *) nullptr, std::declval<const I &>(),
-        std::declval<const mask_t<T> &>()))>> : std::true_type { };
-}
-
 template <typename Value> inline Value safe_mul(const Value &w, const Value &g) {
     if constexpr (detail::has_fused_safe_ops<Value>::value) {
         return Value::safe_mul_(w, g);
