@@ -269,6 +269,16 @@ class Bench:
         ek.hip_sync()
         return step, packer, out
 
+    def stream_ceiling(self):
+        """What a plain streaming kernel of this library reaches on this GPU right now ('also report against a
+        measured copy-kernel ceiling'): abs() over 64 Mi floats, 4 B read + 4 B written per element, HIP events."""
+        from enoki_amd import hiprt
+        n = 1 << 26
+        x = self.synth.uniform_pm1(0, n, 9)
+        ms = min(hiprt.time_region(self.ekc.hip_stream(), lambda: self.ekc.abs(x), iters=10, warmup=2) for _ in range(3))
+        gbs = 8.0 * n / ms / 1e6
+        return {"kernel": "abs, 64 Mi f32 (8 B/elt)", "GB/s": round(gbs, 1), "frac_of_peak": round(gbs / (HBM_PEAK_TBS * 1000), 4)}
+
     def run(self, workload, steps, warmup, profile_steps):
         torch, ek, ekd = self.torch, self.ek, self.ekd
         step, packer, out = self.make_step(workload)
@@ -321,6 +331,8 @@ class Bench:
                                        "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload == "cfg4" else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
                         "kernels": kernels}
+        if roofline and workload == self.args.workload:
+            roofline["measured_stream_ceiling"] = self.stream_ceiling()
         y_val = float(out["y"].numpy()[0])
         if packer:
             y_val = float(packer.slot(0).item())
