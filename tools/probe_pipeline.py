@@ -6,7 +6,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from enoki_amd import capi, hiprt
 capi.init(); st = capi.stream()
-n = 1 << 26
+n = int(os.environ.get("PROBE_N", 1 << 26))
 rng = np.random.default_rng(0)
 h = rng.uniform(-1, 1, n).astype(np.float32)
 B = {k: capi.Buf.from_numpy(h) if k in "axb" else capi.Buf(np.float32, n) for k in ["a", "x", "b", "u", "s", "c", "gu", "ga", "gb"]}
