@@ -24,7 +24,12 @@ def shard_range(n, rank, world):
 
 
 def env_rank_world():
-    return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    """(rank, local device index, world size).  The device index is LOCAL_RANK folded into the devices this process can
+    see, so a launcher that narrows the visibility per rank (one visible GPU each) works like one that does not."""
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if torch.cuda.is_available() and torch.cuda.device_count() > 0:
+        local %= torch.cuda.device_count()
+    return int(os.environ.get("RANK", "0")), local, int(os.environ.get("WORLD_SIZE", "1"))
 
 
 def init(backend=None):
