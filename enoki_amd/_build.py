@@ -5,6 +5,7 @@
 
 Products (git-ignored, but shipped to the GPU box with the tree):
     enoki_amd/libenoki-hip.so            C ABI + HIP kernels      (csrc/*.hip, csrc/runtime.cpp)
+    enoki_amd/libenoki-hip-probe.so      measurement probes       (csrc/probe.hip; tools/ only)
     enoki_amd/libenoki-hip-autodiff.so   Tape<HIPArray<float>>    (src/autodiff.cpp)          [if present]
     enoki_amd/hip*.so                    pybind11 modules         (python/*.cpp)              [if present]
 
@@ -28,7 +29,9 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", 
           "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
 DEVICE = [f"--offload-arch={ARCH}"]
 
-LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "probe.hip"]
+LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip"]
+# measurement scaffolding (tools/probe_*.py): its own library on top of the public C ABI, never loaded by the product
+PROBE_SOURCES = ["probe.hip", "probe_rt.cpp"]
 
 
 def _newer(target, deps):
@@ -69,6 +72,18 @@ def build_core(force=False, verbose=True):
     lib = os.path.join(HERE, "libenoki-hip.so")
     if force or _newer(lib, objs):
         _run([HIPCC] + DEVICE + ["-shared", "-fPIC", "-o", lib] + objs)
+        if verbose:
+            print(f"[enoki_amd] built {os.path.relpath(lib, ROOT)}")
+    return lib
+
+
+def build_probe(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    sources = [os.path.join(CSRC, s) for s in PROBE_SOURCES if os.path.exists(os.path.join(CSRC, s))]
+    objs = [_compile(s, force) for s in sources]
+    lib = os.path.join(HERE, "libenoki-hip-probe.so")
+    if force or _newer(lib, objs + [os.path.join(HERE, "libenoki-hip.so")]):
+        _run([HIPCC] + DEVICE + ["-shared", "-fPIC", "-o", lib] + objs + [f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN"])
         if verbose:
             print(f"[enoki_amd] built {os.path.relpath(lib, ROOT)}")
     return lib
@@ -147,6 +162,7 @@ def build_checkers(force=False, verbose=True):
 
 def build_all(force=False, verbose=True):
     build_core(force, verbose)
+    build_probe(force, verbose)
     build_autodiff(force, verbose)
     build_python(force, verbose)
     build_checkers(force, verbose)

@@ -68,6 +68,20 @@ def load():
 
 lib = load()
 
+_probe = None
+
+
+def probe_lib():
+    """libenoki-hip-probe.so: the measurement kernels of csrc/probe.hip (tools/probe_*.py only; the product never loads it)"""
+    global _probe
+    if _probe is None:
+        path = os.path.join(HERE, "libenoki-hip-probe.so")
+        if not os.path.exists(path):
+            raise ImportError(f"{path} is missing -- run `python -m enoki_amd._build`")
+        _probe = ctypes.CDLL(path)
+        _probe.ek_hip_probe_last_error.restype = ctypes.c_char_p
+    return _probe
+
 
 def check(rc):
     if rc != 0:

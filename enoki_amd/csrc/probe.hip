@@ -174,6 +174,61 @@ __global__ __launch_bounds__(256) void k_probe_gather(float *__restrict__ out, c
     }
 }
 
+// ---- shared-index gather pairs, fused into their consumer (round 2) ---------------------------------
+// a = gather(A, idx), b = gather(B, idx), u = fmadd(a, x, b): what does it cost when
+//   variant 0: two 4-byte lookups per element, a and b written out            (= k_gather_multi<2>)
+//   variant 1: ONE 8-byte lookup per element from an interleaved {A[k], B[k]} table, a and b written out
+//   variant 2: two 4-byte lookups, consumed in place: only u = fma(a, x, b) is written
+//   variant 3: one 8-byte lookup, consumed in place
+//   variant 4: a streamed (materialised by an earlier launch), b looked up, u written
+//   variant 5: one 4-byte lookup consumed in place: u = fma(a, x, c) with c streamed
+// A/B are K floats each; AB is the interleaved table (2K floats).
+using U4 = __attribute__((ext_vector_type(4))) uint32_t;
+using V2 = __attribute__((ext_vector_type(2))) float;
+
+template <int Variant>
+__global__ __launch_bounds__(256) void k_probe_gather_pair(float *__restrict__ o0, float *__restrict__ o1,
+                                                           const float *__restrict__ A, const float *__restrict__ B,
+                                                           const V2 *__restrict__ AB, const float *__restrict__ x,
+                                                           const float *__restrict__ s, const uint32_t *__restrict__ idx, size_t n) {
+    size_t e = ((size_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e + 4 > n) return;
+    U4 p = __builtin_nontemporal_load(reinterpret_cast<const U4 *>(idx + e));
+    V4 a, b;
+    if constexpr (Variant == 0 || Variant == 2) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = A[p[k]];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = B[p[k]];
+    } else if constexpr (Variant == 1 || Variant == 3) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { V2 t = AB[p[k]]; a[k] = t[0]; b[k] = t[1]; }
+    } else if constexpr (Variant == 4) {
+        a = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(s + e));
+#pragma unroll
+        for (int k = 0; k < 4; ++k) b[k] = B[p[k]];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) a[k] = A[p[k]];
+        b = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(s + e));
+    }
+    if constexpr (Variant <= 1) {
+        __builtin_nontemporal_store(a, reinterpret_cast<V4 *>(o0 + e));
+        __builtin_nontemporal_store(b, reinterpret_cast<V4 *>(o1 + e));
+    } else {
+        V4 xv = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(x + e)), r;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) r[k] = __builtin_fmaf(a[k], xv[k], b[k]);
+        __builtin_nontemporal_store(r, reinterpret_cast<V4 *>(o0 + e));
+    }
+}
+
+__global__ __launch_bounds__(256) void k_probe_interleave(V2 *__restrict__ AB, const float *__restrict__ A,
+                                                          const float *__restrict__ B, size_t k) {
+    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i < k) { V2 t = { A[i], B[i] }; AB[i] = t; }
+}
+
 // ---- LDS atomic throughput -------------------------------------------------------------------------
 // variant 0: ds_add_f32 random bins   1: ds_add_u32 random bins   2: plain ds read-modify-write (racy, bound only)
 // 3: ds_add_f32, lane-private bins (no conflicts)   4: ds_add_rtn_u32 random (returning)
@@ -297,4 +352,30 @@ extern "C" EK_API int ek_hip_probe(int body, int unroll, int nt_load, int nt_sto
         case 6: return probe_u<6>(unroll, nt_load, nt_store, blocks_per_cu, out0, out1, a, b, c, n);
         default: return fail(EK_ERR_INVALID, "ek_hip_probe(): unknown body %d", body);
     }
+}
+
+extern "C" EK_API int ek_hip_probe_gather_pair(int variant, float *o0, float *o1, const float *A, const float *B, const float *AB,
+                                               const float *x, const float *s, const uint32_t *idx, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+    unsigned grid = (unsigned) ((n / 4 + 255) / 256);
+#define EK_PGP(V) hipLaunchKernelGGL((k_probe_gather_pair<V>), dim3(grid), dim3(256), 0, cx.stream, o0, o1, A, B, (const V2 *) AB, x, s, idx, n)
+    switch (variant) {
+        case 0: EK_PGP(0); break;
+        case 1: EK_PGP(1); break;
+        case 2: EK_PGP(2); break;
+        case 3: EK_PGP(3); break;
+        case 4: EK_PGP(4); break;
+        default: EK_PGP(5); break;
+    }
+#undef EK_PGP
+    EK_LAUNCH_CHECK("probe_gather_pair", n, 0);
+    return EK_OK;
+}
+
+extern "C" EK_API int ek_hip_probe_interleave(float *AB, const float *A, const float *B, size_t k) {
+    if (int rc = ensure_init()) return rc;
+    hipLaunchKernelGGL(k_probe_interleave, dim3((unsigned) ((k + 255) / 256)), dim3(256), 0, ctx().stream, (V2 *) AB, A, B, k);
+    EK_LAUNCH_CHECK("probe_interleave", k, 16 * k);
+    return EK_OK;
 }

@@ -149,7 +149,23 @@ int ek_hip_init(int device) {
     }
     if (device >= count) return fail(EK_ERR_INVALID, "ek_hip_init(): device %d out of range (%d visible)", device, count);
     if (c.initialized) {
+        // Switching devices: blocks of the old device must not be handed to kernels of the new one.  The free lists are
+        // keyed by size only, so the cache (and the reduction scratch, which lives in it) is released on the old device
+        // first; arrays that are still alive would dangle, so the switch is refused while any exist.
         EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+        if (c.reduce_scratch) {
+            ek_hip_free(c.reduce_scratch);
+            c.reduce_scratch = nullptr;
+            c.reduce_scratch_bytes = 0;
+        }
+        {
+            Allocator &a = alloc();
+            std::lock_guard<std::mutex> guard(a.mutex);
+            if (!a.live.empty())
+                return fail(EK_ERR_INVALID, "ek_hip_init(): cannot switch from device %d to %d while %zu allocations are alive",
+                            c.device, device, a.live.size());
+            EK_HIP_CHECK(a.trim_locked());
+        }
         if (c.owns_stream) EK_HIP_CHECK(hipStreamDestroy(c.stream));
         c.stream = nullptr;
     }

@@ -49,7 +49,7 @@ if args.sweep:
     for body in [0, 1, 2, 3, 4, 5, 6]:
         for u, (ntl, nts), bpc in itertools.product([1, 2, 4], [(0, 0), (0, 1), (1, 0), (1, 1)], [0]):
             def f(body=body, u=u, ntl=ntl, nts=nts, bpc=bpc):
-                capi.check(capi.lib.ek_hip_probe(body, u, ntl, nts, bpc, P(o0.ptr), P(o1.ptr), P(a.ptr), P(b.ptr),
+                capi.check(capi.probe_lib().ek_hip_probe(body, u, ntl, nts, bpc, P(o0.ptr), P(o1.ptr), P(a.ptr), P(b.ptr),
                                                  P(c.ptr), ctypes.c_size_t(n)))
             fns[(body, u, ntl, nts, bpc)] = f
     res = median_ms(fns, args.iters, args.reps)
@@ -82,9 +82,9 @@ prod = {
     ("scatter_add(K=1Mi)", 8): lambda: capi.scatter_add(table, a, idx),
     ("hsum(a)", 4): lambda: keep.append(capi.reduce("hsum", a)) or keep.clear(),
     ("hsum_safe_mul(w,g)", 8): lambda: keep.append(capi.hsum_safe_mul(a, b)) or keep.clear(),
-    ("probe scatter_add shared", 8): lambda: capi.check(capi.lib.ek_hip_probe_scatter_add(
+    ("probe scatter_add shared", 8): lambda: capi.check(capi.probe_lib().ek_hip_probe_scatter_add(
         0, P(table8.ptr), ctypes.c_size_t(K), None, P(a.ptr), P(idx.ptr), ctypes.c_size_t(n))),
-    ("probe scatter_add per-XCD+fold", 8): lambda: capi.check(capi.lib.ek_hip_probe_scatter_add(
+    ("probe scatter_add per-XCD+fold", 8): lambda: capi.check(capi.probe_lib().ek_hip_probe_scatter_add(
         1, P(table8.ptr), ctypes.c_size_t(K), P(table.ptr), P(a.ptr), P(idx.ptr), ctypes.c_size_t(n))),
 }
 res = median_ms(prod, args.iters, args.reps)
@@ -96,7 +96,7 @@ for (name, bpe), ms in res.items():
 # correctness of the per-XCD scatter_add experiment (exact in integers-as-floats)
 ones = capi.fill(np.float32, 1.0, n)
 t8 = capi.fill(np.float32, 0.0, 8 * K); tout = capi.fill(np.float32, 0.0, K)
-capi.check(capi.lib.ek_hip_probe_scatter_add(1, P(t8.ptr), ctypes.c_size_t(K), P(tout.ptr), P(ones.ptr), P(idx.ptr),
+capi.check(capi.probe_lib().ek_hip_probe_scatter_add(1, P(t8.ptr), ctypes.c_size_t(K), P(tout.ptr), P(ones.ptr), P(idx.ptr),
                                              ctypes.c_size_t(n)))
 ok = np.array_equal(tout.numpy(), np.bincount(idx_host, minlength=K).astype(np.float32))
 per_copy = t8.numpy().reshape(8, K).sum(axis=1)

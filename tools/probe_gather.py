@@ -11,7 +11,7 @@ for logk in (16, 20, 22, 24):
     K = 1 << logk
     table = capi.Buf.from_numpy(rng.uniform(-1, 1, K).astype(np.float32))
     idx = capi.Buf.from_numpy(rng.integers(0, K, n).astype(np.uint32))
-    fns = {(e, p): (lambda e=e, p=p: capi.check(capi.lib.ek_hip_probe_gather(e, p, P(out.ptr), P(table.ptr), P(idx.ptr), ctypes.c_size_t(n))))
+    fns = {(e, p): (lambda e=e, p=p: capi.check(capi.probe_lib().ek_hip_probe_gather(e, p, P(out.ptr), P(table.ptr), P(idx.ptr), ctypes.c_size_t(n))))
            for e in (1, 4, 8) for p in (0, 1)}
     fns[("prod", 0)] = lambda: capi.gather(table, idx)
     samples = {k: [] for k in fns}

@@ -16,7 +16,7 @@ for logk in (16, 20, 24):
     ih = rng.integers(0, K, n).astype(np.uint32)
     idx = capi.Buf.from_numpy(ih)
     for p in (0, 1, 2, 3, 4, 5):
-        f = lambda p=p: capi.check(capi.lib.ek_hip_probe_gather(4, p, P(out.ptr), P(table.ptr), P(idx.ptr), ctypes.c_size_t(n)))
+        f = lambda p=p: capi.check(capi.probe_lib().ek_hip_probe_gather(4, p, P(out.ptr), P(table.ptr), P(idx.ptr), ctypes.c_size_t(n)))
         f()
         ok = np.array_equal(out.numpy()[:100000], tab[ih[:100000]])
         ms = statistics.median(hiprt.time_region(st, f, iters=10, warmup=2) for _ in range(5))

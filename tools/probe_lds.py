@@ -11,7 +11,7 @@ for bins_log2 in (6, 10, 14):
     for blocks_per_cu in (1, 2):
         blocks = 256 * blocks_per_cu
         for v in range(5):
-            f = lambda: capi.check(capi.lib.ek_hip_probe_lds_atomic(v, blocks, iters, bins_log2, ctypes.c_void_p(sink.ptr)))
+            f = lambda: capi.check(capi.probe_lib().ek_hip_probe_lds_atomic(v, blocks, iters, bins_log2, ctypes.c_void_p(sink.ptr)))
             ms = hiprt.time_region(st, f, iters=5, warmup=1)
             ops = blocks * 512 * iters
             print(f"bins=2^{bins_log2:2d} blocks/CU={blocks_per_cu} {names[v]:28s} {ms:8.4f} ms  {ops / ms / 1e6:9.1f} Gop/s  "

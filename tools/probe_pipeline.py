@@ -12,7 +12,7 @@ h = rng.uniform(-1, 1, n).astype(np.float32)
 B = {k: capi.Buf.from_numpy(h) if k in "axb" else capi.Buf(np.float32, n) for k in ["a", "x", "b", "u", "s", "c", "gu", "ga", "gb"]}
 P = ctypes.c_void_p
 def launch(body, u, ntl, nts, o0, o1, i0, i1=None, i2=None):
-    capi.check(capi.lib.ek_hip_probe(body, u, ntl, nts, 0, P(B[o0].ptr), P(B[o1].ptr) if o1 else None, P(B[i0].ptr),
+    capi.check(capi.probe_lib().ek_hip_probe(body, u, ntl, nts, 0, P(B[o0].ptr), P(B[o1].ptr) if o1 else None, P(B[i0].ptr),
                                      P(B[i1].ptr) if i1 else None, P(B[i2].ptr) if i2 else None, ctypes.c_size_t(n)))
 # stages of cfg3a: fmadd -> sincos -> hsum(read) -> scale -> mul2 -> scale ; 60 B/elt
 def step(pol):
