@@ -41,12 +41,18 @@ EXPORTS = [
     "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_scatter_add_multi", "ek_hip_concat",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
-    "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum",
+    "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered",
 ]
 
 
 class Operand(ctypes.Structure):
     _fields_ = [("ptr", ctypes.c_void_p), ("imm", ctypes.c_uint64), ("size", ctypes.c_size_t)]
+
+
+class Gathered(ctypes.Structure):
+    """ek_gathered: an operand read through an index array (consumed in place by ek_hip_map_gathered)"""
+    _fields_ = [("table", ctypes.c_void_p), ("table_size", ctypes.c_size_t), ("index", Operand), ("index_type", ctypes.c_int),
+                ("mask", Operand)]
 
 
 class EnokiHipError(RuntimeError):
@@ -299,6 +305,37 @@ def gather(src, index, mask=True, n=None):
     oi = operand(index); om = operand(mask, np.uint8)
     check(lib.ek_hip_gather(src.ek, index.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(src.ptr), ctypes.byref(oi),
                             ctypes.byref(om), ctypes.c_size_t(n)))
+    return out
+
+
+class G:
+    """gathered operand for map_gathered(): table[index] where mask"""
+
+    def __init__(self, table, index, mask=True):
+        self.table, self.index, self.mask = table, index, mask
+
+
+def map_gathered(op, *xs, n=None):
+    """out = op(x0, x1 (, x2)); operands that are `G` instances are gathered in place (ek_hip_map_gathered)"""
+    arity = len(xs)
+    tables = [x.table if isinstance(x, G) else x for x in xs]
+    dt = _dtype(*tables)
+    if n is None:
+        n = max([x.index.n for x in xs if isinstance(x, G)] + [_n(*[x for x in xs if not isinstance(x, G)])])
+    out = Buf(dt, n)
+    ops, gs = [], []
+    for x in xs:
+        if isinstance(x, G):
+            gs.append(Gathered(x.table.ptr, x.table.n, operand(x.index), x.index.ek, operand(x.mask, np.uint8)))
+            ops.append(None)
+        else:
+            gs.append(None)
+            ops.append(operand(x, dt))
+    OpPtr, GPtr = ctypes.POINTER(Operand), ctypes.POINTER(Gathered)
+    po = (OpPtr * arity)(*[ctypes.pointer(o) if o is not None else OpPtr() for o in ops])
+    pg = (GPtr * arity)(*[ctypes.pointer(g) if g is not None else GPtr() for g in gs])
+    code = (BINARY if arity == 2 else TERNARY)[op]
+    check(lib.ek_hip_map_gathered(arity, code, NP2EK[dt], ctypes.c_void_p(out.ptr), po, pg, ctypes.c_size_t(n)))
     return out
 
 

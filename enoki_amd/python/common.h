@@ -531,6 +531,9 @@ inline void bind_runtime(py::module_ &m) {
     m.def("hip_stream", []() { return (uintptr_t) ek_hip_stream(); });
     m.def("hip_set_stream", [](uintptr_t s) { detail::hip_check(ek_hip_set_stream((void *) s), "hip_set_stream"); });
     m.def("hip_launch_count", []() { return ek_hip_launch_count(); });
+    m.def("hip_set_defer_gather", [](bool v) { hip_set_defer_gather(v); },
+          "large gathers from small tables stay deferred until consumed (fused into the consuming add/sub/mul/fma)");
+    m.def("hip_defer_gather", []() { return hip_defer_gather(); });
     m.def("hip_profile_begin", []() { detail::hip_check(ek_hip_profile_begin(), "hip_profile_begin"); });
     m.def("hip_profile_end", []() {
         char *r = ek_hip_profile_end();

@@ -202,6 +202,7 @@ template <typename Value> struct Tape<Value>::Detail {
         bool any_weight = false;
         for (size_t c = 0; c < work.size(); ++c) {
             PendingScatter &p = work[c];
+            materialize_grad(node(p.source));          // a gather of a gather: the table's gradient may be a pending product
             Value &grad_source = node(p.source).grad;
             if (grad_source.empty())
                 grad_source = zero<Value>(p.size);
@@ -647,6 +648,9 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
             } else if (is_gather) {
                 d->defer_gather_adjoint(edge.source, target.grad, target.grad_weight, gather_adjoint);
             } else {
+                // specials accumulate straight into source.grad: a pending product w * g must become an array first
+                // (otherwise the result would be w * (g + contribution))
+                Detail::materialize_grad(source);
                 edge.special->backward(d, target_idx, edge);
             }
             if (free_graph) {

@@ -19,6 +19,7 @@
 #include <enoki/array.h>
 #include <enoki_hip.h>
 
+#include <cstdlib>
 #include <initializer_list>
 #include <vector>
 
@@ -33,16 +34,88 @@ namespace detail {
     }
 
     /// Reference-counted device allocation
+    ///
+    /// A buffer may be a *deferred gather*: `table[index]` under `mask` that has not been executed yet (ptr == nullptr).
+    /// The reference never writes a gather that feeds an arithmetic op to memory -- its JIT fuses the load into the
+    /// consumer (jit.cu:1066-1217) -- and neither does HIPArray: the first add/sub/mul/fma that consumes a deferred gather
+    /// reads the table in place (ek_hip_map_gathered); any other access (data(), operand(), a second consumer, ...) runs
+    /// the plain gather kernel first.  Arrays stay immutable values: the deferred node holds references on its table,
+    /// index and mask buffers, and a buffer with deferred readers forces them before it hands out a mutable pointer.
     struct HIPBuffer {
         void *ptr = nullptr;
         size_t size = 0;          // elements
         uint32_t ref_count = 1;
         bool owned = true;        // false for map()ped memory that the caller keeps
 
+        struct Deferred {
+            HIPBuffer *table, *index, *mask;   // references held; mask == nullptr: every lane is active
+            int type, index_type;
+            size_t elem_size;
+            bool consumed;                     // a fused consumer has read it once: the next access materialises
+        };
+        Deferred *deferred = nullptr;
+        std::vector<HIPBuffer *> readers;      // deferred gathers whose table is THIS buffer (not owning)
+
+        static void unref(HIPBuffer *b) {
+            if (b && --b->ref_count == 0) delete b;
+        }
+
+        ek_gathered gathered() const {
+            ek_gathered g;
+            g.table = deferred->table->ptr;
+            g.table_size = deferred->table->size;
+            g.index = ek_operand{ deferred->index->ptr, 0, deferred->index->size };
+            g.index_type = deferred->index_type;
+            g.mask = deferred->mask ? ek_operand{ deferred->mask->ptr, 0, deferred->mask->size } : ek_operand{ nullptr, 1, 1 };
+            return g;
+        }
+
+        /// Execute the deferred gather
+        void force() {
+            if (!deferred) return;
+            void *p = nullptr;
+            hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (deferred gather)");
+            ek_gathered g = gathered();
+            int rc = ek_hip_gather(deferred->type, deferred->index_type, p, g.table, &g.index, &g.mask, size);
+            if (rc != EK_OK) {
+                ek_hip_free(p);
+                hip_raise("HIPArray (deferred gather)");
+            }
+            ptr = p;
+            drop_deferred();
+        }
+
+        /// Deferred gathers that read this buffer must run before its contents change
+        void force_readers() {
+            while (!readers.empty()) readers.back()->force();
+        }
+
+        void drop_deferred() {
+            Deferred *d = deferred;
+            deferred = nullptr;
+            auto &r = d->table->readers;
+            for (size_t i = 0; i < r.size(); ++i)
+                if (r[i] == this) { r[i] = r.back(); r.pop_back(); break; }
+            unref(d->table);
+            unref(d->index);
+            unref(d->mask);
+            delete d;
+        }
+
         ~HIPBuffer() {
+            if (deferred) drop_deferred();
             if (owned && ptr) ek_hip_free(ptr);
         }
     };
+
+    /// Deferred gathers can be switched off (ENOKI_HIP_DEFER_GATHER=0, or hip_set_defer_gather(false))
+    inline bool &hip_defer_gather_flag() {
+        static bool flag = [] {
+            const char *e = getenv("ENOKI_HIP_DEFER_GATHER");
+            return !(e && e[0] == '0');
+        }();
+        return flag;
+    }
 
     template <typename T> struct hip_type;
     template <> struct hip_type<bool>     { static constexpr int value = EK_BOOL; };
@@ -422,8 +495,36 @@ template <typename Value_> struct HIPArray : ArrayTag {
     template <bool IsPermute, typename Index>
     static HIPArray gather_array_(const HIPArray &source, const Index &index, const MaskType &mask) {
         if (source.size() <= 1) return source & mask;
+        if constexpr (IsFloat && (Index::Type == EK_U32 || Index::Type == EK_I32)) {
+            if (HIPArray r = defer_gather_(source, detach(index), mask); r.valid()) return r;
+        }
         return gather_<sizeof(Value)>(source.data(), detach(index), mask);
     }
+
+    /// Large gathers from small tables are deferred (see detail::HIPBuffer); returns an invalid array when this one is not
+    static constexpr size_t defer_min_size_ = 4096, defer_max_table_bytes_ = (size_t) 16 << 20;
+    template <typename Index>
+    static HIPArray defer_gather_(const HIPArray &source, const Index &index, const MaskType &mask) {
+        HIPArray r;
+        if (!detail::hip_defer_gather_flag() || !source.m_buf || !source.m_buf->owned || !index.m_buf)
+            return r;
+        const size_t n = index.m_buf->size;
+        if (n < defer_min_size_ || source.m_buf->size * sizeof(Value) > defer_max_table_bytes_) return r;
+        if (mask.m_is_imm ? !mask.m_imm : (!mask.m_buf || mask.m_buf->size != n)) return r;
+        source.ptr_();                                       // a table that is itself deferred runs first
+        auto *d = new typename detail::HIPBuffer::Deferred{ source.m_buf, index.m_buf, mask.m_is_imm ? nullptr : mask.m_buf,
+                                                            Type, Index::Type, sizeof(Value), false };
+        d->table->ref_count++;
+        d->index->ref_count++;
+        if (d->mask) d->mask->ref_count++;
+        r.m_buf = new detail::HIPBuffer();
+        r.m_buf->size = n;
+        r.m_buf->deferred = d;
+        d->table->readers.push_back(r.m_buf);
+        return r;
+    }
+
+    bool deferred_() const { return m_buf && m_buf->deferred && !m_buf->deferred->consumed; }
 
     static constexpr size_t gather_multi_small_ = (size_t) 3 << 20, gather_multi_large_ = (size_t) 128 << 20;
 
@@ -547,7 +648,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         size_t n = size();
         if (n <= 1) return *this;
         HIPArray r = empty_(n);
-        detail::hip_check(ek_hip_reverse(Type, r.m_buf->ptr, m_buf->ptr, n), "reverse_");
+        detail::hip_check(ek_hip_reverse(Type, r.m_buf->ptr, ptr_(), n), "reverse_");
         return r;
     }
 
@@ -555,7 +656,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         size_t n = size();
         if (n <= 1) return *this;
         HIPArray r = empty_(n);
-        detail::hip_check(ek_hip_psum(Type, r.m_buf->ptr, m_buf->ptr, n), "psum_");
+        detail::hip_check(ek_hip_psum(Type, r.m_buf->ptr, ptr_(), n), "psum_");
         return r;
     }
 
@@ -573,8 +674,13 @@ template <typename Value_> struct HIPArray : ArrayTag {
     bool is_immediate() const { return m_is_imm; }
 
     /// Device pointer; an immediate is materialised on first use
-    const Value *data() const { materialize(); return m_buf ? (const Value *) m_buf->ptr : nullptr; }
-    Value *data() { materialize(); return m_buf ? (Value *) m_buf->ptr : nullptr; }
+    const Value *data() const { materialize(); return m_buf ? (const Value *) ptr_() : nullptr; }
+    Value *data() {
+        materialize();
+        if (!m_buf) return nullptr;
+        m_buf->force_readers();                // the caller may write through the pointer
+        return (Value *) ptr_();
+    }
 
     /// Broadcast a size-1 array / set the size of an empty array (CUDAArray::resize, cuda.h:935-937)
     void resize(size_t size) { set_slices_(size); }
@@ -602,7 +708,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if (!m_buf || i >= m_buf->size)
             throw std::runtime_error("HIPArray::coeff(): index " + std::to_string(i) + " out of range");
         std::conditional_t<IsMask, uint8_t, Value> v;
-        detail::hip_check(ek_hip_memcpy_to_host(&v, (const uint8_t *) m_buf->ptr + i * sizeof(Value), sizeof(Value)), "coeff");
+        detail::hip_check(ek_hip_memcpy_to_host(&v, (const uint8_t *) ptr_() + i * sizeof(Value), sizeof(Value)), "coeff");
         return (Value) v;
     }
     Value operator[](size_t i) const { return coeff(i); }
@@ -614,7 +720,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         std::vector<std::conditional_t<IsMask, uint8_t, Value>> out(size());
         if (m_is_imm) out[0] = m_imm;
         else if (!out.empty())
-            detail::hip_check(ek_hip_memcpy_to_host(out.data(), m_buf->ptr, out.size() * sizeof(Value)), "to_host");
+            detail::hip_check(ek_hip_memcpy_to_host(out.data(), ptr_(), out.size() * sizeof(Value)), "to_host");
         return out;
     }
 
@@ -656,7 +762,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             o.imm = imm_bits(m_imm);
             o.size = 1;
         } else {
-            o.ptr = m_buf ? m_buf->ptr : nullptr;
+            o.ptr = m_buf ? ptr_() : nullptr;
             o.imm = 0;
             o.size = m_buf ? m_buf->size : 0;
         }
@@ -671,10 +777,14 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// Writers (scatter targets) must not alias other handles
     void make_unique() {
         materialize();
-        if (m_buf && m_buf->ref_count > 1) {
+        if (!m_buf) return;
+        m_buf->force_readers();                // deferred gathers from this array see its contents before the write
+        if (m_buf->ref_count > 1) {
             HIPArray r = empty_(m_buf->size);
-            detail::hip_check(ek_hip_memcpy_device(r.m_buf->ptr, m_buf->ptr, m_buf->size * sizeof(Value)), "make_unique");
+            detail::hip_check(ek_hip_memcpy_device(r.m_buf->ptr, ptr_(), m_buf->size * sizeof(Value)), "make_unique");
             *this = std::move(r);
+        } else {
+            ptr_();
         }
     }
 
@@ -732,6 +842,51 @@ private:
         return r;
     }
 
+    /// Device pointer of a valid buffer; a deferred gather is executed first
+    void *ptr_() const {
+        if (m_buf->deferred) m_buf->force();
+        return m_buf->ptr;
+    }
+
+    /// add / sub / mul / fma with a deferred gather among the operands: the gather is consumed in place
+    /// (ek_hip_map_gathered).  Returns false when the combination is not fusable; operand() then materialises.
+    static bool map_gathered_(int arity, int op, const HIPArray *const *x, size_t n, HIPArray &result, const char *what) {
+        if constexpr (!IsFloat) {
+            return false;
+        } else {
+            bool d[3] = { false, false, false };
+            for (int k = 0; k < arity; ++k) d[k] = x[k]->deferred_() && x[k]->m_buf->size == n;
+            if (d[0] && d[1]) d[1] = false;                                  // one gathered factor per product
+            if (arity == 3 && d[2] && (d[0] || d[1])) {
+                // a gathered factor AND a gathered addend: one 8-byte lookup when they share index, mask and table size
+                const auto *p = x[d[0] ? 0 : 1]->m_buf->deferred, *q = x[2]->m_buf->deferred;
+                if (p->index != q->index || p->mask != q->mask || p->index_type != q->index_type ||
+                    p->table->size != q->table->size || p->table->size * 8 > n)
+                    d[2] = false;
+            }
+            // the same array in a fused AND an unfused slot (g * g): the unfused use materialises it anyway
+            for (int k = 0; k < arity; ++k)
+                for (int j = 0; j < arity; ++j)
+                    if (!d[k] && d[j] && x[k]->m_buf == x[j]->m_buf) d[j] = false;
+            if (!d[0] && !d[1] && !d[2]) return false;
+            ek_gathered g[3];
+            ek_operand o[3];
+            const ek_gathered *pg[3] = { nullptr, nullptr, nullptr };
+            const ek_operand *po[3] = { nullptr, nullptr, nullptr };
+            for (int k = 0; k < arity; ++k) {
+                if (d[k]) { g[k] = x[k]->m_buf->gathered(); pg[k] = &g[k]; }
+                else { o[k] = x[k]->operand(); po[k] = &o[k]; }
+            }
+            result = empty_(n);
+            int rc = ek_hip_map_gathered(arity, op, Type, result.m_buf->ptr, po, pg, n);
+            if (rc == EK_ERR_UNSUPPORTED) return false;
+            detail::hip_check(rc, what);
+            for (int k = 0; k < arity; ++k)
+                if (d[k] && x[k]->m_buf->deferred) x[k]->m_buf->deferred->consumed = true;
+            return true;
+        }
+    }
+
     HIPArray binary(int op, const HIPArray &b, const char *what) const {
         require_valid(what); b.require_valid(what);
         if (m_is_imm && b.m_is_imm) {
@@ -739,6 +894,11 @@ private:
             if (detail::host_binary<Value>(op, m_imm, b.m_imm, r)) return HIPArray(r);
         }
         size_t n = broadcast_size(size(), b.size());
+        if ((op == EK_ADD || op == EK_SUB || op == EK_MUL) && (deferred_() || b.deferred_())) {
+            const HIPArray *x[3] = { this, &b, nullptr };
+            HIPArray r;
+            if (map_gathered_(2, op, x, n, r, what)) return r;
+        }
         HIPArray r = empty_(n);
         ek_operand oa = operand(), ob = b.operand();
         detail::hip_check(ek_hip_binary(op, Type, r.m_buf->ptr, &oa, &ob, n), what);
@@ -748,6 +908,11 @@ private:
     HIPArray ternary(int op, const HIPArray &b, const HIPArray &c, const char *what) const {
         require_valid(what); b.require_valid(what); c.require_valid(what);
         size_t n = broadcast_size(broadcast_size(size(), b.size()), c.size());
+        if (op != EK_SAFE_FMADD && (deferred_() || b.deferred_() || c.deferred_())) {
+            const HIPArray *x[3] = { this, &b, &c };
+            HIPArray g;
+            if (map_gathered_(3, op, x, n, g, what)) return g;
+        }
         HIPArray r = empty_(n);
         ek_operand oa = operand(), ob = b.operand(), oc = c.operand();
         detail::hip_check(ek_hip_ternary(op, Type, r.m_buf->ptr, &oa, &ob, &oc, n), what);
@@ -767,7 +932,7 @@ private:
         size_t n = size();
         if (n == 1) return *this;
         HIPArray r = empty_(1);
-        detail::hip_check(ek_hip_reduce(op, Type, r.m_buf->ptr, m_buf ? m_buf->ptr : nullptr, n), what);
+        detail::hip_check(ek_hip_reduce(op, Type, r.m_buf->ptr, m_buf ? ptr_() : nullptr, n), what);
         return r;
     }
 
@@ -775,7 +940,7 @@ private:
         static_assert(IsMask, "all_/any_/count_ require a mask array");
         if (m_is_imm) return m_imm ? 1 : 0;
         uint64_t result = 0;
-        detail::hip_check(ek_hip_mask_reduce(op, m_buf ? (const uint8_t *) m_buf->ptr : nullptr, size(), &result), what);
+        detail::hip_check(ek_hip_mask_reduce(op, m_buf ? (const uint8_t *) ptr_() : nullptr, size(), &result), what);
         return result;
     }
 
@@ -794,6 +959,10 @@ inline std::string hip_whos() {
     free(w);
     return s;
 }
+
+/// Deferred gathers on / off (on by default; ENOKI_HIP_DEFER_GATHER=0 switches them off for a whole process)
+inline void hip_set_defer_gather(bool value) { detail::hip_defer_gather_flag() = value; }
+inline bool hip_defer_gather() { return detail::hip_defer_gather_flag(); }
 
 template <typename T> inline void set_label(const HIPArray<T> &, const char *) { }
 

@@ -172,6 +172,24 @@ EK_API int ek_hip_gather(int type, int index_type, void *out, const void *base,
  * mask[i] ? bases[c][index[i]] : 0.  4- and 8-byte element types. */
 EK_API int ek_hip_gather_multi(int type, int index_type, int count, void *const *outs, const void *const *bases,
                                const ek_operand *index, const ek_operand *mask, size_t n);
+/* An operand that is read THROUGH an index array: value[i] = mask[i] ? table[index[i]] : 0 -- a gather (cuda.h:845-864)
+ * whose result is consumed by the next vertical op instead of being written out.  The reference gets this for free:
+ * its JIT emits the gather's `ld.global` into the consumer's kernel (jit.cu:1066-1217). */
+typedef struct {
+    const void *table;       /* `table_size` elements of the op's element type */
+    size_t table_size;
+    ek_operand index;        /* EK_U32 / EK_I32 ARRAY of the op's size */
+    int index_type;
+    ek_operand mask;         /* EK_BOOL array of the op's size, or an immediate */
+} ek_gathered;
+/* out[i] = op(x0[i], x1[i] (, x2[i])) where operand k is `*gathered[k]` when that pointer is non-NULL and `*operands[k]`
+ * otherwise; `arity` 2 (`op` an ek_binary_op: ADD, SUB, MUL) or 3 (`op` an ek_ternary_op: FMADD .. FNMSUB), EK_F32 / EK_F64.
+ * One gathered operand per launch -- or, for the fma family, a gathered first (or second) AND third operand that share
+ * their index and mask arrays and table size: the two tables are interleaved into {a, c} records first and every element
+ * issues ONE 8-byte lookup (random lookups are request-rate bound, not byte bound).  Bit-identical to ek_hip_gather followed by
+ * ek_hip_binary / ek_hip_ternary; returns EK_ERR_UNSUPPORTED for every other combination (callers then do exactly that). */
+EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_operand *const *operands,
+                               const ek_gathered *const *gathered, size_t n);
 EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
                           const ek_operand *index, const ek_operand *mask, size_t n);
 /* mode 0: fastest -- LDS-binned accumulation for large inputs (needs `base_size`), hardware atomics otherwise;

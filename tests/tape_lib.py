@@ -214,6 +214,20 @@ def gather_suite(n=1000, k=37, seed=5):
                                    index_inputs=[i0])
     # broadcast gradients (hsum seeds) through a shared index array
     P["broadcast_grads"] = Program([(A, 1), (B, 1)], [("gather", 0, 0), ("gather", 1, 0), ("add", 2, 3), ("hsum", 4)], index_inputs=[i0])
+    # A gather node whose gradient is still a pending product w * g (its multiplication was recorded LAST, so the sweep
+    # reaches it first) and that also feeds an earlier-recorded reverse / psum / scatter_add / gather: those adjoints
+    # accumulate straight into the node's gradient and must see w * g, not g.
+    wm = ints(-4, 4, m)
+    for name in ("reverse", "psum"):
+        P[f"pending_then_{name}"] = Program([(A, 1), (w, 0), (v, 0)],
+                                            [("gather", 0, 0), (name, 3), ("mul", 3, 1), ("mul", 5, 2), ("mul", 4, 2), ("add", 6, 7)],
+                                            index_inputs=[i0])
+    P["pending_then_scatter_add"] = Program([(A, 1), (w, 0), (v, 0), (np.zeros(k, np.float32), 0)],
+                                            [("gather", 0, 0), ("scatter_add", 3, 4, 1), ("mul", 4, 1), ("mul", 6, 2), ("hsum", 7),
+                                             ("mul", 5, 5), ("hsum", 9), ("add", 8, 10)], index_inputs=[i0, i1])
+    P["pending_then_gather"] = Program([(A, 1), (wm, 0), (v, 0)],
+                                       [("gather", 0, 0), ("gather", 3, 1), ("mul", 3, 1), ("mul", 4, 2), ("mul", 5, 5), ("hsum", 7),
+                                        ("hsum", 6), ("add", 8, 9)], index_inputs=[j1, j2])
     # scalar weight times vector gradient
     P["scalar_weight"] = Program([(A, 1), (B, 1), (x, 0)], [("gather", 0, 0), ("gather", 1, 0), ("mulc", 3, 3.0), ("mul", 4, 2), ("add", 5, 6), ("mul", 7, 7)],
                                  index_inputs=[i0])

@@ -334,8 +334,17 @@ def test_vector_gather_is_one_kernel(ekc):
     bsrc = ekc.Vector3f(*[ekc.Float32(c) for c in big])
     before = ekc.hip_launch_count()
     bgot = ekc.gather(bsrc, ekc.UInt32(bidx))
+    assert ekc.hip_launch_count() - before == 0          # the per-component gathers stay deferred until consumed
+    assert bits_equal(bgot.y.numpy(), big[1][bidx]) and bits_equal(bgot.x.numpy(), big[0][bidx]) and bits_equal(bgot.z.numpy(), big[2][bidx])
     assert ekc.hip_launch_count() - before == 3
-    assert bits_equal(bgot.y.numpy(), big[1][bidx])
+    ekc.hip_set_defer_gather(False)
+    try:
+        before = ekc.hip_launch_count()
+        bgot = ekc.gather(bsrc, ekc.UInt32(bidx))
+        assert ekc.hip_launch_count() - before == 3
+        assert bits_equal(bgot.y.numpy(), big[1][bidx])
+    finally:
+        ekc.hip_set_defer_gather(True)
     # a broadcast component falls back to the per-component path and still gives the right values
     src2 = ekc.Vector3f(ekc.Float32(comps[0]), ekc.Float32(2.5), ekc.Float32(comps[2]))
     got2 = ekc.gather(src2, ekc.UInt32(idx))
