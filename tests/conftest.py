@@ -95,6 +95,41 @@ def ulp_diff(a, b):
     return np.abs(ia - ib)
 
 
+def hsum_depth(n):
+    """longest chain of fp additions behind one output of the library's hsum (csrc/reduce.hip): 2^20 lane accumulators in
+    stage 1, each summing ceil(n / 2^20) entries in sequence, then the wave / workgroup trees and stage 2"""
+    return -(-n // (1 << 20)) + 10 + 14
+
+
+def cfg3b_truth(A, B, x, idx):
+    """float64 evaluation of BASELINE config 3b (y = hsum(sin(A[idx] x + B[idx])), gradients w.r.t. A and B) with the
+    class-D bounds of SURVEY 8c for OUR summation orders.  A sum of m terms evaluated in any order of depth d is within
+    d * 2^-24 * sum|terms| of the exact sum of the ROUNDED terms; the terms themselves (u = fma(a, x, b) in f32, then
+    sin / cos of it, then a product) are within 4 * 2^-24 ABSOLUTE of their exact values for |a|, |x|, |b| <= 1 (the
+    rounding of u moves sin u by at most 2 * 2^-24, not by a relative amount)."""
+    eps = 2.0 ** -24
+    K, n = A.size, x.size
+    ii = idx.astype(np.int64)
+    x64 = x.astype(np.float64)
+    u = A.astype(np.float64)[ii] * x64 + B.astype(np.float64)[ii]
+    s, c = np.sin(u), np.cos(u)
+    cnt = np.bincount(ii, minlength=K)
+    sum_abs = float(np.abs(s).sum())
+    out = {"y": float(s.sum()), "y_bound": eps * (hsum_depth(n) * sum_abs + 4 * n), "cnt": cnt,
+           # the reference adds lane-wise: 8 (AVX2) accumulators of n / 8 entries each, then a tree (dynamic.h:632-650)
+           "y_bound_reference": eps * ((n // 8 + 4) * sum_abs + 4 * n)}
+    for name, terms in (("gA", c * x64), ("gB", c)):
+        out[name] = np.bincount(ii, weights=terms, minlength=K)
+        out[name + "_bound"] = eps * (cnt * np.bincount(ii, weights=np.abs(terms), minlength=K) + 4 * cnt)
+    return out
+
+
+def hsum_bound(terms64, per_term_ulps=4):
+    """class-D bound of the library's hsum over float32 roundings of `terms64` (see cfg3b_truth)"""
+    n = terms64.size
+    return 2.0 ** -24 * (hsum_depth(n) * float(np.abs(terms64).sum()) + per_term_ulps * n)
+
+
 @pytest.fixture(scope="session")
 def capi():
     from enoki_amd import capi as c
