@@ -21,18 +21,23 @@ template <int Op, typename T> struct Reducer {
     static __device__ __host__ __forceinline__ T identity() {
         if constexpr (Op == EK_HSUM) return T(0);
         else if constexpr (Op == EK_HPROD) return T(1);
-        else if constexpr (Op == EK_HMIN) {
-            if constexpr (std::is_floating_point_v<T>) return std::numeric_limits<T>::infinity();
-            else return std::numeric_limits<T>::max();
-        } else {
-            if constexpr (std::is_floating_point_v<T>) return -std::numeric_limits<T>::infinity();
-            else return std::numeric_limits<T>::lowest();
-        }
+        else if constexpr (std::is_floating_point_v<T>) return std::numeric_limits<T>::quiet_NaN();   // minNum / maxNum: see combine()
+        else if constexpr (Op == EK_HMIN) return std::numeric_limits<T>::max();
+        else return std::numeric_limits<T>::lowest();
     }
     static __device__ __forceinline__ T combine(T acc, T v) {
         using U = wrap_t<T>;
         if constexpr (Op == EK_HSUM) return (T) ((U) acc + (U) v);
         else if constexpr (Op == EK_HPROD) return (T) ((U) acc * (U) v);
+        else if constexpr (std::is_floating_point_v<T>) {
+            // Floating point hmin / hmax are IEEE minNum / maxNum reductions (v_min_f32 / v_max_f32): NaN entries are
+            // ignored unless every entry is NaN, and -0 < +0 -- well defined and independent of the reduction order.
+            // The reference's AVX path is NOT: MINPS returns its second operand on unordered or equal compares, so
+            // whether a NaN (or which zero) survives depends on its position modulo the packet width
+            // (dynamic.h:669-702); on NaN-free data without mixed zeros both agree bit for bit.
+            if constexpr (sizeof(T) == 4) return Op == EK_HMIN ? __builtin_fminf(acc, v) : __builtin_fmaxf(acc, v);
+            else return Op == EK_HMIN ? __builtin_fmin(acc, v) : __builtin_fmax(acc, v);
+        }
         else if constexpr (Op == EK_HMIN) return v < acc ? v : acc;
         else return v > acc ? v : acc;
     }

@@ -602,6 +602,8 @@ int ref_tape_program(const int32_t *prog, size_t n_ops, const float *const *inpu
 /* ------------------------------------------------------------------ */
 } // extern "C" (templates below)
 
+#if !defined(ENOKI_REF_TAPE_ONLY)   /* the AVX-512 flavour (make ref512) only serves ref_tape_program: the helpers below pin 8-wide packets */
+
 namespace {
 using Vector2fX = Array<FloatX, 2>;
 using Vector3fX = Array<FloatX, 3>;
@@ -734,3 +736,5 @@ extern "C" int ref_complex(const float *a_, const float *b_, size_t n, float *ou
     store(FloatX(arg(a)), out + (size_t) 19 * n, n);
     return 0;
 }
+
+#endif /* !ENOKI_REF_TAPE_ONLY */

@@ -34,6 +34,17 @@ for name, prog in tape_lib.gather_suite().items():
             out[f"g{i}"] = gi
     np.savez_compressed(os.path.join(HERE, f"tape_gather_{name}.npz"), **out)
 
+# two scatters into one buffer: from the AVX-512 flavour of the reference build (the AVX2 row segfaults in the reference
+# itself on this pattern, oracle/Makefile)
+if tape_lib.ref512_available():
+    for name, prog in tape_lib.scatter_twice_suite().items():
+        v, g = tape_lib.run(tape_lib.ref512_fn(), prog)
+        out = {"value": v, "n_grads": np.array(len(g))}
+        for i, gi in enumerate(g):
+            if gi is not None:
+                out[f"g{i}"] = gi
+        np.savez_compressed(os.path.join(HERE, f"tape_scatter_twice_{name}.npz"), **out)
+
 # ---- elementwise ops on a fixed input set (incl. specials) -------------------------------------------
 n = 4096
 a = f32_inputs(n, seed=101, scale=20.0); b = f32_inputs(n, seed=102, scale=20.0)[::-1].copy(); c = f32_inputs(n, seed=103)

@@ -84,6 +84,22 @@ def ref_fn():
     return _libs["ref"].ref_tape_program
 
 
+def ref512_available():
+    """the AVX-512 flavour of the reference build (oracle/Makefile ref512) and a host that can run it"""
+    path = os.path.join(ROOT, "oracle", "_ref", "libenoki_ref512.so")
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return os.path.exists(path) and all(f in flags for f in ("avx512f", "avx512dq", "avx512bw", "avx512vl", "avx512cd"))
+
+
+def ref512_fn():
+    if "ref512" not in _libs:
+        _libs["ref512"] = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libenoki_ref512.so"))
+    return _libs["ref512"].ref_tape_program
+
+
 def host_lib():
     if "host" not in _libs:
         _libs["host"] = ctypes.CDLL(os.path.join(HERE, "cpp", "libtape_host.so"))
@@ -174,6 +190,33 @@ def suite(n=1000, k=37, seed=0):
                                                        ("add", 11, 6), ("add", 12, 8), ("add", 13, 9)])
     P["sw_cbrt_pow"] = Program([(a, 1), (pos, 1), (x, 1)], [("cbrt", 0), ("pow", 1, 2), ("mul", 3, 4)])
     P["sw_sum"] = Program([(u, 1), (w, 1)], [("tanh", 0), ("atan2", 2, 1), ("asinh", 3), ("hsum", 4)])
+    return P
+
+
+def scatter_twice_suite(seed=11):
+    """Two scatters into ONE buffer, then backward: the shape of the reference's tests/autodiff.cpp:433-466
+    (test30_scatter), which segfaults inside the reference under the pinned AVX2 row and is therefore compared against the
+    AVX-512 flavour (oracle/Makefile ref512).  Only exact arithmetic (small integers, products, sums of a few terms), so
+    the packet width cannot change a bit."""
+    rng = np.random.default_rng(seed)
+    ints = lambda lo, hi, size: rng.integers(lo, hi + 1, size).astype(np.float32)
+    P = {}
+    # the literal test30 program (values scaled to integers): x -> buf[0..5), y -> buf[3..7), s = dot(buf, buf)
+    x5, y4 = np.arange(5, dtype=np.float32), np.arange(4, dtype=np.float32) + 4
+    P["test30"] = Program([(x5, 1), (y4, 1), (np.zeros(10, np.float32), 0)],
+                          [("scatter", 2, 0, 0), ("scatter", 3, 1, 1), ("mul", 4, 4), ("hsum", 5)],
+                          index_inputs=[np.arange(5, dtype=np.uint32), np.arange(4, dtype=np.uint32) + 3])
+    for n, m in ((1000, 1500), (70001, 100003)):
+        i1 = rng.permutation(m)[:n].astype(np.uint32)
+        i2 = rng.permutation(m)[:(2 * n) // 3].astype(np.uint32)          # overlaps i1: those entries lose x's gradient
+        x, y = ints(-4, 4, n), ints(-4, 4, i2.size)
+        P[f"overwrite_{n}"] = Program([(x, 1), (y, 1), (np.zeros(m, np.float32), 0)],
+                                      [("scatter", 2, 0, 0), ("scatter", 3, 1, 1), ("mul", 4, 4), ("hsum", 5)], index_inputs=[i1, i2])
+        # a differentiable buffer underneath, and a scatter_add on top of the two scatters
+        base, z = ints(-2, 2, m), ints(-2, 2, n)
+        P[f"leafless_mix_{n}"] = Program([(x, 1), (y, 1), (base, 0), (z, 1)],
+                                         [("mulc", 2, 2.0), ("scatter", 4, 0, 0), ("scatter", 5, 1, 1), ("scatter_add", 6, 3, 0),
+                                          ("mul", 7, 7), ("hsum", 8)], index_inputs=[i1, i2])
     return P
 
 

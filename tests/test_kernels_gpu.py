@@ -371,6 +371,33 @@ def test_reductions(capi, oracle, n):
             assert capi.reduce(op, up(capi, ia)).numpy()[0] == oracle.reduce(op, ia), (dt, op, n)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("n", [2, 9, 1000, 100003, (1 << 20) + 3])
+def test_hmin_hmax_nan_and_signed_zero(capi, dtype, n):
+    """hmin / hmax are IEEE minNum / maxNum reductions: NaNs are ignored unless every entry is NaN, -0 < +0, whatever
+    the reduction order.  (The reference's AVX path is position dependent here -- MINPS returns its second operand
+    on unordered / equal compares, dynamic.h:669-702 -- so this is a documented deviation)"""
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal(n).astype(dtype)
+    a[rng.integers(0, n, max(n // 7, 1))] = np.nan
+    a[rng.integers(0, n, max(n // 9, 1))] = np.inf
+    a[rng.integers(0, n, max(n // 11, 1))] = -np.inf
+    cases = {"mixed": a, "first nan": np.concatenate([[np.nan], a[1:]]).astype(dtype), "last nan": np.concatenate([a[:-1], [np.nan]]).astype(dtype),
+             "all nan": np.full(n, np.nan, dtype), "zeros": np.where(np.arange(n) % 3 == 0, -0.0, 0.0).astype(dtype),
+             "zeros+nan": np.where(np.arange(n) % 2 == 0, np.nan, np.where(np.arange(n) % 3 == 0, -0.0, 0.0)).astype(dtype),
+             "finite": rng.standard_normal(n).astype(dtype)}
+    for name, v in cases.items():
+        lo, hi = capi.reduce("hmin", up(capi, v)).numpy()[0], capi.reduce("hmax", up(capi, v)).numpy()[0]
+        with np.errstate(invalid="ignore"):
+            elo, ehi = np.fmin.reduce(v), np.fmax.reduce(v)
+        zeros = v[v == 0]                       # numpy's fmin does not order the zeros: -0 < +0 here
+        if elo == 0 and zeros.size:
+            elo = dtype(-0.0) if np.signbit(zeros).any() else dtype(0.0)
+        if ehi == 0 and zeros.size:
+            ehi = dtype(0.0) if (~np.signbit(zeros)).any() else dtype(-0.0)
+        assert bits_equal(np.asarray([lo, hi], dtype), np.asarray([elo, ehi], dtype)), (name, n, lo, hi, elo, ehi)
+
+
 def test_hsum_run_to_run_deterministic(capi):
     a = up(capi, f32_inputs(1 << 20, 3, specials=False))
     r = {capi.reduce("hsum", a).numpy()[0].tobytes() for _ in range(5)}

@@ -252,3 +252,40 @@ def test_random_gather_programs_hip_tape_bit_exact(seed):
         assert _values_equal(tl.run(tl.host_lib().host_tape_program, prog), got), (seed, n)
         if HAVE_REF and n == 1000:
             assert _values_equal(tl.run(tl.ref_fn(), prog), got), (seed, n)
+
+
+# ---- two scatters into one buffer (reference tests/autodiff.cpp test30_scatter) ------------------------------------------
+SCATTER_TWICE = sorted(tl.scatter_twice_suite().keys())
+
+
+@pytest.mark.skipif(not tl.ref512_available(), reason="oracle/_ref/libenoki_ref512.so missing or no AVX-512 host")
+@pytest.mark.parametrize("name", SCATTER_TWICE)
+def test_scatter_twice_host_tape_vs_avx512_reference(name):
+    prog = tl.scatter_twice_suite()[name]
+    assert _all_equal(tl.run(tl.ref512_fn(), prog), tl.run(tl.host_lib().host_tape_program, prog)), name
+
+
+@pytest.mark.parametrize("name", SCATTER_TWICE)
+def test_scatter_twice_golden_vs_host_tape(name):
+    prog = tl.scatter_twice_suite()[name]
+    z = np.load(os.path.join(GOLDEN, f"tape_scatter_twice_{name}.npz"))
+    hv, hg = tl.run(tl.host_lib().host_tape_program, prog)
+    assert bits_equal(z["value"], hv)
+    for i, g in enumerate(hg):
+        assert g is None or bits_equal(z[f"g{i}"], g), (name, i)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SCATTER_TWICE)
+def test_scatter_twice_hip_tape_bit_exact(name):
+    """the GPU tape on the pattern that crashes the pinned AVX2 reference: against the committed vectors (made from the
+    AVX-512 reference build), the host tape and -- where the host can run it -- the AVX-512 reference build itself"""
+    prog = tl.scatter_twice_suite()[name]
+    got = tl.run(tl.hip_lib().hip_tape_program, prog)
+    z = np.load(os.path.join(GOLDEN, f"tape_scatter_twice_{name}.npz"))
+    assert bits_equal(z["value"], got[0])
+    for i, g in enumerate(got[1]):
+        assert g is None or bits_equal(z[f"g{i}"], g), (name, i)
+    assert _all_equal(tl.run(tl.host_lib().host_tape_program, prog), got), name
+    if tl.ref512_available():
+        assert _all_equal(tl.run(tl.ref512_fn(), prog), got), name
