@@ -156,6 +156,20 @@ def build_checkers(force=False, verbose=True):
     if force or _newer(call, [os.path.join(tcpp, "call_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "call_hip.cpp"), "-o", call,
               f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+    # The reference's OWN test sources compiled against this repository's headers with the device array types substituted
+    # (tests/cpp/refshim): only where the reference tree exists; the binaries travel to the GPU box.
+    ref_tests = "/root/reference/tests"
+    if os.path.isdir(ref_tests):
+        shim = os.path.join(tcpp, "refshim")
+        for name, source in (("reftest_autodiff_hip", "autodiff.cpp"),):
+            exe = os.path.join(tcpp, name + ".bin")
+            src = os.path.join(tcpp, name + ".cpp")
+            shim_files = [os.path.join(base, f) for base, _, files in os.walk(shim) for f in files]
+            if force or _newer(exe, [src, os.path.join(ref_tests, source), os.path.join(HERE, "libenoki-hip-autodiff.so")] + shim_files + _headers()):
+                # -I- : the reference's `#include "test.h"` must find the shim, not the file next to the test source
+                _run(["g++", "-O1", "-std=c++17", "-iquote", shim, "-iquote", "/usr/include/c++/11/pstl", "-I-", f"-I{shim}", inc,
+                      "-DENOKI_AUTODIFF=1", f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, source)}"', src, "-o", exe,
+                      f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     if verbose:
         print("[enoki_amd] checkers up to date (oracle/, tests/cpp/)")
 

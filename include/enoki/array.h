@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <array>
+#include <cmath>
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
@@ -87,6 +88,12 @@ template <typename T> constexpr bool is_dynamic_v = detail::is_dynamic_impl<T>::
 /// true for arrays whose storage lives in GPU memory (the role of the reference's is_cuda_array_v)
 template <typename T> constexpr bool is_device_array_v = detail::is_device_impl<T>::value;
 template <typename T> constexpr bool is_hip_array_v = is_device_array_v<T>;
+/// The reference's name for "lives on the GPU behind a deferred-evaluation backend" (array_traits.h:228-237).  Templated
+/// code written against the reference asks this to decide whether to call cuda_eval(); the HIP backend is eager, so the
+/// answer that keeps such code correct is `false` (is_device_array_v tells where the storage lives).
+template <typename T> constexpr bool is_cuda_array_v = false;
+inline void cuda_eval(bool = false) { }
+inline void cuda_sync() { }
 
 template <typename T> using int32_array_t  = replace_scalar_t<T, int32_t>;
 template <typename T> using uint32_array_t = replace_scalar_t<T, uint32_t>;
@@ -284,9 +291,40 @@ inline auto lerp(const T1 &a, const T2 &b, const T3 &t) { return fmadd(b, t, fnm
 template <typename T1, typename T2, typename T3, enable_if_t<is_array_v<T1> || is_array_v<T2> || is_array_v<T3>> = 0>
 inline auto clamp(const T1 &value, const T2 &lo, const T3 &hi) { return max(min(value, hi), lo); }
 
-// Scalar fallbacks so that templated code also accepts plain arithmetic types
-inline float  fmadd(float a, float b, float c)    { return __builtin_fmaf(a, b, c); }
-inline double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+// Scalar fallbacks so that templated code also accepts plain arithmetic types (the reference routes these through
+// array_fallbacks.h).  They are TEMPLATES on purpose: where <math.h> has put a non-template ::sqrt(float) & co. into
+// the global namespace, that exact match wins and there is no ambiguity under `using namespace enoki`.
+namespace detail {
+    template <typename... Ts> using common_fp_t = std::common_type_t<float, Ts...>;
+    template <typename... Ts> constexpr bool all_arithmetic_v = (std::is_arithmetic_v<Ts> && ...);
+}
+template <typename T1, typename T2, typename T3, enable_if_t<detail::all_arithmetic_v<T1, T2, T3>> = 0>
+inline auto fmadd(T1 a, T2 b, T3 c) { using F = detail::common_fp_t<T1, T2, T3>; return std::fma(F(a), F(b), F(c)); }
+template <typename T1, typename T2, typename T3, enable_if_t<detail::all_arithmetic_v<T1, T2, T3>> = 0>
+inline auto fmsub(T1 a, T2 b, T3 c) { using F = detail::common_fp_t<T1, T2, T3>; return std::fma(F(a), F(b), -F(c)); }
+template <typename T1, typename T2, typename T3, enable_if_t<detail::all_arithmetic_v<T1, T2, T3>> = 0>
+inline auto fnmadd(T1 a, T2 b, T3 c) { using F = detail::common_fp_t<T1, T2, T3>; return std::fma(-F(a), F(b), F(c)); }
+template <typename T1, typename T2, typename T3, enable_if_t<detail::all_arithmetic_v<T1, T2, T3>> = 0>
+inline auto fnmsub(T1 a, T2 b, T3 c) { using F = detail::common_fp_t<T1, T2, T3>; return std::fma(-F(a), F(b), -F(c)); }
+#define ENOKI_HIP_SCALAR_UNARY(name, expr)                                                        \
+    template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T name(T a) { return expr; }
+ENOKI_HIP_SCALAR_UNARY(sqrt, std::sqrt(a))   ENOKI_HIP_SCALAR_UNARY(rsqrt, T(1) / std::sqrt(a))
+ENOKI_HIP_SCALAR_UNARY(safe_sqrt, std::sqrt(a > T(0) ? a : T(0)))
+ENOKI_HIP_SCALAR_UNARY(safe_rsqrt, T(1) / std::sqrt(a > T(0) ? a : T(0)))
+ENOKI_HIP_SCALAR_UNARY(sin, std::sin(a))     ENOKI_HIP_SCALAR_UNARY(cos, std::cos(a))     ENOKI_HIP_SCALAR_UNARY(tan, std::tan(a))
+ENOKI_HIP_SCALAR_UNARY(exp, std::exp(a))     ENOKI_HIP_SCALAR_UNARY(log, std::log(a))
+ENOKI_HIP_SCALAR_UNARY(asin, std::asin(a))   ENOKI_HIP_SCALAR_UNARY(acos, std::acos(a))   ENOKI_HIP_SCALAR_UNARY(atan, std::atan(a))
+ENOKI_HIP_SCALAR_UNARY(floor, std::floor(a)) ENOKI_HIP_SCALAR_UNARY(ceil, std::ceil(a))   ENOKI_HIP_SCALAR_UNARY(abs, std::fabs(a))
+#undef ENOKI_HIP_SCALAR_UNARY
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline std::pair<T, T> sincos(T a) {
+    return { std::sin(a), std::cos(a) };
+}
+template <typename T1, typename T2, enable_if_t<detail::all_arithmetic_v<T1, T2>> = 0> inline auto min(T1 a, T2 b) {
+    using C = std::common_type_t<T1, T2>; return C(b) < C(a) ? C(b) : C(a);
+}
+template <typename T1, typename T2, enable_if_t<detail::all_arithmetic_v<T1, T2>> = 0> inline auto max(T1 a, T2 b) {
+    using C = std::common_type_t<T1, T2>; return C(b) > C(a) ? C(b) : C(a);
+}
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T sqr(T a) { return a * a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T rcp(T a) { return T(1) / a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T hsum(T a) { return a; }
@@ -712,9 +750,17 @@ private:
     Value m_data[Size_];
 };
 
-template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto dot(const T &a, const T &b) { return a.dot_(b); }
-template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto squared_norm(const T &a) { return a.dot_(a); }
-template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto norm(const T &a) { return sqrt(a.dot_(a)); }
+namespace detail {
+    template <typename T, typename = void> struct has_dot : std::false_type { };
+    template <typename T> struct has_dot<T, std::void_t<decltype(std::declval<const T &>().dot_(std::declval<const T &>()))>>
+        : std::true_type { };
+}
+/// dot(a, b): fmadd chain over the components of a static array, hsum(a * b) for everything else (array_base.h:165)
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto dot(const T &a, const T &b) {
+    if constexpr (detail::has_dot<T>::value) return a.dot_(b); else return hsum(a * b);
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto squared_norm(const T &a) { return dot(a, a); }
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto norm(const T &a) { return sqrt(dot(a, a)); }
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline T normalize(const T &a) { return a * rsqrt(squared_norm(a)); }
 template <typename V> inline Array<V, 3> cross(const Array<V, 3> &a, const Array<V, 3> &b) {
     return Array<V, 3>(fmsub(a.y(), b.z(), a.z() * b.y()), fmsub(a.z(), b.x(), a.x() * b.z()),
@@ -912,6 +958,34 @@ template <typename T> inline auto hsum_nested(const T &a) {
     else return hsum_nested(hsum(a));
 }
 
+/// a == b / a != b reduce to a single bool: all (resp. any) entries compare equal (unequal), array_router.h:494-503.
+/// (Entry-wise comparisons are eq() / neq().)
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0> inline bool operator==(const T1 &a, const T2 &b) {
+    return all_nested(eq(a, b));
+}
+template <typename T1, typename T2, enable_if_array_any_t<T1, T2> = 0> inline bool operator!=(const T1 &a, const T2 &b) {
+    return any_nested(neq(a, b));
+}
+
+/// |a - b| <= |b| rtol + atol for every entry (array_router.h:1309-1321)
+template <typename T1, typename T2> inline bool allclose(const T1 &a, const T2 &b, float rtol = 1e-5f, float atol = 1e-8f,
+                                                         bool equal_nan = false) {
+    if constexpr (!is_array_v<T1> && !is_array_v<T2>) {
+        using S = decltype(a - b);
+        S d = a - b, lim = (b < 0 ? -b : b) * S(rtol) + S(atol);
+        return ((d < 0 ? -d : d) <= lim) || (equal_nan && a != a && b != b);
+    } else {
+        using E = expr_t<T1, T2>;
+        using S = scalar_t<E>;
+        const E ea = detail::as<E>(a), eb = detail::as<E>(b);
+        auto cond = abs(ea - eb) <= abs(eb) * E(S(rtol)) + E(S(atol));
+        if constexpr (std::is_floating_point_v<S>) {
+            if (equal_nan) cond = cond | (isnan(ea) & isnan(eb));
+        }
+        return all_nested(cond);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 //  Masked assignment: masked(x, m) = v;  masked(x, m) += v;  x[m] = v   (array_masked.h, array_base.h:144-157 --
 //  on dynamic arrays every variant is a select)
@@ -957,7 +1031,16 @@ inline auto Array<Value_, Size_>::operator[](const M &mask) { return masked(*thi
 // ---------------------------------------------------------------------------------------------
 
 template <typename T> inline decltype(auto) detach(const T &a) {
-    if constexpr (is_diff_array_v<T>) return a.value_(); else return (const T &) a;
+    if constexpr (!is_diff_array_v<T>) {
+        return (const T &) a;
+    } else if constexpr (std::decay_t<T>::Depth > 1) {           // Array<DiffArray<...>, N>: component by component
+        using V = std::decay_t<decltype(detach(a.coeff(0)))>;
+        Array<V, std::decay_t<T>::Size> result;
+        for (size_t i = 0; i < std::decay_t<T>::Size; ++i) result.coeff(i) = detach(a.coeff(i));
+        return result;
+    } else {
+        return a.value_();
+    }
 }
 
 } // namespace enoki

@@ -211,6 +211,10 @@ template <typename Type_> struct DiffArray : ArrayTag {
     template <typename... Args, enable_if_t<(sizeof...(Args) > 1) && (std::is_arithmetic_v<Args> && ...)> = 0>
     DiffArray(Args... args) : m_value(args...) { }
 
+    /// Arrays of instance pointers (vectorised method calls, array_call.h): broadcast one instance; `->` dispatches
+    template <typename T = Value, enable_if_t<std::is_pointer_v<T>> = 0> DiffArray(T value) : m_value(value) { }
+    template <typename T = Value, enable_if_t<std::is_pointer_v<T>> = 0> auto operator->() const { return m_value.operator->(); }
+
     /// Conversion between element types drops the derivative (autodiff.h:180-184)
     template <typename Type2, enable_if_t<!std::is_same_v<Type, Type2>> = 0>
     DiffArray(const DiffArray<Type2> &a) : m_value(a.value_()) { }
@@ -760,15 +764,43 @@ private:
 // ---------------------------------------------------------------------------------------------
 //  Free functions (autodiff.h:1414-1531)
 // ---------------------------------------------------------------------------------------------
+namespace detail {
+    template <typename T> struct is_static_array : std::false_type { };
+    template <typename V, size_t N> struct is_static_array<Array<V, N>> : std::true_type { };
+    template <typename T> constexpr bool is_static_array_v = is_static_array<std::decay_t<T>>::value;
+}
+
+/// Nested types (Array<DiffArray<...>, N>) are handled component by component (autodiff.h:1414-1500)
 template <typename T> inline bool requires_gradient(const T &a) {
-    if constexpr (is_diff_array_v<T>) return a.requires_gradient_(); else return false;
+    if constexpr (detail::is_static_array_v<T>) {
+        bool result = false;
+        for (size_t i = 0; i < T::Size; ++i) result = result || requires_gradient(a.coeff(i));
+        return result;
+    } else if constexpr (is_diff_array_v<T>) {
+        return a.requires_gradient_();
+    } else {
+        return false;
+    }
 }
 
 template <typename T> inline void set_requires_gradient(T &a, bool value = true) {
-    if constexpr (is_diff_array_v<T>) a.set_requires_gradient_(value);
+    if constexpr (detail::is_static_array_v<T>) {
+        for (size_t i = 0; i < T::Size; ++i) set_requires_gradient(a.coeff(i), value);
+    } else if constexpr (is_diff_array_v<T>) {
+        a.set_requires_gradient_(value);
+    }
 }
 
-template <typename T> inline decltype(auto) gradient(const T &a) { return a.gradient_(); }
+template <typename T> inline decltype(auto) gradient(const T &a) {
+    if constexpr (detail::is_static_array_v<T>) {
+        using G = std::decay_t<decltype(gradient(a.coeff(0)))>;
+        Array<G, T::Size> result;
+        for (size_t i = 0; i < T::Size; ++i) result.coeff(i) = gradient(a.coeff(i));
+        return result;
+    } else {
+        return a.gradient_();
+    }
+}
 template <typename T> inline uint32_t gradient_index(const T &a) { return a.index_(); }
 template <typename T1, typename T2> inline void set_gradient(T1 &a, const T2 &b, bool backward = true) {
     a.set_gradient_(typename T1::Type(b), backward);

@@ -51,6 +51,23 @@ namespace detail {
                      fmadd(x2, fmadd(x, lit<T>(c3), lit<T>(c2)), fmadd(x, lit<T>(c1), lit<T>(c0)) + lit<T>(c8) * x8));
     }
 
+    template <typename T>
+    inline T poly9(const T &x, double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7,
+                   double c8, double c9) {
+        T x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+        return fmadd(x8, fmadd(x, lit<T>(c9), lit<T>(c8)),
+                     fmadd(x4, fmadd(x2, fmadd(x, lit<T>(c7), lit<T>(c6)), fmadd(x, lit<T>(c5), lit<T>(c4))),
+                           fmadd(x2, fmadd(x, lit<T>(c3), lit<T>(c2)), fmadd(x, lit<T>(c1), lit<T>(c0)))));
+    }
+    template <typename T>
+    inline T poly10(const T &x, double c0, double c1, double c2, double c3, double c4, double c5, double c6, double c7,
+                    double c8, double c9, double c10) {
+        T x2 = x * x, x4 = x2 * x2, x8 = x4 * x4;
+        return fmadd(x8, fmadd(x2, lit<T>(c10), fmadd(x, lit<T>(c9), lit<T>(c8))),
+                     fmadd(x4, fmadd(x2, fmadd(x, lit<T>(c7), lit<T>(c6)), fmadd(x, lit<T>(c5), lit<T>(c4))),
+                           fmadd(x2, fmadd(x, lit<T>(c3), lit<T>(c2)), fmadd(x, lit<T>(c1), lit<T>(c0)))));
+    }
+
     /// Chebyshev series at x/2 (special.h:22-36; the recurrence visits coeffs[0] twice, like the reference)
     template <typename T, size_t N> inline T chbevl(const T &x, const double (&coeffs)[N]) {
         T b0 = lit<T>(coeffs[0]), b1 = lit<T>(0), b2 = lit<T>(0);
