@@ -170,6 +170,15 @@ def build_checkers(force=False, verbose=True):
                 _run(["g++", "-O1", "-std=c++17", "-iquote", shim, "-iquote", "/usr/include/c++/11/pstl", "-I-", f"-I{shim}", inc,
                       "-DENOKI_AUTODIFF=1", f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, source)}"', src, "-o", exe,
                       f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+        # tests/sphere.cpp goes through hipcc: its vectorize() calls become fused kernels (include/enoki/vectorize.h)
+        exe = os.path.join(tcpp, "reftest_sphere_hip.bin")
+        src = os.path.join(tcpp, "reftest_sphere_hip.cpp")
+        shim_files = [os.path.join(base, f) for base, _, files in os.walk(shim) for f in files]
+        if force or _newer(exe, [src, os.path.join(ref_tests, "sphere.cpp"), os.path.join(ref_tests, "ray.h"),
+                                 os.path.join(HERE, "libenoki-hip.so")] + shim_files + _headers()):
+            _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{shim}", inc,
+                                     f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, "sphere.cpp")}"', src, "-o", exe,
+                                     f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     if verbose:
         print("[enoki_amd] checkers up to date (oracle/, tests/cpp/)")
 

@@ -357,6 +357,13 @@ void ek_hip_set_log_level(uint32_t level) { ctx().log_level = level; }
 uint32_t ek_hip_log_level(void) { return ctx().log_level; }
 uint64_t ek_hip_launch_count(void) { return ctx().launches; }
 
+int ek_hip_note_launch(const char *name, size_t n, size_t bytes) {
+    if (int rc = ensure_init()) return rc;
+    if (!name) return fail(EK_ERR_INVALID, "ek_hip_note_launch(): null name");
+    EK_LAUNCH_CHECK(name, n, bytes);
+    return EK_OK;
+}
+
 int ek_hip_profile_begin(void) {
     int rc = ensure_init();
     if (rc) return rc;

@@ -26,6 +26,14 @@
 #include <type_traits>
 #include <utility>
 
+/// Annotation macros that templated code written against the reference uses (fwd.h:17-60)
+#if !defined(ENOKI_INLINE)
+#  define ENOKI_INLINE inline __attribute__((always_inline))
+#  define ENOKI_NOINLINE __attribute__((noinline))
+#  define ENOKI_LIKELY(x) __builtin_expect(!!(x), 1)
+#  define ENOKI_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#endif
+
 namespace enoki {
 
 // ---------------------------------------------------------------------------------------------
@@ -580,7 +588,8 @@ inline void scatter_add(Target &target, const Value &value, const Index &index, 
 //  reference's generic static array: hsum = ((c0 + c1) + c2) ..., dot = fmadd(a2, b2, fmadd(a1, b1,
 //  a0 * b0)) (array_static.h:948-960).
 // ---------------------------------------------------------------------------------------------
-template <typename Value_, size_t Size_> struct Array : ArrayTag {
+/// (the default size 1 is the one-element packet that vectorize() instantiates kernels on: one slice per GPU lane)
+template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     using Value = Value_;
     using Scalar = scalar_t<Value_>;
     using ArrayType = Array;
@@ -646,7 +655,15 @@ template <typename Value_, size_t Size_> struct Array : ArrayTag {
         return r;                                                                                 \
     }
 
-    ENOKI_HIP_STATIC_UNARY(neg, operator-) ENOKI_HIP_STATIC_UNARY(not, operator~) ENOKI_HIP_STATIC_UNARY(abs, enoki::abs)
+    Array neg_() const { Array r; for (size_t i = 0; i < Size; ++i) r.m_data[i] = -m_data[i]; return r; }
+    Array not_() const {
+        Array r;
+        for (size_t i = 0; i < Size; ++i) {
+            if constexpr (std::is_same_v<Value, bool>) r.m_data[i] = !m_data[i]; else r.m_data[i] = ~m_data[i];
+        }
+        return r;
+    }
+    ENOKI_HIP_STATIC_UNARY(abs, enoki::abs)
     ENOKI_HIP_STATIC_UNARY(sqrt, enoki::sqrt) ENOKI_HIP_STATIC_UNARY(rcp, enoki::rcp) ENOKI_HIP_STATIC_UNARY(rsqrt, enoki::rsqrt)
     ENOKI_HIP_STATIC_UNARY(floor, enoki::floor) ENOKI_HIP_STATIC_UNARY(ceil, enoki::ceil)
     ENOKI_HIP_STATIC_UNARY(round, enoki::round) ENOKI_HIP_STATIC_UNARY(trunc, enoki::trunc)
@@ -859,11 +876,25 @@ inline Array<T, 2> meshgrid(const T &x, const T &y) {
         return *this;                                                                             \
     }
 
+/// Number of dynamic (device) arrays behind a value: 1 for a dynamic array, the sum over components / FIELDS for
+/// static arrays and ENOKI_STRUCT types, 0 for scalars.  vectorize() sizes its pointer tables with it.
+template <typename T, typename = int> struct dynamic_leaf_count {
+    static constexpr size_t value = (is_array_v<T> && is_dynamic_v<T>) ? 1 : 0;
+};
+template <typename V, size_t N> struct dynamic_leaf_count<Array<V, N>, int> {
+    static constexpr size_t value = N * dynamic_leaf_count<V>::value;
+};
+template <typename T> struct dynamic_leaf_count<T, enable_if_t<is_struct_v<T>>> {
+    static constexpr size_t value = struct_support<T>::leaf_count;
+};
+#define ENOKI_HIP_S_LEAVES(f)   + ::enoki::dynamic_leaf_count<std::decay_t<decltype(std::declval<Value &>().f)>>::value
+
 #define ENOKI_STRUCT_SUPPORT(Struct, ...)                                                         \
     namespace enoki {                                                                             \
     template <typename... Args_> struct struct_support<Struct<Args_...>> {                        \
         static constexpr bool Defined = true;                                                     \
         using Value = Struct<Args_...>;                                                           \
+        static constexpr size_t leaf_count = 0 ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_LEAVES, __VA_ARGS__); \
         template <typename F> static void apply(Value &v, F &&fn) {                               \
             ENOKI_HIP_FOR_EACH(ENOKI_HIP_S_VISIT1, __VA_ARGS__)                                   \
         }                                                                                         \

@@ -55,6 +55,7 @@ namespace detail {
         };
         Deferred *deferred = nullptr;
         std::vector<HIPBuffer *> readers;      // deferred gathers whose table is THIS buffer (not owning)
+        void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
 
         static void unref(HIPBuffer *b) {
             if (b && --b->ref_count == 0) delete b;
@@ -102,8 +103,13 @@ namespace detail {
             delete d;
         }
 
+        void drop_host_mirror() {
+            if (host_mirror) { free(host_mirror); host_mirror = nullptr; }
+        }
+
         ~HIPBuffer() {
             if (deferred) drop_deferred();
+            drop_host_mirror();
             if (owned && ptr) ek_hip_free(ptr);
         }
     };
@@ -679,8 +685,27 @@ template <typename Value_> struct HIPArray : ArrayTag {
         materialize();
         if (!m_buf) return nullptr;
         m_buf->force_readers();                // the caller may write through the pointer
+        m_buf->drop_host_mirror();
         return (Value *) ptr_();
     }
+
+    /// Host-side iteration `for (float v : array)` (the reference's CUDAArray iterates its managed memory, cuda.h:945-949):
+    /// a read-only host copy made on first use (synchronises); discarded when a mutable pointer is handed out
+    const Value *begin() const {
+        if (!valid() || size() == 0) return nullptr;
+        materialize();
+        if (!m_buf->host_mirror) {
+            void *h = malloc(m_buf->size * sizeof(Value));
+            if (!h) throw std::bad_alloc();
+            if (ek_hip_memcpy_to_host(h, ptr_(), m_buf->size * sizeof(Value)) != EK_OK) {
+                free(h);
+                detail::hip_raise("HIPArray::begin");
+            }
+            m_buf->host_mirror = h;
+        }
+        return (const Value *) m_buf->host_mirror;
+    }
+    const Value *end() const { const Value *b = begin(); return b ? b + size() : nullptr; }
 
     /// Broadcast a size-1 array / set the size of an empty array (CUDAArray::resize, cuda.h:935-937)
     void resize(size_t size) { set_slices_(size); }
@@ -779,6 +804,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         materialize();
         if (!m_buf) return;
         m_buf->force_readers();                // deferred gathers from this array see its contents before the write
+        m_buf->drop_host_mirror();
         if (m_buf->ref_count > 1) {
             HIPArray r = empty_(m_buf->size);
             detail::hip_check(ek_hip_memcpy_device(r.m_buf->ptr, ptr_(), m_buf->size * sizeof(Value)), "make_unique");

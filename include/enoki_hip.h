@@ -122,6 +122,10 @@ EK_API char *ek_hip_whos(void);
 EK_API void ek_hip_set_log_level(uint32_t level);   /* 0 silent .. 3 every launch (cuda.h:195-200) */
 EK_API uint32_t ek_hip_log_level(void);
 EK_API uint64_t ek_hip_launch_count(void);          /* kernels launched since init (diagnostics) */
+/* Kernels that callers launch THEMSELVES on ek_hip_stream() (the fused kernels that enoki/vectorize.h instantiates from user
+   code) report here so that they show up in ek_hip_launch_count(), the ENOKI_HIP_LOG=3 trace and ek_hip_profile_*;
+   `bytes` = algorithmic bytes of the launch.  `name` must outlive the profile (a string literal). */
+EK_API int ek_hip_note_launch(const char *name, size_t n, size_t bytes);
 EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic" */
 /* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
    launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of

@@ -28,3 +28,38 @@ def test_reference_autodiff_suite_on_device():
     passed, total, log = _run("reftest_autodiff_hip")
     assert total == 47, log[-3000:]
     assert passed == total, "\n".join(l for l in log.splitlines() if "failure --" in l or "FAILED" in l)
+
+
+def test_reference_sphere_program_on_device(tmp_path):
+    """tests/sphere.cpp of the reference (ray.h's ENOKI_STRUCT Ray, make_rays / intersect_rays / shade_hits through
+    vectorize()): compiled unmodified by hipcc, every vectorize() call is ONE fused kernel.  The program has no
+    assertion of its own; its two images (separate kernels, combined kernel) must equal the CPU oracle's pixel for pixel."""
+    import ctypes
+    import numpy as np
+    import oracle_lib as ol
+    from test_sphere_gpu import run, scene
+    exe = os.path.join(HERE, "cpp", "reftest_sphere_hip.bin")
+    if not os.path.exists(exe):
+        pytest.skip(f"{exe} was not built (needs /root/reference at build time)")
+    r = subprocess.run([exe], cwd=tmp_path, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout
+    # linspace + meshgrid (2 kernels for linspace/arange products, 2 gathers ...) and 3 + 1 vectorize kernels: the ray
+    # tracing itself is 4 launches, not ~80
+    launches = int(re.search(r"kernel launches: (\d+)", r.stdout).group(1))
+    assert launches <= 16, r.stdout
+    # the oracle on the same 1024 x 1024 grid, identity permutation, every ray active
+    res = 1024
+    gx, gy, _, _ = scene(res)
+    perm = np.arange(res * res, dtype=np.uint32); mask = np.ones(res * res, np.uint8)
+    img, hits = run(ol.port().lib.orc_cfg4, gx, gy, perm, mask)
+    # write_image() prints (int) v; the oracle's cfg4 leaves missed pixels at their initial -1 where the reference program
+    # shades the zero vector of a miss: 0.2 + max(dot(0, light), 0) * 90 = 0.2 -> 0
+    expect = np.where(img < 0, 0, img.astype(np.int32))
+    for name in ("sphere1.ppm", "sphere2.ppm"):
+        tokens = open(os.path.join(tmp_path, name)).read().split()
+        assert tokens[:4] == ["P3", "1024", "1024", "255"]
+        got = np.array(tokens[4:], dtype=np.int64).reshape(-1, 3)
+        bad = np.flatnonzero(got[:, 0] != expect)
+        assert bad.size == 0, (name, bad.size, bad[:8], got[bad[:8], 0], expect[bad[:8]])
+        assert np.array_equal(got[:, 1], expect) and np.array_equal(got[:, 2], expect), name
+    assert hits > 0
