@@ -43,9 +43,10 @@ DESCRIPTION = {
     "cfg3b": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)), a=gather(A,idx), b=gather(B,idx), K=1Mi; backward() with scatter_add grads",
     "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves of size N",
     "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))",
-    "cfg4": "ray-sphere (tests/sphere.cpp:58-83) on Array<HIPArray<float>,3>: masked gather of a 16384^2-style pixel "
-            "grid through a random permutation, make_rays/intersect_rays/shade_hits, masked scatter, count(hit); "
-            "32 Mi rays per GPU, unfused eager kernels",
+    "cfg4": "ray-sphere (tests/sphere.cpp:58-83): masked gather of a 16384^2-style pixel grid through a random "
+            "permutation, make_rays/intersect_rays/shade_hits, masked scatter, count(hit); 32 Mi rays per GPU; ONE fused "
+            "kernel through enoki::vectorize() (examples/sphere_fused.cpp)",
+    "cfg4_unfused": "the same program on Array<HIPArray<float>,3> op by op (~40 eager kernels), bit-identical image",
 }
 N_RAYS_PER_GPU = 1 << 25
 N_PATHS_PER_GPU = 1 << 24
@@ -64,7 +65,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg5"])
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_unfused", "cfg5"])
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
@@ -221,7 +222,7 @@ class Bench:
                     packer.all_reduce()
                 out["y"] = ek.detach(loss)
                 out["grad"] = g
-        elif workload == "cfg4":
+        elif workload in ("cfg4", "cfg4_unfused"):
             torch = self.torch
             nr = N_RAYS_PER_GPU                                    # weak: every rank traces its own 32 Mi rays
             res = int(round(nr ** 0.5)); res -= res % 2
@@ -238,7 +239,25 @@ class Bench:
             F, V3 = ekc.Float32, ekc.Vector3f
             light = V3(F(-1.0), F(-1.0), F(2.0))
 
-            def step():
+            import ctypes
+            fused_lib = ctypes.CDLL(os.path.join(ROOT, "examples", "libsphere_fused.so"))
+            hits_c = ctypes.c_uint64()
+
+            def step_fused():
+                # the same program as ONE kernel: enoki::vectorize() over the reference's templated kernels
+                # (examples/sphere_fused.cpp); 18 B per ray instead of ~318
+                image = F.full(-1.0, nr)
+                P = ctypes.c_void_p
+                rc = fused_lib.sphere_fused_device(P(grid.x.data_ptr()), P(grid.y.data_ptr()), P(perm.data_ptr()), P(mask.data_ptr()),
+                                                   ctypes.c_size_t(nr), P(image.data_ptr()), ctypes.byref(hits_c))
+                assert rc == 0
+                cnt = torch.tensor([hits_c.value], device=self.dev, dtype=torch.int64)
+                if ekd.active():
+                    ekd.all_reduce_(cnt)
+                out["y"] = ekc.Float32(float(cnt.item()))
+                out["image"] = image
+
+            def step_unfused():
                 pp = ekc.gather(grid, perm, mask)
                 o = V3(pp.x, pp.y, F(-1.0)); d = V3(F(0.0), F(0.0), F(1.0))
                 a = ekc.dot(d, d)
@@ -257,6 +276,7 @@ class Bench:
                     ekd.all_reduce_(cnt)
                 out["y"] = ekc.Float32(float(cnt.item()))
                 out["image"] = image
+            step = step_unfused if workload == "cfg4_unfused" else step_fused
         else:
             a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
             packer = ekd.Packer([1], self.dev) if ekd.active() else None
@@ -296,7 +316,7 @@ class Bench:
         torch.cuda.synchronize(); ekd.barrier()
         elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
         ms_per_step = elapsed / steps * 1e3
-        units = N_RAYS_PER_GPU * self.world if workload == "cfg4" else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
+        units = N_RAYS_PER_GPU * self.world if workload.startswith("cfg4") else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
         gelem_s = units / (ms_per_step * 1e-3) / 1e9
 
         # per-kernel timing of the same step: one HIP event per launch on the library stream
@@ -329,7 +349,7 @@ class Bench:
                         "traffic": pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else None,
                         "traffic_source": "profiles/rocprof_pmc_r01.txt (separate rocprofv3 --pmc passes, same command)",
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
-                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload == "cfg4" else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
+                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload.startswith("cfg4") else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
                         "kernels": kernels}
         if roofline and workload == self.args.workload:
@@ -368,7 +388,7 @@ def cpu_baseline(workload, N):
         def fn():
             ref_out["y"], ref_out["ga"], ref_out["gb"], t = chk.cfg3a(a, x, b)
             return t
-    elif workload == "cfg4":
+    elif workload in ("cfg4", "cfg4_unfused"):
         import ctypes
         n = 1 << 22                                   # bounded sample: 4 Mi rays of the same program
         res = 2048
@@ -505,7 +525,7 @@ def main():
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
     if b.world == 1 and not args.no_also:
-        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4", "cfg5"):
+        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4", "cfg4_unfused", "cfg5"):
             if w != args.workload:
                 r = b.run(w, max(5, args.steps // 2), 2, 3)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
@@ -526,12 +546,12 @@ def main():
             "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
-            "scaling": "weak" if args.workload in ("cfg4", "cfg5") else "strong", "vs_baseline": None,
+            "scaling": "weak" if args.workload in ("cfg4", "cfg4_unfused", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}",
-                       "elements_total": (N_RAYS_PER_GPU if args.workload == "cfg4" else N_PATHS_PER_GPU) * b.world
-                       if args.workload in ("cfg4", "cfg5") else b.N,
-                       "elements_per_gpu": N_RAYS_PER_GPU if args.workload == "cfg4" else N_PATHS_PER_GPU if args.workload == "cfg5" else b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
+                       "elements_total": (N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU) * b.world
+                       if args.workload in ("cfg4", "cfg4_unfused", "cfg5") else b.N,
+                       "elements_per_gpu": N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU if args.workload == "cfg5" else b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
                        "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"]},
             "result_y": main_res["result_y"], "parity_checked": bool(parity and parity["parity_checked"]), "parity": parity,
             "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,

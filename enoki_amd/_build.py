@@ -183,11 +183,31 @@ def build_checkers(force=False, verbose=True):
         print("[enoki_amd] checkers up to date (oracle/, tests/cpp/)")
 
 
+def build_examples(force=False, verbose=True):
+    """user-level programs that go through hipcc because they use enoki::vectorize() (compile-time fusion)"""
+    ex = os.path.join(ROOT, "examples")
+    out = []
+    for name in ("sphere_fused",):
+        src = os.path.join(ex, name + ".cpp")
+        lib = os.path.join(ex, f"lib{name}.so")
+        if not os.path.exists(src):
+            continue
+        if force or _newer(lib, [src, os.path.join(HERE, "libenoki-hip.so")] + _headers()):
+            _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+                                     f"-I{os.path.join(ROOT, 'include')}", src, "-o", lib, f"-L{HERE}", "-lenoki-hip",
+                                     "-Wl,-rpath,$ORIGIN/../enoki_amd"])
+            if verbose:
+                print(f"[enoki_amd] built {os.path.relpath(lib, ROOT)}")
+        out.append(lib)
+    return out
+
+
 def build_all(force=False, verbose=True):
     build_core(force, verbose)
     build_probe(force, verbose)
     build_autodiff(force, verbose)
     build_python(force, verbose)
+    build_examples(force, verbose)
     build_checkers(force, verbose)
 
 

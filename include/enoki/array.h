@@ -581,6 +581,46 @@ inline void scatter_add(Target &target, const Value &value, const Index &index, 
 }
 
 // ---------------------------------------------------------------------------------------------
+//  Gather / scatter of STATIC arrays and scalars from raw memory (array_router.h:1075-1131): what a function that runs
+//  under vectorize() uses for indirect accesses -- `mem` is then a device pointer captured by the kernel's functor.
+// ---------------------------------------------------------------------------------------------
+template <typename Array, size_t Stride = 0, typename Index, typename Mask = bool,
+          enable_if_t<!is_array_v<Array> || !is_dynamic_v<Array>> = 0>
+inline Array gather(const void *mem, const Index &index, const Mask &mask = true) {
+    using S = scalar_t<Array>;
+    using Stored = std::conditional_t<std::is_same_v<S, bool>, uint8_t, S>;
+    if constexpr (!is_array_v<Array>) {
+        return mask ? (Array) static_cast<const Stored *>(mem)[index] : Array(0);
+    } else {
+        static_assert(std::decay_t<Array>::Depth == 1, "gather(): arrays of scalars only");
+        Array r;
+        for (size_t i = 0; i < Array::Size; ++i) {
+            bool on;
+            if constexpr (is_array_v<Mask>) on = mask.coeff(i); else on = mask;
+            r.coeff(i) = on ? (S) static_cast<const Stored *>(mem)[index.coeff(i)] : S(0);
+        }
+        return r;
+    }
+}
+
+template <size_t Stride = 0, typename Value, typename Index, typename Mask = bool,
+          enable_if_t<!is_array_v<Value> || !is_dynamic_v<Value>> = 0>
+inline void scatter(void *mem, const Value &value, const Index &index, const Mask &mask = true) {
+    using S = scalar_t<Value>;
+    using Stored = std::conditional_t<std::is_same_v<S, bool>, uint8_t, S>;
+    if constexpr (!is_array_v<Value>) {
+        if (mask) static_cast<Stored *>(mem)[index] = (Stored) value;
+    } else {
+        static_assert(std::decay_t<Value>::Depth == 1, "scatter(): arrays of scalars only");
+        for (size_t i = 0; i < Value::Size; ++i) {
+            bool on;
+            if constexpr (is_array_v<Mask>) on = mask.coeff(i); else on = mask;
+            if (on) static_cast<Stored *>(mem)[index.coeff(i)] = (Stored) value.coeff(i);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 //  Static arrays: Array<Value, N> -- N components stored side by side (SoA when Value is itself a
 //  dynamic array, e.g. Array<HIPArray<float>, 3> = three independent device arrays).  Every
 //  operation is applied component by component through the free functions above, so it costs N

@@ -102,3 +102,7 @@ def test_cfg4_headline_image_bit_exact():
     pi, ph = run(ol.port().lib.orc_cfg4, *args)
     assert gh == ph and gh > (1 << 23)
     assert np.array_equal(gi.view(np.uint32), pi.view(np.uint32))
+    # ... and the fused single-kernel version (enoki::vectorize, examples/sphere_fused.cpp)
+    fused = ctypes.CDLL(os.path.join(here, "..", "examples", "libsphere_fused.so"))
+    fi, fh = run(fused.sphere_fused, *args)
+    assert fh == ph and np.array_equal(fi.view(np.uint32), pi.view(np.uint32))

@@ -67,6 +67,18 @@ def test_hip_cfg4_bit_exact(res):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("res", [8, 64, 257, 1024])
+def test_hip_cfg4_fused_bit_exact(res):
+    """the same program as ONE kernel through enoki::vectorize() (examples/sphere_fused.cpp): bit-identical image"""
+    lib = ctypes.CDLL(os.path.join(HERE, "..", "examples", "libsphere_fused.so"))
+    args = scene(res, seed=res + 1)
+    gi, gh = run(lib.sphere_fused, *args)
+    pi, ph = run(ol.port().lib.orc_cfg4, *args)
+    assert gh == ph and np.array_equal(gi.view(np.uint32), pi.view(np.uint32))
+    assert gh > 0 and gi.max() > 100
+
+
+@pytest.mark.gpu
 def test_hip_meshgrid_linspace_grid():
     """the pixel grid built by the product's own linspace + meshgrid (closed form fmadd(i, step, min))"""
     lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libsphere_hip.so"))
