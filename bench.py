@@ -71,6 +71,7 @@ def parse():
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--deterministic", action="store_true", help="bit-reproducible fp scatter_add (sorted path)")
+    ap.add_argument("--eager", action="store_true", help="time python-driven eager steps instead of step-graph replays")
     return ap.parse_args()
 
 
@@ -179,33 +180,36 @@ class Bench:
             xd = ek.Float32(x)
             packer = ekd.Packer([1, K_TABLE, K_TABLE], self.dev) if ekd.active() else None
 
-            def step():
+            def compute():
                 A = ek.Float32(A0); B = ek.Float32(B0)
                 ek.set_requires_gradient(A); ek.set_requires_gradient(B)
                 a = ek.gather(A, idx); b = ek.gather(B, idx)
                 y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
                 ek.backward(y)
-                gA = ek.gradient(A); gB = ek.gradient(B)
-                if packer:
-                    packer.pack([ekd.as_tensor(ek.detach(y)), ekd.as_tensor(gA), ekd.as_tensor(gB)])
-                    packer.all_reduce()
                 out["y"] = ek.detach(y)
-                out["gA"], out["gB"] = gA, gB
+                out["gA"], out["gB"] = ek.gradient(A), ek.gradient(B)
+
+            def exchange():
+                if packer:
+                    packer.pack([ekd.as_tensor(out["y"]), ekd.as_tensor(out["gA"]), ekd.as_tensor(out["gB"])])
+                    packer.all_reduce()
         elif workload == "cfg3a":
             a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
             xd = ek.Float32(x)
             packer = ekd.Packer([1], self.dev) if ekd.active() else None
 
-            def step():
+            def compute():
                 a = ek.Float32(a0); b = ek.Float32(b0)
                 ek.set_requires_gradient(a); ek.set_requires_gradient(b)
                 y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
                 ek.backward(y)
                 out["ga"], out["gb"] = ek.gradient(a), ek.gradient(b)
-                if packer:
-                    packer.pack([ekd.as_tensor(ek.detach(y))])
-                    packer.all_reduce()
                 out["y"] = ek.detach(y)
+
+            def exchange():
+                if packer:
+                    packer.pack([ekd.as_tensor(out["y"])])
+                    packer.all_reduce()
         elif workload == "cfg5":
             n5 = N_PATHS_PER_GPU
             tex0 = ekc.fmadd(synth.uniform_pm1(0, K_TABLE, 8), ekc.Float32(0.3), ekc.Float32(0.5))    # albedo in [0.2, 0.8)
@@ -281,14 +285,20 @@ class Bench:
             a0 = synth.uniform_pm1(begin, n, 1); b0 = synth.uniform_pm1(begin, n, 3)
             packer = ekd.Packer([1], self.dev) if ekd.active() else None
 
-            def step():
-                y = ekc.hsum(ekc.sin(ekc.exp(ekc.fmadd(a0, x, b0))))
+            def compute():
+                out["y"] = ekc.hsum(ekc.sin(ekc.exp(ekc.fmadd(a0, x, b0))))
+
+            def exchange():
                 if packer:
-                    packer.pack([ekd.as_tensor(y)])
+                    packer.pack([ekd.as_tensor(out["y"])])
                     packer.all_reduce()
-                out["y"] = y
         ek.hip_sync()
-        return step, packer, out
+        if workload in ("cfg3b", "cfg3a", "cfg2"):
+            def step():
+                compute()
+                exchange()
+            return step, packer, out, compute, exchange
+        return step, packer, out, None, None
 
     def stream_ceiling(self):
         """What a plain streaming kernel of this library reaches on this GPU right now ('also report against a
@@ -302,15 +312,37 @@ class Bench:
 
     def run(self, workload, steps, warmup, profile_steps):
         torch, ek, ekd = self.torch, self.ek, self.ekd
-        step, packer, out = self.make_step(workload)
+        step, packer, out, compute, exchange = self.make_step(workload)
         for _ in range(warmup):
             step()
+        if packer:
+            packer.wait_all()
+        # The timed steps replay a step graph: the launches of ONE forward + backward() captured on the library stream
+        # (ek_hip_graph_*), so a step costs no host work (tape walk, allocator, ~12 launch calls).  The collective stays
+        # outside the graph.  Workloads that read back to the host inside the step (cfg4: count) run eagerly.
+        graph, replay = None, "eager"
+        if compute is not None and not self.args.eager:
+            try:
+                ek.hip_sync()
+                ek.hip_graph_begin()
+                try:
+                    compute()
+                finally:
+                    graph = ek.hip_graph_end()
+                replay = f"hipGraph ({ek.hip_graph_launch_count(graph)} kernel launches per replay)"
+                timed_step = lambda: (ek.hip_graph_launch(graph), exchange())
+                timed_step()                          # first replay outside the timed region (graph upload)
+            except Exception as e:                    # never let the replay machinery break the measurement
+                print(f"[bench] step graph unavailable ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr)
+                graph, replay, timed_step = None, "eager (graph capture failed)", step
+        else:
+            timed_step = step
         if packer:
             packer.wait_all()
         ekd.barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            step()
+            timed_step()
         if packer:
             packer.wait_all()             # every step's all-reduce completes inside the timed region
         torch.cuda.synchronize(); ekd.barrier()
@@ -319,7 +351,9 @@ class Bench:
         units = N_RAYS_PER_GPU * self.world if workload.startswith("cfg4") else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
         gelem_s = units / (ms_per_step * 1e-3) / 1e9
 
-        # per-kernel timing of the same step: one HIP event per launch on the library stream
+        if graph is not None:
+            ek.hip_graph_destroy(graph)
+        # per-kernel timing of the same step (run eagerly): one HIP event per launch on the library stream
         ek.hip_profile_begin()
         for _ in range(profile_steps):
             step()
@@ -360,7 +394,7 @@ class Bench:
         outputs = {k: out[k].numpy() for k in ("gA", "gB", "ga", "gb") if k in out} if self.world == 1 and workload == self.args.workload else {}
         outputs["y"] = y_val
         return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "result_y": y_val,
-                "roofline": roofline, "collectives_per_step": 1 if packer else 0, "outputs": outputs}
+                "roofline": roofline, "collectives_per_step": 1 if packer else 0, "outputs": outputs, "replay": replay}
 
 
 def cpu_baseline(workload, N):
@@ -552,7 +586,8 @@ def main():
                        "elements_total": (N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU) * b.world
                        if args.workload in ("cfg4", "cfg4_unfused", "cfg5") else b.N,
                        "elements_per_gpu": N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU if args.workload == "cfg5" else b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
-                       "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"]},
+                       "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"],
+                       "step_replay": main_res["replay"]},
             "result_y": main_res["result_y"], "parity_checked": bool(parity and parity["parity_checked"]), "parity": parity,
             "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,
         }

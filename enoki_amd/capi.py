@@ -41,7 +41,8 @@ EXPORTS = [
     "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_scatter_add_multi", "ek_hip_concat",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
-    "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch",
+    "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
+    "ek_hip_graph_launch_count", "ek_hip_graph_destroy",
 ]
 
 

@@ -60,6 +60,19 @@ inline void note_launch(const char *name, size_t n, size_t bytes) {
     if (c.profiling) profile_mark(name, n, bytes);
 }
 
+// ---- roctx ranges ------------------------------------------------------------------------------
+// One range per kernel FAMILY (the multi-launch pipelines: scatter_add, reductions, prefix sums, fused gathers), so a
+// rocprofv3 --marker-trace timeline groups the 5-7 launches of e.g. one scatter_add under one bar.  The roctx library
+// (librocprofiler-sdk-roctx.so) is loaded lazily and only when ENOKI_HIP_ROCTX=1: no link dependency, no cost otherwise.
+void roctx_push(const char *name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 // post-launch check: kernel launch failures surface through hipGetLastError
 #define EK_LAUNCH_CHECK(name, n, bytes)                                                        \
     do {                                                                                       \

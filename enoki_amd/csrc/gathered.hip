@@ -88,14 +88,37 @@ __global__ __launch_bounds__(256) void k_map_gathered(T *__restrict__ out, size_
     out_store<T, N, true>(out, po, e, n, fast);
 }
 
+// {a[k], b[k]} records.  Four entries per lane: two 16-byte loads, two 16-byte stores (f32); the scalar body covers the
+// tail and tables that are not 16-byte aligned.
 template <typename T>
-__global__ __launch_bounds__(256) void k_interleave2(Pack<T, 2> *__restrict__ out, const T *__restrict__ a, const T *__restrict__ b, size_t k) {
-    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
-    if (i < k) {
-        Pack<T, 2> r;
-        r.v[0] = a[i];
-        r.v[1] = b[i];
-        out[i] = r;
+__global__ __launch_bounds__(256) void k_interleave2(Pack<T, 2> *__restrict__ out, const T *__restrict__ a, const T *__restrict__ b, size_t k,
+                                                     int vec_ok) {
+    constexpr int N = 16 / sizeof(T);
+    const size_t e = ((size_t) blockIdx.x * 256 + threadIdx.x) * N;
+    if (e >= k) return;
+    if (vec_ok && e + N <= k) {
+        Pack<T, N> pa = pack_load<T, N, false>(a + e), pb = pack_load<T, N, false>(b + e);
+        if constexpr (N == 4) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                Pack<T, 4> r;
+                r.v[0] = pa.v[2 * h]; r.v[1] = pb.v[2 * h]; r.v[2] = pa.v[2 * h + 1]; r.v[3] = pb.v[2 * h + 1];
+                pack_store<T, 4, false>(reinterpret_cast<T *>(out + e) + 4 * h, r);
+            }
+        } else {                     // 8-byte elements: one record per 16-byte store
+            Pack<T, 2> r0, r1;
+            r0.v[0] = pa.v[0]; r0.v[1] = pb.v[0];
+            r1.v[0] = pa.v[1]; r1.v[1] = pb.v[1];
+            out[e] = r0;
+            out[e + 1] = r1;
+        }
+    } else {
+        for (size_t i = e; i < k && i < e + N; ++i) {
+            Pack<T, 2> r;
+            r.v[0] = a[i];
+            r.v[1] = b[i];
+            out[i] = r;
+        }
     }
 }
 
@@ -174,8 +197,10 @@ int map_gathered(int arity, int op, void *out, const ek_operand *const *o, const
         if (int rc = make_garg_common(g0, n, ga.index, ga.mask)) return rc;
         const size_t K = g0->table_size;
         if (int rc = ek_hip_malloc(2 * K * sizeof(T), &pair_table)) return rc;
-        hipLaunchKernelGGL((k_interleave2<T>), dim3((unsigned) ((K + 255) / 256)), dim3(256), 0, ctx().stream,
-                           (Pack<T, 2> *) pair_table, (const T *) g0->table, (const T *) g2->table, K);
+        constexpr size_t per_block = 256 * (16 / sizeof(T));
+        hipLaunchKernelGGL((k_interleave2<T>), dim3((unsigned) ((K + per_block - 1) / per_block)), dim3(256), 0, ctx().stream,
+                           (Pack<T, 2> *) pair_table, (const T *) g0->table, (const T *) g2->table, K,
+                           (int) (aligned16(g0->table) && aligned16(g2->table)));
         note_launch("gather_interleave", K, 4 * K * sizeof(T));
         ga.table = (const T *) pair_table;
         if (int rc = make_arg<T>(ob, n, s0, "ek_hip_map_gathered")) { ek_hip_free(pair_table); return rc; }
@@ -218,6 +243,7 @@ extern "C" int ek_hip_map_gathered(int arity, int op, int type, void *out, const
                                    const ek_gathered *const *gathered, size_t n) {
     if (int rc = ensure_init()) return rc;
     if (n == 0) return EK_OK;
+    RoctxRange range("enoki-hip: gather consumed in place");
     if (!out || !operands || !gathered) return fail(EK_ERR_INVALID, "ek_hip_map_gathered(): null pointer");
     for (int k = 0; k < arity && k < 3; ++k)
         if (!operands[k] && !gathered[k]) return fail(EK_ERR_INVALID, "ek_hip_map_gathered(): operand %d is missing", k);

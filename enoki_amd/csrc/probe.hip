@@ -223,6 +223,31 @@ __global__ __launch_bounds__(256) void k_probe_gather_pair(float *__restrict__ o
     }
 }
 
+// L2 blocking in time for the pair lookup: launch h serves the elements whose index falls into slice h of the table
+// (the interleaved slice is K / S * 8 bytes: with S = 2 and K = 1 Mi each launch works out of 4 MiB, one XCD's L2); both
+// launches stream idx and x, each element's result is written by exactly one of them (4-byte stores under a lane mask).
+__global__ __launch_bounds__(256) void k_probe_gather_pair_sliced(float *__restrict__ o0, const V2 *__restrict__ AB,
+                                                                  const float *__restrict__ x, const uint32_t *__restrict__ idx,
+                                                                  size_t n, uint32_t lo, uint32_t hi) {
+    size_t e = ((size_t) blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e + 4 > n) return;
+    U4 p = __builtin_nontemporal_load(reinterpret_cast<const U4 *>(idx + e));
+    bool in[4];
+    bool any = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { in[k] = p[k] >= lo && p[k] < hi; any = any || in[k]; }
+    if (!any) return;
+    V4 xv = __builtin_nontemporal_load(reinterpret_cast<const V4 *>(x + e));
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        if (in[k]) { V2 t = AB[p[k]]; r[k] = __builtin_fmaf(t[0], xv[k], t[1]); }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (in[k]) o0[e + k] = r[k];
+}
+
 __global__ __launch_bounds__(256) void k_probe_interleave(V2 *__restrict__ AB, const float *__restrict__ A,
                                                           const float *__restrict__ B, size_t k) {
     size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -377,5 +402,18 @@ extern "C" EK_API int ek_hip_probe_interleave(float *AB, const float *A, const f
     if (int rc = ensure_init()) return rc;
     hipLaunchKernelGGL(k_probe_interleave, dim3((unsigned) ((k + 255) / 256)), dim3(256), 0, ctx().stream, (V2 *) AB, A, B, k);
     EK_LAUNCH_CHECK("probe_interleave", k, 16 * k);
+    return EK_OK;
+}
+
+extern "C" EK_API int ek_hip_probe_gather_pair_sliced(int slices, float *o0, const float *AB, size_t table_size, const float *x,
+                                                      const uint32_t *idx, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+    for (int s = 0; s < slices; ++s) {
+        uint32_t lo = (uint32_t) (table_size * (size_t) s / slices), hi = (uint32_t) (table_size * (size_t) (s + 1) / slices);
+        hipLaunchKernelGGL(k_probe_gather_pair_sliced, dim3((unsigned) ((n / 4 + 255) / 256)), dim3(256), 0, cx.stream, o0,
+                           (const V2 *) AB, x, idx, n, lo, hi);
+    }
+    EK_LAUNCH_CHECK("probe_gather_pair_sliced", n, 0);
     return EK_OK;
 }

@@ -163,6 +163,7 @@ __global__ __launch_bounds__(256) void k_reduce_stage2(T *__restrict__ out, cons
 
 template <typename R, typename T, typename Loader>
 int reduce_launch(const char *name, T *out, size_t n, int vec_ok, const Loader &ld, size_t bytes) {
+    RoctxRange range("enoki-hip: horizontal reduction");
     Context &c = ctx();
     constexpr int N = Loader::N;
     size_t items = (n / N + 3) / 4 + 1;

@@ -5,6 +5,8 @@
 // There is no trace/variable table: arrays are plain device buffers owned by HIPArray<T>.
 #include "ek_internal.h"
 
+#include <dlfcn.h>
+
 #include <cstdlib>
 #include <mutex>
 #include <string>
@@ -44,10 +46,20 @@ Context &ctx() {
 //  list and are reused in stream order (single stream => no event bookkeeping needed); on
 //  out-of-memory the cache is released and the allocation retried once (jit.cu:1716-1723).
 // ------------------------------------------------------------------------------------------------
+// Blocks that a captured step graph (ek_hip_graph_*) touches form the graph's private POOL: the graph has their
+// addresses baked in, so until the graph is destroyed they are only ever handed out again to allocations made while
+// capturing that same graph -- never to eager code, whose data a replay would overwrite.
+struct GraphPool {
+    std::unordered_map<size_t, std::vector<void *>> free_lists;
+    std::vector<void *> blocks;                                   // every block that ever entered the pool
+};
+
 struct Allocator {
     std::mutex mutex;
     std::unordered_map<size_t, std::vector<void *>> free_lists;   // class size -> blocks
     std::unordered_map<void *, size_t> live;                      // block -> class size
+    std::unordered_map<void *, GraphPool *> pool_of;              // blocks owned by a graph pool (live or free)
+    GraphPool *capture_pool = nullptr;                            // non-null between ek_hip_graph_begin / _end
     size_t live_bytes = 0, cached_bytes = 0, watermark = 0, n_malloc = 0, n_reuse = 0;
 
     static size_t round_size(size_t bytes) {
@@ -128,6 +140,32 @@ void profile_mark(const char *name, size_t n, size_t bytes) {
     if (!e) return;
     (void) hipEventRecord(e, ctx().stream);
     g_profile.push_back(ProfileRecord{ name, n, bytes, e });
+}
+
+// roctx through dlopen (see ek_internal.h)
+static void (*g_roctx_push)(const char *) = nullptr;
+static void (*g_roctx_pop)() = nullptr;
+static int g_roctx_state = 0;      // 0: not looked at, 1: active, -1: off
+
+static void roctx_load() {
+    g_roctx_state = -1;
+    const char *e = getenv("ENOKI_HIP_ROCTX");
+    if (!e || e[0] == '0') return;
+    void *lib = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return;
+    g_roctx_push = (void (*)(const char *)) dlsym(lib, "roctxRangePushA");
+    g_roctx_pop = (void (*)()) dlsym(lib, "roctxRangePop");
+    if (g_roctx_push && g_roctx_pop) g_roctx_state = 1;
+}
+
+void roctx_push(const char *name) {
+    if (g_roctx_state == 0) roctx_load();
+    if (g_roctx_state == 1) g_roctx_push(name);
+}
+
+void roctx_pop() {
+    if (g_roctx_state == 1) g_roctx_pop();
 }
 
 } // namespace ek
@@ -223,8 +261,19 @@ int ek_hip_malloc(size_t bytes, void **out) {
     size_t cls = Allocator::round_size(bytes);
     std::lock_guard<std::mutex> guard(a.mutex);
     void *ptr = nullptr;
+    GraphPool *pool = a.capture_pool;
+    if (pool) {
+        auto pit = pool->free_lists.find(cls);
+        if (pit != pool->free_lists.end() && !pit->second.empty()) {
+            ptr = pit->second.back();
+            pit->second.pop_back();
+            a.n_reuse++;
+        }
+    }
     auto it = a.free_lists.find(cls);
-    if (it != a.free_lists.end() && !it->second.empty()) {
+    if (ptr) {
+        /* reused inside the graph's pool */
+    } else if (it != a.free_lists.end() && !it->second.empty()) {
         ptr = it->second.back();
         it->second.pop_back();
         a.cached_bytes -= cls;
@@ -244,6 +293,10 @@ int ek_hip_malloc(size_t bytes, void **out) {
         }
         a.n_malloc++;
     }
+    if (pool && !a.pool_of.count(ptr)) {
+        a.pool_of[ptr] = pool;
+        pool->blocks.push_back(ptr);
+    }
     a.live[ptr] = cls;
     a.live_bytes += cls;
     if (a.live_bytes > a.watermark) a.watermark = a.live_bytes;
@@ -261,8 +314,13 @@ int ek_hip_free(void *ptr) {
     size_t cls = it->second;
     a.live.erase(it);
     a.live_bytes -= cls;
-    a.free_lists[cls].push_back(ptr);
-    a.cached_bytes += cls;
+    auto pit = a.pool_of.find(ptr);
+    if (pit != a.pool_of.end()) {
+        pit->second->free_lists[cls].push_back(ptr);     // stays reserved for its graph
+    } else {
+        a.free_lists[cls].push_back(ptr);
+        a.cached_bytes += cls;
+    }
     return EK_OK;
 }
 
@@ -313,6 +371,9 @@ int ek_hip_memcpy_to_host(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!bytes) return EK_OK;
+    if (alloc().capture_pool)
+        return fail(EK_ERR_INVALID, "ek_hip_memcpy_to_host(): device -> host reads (coeff, count, any, all, to_host) cannot be "
+                                    "part of a captured step graph");
     EK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx().stream));
     EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     return EK_OK;
@@ -356,6 +417,105 @@ char *ek_hip_whos(void) {
 void ek_hip_set_log_level(uint32_t level) { ctx().log_level = level; }
 uint32_t ek_hip_log_level(void) { return ctx().log_level; }
 uint64_t ek_hip_launch_count(void) { return ctx().launches; }
+
+// ---------------------------------------------------------------------------------------------
+//  Step graphs: capture the launches of one step once, replay them without host work
+// ---------------------------------------------------------------------------------------------
+struct ek_hip_graph {
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    GraphPool pool;
+    void *reduce_scratch = nullptr;       // the graph's private reduction scratch
+    size_t reduce_scratch_bytes = 0;
+    uint64_t launches = 0;                // kernel launches captured
+};
+
+static ek_hip_graph *g_capturing = nullptr;
+static void *g_stashed_scratch = nullptr;
+static size_t g_stashed_scratch_bytes = 0;
+static uint64_t g_capture_launch_base = 0;
+
+int ek_hip_graph_begin(void) {
+    if (int rc = ensure_init()) return rc;
+    Context &c = ctx();
+    if (g_capturing) return fail(EK_ERR_INVALID, "ek_hip_graph_begin(): a capture is already in progress");
+    if (c.profiling) return fail(EK_ERR_INVALID, "ek_hip_graph_begin(): stop ek_hip_profile_* first (events are not captured)");
+    ek_hip_graph *g = new ek_hip_graph();
+    {
+        Allocator &a = alloc();
+        std::lock_guard<std::mutex> guard(a.mutex);
+        a.capture_pool = &g->pool;
+    }
+    // the shared reduction scratch may be re-allocated by later eager code: the graph gets its own
+    g_stashed_scratch = c.reduce_scratch; g_stashed_scratch_bytes = c.reduce_scratch_bytes;
+    c.reduce_scratch = nullptr; c.reduce_scratch_bytes = 0;
+    g_capture_launch_base = c.launches;
+    hipError_t e = hipStreamBeginCapture(c.stream, hipStreamCaptureModeRelaxed);
+    if (e != hipSuccess) {
+        { Allocator &a = alloc(); std::lock_guard<std::mutex> guard(a.mutex); a.capture_pool = nullptr; }
+        c.reduce_scratch = g_stashed_scratch; c.reduce_scratch_bytes = g_stashed_scratch_bytes;
+        delete g;
+        (void) hipGetLastError();          // (do not leave the failure behind as a sticky launch error)
+        return hip_fail(e, "hipStreamBeginCapture", __FILE__, __LINE__);
+    }
+    g_capturing = g;
+    return EK_OK;
+}
+
+static void graph_release_pool(ek_hip_graph *g) {
+    Allocator &a = alloc();
+    std::lock_guard<std::mutex> guard(a.mutex);
+    for (auto &kv : g->pool.free_lists)
+        for (void *p : kv.second) {
+            a.free_lists[kv.first].push_back(p);
+            a.cached_bytes += kv.first;
+        }
+    g->pool.free_lists.clear();
+    for (void *p : g->pool.blocks) a.pool_of.erase(p);      // blocks that are still alive become ordinary blocks
+    g->pool.blocks.clear();
+}
+
+int ek_hip_graph_end(ek_hip_graph **out) {
+    Context &c = ctx();
+    if (!g_capturing) return fail(EK_ERR_INVALID, "ek_hip_graph_end(): no capture in progress");
+    ek_hip_graph *g = g_capturing;
+    g_capturing = nullptr;
+    hipError_t e = hipStreamEndCapture(c.stream, &g->graph);
+    { Allocator &a = alloc(); std::lock_guard<std::mutex> guard(a.mutex); a.capture_pool = nullptr; }
+    g->reduce_scratch = c.reduce_scratch; g->reduce_scratch_bytes = c.reduce_scratch_bytes;
+    c.reduce_scratch = g_stashed_scratch; c.reduce_scratch_bytes = g_stashed_scratch_bytes;
+    g->launches = c.launches - g_capture_launch_base;
+    if (e == hipSuccess) e = hipGraphInstantiate(&g->exec, g->graph, nullptr, nullptr, 0);
+    if (e != hipSuccess || !out) {
+        (void) hipGetLastError();
+        ek_hip_graph_destroy(g);
+        if (!out) return fail(EK_ERR_INVALID, "ek_hip_graph_end(): null output pointer");
+        return hip_fail(e, "hipStreamEndCapture / hipGraphInstantiate", __FILE__, __LINE__);
+    }
+    *out = g;
+    return EK_OK;
+}
+
+int ek_hip_graph_launch(ek_hip_graph *g) {
+    if (!g || !g->exec) return fail(EK_ERR_INVALID, "ek_hip_graph_launch(): invalid graph");
+    Context &c = ctx();
+    EK_HIP_CHECK(hipGraphLaunch(g->exec, c.stream));
+    c.launches += g->launches;
+    return EK_OK;
+}
+
+uint64_t ek_hip_graph_launch_count(const ek_hip_graph *g) { return g ? g->launches : 0; }
+
+int ek_hip_graph_destroy(ek_hip_graph *g) {
+    if (!g) return EK_OK;
+    if (ctx().initialized) (void) hipStreamSynchronize(ctx().stream);
+    if (g->exec) (void) hipGraphExecDestroy(g->exec);
+    if (g->graph) (void) hipGraphDestroy(g->graph);
+    if (g->reduce_scratch) ek_hip_free(g->reduce_scratch);
+    graph_release_pool(g);
+    delete g;
+    return EK_OK;
+}
 
 int ek_hip_note_launch(const char *name, size_t n, size_t bytes) {
     if (int rc = ensure_init()) return rc;

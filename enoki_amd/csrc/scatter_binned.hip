@@ -479,6 +479,10 @@ __global__ __launch_bounds__(kThreads) void k_bin_accumulate(T *__restrict__ par
             if (piece_prefix[b] <= blockIdx.x && blockIdx.x < piece_prefix[b + 1]) s_bucket = b;
         __syncthreads();
         const int bucket = s_bucket;
+        // value stream blockIdx.y: its pair values follow those of the previous stream (`n` = pairs per stream), its
+        // partial tables likewise
+        pair_val += (size_t) blockIdx.y * n;
+        partials += (size_t) blockIdx.y * gridDim.x * Bins;
         const size_t lo = bucket_base[bucket], hi = bucket_base[bucket + 1], q = blockIdx.x - piece_prefix[bucket];
         const size_t pieces = piece_prefix[bucket + 1] - piece_prefix[bucket], per = (hi - lo + pieces - 1) / pieces;
         begin = lo + q * per < hi ? lo + q * per : hi;
@@ -606,13 +610,18 @@ __global__ __launch_bounds__(256) void k_bin_fold_groups(T *__restrict__ out, co
     out[(size_t) g * table_size + k] = s;
 }
 
-// binned path: bin k of bucket b sums the partials of the bucket's pieces
-template <typename T>
-__global__ __launch_bounds__(256) void k_bin_fold_pieces(T *__restrict__ target, const T *__restrict__ partials,
-                                                         const uint32_t *__restrict__ piece_prefix, size_t table_size) {
+// binned path: bin k of bucket b sums the partials of the bucket's pieces; blockIdx.y = value stream (table)
+template <typename T, int C> struct FoldTargets { T *table[C]; };
+
+template <typename T, int C>
+__global__ __launch_bounds__(256) void k_bin_fold_pieces(FoldTargets<T, C> targets, const T *__restrict__ partials,
+                                                         const uint32_t *__restrict__ piece_prefix, size_t table_size,
+                                                         size_t partial_stride) {
     size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
     if (k >= table_size) return;
     using U = wrap_t<T>;
+    T *__restrict__ target = targets.table[blockIdx.y];
+    partials += (size_t) blockIdx.y * partial_stride;
     const uint32_t b = (uint32_t) (k >> bin_shift_of<T>), local = (uint32_t) (k & (bins_of<T> - 1));
     T s = target[k];
     for (uint32_t p = piece_prefix[b]; p < piece_prefix[b + 1]; ++p)
@@ -687,6 +696,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
 template <typename T, typename I, int C>
 int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
                              const Arg<I> &index, const Arg<uint8_t> &mask, size_t n) {
+    RoctxRange range("enoki-hip: scatter_add (LDS-binned)");
     Context &c = ctx();
     constexpr int Bins = bins_of<T>, Shift = bin_shift_of<T>;
     const int n_buckets = (int) ((table_size + Bins - 1) / Bins);
@@ -714,14 +724,12 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
     int rep_shift = 0;
     while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
     const size_t count_entries = (size_t) n_buckets * blocks;
-    Scratch counts, pairs_idx, pairs_val[C], partials;
+    Scratch counts, pairs_idx, pairs_val, partials;
     // layout: counts[n_buckets][blocks] | row_total[kMaxBuckets] | bucket_base[kMaxBuckets + 1] | piece_prefix[kMaxBuckets + 1]
     if (int rc = counts.alloc((count_entries + 3 * kMaxBuckets + 2) * sizeof(uint32_t))) return rc;
     if (int rc = pairs_idx.alloc(n * sizeof(uint16_t))) return rc;
-    for (int s = 0; s < C; ++s) {
-        if (int rc = pairs_val[s].alloc(n * sizeof(T))) return rc;
-        st.pair_val[s] = (T *) pairs_val[s].ptr;
-    }
+    if (int rc = pairs_val.alloc((size_t) C * n * sizeof(T))) return rc;        // stream s at offset s * n
+    for (int s = 0; s < C; ++s) st.pair_val[s] = (T *) pairs_val.ptr + (size_t) s * n;
     uint32_t *row_total = (uint32_t *) counts.ptr + count_entries;
     uint32_t *bucket_base = row_total + kMaxBuckets;
     uint32_t *piece_prefix = bucket_base + kMaxBuckets + 1;
@@ -742,17 +750,19 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
     EK_LAUNCH_CHECK("scatter_add_partition", n, stream_bytes + arg_bytes(index, n) + arg_bytes(mask, n) +
                                                 n * (sizeof(uint16_t) + C * sizeof(T)));
 
-    if (int rc = partials.alloc((size_t) max_pieces * Bins * sizeof(T))) return rc;
-    for (int s = 0; s < C; ++s) {
-        // (the partials buffer is reused: the launches of one stream are ordered on the stream)
-        hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3(max_pieces), dim3(kThreads), lds_bytes, c.stream,
-                           (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr, (const T *) pairs_val[s].ptr,
-                           (const uint32_t *) bucket_base, values[s], index.ptr, mask, n, n_buckets, (const uint32_t *) piece_prefix);
-        EK_LAUNCH_CHECK("scatter_add_accumulate", n, n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * Bins * sizeof(T));
-        hipLaunchKernelGGL((k_bin_fold_pieces<T>), dim3((unsigned) ((table_size + 255) / 256)), dim3(256), 0, c.stream, bases[s],
-                           (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size);
-        EK_LAUNCH_CHECK("scatter_add_fold", table_size, (size_t) max_pieces * Bins * sizeof(T) + 2 * table_size * sizeof(T));
-    }
+    // ONE accumulate launch and ONE fold launch for all value streams (grid.y = stream): fewer launches per backward()
+    if (int rc = partials.alloc((size_t) C * max_pieces * Bins * sizeof(T))) return rc;
+    hipLaunchKernelGGL((k_bin_accumulate<T, I, false, true>), dim3(max_pieces, C), dim3(kThreads), lds_bytes, c.stream,
+                       (T *) partials.ptr, table_size, (const uint16_t *) pairs_idx.ptr, (const T *) pairs_val.ptr,
+                       (const uint32_t *) bucket_base, values[0], index.ptr, mask, n, n_buckets, (const uint32_t *) piece_prefix);
+    EK_LAUNCH_CHECK("scatter_add_accumulate", (size_t) C * n,
+                    (size_t) C * (n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * Bins * sizeof(T)));
+    FoldTargets<T, C> targets;
+    for (int s = 0; s < C; ++s) targets.table[s] = bases[s];
+    hipLaunchKernelGGL((k_bin_fold_pieces<T, C>), dim3((unsigned) ((table_size + 255) / 256), C), dim3(256), 0, c.stream, targets,
+                       (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size, (size_t) max_pieces * Bins);
+    EK_LAUNCH_CHECK("scatter_add_fold", (size_t) C * table_size,
+                    (size_t) C * ((size_t) max_pieces * Bins * sizeof(T) + 2 * table_size * sizeof(T)));
     return EK_OK;
 }
 

@@ -51,8 +51,19 @@ def init(backend=None):
     return rank, local_rank, world
 
 
+_own_stream = None
+
+
 def adopt_torch_stream(ek_module):
-    """run the library's kernels on torch's current stream so collectives and kernels are stream ordered"""
+    """Run the library's kernels on torch's current stream so that collectives and kernels are stream ordered.  When
+    that is the (legacy) default stream, a dedicated stream is created and made current first: the default stream
+    cannot be captured into a step graph (ek_hip_graph_*), and its implicit synchronisation with every other stream is
+    not wanted on the hot path either."""
+    global _own_stream
+    if torch.cuda.current_stream() == torch.cuda.default_stream():
+        torch.cuda.synchronize()
+        _own_stream = torch.cuda.Stream()
+        torch.cuda.set_stream(_own_stream)
     ek_module.hip_set_stream(torch.cuda.current_stream().cuda_stream)
 
 
@@ -99,10 +110,13 @@ class Packer:
             self.work[self.cur].wait()
             self.work[self.cur] = None
         self.flat = self.bufs[self.cur]
+        from enoki_amd import hip as _ek
         if self.flat.is_cuda and self.flat.dtype == torch.float32 and len(tensors) <= 8 and \
+                _ek.hip_stream() == torch.cuda.current_stream().cuda_stream and \
                 all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
-            # one launch for all parts (ek_hip_concat) on the stream shared with torch, instead of one copy per part
-            from enoki_amd import hip as _ek
+            # one launch for all parts (ek_hip_concat) instead of one copy per part -- only when the library runs on
+            # torch's current stream (adopt_torch_stream): otherwise the launch would race with the producers of
+            # `tensors` and with the collective, and the per-part copies below (torch's stream) are used
             assert [t.numel() for t in tensors] == self.sizes
             _ek.hip_concat_f32(self.flat.data_ptr(), [(t.data_ptr(), t.numel()) for t in tensors])
             return

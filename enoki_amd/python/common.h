@@ -531,6 +531,16 @@ inline void bind_runtime(py::module_ &m) {
     m.def("hip_stream", []() { return (uintptr_t) ek_hip_stream(); });
     m.def("hip_set_stream", [](uintptr_t s) { detail::hip_check(ek_hip_set_stream((void *) s), "hip_set_stream"); });
     m.def("hip_launch_count", []() { return ek_hip_launch_count(); });
+    // step graphs: capture once, replay without host work (ek_hip_graph_*)
+    m.def("hip_graph_begin", []() { detail::hip_check(ek_hip_graph_begin(), "hip_graph_begin"); });
+    m.def("hip_graph_end", []() {
+        ek_hip_graph *g = nullptr;
+        detail::hip_check(ek_hip_graph_end(&g), "hip_graph_end");
+        return (uintptr_t) g;
+    }, "returns a graph handle for hip_graph_launch / hip_graph_destroy");
+    m.def("hip_graph_launch", [](uintptr_t g) { detail::hip_check(ek_hip_graph_launch((ek_hip_graph *) g), "hip_graph_launch"); });
+    m.def("hip_graph_launch_count", [](uintptr_t g) { return ek_hip_graph_launch_count((const ek_hip_graph *) g); });
+    m.def("hip_graph_destroy", [](uintptr_t g) { detail::hip_check(ek_hip_graph_destroy((ek_hip_graph *) g), "hip_graph_destroy"); });
     m.def("hip_set_defer_gather", [](bool v) { hip_set_defer_gather(v); },
           "large gathers from small tables stay deferred until consumed (fused into the consuming add/sub/mul/fma)");
     m.def("hip_defer_gather", []() { return hip_defer_gather(); });

@@ -126,6 +126,21 @@ EK_API uint64_t ek_hip_launch_count(void);          /* kernels launched since in
    code) report here so that they show up in ek_hip_launch_count(), the ENOKI_HIP_LOG=3 trace and ek_hip_profile_*;
    `bytes` = algorithmic bytes of the launch.  `name` must outlive the profile (a string literal). */
 EK_API int ek_hip_note_launch(const char *name, size_t n, size_t bytes);
+/* Step graphs (hipGraph): between ek_hip_graph_begin() and ek_hip_graph_end() every launch of this library -- kernels,
+   memsets, device-to-device copies -- is CAPTURED on the library stream instead of executed; ek_hip_graph_launch()
+   replays the captured step without any host-side work (no tape walk, no allocator, no per-kernel launch call), which
+   is what strong scaling needs once a shard's step is a dozen kernels of 10-50 us.  Memory that the captured code
+   allocates comes from a pool private to the graph and stays reserved until ek_hip_graph_destroy(): the arrays that
+   are alive when the capture ends (results, gradients) keep their addresses, and every replay refreshes their contents.
+   Not capturable (fail with EK_ERR_INVALID / EK_ERR_HIP): anything that reads back to the host -- ek_hip_memcpy_to_host,
+   ek_hip_mask_reduce (all / any / count), deterministic scatter_add, ek_hip_profile_*.
+   The reference has no counterpart: its cuda_eval() re-assembles and re-launches PTX per evaluation (jit.cu:1385-1471). */
+typedef struct ek_hip_graph ek_hip_graph;
+EK_API int ek_hip_graph_begin(void);
+EK_API int ek_hip_graph_end(ek_hip_graph **out);
+EK_API int ek_hip_graph_launch(ek_hip_graph *graph);
+EK_API uint64_t ek_hip_graph_launch_count(const ek_hip_graph *graph);   /* kernel launches inside one replay */
+EK_API int ek_hip_graph_destroy(ek_hip_graph *graph);
 EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic" */
 /* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
    launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of

@@ -1,0 +1,77 @@
+"""Step graphs (ek_hip_graph_*): the launches of one forward + backward() are captured once and replayed without host work;
+the replay must produce what the eager step produces -- also after the INPUT BUFFERS were refilled in place."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, cfg3b_truth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ek():
+    import enoki_amd.hip_autodiff as m
+    m.hip_init(0)
+    return m
+
+
+def _refill(capi, arr, host):
+    host = np.ascontiguousarray(host)
+    capi.check(capi.lib.ek_hip_memcpy_to_device(ctypes.c_void_p(arr.data_ptr()), host.ctypes.data_as(ctypes.c_void_p),
+                                                ctypes.c_size_t(host.nbytes)))
+
+
+@pytest.mark.parametrize("n,K", [(300007, 65536), (1 << 22, 1 << 20)])
+def test_cfg3b_step_graph_replay(ek, capi, n, K):
+    rng = np.random.default_rng(n)
+    hA, hB = rng.uniform(-1, 1, K).astype(np.float32), rng.uniform(-1, 1, K).astype(np.float32)
+    hx = rng.uniform(-1, 1, n).astype(np.float32); hidx = rng.integers(0, K, n).astype(np.uint32)
+    A0, B0, x, idx = ek.Float32(hA), ek.Float32(hB), ek.Float32(hx), ek.UInt32(hidx)
+    out = {}
+
+    def step():
+        A, B = ek.Float32(A0), ek.Float32(B0)
+        ek.set_requires_gradient(A); ek.set_requires_gradient(B)
+        y = ek.hsum(ek.sin(ek.fmadd(ek.gather(A, idx), x, ek.gather(B, idx))))
+        ek.backward(y)
+        out["y"], out["gA"], out["gB"] = ek.detach(y), ek.gradient(A), ek.gradient(B)
+
+    step()                                              # eager: warms the allocator, gives the reference values
+    eager = (out["y"].numpy().copy(), out["gA"].numpy().copy(), out["gB"].numpy().copy())
+    launches0 = ek.hip_launch_count()
+    ek.hip_graph_begin()
+    step()
+    g = ek.hip_graph_end()
+    try:
+        per_step = ek.hip_graph_launch_count(g)
+        assert per_step >= 8 and ek.hip_launch_count() - launches0 == per_step
+        t = cfg3b_truth(hA, hB, hx, hidx)
+        for _ in range(3):
+            ek.hip_graph_launch(g)
+            y, gA, gB = out["y"].numpy(), out["gA"].numpy(), out["gB"].numpy()
+            assert bits_equal(y, eager[0])                              # hsum is run-to-run deterministic
+            assert np.all(np.abs(gA - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(gB - t["gB"]) <= t["gB_bound"])
+        # new contents in the SAME buffers: the graph reads the new inputs
+        hA2, hx2 = rng.uniform(-1, 1, K).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32)
+        _refill(capi, A0, hA2); _refill(capi, x, hx2)
+        ek.hip_graph_launch(g)
+        t2 = cfg3b_truth(hA2, hB, hx2, hidx)
+        assert abs(float(out["y"].numpy()[0]) - t2["y"]) <= t2["y_bound"]
+        assert np.all(np.abs(out["gA"].numpy() - t2["gA"]) <= t2["gA_bound"])
+        # eager work after the capture must not disturb the graph's buffers
+        junk = [ek.Float32(np.full(n, 3.0, np.float32)) * ek.Float32(2.0) for _ in range(4)]
+        ek.hip_graph_launch(g)
+        assert np.all(np.abs(out["gB"].numpy() - t2["gB"]) <= t2["gB_bound"])
+        del junk
+    finally:
+        ek.hip_graph_destroy(g)
+    # reads to the host are refused inside a capture, and the library recovers
+    ek.hip_graph_begin()
+    with pytest.raises(RuntimeError):
+        ek.count(x > ek.Float32(0.0))
+    g2 = ek.hip_graph_end()
+    ek.hip_graph_destroy(g2)
+    step()
+    assert bits_equal(out["y"].numpy(), ek.hsum(ek.sin(ek.fmadd(ek.gather(A0, idx), x, ek.gather(B0, idx)))).numpy())

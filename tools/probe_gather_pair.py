@@ -14,7 +14,7 @@ x = capi.Buf.from_numpy(rng.uniform(-1, 1, n).astype(np.float32))
 names = {0: "2 x 4-B lookups, a and b written", 1: "1 x 8-B lookup, a and b written", 2: "2 x 4-B lookups -> fma",
          3: "1 x 8-B lookup -> fma", 4: "a streamed, b looked up -> fma", 5: "a looked up, c streamed -> fma"}
 print(f"# tools/probe_gather_pair.py on 1 x MI355X: {n >> 20} Mi elements, random indices into K-entry tables")
-for logk in (14, 16, 18, 19, 20, 21, 22):
+for logk in (19, 20, 21, 22):
     K = 1 << logk
     A = capi.Buf.from_numpy(rng.uniform(-1, 1, K).astype(np.float32))
     B = capi.Buf.from_numpy(rng.uniform(-1, 1, K).astype(np.float32))
@@ -23,6 +23,9 @@ for logk in (14, 16, 18, 19, 20, 21, 22):
     capi.check(pl.ek_hip_probe_interleave(P(AB.ptr), P(A.ptr), P(B.ptr), ctypes.c_size_t(K)))
     fns = {v: (lambda v=v: capi.check(pl.ek_hip_probe_gather_pair(v, P(o0.ptr), P(o1.ptr), P(A.ptr), P(B.ptr), P(AB.ptr), P(x.ptr),
                                                                    P(s.ptr), P(idx.ptr), ctypes.c_size_t(n)))) for v in range(6)}
+    for S in (2, 4):
+        fns[f"1 x 8-B lookup -> fma, {S} table slices in time"] = lambda S=S: capi.check(pl.ek_hip_probe_gather_pair_sliced(
+            S, P(o0.ptr), P(AB.ptr), ctypes.c_size_t(K), P(x.ptr), P(idx.ptr), ctypes.c_size_t(n)))
     fns["interleave"] = lambda: capi.check(pl.ek_hip_probe_interleave(P(AB.ptr), P(A.ptr), P(B.ptr), ctypes.c_size_t(K)))
 
     def prod():
@@ -41,4 +44,4 @@ for logk in (14, 16, 18, 19, 20, 21, 22):
     for k, v in samples.items():
         ms = statistics.median(v)
         label = names.get(k, k)
-        print(f"K=2^{logk} ({K * 4 >> 10:6d} KiB per table)  {label:36s} {ms:7.4f} ms")
+        print(f"K=2^{logk} ({K * 4 >> 10:6d} KiB per table)  {label:52s} {ms:7.4f} ms")
