@@ -161,4 +161,7 @@ template <typename T, typename I, int C>
 int scatter_add_sorted_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
                              const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);
 
+// stable LSD radix sort of (key, element number) pairs by the low `key_bits` bits (scatter_binned.hip)
+int sort_pairs_u32(int key_bits, const uint32_t *keys, size_t n, uint32_t *keys_out, uint32_t *perm_out);
+
 } // namespace ek

@@ -340,6 +340,15 @@ int ek_hip_concat(int type, void *out, int count, const void *const *srcs, const
     return EK_OK;
 }
 
+int ek_hip_sort_pairs(int key_bits, const uint32_t *keys, size_t n, uint32_t *keys_out, uint32_t *perm_out) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!keys || !keys_out || !perm_out) return fail(EK_ERR_INVALID, "ek_hip_sort_pairs(): null pointer");
+    if (n >= ((size_t) 1 << 32)) return fail(EK_ERR_UNSUPPORTED, "ek_hip_sort_pairs(): more than 2^32 - 1 entries");
+    if (key_bits > 32) key_bits = 32;
+    return sort_pairs_u32(key_bits, keys, n, keys_out, perm_out);
+}
+
 int ek_hip_gather(int type, int index_type, void *out, const void *base, const ek_operand *index,
                   const ek_operand *mask, size_t n) {
     if (int rc = ensure_init()) return rc;

@@ -255,8 +255,13 @@ __global__ __launch_bounds__(256) void k_scan_apply(T *__restrict__ out, const T
     }
 }
 
+template <typename T> int psum_single_pass(void *out, const void *in, size_t n);      // scan.hip: decoupled look-back
+
 template <typename T> int psum_typed(void *out, const void *in, size_t n) {
     Context &c = ctx();
+    // one pass over the data (8 B per 4-byte element) unless a floating point sum has to be run-to-run reproducible:
+    // the look-back's association depends on timing, the three kernels below have a fixed shape
+    if (!(std::is_floating_point_v<T> && c.tuning.deterministic)) return psum_single_pass<T>(out, in, n);
     unsigned blocks = (unsigned) std::min<size_t>((n + 4095) / 4096, (size_t) c.num_cu * 4);
     if (blocks == 0) blocks = 1;
     size_t chunk = (n + blocks - 1) / blocks;

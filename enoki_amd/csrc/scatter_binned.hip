@@ -941,7 +941,9 @@ __global__ __launch_bounds__(kThreads) void k_radix_partition_stable(uint32_t *_
         for (int j = 0; j < kPerThread; ++j) {
             const size_t i = base + (size_t) wave * (kTile / kSortWaves) + (size_t) j * 64 + lane;
             T v = (st.value[c].vec && i < end) ? st.value[c].ptr[i] : sv[c];
-            if ((st.weighted >> c) & 1u) v = dev::safe_mul((st.weight[c].vec && i < end) ? st.weight[c].ptr[i] : sw[c], v);
+            if constexpr (std::is_floating_point_v<T>) {
+                if ((st.weighted >> c) & 1u) v = dev::safe_mul((st.weight[c].vec && i < end) ? st.weight[c].ptr[i] : sw[c], v);
+            }
             val[j] = v;
         }
     };
@@ -1229,6 +1231,53 @@ int scatter_add_sorted(T *base, size_t table_size, const Arg<T> &value, const Ar
     const Arg<T> values[1] = { value }, weights[1] = { Arg<T>{ nullptr, T(1), 0u } };
     T *bases[1] = { base };
     return scatter_add_sorted_multi<T, I, 1>(bases, table_size, values, weights, 0u, index, mask, n);
+}
+
+// Stable sort of (key, element number) pairs by the low `key_bits` bits of 32-bit keys: the building block of
+// partition() (the reference sorts (pointer, lane) pairs with cub::DeviceRadixSort, horiz.cu:35-122).  Same ballot-ranked
+// LSD passes as above with the element numbers as the value stream.
+int sort_pairs_u32(int key_bits, const uint32_t *keys, size_t n, uint32_t *keys_out, uint32_t *perm_out) {
+    RoctxRange range("enoki-hip: sort (key, lane) pairs");
+    Context &c = ctx();
+    if (key_bits < 1) key_bits = 1;
+    const int passes = (key_bits + kRadixBits - 1) / kRadixBits;
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+    const size_t count_entries = (size_t) kRadix * blocks;
+    Scratch counts, keys_tmp, perm_tmp, iota;
+    if (int rc = counts.alloc((count_entries + 2 * kRadix + 1) * sizeof(uint32_t))) return rc;
+    if (int rc = keys_tmp.alloc(n * sizeof(uint32_t))) return rc;
+    if (int rc = perm_tmp.alloc(n * sizeof(uint32_t))) return rc;
+    if (int rc = iota.alloc(n * sizeof(uint32_t))) return rc;
+    if (int rc = ek_hip_arange(EK_U32, iota.ptr, 0, 1, n)) return rc;
+    uint32_t *row_total = (uint32_t *) counts.ptr + count_entries, *bucket_base = row_total + kRadix;
+    const Arg<uint8_t> all_on{ nullptr, 1, 0 };
+    const uint32_t *in_keys = keys, *in_vals = (const uint32_t *) iota.ptr;
+    for (int p = 0; p < passes; ++p) {
+        // ping-pong so that the LAST pass writes the caller's buffers
+        const bool to_caller = ((passes - 1 - p) & 1) == 0;
+        uint32_t *out_keys = to_caller ? keys_out : (uint32_t *) keys_tmp.ptr;
+        BinStreams<uint32_t, 1> st;
+        st.weighted = 0u;
+        st.pair_val[0] = to_caller ? perm_out : (uint32_t *) perm_tmp.ptr;
+        st.value[0] = Arg<uint32_t>{ in_vals, 0u, 1u };
+        st.weight[0] = Arg<uint32_t>{ nullptr, 1u, 0u };
+        const int shift = p * kRadixBits;
+        hipLaunchKernelGGL((k_radix_count<uint32_t>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, in_keys,
+                           all_on, n, chunk, shift);
+        hipLaunchKernelGGL(k_bin_scan_rows, dim3(kRadix), dim3(1024), 0, c.stream, (uint32_t *) counts.ptr, row_total, blocks);
+        hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr,
+                           (const uint32_t *) row_total, kRadix, 0u);
+        hipLaunchKernelGGL((k_radix_partition_stable<uint32_t, uint32_t, 1>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys, st,
+                           in_keys, all_on, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, n, chunk, shift);
+        EK_LAUNCH_CHECK("sort_pass", n, n * 5 * sizeof(uint32_t));
+        in_keys = out_keys;
+        in_vals = st.pair_val[0];
+    }
+    return EK_OK;
 }
 
 #define EK_SORTED_INSTANCE(T, I)                                                                                      \

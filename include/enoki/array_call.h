@@ -92,7 +92,14 @@ template <typename Class_> struct HIPArray<Class_ *> : ArrayTag {
     }
 
     /// Groups of lanes that share an instance: ascending pointer value, ascending lane index within a group
-    /// (a null pointer forms a group of its own, which the call dispatcher skips)
+    /// (a null pointer forms a group of its own, which the call dispatcher skips).
+    ///
+    /// Like the reference (cuda_partition, horiz.cu:35-122: radix sort of (pointer, lane) pairs + run-length encoding), the
+    /// cost does not depend on the number of distinct instances: the pointers are mapped to dense 32-bit keys
+    /// ((p - lowest) / 8 + 1, 0 for null -- as many key bits as the instances' address span needs), (key, lane) pairs go
+    /// through ONE stable LSD radix sort (ek_hip_sort_pairs), run starts come from a compare with the left neighbour + an
+    /// order-preserving compress.  Groups are views into the sorted lane array.  Pointer sets that do not fit 32-bit keys
+    /// (spans >= 32 GiB, pointers that are not 8-byte aligned) take the instance-by-instance extraction below.
     const Partition &partition_() const {
         if (!m_partition) {
             auto result = std::make_shared<Partition>();
@@ -100,7 +107,7 @@ template <typename Class_> struct HIPArray<Class_ *> : ArrayTag {
             using UInt32 = HIPArray<uint32_t>;
             if (n == 1) {
                 result->emplace_back(coeff(0), UInt32(0u));
-            } else if (n > 1) {
+            } else if (n > 1 && !partition_sorted_(*result)) {
                 const uint64_t none = ~uint64_t(0);
                 MaskType remaining = MaskType::full_(true, n);
                 UInt32 lane = UInt32::arange_(0, (ptrdiff_t) n, 1);
@@ -124,8 +131,46 @@ template <typename Class_> struct HIPArray<Class_ *> : ArrayTag {
     }
 
 private:
+    /// sort-based partition (see partition_()); false when the pointers do not map to 32-bit keys
+    bool partition_sorted_(Partition &result) const {
+        using UInt32 = HIPArray<uint32_t>;
+        using UInt64 = UnderlyingType;
+        const size_t n = size();
+        if (n >= ((size_t) 1 << 32)) return false;
+        const UInt64 zero(uint64_t(0));
+        MaskType is_null = m_bits.eq_(zero);
+        const uint64_t lowest = UInt64::select_(is_null, UInt64(~uint64_t(0)), m_bits).hmin_().coeff(0);
+        if (lowest == ~uint64_t(0)) {                         // every lane is null
+            result.emplace_back((Value) nullptr, UInt32::arange_(0, (ptrdiff_t) n, 1));
+            return true;
+        }
+        const uint64_t highest = m_bits.hmax_().coeff(0);
+        const uint64_t misaligned = m_bits.or_(UInt64(lowest)).and_(UInt64(uint64_t(7))).hmax_().coeff(0);
+        const uint64_t span = ((highest - lowest) >> 3) + 2;       // keys 1 .. span - 1, 0 = null
+        if (misaligned || span > (uint64_t(1) << 32)) return false;
+        int key_bits = 1;
+        while ((uint64_t(1) << key_bits) < span) ++key_bits;
+        UInt32 keys = UInt32(UInt64::select_(is_null, zero, m_bits.sub_(UInt64(lowest)).sr_(UInt64(uint64_t(3))).add_(UInt64(uint64_t(1)))));
+        UInt32 sorted = UInt32::empty_(n), lanes = UInt32::empty_(n);
+        detail::hip_check(ek_hip_sort_pairs(key_bits, keys.data(), n, sorted.data(), lanes.data()), "partition_");
+        // run starts: entries whose key differs from the left neighbour's (the first entry always starts a run)
+        UInt32 pos = UInt32::arange_(0, (ptrdiff_t) n, 1);
+        UInt32 left = UInt32::template gather_<sizeof(uint32_t)>(sorted.data(), pos.sub_(UInt32(1u)), pos.neq_(UInt32(0u)));
+        MaskType starts_here = sorted.neq_(left).or_(pos.eq_(UInt32(0u)));
+        std::vector<uint32_t> starts = pos.compress_(starts_here).to_host();
+        std::vector<uint32_t> start_keys = sorted.compress_(starts_here).to_host();
+        m_partition_lanes = lanes;                              // the groups below are views into this array
+        for (size_t g = 0; g < starts.size(); ++g) {
+            const size_t begin = starts[g], end = g + 1 < starts.size() ? starts[g + 1] : n;
+            const uint64_t p = start_keys[g] == 0 ? 0 : lowest + ((uint64_t) (start_keys[g] - 1) << 3);
+            result.emplace_back((Value) (uintptr_t) p, UInt32::map((void *) (m_partition_lanes.data() + begin), end - begin));
+        }
+        return true;
+    }
+
     UnderlyingType m_bits;
     mutable std::shared_ptr<Partition> m_partition;
+    mutable HIPArray<uint32_t> m_partition_lanes;      // storage behind the sort-based partition's group views
 };
 
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline decltype(auto) partition(const T &a) { return a.partition_(); }

@@ -241,6 +241,13 @@ EK_API int ek_hip_mask_reduce(int op, const uint8_t *mask, size_t n, uint64_t *h
 /* inclusive prefix sum (cuda.h:717-726 / horiz.cu:182-200) */
 EK_API int ek_hip_psum(int type, void *out, const void *in, size_t n);
 
+/* Stable sort of (key, element number) pairs by the low `key_bits` bits of 32-bit keys:
+ *     keys_out = keys sorted ascending, perm_out[j] = original position of keys_out[j]; equal keys keep their order.
+ * The building block of partition() -- the reference sorts (pointer, lane) pairs with a 64-bit CUB radix sort and run-length
+ * encodes them (cuda_partition, src/cuda/horiz.cu:35-122); callers here first map the pointers to dense 32-bit keys.
+ * ceil(key_bits / 8) ballot-ranked LSD passes, 20 B per entry and pass. */
+EK_API int ek_hip_sort_pairs(int key_bits, const uint32_t *keys, size_t n, uint32_t *keys_out, uint32_t *perm_out);
+
 /* PCG32 draw (include/enoki/random.h:68-133): one fused kernel that advances `state` by `inc` where `mask`
  * is set (state_out[i] = mask[i] ? state[i] * 0x5851f42d4c957f2d + inc[i] : state[i]) and writes the output
  * function of the OLD state: u32[n], f32[n] in [0,1), f64[n] in [0,1), or u64[n] (two steps; the FIRST draw is the high

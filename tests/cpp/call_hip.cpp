@@ -244,3 +244,40 @@ int hip_getter_test(const uint8_t *which, const uint8_t *mask_, size_t n, float 
         return -3;
     }
 }
+
+// ---- partition() with many instances ---------------------------------------------------------------------------------
+// `which[i]` selects one of `instances` objects (or none: which[i] == 0xFFFFFFFF -> null pointer).  Returns, per group in
+// partition order, the instance number (0xFFFFFFFF for null) and the group size; `perm_out` receives the concatenated
+// lane lists; `elapsed_ms` the wall time of partition() itself (cold: the array has no cached partition).
+#include <chrono>
+extern "C" __attribute__((visibility("default")))
+int hip_partition_many(const uint32_t *which, size_t n, uint32_t instances, uint32_t *group_instance, uint32_t *group_size,
+                       uint32_t *n_groups, uint32_t *perm_out, double *elapsed_ms, uint64_t *launches) {
+    try {
+        struct Dummy { virtual ~Dummy() = default; double pad[3]; };
+        std::vector<Dummy> pool(instances);
+        std::vector<Dummy *> host(n);
+        for (size_t i = 0; i < n; ++i) host[i] = which[i] == 0xFFFFFFFFu ? nullptr : &pool[which[i]];
+        HIPArray<Dummy *> ptrs = HIPArray<Dummy *>::copy(host.data(), n);
+        hip_sync();
+        const uint64_t before = ek_hip_launch_count();
+        auto t0 = std::chrono::steady_clock::now();
+        const auto &groups = partition(ptrs);
+        hip_sync();
+        *elapsed_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        *launches = ek_hip_launch_count() - before;
+        *n_groups = (uint32_t) groups.size();
+        size_t at = 0;
+        for (size_t g = 0; g < groups.size(); ++g) {
+            group_instance[g] = groups[g].first ? (uint32_t) (groups[g].first - pool.data()) : 0xFFFFFFFFu;
+            auto lanes = groups[g].second.to_host();
+            group_size[g] = (uint32_t) lanes.size();
+            memcpy(perm_out + at, lanes.data(), lanes.size() * sizeof(uint32_t));
+            at += lanes.size();
+        }
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hip_partition_many: %s\n", e.what());
+        return -3;
+    }
+}

@@ -153,3 +153,32 @@ def test_call_support_getters():
     want = np.select([which == 0, which == 1, which == 2], [10.5, -3.25, 7.0], 0.0).astype(np.float32)
     assert np.array_equal(tag, want) and np.array_equal(tagm, np.where(mask != 0, want, np.float32(0)))
     assert np.array_equal(lanes, np.select([which == 0, which == 1, which == 2], [11, 22, 33], 0).astype(np.uint64))
+
+
+@pytest.mark.parametrize("instances", [1, 3, 1000, 70000])
+def test_partition_scales_with_instances(instances):
+    """partition() = dense 32-bit keys + ONE stable radix sort + run starts (like cuda_partition, horiz.cu:35-122): groups
+    in ascending pointer order, lanes ascending inside a group, null pointers first; the number of kernel launches does
+    not depend on the number of distinct instances"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libcall_hip.so"))
+    n = 1 << 20
+    rng = np.random.default_rng(instances)
+    which = rng.integers(0, instances, n).astype(np.uint32)
+    which[rng.integers(0, n, n // 50)] = 0xFFFFFFFF               # some null pointers
+    gi = np.zeros(instances + 1, np.uint32); gs = np.zeros(instances + 1, np.uint32); ng = ctypes.c_uint32()
+    perm = np.zeros(n, np.uint32); ms = ctypes.c_double(); launches = ctypes.c_uint64()
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.hip_partition_many(p(which), ctypes.c_size_t(n), ctypes.c_uint32(instances), p(gi), p(gs), ctypes.byref(ng), p(perm),
+                                  ctypes.byref(ms), ctypes.byref(launches)) == 0
+    g = ng.value
+    present = np.unique(which)
+    expect_order = np.concatenate([[0xFFFFFFFF], present[present != 0xFFFFFFFF]]).astype(np.uint32)     # null (0) sorts first
+    assert g == expect_order.size and np.array_equal(gi[:g], expect_order)
+    at = 0
+    for k in range(g):
+        lanes = perm[at:at + gs[k]]
+        assert np.array_equal(lanes, np.flatnonzero(which == gi[k]).astype(np.uint32)), k
+        at += gs[k]
+    assert at == n
+    assert launches.value <= 40, launches.value                    # independent of the number of instances
+    print(f"partition of {n} lanes over {instances} instances: {ms.value:.3f} ms, {launches.value} launches")
