@@ -20,6 +20,7 @@
 #include <enoki/matrix.h>
 #include <enoki/special.h>
 #include <enoki/complex.h>
+#include <enoki/quaternion.h>
 
 #include <sstream>
 
@@ -347,12 +348,18 @@ template <typename Dst, typename Src> void bind_cast(py::class_<Dst> &cl) {
     cl.def(py::init([](const Src &s) { return Dst(s); }));
 }
 
-/// Static vectors of device arrays: Vector2f / Vector3f / Vector4f (cuda_2d.cpp ... cuda_4d.cpp in the reference)
+/// Static vectors of device arrays: Vector{1,2,3,4}{m,i,u,f,d} (cuda_1d.cpp ... cuda_4d.cpp / cuda_autodiff_*d.cpp of the
+/// reference bind the same family through bind<>, src/python/common.h:338-998).  The operator set follows the element
+/// type: masks get the logical operators and all / any, integers + - * and the bit operators, floats the full arithmetic
+/// and the geometric helpers.
 template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::module_ &m, const char *name) {
     using Vec = Array<Value, N>;
     using Scalar = scalar_t<Value>;
     using Mask = mask_t<Value>;
+    using VecMask = mask_t<Vec>;
     using UInt32 = uint32_array_t<Value>;
+    constexpr bool IsMaskV = is_mask_v<Value>, IsFloatV = std::is_floating_point_v<Scalar>,
+                   IsIntV = std::is_integral_v<Scalar> && !IsMaskV;
     py::class_<Vec> cl(m, name);
     cl.def(py::init<>())
       .def(py::init<const Vec &>())
@@ -361,21 +368,12 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
       .def("__len__", [](const Vec &) { return N; })
       .def("__getitem__", [](const Vec &v, size_t i) { if (i >= N) throw py::index_error(); return v.coeff(i); })
       .def("__setitem__", [](Vec &v, size_t i, const Value &x) { if (i >= N) throw py::index_error(); v.coeff(i) = x; })
-      .def("__setitem__", [](Vec &v, const Mask &m, const Vec &x) { masked(v, m) = x; })
+      .def("__setitem__", [](Vec &v, const Mask &mk, const Vec &x) { masked(v, mk) = x; })
       .def("__repr__", [](const Vec &v) {
           std::string s = "[";
           for (size_t i = 0; i < N; ++i) s += array_repr(v.coeff(i)) + (i + 1 < N ? ",\n " : "]");
           return s;
-      })
-      .def(py::self + py::self).def(py::self - py::self).def(py::self * py::self).def(py::self / py::self)
-      .def(-py::self)
-      .def("__mul__", [](const Vec &a, const Value &b) { return Vec(a * b); })
-      .def("__rmul__", [](const Vec &a, const Value &b) { return Vec(a * b); })
-      .def("__truediv__", [](const Vec &a, const Value &b) { return Vec(a / b); })
-      .def("__mul__", [](const Vec &a, Scalar b) { return Vec(a * b); })
-      .def("__rmul__", [](const Vec &a, Scalar b) { return Vec(a * b); })
-      .def("__add__", [](const Vec &a, Scalar b) { return Vec(a + b); })
-      .def("__sub__", [](const Vec &a, Scalar b) { return Vec(a - b); });
+      });
     if constexpr (N == 2) cl.def(py::init<const Value &, const Value &>());
     if constexpr (N == 3) cl.def(py::init<const Value &, const Value &, const Value &>());
     if constexpr (N == 4) cl.def(py::init<const Value &, const Value &, const Value &, const Value &>());
@@ -384,44 +382,117 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
     if constexpr (N >= 3) cl.def_property("z", [](const Vec &v) { return v.z(); }, [](Vec &v, const Value &x) { v.z() = x; });
     if constexpr (N >= 4) cl.def_property("w", [](const Vec &v) { return v.w(); }, [](Vec &v, const Value &x) { v.w() = x; });
 
-    m.def("dot", [](const Vec &a, const Vec &b) { return dot(a, b); });
-    m.def("abs_dot", [](const Vec &a, const Vec &b) { return abs(dot(a, b)); });
-    m.def("hsum_nested", [](const Vec &a) { return hsum(hsum(a)); });
-    m.def("hprod_nested", [](const Vec &a) { return hprod(hprod(a)); });
-    m.def("hmin_nested", [](const Vec &a) { return hmin(hmin(a)); });
-    m.def("hmax_nested", [](const Vec &a) { return hmax(hmax(a)); });
-    m.def("squared_norm", [](const Vec &a) { return squared_norm(a); });
-    m.def("norm", [](const Vec &a) { return norm(a); });
-    m.def("normalize", [](const Vec &a) { return normalize(a); });
-    m.def("hsum", [](const Vec &a) { return hsum(a); });
-    m.def("hprod", [](const Vec &a) { return hprod(a); });
-    m.def("hmin", [](const Vec &a) { return hmin(a); });
-    m.def("hmax", [](const Vec &a) { return hmax(a); });
-    m.def("abs", [](const Vec &a) { return abs(a); });
-    m.def("sqrt", [](const Vec &a) { return sqrt(a); });
-    m.def("min", [](const Vec &a, const Vec &b) { return min(a, b); });
-    m.def("max", [](const Vec &a, const Vec &b) { return max(a, b); });
-    m.def("fmadd", [](const Vec &a, const Vec &b, const Vec &c) { return fmadd(a, b, c); });
+    if constexpr (IsMaskV) {
+        cl.def("__and__", [](const Vec &a, const Vec &b) { return Vec(a & b); })
+          .def("__or__", [](const Vec &a, const Vec &b) { return Vec(a | b); })
+          .def("__xor__", [](const Vec &a, const Vec &b) { return Vec(a ^ b); })
+          .def("__invert__", [](const Vec &a) { return Vec(!a); });
+        m.def("all", [](const Vec &a) { return all(a); });          // over the components -> a mask array (cuda semantics)
+        m.def("any", [](const Vec &a) { return any(a); });
+        m.def("all_nested", [](const Vec &a) { return all_nested(a); });
+        m.def("any_nested", [](const Vec &a) { return any_nested(a); });
+        m.def("none_nested", [](const Vec &a) { return none_nested(a); });
+    } else {
+        cl.def(py::self + py::self).def(py::self - py::self).def(py::self * py::self).def(-py::self)
+          .def("__mul__", [](const Vec &a, const Value &b) { return Vec(a * b); })
+          .def("__rmul__", [](const Vec &a, const Value &b) { return Vec(a * b); })
+          .def("__mul__", [](const Vec &a, Scalar b) { return Vec(a * b); })
+          .def("__rmul__", [](const Vec &a, Scalar b) { return Vec(a * b); })
+          .def("__add__", [](const Vec &a, Scalar b) { return Vec(a + b); })
+          .def("__sub__", [](const Vec &a, Scalar b) { return Vec(a - b); })
+          .def("__lt__", [](const Vec &a, const Vec &b) { return VecMask(a < b); })
+          .def("__le__", [](const Vec &a, const Vec &b) { return VecMask(a <= b); })
+          .def("__gt__", [](const Vec &a, const Vec &b) { return VecMask(a > b); })
+          .def("__ge__", [](const Vec &a, const Vec &b) { return VecMask(a >= b); });
+        m.def("eq", [](const Vec &a, const Vec &b) { return VecMask(eq(a, b)); });
+        m.def("neq", [](const Vec &a, const Vec &b) { return VecMask(neq(a, b)); });
+        m.def("hsum_nested", [](const Vec &a) { return hsum(hsum(a)); });
+        m.def("hprod_nested", [](const Vec &a) { return hprod(hprod(a)); });
+        m.def("hmin_nested", [](const Vec &a) { return hmin(hmin(a)); });
+        m.def("hmax_nested", [](const Vec &a) { return hmax(hmax(a)); });
+        m.def("hsum", [](const Vec &a) { return hsum(a); });
+        m.def("hprod", [](const Vec &a) { return hprod(a); });
+        m.def("hmin", [](const Vec &a) { return hmin(a); });
+        m.def("hmax", [](const Vec &a) { return hmax(a); });
+        m.def("abs", [](const Vec &a) { return abs(a); });
+        m.def("min", [](const Vec &a, const Vec &b) { return min(a, b); });
+        m.def("max", [](const Vec &a, const Vec &b) { return max(a, b); });
+        m.def("fmadd", [](const Vec &a, const Vec &b, const Vec &c) { return fmadd(a, b, c); });
+        m.def("dot", [](const Vec &a, const Vec &b) { return dot(a, b); });
+        m.def("scatter_add", [](Vec &target, const Vec &source, const UInt32 &index, const Mask &mask) { scatter_add(target, source, index, mask); },
+              "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
+    }
+    if constexpr (IsIntV) {
+        cl.def("__and__", [](const Vec &a, const Vec &b) { return Vec(a & b); })
+          .def("__or__", [](const Vec &a, const Vec &b) { return Vec(a | b); })
+          .def("__xor__", [](const Vec &a, const Vec &b) { return Vec(a ^ b); })
+          .def("__lshift__", [](const Vec &a, const Vec &b) { return Vec(a << b); })
+          .def("__rshift__", [](const Vec &a, const Vec &b) { return Vec(a >> b); })
+          .def("__floordiv__", [](const Vec &a, const Vec &b) { return Vec(a / b); })
+          .def("__mod__", [](const Vec &a, const Vec &b) { return Vec(a % b); });
+    }
+    if constexpr (IsFloatV) {
+        cl.def(py::self / py::self)
+          .def("__truediv__", [](const Vec &a, const Value &b) { return Vec(a / b); })
+          .def("__truediv__", [](const Vec &a, Scalar b) { return Vec(a / b); });
+        m.def("abs_dot", [](const Vec &a, const Vec &b) { return abs(dot(a, b)); });
+        m.def("squared_norm", [](const Vec &a) { return squared_norm(a); });
+        m.def("norm", [](const Vec &a) { return norm(a); });
+        m.def("normalize", [](const Vec &a) { return normalize(a); });
+        m.def("sqrt", [](const Vec &a) { return sqrt(a); });
+        if constexpr (N == 3) m.def("cross", [](const Vec &a, const Vec &b) { return cross(a, b); });
+    }
     m.def("select", [](const Mask &mk, const Vec &t, const Vec &f) { return select(mk, t, f); });
     m.def("slices", [](const Vec &a) { return slices(a); });
     m.def("gather", [](const Vec &source, const UInt32 &index, const Mask &mask) { return gather<Vec>(source, index, mask); },
           "source"_a, "index"_a, "mask"_a = Mask(true));
     m.def("scatter", [](Vec &target, const Vec &source, const UInt32 &index, const Mask &mask) { scatter(target, source, index, mask); },
           "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
-    m.def("scatter_add", [](Vec &target, const Vec &source, const UInt32 &index, const Mask &mask) { scatter_add(target, source, index, mask); },
-          "target"_a, "source"_a, "index"_a, "mask"_a = Mask(true));
-    if constexpr (N == 3) m.def("cross", [](const Vec &a, const Vec &b) { return cross(a, b); });
-    if constexpr (is_diff_array_v<Value>) {
-        m.def("set_requires_gradient", [](Vec &a, bool value) { for (size_t i = 0; i < N; ++i) set_requires_gradient(a.coeff(i), value); },
-              "array"_a, "value"_a = true);
-        m.def("gradient", [](const Vec &a) {
-            using Plain = std::decay_t<decltype(detach(std::declval<const Value &>()))>;
-            Array<Plain, N> g;
-            for (size_t i = 0; i < N; ++i) g.coeff(i) = gradient(a.coeff(i));
-            return g;
-        });
+    if constexpr (is_diff_array_v<Value> && IsFloatV) {
+        m.def("set_requires_gradient", [](Vec &a, bool value) { set_requires_gradient(a, value); }, "array"_a, "value"_a = true);
+        m.def("gradient", [](const Vec &a) { return gradient(a); });
+        m.def("detach", [](const Vec &a) { return detach(a); });
     }
     return cl;
+}
+
+/// Conversions between the element flavours of one vector size (cuda_3d.cpp:10-33): Vector3f(Vector3i) ...
+template <typename Dst, typename Src> void bind_vector_cast(py::class_<Dst> &cl) {
+    cl.def(py::init([](const Src &s) { return Dst(s); }));
+}
+
+/// Vector0*: the degenerate size-0 members of the family (cuda_0d.cpp); nothing to compute, kept for API completeness
+template <typename Tag> struct EmptyVector { };
+template <typename Tag> void bind_vector0(py::module_ &m, const char *name) {
+    py::class_<EmptyVector<Tag>>(m, name)
+        .def(py::init<>())
+        .def("__len__", [](const EmptyVector<Tag> &) { return 0; })
+        .def("__repr__", [](const EmptyVector<Tag> &) { return std::string("[]"); });
+}
+
+/// The whole family for one module: `A<T>` maps an element type to the module's array type
+template <template <typename> class A> void bind_vector_family(py::module_ &m) {
+    bind_vector0<A<bool>>(m, "Vector0m"); bind_vector0<A<int32_t>>(m, "Vector0i"); bind_vector0<A<uint32_t>>(m, "Vector0u");
+    bind_vector0<A<float>>(m, "Vector0f"); bind_vector0<A<double>>(m, "Vector0d");
+#define ENOKI_BIND_VECTORS(N)                                                                                      \
+    {                                                                                                              \
+        auto vm = bind_vector<A<bool>, N>(m, "Vector" #N "m");                                                     \
+        auto vi = bind_vector<A<int32_t>, N>(m, "Vector" #N "i");                                                  \
+        auto vu = bind_vector<A<uint32_t>, N>(m, "Vector" #N "u");                                                 \
+        auto vf = bind_vector<A<float>, N>(m, "Vector" #N "f");                                                    \
+        auto vd = bind_vector<A<double>, N>(m, "Vector" #N "d");                                                   \
+        (void) vm;                                                                                                 \
+        bind_vector_cast<Array<A<float>, N>, Array<A<double>, N>>(vf); bind_vector_cast<Array<A<float>, N>, Array<A<int32_t>, N>>(vf);   \
+        bind_vector_cast<Array<A<float>, N>, Array<A<uint32_t>, N>>(vf);                                           \
+        bind_vector_cast<Array<A<double>, N>, Array<A<float>, N>>(vd); bind_vector_cast<Array<A<double>, N>, Array<A<int32_t>, N>>(vd);  \
+        bind_vector_cast<Array<A<double>, N>, Array<A<uint32_t>, N>>(vd);                                          \
+        bind_vector_cast<Array<A<int32_t>, N>, Array<A<uint32_t>, N>>(vi); bind_vector_cast<Array<A<int32_t>, N>, Array<A<float>, N>>(vi); \
+        bind_vector_cast<Array<A<int32_t>, N>, Array<A<double>, N>>(vi);                                           \
+        bind_vector_cast<Array<A<uint32_t>, N>, Array<A<int32_t>, N>>(vu); bind_vector_cast<Array<A<uint32_t>, N>, Array<A<float>, N>>(vu); \
+        bind_vector_cast<Array<A<uint32_t>, N>, Array<A<double>, N>>(vu);                                          \
+    }
+    ENOKI_BIND_VECTORS(1) ENOKI_BIND_VECTORS(2) ENOKI_BIND_VECTORS(3) ENOKI_BIND_VECTORS(4)
+#undef ENOKI_BIND_VECTORS
 }
 
 /// Matrix<Value, N> (src/python/matrix.h of the reference): N x N entries in row-major order, products, transpose, ...
@@ -511,6 +582,56 @@ template <typename Value> py::class_<Complex<Value>> bind_complex(py::module_ &m
     m.def("sin", [](const C &z) { return sin(z); });
     m.def("cos", [](const C &z) { return cos(z); });
     m.def("tan", [](const C &z) { return tan(z); });
+    return cl;
+}
+
+/// Quaternion<Value> (src/python/quat.h of the reference)
+template <typename Value> py::class_<Quaternion<Value>> bind_quaternion(py::module_ &m, const char *name) {
+    using Q = Quaternion<Value>;
+    using Scalar = scalar_t<Value>;
+    using Vector3 = Array<Value, 3>;
+    py::class_<Q> cl(m, name);
+    cl.def(py::init<>())
+      .def(py::init<const Q &>())
+      .def(py::init<const Value &>(), "w"_a)
+      .def(py::init<const Value &, const Value &, const Value &, const Value &>(), "x"_a, "y"_a, "z"_a, "w"_a)
+      .def("__getitem__", [](const Q &q, size_t i) { if (i >= 4) throw py::index_error(); return q.coeff(i); })
+      .def("__setitem__", [](Q &q, size_t i, const Value &v) { if (i >= 4) throw py::index_error(); q.coeff(i) = v; })
+      .def("__len__", [](const Q &) { return 4; })
+      .def("__add__", [](const Q &a, const Q &b) { return Q(a + b); })
+      .def("__sub__", [](const Q &a, const Q &b) { return Q(a - b); })
+      .def("__neg__", [](const Q &a) { return Q(-a); })
+      .def("__mul__", [](const Q &a, const Q &b) { return Q(a * b); })
+      .def("__mul__", [](const Q &a, const Value &b) { return Q(a * b); })
+      .def("__truediv__", [](const Q &a, const Q &b) { return Q(a / b); })
+      .def("__truediv__", [](const Q &a, const Value &b) { return Q(a / b); })
+      .def_static("identity", [](size_t size) { return identity<Q>(size); }, "size"_a = 1)
+      .def_static("zero", [](size_t size) { Value z = zero<Value>(size); return Q(z, z, z, z); }, "size"_a = 1)
+      .def_static("full", [](Scalar v, size_t size) { Value f = full<Value>(v, size); return Q(f, f, f, f); }, "value"_a, "size"_a = 1);
+    cl.def_property("x", [](const Q &q) { return q.x(); }, [](Q &q, const Value &v) { q.x() = v; });
+    cl.def_property("y", [](const Q &q) { return q.y(); }, [](Q &q, const Value &v) { q.y() = v; });
+    cl.def_property("z", [](const Q &q) { return q.z(); }, [](Q &q, const Value &v) { q.z() = v; });
+    cl.def_property("w", [](const Q &q) { return q.w(); }, [](Q &q, const Value &v) { q.w() = v; });
+    m.def("real", [](const Q &q) { return real(q); });
+    m.def("imag", [](const Q &q) { return imag(q); });
+    m.def("conj", [](const Q &q) { return conj(q); });
+    m.def("norm", [](const Q &q) { return norm(q); });
+    m.def("squared_norm", [](const Q &q) { return squared_norm(q); });
+    m.def("rcp", [](const Q &q) { return rcp(q); });
+    m.def("normalize", [](const Q &q) { return normalize(q); });
+    m.def("dot", [](const Q &a, const Q &b) { return dot(a, b); });
+    m.def("abs", [](const Q &q) { return abs(q); });
+    m.def("sqrt", [](const Q &q) { return sqrt(q); });
+    m.def("exp", [](const Q &q) { return exp(q); });
+    m.def("log", [](const Q &q) { return log(q); });
+    m.def("pow", [](const Q &a, const Q &b) { return pow(a, b); });
+    m.def("slerp", [](const Q &a, const Q &b, const Value &t) { return slerp(a, b, t); }, "a"_a, "b"_a, "t"_a);
+    m.def("quat_to_euler", [](const Q &q) { return quat_to_euler<Vector3>(q); });
+    m.def("quat_to_matrix", [](const Q &q) { return quat_to_matrix<Matrix<Value, 4>>(q); });
+    m.def("quat_to_matrix3", [](const Q &q) { return quat_to_matrix<Matrix<Value, 3>>(q); });
+    m.def("matrix_to_quat", [](const Matrix<Value, 4> &mat) { return matrix_to_quat(mat); });
+    m.def("matrix_to_quat", [](const Matrix<Value, 3> &mat) { return matrix_to_quat(mat); });
+    m.def("rotate", [](const Vector3 &axis, const Value &angle) { return rotate<Q>(axis, angle); }, "axis"_a, "angle"_a);
     return cl;
 }
 

@@ -22,13 +22,12 @@ PYBIND11_MODULE(hip, m) {
     auto i64 = bind_array<Int64C>(m, "Int64");
     auto u64 = bind_array<UInt64C>(m, "UInt64");
     m.attr("Float") = m.attr("Float32");
-    bind_vector<FloatC, 2>(m, "Vector2f");
-    bind_vector<FloatC, 3>(m, "Vector3f");
-    bind_vector<FloatC, 4>(m, "Vector4f");
-    bind_matrix<FloatC, 2>(m, "Matrix2f");
-    bind_matrix<FloatC, 3>(m, "Matrix3f");
-    bind_matrix<FloatC, 4>(m, "Matrix4f");
-    bind_complex<FloatC>(m, "Complex2f");
+    bind_vector_family<HIPArray>(m);             // Vector{0..4}{m,i,u,f,d}
+    bind_matrix<FloatC, 2>(m, "Matrix2f"); bind_matrix<DoubleC, 2>(m, "Matrix2d");
+    bind_matrix<FloatC, 3>(m, "Matrix3f"); bind_matrix<DoubleC, 3>(m, "Matrix3d");
+    bind_matrix<FloatC, 4>(m, "Matrix4f"); bind_matrix<DoubleC, 4>(m, "Matrix4d");
+    bind_complex<FloatC>(m, "Complex2f"); bind_complex<DoubleC>(m, "Complex2d");
+    bind_quaternion<FloatC>(m, "Quaternion4f"); bind_quaternion<DoubleC>(m, "Quaternion4d");
     m.def("meshgrid", [](const FloatC &x, const FloatC &y) { return meshgrid(x, y); });
 
     bind_cast<FloatC, Int32C>(f32); bind_cast<FloatC, UInt32C>(f32); bind_cast<FloatC, DoubleC>(f32);

@@ -9,6 +9,7 @@ using DoubleD = DiffArray<HIPArray<double>>;
 using Int32D = DiffArray<HIPArray<int32_t>>;
 using UInt32D = DiffArray<HIPArray<uint32_t>>;
 using MaskD = DiffArray<HIPArray<bool>>;
+template <typename T> using DiffHIP = DiffArray<HIPArray<T>>;
 
 PYBIND11_MODULE(hip_autodiff, m) {
     m.doc() = "MI355X-native differentiable Enoki arrays (tape-based reverse/forward mode)";
@@ -20,13 +21,12 @@ PYBIND11_MODULE(hip_autodiff, m) {
     auto i32 = bind_array<Int32D>(m, "Int32");
     auto u32 = bind_array<UInt32D>(m, "UInt32");
     m.attr("Float") = m.attr("Float32");
-    bind_vector<FloatD, 2>(m, "Vector2f");
-    bind_vector<FloatD, 3>(m, "Vector3f");
-    bind_vector<FloatD, 4>(m, "Vector4f");
-    bind_matrix<FloatD, 2>(m, "Matrix2f");
-    bind_matrix<FloatD, 3>(m, "Matrix3f");
-    bind_matrix<FloatD, 4>(m, "Matrix4f");
-    bind_complex<FloatD>(m, "Complex2f");
+    bind_vector_family<DiffHIP>(m);              // Vector{0..4}{m,i,u,f,d} (cuda_autodiff_{0..4}d.cpp)
+    bind_matrix<FloatD, 2>(m, "Matrix2f"); bind_matrix<DoubleD, 2>(m, "Matrix2d");
+    bind_matrix<FloatD, 3>(m, "Matrix3f"); bind_matrix<DoubleD, 3>(m, "Matrix3d");
+    bind_matrix<FloatD, 4>(m, "Matrix4f"); bind_matrix<DoubleD, 4>(m, "Matrix4d");
+    bind_complex<FloatD>(m, "Complex2f"); bind_complex<DoubleD>(m, "Complex2d");
+    bind_quaternion<FloatD>(m, "Quaternion4f"); bind_quaternion<DoubleD>(m, "Quaternion4d");
 
     f32.def(py::init([](const FloatC &v) { return FloatD(v); }));
     f64.def(py::init([](const DoubleC &v) { return DoubleD(v); }));

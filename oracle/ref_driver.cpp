@@ -26,6 +26,7 @@
 #include <enoki/matrix.h>
 #include <enoki/special.h>
 #include <enoki/complex.h>
+#include <enoki/quaternion.h>
 
 #include <chrono>
 #include <cstdint>
@@ -734,6 +735,26 @@ extern "C" int ref_complex(const float *a_, const float *b_, size_t n, float *ou
     }
     store(FloatX(abs(a)), out + (size_t) 18 * n, n);
     store(FloatX(arg(a)), out + (size_t) 19 * n, n);
+    return 0;
+}
+
+/* Quaternion<FloatX> (include/enoki/quaternion.h): a, b are (4, n) arrays {x, y, z, w}, t is (n).  out is (8, 4, n):
+   a*b, a/b (= a*rcp(b)), exp(a), log(a), slerp(na, nb, t) for the normalised inputs, matrix_to_quat(quat_to_matrix(na)),
+   sqrt(a), rcp(a); mat is (9, n): quat_to_matrix<Matrix3>(na) in row-major order. */
+extern "C" int ref_quaternion(const float *a_, const float *b_, const float *t_, size_t n, float *out, float *mat) {
+    using Q = Quaternion<FloatX>;
+    auto load_q = [&](const float *p) { return Q(FloatX::copy(p, n), FloatX::copy(p + n, n), FloatX::copy(p + 2 * n, n), FloatX::copy(p + 3 * n, n)); };
+    Q a = load_q(a_), b = load_q(b_);
+    FloatX t = FloatX::copy(t_, n);
+    Q na = normalize(a), nb = normalize(b);
+    Matrix<FloatX, 3> m3 = quat_to_matrix<Matrix<FloatX, 3>>(na);
+    Q r[8] = { a * b, a / b, exp(a), log(a), slerp(na, nb, t), matrix_to_quat(m3), sqrt(a), rcp(a) };
+    for (int k = 0; k < 8; ++k)
+        for (int c = 0; c < 4; ++c)
+            store(FloatX(r[k].coeff(c)), out + ((size_t) k * 4 + c) * n, n);
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j)
+            store(FloatX(m3(i, j)), mat + ((size_t) i * 3 + j) * n, n);
     return 0;
 }
 

@@ -106,6 +106,13 @@ for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
         sp[f"{tag}_{op}"] = R.unary(op, unit)
 np.savez_compressed(os.path.join(HERE, "special.npz"), **sp)
 
+# ---- Quaternion<FloatX> (include/enoki/quaternion.h), see oracle/ref_driver.cpp:ref_quaternion ------------------
+rq = np.random.default_rng(77)
+qa = rq.uniform(-1.5, 1.5, (4, 1000)).astype(np.float32); qb = rq.uniform(-1.5, 1.5, (4, 1000)).astype(np.float32)
+qt = rq.uniform(0, 1, 1000).astype(np.float32)
+qout, qmat = R.quaternion(qa, qb, qt)
+np.savez_compressed(os.path.join(HERE, "quaternion.npz"), a=qa, b=qb, t=qt, out=qout, mat=qmat)
+
 # ---- Complex<FloatX> (include/enoki/complex.h), see oracle/ref_driver.cpp:ref_complex ------------------------
 ca = uniform_pm1(2 * 2048, 401).reshape(2, 2048) * np.float32(2.5)
 cb = uniform_pm1(2 * 2048, 402).reshape(2, 2048) * np.float32(1.5)

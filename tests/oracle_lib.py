@@ -159,6 +159,14 @@ class Checker:
                                     _p(o["trace"]), _p(o["frob"]), _p(o["det"]), _p(o["inv"])), "matrix")
         return o
 
+    def quaternion(self, a, b, t):
+        """Quaternion<FloatX> script of oracle/ref_driver.cpp:ref_quaternion; a, b: (4, n), t: (n) -> (8, 4, n), (9, n)"""
+        a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32); t = np.ascontiguousarray(t, np.float32)
+        n = a.shape[1]
+        out = np.empty((8, 4, n), np.float32); mat = np.empty((9, n), np.float32)
+        self._chk(self._f("quaternion")(_p(a), _p(b), _p(t), ctypes.c_size_t(n), _p(out), _p(mat)), "quaternion")
+        return out, mat
+
     def complex(self, a, b):
         """Complex<FloatX> script of oracle/ref_driver.cpp:ref_complex; a, b: (2, n) -> (10, 2, n)"""
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)

@@ -408,7 +408,7 @@ def test_shared_index_gathers_backward_is_one_scatter_pipeline(ek):
     import json
     prof = {r["kernel"]: r for r in json.loads(ek.hip_profile_end())}
     assert prof["scatter_add_partition"]["launches"] == 1 and prof["scatter_add_count"]["launches"] == 1
-    assert prof["scatter_add_accumulate"]["launches"] == 2 and "safe_mul" not in prof
+    assert prof["scatter_add_accumulate"]["launches"] == 1 and "safe_mul" not in prof
     uu = np.where(m, A[idx] * x + B[idx], np.float32(0))
     gA = np.zeros(k, np.float64); gB = np.zeros(k, np.float64)
     np.add.at(gA, idx[m], (2 * uu * x)[m]); np.add.at(gB, idx[m], (2 * uu)[m])
@@ -486,7 +486,7 @@ def test_vector_scatter_add_is_one_binning_pass(ekc):
     ekc.scatter_add(T, V, ekc.UInt32(idx), ekc.Mask(m.astype(np.uint8)))
     prof = {r["kernel"]: r for r in json.loads(ekc.hip_profile_end())}
     assert prof["scatter_add_partition"]["launches"] == 1 and prof["scatter_add_count"]["launches"] == 1
-    assert prof["scatter_add_accumulate"]["launches"] == 3
+    assert prof["scatter_add_accumulate"]["launches"] == 1        # one launch covers the three tables (grid.y)
     for c, name in enumerate("xyz"):
         want = tgt[c].astype(np.float64); np.add.at(want, idx[m], vals[c][m])
         assert np.array_equal(getattr(T, name).numpy(), want.astype(np.float32)), name
