@@ -20,8 +20,9 @@ for _name, _mod in (("hip", hip), ("hip_autodiff", hip_autodiff), ("cuda", hip),
     _sys.modules[__name__ + "." + _name] = _mod
 
 # type aliases: <Type>C = plain device array, <Type>D = differentiable device array
-_TYPES = ["Float32", "Float64", "Int32", "UInt32", "Int64", "UInt64", "Mask", "Vector2f", "Vector3f", "Vector4f",
-          "Matrix2f", "Matrix3f", "Matrix4f", "Complex2f"]
+_TYPES = ["Float32", "Float64", "Int32", "UInt32", "Int64", "UInt64", "Mask"] + \
+         [f"Vector{n}{k}" for n in range(5) for k in "miufd"] + \
+         [f"Matrix{n}{k}" for n in (2, 3, 4) for k in "fd"] + ["Complex2f", "Complex2d", "Quaternion4f", "Quaternion4d"]
 _SHORT = {"Float32": "Float", "Mask": "Bool"}
 for _t in _TYPES:
     for _mod, _suffix in ((hip, "C"), (hip_autodiff, "D")):
