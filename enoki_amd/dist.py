@@ -137,6 +137,211 @@ class Packer:
                 self.work[i] = None
 
 
+_TORCH_OPS = {"sum": dist.ReduceOp.SUM, "prod": dist.ReduceOp.PRODUCT, "max": dist.ReduceOp.MAX, "min": dist.ReduceOp.MIN}
+
+
+def _to_tensor(value, device, dtype=None):
+    """contribution -> flat torch tensor on `device` (zero-copy for device arrays and torch tensors)"""
+    if isinstance(value, torch.Tensor):
+        t = value
+    elif hasattr(value, "__cuda_array_interface__") and torch.device(device).type == "cuda":
+        t = torch.as_tensor(value, device=device)
+    elif isinstance(value, (bool, int, float)):
+        t = torch.tensor([value], dtype=dtype or (torch.int64 if isinstance(value, (bool, int)) else torch.float32))
+    else:
+        import numpy as np
+        t = torch.from_numpy(np.ascontiguousarray(np.asarray(value)))
+    t = t.reshape(-1)
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if t.device != torch.device(device):
+        t = t.to(device)
+    return t
+
+
+class Handle:
+    """A contribution to an Exchange: after flush() `tensor()` is the REDUCED value (a view of the staging buffer, valid
+    until the buffer rotates back: `depth` flushes later)"""
+
+    def __init__(self):
+        self._slot, self._work = None, None
+
+    def tensor(self):
+        if self._slot is None:
+            raise RuntimeError("Exchange.flush() has not been called for this contribution")
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._slot
+
+    def item(self):
+        return self.tensor()[0].item()
+
+
+class Exchange:
+    """The exchange step of one backward() / one frame: every horizontal result of a sharded computation -- hsum / hprod /
+    hmin / hmax partials, mask counts, gradients of replicated tables -- is registered with `add()`, and `flush()` issues
+    ONE all-reduce per (dtype, reduction) group: for the usual "float32 loss + float32 table gradients" that is a single
+    collective per step (xGMI is point-to-point: per-collective latency, not bytes, dominates at these sizes).  The
+    collectives are asynchronous and the staging buffers rotate (`depth`), so the exchange of step i overlaps the kernels
+    of step i + 1.  flush() returns a Plan; `plan.run()` repeats the same exchange on the same source buffers, which is
+    what a replayed step graph (ek_hip_graph_*) needs: the sources keep their addresses, only their contents change."""
+
+    def __init__(self, device="cpu", depth=2):
+        self.device, self.depth = torch.device(device), depth
+        self._pending = []                 # (handle, tensor, op)
+        self._bufs = {}                    # (dtype, op, total) -> [buffers], cursor
+        self._inflight = []
+        self.collectives = 0
+
+    def add(self, value, op="sum", dtype=None):
+        if op not in _TORCH_OPS:
+            raise ValueError(f"unknown reduction '{op}'")
+        h = Handle()
+        self._pending.append((h, _to_tensor(value, self.device, dtype), op))
+        return h
+
+    def flush(self, async_op=True):
+        plan = Plan(self, self._pending, async_op)
+        self._pending = []
+        plan.run()
+        return plan
+
+    def _buffer(self, key, total, dtype):
+        entry = self._bufs.get((key, total))
+        if entry is None:
+            entry = self._bufs[(key, total)] = {"bufs": [torch.empty(total, device=self.device, dtype=dtype) for _ in range(self.depth)],
+                                                "work": [None] * self.depth, "cur": -1}
+        entry["cur"] = (entry["cur"] + 1) % self.depth
+        i = entry["cur"]
+        if entry["work"][i] is not None:          # the buffer's previous collective must have finished
+            entry["work"][i].wait()
+            entry["work"][i] = None
+        return entry, i
+
+    def wait_all(self):
+        for entry in self._bufs.values():
+            for i, w in enumerate(entry["work"]):
+                if w is not None:
+                    w.wait()
+                    entry["work"][i] = None
+
+
+class Plan:
+    def __init__(self, exchange, items, async_op):
+        self.ex, self.async_op = exchange, async_op
+        self.groups = {}
+        for h, t, op in items:
+            self.groups.setdefault((t.dtype, op), []).append((h, t))
+
+    def run(self):
+        ex = self.ex
+        for (dtype, op), parts in self.groups.items():
+            total = sum(t.numel() for _, t in parts)
+            entry, i = ex._buffer((dtype, op), total, dtype)
+            flat = entry["bufs"][i]
+            fast = False
+            if flat.is_cuda and dtype == torch.float32 and len(parts) <= 8 and all(t.is_cuda and t.is_contiguous() for _, t in parts):
+                from enoki_amd import hip as _ek
+                if _ek.hip_stream() == torch.cuda.current_stream().cuda_stream:
+                    _ek.hip_concat_f32(flat.data_ptr(), [(t.data_ptr(), t.numel()) for _, t in parts])   # one launch
+                    fast = True
+            offset = 0
+            for h, t in parts:
+                n = t.numel()
+                if not fast:
+                    flat[offset:offset + n].copy_(t, non_blocking=True)
+                h._slot = flat[offset:offset + n]
+                offset += n
+            work = None
+            if dist.is_initialized():
+                work = dist.all_reduce(flat, op=_TORCH_OPS[op], async_op=self.async_op)
+                ex.collectives += 1
+                if not self.async_op:
+                    work = None
+            entry["work"][i] = work
+            for h, _ in parts:
+                h._work = work
+
+
+class Sharded:
+    """Index-range sharding as a LIBRARY feature: rank r owns [begin, end) of every size-N array; tables and
+    scalars are replicated.  Horizontal operations on shards go through this object, which computes the local part with
+    the array module `ek` and registers it with the step's Exchange; `flush()` then finishes ALL of them with one
+    all-reduce per (dtype, reduction).  Vertical operations need nothing: they are local by construction.
+
+        sh = Sharded(ek, N)                        # rank / world from the process group (or 0 / 1)
+        x = ek.Float32(...[sh.begin:sh.end])
+        y = sh.hsum(f(x)); g = sh.gradient(table); hits = sh.count(mask)
+        sh.flush()                                 # ONE collective for y and g, one for hits (int64)
+        y.tensor(), g.tensor(), hits.item()
+    """
+
+    def __init__(self, ek, n_total, device=None, depth=2):
+        self.ek = ek
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.n_total = n_total
+        self.begin, self.end = shard_range(n_total, self.rank, self.world)
+        self.n = self.end - self.begin
+        if device is None:
+            device = "cuda" if (torch.cuda.is_available() and (not dist.is_initialized() or dist.get_backend() == "nccl")) else "cpu"
+        self.exchange = Exchange(device, depth)
+
+    def _reduce(self, name, op, x):
+        local = getattr(self.ek, name)(x)
+        try:
+            local = self.ek.detach(local)
+        except Exception:
+            pass
+        return self.exchange.add(local, op)
+
+    def hsum(self, x):
+        return self._reduce("hsum", "sum", x)
+
+    def hprod(self, x):
+        return self._reduce("hprod", "prod", x)
+
+    def hmax(self, x):
+        return self._reduce("hmax", "max", x)
+
+    def hmin(self, x):
+        return self._reduce("hmin", "min", x)
+
+    def count(self, mask):
+        return self.exchange.add(int(self.ek.count(mask)), "sum", torch.int64)
+
+    def any(self, mask):
+        return _Predicate(self.exchange.add(int(self.ek.count(mask)), "sum", torch.int64), lambda c: c > 0)
+
+    def all(self, mask, size=None):
+        """`size`: global number of entries (default: the sharded length)"""
+        return _Predicate(self.exchange.add(int(self.ek.count(mask)), "sum", torch.int64),
+                          lambda c, n=(self.n_total if size is None else size): c == n)
+
+    def gradient(self, table):
+        """gradient of a REPLICATED table: the local scatter_add result, summed over the ranks"""
+        return self.exchange.add(self.ek.gradient(table), "sum")
+
+    def reduce(self, array, op="sum"):
+        """an already computed local partial (e.g. kept from a captured step graph)"""
+        return self.exchange.add(array, op)
+
+    def flush(self, async_op=True):
+        return self.exchange.flush(async_op)
+
+    def wait_all(self):
+        self.exchange.wait_all()
+
+
+class _Predicate:
+    def __init__(self, handle, fn):
+        self.handle, self.fn = handle, fn
+
+    def item(self):
+        return bool(self.fn(self.handle.item()))
+
+
 def active():
     """True when collectives are live (a process group exists)"""
     return dist.is_initialized()

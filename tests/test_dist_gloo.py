@@ -78,3 +78,111 @@ def test_shard_range_partitions_exactly():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
             sizes = [e - b for b, e in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+WORKER_SHARDED = r'''
+import os, sys, ctypes
+import numpy as np
+sys.path.insert(0, os.environ["EK_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EK_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from enoki_amd import dist as ekd
+import oracle_lib
+from conftest import hash_u32, uniform_pm1
+
+P = oracle_lib.port()
+
+
+class HostArrays:
+    """the array module the sharding layer drives: here the CPU oracle on numpy arrays (the device modules have the same names)"""
+    hsum = staticmethod(lambda x: np.array([P.reduce("hsum", x)], x.dtype))
+    hprod = staticmethod(lambda x: np.array([P.reduce("hprod", x)], x.dtype))
+    hmax = staticmethod(lambda x: np.array([P.reduce("hmax", x)], x.dtype))
+    hmin = staticmethod(lambda x: np.array([P.reduce("hmin", x)], x.dtype))
+    count = staticmethod(lambda m: int(np.count_nonzero(m)))
+    detach = staticmethod(lambda x: x)
+    gradient = staticmethod(lambda t: t.grad)
+
+
+class Table:
+    def __init__(self, values): self.values, self.grad = values, None
+
+
+rank, local_rank, world = ekd.init("gloo")
+N, K = 200003, 4096
+sh = ekd.Sharded(HostArrays, N, device="cpu")
+assert (sh.begin, sh.end) == ekd.shard_range(N, rank, world)
+
+# ---- cfg3b: loss + two table gradients -> ONE float32 all-reduce, no explicit packing ----
+x = uniform_pm1(N, 2)[sh.begin:sh.end]
+idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)[sh.begin:sh.end]
+A, B = Table(uniform_pm1(K, 6)), Table(uniform_pm1(K, 7))
+u = P.ternary("fmadd", A.values[idx], np.ascontiguousarray(x), B.values[idx])
+_, A.grad, B.grad, _ = P.cfg3b(A.values, B.values, np.ascontiguousarray(x), np.ascontiguousarray(idx))
+y = sh.hsum(P.unary("sin", u)); gA = sh.gradient(A); gB = sh.gradient(B)
+before = sh.exchange.collectives
+plan = sh.flush()
+assert sh.exchange.collectives - before == 1, "loss and gradients must share one collective"
+res = {"y": y.tensor().numpy().copy(), "gA": gA.tensor().numpy().copy(), "gB": gB.tensor().numpy().copy()}
+plan.run()                                                  # replay on the same sources (step-graph path)
+assert np.array_equal(y.tensor().numpy(), res["y"]) and np.array_equal(gA.tensor().numpy(), res["gA"])
+
+# ---- cfg4: shard-local permutation, count / max / min / any / all -> one int64 and two float32 collectives ----
+res4 = 64
+n4 = res4 * res4
+lin = np.linspace(-1.2, 1.2, res4, dtype=np.float32)
+gx, gy = np.tile(lin, res4), np.repeat(lin, res4)
+b4, e4 = ekd.shard_range(n4, rank, world)
+rng = np.random.default_rng(100 + rank)
+perm = (rng.permutation(e4 - b4)).astype(np.uint32)         # shard-local indices
+mask = np.ones(e4 - b4, np.uint8)
+img = np.full(e4 - b4, -1.0, np.float32); hc = ctypes.c_uint64()
+p_ = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+assert P.lib.orc_cfg4(p_(np.ascontiguousarray(gx[b4:e4])), p_(np.ascontiguousarray(gy[b4:e4])), p_(perm), p_(mask), ctypes.c_size_t(e4 - b4), p_(img),
+                      ctypes.byref(hc)) == 0
+sh4 = ekd.Sharded(HostArrays, n4, device="cpu")
+hits = sh4.count(img >= 0); brightest = sh4.hmax(img); darkest = sh4.hmin(img)
+anyhit = sh4.any(img >= 0); allhit = sh4.all(img >= 0)
+before = sh4.exchange.collectives
+sh4.flush()
+assert sh4.exchange.collectives - before == 3             # int64 sum, float32 max, float32 min
+res.update(hits=np.array([hits.item()]), hmax=brightest.tensor().numpy().copy(), hmin=darkest.tensor().numpy().copy(),
+           anyhit=np.array([anyhit.item()]), allhit=np.array([allhit.item()]), local_hits=np.array([hc.value]))
+ekd.barrier()
+if rank == 0:
+    np.savez(os.environ["EK_OUT"], **res)
+dist.destroy_process_group()
+'''
+
+
+def test_library_level_sharding_cfg3b_and_cfg4(tmp_path):
+    """enoki_amd.dist.Sharded: hsum / hmax / hmin / count / any / all / gradient(table) register themselves with the step's
+    Exchange; flush() = one all-reduce per (dtype, reduction); no explicit Packer anywhere"""
+    out = tmp_path / "out.npz"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_SHARDED)
+    env = dict(os.environ, EK_ROOT=ROOT, EK_OUT=str(out), MASTER_ADDR="127.0.0.1", MASTER_PORT="29543")
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2"))
+             for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    z = np.load(out)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import ctypes
+    import oracle_lib
+    from conftest import cfg3b_truth, hash_u32, uniform_pm1
+    N, K = 200003, 4096
+    x = uniform_pm1(N, 2); idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)
+    t = cfg3b_truth(uniform_pm1(K, 6), uniform_pm1(K, 7), x, idx)
+    assert abs(float(z["y"][0]) - t["y"]) <= t["y_bound_reference"]
+    assert np.all(np.abs(z["gA"] - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(z["gB"] - t["gB"]) <= t["gB_bound"])
+    # cfg4: the unsharded image has the same multiset of shaded values (the permutation only moves pixels inside a shard)
+    P = oracle_lib.port()
+    res4 = 64; n4 = res4 * res4
+    lin = np.linspace(-1.2, 1.2, res4, dtype=np.float32)
+    gx, gy = np.tile(lin, res4), np.repeat(lin, res4)
+    img = np.full(n4, -1.0, np.float32); hc = ctypes.c_uint64()
+    p_ = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    perm = np.arange(n4, dtype=np.uint32); mask = np.ones(n4, np.uint8)
+    assert P.lib.orc_cfg4(p_(gx), p_(gy), p_(perm), p_(mask), ctypes.c_size_t(n4), p_(img), ctypes.byref(hc)) == 0
+    assert int(z["hits"][0]) == hc.value and z["hmax"][0] == img.max() and z["hmin"][0] == img.min()
+    assert bool(z["anyhit"][0]) and not bool(z["allhit"][0])

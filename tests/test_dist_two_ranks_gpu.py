@@ -39,3 +39,27 @@ def test_two_ranks_match_one(workload):
     assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2 and two["config"]["collectives_per_step"] == 1
     assert abs(one["result_y"] - two["result_y"]) <= n * 2.0 ** -23 * max(abs(one["result_y"]), 1.0) * 4
     assert two["value"] > 0 and two["scaling"] == "strong"
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs: RCCL refuses two ranks on one device")
+def test_two_gpus_rccl():
+    """the first multi-GPU box exercises the real thing: one rank per GPU, backend nccl (= RCCL over xGMI), launched the
+    way the driver launches it (torch.distributed.run)"""
+    n = 1 << 24
+    one = run_bench("cfg3b", n, 1, 29621)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29622", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--n", str(n),
+           "--no-cpu-baseline", "--no-also", "--profile-steps", "1"]
+    out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    two = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 1
+    assert abs(one["result_y"] - two["result_y"]) <= n * 2.0 ** -23 * max(abs(one["result_y"]), 1.0) * 4
