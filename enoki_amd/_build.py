@@ -156,6 +156,12 @@ def build_checkers(force=False, verbose=True):
     if force or _newer(call, [os.path.join(tcpp, "call_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "call_hip.cpp"), "-o", call,
               f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+    # sanitizer driver of the runtime's host side (profiles/asan_ubsan_allocator_r02.txt); run by hand on a GPU box
+    asan = os.path.join(tcpp, "asan_allocator.bin")
+    if force or _newer(asan, [os.path.join(tcpp, "asan_allocator.cpp"), os.path.join(CSRC, "runtime.cpp"), os.path.join(CSRC, "ek_internal.h")]):
+        _run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+              "-I/opt/rocm/include", inc, os.path.join(tcpp, "asan_allocator.cpp"), "-o", asan, "-L/opt/rocm/lib", "-lamdhip64", "-ldl",
+              "-Wl,-rpath,/opt/rocm/lib"])
     # The reference's OWN test sources compiled against this repository's headers with the device array types substituted
     # (tests/cpp/refshim): only where the reference tree exists; the binaries travel to the GPU box.
     ref_tests = "/root/reference/tests"

@@ -393,13 +393,26 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
     if (n == 0) return EK_OK;
     if (!base) return fail(EK_ERR_INVALID, "ek_hip_scatter_add(): null pointer");
     bool is_fp = type == EK_F32 || type == EK_F64;
-    if (mode == 0 && ctx().tuning.deterministic) mode = 1;
+    // the process-wide switch (ENOKI_HIP_DETERMINISTIC / tuning "deterministic") PROMOTES mode 0; an explicit mode 1 is a demand
+    const bool promoted = mode == 0 && ctx().tuning.deterministic;
+    if (promoted) mode = 1;
     if (mode == 1 && is_fp) {
         // deterministic: bit-identical to the CPU reference's element-order accumulation
-        if (!index || !mask || !value || index->ptr == nullptr || index->size != n || base_size == 0 ||
-            (index_type != EK_U32 && index_type != EK_I32) || n >= ((size_t) 1 << 32))
+        const bool sortable = index && mask && value && index->ptr != nullptr && index->size == n && base_size != 0 &&
+                              (index_type == EK_U32 || index_type == EK_I32) && n < ((size_t) 1 << 32);
+        if (!sortable && !promoted)
             return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add(): deterministic mode needs a 32-bit index ARRAY of size n "
                                             "and the target size (base_size)");
+        if (!sortable) {
+            // promoted by the global switch but not expressible as a sort (64-bit / broadcast index, unknown target size):
+            // programs that work in the default mode keep working -- this call takes the unordered path
+            if (ctx().log_level >= 1)
+                fprintf(stderr, "enoki-hip: scatter_add(): deterministic order not available for this call (needs a 32-bit "
+                                "index array and the target size); using the unordered path\n");
+            mode = 0;
+        }
+    }
+    if (mode == 1 && is_fp) {
         Arg<uint8_t> mm;
         if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add")) return rc;
 #define EK_SORTED_CALL(T, I)                                                                                          \

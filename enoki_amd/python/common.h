@@ -15,6 +15,8 @@
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
 
+#include <unordered_map>
+
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
@@ -139,8 +141,13 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
       })
       .def("data_ptr", [](Array &a) { return (uintptr_t) a.data(); }, "raw device pointer")
       .def_property_readonly("__cuda_array_interface__", [](Array &a) {
-          // consumed by torch.as_tensor(obj, device='cuda') on ROCm builds: zero-copy view
+          // consumed by torch.as_tensor(obj, device='cuda') on ROCm builds: zero-copy view.  The consumer keeps the python
+          // OBJECT alive, not the buffer: the buffer is marked as exported so that a later copy-on-write (a scatter into
+          // this array while another handle shares it) parks the old buffer instead of letting it return to the allocator
+          // under the view -- such a view goes stale, it never dangles.
           py::dict d;
+          a.data();
+          detach(a).mark_exported_();
           char typestr[4] = { '<', IsFloat ? 'f' : (IsMask ? 'b' : (std::is_unsigned_v<Scalar> ? 'u' : 'i')),
                               char('0' + sizeof(Store)), 0 };
           d["shape"] = py::make_tuple(a.size());

@@ -56,6 +56,7 @@ namespace detail {
         Deferred *deferred = nullptr;
         std::vector<HIPBuffer *> readers;      // deferred gathers whose table is THIS buffer (not owning)
         void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
+        bool exported = false;                 // an external zero-copy view (torch, __cuda_array_interface__) may exist
 
         static void unref(HIPBuffer *b) {
             if (b && --b->ref_count == 0) delete b;
@@ -616,6 +617,9 @@ template <typename Value_> struct HIPArray : ArrayTag {
                                                    any_weight ? pw : nullptr, &oi, &om, n, 0), "scatter_add_multi_");
     }
 
+    /// An external consumer received this buffer's address (see make_unique())
+    void mark_exported_() const { if (m_buf) m_buf->exported = true; }
+
     /// Same device buffer (or the same host-known scalar)?  Lets the tape recognise gathers that share an index array.
     bool same_storage_(const HIPArray &o) const {
         if (m_is_imm || o.m_is_imm) return m_is_imm && o.m_is_imm && imm_bits(m_imm) == imm_bits(o.m_imm);
@@ -806,6 +810,9 @@ template <typename Value_> struct HIPArray : ArrayTag {
         m_buf->force_readers();                // deferred gathers from this array see its contents before the write
         m_buf->drop_host_mirror();
         if (m_buf->ref_count > 1) {
+            // copy on write.  An exported buffer is parked (one reference is never given back): the external view keeps
+            // reading valid -- if from now on stale -- memory after the other handles are gone
+            if (m_buf->exported) { m_buf->exported = false; m_buf->ref_count++; }
             HIPArray r = empty_(m_buf->size);
             detail::hip_check(ek_hip_memcpy_device(r.m_buf->ptr, ptr_(), m_buf->size * sizeof(Value)), "make_unique");
             *this = std::move(r);
