@@ -55,7 +55,7 @@ DESCRIPTION["cfg5"] = ("synthetic 3-bounce path tracer inside a textured unit sp
                        "texture (K = 1 Mi), cosine-weighted bounce; loss = hsum(radiance); backward() scatter_adds the "
                        "texture gradient; 16 Mi paths per GPU; report only")
 # kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
-PMC_SYMBOL = {"gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
+PMC_SYMBOL = {"gather_pair_fmadd": "k_map_gathered<GTernary<0", "gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
               "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",
               "safe_mul": "k_map2<BinaryOp<13", "hsum": "k_reduce_stage1", "sin": "k_map1<UnaryOp<10", "exp": "k_map1<UnaryOp<12"}
 
@@ -78,7 +78,7 @@ def parse():
 def pmc_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes,
     FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/rocprof_summary.py), or None"""
-    path = os.path.join(ROOT, "profiles", "rocprof_pmc_r01.txt")
+    path = os.path.join(ROOT, "profiles", "rocprof_pmc_r02.txt")
     sym = PMC_SYMBOL.get(kernel)
     if not sym or not os.path.exists(path):
         return None
@@ -283,7 +283,7 @@ class Bench:
                 hit = hit & mask
                 image = F.full(-1.0, nr)
                 ekc.scatter(image, shade, perm, hit)
-                total = self.sh.count(hit)
+                total = self.sh.exchange.add(int(ekc.count(hit)), "sum", torch.int64)
                 self.sh.flush()
                 out["y"] = ekc.Float32(float(total.item()))
                 out["image"] = image
@@ -392,7 +392,9 @@ class Bench:
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
                         "traffic": pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else None,
-                        "traffic_source": "profiles/rocprof_pmc_r01.txt (separate rocprofv3 --pmc passes, same command)",
+                        "traffic_source": "profiles/rocprof_pmc_r02.txt (separate rocprofv3 --pmc passes, same command; 2 x FETCH_SIZE + WRITE_SIZE. "
+                                          "For the pair gather the read side is L2-miss traffic of random 8-byte lookups -- 64-byte fabric "
+                                          "requests mostly served by the Infinity Cache -- for which the x2 streaming correction is not calibrated)",
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
                                        "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload.startswith("cfg4") else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},

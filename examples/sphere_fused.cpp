@@ -59,6 +59,7 @@ int sphere_fused_device(const float *gx, const float *gy, const uint32_t *perm_,
     try {
         UInt32C perm = UInt32C::map((void *) perm_, n);
         MaskC mask = MaskC::map((void *) mask_, n);
+        vectorize_indirect_bytes(12);          // two 4-byte lookups + one 4-byte scatter per ray through gx / gy / image
         MaskC hit = vectorize(
             [gx, gy, image](auto &&perm, auto &&mask) {
                 using Vector2fP = Array<FloatP, 2>;

@@ -192,6 +192,9 @@ namespace detail {
 }
 
 namespace detail {
+    /// bytes per slice that the NEXT vectorize() call moves through pointers captured by its functor (see below)
+    inline size_t &vectorize_indirect_bytes_slot() { static thread_local size_t bytes = 0; return bytes; }
+
     template <typename Func, typename OutTable, typename ResultPacket, typename... Views>
     __global__ __launch_bounds__(256) void k_vectorize(size_t n, Func f, OutTable out, Views... views) {
         const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
@@ -248,9 +251,12 @@ auto vectorize(Func &&f, Args &&... args)
     if constexpr (!std::is_void_v<Result>) return Result();
 #else
     detail::LeafScan scan;
+    scan.bytes = 0;
     auto views = std::make_tuple(detail::make_view<Args>(std::forward<Args>(args), scan)...);
     if (!scan.ok) throw std::runtime_error("vectorize(): vector arguments have incompatible lengths");
     const size_t slice_count = scan.slices ? scan.slices : 1;
+    scan.bytes += detail::vectorize_indirect_bytes_slot() * slice_count;     // gathers / scatters inside f (declared by the caller)
+    detail::vectorize_indirect_bytes_slot() = 0;
 
     detail::hip_check(ek_hip_init(-1), "vectorize");
     hipStream_t stream = (hipStream_t) ek_hip_stream();
@@ -271,6 +277,11 @@ auto vectorize(Func &&f, Args &&... args)
     }
 #endif
 }
+
+/// Accounting only: the next vectorize() call of this thread gathers / scatters `bytes_per_slice` bytes per slice through
+/// raw pointers captured by its functor (the kernel cannot know); they are added to the algorithmic bytes that the launch
+/// reports to ek_hip_profile_* / bench.py.
+inline void vectorize_indirect_bytes(size_t bytes_per_slice) { detail::vectorize_indirect_bytes_slot() = bytes_per_slice; }
 
 template <typename Func, typename... Args> auto vectorize_safe(Func &&f, Args &&... args) {
     return vectorize<true>(std::forward<Func>(f), std::forward<Args>(args)...);
