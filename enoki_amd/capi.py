@@ -42,7 +42,7 @@ EXPORTS = [
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
-    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs",
+    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_scatter_add_multi_map",
 ]
 
 
@@ -369,6 +369,32 @@ def scatter_add_multi(targets, values, index, mask=True, weights=None, n=None, m
     check(lib.ek_hip_scatter_add_multi(targets[0].ek, index.ek, count, bases, ctypes.c_size_t(targets[0].n), vals,
                                        wts if weights is not None else None, ctypes.byref(oi), ctypes.byref(om),
                                        ctypes.c_size_t(n), mode))
+
+
+def reduce_map(op, map_op, a):
+    """op(map_op(a)) in one pass: the unary op is applied on load (ek_hip_reduce_map)"""
+    out = Buf(a.dtype, 1)
+    check(lib.ek_hip_reduce_map(REDUCE[op], UNARY[map_op], a.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(a.ptr),
+                                ctypes.c_size_t(a.n)))
+    return out
+
+
+def scatter_add_multi_map(targets, values, ops, index, mask=True, weights=None, n=None, mode=0):
+    """scatter_add_multi with unary ops[c] (name or None) applied to values[c] on load (ek_hip_scatter_add_multi_map)"""
+    count = len(targets)
+    dt = targets[0].dtype
+    n = _n(index, mask, *values) if n is None else n
+    ovs = [operand(v, dt) for v in values]
+    ows = [None if (weights is None or w is None) else operand(w, dt) for w in (weights or [None] * count)]
+    OpPtr = ctypes.POINTER(Operand)
+    bases = (ctypes.c_void_p * count)(*[t.ptr for t in targets])
+    vals = (OpPtr * count)(*[ctypes.pointer(o) for o in ovs])
+    wts = (OpPtr * count)(*[ctypes.pointer(o) if o is not None else OpPtr() for o in ows])
+    codes = (ctypes.c_int * count)(*[UNARY["copy"] if o is None else UNARY[o] for o in ops])
+    oi, om = operand(index), operand(mask, np.uint8)
+    check(lib.ek_hip_scatter_add_multi_map(targets[0].ek, index.ek, count, bases, ctypes.c_size_t(targets[0].n), vals, codes,
+                                           wts if weights is not None else None, ctypes.byref(oi), ctypes.byref(om),
+                                           ctypes.c_size_t(n), mode))
 
 
 def reduce(op, a):

@@ -147,10 +147,19 @@ template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n);
 
+// The unary ops that a consumer may apply on load (HIPArray defers exactly these: include/enoki/hip.h)
+constexpr inline bool unary_fusable(int op) {
+    switch (op) {
+        case EK_NEG: case EK_ABS: case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
+            return true;
+        default: return false;
+    }
+}
+
 bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array, size_t elem_size = 4);
 template <typename T, typename I, int C>
 int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
-                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n, const int *value_ops = nullptr);
 
 // deterministic scatter_add: stable radix sort by index + sequential per-bin sums (scatter_binned.hip)
 template <typename T, typename I>

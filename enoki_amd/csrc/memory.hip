@@ -470,7 +470,7 @@ int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, c
 namespace {
 template <typename T, typename I, int C, bool Sorted = false>
 int scatter_add_multi_fused(void *const *bases, size_t base_size, const ek_operand *const *values, const ek_operand *const *weights,
-                            const ek_operand *index, const ek_operand *mask, size_t n) {
+                            const ek_operand *index, const ek_operand *mask, size_t n, const int *ops = nullptr) {
     Arg<T> vv[C], ww[C];
     Arg<I> ii;
     Arg<uint8_t> mm;
@@ -488,7 +488,7 @@ int scatter_add_multi_fused(void *const *bases, size_t base_size, const ek_opera
     if (int rc = make_arg<I>(index, n, ii, "ek_hip_scatter_add_multi")) return rc;
     if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_scatter_add_multi")) return rc;
     if constexpr (Sorted) return scatter_add_sorted_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n);
-    else return scatter_add_binned_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n);
+    else return scatter_add_binned_multi<T, I, C>(tables, base_size, vv, ww, weighted, ii, mm, n, ops);
 }
 
 // deterministic mode: 2 or 3 streams per sort (one stream goes through ek_hip_scatter_add)
@@ -507,15 +507,17 @@ int scatter_add_multi_sorted_count(int count, void *const *bases, size_t base_si
 
 template <typename T, typename I>
 int scatter_add_multi_fused_count(int count, void *const *bases, size_t base_size, const ek_operand *const *values,
-                                  const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask, size_t n) {
+                                  const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask, size_t n,
+                                  const int *ops = nullptr) {
     switch (count) {
-        case 1: return scatter_add_multi_fused<T, I, 1>(bases, base_size, values, weights, index, mask, n);
-        case 2: return scatter_add_multi_fused<T, I, 2>(bases, base_size, values, weights, index, mask, n);
-        case 3: return scatter_add_multi_fused<T, I, 3>(bases, base_size, values, weights, index, mask, n);
+        case 1: return scatter_add_multi_fused<T, I, 1>(bases, base_size, values, weights, index, mask, n, ops);
+        case 2: return scatter_add_multi_fused<T, I, 2>(bases, base_size, values, weights, index, mask, n, ops);
+        case 3: return scatter_add_multi_fused<T, I, 3>(bases, base_size, values, weights, index, mask, n, ops);
         default: {
             // four streams would cost the partition kernel its second workgroup per CU (152 VGPRs): run 2 + 2
-            if (int rc = scatter_add_multi_fused<T, I, 2>(bases, base_size, values, weights, index, mask, n)) return rc;
-            return scatter_add_multi_fused<T, I, 2>(bases + 2, base_size, values + 2, weights ? weights + 2 : nullptr, index, mask, n);
+            if (int rc = scatter_add_multi_fused<T, I, 2>(bases, base_size, values, weights, index, mask, n, ops)) return rc;
+            return scatter_add_multi_fused<T, I, 2>(bases + 2, base_size, values + 2, weights ? weights + 2 : nullptr, index, mask, n,
+                                                    ops ? ops + 2 : nullptr);
         }
     }
 }
@@ -588,6 +590,64 @@ int ek_hip_scatter_add_multi(int type, int index_type, int count, void *const *b
         if (rc) return rc;
     }
     return EK_OK;
+}
+
+int ek_hip_scatter_add_multi_map(int type, int index_type, int count, void *const *bases, size_t base_size,
+                                 const ek_operand *const *values, const int *value_ops, const ek_operand *const *weights,
+                                 const ek_operand *index, const ek_operand *mask, size_t n, int mode) {
+    if (int rc = ensure_init()) return rc;
+    bool mapped = false;
+    if (value_ops) {
+        if (count < 1 || count > 4) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi_map(): 1 to 4 streams expected, got %d", count);
+        for (int c = 0; c < count; ++c) {
+            if (value_ops[c] == EK_COPY) continue;
+            if (!unary_fusable(value_ops[c]) || (type != EK_F32 && type != EK_F64))
+                return fail(EK_ERR_UNSUPPORTED, "ek_hip_scatter_add_multi_map(): op %d cannot be applied on load", value_ops[c]);
+            mapped = true;
+        }
+    }
+    if (!mapped) return ek_hip_scatter_add_multi(type, index_type, count, bases, base_size, values, weights, index, mask, n, mode);
+    if (!bases || !values || !index || !mask) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi_map(): null pointer");
+    for (int c = 0; c < count; ++c) {
+        if (!bases[c] || !values[c]) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi_map(): null pointer");
+        for (int d = 0; d < c; ++d)
+            if (bases[d] == bases[c]) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi_map(): the tables must be distinct");
+    }
+    if (n == 0) return EK_OK;
+    const bool deterministic = mode == 1 || (mode == 0 && ctx().tuning.deterministic);
+    const bool fused = !deterministic && ctx().tuning.scatter_add_binned && (index_type == EK_U32 || index_type == EK_I32) &&
+                       scatter_add_binned_multi_applicable(base_size, n, index->ptr != nullptr && index->size == n, type_size(type));
+    if (fused) {
+        if (type == EK_F32) {
+            if (index_type == EK_U32) return scatter_add_multi_fused_count<float, uint32_t>(count, bases, base_size, values, weights, index, mask, n, value_ops);
+            return scatter_add_multi_fused_count<float, int32_t>(count, bases, base_size, values, weights, index, mask, n, value_ops);
+        }
+        if (index_type == EK_U32) return scatter_add_multi_fused_count<double, uint32_t>(count, bases, base_size, values, weights, index, mask, n, value_ops);
+        return scatter_add_multi_fused_count<double, int32_t>(count, bases, base_size, values, weights, index, mask, n, value_ops);
+    }
+    // paths without an on-load map (deterministic mode, small tables, atomics): evaluate the mapped streams first; streams
+    // that share array and op share the temporary
+    ek_operand mapped_value[4];
+    const ek_operand *vv[4];
+    void *tmp[4] = { nullptr, nullptr, nullptr, nullptr };
+    int rc = EK_OK;
+    for (int c = 0; c < count && rc == EK_OK; ++c) {
+        vv[c] = values[c];
+        if (value_ops[c] == EK_COPY) continue;
+        int same = -1;
+        for (int d = 0; d < c; ++d)
+            if (tmp[d] && value_ops[d] == value_ops[c] && values[d]->ptr == values[c]->ptr && values[d]->size == values[c]->size) same = d;
+        if (same >= 0) { vv[c] = vv[same]; continue; }
+        const size_t m = values[c]->ptr && values[c]->size != 1 ? n : 1;
+        rc = ek_hip_malloc(m * type_size(type), &tmp[c]);
+        if (rc == EK_OK) rc = ek_hip_unary(value_ops[c], type, tmp[c], values[c], m);
+        mapped_value[c] = ek_operand{ tmp[c], 0, m };
+        vv[c] = &mapped_value[c];
+    }
+    if (rc == EK_OK) rc = ek_hip_scatter_add_multi(type, index_type, count, bases, base_size, vv, weights, index, mask, n, mode);
+    for (int c = 0; c < count; ++c)
+        if (tmp[c]) ek_hip_free(tmp[c]);
+    return rc;
 }
 
 } // extern "C"

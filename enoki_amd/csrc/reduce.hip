@@ -9,8 +9,7 @@
 // No floating point atomics: the result is deterministic for a given (n, grid), i.e. run-to-run
 // reproducible, but the summation ORDER differs from the CPU's lane-wise packet accumulation
 // (dynamic.h:632-702), so fp results agree to the order-dependent bound documented in tests/.
-#include "ek_map.h"
-#include "ek_math.h"
+#include "ek_unary.h"
 
 #include <algorithm>
 #include <limits>
@@ -119,6 +118,22 @@ template <typename T> struct SafeMulLoader {
     }
 };
 
+// A unary operation applied while loading: hsum(sin(x)) reads x once and writes nothing (HIPArray leaves the result of a
+// fusable unary op unevaluated until its first consumer, include/enoki/hip.h); same values, same reduction tree as
+// the two-kernel version.
+template <int Map, typename T> struct MapLoader {
+    const T *ptr;
+    static constexpr int N = 16 / sizeof(T), M = N;
+    __device__ __forceinline__ void init() { }
+    __device__ __forceinline__ Pack<T, N> load_pack(size_t v) const {
+        Pack<T, N> p = pack_load<T, N, true>(ptr + v * N);
+#pragma unroll
+        for (int i = 0; i < N; ++i) p.v[i] = UnaryOp<Map, T>::apply(p.v[i]);
+        return p;
+    }
+    __device__ __forceinline__ T load(size_t i) const { return UnaryOp<Map, T>::apply(ptr[i]); }
+};
+
 template <typename R, typename T, typename Loader>
 __global__ __launch_bounds__(256) void k_reduce_stage1(T *__restrict__ partials, size_t n, int vec_ok, Loader ld) {
     constexpr int N = Loader::N, M = Loader::M, U = 4;
@@ -191,6 +206,37 @@ template <typename T> int reduce_dispatch(int op, void *out, const void *in, siz
         case EK_HMIN: return reduce_typed<EK_HMIN, T>(out, in, n);
         case EK_HMAX: return reduce_typed<EK_HMAX, T>(out, in, n);
         default: return fail(EK_ERR_INVALID, "ek_hip_reduce(): unknown op %d", op);
+    }
+}
+
+template <int Op, int Map, typename T> int reduce_map_typed(void *out, const void *in, size_t n) {
+    MapLoader<Map, T> ld{ (const T *) in };
+    return reduce_launch<Reducer<Op, T>>(Op == EK_HSUM ? "hsum_map" : Op == EK_HPROD ? "hprod_map" : Op == EK_HMIN ? "hmin_map" : "hmax_map",
+                                         (T *) out, n, aligned16(in), ld, n * sizeof(T));
+}
+
+template <int Op, typename T> int reduce_map_select(int map, void *out, const void *in, size_t n) {
+    switch (map) {
+        case EK_NEG: return reduce_map_typed<Op, EK_NEG, T>(out, in, n);
+        case EK_ABS: return reduce_map_typed<Op, EK_ABS, T>(out, in, n);
+        case EK_SQRT: return reduce_map_typed<Op, EK_SQRT, T>(out, in, n);
+        case EK_RCP: return reduce_map_typed<Op, EK_RCP, T>(out, in, n);
+        case EK_RSQRT: return reduce_map_typed<Op, EK_RSQRT, T>(out, in, n);
+        case EK_SIN: return reduce_map_typed<Op, EK_SIN, T>(out, in, n);
+        case EK_COS: return reduce_map_typed<Op, EK_COS, T>(out, in, n);
+        case EK_EXP: return reduce_map_typed<Op, EK_EXP, T>(out, in, n);
+        case EK_LOG: return reduce_map_typed<Op, EK_LOG, T>(out, in, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): op %d cannot be applied on load", map);
+    }
+}
+
+template <typename T> int reduce_map_dispatch(int op, int map, void *out, const void *in, size_t n) {
+    switch (op) {
+        case EK_HSUM: return reduce_map_select<EK_HSUM, T>(map, out, in, n);
+        case EK_HPROD: return reduce_map_select<EK_HPROD, T>(map, out, in, n);
+        case EK_HMIN: return reduce_map_select<EK_HMIN, T>(map, out, in, n);
+        case EK_HMAX: return reduce_map_select<EK_HMAX, T>(map, out, in, n);
+        default: return fail(EK_ERR_INVALID, "ek_hip_reduce_map(): unknown op %d", op);
     }
 }
 
@@ -310,6 +356,18 @@ int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n) {
         case EK_F32: return reduce_dispatch<float>(op, out, in, n);
         case EK_F64: return reduce_dispatch<double>(op, out, in, n);
         default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce(): unsupported type %d", type);
+    }
+}
+
+int ek_hip_reduce_map(int op, int map_op, int type, void *out, const void *in, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (!out || !in) return fail(EK_ERR_INVALID, "ek_hip_reduce_map(): null pointer");
+    if (n == 0) return fail(EK_ERR_INVALID, "ek_hip_reduce_map(): empty input");
+    if (!unary_fusable(map_op)) return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): op %d cannot be applied on load", map_op);
+    switch (type) {
+        case EK_F32: return reduce_map_dispatch<float>(op, map_op, out, in, n);
+        case EK_F64: return reduce_map_dispatch<double>(op, map_op, out, in, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): floating point types only");
     }
 }
 

@@ -19,8 +19,7 @@
 // = 24 B/elt of streaming traffic and no global atomics.  Tables of <= 16 Ki bins skip steps 1-3.
 // The result is the same set of additions as the atomic version in a different (unspecified) order
 // -- parity class D, like the reference's own GPU path.
-#include "ek_map.h"
-#include "ek_math.h"
+#include "ek_unary.h"
 
 #include <algorithm>
 #include <vector>
@@ -118,6 +117,7 @@ template <typename T, int C> struct BinStreams {
     Arg<T> weight[C];
     T *pair_val[C];
     unsigned weighted;
+    int value_op[C];      // fusable unary op applied to value[c] on load (EK_COPY: none); partition kernels with Mapped = true only
 };
 
 // ---- 1. count ------------------------------------------------------------------------------------
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__restrict__
 }
 
 // ---- 3. partition ----------------------------------------------------------------------------------
-template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t, int C = 1>
+template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t, int C = 1, bool Mapped = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_bin_partition(OutIdx *__restrict__ pair_idx, BinStreams<T, C> st,
                                                             const uint32_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ bucket_base,
@@ -263,10 +263,20 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     // is not loaded a second time.
     auto load_stream = [&](auto full, int c, size_t base, T (&val)[kPerThread]) {
         constexpr bool Full = decltype(full)::value;
-        const bool reuse = c > 0 && st.value[c].vec && st.value[c].ptr == st.value[c > 0 ? c - 1 : 0].ptr &&
-                           !((st.weighted >> (c > 0 ? c - 1 : 0)) & 1u);
-        if (!reuse)                        // `val` still holds the values of stream c - 1
+        bool reuse = c > 0 && st.value[c].vec && st.value[c].ptr == st.value[c > 0 ? c - 1 : 0].ptr &&
+                     !((st.weighted >> (c > 0 ? c - 1 : 0)) & 1u);
+        if constexpr (Mapped) reuse = reuse && st.value_op[c] == st.value_op[c > 0 ? c - 1 : 0];
+        if (!reuse) {                      // otherwise `val` still holds the (mapped) values of stream c - 1
             load_tile_operand<Full>(st.value[c], sv[c], base, end, vec_ok, val);
+            if constexpr (Mapped && std::is_floating_point_v<T>) {
+                // the producer of this stream was left unevaluated (HIPArray defers fusable unary ops): apply it here
+                const int op = st.value_op[c];
+                if (op != EK_COPY) {
+#pragma unroll
+                    for (int k = 0; k < kPerThread; ++k) val[k] = unary_fused<T>(op, val[k]);
+                }
+            }
+        }
         if ((st.weighted >> c) & 1u) {
             T w[kPerThread];
             load_tile_operand<Full>(st.weight[c], sw[c], base, end, vec_ok, w);
@@ -668,7 +678,7 @@ int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, co
                              size_t n);
 template <typename T, typename I, int C>
 int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
-                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n);
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n, const int *value_ops);
 
 template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
@@ -723,7 +733,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
 // scan, one partition pass that reads the indices once; accumulate + fold per stream.
 template <typename T, typename I, int C>
 int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *values, const Arg<T> *weights, unsigned weighted,
-                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n) {
+                             const Arg<I> &index, const Arg<uint8_t> &mask, size_t n, const int *value_ops) {
     RoctxRange range("enoki-hip: scatter_add (LDS-binned)");
     Context &c = ctx();
     constexpr int Bins = bins_of<T>, Shift = bin_shift_of<T>;
@@ -742,11 +752,15 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
     size_t stream_bytes = 0;
     BinStreams<T, C> st;
     st.weighted = weighted;
+    bool mapped = false;
     for (int s = 0; s < C; ++s) {
         st.value[s] = values[s];
         st.weight[s] = weights[s];
+        st.value_op[s] = value_ops ? value_ops[s] : (int) EK_COPY;
+        mapped = mapped || st.value_op[s] != EK_COPY;
         vec_ok = vec_ok && arg_aligned(values[s]) && (!((weighted >> s) & 1u) || arg_aligned(weights[s]));
-        const bool reused = s > 0 && values[s].vec && values[s].ptr == values[s - 1].ptr && !((weighted >> (s - 1)) & 1u);
+        const bool reused = s > 0 && values[s].vec && values[s].ptr == values[s - 1].ptr && !((weighted >> (s - 1)) & 1u) &&
+                            st.value_op[s] == st.value_op[s - 1];
         stream_bytes += (reused ? 0 : arg_bytes(values[s], n)) + (((weighted >> s) & 1u) ? arg_bytes(weights[s], n) : 0);
     }
     int rep_shift = 0;
@@ -772,9 +786,18 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
     hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, piece_prefix,
                        (const uint32_t *) row_total, n_buckets, target_pieces);
     EK_LAUNCH_CHECK("scatter_add_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
-    hipLaunchKernelGGL((k_bin_partition<T, I, Shift, uint16_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream,
-                       (uint16_t *) pairs_idx.ptr, st, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, index.ptr,
-                       mask, n, chunk, n_buckets, 0, vec_ok);
+    if constexpr (std::is_floating_point_v<T>) {
+        if (mapped)
+            hipLaunchKernelGGL((k_bin_partition<T, I, Shift, uint16_t, C, true>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                               (uint16_t *) pairs_idx.ptr, st, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base,
+                               index.ptr, mask, n, chunk, n_buckets, 0, vec_ok);
+    } else if (mapped) {
+        return fail(EK_ERR_UNSUPPORTED, "scatter_add_binned_multi(): mapped value streams need a floating point type");
+    }
+    if (!mapped)
+        hipLaunchKernelGGL((k_bin_partition<T, I, Shift, uint16_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                           (uint16_t *) pairs_idx.ptr, st, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base,
+                           index.ptr, mask, n, chunk, n_buckets, 0, vec_ok);
     EK_LAUNCH_CHECK("scatter_add_partition", n, stream_bytes + arg_bytes(index, n) + arg_bytes(mask, n) +
                                                 n * (sizeof(uint16_t) + C * sizeof(T)));
 
@@ -894,11 +917,11 @@ bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index
 #define EK_BINNED_INSTANCE(T, I)                                                                                      \
     template int scatter_add_binned<T, I>(T *, size_t, const Arg<T> &, const Arg<I> &, const Arg<uint8_t> &, size_t);  \
     template int scatter_add_binned_multi<T, I, 1>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
-                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);                     \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t, const int *);        \
     template int scatter_add_binned_multi<T, I, 2>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
-                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);                     \
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t, const int *);        \
     template int scatter_add_binned_multi<T, I, 3>(T *const *, size_t, const Arg<T> *, const Arg<T> *, unsigned,       \
-                                                   const Arg<I> &, const Arg<uint8_t> &, size_t);
+                                                   const Arg<I> &, const Arg<uint8_t> &, size_t, const int *);
 EK_BINNED_INSTANCE(float, uint32_t) EK_BINNED_INSTANCE(float, int32_t)
 EK_BINNED_INSTANCE(uint32_t, uint32_t) EK_BINNED_INSTANCE(uint32_t, int32_t)
 EK_BINNED_INSTANCE(double, uint32_t) EK_BINNED_INSTANCE(double, int32_t)

@@ -47,14 +47,23 @@ namespace detail {
         uint32_t ref_count = 1;
         bool owned = true;        // false for map()ped memory that the caller keeps
 
+        ///
+        /// The same mechanism carries *deferred unary maps* (kind 1): `op(source)` for the ops a streaming consumer can
+        /// apply while it loads (neg, abs, sqrt, rcp, rsqrt, sin, cos, exp, log).  Horizontal reductions and the value
+        /// streams of scatter_add consume them in place (ek_hip_reduce_map, ek_hip_scatter_add_multi_map):
+        /// `hsum(sin(u))` reads u once and writes nothing, and the cos(u) that `backward()` needs as the derivative is
+        /// evaluated inside the adjoint scatter_add of the gathers that produced u.  Any other access runs the plain
+        /// kernel -- for the two halves of a sincos() ONE kernel that fills both, as before.
         struct Deferred {
-            HIPBuffer *table, *index, *mask;   // references held; mask == nullptr: every lane is active
-            int type, index_type;
+            HIPBuffer *table, *index, *mask;   // references held; mask == nullptr: every lane is active.  Map: table = source
+            int type, index_type;              // map: index_type holds the unary op
             size_t elem_size;
-            bool consumed;                     // a fused consumer has read it once: the next access materialises
+            bool consumed;                     // a fused consumer has read it once: the next access materialises (gathers)
+            int kind = 0;                      // 0: gather, 1: unary map
+            HIPBuffer *partner = nullptr;      // map: the other half of an unevaluated sincos pair (not owning)
         };
         Deferred *deferred = nullptr;
-        std::vector<HIPBuffer *> readers;      // deferred gathers whose table is THIS buffer (not owning)
+        std::vector<HIPBuffer *> readers;      // deferred nodes whose table / source is THIS buffer (not owning)
         void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
         bool exported = false;                 // an external zero-copy view (torch, __cuda_array_interface__) may exist
 
@@ -72,9 +81,41 @@ namespace detail {
             return g;
         }
 
-        /// Execute the deferred gather
+        /// Execute a deferred unary map; a sincos pair is evaluated by one kernel
+        void force_map() {
+            Deferred *d = deferred;
+            const size_t bytes = (size ? size : 1) * d->elem_size;
+            ek_operand src{ d->table->ptr, 0, d->table->size };
+            HIPBuffer *other = d->partner && d->partner->deferred ? d->partner : nullptr;
+            void *p = nullptr, *q = nullptr;
+            hip_check(ek_hip_malloc(bytes, &p), "HIPArray (deferred map)");
+            int rc;
+            if (other) {
+                rc = ek_hip_malloc(bytes, &q);
+                if (rc == EK_OK) {
+                    const bool is_sin = d->index_type == EK_SIN;
+                    rc = ek_hip_sincos(d->type, is_sin ? p : q, is_sin ? q : p, &src, size);
+                }
+            } else {
+                rc = ek_hip_unary(d->index_type, d->type, p, &src, size);
+            }
+            if (rc != EK_OK) {
+                ek_hip_free(p);
+                if (q) ek_hip_free(q);
+                hip_raise("HIPArray (deferred map)");
+            }
+            ptr = p;
+            if (other) {
+                other->ptr = q;
+                other->drop_deferred();
+            }
+            drop_deferred();
+        }
+
+        /// Execute the deferred gather / map
         void force() {
             if (!deferred) return;
+            if (deferred->kind == 1) { force_map(); return; }
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (deferred gather)");
             ek_gathered g = gathered();
@@ -95,6 +136,7 @@ namespace detail {
         void drop_deferred() {
             Deferred *d = deferred;
             deferred = nullptr;
+            if (d->partner && d->partner->deferred) d->partner->deferred->partner = nullptr;
             auto &r = d->table->readers;
             for (size_t i = 0; i < r.size(); ++i)
                 if (r[i] == this) { r[i] = r.back(); r.pop_back(); break; }
@@ -345,6 +387,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// Both results from one pass over the input
     std::pair<HIPArray, HIPArray> sincos_() const {
         require_valid("sincos_");
+        if constexpr (IsFloat) {
+            if (can_defer_map_()) {
+                // both halves unevaluated and linked: whichever is materialised first fills both with ONE sincos kernel;
+                // a half that is only ever consumed on load (hsum(sin(x)), the cos(x) of the adjoint) is never written
+                HIPArray s = defer_map_(EK_SIN), c = defer_map_(EK_COS);
+                s.m_buf->deferred->partner = c.m_buf;
+                c.m_buf->deferred->partner = s.m_buf;
+                return { std::move(s), std::move(c) };
+            }
+        }
         size_t n = size();
         HIPArray s = empty_(n), c = empty_(n);
         ek_operand oa = operand();
@@ -531,7 +583,31 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return r;
     }
 
-    bool deferred_() const { return m_buf && m_buf->deferred && !m_buf->deferred->consumed; }
+    bool deferred_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 0 && !m_buf->deferred->consumed; }
+    /// An unevaluated unary map (see detail::HIPBuffer)
+    bool mapped_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 1; }
+
+    /// Unary ops whose result is left unevaluated until its first consumer: the ones ek_hip_reduce_map /
+    /// ek_hip_scatter_add_multi_map can apply on load.  Small arrays are evaluated right away (nothing to win).
+    static constexpr size_t defer_map_min_size_ = (size_t) 1 << 16;
+    static constexpr bool map_fusable_(int op) {
+        return op == EK_NEG || op == EK_ABS || op == EK_SQRT || op == EK_RCP || op == EK_RSQRT || op == EK_SIN ||
+               op == EK_COS || op == EK_EXP || op == EK_LOG;
+    }
+    bool can_defer_map_() const {
+        return IsFloat && detail::hip_defer_gather_flag() && !m_is_imm && m_buf && m_buf->owned && m_buf->size >= defer_map_min_size_;
+    }
+    HIPArray defer_map_(int op) const {
+        ptr_();                                              // a source that is itself deferred runs first
+        auto *d = new typename detail::HIPBuffer::Deferred{ m_buf, nullptr, nullptr, Type, op, sizeof(Value), false, 1, nullptr };
+        m_buf->ref_count++;
+        HIPArray r;
+        r.m_buf = new detail::HIPBuffer();
+        r.m_buf->size = m_buf->size;
+        r.m_buf->deferred = d;
+        m_buf->readers.push_back(r.m_buf);
+        return r;
+    }
 
     static constexpr size_t gather_multi_small_ = (size_t) 3 << 20, gather_multi_large_ = (size_t) 128 << 20;
 
@@ -593,13 +669,30 @@ template <typename Value_> struct HIPArray : ArrayTag {
         void *bases[kMax];
         ek_operand ov[kMax], ow[kMax];
         const ek_operand *pv[kMax], *pw[kMax];
-        bool any_weight = false;
+        int ops[kMax];
+        bool any_weight = false, any_map = false;
         for (size_t c = 0; c < count; ++c) {
             values[c]->require_valid("scatter_add_multi_");
             if (targets[c]->size() != targets[0]->size())
                 throw std::runtime_error("HIPArray::scatter_add_multi_(): the targets must have the same size");
             n = broadcast_size(n, values[c]->size());
-            ov[c] = values[c]->operand();
+            ops[c] = EK_COPY;
+            bool in_place = false;
+            if constexpr (IsFloat) {
+                // an unevaluated unary result (the cos(u) of d/du sin(u), ...) is applied while the stream is loaded --
+                // unless a target is its own source buffer
+                if (values[c]->mapped_()) {
+                    const auto *d = values[c]->m_buf->deferred;
+                    in_place = true;
+                    for (size_t t = 0; t < count; ++t) in_place = in_place && targets[t]->m_buf != d->table;
+                    if (in_place) {
+                        ov[c] = ek_operand{ d->table->ptr, 0, d->table->size };
+                        ops[c] = d->index_type;
+                        any_map = true;
+                    }
+                }
+            }
+            if (!in_place) ov[c] = values[c]->operand();
             pv[c] = &ov[c];
             pw[c] = nullptr;
             if (weights && weights[c]) {
@@ -613,8 +706,12 @@ template <typename Value_> struct HIPArray : ArrayTag {
             bases[c] = targets[c]->data();
         }
         ek_operand oi = index.operand(), om = mask.operand();
-        detail::hip_check(ek_hip_scatter_add_multi(Type, Index::Type, (int) count, bases, targets[0]->size(), pv,
-                                                   any_weight ? pw : nullptr, &oi, &om, n, 0), "scatter_add_multi_");
+        if (any_map)
+            detail::hip_check(ek_hip_scatter_add_multi_map(Type, Index::Type, (int) count, bases, targets[0]->size(), pv, ops,
+                                                           any_weight ? pw : nullptr, &oi, &om, n, 0), "scatter_add_multi_");
+        else
+            detail::hip_check(ek_hip_scatter_add_multi(Type, Index::Type, (int) count, bases, targets[0]->size(), pv,
+                                                       any_weight ? pw : nullptr, &oi, &om, n, 0), "scatter_add_multi_");
     }
 
     /// An external consumer received this buffer's address (see make_unique())
@@ -868,6 +965,9 @@ private:
                 else return HIPArray((Value) (std::make_unsigned_t<Value>(0) - (std::make_unsigned_t<Value>) m_imm));
             }
         }
+        if constexpr (IsFloat) {
+            if (map_fusable_(op) && can_defer_map_()) return defer_map_(op);
+        }
         size_t n = size();
         HIPArray r = empty_(n);
         ek_operand oa = operand();
@@ -875,7 +975,7 @@ private:
         return r;
     }
 
-    /// Device pointer of a valid buffer; a deferred gather is executed first
+    /// Device pointer of a valid buffer; a deferred gather / map is executed first
     void *ptr_() const {
         if (m_buf->deferred) m_buf->force();
         return m_buf->ptr;
@@ -965,6 +1065,13 @@ private:
         size_t n = size();
         if (n == 1) return *this;
         HIPArray r = empty_(1);
+        if constexpr (IsFloat) {
+            if (mapped_()) {
+                const auto *d = m_buf->deferred;
+                detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, d->table->ptr, n), what);
+                return r;
+            }
+        }
         detail::hip_check(ek_hip_reduce(op, Type, r.m_buf->ptr, m_buf ? ptr_() : nullptr, n), what);
         return r;
     }

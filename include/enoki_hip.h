@@ -230,11 +230,28 @@ EK_API int ek_hip_scatter_add_multi(int type, int index_type, int count, void *c
                                     const ek_operand *const *values, const ek_operand *const *weights,
                                     const ek_operand *index, const ek_operand *mask, size_t n, int mode);
 
+/* ek_hip_scatter_add_multi with a unary operation applied to value stream c while it is loaded:
+ *     bases[c][index[i]] += w_c[i] * map_c(values[c][i]),   map_c = value_ops[c]  (EK_COPY: none; value_ops == NULL: none)
+ * Ops as for ek_hip_reduce_map, floating point types.  This is the adjoint of `gather` when the incoming gradient is
+ * itself an unevaluated unary result -- the cos(u) of d/du sin(u) in `hsum(sin(gather(A, i) * x + gather(B, i)))` --
+ * so the derivative array is never written or re-read (HIPArray defers fusable unary ops until their first consumer).
+ * Paths without an on-load map (deterministic mode, tables of <= 16 Ki bins, 64-bit indices) evaluate the op first. */
+EK_API int ek_hip_scatter_add_multi_map(int type, int index_type, int count, void *const *bases, size_t base_size,
+                                        const ek_operand *const *values, const int *value_ops,
+                                        const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask,
+                                        size_t n, int mode);
+
 /* ---------------------------------------------------------------------------------------------
  *  Horizontal ops.  Results of ek_hip_reduce* stay on the device (`out` = 1 element, async);
  *  mask reductions return to the host and therefore synchronize (cuda.h:761-794).
  * ------------------------------------------------------------------------------------------- */
 EK_API int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n);
+/* op(map_op(in[0..n))) in ONE pass over `in`: the unary operation is applied while loading (hsum(sin(x)): 4 B/element
+ * instead of 12).  map_op: EK_NEG, EK_ABS, EK_SQRT, EK_RCP, EK_RSQRT, EK_SIN, EK_COS, EK_EXP, EK_LOG; floating point
+ * types; n >= 1.  Same element values and the same reduction tree as ek_hip_unary followed by ek_hip_reduce (bit-identical
+ * results).  The reference reaches this through its trace: `hsum(sin(x))` is one PTX kernel + the CUB reduction
+ * (jit.cu:560-760, horiz.cu:162-268); HIPArray defers fusable unary ops until their first consumer. */
+EK_API int ek_hip_reduce_map(int op, int map_op, int type, void *out, const void *in, size_t n);
 /* fused backward edge to a scalar source: out[0] = hsum(safe_mul(w, g))  (autodiff.cpp:867-871) */
 EK_API int ek_hip_hsum_safe_mul(int type, void *out, const ek_operand *w, const ek_operand *g, size_t n);
 EK_API int ek_hip_mask_reduce(int op, const uint8_t *mask, size_t n, uint64_t *host_result);

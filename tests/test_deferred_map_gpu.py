@@ -1,0 +1,198 @@
+"""Unary operations applied on load (ek_hip_reduce_map, ek_hip_scatter_add_multi_map) and the deferred unary results of
+HIPArray that feed them.  The map is the SAME device function as the stand-alone kernel and the reductions keep their
+tree, so every result here is bit-identical to "evaluate, then consume" (class A relative to the unfused path)."""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, f32_inputs, f64_inputs
+
+pytestmark = pytest.mark.gpu
+
+MAP_OPS = ["neg", "abs", "sqrt", "rcp", "rsqrt", "sin", "cos", "exp", "log"]
+SIZES = [1, 5, 255, 1024, 4099, 100003, (1 << 20) + 7]
+
+
+def up(capi, a):
+    return capi.Buf.from_numpy(a)
+
+
+def _inputs(dtype, n, seed, op):
+    gen = f32_inputs if dtype == np.float32 else f64_inputs
+    x = gen(n, seed=seed).astype(dtype)
+    if op in ("sqrt", "rsqrt", "log"):
+        x = np.abs(x) + dtype(1e-3)
+    if op == "exp":
+        x = np.clip(x, -20, 20).astype(dtype)
+    return x
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("op", MAP_OPS)
+def test_reduce_map_equals_unary_then_reduce(capi, dtype, op):
+    for n in SIZES:
+        x = _inputs(dtype, n, n + 11, op)
+        dx = up(capi, x)
+        mapped = capi.unary(op, dx)
+        for red in ("hsum", "hmax", "hmin", "hprod"):
+            if red == "hprod" and n > 5000:
+                continue
+            ref = capi.reduce(red, mapped)
+            got = capi.reduce_map(red, op, dx)
+            assert bits_equal(got.numpy(), ref.numpy()), (op, red, n)
+
+
+def test_reduce_map_rejects_unfusable(capi):
+    dx = up(capi, np.ones(100, np.float32))
+    with pytest.raises(Exception):
+        capi.reduce_map("hsum", "tanh", dx)
+    with pytest.raises(Exception):
+        capi.reduce_map("hsum", "sin", up(capi, np.ones(100, np.uint32)))
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_scatter_add_multi_map(capi, dtype):
+    """value streams mapped on load == streams evaluated first; every path: LDS-binned (large), small table (direct),
+    deterministic (mode 1: bit-exact in element order)"""
+    rng = np.random.default_rng(3)
+    for n, K in ((200003, 1 << 17), (1 << 20, 1 << 18), (50000, 1000), (70000, 1 << 17)):
+        u = (rng.standard_normal(n) * 3).astype(dtype)       # finite values: the unordered sums are compared by bound
+        w = rng.standard_normal(n).astype(dtype)
+        idx = rng.integers(0, K, n).astype(np.uint32)
+        du, dw, di = up(capi, u), up(capi, w), up(capi, idx)
+        c = capi.unary("cos", du)
+        for mode in (1, 0):
+            ref = [up(capi, np.zeros(K, dtype)) for _ in range(2)]
+            got = [up(capi, np.zeros(K, dtype)) for _ in range(2)]
+            capi.scatter_add_multi(ref, [c, c], di, weights=[dw, None], mode=mode)
+            capi.scatter_add_multi_map(got, [du, du], ["cos", "cos"], di, weights=[dw, None], mode=mode)
+            for r, g in zip(ref, got):
+                if mode == 1:
+                    assert bits_equal(g.numpy(), r.numpy()), (n, K)
+                else:                                  # unordered accumulation on both sides: same addends
+                    cnt = np.bincount(idx, minlength=K) + 1
+                    assert np.all(np.abs(g.numpy().astype(np.float64) - r.numpy()) <= cnt * cnt * np.finfo(dtype).eps), (n, K)
+        # different ops per stream, one stream unmapped, three streams
+        s = capi.unary("sin", du)
+        ref = [up(capi, np.zeros(K, dtype)) for _ in range(3)]
+        got = [up(capi, np.zeros(K, dtype)) for _ in range(3)]
+        capi.scatter_add_multi(ref, [s, dw, c], di, weights=[None, None, dw], mode=1)
+        capi.scatter_add_multi_map(got, [du, dw, du], ["sin", None, "cos"], di, weights=[None, None, dw], mode=1)
+        for r, g in zip(ref, got):
+            assert bits_equal(g.numpy(), r.numpy())
+
+
+def test_scatter_add_multi_map_integer_counts(capi):
+    """the binned path itself (mode 0) with a mapped stream: exp(0) = 1 per element -> exact counts"""
+    rng = np.random.default_rng(9)
+    n, K = 1 << 21, 1 << 18
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    dz, di = up(capi, np.zeros(n, np.float32)), up(capi, idx)
+    t0, t1 = up(capi, np.zeros(K, np.float32)), up(capi, np.zeros(K, np.float32))
+    capi.scatter_add_multi_map([t0, t1], [dz, dz], ["exp", "cos"], di)
+    cnt = np.bincount(idx, minlength=K).astype(np.float32)
+    assert np.array_equal(t0.numpy(), cnt) and np.array_equal(t1.numpy(), cnt)
+
+
+# ----------------------------------------------------------------------------------------------
+#  HIPArray level: deferred unary results keep value semantics
+# ----------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def ek():
+    import enoki_amd.hip as m
+    m.hip_init(0)
+    return m
+
+
+def test_deferred_map_semantics(ek):
+    n = 300000
+    x = f32_inputs(n, seed=21)
+    dx = ek.Float32(x)
+    eager = {}
+    ek.hip_set_defer_gather(False)
+    try:
+        eager["sin"] = ek.sin(dx).numpy(); eager["hsum_sin"] = ek.hsum(ek.sin(dx)).numpy()
+        s0, c0 = ek.sincos(dx); eager["cos"] = c0.numpy()
+        eager["hmax_abs"] = ek.hmax(ek.abs(dx)).numpy()
+    finally:
+        ek.hip_set_defer_gather(True)
+
+    # consumed by a reduction: one pass, nothing materialised
+    l0 = ek.hip_launch_count()
+    y = ek.hsum(ek.sin(dx))
+    assert ek.hip_launch_count() - l0 == 2                     # reduce stage 1 + 2; no sin kernel
+    assert bits_equal(y.numpy(), eager["hsum_sin"])
+    assert bits_equal(ek.hmax(ek.abs(dx)).numpy(), eager["hmax_abs"])
+    # looked at directly: an ordinary array
+    s = ek.sin(dx)
+    assert bits_equal(s.numpy(), eager["sin"])
+    # consumed by an elementwise op: materialised first, same bits
+    s = ek.sin(dx)
+    assert bits_equal((s + dx).numpy(), eager["sin"] + x)
+    # reduced AND used afterwards
+    s = ek.sin(dx)
+    y = ek.hsum(s)
+    assert bits_equal(y.numpy(), eager["hsum_sin"]) and bits_equal(s.numpy(), eager["sin"])
+    # the source changes after the op: the result must not
+    T = ek.Float32(x)
+    s = ek.sin(T)
+    ek.scatter(T, ek.Float32(np.zeros(n, np.float32)), ek.UInt32.arange(n))
+    assert bits_equal(s.numpy(), eager["sin"]) and np.all(T.numpy() == 0)
+    # the source goes away
+    s = ek.sin(ek.Float32(x))
+    assert bits_equal(ek.hsum(s).numpy(), eager["hsum_sin"]) and bits_equal(s.numpy(), eager["sin"])
+    # sincos: one kernel fills both halves whichever is touched first
+    l0 = ek.hip_launch_count()
+    s, c = ek.sincos(dx)
+    assert ek.hip_launch_count() - l0 == 0
+    assert bits_equal(c.numpy(), eager["cos"])
+    assert ek.hip_launch_count() - l0 == 1
+    assert bits_equal(s.numpy(), eager["sin"])
+    assert ek.hip_launch_count() - l0 == 1
+    # one half reduced on load, the other evaluated on its own
+    s, c = ek.sincos(dx)
+    assert bits_equal(ek.hsum(s).numpy(), eager["hsum_sin"])
+    assert bits_equal(c.numpy(), eager["cos"]) and bits_equal(s.numpy(), eager["sin"])
+    # one half dropped before the other is evaluated
+    s, c = ek.sincos(dx)
+    del s
+    assert bits_equal(c.numpy(), eager["cos"])
+    # small arrays are evaluated right away
+    l0 = ek.hip_launch_count()
+    t = ek.sin(ek.Float32(x[:1000]))
+    assert ek.hip_launch_count() - l0 >= 1
+
+
+def test_deferred_map_in_backward(ek):
+    """y = hsum(sin(A[i] * x + B[i])); backward(): cos(u) is applied inside the adjoint scatter_add -- same gradients as with
+    deferred evaluation switched off (both sides accumulate unordered: per-bin bound)"""
+    import enoki_amd.hip_autodiff as ad
+    ad.hip_init(0)
+    rng = np.random.default_rng(17)
+    n, K = 1 << 20, 1 << 17
+    A = rng.standard_normal(K).astype(np.float32); B = rng.standard_normal(K).astype(np.float32)
+    x = rng.standard_normal(n).astype(np.float32); idx = rng.integers(0, K, n).astype(np.uint32)
+
+    def run():
+        dA, dB = ad.Float32(A), ad.Float32(B)
+        ad.set_requires_gradient(dA); ad.set_requires_gradient(dB)
+        di = ad.UInt32(idx)
+        l0 = ad.hip_launch_count()
+        y = ad.hsum(ad.sin(ad.fmadd(ad.gather(dA, di), ad.Float32(x), ad.gather(dB, di))))
+        ad.backward(y)
+        launches = ad.hip_launch_count() - l0
+        return ad.detach(y).numpy(), ad.gradient(dA).numpy(), ad.gradient(dB).numpy(), launches
+
+    y1, ga1, gb1, l1 = run()
+    ad.hip_set_defer_gather(False)
+    try:
+        y0, ga0, gb0, l0 = run()
+    finally:
+        ad.hip_set_defer_gather(True)
+    assert l1 < l0
+    u = A[idx].astype(np.float64) * x + B[idx]
+    cnt = np.bincount(idx, minlength=K) + 1
+    assert abs(float(y1[0]) - np.sin(u).sum()) <= n * 2.0 ** -23 * 30
+    assert np.all(np.abs(ga1.astype(np.float64) - ga0) <= cnt * cnt * 2.0 ** -22 * 4)
+    assert np.all(np.abs(gb1.astype(np.float64) - gb0) <= cnt * cnt * 2.0 ** -22)
+    gb = np.bincount(idx, weights=np.cos(u), minlength=K)
+    assert np.all(np.abs(gb1 - gb) <= cnt * cnt * 2.0 ** -22)
