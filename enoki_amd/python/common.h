@@ -671,6 +671,8 @@ inline void bind_runtime(py::module_ &m) {
     m.def("hip_graph_destroy", [](uintptr_t g) { detail::hip_check(ek_hip_graph_destroy((ek_hip_graph *) g), "hip_graph_destroy"); });
     m.def("hip_set_defer_gather", [](bool v) { hip_set_defer_gather(v); },
           "large gathers from small tables stay deferred until consumed (fused into the consuming add/sub/mul/fma)");
+    m.def("hip_set_defer", [](bool v) { hip_set_defer(v); }, "deferred evaluation of gathers and fusable unary ops on / off");
+    m.def("hip_defer", []() { return hip_defer(); });
     m.def("hip_defer_gather", []() { return hip_defer_gather(); });
     m.def("hip_profile_begin", []() { detail::hip_check(ek_hip_profile_begin(), "hip_profile_begin"); });
     m.def("hip_profile_end", []() {

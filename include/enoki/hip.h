@@ -157,11 +157,12 @@ namespace detail {
         }
     };
 
-    /// Deferred gathers can be switched off (ENOKI_HIP_DEFER_GATHER=0, or hip_set_defer_gather(false))
+    /// Deferred evaluation (gathers and unary maps) can be switched off: ENOKI_HIP_DEFER=0 (or its first name,
+    /// ENOKI_HIP_DEFER_GATHER=0), or hip_set_defer(false) / hip_set_defer_gather(false)
     inline bool &hip_defer_gather_flag() {
         static bool flag = [] {
-            const char *e = getenv("ENOKI_HIP_DEFER_GATHER");
-            return !(e && e[0] == '0');
+            const char *e = getenv("ENOKI_HIP_DEFER"), *g = getenv("ENOKI_HIP_DEFER_GATHER");
+            return !((e && e[0] == '0') || (g && g[0] == '0'));
         }();
         return flag;
     }
@@ -1100,9 +1101,12 @@ inline std::string hip_whos() {
     return s;
 }
 
-/// Deferred gathers on / off (on by default; ENOKI_HIP_DEFER_GATHER=0 switches them off for a whole process)
-inline void hip_set_defer_gather(bool value) { detail::hip_defer_gather_flag() = value; }
-inline bool hip_defer_gather() { return detail::hip_defer_gather_flag(); }
+/// Deferred evaluation of gathers and fusable unary ops on / off (on by default; ENOKI_HIP_DEFER=0 switches it off for a
+/// whole process).  Off: every operation runs its own kernel when it is called.
+inline void hip_set_defer(bool value) { detail::hip_defer_gather_flag() = value; }
+inline bool hip_defer() { return detail::hip_defer_gather_flag(); }
+inline void hip_set_defer_gather(bool value) { hip_set_defer(value); }
+inline bool hip_defer_gather() { return hip_defer(); }
 
 template <typename T> inline void set_label(const HIPArray<T> &, const char *) { }
 
