@@ -162,6 +162,12 @@ def build_checkers(force=False, verbose=True):
         _run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
               "-I/opt/rocm/include", inc, os.path.join(tcpp, "asan_allocator.cpp"), "-o", asan, "-L/opt/rocm/lib", "-lamdhip64", "-ldl",
               "-Wl,-rpath,/opt/rocm/lib"])
+    # host logic of the binding's deferred nodes against a host stand-in of the C ABI, under ASan + LSan + UBSan: needs no
+    # GPU, runs in the CPU suite (tests/test_host_sanitizers.py)
+    asan_def = os.path.join(tcpp, "asan_deferred.bin")
+    if force or _newer(asan_def, [os.path.join(tcpp, "asan_deferred.cpp")] + _headers()):
+        _run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", inc,
+              os.path.join(tcpp, "asan_deferred.cpp"), "-o", asan_def])
     # The reference's OWN test sources compiled against this repository's headers with the device array types substituted
     # (tests/cpp/refshim): only where the reference tree exists; the binaries travel to the GPU box.
     ref_tests = "/root/reference/tests"

@@ -287,9 +287,10 @@ template <typename Value_> struct HIPArray : ArrayTag {
     HIPArray(const HIPArray &v, detail::reinterpret_flag) : HIPArray(v) { }
 
     HIPArray &operator=(const HIPArray &a) {
-        if (a.m_buf) a.m_buf->ref_count++;
+        detail::HIPBuffer *buf = a.m_buf;       // `a` may be *this: read it before this handle lets go
+        if (buf) buf->ref_count++;
         release();
-        m_buf = a.m_buf;
+        m_buf = buf;
         m_imm = a.m_imm;
         m_is_imm = a.m_is_imm;
         return *this;
