@@ -162,6 +162,12 @@ def build_checkers(force=False, verbose=True):
         _run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
               "-I/opt/rocm/include", inc, os.path.join(tcpp, "asan_allocator.cpp"), "-o", asan, "-L/opt/rocm/lib", "-lamdhip64", "-ldl",
               "-Wl,-rpath,/opt/rocm/lib"])
+    # fused (vectorize) == unfused, bit for bit, for every floating point function (hipcc translation unit)
+    vmath = os.path.join(tcpp, "libvectorize_math_hip.so")
+    if force or _newer(vmath, [os.path.join(tcpp, "vectorize_math_hip.cpp"), os.path.join(HERE, "libenoki-hip.so")] + _headers()):
+        _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc,
+                                 os.path.join(tcpp, "vectorize_math_hip.cpp"), "-o", vmath, f"-L{HERE}", "-lenoki-hip",
+                                 "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     # host logic of the binding's deferred nodes against a host stand-in of the C ABI, under ASan + LSan + UBSan: needs no
     # GPU, runs in the CPU suite (tests/test_host_sanitizers.py)
     asan_def = os.path.join(tcpp, "asan_deferred.bin")

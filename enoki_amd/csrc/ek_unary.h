@@ -3,8 +3,8 @@
 // scatter_add (scatter_binned.hip, ek_hip_scatter_add_multi_map).  One definition = one rounding behaviour everywhere.
 #pragma once
 #include "ek_map.h"
-#include "ek_math.h"
-#include "ek_special.h"
+#include <enoki/device/ek_math.h>
+#include <enoki/device/ek_special.h>
 
 namespace ek {
 

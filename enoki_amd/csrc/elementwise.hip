@@ -8,7 +8,7 @@
 //   * min/max: first operand wins on unordered compares (array_avx.h:244-245);
 //   * f32 -> i32 casts truncate, out of range gives 0x80000000 (cvttps2dq);
 //   * variable shifts with count >= width give 0 / sign fill (vpsllvd & co., array_avx2.h);
-//   * sin/cos/exp/log: array_math.h algorithms (csrc/ek_math.h), bit-exact.
+//   * sin/cos/exp/log: array_math.h algorithms (include/enoki/device/ek_math.h), bit-exact.
 #include "ek_unary.h"
 
 namespace ek {

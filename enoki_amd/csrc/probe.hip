@@ -3,7 +3,7 @@
 // compile-time choices in ek_map.h (EK_MAP_U, EK_MAP_NT) and the blocks_per_cu default can be
 // re-measured on hardware.  tools/probe_bw.py drives it; results are kept under profiles/.
 #include "ek_map.h"
-#include "ek_math.h"
+#include <enoki/device/ek_math.h>
 
 namespace ek {
 

@@ -314,19 +314,67 @@ template <typename T1, typename T2, typename T3, enable_if_t<detail::all_arithme
 inline auto fnmadd(T1 a, T2 b, T3 c) { using F = detail::common_fp_t<T1, T2, T3>; return std::fma(-F(a), F(b), F(c)); }
 template <typename T1, typename T2, typename T3, enable_if_t<detail::all_arithmetic_v<T1, T2, T3>> = 0>
 inline auto fnmsub(T1 a, T2 b, T3 c) { using F = detail::common_fp_t<T1, T2, T3>; return std::fma(-F(a), F(b), -F(c)); }
+// Inside the fused kernels of enoki/vectorize.h (device compilation, ENOKI_HIP_DEVICE_MATH) the transcendental functions
+// are the device algorithms of the stand-alone kernels -- the restated CEPHES code of array_math.h -- so that a fused
+// kernel and the op-by-op program agree bit for bit; on the host they are libm.
+#if defined(ENOKI_HIP_DEVICE_MATH) && defined(__HIP_DEVICE_COMPILE__)
+namespace detail {
+    inline float dev_sin(float a) { float s, c; ek::dev::sincos_f32<true, false>(a, s, c); return s; }
+    inline float dev_cos(float a) { float s, c; ek::dev::sincos_f32<false, true>(a, s, c); return c; }
+    inline double dev_sin(double a) { double s, c; ek::dev::sincos_f64<true, false>(a, s, c); return s; }
+    inline double dev_cos(double a) { double s, c; ek::dev::sincos_f64<false, true>(a, s, c); return c; }
+    inline float dev_tan(float a) { return ek::dev::tancot_f32<true>(a); }
+    inline double dev_tan(double a) { return ek::dev::tancot_f64<true>(a); }
+    inline float dev_exp(float a) { return ek::dev::exp_f32(a); }     inline double dev_exp(double a) { return ek::dev::exp_f64(a); }
+    inline float dev_log(float a) { return ek::dev::log_f32(a); }     inline double dev_log(double a) { return ek::dev::log_f64(a); }
+    inline float dev_asin(float a) { return ek::dev::asin_f32(a); }   inline double dev_asin(double a) { return ek::dev::asin_f64(a); }
+    inline float dev_acos(float a) { return ek::dev::acos_f32(a); }   inline double dev_acos(double a) { return ek::dev::acos_f64(a); }
+    inline float dev_atan(float a) { return ek::dev::atan2_f32(a, 1.0f); }
+    inline double dev_atan(double a) { return ek::dev::atan2_f64(a, 1.0); }
+    inline float dev_sinh(float a) { return ek::dev::sinh_f32(a); }   inline double dev_sinh(double a) { return ek::dev::sinh_f64(a); }
+    inline float dev_cosh(float a) { return ek::dev::cosh_f32(a); }   inline double dev_cosh(double a) { return ek::dev::cosh_f64(a); }
+    inline float dev_tanh(float a) { return ek::dev::tanh_f32(a); }   inline double dev_tanh(double a) { return ek::dev::tanh_f64(a); }
+    inline float dev_cbrt(float a) { return ek::dev::cbrt_f32(a); }   inline double dev_cbrt(double a) { return ek::dev::cbrt_f64(a); }
+    inline float dev_cot(float a) { return ek::dev::tancot_f32<false>(a); }
+    inline double dev_cot(double a) { return ek::dev::tancot_f64<false>(a); }
+    inline float dev_asinh(float a) { return ek::dev::asinh_f32(a); } inline double dev_asinh(double a) { return ek::dev::asinh_f64(a); }
+    inline float dev_acosh(float a) { return ek::dev::acosh_f32(a); } inline double dev_acosh(double a) { return ek::dev::acosh_f64(a); }
+    inline float dev_atanh(float a) { return ek::dev::atanh_f32(a); } inline double dev_atanh(double a) { return ek::dev::atanh_f64(a); }
+    inline float dev_atan2(float y, float x) { return ek::dev::atan2_f32(y, x); }
+    inline double dev_atan2(double y, double x) { return ek::dev::atan2_f64(y, x); }
+    inline float dev_pow(float x, float y) { return ek::dev::pow_f32(x, y); }
+    inline double dev_pow(double x, double y) { return ek::dev::pow_f64(x, y); }
+}
+#  define ENOKI_HIP_SCALAR_MATH(name) detail::dev_##name
+#else
+#  define ENOKI_HIP_SCALAR_MATH(name) detail::host_math::name
+namespace detail { namespace host_math {
+    using std::sin; using std::cos; using std::tan; using std::exp; using std::log; using std::asin; using std::acos; using std::atan;
+    using std::sinh; using std::cosh; using std::tanh; using std::cbrt; using std::asinh; using std::acosh; using std::atanh;
+    using std::atan2; using std::pow;
+    template <typename T> inline T cot(T a) { return T(1) / std::tan(a); }
+} }
+#endif
 #define ENOKI_HIP_SCALAR_UNARY(name, expr)                                                        \
     template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T name(T a) { return expr; }
 ENOKI_HIP_SCALAR_UNARY(sqrt, std::sqrt(a))   ENOKI_HIP_SCALAR_UNARY(rsqrt, T(1) / std::sqrt(a))
 ENOKI_HIP_SCALAR_UNARY(safe_sqrt, std::sqrt(a > T(0) ? a : T(0)))
 ENOKI_HIP_SCALAR_UNARY(safe_rsqrt, T(1) / std::sqrt(a > T(0) ? a : T(0)))
-ENOKI_HIP_SCALAR_UNARY(sin, std::sin(a))     ENOKI_HIP_SCALAR_UNARY(cos, std::cos(a))     ENOKI_HIP_SCALAR_UNARY(tan, std::tan(a))
-ENOKI_HIP_SCALAR_UNARY(exp, std::exp(a))     ENOKI_HIP_SCALAR_UNARY(log, std::log(a))
-ENOKI_HIP_SCALAR_UNARY(asin, std::asin(a))   ENOKI_HIP_SCALAR_UNARY(acos, std::acos(a))   ENOKI_HIP_SCALAR_UNARY(atan, std::atan(a))
+ENOKI_HIP_SCALAR_UNARY(sin, ENOKI_HIP_SCALAR_MATH(sin)(a))     ENOKI_HIP_SCALAR_UNARY(cos, ENOKI_HIP_SCALAR_MATH(cos)(a))
+ENOKI_HIP_SCALAR_UNARY(tan, ENOKI_HIP_SCALAR_MATH(tan)(a))     ENOKI_HIP_SCALAR_UNARY(exp, ENOKI_HIP_SCALAR_MATH(exp)(a))
+ENOKI_HIP_SCALAR_UNARY(log, ENOKI_HIP_SCALAR_MATH(log)(a))     ENOKI_HIP_SCALAR_UNARY(asin, ENOKI_HIP_SCALAR_MATH(asin)(a))
+ENOKI_HIP_SCALAR_UNARY(acos, ENOKI_HIP_SCALAR_MATH(acos)(a))   ENOKI_HIP_SCALAR_UNARY(atan, ENOKI_HIP_SCALAR_MATH(atan)(a))
+ENOKI_HIP_SCALAR_UNARY(sinh, ENOKI_HIP_SCALAR_MATH(sinh)(a))   ENOKI_HIP_SCALAR_UNARY(cosh, ENOKI_HIP_SCALAR_MATH(cosh)(a))
+ENOKI_HIP_SCALAR_UNARY(tanh, ENOKI_HIP_SCALAR_MATH(tanh)(a))   ENOKI_HIP_SCALAR_UNARY(cbrt, ENOKI_HIP_SCALAR_MATH(cbrt)(a))
+ENOKI_HIP_SCALAR_UNARY(cot, ENOKI_HIP_SCALAR_MATH(cot)(a))     ENOKI_HIP_SCALAR_UNARY(asinh, ENOKI_HIP_SCALAR_MATH(asinh)(a))
+ENOKI_HIP_SCALAR_UNARY(acosh, ENOKI_HIP_SCALAR_MATH(acosh)(a)) ENOKI_HIP_SCALAR_UNARY(atanh, ENOKI_HIP_SCALAR_MATH(atanh)(a))
 ENOKI_HIP_SCALAR_UNARY(floor, std::floor(a)) ENOKI_HIP_SCALAR_UNARY(ceil, std::ceil(a))   ENOKI_HIP_SCALAR_UNARY(abs, std::fabs(a))
 #undef ENOKI_HIP_SCALAR_UNARY
 template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline std::pair<T, T> sincos(T a) {
-    return { std::sin(a), std::cos(a) };
+    return { ENOKI_HIP_SCALAR_MATH(sin)(a), ENOKI_HIP_SCALAR_MATH(cos)(a) };
 }
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T atan2(T y, T x) { return ENOKI_HIP_SCALAR_MATH(atan2)(y, x); }
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T pow(T x, T y) { return ENOKI_HIP_SCALAR_MATH(pow)(x, y); }
 template <typename T1, typename T2, enable_if_t<detail::all_arithmetic_v<T1, T2>> = 0> inline auto min(T1 a, T2 b) {
     using C = std::common_type_t<T1, T2>; return C(b) < C(a) ? C(b) : C(a);
 }
@@ -709,10 +757,20 @@ template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     ENOKI_HIP_STATIC_UNARY(round, enoki::round) ENOKI_HIP_STATIC_UNARY(trunc, enoki::trunc)
     ENOKI_HIP_STATIC_UNARY(sin, enoki::sin) ENOKI_HIP_STATIC_UNARY(cos, enoki::cos) ENOKI_HIP_STATIC_UNARY(exp, enoki::exp)
     ENOKI_HIP_STATIC_UNARY(log, enoki::log) ENOKI_HIP_STATIC_UNARY(sign, enoki::sign)
+    ENOKI_HIP_STATIC_UNARY(tan, enoki::tan) ENOKI_HIP_STATIC_UNARY(cot, enoki::cot) ENOKI_HIP_STATIC_UNARY(asin, enoki::asin)
+    ENOKI_HIP_STATIC_UNARY(acos, enoki::acos) ENOKI_HIP_STATIC_UNARY(atan, enoki::atan) ENOKI_HIP_STATIC_UNARY(sinh, enoki::sinh)
+    ENOKI_HIP_STATIC_UNARY(cosh, enoki::cosh) ENOKI_HIP_STATIC_UNARY(tanh, enoki::tanh) ENOKI_HIP_STATIC_UNARY(asinh, enoki::asinh)
+    ENOKI_HIP_STATIC_UNARY(acosh, enoki::acosh) ENOKI_HIP_STATIC_UNARY(atanh, enoki::atanh) ENOKI_HIP_STATIC_UNARY(cbrt, enoki::cbrt)
+    std::pair<Array, Array> sincos_() const {
+        Array s, c;
+        for (size_t i = 0; i < Size; ++i) { auto sc = enoki::sincos(m_data[i]); s.m_data[i] = sc.first; c.m_data[i] = sc.second; }
+        return { s, c };
+    }
     ENOKI_HIP_STATIC_BINARY(add, a + b) ENOKI_HIP_STATIC_BINARY(sub, a - b) ENOKI_HIP_STATIC_BINARY(mul, a * b)
     ENOKI_HIP_STATIC_BINARY(div, a / b) ENOKI_HIP_STATIC_BINARY(mod, a % b) ENOKI_HIP_STATIC_BINARY(min, enoki::min(a, b))
     ENOKI_HIP_STATIC_BINARY(max, enoki::max(a, b)) ENOKI_HIP_STATIC_BINARY(and, a & b) ENOKI_HIP_STATIC_BINARY(or, a | b)
     ENOKI_HIP_STATIC_BINARY(xor, a ^ b) ENOKI_HIP_STATIC_BINARY(sl, a << b) ENOKI_HIP_STATIC_BINARY(sr, a >> b)
+    ENOKI_HIP_STATIC_BINARY(atan2, enoki::atan2(a, b)) ENOKI_HIP_STATIC_BINARY(pow, enoki::pow(a, b))
     ENOKI_HIP_STATIC_COMPARE(eq, enoki::eq(a, b)) ENOKI_HIP_STATIC_COMPARE(neq, enoki::neq(a, b))
     ENOKI_HIP_STATIC_COMPARE(lt, a < b) ENOKI_HIP_STATIC_COMPARE(le, a <= b)
     ENOKI_HIP_STATIC_COMPARE(gt, a > b) ENOKI_HIP_STATIC_COMPARE(ge, a >= b)

@@ -7,7 +7,7 @@
 // class C on AVX2, exact in float64 where the reference divides).
 #pragma once
 
-#include "ek_math.h"
+#include <enoki/device/ek_math.h>
 
 namespace ek {
 namespace dev {

@@ -4,7 +4,7 @@
     Same algorithms as the reference's math support library (include/enoki/special.h:22-312): Cephes-style
     polynomial / rational / Chebyshev approximations composed from the vertical ops of the array type, with the
     Estrin groupings of array_math.h:25-100.  Arrays that offer a fused member (`HIPArray::erf_()` ... -- one kernel,
-    enoki_amd/csrc/ek_special.h) use it; every other array type -- in particular `DiffArray`, which thereby
+    include/enoki/device/ek_special.h) use it; every other array type -- in particular `DiffArray`, which thereby
     differentiates through the approximation exactly like the reference does -- runs the composition below.  Both
     evaluate the same operations in the same order, so their values agree bit for bit.
 

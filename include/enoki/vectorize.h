@@ -25,7 +25,8 @@
     calls fuse, like everywhere else in this backend), this header is the FIRST enoki header it includes (it makes the
     array vocabulary callable from device code), and the user's own templates are bracketed by
     ENOKI_DEVICE_CODE_BEGIN / ENOKI_DEVICE_CODE_END.  Arithmetic inside `f` is IEEE (correctly rounded + - * / sqrt,
-    fma); transcendental functions resolve to the scalar fallbacks of array.h.
+    fma); sin, cos, sincos, tan, exp, log, asin, acos, atan, atan2, sinh, cosh, tanh, pow, cbrt are the device algorithms
+    of the stand-alone kernels (enoki/device/ek_math.h): a fused kernel returns the same bits as the op-by-op program.
 */
 #pragma once
 
@@ -58,6 +59,10 @@
 #include <vector>
 
 #include <enoki_hip.h>
+// the device algorithms of the stand-alone kernels: inside a fused kernel sin / cos / exp / log / tan / asin / ... of a
+// packet are the SAME functions, hence the same bits, as the op-by-op path (array.h routes its scalar functions here)
+#include <enoki/device/ek_math.h>
+#define ENOKI_HIP_DEVICE_MATH 1
 
 ENOKI_DEVICE_CODE_BEGIN
 #include <enoki/array.h>
@@ -271,6 +276,7 @@ auto vectorize(Func &&f, Args &&... args)
         detail::LeafScan out_scan;
         size_t k = 0;
         detail::collect_leaves<false>(result, out, k, out_scan);          // freshly allocated: nothing shares these buffers
+        for (size_t j = 0; j < k; ++j) out.stride[j] = 1;                 // results are always stored, also when there is ONE slice
         std::apply([&](auto &... v) { hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), 0, stream, slice_count, f, out, v...); }, views);
         detail::hip_check(ek_hip_note_launch("vectorize", slice_count, scan.bytes + out_scan.bytes), "vectorize");
         return result;

@@ -87,3 +87,17 @@ def test_hip_meshgrid_linspace_grid():
     assert lib.hip_sphere_grid(ctypes.c_size_t(res), gx.ctypes.data_as(ctypes.c_void_p), gy.ctypes.data_as(ctypes.c_void_p)) == 0
     egx, egy, _, _ = scene(res)
     assert np.array_equal(gx.view(np.uint32), egx.view(np.uint32)) and np.array_equal(gy.view(np.uint32), egy.view(np.uint32))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("is_double", [0, 1])
+def test_fused_math_matches_kernels(is_double):
+    """every floating point function inside a vectorize() kernel (one-element packets -> the device algorithms of
+    enoki/device/ek_math.h) returns the bits of the stand-alone kernels: 21 expressions, fused vs op by op, compared on
+    the device (tests/cpp/vectorize_math_hip.cpp)"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libvectorize_math_hip.so"))
+    lib.vectorize_math_check.restype = ctypes.c_int
+    report = ctypes.create_string_buffer(4096)
+    for n in (1, 1000, (1 << 20) + 3):
+        bad = lib.vectorize_math_check(is_double, ctypes.c_size_t(n), report, ctypes.c_size_t(len(report)))
+        assert bad == 0, (n, report.value.decode())
