@@ -776,7 +776,11 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
     uint32_t *bucket_base = row_total + kMaxBuckets;
     uint32_t *piece_prefix = bucket_base + kMaxBuckets + 1;
     // accumulate work items: about two workgroups per CU (64 KiB of LDS each), shared out by bucket population
-    const uint32_t target_pieces = (uint32_t) std::max(2 * c.num_cu, n_buckets);
+    // ... but not more pieces than the input can feed: every piece costs a zeroed 64 KiB LDS table and a 64 KiB partial
+    // that the fold reads back, which for small inputs (the 8 Mi-element shards of an 8-GPU run) is more traffic than
+    // the pairs themselves
+    static const size_t piece_elems = [] { const char *e = getenv("ENOKI_HIP_PIECE_ELEMS"); return e ? (size_t) atol(e) : (size_t) 32768; }();
+    const uint32_t target_pieces = (uint32_t) std::max<size_t>(std::min<size_t>(2 * (size_t) c.num_cu, n / piece_elems), (size_t) n_buckets);
     const unsigned max_pieces = target_pieces + (unsigned) n_buckets;       // rounding + "at least one" slack
 
     hipLaunchKernelGGL((k_bin_count<I, Shift>), dim3(blocks), dim3(kThreads), 0, c.stream, (uint32_t *) counts.ptr, index.ptr,

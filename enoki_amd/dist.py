@@ -214,8 +214,17 @@ class Exchange:
                                                 "work": [None] * self.depth, "cur": -1}
         entry["cur"] = (entry["cur"] + 1) % self.depth
         i = entry["cur"]
-        if entry["work"][i] is not None:          # the buffer's previous collective must have finished
-            entry["work"][i].wait()
+        w = entry["work"][i]
+        if w is not None:                         # the buffer's previous collective must have finished
+            # usually it has (depth - 1 steps ago): ask first, and only make the compute stream wait when it has not --
+            # a stream-wait in front of every step's graph launch keeps consecutive launches from overlapping
+            done = False
+            try:
+                done = w.is_completed()
+            except Exception:
+                pass
+            if not done:
+                w.wait()
             entry["work"][i] = None
         return entry, i
 
