@@ -398,6 +398,93 @@ extern "C" EK_API int ek_hip_probe_gather_pair(int variant, float *o0, float *o1
     return EK_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+//  Partition experiment (round 2): 64-way split of (idx, c, x) into bucket-ordered 12-byte RECORDS {bucket-local index,
+//  c * x, c} written with one dwordx3 store per element, against the product's SoA pair lists (2-byte + 4-byte + 4-byte
+//  streams, values restaged per stream).  Bucket space is reserved per tile with one global atomic per bucket (the
+//  caller hands in regions of `capacity` records per bucket), so there is no count / scan pass either.
+// ---------------------------------------------------------------------------------------------------------------------
+struct Rec3 { uint32_t key; float a, b; };
+
+template <int Threads, int PerThread, int Shift>
+__global__ __launch_bounds__(Threads) void k_probe_partition_aos(Rec3 *__restrict__ out, uint32_t *__restrict__ cursor,
+                                                                  uint32_t capacity, const uint32_t *__restrict__ index,
+                                                                  const float *__restrict__ c, const float *__restrict__ x,
+                                                                  size_t n, size_t chunk) {
+    constexpr int Tile = Threads * PerThread, Runs = PerThread / 4, Buckets = 64;
+    __shared__ uint32_t hist[Buckets], off[Buckets], gbase[Buckets];
+    __shared__ Rec3 stage[Tile];
+    if (threadIdx.x < Buckets) hist[threadIdx.x] = 0;
+    __syncthreads();
+    const size_t begin = (size_t) blockIdx.x * chunk, end = begin + chunk < n ? begin + chunk : n;
+    for (size_t base = begin; base + Tile <= end; base += Tile) {
+        uint32_t ix[PerThread], rank[PerThread];
+        float va[PerThread], vb[PerThread];
+#pragma unroll
+        for (int h = 0; h < Runs; ++h) {
+            const size_t e = base + (size_t) h * (Tile / Runs) + (size_t) threadIdx.x * 4;
+            Pack<uint32_t, 4> pi = pack_load<uint32_t, 4, true>(index + e);
+            Pack<float, 4> pc = pack_load<float, 4, true>(c + e), px = pack_load<float, 4, true>(x + e);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ix[h * 4 + j] = pi.v[j]; vb[h * 4 + j] = pc.v[j]; va[h * 4 + j] = pc.v[j] * px.v[j]; }
+        }
+#pragma unroll
+        for (int k = 0; k < PerThread; ++k) rank[k] = atomicAdd(&hist[ix[k] >> Shift], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            const uint32_t h = hist[threadIdx.x];
+            uint32_t incl = h;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                uint32_t up = __shfl_up(incl, d, 64);
+                if ((int) threadIdx.x >= d) incl += up;
+            }
+            off[threadIdx.x] = incl - h;
+            gbase[threadIdx.x] = threadIdx.x * capacity + atomicAdd(&cursor[threadIdx.x], h);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PerThread; ++k) {
+            const uint32_t b = ix[k] >> Shift;
+            stage[off[b] + rank[k]] = Rec3{ ix[k], va[k], vb[k] };
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < PerThread; ++k) {
+            const uint32_t j = k * Threads + threadIdx.x;
+            Rec3 r = stage[j];
+            const uint32_t b = r.key >> Shift;
+            r.key &= (1u << Shift) - 1u;
+            out[gbase[b] + (j - off[b])] = r;
+        }
+        if (threadIdx.x < Buckets) hist[threadIdx.x] = 0;
+        __syncthreads();
+    }
+}
+
+extern "C" EK_API int ek_hip_probe_partition_aos(int variant, void *out, uint32_t *cursor, uint32_t capacity, const uint32_t *index,
+                                                 const float *c, const float *x, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+    if (hipMemsetAsync(cursor, 0, 64 * sizeof(uint32_t), cx.stream) != hipSuccess) return fail(EK_ERR_HIP, "memset");
+#define EK_PPA(T, P, BPC) {                                                                                            \
+        constexpr int Tile = T * P;                                                                                     \
+        unsigned blocks = (unsigned) std::min<size_t>((size_t) cx.num_cu * BPC, n / Tile);                              \
+        size_t chunk = ((n / blocks) / Tile) * Tile;                                                                    \
+        hipLaunchKernelGGL((k_probe_partition_aos<T, P, 14>), dim3(blocks), dim3(T), 0, cx.stream, (Rec3 *) out, cursor, \
+                           capacity, index, c, x, chunk * blocks, chunk); }
+    switch (variant) {
+        case 0: EK_PPA(512, 8, 6) break;       // 4096-record tiles (48 KiB): 3 workgroups per CU
+        case 1: EK_PPA(1024, 4, 6) break;      // same tile, 1024 threads
+        case 2: EK_PPA(512, 16, 2) break;      // 8192-record tiles (96 KiB): 1 workgroup per CU
+        case 3: EK_PPA(256, 8, 12) break;      // 2048-record tiles (24 KiB): 6 workgroups per CU
+        default: EK_PPA(1024, 8, 2) break;     // 8192-record tiles, 1024 threads
+    }
+#undef EK_PPA
+    EK_LAUNCH_CHECK("probe_partition_aos", n, n * 24);
+    return EK_OK;
+}
+
 extern "C" EK_API int ek_hip_probe_interleave(float *AB, const float *A, const float *B, size_t k) {
     if (int rc = ensure_init()) return rc;
     hipLaunchKernelGGL(k_probe_interleave, dim3((unsigned) ((k + 255) / 256)), dim3(256), 0, ctx().stream, (V2 *) AB, A, B, k);
