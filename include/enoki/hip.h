@@ -159,6 +159,16 @@ namespace detail {
 
     /// Deferred evaluation (gathers and unary maps) can be switched off: ENOKI_HIP_DEFER=0 (or its first name,
     /// ENOKI_HIP_DEFER_GATHER=0), or hip_set_defer(false) / hip_set_defer_gather(false)
+    /// Smallest array whose fusable unary results / gathers are left unevaluated (defaults 64 Ki / 4096 elements: below
+    /// that a kernel launch costs more than the bytes it moves).  ENOKI_HIP_DEFER_MIN=<n> overrides both -- the test
+    /// suites run with 1 so that every small tape program goes through the deferred paths.
+    inline size_t hip_defer_min_override() {
+        static const size_t value = [] {
+            const char *e = getenv("ENOKI_HIP_DEFER_MIN");
+            return e ? (size_t) strtoull(e, nullptr, 10) : (size_t) 0;
+        }();
+        return value;
+    }
     inline bool &hip_defer_gather_flag() {
         static bool flag = [] {
             const char *e = getenv("ENOKI_HIP_DEFER"), *g = getenv("ENOKI_HIP_DEFER_GATHER");
@@ -570,7 +580,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if (!detail::hip_defer_gather_flag() || !source.m_buf || !source.m_buf->owned || !index.m_buf)
             return r;
         const size_t n = index.m_buf->size;
-        if (n < defer_min_size_ || source.m_buf->size * sizeof(Value) > defer_max_table_bytes_) return r;
+        const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_min_size_;
+        if (n < least || n < 2 || source.m_buf->size * sizeof(Value) > defer_max_table_bytes_) return r;
         if (mask.m_is_imm ? !mask.m_imm : (!mask.m_buf || mask.m_buf->size != n)) return r;
         source.ptr_();                                       // a table that is itself deferred runs first
         auto *d = new typename detail::HIPBuffer::Deferred{ source.m_buf, index.m_buf, mask.m_is_imm ? nullptr : mask.m_buf,
@@ -597,7 +608,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
                op == EK_COS || op == EK_EXP || op == EK_LOG;
     }
     bool can_defer_map_() const {
-        return IsFloat && detail::hip_defer_gather_flag() && !m_is_imm && m_buf && m_buf->owned && m_buf->size >= defer_map_min_size_;
+        const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_map_min_size_;
+        return IsFloat && detail::hip_defer_gather_flag() && !m_is_imm && m_buf && m_buf->owned && m_buf->size >= least && m_buf->size > 1;
     }
     HIPArray defer_map_(int op) const {
         ptr_();                                              // a source that is itself deferred runs first
