@@ -168,6 +168,10 @@ def build_checkers(force=False, verbose=True):
         _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc,
                                  os.path.join(tcpp, "vectorize_math_hip.cpp"), "-o", vmath, f"-L{HERE}", "-lenoki-hip",
                                  "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+    # include/enoki/ellint.h on host packets (CPU check of the elliptic integrals against the reference's golden vectors)
+    ell = os.path.join(tcpp, "libellint_host.so")
+    if force or _newer(ell, [os.path.join(tcpp, "ellint_host.cpp")] + _headers()):
+        _run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc, os.path.join(tcpp, "ellint_host.cpp"), "-o", ell])
     # host logic of the binding's deferred nodes against a host stand-in of the C ABI, under ASan + LSan + UBSan: needs no
     # GPU, runs in the CPU suite (tests/test_host_sanitizers.py)
     asan_def = os.path.join(tcpp, "asan_deferred.bin")

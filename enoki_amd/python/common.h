@@ -285,6 +285,17 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
             m.def("erfi", [](const Array &a) { return erfi(a); });
             m.def("lgamma", [](const Array &a) { return lgamma(a); });
             m.def("tgamma", [](const Array &a) { return tgamma(a); });
+            // elliptic integrals (special.h:314-672; include/enoki/ellint.h)
+            m.def("comp_ellint_1", [](const Array &k) { return comp_ellint_1(k); });
+            m.def("comp_ellint_2", [](const Array &k) { return comp_ellint_2(k); });
+            m.def("comp_ellint_3", [](const Array &k, const Array &nu) { return comp_ellint_3(k, nu); });
+            m.def("ellint_1", [](const Array &phi, const Array &k) { return ellint_1(phi, k); });
+            m.def("ellint_2", [](const Array &phi, const Array &k) { return ellint_2(phi, k); });
+            m.def("ellint_3", [](const Array &phi, const Array &k, const Array &nu) { return ellint_3(phi, k, nu); });
+            m.def("carlson_rf", [](const Array &x, const Array &y, const Array &z) { return carlson_rf(x, y, z); });
+            m.def("carlson_rd", [](const Array &x, const Array &y, const Array &z) { return carlson_rd(x, y, z); });
+            m.def("carlson_rc", [](const Array &x, const Array &y) { return carlson_rc(x, y); });
+            m.def("carlson_rj", [](const Array &x, const Array &y, const Array &z, const Array &r) { return carlson_rj(x, y, z, r); });
             m.def("pow", [](const Array &a, const Array &b) { return pow(a, b); });
             m.def("pow", [](const Array &a, int b) { return pow(a, b); });
             m.def("fmod", [](const Array &a, const Array &b) { return fmod(a, b); });

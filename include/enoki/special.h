@@ -8,11 +8,12 @@
     differentiates through the approximation exactly like the reference does -- runs the composition below.  Both
     evaluate the same operations in the same order, so their values agree bit for bit.
 
-    Not provided: the Carlson / Legendre elliptic integrals (special.h:314-672).
+    The Carlson / Legendre elliptic integrals (special.h:314-672) live in <enoki/ellint.h>, included below.
 */
 #pragma once
 
 #include <enoki/array.h>
+#include <enoki/ellint.h>
 
 #include <limits>
 

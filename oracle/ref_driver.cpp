@@ -758,4 +758,21 @@ extern "C" int ref_quaternion(const float *a_, const float *b_, const float *t_,
     return 0;
 }
 
+/* Elliptic integrals of the reference (include/enoki/special.h:314-672) on DynamicArray<Packet<T>>: out is (10, n):
+   comp_ellint_1(k), comp_ellint_2(k), comp_ellint_3(k, nu), ellint_1(phi, k), ellint_2(phi, k), ellint_3(phi, k, nu),
+   carlson_rf(x, y, z), carlson_rd(x, y, z), carlson_rc(x, y), carlson_rj(x, y, z, r) with x = phi^2, y = 1.5 - k^2,
+   z = 1 + |nu|, r = 0.5 + |nu| (positive by construction). */
+template <typename T> static int ellint_impl(const T *phi_, const T *k_, const T *nu_, size_t n, T *out) {
+    using V = Dyn<T>;
+    V phi = load(phi_, n), k = load(k_, n), nu = load(nu_, n);
+    V x = phi * phi, y = T(1.5) - k * k, z = T(1) + abs(nu), r = T(0.5) + abs(nu);
+    V res[10] = { comp_ellint_1(k), comp_ellint_2(k), comp_ellint_3(k, nu), ellint_1(phi, k), ellint_2(phi, k), ellint_3(phi, k, nu),
+                  carlson_rf(Array<V, 3>(x, y, z)), carlson_rd(Array<V, 3>(x, y, z)), carlson_rc(Array<V, 2>(x, y)),
+                  carlson_rj(Array<V, 4>(x, y, z, r)) };
+    for (int i = 0; i < 10; ++i) store(res[i], out + (size_t) i * n, n);
+    return 0;
+}
+extern "C" int ref_ellint_f32(const float *phi, const float *k, const float *nu, size_t n, float *out) { return ellint_impl<float>(phi, k, nu, n, out); }
+extern "C" int ref_ellint_f64(const double *phi, const double *k, const double *nu, size_t n, double *out) { return ellint_impl<double>(phi, k, nu, n, out); }
+
 #endif /* !ENOKI_REF_TAPE_ONLY */

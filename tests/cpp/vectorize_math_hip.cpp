@@ -3,6 +3,9 @@
 // on the device.  hipcc translation unit (built by enoki_amd/_build.py into tests/cpp/libvectorize_math_hip.so), driven by
 // tests/test_sphere_gpu.py::test_fused_math_matches_kernels.
 #include <enoki/vectorize.h>
+ENOKI_DEVICE_CODE_BEGIN
+#include <enoki/special.h>
+ENOKI_DEVICE_CODE_END
 
 #include <cstdio>
 
@@ -18,6 +21,10 @@ MATH_CASE(sinh, sinh(x))     MATH_CASE(cosh, cosh(x))     MATH_CASE(tanh, tanh(x
 MATH_CASE(atan2, atan2(x, y)) MATH_CASE(pow, pow(abs(x), y)) MATH_CASE(sqrt, sqrt(abs(x))) MATH_CASE(rsqrt, rsqrt(abs(x)))
 MATH_CASE(rcp, rcp(x))       MATH_CASE(div, x / y)        MATH_CASE(fma, fmadd(x, y, x))
 MATH_CASE(mix, sin(x) * exp(y * 0.5f) + log(abs(x) + 1.f) / (cos(y) + 2.f))
+// elliptic integrals: inside the fused kernel the duplication loop runs per lane (include/enoki/ellint.h)
+MATH_CASE(ellint_1, ellint_1(x, y * 0.25f))   MATH_CASE(ellint_2, ellint_2(x, y * 0.25f))
+MATH_CASE(ellint_3, ellint_3(x, y * 0.25f, abs(x) * 0.2f))   MATH_CASE(comp_ellint_1, comp_ellint_1(y * 0.25f))
+MATH_CASE(carlson_rd, carlson_rd(x * x, abs(y) + 0.5f, abs(x) + 1.f))
 struct case_sincos { template <typename T> auto operator()(const T &x, const T &y) const { auto [s, c] = sincos(x); return s * y + c; } };
 ENOKI_DEVICE_CODE_END
 
@@ -44,6 +51,7 @@ template <typename Scalar> static int run(size_t n, char *report, size_t report_
     RUN_CASE(sin) RUN_CASE(cos) RUN_CASE(tan) RUN_CASE(exp) RUN_CASE(log) RUN_CASE(asin) RUN_CASE(acos) RUN_CASE(atan)
     RUN_CASE(sinh) RUN_CASE(cosh) RUN_CASE(tanh) RUN_CASE(cbrt) RUN_CASE(atan2) RUN_CASE(pow) RUN_CASE(sqrt) RUN_CASE(rsqrt)
     RUN_CASE(rcp) RUN_CASE(div) RUN_CASE(fma) RUN_CASE(mix) RUN_CASE(sincos)
+    RUN_CASE(ellint_1) RUN_CASE(ellint_2) RUN_CASE(ellint_3) RUN_CASE(comp_ellint_1) RUN_CASE(carlson_rd)
     return bad;
 }
 

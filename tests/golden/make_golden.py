@@ -182,3 +182,15 @@ from test_sphere_gpu import scene, run  # noqa: E402
 gx, gy, perm, mask = scene(64, seed=1)
 img, h = run(R.lib.ref_cfg4, gx, gy, perm, mask)
 np.savez_compressed(os.path.join(HERE, "cfg4.npz"), gx=gx, gy=gy, perm=perm, mask=mask, image=img, hits=np.array(h))
+
+# ---- elliptic integrals (include/enoki/special.h:314-672), see oracle/ref_driver.cpp:ref_ellint_* -----------------
+rng = np.random.default_rng(77)
+n_e = 4096
+for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
+    phi = rng.uniform(-7.0, 7.0, n_e).astype(dt)            # several periods: exercises the reduction
+    phi[:16] = np.linspace(-1.5, 1.5, 16).astype(dt)        # and a stretch inside the principal interval
+    k = rng.uniform(-0.95, 0.95, n_e).astype(dt)
+    nu = rng.uniform(-0.9, 2.0, n_e).astype(dt)
+    ell = {"phi": phi, "k": k, "nu": nu, "out": R.ellint(phi, k, nu)}
+    np.savez_compressed(os.path.join(HERE, f"ellint_{tag}.npz"), **ell)
+

@@ -167,6 +167,16 @@ class Checker:
         self._chk(self._f("quaternion")(_p(a), _p(b), _p(t), ctypes.c_size_t(n), _p(out), _p(mat)), "quaternion")
         return out, mat
 
+    def ellint(self, phi, k, nu):
+        """elliptic integrals of the reference (oracle/ref_driver.cpp:ref_ellint_*); phi, k, nu: (n) -> (10, n), rows
+        comp_1, comp_2, comp_3, ellint_1, ellint_2, ellint_3, rf, rd, rc, rj"""
+        dt = np.asarray(phi).dtype
+        phi, k, nu = (np.ascontiguousarray(v, dt) for v in (phi, k, nu))
+        out = np.empty((10, phi.shape[0]), dt)
+        name = "ellint_f32" if dt == np.float32 else "ellint_f64"
+        self._chk(self._f(name)(_p(phi), _p(k), _p(nu), ctypes.c_size_t(phi.shape[0]), _p(out)), name)
+        return out
+
     def complex(self, a, b):
         """Complex<FloatX> script of oracle/ref_driver.cpp:ref_complex; a, b: (2, n) -> (10, 2, n)"""
         a = np.ascontiguousarray(a, np.float32); b = np.ascontiguousarray(b, np.float32)

@@ -103,3 +103,60 @@ def test_gradients_through_the_composition():
     ek.backward(ek.hsum(y))
     want = math.sqrt(math.pi) / 2 * np.exp(ek.detach(y).numpy().astype(np.float64) ** 2)
     assert np.allclose(ek.gradient(v).numpy(), want, rtol=5e-3)
+
+
+# ---- elliptic integrals (include/enoki/ellint.h; reference special.h:314-672) ---------------------------------------
+ELLINT = ["comp_ellint_1", "comp_ellint_2", "comp_ellint_3", "ellint_1", "ellint_2", "ellint_3", "carlson_rf", "carlson_rd",
+          "carlson_rc", "carlson_rj"]
+
+
+def _ellint_golden(tag):
+    z = np.load(os.path.join(GOLDEN, f"ellint_{tag}.npz"))        # from the reference build, tests/golden/make_golden.py
+    return z["phi"], z["k"], z["nu"], z["out"]
+
+
+def test_ellint_host_packets_match_golden():
+    """the restated integrals on one-element packets, on the HOST (tests/cpp/ellint_host.cpp): Carlson forms and complete
+    integrals are bit-exact in float64; the incomplete ones go through the host's libm sincos here (1 ulp); float32 differs
+    by the reference's rcpps-based rcp() (class C)"""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "libellint_host.so"))
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    for tag, fn in (("f64", lib.ellint_host_f64), ("f32", lib.ellint_host_f32)):
+        phi, k, nu, want = _ellint_golden(tag)
+        got = np.empty_like(want)
+        fn(p(phi), p(k), p(nu), ctypes.c_size_t(phi.size), p(got))
+        for i, name in enumerate(ELLINT):
+            if tag == "f64" and not name.startswith("ellint_"):
+                assert bits_equal(got[i], want[i]), name
+            else:
+                rel = np.abs(got[i].astype(np.float64) - want[i]) / np.abs(want[i])
+                assert rel.max() <= (2e-15 if tag == "f64" else 1e-6), (tag, name, rel.max())
+    # and against scipy's independent implementations (k enters squared: m = k^2)
+    from scipy import special as sp
+    phi, k, nu, want = _ellint_golden("f64")
+    assert np.abs(want[3] - sp.ellipkinc(phi, k * k)).max() < 1e-13 and np.abs(want[4] - sp.ellipeinc(phi, k * k)).max() < 1e-13
+    assert np.abs(want[0] - sp.ellipk(k * k)).max() < 1e-14 and np.abs(want[1] - sp.ellipe(k * k)).max() < 1e-14
+    assert np.abs(want[6] - sp.elliprf(phi * phi, 1.5 - k * k, 1 + np.abs(nu))).max() < 1e-14
+
+
+@pytest.mark.gpu
+def test_ellint_device_matches_golden():
+    """HIPArray composition (one kernel per operation, device sincos = the reference's algorithm): ALL ten functions are
+    bit-exact against the reference build in float64; float32 is class C (rcp)"""
+    import enoki_amd.hip as ek
+    ek.hip_init(0)
+    for tag, T in (("f64", ek.Float64), ("f32", ek.Float32)):
+        phi, k, nu, want = _ellint_golden(tag)
+        P, K, N = T(phi), T(k), T(nu)
+        X, Y, Z, R = P * P, T(1.5) - K * K, T(1.0) + ek.abs(N), T(0.5) + ek.abs(N)
+        got = [ek.comp_ellint_1(K), ek.comp_ellint_2(K), ek.comp_ellint_3(K, N), ek.ellint_1(P, K), ek.ellint_2(P, K),
+               ek.ellint_3(P, K, N), ek.carlson_rf(X, Y, Z), ek.carlson_rd(X, Y, Z), ek.carlson_rc(X, Y), ek.carlson_rj(X, Y, Z, R)]
+        for i, name in enumerate(ELLINT):
+            g = got[i].numpy()
+            if tag == "f64":
+                assert bits_equal(g, want[i]), name
+            else:
+                rel = np.abs(g.astype(np.float64) - want[i]) / np.abs(want[i])
+                assert rel.max() <= 1e-6, (name, rel.max())
+
