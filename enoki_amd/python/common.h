@@ -600,6 +600,15 @@ template <typename Value> py::class_<Complex<Value>> bind_complex(py::module_ &m
     m.def("sin", [](const C &z) { return sin(z); });
     m.def("cos", [](const C &z) { return cos(z); });
     m.def("tan", [](const C &z) { return tan(z); });
+    m.def("sinh", [](const C &z) { return sinh(z); });
+    m.def("cosh", [](const C &z) { return cosh(z); });
+    m.def("tanh", [](const C &z) { return tanh(z); });
+    m.def("asin", [](const C &z) { return asin(z); });
+    m.def("acos", [](const C &z) { return acos(z); });
+    m.def("atan", [](const C &z) { return atan(z); });
+    m.def("asinh", [](const C &z) { return asinh(z); });
+    m.def("acosh", [](const C &z) { return acosh(z); });
+    m.def("atanh", [](const C &z) { return atanh(z); });
     return cl;
 }
 

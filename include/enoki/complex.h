@@ -92,4 +92,45 @@ template <typename V> inline Complex<V> tan(const Complex<V> &z) {
     return sc.first / sc.second;
 }
 
+// ---- hyperbolic functions: sinh(a + ib) = sinh a cos b + i cosh a sin b, cosh(a + ib) = cosh a cos b + i sinh a sin b
+//      (reference complex.h:223-251) ----
+template <typename V> inline std::pair<Complex<V>, Complex<V>> sincosh(const Complex<V> &z) {
+    auto sc = sincos(imag(z));
+    auto sch = sincosh(real(z));
+    return { Complex<V>(sch.first * sc.second, sch.second * sc.first), Complex<V>(sch.second * sc.second, sch.first * sc.first) };
+}
+template <typename V> inline Complex<V> sinh(const Complex<V> &z) { return sincosh(z).first; }
+template <typename V> inline Complex<V> cosh(const Complex<V> &z) { return sincosh(z).second; }
+template <typename V> inline Complex<V> tanh(const Complex<V> &z) {
+    auto sch = sincosh(z);
+    return sch.first / sch.second;
+}
+
+// ---- inverse functions through the principal logarithm and square root (reference complex.h:202-267):
+//      asin z = -i log(i z + sqrt(1 - z^2)),  acos z = -i log(z + i sqrt(1 - z^2)),  atan z = -i/2 log((i - z) / (i + z)),
+//      asinh z = log(z + sqrt(z^2 + 1)),  acosh z = log(z + sqrt(z^2 - 1)),  atanh z = 1/2 log((1 + z) / (1 - z)) ----
+namespace detail {
+    template <typename V> inline Complex<V> complex_one() { return Complex<V>(V(scalar_t<V>(1)), V(scalar_t<V>(0))); }
+    template <typename V> inline Complex<V> complex_minus_i_times(const Complex<V> &w) { return Complex<V>(imag(w), -real(w)); }
+    template <typename V> inline Complex<V> complex_i_times(const Complex<V> &w) { return Complex<V>(-imag(w), real(w)); }
+}
+template <typename V> inline Complex<V> asin(const Complex<V> &z) {
+    return detail::complex_minus_i_times(log(detail::complex_i_times(z) + sqrt(detail::complex_one<V>() - z * z)));
+}
+template <typename V> inline Complex<V> acos(const Complex<V> &z) {
+    return detail::complex_minus_i_times(log(z + detail::complex_i_times(sqrt(detail::complex_one<V>() - z * z))));
+}
+template <typename V> inline Complex<V> atan(const Complex<V> &z) {
+    const Complex<V> i(V(scalar_t<V>(0)), V(scalar_t<V>(1)));
+    Complex<V> w = log((i - z) / (i + z));
+    return Complex<V>(imag(w) * V(scalar_t<V>(0.5)), -real(w) * V(scalar_t<V>(0.5)));
+}
+template <typename V> inline Complex<V> asinh(const Complex<V> &z) { return log(z + sqrt(z * z + detail::complex_one<V>())); }
+template <typename V> inline Complex<V> acosh(const Complex<V> &z) { return log(z + sqrt(z * z - detail::complex_one<V>())); }
+template <typename V> inline Complex<V> atanh(const Complex<V> &z) {
+    const Complex<V> one = detail::complex_one<V>();
+    Complex<V> w = log((one + z) / (one - z));
+    return Complex<V>(real(w) * V(scalar_t<V>(0.5)), imag(w) * V(scalar_t<V>(0.5)));
+}
+
 } // namespace enoki

@@ -738,6 +738,19 @@ extern "C" int ref_complex(const float *a_, const float *b_, size_t n, float *ou
     return 0;
 }
 
+/* More of Complex<FloatX> (include/enoki/complex.h:196-267): out is (9, 2, n): sinh, cosh, tanh, asin, acos, atan, asinh,
+   acosh, atanh of a */
+extern "C" int ref_complex_more(const float *a_, size_t n, float *out) {
+    using C = Complex<FloatX>;
+    C a(FloatX::copy(a_, n), FloatX::copy(a_ + n, n));
+    C r[9] = { sinh(a), cosh(a), tanh(a), asin(a), acos(a), atan(a), asinh(a), acosh(a), atanh(a) };
+    for (int k = 0; k < 9; ++k) {
+        store(FloatX(real(r[k])), out + ((size_t) k * 2 + 0) * n, n);
+        store(FloatX(imag(r[k])), out + ((size_t) k * 2 + 1) * n, n);
+    }
+    return 0;
+}
+
 /* Quaternion<FloatX> (include/enoki/quaternion.h): a, b are (4, n) arrays {x, y, z, w}, t is (n).  out is (8, 4, n):
    a*b, a/b (= a*rcp(b)), exp(a), log(a), slerp(na, nb, t) for the normalised inputs, matrix_to_quat(quat_to_matrix(na)),
    sqrt(a), rcp(a); mat is (9, n): quat_to_matrix<Matrix3>(na) in row-major order. */

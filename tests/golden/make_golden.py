@@ -194,3 +194,8 @@ for dt, tag in ((np.float32, "f32"), (np.float64, "f64")):
     ell = {"phi": phi, "k": k, "nu": nu, "out": R.ellint(phi, k, nu)}
     np.savez_compressed(os.path.join(HERE, f"ellint_{tag}.npz"), **ell)
 
+# ---- Complex<FloatX>: hyperbolic and inverse functions (complex.h:196-267), see oracle/ref_driver.cpp:ref_complex_more ----
+rng = np.random.default_rng(78)
+ca = rng.uniform(-1.5, 1.5, (2, 2048)).astype(np.float32)
+np.savez_compressed(os.path.join(HERE, "complex_more.npz"), a=ca, out=R.complex_more(ca))
+

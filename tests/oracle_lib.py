@@ -167,6 +167,13 @@ class Checker:
         self._chk(self._f("quaternion")(_p(a), _p(b), _p(t), ctypes.c_size_t(n), _p(out), _p(mat)), "quaternion")
         return out, mat
 
+    def complex_more(self, a):
+        """sinh, cosh, tanh, asin, acos, atan, asinh, acosh, atanh of Complex<FloatX> (ref_complex_more); a: (2, n) -> (9, 2, n)"""
+        a = np.ascontiguousarray(a, np.float32)
+        out = np.empty((9, 2, a.shape[1]), np.float32)
+        self._chk(self._f("complex_more")(_p(a), ctypes.c_size_t(a.shape[1]), _p(out)), "complex_more")
+        return out
+
     def ellint(self, phi, k, nu):
         """elliptic integrals of the reference (oracle/ref_driver.cpp:ref_ellint_*); phi, k, nu: (n) -> (10, n), rows
         comp_1, comp_2, comp_3, ellint_1, ellint_2, ellint_3, rf, rd, rc, rj"""

@@ -68,3 +68,32 @@ def test_complex_gradient():
     ek.backward(ek.hsum(p.real))
     assert np.allclose(ek.gradient(re).numpy(), 2 * z["a"][0], rtol=1e-6)
     assert np.allclose(ek.gradient(im).numpy(), 2 * z["a"][1], rtol=1e-6)
+
+
+MORE = ["sinh", "cosh", "tanh", "asin", "acos", "atan", "asinh", "acosh", "atanh"]
+
+
+def test_complex_more_golden_is_sane():
+    """CPU: the reference's outputs for the hyperbolic / inverse functions against numpy's complex functions (acosh only where
+    the two branch-cut conventions agree: the reference evaluates log(z + sqrt(z*z - 1)))"""
+    z = np.load(os.path.join(GOLDEN, "complex_more.npz"))
+    a = z["a"][0].astype(np.float64) + 1j * z["a"][1]
+    fns = [np.sinh, np.cosh, np.tanh, np.arcsin, np.arccos, np.arctan, np.arcsinh, np.arccosh, np.arctanh]
+    for k, f in enumerate(fns):
+        g = z["out"][k][0].astype(np.float64) + 1j * z["out"][k][1]
+        sel = (a.real > 0) if MORE[k] == "acosh" else np.ones(a.shape, bool)
+        assert np.abs(g[sel] - f(a[sel])).max() < 5e-6, MORE[k]
+
+
+@pytest.mark.gpu
+def test_complex_more_matches_reference():
+    """sinh ... atanh of Complex2f against the reference build (tests/golden/complex_more.npz): the same compositions of
+    log / sqrt / sincos / sincosh; class C where rcp() or a division enters"""
+    import enoki_amd.hip as ek
+    z = np.load(os.path.join(GOLDEN, "complex_more.npz"))
+    a = ek.Complex2f(ek.Float32(z["a"][0]), ek.Float32(z["a"][1]))
+    for k, name in enumerate(MORE):
+        r = getattr(ek, name)(a)
+        re, im = r.real.numpy(), r.imag.numpy()
+        assert np.allclose(re, z["out"][k][0], rtol=2e-5, atol=2e-5) and np.allclose(im, z["out"][k][1], rtol=2e-5, atol=2e-5), name
+
