@@ -698,7 +698,11 @@ template <typename Value_> struct HIPArray : ArrayTag {
                 if (values[c]->mapped_()) {
                     const auto *d = values[c]->m_buf->deferred;
                     in_place = true;
-                    for (size_t t = 0; t < count; ++t) in_place = in_place && targets[t]->m_buf != d->table;
+                    for (size_t t = 0; t < count; ++t) {
+                        in_place = in_place && targets[t]->m_buf != d->table;
+                        // the same array as a WEIGHT is evaluated below (operand()), which would release this node
+                        in_place = in_place && !(weights && weights[t] && weights[t]->m_buf == values[c]->m_buf);
+                    }
                     if (in_place) {
                         ov[c] = ek_operand{ d->table->ptr, 0, d->table->size };
                         ops[c] = d->index_type;

@@ -304,6 +304,16 @@ static void directed() {
         std::vector<float> ha = host(ta), hb = host(tb);
         for (size_t i = 0; i < N; i += 101) CHECK(hb[i] == hc[i] && ha[i] == ((hx[i] == 0 || hc[i] == 0) ? 0.f : hx[i] * hc[i]));
         CHECK(same(host(su), hs));
+        // the mapped value is also a weight: evaluated once, used as both
+        {
+            F cw = cos(input(N, 1.f));
+            F t0 = zero<F>(N), t1 = zero<F>(N);
+            F *t3[2] = { &t0, &t1 };
+            const F *v3[2] = { &cw, &cw }, *w3[2] = { &cw, nullptr };
+            F::scatter_add_multi_(2, t3, v3, w3, idx, M(true));
+            std::vector<float> h0 = host(t0), h1 = host(t1);
+            for (size_t i = 0; i < N; i += 101) CHECK(h1[i] == hc[i] && h0[i] == ((hc[i] == 0) ? 0.f : hc[i] * hc[i]));
+        }
         // target == source of the mapped value: evaluated first, then accumulated
         F v = input(N, 1.f);
         F cv = cos(v);
