@@ -137,9 +137,12 @@ namespace detail {
             Deferred *d = deferred;
             deferred = nullptr;
             if (d->partner && d->partner->deferred) d->partner->deferred->partner = nullptr;
-            auto &r = d->table->readers;
-            for (size_t i = 0; i < r.size(); ++i)
-                if (r[i] == this) { r[i] = r.back(); r.pop_back(); break; }
+            for (HIPBuffer *src : { d->table, d->index, d->mask }) {
+                if (!src) continue;
+                auto &r = src->readers;
+                for (size_t i = 0; i < r.size(); ++i)
+                    if (r[i] == this) { r[i] = r.back(); r.pop_back(); break; }
+            }
             unref(d->table);
             unref(d->index);
             unref(d->mask);
@@ -592,7 +595,10 @@ template <typename Value_> struct HIPArray : ArrayTag {
         r.m_buf = new detail::HIPBuffer();
         r.m_buf->size = n;
         r.m_buf->deferred = d;
+        // every buffer the node will read hands out mutable pointers only after the node has run (data(), make_unique())
         d->table->readers.push_back(r.m_buf);
+        if (d->index != d->table) d->index->readers.push_back(r.m_buf);
+        if (d->mask && d->mask != d->table && d->mask != d->index) d->mask->readers.push_back(r.m_buf);
         return r;
     }
 

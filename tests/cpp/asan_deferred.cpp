@@ -291,6 +291,21 @@ static void directed() {
         for (size_t i = 0; i < N; i += 997) CHECK(hf[i] == std::fma(ht[i & 1023], hx[i], ht[i & 1023]));
     }
 
+    // --- a deferred gather reads its INDEX array: a write through data() / scatter into the indices comes after the gather ---
+    {
+        F table = input(4096, 1.f);
+        U gi = arange<U>(N) & U(4095u);
+        F g = gather<F>(table, gi);
+        scatter(gi, U(0u), arange<U>(N));             // in-place write into the index array
+        std::vector<float> ht = host(table), hg = host(g);
+        for (size_t i = 0; i < N; i += 499) CHECK(hg[i] == ht[i & 4095]);
+        U gj = arange<U>(N) & U(4095u);
+        F g2 = gather<F>(table, gj);
+        uint32_t *raw = gj.data();                    // mutable pointer: the pending gather runs first
+        (void) raw;
+        CHECK(!g2.deferred_());
+    }
+
     // --- scatter_add_multi_ with mapped values; one target IS the map's source ---
     {
         F u = input(N, 1.f);
