@@ -192,6 +192,16 @@ def build_checkers(force=False, verbose=True):
                 _run(["g++", "-O1", "-std=c++17", "-iquote", shim, "-iquote", "/usr/include/c++/11/pstl", "-I-", f"-I{shim}", inc,
                       "-DENOKI_AUTODIFF=1", f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, source)}"', src, "-o", exe,
                       f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+        # the reference's own HEADERS (router, math, struct support) driving this backend through integration/enoki/hip.h, with
+        # the reference's CPU arrays in the same binary as the yardstick (reference flags of oracle/Makefile)
+        exe = os.path.join(tcpp, "reference_side_hip.bin")
+        integ = os.path.join(ROOT, "integration")
+        deps = [os.path.join(tcpp, "reference_side_hip.cpp"), os.path.join(integ, "enoki", "hip.h"), os.path.join(integ, "hip_hooks.cpp"),
+                os.path.join(ROOT, "include", "enoki_hip.h"), os.path.join(HERE, "libenoki-hip.so")]
+        if force or _newer(exe, deps):
+            _run(["g++", "-std=c++17", "-O2", "-mavx2", "-mfma", "-mf16c", "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno",
+                  "-I/root/reference/include", f"-I{integ}", inc, deps[0], deps[2], "-o", exe, f"-L{HERE}", "-lenoki-hip",
+                  "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
         # tests/sphere.cpp goes through hipcc: its vectorize() calls become fused kernels (include/enoki/vectorize.h)
         exe = os.path.join(tcpp, "reftest_sphere_hip.bin")
         src = os.path.join(tcpp, "reftest_sphere_hip.cpp")

@@ -63,3 +63,17 @@ def test_reference_sphere_program_on_device(tmp_path):
         assert bad.size == 0, (name, bad.size, bad[:8], got[bad[:8], 0], expect[bad[:8]])
         assert np.array_equal(got[:, 1], expect) and np.array_equal(got[:, 2], expect), name
     assert hits > 0
+
+
+def test_reference_headers_drive_the_backend():
+    """integration/enoki/hip.h is written against the REFERENCE's headers: ArrayBase, array_router.h, array_math.h,
+    array_struct.h dispatch into its member concept, which forwards to the C ABI.  tests/cpp/reference_side_hip.cpp
+    instantiates the same templated functions on DynamicArray<Packet<float>> (reference CPU path) and on that HIPArray in
+    one binary: class-A operations must agree bit for bit, reductions / rsqrt to their documented bounds."""
+    exe = os.path.join(HERE, "cpp", "reference_side_hip.bin")
+    if not os.path.exists(exe):
+        pytest.skip("built only where /root/reference exists (enoki_amd/_build.py)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert "13/13 checks passed" in out.stdout, out.stdout[-2000:]
+
