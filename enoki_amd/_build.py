@@ -202,6 +202,20 @@ def build_checkers(force=False, verbose=True):
             _run(["g++", "-std=c++17", "-O2", "-mavx2", "-mfma", "-mf16c", "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno",
                   "-I/root/reference/include", f"-I{integ}", inc, deps[0], deps[2], "-o", exe, f"-L{HERE}", "-lenoki-hip",
                   "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+        # ... and the reference's own TAPE (src/autodiff/autodiff.cpp) + its own autodiff test suite on top of that header: every
+        # line above the C ABI in this binary is reference code.  autodiff.cpp also instantiates Tape<CUDAArray<float>> under
+        # ENOKI_CUDA; that instantiation is dead code here, its references into libenoki-cuda.so stay unresolved.
+        exe = os.path.join(tcpp, "reference_tape_hip.bin")
+        src = os.path.join(tcpp, "reference_tape_hip.cpp")
+        shim_files = [os.path.join(base, f) for base, _, files in os.walk(shim) for f in files]
+        if force or _newer(exe, [src, os.path.join(integ, "enoki", "hip.h"), os.path.join(integ, "hip_hooks.cpp"), os.path.join(ref_tests, "autodiff.cpp"),
+                                 "/root/reference/src/autodiff/autodiff.cpp", os.path.join(HERE, "libenoki-hip.so")] + shim_files):
+            _run(["g++", "-std=c++17", "-O1", "-g", "-mavx2", "-mfma", "-mf16c", "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno",
+                  "-iquote", shim, "-iquote", "/root/reference/include/enoki", "-iquote", "/usr/include/c++/11/pstl", "-I-",
+                  "-I/root/reference/include", f"-I{integ}", inc, f"-I{shim}", "-DENOKI_AUTODIFF=1", "-DENOKI_BUILD=1", "-DENOKI_AUTODIFF_BUILD=1",
+                  '-DREFERENCE_TAPE_FILE="/root/reference/src/autodiff/autodiff.cpp"', f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, "autodiff.cpp")}"',
+                  src, os.path.join(integ, "hip_hooks.cpp"), "-o", exe, f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd",
+                  "-Wl,--unresolved-symbols=ignore-all"])
         # tests/sphere.cpp goes through hipcc: its vectorize() calls become fused kernels (include/enoki/vectorize.h)
         exe = os.path.join(tcpp, "reftest_sphere_hip.bin")
         src = os.path.join(tcpp, "reftest_sphere_hip.cpp")

@@ -20,7 +20,9 @@
 #include <enoki_hip.h>
 
 #include <cstring>
+#include <map>
 #include <memory>
+#include <vector>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -40,6 +42,7 @@ template <typename T> constexpr int type_code() {
     else if constexpr (std::is_same_v<T, double>) return EK_F64;
     else if constexpr (std::is_integral_v<T> && sizeof(T) == 4) return std::is_signed_v<T> ? EK_I32 : EK_U32;
     else if constexpr (std::is_integral_v<T> && sizeof(T) == 8) return std::is_signed_v<T> ? EK_I64 : EK_U64;
+    else if constexpr (std::is_pointer_v<T>) return EK_U64;        // arrays of instance pointers (array_call.h)
     else return -1;
 }
 
@@ -49,6 +52,22 @@ struct Buffer {
     size_t size = 0;
     bool owned = true;
     ~Buffer() { if (owned && ptr) ek_hip_free(ptr); }
+};
+
+/// The reference's autodiff.cpp spells safe_mul / safe_fmadd for "CUDA" arrays as three trace fragments on variable
+/// indices (autodiff.cpp:1198-1202, 1214-1218).  An eager backend has no variables; index_() therefore parks the buffer in a
+/// small ring of recently named buffers and from_index_() picks it up again -- enough for integration/hip_hooks.cpp to
+/// execute those fragments as kernels (a maintainer would rather replace the 30 lines by Value::safe_mul_()).
+struct Handles {
+    static constexpr uint32_t kSlots = 256;
+    std::shared_ptr<Buffer> slot[kSlots];
+    uint32_t next = 1;
+    static Handles &get() { static Handles h; return h; }
+    uint32_t park(const std::shared_ptr<Buffer> &b) { uint32_t id = next++; slot[id % kSlots] = b; return id; }
+    std::shared_ptr<Buffer> find(uint32_t id) const {
+        if (id == 0 || id + kSlots < next) throw std::runtime_error("HIPArray: stale variable index");
+        return slot[id % kSlots];
+    }
 };
 
 NAMESPACE_END(hip_detail)
@@ -267,12 +286,30 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
                                              broadcast(broadcast(size(), index.size()), mask.size()), 0), "scatter_add");
     }
 
+    /// Groups of equal instance pointers for vectorised method calls (cuda.h:814-843; array_router.h:671).  A compatibility
+    /// implementation on the host; the production class sorts on the device (include/enoki/array_call.h, ek_hip_sort_pairs).
+    template <typename T = Value, enable_if_t<std::is_pointer_v<T> || std::is_same_v<T, uintptr_t>> = 0>
+    std::vector<std::pair<Value, HIPArray<uint32_t>>> partition_() const {
+        std::vector<Value> host(size());
+        if (!host.empty()) hip_detail::check(ek_hip_memcpy_to_host(host.data(), m_buf->ptr, host.size() * sizeof(Value)), "partition");
+        std::map<uintptr_t, std::vector<uint32_t>> groups;
+        for (size_t i = 0; i < host.size(); ++i) groups[(uintptr_t) host[i]].push_back((uint32_t) i);
+        std::vector<std::pair<Value, HIPArray<uint32_t>>> result;
+        for (auto &g : groups) result.emplace_back((Value) g.first, HIPArray<uint32_t>::copy(g.second.data(), g.second.size()));
+        return result;
+    }
+    auto operator->() const {
+        using BaseType = std::decay_t<std::remove_pointer_t<Value>>;
+        return call_support<BaseType, HIPArray>(*this);
+    }
+
     // ---- storage (cuda.h:781-812, 930-949) ---------------------------------------------------------------------------
     HIPArray &eval() { return *this; }                 // eager backend: nothing is pending
     const HIPArray &eval() const { return *this; }
     HIPArray &managed() { return *this; }
     const HIPArray &managed() const { return *this; }
-    Index index_() const { return 0; }                 // no trace variables
+    Index index_() const { return m_buf ? hip_detail::Handles::get().park(m_buf) : 0; }   // see hip_detail::Handles
+    static HIPArray from_index_(Index index) { HIPArray r; r.m_buf = hip_detail::Handles::get().find(index); return r; }
     size_t size() const { return m_buf ? m_buf->size : 0; }
     bool empty() const { return size() == 0; }
     const Value *data() const { return m_buf ? (const Value *) m_buf->ptr : nullptr; }

@@ -1,15 +1,84 @@
-// The hooks of the reference's JIT backend that its generic headers call on "CUDA" arrays (include/enoki/cuda.h:33-63,
-// 181; callers: array_struct.h scatter / gather wrappers, array_router.h any_or, array_macro.h) -- for an eager backend
-// there is no trace to flush and no variable to mark, so they do nothing.  A maintainer would compile this file into the
-// library that ships integration/enoki/hip.h; the reference tree itself is untouched.
-#include <enoki/array.h>
-#include <enoki/cuda.h>
-#include <enoki_hip.h>
+// The hooks of the reference's JIT backend that its generic code calls on "CUDA" arrays, for an EAGER backend:
+//   * cuda_eval / cuda_eval_var / cuda_sync / cuda_var_mark_dirty / cuda_set_scatter_gather_operand / cuda_var_set_label (cuda.h:33-63, 181;
+//     callers: array_struct.h scatter / gather wrappers, array_router.h any_or, array_macro.h): nothing is pending, nothing
+//     to mark -- no-ops;
+//   * cuda_register_callback / cuda_unregister_callback (Tape's constructor, autodiff.cpp:218-219): there is no cuda_eval()
+//     to call back from -- no-ops;
+//   * cuda_trace_append for the FOUR trace fragments with which autodiff.cpp:1198-1218 spells safe_mul / safe_fmadd
+//     ((w == 0 || g == 0) ? 0 : w * g and its fma form): executed right away as compare / or / select kernels on the
+//     buffers that HIPArray::index_() parked (integration/enoki/hip.h).  Any other fragment is an error.
+// A maintainer would compile this file into the library that ships integration/enoki/hip.h; the reference tree itself is
+// untouched.
+#include <enoki/hip.h>
+
+#include <cstring>
 
 NAMESPACE_BEGIN(enoki)
+
 void cuda_eval(bool) { }
 void cuda_eval_var(uint32_t, bool) { }
 void cuda_sync() { ek_hip_sync(); }
 void cuda_var_mark_dirty(uint32_t) { }
 void cuda_set_scatter_gather_operand(uint32_t, bool) { }
+void cuda_var_set_label(uint32_t, const char *) { }          // set_label() on device arrays (cuda.h:956-964): no trace to label
+void cuda_register_callback(void (*)(void *), void *) { }
+void cuda_unregister_callback(void (*)(void *), void *) { }
+
+namespace {
+using hip_detail::Buffer;
+using hip_detail::Handles;
+
+std::shared_ptr<Buffer> make(size_t size, size_t elem) {
+    auto b = std::make_shared<Buffer>();
+    b->size = size;
+    hip_detail::check(ek_hip_malloc((size ? size : 1) * elem, &b->ptr), "trace fragment");
+    return b;
+}
+ek_operand op(const std::shared_ptr<Buffer> &b) { return ek_operand{ b->ptr, 0, b->size }; }
+size_t bsize(size_t a, size_t b) { return a == 1 ? b : a; }
+[[noreturn]] void unknown(const char *fragment) {
+    throw std::runtime_error(std::string("integration/hip_hooks.cpp: trace fragment not provided by the eager backend: ") + fragment);
+}
+} // namespace
+
+uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1) {
+    if (strcmp(fragment, "setp.eq.f32 $r1, $r2, 0.0") != 0) unknown(fragment);
+    auto v = Handles::get().find(i1);
+    auto m = make(v->size, 1);
+    ek_operand a = op(v), zero{ nullptr, 0, 1 };
+    hip_detail::check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) m->ptr, &a, &zero, v->size), "setp.eq");
+    return Handles::get().park(m);
+}
+
+uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_t i2) {
+    auto x = Handles::get().find(i1), y = Handles::get().find(i2);
+    if (strcmp(fragment, "setp.eq.or.f32 $r1, $r2, 0.0, $r3") == 0) {          // (x == 0) | y
+        const size_t n = bsize(x->size, y->size);
+        auto e = make(x->size, 1), m = make(n, 1);
+        ek_operand a = op(x), zero{ nullptr, 0, 1 };
+        hip_detail::check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) e->ptr, &a, &zero, x->size), "setp.eq.or");
+        ek_operand oe = op(e), oy = op(y);
+        hip_detail::check(ek_hip_binary(EK_OR, EK_BOOL, m->ptr, &oe, &oy, n), "setp.eq.or");
+        return Handles::get().park(m);
+    }
+    if (strcmp(fragment, "selp.$t1 $r1, 0.0, $r2, $r3") == 0) {                // y ? 0 : x
+        const size_t n = bsize(x->size, y->size);
+        auto r = make(n, 4);
+        ek_operand om = op(y), zero{ nullptr, 0, 1 }, ox = op(x);
+        hip_detail::check(ek_hip_select(EK_F32, r->ptr, &om, &zero, &ox, n), "selp");
+        return Handles::get().park(r);
+    }
+    unknown(fragment);
+}
+
+uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_t i2, uint32_t i3) {
+    if (strcmp(fragment, "selp.$t1 $r1, $r2, $r3, $r4") != 0) unknown(fragment);   // m ? x : y
+    auto x = Handles::get().find(i1), y = Handles::get().find(i2), m = Handles::get().find(i3);
+    const size_t n = bsize(bsize(x->size, y->size), m->size);
+    auto r = make(n, 4);
+    ek_operand om = op(m), ox = op(x), oy = op(y);
+    hip_detail::check(ek_hip_select(EK_F32, r->ptr, &om, &ox, &oy, n), "selp");
+    return Handles::get().park(r);
+}
+
 NAMESPACE_END(enoki)

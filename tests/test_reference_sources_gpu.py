@@ -77,3 +77,15 @@ def test_reference_headers_drive_the_backend():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "13/13 checks passed" in out.stdout, out.stdout[-2000:]
 
+
+def test_reference_tape_and_tests_on_the_backend():
+    """The reference's own tape (src/autodiff/autodiff.cpp), its own autodiff suite (tests/autodiff.cpp) and its own headers,
+    all unmodified, with integration/enoki/hip.h + integration/hip_hooks.cpp as the array backend: 47 / 47 on the device.
+    (tests/cpp/reftest_autodiff_hip.bin is the mirror image: the same suite on THIS repository's headers and tape.)"""
+    exe = os.path.join(HERE, "cpp", "reference_tape_hip.bin")
+    if not os.path.exists(exe):
+        pytest.skip("built only where /root/reference exists (enoki_amd/_build.py)")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
+    assert "47/47 passed" in out.stdout, out.stdout[-2000:]
+
