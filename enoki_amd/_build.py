@@ -210,7 +210,7 @@ def build_checkers(force=False, verbose=True):
         shim_files = [os.path.join(base, f) for base, _, files in os.walk(shim) for f in files]
         if force or _newer(exe, [src, os.path.join(integ, "enoki", "hip.h"), os.path.join(integ, "hip_hooks.cpp"), os.path.join(ref_tests, "autodiff.cpp"),
                                  "/root/reference/src/autodiff/autodiff.cpp", os.path.join(HERE, "libenoki-hip.so")] + shim_files):
-            _run(["g++", "-std=c++17", "-O1", "-g", "-mavx2", "-mfma", "-mf16c", "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno",
+            _run(["g++", "-std=c++17", "-O1", "-mavx2", "-mfma", "-mf16c", "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno",
                   "-iquote", shim, "-iquote", "/root/reference/include/enoki", "-iquote", "/usr/include/c++/11/pstl", "-I-",
                   "-I/root/reference/include", f"-I{integ}", inc, f"-I{shim}", "-DENOKI_AUTODIFF=1", "-DENOKI_BUILD=1", "-DENOKI_AUTODIFF_BUILD=1",
                   '-DREFERENCE_TAPE_FILE="/root/reference/src/autodiff/autodiff.cpp"', f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, "autodiff.cpp")}"',
