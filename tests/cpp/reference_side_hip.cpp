@@ -11,6 +11,7 @@
 #include <enoki/array.h>
 #include <enoki/dynamic.h>
 #include <enoki/hip.h>
+#include <enoki/special.h>
 
 #include <cmath>
 #include <cstdio>
@@ -69,6 +70,16 @@ template <typename Float> Float arithmetic(const Float &x, const Float &y) {
     return fmadd(x, y, 0.5f) * (x - y) / (abs(y) + 1.f) + sqrt(abs(x)) - min(x, y) * max(x, 0.25f);
 }
 template <typename Float> Float transcendental(const Float &x) { return sin(x) * exp(x * 0.25f) + cos(x) - log(abs(x) + 1.f); }
+// the second wave: the reference composes these from primitives with the array type's own operations (array_math.h) -- on
+// HIPArray that is dozens of kernels per function, all dispatched by the reference's code
+template <typename Float> Float second_wave_exact(const Float &x, const Float &y) {
+    Float u = x * 0.3f;                                     // |u| < 1
+    return asin(u) + acos(u) * atan(x) - atan2(y, x) + asinh(x) * cbrt(y) + pow(abs(x) + 0.5f, y) + erf(u) + erfinv(u);
+}
+template <typename Float> Float second_wave_rcp(const Float &x) {
+    Float u = x * 0.4f;                                     // away from the poles of tan
+    return tan(u) + sinh(x) * 0.1f + cosh(x) * 0.1f + tanh(x) + 4.f;
+}
 template <typename Float> Float branches(const Float &x, const Float &y) {
     auto m = (x > y) & (x * y < 0.5f);
     Float r = select(m, x * 2.f, y - 1.f);
@@ -117,6 +128,8 @@ int main() {
 
     expect_bits("arithmetic (fmadd, div, sqrt, min, max)", host(arithmetic(xc, yc)), host(arithmetic(xd, yd)));
     expect_bits("transcendental (sin, cos, exp, log)", host(transcendental(xc)), host(transcendental(xd)));
+    expect_bits("asin acos atan atan2 asinh cbrt pow erf erfinv", host(second_wave_exact(xc, yc)), host(second_wave_exact(xd, yd)));
+    expect_close("tan sinh cosh tanh (contain rcp: class C)", host(second_wave_rcp(xc)), host(second_wave_rcp(xd)), 2e-5);
     expect_bits("compare / select / masked assign / rounding", host(branches(xc, yc)), host(branches(xd, yd)));
     expect_bits("integer ops (shifts, popcnt, and / or / xor, mul)", host(integers(xc)), host(integers(xd)));
     expect_bits("masked gather through array_struct.h", host(indexed(tc, ic, xc)), host(indexed(td, id, xd)));
@@ -142,6 +155,18 @@ int main() {
                     host(FloatH(dot(vd + 1.f, cross(vd, Vector3d(1.f, 2.f, 3.f))) + squared_norm(vd))));
         // normalize() goes through rsqrt: rsqrtps + one Newton step on the CPU, an exact 1 / sqrt on the device (class C)
         expect_close("Array<HIPArray, 3>: normalize (rsqrt, class C)", host(FloatX(normalize(vc + 2.f).y())), host(FloatH(normalize(vd + 2.f).y())), 1e-6);
+    }
+    {
+        // float64 through the same code
+        using DoubleX = DynamicArray<Packet<double>>; using DoubleH = HIPArray<double>;
+        DoubleX ac = linspace<DoubleX>(-3.0, 3.0, 50021), bc = cos(ac * 7.0);
+        DoubleH ad = DoubleH::copy(ac.data(), ac.size()), bd = DoubleH::copy(bc.data(), bc.size());
+        auto f64 = [](const auto &a, const auto &b) { return fmadd(sin(a), exp(b), log(abs(a) + 1.0)) / (sqrt(abs(b)) + 1.0) + atan2(a, b) + tanh(a); };
+        std::vector<double> c1(ac.size()), d1(ac.size());
+        auto rc = f64(ac, bc); auto rd = f64(ad, bd);
+        for (size_t i = 0; i < c1.size(); ++i) c1[i] = rc.coeff(i);
+        ek_hip_memcpy_to_host(d1.data(), rd.data(), d1.size() * sizeof(double));
+        expect_bits("float64: sin exp log sqrt div atan2 tanh", c1, d1);
     }
     printf("%d/%d checks passed\n", g_checks - g_failures, g_checks);
     return g_failures ? 1 : 0;

@@ -75,7 +75,7 @@ def test_reference_headers_drive_the_backend():
         pytest.skip("built only where /root/reference exists (enoki_amd/_build.py)")
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
-    assert "13/13 checks passed" in out.stdout, out.stdout[-2000:]
+    assert "16/16 checks passed" in out.stdout, out.stdout[-2000:]
 
 
 def test_reference_tape_and_tests_on_the_backend():
