@@ -70,6 +70,13 @@ struct Handles {
     }
 };
 
+/// The array that the next gather / scatter / scatter_add addresses: array_struct.h announces it through
+/// cuda_set_scatter_gather_operand(array.index_()) before it hands the bare data() pointer to the member (and withdraws it
+/// afterwards).  The eager backend uses the announcement to recover the table SIZE, which the member concept does not
+/// carry: ek_hip_scatter_add needs it for its LDS-binned path (8x the device atomics on large inputs).
+struct Operand { const void *ptr = nullptr; size_t size = 0; };
+inline Operand &announced_operand() { static thread_local Operand o; return o; }
+
 NAMESPACE_END(hip_detail)
 
 template <typename Value>
@@ -282,7 +289,8 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     void scatter_add_(void *ptr, const Index_ &index, const Mask &mask) const {
         static_assert(Stride == sizeof(Value), "HIPArray::scatter_add_(): element stride expected");
         ek_operand ov = operand(), oi = index.operand(), om = mask.operand();
-        hip_detail::check(ek_hip_scatter_add(Code, Index_::Code, ptr, 0, &ov, &oi, &om,
+        const hip_detail::Operand &target = hip_detail::announced_operand();
+        hip_detail::check(ek_hip_scatter_add(Code, Index_::Code, ptr, target.ptr == ptr ? target.size : 0, &ov, &oi, &om,
                                              broadcast(broadcast(size(), index.size()), mask.size()), 0), "scatter_add");
     }
 

@@ -19,7 +19,14 @@ void cuda_eval(bool) { }
 void cuda_eval_var(uint32_t, bool) { }
 void cuda_sync() { ek_hip_sync(); }
 void cuda_var_mark_dirty(uint32_t) { }
-void cuda_set_scatter_gather_operand(uint32_t, bool) { }
+void cuda_set_scatter_gather_operand(uint32_t index, bool) {
+    // array_struct.h:25-37, 69-84, 103-118: announces the array behind the pointer of the next indexed operation (0: done)
+    hip_detail::Operand &o = hip_detail::announced_operand();
+    if (index == 0) { o = hip_detail::Operand(); return; }
+    auto b = hip_detail::Handles::get().find(index);
+    o.ptr = b ? b->ptr : nullptr;
+    o.size = b ? b->size : 0;
+}
 void cuda_var_set_label(uint32_t, const char *) { }          // set_label() on device arrays (cuda.h:956-964): no trace to label
 void cuda_register_callback(void (*)(void *), void *) { }
 void cuda_unregister_callback(void (*)(void *), void *) { }

@@ -24,6 +24,35 @@ NAMESPACE_END(enoki)
 #define DynamicArray HIPArrayOfPacket
 #include REFERENCE_TEST_FILE               /* /root/reference/tests/autodiff.cpp */
 
+// ---- `--bench n`: BASELINE config 3b on this stack (reference tape + reference router + integration header), for the table in
+// DESIGN.md that separates what the C ABI's kernels deliver from what this repository's own binding adds on top ------------
+#include <chrono>
+static int bench_cfg3b(size_t n, int steps) {
+    const size_t K = 1 << 20;
+    FloatD A = sin(linspace<FloatD>(0.f, 100.f, K)), B = cos(linspace<FloatD>(0.f, 70.f, K));
+    FloatD x = linspace<FloatD>(-1.f, 1.f, n);
+    UInt32D idx = (arange<UInt32D>(n) * 2654435761u) >> 12;                    // < 2^20, pseudo-random
+    double best = 1e30, y_value = 0;
+    for (int s = 0; s < steps + 2; ++s) {
+        ek_hip_sync();
+        auto t0 = std::chrono::steady_clock::now();
+        set_requires_gradient(A); set_requires_gradient(B);
+        FloatD u = fmadd(gather<FloatD>(A, idx), x, gather<FloatD>(B, idx));
+        FloatD y = hsum(sin(u));
+        backward(y);
+        FloatX gA = gradient(A), gB = gradient(B);
+        ek_hip_sync();
+        double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (s >= 2) best = std::min(best, ms);
+        y_value = detach(y).coeff(0);
+        (void) gA; (void) gB;
+        A = detach(A); B = detach(B);
+    }
+    printf("reference tape + reference router + integration/enoki/hip.h: cfg3b n=%zu K=%zu: %.3f ms per step (best of %d), y = %.4f\n",
+           n, K, best, steps, y_value);
+    return 0;
+}
+
 #include <execinfo.h>
 #include <signal.h>
 #include <unistd.h>
@@ -36,8 +65,9 @@ static void on_crash(int sig) {
     _exit(128 + sig);
 }
 
-int main() {
+int main(int argc, char **argv) {
     signal(SIGSEGV, on_crash); signal(SIGABRT, on_crash); signal(SIGBUS, on_crash);
     if (ek_hip_init(-1) != EK_OK) { std::cerr << ek_hip_last_error() << std::endl; return 2; }
+    if (argc >= 3 && strcmp(argv[1], "--bench") == 0) return bench_cfg3b((size_t) atoll(argv[2]), 5);
     return test::run_all();
 }
