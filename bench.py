@@ -346,7 +346,12 @@ class Bench:
                 timed_step()                          # first replay outside the timed region (graph upload)
             except Exception as e:                    # never let the replay machinery break the measurement
                 print(f"[bench] step graph unavailable ({type(e).__name__}: {e}); timing eager steps", file=sys.stderr)
-                graph, replay, timed_step = None, "eager (graph capture failed)", step
+                if graph is not None:                 # a partial capture: give its pool back
+                    try:
+                        ek.hip_graph_destroy(graph)
+                    except Exception:
+                        pass
+                graph, replay, timed_step = None, "eager (the step cannot be captured: " + str(e).split(":")[0][:60] + ")", step
         else:
             timed_step = step
         if packer:

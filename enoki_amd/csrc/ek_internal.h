@@ -147,6 +147,11 @@ template <typename T, typename I>
 int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Arg<I> &index, const Arg<uint8_t> &mask,
                        size_t n);
 
+// A step graph is being captured on the library stream (ek_hip_graph_begin): anything that makes the HOST wait for the
+// device -- a read-back, a synchronisation -- cannot be recorded and would invalidate the capture.  Such entry points call
+// this first and fail cleanly (the capture stays valid, the caller ends it and runs the step eagerly).
+int refuse_while_capturing(const char *what);
+
 // The unary ops that a consumer may apply on load (HIPArray defers exactly these: include/enoki/hip.h)
 constexpr inline bool unary_fusable(int op) {
     switch (op) {

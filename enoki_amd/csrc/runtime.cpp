@@ -247,6 +247,7 @@ int ek_hip_set_stream(void *s) {
 int ek_hip_sync(void) {
     int rc = ensure_init();
     if (rc) return rc;
+    if (int busy = refuse_while_capturing("ek_hip_sync()")) return busy;
     EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     return EK_OK;
 }
@@ -328,6 +329,7 @@ int ek_hip_malloc_trim(void) {
     int rc = ensure_init();
     if (rc) return rc;
     Allocator &a = alloc();
+    if (int busy = refuse_while_capturing("ek_hip_malloc_trim()")) return busy;
     EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     std::lock_guard<std::mutex> guard(a.mutex);
     EK_HIP_CHECK(a.trim_locked());
@@ -362,6 +364,7 @@ int ek_hip_memcpy_to_device(void *dst, const void *src, size_t bytes) {
     int rc = ensure_init();
     if (rc) return rc;
     if (!bytes) return EK_OK;
+    if (int busy = refuse_while_capturing("ek_hip_memcpy_to_device()")) return busy;
     EK_HIP_CHECK(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx().stream));
     EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
     return EK_OK;
@@ -431,6 +434,14 @@ struct ek_hip_graph {
 };
 
 static ek_hip_graph *g_capturing = nullptr;
+
+} // extern "C"
+int ek::refuse_while_capturing(const char *what) {
+    if (!g_capturing) return EK_OK;
+    return fail(EK_ERR_INVALID, "%s: the host would have to wait for the device, which cannot be part of a captured step graph "
+                                "(end the capture and run this step eagerly)", what);
+}
+extern "C" {
 static void *g_stashed_scratch = nullptr;
 static size_t g_stashed_scratch_bytes = 0;
 static uint64_t g_capture_launch_base = 0;

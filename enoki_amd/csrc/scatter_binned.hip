@@ -881,6 +881,7 @@ int scatter_add_binned_large(T *base, size_t table_size, const Arg<T> &value, co
                                                 n * (sizeof(uint32_t) + sizeof(T)));
 
     std::vector<uint32_t> offsets((size_t) n_super + 1);
+    if (int busy = refuse_while_capturing("scatter_add into a table of more than 4 Mi bins (slice populations are read back)")) return busy;
     EK_HIP_CHECK(hipMemcpyAsync(offsets.data(), bucket_base, offsets.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
     EK_HIP_CHECK(hipStreamSynchronize(c.stream));
 
@@ -1251,6 +1252,7 @@ int scatter_add_sorted_multi(T *const *bases, size_t table_size, const Arg<T> *v
             hipLaunchKernelGGL((k_radix_partition_stable<T, I, C>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys, st,
                                index.ptr, mask, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, n, chunk, shift);
             uint32_t valid = 0;           // the only synchronisation of the deterministic path
+            if (int busy = refuse_while_capturing("deterministic scatter_add (the number of active pairs is read back)")) return busy;
             EK_HIP_CHECK(hipMemcpyAsync(&valid, bucket_base + kRadix, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
             EK_HIP_CHECK(hipStreamSynchronize(c.stream));
             m = valid;

@@ -75,3 +75,38 @@ def test_cfg3b_step_graph_replay(ek, capi, n, K):
     ek.hip_graph_destroy(g2)
     step()
     assert bits_equal(out["y"].numpy(), ek.hsum(ek.sin(ek.fmadd(ek.gather(A0, idx), x, ek.gather(B0, idx)))).numpy())
+
+
+def test_host_waits_are_refused_inside_a_capture(ek):
+    """everything that makes the host wait for the device -- hip_sync, the read-back of the deterministic scatter_add,
+    host -> device uploads -- fails with a clear message while a step graph is being captured and leaves BOTH the capture
+    and the library usable (a hipStreamSynchronize on a capturing stream would invalidate the capture and poison every
+    later launch: the state `bench.py --deterministic` ran into)"""
+    rng = np.random.default_rng(2)
+    n, K = 1 << 18, 1 << 16
+    v = ek.Float32(rng.standard_normal(n).astype(np.float32))
+    idx = ek.UInt32(rng.integers(0, K, n).astype(np.uint32))
+    ek.hip_sync()
+    ek.hip_graph_begin()
+    try:
+        with pytest.raises(RuntimeError, match="captured step graph"):
+            ek.hip_sync()
+        ek.hip_set_tuning("deterministic", 1)
+        try:
+            t = ek.Float32.zero(K)
+            with pytest.raises(RuntimeError, match="captured step graph"):
+                ek.scatter_add(t, v, idx)
+        finally:
+            ek.hip_set_tuning("deterministic", 0)
+        with pytest.raises(RuntimeError, match="captured step graph"):
+            ek.Float32(np.ones(16, np.float32))                  # host -> device upload
+        w = v * ek.Float32(2.0)                                     # ordinary work is still recorded
+    finally:
+        g = ek.hip_graph_end()
+    ek.hip_graph_launch(g)
+    assert bits_equal(w.numpy(), v.numpy() * np.float32(2))
+    ek.hip_graph_destroy(g)
+    # and the eager library is alive
+    t = ek.Float32.zero(K)
+    ek.scatter_add(t, v, idx)
+    assert np.allclose(t.numpy(), np.bincount(idx.numpy(), weights=v.numpy().astype(np.float64), minlength=K), atol=1e-3)
