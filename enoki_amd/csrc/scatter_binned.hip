@@ -1251,11 +1251,16 @@ int scatter_add_sorted_multi(T *const *bases, size_t table_size, const Arg<T> *v
         if (p == 0) {
             hipLaunchKernelGGL((k_radix_partition_stable<T, I, C>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys, st,
                                index.ptr, mask, (const uint32_t *) counts.ptr, (const uint32_t *) bucket_base, n, chunk, shift);
-            uint32_t valid = 0;           // the only synchronisation of the deterministic path
-            if (int busy = refuse_while_capturing("deterministic scatter_add (the number of active pairs is read back)")) return busy;
-            EK_HIP_CHECK(hipMemcpyAsync(&valid, bucket_base + kRadix, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
-            EK_HIP_CHECK(hipStreamSynchronize(c.stream));
-            m = valid;
+            if (!mask.vec && mask.ptr == nullptr && mask.imm != 0) {
+                m = n;                    // a host-known `true`: every pair is active, nothing to read back (and the path can be
+                                          // part of a captured step graph)
+            } else {
+                uint32_t valid = 0;       // the only synchronisation of the deterministic path
+                if (int busy = refuse_while_capturing("deterministic scatter_add under a mask array (the number of active pairs is read back)")) return busy;
+                EK_HIP_CHECK(hipMemcpyAsync(&valid, bucket_base + kRadix, sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+                EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+                m = valid;
+            }
         } else {
             Arg<uint8_t> all_on{ nullptr, 1, 0 };
             hipLaunchKernelGGL((k_radix_partition_stable<T, uint32_t, C>), dim3(blocks), dim3(kThreads), 0, c.stream, out_keys, st,

@@ -95,7 +95,9 @@ def test_host_waits_are_refused_inside_a_capture(ek):
         try:
             t = ek.Float32.zero(K)
             with pytest.raises(RuntimeError, match="captured step graph"):
-                ek.scatter_add(t, v, idx)
+                ek.scatter_add(t, v, idx, idx < ek.UInt32(K // 2))   # a mask ARRAY: the number of active pairs is read back
+            td = ek.Float32.zero(K)
+            ek.scatter_add(td, v, idx)                               # no mask array: nothing to read back, recorded
         finally:
             ek.hip_set_tuning("deterministic", 0)
         with pytest.raises(RuntimeError, match="captured step graph"):
@@ -105,6 +107,10 @@ def test_host_waits_are_refused_inside_a_capture(ek):
         g = ek.hip_graph_end()
     ek.hip_graph_launch(g)
     assert bits_equal(w.numpy(), v.numpy() * np.float32(2))
+    # the deterministic scatter_add inside the graph: element-order sums, bit for bit
+    want = np.zeros(K, np.float32)
+    np.add.at(want, idx.numpy(), v.numpy())
+    assert bits_equal(td.numpy(), want)
     ek.hip_graph_destroy(g)
     # and the eager library is alive
     t = ek.Float32.zero(K)
