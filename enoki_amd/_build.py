@@ -174,10 +174,11 @@ def build_checkers(force=False, verbose=True):
         _run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc, os.path.join(tcpp, "ellint_host.cpp"), "-o", ell])
     # host logic of the binding's deferred nodes against a host stand-in of the C ABI, under ASan + LSan + UBSan: needs no
     # GPU, runs in the CPU suite (tests/test_host_sanitizers.py)
-    asan_def = os.path.join(tcpp, "asan_deferred.bin")
-    if force or _newer(asan_def, [os.path.join(tcpp, "asan_deferred.cpp")] + _headers()):
-        _run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", inc,
-              os.path.join(tcpp, "asan_deferred.cpp"), "-o", asan_def])
+    for name, extra in (("asan_deferred", []), ("asan_tape", [os.path.join(HERE, "src", "autodiff_impl.h")])):
+        exe = os.path.join(tcpp, name + ".bin")
+        if force or _newer(exe, [os.path.join(tcpp, name + ".cpp"), os.path.join(tcpp, "host_abi_stub.h")] + extra + _headers()):
+            _run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", inc,
+                  os.path.join(tcpp, name + ".cpp"), "-o", exe])
     # The reference's OWN test sources compiled against this repository's headers with the device array types substituted
     # (tests/cpp/refshim): only where the reference tree exists; the binaries travel to the GPU box.
     ref_tests = "/root/reference/tests"

@@ -20,176 +20,8 @@
 #include <random>
 #include <vector>
 
-// ------------------------------------------------------------------------------------------------------------------
-//  Host stand-in for the C ABI (float32 values, uint32 indices, u8 masks)
-// ------------------------------------------------------------------------------------------------------------------
-static std::map<void *, size_t> g_live;
-static long g_unary_calls = 0, g_sincos_calls = 0, g_gather_calls = 0, g_fused_calls = 0;
-static const char *g_error = "";
+#include "host_abi_stub.h"
 
-static float op_f(const ek_operand *o, size_t i) {
-    if (!o->ptr) { float v; uint32_t b = (uint32_t) o->imm; memcpy(&v, &b, 4); return v; }
-    return ((const float *) o->ptr)[o->size == 1 ? 0 : i];
-}
-static uint32_t op_u(const ek_operand *o, size_t i) {
-    if (!o->ptr) return (uint32_t) o->imm;
-    return ((const uint32_t *) o->ptr)[o->size == 1 ? 0 : i];
-}
-static bool op_m(const ek_operand *o, size_t i) {
-    if (!o->ptr) return (o->imm & 1) != 0;
-    return ((const uint8_t *) o->ptr)[o->size == 1 ? 0 : i] != 0;
-}
-static float unary_f(int op, float x) {
-    switch (op) {
-        case EK_NEG: return -x;
-        case EK_ABS: return std::fabs(x);
-        case EK_SQRT: return std::sqrt(x);
-        case EK_RCP: return 1.0f / x;
-        case EK_RSQRT: return 1.0f / std::sqrt(x);
-        case EK_SIN: return std::sin(x);
-        case EK_COS: return std::cos(x);
-        case EK_EXP: return std::exp(x);
-        case EK_LOG: return std::log(x);
-        case EK_FLOOR: return std::floor(x);
-        case EK_COPY: return x;
-        default: fprintf(stderr, "stand-in: unary op %d\n", op); abort();
-    }
-}
-
-extern "C" {
-const char *ek_hip_last_error(void) { return g_error; }
-int ek_hip_malloc(size_t bytes, void **out) {
-    *out = malloc(bytes ? bytes : 1);
-    g_live[*out] = bytes;
-    return EK_OK;
-}
-int ek_hip_free(void *p) {
-    if (!p) return EK_OK;
-    if (!g_live.erase(p)) { fprintf(stderr, "stand-in: free of an unknown block\n"); abort(); }
-    free(p);
-    return EK_OK;
-}
-int ek_hip_memcpy_device(void *d, const void *s, size_t b) { memcpy(d, s, b); return EK_OK; }
-int ek_hip_memcpy_to_host(void *d, const void *s, size_t b) { memcpy(d, s, b); return EK_OK; }
-int ek_hip_memcpy_to_device(void *d, const void *s, size_t b) { memcpy(d, s, b); return EK_OK; }
-int ek_hip_memset(void *d, int v, size_t b) { memset(d, v, b); return EK_OK; }
-int ek_hip_fill(int type, void *out, uint64_t bits, size_t n) {
-    const size_t w = type == EK_BOOL ? 1 : (type == EK_I64 || type == EK_U64 || type == EK_F64) ? 8 : 4;
-    for (size_t i = 0; i < n; ++i) memcpy((char *) out + i * w, &bits, w);
-    return EK_OK;
-}
-int ek_hip_arange(int type, void *out, int64_t start, int64_t step, size_t n) {
-    for (size_t i = 0; i < n; ++i) {
-        if (type == EK_F32) ((float *) out)[i] = (float) (start + (int64_t) i * step);
-        else ((uint32_t *) out)[i] = (uint32_t) (start + (int64_t) i * step);
-    }
-    return EK_OK;
-}
-int ek_hip_linspace(int, void *out, double lo, double hi, size_t n) {
-    for (size_t i = 0; i < n; ++i) ((float *) out)[i] = (float) (lo + (hi - lo) * (double) i / (double) (n > 1 ? n - 1 : 1));
-    return EK_OK;
-}
-int ek_hip_unary(int op, int type, void *out, const ek_operand *a, size_t n) {
-    ++g_unary_calls;
-    if (type == EK_F32) for (size_t i = 0; i < n; ++i) ((float *) out)[i] = unary_f(op, op_f(a, i));
-    else if (op == EK_COPY) for (size_t i = 0; i < n; ++i) ((uint32_t *) out)[i] = op_u(a, i);
-    else abort();
-    return EK_OK;
-}
-int ek_hip_sincos(int, void *s, void *c, const ek_operand *a, size_t n) {
-    ++g_sincos_calls;
-    for (size_t i = 0; i < n; ++i) { float x = op_f(a, i); ((float *) s)[i] = std::sin(x); ((float *) c)[i] = std::cos(x); }
-    return EK_OK;
-}
-static float binary_f(int op, float a, float b) {
-    switch (op) {
-        case EK_ADD: return a + b;
-        case EK_SUB: return a - b;
-        case EK_MUL: return a * b;
-        case EK_SAFE_MUL: return (a == 0 || b == 0) ? 0.f : a * b;
-        default: fprintf(stderr, "stand-in: binary op %d\n", op); abort();
-    }
-}
-int ek_hip_binary(int op, int type, void *out, const ek_operand *a, const ek_operand *b, size_t n) {
-    if (type == EK_U32) {
-        for (size_t i = 0; i < n; ++i) {
-            uint32_t x = op_u(a, i), y = op_u(b, i);
-            ((uint32_t *) out)[i] = op == EK_AND ? (x & y) : op == EK_MUL ? x * y : op == EK_ADD ? x + y : (abort(), 0u);
-        }
-        return EK_OK;
-    }
-    for (size_t i = 0; i < n; ++i) ((float *) out)[i] = binary_f(op, op_f(a, i), op_f(b, i));
-    return EK_OK;
-}
-int ek_hip_ternary(int op, int, void *out, const ek_operand *a, const ek_operand *b, const ek_operand *c, size_t n) {
-    if (op != EK_FMADD) abort();
-    for (size_t i = 0; i < n; ++i) ((float *) out)[i] = std::fma(op_f(a, i), op_f(b, i), op_f(c, i));
-    return EK_OK;
-}
-int ek_hip_select(int, void *out, const ek_operand *m, const ek_operand *t, const ek_operand *f, size_t n) {
-    for (size_t i = 0; i < n; ++i) ((float *) out)[i] = op_m(m, i) ? op_f(t, i) : op_f(f, i);
-    return EK_OK;
-}
-int ek_hip_compare(int op, int type, uint8_t *out, const ek_operand *a, const ek_operand *b, size_t n) {
-    if (op != EK_LT || type != EK_U32) abort();
-    for (size_t i = 0; i < n; ++i) out[i] = op_u(a, i) < op_u(b, i);
-    return EK_OK;
-}
-int ek_hip_gather(int, int, void *out, const void *base, const ek_operand *index, const ek_operand *mask, size_t n) {
-    ++g_gather_calls;
-    for (size_t i = 0; i < n; ++i) ((float *) out)[i] = op_m(mask, i) ? ((const float *) base)[op_u(index, i)] : 0.f;
-    return EK_OK;
-}
-int ek_hip_map_gathered(int arity, int op, int, void *out, const ek_operand *const *o, const ek_gathered *const *g, size_t n) {
-    ++g_fused_calls;
-    for (size_t i = 0; i < n; ++i) {
-        float x[3] = { 0, 0, 0 };
-        for (int k = 0; k < arity; ++k)
-            x[k] = g[k] ? (op_m(&g[k]->mask, i) ? ((const float *) g[k]->table)[op_u(&g[k]->index, i)] : 0.f) : op_f(o[k], i);
-        ((float *) out)[i] = arity == 2 ? binary_f(op, x[0], x[1]) : std::fma(x[0], x[1], x[2]);
-        if (arity == 3 && op != EK_FMADD) abort();
-    }
-    return EK_OK;
-}
-int ek_hip_scatter(int, int, void *base, const ek_operand *v, const ek_operand *index, const ek_operand *mask, size_t n) {
-    for (size_t i = 0; i < n; ++i) if (op_m(mask, i)) ((float *) base)[op_u(index, i)] = op_f(v, i);
-    return EK_OK;
-}
-int ek_hip_scatter_add(int, int, void *base, size_t, const ek_operand *v, const ek_operand *index, const ek_operand *mask, size_t n, int) {
-    for (size_t i = 0; i < n; ++i) if (op_m(mask, i)) ((float *) base)[op_u(index, i)] += op_f(v, i);
-    return EK_OK;
-}
-int ek_hip_scatter_add_multi_map(int, int, int count, void *const *bases, size_t, const ek_operand *const *values, const int *ops,
-                                 const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask, size_t n, int) {
-    for (int c = 0; c < count; ++c)
-        for (size_t i = 0; i < n; ++i) {
-            if (!op_m(mask, i)) continue;
-            float v = op_f(values[c], i);
-            if (ops && ops[c] != EK_COPY) v = unary_f(ops[c], v);
-            if (weights && weights[c]) v = binary_f(EK_SAFE_MUL, op_f(weights[c], i), v);
-            ((float *) bases[c])[op_u(index, i)] += v;
-        }
-    return EK_OK;
-}
-int ek_hip_scatter_add_multi(int t, int it, int count, void *const *bases, size_t bs, const ek_operand *const *values,
-                             const ek_operand *const *weights, const ek_operand *index, const ek_operand *mask, size_t n, int mode) {
-    return ek_hip_scatter_add_multi_map(t, it, count, bases, bs, values, nullptr, weights, index, mask, n, mode);
-}
-static float reduce_f(int op, int map, const float *in, size_t n) {
-    float acc = op == EK_HSUM ? 0.f : op == EK_HPROD ? 1.f : unary_f(map, in[0]);
-    for (size_t i = 0; i < n; ++i) {
-        float v = unary_f(map, in[i]);
-        acc = op == EK_HSUM ? acc + v : op == EK_HPROD ? acc * v : op == EK_HMIN ? std::fmin(acc, v) : std::fmax(acc, v);
-    }
-    return acc;
-}
-int ek_hip_reduce(int op, int, void *out, const void *in, size_t n) { *(float *) out = reduce_f(op, EK_COPY, (const float *) in, n); return EK_OK; }
-int ek_hip_reduce_map(int op, int map, int, void *out, const void *in, size_t n) {
-    ++g_fused_calls;
-    *(float *) out = reduce_f(op, map, (const float *) in, n);
-    return EK_OK;
-}
-} // extern "C"
 
 // ------------------------------------------------------------------------------------------------------------------
 using namespace enoki;
