@@ -215,7 +215,8 @@ EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand
            the order of fp additions is unspecified, like the reference's atom.global.add;
    mode 1: deterministic -- stable radix sort by index + sequential per-bin sums: bit-identical to the CPU
            reference's element-order accumulation (dynamic.h:517-534).  Needs `base_size` and a 32-bit
-           index array; synchronizes once.  Integer types are exact in either mode. */
+           index array; under a mask ARRAY it synchronizes once (the number of active pairs is read back), otherwise not
+           at all.  Integer types are exact in either mode. */
 EK_API int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size,
                               const ek_operand *value, const ek_operand *index,
                               const ek_operand *mask, size_t n, int mode);
