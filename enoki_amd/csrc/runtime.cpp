@@ -528,6 +528,11 @@ int ek_hip_graph_destroy(ek_hip_graph *g) {
     return EK_OK;
 }
 
+void **ek_hip_binding_slot(void) {
+    static void *slot = nullptr;
+    return &slot;
+}
+
 int ek_hip_note_launch(const char *name, size_t n, size_t bytes) {
     if (int rc = ensure_init()) return rc;
     if (!name) return fail(EK_ERR_INVALID, "ek_hip_note_launch(): null name");

@@ -680,7 +680,8 @@ inline void bind_runtime(py::module_ &m) {
     m.def("hip_set_stream", [](uintptr_t s) { detail::hip_check(ek_hip_set_stream((void *) s), "hip_set_stream"); });
     m.def("hip_launch_count", []() { return ek_hip_launch_count(); });
     // step graphs: capture once, replay without host work (ek_hip_graph_*)
-    m.def("hip_graph_begin", []() { detail::hip_check(ek_hip_graph_begin(), "hip_graph_begin"); });
+    m.def("hip_graph_begin", []() { hip_graph_begin(); },
+          "start capturing a step graph; arrays that are still unevaluated (deferred gathers / unary results) are evaluated first");
     m.def("hip_graph_end", []() {
         ek_hip_graph *g = nullptr;
         detail::hip_check(ek_hip_graph_end(&g), "hip_graph_end");

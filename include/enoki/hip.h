@@ -64,6 +64,39 @@ namespace detail {
         };
         Deferred *deferred = nullptr;
         std::vector<HIPBuffer *> readers;      // deferred nodes whose table / source is THIS buffer (not owning)
+        HIPBuffer *pending_prev = nullptr, *pending_next = nullptr;   // list of all unevaluated buffers (see pending_head())
+
+        /// Every buffer that is still unevaluated, newest first.  hip_graph_begin() evaluates them all: a node that predates a
+        /// capture must not receive its storage from the graph's private pool (it would dangle once the graph is destroyed).
+        /// (The head lives in libenoki-hip.so, ek_hip_binding_slot(): this header is compiled into several shared objects --
+        /// the two python modules, the tape library, user code -- that hand buffers to each other.)
+        struct Shared { HIPBuffer *pending = nullptr; bool defer = true; };
+        static Shared &shared() {
+            void **slot = ek_hip_binding_slot();
+            if (!*slot) {
+                Shared *s = new Shared();             // once per process, never freed
+                const char *e = getenv("ENOKI_HIP_DEFER"), *g = getenv("ENOKI_HIP_DEFER_GATHER");
+                s->defer = !((e && e[0] == '0') || (g && g[0] == '0'));
+                *slot = s;
+            }
+            return *static_cast<Shared *>(*slot);
+        }
+        static HIPBuffer *&pending_head() { return shared().pending; }
+        void pending_link() {
+            pending_prev = nullptr;
+            pending_next = pending_head();
+            if (pending_next) pending_next->pending_prev = this;
+            pending_head() = this;
+        }
+        void pending_unlink() {
+            if (pending_prev) pending_prev->pending_next = pending_next;
+            else if (pending_head() == this) pending_head() = pending_next;
+            if (pending_next) pending_next->pending_prev = pending_prev;
+            pending_prev = pending_next = nullptr;
+        }
+        static void force_all_pending() {
+            while (pending_head()) pending_head()->force();
+        }
         void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
         bool exported = false;                 // an external zero-copy view (torch, __cuda_array_interface__) may exist
 
@@ -136,6 +169,7 @@ namespace detail {
         void drop_deferred() {
             Deferred *d = deferred;
             deferred = nullptr;
+            pending_unlink();
             if (d->partner && d->partner->deferred) d->partner->deferred->partner = nullptr;
             for (HIPBuffer *src : { d->table, d->index, d->mask }) {
                 if (!src) continue;
@@ -162,6 +196,11 @@ namespace detail {
 
     /// Deferred evaluation (gathers and unary maps) can be switched off: ENOKI_HIP_DEFER=0 (or its first name,
     /// ENOKI_HIP_DEFER_GATHER=0), or hip_set_defer(false) / hip_set_defer_gather(false)
+    /// Deferred evaluation (gathers and unary maps) can be switched off: ENOKI_HIP_DEFER=0 (or its first name,
+    /// ENOKI_HIP_DEFER_GATHER=0), or hip_set_defer(false) / hip_set_defer_gather(false).  One switch per process, whichever
+    /// shared object asks.
+    inline bool &hip_defer_gather_flag() { return HIPBuffer::shared().defer; }
+
     /// Smallest array whose fusable unary results / gathers are left unevaluated (defaults 64 Ki / 4096 elements: below
     /// that a kernel launch costs more than the bytes it moves).  ENOKI_HIP_DEFER_MIN=<n> overrides both -- the test
     /// suites run with 1 so that every small tape program goes through the deferred paths.
@@ -172,14 +211,6 @@ namespace detail {
         }();
         return value;
     }
-    inline bool &hip_defer_gather_flag() {
-        static bool flag = [] {
-            const char *e = getenv("ENOKI_HIP_DEFER"), *g = getenv("ENOKI_HIP_DEFER_GATHER");
-            return !((e && e[0] == '0') || (g && g[0] == '0'));
-        }();
-        return flag;
-    }
-
     template <typename T> struct hip_type;
     template <> struct hip_type<bool>     { static constexpr int value = EK_BOOL; };
     template <> struct hip_type<int32_t>  { static constexpr int value = EK_I32; };
@@ -595,6 +626,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         r.m_buf = new detail::HIPBuffer();
         r.m_buf->size = n;
         r.m_buf->deferred = d;
+        r.m_buf->pending_link();
         // every buffer the node will read hands out mutable pointers only after the node has run (data(), make_unique())
         d->table->readers.push_back(r.m_buf);
         if (d->index != d->table) d->index->readers.push_back(r.m_buf);
@@ -625,6 +657,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         r.m_buf = new detail::HIPBuffer();
         r.m_buf->size = m_buf->size;
         r.m_buf->deferred = d;
+        r.m_buf->pending_link();
         m_buf->readers.push_back(r.m_buf);
         return r;
     }
@@ -1116,6 +1149,21 @@ private:
 /// Runtime helpers mirroring cuda_eval / cuda_sync / cuda_whos / cuda_malloc_trim (cuda.h:109-200)
 inline void hip_eval() { }
 inline void hip_sync() { detail::hip_check(ek_hip_sync(), "hip_sync"); }
+
+/// Step graphs (ek_hip_graph_*, include/enoki_hip.h).  Use these wrappers rather than the C entry points: arrays that are still
+/// unevaluated when a capture starts (deferred gathers / unary results) are evaluated first, so that none of them receives
+/// its storage from the graph's private pool.
+inline void hip_graph_begin() {
+    detail::HIPBuffer::force_all_pending();
+    detail::hip_check(ek_hip_graph_begin(), "hip_graph_begin");
+}
+inline ek_hip_graph *hip_graph_end() {
+    ek_hip_graph *g = nullptr;
+    detail::hip_check(ek_hip_graph_end(&g), "hip_graph_end");
+    return g;
+}
+inline void hip_graph_launch(ek_hip_graph *g) { detail::hip_check(ek_hip_graph_launch(g), "hip_graph_launch"); }
+inline void hip_graph_destroy(ek_hip_graph *g) { detail::hip_check(ek_hip_graph_destroy(g), "hip_graph_destroy"); }
 inline void hip_malloc_trim() { detail::hip_check(ek_hip_malloc_trim(), "hip_malloc_trim"); }
 inline std::string hip_whos() {
     char *w = ek_hip_whos();

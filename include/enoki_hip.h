@@ -126,6 +126,10 @@ EK_API uint64_t ek_hip_launch_count(void);          /* kernels launched since in
    code) report here so that they show up in ek_hip_launch_count(), the ENOKI_HIP_LOG=3 trace and ek_hip_profile_*;
    `bytes` = algorithmic bytes of the launch.  `name` must outlive the profile (a string literal). */
 EK_API int ek_hip_note_launch(const char *name, size_t n, size_t bytes);
+/* One process-wide pointer variable for the C++ binding (include/enoki/hip.h keeps the head of its list of unevaluated
+   buffers here): header-only code that is compiled into several shared objects needs ONE home for such state, and this
+   library is the one object they all link.  Returns the variable's address; never NULL; no initialisation needed. */
+EK_API void **ek_hip_binding_slot(void);
 /* Step graphs (hipGraph): between ek_hip_graph_begin() and ek_hip_graph_end() every launch of this library -- kernels,
    memsets, device-to-device copies -- is CAPTURED on the library stream instead of executed; ek_hip_graph_launch()
    replays the captured step without any host-side work (no tape walk, no allocator, no per-kernel launch call), which

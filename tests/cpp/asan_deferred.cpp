@@ -138,6 +138,20 @@ static void directed() {
         CHECK(!g2.deferred_());
     }
 
+    // --- the list of unevaluated buffers (hip_graph_begin() evaluates them all before a capture starts) ---
+    {
+        F table = input(4096, 1.f);
+        U gi = arange<U>(N) & U(4095u);
+        F a = sin(x), b = gather<F>(table, gi);
+        { F dropped = cos(x); }                               // leaves the list when it dies
+        auto sc = sincos(x);
+        CHECK(a.mapped_() && b.deferred_() && sc.first.mapped_() && sc.second.mapped_());
+        enoki::detail::HIPBuffer::force_all_pending();
+        CHECK(!a.mapped_() && !b.deferred_() && !sc.first.mapped_() && !sc.second.mapped_());
+        CHECK(enoki::detail::HIPBuffer::pending_head() == nullptr);
+        CHECK(same(host(a), hs) && same(host(sc.second), hc));
+    }
+
     // --- scatter_add_multi_ with mapped values; one target IS the map's source ---
     {
         F u = input(N, 1.f);

@@ -51,6 +51,7 @@ static float unary_f(int op, float x) {
 
 extern "C" {
 const char *ek_hip_last_error(void) { return g_error; }
+void **ek_hip_binding_slot(void) { static void *slot = nullptr; return &slot; }
 int ek_hip_malloc(size_t bytes, void **out) {
     *out = malloc(bytes ? bytes : 1);
     g_live[*out] = bytes;

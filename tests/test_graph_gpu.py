@@ -116,3 +116,24 @@ def test_host_waits_are_refused_inside_a_capture(ek):
     t = ek.Float32.zero(K)
     ek.scatter_add(t, v, idx)
     assert np.allclose(t.numpy(), np.bincount(idx.numpy(), weights=v.numpy().astype(np.float64), minlength=K), atol=1e-3)
+
+
+def test_arrays_deferred_before_a_capture_do_not_live_in_the_graph_pool(ek):
+    """an unevaluated result that predates a capture is evaluated by hip_graph_begin(): if it were evaluated INSIDE the capture
+    its storage would come from the graph's private pool and dangle once the graph is destroyed"""
+    n = 1 << 18
+    x = ek.Float32.linspace(0.0, 3.0, n)
+    s = ek.sin(x)                                   # deferred (n >= 64 Ki): no storage yet
+    l0 = ek.hip_launch_count()
+    ek.hip_graph_begin()
+    assert ek.hip_launch_count() - l0 == 1          # evaluated by hip_graph_begin, outside the capture
+    y = s * ek.Float32(2.0)
+    g = ek.hip_graph_end()
+    ek.hip_graph_launch(g)
+    want = np.sin(np.linspace(0.0, 3.0, n, dtype=np.float32).astype(np.float64))
+    assert np.allclose(y.numpy(), 2 * want, atol=1e-6)
+    ek.hip_graph_destroy(g)
+    junk = [ek.Float32.zero(n) for _ in range(8)]   # would reuse the pool's blocks
+    assert np.allclose(s.numpy(), want, atol=1e-6)
+    del junk
+
