@@ -172,6 +172,9 @@ def build_checkers(force=False, verbose=True):
     ell = os.path.join(tcpp, "libellint_host.so")
     if force or _newer(ell, [os.path.join(tcpp, "ellint_host.cpp")] + _headers()):
         _run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc, os.path.join(tcpp, "ellint_host.cpp"), "-o", ell])
+    tr = os.path.join(tcpp, "libtransform_host.so")
+    if force or _newer(tr, [os.path.join(tcpp, "transform_host.cpp")] + _headers()):
+        _run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc, os.path.join(tcpp, "transform_host.cpp"), "-o", tr])
     # host logic of the binding's deferred nodes against a host stand-in of the C ABI, under ASan + LSan + UBSan: needs no
     # GPU, runs in the CPU suite (tests/test_host_sanitizers.py)
     for name, extra in (("asan_deferred", []), ("asan_tape", [os.path.join(HERE, "src", "autodiff_impl.h")])):

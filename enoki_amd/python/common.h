@@ -20,6 +20,7 @@
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
+#include <enoki/transform.h>
 #include <enoki/special.h>
 #include <enoki/complex.h>
 #include <enoki/quaternion.h>
@@ -554,6 +555,23 @@ template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py:
       .def("__rmul__", [](const Mat &a, const Value &s) { return Mat(s * a); })
       .def("__add__", [](const Mat &a, const Mat &b) { return Mat(a + b); })
       .def("__sub__", [](const Mat &a, const Mat &b) { return Mat(a - b); });
+    // homogeneous transformations (include/enoki/transform.h; reference src/python/common.h binds them as static methods)
+    if constexpr (N == 4) {
+        using Vec3 = Array<Value, 3>;
+        cl.def_static("translate", [](const Vec3 &v) { return translate<Mat>(v); })
+          .def_static("scale", [](const Vec3 &v) { return scale<Mat>(v); })
+          .def_static("rotate", [](const Vec3 &axis, const Value &angle) { return rotate<Mat>(axis, angle); }, "axis"_a, "angle"_a)
+          .def_static("perspective", [](const Value &fov, const Value &near_, const Value &far_, const Value &aspect) {
+              return perspective<Mat>(fov, near_, far_, aspect); }, "fov"_a, "near"_a, "far"_a, "aspect"_a = Value(scalar_t<Value>(1)))
+          .def_static("frustum", [](const Value &l, const Value &r, const Value &b, const Value &t, const Value &n, const Value &f) {
+              return frustum<Mat>(l, r, b, t, n, f); }, "left"_a, "right"_a, "bottom"_a, "top"_a, "near"_a, "far"_a)
+          .def_static("ortho", [](const Value &l, const Value &r, const Value &b, const Value &t, const Value &n, const Value &f) {
+              return ortho<Mat>(l, r, b, t, n, f); }, "left"_a, "right"_a, "bottom"_a, "top"_a, "near"_a, "far"_a)
+          .def_static("look_at", [](const Vec3 &origin, const Vec3 &target, const Vec3 &up) { return look_at<Mat>(origin, target, up); },
+                      "origin"_a, "target"_a, "up"_a);
+    } else if constexpr (N == 3) {
+        cl.def_static("rotate", [](const Value &angle) { return rotate<Mat>(angle); }, "angle"_a);
+    }
     m.def("transpose", [](const Mat &a) { return Mat(transpose(a)); });
     m.def("trace", [](const Mat &a) { return trace(a); });
     m.def("frob", [](const Mat &a) { return frob(a); });

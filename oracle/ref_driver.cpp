@@ -27,6 +27,7 @@
 #include <enoki/special.h>
 #include <enoki/complex.h>
 #include <enoki/quaternion.h>
+#include <enoki/transform.h>
 
 #include <chrono>
 #include <cstdint>
@@ -747,6 +748,36 @@ extern "C" int ref_complex_more(const float *a_, size_t n, float *out) {
     for (int k = 0; k < 9; ++k) {
         store(FloatX(real(r[k])), out + ((size_t) k * 2 + 0) * n, n);
         store(FloatX(imag(r[k])), out + ((size_t) k * 2 + 1) * n, n);
+    }
+    return 0;
+}
+
+/* include/enoki/transform.h on Matrix<FloatX, 4> / Matrix<FloatX, 3>: v is (3, n) (a direction / offset), p is (6, n) =
+   {angle, fov, near, far, aspect, unused}.  out is (8, 16, n), row-major entries of: translate(v), scale(v),
+   rotate(normalize(v), angle), perspective(fov, near, far, aspect), frustum(-aspect, aspect, -1, 1, near, far),
+   ortho(-aspect, aspect, -1, 1, near, far), look_at(v, v * 0.25 + 1, (0, 1, 0)), and the 3 x 3 rotate(angle) padded to 16. */
+extern "C" int ref_transform(const float *v_, const float *p_, size_t n, float *out) {
+    using M4 = Matrix<FloatX, 4>;
+    using M3 = Matrix<FloatX, 3>;
+    using V3 = Array<FloatX, 3>;
+    V3 v(FloatX::copy(v_, n), FloatX::copy(v_ + n, n), FloatX::copy(v_ + 2 * n, n));
+    FloatX angle = FloatX::copy(p_, n), fov = FloatX::copy(p_ + n, n), nr = FloatX::copy(p_ + 2 * n, n), fr = FloatX::copy(p_ + 3 * n, n),
+           aspect = FloatX::copy(p_ + 4 * n, n), one = FloatX(1.f) + zero<FloatX>(n);
+    M4 m[7] = { translate<M4>(v), scale<M4>(v), rotate<M4>(normalize(v), angle), perspective<M4>(fov, nr, fr, aspect),
+                frustum<M4>(-aspect, aspect, -one, one, nr, fr), ortho<M4>(-aspect, aspect, -one, one, nr, fr),
+                look_at<M4>(v, v * 0.25f + 1.f, V3(zero<FloatX>(n), one, zero<FloatX>(n))) };
+    for (int k = 0; k < 7; ++k)
+        for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < 4; ++j) {
+                FloatX e = m[k](i, j);
+                if (e.size() == 1) e = e + zero<FloatX>(n);
+                store(e, out + ((size_t) k * 16 + i * 4 + j) * n, n);
+            }
+    M3 r = rotate<M3>(angle);
+    for (int i = 0; i < 16; ++i) {
+        FloatX e = i < 9 ? FloatX(r(i / 3, i % 3)) : zero<FloatX>(n);
+        if (e.size() == 1) e = e + zero<FloatX>(n);
+        store(e, out + ((size_t) 7 * 16 + i) * n, n);
     }
     return 0;
 }

@@ -199,3 +199,10 @@ rng = np.random.default_rng(78)
 ca = rng.uniform(-1.5, 1.5, (2, 2048)).astype(np.float32)
 np.savez_compressed(os.path.join(HERE, "complex_more.npz"), a=ca, out=R.complex_more(ca))
 
+# ---- transform.h (translate ... look_at), see oracle/ref_driver.cpp:ref_transform ------------------------------------
+rng = np.random.default_rng(79)
+tv = rng.uniform(0.3, 2.0, (3, 512)).astype(np.float32) * rng.choice([-1.0, 1.0], (3, 512)).astype(np.float32)
+tp = np.stack([rng.uniform(-3, 3, 512), rng.uniform(0.4, 2.0, 512), rng.uniform(0.05, 1.0, 512), rng.uniform(5.0, 100.0, 512),
+               rng.uniform(0.5, 2.0, 512), np.zeros(512)]).astype(np.float32)
+np.savez_compressed(os.path.join(HERE, "transform.npz"), v=tv, p=tp, out=R.transform(tv, tp))
+

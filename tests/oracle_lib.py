@@ -174,6 +174,13 @@ class Checker:
         self._chk(self._f("complex_more")(_p(a), ctypes.c_size_t(a.shape[1]), _p(out)), "complex_more")
         return out
 
+    def transform(self, v, p):
+        """include/enoki/transform.h of the reference (ref_transform); v: (3, n), p: (6, n) -> (8, 16, n) row-major entries"""
+        v = np.ascontiguousarray(v, np.float32); p = np.ascontiguousarray(p, np.float32)
+        out = np.empty((8, 16, v.shape[1]), np.float32)
+        self._chk(self._f("transform")(_p(v), _p(p), ctypes.c_size_t(v.shape[1]), _p(out)), "transform")
+        return out
+
     def ellint(self, phi, k, nu):
         """elliptic integrals of the reference (oracle/ref_driver.cpp:ref_ellint_*); phi, k, nu: (n) -> (10, n), rows
         comp_1, comp_2, comp_3, ellint_1, ellint_2, ellint_3, rf, rd, rc, rj"""

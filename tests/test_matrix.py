@@ -103,3 +103,63 @@ def test_matrix_gradient():
     for k in range(3):
         want = g["a"][0 * 3 + k].astype(np.float64) + g["a"][1 * 3 + k] + g["a"][2 * 3 + k]
         assert np.allclose(ek.gradient(vs[k]).numpy(), want, rtol=1e-6)
+
+
+# ---- transform.h: translate, scale, rotate, perspective, frustum, ortho, look_at --------------------------------------
+TRANSFORMS = ["translate", "scale", "rotate4", "perspective", "frustum", "ortho", "look_at", "rotate3"]
+
+
+def _close(a, b):
+    return np.all(np.abs(a.astype(np.float64) - b) <= 2e-6 + 2e-6 * np.abs(b))
+
+
+def test_transform_host_matches_golden():
+    """include/enoki/transform.h on scalar entries (tests/cpp/transform_host.cpp) against the matrices of the reference build
+    (tests/golden/transform.npz): translate / scale bit-exact, the rest to class C (the reference's rcp / rsqrt are
+    rcpps / rsqrtps + Newton; the host's sincos is libm)"""
+    import ctypes
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "libtransform_host.so"))
+    z = np.load(os.path.join(GOLDEN, "transform.npz"))
+    out = np.empty_like(z["out"])
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    lib.transform_host(p(z["v"]), p(z["p"]), ctypes.c_size_t(z["v"].shape[1]), p(out))
+    for k, name in enumerate(TRANSFORMS):
+        if name in ("translate", "scale"):
+            assert bits_equal(out[k], z["out"][k]), name
+        else:
+            assert _close(out[k], z["out"][k]), name
+    # sanity of the conventions: a perspective matrix maps the near / far planes to -1 / +1, look_at moves the origin to 0
+    n, f = z["p"][2].astype(np.float64), z["p"][3].astype(np.float64)
+    P = z["out"][3].reshape(4, 4, -1).astype(np.float64)
+    for depth, want in ((-n, -1.0), (-f, 1.0)):
+        clip = P[2, 2] * depth + P[2, 3]
+        w = P[3, 2] * depth
+        assert np.allclose(clip / w, want, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_transform_device_matches_golden():
+    import enoki_amd.hip as ek
+    z = np.load(os.path.join(GOLDEN, "transform.npz"))
+    v = ek.Vector3f(*[ek.Float32(z["v"][i]) for i in range(3)])
+    angle, fov, nr, fr, aspect = (ek.Float32(z["p"][i]) for i in range(5))
+    one = ek.Float32(np.ones(z["v"].shape[1], np.float32))
+    M = ek.Matrix4f
+    mats = [M.translate(v), M.scale(v), M.rotate(ek.normalize(v), angle), M.perspective(fov, nr, fr, aspect),
+            M.frustum(-aspect, aspect, -one, one, nr, fr), M.ortho(-aspect, aspect, -one, one, nr, fr),
+            M.look_at(v, ek.Vector3f(*[v[i] * ek.Float32(0.25) + ek.Float32(1.0) for i in range(3)]),
+                      ek.Vector3f(ek.Float32(0.0), ek.Float32(1.0), ek.Float32(0.0)))]
+    n = z["v"].shape[1]
+    for k, m in enumerate(mats):
+        for i in range(4):
+            for j in range(4):
+                got = np.broadcast_to(m[i, j].numpy(), (n,))
+                want = z["out"][k][i * 4 + j]
+                if TRANSFORMS[k] in ("translate", "scale"):
+                    assert bits_equal(np.ascontiguousarray(got), want), (TRANSFORMS[k], i, j)
+                else:
+                    assert _close(got, want), (TRANSFORMS[k], i, j)
+    r = ek.Matrix3f.rotate(angle)
+    for i in range(3):
+        for j in range(3):
+            assert _close(np.broadcast_to(r[i, j].numpy(), (n,)), z["out"][7][i * 3 + j]), ("rotate3", i, j)
