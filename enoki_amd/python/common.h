@@ -20,6 +20,7 @@
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
+#include <enoki/morton.h>
 #include <enoki/transform.h>
 #include <enoki/special.h>
 #include <enoki/complex.h>
@@ -449,6 +450,11 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
           .def("__rshift__", [](const Vec &a, const Vec &b) { return Vec(a >> b); })
           .def("__floordiv__", [](const Vec &a, const Vec &b) { return Vec(a / b); })
           .def("__mod__", [](const Vec &a, const Vec &b) { return Vec(a % b); });
+        if constexpr (std::is_unsigned_v<Scalar> && N >= 2 && N <= 4) {
+            // Morton / Z-order codes (include/enoki/morton.h)
+            m.def("morton_encode", [](const Vec &coords) { return morton_encode(coords); });
+            cl.def_static("morton_decode", [](const Value &code) { return morton_decode<Vec>(code); });
+        }
     }
     if constexpr (IsFloatV) {
         cl.def(py::self / py::self)
