@@ -5,6 +5,7 @@
 #include <enoki/vectorize.h>
 ENOKI_DEVICE_CODE_BEGIN
 #include <enoki/special.h>
+#include <enoki/stl.h>
 ENOKI_DEVICE_CODE_END
 
 #include <cstdio>
@@ -39,6 +40,19 @@ template <typename Float, typename Case> static size_t mismatches(const Float &x
     return bad;
 }
 
+/// std::pair / std::tuple as results and as arguments of a fused kernel (include/enoki/stl.h)
+template <typename Float> static size_t stl_mismatches(const Float &x, const Float &y) {
+    using UInt = HIPArray<std::conditional_t<sizeof(scalar_t<Float>) == 4, uint32_t, uint64_t>>;
+    auto differ = [](const Float &a, const Float &b) { return count(neq(reinterpret_array<UInt>(a), reinterpret_array<UInt>(b))); };
+    std::pair<Float, Float> sc = vectorize([](auto &&a) { return sincos(a); }, x);
+    auto ref = sincos(x);
+    size_t bad = differ(sc.first, ref.first) + differ(sc.second, ref.second);
+    std::tuple<Float, Float, Float> t = vectorize([](auto &&a, auto &&b) { return std::make_tuple(a + b, a * b, fmadd(a, b, a)); }, x, y);
+    bad += differ(std::get<0>(t), x + y) + differ(std::get<1>(t), x * y) + differ(std::get<2>(t), fmadd(x, y, x));
+    Float packed = vectorize([](auto &&p) { return p.first - p.second; }, sc);             // a pair as a sliced ARGUMENT
+    return bad + differ(packed, ref.first - ref.second);
+}
+
 template <typename Scalar> static int run(size_t n, char *report, size_t report_size) {
     using Float = HIPArray<Scalar>;
     // (not linspace: one slice would divide by n - 1 = 0)
@@ -52,6 +66,8 @@ template <typename Scalar> static int run(size_t n, char *report, size_t report_
     RUN_CASE(sinh) RUN_CASE(cosh) RUN_CASE(tanh) RUN_CASE(cbrt) RUN_CASE(atan2) RUN_CASE(pow) RUN_CASE(sqrt) RUN_CASE(rsqrt)
     RUN_CASE(rcp) RUN_CASE(div) RUN_CASE(fma) RUN_CASE(mix) RUN_CASE(sincos)
     RUN_CASE(ellint_1) RUN_CASE(ellint_2) RUN_CASE(ellint_3) RUN_CASE(comp_ellint_1) RUN_CASE(carlson_rd)
+    { size_t m = stl_mismatches(x, y); if (m) ++bad;
+      used += (size_t) snprintf(report + used, used < report_size ? report_size - used : 0, "pair_tuple:%zu ", m); }
     return bad;
 }
 
