@@ -21,6 +21,7 @@
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
 #include <enoki/morton.h>
+#include <enoki/sh.h>
 #include <enoki/transform.h>
 #include <enoki/special.h>
 #include <enoki/complex.h>
@@ -466,6 +467,12 @@ template <typename Value, size_t N> py::class_<Array<Value, N>> bind_vector(py::
         m.def("normalize", [](const Vec &a) { return normalize(a); });
         m.def("sqrt", [](const Vec &a) { return sqrt(a); });
         if constexpr (N == 3) m.def("cross", [](const Vec &a, const Vec &b) { return cross(a, b); });
+        if constexpr (N == 3)
+            m.def("sh_eval", [](const Vec &d, size_t order) {
+                std::vector<Value> out((order + 1) * (order + 1));
+                sh_eval(d, order, out.data());
+                return out;
+            }, "d"_a, "order"_a, "real spherical harmonics Y_l^m(d), index l * (l + 1) + m (include/enoki/sh.h)");
     }
     m.def("select", [](const Mask &mk, const Vec &t, const Vec &f) { return select(mk, t, f); });
     m.def("slices", [](const Vec &a) { return slices(a); });

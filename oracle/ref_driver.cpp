@@ -28,6 +28,7 @@
 #include <enoki/complex.h>
 #include <enoki/quaternion.h>
 #include <enoki/transform.h>
+#include <enoki/sh.h>
 
 #include <chrono>
 #include <cstdint>
@@ -778,6 +779,19 @@ extern "C" int ref_transform(const float *v_, const float *p_, size_t n, float *
         FloatX e = i < 9 ? FloatX(r(i / 3, i % 3)) : zero<FloatX>(n);
         if (e.size() == 1) e = e + zero<FloatX>(n);
         store(e, out + ((size_t) 7 * 16 + i) * n, n);
+    }
+    return 0;
+}
+
+/* sh_eval (include/enoki/sh.h, generated code for orders 0..9), element by element on Array<float, 3> (the reference's
+   store() does not take DynamicArray): d is (3, n), out is ((order + 1)^2, n) */
+extern "C" int ref_sh(const float *d_, size_t n, size_t order, float *out) {
+    if (order > 9) return -1;
+    const size_t count = (order + 1) * (order + 1);
+    std::vector<float> coeffs(count);
+    for (size_t i = 0; i < n; ++i) {
+        sh_eval(Array<float, 3>(d_[i], d_[n + i], d_[2 * n + i]), order, coeffs.data());
+        for (size_t k = 0; k < count; ++k) out[k * n + i] = coeffs[k];
     }
     return 0;
 }

@@ -206,3 +206,8 @@ tp = np.stack([rng.uniform(-3, 3, 512), rng.uniform(0.4, 2.0, 512), rng.uniform(
                rng.uniform(0.5, 2.0, 512), np.zeros(512)]).astype(np.float32)
 np.savez_compressed(os.path.join(HERE, "transform.npz"), v=tv, p=tp, out=R.transform(tv, tp))
 
+# ---- sh.h (real spherical harmonics, order 9), see oracle/ref_driver.cpp:ref_sh ---------------------------------------
+rng = np.random.default_rng(80)
+sd = rng.standard_normal((3, 1024)); sd = (sd / np.linalg.norm(sd, axis=0)).astype(np.float32)
+np.savez_compressed(os.path.join(HERE, "sh.npz"), d=sd, out=R.sh(sd, 9))
+

@@ -174,6 +174,13 @@ class Checker:
         self._chk(self._f("complex_more")(_p(a), ctypes.c_size_t(a.shape[1]), _p(out)), "complex_more")
         return out
 
+    def sh(self, d, order):
+        """sh_eval of the reference (ref_sh); d: (3, n) unit vectors -> ((order + 1)^2, n)"""
+        d = np.ascontiguousarray(d, np.float32)
+        out = np.empty(((order + 1) ** 2, d.shape[1]), np.float32)
+        self._chk(self._f("sh")(_p(d), ctypes.c_size_t(d.shape[1]), ctypes.c_size_t(order), _p(out)), "sh")
+        return out
+
     def transform(self, v, p):
         """include/enoki/transform.h of the reference (ref_transform); v: (3, n), p: (6, n) -> (8, 16, n) row-major entries"""
         v = np.ascontiguousarray(v, np.float32); p = np.ascontiguousarray(p, np.float32)
