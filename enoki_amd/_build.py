@@ -175,6 +175,9 @@ def build_checkers(force=False, verbose=True):
     mo = os.path.join(tcpp, "morton_host.bin")
     if force or _newer(mo, [os.path.join(tcpp, "morton_host.cpp"), os.path.join(ROOT, "include", "enoki", "morton.h")]):
         _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "morton_host.cpp"), "-o", mo])
+    po = os.path.join(tcpp, "polar_host.bin")
+    if force or _newer(po, [os.path.join(tcpp, "polar_host.cpp")] + _headers()):
+        _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "polar_host.cpp"), "-o", po])
     shl = os.path.join(tcpp, "libsh_host.so")
     if force or _newer(shl, [os.path.join(tcpp, "sh_host.cpp"), os.path.join(ROOT, "include", "enoki", "sh.h")]):
         _run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", inc, os.path.join(tcpp, "sh_host.cpp"), "-o", shl])

@@ -585,6 +585,17 @@ template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py:
     } else if constexpr (N == 3) {
         cl.def_static("rotate", [](const Value &angle) { return rotate<Mat>(angle); }, "angle"_a);
     }
+    if constexpr (N == 3 || N == 4)
+        m.def("polar_decomp", [](const Mat &a, size_t it) { return polar_decomp(a, it); }, "a"_a, "it"_a = 10,
+              "A = Q P: (orthogonal Q, symmetric P) by the scaled Newton iteration (matrix.h)");
+    if constexpr (N == 4) {
+        using Vec3 = Array<Value, 3>;
+        using Mat3 = Matrix<Value, 3>;
+        m.def("transform_decompose", [](const Mat &a, size_t it) { return transform_decompose(a, it); }, "a"_a, "it"_a = 10,
+              "affine 4x4 -> (scale / shear 3x3, rotation quaternion, translation)");
+        m.def("transform_compose", [](const Mat3 &s, const Quaternion<Value> &q, const Vec3 &t) { return transform_compose(s, q, t); });
+        m.def("transform_compose_inverse", [](const Mat3 &s, const Quaternion<Value> &q, const Vec3 &t) { return transform_compose_inverse(s, q, t); });
+    }
     m.def("transpose", [](const Mat &a) { return Mat(transpose(a)); });
     m.def("trace", [](const Mat &a) { return trace(a); });
     m.def("frob", [](const Mat &a) { return frob(a); });

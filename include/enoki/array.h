@@ -382,6 +382,8 @@ template <typename T1, typename T2, enable_if_t<detail::all_arithmetic_v<T1, T2>
     using C = std::common_type_t<T1, T2>; return C(b) > C(a) ? C(b) : C(a);
 }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T sqr(T a) { return a * a; }
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline bool isnan(T a) { return a != a; }
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T mulsign(T a, T b) { return std::signbit(b) ? -a : a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T rcp(T a) { return T(1) / a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T hsum(T a) { return a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline bool eq(T a, T b) { return a == b; }

@@ -17,6 +17,8 @@
 
 #include <enoki/array.h>
 
+#include <utility>
+
 namespace enoki {
 
 template <typename Value_, size_t Size_> struct Matrix : Array<Array<Value_, Size_>, Size_> {
@@ -227,5 +229,21 @@ template <typename V> inline Matrix<V, 4> inverse(const Matrix<V, 4> &m) {
 }
 
 template <typename V> inline Matrix<V, 4> inverse_transpose(const Matrix<V, 4> &m) { return transpose(inverse(m)); }
+
+/// Polar decomposition A = Q P (Q orthogonal, P symmetric positive semi-definite) by the scaled Newton iteration
+/// Q <- (g Q + Q^-T / g) / 2, g = sqrt(|Q^-T|_F / |Q|_F) (N. Higham, "Computing the polar decomposition -- with
+/// applications", SIAM J. Sci. Stat. Comput. 7 (1986); reference matrix.h:526-539: the same update, `it` rounds).
+template <typename V, size_t N> inline std::pair<Matrix<V, N>, Matrix<V, N>> polar_decomp(const Matrix<V, N> &A, size_t it = 10) {
+    using S = scalar_t<V>;
+    Matrix<V, N> Q = A;
+    for (size_t round = 0; round < it; ++round) {
+        Matrix<V, N> Qi = inverse_transpose(Q);
+        V gamma = sqrt(frob(Qi) / frob(Q));
+        V a = gamma * V(S(0.5)), b = rcp(gamma) * V(S(0.5));
+        for (size_t j = 0; j < N; ++j)
+            for (size_t i = 0; i < N; ++i) Q(i, j) = fmadd(Q(i, j), a, Qi(i, j) * b);
+    }
+    return { Q, transpose(Q) * A };
+}
 
 } // namespace enoki

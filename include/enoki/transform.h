@@ -10,11 +10,15 @@
     Rodrigues' formula in the sign convention of a right-handed system).  Every entry is evaluated in the reference's
     operation order, so results on device arrays agree with its CPU arrays bit for bit wherever no rcp() / normalize() is
     involved and to their class-C bound otherwise (tests/test_matrix.py, tests/golden/transform.npz).
-    transform_decompose / transform_compose (polar decomposition) are not provided.
+    transform_decompose / transform_compose / transform_compose_inverse split an affine 4 x 4 matrix into scale / shear
+    (symmetric 3 x 3), rotation (quaternion) and translation through the polar decomposition of matrix.h, and back.
 */
 #pragma once
 
 #include <enoki/matrix.h>
+#include <enoki/quaternion.h>
+
+#include <tuple>
 
 namespace enoki {
 
@@ -117,6 +121,43 @@ inline M look_at(const Point &origin, const Point &target, const Vector &up) {
     auto new_up = cross(left, dir);
     return M(Col(left.coeff(0), left.coeff(1), left.coeff(2), z), Col(new_up.coeff(0), new_up.coeff(1), new_up.coeff(2), z),
              Col(-dir.coeff(0), -dir.coeff(1), -dir.coeff(2), z), Col(-dot(left, origin), -dot(new_up, origin), dot(dir, origin), o));
+}
+
+/// A = T(t) R(q) S: returns (S, q, t).  A reflection is moved from the rotation into S (det R = +1), like the reference
+/// (transform.h:152-173).
+template <typename V> inline std::tuple<Matrix<V, 3>, Quaternion<V>, Array<V, 3>> transform_decompose(const Matrix<V, 4> &A, size_t it = 10) {
+    using M3 = Matrix<V, 3>;
+    M3 sub;
+    for (size_t j = 0; j < 3; ++j)
+        for (size_t i = 0; i < 3; ++i) sub(i, j) = A(i, j);
+    auto qp = polar_decomp(sub, it);
+    M3 Q = qp.first, P = qp.second;
+    if (any_nested(isnan(Q(0, 0)))) Q = identity<M3>();          // singular input
+    V sign = det(Q);
+    for (size_t j = 0; j < 3; ++j)
+        for (size_t i = 0; i < 3; ++i) { Q(i, j) = mulsign(Q(i, j), sign); P(i, j) = mulsign(P(i, j), sign); }
+    return { P, matrix_to_quat(Q), Array<V, 3>(A(0, 3), A(1, 3), A(2, 3)) };
+}
+
+template <typename V, typename Vector3> inline Matrix<V, 4> transform_compose(const Matrix<V, 3> &S, const Quaternion<V> &q, const Vector3 &t) {
+    using E = scalar_t<V>;
+    Matrix<V, 3> RS = quat_to_matrix<Matrix<V, 3>>(q) * S;
+    Matrix<V, 4> r = identity<Matrix<V, 4>>();
+    for (size_t j = 0; j < 3; ++j)
+        for (size_t i = 0; i < 3; ++i) r(i, j) = RS(i, j);
+    for (size_t i = 0; i < 3; ++i) r(i, 3) = V(t.coeff(i));
+    (void) sizeof(E);
+    return r;
+}
+
+template <typename V, typename Vector3> inline Matrix<V, 4> transform_compose_inverse(const Matrix<V, 3> &S, const Quaternion<V> &q, const Vector3 &t) {
+    Matrix<V, 3> inv = inverse(quat_to_matrix<Matrix<V, 3>>(q) * S);
+    Array<V, 3> back = inv * Array<V, 3>(-V(t.coeff(0)), -V(t.coeff(1)), -V(t.coeff(2)));
+    Matrix<V, 4> r = identity<Matrix<V, 4>>();
+    for (size_t j = 0; j < 3; ++j)
+        for (size_t i = 0; i < 3; ++i) r(i, j) = inv(i, j);
+    for (size_t i = 0; i < 3; ++i) r(i, 3) = back.coeff(i);
+    return r;
 }
 
 } // namespace enoki

@@ -163,3 +163,39 @@ def test_transform_device_matches_golden():
     for i in range(3):
         for j in range(3):
             assert _close(np.broadcast_to(r[i, j].numpy(), (n,)), z["out"][7][i * 3 + j]), ("rotate3", i, j)
+
+
+def test_polar_decomposition_host_properties():
+    """polar_decomp / transform_decompose / transform_compose(_inverse) on host scalars: tests/cpp/polar_host.cpp"""
+    import subprocess
+    exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "polar_host.bin")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+
+
+@pytest.mark.gpu
+def test_transform_decompose_device():
+    """device arrays: compose(decompose(A)) = A and A * compose_inverse = I; Q of the polar decomposition against scipy"""
+    import enoki_amd.hip as ek
+    from scipy.linalg import polar
+    rng = np.random.default_rng(4)
+    n = 500
+    A = np.tile(np.eye(4, dtype=np.float32)[:, :, None], (1, 1, n))
+    A[:3, :, :] = rng.uniform(-2, 2, (3, 4, n)).astype(np.float32)
+    keep = np.abs(np.linalg.det(np.moveaxis(A[:3, :3], 2, 0))) > 0.2
+    A = A[:, :, keep]; n = A.shape[2]
+    M = ek.Matrix4f([ek.Float32(np.ascontiguousarray(A[i, j])) for i in range(4) for j in range(4)])
+    S, q, t = ek.transform_decompose(M)
+    B = ek.transform_compose(S, q, t)
+    I = B @ ek.transform_compose_inverse(S, q, t)
+    for i in range(4):
+        for j in range(4):
+            assert np.allclose(np.broadcast_to(B[i, j].numpy(), (n,)), A[i, j], atol=2e-4), (i, j)
+            assert np.allclose(np.broadcast_to(I[i, j].numpy(), (n,)), 1.0 if i == j else 0.0, atol=2e-4), (i, j)
+    M3 = ek.Matrix3f([ek.Float32(np.ascontiguousarray(A[i, j])) for i in range(3) for j in range(3)])
+    Q, P = ek.polar_decomp(M3)
+    for s in range(0, n, 37):
+        u, _ = polar(A[:3, :3, s].astype(np.float64))
+        got = np.array([[Q[i, j].numpy()[s] for j in range(3)] for i in range(3)])
+        assert np.allclose(got, u, atol=5e-4), s
+
