@@ -1,0 +1,43 @@
+// A program written with the reference's names -- <enoki/cuda.h>, CUDAArray<float>, DiffArray<CUDAArray<float>>, cuda_eval(),
+// <enoki/dynamic.h>, DynamicArray<Packet<float>> -- compiled against this repository's headers without an edit
+// (include/enoki/cuda.h, include/enoki/dynamic.h).  Run by tests/test_reference_sources_gpu.py.
+#include <enoki/cuda.h>
+#include <enoki/dynamic.h>
+#include <enoki/autodiff.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace enoki;
+
+using FloatC = CUDAArray<float>;
+using FloatD = DiffArray<FloatC>;
+using UInt32D = DiffArray<CUDAArray<uint32_t>>;
+using FloatX = DynamicArray<Packet<float>>;
+
+int main() {
+    const size_t n = 1 << 16, K = 1024;
+    FloatD table = linspace<FloatD>(0.f, 1.f, K);
+    set_requires_gradient(table);
+    UInt32D idx = arange<UInt32D>(n) & UInt32D(uint32_t(K - 1));
+    FloatD x = linspace<FloatD>(-1.f, 1.f, n);
+    FloatD y = hsum(sin(gather<FloatD>(table, idx) * x));
+    cuda_eval();                                    // nothing to flush: accepted and ignored
+    backward(y);
+    FloatC g = gradient(table);
+    cuda_device_sync();
+    // analytic gradient of bin k: sum over the elements that read it of cos(t_k x_i) x_i
+    double worst = 0;
+    for (size_t k = 0; k < K; k += 97) {
+        double want = 0, tk = (double) k / (K - 1);
+        for (size_t i = k; i < n; i += K) { double xi = -1.0 + 2.0 * (double) i / (n - 1); want += std::cos(tk * xi) * xi; }
+        worst = std::fmax(worst, std::fabs(want - (double) g.coeff(k)));
+    }
+    FloatX z = zero<FloatX>(8) + 1.f;
+    char *w = cuda_whos();
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr;
+    free(w);
+    printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
+    return ok ? 0 : 1;
+}

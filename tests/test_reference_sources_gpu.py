@@ -89,3 +89,12 @@ def test_reference_tape_and_tests_on_the_backend():
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-1000:]
     assert "47/47 passed" in out.stdout, out.stdout[-2000:]
 
+
+def test_programs_written_with_the_reference_names_compile_unchanged():
+    """<enoki/cuda.h> / CUDAArray / cuda_eval() and <enoki/dynamic.h> / DynamicArray<Packet<T>> are source-compatible aliases
+    (include/enoki/cuda.h, include/enoki/dynamic.h): tests/cpp/compat_names_hip.cpp differentiates through a gather with
+    them and checks the gradient analytically"""
+    exe = os.path.join(HERE, "cpp", "compat_names_hip.bin")
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+
