@@ -179,6 +179,9 @@ def build_checkers(force=False, verbose=True):
     mo = os.path.join(tcpp, "morton_host.bin")
     if force or _newer(mo, [os.path.join(tcpp, "morton_host.cpp"), os.path.join(ROOT, "include", "enoki", "morton.h")]):
         _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "morton_host.cpp"), "-o", mo])
+    pk = os.path.join(tcpp, "packed_host.bin")
+    if force or _newer(pk, [os.path.join(tcpp, "packed_host.cpp"), os.path.join(ROOT, "include", "enoki", "array.h")]):
+        _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "packed_host.cpp"), "-o", pk])
     po = os.path.join(tcpp, "polar_host.bin")
     if force or _newer(po, [os.path.join(tcpp, "polar_host.cpp")] + _headers()):
         _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "polar_host.cpp"), "-o", po])

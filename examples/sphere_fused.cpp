@@ -12,6 +12,7 @@
 #include <enoki/vectorize.h>
 
 #include <cstdio>
+#include <vector>
 
 using namespace enoki;
 using FloatC = HIPArray<float>;
@@ -77,6 +78,58 @@ int sphere_fused_device(const float *gx, const float *gy, const uint32_t *perm_,
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "sphere_fused_device: %s\n", e.what());
+        return -3;
+    }
+}
+
+/// The same program over a PACKED pixel grid: `gxy` holds {x, y} records side by side (2 n floats), so the lookup through
+/// the permutation is ONE 8-byte request per ray instead of two 4-byte ones (array.h gather_packed; the reference's
+/// gather<Vector2fP>(mem, index) has the same record layout, array_router.h:1097-1107).  Same image, bit for bit.
+extern "C" __attribute__((visibility("default")))
+int sphere_fused_packed_device(const float *gxy, const uint32_t *perm_, const uint8_t *mask_, size_t n, float *image,
+                               uint64_t *hit_count) {
+    try {
+        UInt32C perm = UInt32C::map((void *) perm_, n);
+        MaskC mask = MaskC::map((void *) mask_, n);
+        vectorize_indirect_bytes(12);          // one 8-byte lookup + one 4-byte scatter per ray
+        MaskC hit = vectorize(
+            [gxy, image](auto &&perm, auto &&mask) {
+                using Vector2fP = Array<FloatP, 2>;
+                using MaskP = mask_t<FloatP>;
+                Vector2fP p = gather<Vector2fP>(gxy, perm, mask);
+                MaskP hit;
+                auto pos = intersect_rays(make_rays(p), hit);
+                FloatP shade = shade_hits(pos);
+                hit = hit & mask;
+                scatter(image, shade, perm, hit);
+                return hit;
+            },
+            (const UInt32C &) perm, (const MaskC &) mask);
+        if (hit_count) *hit_count = count(hit);
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "sphere_fused_packed_device: %s\n", e.what());
+        return -3;
+    }
+}
+
+/// Host-pointer wrapper of the packed version: interleaves the two planes on the host, otherwise like sphere_fused()
+extern "C" __attribute__((visibility("default")))
+int sphere_fused_packed(const float *gx, const float *gy, const uint32_t *perm_, const uint8_t *mask_, size_t n, float *image,
+                        uint64_t *hit_count) {
+    try {
+        std::vector<float> xy(2 * n);
+        for (size_t i = 0; i < n; ++i) { xy[2 * i] = gx[i]; xy[2 * i + 1] = gy[i]; }
+        FloatC dxy = FloatC::copy(xy.data(), 2 * n), img = FloatC::copy(image, n);
+        UInt32C perm = UInt32C::copy(perm_, n);
+        MaskC mask = MaskC::copy(mask_, n);
+        int rc = sphere_fused_packed_device(dxy.data(), perm.data(), (const uint8_t *) mask.data(), n, img.data(), hit_count);
+        if (rc) return rc;
+        auto host = img.to_host();
+        memcpy(image, host.data(), n * sizeof(float));
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "sphere_fused_packed: %s\n", e.what());
         return -3;
     }
 }

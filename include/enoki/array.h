@@ -634,6 +634,68 @@ inline void scatter_add(Target &target, const Value &value, const Index &index, 
 //  Gather / scatter of STATIC arrays and scalars from raw memory (array_router.h:1075-1131): what a function that runs
 //  under vectorize() uses for indirect accesses -- `mem` is then a device pointer captured by the kernel's functor.
 // ---------------------------------------------------------------------------------------------
+namespace detail {
+    /// One record of N scalars, loaded / stored with ONE memory instruction when N * sizeof(S) is 8 or 16 and the table is
+    /// aligned to it -- a random lookup costs one request per record instead of one per component
+#if defined(__clang__)
+    template <typename S, size_t N> struct PackedRecord {
+        typedef S Vec __attribute__((ext_vector_type(N)));   // stays ONE load / store through the optimiser
+        Vec v = Vec(0);
+        S get(size_t k) const { return v[k]; }
+        void set(size_t k, S x) { v[k] = x; }
+    };
+    template <typename S, size_t N> constexpr bool packed_record_v =
+        std::is_arithmetic_v<S> && !std::is_same_v<S, bool> && (N * sizeof(S) == 8 || N * sizeof(S) == 16);
+#else
+    template <typename S, size_t N> struct PackedRecord { S v[N] = { }; S get(size_t k) const { return v[k]; } void set(size_t k, S x) { v[k] = x; } };
+    template <typename S, size_t N> constexpr bool packed_record_v = false;
+#endif
+
+    template <typename Array, typename Stored, typename Index, typename Mask>
+    inline Array gather_packed(const Stored *mem, const Index &index, const Mask &mask) {
+        using Inner = value_t<Array>;                     // a packet: Array<S, lanes>
+        using S = scalar_t<Array>;
+        constexpr size_t N = Array::Size;
+        Array r;
+        for (size_t i = 0; i < Inner::Size; ++i) {
+            bool on;
+            if constexpr (is_array_v<Mask>) on = mask.coeff(i); else on = mask;
+            const size_t at = (size_t) index.coeff(i) * N;
+            if constexpr (packed_record_v<Stored, N>) {
+                if (((uintptr_t) mem & (N * sizeof(Stored) - 1)) == 0) {
+                    PackedRecord<Stored, N> rec;
+                    if (on) rec = *reinterpret_cast<const PackedRecord<Stored, N> *>(mem + at);
+                    for (size_t k = 0; k < N; ++k) r.coeff(k).coeff(i) = (S) rec.get(k);
+                    continue;
+                }
+            }
+            for (size_t k = 0; k < N; ++k) r.coeff(k).coeff(i) = on ? (S) mem[at + k] : S(0);
+        }
+        return r;
+    }
+
+    template <typename Stored, typename Value, typename Index, typename Mask>
+    inline void scatter_packed(Stored *mem, const Value &value, const Index &index, const Mask &mask) {
+        using Inner = value_t<Value>;
+        constexpr size_t N = Value::Size;
+        for (size_t i = 0; i < Inner::Size; ++i) {
+            bool on;
+            if constexpr (is_array_v<Mask>) on = mask.coeff(i); else on = mask;
+            if (!on) continue;
+            const size_t at = (size_t) index.coeff(i) * N;
+            if constexpr (packed_record_v<Stored, N>) {
+                if (((uintptr_t) mem & (N * sizeof(Stored) - 1)) == 0) {
+                    PackedRecord<Stored, N> rec;
+                    for (size_t k = 0; k < N; ++k) rec.set(k, (Stored) value.coeff(k).coeff(i));
+                    *reinterpret_cast<PackedRecord<Stored, N> *>(mem + at) = rec;
+                    continue;
+                }
+            }
+            for (size_t k = 0; k < N; ++k) mem[at + k] = (Stored) value.coeff(k).coeff(i);
+        }
+    }
+}
+
 template <typename Array, size_t Stride = 0, typename Index, typename Mask = bool,
           enable_if_t<!is_array_v<Array> || !is_dynamic_v<Array>> = 0>
 inline Array gather(const void *mem, const Index &index, const Mask &mask = true) {
@@ -642,6 +704,10 @@ inline Array gather(const void *mem, const Index &index, const Mask &mask = true
     if constexpr (!is_array_v<Array>) {
         return mask ? (Array) static_cast<const Stored *>(mem)[index] : Array(0);
     } else {
+        if constexpr (std::decay_t<Array>::Depth == 2) {
+            // packed records (array_router.h:1097-1107): component k of record i lives at mem[index[i] * Size + k]
+            return detail::gather_packed<Array>(static_cast<const Stored *>(mem), index, mask);
+        } else {
         static_assert(std::decay_t<Array>::Depth == 1, "gather(): arrays of scalars only");
         Array r;
         for (size_t i = 0; i < Array::Size; ++i) {
@@ -650,6 +716,7 @@ inline Array gather(const void *mem, const Index &index, const Mask &mask = true
             r.coeff(i) = on ? (S) static_cast<const Stored *>(mem)[index.coeff(i)] : S(0);
         }
         return r;
+        }
     }
 }
 
@@ -661,11 +728,15 @@ inline void scatter(void *mem, const Value &value, const Index &index, const Mas
     if constexpr (!is_array_v<Value>) {
         if (mask) static_cast<Stored *>(mem)[index] = (Stored) value;
     } else {
+        if constexpr (std::decay_t<Value>::Depth == 2) {
+            detail::scatter_packed(static_cast<Stored *>(mem), value, index, mask);
+        } else {
         static_assert(std::decay_t<Value>::Depth == 1, "scatter(): arrays of scalars only");
         for (size_t i = 0; i < Value::Size; ++i) {
             bool on;
             if constexpr (is_array_v<Mask>) on = mask.coeff(i); else on = mask;
             if (on) static_cast<Stored *>(mem)[index.coeff(i)] = (Stored) value.coeff(i);
+        }
         }
     }
 }

@@ -106,3 +106,6 @@ def test_cfg4_headline_image_bit_exact():
     fused = ctypes.CDLL(os.path.join(here, "..", "examples", "libsphere_fused.so"))
     fi, fh = run(fused.sphere_fused, *args)
     assert fh == ph and np.array_equal(fi.view(np.uint32), pi.view(np.uint32))
+    # ... and over packed {x, y} records (one 8-byte lookup per ray)
+    fi, fh = run(fused.sphere_fused_packed, *args)
+    assert fh == ph and np.array_equal(fi.view(np.uint32), pi.view(np.uint32))

@@ -68,14 +68,24 @@ def test_hip_cfg4_bit_exact(res):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("res", [8, 64, 257, 1024])
-def test_hip_cfg4_fused_bit_exact(res):
-    """the same program as ONE kernel through enoki::vectorize() (examples/sphere_fused.cpp): bit-identical image"""
+@pytest.mark.parametrize("entry", ["sphere_fused", "sphere_fused_packed"])
+def test_hip_cfg4_fused_bit_exact(res, entry):
+    """the same program as ONE kernel through enoki::vectorize() (examples/sphere_fused.cpp): bit-identical image, with
+    the pixel grid as two planes or as packed {x, y} records (ONE 8-byte lookup per ray, array.h gather_packed)"""
     lib = ctypes.CDLL(os.path.join(HERE, "..", "examples", "libsphere_fused.so"))
     args = scene(res, seed=res + 1)
-    gi, gh = run(lib.sphere_fused, *args)
+    gi, gh = run(getattr(lib, entry), *args)
     pi, ph = run(ol.port().lib.orc_cfg4, *args)
     assert gh == ph and np.array_equal(gi.view(np.uint32), pi.view(np.uint32))
     assert gh > 0 and gi.max() > 100
+
+
+def test_packed_record_gather_scatter_on_host_packets():
+    """gather<Array<Packet, N>>(mem, index, mask) / scatter of packed records (array.h; array_router.h:1097-1107)"""
+    import subprocess
+    out = subprocess.run([os.path.join(HERE, "cpp", "packed_host.bin")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "packed_host:" in out.stdout
 
 
 @pytest.mark.gpu
