@@ -38,7 +38,7 @@ EXPORTS = [
     "ek_hip_last_error", "ek_hip_malloc", "ek_hip_free", "ek_hip_malloc_trim", "ek_hip_host_malloc",
     "ek_hip_host_free", "ek_hip_mem_get_info", "ek_hip_memcpy_to_device", "ek_hip_memcpy_to_host",
     "ek_hip_memcpy_device", "ek_hip_memset", "ek_hip_whos", "ek_hip_set_log_level", "ek_hip_log_level",
-    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_scatter_add_multi", "ek_hip_concat",
+    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_gather_multi_sized", "ek_hip_gather_multi_plan", "ek_hip_scatter_add_multi", "ek_hip_concat",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
@@ -307,6 +307,23 @@ def gather(src, index, mask=True, n=None):
     check(lib.ek_hip_gather(src.ek, index.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(src.ptr), ctypes.byref(oi),
                             ctypes.byref(om), ctypes.c_size_t(n)))
     return out
+
+
+def gather_multi(tables, index, mask=True, n=None, sized=True):
+    """outs[c][i] = mask[i] ? tables[c][index[i]] : 0 for 2..4 tables of one length sharing ONE index / mask array
+    (ek_hip_gather_multi_sized: may stage {x, y, ..} records; ``sized=False``: plain ek_hip_gather_multi)"""
+    n = _n(index, mask) if n is None else n
+    count = len(tables)
+    outs = [Buf(tables[0].dtype, n) for _ in range(count)]
+    oi = operand(index); om = operand(mask, np.uint8)
+    po = (ctypes.c_void_p * count)(*[o.ptr for o in outs])
+    pb = (ctypes.c_void_p * count)(*[t.ptr for t in tables])
+    if sized:
+        check(lib.ek_hip_gather_multi_sized(tables[0].ek, index.ek, count, po, pb, ctypes.c_size_t(tables[0].n), ctypes.byref(oi),
+                                            ctypes.byref(om), ctypes.c_size_t(n)))
+    else:
+        check(lib.ek_hip_gather_multi(tables[0].ek, index.ek, count, po, pb, ctypes.byref(oi), ctypes.byref(om), ctypes.c_size_t(n)))
+    return outs
 
 
 class G:

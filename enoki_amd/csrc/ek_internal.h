@@ -29,6 +29,7 @@ struct Tuning {
     int reduce_blocks_per_cu = 4;
     int scatter_add_binned = 1;   // 1: LDS-binned scatter_add for large inputs, 0: global atomics only
     int deterministic = 0;        // 1: fp scatter_add always takes the bit-reproducible sorted path (ENOKI_HIP_DETERMINISTIC)
+    int gather_records = 1;       // struct gathers through staged {x, y, ..} records: 1 by size, 2 always, 0 never
 };
 
 struct Context {

@@ -130,6 +130,116 @@ int gather_multi_dispatch(int count, void *const *outs, const void *const *bases
     }
 }
 
+// Struct gathers through staged records.  Every lookup that misses the L2 is one 64-byte request to the fabric whatever
+// its width, and that request rate -- not bytes -- bounds a random gather (profiles/rocprof_l2_r0*.txt).  C tables of K
+// entries are therefore first interleaved into ONE table of K records of R = 2 or 4 slots (8 or 16 bytes; a third
+// component is padded to four), a streaming pass of (C + R) * sizeof(T) * K bytes, and the gather issues one R-slot load
+// per element instead of C scalar ones.
+template <typename T, int C, int R>
+__global__ __launch_bounds__(256) void k_stage_records(Pack<T, R> *__restrict__ rec, TablePtrs<T, C> t, size_t k, int vec_ok) {
+    constexpr int N = 16 / sizeof(T);
+    const size_t e = ((size_t) blockIdx.x * 256 + threadIdx.x) * N;
+    if (e >= k) return;
+    if (vec_ok && e + N <= k) {
+        Pack<T, N> p[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) p[c] = pack_load<T, N, false>(t.base[c] + e);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            Pack<T, R> r;
+#pragma unroll
+            for (int c = 0; c < R; ++c) r.v[c] = c < C ? p[c < C ? c : 0].v[j] : T(0);
+            rec[e + j] = r;
+        }
+    } else {
+        for (size_t i = e; i < k && i < e + N; ++i) {
+            Pack<T, R> r;
+#pragma unroll
+            for (int c = 0; c < R; ++c) r.v[c] = c < C ? t.base[c < C ? c : 0][i] : T(0);
+            rec[i] = r;
+        }
+    }
+}
+
+template <typename T, typename I, int N, int C, int R>
+__global__ __launch_bounds__(256) void k_gather_records(TablePtrs<T, C> t, const Pack<T, R> *__restrict__ rec, Arg<I> index,
+                                                        Arg<uint8_t> mask, size_t n, int vec_ok) {
+    const I si = index.vec ? I(0) : arg_scalar(index);
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    const size_t e = lane_elem<N, 1>(0);
+    if (e >= n) return;
+    const bool fast = vec_ok && e + N <= n;
+    Pack<I, N> pi = arg_load<I, N, true>(index, si, e, n, fast);
+    Pack<uint8_t, N> pm = arg_load<uint8_t, N, true>(mask, sm, e, n, fast);
+    Pack<T, R> got[N];
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        Pack<T, R> zero;
+#pragma unroll
+        for (int c = 0; c < R; ++c) zero.v[c] = T(0);
+        got[k] = (pm.v[k] && e + k < n) ? rec[index_offset(pi.v[k])] : zero;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        Pack<T, N> po;
+#pragma unroll
+        for (int k = 0; k < N; ++k) po.v[k] = got[k].v[c];
+        out_store<T, N, true>(t.out[c], po, e, n, fast);
+    }
+}
+
+/// Worth staging?  Fitted to profiles/probe_gather_records_r02.txt (C = 2..4, K = 256 Ki..32 Mi entries, 1 Mi..64 Mi lookups):
+///  * a table that fits the 4 MiB L2 of an XCD is left alone -- its lookups mostly hit, the gain is a few percent, and the
+///    binding can keep such gathers unevaluated and fuse them into their consumers, which is worth as much;
+///  * beyond that every component lookup that misses is one fabric request of ~16 ps, and records save C - 1 of them
+///    for the share of the table that does not fit (1 - 4 MiB / table), of which 80 % is counted;
+///  * staging streams (C + R) * sizeof(T) bytes per entry at ~5 TB/s plus ~10 us of launch and allocation, with a 25 %
+///    margin.  The rule reproduces every win / loss of the probe outside +-8 %.
+static bool gather_records_pays(int mode, int count, size_t elem, size_t base_size, size_t n) {
+    if (mode == 0 || base_size == 0) return false;
+    if (mode == 2) return true;
+    const double table = (double) elem * (double) base_size, l2 = (double) ((size_t) 4 << 20);
+    if (table <= l2) return false;
+    const int slots = count == 2 ? 2 : 4;
+    const double saved_ps = (double) (count - 1) * 16.0 * (1.0 - l2 / table) * 0.8 * (double) n;
+    const double stage_ps = (double) (count + slots) * table * 0.2 + 1e7;
+    return saved_ps > 1.25 * stage_ps;
+}
+
+template <typename T, typename I, int C>
+int gather_records_launch(void *const *outs, const void *const *bases, size_t base_size, const ek_operand *index,
+                          const ek_operand *mask, size_t n) {
+    constexpr int R = C == 2 ? 2 : 4;
+    constexpr int N = 16 / (sizeof(T) > sizeof(I) ? sizeof(T) : sizeof(I));
+    Arg<I> ii;
+    Arg<uint8_t> mm;
+    if (int rc = make_arg<I>(index, n, ii, "ek_hip_gather_multi_sized")) return rc;
+    if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_gather_multi_sized")) return rc;
+    TablePtrs<T, C> t;
+    int vec_ok = arg_aligned(ii) && arg_aligned(mm), stage_vec = 1;
+    for (int c = 0; c < C; ++c) {
+        if (!outs[c] || !bases[c]) return fail(EK_ERR_INVALID, "ek_hip_gather_multi_sized(): null pointer");
+        t.base[c] = (const T *) bases[c];
+        t.out[c] = (T *) outs[c];
+        vec_ok = vec_ok && aligned16(outs[c]);
+        stage_vec = stage_vec && aligned16(bases[c]);
+    }
+    void *rec = nullptr;
+    if (int rc = ek_hip_malloc(base_size * sizeof(Pack<T, R>), &rec)) return rc;
+    Context &c = ctx();
+    constexpr size_t per_block = 256 * (16 / sizeof(T));
+    hipLaunchKernelGGL((k_stage_records<T, C, R>), dim3((unsigned) ((base_size + per_block - 1) / per_block)), dim3(256), 0, c.stream,
+                       (Pack<T, R> *) rec, t, base_size, stage_vec);
+    note_launch("gather_stage_records", base_size, (size_t) (C + R) * sizeof(T) * base_size);
+    unsigned grid = (unsigned) ((n + (size_t) 256 * N - 1) / ((size_t) 256 * N));
+    hipLaunchKernelGGL((k_gather_records<T, I, N, C, R>), dim3(grid), dim3(256), 0, c.stream, t, (const Pack<T, R> *) rec, ii, mm, n, vec_ok);
+    int rc = EK_OK;
+    if (hipError_t e = hipGetLastError(); e != hipSuccess) rc = hip_fail(e, "k_gather_records", __FILE__, __LINE__);
+    else note_launch("gather_records", n, arg_bytes(ii, n) + arg_bytes(mm, n) + (size_t) C * 2 * n * sizeof(T));
+    ek_hip_free(rec);                 // stream-ordered reuse: the kernel above is already enqueued
+    return rc;
+}
+
 // ---- scatter / scatter_add ---------------------------------------------------------------------
 template <typename T> __device__ __forceinline__ void atomic_add(T *addr, T v) {
     if constexpr (std::is_same_v<T, float>) {
@@ -372,6 +482,48 @@ int ek_hip_gather_multi(int type, int index_type, int count, void *const *outs, 
         case 8: EK_INDEX_SWITCH(index_type, (gather_multi_dispatch<uint64_t, I>(count, outs, bases, index, mask, n)), "ek_hip_gather_multi()")
         default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_gather_multi(): 4- and 8-byte element types only");
     }
+}
+
+int ek_hip_gather_multi_plan(int type, int index_type, int count, size_t base_size, size_t n) {
+    if (ensure_init()) return EK_GATHER_ONE_LAUNCH;
+    const size_t elem = type_size(type);
+    const bool narrow = index_type == EK_U32 || index_type == EK_I32;
+    const bool shape_ok = (elem == 4 && count >= 2 && count <= 4) || (elem == 8 && count == 2);
+    if (narrow && shape_ok && base_size <= ((size_t) 1 << 32) &&
+        gather_records_pays(ctx().tuning.gather_records, count, elem, base_size, n))
+        return EK_GATHER_RECORDS;
+    // One launch reads the indices once, but its working set is ALL tables: when one table fits the 4 MiB L2 of an XCD
+    // and the set does not, one launch per table is up to 2x faster (profiles/probe_gather_multi_r01.txt)
+    if (base_size != 0 && (size_t) count * elem * base_size > ((size_t) 3 << 20) && elem * base_size < ((size_t) 128 << 20))
+        return EK_GATHER_PER_TABLE;
+    return EK_GATHER_ONE_LAUNCH;
+}
+
+int ek_hip_gather_multi_sized(int type, int index_type, int count, void *const *outs, const void *const *bases, size_t base_size,
+                              const ek_operand *index, const ek_operand *mask, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!outs || !bases) return fail(EK_ERR_INVALID, "ek_hip_gather_multi_sized(): null pointer");
+    const size_t elem = type_size(type);
+    int plan = ek_hip_gather_multi_plan(type, index_type, count, base_size, n);
+    if (plan == EK_GATHER_RECORDS && (!index || !index->ptr)) plan = EK_GATHER_ONE_LAUNCH;     // one record for all lanes
+    if (plan == EK_GATHER_PER_TABLE) {
+        for (int c = 0; c < count; ++c)
+            if (int rc = ek_hip_gather(type, index_type, outs[c], bases[c], index, mask, n)) return rc;
+        return EK_OK;
+    }
+    if (plan == EK_GATHER_ONE_LAUNCH) return ek_hip_gather_multi(type, index_type, count, outs, bases, index, mask, n);
+    RoctxRange range("enoki-hip: struct gather through staged records");
+#define EK_RECORDS(T, C)                                                                                               \
+    (index_type == EK_U32 ? gather_records_launch<T, uint32_t, C>(outs, bases, base_size, index, mask, n)              \
+                          : gather_records_launch<T, int32_t, C>(outs, bases, base_size, index, mask, n))
+    if (elem == 8) return EK_RECORDS(uint64_t, 2);
+    switch (count) {
+        case 2: return EK_RECORDS(uint32_t, 2);
+        case 3: return EK_RECORDS(uint32_t, 3);
+        default: return EK_RECORDS(uint32_t, 4);
+    }
+#undef EK_RECORDS
 }
 
 int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value, const ek_operand *index,

@@ -591,6 +591,7 @@ int ek_hip_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "reduce_blocks_per_cu") && value > 0) t.reduce_blocks_per_cu = value;
     else if (!strcmp(key, "scatter_add_binned") && (value == 0 || value == 1)) t.scatter_add_binned = value;
     else if (!strcmp(key, "deterministic") && (value == 0 || value == 1)) t.deterministic = value;
+    else if (!strcmp(key, "gather_records") && value >= 0 && value <= 2) t.gather_records = value;
     else return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): unknown key/value %s=%d", key, value);
     return EK_OK;
 }

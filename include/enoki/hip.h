@@ -671,9 +671,11 @@ template <typename Value_> struct HIPArray : ArrayTag {
             return false;
         } else {
             size_t table_bytes = 0;
+            bool same_size = true;
             for (size_t c = 0; c < N; ++c) {
                 if (sources[c].size() <= 1) return false;          // broadcast components take the generic path
                 table_bytes = std::max(table_bytes, sources[c].size() * sizeof(Value));
+                same_size &= sources[c].size() == sources[0].size();
             }
             // One launch reads the indices once, but its working set is ALL tables: when one table fits the 4 MiB L2 of
             // an XCD and the set does not, separate launches are up to 2x faster (profiles/probe_gather_multi_r01.txt)
@@ -681,7 +683,12 @@ template <typename Value_> struct HIPArray : ArrayTag {
                 const char *e = getenv("ENOKI_HIP_GATHER_MULTI");
                 return !e ? 0 : (e[0] == 'a' ? 1 : e[0] == 'n' ? 2 : 0);      // always / never / (default) by size
             }();
-            if (policy == 2 || (policy == 0 && N * table_bytes > gather_multi_small_ && table_bytes < gather_multi_large_))
+            // components of one length (the usual structure of arrays): the library picks between staged {x, y, ..}
+            // records, one launch over all tables and one launch per table (ek_hip_gather_multi_sized)
+            const bool sized = policy == 0 && same_size &&
+                ek_hip_gather_multi_plan(Type, Index::Type, (int) N, sources[0].size(),
+                                         broadcast_size(index.size(), mask.size())) == EK_GATHER_RECORDS;
+            if (policy == 2 || (policy == 0 && !sized && N * table_bytes > gather_multi_small_ && table_bytes < gather_multi_large_))
                 return false;
             size_t n = broadcast_size(index.size(), mask.size());
             void *outs[N];
@@ -692,7 +699,11 @@ template <typename Value_> struct HIPArray : ArrayTag {
                 bases[c] = sources[c].data();
             }
             ek_operand oi = index.operand(), om = mask.operand();
-            detail::hip_check(ek_hip_gather_multi(Type, Index::Type, (int) N, outs, bases, &oi, &om, n), "gather_multi_");
+            if (sized)
+                detail::hip_check(ek_hip_gather_multi_sized(Type, Index::Type, (int) N, outs, bases, sources[0].size(), &oi, &om, n),
+                                  "gather_multi_");
+            else
+                detail::hip_check(ek_hip_gather_multi(Type, Index::Type, (int) N, outs, bases, &oi, &om, n), "gather_multi_");
             return true;
         }
     }

@@ -145,7 +145,7 @@ EK_API int ek_hip_graph_end(ek_hip_graph **out);
 EK_API int ek_hip_graph_launch(ek_hip_graph *graph);
 EK_API uint64_t ek_hip_graph_launch_count(const ek_hip_graph *graph);   /* kernel launches inside one replay */
 EK_API int ek_hip_graph_destroy(ek_hip_graph *graph);
-EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic" */
+EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic", "gather_records" */
 /* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
    launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of
    {"kernel", "launches", "total_ms", "bytes", "elements"}; `bytes` are the ALGORITHMIC bytes of the
@@ -195,6 +195,17 @@ EK_API int ek_hip_gather(int type, int index_type, void *out, const void *base,
  * mask[i] ? bases[c][index[i]] : 0.  4- and 8-byte element types. */
 EK_API int ek_hip_gather_multi(int type, int index_type, int count, void *const *outs, const void *const *bases,
                                const ek_operand *index, const ek_operand *mask, size_t n);
+/* The same with the tables' common length known (`base_size` entries each; 0 = unknown, plain ek_hip_gather_multi).  When
+ * the tables are too large for the L2 and there are enough lookups to pay for it, the components are first staged as
+ * packed 8- or 16-byte records {x, y(, z, w)} and every lane issues ONE request per element instead of `count`: random
+ * lookups are bound by the number of memory requests, not by bytes.  Same results bit for bit.
+ * Replaces the per-component gather_ calls of array_struct.h:9-40 for Array<CUDAArray<T>, N> sources. */
+enum { EK_GATHER_PER_TABLE = 0, EK_GATHER_ONE_LAUNCH = 1, EK_GATHER_RECORDS = 2 };
+/* which of the three ek_hip_gather_multi_sized() would take for this shape (callers that can leave per-table gathers
+ * unevaluated -- enoki/hip.h consumes them inside the next arithmetic kernel -- ask before committing to a launch) */
+EK_API int ek_hip_gather_multi_plan(int type, int index_type, int count, size_t base_size, size_t n);
+EK_API int ek_hip_gather_multi_sized(int type, int index_type, int count, void *const *outs, const void *const *bases,
+                                     size_t base_size, const ek_operand *index, const ek_operand *mask, size_t n);
 /* An operand that is read THROUGH an index array: value[i] = mask[i] ? table[index[i]] : 0 -- a gather (cuda.h:845-864)
  * whose result is consumed by the next vertical op instead of being written out.  The reference gets this for free:
  * its JIT emits the gather's `ld.global` into the consumer's kernel (jit.cu:1066-1217). */
