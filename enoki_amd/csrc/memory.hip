@@ -539,11 +539,40 @@ int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value
     }
 }
 
+/// 64-bit index ARRAYS into a table of known size <= 2^32 are narrowed once (12 bytes per element, streamed) so that a
+/// large scatter_add can take the binned / sorted paths, which are written for 32-bit indices.  The reference's tape
+/// records the offsets of every gather as Int64 (autodiff.cpp:355-366, 524-535), so the adjoint of a gather arrives
+/// here with 64-bit indices when the reference's own autodiff layer drives this library;
+/// the device atomics it would otherwise fall back to are ~8x slower on large inputs.
+static bool narrowable_index(int index_type, const ek_operand *index, size_t base_size, size_t n) {
+    return (index_type == EK_I64 || index_type == EK_U64) && index && index->ptr && index->size == n &&
+           base_size != 0 && base_size <= ((size_t) 1 << 32) && n >= ((size_t) 1 << 18) && n < ((size_t) 1 << 32);
+}
+
+struct NarrowedIndex {
+    void *ptr = nullptr;
+    ek_operand operand { nullptr, 0, 0 };
+    int make(int index_type, const ek_operand *index, size_t n) {
+        if (int rc = ek_hip_malloc(n * sizeof(uint32_t), &ptr)) return rc;
+        if (int rc = ek_hip_cast(index_type, EK_U32, ptr, index, n)) return rc;
+        operand = ek_operand{ ptr, 0, n };
+        return EK_OK;
+    }
+    ~NarrowedIndex() { if (ptr) ek_hip_free(ptr); }       // stream-ordered reuse: the consumers are already enqueued
+};
+
 int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size, const ek_operand *value,
                        const ek_operand *index, const ek_operand *mask, size_t n, int mode) {
     if (int rc = ensure_init()) return rc;
     if (n == 0) return EK_OK;
     if (!base) return fail(EK_ERR_INVALID, "ek_hip_scatter_add(): null pointer");
+    if (narrowable_index(index_type, index, base_size, n) && type != EK_BOOL &&
+        (mode == 1 || ctx().tuning.deterministic ||
+         (ctx().tuning.scatter_add_binned && scatter_add_binned_applicable(base_size, n, true, type_size(type))))) {
+        NarrowedIndex narrow;
+        if (int rc = narrow.make(index_type, index, n)) return rc;
+        return ek_hip_scatter_add(type, EK_U32, base, base_size, value, &narrow.operand, mask, n, mode);
+    }
     bool is_fp = type == EK_F32 || type == EK_F64;
     // the process-wide switch (ENOKI_HIP_DETERMINISTIC / tuning "deterministic") PROMOTES mode 0; an explicit mode 1 is a demand
     const bool promoted = mode == 0 && ctx().tuning.deterministic;
@@ -689,6 +718,11 @@ int ek_hip_scatter_add_multi(int type, int index_type, int count, void *const *b
             if (bases[d] == bases[c]) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi(): the tables must be distinct");
     }
     if (n == 0) return EK_OK;
+    if (narrowable_index(index_type, index, base_size, n) && type != EK_BOOL) {
+        NarrowedIndex narrow;
+        if (int rc = narrow.make(index_type, index, n)) return rc;
+        return ek_hip_scatter_add_multi(type, EK_U32, count, bases, base_size, values, weights, &narrow.operand, mask, n, mode);
+    }
     if (mode == 0 && ctx().tuning.deterministic) mode = 1;
     const bool fused = mode == 0 && ctx().tuning.scatter_add_binned && type != EK_BOOL &&
                        (index_type == EK_U32 || index_type == EK_I32) &&
@@ -766,6 +800,11 @@ int ek_hip_scatter_add_multi_map(int type, int index_type, int count, void *cons
             if (bases[d] == bases[c]) return fail(EK_ERR_INVALID, "ek_hip_scatter_add_multi_map(): the tables must be distinct");
     }
     if (n == 0) return EK_OK;
+    if (narrowable_index(index_type, index, base_size, n)) {
+        NarrowedIndex narrow;
+        if (int rc = narrow.make(index_type, index, n)) return rc;
+        return ek_hip_scatter_add_multi_map(type, EK_U32, count, bases, base_size, values, value_ops, weights, &narrow.operand, mask, n, mode);
+    }
     const bool deterministic = mode == 1 || (mode == 0 && ctx().tuning.deterministic);
     const bool fused = !deterministic && ctx().tuning.scatter_add_binned && (index_type == EK_U32 || index_type == EK_I32) &&
                        scatter_add_binned_multi_applicable(base_size, n, index->ptr != nullptr && index->size == n, type_size(type));

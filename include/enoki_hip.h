@@ -229,9 +229,11 @@ EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand
 /* mode 0: fastest -- LDS-binned accumulation for large inputs (needs `base_size`), hardware atomics otherwise;
            the order of fp additions is unspecified, like the reference's atom.global.add;
    mode 1: deterministic -- stable radix sort by index + sequential per-bin sums: bit-identical to the CPU
-           reference's element-order accumulation (dynamic.h:517-534).  Needs `base_size` and a 32-bit
+           reference's element-order accumulation (dynamic.h:517-534).  Needs `base_size` and an
            index array; under a mask ARRAY it synchronizes once (the number of active pairs is read back), otherwise not
-           at all.  Integer types are exact in either mode. */
+           at all.  Integer types are exact in either mode.
+   64-bit index arrays of 256 Ki+ elements into a table of known size <= 2^32 are narrowed once (the reference's tape
+   records gather offsets as Int64, autodiff.cpp:355-366) and then take the same paths as 32-bit ones. */
 EK_API int ek_hip_scatter_add(int type, int index_type, void *base, size_t base_size,
                               const ek_operand *value, const ek_operand *index,
                               const ek_operand *mask, size_t n, int mode);

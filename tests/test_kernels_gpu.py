@@ -623,6 +623,42 @@ def test_scatter_add_deterministic_switch(capi, oracle):
         capi.set_tuning("deterministic", 0)
 
 
+@pytest.mark.parametrize("index_dtype", [np.int64, np.uint64])
+@pytest.mark.parametrize("K", [1000, 1 << 20, (1 << 22) + 9])
+def test_scatter_add_64bit_index_arrays_take_the_fast_paths(capi, oracle, index_dtype, K):
+    """the reference's tape hands the adjoint of a gather 64-bit offsets (autodiff.cpp:355-366): large calls narrow them
+    once and run the binned kernels (no device atomics), the multi-table entry and the deterministic sort included"""
+    n = (1 << 19) + 977
+    rng = np.random.default_rng(K + 3)
+    idx = rng.integers(0, K, n).astype(index_dtype)
+    m = (rng.integers(0, 4, n) != 0).astype(np.uint8)
+    ival = rng.integers(-1000, 1000, n).astype(np.int32)
+    tgt = rng.integers(-5, 5, K).astype(np.int32)
+    d = up(capi, tgt)
+    capi.profile_begin()
+    capi.scatter_add(d, up(capi, ival), up(capi, idx), up(capi, m))
+    names = {p["kernel"] for p in capi.profile_end()}
+    assert "cast" in names and not any(k.startswith("scatter_add_atomic") or k == "scatter_add" for k in names), names
+    expect = tgt.copy(); np.add.at(expect, idx[m != 0].astype(np.int64), ival[m != 0])
+    assert np.array_equal(d.numpy(), expect)
+    # two weighted float tables through one 64-bit index array
+    vals = [rng.standard_normal(n).astype(np.float32) for _ in range(2)]
+    w = rng.standard_normal(n).astype(np.float32)
+    d2 = [up(capi, np.zeros(K, np.float32)) for _ in range(2)]
+    capi.scatter_add_multi(d2, [up(capi, v) for v in vals], up(capi, idx), up(capi, m), weights=[up(capi, w), None])
+    for c, v in enumerate([vals[0] * w, vals[1]]):
+        truth = np.zeros(K); np.add.at(truth, idx[m != 0].astype(np.int64), v[m != 0].astype(np.float64))
+        mag = np.zeros(K); np.add.at(mag, idx[m != 0].astype(np.int64), np.abs(v[m != 0]).astype(np.float64))
+        cnt = np.bincount(idx[m != 0].astype(np.int64), minlength=K) + 1
+        assert np.all(np.abs(d2[c].numpy() - truth) <= cnt * 2.0 ** -24 * mag + 1e-30), c
+    # deterministic order: bit-identical to the CPU element order, as with 32-bit indices
+    fval = (rng.standard_normal(n) * 10.0 ** rng.integers(-3, 4, n)).astype(np.float32)
+    ftgt = rng.standard_normal(K).astype(np.float32)
+    d3 = up(capi, ftgt)
+    capi.scatter_add(d3, up(capi, fval), up(capi, idx), up(capi, m), mode=1)
+    assert bits_equal(d3.numpy(), oracle.scatter(ftgt, fval, idx.astype(np.uint32), m, add=True))
+
+
 @pytest.mark.parametrize("pattern", ["all_same", "two_bins", "zipf", "one_bucket", "sorted"])
 @pytest.mark.parametrize("dt", [np.float32, np.uint32, np.float64, np.int64])
 def test_scatter_add_binned_skewed_indices(capi, pattern, dt):
