@@ -50,6 +50,16 @@ static int bench_cfg3b(size_t n, int steps) {
     }
     printf("reference tape + reference router + integration/enoki/hip.h: cfg3b n=%zu K=%zu: %.3f ms per step (best of %d), y = %.4f\n",
            n, K, best, steps, y_value);
+    // one more step under the library's per-launch events: which kernels the reference's layers issue
+    ek_hip_profile_begin();
+    {
+        set_requires_gradient(A); set_requires_gradient(B);
+        FloatD y = hsum(sin(fmadd(gather<FloatD>(A, idx), x, gather<FloatD>(B, idx))));
+        backward(y);
+        ek_hip_sync();
+    }
+    char *report = ek_hip_profile_end();
+    if (report) { printf("kernels of one step: %s\n", report); free(report); }
     return 0;
 }
 
