@@ -179,6 +179,16 @@ def build_checkers(force=False, verbose=True):
     mo = os.path.join(tcpp, "morton_host.bin")
     if force or _newer(mo, [os.path.join(tcpp, "morton_host.cpp"), os.path.join(ROOT, "include", "enoki", "morton.h")]):
         _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "morton_host.cpp"), "-o", mo])
+    hf = os.path.join(tcpp, "half_host.bin")
+    if force or _newer(hf, [os.path.join(tcpp, "half_host.cpp"), os.path.join(ROOT, "include", "enoki", "half.h"),
+                            os.path.join(ROOT, "include", "enoki", "array.h")]):
+        f16c = []
+        try:
+            with open("/proc/cpuinfo") as f:
+                f16c = ["-mf16c"] if " f16c" in f.read() else []       # compare with the instruction the reference's build uses
+        except OSError:
+            pass
+        _run(["g++", "-O1", "-std=c++17"] + f16c + [inc, os.path.join(tcpp, "half_host.cpp"), "-o", hf])
     pk = os.path.join(tcpp, "packed_host.bin")
     if force or _newer(pk, [os.path.join(tcpp, "packed_host.cpp"), os.path.join(ROOT, "include", "enoki", "array.h")]):
         _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "packed_host.cpp"), "-o", pk])

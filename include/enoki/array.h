@@ -742,6 +742,56 @@ inline void scatter(void *mem, const Value &value, const Index &index, const Mas
 }
 
 // ---------------------------------------------------------------------------------------------
+//  load / store of STATIC arrays and scalars from consecutive memory (array_router.h:886-1015).  Nested arrays are stored
+//  component after component, i.e. Array<Packet, 3> occupies 3 * Packet::Size scalars.  The aligned and unaligned spellings
+//  are the same code here (the packets of this header are plain C++ arrays; there is no aligned-move instruction to
+//  pick).  Masked forms leave inactive lanes zero (load) / untouched (store).  The memory type may differ from the
+//  array's scalar type only through the array's own converting constructor, e.g. Array<float, 4>(load<Array<half, 4>>(p)).
+// ---------------------------------------------------------------------------------------------
+namespace detail {
+    template <typename T, typename Mask> inline void load_into(T &dst, const scalar_t<T> *&mem, const Mask &mask) {
+        if constexpr (!is_array_v<T>) {
+            dst = mask ? *mem : T(0);
+            ++mem;
+        } else {
+            for (size_t i = 0; i < std::decay_t<T>::Size; ++i) {
+                if constexpr (is_array_v<Mask>) load_into(dst.coeff(i), mem, mask.coeff(i));
+                else load_into(dst.coeff(i), mem, mask);
+            }
+        }
+    }
+    template <typename T, typename Mask> inline void store_from(const T &src, scalar_t<T> *&mem, const Mask &mask) {
+        if constexpr (!is_array_v<T>) {
+            if (mask) *mem = src;
+            ++mem;
+        } else {
+            for (size_t i = 0; i < std::decay_t<T>::Size; ++i) {
+                if constexpr (is_array_v<Mask>) store_from(src.coeff(i), mem, mask.coeff(i));
+                else store_from(src.coeff(i), mem, mask);
+            }
+        }
+    }
+}
+
+template <typename T, typename Mask = bool, enable_if_t<!is_array_v<T> || !is_dynamic_v<T>> = 0>
+inline T load_unaligned(const void *mem, const Mask &mask = true) {
+    T result;
+    const scalar_t<T> *p = static_cast<const scalar_t<T> *>(mem);
+    detail::load_into(result, p, mask);
+    return result;
+}
+template <typename T, typename Mask = bool, enable_if_t<!is_array_v<T> || !is_dynamic_v<T>> = 0>
+inline T load(const void *mem, const Mask &mask = true) { return load_unaligned<T>(mem, mask); }
+
+template <typename T, typename Mask = bool, enable_if_t<!is_array_v<T> || !is_dynamic_v<T>> = 0>
+inline void store_unaligned(void *mem, const T &value, const Mask &mask = true) {
+    scalar_t<T> *p = static_cast<scalar_t<T> *>(mem);
+    detail::store_from(value, p, mask);
+}
+template <typename T, typename Mask = bool, enable_if_t<!is_array_v<T> || !is_dynamic_v<T>> = 0>
+inline void store(void *mem, const T &value, const Mask &mask = true) { store_unaligned(mem, value, mask); }
+
+// ---------------------------------------------------------------------------------------------
 //  Static arrays: Array<Value, N> -- N components stored side by side (SoA when Value is itself a
 //  dynamic array, e.g. Array<HIPArray<float>, 3> = three independent device arrays).  Every
 //  operation is applied component by component through the free functions above, so it costs N

@@ -1,0 +1,13 @@
+"""enoki/half.h (binary16 storage type) and load / store of static arrays (array.h): tests/cpp/half_host.cpp checks every
+encoding, 8.7 M roundings against an independent rounding in double arithmetic (and 70 M more against F16C when the
+machine has it), the reference's own Array<half, 4> test (tests/float.cpp:215-238) and the load / store forms."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def test_half_and_load_store_on_the_host():
+    out = subprocess.run([os.path.join(HERE, "cpp", "half_host.bin")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "65536 encodings" in out.stdout
