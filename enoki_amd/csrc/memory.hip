@@ -225,7 +225,8 @@ int gather_records_launch(void *const *outs, const void *const *bases, size_t ba
         stage_vec = stage_vec && aligned16(bases[c]);
     }
     void *rec = nullptr;
-    if (int rc = ek_hip_malloc(base_size * sizeof(Pack<T, R>), &rec)) return rc;
+    if (ek_hip_malloc(base_size * sizeof(Pack<T, R>), &rec) != EK_OK)      // no room for the records: the plain kernels need none
+        return gather_multi_launch<T, I, C>(outs, bases, index, mask, n);
     Context &c = ctx();
     constexpr size_t per_block = 256 * (16 / sizeof(T));
     hipLaunchKernelGGL((k_stage_records<T, C, R>), dim3((unsigned) ((base_size + per_block - 1) / per_block)), dim3(256), 0, c.stream,

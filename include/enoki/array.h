@@ -525,6 +525,13 @@ namespace detail {
 }
 
 namespace detail {
+    template <typename V, typename I, typename = void> struct has_gather_records : std::false_type { };
+    template <typename V, typename I>
+    struct has_gather_records<V, I, std::void_t<decltype(V::template gather_records_<2>(
+        (const V *) nullptr, (V *) nullptr, std::declval<const I &>(), std::declval<const mask_t<V> &>()))>> : std::true_type { };
+}
+
+namespace detail {
     /// Backends that can run several scatter_adds through one index array in one pass (HIPArray::scatter_add_multi_)
     template <typename T, typename I, typename = void> struct has_scatter_add_multi : std::false_type { };
     template <typename T, typename I>
@@ -952,7 +959,8 @@ template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     template <bool IsPermute, typename Index, typename Mask>
     static Array gather_array_(const Array &source, const Index &index, const Mask &mask) {
         Array r;
-        if constexpr (detail::has_gather_multi<Value, Index>::value && !is_diff_array_v<Index>) {
+        if constexpr (detail::has_gather_multi<Value, Index>::value &&
+                      (is_diff_array_v<Value> ? !IsPermute : !is_diff_array_v<Index>)) {
             // device components sharing one index array: one kernel instead of Size
             if (Value::template gather_multi_<Size>(source.m_data, r.m_data, index, detail::as<mask_t<Value>>(mask)))
                 return r;

@@ -596,6 +596,34 @@ template <typename Type_> struct DiffArray : ArrayTag {
         return create(idx, std::move(result));
     }
 
+    /// Structure-of-arrays gather (Array<DiffArray, N> sources) when the backend looks the N components up as ONE record
+    /// per element (HIPArray::gather_records_): the values come from that kernel, the tape gets the same N gather nodes as
+    /// from N calls of gather_array_ -- their adjoints share the index array and run as one multi-table scatter_add.
+    template <size_t N, typename Index_>
+    static bool gather_multi_(const DiffArray *sources, DiffArray *results, const Index_ &index, const MaskType &mask) {
+        if constexpr (!detail::has_gather_records<Type, std::decay_t<decltype(detach(index))>>::value) {
+            return false;
+        } else {
+            Type src[N], res[N];
+            for (size_t c = 0; c < N; ++c) src[c] = sources[c].m_value;
+            if (!Type::template gather_records_<N>(src, res, detach(index), mask.value_()))
+                return false;
+            for (size_t c = 0; c < N; ++c) {
+                Index idx = 0;
+                if constexpr (Enabled) {
+                    if (sources[c].m_index) {
+                        auto *t = tape();
+                        t->set_scatter_gather_operand(const_cast<Index *>(&sources[c].m_index), sources[c].size(), false);
+                        idx = t->append_gather(typename TapeType::Offset(detach(index)), mask.value_());
+                        t->set_scatter_gather_operand(nullptr, 0, false);
+                    }
+                }
+                results[c] = create(idx, std::move(res[c]));
+            }
+            return true;
+        }
+    }
+
     template <bool IsPermute, typename Index_>
     static void scatter_array_(DiffArray &target, const DiffArray &value, const Index_ &index, const MaskType &mask) {
         Type::template scatter_array_<IsPermute>(target.m_value, value.m_value, detach(index), mask.value_());

@@ -664,6 +664,22 @@ template <typename Value_> struct HIPArray : ArrayTag {
 
     static constexpr size_t gather_multi_small_ = (size_t) 3 << 20, gather_multi_large_ = (size_t) 128 << 20;
 
+    /// gather_multi_ restricted to the shapes that go through staged records (used by DiffArray, whose other struct
+    /// gathers stay one deferred gather per component so that their consumers can fuse them)
+    template <size_t N, typename Index>
+    static bool gather_records_(const HIPArray *sources, HIPArray *results, const Index &index, const MaskType &mask) {
+        if constexpr (IsMask || (sizeof(Value) != 4 && sizeof(Value) != 8) || N < 2 || N > 4) {
+            return false;
+        } else {
+            for (size_t c = 0; c < N; ++c)
+                if (sources[c].size() <= 1 || sources[c].size() != sources[0].size()) return false;
+            if (ek_hip_gather_multi_plan(Type, Index::Type, (int) N, sources[0].size(),
+                                         broadcast_size(index.size(), mask.size())) != EK_GATHER_RECORDS)
+                return false;
+            return gather_multi_<N>(sources, results, index, mask);
+        }
+    }
+
     /// N tables, one index / mask array: a single kernel that reads the indices once (Array<HIPArray, N> sources)
     template <size_t N, typename Index>
     static bool gather_multi_(const HIPArray *sources, HIPArray *results, const Index &index, const MaskType &mask) {
