@@ -217,6 +217,7 @@ int ek_hip_init(int device) {
     c.initialized = true;
     if (const char *lv = getenv("ENOKI_HIP_LOG")) c.log_level = (uint32_t) atoi(lv);
     if (const char *dv = getenv("ENOKI_HIP_DETERMINISTIC")) c.tuning.deterministic = atoi(dv) != 0;
+    if (const char *gr = getenv("ENOKI_HIP_GATHER_RECORDS")) { int v = atoi(gr); if (v >= 0 && v <= 2) c.tuning.gather_records = v; }
     if (c.log_level >= 1)
         fprintf(stderr, "enoki-hip: device %d (%s, %d CUs, %.1f GiB)\n", device, prop.name, c.num_cu,
                 (double) prop.totalGlobalMem / (1024.0 * 1024.0 * 1024.0));
