@@ -1,7 +1,7 @@
 // The tape (enoki_amd/src/autodiff_impl.h, Tape<HIPArray<float>>) on top of HIPArray's deferred nodes, under
 // AddressSanitizer + LeakSanitizer + UBSan and WITHOUT a GPU: the C ABI is the host stand-in of host_abi_stub.h.
 //
-// Random differentiable programs -- leaves, tables, shared-index gathers, arithmetic, unary maps, select, hsum, broadcast
+// Random differentiable programs -- leaves, tables, shared-index gathers, struct gathers through records, arithmetic, unary maps, select, hsum, broadcast
 // scalars -- are recorded and differentiated twice, once with every gather / unary result deferred (ENOKI_HIP_DEFER_MIN=1)
 // and once with deferral switched off.  The tape keeps deferred arrays as edge weights, hands them to the fused
 // scatter_add and hsum consumers, shares buffers between gradients: every value and every gradient must come out with the
@@ -51,7 +51,7 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
         auto pick = [&]() -> D & { return pool[rng() % pool.size()]; };
         for (int step = 0; step < 14; ++step) {
             D r;
-            switch (rng() % 11) {
+            switch (rng() % 12) {
                 case 0: r = sin(pick()); break;
                 case 1: r = cos(pick()) * pick(); break;
                 case 2: r = exp(pick() * D(F(0.2f))); break;
@@ -63,6 +63,12 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
                 case 8: { auto sc = sincos(pick()); r = sc.first * sc.second; break; }
                 case 9: r = pick() - hsum(sin(pick())) * D(F(1e-3f)); break;                             // reduction mid-graph
                 case 10: r = abs(pick()) * rcp(abs(pick()) + D(F(2.f))); break;
+                case 11: {                                                                       // struct gather: one record lookup,
+                    Array<D, 2> tables(leaves[2], leaves[3]);                                    // one tape node per component
+                    Array<D, 2> g = gather<Array<D, 2>>(tables, idx);
+                    r = fmadd(g.x(), pick(), g.y() * leaves[4]);
+                    break;
+                }
             }
             pool[rng() % pool.size()] = r;
         }
@@ -98,6 +104,7 @@ int main() {
     }
     hip_set_defer(true);
     CHECK(fused_total > 100);
+    CHECK(g_record_gathers > 20);
     printf("asan_tape: 60 fuzzed differentiable programs give identical values and gradients with and without deferred evaluation "
            "(%ld fused consumer launches), no block left allocated\n", fused_total);
     return 0;

@@ -196,6 +196,21 @@ int ek_hip_gather(int, int, void *out, const void *base, const ek_operand *index
     for (size_t i = 0; i < n; ++i) ((float *) out)[i] = op_m(mask, i) ? ((const float *) base)[op_u(index, i)] : 0.f;
     return EK_OK;
 }
+// struct gathers: the plan is "records" for every table of 64+ entries, so that the binding's record paths (HIPArray::
+// gather_records_, DiffArray::gather_multi_) run on the host stand-in
+static long g_record_gathers = 0;
+int ek_hip_gather_multi(int, int, int count, void *const *outs, const void *const *bases, const ek_operand *index,
+                        const ek_operand *mask, size_t n) {
+    for (int c = 0; c < count; ++c)
+        for (size_t i = 0; i < n; ++i) ((float *) outs[c])[i] = op_m(mask, i) ? ((const float *) bases[c])[op_u(index, i)] : 0.f;
+    return EK_OK;
+}
+int ek_hip_gather_multi_plan(int, int, int, size_t base_size, size_t) { return base_size >= 64 ? EK_GATHER_RECORDS : EK_GATHER_ONE_LAUNCH; }
+int ek_hip_gather_multi_sized(int type, int index_type, int count, void *const *outs, const void *const *bases, size_t base_size,
+                              const ek_operand *index, const ek_operand *mask, size_t n) {
+    if (base_size >= 64) ++g_record_gathers;
+    return ek_hip_gather_multi(type, index_type, count, outs, bases, index, mask, n);
+}
 int ek_hip_map_gathered(int arity, int op, int, void *out, const ek_operand *const *o, const ek_gathered *const *g, size_t n) {
     ++g_fused_calls;
     for (size_t i = 0; i < n; ++i) {
