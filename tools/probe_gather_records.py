@@ -24,11 +24,12 @@ def timed(tables, di, reps=6):
 
 
 print(f"{'C':>2} {'K':>10} {'n':>10} | {'plain us':>9} {'kernels':<28} | {'records us':>10} {'stage us':>8} | speedup | default plan")
-for count in (2, 3, 4):
-    for log2k in (18, 20, 21, 22, 23, 25):
+ONE = "--one" in sys.argv          # a single shape, for counter runs: tools/profile_gather_records.sh
+for count in ((3,) if ONE else (2, 3, 4)):
+    for log2k in ((23,) if ONE else (18, 20, 21, 22, 23, 25)):
         k = 1 << log2k
         tables = [ek.Buf.from_numpy(rng.standard_normal(k).astype(np.float32)) for _ in range(count)]
-        for log2n in (20, 22, 24, 26):
+        for log2n in ((24,) if ONE else (20, 22, 24, 26)):
             n = 1 << log2n
             di = ek.Buf.from_numpy(rng.integers(0, k, n).astype(np.uint32))
             ek.set_tuning("gather_records", 0)
