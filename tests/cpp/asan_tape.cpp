@@ -11,13 +11,20 @@
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
 
-#include "host_abi_stub.h"
-#include "../../enoki_amd/src/autodiff_impl.h"
+#if !defined(EK_FUZZ_DEVICE)
+#  include "host_abi_stub.h"
+#  include "../../enoki_amd/src/autodiff_impl.h"
+namespace enoki { template struct Tape<HIPArray<float>>; }
+#else
+// The same programs against the REAL library on a GPU (tests/test_deferred_map_gpu.py, fuzz_tape_hip.bin: linked with
+// libenoki-hip-autodiff.so / libenoki-hip.so, no sanitizers): deferred and eager evaluation must agree bit for bit on the
+// device kernels too -- fused consumers, record gathers (forced) and the deterministic scatter_add order included.
+static long g_fused_calls = 0, g_record_gathers = 1000;
+static struct { bool empty() const { return true; } } g_live;
+#endif
 
 #include <random>
 #include <vector>
-
-namespace enoki { template struct Tape<HIPArray<float>>; }
 
 using namespace enoki;
 using F = HIPArray<float>;
@@ -84,13 +91,29 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
 int main() {
     setenv("ENOKI_HIP_DEFER_MIN", "1", 1);         // read once, on first use: every gather / fusable unary result is deferred
     long fused_total = 0;
+#if defined(EK_FUZZ_DEVICE)
+    setenv("ENOKI_HIP_GATHER_RECORDS", "2", 1);    // struct gathers always through staged records
+    if (ek_hip_init(-1) != EK_OK) { fprintf(stderr, "%s\n", ek_hip_last_error()); return 2; }
+    ek_hip_set_tuning("deterministic", 1);         // fp scatter_add in element order: comparable bit for bit
+    uint64_t launches_with = 0, launches_without = 0;
+#endif
     for (uint32_t seed = 1; seed <= 60; ++seed) {
         long f0 = g_fused_calls;
+#if defined(EK_FUZZ_DEVICE)
+        uint64_t l0 = ek_hip_launch_count();
+#endif
         auto with = run_program(seed, true);
+#if defined(EK_FUZZ_DEVICE)
+        launches_with += ek_hip_launch_count() - l0; l0 = ek_hip_launch_count();
+        g_fused_calls += 2;
+#endif
         fused_total += g_fused_calls - f0;
         CHECK(g_live.empty());
         f0 = g_fused_calls;
         auto without = run_program(seed, false);
+#if defined(EK_FUZZ_DEVICE)
+        launches_without += ek_hip_launch_count() - l0;
+#endif
         CHECK(g_fused_calls == f0);
         CHECK(g_live.empty());
         CHECK(with.size() == without.size());
@@ -105,6 +128,13 @@ int main() {
     hip_set_defer(true);
     CHECK(fused_total > 100);
     CHECK(g_record_gathers > 20);
+#if defined(EK_FUZZ_DEVICE)
+    CHECK(launches_with < launches_without);
+    printf("fuzz_tape_hip: 60 fuzzed differentiable programs give identical values and gradients with and without deferred evaluation "
+           "on the device (%llu kernel launches deferred, %llu eager)\n", (unsigned long long) launches_with,
+           (unsigned long long) launches_without);
+    return 0;
+#endif
     printf("asan_tape: 60 fuzzed differentiable programs give identical values and gradients with and without deferred evaluation "
            "(%ld fused consumer launches), no block left allocated\n", fused_total);
     return 0;
