@@ -148,10 +148,12 @@ def build_checkers(force=False, verbose=True):
     if force or _newer(hip, [os.path.join(tcpp, "tape_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + deps):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "tape_hip.cpp"), "-o", hip,
               f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
-    fuzz = os.path.join(tcpp, "fuzz_tape_hip.bin")          # tests/cpp/asan_tape.cpp against the real library (runs on the GPU box)
-    if force or _newer(fuzz, [os.path.join(tcpp, "asan_tape.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + deps):
-        _run(["g++", "-O1", "-std=c++17", "-DEK_FUZZ_DEVICE", inc, os.path.join(tcpp, "asan_tape.cpp"), "-o", fuzz,
-              f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+    # tests/cpp/asan_tape.cpp against the real library (runs on the GPU box), in float32 and float64
+    for fuzz_name, fuzz_flags in (("fuzz_tape_hip.bin", []), ("fuzz_tape_hip_f64.bin", ["-DEK_FUZZ_DOUBLE"])):
+        fuzz = os.path.join(tcpp, fuzz_name)
+        if force or _newer(fuzz, [os.path.join(tcpp, "asan_tape.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + deps):
+            _run(["g++", "-O1", "-std=c++17", "-DEK_FUZZ_DEVICE"] + fuzz_flags + [inc, os.path.join(tcpp, "asan_tape.cpp"), "-o", fuzz,
+                  f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     sphere = os.path.join(tcpp, "libsphere_hip.so")
     if force or _newer(sphere, [os.path.join(tcpp, "sphere_hip.cpp"), os.path.join(HERE, "libenoki-hip.so")] + _headers()):
         _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wall", inc, os.path.join(tcpp, "sphere_hip.cpp"), "-o", sphere,

@@ -27,26 +27,31 @@ static struct { bool empty() const { return true; } } g_live;
 #include <vector>
 
 using namespace enoki;
-using F = HIPArray<float>;
+#if defined(EK_FUZZ_DEVICE) && defined(EK_FUZZ_DOUBLE)
+using Real = double;                               // the device build also runs in float64 (fuzz_tape_hip_f64.bin)
+#else
+using Real = float;
+#endif
+using F = HIPArray<Real>;
 using U = HIPArray<uint32_t>;
 using D = DiffArray<F>;
 using UD = DiffArray<U>;
 
 #define CHECK(expr) do { if (!(expr)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #expr); exit(1); } } while (0)
 
-static std::vector<float> host(const F &a) {
-    std::vector<float> v(a.size());
+static std::vector<Real> host(const F &a) {
+    std::vector<Real> v(a.size());
     for (size_t i = 0; i < v.size(); ++i) v[i] = a.coeff(i);
     return v;
 }
-static bool same(const std::vector<float> &a, const std::vector<float> &b) {
-    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * 4) == 0);
+static bool same(const std::vector<Real> &a, const std::vector<Real> &b) {
+    return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(Real)) == 0);
 }
 
-static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
+static std::vector<std::vector<Real>> run_program(uint32_t seed, bool defer) {
     hip_set_defer(defer);
     std::mt19937 rng(seed);
-    std::vector<std::vector<float>> seen;
+    std::vector<std::vector<Real>> seen;
     {
         const size_t n = 3000 + rng() % 2000, K = 64 + rng() % 200;
         // leaves: two arrays of size n, two tables of size K, one scalar
@@ -130,9 +135,9 @@ int main() {
     CHECK(g_record_gathers > 20);
 #if defined(EK_FUZZ_DEVICE)
     CHECK(launches_with < launches_without);
-    printf("fuzz_tape_hip: 60 fuzzed differentiable programs give identical values and gradients with and without deferred evaluation "
-           "on the device (%llu kernel launches deferred, %llu eager)\n", (unsigned long long) launches_with,
-           (unsigned long long) launches_without);
+    printf("fuzz_tape_hip: 60 fuzzed differentiable programs (float%d) give identical values and gradients with and without deferred "
+           "evaluation on the device (%llu kernel launches deferred, %llu eager)\n", (int) (8 * sizeof(Real)),
+           (unsigned long long) launches_with, (unsigned long long) launches_without);
     return 0;
 #endif
     printf("asan_tape: 60 fuzzed differentiable programs give identical values and gradients with and without deferred evaluation "
