@@ -1,16 +1,17 @@
 /*
-    enoki/stl.h -- std::pair and std::tuple as structures of arrays (reference: include/enoki/stl.h)
+    enoki/stl.h -- std::pair, std::tuple and std::array as structures of arrays (reference: include/enoki/stl.h)
 
     With this header included, pairs and tuples whose members are arrays behave like ENOKI_STRUCT types: zero / empty /
     slices / set_slices / gather / scatter / select work member by member, and enoki::vectorize() slices them as arguments
     and builds them as results -- `vectorize([](auto &&x) { return sincos(x); }, x)` returns a
-    std::pair<HIPArray<float>, HIPArray<float>> computed by one fused kernel.  (std::array is not covered: its
-    non-type template parameter does not fit the structure mapping; use Array<T, N>.)
+    std::pair<HIPArray<float>, HIPArray<float>> computed by one fused kernel.  std::array<T, N> is covered the same way
+    (N members of one type).
 */
 #pragma once
 
 #include <enoki/array.h>
 
+#include <array>
 #include <tuple>
 #include <utility>
 
@@ -45,6 +46,18 @@ template <typename... T> struct struct_support<std::tuple<T...>> {
     template <typename V2, typename F> static void apply2(Value &v, const V2 &w, F &&fn) { visit2(v, w, fn, std::index_sequence_for<T...>()); }
     template <typename V2, typename V3, typename F> static void apply3(Value &v, const V2 &w, const V3 &u, F &&fn) {
         visit3(v, w, u, fn, std::index_sequence_for<T...>());
+    }
+};
+
+template <typename T, size_t N> struct struct_support<std::array<T, N>> {
+    static constexpr bool Defined = true;
+    using Value = std::array<T, N>;
+    static constexpr size_t leaf_count = N * dynamic_leaf_count<std::decay_t<T>>::value;
+    template <typename F> static void apply(Value &v, F &&fn) { for (size_t i = 0; i < N; ++i) fn(v[i]); }
+    template <typename F> static void apply(const Value &v, F &&fn) { for (size_t i = 0; i < N; ++i) fn(v[i]); }
+    template <typename V2, typename F> static void apply2(Value &v, const V2 &w, F &&fn) { for (size_t i = 0; i < N; ++i) fn(v[i], w[i]); }
+    template <typename V2, typename V3, typename F> static void apply3(Value &v, const V2 &w, const V3 &u, F &&fn) {
+        for (size_t i = 0; i < N; ++i) fn(v[i], w[i], u[i]);
     }
 };
 

@@ -90,6 +90,9 @@ namespace detail {
     template <template <typename...> class S, typename... A>
     struct packet_of<S<A...>, enable_if_t<is_struct_v<S<A...>>>> { using type = S<typename packet_of<A>::type...>; };
 
+    template <typename T, size_t N>                                      // std::array with enoki/stl.h included
+    struct packet_of<std::array<T, N>, enable_if_t<is_struct_v<std::array<T, N>>>> { using type = std::array<typename packet_of<T>::type, N>; };
+
     template <typename P, typename = int> struct dynamic_of { using type = P; };
     template <> struct dynamic_of<void> { using type = void; };
     template <typename T> struct dynamic_of<T, enable_if_t<std::is_arithmetic_v<T>>> { using type = HIPArray<T>; };
@@ -99,6 +102,9 @@ namespace detail {
     };
     template <template <typename...> class S, typename... A>
     struct dynamic_of<S<A...>, enable_if_t<is_struct_v<S<A...>>>> { using type = S<typename dynamic_of<A>::type...>; };
+
+    template <typename T, size_t N>
+    struct dynamic_of<std::array<T, N>, enable_if_t<is_struct_v<std::array<T, N>>>> { using type = std::array<typename dynamic_of<T>::type, N>; };
 
     template <typename T> constexpr bool is_sliced_v =
         (is_array_v<T> && is_dynamic_v<T>) || (is_struct_v<T> && !std::is_same_v<typename packet_of<T>::type, T>);

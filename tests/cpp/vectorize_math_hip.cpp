@@ -40,7 +40,7 @@ template <typename Float, typename Case> static size_t mismatches(const Float &x
     return bad;
 }
 
-/// std::pair / std::tuple as results and as arguments of a fused kernel (include/enoki/stl.h)
+/// std::pair / std::tuple / std::array as results and as arguments of a fused kernel (include/enoki/stl.h)
 template <typename Float> static size_t stl_mismatches(const Float &x, const Float &y) {
     using UInt = HIPArray<std::conditional_t<sizeof(scalar_t<Float>) == 4, uint32_t, uint64_t>>;
     auto differ = [](const Float &a, const Float &b) { return count(neq(reinterpret_array<UInt>(a), reinterpret_array<UInt>(b))); };
@@ -50,7 +50,14 @@ template <typename Float> static size_t stl_mismatches(const Float &x, const Flo
     std::tuple<Float, Float, Float> t = vectorize([](auto &&a, auto &&b) { return std::make_tuple(a + b, a * b, fmadd(a, b, a)); }, x, y);
     bad += differ(std::get<0>(t), x + y) + differ(std::get<1>(t), x * y) + differ(std::get<2>(t), fmadd(x, y, x));
     Float packed = vectorize([](auto &&p) { return p.first - p.second; }, sc);             // a pair as a sliced ARGUMENT
-    return bad + differ(packed, ref.first - ref.second);
+    bad += differ(packed, ref.first - ref.second);
+    std::array<Float, 3> arr = vectorize([](auto &&a, auto &&b) {                          // std::array as a result ...
+        using P = std::decay_t<decltype(a)>;
+        return std::array<P, 3>{ { a + b, a - b, a * b } };
+    }, x, y);
+    bad += differ(arr[0], x + y) + differ(arr[1], x - y) + differ(arr[2], x * y);
+    Float folded = vectorize([](auto &&v) { return fmadd(v[0], v[1], v[2]); }, arr);       // ... and as a sliced argument
+    return bad + differ(folded, fmadd(x + y, x - y, x * y));
 }
 
 template <typename Scalar> static int run(size_t n, char *report, size_t report_size) {
