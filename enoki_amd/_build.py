@@ -121,6 +121,14 @@ def build_python(force=False, verbose=True):
         if force or _newer(mod, [src] + _headers() + [os.path.join(pydir, h) for h in os.listdir(pydir) if h.endswith(".h")]):
             jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall"] + inc +
                         [src, "-o", mod, f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN"])
+    # a downstream extension module written against the headers only (tests/test_user_extension_gpu.py)
+    user_src = os.path.join(ROOT, "tests", "cpp", "user_ext", "user_ext.cpp")
+    if os.path.exists(user_src):
+        user_mod = os.path.join(os.path.dirname(user_src), "user_ext" + ext)
+        if force or _newer(user_mod, [user_src] + _headers()):
+            jobs.append(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-fvisibility=hidden", "-Wall"] + inc +
+                        [user_src, "-o", user_mod, f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip",
+                         "-Wl,-rpath,$ORIGIN/../../../enoki_amd"])
     if jobs:
         with concurrent.futures.ThreadPoolExecutor(max_workers=4) as ex:
             list(ex.map(_run, jobs))
