@@ -40,9 +40,13 @@ using UD = DiffArray<U>;
 #define CHECK(expr) do { if (!(expr)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #expr); exit(1); } } while (0)
 
 static std::vector<Real> host(const F &a) {
+#if defined(EK_FUZZ_DEVICE)
+    return a.to_host();                             // one copy per array
+#else
     std::vector<Real> v(a.size());
     for (size_t i = 0; i < v.size(); ++i) v[i] = a.coeff(i);
     return v;
+#endif
 }
 static bool same(const std::vector<Real> &a, const std::vector<Real> &b) {
     return a.size() == b.size() && (a.empty() || memcmp(a.data(), b.data(), a.size() * sizeof(Real)) == 0);
@@ -102,7 +106,12 @@ int main() {
     ek_hip_set_tuning("deterministic", 1);         // fp scatter_add in element order: comparable bit for bit
     uint64_t launches_with = 0, launches_without = 0;
 #endif
-    for (uint32_t seed = 1; seed <= 60; ++seed) {
+#if defined(EK_FUZZ_DEVICE)
+    const uint32_t programs = 400;                 // 0.01 s each on the device
+#else
+    const uint32_t programs = 60;                  // ASan + UBSan on the host stand-in
+#endif
+    for (uint32_t seed = 1; seed <= programs; ++seed) {
         long f0 = g_fused_calls;
 #if defined(EK_FUZZ_DEVICE)
         uint64_t l0 = ek_hip_launch_count();
@@ -135,8 +144,8 @@ int main() {
     CHECK(g_record_gathers > 20);
 #if defined(EK_FUZZ_DEVICE)
     CHECK(launches_with < launches_without);
-    printf("fuzz_tape_hip: 60 fuzzed differentiable programs (float%d) give identical values and gradients with and without deferred "
-           "evaluation on the device (%llu kernel launches deferred, %llu eager)\n", (int) (8 * sizeof(Real)),
+    printf("fuzz_tape_hip: %u fuzzed differentiable programs (float%d) give identical values and gradients with and without deferred "
+           "evaluation on the device (%llu kernel launches deferred, %llu eager)\n", programs, (int) (8 * sizeof(Real)),
            (unsigned long long) launches_with, (unsigned long long) launches_without);
     return 0;
 #endif

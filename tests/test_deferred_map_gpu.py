@@ -219,11 +219,11 @@ def test_tape_suites_with_everything_deferred():
 @pytest.mark.gpu
 @pytest.mark.parametrize("exe_name", ["fuzz_tape_hip.bin", "fuzz_tape_hip_f64.bin"])
 def test_fuzzed_tape_programs_deferred_equals_eager_on_the_device(exe_name):
-    """tests/cpp/asan_tape.cpp (60 random differentiable programs: shared-index gathers, struct gathers through records,
+    """tests/cpp/asan_tape.cpp (400 random differentiable programs: shared-index gathers, struct gathers through records,
     unary maps, select, mid-graph reductions, sincos) linked against the REAL library: values and gradients with every
     gather / unary result deferred are bit-identical to eager evaluation (deterministic scatter_add order)"""
     import os, subprocess
     exe = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", exe_name)
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
-    assert "fuzz_tape_hip: 60 fuzzed" in out.stdout
+    assert "fuzz_tape_hip: 400 fuzzed" in out.stdout
