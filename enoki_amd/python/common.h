@@ -19,6 +19,7 @@
 
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
+#include <enoki/array_call.h>
 #include <enoki/matrix.h>
 #include <enoki/morton.h>
 #include <enoki/sh.h>
@@ -165,6 +166,22 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
       .def_static("empty", [](size_t size) { return empty<Array>(size); }, "size"_a = 1)
       .def_static("full", [](Scalar value, size_t size) { return full<Array>(value, size); }, "value"_a, "size"_a = 1);
 
+    // the rest of the reference's per-array surface (src/python/common.h:668-740): iteration over a host copy, a[mask],
+    // resize, the raw pointer as a property, shape()
+    cl.def("__iter__", [](const Array &a) {
+          auto host = detach(a).to_host();
+          py::list values;
+          for (auto v : host) values.append(py::cast((Scalar) v));
+          return py::iter(values);
+      })
+      .def("__getitem__", [](const Array &a, const Mask &mk) { return select(mk, a, Array(Scalar(0))); },
+           "a[mask]: the active entries, zero elsewhere (a select, common.h:699-701)")
+      .def("resize", [](Array &a, size_t size) { a.resize(size); })
+      .def_property_readonly("data", [](Array &a) { return (uintptr_t) a.data(); });
+    if constexpr (IsDiff)
+        cl.def_property_readonly("index", [](const Array &a) { return a.index_(); }, "index of the array's node on the tape (0: none)");
+    m.def("shape", [](const Array &a) { return std::vector<size_t>{ a.size() }; });
+
     m.def("slices", [](const Array &a) { return slices(a); });
     m.def("set_slices", [](Array &a, size_t n) { set_slices(a, n); });
     m.def("detach", [](const Array &a) { return Plain(detach(a)); });
@@ -301,6 +318,9 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
             m.def("carlson_rj", [](const Array &x, const Array &y, const Array &z, const Array &r) { return carlson_rj(x, y, z, r); });
             m.def("pow", [](const Array &a, const Array &b) { return pow(a, b); });
             m.def("pow", [](const Array &a, int b) { return pow(a, b); });
+            cl.def("__pow__", [](const Array &a, const Array &b) { return pow(a, b); })
+              .def("__pow__", [](const Array &a, int b) { return pow(a, b); })
+              .def("__pow__", [](const Array &a, Scalar b) { return pow(a, Array(b)); });
             m.def("fmod", [](const Array &a, const Array &b) { return fmod(a, b); });
             m.def("lerp", [](const Array &a, const Array &b, const Array &t) { return lerp(a, b, t); });
             m.def("clamp", [](const Array &v, const Array &lo, const Array &hi) { return clamp(v, lo, hi); });
@@ -322,6 +342,8 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("lzcnt", [](const Array &a) { return lzcnt(a); });
         m.def("tzcnt", [](const Array &a) { return tzcnt(a); });
         m.def("mulhi", [](const Array &a, const Array &b) { return mulhi(a, b); });
+        // floor(log2(a)) = (bits - 1) - lzcnt(a)  (array_router.h log2i, bound in src/python/common.h:832)
+        m.def("log2i", [](const Array &a) { return Array(Scalar(sizeof(Scalar) * 8 - 1)) - lzcnt(a); });
     }
 
     if constexpr (IsDiff && IsFloat) {
@@ -345,7 +367,19 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
           .def_static("simplify_graph", []() { Array::simplify_graph_(); })
           .def_static("set_log_level", [](uint32_t level) { Array::set_log_level_(level); })
           .def_static("push_prefix", [](const char *label) { Array::push_prefix_(label); })
-          .def_static("pop_prefix", []() { Array::pop_prefix_(); });
+          .def_static("pop_prefix", []() { Array::pop_prefix_(); })
+          .def_static("log_level", []() { return Array::log_level_(); })
+          .def_static("set_graph_simplification", [](bool value) { Array::set_graph_simplification_(value); });
+        // `with Float32.Scope("name"): ...` prefixes the labels of the nodes recorded inside (cuda_autodiff_1d.cpp:144-155)
+        struct Scope {
+            std::string name;
+            void enter() { Array::push_prefix_(name.c_str()); }
+            void exit(py::handle, py::handle, py::handle) { Array::pop_prefix_(); }
+        };
+        py::class_<Scope>(cl, "Scope")
+            .def(py::init([](const std::string &name) { return Scope{ name }; }))
+            .def("__enter__", &Scope::enter)
+            .def("__exit__", &Scope::exit);
     }
     return cl;
 }
@@ -597,6 +631,7 @@ template <typename Value, size_t N> py::class_<Matrix<Value, N>> bind_matrix(py:
         m.def("transform_compose_inverse", [](const Mat3 &s, const Quaternion<Value> &q, const Vec3 &t) { return transform_compose_inverse(s, q, t); });
     }
     m.def("transpose", [](const Mat &a) { return Mat(transpose(a)); });
+    cl.def_property_readonly("T", [](const Mat &a) { return Mat(transpose(a)); });
     m.def("trace", [](const Mat &a) { return trace(a); });
     m.def("frob", [](const Mat &a) { return frob(a); });
     m.def("diag", [](const Mat &a) { return Vec(diag(a)); });

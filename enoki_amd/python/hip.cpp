@@ -29,6 +29,15 @@ PYBIND11_MODULE(hip, m) {
     bind_complex<FloatC>(m, "Complex2f"); bind_complex<DoubleC>(m, "Complex2d");
     bind_quaternion<FloatC>(m, "Quaternion4f"); bind_quaternion<DoubleC>(m, "Quaternion4d");
     m.def("meshgrid", [](const FloatC &x, const FloatC &y) { return meshgrid(x, y); });
+    m.def("meshgrid", [](const DoubleC &x, const DoubleC &y) { return meshgrid(x, y); });
+    // groups of lanes holding the same 64-bit value (instance pointers), ascending by value: [(value, UInt32 lanes), ...]
+    // (cuda_1d.cpp:104-106 over cuda_partition; here the sort-based partition_ of enoki/array_call.h)
+    m.def("partition", [](const UInt64C &x) {
+        HIPArray<void *> pointers(x);
+        std::vector<std::pair<uint64_t, UInt32C>> groups;
+        for (const auto &g : pointers.partition_()) groups.emplace_back((uint64_t) (uintptr_t) g.first, g.second);
+        return groups;
+    });
 
     bind_cast<FloatC, Int32C>(f32); bind_cast<FloatC, UInt32C>(f32); bind_cast<FloatC, DoubleC>(f32);
     bind_cast<FloatC, Int64C>(f32); bind_cast<FloatC, UInt64C>(f32);

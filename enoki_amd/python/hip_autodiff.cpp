@@ -8,6 +8,8 @@ using DoubleC = HIPArray<double>;
 using DoubleD = DiffArray<HIPArray<double>>;
 using Int32D = DiffArray<HIPArray<int32_t>>;
 using UInt32D = DiffArray<HIPArray<uint32_t>>;
+using Int64D = DiffArray<HIPArray<int64_t>>;
+using UInt64D = DiffArray<HIPArray<uint64_t>>;
 using MaskD = DiffArray<HIPArray<bool>>;
 template <typename T> using DiffHIP = DiffArray<HIPArray<T>>;
 
@@ -20,6 +22,8 @@ PYBIND11_MODULE(hip_autodiff, m) {
     auto f64 = bind_array<DoubleD>(m, "Float64");       // Tape<HIPArray<double>> (autodiff.cpp:1240 analogue)
     auto i32 = bind_array<Int32D>(m, "Int32");
     auto u32 = bind_array<UInt32D>(m, "UInt32");
+    auto i64 = bind_array<Int64D>(m, "Int64");          // cuda_autodiff_1d.cpp:56-97 binds the 64-bit integers too
+    auto u64 = bind_array<UInt64D>(m, "UInt64");
     m.attr("Float") = m.attr("Float32");
     bind_vector_family<DiffHIP>(m);              // Vector{0..4}{m,i,u,f,d} (cuda_autodiff_{0..4}d.cpp)
     bind_matrix<FloatD, 2>(m, "Matrix2f"); bind_matrix<DoubleD, 2>(m, "Matrix2d");
@@ -37,6 +41,15 @@ PYBIND11_MODULE(hip_autodiff, m) {
     bind_cast<FloatD, Int32D>(f32); bind_cast<FloatD, UInt32D>(f32);
     bind_cast<Int32D, FloatD>(i32); bind_cast<Int32D, UInt32D>(i32);
     bind_cast<UInt32D, FloatD>(u32); bind_cast<UInt32D, Int32D>(u32);
+
+    i64.def(py::init([](const HIPArray<int64_t> &v) { return Int64D(v); }));
+    u64.def(py::init([](const HIPArray<uint64_t> &v) { return UInt64D(v); }));
+    bind_cast<FloatD, Int64D>(f32); bind_cast<FloatD, UInt64D>(f32);
+    bind_cast<Int64D, Int32D>(i64); bind_cast<Int64D, FloatD>(i64); bind_cast<Int64D, UInt64D>(i64);
+    bind_cast<UInt64D, UInt32D>(u64); bind_cast<UInt64D, FloatD>(u64); bind_cast<UInt64D, Int64D>(u64);
+    bind_cast<Int32D, Int64D>(i32); bind_cast<UInt32D, UInt64D>(u32);
+    m.def("meshgrid", [](const FloatD &x, const FloatD &y) { return meshgrid(x, y); });
+    m.def("meshgrid", [](const DoubleD &x, const DoubleD &y) { return meshgrid(x, y); });
 
     bind_memory<FloatD, UInt32D>(m); bind_memory<FloatD, Int32D>(m);
     bind_memory<UInt32D, UInt32D>(m); bind_memory<Int32D, UInt32D>(m);

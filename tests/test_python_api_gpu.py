@@ -495,3 +495,44 @@ def test_vector_scatter_add_is_one_binning_pass(ekc):
     ekc.scatter_add(T2, ekc.Vector3f(ekc.Float32(vals[0][:100]), ekc.Float32(2.0), ekc.Float32(vals[2][:100])), ekc.UInt32(idx[:100]), ekc.Mask(np.ones(100, np.uint8)))
     want = tgt[1].astype(np.float64); np.add.at(want, idx[:100], 2.0)
     assert np.array_equal(T2.y.numpy(), want.astype(np.float32))
+
+
+def test_remaining_per_array_surface(ekc, ek):
+    """the rest of src/python/common.h:668-740, 832, 882-892 and cuda_1d.cpp:104: iteration, a[mask], resize, .data, shape(),
+    ** , log2i, Matrix.T, partition, 64-bit integer arrays in the autodiff module, meshgrid on differentiable arrays"""
+    a = np.array([1.5, -2.0, 0.25, 8.0], np.float32)
+    x = ekc.Float32(a)
+    assert [v for v in x] == a.tolist() and list(ekc.UInt32(np.arange(3, dtype=np.uint32))) == [0, 1, 2]
+    assert np.array_equal(x[x > ekc.Float32(0.0)].numpy(), np.where(a > 0, a, 0).astype(np.float32))
+    assert x.data == x.data_ptr() and ekc.shape(x) == [4]
+    assert bits_equal((x ** 2).numpy(), (a * a).astype(np.float32))
+    assert bits_equal((ekc.abs(x) ** ekc.Float32(0.5)).numpy(), ekc.pow(ekc.abs(x), ekc.Float32(0.5)).numpy())
+    assert bits_equal((ekc.abs(x) ** 1.5).numpy(), ekc.pow(ekc.abs(x), ekc.Float32(1.5)).numpy())
+    r = ekc.Float32(3.0); r.resize(5)
+    assert r.numpy().tolist() == [3.0] * 5
+    v = np.array([1, 2, 3, 255, 256, 2 ** 31, 2 ** 32 - 1], np.uint32)
+    assert ekc.log2i(ekc.UInt32(v)).numpy().tolist() == [int(np.floor(np.log2(float(t)))) for t in v]
+    assert ekc.log2i(ekc.UInt64(np.array([1, 2 ** 40 + 5], np.uint64))).numpy().tolist() == [0, 40]
+    m4 = ekc.Matrix4f.translate(ekc.Vector3f(ekc.Float32(1.0), ekc.Float32(2.0), ekc.Float32(3.0)))
+    assert all(m4.T[i, j].numpy().tolist() == m4[j, i].numpy().tolist() for i in range(4) for j in range(4))
+    assert m4.T[3, 0].numpy().tolist() == [1.0] and m4[0, 3].numpy().tolist() == [1.0]
+    ptrs = np.array([0x7000, 0x5000, 0x7000, 0, 0x5000, 0x7000], np.uint64)
+    groups = ekc.partition(ekc.UInt64(ptrs))
+    assert [(g[0], g[1].numpy().tolist()) for g in groups] == [(0, [3]), (0x5000, [1, 4]), (0x7000, [0, 2, 5])]
+    # autodiff module: 64-bit integers, meshgrid, index, Scope, switches
+    i64 = ek.Int64(np.array([-5, 2 ** 40], np.int64))
+    assert (i64 + ek.Int64(np.array([5, 1], np.int64))).numpy().tolist() == [0, 2 ** 40 + 1]
+    assert ek.UInt64(ek.UInt32(np.array([7], np.uint32))).numpy().tolist() == [7]
+    gx, gy = ek.meshgrid(ek.Float32(np.array([0.0, 1.0], np.float32)), ek.Float32(np.array([5.0, 6.0, 7.0], np.float32)))
+    assert gx.numpy().tolist() == [0.0, 1.0] * 3 and gy.numpy().tolist() == [5.0, 5.0, 6.0, 6.0, 7.0, 7.0]
+    d = ek.Float32(a)
+    assert d.index == 0
+    ek.set_requires_gradient(d)
+    assert d.index != 0 and d.index == ek.gradient_index(d)
+    with ek.Float32.Scope("outer"):
+        y = d * d                                                  # the node's label becomes "outer/<op>" (autodiff.cpp:318-320)
+    assert "outer/" in ek.graphviz(y)
+    assert ek.Float32.log_level() == 0
+    ek.Float32.set_graph_simplification(False); ek.Float32.set_graph_simplification(True)
+    ek.backward(ek.hsum(y ** 2))                                   # d/dx x^4 = 4 x^3
+    assert np.allclose(ek.gradient(d).numpy(), 4 * a ** 3, rtol=1e-6)
