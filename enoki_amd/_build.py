@@ -203,6 +203,9 @@ def build_checkers(force=False, verbose=True):
         except OSError:
             pass
         _run(["g++", "-O1", "-std=c++17"] + f16c + [inc, os.path.join(tcpp, "half_host.cpp"), "-o", hf])
+    rt = os.path.join(tcpp, "router_host.bin")
+    if force or _newer(rt, [os.path.join(tcpp, "router_host.cpp"), os.path.join(ROOT, "include", "enoki", "array.h")]):
+        _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "router_host.cpp"), "-o", rt])
     pk = os.path.join(tcpp, "packed_host.bin")
     if force or _newer(pk, [os.path.join(tcpp, "packed_host.cpp"), os.path.join(ROOT, "include", "enoki", "array.h")]):
         _run(["g++", "-O1", "-std=c++17", inc, os.path.join(tcpp, "packed_host.cpp"), "-o", pk])

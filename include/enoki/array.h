@@ -384,6 +384,8 @@ template <typename T1, typename T2, enable_if_t<detail::all_arithmetic_v<T1, T2>
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T sqr(T a) { return a * a; }
 template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline bool isnan(T a) { return a != a; }
 template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T mulsign(T a, T b) { return std::signbit(b) ? -a : a; }
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T sign(T a) { return std::copysign(T(1), a); }
+template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T copysign(T a, T b) { return std::copysign(a, b); }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T rcp(T a) { return T(1) / a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T hsum(T a) { return a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline bool eq(T a, T b) { return a == b; }
@@ -946,6 +948,20 @@ template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     }
     auto all_() const { auto r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = r & m_data[i]; return r; }
     auto any_() const { auto r = m_data[0]; for (size_t i = 1; i < Size; ++i) r = r | m_data[i]; return r; }
+    /// number of active components (array_static.h count_): a size_t for masks of bools, per lane for nested static masks
+    auto count_() const {
+        if constexpr (std::is_same_v<Value_, bool>) {
+            size_t r = 0;
+            for (size_t i = 0; i < Size; ++i) r += m_data[i] ? 1 : 0;
+            return r;
+        } else {
+            static_assert(is_array_v<Value_> && !is_dynamic_v<Value_>, "count(): per-component device masks: use count(m.x()) ...");
+            Array<size_t, Value_::Size> r(size_t(0));
+            for (size_t i = 0; i < Size; ++i)
+                for (size_t j = 0; j < Value_::Size; ++j) r.coeff(j) += m_data[i].coeff(j) ? 1 : 0;
+            return r;
+        }
+    }
 
     /// Dynamic (slice) interface when the components are dynamic arrays
     size_t slices_() const { size_t n = 0; for (size_t i = 0; i < Size; ++i) n = std::max(n, slices(m_data[i])); return n; }
@@ -1217,6 +1233,98 @@ template <typename T> inline auto hsum_nested(const T &a) {
     else if constexpr (std::decay_t<T>::Depth == 1) return hsum(a);
     else return hsum_nested(hsum(a));
 }
+
+template <typename T> inline auto hmean(const T &a) {                       // array_base.h:167-170
+    if constexpr (!is_array_v<T>) return a;
+    else return hsum(a) * (1.f / (float) a.size());
+}
+#define ENOKI_HIP_NESTED(name)                                                                       \
+    template <typename T> inline auto name##_nested(const T &a) {                                   \
+        if constexpr (!is_array_v<T>) return a;                                                     \
+        else if constexpr (std::decay_t<T>::Depth == 1) return name(a);                             \
+        else return name##_nested(name(a));                                                         \
+    }
+ENOKI_HIP_NESTED(hprod) ENOKI_HIP_NESTED(hmin) ENOKI_HIP_NESTED(hmax) ENOKI_HIP_NESTED(hmean)
+#undef ENOKI_HIP_NESTED
+template <typename T> inline auto count_nested(const T &a) {
+    if constexpr (std::is_same_v<T, bool>) return (size_t) (a ? 1 : 0); else return hsum_nested(count(a));
+}
+
+// ---------------------------------------------------------------------------------------------
+//  Horizontal operations over the INNERMOST dimension (array_router.h:241-249, array_static.h:743-900): a depth-1 array is
+//  reduced, a nested one keeps its outer shape -- hsum_inner(Array<Packet, 3>) is an Array of three sums.
+// ---------------------------------------------------------------------------------------------
+#define ENOKI_HIP_INNER(name, scalar_result)                                                         \
+    template <typename T> inline auto name##_inner(const T &a) {                                    \
+        if constexpr (!is_array_v<T>) {                                                             \
+            return scalar_result;                                                                   \
+        } else if constexpr (std::decay_t<T>::Depth == 1) {                                         \
+            return name(a);                                                                         \
+        } else {                                                                                    \
+            using Inner = decltype(name##_inner(a.coeff(0)));                                       \
+            Array<Inner, std::decay_t<T>::Size> r;                                                  \
+            for (size_t i = 0; i < std::decay_t<T>::Size; ++i) r.coeff(i) = name##_inner(a.coeff(i)); \
+            return r;                                                                               \
+        }                                                                                           \
+    }
+ENOKI_HIP_INNER(hsum, a) ENOKI_HIP_INNER(hprod, a) ENOKI_HIP_INNER(hmin, a) ENOKI_HIP_INNER(hmax, a) ENOKI_HIP_INNER(hmean, a)
+ENOKI_HIP_INNER(psum, a) ENOKI_HIP_INNER(all, (bool) a) ENOKI_HIP_INNER(any, (bool) a)
+ENOKI_HIP_INNER(count, (size_t) ((bool) a ? 1 : 0))
+#undef ENOKI_HIP_INNER
+template <typename T> inline auto none_inner(const T &a) { return !any_inner(a); }
+
+// ---------------------------------------------------------------------------------------------
+//  Reductions that return `Default` for device arrays instead of synchronising (array_router.h:1327-1389): generic code
+//  asks `if (any_or<true>(mask))` to skip work on the CPU and simply proceeds on the device.
+// ---------------------------------------------------------------------------------------------
+#define ENOKI_HIP_OR(name)                                                                           \
+    template <bool Default, typename T> inline bool name##_or(const T &value) {                     \
+        if constexpr (is_device_array_v<T>) { (void) value; return Default; }                       \
+        else return name(value);                                                                    \
+    }
+ENOKI_HIP_OR(any) ENOKI_HIP_OR(all) ENOKI_HIP_OR(none) ENOKI_HIP_OR(any_nested) ENOKI_HIP_OR(all_nested) ENOKI_HIP_OR(none_nested)
+#undef ENOKI_HIP_OR
+
+// ---------------------------------------------------------------------------------------------
+//  Small routines of array_router.h that compose from the above (lines 341-348, 403-470, 653-655) and of
+//  array_static.h (fmaddsub / fmsubadd: 490-521, rol_array / ror_array: 599-642, low / high: 650-660)
+// ---------------------------------------------------------------------------------------------
+template <typename T> inline auto rad_to_deg(const T &a) { return a * scalar_t<T>(180 / 3.14159265358979323846); }
+template <typename T> inline auto deg_to_rad(const T &a) { return a * scalar_t<T>(3.14159265358979323846 / 180); }
+template <typename T1, typename T2> inline auto abs_dot(const T1 &a, const T2 &b) { return abs(dot(a, b)); }
+template <typename T1, typename T2> inline auto copysign_neg(const T1 &a, const T2 &b) { return copysign(a, -b); }
+template <typename T1, typename T2> inline auto mulsign_neg(const T1 &a, const T2 &b) { return mulsign(a, -b); }
+template <typename... Args> inline void prefetch(const Args &...) { }       // no counterpart on the device
+
+/// even components a * b - c, odd components a * b + c (and the other way round)
+template <typename V, size_t N> inline Array<V, N> fmaddsub(const Array<V, N> &a, const Array<V, N> &b, const Array<V, N> &c) {
+    Array<V, N> r;
+    for (size_t i = 0; i < N; ++i) r.coeff(i) = (i % 2 == 0) ? fmsub(a.coeff(i), b.coeff(i), c.coeff(i)) : fmadd(a.coeff(i), b.coeff(i), c.coeff(i));
+    return r;
+}
+template <typename V, size_t N> inline Array<V, N> fmsubadd(const Array<V, N> &a, const Array<V, N> &b, const Array<V, N> &c) {
+    Array<V, N> r;
+    for (size_t i = 0; i < N; ++i) r.coeff(i) = (i % 2 == 0) ? fmadd(a.coeff(i), b.coeff(i), c.coeff(i)) : fmsub(a.coeff(i), b.coeff(i), c.coeff(i));
+    return r;
+}
+/// rotate the COMPONENTS of a static array: rol_array<1>({a, b, c}) = {b, c, a}
+template <size_t Imm, typename V, size_t N> inline Array<V, N> rol_array(const Array<V, N> &a) {
+    Array<V, N> r;
+    for (size_t i = 0; i < N; ++i) r.coeff(i) = a.coeff((i + Imm) % N);
+    return r;
+}
+template <size_t Imm, typename V, size_t N> inline Array<V, N> ror_array(const Array<V, N> &a) {
+    Array<V, N> r;
+    for (size_t i = 0; i < N; ++i) r.coeff(i) = a.coeff((i + N - Imm % N) % N);
+    return r;
+}
+namespace detail {
+    constexpr size_t fill_bits(size_t i) { return i != 0 ? i | fill_bits(i >> 1) : 0; }
+    constexpr size_t lpow2(size_t i) { return i != 0 ? (fill_bits(i - 1) >> 1) + 1 : 0; }      // largest power of two below i
+}
+/// the two parts a static array splits into: the low part has the largest power-of-two size below N
+template <typename V, size_t N> inline auto low(const Array<V, N> &a) { return head<detail::lpow2(N)>(a); }
+template <typename V, size_t N> inline auto high(const Array<V, N> &a) { return tail<N - detail::lpow2(N)>(a); }
 
 /// a == b / a != b reduce to a single bool: all (resp. any) entries compare equal (unequal), array_router.h:494-503.
 /// (Entry-wise comparisons are eq() / neq().)

@@ -34,9 +34,20 @@ int main() {
         for (size_t i = k; i < n; i += K) { double xi = -1.0 + 2.0 * (double) i / (n - 1); want += std::cos(tk * xi) * xi; }
         worst = std::fmax(worst, std::fabs(want - (double) g.coeff(k)));
     }
+    // generic code of the reference's users: reductions with a device default, inner / nested reductions, small helpers
+    using Vector3fC = Array<FloatC, 3>;
+    FloatC t = linspace<FloatC>(1.f, 4.f, 4);
+    Vector3fC v(t, t * 2.f, FloatC(-1.f));
+    const bool skipped = any_or<true>(t > 100.f) && !all_or<false>(t > 0.f) && none_or<true>(t > 0.f);    // no evaluation, no sync
+    auto inner = hsum_inner(v);                      // one sum per component
+    const bool helpers = skipped && inner.x().coeff(0) == 10.f && inner.y().coeff(0) == 20.f && inner.z().coeff(0) == -1.f &&
+                         hmean(t).coeff(0) == 2.5f && hmax_nested(v).coeff(0) == 8.f &&
+                         abs_dot(v, Vector3fC(FloatC(-1.f), FloatC(0.f), FloatC(2.f))).coeff(3) == 6.f &&
+                         std::fabs(rad_to_deg(FloatC(3.14159265f)).coeff(0) - 180.f) < 1e-3f &&
+                         copysign_neg(t, t).coeff(1) == -2.f;
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
-    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr;
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers;
     free(w);
     printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
     return ok ? 0 : 1;

@@ -1,0 +1,64 @@
+// The small routines of the reference's array_router.h / array_static.h that compose from the core operations, on host
+// packets (device arrays go through the same templates): hmean, the *_nested and *_inner reductions, any_or / all_or /
+// none_or, rad_to_deg / deg_to_rad, abs_dot, copysign_neg / mulsign_neg, fmaddsub / fmsubadd, rol_array / ror_array,
+// low / high.
+//
+//     g++ -O1 -std=c++17 -Iinclude tests/cpp/router_host.cpp -o tests/cpp/router_host.bin
+#include <enoki/array.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+using namespace enoki;
+
+#define CHECK(expr) do { if (!(expr)) { fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #expr); exit(1); } } while (0)
+
+int main() {
+    using F4 = Array<float, 4>;
+    using F3 = Array<float, 3>;
+    using N = Array<F4, 3>;                                   // three packets of four lanes
+    F4 a(1.f, 2.f, 3.f, 6.f), b(-1.f, 0.5f, 2.f, -2.f), c(10.f, 20.f, 30.f, 40.f);
+    N n(a, b, c);
+
+    CHECK(hmean(a) == 3.f && hmean(2.5f) == 2.5f);
+    CHECK(hsum_nested(n) == 12.f - 0.5f + 100.f && hprod_nested(F4(1.f, 2.f, 3.f, 4.f)) == 24.f);
+    CHECK(hmin_nested(n) == -2.f && hmax_nested(n) == 40.f && hmean_nested(a) == 3.f);
+    CHECK(count_nested(n > 1.5f) == 3 + 1 + 4);
+
+    auto si = hsum_inner(n);                                  // one sum per packet
+    CHECK(si.coeff(0) == 12.f && si.coeff(1) == -0.5f && si.coeff(2) == 100.f);
+    auto mi = hmax_inner(n), ni = hmin_inner(n), pi = hprod_inner(n), ai = hmean_inner(n);
+    CHECK(mi.coeff(1) == 2.f && ni.coeff(1) == -2.f && pi.coeff(0) == 36.f && ai.coeff(2) == 25.f);
+    CHECK(hsum_inner(a) == 12.f && hsum_inner(7.f) == 7.f);
+    auto any_i = any_inner(n > 30.f); auto all_i = all_inner(n > 0.f); auto cnt_i = count_inner(n > 1.5f);
+    CHECK(!any_i.coeff(0) && !any_i.coeff(1) && any_i.coeff(2));
+    CHECK(all_i.coeff(0) && !all_i.coeff(1) && all_i.coeff(2));
+    CHECK(cnt_i.coeff(0) == 3 && cnt_i.coeff(1) == 1 && cnt_i.coeff(2) == 4);
+    auto none_i = none_inner(n > 30.f);
+    CHECK(none_i.coeff(0) && !none_i.coeff(2));
+
+    CHECK(any_or<false>(a > 5.f) && !any_or<true>(a > 7.f));  // host arrays are evaluated, the default is for device arrays
+    CHECK(all_or<false>(a > 0.f) && none_or<false>(a > 7.f) && any_nested_or<false>(n > 39.f) && !all_nested_or<true>(n > 0.f));
+    CHECK(none_nested_or<false>(n > 50.f));
+
+    CHECK(std::abs(rad_to_deg(3.14159265f) - 180.f) < 1e-4f && std::abs(deg_to_rad(F3(90.f)).x() - 1.5707964f) < 1e-6f);
+    CHECK(abs_dot(F3(1.f, -2.f, 3.f), F3(-1.f, 1.f, -1.f)) == 6.f);
+    F4 cs = copysign_neg(a, b), ms = mulsign_neg(a, b);
+    CHECK(cs[0] == 1.f && cs[1] == -2.f && cs[3] == 6.f && ms[0] == 1.f && ms[1] == -2.f && ms[2] == -3.f);
+
+    F4 fas = fmaddsub(a, b, c), fsa = fmsubadd(a, b, c);
+    CHECK(fas[0] == -1.f - 10.f && fas[1] == 1.f + 20.f && fas[2] == 6.f - 30.f && fas[3] == -12.f + 40.f);
+    CHECK(fsa[0] == -1.f + 10.f && fsa[1] == 1.f - 20.f);
+
+    F4 rl = rol_array<1>(a), rr = ror_array<1>(a);
+    CHECK(rl[0] == 2.f && rl[3] == 1.f && rr[0] == 6.f && rr[1] == 1.f);
+    CHECK(rol_array<4>(a)[2] == a[2] && ror_array<5>(a)[1] == a[0]);
+
+    auto lo = low(a), hi = high(a);
+    CHECK(lo.Size == 2 && hi.Size == 2 && lo[1] == 2.f && hi[0] == 3.f);
+    auto lo3 = low(F3(1.f, 2.f, 3.f)); auto hi3 = high(F3(1.f, 2.f, 3.f));
+    CHECK(lo3.Size == 2 && hi3.Size == 1 && hi3[0] == 3.f);
+
+    printf("router_host: hmean, nested / inner reductions, *_or, angles, abs_dot, sign transfers, fmaddsub, array rotations, low / high\n");
+    return 0;
+}

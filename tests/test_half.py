@@ -11,3 +11,11 @@ def test_half_and_load_store_on_the_host():
     out = subprocess.run([os.path.join(HERE, "cpp", "half_host.bin")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     assert "65536 encodings" in out.stdout
+
+
+def test_router_helpers_on_host_packets():
+    """hmean, *_nested, *_inner, any_or / all_or / none_or, rad_to_deg, abs_dot, copysign_neg, fmaddsub, rol_array, low / high
+    (array_router.h / array_static.h routines that compose from the core operations): tests/cpp/router_host.cpp"""
+    out = subprocess.run([os.path.join(HERE, "cpp", "router_host.bin")], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    assert "router_host:" in out.stdout
