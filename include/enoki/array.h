@@ -1292,6 +1292,45 @@ ENOKI_HIP_OR(any) ENOKI_HIP_OR(all) ENOKI_HIP_OR(none) ENOKI_HIP_OR(any_nested) 
 template <typename T> inline auto rad_to_deg(const T &a) { return a * scalar_t<T>(180 / 3.14159265358979323846); }
 template <typename T> inline auto deg_to_rad(const T &a) { return a * scalar_t<T>(3.14159265358979323846 / 180); }
 template <typename T1, typename T2> inline auto abs_dot(const T1 &a, const T2 &b) { return abs(dot(a, b)); }
+
+/// Angle between two unit vectors / between a unit vector and the z axis, well behaved near 0 and pi (array_math.h:1404-1436)
+template <typename T> inline auto unit_angle(const T &a, const T &b) {
+    auto dot_uv = dot(a, b);
+    auto temp = 2.f * asin(.5f * norm(b - T(mulsign(value_t<T>(1.f), dot_uv)) * a));
+    using E = decltype(temp);
+    return select(dot_uv >= 0.f, temp, E(scalar_t<E>(3.14159265358979323846)) - temp);
+}
+template <typename T> inline auto unit_angle_z(const T &v) {
+    static_assert(std::decay_t<T>::Size == 3, "unit_angle_z(): input is not a 3D vector");
+    using E = value_t<T>;
+    E temp = 2.f * asin(.5f * sqrt(sqr(v.x()) + sqr(v.y()) + sqr(v.z() - copysign(E(1.f), v.z()))));
+    return select(v.z() >= 0.f, temp, E(scalar_t<E>(3.14159265358979323846)) - temp);
+}
+
+/// Neighbouring floating point values (array_math.h:1445-1495) and the denormal test (1497-1500)
+template <typename T> inline T prev_float(const T &value) {
+    using Int = int_array_t<T>;
+    using IS = scalar_t<Int>;
+    const Int exponent_mask(sizeof(IS) == 4 ? IS(0x7f800000) : IS(0x7ff0000000000000ll));
+    const Int pos_denorm(sizeof(IS) == 4 ? IS(0x80000001) : IS(0x8000000000000001ll));
+    Int i = reinterpret_array<Int>(value);
+    auto is_nan_inf = eq(i & exponent_mask, exponent_mask), is_pos_0 = eq(i, Int(IS(0))), is_gt_0 = i >= Int(IS(0));
+    Int j1 = i + select(is_gt_0, Int(IS(-1)), Int(IS(1))), j2 = select(is_pos_0, pos_denorm, i);
+    return reinterpret_array<T>(select(is_nan_inf | is_pos_0, j2, j1));
+}
+template <typename T> inline T next_float(const T &value) {
+    using Int = int_array_t<T>;
+    using IS = scalar_t<Int>;
+    const Int exponent_mask(sizeof(IS) == 4 ? IS(0x7f800000) : IS(0x7ff0000000000000ll));
+    const Int sign_mask(sizeof(IS) == 4 ? IS(0x80000000) : IS(0x8000000000000000ll));
+    Int i = reinterpret_array<Int>(value);
+    auto is_nan_inf = eq(i & exponent_mask, exponent_mask), is_neg_0 = eq(i, sign_mask), is_gt_0 = i >= Int(IS(0));
+    Int j1 = i + select(is_gt_0, Int(IS(1)), Int(IS(-1))), j2 = select(is_neg_0, Int(IS(1)), i);
+    return reinterpret_array<T>(select(is_nan_inf | is_neg_0, j2, j1));
+}
+template <typename T> inline auto isdenormal(const T &a) {
+    return (abs(a) < T(std::numeric_limits<scalar_t<T>>::min())) & neq(a, T(scalar_t<T>(0)));
+}
 template <typename T1, typename T2> inline auto copysign_neg(const T1 &a, const T2 &b) { return copysign(a, -b); }
 template <typename T1, typename T2> inline auto mulsign_neg(const T1 &a, const T2 &b) { return mulsign(a, -b); }
 template <typename... Args> inline void prefetch(const Args &...) { }       // no counterpart on the device

@@ -70,6 +70,12 @@ template <typename T> struct PCG32 {
         return result % UInt32(bound);
     }
 
+    /// next_uint32_bounded / next_uint64_bounded selected by the requested array type (random.h:248-256)
+    template <typename Value> Value next_uint_bounded(scalar_t<Value> bound, Mask mask = Mask(true)) {
+        if constexpr (sizeof(scalar_t<Value>) == 8) return Value(next_uint64_bounded((uint64_t) bound, mask));
+        else return Value(next_uint32_bounded((uint32_t) bound, mask));
+    }
+
     UInt64 next_uint64_bounded(uint64_t bound, Mask mask = Mask(true)) {
         const uint64_t threshold = (~bound + (uint64_t) 1) % bound;
         UInt64 result = UInt64(uint64_t(0));

@@ -23,6 +23,14 @@ namespace detail {
     // ---- polyN: Estrin's scheme, coefficients rounded to the scalar type first (array_math.h:25-100) ----
     template <typename T, typename S = scalar_t<T>> inline T lit(double c) { return T(S(c)); }
 
+    template <typename T> inline T poly2(const T &x, double c0, double c1, double c2) {
+        T x2 = x * x;
+        return fmadd(x2, lit<T>(c2), fmadd(x, lit<T>(c1), lit<T>(c0)));
+    }
+    template <typename T> inline T poly3(const T &x, double c0, double c1, double c2, double c3) {
+        T x2 = x * x;
+        return fmadd(x2, fmadd(x, lit<T>(c3), lit<T>(c2)), fmadd(x, lit<T>(c1), lit<T>(c0)));
+    }
     template <typename T> inline T poly4(const T &x, double c0, double c1, double c2, double c3, double c4) {
         T x2 = x * x, x4 = x2 * x2;
         return fmadd(x2, fmadd(x, lit<T>(c3), lit<T>(c2)), fmadd(x, lit<T>(c1), lit<T>(c0)) + lit<T>(c4) * x4);
@@ -199,6 +207,10 @@ namespace detail {
     ENOKI_HIP_SPECIAL_TRAIT(dawson) ENOKI_HIP_SPECIAL_TRAIT(erfi) ENOKI_HIP_SPECIAL_TRAIT(lgamma) ENOKI_HIP_SPECIAL_TRAIT(tgamma)
 #undef ENOKI_HIP_SPECIAL_TRAIT
 } // namespace detail
+
+/// Polynomial evaluation in the reference's association (array_math.h:25-105): public like there
+using detail::poly2; using detail::poly3; using detail::poly4; using detail::poly5; using detail::poly6;
+using detail::poly7; using detail::poly8; using detail::poly9; using detail::poly10;
 
 #define ENOKI_HIP_SPECIAL(name)                                                                                     \
     template <typename T, enable_if_t<is_array_v<T>> = 0> inline T name(const T &x) {                              \

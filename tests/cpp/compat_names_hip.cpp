@@ -44,7 +44,12 @@ int main() {
                          hmean(t).coeff(0) == 2.5f && hmax_nested(v).coeff(0) == 8.f &&
                          abs_dot(v, Vector3fC(FloatC(-1.f), FloatC(0.f), FloatC(2.f))).coeff(3) == 6.f &&
                          std::fabs(rad_to_deg(FloatC(3.14159265f)).coeff(0) - 180.f) < 1e-3f &&
-                         copysign_neg(t, t).coeff(1) == -2.f;
+                         copysign_neg(t, t).coeff(1) == -2.f &&
+                         next_float(t).coeff(0) == std::nextafter(1.f, 2.f) && prev_float(t).coeff(3) == std::nextafter(4.f, 0.f) &&
+                         !any(isdenormal(t)) && count(isdenormal(t * 1e-39f)) == 4 &&
+                         std::fabs(unit_angle_z(normalize(Vector3fC(t, FloatC(0.f), FloatC(1.f)))).coeff(0) - 0.78539816f) < 1e-6f &&
+                         std::fabs(unit_angle(Vector3fC(FloatC(0.f), FloatC(0.f), FloatC(1.f)),
+                                              Vector3fC(FloatC(0.f), FloatC(1.f), FloatC(0.f))).coeff(0) - 1.5707964f) < 1e-6f;
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
     const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers;

@@ -5,7 +5,9 @@
 //
 //     g++ -O1 -std=c++17 -Iinclude tests/cpp/router_host.cpp -o tests/cpp/router_host.bin
 #include <enoki/array.h>
+#include <enoki/special.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 
@@ -59,6 +61,24 @@ int main() {
     auto lo3 = low(F3(1.f, 2.f, 3.f)); auto hi3 = high(F3(1.f, 2.f, 3.f));
     CHECK(lo3.Size == 2 && hi3.Size == 1 && hi3[0] == 3.f);
 
-    printf("router_host: hmean, nested / inner reductions, *_or, angles, abs_dot, sign transfers, fmaddsub, array rotations, low / high\n");
+    // array_math.h: unit_angle / unit_angle_z, prev_float / next_float, isdenormal, polyN
+    {
+        using V = Array<F4, 3>;                                // four unit vectors at once
+        F4 th(0.f, 0.3f, 1.5707964f, 3.0f);
+        V u(sin(th), F4(0.f), cos(th)), ez(F4(0.f), F4(0.f), F4(1.f));
+        F4 ang = unit_angle(ez, u), angz = unit_angle_z(u);
+        for (int i = 0; i < 4; ++i) CHECK(std::abs(ang[i] - th[i]) < 2e-6f && std::abs(angz[i] - th[i]) < 2e-6f);
+        F4 x(1.f, -1.f, 0.f, 1e-40f);
+        F4 nx = next_float(x), px = prev_float(x);
+        CHECK(nx[0] == std::nextafter(1.f, 2.f) && nx[1] == std::nextafter(-1.f, 2.f) && nx[2] == std::nextafter(0.f, 1.f));
+        CHECK(px[0] == std::nextafter(1.f, -2.f) && px[1] == std::nextafter(-1.f, -2.f) && px[2] == std::nextafter(0.f, -1.f));
+        CHECK(next_float(F4(INFINITY))[0] == INFINITY && std::isnan(prev_float(F4(NAN))[0]));
+        auto dn = isdenormal(x);
+        CHECK(!dn[0] && !dn[2] && dn[3]);
+        F4 t(0.5f);
+        CHECK(poly2(t, 1.0, 2.0, 4.0)[0] == 3.f && poly3(t, 1.0, 2.0, 4.0, 8.0)[0] == 4.f && poly4(t, 1.0, 0.0, 0.0, 0.0, 16.0)[0] == 2.f);
+    }
+
+    printf("router_host: hmean, nested / inner reductions, *_or, angles, abs_dot, sign transfers, fmaddsub, array rotations, low / high, unit_angle, next / prev_float, polyN\n");
     return 0;
 }
