@@ -114,6 +114,68 @@ template <typename T> using int_array_t = replace_scalar_t<T,
 template <typename T> using uint_array_t = replace_scalar_t<T,
     std::conditional_t<sizeof(scalar_t<T>) == 8, uint64_t, std::conditional_t<sizeof(scalar_t<T>) == 4, uint32_t, uint8_t>>>;
 
+// ---- the remaining public names of array_traits.h (66-155, 195-263, 499-511): spelled like the reference so that
+//      templated user code (SFINAE guards, result types) compiles unchanged -----------------------------------------------
+template <typename... Ts> struct identity_impl;
+template <typename T> struct identity_impl<T> { using type = T; };
+template <typename T> using identity_t = typename identity_impl<T>::type;
+
+template <typename T> constexpr bool is_int8_v = std::is_same_v<T, int8_t> || std::is_same_v<T, uint8_t>;
+template <typename T> constexpr bool is_int16_v = std::is_same_v<T, int16_t> || std::is_same_v<T, uint16_t>;
+template <typename T> constexpr bool is_int32_v = std::is_same_v<T, int32_t> || std::is_same_v<T, uint32_t>;
+template <typename T> constexpr bool is_int64_v = std::is_same_v<T, int64_t> || std::is_same_v<T, uint64_t> ||
+                                                  (std::is_integral_v<T> && sizeof(T) == 8 && !std::is_same_v<T, bool>);
+template <typename T> constexpr bool is_float_v = std::is_same_v<T, float>;
+template <typename T> constexpr bool is_double_v = std::is_same_v<T, double>;
+template <typename T> constexpr bool is_std_float_v = is_float_v<T> || is_double_v<T>;
+template <typename T> constexpr bool is_std_int_v = is_int32_v<T> || is_int64_v<T>;
+template <typename T> constexpr bool is_std_type_v = is_std_int_v<T> || is_std_float_v<T>;
+template <typename T> constexpr bool is_scalar_v = std::is_scalar_v<std::decay_t<T>>;
+template <typename T> using enable_if_int32_t = enable_if_t<is_int32_v<T>>;
+template <typename T> using enable_if_int64_t = enable_if_t<is_int64_v<T>>;
+template <typename T> using enable_if_std_int_v = enable_if_t<is_std_int_v<T>>;
+template <typename T> using enable_if_std_float_v = enable_if_t<is_std_float_v<T>>;
+template <typename T> using enable_if_std_type_v = enable_if_t<is_std_type_v<T>>;
+
+template <typename T> using is_array = std::bool_constant<is_array_v<T>>;
+template <typename T> using is_mask = std::bool_constant<is_mask_v<T>>;
+template <typename T> using is_diff_array = std::bool_constant<is_diff_array_v<T>>;
+template <typename T> using is_cuda_array = std::bool_constant<is_cuda_array_v<T>>;
+template <typename... Ts> constexpr bool is_array_any_v = (is_array_v<Ts> || ...);
+/// dynamic = the size is a run-time property at the OUTERMOST level (DynamicArray, CUDAArray there; HIPArray, DiffArray here)
+template <typename T> constexpr bool is_dynamic_array_v = is_array_v<T> && is_dynamic_v<T> && array_depth_v<T> == 1;
+template <typename T> constexpr bool is_static_array_v = is_array_v<T> && !is_dynamic_array_v<T>;
+template <typename T> using is_dynamic_array = std::bool_constant<is_dynamic_array_v<T>>;
+template <typename T> using is_static_array = std::bool_constant<is_static_array_v<T>>;
+template <typename T> using enable_if_array_t = enable_if_t<is_array_v<T>>;
+template <typename T> using enable_if_not_array_t = enable_if_t<!is_array_v<T>>;
+template <typename T> using enable_if_static_array_t = enable_if_t<is_static_array_v<T>>;
+template <typename T> using enable_if_dynamic_array_t = enable_if_t<is_dynamic_array_v<T>>;
+template <typename T> using enable_if_mask_t = enable_if_t<is_mask_v<T>>;
+template <typename T> using enable_if_not_mask_t = enable_if_t<!is_mask_v<T>>;
+template <typename T> using enable_if_diff_array_t = enable_if_t<is_diff_array_v<T>>;
+template <typename T> using enable_if_cuda_t = enable_if_t<is_cuda_array_v<T>>;
+
+template <typename T> struct array_depth { static constexpr size_t value = array_depth_v<T>; };
+namespace detail {
+    template <typename T, typename = int> struct array_size_impl { static constexpr size_t value = 1; };
+    template <typename T> struct array_size_impl<T, enable_if_t<is_array_v<T> && !(is_dynamic_v<T> && depth<T>::value == 1)>> {
+        static constexpr size_t value = std::decay_t<T>::Size;
+    };
+    template <typename T> struct array_size_impl<T, enable_if_t<is_array_v<T> && is_dynamic_v<T> && depth<T>::value == 1>> {
+        static constexpr size_t value = size_t(-1);                 // Dynamic (array_traits.h:259-261)
+    };
+}
+template <typename T> struct array_size : detail::array_size_impl<T> { };
+template <typename T> constexpr size_t array_size_v = array_size<T>::value;
+constexpr size_t Dynamic = size_t(-1);
+
+template <typename T> using array_t = std::decay_t<T>;              // the array type behind an expression: there are no proxies here
+template <typename T> using bool_array_t = replace_scalar_t<T, bool>;
+template <typename T> using size_array_t = replace_scalar_t<T, size_t>;
+template <typename T> using ssize_array_t = replace_scalar_t<T, std::make_signed_t<size_t>>;
+template <typename T> using float_array_t = replace_scalar_t<T, std::conditional_t<sizeof(scalar_t<T>) == 8, double, float>>;
+
 namespace detail {
     template <typename T1, typename T2> struct expr2 {
         using D1 = std::decay_t<T1>;

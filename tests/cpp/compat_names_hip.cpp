@@ -16,6 +16,10 @@ using FloatD = DiffArray<FloatC>;
 using UInt32D = DiffArray<CUDAArray<uint32_t>>;
 using FloatX = DynamicArray<Packet<float>>;
 
+static_assert(is_dynamic_array_v<FloatC> && array_size_v<FloatC> == Dynamic && is_dynamic_array_v<FloatD> && !is_static_array_v<FloatD>);
+static_assert(is_diff_array<FloatD>::value && !is_diff_array<FloatC>::value && is_static_array_v<Array<FloatC, 3>> && array_size_v<Array<FloatC, 3>> == 3);
+static_assert(std::is_same_v<bool_array_t<FloatC>, mask_t<FloatC>> && std::is_same_v<float_array_t<UInt32D>, FloatD>);
+
 int main() {
     const size_t n = 1 << 16, K = 1024;
     FloatD table = linspace<FloatD>(0.f, 1.f, K);

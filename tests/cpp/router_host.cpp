@@ -82,3 +82,19 @@ int main() {
     printf("router_host: hmean, nested / inner reductions, *_or, angles, abs_dot, sign transfers, fmaddsub, array rotations, low / high, unit_angle, next / prev_float, polyN\n");
     return 0;
 }
+
+// ---- the trait names of array_traits.h that templated user code relies on (compile-time only) ----------------------------
+namespace traits_check {
+    using F4 = Array<float, 4>;
+    using N = Array<F4, 3>;
+    static_assert(is_static_array_v<F4> && !is_dynamic_array_v<F4> && array_size_v<F4> == 4 && array_size_v<N> == 3 && array_size_v<float> == 1);
+    static_assert(array_depth<N>::value == 2 && is_array<F4>::value && !is_array<float>::value && is_array_any_v<float, F4>);
+    static_assert(std::is_same_v<bool_array_t<F4>, Array<bool, 4>> && std::is_same_v<float_array_t<Array<int64_t, 4>>, Array<double, 4>>);
+    static_assert(std::is_same_v<size_array_t<F4>, Array<size_t, 4>> && std::is_same_v<array_t<const F4 &>, F4>);
+    static_assert(is_std_float_v<double> && is_std_int_v<uint32_t> && is_int64_v<int64_t> && !is_std_type_v<bool> && is_scalar_v<float>);
+    static_assert(is_mask<mask_t<F4>>::value && !is_mask<F4>::value && !is_diff_array<F4>::value && !is_cuda_array<F4>::value);
+    template <typename T, enable_if_static_array_t<T> = 0> constexpr int pick(const T &) { return 1; }
+    template <typename T, enable_if_not_array_t<T> = 0> constexpr int pick(const T &) { return 2; }
+    template <typename T, enable_if_std_float_v<T> = 0> constexpr bool fp(T) { return true; }
+    static_assert(fp(1.f) && std::is_same_v<identity_t<int>, int>);
+}
