@@ -10,6 +10,7 @@
 */
 #pragma once
 
+#include <pybind11/functional.h>
 #include <pybind11/numpy.h>
 #include <pybind11/operators.h>
 #include <pybind11/pybind11.h>
@@ -343,7 +344,13 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
         m.def("tzcnt", [](const Array &a) { return tzcnt(a); });
         m.def("mulhi", [](const Array &a, const Array &b) { return mulhi(a, b); });
         // floor(log2(a)) = (bits - 1) - lzcnt(a)  (array_router.h log2i, bound in src/python/common.h:832)
-        m.def("log2i", [](const Array &a) { return Array(Scalar(sizeof(Scalar) * 8 - 1)) - lzcnt(a); });
+        m.def("log2i", [](const Array &a) { return log2i(a); });
+        if constexpr (std::is_same_v<Scalar, uint32_t>)
+            // every lane searches [start, end) for the first index where pred(index) is False (cuda_1d.cpp:85-92,
+            // cuda_autodiff_1d.cpp; array_utils.h:130-171): pred maps a UInt32 array to a Mask
+            m.def("binary_search", [](uint32_t start, uint32_t end, const std::function<Mask(const Array &)> &pred) {
+                return binary_search<Array>(start, end, pred);
+            }, "start"_a, "end"_a, "pred"_a);
     }
 
     if constexpr (IsDiff && IsFloat) {

@@ -448,6 +448,17 @@ template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline bool 
 template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T mulsign(T a, T b) { return std::signbit(b) ? -a : a; }
 template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T sign(T a) { return std::copysign(T(1), a); }
 template <typename T, enable_if_t<std::is_floating_point_v<T>> = 0> inline T copysign(T a, T b) { return std::copysign(a, b); }
+/// Bit counts of scalars (array_fallbacks.h)
+template <typename T, enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool>> = 0> inline T popcnt(T v) {
+    return (T) __builtin_popcountll((unsigned long long) std::make_unsigned_t<T>(v));
+}
+template <typename T, enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool>> = 0> inline T lzcnt(T v) {
+    using U = std::make_unsigned_t<T>;
+    return v == 0 ? T(sizeof(T) * 8) : T(__builtin_clzll((unsigned long long) U(v)) - (64 - (int) sizeof(T) * 8));
+}
+template <typename T, enable_if_t<std::is_integral_v<T> && !std::is_same_v<T, bool>> = 0> inline T tzcnt(T v) {
+    return v == 0 ? T(sizeof(T) * 8) : T(__builtin_ctzll((unsigned long long) std::make_unsigned_t<T>(v)));
+}
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T rcp(T a) { return T(1) / a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline T hsum(T a) { return a; }
 template <typename T, enable_if_t<std::is_arithmetic_v<T>> = 0> inline bool eq(T a, T b) { return a == b; }
@@ -955,6 +966,7 @@ template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     ENOKI_HIP_STATIC_UNARY(acos, enoki::acos) ENOKI_HIP_STATIC_UNARY(atan, enoki::atan) ENOKI_HIP_STATIC_UNARY(sinh, enoki::sinh)
     ENOKI_HIP_STATIC_UNARY(cosh, enoki::cosh) ENOKI_HIP_STATIC_UNARY(tanh, enoki::tanh) ENOKI_HIP_STATIC_UNARY(asinh, enoki::asinh)
     ENOKI_HIP_STATIC_UNARY(acosh, enoki::acosh) ENOKI_HIP_STATIC_UNARY(atanh, enoki::atanh) ENOKI_HIP_STATIC_UNARY(cbrt, enoki::cbrt)
+    ENOKI_HIP_STATIC_UNARY(popcnt, enoki::popcnt) ENOKI_HIP_STATIC_UNARY(lzcnt, enoki::lzcnt) ENOKI_HIP_STATIC_UNARY(tzcnt, enoki::tzcnt)
     std::pair<Array, Array> sincos_() const {
         Array s, c;
         for (size_t i = 0; i < Size; ++i) { auto sc = enoki::sincos(m_data[i]); s.m_data[i] = sc.first; c.m_data[i] = sc.second; }
@@ -1354,6 +1366,62 @@ ENOKI_HIP_OR(any) ENOKI_HIP_OR(all) ENOKI_HIP_OR(none) ENOKI_HIP_OR(any_nested) 
 template <typename T> inline auto rad_to_deg(const T &a) { return a * scalar_t<T>(180 / 3.14159265358979323846); }
 template <typename T> inline auto deg_to_rad(const T &a) { return a * scalar_t<T>(3.14159265358979323846 / 180); }
 template <typename T1, typename T2> inline auto abs_dot(const T1 &a, const T2 &b) { return abs(dot(a, b)); }
+
+/// Shifts / rotations by a compile-time amount (array_router.h:253-256)
+template <size_t Imm, typename T> inline auto sl(const T &a) {
+    if constexpr (is_array_v<T>) return a << T(scalar_t<T>(Imm)); else return T(a << Imm);
+}
+template <size_t Imm, typename T> inline auto sr(const T &a) {
+    if constexpr (is_array_v<T>) return a >> T(scalar_t<T>(Imm)); else return T(a >> Imm);
+}
+template <size_t Imm, typename T, enable_if_t<is_array_v<T>> = 0> inline auto rol(const T &a) { return rol(a, T(scalar_t<T>(Imm))); }
+template <size_t Imm, typename T, enable_if_t<is_array_v<T>> = 0> inline auto ror(const T &a) { return ror(a, T(scalar_t<T>(Imm))); }
+
+/// floor(log2(value)) for integers (array_router.h:567-570)
+template <typename T> inline auto log2i(const T &value) {
+    if constexpr (is_array_v<T>) return T(scalar_t<T>(sizeof(scalar_t<T>) * 8 - 1)) - lzcnt(value);
+    else return T(sizeof(T) * 8 - 1) - lzcnt(value);
+}
+
+/// the single entry of a size-1 array, or the scalar itself (array_router.h:1297-1307)
+template <typename T> inline scalar_t<T> scalar_cast(const T &v) {
+    static_assert(array_depth_v<T> <= 1, "scalar_cast(): scalars and flat arrays only");
+    if constexpr (is_array_v<T>) {
+        if (v.size() != 1) throw std::runtime_error("scalar_cast(): array should be of size 1!");
+        return v.coeff(0);
+    } else {
+        return v;
+    }
+}
+
+namespace detail {
+    template <typename F> struct first_argument_of { };
+    template <typename C, typename R, typename A> struct first_argument_of<R (C::*)(A) const> { using type = std::decay_t<A>; };
+    template <typename C, typename R, typename A> struct first_argument_of<R (C::*)(A)> { using type = std::decay_t<A>; };
+    template <typename F, typename = void> struct first_argument { };                    // generic lambdas, arrays: no member `type`
+    template <typename F> struct first_argument<F, std::void_t<decltype(&F::operator())>> : first_argument_of<decltype(&F::operator())> { };
+    template <typename R, typename A> struct first_argument<R (*)(A), void> { using type = std::decay_t<A>; };
+}
+
+/// Vectorised binary search (array_utils.h:130-171): the first index in [start, end) for which `pred(index)` is false,
+/// assuming the predicate is true on a prefix.  Every lane searches its own answer: `pred` maps an index ARRAY to a mask;
+/// the index type is taken from the predicate's parameter (or given explicitly for generic lambdas).
+template <typename Index, typename Predicate>
+inline Index binary_search(scalar_t<Index> start_, scalar_t<Index> end_, const Predicate &pred) {
+    Index start(start_), end(end_);
+    const size_t iterations = start_ < end_ ? (size_t) log2i((scalar_t<Index>) (end_ - start_)) + 1 : 0;
+    for (size_t i = 0; i < iterations; ++i) {
+        Index middle = sr<1>(start + end);
+        mask_t<Index> cond = pred(middle);
+        start = select(cond, min(middle + Index(scalar_t<Index>(1)), end), start);
+        end = select(cond, end, middle);
+    }
+    return start;
+}
+template <typename Predicate, typename Index = typename detail::first_argument<Predicate>::type>
+inline Index binary_search(scalar_t<Index> start_, scalar_t<Index> end_, const Predicate &pred) {
+    return binary_search<Index, Predicate>(start_, end_, pred);
+}
 
 /// Angle between two unit vectors / between a unit vector and the z axis, well behaved near 0 and pi (array_math.h:1404-1436)
 template <typename T> inline auto unit_angle(const T &a, const T &b) {

@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 using namespace enoki;
 
@@ -54,9 +55,16 @@ int main() {
                          std::fabs(unit_angle_z(normalize(Vector3fC(t, FloatC(0.f), FloatC(1.f)))).coeff(0) - 0.78539816f) < 1e-6f &&
                          std::fabs(unit_angle(Vector3fC(FloatC(0.f), FloatC(0.f), FloatC(1.f)),
                                               Vector3fC(FloatC(0.f), FloatC(1.f), FloatC(0.f))).coeff(0) - 1.5707964f) < 1e-6f;
+    // a per-lane binary search over a sorted device table (array_utils.h:130-171)
+    using UInt32C = CUDAArray<uint32_t>;
+    FloatC sorted = linspace<FloatC>(0.f, 99.f, 100);           // sorted[i] = i
+    FloatC needles = FloatC::copy(std::vector<float>{ -5.f, 0.5f, 42.f, 98.5f, 1000.f }.data(), 5);
+    UInt32C lower = binary_search(0u, 100u, [&](const UInt32C &i) { return gather<FloatC>(sorted, min(i, UInt32C(99u))) < needles; });
+    const bool searched = lower.coeff(0) == 0 && lower.coeff(1) == 1 && lower.coeff(2) == 42 && lower.coeff(3) == 99 && lower.coeff(4) == 100 &&
+                          log2i(UInt32C(1000u)).coeff(0) == 9 && scalar_cast(hsum(t)) == 10.f && sr<2>(UInt32C(64u)).coeff(0) == 16;
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
-    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers;
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched;
     free(w);
     printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
     return ok ? 0 : 1;

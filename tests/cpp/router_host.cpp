@@ -7,6 +7,7 @@
 #include <enoki/array.h>
 #include <enoki/special.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -98,3 +99,32 @@ namespace traits_check {
     template <typename T, enable_if_std_float_v<T> = 0> constexpr bool fp(T) { return true; }
     static_assert(fp(1.f) && std::is_same_v<identity_t<int>, int>);
 }
+
+// ---- log2i / scalar bit counts / sl, sr / scalar_cast / binary_search ------------------------------------------------------
+static int run_search_checks() {
+    using U4 = Array<uint32_t, 4>;
+    CHECK(log2i(1u) == 0 && log2i(255u) == 7 && log2i(256u) == 8 && log2i(uint64_t(1) << 40) == 40);
+    CHECK(lzcnt(1u) == 31 && lzcnt(0u) == 32 && tzcnt(8u) == 3 && popcnt(0xF0F0u) == 8 && lzcnt(uint64_t(1)) == 63);
+    U4 v(1u, 2u, 255u, 1u << 31);
+    U4 l = log2i(v);
+    CHECK(l[0] == 0 && l[1] == 1 && l[2] == 7 && l[3] == 31);
+    CHECK(sl<3>(v)[1] == 16 && sr<1>(v)[2] == 127 && sl<2>(5u) == 20u);
+    CHECK(scalar_cast(Array<float, 1>(2.5f)) == 2.5f && scalar_cast(7) == 7);
+    // every lane looks its own value up in a sorted table: first index whose entry is >= the value
+    const uint32_t table[10] = { 1, 3, 3, 7, 10, 15, 21, 22, 40, 90 };
+    U4 needle(0u, 7u, 23u, 100u);
+    U4 found = binary_search(0u, 10u, [&](const U4 &index) {
+        Array<bool, 4> m;
+        for (size_t i = 0; i < 4; ++i) m[i] = table[std::min<uint32_t>(index[i], 9)] < needle[i];
+        return m;
+    });
+    CHECK(found[0] == 0 && found[1] == 3 && found[2] == 8 && found[3] == 10);
+    U4 again = binary_search<U4>(0u, 10u, [&](const auto &index) {        // generic lambda: index type given explicitly
+        Array<bool, 4> m;
+        for (size_t i = 0; i < 4; ++i) m[i] = table[std::min<uint32_t>(index[i], 9)] < needle[i];
+        return m;
+    });
+    CHECK(again[1] == 3 && again[3] == 10);
+    return 0;
+}
+static const int search_checks_ran = run_search_checks();

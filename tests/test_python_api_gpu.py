@@ -536,3 +536,15 @@ def test_remaining_per_array_surface(ekc, ek):
     ek.Float32.set_graph_simplification(False); ek.Float32.set_graph_simplification(True)
     ek.backward(ek.hsum(y ** 2))                                   # d/dx x^4 = 4 x^3
     assert np.allclose(ek.gradient(d).numpy(), 4 * a ** 3, rtol=1e-6)
+
+
+def test_binary_search(ekc, ek):
+    """every lane finds the first table entry >= its needle (cuda_1d.cpp:85-92 over array_utils.h:130-171)"""
+    rng = np.random.default_rng(2)
+    table = np.sort(rng.standard_normal(1000).astype(np.float32))
+    needles = rng.standard_normal(4099).astype(np.float32) * 1.5
+    for mod in (ekc, ek):
+        T, Nd = mod.Float32(table), mod.Float32(needles)
+        last = mod.UInt32(np.array([999], np.uint32))
+        found = mod.binary_search(0, 1000, lambda i: mod.gather(T, mod.min(i, last)) < Nd)
+        assert np.array_equal(found.numpy(), np.searchsorted(table, needles, side="left").astype(np.uint32))
