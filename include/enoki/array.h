@@ -1383,6 +1383,62 @@ template <typename T> inline auto log2i(const T &value) {
     else return T(sizeof(T) * 8 - 1) - lzcnt(value);
 }
 
+/// Division by an integer chosen at run time (array_idiv.h:150-242).  The reference precomputes a multiplier and a shift
+/// for its CPU packets; a uniform divisor costs the device nothing extra, so here the type only carries the value -- the
+/// quotients are the same integers either way.  `x / divisor<T>(d)`, `d(x)`, `x % divisor_ext<T>(d)`.
+template <typename T> struct divisor {
+    T value = T(1);
+    divisor() = default;
+    divisor(T d) : value(d) { }
+    template <typename T2> auto operator()(const T2 &v) const {
+        if constexpr (is_array_v<T2>) return v / T2(scalar_t<T2>(value)); else return T2(v / (T2) value);
+    }
+};
+template <typename T> struct divisor_ext : divisor<T> { using divisor<T>::divisor; };
+template <typename T1, typename T2> inline auto operator/(const T1 &a, const divisor<T2> &d) { return d(a); }
+template <typename T1, typename T2> inline auto operator/(const T1 &a, const divisor_ext<T2> &d) { return d(a); }
+template <typename T1, typename T2> inline auto operator%(const T1 &a, const divisor_ext<T2> &d) {
+    if constexpr (is_array_v<T1>) return a - d(a) * T1(scalar_t<T1>(d.value)); else return T1(a - d(a) * (T1) d.value);
+}
+
+/// Shape of a (nested) array, outermost dimension first (array_struct.h:468-539): shape(Array<HIPArray<float>, 3>) = {3, n}
+namespace detail {
+    template <typename T> inline void extract_shape(size_t *out, const T &a) {
+        if constexpr (is_array_v<T>) {
+            *out = a.size();
+            if constexpr (is_array_v<value_t<T>>) { if (*out > 0) extract_shape(out + 1, a.coeff(0)); }
+        }
+    }
+    template <typename T> inline bool is_ragged(const T &a, const size_t *shape) {
+        if constexpr (is_array_v<T>) {
+            if (*shape != a.size()) return true;
+            bool match = true;
+            if constexpr (is_static_array_v<T> && is_dynamic_v<value_t<T>>)
+                for (size_t i = 0; i < a.size(); ++i) match &= !is_ragged(a.coeff(i), shape + 1);
+            return !match;
+        } else {
+            return false;
+        }
+    }
+    template <typename T> inline void set_shape_impl(T &a, const size_t *shape) {
+        if constexpr (is_array_v<T>) {
+            if constexpr (is_dynamic_array_v<T>) {
+                a.resize(*shape);
+            } else if constexpr (is_array_v<value_t<T>>) {
+                for (size_t i = 0; i < a.size(); ++i) set_shape_impl(a.coeff(i), shape + 1);
+            }
+        }
+    }
+}
+template <typename T> inline std::array<size_t, array_depth_v<T>> shape(const T &a) {
+    std::array<size_t, array_depth_v<T>> result{ };
+    detail::extract_shape(result.data(), a);
+    return result;
+}
+template <typename T> inline void set_shape(T &a, const std::array<size_t, array_depth_v<T>> &value) { detail::set_shape_impl(a, value.data()); }
+/// do the dynamic components of a nested array disagree about their length?
+template <typename T> inline bool ragged(const T &a) { auto s = shape(a); return detail::is_ragged(a, s.data()); }
+
 /// the single entry of a size-1 array, or the scalar itself (array_router.h:1297-1307)
 template <typename T> inline scalar_t<T> scalar_cast(const T &v) {
     static_assert(array_depth_v<T> <= 1, "scalar_cast(): scalars and flat arrays only");

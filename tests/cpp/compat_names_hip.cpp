@@ -62,9 +62,16 @@ int main() {
     UInt32C lower = binary_search(0u, 100u, [&](const UInt32C &i) { return gather<FloatC>(sorted, min(i, UInt32C(99u))) < needles; });
     const bool searched = lower.coeff(0) == 0 && lower.coeff(1) == 1 && lower.coeff(2) == 42 && lower.coeff(3) == 99 && lower.coeff(4) == 100 &&
                           log2i(UInt32C(1000u)).coeff(0) == 9 && scalar_cast(hsum(t)) == 10.f && sr<2>(UInt32C(64u)).coeff(0) == 16;
+    // shape / ragged / set_shape of a structure of arrays, division by a run-time constant
+    Vector3fC soa(t, t, FloatC(1.f));
+    auto shp = shape(soa);
+    bool shaped = shp[0] == 3 && shp[1] == 4 && ragged(soa);           // the broadcast component has length 1
+    set_shape(soa, { 3, 4 });
+    shaped = shaped && !ragged(soa) && soa.z().size() == 4 && soa.z().coeff(3) == 1.f &&
+             (UInt32C(100u) / divisor<uint32_t>(7u)).coeff(0) == 14u;
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
-    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched;
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped;
     free(w);
     printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
     return ok ? 0 : 1;

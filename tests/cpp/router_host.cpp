@@ -128,3 +128,21 @@ static int run_search_checks() {
     return 0;
 }
 static const int search_checks_ran = run_search_checks();
+
+// ---- divisor, shape / set_shape / ragged ---------------------------------------------------------------------------------
+static int run_shape_checks() {
+    using U4 = Array<uint32_t, 4>;
+    using I4 = Array<int32_t, 4>;
+    U4 v(0u, 13u, 100u, 4000000000u);
+    divisor<uint32_t> d7(7u);
+    U4 q = v / d7, q2 = d7(v);
+    CHECK(q[1] == 1 && q[2] == 14 && q[3] == 4000000000u / 7u && q2[3] == q[3] && (91u / d7) == 13u);
+    divisor_ext<int32_t> dm(-3);
+    I4 w(-10, -1, 0, 11), r = w % dm, qq = w / dm;
+    for (size_t i = 0; i < 4; ++i) CHECK(qq[i] == w[i] / -3 && r[i] == w[i] % -3);
+    auto s1 = shape(v);
+    auto s2 = shape(Array<U4, 3>(v, v, v));
+    CHECK(s1.size() == 1 && s1[0] == 4 && s2.size() == 2 && s2[0] == 3 && s2[1] == 4 && !ragged(v));
+    return 0;
+}
+static const int shape_checks_ran = run_shape_checks();
