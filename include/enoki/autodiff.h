@@ -568,6 +568,14 @@ template <typename Type_> struct DiffArray : ArrayTag {
     DiffArray lzcnt_() const { return create(0, lzcnt(m_value)); }
     DiffArray tzcnt_() const { return create(0, tzcnt(m_value)); }
     DiffArray sign_() const { return create(0, sign(m_value)); }
+    // the remaining gradient-free members of the reference's DiffArray (autodiff.h:480-489, 803-815, 847-852, 920-947)
+    template <typename T> T floor2int_() const { return T(floor2int<typename T::UnderlyingType>(m_value)); }
+    template <typename T> T ceil2int_() const { return T(ceil2int<typename T::UnderlyingType>(m_value)); }
+    DiffArray andnot_(const DiffArray &a) const { return create(0, m_value & ~a.m_value); }
+    DiffArray rol_(const DiffArray &a) const { return create(0, rol(m_value, a.m_value)); }
+    DiffArray ror_(const DiffArray &a) const { return create(0, ror(m_value, a.m_value)); }
+    /// the first active entry (no gradient is carried by the returned scalar)
+    Scalar extract_(const MaskType &mask) const { return extract(m_value, mask.value_()); }
 
     MaskType eq_(const DiffArray &d) const { return MaskType(eq(m_value, d.m_value)); }
     MaskType neq_(const DiffArray &d) const { return MaskType(neq(m_value, d.m_value)); }

@@ -69,9 +69,14 @@ int main() {
     set_shape(soa, { 3, 4 });
     shaped = shaped && !ragged(soa) && soa.z().size() == 4 && soa.z().coeff(3) == 1.f &&
              (UInt32C(100u) / divisor<uint32_t>(7u)).coeff(0) == 14u;
+    // gradient-free members on differentiable arrays: texel coordinates, bit rotations, first active entry
+    FloatD coord = linspace<FloatD>(0.25f, 7.75f, 4);
+    UInt32D texel = floor2int<UInt32D>(coord), upper = ceil2int<UInt32D>(coord);
+    const bool casts = texel.coeff(1) == 2 && upper.coeff(1) == 3 && rol(texel, UInt32D(31u)).coeff(1) == 1 &&
+                       extract(coord, coord > 3.f) == 5.25f && andnot(texel, UInt32D(2u)).coeff(1) == 0;
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
-    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped;
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped && casts;
     free(w);
     printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
     return ok ? 0 : 1;
