@@ -19,6 +19,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#include <ios>
 #include <limits>
 #include <stdexcept>
 #include <string>
@@ -1438,6 +1439,56 @@ template <typename T> inline std::array<size_t, array_depth_v<T>> shape(const T 
 template <typename T> inline void set_shape(T &a, const std::array<size_t, array_depth_v<T>> &value) { detail::set_shape_impl(a, value.data()); }
 /// do the dynamic components of a nested array disagree about their length?
 template <typename T> inline bool ragged(const T &a) { auto s = shape(a); return detail::is_ragged(a, s.data()); }
+
+/// `os << array` (array_base.h:190-237): entries grouped so that one row is one SLICE -- an Array<HIPArray<float>, 3> prints as
+/// [[x0, y0, z0],\n [x1, y1, z1], ...] -- and dynamic dimensions beyond 20 entries abbreviated to the first and last five.
+/// (Device arrays are read entry by entry through coeff(): meant for debugging output.)
+namespace detail {
+    template <typename T, size_t N> inline auto entry_at(const T &a, const size_t (&idx)[N], size_t level) {
+        // by value: coeff() of a device array returns a temporary
+        if constexpr (is_array_v<T>) return entry_at(a.coeff(idx[level]), idx, level + 1); else return a;
+    }
+    template <typename T> constexpr bool dim_is_dynamic(size_t level) {
+        if constexpr (!is_array_v<T>) return false;
+        else return level == 0 ? is_dynamic_array_v<T> : dim_is_dynamic<value_t<T>>(level - 1);
+    }
+    template <typename Stream, typename T, size_t N>
+    inline void print_entries(Stream &os, const T &a, const std::array<size_t, N> &size, size_t (&idx)[N], size_t fixed) {
+        if (fixed == N) {
+            const auto v = entry_at(a, idx, 0);
+            if constexpr (std::is_same_v<std::decay_t<decltype(v)>, bool>) os << (v ? 1 : 0); else os << v;
+            return;
+        }
+        const size_t k = N - fixed - 1;                       // the innermost dimension varies slowest in the output
+        os << "[";
+        for (size_t i = 0; i < size[k]; ++i) {
+            if (dim_is_dynamic<T>(k) && size[k] > 20 && i == 5) {
+                os << ".. " << size[k] - 10 << " skipped ..,";
+                if (k > 0) { os << "\n"; for (size_t j = 0; j <= fixed; ++j) os << " "; } else { os << " "; }
+                i = size[k] - 6;
+                continue;
+            }
+            idx[k] = i;
+            print_entries(os, a, size, idx, fixed + 1);
+            if (i + 1 < size[k]) {
+                if (k == 0) { os << ", "; } else { os << ",\n"; for (size_t j = 0; j <= fixed; ++j) os << " "; }
+            }
+        }
+        os << "]";
+    }
+}
+template <typename Stream, typename T,
+          enable_if_t<is_array_v<T> && std::is_base_of_v<std::ios_base, std::decay_t<Stream>>> = 0>
+inline Stream &operator<<(Stream &os, const T &a) {
+    if (ragged(a)) {
+        os << "[ragged array]";
+    } else {
+        auto size = shape(a);
+        size_t idx[array_depth_v<T>] = { };
+        detail::print_entries(os, a, size, idx, 0);
+    }
+    return os;
+}
 
 /// the single entry of a size-1 array, or the scalar itself (array_router.h:1297-1307)
 template <typename T> inline scalar_t<T> scalar_cast(const T &v) {

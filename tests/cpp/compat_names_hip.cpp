@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <sstream>
 #include <vector>
 
 using namespace enoki;
@@ -74,10 +75,20 @@ int main() {
     UInt32D texel = floor2int<UInt32D>(coord), upper = ceil2int<UInt32D>(coord);
     const bool casts = texel.coeff(1) == 2 && upper.coeff(1) == 3 && rol(texel, UInt32D(31u)).coeff(1) == 1 &&
                        extract(coord, coord > 3.f) == 5.25f && andnot(texel, UInt32D(2u)).coeff(1) == 0;
+    // printing (array_base.h:190-237): one row per slice, long arrays abbreviated
+    std::ostringstream small, large;
+    small << Vector3fC(FloatC::copy(std::vector<float>{ 1.f, 2.f }.data(), 2), FloatC::copy(std::vector<float>{ 3.f, 4.f }.data(), 2),
+                       FloatC::copy(std::vector<float>{ 5.f, 6.f }.data(), 2));
+    large << arange<UInt32C>(100);
+    const bool printed = small.str() == "[[1, 3, 5],\n [2, 4, 6]]" &&
+                         large.str() == "[0, 1, 2, 3, 4, .. 90 skipped .., 95, 96, 97, 98, 99]";
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
-    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped && casts;
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped && casts && printed;
     free(w);
+    if (!ok)
+        printf("  helpers %d searched %d shaped %d casts %d printed %d  [%s] [%s]\n", (int) helpers, (int) searched, (int) shaped,
+               (int) casts, (int) printed, small.str().c_str(), large.str().c_str());
     printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
     return ok ? 0 : 1;
 }

@@ -146,3 +146,18 @@ static int run_shape_checks() {
     return 0;
 }
 static const int shape_checks_ran = run_shape_checks();
+
+// ---- stream output ---------------------------------------------------------------------------------------------------------
+#include <sstream>
+static int run_print_checks() {
+    using F3 = Array<float, 3>;
+    std::ostringstream a, b, c;
+    a << F3(1.f, 2.5f, -3.f);
+    CHECK(a.str() == "[1, 2.5, -3]");
+    b << Array<F3, 2>(F3(1.f, 2.f, 3.f), F3(4.f, 5.f, 6.f));           // rows = slices of the inner dimension
+    CHECK(b.str() == "[[1, 4],\n [2, 5],\n [3, 6]]");
+    c << (F3(1.f, 2.f, 3.f) > 1.5f);
+    CHECK(c.str() == "[0, 1, 1]");
+    return 0;
+}
+static const int print_checks_ran = run_print_checks();
