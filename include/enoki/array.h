@@ -1490,6 +1490,28 @@ inline Stream &operator<<(Stream &os, const T &a) {
     return os;
 }
 
+/// Conflict-free read-modify-write through an index packet (array_router.h:1168-1190, array_static.h:982-991): lane after
+/// lane, `func(memory[index[i]], args[i]..., mask[i])` -- two lanes that address the same entry both take effect.  For static
+/// packets and scalars over raw memory (host code, or per-lane code inside vectorize() kernels); the last argument may be a
+/// mask.  Device arrays use scatter_add, which is what the reference's own CUDA path offers too.
+template <typename Arg, size_t Stride = sizeof(scalar_t<Arg>), typename Func, typename Index, typename... Args>
+inline void transform(void *mem, const Index &index, Func &&func, const Args &... args) {
+    if constexpr (is_array_v<Arg>) {
+        static_assert(!is_dynamic_v<Arg>, "transform(): static packets and scalars only; device arrays: scatter_add()");
+        for (size_t i = 0; i < std::decay_t<Arg>::Size; ++i)
+            transform<value_t<Arg>, Stride>(mem, index.coeff(i), func, [&](const auto &a) -> decltype(auto) {
+                if constexpr (is_array_v<std::decay_t<decltype(a)>>) return a.coeff(i); else return (a);
+            }(args)...);
+    } else {
+        Arg &ref = *reinterpret_cast<Arg *>(static_cast<uint8_t *>(mem) + (size_t) index * Stride);
+        if constexpr (sizeof...(Args) > 0 && (false || ... || std::is_same_v<std::decay_t<Args>, bool>)) {
+            if ((... , (bool) args)) func(ref, args...);        // the trailing mask decides
+        } else {
+            func(ref, args..., true);
+        }
+    }
+}
+
 /// the single entry of a size-1 array, or the scalar itself (array_router.h:1297-1307)
 template <typename T> inline scalar_t<T> scalar_cast(const T &v) {
     static_assert(array_depth_v<T> <= 1, "scalar_cast(): scalars and flat arrays only");

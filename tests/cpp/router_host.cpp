@@ -161,3 +161,19 @@ static int run_print_checks() {
     return 0;
 }
 static const int print_checks_ran = run_print_checks();
+
+// ---- transform: conflict-free read-modify-write -------------------------------------------------------------------------
+static int run_transform_checks() {
+    using F4 = Array<float, 4>;
+    using U4 = Array<uint32_t, 4>;
+    float hist[4] = { 0.f, 0.f, 0.f, 0.f };
+    U4 bin(1u, 3u, 1u, 1u);                                  // three lanes hit the same bin
+    transform<F4>(hist, bin, [](float &slot, float w, bool) { slot += w; }, F4(1.f, 2.f, 4.f, 8.f));
+    CHECK(hist[1] == 13.f && hist[3] == 2.f && hist[0] == 0.f);
+    transform<F4>(hist, bin, [](float &slot, float w, bool) { slot *= w; }, F4(2.f), Array<bool, 4>(true, false, true, false));
+    CHECK(hist[1] == 52.f && hist[3] == 2.f);
+    transform<float>(hist, 2u, [](float &slot, bool) { slot = 7.f; });
+    CHECK(hist[2] == 7.f);
+    return 0;
+}
+static const int transform_checks_ran = run_transform_checks();
