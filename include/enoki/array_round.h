@@ -1,0 +1,6 @@
+/*
+    enoki/array_round.h -- kept for source compatibility: in this implementation the contents of the reference's array_round.h
+    (traits, routing, static arrays, structure support, ...) live in one header, enoki/array.h
+*/
+#pragma once
+#include <enoki/array.h>

@@ -19,3 +19,12 @@ def test_router_helpers_on_host_packets():
     out = subprocess.run([os.path.join(HERE, "cpp", "router_host.bin")], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert "router_host:" in out.stdout
+
+
+def test_every_reference_header_name_is_includable(tmp_path):
+    """<enoki/fwd.h>, <enoki/array_traits.h>, <enoki/array_router.h>, ... <enoki/array_math.h> and the type headers in one
+    translation unit (tests/cpp/headers_host.cpp): compile-only"""
+    root = os.path.dirname(HERE)
+    out = subprocess.run(["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", "-c", os.path.join(HERE, "cpp", "headers_host.cpp"),
+                          "-o", str(tmp_path / "headers_host.o")], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
