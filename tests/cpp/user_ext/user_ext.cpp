@@ -7,6 +7,7 @@
 //         -o tests/cpp/user_ext/user_ext<EXT_SUFFIX> -Lenoki_amd -lenoki-hip-autodiff -lenoki-hip
 #include <enoki/hip.h>
 #include <enoki/autodiff.h>
+#include <enoki/python.h>          // NumPy <-> host static arrays
 
 #include <pybind11/pybind11.h>
 
@@ -31,4 +32,13 @@ PYBIND11_MODULE(user_ext, m) {
     m.def("shade", [](const Vector3fD &n, const Vector3fD &l, const FloatD &albedo) { return shade(n, l, albedo); });
     m.def("lookup", [](const Vector3fC &table, const UInt32C &index, const MaskC &mask) { return gather<Vector3fC>(table, index, mask); });
     m.def("count_positive", [](const FloatC &x) { return count(x > 0.f); });
+    // host static arrays travel as NumPy arrays (enoki/python.h), innermost dimension first
+    using Vector3f = Array<float, 3>;
+    m.def("reflect", [](const Vector3f &d, const Vector3f &n) { return d - n * (2.f * dot(d, n)); });
+    m.def("outer", [](const Vector3f &a, const Array<float, 2> &b) {
+        Array<Vector3f, 2> r(a * b.x(), a * b.y());              // shape (3, 2) on the NumPy side
+        return r;
+    });
+    m.def("trace", [](const Array<Array<double, 2>, 2> &m2) { return m2.coeff(0).coeff(0) + m2.coeff(1).coeff(1); });
+    m.def("positive", [](const Vector3f &v) { return v > 0.f; });
 }

@@ -20,6 +20,23 @@ def test_signatures_name_the_library_types():
     assert "enoki_amd.hip.UInt32" in user_ext.lookup.__doc__ and "enoki_amd.hip.Mask" in user_ext.lookup.__doc__
 
 
+def test_host_static_arrays_travel_as_numpy():
+    """enoki/python.h: Array<float, 3> etc. <-> NumPy, innermost dimension first (no GPU involved)"""
+    import enoki_amd.hip            # noqa: F401
+    import enoki_amd.hip_autodiff   # noqa: F401
+    import user_ext
+    d = np.array([1.0, -1.0, 0.5], np.float32); n = np.array([0.0, 1.0, 0.0], np.float32)
+    r = user_ext.reflect(d, n)
+    assert isinstance(r, np.ndarray) and r.dtype == np.float32 and np.array_equal(r, d - n * 2 * d.dot(n))
+    assert np.array_equal(user_ext.reflect([1, -1, 0.5], (0, 1, 0)), r)          # lists / tuples / other dtypes convert
+    o = user_ext.outer(d, np.array([2.0, 3.0], np.float32))
+    assert o.shape == (3, 2) and np.array_equal(o, np.outer(d, [2.0, 3.0]).astype(np.float32))
+    assert user_ext.trace(np.array([[1.0, 7.0], [9.0, 4.0]])) == 5.0
+    assert user_ext.positive(d).tolist() == [True, False, True]
+    with pytest.raises(TypeError):
+        user_ext.reflect(np.zeros(4, np.float32), n)                               # wrong shape
+
+
 @pytest.mark.gpu
 def test_downstream_functions_on_device_arrays():
     import enoki_amd.hip as ekc
