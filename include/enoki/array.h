@@ -33,6 +33,7 @@
 #  define ENOKI_NOINLINE __attribute__((noinline))
 #  define ENOKI_LIKELY(x) __builtin_expect(!!(x), 1)
 #  define ENOKI_UNLIKELY(x) __builtin_expect(!!(x), 0)
+#  define ENOKI_MARK_USED(x) (void) x
 #endif
 
 namespace enoki {
@@ -1509,6 +1510,22 @@ inline void transform(void *mem, const Index &index, Func &&func, const Args &..
         } else {
             func(ref, args..., true);
         }
+    }
+}
+
+/// The i-th slice of a (nested) dynamic array as scalars / static arrays of scalars: slice(Array<HIPArray<float>, 3>, i) is the
+/// Array<float, 3> (x_i, y_i, z_i) (array_struct.h:179-236, read-only here: entries of device arrays are copies).
+template <typename T> inline auto slice(const T &a, size_t i) {
+    if constexpr (!is_array_v<T>) {
+        (void) i;
+        return a;
+    } else if constexpr (is_dynamic_array_v<T>) {
+        if (i >= a.size() && a.size() != 1) throw std::out_of_range("slice(): index out of range");
+        return a.coeff(a.size() == 1 ? 0 : i);               // size-1 arrays broadcast
+    } else {
+        Array<decltype(slice(a.coeff(0), i)), std::decay_t<T>::Size> r;
+        for (size_t k = 0; k < std::decay_t<T>::Size; ++k) r.coeff(k) = slice(a.coeff(k), i);
+        return r;
     }
 }
 

@@ -82,13 +82,15 @@ int main() {
     large << arange<UInt32C>(100);
     const bool printed = small.str() == "[[1, 3, 5],\n [2, 4, 6]]" &&
                          large.str() == "[0, 1, 2, 3, 4, .. 90 skipped .., 95, 96, 97, 98, 99]";
+    Array<float, 3> third = slice(Vector3fC(t, t * 2.f, FloatC(-1.f)), 2);                  // (x_2, y_2, z_2)
+    const bool sliced = third.x() == 3.f && third.y() == 6.f && third.z() == -1.f && slice(t, 3) == 4.f;
     FloatX z = zero<FloatX>(8) + 1.f;
     char *w = cuda_whos();
-    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped && casts && printed;
+    const bool ok = worst < 2e-3 && hsum(z).coeff(0) == 8.f && w != nullptr && helpers && searched && shaped && casts && printed && sliced;
     free(w);
     if (!ok)
         printf("  helpers %d searched %d shaped %d casts %d printed %d  [%s] [%s]\n", (int) helpers, (int) searched, (int) shaped,
-               (int) casts, (int) printed, small.str().c_str(), large.str().c_str());
+               (int) casts, (int) (printed && sliced), small.str().c_str(), large.str().c_str());
     printf("compat names: max gradient error %.2e -> %s\n", worst, ok ? "ok" : "FAILED");
     return ok ? 0 : 1;
 }

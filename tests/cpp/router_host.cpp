@@ -177,3 +177,13 @@ static int run_transform_checks() {
     return 0;
 }
 static const int transform_checks_ran = run_transform_checks();
+
+static int run_slice_checks() {
+    using F3 = Array<float, 3>;
+    F3 v(1.f, 2.f, 3.f);
+    auto s = slice(Array<F3, 2>(v, v * 2.f), 1);            // static arrays have no dynamic dimension: returned unchanged in shape
+    CHECK(s.coeff(1).coeff(2) == 6.f && slice(5.f, 9) == 5.f);
+    int unused = 0; ENOKI_MARK_USED(unused);
+    return 0;
+}
+static const int slice_checks_ran = run_slice_checks();
