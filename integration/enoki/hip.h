@@ -51,6 +51,44 @@ struct Buffer {
     void *ptr = nullptr;
     size_t size = 0;
     bool owned = true;
+
+    /// What a float array was computed from, when that was a plain product or fused multiply-add (set by mul_ / fmadd_):
+    /// lets integration/hip_hooks.cpp recognise the reference's spelling of safe_mul / safe_fmadd (autodiff.cpp:1191-1221)
+    /// and run ONE fused kernel for it.  Weak: a tag never keeps an operand alive.
+    std::weak_ptr<Buffer> prod[3];
+    int prod_kind = 0;                          // 0: unknown, 1: prod[0] * prod[1], 2: fma(prod[0], prod[1], prod[2])
+
+    /// A mask that is still a recipe: 1: (lazy[0] == 0), 2: (lazy[0] == 0) | (lazy[1] == 0) over float arrays.  The trace
+    /// fragments of safe_mul produce exactly these; they are evaluated only if somebody reads the mask (get()).
+    std::shared_ptr<Buffer> lazy[2];
+    int lazy_kind = 0;
+
+    /// the device pointer of an INPUT (evaluates a pending recipe first)
+    void *get() {
+        if (lazy_kind != 0) materialize();
+        return ptr;
+    }
+    void materialize() {
+        const int kind = lazy_kind;
+        lazy_kind = 0;
+        check(ek_hip_malloc(size ? size : 1, &ptr), "mask recipe");
+        ek_operand zero{ nullptr, 0, 1 }, a{ lazy[0]->get(), 0, lazy[0]->size };
+        if (kind == 1) {
+            check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) ptr, &a, &zero, size), "mask recipe");
+        } else {
+            void *tmp = nullptr;
+            check(ek_hip_malloc(lazy[0]->size ? lazy[0]->size : 1, &tmp), "mask recipe");
+            check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) tmp, &a, &zero, lazy[0]->size), "mask recipe");
+            ek_operand b{ lazy[1]->get(), 0, lazy[1]->size };
+            void *tmp2 = nullptr;
+            check(ek_hip_malloc(lazy[1]->size ? lazy[1]->size : 1, &tmp2), "mask recipe");
+            check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) tmp2, &b, &zero, lazy[1]->size), "mask recipe");
+            ek_operand ea{ tmp, 0, lazy[0]->size }, eb{ tmp2, 0, lazy[1]->size };
+            check(ek_hip_binary(EK_OR, EK_BOOL, ptr, &ea, &eb, size), "mask recipe");
+            ek_hip_free(tmp); ek_hip_free(tmp2);              // stream-ordered reuse
+        }
+        lazy[0].reset(); lazy[1].reset();
+    }
     ~Buffer() { if (owned && ptr) ek_hip_free(ptr); }
 };
 
@@ -138,6 +176,7 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
         HIPArray r = empty_(broadcast(size(), v.size()));                                                              \
         ek_operand a = operand(), b = v.operand();                                                                     \
         hip_detail::check(ek_hip_binary(code, Code, r.m_buf->ptr, &a, &b, r.size()), #name);                           \
+        if ((code) == EK_MUL && Code == EK_F32) { r.m_buf->prod_kind = 1; r.m_buf->prod[0] = m_buf; r.m_buf->prod[1] = v.m_buf; } \
         return r;                                                                                                      \
     }
 #define ENOKI_HIP_TERNARY(name, code)                                                                                  \
@@ -145,6 +184,9 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
         HIPArray r = empty_(broadcast(broadcast(size(), v.size()), w.size()));                                         \
         ek_operand a = operand(), b = v.operand(), c = w.operand();                                                    \
         hip_detail::check(ek_hip_ternary(code, Code, r.m_buf->ptr, &a, &b, &c, r.size()), #name);                      \
+        if ((code) == EK_FMADD && Code == EK_F32) {                                                                    \
+            r.m_buf->prod_kind = 2; r.m_buf->prod[0] = m_buf; r.m_buf->prod[1] = v.m_buf; r.m_buf->prod[2] = w.m_buf;  \
+        }                                                                                                              \
         return r;                                                                                                      \
     }
 #define ENOKI_HIP_COMPARE(name, code)                                                                                  \
@@ -251,7 +293,7 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     HIPArray name##_() const {                                                                                         \
         if (size() == 1) return *this;                                                                                 \
         HIPArray r = empty_(1);                                                                                        \
-        hip_detail::check(ek_hip_reduce(code, Code, r.m_buf->ptr, m_buf ? m_buf->ptr : nullptr, size()), #name);       \
+        hip_detail::check(ek_hip_reduce(code, Code, r.m_buf->ptr, m_buf ? m_buf->get() : nullptr, size()), #name);       \
         return r;                                                                                                      \
     }
     ENOKI_HIP_REDUCE(hsum, EK_HSUM) ENOKI_HIP_REDUCE(hprod, EK_HPROD) ENOKI_HIP_REDUCE(hmin, EK_HMIN) ENOKI_HIP_REDUCE(hmax, EK_HMAX)
@@ -261,12 +303,12 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     size_t count_() const { return (size_t) mask_reduce(EK_COUNT); }
     HIPArray psum_() const {
         HIPArray r = empty_(size());
-        hip_detail::check(ek_hip_psum(Code, r.m_buf->ptr, m_buf->ptr, size()), "psum");
+        hip_detail::check(ek_hip_psum(Code, r.m_buf->ptr, m_buf->get(), size()), "psum");
         return r;
     }
     HIPArray reverse_() const {
         HIPArray r = empty_(size());
-        hip_detail::check(ek_hip_reverse(Code, r.m_buf->ptr, m_buf->ptr, size()), "reverse");
+        hip_detail::check(ek_hip_reverse(Code, r.m_buf->ptr, m_buf->get(), size()), "reverse");
         return r;
     }
 
@@ -299,7 +341,7 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     template <typename T = Value, enable_if_t<std::is_pointer_v<T> || std::is_same_v<T, uintptr_t>> = 0>
     std::vector<std::pair<Value, HIPArray<uint32_t>>> partition_() const {
         std::vector<Value> host(size());
-        if (!host.empty()) hip_detail::check(ek_hip_memcpy_to_host(host.data(), m_buf->ptr, host.size() * sizeof(Value)), "partition");
+        if (!host.empty()) hip_detail::check(ek_hip_memcpy_to_host(host.data(), m_buf->get(), host.size() * sizeof(Value)), "partition");
         std::map<uintptr_t, std::vector<uint32_t>> groups;
         for (size_t i = 0; i < host.size(); ++i) groups[(uintptr_t) host[i]].push_back((uint32_t) i);
         std::vector<std::pair<Value, HIPArray<uint32_t>>> result;
@@ -320,8 +362,8 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     static HIPArray from_index_(Index index) { HIPArray r; r.m_buf = hip_detail::Handles::get().find(index); return r; }
     size_t size() const { return m_buf ? m_buf->size : 0; }
     bool empty() const { return size() == 0; }
-    const Value *data() const { return m_buf ? (const Value *) m_buf->ptr : nullptr; }
-    Value *data() { return m_buf ? (Value *) m_buf->ptr : nullptr; }
+    const Value *data() const { return m_buf ? (const Value *) m_buf->get() : nullptr; }
+    Value *data() { return m_buf ? (Value *) m_buf->get() : nullptr; }
     void resize(size_t size) {
         if (size == this->size()) return;
         if (this->size() > 1) throw std::runtime_error("HIPArray::resize(): only size-1 arrays can be broadcast");
@@ -334,11 +376,11 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     }
     Value coeff(size_t i) const {
         Value result = Value(0);
-        hip_detail::check(ek_hip_memcpy_to_host(&result, (const Value *) m_buf->ptr + i, sizeof(Value)), "coeff");
+        hip_detail::check(ek_hip_memcpy_to_host(&result, (const Value *) m_buf->get() + i, sizeof(Value)), "coeff");
         return result;
     }
 
-    ek_operand operand() const { return ek_operand{ m_buf ? m_buf->ptr : nullptr, 0, size() }; }
+    ek_operand operand() const { return ek_operand{ m_buf ? m_buf->get() : nullptr, 0, size() }; }
 
 private:
     static size_t broadcast(size_t a, size_t b) {
@@ -369,7 +411,7 @@ private:
     uint64_t mask_reduce(int code) const {
         static_assert(std::is_same_v<Value, bool>, "all / any / count need a mask array");
         uint64_t result = 0;
-        hip_detail::check(ek_hip_mask_reduce(code, (const uint8_t *) (m_buf ? m_buf->ptr : nullptr), size(), &result), "mask reduction");
+        hip_detail::check(ek_hip_mask_reduce(code, (const uint8_t *) (m_buf ? m_buf->get() : nullptr), size(), &result), "mask reduction");
         return result;
     }
 

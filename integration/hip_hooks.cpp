@@ -5,8 +5,9 @@
 //   * cuda_register_callback / cuda_unregister_callback (Tape's constructor, autodiff.cpp:218-219): there is no cuda_eval()
 //     to call back from -- no-ops;
 //   * cuda_trace_append for the FOUR trace fragments with which autodiff.cpp:1198-1218 spells safe_mul / safe_fmadd
-//     ((w == 0 || g == 0) ? 0 : w * g and its fma form): executed right away as compare / or / select kernels on the
-//     buffers that HIPArray::index_() parked (integration/enoki/hip.h).  Any other fragment is an error.
+//     ((w == 0 || g == 0) ? 0 : w * g and its fma form): recognised as a whole and executed as ONE fused kernel when the
+//     operands match (see below), otherwise literally as compare / or / select kernels on the buffers that
+//     HIPArray::index_() parked (integration/enoki/hip.h).  Any other fragment is an error.
 // A maintainer would compile this file into the library that ships integration/enoki/hip.h; the reference tree itself is
 // untouched.
 #include <enoki/hip.h>
@@ -24,7 +25,7 @@ void cuda_set_scatter_gather_operand(uint32_t index, bool) {
     hip_detail::Operand &o = hip_detail::announced_operand();
     if (index == 0) { o = hip_detail::Operand(); return; }
     auto b = hip_detail::Handles::get().find(index);
-    o.ptr = b ? b->ptr : nullptr;
+    o.ptr = b ? b->get() : nullptr;
     o.size = b ? b->size : 0;
 }
 void cuda_var_set_label(uint32_t, const char *) { }          // set_label() on device arrays (cuda.h:956-964): no trace to label
@@ -41,26 +42,50 @@ std::shared_ptr<Buffer> make(size_t size, size_t elem) {
     hip_detail::check(ek_hip_malloc((size ? size : 1) * elem, &b->ptr), "trace fragment");
     return b;
 }
-ek_operand op(const std::shared_ptr<Buffer> &b) { return ek_operand{ b->ptr, 0, b->size }; }
+ek_operand op(const std::shared_ptr<Buffer> &b) { return ek_operand{ b->get(), 0, b->size }; }
 size_t bsize(size_t a, size_t b) { return a == 1 ? b : a; }
 [[noreturn]] void unknown(const char *fragment) {
     throw std::runtime_error(std::string("integration/hip_hooks.cpp: trace fragment not provided by the eager backend: ") + fragment);
 }
 } // namespace
 
+// The three fragments of safe_mul(value1, value2) arrive as: m1 = (value1 == 0); m2 = (value2 == 0) | m1;
+// result = m2 ? 0 : tentative, with tentative = value1 * value2 computed by the router just before (autodiff.cpp:1192-1202;
+// safe_fmadd: 1207-1218 with tentative = fmadd(value1, value2, value3) and result = m2 ? value3 : tentative).  The masks
+// are kept as recipes (Buffer::lazy); when the final select finds that its `tentative` operand is tagged as the product of
+// exactly the two arrays the mask tests (Buffer::prod, set by mul_ / fmadd_), ONE fused kernel (EK_SAFE_MUL / EK_SAFE_FMADD
+// of the C ABI, the same arithmetic) replaces compare + compare + or + select.  Any other use of the fragments evaluates
+// them literally, as before.
+namespace {
+std::shared_ptr<Buffer> recipe(int kind, size_t size, const std::shared_ptr<Buffer> &a, const std::shared_ptr<Buffer> &b) {
+    auto m = std::make_shared<Buffer>();
+    m->size = size;
+    m->lazy_kind = kind;
+    m->lazy[0] = a;
+    m->lazy[1] = b;
+    return m;
+}
+/// does `mask` test exactly the two factors that `tentative` was computed from?
+bool tests_factors_of(const std::shared_ptr<Buffer> &mask, const std::shared_ptr<Buffer> &tentative, int kind) {
+    if (mask->lazy_kind != 2 || tentative->prod_kind != kind) return false;
+    Buffer *p0 = tentative->prod[0].lock().get(), *p1 = tentative->prod[1].lock().get();
+    Buffer *l0 = mask->lazy[0].get(), *l1 = mask->lazy[1].get();
+    return p0 && p1 && ((p0 == l0 && p1 == l1) || (p0 == l1 && p1 == l0));
+}
+} // namespace
+
 uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1) {
     if (strcmp(fragment, "setp.eq.f32 $r1, $r2, 0.0") != 0) unknown(fragment);
     auto v = Handles::get().find(i1);
-    auto m = make(v->size, 1);
-    ek_operand a = op(v), zero{ nullptr, 0, 1 };
-    hip_detail::check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) m->ptr, &a, &zero, v->size), "setp.eq");
-    return Handles::get().park(m);
+    return Handles::get().park(recipe(1, v->size, v, nullptr));                  // (v == 0), not evaluated yet
 }
 
 uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_t i2) {
     auto x = Handles::get().find(i1), y = Handles::get().find(i2);
     if (strcmp(fragment, "setp.eq.or.f32 $r1, $r2, 0.0, $r3") == 0) {          // (x == 0) | y
         const size_t n = bsize(x->size, y->size);
+        if (y->lazy_kind == 1)                                                   // y = (v1 == 0): keep (v1 == 0) | (x == 0) as a recipe
+            return Handles::get().park(recipe(2, n, y->lazy[0], x));
         auto e = make(x->size, 1), m = make(n, 1);
         ek_operand a = op(x), zero{ nullptr, 0, 1 };
         hip_detail::check(ek_hip_compare(EK_EQ, EK_F32, (uint8_t *) e->ptr, &a, &zero, x->size), "setp.eq.or");
@@ -71,6 +96,11 @@ uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_
     if (strcmp(fragment, "selp.$t1 $r1, 0.0, $r2, $r3") == 0) {                // y ? 0 : x
         const size_t n = bsize(x->size, y->size);
         auto r = make(n, 4);
+        if (tests_factors_of(y, x, 1)) {                                         // safe_mul: one fused kernel
+            ek_operand oa = op(y->lazy[0]), ob = op(y->lazy[1]);
+            hip_detail::check(ek_hip_binary(EK_SAFE_MUL, EK_F32, r->ptr, &oa, &ob, n), "safe_mul");
+            return Handles::get().park(r);
+        }
         ek_operand om = op(y), zero{ nullptr, 0, 1 }, ox = op(x);
         hip_detail::check(ek_hip_select(EK_F32, r->ptr, &om, &zero, &ox, n), "selp");
         return Handles::get().park(r);
@@ -83,6 +113,12 @@ uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_
     auto x = Handles::get().find(i1), y = Handles::get().find(i2), m = Handles::get().find(i3);
     const size_t n = bsize(bsize(x->size, y->size), m->size);
     auto r = make(n, 4);
+    if (tests_factors_of(m, y, 2) && y->prod[2].lock().get() == x.get()) {       // safe_fmadd: one fused kernel
+        auto f0 = y->prod[0].lock(), f1 = y->prod[1].lock();
+        ek_operand oa = op(f0), ob = op(f1), oc = op(x);
+        hip_detail::check(ek_hip_ternary(EK_SAFE_FMADD, EK_F32, r->ptr, &oa, &ob, &oc, n), "safe_fmadd");
+        return Handles::get().park(r);
+    }
     ek_operand om = op(m), ox = op(x), oy = op(y);
     hip_detail::check(ek_hip_select(EK_F32, r->ptr, &om, &ox, &oy, n), "selp");
     return Handles::get().park(r);
