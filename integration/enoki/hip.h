@@ -56,7 +56,16 @@ struct Buffer {
     /// lets integration/hip_hooks.cpp recognise the reference's spelling of safe_mul / safe_fmadd (autodiff.cpp:1191-1221)
     /// and run ONE fused kernel for it.  Weak: a tag never keeps an operand alive.
     std::weak_ptr<Buffer> prod[3];
+    uint64_t prod_version[3] = { 0, 0, 0 };     // the operands' `version` when the tag was made
     int prod_kind = 0;                          // 0: unknown, 1: prod[0] * prod[1], 2: fma(prod[0], prod[1], prod[2])
+
+    /// A 64-bit integer array that was widened from a 32-bit one (the reference's tape turns every gather offset into Int64,
+    /// autodiff.cpp:355-366): gather_ / scatter_add_ hand the ORIGINAL to the library while it is alive and unmodified --
+    /// the kernels are written for 32-bit indices and would otherwise narrow the array again (12 bytes per element).
+    std::weak_ptr<Buffer> narrow_src;
+    int narrow_code = 0;
+    uint64_t narrow_version = 0;
+    uint64_t version = 0;                       // bumped whenever a mutable pointer is handed out
 
     /// A mask that is still a recipe: 1: (lazy[0] == 0), 2: (lazy[0] == 0) | (lazy[1] == 0) over float arrays.  The trace
     /// fragments of safe_mul produce exactly these; they are evaluated only if somebody reads the mask (get()).
@@ -150,6 +159,24 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
         allocate(v.size());
         ek_operand a = v.operand();
         hip_detail::check(ek_hip_cast(HIPArray<T>::Code, Code, m_buf->ptr, &a, size()), "HIPArray(cast)");
+        if constexpr (std::is_integral_v<T> && sizeof(T) == 4 && std::is_integral_v<Value> && sizeof(Value) == 8 &&
+                      !std::is_same_v<T, bool>) {
+            m_buf->narrow_src = v.m_buf;
+            m_buf->narrow_code = HIPArray<T>::Code;
+            m_buf->narrow_version = v.m_buf->version;
+        }
+    }
+
+    /// index operand for the library: the 32-bit array this one was widened from, if that is still valid
+    ek_operand index_operand(int &code) const {
+        code = Code;
+        if (m_buf && m_buf->narrow_code != 0) {
+            if (auto src = m_buf->narrow_src.lock(); src && src->version == m_buf->narrow_version && src->size == m_buf->size) {
+                code = m_buf->narrow_code;
+                return ek_operand{ src->get(), 0, src->size };
+            }
+        }
+        return operand();
     }
     template <typename T> HIPArray(const HIPArray<T> &v, detail::reinterpret_flag) {   // same bits (cuda.h:249-258)
         static_assert(sizeof(T) == sizeof(Value));
@@ -176,7 +203,10 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
         HIPArray r = empty_(broadcast(size(), v.size()));                                                              \
         ek_operand a = operand(), b = v.operand();                                                                     \
         hip_detail::check(ek_hip_binary(code, Code, r.m_buf->ptr, &a, &b, r.size()), #name);                           \
-        if ((code) == EK_MUL && Code == EK_F32) { r.m_buf->prod_kind = 1; r.m_buf->prod[0] = m_buf; r.m_buf->prod[1] = v.m_buf; } \
+        if ((code) == EK_MUL && Code == EK_F32 && m_buf && v.m_buf) {                                                  \
+            r.m_buf->prod_kind = 1; r.m_buf->prod[0] = m_buf; r.m_buf->prod[1] = v.m_buf;                              \
+            r.m_buf->prod_version[0] = m_buf->version; r.m_buf->prod_version[1] = v.m_buf->version;                    \
+        }                                                                                                              \
         return r;                                                                                                      \
     }
 #define ENOKI_HIP_TERNARY(name, code)                                                                                  \
@@ -184,8 +214,10 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
         HIPArray r = empty_(broadcast(broadcast(size(), v.size()), w.size()));                                         \
         ek_operand a = operand(), b = v.operand(), c = w.operand();                                                    \
         hip_detail::check(ek_hip_ternary(code, Code, r.m_buf->ptr, &a, &b, &c, r.size()), #name);                      \
-        if ((code) == EK_FMADD && Code == EK_F32) {                                                                    \
+        if ((code) == EK_FMADD && Code == EK_F32 && m_buf && v.m_buf && w.m_buf) {                                      \
             r.m_buf->prod_kind = 2; r.m_buf->prod[0] = m_buf; r.m_buf->prod[1] = v.m_buf; r.m_buf->prod[2] = w.m_buf;  \
+            r.m_buf->prod_version[0] = m_buf->version; r.m_buf->prod_version[1] = v.m_buf->version;                    \
+            r.m_buf->prod_version[2] = w.m_buf->version;                                                               \
         }                                                                                                              \
         return r;                                                                                                      \
     }
@@ -317,8 +349,9 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     static HIPArray gather_(const void *ptr, const Index_ &index, const Mask &mask) {
         static_assert(Stride == sizeof(Value), "HIPArray::gather_(): element stride expected");
         HIPArray r = empty_(broadcast(index.size(), mask.size()));
-        ek_operand oi = index.operand(), om = mask.operand();
-        hip_detail::check(ek_hip_gather(Code, Index_::Code, r.m_buf->ptr, ptr, &oi, &om, r.size()), "gather");
+        int index_code = 0;
+        ek_operand oi = index.index_operand(index_code), om = mask.operand();
+        hip_detail::check(ek_hip_gather(Code, index_code, r.m_buf->ptr, ptr, &oi, &om, r.size()), "gather");
         return r;
     }
     template <size_t Stride, typename Index_, typename Mask>
@@ -330,9 +363,10 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     template <size_t Stride, typename Index_, typename Mask>
     void scatter_add_(void *ptr, const Index_ &index, const Mask &mask) const {
         static_assert(Stride == sizeof(Value), "HIPArray::scatter_add_(): element stride expected");
-        ek_operand ov = operand(), oi = index.operand(), om = mask.operand();
+        int index_code = 0;
+        ek_operand ov = operand(), oi = index.index_operand(index_code), om = mask.operand();
         const hip_detail::Operand &target = hip_detail::announced_operand();
-        hip_detail::check(ek_hip_scatter_add(Code, Index_::Code, ptr, target.ptr == ptr ? target.size : 0, &ov, &oi, &om,
+        hip_detail::check(ek_hip_scatter_add(Code, index_code, ptr, target.ptr == ptr ? target.size : 0, &ov, &oi, &om,
                                              broadcast(broadcast(size(), index.size()), mask.size()), 0), "scatter_add");
     }
 
@@ -363,7 +397,13 @@ struct HIPArray : ArrayBase<value_t<Value>, HIPArray<Value>> {
     size_t size() const { return m_buf ? m_buf->size : 0; }
     bool empty() const { return size() == 0; }
     const Value *data() const { return m_buf ? (const Value *) m_buf->get() : nullptr; }
-    Value *data() { return m_buf ? (Value *) m_buf->get() : nullptr; }
+    Value *data() {
+        if (!m_buf) return nullptr;
+        m_buf->version++;                                   // the caller may write: tags that describe the old contents expire
+        m_buf->narrow_code = 0;
+        m_buf->prod_kind = 0;
+        return (Value *) m_buf->get();
+    }
     void resize(size_t size) {
         if (size == this->size()) return;
         if (this->size() > 1) throw std::runtime_error("HIPArray::resize(): only size-1 arrays can be broadcast");

@@ -68,9 +68,11 @@ std::shared_ptr<Buffer> recipe(int kind, size_t size, const std::shared_ptr<Buff
 /// does `mask` test exactly the two factors that `tentative` was computed from?
 bool tests_factors_of(const std::shared_ptr<Buffer> &mask, const std::shared_ptr<Buffer> &tentative, int kind) {
     if (mask->lazy_kind != 2 || tentative->prod_kind != kind) return false;
-    Buffer *p0 = tentative->prod[0].lock().get(), *p1 = tentative->prod[1].lock().get();
-    Buffer *l0 = mask->lazy[0].get(), *l1 = mask->lazy[1].get();
-    return p0 && p1 && ((p0 == l0 && p1 == l1) || (p0 == l1 && p1 == l0));
+    auto f0 = tentative->prod[0].lock(), f1 = tentative->prod[1].lock();
+    Buffer *p0 = f0.get(), *p1 = f1.get(), *l0 = mask->lazy[0].get(), *l1 = mask->lazy[1].get();
+    if (!p0 || !p1 || p0->version != tentative->prod_version[0] || p1->version != tentative->prod_version[1])
+        return false;                                                            // an operand was written to since
+    return (p0 == l0 && p1 == l1) || (p0 == l1 && p1 == l0);
 }
 } // namespace
 
@@ -113,7 +115,7 @@ uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_
     auto x = Handles::get().find(i1), y = Handles::get().find(i2), m = Handles::get().find(i3);
     const size_t n = bsize(bsize(x->size, y->size), m->size);
     auto r = make(n, 4);
-    if (tests_factors_of(m, y, 2) && y->prod[2].lock().get() == x.get()) {       // safe_fmadd: one fused kernel
+    if (tests_factors_of(m, y, 2) && y->prod[2].lock().get() == x.get() && x->version == y->prod_version[2]) {   // safe_fmadd
         auto f0 = y->prod[0].lock(), f1 = y->prod[1].lock();
         ek_operand oa = op(f0), ob = op(f1), oc = op(x);
         hip_detail::check(ek_hip_ternary(EK_SAFE_FMADD, EK_F32, r->ptr, &oa, &ob, &oc, n), "safe_fmadd");
