@@ -10,6 +10,12 @@
     (cuda_eval, cuda_sync, cuda_set_scatter_gather_operand, cuda_var_mark_dirty: cuda.h:53-170) are no-ops for an eager
     backend and are defined in integration/hip_hooks.cpp.
 
+    Two pieces of bookkeeping let the reference's autodiff layer run at a sensible speed without an edit (see
+    hip_detail::Buffer): a float array remembers that it is the product / fused multiply-add of two (three) others, so
+    that the trace fragments with which autodiff.cpp spells safe_mul / safe_fmadd become one fused kernel
+    (integration/hip_hooks.cpp), and a 64-bit integer array remembers the 32-bit array it was widened from, so that
+    gather_ / scatter_add_ pass the original to the library.  Both tags expire when an operand hands out a mutable pointer.
+
     tests/cpp/reference_side_hip.cpp instantiates the same templated functions on the reference's CPU arrays
     (DynamicArray<Packet<float>>) and on this class, in ONE binary, and compares the results on the device box.
 */
