@@ -249,6 +249,14 @@ def build_checkers(force=False, verbose=True):
             _run(["g++", "-std=c++17", "-O2", "-mavx2", "-mfma", "-mf16c", "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno",
                   "-I/root/reference/include", f"-I{integ}", inc, deps[0], deps[2], "-o", exe, f"-L{HERE}", "-lenoki-hip",
                   "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
+        # the same binding on the host stand-in of the C ABI under ASan / UBSan (tests/test_host_sanitizers.py): tag bookkeeping
+        exe = os.path.join(tcpp, "integration_host.bin")
+        if force or _newer(exe, [os.path.join(tcpp, "integration_host.cpp"), os.path.join(tcpp, "host_abi_stub.h"),
+                                 os.path.join(integ, "enoki", "hip.h"), os.path.join(integ, "hip_hooks.cpp"),
+                                 os.path.join(ROOT, "include", "enoki_hip.h")]):
+            _run(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-mavx2", "-mfma", "-mf16c",
+                  "-mbmi", "-mbmi2", "-mlzcnt", "-ffp-contract=off", "-fno-math-errno", "-I/root/reference/include", f"-I{integ}", inc,
+                  os.path.join(tcpp, "integration_host.cpp"), "-o", exe])
         # ... and the reference's own TAPE (src/autodiff/autodiff.cpp) + its own autodiff test suite on top of that header: every
         # line above the C ABI in this binary is reference code.  autodiff.cpp also instantiates Tape<CUDAArray<float>> under
         # ENOKI_CUDA; that instantiation is dead code here, its references into libenoki-cuda.so stay unresolved.

@@ -63,6 +63,7 @@ int ek_hip_free(void *p) {
     free(p);
     return EK_OK;
 }
+int ek_hip_sync(void) { return EK_OK; }
 int ek_hip_memcpy_device(void *d, const void *s, size_t b) { memcpy(d, s, b); return EK_OK; }
 int ek_hip_memcpy_to_host(void *d, const void *s, size_t b) { memcpy(d, s, b); return EK_OK; }
 int ek_hip_memcpy_to_device(void *d, const void *s, size_t b) { memcpy(d, s, b); return EK_OK; }
@@ -97,6 +98,7 @@ int ek_hip_sincos(int, void *s, void *c, const ek_operand *a, size_t n) {
     for (size_t i = 0; i < n; ++i) { float x = op_f(a, i); ((float *) s)[i] = std::sin(x); ((float *) c)[i] = std::cos(x); }
     return EK_OK;
 }
+static long g_safe_calls = 0;               // elements that went through EK_SAFE_MUL / EK_SAFE_FMADD
 static float binary_f(int op, float a, float b) {
     switch (op) {
         case EK_ADD: return a + b;
@@ -105,7 +107,7 @@ static float binary_f(int op, float a, float b) {
         case EK_DIV: return a / b;
         case EK_MIN: return b < a ? b : a;
         case EK_MAX: return b > a ? b : a;
-        case EK_SAFE_MUL: return (a == 0 || b == 0) ? 0.f : a * b;
+        case EK_SAFE_MUL: ++g_safe_calls; return (a == 0 || b == 0) ? 0.f : a * b;
         default: fprintf(stderr, "stand-in: binary op %d\n", op); abort();
     }
 }
@@ -137,7 +139,7 @@ int ek_hip_ternary(int op, int, void *out, const ek_operand *a, const ek_operand
             case EK_FMSUB: r = std::fma(x, y, -z); break;
             case EK_FNMADD: r = std::fma(-x, y, z); break;
             case EK_FNMSUB: r = std::fma(-x, y, -z); break;
-            case EK_SAFE_FMADD: r = (x == 0 || y == 0) ? z : std::fma(x, y, z); break;
+            case EK_SAFE_FMADD: ++g_safe_calls; r = (x == 0 || y == 0) ? z : std::fma(x, y, z); break;
             default: STUB_UNSUPPORTED("ternary", op, 0);
         }
         ((float *) out)[i] = r;
@@ -169,6 +171,8 @@ int ek_hip_cast(int src, int dst, void *out, const ek_operand *a, size_t n) {
     for (size_t i = 0; i < n; ++i) {
         if (src == EK_U32 && dst == EK_F32) ((float *) out)[i] = (float) op_u(a, i);
         else if (src == EK_F32 && dst == EK_U32) ((uint32_t *) out)[i] = (uint32_t) op_f(a, i);
+        else if (src == EK_U32 && dst == EK_I64) ((int64_t *) out)[i] = (int64_t) op_u(a, i);
+        else if (src == EK_U32 && dst == EK_U64) ((uint64_t *) out)[i] = (uint64_t) op_u(a, i);
         else STUB_UNSUPPORTED("cast", src, dst);
     }
     return EK_OK;

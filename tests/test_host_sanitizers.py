@@ -36,3 +36,19 @@ def test_tape_over_deferred_nodes_under_sanitizers():
     assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
     assert "identical values and gradients" in out.stdout
 
+
+
+def test_reference_side_binding_under_sanitizers():
+    """integration/enoki/hip.h + integration/hip_hooks.cpp against the REFERENCE's headers and the host stand-in
+    (tests/cpp/integration_host.cpp): the safe_mul / safe_fmadd fragments are fused exactly when the select's operand is the
+    tagged product, tags expire on writes, widened index arrays find their 32-bit origin.  Built where the reference tree
+    exists (this container); the binary is what gets checked elsewhere."""
+    import pytest
+    exe = os.path.join(ROOT, "tests", "cpp", "integration_host.bin")
+    if not os.path.exists(exe):
+        pytest.skip("needs the reference's headers to build (enoki_amd/_build.py builds it where /root/reference exists)")
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    out = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.stdout + out.stderr)[-3000:]
+    assert "ERROR: AddressSanitizer" not in out.stderr and "runtime error" not in out.stderr, out.stderr[-3000:]
+    assert "fused exactly when tagged" in out.stdout
