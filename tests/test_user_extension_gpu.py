@@ -35,6 +35,14 @@ def test_host_static_arrays_travel_as_numpy():
     assert user_ext.positive(d).tolist() == [True, False, True]
     with pytest.raises(TypeError):
         user_ext.reflect(np.zeros(4, np.float32), n)                               # wrong shape
+    with pytest.raises(TypeError):
+        user_ext.trace(np.zeros((2, 3)))                                           # wrong shape in the second axis
+    with pytest.raises(TypeError):
+        user_ext.reflect(None, n)                                                  # None is not an array
+    assert user_ext.trace(np.array([[1, 2], [3, 4]], np.int32)) == 5.0             # other dtypes convert
+    assert user_ext.trace(np.asfortranarray(np.array([[1.0, 2.0], [3.0, 4.0]]))) == 5.0      # any memory order
+    strided = np.arange(12, dtype=np.float32)[::4]                                 # non-contiguous input
+    assert np.array_equal(user_ext.reflect(strided, n), strided - n * 2 * strided.dot(n))
 
 
 @pytest.mark.gpu
