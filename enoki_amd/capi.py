@@ -43,6 +43,8 @@ EXPORTS = [
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
     "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
+    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add",
+    "ek_hip_bucketed_destroy",
 ]
 
 
@@ -440,3 +442,47 @@ def psum(a):
     out = Buf(a.dtype, a.n)
     check(lib.ek_hip_psum(a.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(a.ptr), ctypes.c_size_t(a.n)))
     return out
+
+
+class Bucketed:
+    """u = op(A[index], x, C[index]) kept in bucket order (ek_hip_bucketed_*): reductions over map(u) and the adjoint
+    scatter_add of the two gathers without a lookup that leaves the CU.  Keeps A, C alive; x and index may be dropped."""
+
+    def __init__(self, op, A, x, C, index):
+        self.A, self.C, self.dtype, self.K = A, C, A.dtype, A.n
+        h = ctypes.c_void_p()
+        check(lib.ek_hip_bucketed_pair_create(A.ek, index.ek, TERNARY[op], ctypes.c_void_p(A.ptr), ctypes.c_void_p(C.ptr),
+                                              ctypes.c_size_t(A.n), ctypes.c_void_p(x.ptr), ctypes.c_void_p(index.ptr),
+                                              ctypes.c_size_t(index.n), ctypes.byref(h)))
+        self.handle = h
+
+    @staticmethod
+    def applicable(dtype, index_dtype, table_size, n):
+        return bool(lib.ek_hip_bucketed_applicable(NP2EK[np.dtype(dtype)], NP2EK[np.dtype(index_dtype)], ctypes.c_size_t(table_size),
+                                                   ctypes.c_size_t(n)))
+
+    def reduce(self, op, map_op=None, keep=True):
+        out = Buf(self.dtype, 1)
+        check(lib.ek_hip_bucketed_reduce(self.handle, REDUCE[op], UNARY[map_op or "copy"], ctypes.c_void_p(out.ptr), int(keep)))
+        return out
+
+    def scatter_add(self, targets, streams):
+        """streams[c] = (map_op name | None for a constant, constant value, weighted by x?)"""
+        count = len(targets)
+        bases = (ctypes.c_void_p * count)(*[t.ptr for t in targets])
+        from_u = (ctypes.c_int * count)(*[0 if s[0] is None else 1 for s in streams])
+        ops = (ctypes.c_int * count)(*[UNARY[s[0] or "copy"] for s in streams])
+        imm = (ctypes.c_uint64 * count)(*[_imm_bits(s[1], self.dtype) for s in streams])
+        wt = (ctypes.c_int * count)(*[int(bool(s[2])) for s in streams])
+        check(lib.ek_hip_bucketed_scatter_add(self.handle, count, bases, from_u, ops, imm, wt))
+
+    def destroy(self):
+        if self.handle:
+            lib.ek_hip_bucketed_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass

@@ -1,0 +1,673 @@
+// Bucket-ordered evaluation of  u = fma(gather(A, idx), x, gather(C, idx))  and of what consumes it.
+//
+// What this replaces.  The reference's JIT emits a gather into the kernel of its consumer and fuses the whole chain
+// up to the next horizontal operation into ONE kernel (src/cuda/jit.cu:984 cuda_jit_assemble, :1066-1217 the gather's
+// ld.global inside the consumer, :1418-1471 cuda_eval); the adjoint scatter_add goes through atom.global.add
+// (cuda.h:892-905).  An eager kernel that does the same lookups in ELEMENT order is bound by the L2 miss rate of the
+// parameter tables, not by HBM: for K = 1 Mi entries the interleaved {A, C} table is 8 MiB, twice the 4 MiB L2 of an
+// XCD, 54 % of the lookups miss and the kernel stops at 0.25 of the HBM roofline (profiles/rocprof_l2_r02.txt).
+//
+// What it does instead.  When the consumer of u does not care about the element order -- a horizontal reduction
+// (hsum(sin(u))), and the adjoint scatter_add of the two gathers through the SAME index array -- the elements are
+// processed BUCKET BY BUCKET:
+//
+//   1. count / scan / partition  (ek_binned.h, the scatter_add pipeline's own kernels) sorts (idx, x) by bucket of
+//      16 Ki table entries (8 Ki for 8-byte types): idx is read twice (count, partition), x once; written: a 16-bit
+//      bucket-local index and x in bucket order                                                4 + 8 + 6 B/elt
+//   2. forward   one 1024-thread workgroup per piece of a bucket stages the bucket's {A, C} slice in LDS (128 KiB),
+//                streams (l16, x_b), computes u = fma(A[l], x, C[l]) from LDS, reduces map(u) and -- when somebody
+//                else still holds u -- keeps u in bucket order                                     6 (+ 4) B/elt
+//   3. adjoint   Tape::backward() finds the partition on the node: one workgroup per piece streams (l16, u_b, x_b),
+//                evaluates the value streams (cos(u_b), safe_mul(x_b, cos(u_b))) and adds them into LDS tables under
+//                the exchange lock of the scatter_add pipeline; partial tables are folded            10 B/elt
+//
+// No lookup leaves the CU, no second count / scan / partition in the backward.  Every access that needs ELEMENT order
+// (data(), an elementwise consumer, another index array) takes the element-order kernels (gathered.hip) -- same bits
+// for u; reductions and gradients differ from the element-order path only by the order of their fp additions (parity
+// class D, like every reduction / scatter_add of this library).  Deterministic mode never comes here.
+#include "ek_binned.h"
+
+#include <limits>
+
+namespace ek {
+
+template <typename T> struct alignas(2 * sizeof(T)) PairRec { T a, c; };
+
+constexpr int kBucketThreads = 1024;        // one workgroup per CU: the {A, C} slice / two gradient tables fill 128 KiB of LDS
+constexpr int kBucketWaves = kBucketThreads / 64;
+enum { EK_REDUCE_NONE = EK_REDUCE_COUNT };   // forward kernel without a reduction: only keeps u in bucket order
+
+template <int Op, typename T> struct BucketReducer {
+    static __device__ __host__ __forceinline__ T identity() {
+        if constexpr (Op == EK_HSUM || Op == EK_REDUCE_NONE) return T(0);
+        else if constexpr (Op == EK_HPROD) return T(1);
+        else return std::numeric_limits<T>::quiet_NaN();           // minNum / maxNum (reduce.hip)
+    }
+    static __device__ __forceinline__ T combine(T acc, T v) {
+        if constexpr (Op == EK_HSUM) return acc + v;
+        else if constexpr (Op == EK_HPROD) return acc * v;
+        else if constexpr (Op == EK_HMIN) { if constexpr (sizeof(T) == 4) return __builtin_fminf(acc, v); else return __builtin_fmin(acc, v); }
+        else if constexpr (Op == EK_HMAX) { if constexpr (sizeof(T) == 4) return __builtin_fmaxf(acc, v); else return __builtin_fmax(acc, v); }
+        else return acc;
+    }
+};
+
+template <typename T> __device__ __forceinline__ T bucket_shfl_down(T v, int delta) {
+    if constexpr (sizeof(T) == 8) {
+        uint64_t u;
+        __builtin_memcpy(&u, &v, 8);
+        uint32_t lo = (uint32_t) u, hi = (uint32_t) (u >> 32);
+        lo = __shfl_down(lo, delta, 64);
+        hi = __shfl_down(hi, delta, 64);
+        u = ((uint64_t) hi << 32) | lo;
+        __builtin_memcpy(&v, &u, 8);
+        return v;
+    } else {
+        return __shfl_down(v, delta, 64);
+    }
+}
+
+template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c) {
+    if constexpr (sizeof(T) == 4) return __builtin_fmaf(a, b, c); else return __builtin_fma(a, b, c);
+}
+
+// piece `blockIdx.x` -> its bucket and its range of the bucket-ordered lists (the same cut as k_bin_accumulate)
+__device__ __forceinline__ bool bucket_piece(const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ piece_prefix,
+                                             int n_buckets, int &bucket, size_t &begin, size_t &end) {
+    __shared__ int s_bucket;
+    if (blockIdx.x >= piece_prefix[n_buckets]) return false;
+    for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
+        if (piece_prefix[b] <= blockIdx.x && blockIdx.x < piece_prefix[b + 1]) s_bucket = b;
+    __syncthreads();
+    bucket = s_bucket;
+    const size_t lo = bucket_base[bucket], hi = bucket_base[bucket + 1], q = blockIdx.x - piece_prefix[bucket];
+    const size_t pieces = piece_prefix[bucket + 1] - piece_prefix[bucket], per = (hi - lo + pieces - 1) / pieces;
+    begin = lo + q * per < hi ? lo + q * per : hi;
+    end = begin + per < hi ? begin + per : hi;
+    return true;
+}
+
+// ---- 2. forward ------------------------------------------------------------------------------------
+// The streaming part, specialised for the unary op that is applied to u before the reduction (Map, compile time: the
+// kernel switches ONCE, outside the loops -- a runtime switch per element would inline nine transcendental bodies into an
+// eight-fold unrolled loop and blow the instruction cache).
+template <typename T, int ROp, int V, int Map>
+__device__ __forceinline__ void bucket_forward_stream(const PairRec<T> *__restrict__ rec, T (&acc)[4], T *__restrict__ u_out,
+                                                      const uint16_t *__restrict__ pair_idx, const T *__restrict__ x_b,
+                                                      size_t begin, size_t end) {
+    using R = BucketReducer<ROp, T>;
+    constexpr int Bins = bins_of<T>;
+    auto one = [&](uint32_t l, T x, int slot) -> T {
+        const PairRec<T> r = rec[l & (Bins - 1)];
+        const T u = fma_t(r.a, x, r.c);
+        if constexpr (ROp != EK_REDUCE_NONE) acc[slot] = R::combine(acc[slot], UnaryOp<Map, T>::apply(u));
+        return u;
+    };
+    // a piece starts anywhere: up to 3 leading elements go one per lane, then every lane moves 4-element vectors
+    const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
+    {
+        const size_t i = begin + threadIdx.x;
+        if (i < head_end) {
+            const T u = one(pair_idx[i], x_b[i], 0);
+            if (u_out) u_out[i] = u;
+        }
+    }
+    constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;      // V vectors of 4 per lane and step
+    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
+    auto fetch = [&](Step &s, size_t at) {
+#pragma unroll
+        for (int h = 0; h < V; ++h) {
+            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
+            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
+            load4<T, true>(x_b + e, s.px[h]);
+        }
+    };
+    auto apply = [&](const Step &s, size_t at) {
+#pragma unroll
+        for (int h = 0; h < V; ++h) {
+            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
+            T u[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) u[j] = one(s.pi[h].v[j], s.px[h][j], j);
+            if (u_out) {
+                if constexpr (sizeof(T) == 4) {
+                    Pack<T, 4> po;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) po.v[j] = u[j];
+                    pack_store<T, 4, true>(u_out + e, po);
+                } else {
+                    Pack<T, 2> p0, p1;
+                    p0.v[0] = u[0]; p0.v[1] = u[1]; p1.v[0] = u[2]; p1.v[1] = u[3];
+                    pack_store<T, 2, true>(u_out + e, p0);
+                    pack_store<T, 2, true>(u_out + e + 2, p1);
+                }
+            }
+        }
+    };
+    size_t base = head_end;
+    if (base + kStep <= end) {
+        Step cur, next;
+        fetch(cur, base);
+        for (; base + 2 * kStep <= end; base += kStep) {
+            fetch(next, base + kStep);
+            apply(cur, base);
+            cur = next;
+        }
+        apply(cur, base);
+        base += kStep;
+    }
+    for (; base < end; base += (size_t) 4 * kBucketThreads) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const size_t i = base + (size_t) k * kBucketThreads + threadIdx.x;
+            if (i < end) {
+                const T u = one(__builtin_nontemporal_load(pair_idx + i), __builtin_nontemporal_load(x_b + i), k);
+                if (u_out) u_out[i] = u;
+            }
+        }
+    }
+}
+
+// flip_a / flip_c: the fma family differs by the signs of its first and third operand (fmsub: -c, fnmadd: -a, fnmsub:
+// both); the signs are applied ONCE to the staged table entries -- exact -- and the inner loop is always one fma.
+template <typename T, int ROp, int V = 2>
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__restrict__ partials, T *__restrict__ u_out,
+                                                                        const T *__restrict__ table_a, const T *__restrict__ table_c,
+                                                                        size_t table_size, int flip_a, int flip_c,
+                                                                        const uint16_t *__restrict__ pair_idx,
+                                                                        const T *__restrict__ x_b,
+                                                                        const uint32_t *__restrict__ bucket_base,
+                                                                        const uint32_t *__restrict__ piece_prefix, int n_buckets,
+                                                                        int map_op) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
+    __shared__ T wave_part[kBucketWaves];
+    using R = BucketReducer<ROp, T>;
+    constexpr int Bins = bins_of<T>;
+    int bucket;
+    size_t begin, end;
+    if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) {
+        if (ROp != EK_REDUCE_NONE && threadIdx.x == 0) partials[blockIdx.x] = R::identity();
+        return;
+    }
+    {
+        // the bucket's slice of both tables, interleaved: every element then costs ONE ds_read_b64 (b128 for doubles)
+        const size_t first = (size_t) bucket * Bins;
+        for (int j = threadIdx.x; j < Bins; j += kBucketThreads) {
+            const size_t k = first + j;
+            T a = k < table_size ? table_a[k] : T(0), c = k < table_size ? table_c[k] : T(0);
+            if (flip_a) a = -a;
+            if (flip_c) c = -c;
+            rec[j] = PairRec<T>{ a, c };
+        }
+    }
+    __syncthreads();
+
+    T acc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) acc[k] = R::identity();
+#define EK_FWD_CASE(OP) case OP: bucket_forward_stream<T, ROp, V, OP>(rec, acc, u_out, pair_idx, x_b, begin, end); break;
+    if constexpr (ROp == EK_REDUCE_NONE) {
+        bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end);
+    } else {
+        switch (map_op) {
+            EK_FWD_CASE(EK_NEG) EK_FWD_CASE(EK_ABS) EK_FWD_CASE(EK_SQRT) EK_FWD_CASE(EK_RCP) EK_FWD_CASE(EK_RSQRT)
+            EK_FWD_CASE(EK_SIN) EK_FWD_CASE(EK_COS) EK_FWD_CASE(EK_EXP) EK_FWD_CASE(EK_LOG)
+            default: bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end); break;
+        }
+    }
+#undef EK_FWD_CASE
+    if constexpr (ROp != EK_REDUCE_NONE) {
+        T v = R::combine(R::combine(acc[0], acc[1]), R::combine(acc[2], acc[3]));
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) wave_part[wave] = v;
+        __syncthreads();
+        if (threadIdx.x < 64) {
+            v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : R::identity();
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
+            if (threadIdx.x == 0) partials[blockIdx.x] = v;
+        }
+    }
+}
+
+template <typename T, int ROp>
+__global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out, const T *__restrict__ partials, unsigned count) {
+    using R = BucketReducer<ROp, T>;
+    __shared__ T wave_part[4];
+    T v = R::identity();
+    for (unsigned i = threadIdx.x; i < count; i += 256) v = R::combine(v, partials[i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
+    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = R::combine(R::combine(wave_part[0], wave_part[1]), R::combine(wave_part[2], wave_part[3]));
+}
+
+// ---- 3. adjoint ------------------------------------------------------------------------------------
+// Value stream c of the scatter_add:  v_c = from_u(c) ? map_c(u) : imm_c,  times x with safe_mul semantics when weighted(c)
+// (the tape's pending edge product w * g, autodiff.cpp:1191-1199) -- added to table c at the element's index.
+template <typename T, int C> struct BucketStreams {
+    int map_op[C];
+    T imm[C];
+    unsigned from_u, weighted;
+};
+
+// Two f32 tables share ONE lock per bin: the LDS holds {table 0, table 1} pairs and a bin pair is claimed by a 64-bit
+// exchange (ds_wrxchg_rtn_b64), updated and released by one 64-bit store -- half the LDS atomics and half the dependent
+// round trips of two independent 32-bit locks.  Same protocol as lds_add (ek_binned.h), see there for why the retry loop
+// is wave-uniform.
+constexpr unsigned long long kLockedPair = 0xFFC00001FFC00001ull;
+
+__device__ __forceinline__ unsigned long long pair_sum(unsigned long long old, float v0, float v1) {
+    const float s0 = __uint_as_float((unsigned) old) + v0, s1 = __uint_as_float((unsigned) (old >> 32)) + v1;
+    unsigned long long bits = (unsigned long long) __float_as_uint(s0) | ((unsigned long long) __float_as_uint(s1) << 32);
+    if (bits == kLockedPair) bits = 0x7FC000007FC00000ull;          // never publish the lock pattern
+    return bits;
+}
+
+__device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, float v1, bool active) {
+    bool pending = active;
+    if (pending) {
+        const unsigned long long old = atomicExch(p, kLockedPair);
+        if (old != kLockedPair) {
+            __hip_atomic_store(p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pending = false;
+        }
+    }
+    const unsigned key = (unsigned) (uintptr_t) p;
+    const int lane = threadIdx.x & 63;
+    while (__any(pending)) {
+        const unsigned long long pend = __ballot(pending);
+        const int leader = __ffsll((long long) pend) - 1;
+        const unsigned leader_key = __shfl(key, leader);
+        const bool grouped = pending && key == leader_key;
+        float t0 = grouped ? v0 : 0.0f, t1 = grouped ? v1 : 0.0f;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { t0 += __shfl_xor(t0, d); t1 += __shfl_xor(t1, d); }
+        if (lane == leader) {
+            unsigned long long old;
+            do { old = atomicExch(p, kLockedPair); } while (old == kLockedPair);
+            __hip_atomic_store(p, pair_sum(old, t0, t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        pending = pending && !grouped;
+    }
+}
+
+// The streaming part.  Map >= 0: every stream that is a function of u applies THIS op (compile time; evaluated once per
+// element however many streams share it -- the usual pair cos(u), x * cos(u)); Map < 0: per-stream ops chosen at run time.
+template <typename T, int C, int V, int Map>
+__device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, const BucketStreams<T, C> &st,
+                                                         const uint16_t *__restrict__ pair_idx, const T *__restrict__ u_b,
+                                                         const T *__restrict__ x_b, size_t begin, size_t end) {
+    constexpr int Bins = bins_of<T>;
+    constexpr bool Paired = C == 2 && sizeof(T) == 4;
+    const bool need_u = st.from_u != 0, need_x = st.weighted != 0;
+    // every lane of a wave passes through the lock (its retry loop is wave-uniform): inactive lanes add nothing
+    auto one = [&](uint32_t l, T u, T x, bool on) {
+        T v[C];
+        T m = T(0);
+        if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            if constexpr (Map >= 0) v[c] = ((st.from_u >> c) & 1u) ? m : st.imm[c];
+            else v[c] = ((st.from_u >> c) & 1u) ? unary_fused<T>(st.map_op[c], u) : st.imm[c];
+            if ((st.weighted >> c) & 1u) v[c] = dev::safe_mul(x, v[c]);
+        }
+        if constexpr (Paired) {
+            lds_add_pair(reinterpret_cast<unsigned long long *>(acc) + (l & (Bins - 1)), v[0], v[C - 1], on);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) lds_add<true>(&acc[c * Bins + (l & (Bins - 1))], v[c], on);
+        }
+    };
+
+    const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
+    {
+        const size_t i = begin + threadIdx.x;
+        const bool on = i < head_end;
+        one(on ? (uint32_t) pair_idx[i] : 0u, (on && need_u) ? u_b[i] : T(0), (on && need_x) ? x_b[i] : T(0), on);
+    }
+    // V vectors of 4 per lane, array and step; the loads of step i + 1 are issued before the LDS updates of step i
+    constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;
+    struct Step { Pack<uint16_t, 4> pi[V]; T pu[V][4], px[V][4]; };
+    auto fetch = [&](Step &s, size_t at) {
+#pragma unroll
+        for (int h = 0; h < V; ++h) {
+            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
+            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
+            if (need_u) load4<T, true>(u_b + e, s.pu[h]);
+            if (need_x) load4<T, true>(x_b + e, s.px[h]);
+        }
+    };
+    auto apply = [&](const Step &s) {
+#pragma unroll
+        for (int h = 0; h < V; ++h)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) one(s.pi[h].v[j], need_u ? s.pu[h][j] : T(0), need_x ? s.px[h][j] : T(0), true);
+    };
+    size_t base = head_end;
+    if (base + kStep <= end) {
+        Step cur, next;
+        fetch(cur, base);
+        for (; base + 2 * kStep <= end; base += kStep) {
+            fetch(next, base + kStep);
+            apply(cur);
+            cur = next;
+        }
+        apply(cur);
+        base += kStep;
+    }
+    for (; base < end; base += kBucketThreads) {
+        const size_t i = base + threadIdx.x;
+        const bool on = i < end;
+        one(on ? (uint32_t) pair_idx[i] : 0u, (on && need_u) ? u_b[i] : T(0), (on && need_x) ? x_b[i] : T(0), on);
+    }
+}
+
+template <typename T, int C, int V = 2>
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restrict__ partials,
+                                                                      const uint16_t *__restrict__ pair_idx,
+                                                                      const T *__restrict__ u_b, const T *__restrict__ x_b,
+                                                                      const uint32_t *__restrict__ bucket_base,
+                                                                      const uint32_t *__restrict__ piece_prefix, int n_buckets,
+                                                                      BucketStreams<T, C> st) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    T *acc = reinterpret_cast<T *>(lds_raw);                 // C tables of Bins entries; two f32 tables: Bins {t0, t1} pairs
+    constexpr int Bins = bins_of<T>;
+    constexpr bool Paired = C == 2 && sizeof(T) == 4;
+    int bucket;
+    size_t begin, end;
+    if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) return;
+    for (int j = threadIdx.x; j < C * Bins; j += kBucketThreads) acc[j] = T(0);
+    __syncthreads();
+
+    // one op for all streams that read u?  (streams that do not read u do not care)
+    int op = EK_COPY;
+    bool uniform = true, first = true;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        if (!((st.from_u >> c) & 1u)) continue;
+        if (first) { op = st.map_op[c]; first = false; }
+        else uniform = uniform && st.map_op[c] == op;
+    }
+#define EK_ACC_CASE(OP) case OP: bucket_accumulate_stream<T, C, V, OP>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+    if (uniform) {
+        switch (op) {
+            EK_ACC_CASE(EK_NEG) EK_ACC_CASE(EK_ABS) EK_ACC_CASE(EK_SQRT) EK_ACC_CASE(EK_RCP) EK_ACC_CASE(EK_RSQRT)
+            EK_ACC_CASE(EK_SIN) EK_ACC_CASE(EK_COS) EK_ACC_CASE(EK_EXP) EK_ACC_CASE(EK_LOG)
+            default: bucket_accumulate_stream<T, C, V, EK_COPY>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+        }
+    } else {
+        bucket_accumulate_stream<T, C, V, -1>(acc, st, pair_idx, u_b, x_b, begin, end);
+    }
+#undef EK_ACC_CASE
+    __syncthreads();
+    // one bucket-sized partial per piece and table: table c at partials + c * gridDim.x * Bins (k_bin_fold_pieces)
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        T *out = partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
+        for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? acc[2 * j + c] : acc[c * Bins + j];
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+struct Bucketed {
+    int type = 0, index_type = 0, op = 0;
+    size_t n = 0, table_size = 0;
+    const void *table_a = nullptr, *table_c = nullptr;    // not owned: the caller keeps the tables alive and unchanged
+    int n_buckets = 0;
+    unsigned max_pieces = 0;
+    void *meta = nullptr;          // counts[n_buckets][blocks] | row_total | bucket_base | piece_prefix | reduce partials
+    uint32_t *bucket_base = nullptr, *piece_prefix = nullptr;
+    void *reduce_partials = nullptr;
+    void *pair_idx = nullptr;      // uint16_t[n]: index within the bucket, bucket order
+    void *x_b = nullptr;           // x in bucket order
+    void *u_b = nullptr;           // u in bucket order (allocated by the first consumer that keeps it)
+    bool has_u = false;
+
+    ~Bucketed() {
+        for (void *p : { meta, pair_idx, x_b, u_b })
+            if (p) ek_hip_free(p);
+    }
+};
+
+static size_t bucket_target_pieces(size_t n, int n_buckets) {
+    Context &c = ctx();
+    static const int per_cu = [] { const char *e = getenv("ENOKI_HIP_BUCKET_PIECES_PER_CU"); return e ? atoi(e) : 1; }();
+    static const size_t piece_elems = [] { const char *e = getenv("ENOKI_HIP_PIECE_ELEMS"); return e ? (size_t) atol(e) : (size_t) 32768; }();
+    return std::max<size_t>(std::min<size_t>((size_t) std::max(per_cu, 1) * (size_t) c.num_cu, n / piece_elems), (size_t) n_buckets);
+}
+
+template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
+    // beyond 64 KiB of dynamic LDS a kernel has to opt in
+    EK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+    return EK_OK;
+}
+
+template <typename T, typename I>
+static int bucketed_create(Bucketed *b, const T *x, const I *index) {
+    RoctxRange range("enoki-hip: bucket partition");
+    Context &c = ctx();
+    constexpr int Bins = bins_of<T>, Shift = bin_shift_of<T>;
+    const size_t n = b->n;
+    const int n_buckets = b->n_buckets = (int) ((b->table_size + Bins - 1) / Bins);
+
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+
+    const Arg<uint8_t> mask{ nullptr, 1, 0u };
+    const Arg<T> xv{ x, T(0), 1u };
+    const int vec_ok = aligned16(index) && aligned16(x);
+    int rep_shift = 0;
+    while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
+
+    const uint32_t target_pieces = (uint32_t) bucket_target_pieces(n, n_buckets);
+    b->max_pieces = target_pieces + (unsigned) n_buckets;
+    const size_t count_entries = (size_t) n_buckets * blocks;
+    const size_t meta_words = count_entries + 3 * kMaxBuckets + 2;
+    if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(T) + 16, &b->meta)) return rc;
+    if (int rc = ek_hip_malloc(n * sizeof(uint16_t), &b->pair_idx)) return rc;
+    if (int rc = ek_hip_malloc(n * sizeof(T), &b->x_b)) return rc;
+    uint32_t *counts = (uint32_t *) b->meta, *row_total = counts + count_entries;
+    b->bucket_base = row_total + kMaxBuckets;
+    b->piece_prefix = b->bucket_base + kMaxBuckets + 1;
+    b->reduce_partials = (void *) (((uintptr_t) (counts + meta_words) + 15) & ~(uintptr_t) 15);
+
+    hipLaunchKernelGGL((k_bin_count<I, Shift>), dim3(blocks), dim3(kThreads), 0, c.stream, counts, index, mask, n, chunk,
+                       n_buckets, rep_shift, vec_ok);
+    EK_LAUNCH_CHECK("bucket_count", n, n * sizeof(I));
+    hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_buckets), dim3(1024), 0, c.stream, counts, row_total, blocks);
+    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, b->bucket_base, b->piece_prefix,
+                       (const uint32_t *) row_total, n_buckets, target_pieces);
+    EK_LAUNCH_CHECK("bucket_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
+    BinStreams<T, 1> st;
+    st.value[0] = xv;
+    st.weight[0] = Arg<T>{ nullptr, T(1), 0u };
+    st.pair_val[0] = (T *) b->x_b;
+    st.weighted = 0u;
+    st.value_op[0] = EK_COPY;
+    hipLaunchKernelGGL((k_bin_partition<T, I, Shift, uint16_t, 1>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                       (uint16_t *) b->pair_idx, st, (const uint32_t *) counts, (const uint32_t *) b->bucket_base, index, mask, n,
+                       chunk, n_buckets, 0, vec_ok);
+    EK_LAUNCH_CHECK("bucket_partition", n, n * (sizeof(I) + sizeof(T)) + n * (sizeof(uint16_t) + sizeof(T)));
+    return EK_OK;
+}
+
+template <typename T, int ROp>
+static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep) {
+    Context &c = ctx();
+    constexpr int Bins = bins_of<T>;
+    const size_t lds = (size_t) Bins * sizeof(PairRec<T>);
+    if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp>, lds)) return rc;
+    if (keep && !b->u_b)
+        if (int rc = ek_hip_malloc(b->n * sizeof(T), &b->u_b)) return rc;
+    const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
+#define EK_FWD(VV)                                                                                                          \
+    hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,           \
+                       (T *) b->reduce_partials, keep ? (T *) b->u_b : (T *) nullptr, (const T *) b->table_a,                   \
+                       (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,                   \
+                       (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, \
+                       map_op)
+    EK_FWD(2);
+#undef EK_FWD
+    EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
+                    b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
+    if (keep) b->has_u = true;
+    if constexpr (ROp != EK_REDUCE_NONE) {
+        hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out,
+                           (const T *) b->reduce_partials, b->max_pieces);
+        EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    }
+    return EK_OK;
+}
+
+template <typename T>
+static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bool keep) {
+    RoctxRange range("enoki-hip: bucket-ordered gather + fma + reduction");
+    if (b->has_u) {
+        // u already exists in bucket order: an ordinary reduction over it
+        if (map_op == EK_COPY) return ek_hip_reduce(reduce_op, b->type, out, b->u_b, b->n);
+        return ek_hip_reduce_map(reduce_op, map_op, b->type, out, b->u_b, b->n);
+    }
+    switch (reduce_op) {
+        case EK_HSUM: return bucketed_forward_launch<T, EK_HSUM>(b, out, map_op, keep);
+        case EK_HPROD: return bucketed_forward_launch<T, EK_HPROD>(b, out, map_op, keep);
+        case EK_HMIN: return bucketed_forward_launch<T, EK_HMIN>(b, out, map_op, keep);
+        case EK_HMAX: return bucketed_forward_launch<T, EK_HMAX>(b, out, map_op, keep);
+        default: return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): unknown op %d", reduce_op);
+    }
+}
+
+template <typename T, int C>
+static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams<T, C> &st) {
+    Context &c = ctx();
+    constexpr int Bins = bins_of<T>;
+    const size_t lds = (size_t) C * Bins * sizeof(T);
+    if (int rc = allow_big_lds(k_bucket_accumulate<T, C>, lds)) return rc;
+    Scratch partials;
+    if (int rc = partials.alloc((size_t) C * b->max_pieces * Bins * sizeof(T))) return rc;
+#define EK_ACC(VV)                                                                                                          \
+    hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,               \
+                       (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) b->u_b, (const T *) b->x_b,              \
+                       (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st)
+    EK_ACC(2);
+#undef EK_ACC
+    EK_LAUNCH_CHECK("bucket_accumulate", (size_t) C * b->n,
+                    b->n * (sizeof(uint16_t) + (st.from_u ? sizeof(T) : 0) + (st.weighted ? sizeof(T) : 0)) +
+                    (size_t) C * b->max_pieces * Bins * sizeof(T));
+    FoldTargets<T, C> targets;
+    for (int s = 0; s < C; ++s) targets.table[s] = bases[s];
+    hipLaunchKernelGGL((k_bin_fold_pieces<T, C>), dim3((unsigned) ((b->table_size + 255) / 256), C), dim3(256), 0, c.stream, targets,
+                       (const T *) partials.ptr, (const uint32_t *) b->piece_prefix, b->table_size, (size_t) b->max_pieces * Bins);
+    EK_LAUNCH_CHECK("scatter_add_fold", (size_t) C * b->table_size,
+                    (size_t) C * ((size_t) b->max_pieces * Bins * sizeof(T) + 2 * b->table_size * sizeof(T)));
+    return EK_OK;
+}
+
+template <typename T>
+static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
+                                const uint64_t *imm_bits, const int *weighted) {
+    RoctxRange range("enoki-hip: bucket-ordered scatter_add");
+    bool need_u = false;
+    for (int s = 0; s < count; ++s) need_u = need_u || from_u[s];
+    if (need_u && !b->has_u)
+        if (int rc = bucketed_forward_launch<T, EK_REDUCE_NONE>(b, nullptr, EK_COPY, true)) return rc;
+    // two tables per launch: their LDS tables fill the 128 KiB a workgroup may use
+    for (int s0 = 0; s0 < count; s0 += 2) {
+        const int C = std::min(2, count - s0);
+        T *tb[2] = { (T *) bases[s0], C == 2 ? (T *) bases[s0 + 1] : nullptr };
+        if (C == 2) {
+            BucketStreams<T, 2> st{};
+            for (int s = 0; s < 2; ++s) {
+                st.map_op[s] = map_ops ? map_ops[s0 + s] : (int) EK_COPY;
+                memcpy(&st.imm[s], &imm_bits[s0 + s], sizeof(T));
+                st.from_u |= (from_u[s0 + s] ? 1u : 0u) << s;
+                st.weighted |= (weighted[s0 + s] ? 1u : 0u) << s;
+            }
+            if (int rc = bucketed_accumulate<T, 2>(b, tb, st)) return rc;
+        } else {
+            BucketStreams<T, 1> st{};
+            st.map_op[0] = map_ops ? map_ops[s0] : (int) EK_COPY;
+            memcpy(&st.imm[0], &imm_bits[s0], sizeof(T));
+            st.from_u = from_u[s0] ? 1u : 0u;
+            st.weighted = weighted[s0] ? 1u : 0u;
+            if (int rc = bucketed_accumulate<T, 1>(b, tb, st)) return rc;
+        }
+    }
+    return EK_OK;
+}
+
+} // namespace ek
+
+using namespace ek;
+
+struct ek_hip_bucketed : ek::Bucketed { };
+
+extern "C" {
+
+int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n) {
+    if (type != EK_F32 && type != EK_F64) return 0;
+    if (index_type != EK_U32 && index_type != EK_I32) return 0;
+    if (ctx().tuning.deterministic || !ctx().tuning.bucket_ordered) return 0;
+    const size_t bins = type == EK_F64 ? (size_t) bins_of<double> : (size_t) bins_of<float>;
+    return n >= ((size_t) 1 << 18) && n < ((size_t) 1 << 32) && table_size > bins && table_size <= (size_t) kMaxBuckets * bins;
+}
+
+int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
+                                const void *x, const void *index, size_t n, ek_hip_bucketed **out) {
+    if (int rc = ensure_init()) return rc;
+    if (!out || !table_a || !table_c || !x || !index) return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): null pointer");
+    *out = nullptr;
+    if (op != EK_FMADD && op != EK_FMSUB && op != EK_FNMADD && op != EK_FNMSUB)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): op %d is not of the fma family", op);
+    if (!ek_hip_bucketed_applicable(type, index_type, table_size, n))
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): shape not covered (type %d, %zu lookups into %zu entries%s)",
+                    type, n, table_size, ctx().tuning.deterministic ? ", deterministic mode" : "");
+    ek_hip_bucketed *b = new ek_hip_bucketed();
+    b->type = type; b->index_type = index_type; b->op = op;
+    b->n = n; b->table_size = table_size;
+    b->table_a = table_a; b->table_c = table_c;
+    int rc;
+    // valid int32 indices are non-negative: same bits as uint32
+    if (type == EK_F32) rc = bucketed_create<float, uint32_t>(b, (const float *) x, (const uint32_t *) index);
+    else rc = bucketed_create<double, uint32_t>(b, (const double *) x, (const uint32_t *) index);
+    if (rc != EK_OK) { delete b; return rc; }
+    *out = b;
+    return EK_OK;
+}
+
+int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values) {
+    if (int rc = ensure_init()) return rc;
+    if (!b || !out) return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): null pointer");
+    if (map_op != EK_COPY && !unary_fusable(map_op))
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_reduce(): op %d cannot be applied on load", map_op);
+    if (b->type == EK_F32) return bucketed_reduce<float>(b, reduce_op, map_op, out, keep_values != 0);
+    return bucketed_reduce<double>(b, reduce_op, map_op, out, keep_values != 0);
+}
+
+int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
+                                const uint64_t *imm_bits, const int *weighted) {
+    if (int rc = ensure_init()) return rc;
+    if (!b || !bases || !from_u || !imm_bits || !weighted || count < 1 || count > 4)
+        return fail(EK_ERR_INVALID, "ek_hip_bucketed_scatter_add(): bad arguments");
+    for (int s = 0; s < count; ++s) {
+        if (!bases[s]) return fail(EK_ERR_INVALID, "ek_hip_bucketed_scatter_add(): null table");
+        if (from_u[s] && map_ops && map_ops[s] != EK_COPY && !unary_fusable(map_ops[s]))
+            return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_scatter_add(): op %d cannot be applied on load", map_ops[s]);
+    }
+    if (b->type == EK_F32) return bucketed_scatter_add<float>(b, count, bases, from_u, map_ops, imm_bits, weighted);
+    return bucketed_scatter_add<double>(b, count, bases, from_u, map_ops, imm_bits, weighted);
+}
+
+int ek_hip_bucketed_destroy(ek_hip_bucketed *b) {
+    delete b;
+    return EK_OK;
+}
+
+} // extern "C"

@@ -30,6 +30,7 @@ struct Tuning {
     int scatter_add_binned = 1;   // 1: LDS-binned scatter_add for large inputs, 0: global atomics only
     int deterministic = 0;        // 1: fp scatter_add always takes the bit-reproducible sorted path (ENOKI_HIP_DETERMINISTIC)
     int gather_records = 1;       // struct gathers through staged {x, y, ..} records: 1 by size, 2 always, 0 never
+    int bucket_ordered = 1;       // gather -> fma -> {reduction, scatter_add} chains in bucket order (bucketed.hip); 0: element order only
 };
 
 struct Context {

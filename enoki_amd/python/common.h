@@ -766,11 +766,9 @@ inline void bind_runtime(py::module_ &m) {
     // step graphs: capture once, replay without host work (ek_hip_graph_*)
     m.def("hip_graph_begin", []() { hip_graph_begin(); },
           "start capturing a step graph; arrays that are still unevaluated (deferred gathers / unary results) are evaluated first");
-    m.def("hip_graph_end", []() {
-        ek_hip_graph *g = nullptr;
-        detail::hip_check(ek_hip_graph_end(&g), "hip_graph_end");
-        return (uintptr_t) g;
-    }, "returns a graph handle for hip_graph_launch / hip_graph_destroy");
+    m.def("hip_graph_end", []() { return (uintptr_t) hip_graph_end(); },
+          "ends the capture (arrays that are still unevaluated are evaluated INSIDE the graph first, so every replay refreshes "
+          "them); returns a graph handle for hip_graph_launch / hip_graph_destroy");
     m.def("hip_graph_launch", [](uintptr_t g) { detail::hip_check(ek_hip_graph_launch((ek_hip_graph *) g), "hip_graph_launch"); });
     m.def("hip_graph_launch_count", [](uintptr_t g) { return ek_hip_graph_launch_count((const ek_hip_graph *) g); });
     m.def("hip_graph_destroy", [](uintptr_t g) { detail::hip_check(ek_hip_graph_destroy((ek_hip_graph *) g), "hip_graph_destroy"); });

@@ -59,8 +59,17 @@ namespace detail {
             int type, index_type;              // map: index_type holds the unary op
             size_t elem_size;
             bool consumed;                     // a fused consumer has read it once: the next access materialises (gathers)
-            int kind = 0;                      // 0: gather, 1: unary map
+            int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below)
             HIPBuffer *partner = nullptr;      // map: the other half of an unevaluated sincos pair (not owning)
+            // kind 2:  u = op(table[index], arg0, table2[index])  with op of the fma family -- the parameter lookup
+            // `fmadd(gather(A, idx), x, gather(B, idx))`.  Left unevaluated one step longer than its gathers: when the
+            // consumer does not care about the element order (a horizontal reduction, possibly through a deferred unary map;
+            // the adjoint scatter_add of the two gathers through the same index array) the chain runs BUCKET BY BUCKET out
+            // of LDS-resident table slices (ek_hip_bucketed_*) and the partition is kept here for the backward sweep.  Every
+            // other access evaluates u in element order with the kernels that consume a gather in place (same bits).
+            HIPBuffer *table2 = nullptr, *arg0 = nullptr;      // references held
+            int op = 0;
+            ek_hip_bucketed *bucketed = nullptr;               // the partition of (index, arg0) by table bucket, once built
         };
         Deferred *deferred = nullptr;
         std::vector<HIPBuffer *> readers;      // deferred nodes whose table / source is THIS buffer (not owning)
@@ -117,6 +126,7 @@ namespace detail {
         /// Execute a deferred unary map; a sincos pair is evaluated by one kernel
         void force_map() {
             Deferred *d = deferred;
+            if (d->table->deferred) d->table->force();          // a source that is an unevaluated fma of gathers runs first
             const size_t bytes = (size ? size : 1) * d->elem_size;
             ek_operand src{ d->table->ptr, 0, d->table->size };
             HIPBuffer *other = d->partner && d->partner->deferred ? d->partner : nullptr;
@@ -145,10 +155,48 @@ namespace detail {
             drop_deferred();
         }
 
+        /// Element-order evaluation of a deferred fma over a gathered pair: one kernel, gathers consumed in place
+        void force_pair() {
+            Deferred *d = deferred;
+            void *p = nullptr;
+            hip_check(ek_hip_malloc((size ? size : 1) * d->elem_size, &p), "HIPArray (deferred fma of gathers)");
+            ek_gathered ga, gc;
+            ga.table = d->table->ptr;
+            ga.table_size = d->table->size;
+            ga.index = ek_operand{ d->index->ptr, 0, d->index->size };
+            ga.index_type = d->index_type;
+            ga.mask = ek_operand{ nullptr, 1, 1 };
+            gc = ga;
+            gc.table = d->table2->ptr;
+            gc.table_size = d->table2->size;
+            ek_operand x{ d->arg0->ptr, 0, d->arg0->size };
+            const ek_gathered *pg[3] = { &ga, nullptr, &gc };
+            const ek_operand *po[3] = { nullptr, &x, nullptr };
+            if (ek_hip_map_gathered(3, d->op, d->type, p, po, pg, size) != EK_OK) {
+                ek_hip_free(p);
+                hip_raise("HIPArray (deferred fma of gathers)");
+            }
+            ptr = p;
+            drop_deferred();
+        }
+
+        /// The bucket partition of a kind-2 node (built on first use); nullptr when the library does not cover the shape
+        ek_hip_bucketed *bucketed() {
+            Deferred *d = deferred;
+            if (!d->bucketed) {
+                int rc = ek_hip_bucketed_pair_create(d->type, d->index_type, d->op, d->table->ptr, d->table2->ptr, d->table->size,
+                                                     d->arg0->ptr, d->index->ptr, size, &d->bucketed);
+                if (rc == EK_ERR_UNSUPPORTED) return nullptr;
+                hip_check(rc, "HIPArray (bucket partition)");
+            }
+            return d->bucketed;
+        }
+
         /// Execute the deferred gather / map
         void force() {
             if (!deferred) return;
             if (deferred->kind == 1) { force_map(); return; }
+            if (deferred->kind == 2) { force_pair(); return; }
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (deferred gather)");
             ek_gathered g = gathered();
@@ -171,7 +219,8 @@ namespace detail {
             deferred = nullptr;
             pending_unlink();
             if (d->partner && d->partner->deferred) d->partner->deferred->partner = nullptr;
-            for (HIPBuffer *src : { d->table, d->index, d->mask }) {
+            if (d->bucketed) ek_hip_bucketed_destroy(d->bucketed);
+            for (HIPBuffer *src : { d->table, d->index, d->mask, d->table2, d->arg0 }) {
                 if (!src) continue;
                 auto &r = src->readers;
                 for (size_t i = 0; i < r.size(); ++i)
@@ -180,6 +229,8 @@ namespace detail {
             unref(d->table);
             unref(d->index);
             unref(d->mask);
+            unref(d->table2);
+            unref(d->arg0);
             delete d;
         }
 
@@ -611,12 +662,15 @@ template <typename Value_> struct HIPArray : ArrayTag {
     template <typename Index>
     static HIPArray defer_gather_(const HIPArray &source, const Index &index, const MaskType &mask) {
         HIPArray r;
-        if (!detail::hip_defer_gather_flag() || !source.m_buf || !source.m_buf->owned || !index.m_buf)
+        // tables that an external view may write behind our back (zero-copy exports), index / mask arrays in foreign memory:
+        // evaluated right away
+        if (!detail::hip_defer_gather_flag() || !source.m_buf || !source.m_buf->owned || source.m_buf->exported ||
+            !index.m_buf || !index.m_buf->owned || index.m_buf->exported)
             return r;
         const size_t n = index.m_buf->size;
         const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_min_size_;
         if (n < least || n < 2 || source.m_buf->size * sizeof(Value) > defer_max_table_bytes_) return r;
-        if (mask.m_is_imm ? !mask.m_imm : (!mask.m_buf || mask.m_buf->size != n)) return r;
+        if (mask.m_is_imm ? !mask.m_imm : (!mask.m_buf || mask.m_buf->size != n || !mask.m_buf->owned || mask.m_buf->exported)) return r;
         source.ptr_();                                       // a table that is itself deferred runs first
         auto *d = new typename detail::HIPBuffer::Deferred{ source.m_buf, index.m_buf, mask.m_is_imm ? nullptr : mask.m_buf,
                                                             Type, Index::Type, sizeof(Value), false };
@@ -637,6 +691,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
     bool deferred_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 0 && !m_buf->deferred->consumed; }
     /// An unevaluated unary map (see detail::HIPBuffer)
     bool mapped_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 1; }
+    /// An unevaluated fma over a gathered pair (kind 2, see detail::HIPBuffer)
+    bool paired_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 2; }
 
     /// Unary ops whose result is left unevaluated until its first consumer: the ones ek_hip_reduce_map /
     /// ek_hip_scatter_add_multi_map can apply on load.  Small arrays are evaluated right away (nothing to win).
@@ -647,10 +703,12 @@ template <typename Value_> struct HIPArray : ArrayTag {
     }
     bool can_defer_map_() const {
         const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_map_min_size_;
-        return IsFloat && detail::hip_defer_gather_flag() && !m_is_imm && m_buf && m_buf->owned && m_buf->size >= least && m_buf->size > 1;
+        return IsFloat && detail::hip_defer_gather_flag() && !m_is_imm && m_buf && m_buf->owned && !m_buf->exported &&
+               m_buf->size >= least && m_buf->size > 1;
     }
     HIPArray defer_map_(int op) const {
-        ptr_();                                              // a source that is itself deferred runs first
+        if (!paired_()) ptr_();                              // a source that is a deferred gather / map runs first; an fma of
+                                                             // gathers stays: its consumer may want it in bucket order
         auto *d = new typename detail::HIPBuffer::Deferred{ m_buf, nullptr, nullptr, Type, op, sizeof(Value), false, 1, nullptr };
         m_buf->ref_count++;
         HIPArray r;
@@ -660,6 +718,57 @@ template <typename Value_> struct HIPArray : ArrayTag {
         r.m_buf->pending_link();
         m_buf->readers.push_back(r.m_buf);
         return r;
+    }
+
+    /// op(gather(A, idx), x, gather(C, idx)) (fma family, shared index array, no mask, x an array) stays unevaluated as a
+    /// kind-2 node when the library's bucket-ordered path covers the shape (see detail::HIPBuffer::Deferred); returns an
+    /// invalid array otherwise.  The two gathers are marked as consumed, exactly as if the fused kernel had run.
+    static HIPArray defer_pair_fma_(int op, const HIPArray &ga, const HIPArray &x, const HIPArray &gc, size_t n) {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const auto *p = ga.m_buf->deferred, *q = gc.m_buf->deferred;
+            if (!detail::hip_defer_gather_flag() || p->mask || q->mask || x.m_is_imm || !x.m_buf || x.m_buf->size != n ||
+                !x.m_buf->owned || x.m_buf->exported || x.m_buf->deferred)
+                return r;
+            if (!ek_hip_bucketed_applicable(Type, p->index_type, p->table->size, n)) return r;
+            auto *d = new typename detail::HIPBuffer::Deferred{ p->table, p->index, nullptr, Type, p->index_type, sizeof(Value),
+                                                                false, 2, nullptr };
+            d->table2 = q->table;
+            d->arg0 = x.m_buf;
+            d->op = op;
+            r.m_buf = new detail::HIPBuffer();
+            r.m_buf->size = n;
+            r.m_buf->deferred = d;
+            r.m_buf->pending_link();
+            detail::HIPBuffer *seen[4] = { nullptr, nullptr, nullptr, nullptr };
+            int k = 0;
+            for (detail::HIPBuffer *src : { d->table, d->index, d->table2, d->arg0 }) {
+                src->ref_count++;
+                bool dup = false;
+                for (int j = 0; j < k; ++j) dup = dup || seen[j] == src;
+                if (!dup) { src->readers.push_back(r.m_buf); seen[k++] = src; }
+            }
+            ga.m_buf->deferred->consumed = true;
+            gc.m_buf->deferred->consumed = true;
+        }
+        return r;
+    }
+
+    /// Horizontal reduction over map_op(u) of an unevaluated kind-2 node `u` in bucket order; false: not covered (the caller
+    /// evaluates u in element order).  `held_by_consumer`: references on u that belong to the array being reduced.
+    static bool reduce_bucketed_(detail::HIPBuffer *u, int op, int map_op, void *out, uint32_t held_by_consumer) {
+        if constexpr (!IsFloat) {
+            return false;
+        } else {
+            ek_hip_bucketed *b = u->bucketed();
+            if (!b) return false;
+            // somebody else can still ask for u (the cos(u) of the derivative, a user handle): keep it in bucket order
+            const int keep = u->ref_count > held_by_consumer ? 1 : 0;
+            int rc = ek_hip_bucketed_reduce(b, op, map_op, out, keep);
+            if (rc == EK_ERR_UNSUPPORTED) return false;
+            detail::hip_check(rc, "HIPArray (bucket-ordered reduction)");
+            return true;
+        }
     }
 
     static constexpr size_t gather_multi_small_ = (size_t) 3 << 20, gather_multi_large_ = (size_t) 128 << 20;
@@ -746,6 +855,9 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if (count == 0 || count > kMax) throw std::runtime_error("HIPArray::scatter_add_multi_(): 1 to 4 streams expected");
         index.require_valid("scatter_add_multi_"); mask.require_valid("scatter_add_multi_");
         size_t n = broadcast_size(index.size(), mask.size());
+        if constexpr (IsFloat) {
+            if (scatter_add_bucketed_(count, targets, values, weights, index, mask)) return;
+        }
         void *bases[kMax];
         ek_operand ov[kMax], ow[kMax];
         const ek_operand *pv[kMax], *pw[kMax];
@@ -770,6 +882,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
                         in_place = in_place && !(weights && weights[t] && weights[t]->m_buf == values[c]->m_buf);
                     }
                     if (in_place) {
+                        if (d->table->deferred) d->table->force();      // the map of an unevaluated fma of gathers
                         ov[c] = ek_operand{ d->table->ptr, 0, d->table->size };
                         ops[c] = d->index_type;
                         any_map = true;
@@ -796,6 +909,59 @@ template <typename Value_> struct HIPArray : ArrayTag {
         else
             detail::hip_check(ek_hip_scatter_add_multi(Type, Index::Type, (int) count, bases, targets[0]->size(), pv,
                                                        any_weight ? pw : nullptr, &oi, &om, n, 0), "scatter_add_multi_");
+    }
+
+    /// The adjoint of gathers whose results went into ONE unevaluated fma `u = op(gather(A, idx), x, gather(C, idx))`: when every
+    /// value stream is a unary function of that u (or a host scalar), every weight is u's own x, and index is u's index array,
+    /// the streams are evaluated and accumulated bucket by bucket on u's partition -- no count / scan / partition of the
+    /// indices in the backward sweep.  false: not this shape (the caller takes the element-order pipeline).
+    template <typename Index>
+    static bool scatter_add_bucketed_(size_t count, HIPArray *const *targets, const HIPArray *const *values,
+                                      const HIPArray *const *weights, const Index &index, const MaskType &mask) {
+        if (!(mask.m_is_imm && mask.m_imm) || !index.m_buf || index.m_is_imm) return false;
+        detail::HIPBuffer *u = nullptr;
+        int from_u[4], ops[4], weighted[4];
+        uint64_t imm[4];
+        for (size_t c = 0; c < count; ++c) {
+            const HIPArray &v = *values[c];
+            detail::HIPBuffer *src = nullptr;
+            from_u[c] = 1; ops[c] = EK_COPY; imm[c] = 0;
+            if (v.mapped_()) { src = v.m_buf->deferred->table; ops[c] = v.m_buf->deferred->index_type; }
+            else if (v.paired_()) src = v.m_buf;
+            else if (v.m_is_imm) { from_u[c] = 0; imm[c] = imm_bits(v.m_imm); }
+            else return false;
+            if (src) {
+                if (!src->deferred || src->deferred->kind != 2 || (u && u != src)) return false;
+                u = src;
+            }
+            weighted[c] = weights && weights[c] ? 1 : 0;
+        }
+        if (!u) {
+            // only host scalars: the partition still pays when a weight names the x of a pending fma over this index array
+            for (size_t c = 0; c < count && !u; ++c)
+                if (weighted[c] && weights[c]->m_buf)
+                    for (detail::HIPBuffer *rd : weights[c]->m_buf->readers)
+                        if (rd->deferred && rd->deferred->kind == 2 && rd->deferred->arg0 == weights[c]->m_buf &&
+                            rd->deferred->index == index.m_buf && rd->deferred->bucketed) { u = rd; break; }
+            if (!u) return false;
+        }
+        const auto *d = u->deferred;
+        if (d->index != index.m_buf || d->index_type != Index::Type || u->size != index.m_buf->size) return false;
+        for (size_t c = 0; c < count; ++c) {
+            if (weighted[c] && (weights[c]->m_is_imm || weights[c]->m_buf != d->arg0)) return false;
+            if (targets[c]->size() != d->table->size) return false;
+        }
+        // writers first: a target that aliases one of u's sources evaluates u (and drops its partition) right here
+        void *bases[4];
+        for (size_t c = 0; c < count; ++c) targets[c]->make_unique();
+        if (!u->deferred) return false;
+        ek_hip_bucketed *b = u->bucketed();
+        if (!b) return false;
+        for (size_t c = 0; c < count; ++c) bases[c] = targets[c]->data();
+        int rc = ek_hip_bucketed_scatter_add(b, (int) count, bases, from_u, ops, imm, weighted);
+        if (rc == EK_ERR_UNSUPPORTED) return false;
+        detail::hip_check(rc, "scatter_add_multi_ (bucket order)");
+        return true;
     }
 
     /// An external consumer received this buffer's address (see make_unique())
@@ -1086,6 +1252,12 @@ private:
                 for (int j = 0; j < arity; ++j)
                     if (!d[k] && d[j] && x[k]->m_buf == x[j]->m_buf) d[j] = false;
             if (!d[0] && !d[1] && !d[2]) return false;
+            if (arity == 3 && d[2] && (d[0] || d[1])) {
+                if (HIPArray r = defer_pair_fma_(op, *x[d[0] ? 0 : 1], *x[d[0] ? 1 : 0], *x[2], n); r.valid()) {
+                    result = std::move(r);
+                    return true;
+                }
+            }
             ek_gathered g[3];
             ek_operand o[3];
             const ek_gathered *pg[3] = { nullptr, nullptr, nullptr };
@@ -1152,9 +1324,15 @@ private:
         if constexpr (IsFloat) {
             if (mapped_()) {
                 const auto *d = m_buf->deferred;
-                detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, d->table->ptr, n), what);
+                detail::HIPBuffer *src = d->table;
+                // map(u) with u an unevaluated fma of gathers: gathers, fma, map and reduction bucket by bucket
+                if (src->deferred && src->deferred->kind == 2 && reduce_bucketed_(src, op, d->index_type, r.m_buf->ptr, 1))
+                    return r;
+                if (src->deferred) src->force();
+                detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, src->ptr, n), what);
                 return r;
             }
+            if (paired_() && reduce_bucketed_(m_buf, op, EK_COPY, r.m_buf->ptr, 1)) return r;
         }
         detail::hip_check(ek_hip_reduce(op, Type, r.m_buf->ptr, m_buf ? ptr_() : nullptr, n), what);
         return r;
@@ -1185,6 +1363,15 @@ inline void hip_graph_begin() {
     detail::hip_check(ek_hip_graph_begin(), "hip_graph_begin");
 }
 inline ek_hip_graph *hip_graph_end() {
+    // arrays that are still unevaluated get their kernels and their storage INSIDE the graph (while the stream is still
+    // capturing): every replay then refreshes them like any other array that is alive at the end of the capture
+    try {
+        detail::HIPBuffer::force_all_pending();
+    } catch (...) {
+        ek_hip_graph *dead = nullptr;
+        if (ek_hip_graph_end(&dead) == EK_OK && dead) ek_hip_graph_destroy(dead);
+        throw;
+    }
     ek_hip_graph *g = nullptr;
     detail::hip_check(ek_hip_graph_end(&g), "hip_graph_end");
     return g;

@@ -145,7 +145,7 @@ EK_API int ek_hip_graph_end(ek_hip_graph **out);
 EK_API int ek_hip_graph_launch(ek_hip_graph *graph);
 EK_API uint64_t ek_hip_graph_launch_count(const ek_hip_graph *graph);   /* kernel launches inside one replay */
 EK_API int ek_hip_graph_destroy(ek_hip_graph *graph);
-EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic", "gather_records" */
+EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic", "gather_records", "bucket_ordered" */
 /* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
    launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of
    {"kernel", "launches", "total_ms", "bytes", "elements"}; `bytes` are the ALGORITHMIC bytes of the
@@ -224,6 +224,32 @@ typedef struct {
  * ek_hip_binary / ek_hip_ternary; returns EK_ERR_UNSUPPORTED for every other combination (callers then do exactly that). */
 EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_operand *const *operands,
                                const ek_gathered *const *gathered, size_t n);
+/* Bucket-ordered evaluation of  u[i] = op(A[index[i]], x[i], C[index[i]])  (op of the fma family) for consumers that do not
+ * care about the ELEMENT order of u: horizontal reductions, and the adjoint scatter_add of the two gathers through the same
+ * index array.  The reference gets the forward half from its JIT -- the gathers' ld.global and the arithmetic are emitted
+ * into one kernel per evaluation (src/cuda/jit.cu:984, 1066-1217, 1418-1471) -- and pays atom.global.add per element in the
+ * adjoint (cuda.h:892-905).  Here (index, x) is partitioned ONCE by bucket of 16 Ki table entries (8 Ki for 8-byte types);
+ * every bucket's {A, C} slice is then served from LDS (no lookup leaves the CU: element-order lookups into tables beyond
+ * the 4 MiB L2 of an XCD run at 0.25 of the HBM roofline), and the adjoint reuses the partition instead of counting,
+ * scanning and partitioning again.
+ *   create        count / scan / partition; `table_a`, `table_c` (`table_size` entries each), are read by later calls:
+ *                 the caller keeps them alive and unchanged for the lifetime of the object.  x and index: n-element arrays.
+ *                 EK_ERR_UNSUPPORTED for shapes the path does not cover (ask ek_hip_bucketed_applicable first): tables of
+ *                 one bucket or of more than 256, fewer than 256 Ki lookups, deterministic mode, non-fp types.
+ *   reduce        out[0] = reduce_op over map_op(u)  (map_op: EK_COPY or an op ek_hip_reduce_map accepts); keep_values != 0
+ *                 also keeps u in bucket order for later calls (4 B/elt more).
+ *   scatter_add   bases[c][index[i]] += (weighted[c] ? safe_mul(x[i], v_c[i]) : v_c[i]),  v_c = from_u[c] ? map_ops[c](u) :
+ *                 the scalar imm_bits[c];  count 1..4 tables of table_size entries.
+ * Values of u are bit-identical to the element-order kernels; reductions and sums differ by the ORDER of their fp
+ * additions only (unspecified, like ek_hip_reduce / ek_hip_scatter_add mode 0). */
+typedef struct ek_hip_bucketed ek_hip_bucketed;
+EK_API int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n);
+EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c,
+                                       size_t table_size, const void *x, const void *index, size_t n, ek_hip_bucketed **out);
+EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values);
+EK_API int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
+                                       const uint64_t *imm_bits, const int *weighted);
+EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
 EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
                           const ek_operand *index, const ek_operand *mask, size_t n);
 /* mode 0: fastest -- LDS-binned accumulation for large inputs (needs `base_size`), hardware atomics otherwise;

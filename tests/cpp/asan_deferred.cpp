@@ -152,6 +152,104 @@ static void directed() {
         CHECK(same(host(a), hs) && same(host(sc.second), hc));
     }
 
+    // --- fma over a gathered pair (kind 2): bucket-ordered consumers, and every way of asking for element order ---
+    {
+        const size_t K = 1024;
+        F A = input(K, 1.f), C = input(K, 0.5f);
+        U gi = (arange<U>(N) * U(2654435761u)) & U((uint32_t) K - 1u);
+        std::vector<float> hA = host(A), hC = host(C);
+        std::vector<uint32_t> hi(N);
+        for (size_t i = 0; i < N; ++i) hi[i] = (uint32_t) ((i * 2654435761ull) & (K - 1));
+        std::vector<float> hu(N);
+        for (size_t i = 0; i < N; ++i) hu[i] = std::fma(hA[hi[i]], hx[i], hC[hi[i]]);
+        auto make_u = [&]() { return fmadd(gather<F>(A, gi), x, gather<F>(C, gi)); };
+
+        long f0 = g_fused_calls, r0 = g_bucketed_reduces, s0 = g_bucketed_scatters;
+        F u = make_u();
+        CHECK(u.paired_() && g_fused_calls == f0);                     // nothing ran
+        // (1) the forward of BASELINE config 3b: sincos(u), hsum(sin) in bucket order; u stays unevaluated with its partition
+        auto [su, cu] = sincos(u);
+        CHECK(su.mapped_() && cu.mapped_() && u.paired_());
+        float y = hsum(su).coeff(0), ye = 0.f;
+        for (size_t i = 0; i < N; ++i) ye += std::sin(hu[i]);
+        CHECK(y == ye && g_bucketed_reduces == r0 + 1 && g_fused_calls == f0 && u.paired_() && g_bucketed_live == 1);
+        // (2) the adjoint: cos(u) and x * cos(u) through the same index array reuse the partition
+        F ga = zero<F>(K), gc = zero<F>(K);
+        F *targets[2] = { &gc, &ga };
+        const F *values[2] = { &cu, &cu }, *weights[2] = { nullptr, &x };
+        F::scatter_add_multi_(2, targets, values, weights, gi, M(true));
+        CHECK(g_bucketed_scatters == s0 + 1 && g_fused_calls == f0 && cu.mapped_());
+        std::vector<float> ea(K, 0.f), ec(K, 0.f);
+        for (size_t i = 0; i < N; ++i) {
+            float c = std::cos(hu[i]);
+            ec[hi[i]] += c;
+            ea[hi[i]] += (hx[i] == 0 || c == 0) ? 0.f : hx[i] * c;
+        }
+        CHECK(same(host(ga), ea) && same(host(gc), ec));
+        // (3) a second, element-order consumer: u is evaluated once by the fused gather kernel, the partition goes away, and
+        // the maps that were built on the unevaluated u read the evaluated one
+        F twice = u + u;
+        CHECK(!u.paired_() && g_fused_calls == f0 + 1 && g_bucketed_live == 0);
+        CHECK(same(host(u), hu) && twice.coeff(77) == hu[77] + hu[77]);
+        std::vector<float> hcu(N);
+        for (size_t i = 0; i < N; ++i) hcu[i] = std::cos(hu[i]);
+        CHECK(same(host(cu), hcu));
+        // (4) forced through data()
+        F u2 = make_u();
+        CHECK(u2.paired_());
+        CHECK(hsum(u2).coeff(0) != 0.f && u2.paired_());                // reduced in bucket order, still unevaluated
+        const float *raw = ((const F &) u2).data();
+        CHECK(raw && !u2.paired_() && g_bucketed_live == 0 && same(host(u2), hu));
+        // (5) a table changes while u is pending: u is evaluated with the OLD contents first
+        F A2 = input(K, 1.f);
+        F u3 = fmadd(gather<F>(A2, gi), x, gather<F>(C, gi));
+        float m3 = hmax(u3).coeff(0);
+        scatter(A2, F(100.f), arange<U>(K));
+        CHECK(!u3.paired_() && same(host(u3), hu) && g_bucketed_live == 0);
+        float em = hu[0];
+        for (float v : hu) em = std::fmax(em, v);
+        CHECK(m3 == em);
+        // (6) ... and so does x, and the index array
+        F x2 = input(N, 1.f);
+        U gi2 = (arange<U>(N) * U(2654435761u)) & U((uint32_t) K - 1u);
+        F u4 = fmadd(gather<F>(A, gi2), x2, gather<F>(C, gi2));
+        (void) hsum(sin(u4));
+        scatter(x2, F(0.f), idx);
+        CHECK(!u4.paired_() && same(host(u4), hu));
+        F u5 = fmadd(gather<F>(A, gi2), x, gather<F>(C, gi2));
+        scatter(gi2, U(0u), idx);
+        CHECK(!u5.paired_() && same(host(u5), hu));
+        // (7) the adjoint with a DIFFERENT weight array, or through a different index array: element-order pipeline, same sums
+        F u6 = make_u();
+        F c6 = cos(u6);
+        F other = input(N, 1.f);                                      // same values as x, different buffer
+        F g6 = zero<F>(K), g7 = zero<F>(K);
+        F *t6[2] = { &g6, &g7 };
+        const F *v6[2] = { &c6, &c6 }, *w6[2] = { nullptr, &other };
+        long s1 = g_bucketed_scatters;
+        F::scatter_add_multi_(2, t6, v6, w6, gi, M(true));
+        CHECK(g_bucketed_scatters == s1 && !u6.paired_());
+        CHECK(same(host(g7), ea) && same(host(g6), ec));
+        // (8) never consumed: released with the handle
+        { F dead = make_u(); F sd = sin(dead); }
+        // (9) the four ops of the family and a target that aliases a table
+        F un = fnmsub(gather<F>(A, gi), x, gather<F>(C, gi));
+        CHECK(un.paired_());
+        float sn = hsum(un).coeff(0), esn = 0.f;
+        for (size_t i = 0; i < N; ++i) esn += std::fma(-hA[hi[i]], hx[i], -hC[hi[i]]);
+        CHECK(sn == esn);
+        F A3 = input(K, 1.f);
+        F u7 = fmadd(gather<F>(A3, gi), x, gather<F>(C, gi));
+        F c7 = cos(u7);
+        F *t7[1] = { &A3 };
+        const F *v7[1] = { &c7 };
+        F::scatter_add_multi_(1, t7, v7, nullptr, gi, M(true));       // the target IS table A of the pending u
+        std::vector<float> hA3 = host(A3), eA3 = hA;
+        for (size_t i = 0; i < N; ++i) eA3[hi[i]] += std::cos(hu[i]);     // u7 was evaluated with the OLD table first
+        CHECK(same(hA3, eA3) && !u7.paired_());
+    }
+    CHECK(g_bucketed_live == 0);
+
     // --- scatter_add_multi_ with mapped values; one target IS the map's source ---
     {
         F u = input(N, 1.f);
@@ -205,7 +303,7 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
         static const int maps[] = { EK_NEG, EK_ABS, EK_SIN, EK_COS, EK_EXP };
         auto pick = [&]() -> F & { return pool[rng() % pool.size()]; };
         for (int step = 0; step < 60; ++step) {
-            const int what = rng() % 12;
+            const int what = rng() % 13;
             if (getenv("TRACE")) fprintf(stderr, "seed %u step %d op %d\n", seed, step, what);
             switch (what) {
                 case 0: {   // unary map
@@ -233,6 +331,22 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
                     break;
                 }
                 case 9: { seen.push_back(host(pick())); break; }
+                case 12: {  // the shape of BASELINE config 3b: parameter lookup, sincos, reduction, adjoint through the same indices
+                    F &xx = pick();
+                    F u = fmadd(gather<F>(tables[0], idx), xx, gather<F>(tables[1], idx));
+                    auto [su, cu] = sincos(u);
+                    seen.push_back({ hsum(su).coeff(0) });
+                    if (rng() & 1) seen.push_back({ hmin(u).coeff(0) });
+                    F ta = zero<F>(K), tb = zero<F>(K);
+                    F *targets[2] = { &tb, &ta };
+                    const F *values[2] = { &cu, &cu }, *weights[2] = { nullptr, (rng() & 3) ? &xx : &pick() };
+                    F::scatter_add_multi_(2, targets, values, weights, idx, M(true));
+                    seen.push_back(host(ta));
+                    seen.push_back(host(tb));
+                    if (rng() & 1) pick() = u;
+                    if (rng() & 1) pick() = cu;
+                    break;
+                }
                 case 10: { pick() = pick(); break; }                     // handle copy
                 case 11: {  // adjoint-style multi scatter with (possibly) mapped values
                     F v = cos(pick());
@@ -260,7 +374,7 @@ int main() {
         long f0 = g_fused_calls;
         auto with = run_program(seed, true);
         fused_total += g_fused_calls - f0;
-        CHECK(g_live.empty());
+        CHECK(g_live.empty() && g_bucketed_live == 0);
         f0 = g_fused_calls;
         auto without = run_program(seed, false);
         CHECK(g_fused_calls == f0);                    // switched off means off
@@ -270,7 +384,7 @@ int main() {
             if (!same(with[i], without[i])) { fprintf(stderr, "seed %u: observation %zu differs\n", seed, i); return 1; }
     }
     hip_set_defer(true);
-    CHECK(fused_total > 100);                          // the deferred paths were really taken
+    CHECK(fused_total > 100 && g_bucketed_reduces > 20 && g_bucketed_scatters > 10);      // the deferred paths were really taken
     printf("asan_deferred: directed scenarios + 40 fuzzed programs agree with eager evaluation (%ld fused consumer launches), no block left allocated\n",
            fused_total);
     return 0;

@@ -221,9 +221,71 @@ int ek_hip_map_gathered(int arity, int op, int, void *out, const ek_operand *con
         float x[3] = { 0, 0, 0 };
         for (int k = 0; k < arity; ++k)
             x[k] = g[k] ? (op_m(&g[k]->mask, i) ? ((const float *) g[k]->table)[op_u(&g[k]->index, i)] : 0.f) : op_f(o[k], i);
+        if (arity == 3 && (op == EK_FNMADD || op == EK_FNMSUB)) x[0] = -x[0];
+        if (arity == 3 && (op == EK_FMSUB || op == EK_FNMSUB)) x[2] = -x[2];
         ((float *) out)[i] = arity == 2 ? binary_f(op, x[0], x[1]) : std::fma(x[0], x[1], x[2]);
-        if (arity == 3 && op != EK_FMADD) abort();
     }
+    return EK_OK;
+}
+// bucket-ordered evaluation (ek_hip_bucketed_*): the stand-in keeps the operands and evaluates in ELEMENT order -- the host
+// logic of the binding (which nodes stay unevaluated, who holds what, when the partition dies) is what the checkers exercise
+struct ek_hip_bucketed {
+    int op;
+    const float *a, *c;
+    size_t table_size, n;
+    float *x;
+    uint32_t *idx;
+    float *u;
+};
+static long g_bucketed_live = 0, g_bucketed_reduces = 0, g_bucketed_scatters = 0;
+static float bucketed_u(const ek_hip_bucketed *b, size_t i) {
+    float a = b->a[b->idx[i]], c = b->c[b->idx[i]];
+    if (b->op == EK_FNMADD || b->op == EK_FNMSUB) a = -a;
+    if (b->op == EK_FMSUB || b->op == EK_FNMSUB) c = -c;
+    return std::fma(a, b->x[i], c);
+}
+int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n) {
+    return type == EK_F32 && (index_type == EK_U32 || index_type == EK_I32) && table_size >= 8 && n >= 16;
+}
+int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *a, const void *c, size_t table_size, const void *x,
+                                const void *index, size_t n, ek_hip_bucketed **out) {
+    if (!ek_hip_bucketed_applicable(type, index_type, table_size, n)) return EK_ERR_UNSUPPORTED;
+    ek_hip_bucketed *b = new ek_hip_bucketed{ op, (const float *) a, (const float *) c, table_size, n, nullptr, nullptr, nullptr };
+    // like the device version: x and index are only read here, the tables by later calls
+    b->x = (float *) malloc(n * sizeof(float)); memcpy(b->x, x, n * sizeof(float));
+    b->idx = (uint32_t *) malloc(n * sizeof(uint32_t)); memcpy(b->idx, index, n * sizeof(uint32_t));
+    ++g_bucketed_live;
+    *out = b;
+    return EK_OK;
+}
+int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int keep) {
+    ++g_bucketed_reduces;
+    float *u = (float *) malloc(b->n * sizeof(float));
+    for (size_t i = 0; i < b->n; ++i) u[i] = b->u ? b->u[i] : bucketed_u(b, i);
+    float acc = op == EK_HSUM ? 0.f : op == EK_HPROD ? 1.f : unary_f(map, u[0]);
+    for (size_t i = 0; i < b->n; ++i) {
+        float v = unary_f(map, u[i]);
+        acc = op == EK_HSUM ? acc + v : op == EK_HPROD ? acc * v : op == EK_HMIN ? std::fmin(acc, v) : std::fmax(acc, v);
+    }
+    *(float *) out = acc;
+    if (keep && !b->u) b->u = u; else free(u);
+    return EK_OK;
+}
+int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
+                                const uint64_t *imm, const int *weighted) {
+    ++g_bucketed_scatters;
+    for (int c = 0; c < count; ++c)
+        for (size_t i = 0; i < b->n; ++i) {
+            float v;
+            if (from_u[c]) v = unary_f(ops ? ops[c] : (int) EK_COPY, b->u ? b->u[i] : bucketed_u(b, i));
+            else { uint32_t bits = (uint32_t) imm[c]; memcpy(&v, &bits, 4); }
+            if (weighted[c]) v = (b->x[i] == 0.f || v == 0.f) ? 0.f : b->x[i] * v;
+            ((float *) bases[c])[b->idx[i]] += v;
+        }
+    return EK_OK;
+}
+int ek_hip_bucketed_destroy(ek_hip_bucketed *b) {
+    if (b) { free(b->x); free(b->idx); free(b->u); delete b; --g_bucketed_live; }
     return EK_OK;
 }
 int ek_hip_scatter(int, int, void *base, const ek_operand *v, const ek_operand *index, const ek_operand *mask, size_t n) {

@@ -1,0 +1,167 @@
+"""Bucket-ordered gather -> fma -> {reduction, scatter_add} (ek_hip_bucketed_*, csrc/bucketed.hip) through the C ABI.
+
+Oracle: the element-order kernels of the same library give u = fma(A[idx], x, C[idx]) bit for bit (class A, pinned against
+the reference build in test_gathered_gpu.py / test_kernels_gpu.py); the bucket-ordered path must
+  * reduce exactly the multiset { map(u_i) } -- checked against the float64 sum of the f32 terms with the class-D bound of
+    OUR summation depth, and a statistical sqrt(n) bound ten times tighter than the worst case,
+  * add exactly the multiset of contributions per bin -- float64 bincount of the f32 terms, bound cnt * sum|terms| * 2^-24,
+    and EXACTLY (bit for bit) for integer-valued data, where the order of the additions cannot matter,
+  * give hmin / hmax bit for bit (order independent).
+"""
+import numpy as np
+import pytest
+
+from conftest import bits_equal, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+
+EPS = {np.float32: 2.0 ** -24, np.float64: 2.0 ** -53}
+
+
+def up(capi, a):
+    return capi.Buf.from_numpy(a)
+
+
+def make(dtype, n, K, seed, integer=False):
+    rng = np.random.default_rng(seed)
+    if integer:
+        A = rng.integers(-3, 4, K).astype(dtype); C = rng.integers(-3, 4, K).astype(dtype); x = rng.integers(-2, 3, n).astype(dtype)
+    else:
+        A = uniform_pm1(K, seed + 1).astype(dtype); C = uniform_pm1(K, seed + 2).astype(dtype); x = uniform_pm1(n, seed + 3).astype(dtype)
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    return A, C, x, idx
+
+
+def element_order_u(capi, op, dA, dx, dC, di):
+    return capi.map_gathered(op, capi.G(dA, di), dx, capi.G(dC, di))
+
+
+def depth(n):
+    """additions behind one output of the bucket-ordered reduction: 4 accumulators per lane of a 1024-lane workgroup over a
+    piece of at least 32 Ki elements (at most n / 256 for large inputs), then 2 + 6 + 4 tree levels, then <= 768 partials
+    in a 256-lane workgroup (3 + 6 + 2)"""
+    piece = max(32768, n // 256 + 1)
+    return piece // 4096 + 1 + 12 + 11
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("op", ["fmadd", "fmsub", "fnmadd", "fnmsub"])
+def test_reduce_matches_element_order(capi, dtype, op):
+    K = (1 << 16) + 77 if dtype == np.float32 else (1 << 15) + 77       # 5 buckets, a ragged last one
+    n = (1 << 19) + 12345
+    A, C, x, idx = make(dtype, n, K, seed=11)
+    assert capi.Bucketed.applicable(dtype, np.uint32, K, n)
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    u = element_order_u(capi, op, dA, dx, dC, di).numpy()
+    for rop, mop in (("hsum", "sin"), ("hsum", None), ("hmax", "cos"), ("hmin", None), ("hsum", "exp"), ("hprod", "cos")):
+        b = capi.Bucketed(op, dA, dx, dC, di)
+        got = b.reduce(rop, mop, keep=False).numpy()[0]
+        terms = capi.unary(mop, up(capi, u)).numpy() if mop else u
+        t64 = terms.astype(np.float64)
+        if rop == "hsum":
+            err = abs(float(got) - t64.sum())
+            assert err <= EPS[dtype] * depth(n) * np.abs(t64).sum(), (rop, mop, err)
+            # statistically: roundings are independent, so the sequential chains contribute like a random walk over the
+            # terms (sqrt(depth * sum t^2)) and the tree levels a few ulps of the total
+            assert err <= EPS[dtype] * (8 * np.sqrt(depth(n) * (t64 ** 2).sum()) + 4 * abs(t64.sum())), (rop, mop, err)
+        elif rop == "hprod":
+            ref = np.exp(np.log(np.abs(t64)).sum())
+            assert abs(abs(float(got)) - ref) <= 4 * n * EPS[dtype] * ref + 1e-300
+        else:
+            ref = terms.max() if rop == "hmax" else terms.min()
+            assert bits_equal(np.array([got]), np.array([ref])), (rop, mop)
+        b.destroy()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_kept_values_are_the_element_order_values(capi, dtype):
+    """reduce(keep) then reductions over the kept u: the same multiset as the element-order u (sorted values equal)"""
+    K, n = (1 << 17) + 5, (1 << 20) + 3
+    A, C, x, idx = make(dtype, n, K, seed=3)
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    u = element_order_u(capi, "fmadd", dA, dx, dC, di).numpy()
+    b = capi.Bucketed("fmadd", dA, dx, dC, di)
+    b.reduce("hsum", "sin", keep=True)
+    for rop in ("hmin", "hmax"):             # now served from the kept values
+        got = b.reduce(rop, None).numpy()[0]
+        assert bits_equal(np.array([got]), np.array([u.min() if rop == "hmin" else u.max()]))
+    got = float(b.reduce("hsum", "abs").numpy()[0])
+    assert abs(got - np.abs(u.astype(np.float64)).sum()) <= EPS[dtype] * depth(n) * np.abs(u.astype(np.float64)).sum()
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_scatter_add_integer_data_is_exact(capi, dtype):
+    """integer-valued tables and x: every product and partial sum is exact, so any order gives the same bits"""
+    K = (1 << 16) + 9 if dtype == np.float32 else (1 << 15) + 9
+    n = (1 << 19) + 777
+    A, C, x, idx = make(dtype, n, K, seed=5, integer=True)
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    u = A[idx] * x + C[idx]
+    ii = idx.astype(np.int64)
+    b = capi.Bucketed("fmadd", dA, dx, dC, di)
+    # four streams (two launches): |u|, x * |u|, the constant 1 weighted by x (= x), the constant 2
+    T = [up(capi, np.full(K, 1.0, dtype)) for _ in range(4)]
+    b.scatter_add(T, [("abs", 0, False), ("abs", 0, True), (None, 1.0, True), (None, 2.0, False)])
+    refs = [np.abs(u), x * np.abs(u), x, np.full(n, 2.0)]
+    for t, r in zip(T, refs):
+        want = 1.0 + np.bincount(ii, weights=r.astype(np.float64), minlength=K)
+        assert np.array_equal(t.numpy().astype(np.float64), want)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_scatter_add_cos_pair_within_class_d(capi, dtype):
+    """the adjoint of BASELINE config 3b: gA[idx] += x * cos(u), gC[idx] += cos(u), after a forward hsum(sin(u))"""
+    K, n = (1 << 16) + 1, (1 << 20) + 17
+    A, C, x, idx = make(dtype, n, K, seed=9)
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    u = element_order_u(capi, "fmadd", dA, dx, dC, di)
+    cu = capi.unary("cos", u).numpy().astype(np.float64)
+    ii = idx.astype(np.int64)
+    cnt = np.bincount(ii, minlength=K)
+    for forward_first in (True, False):
+        b = capi.Bucketed("fmadd", dA, dx, dC, di)
+        if forward_first:
+            b.reduce("hsum", "sin", keep=True)
+        gA, gC = up(capi, np.zeros(K, dtype)), up(capi, np.zeros(K, dtype))
+        b.scatter_add([gC, gA], [("cos", 0, False), ("cos", 0, True)])
+        for got, terms in ((gA, cu * x.astype(np.float64)), (gC, cu)):
+            # the product x * cos(u) is rounded once more in the working precision
+            tr = terms.astype(dtype).astype(np.float64)
+            ref = np.bincount(ii, weights=tr, minlength=K)
+            bound = EPS[dtype] * (cnt * np.bincount(ii, weights=np.abs(tr), minlength=K)) + 1e-300
+            err = np.abs(got.numpy().astype(np.float64) - ref)
+            assert (err <= bound).all(), (forward_first, float((err / bound).max()))
+
+
+def test_not_applicable_shapes_are_refused(capi):
+    assert not capi.Bucketed.applicable(np.float32, np.uint32, 1 << 14, 1 << 20)        # one bucket
+    assert not capi.Bucketed.applicable(np.float32, np.uint32, (256 << 14) + 1, 1 << 20)  # more than 256 buckets
+    assert not capi.Bucketed.applicable(np.float32, np.uint32, 1 << 20, 1 << 17)        # too few lookups
+    assert not capi.Bucketed.applicable(np.int32, np.uint32, 1 << 20, 1 << 20)
+    capi.set_tuning("deterministic", 1)
+    try:
+        assert not capi.Bucketed.applicable(np.float32, np.uint32, 1 << 20, 1 << 20)
+        A = up(capi, np.zeros(1 << 20, np.float32)); x = up(capi, np.zeros(1 << 20, np.float32)); i = up(capi, np.zeros(1 << 20, np.uint32))
+        with pytest.raises(capi.EnokiHipError):
+            capi.Bucketed("fmadd", A, x, A, i)
+    finally:
+        capi.set_tuning("deterministic", 0)
+
+
+def test_skewed_indices(capi):
+    """all lookups in one bucket / one bin: the exchange lock's wave-combining path and the piece split stay correct"""
+    K, n = 1 << 18, (1 << 19) + 5
+    rng = np.random.default_rng(1)
+    A = rng.integers(-3, 4, K).astype(np.float32); C = rng.integers(-3, 4, K).astype(np.float32)
+    x = rng.integers(-2, 3, n).astype(np.float32)
+    for idx in (np.full(n, 70001, np.uint32), (rng.integers(0, 100, n) + 5 * 16384).astype(np.uint32),
+                np.where(rng.integers(0, 2, n) == 0, 3, rng.integers(0, K, n)).astype(np.uint32)):
+        dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+        u = A[idx] * x + C[idx]
+        b = capi.Bucketed("fmadd", dA, dx, dC, di)
+        got = float(b.reduce("hsum", None, keep=True).numpy()[0])
+        assert got == float(u.astype(np.float64).sum())
+        g = up(capi, np.zeros(K, np.float32))
+        b.scatter_add([g], [("copy", 0, True)])
+        want = np.bincount(idx.astype(np.int64), weights=(x * u).astype(np.float64), minlength=K)
+        assert np.array_equal(g.numpy().astype(np.float64), want)
