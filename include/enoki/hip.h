@@ -1243,21 +1243,22 @@ private:
             if (arity == 3 && d[2] && (d[0] || d[1])) {
                 // a gathered factor AND a gathered addend: one 8-byte lookup when they share index, mask and table size
                 const auto *p = x[d[0] ? 0 : 1]->m_buf->deferred, *q = x[2]->m_buf->deferred;
-                if (p->index != q->index || p->mask != q->mask || p->index_type != q->index_type ||
-                    p->table->size != q->table->size || p->table->size * 8 > n)
-                    d[2] = false;
+                const bool shared = p->index == q->index && p->mask == q->mask && p->index_type == q->index_type &&
+                                    p->table->size == q->table->size;
+                // the parameter lookup of BASELINE config 3b: left unevaluated for a consumer that may take it bucket by bucket
+                if (shared) {
+                    if (HIPArray r = defer_pair_fma_(op, *x[d[0] ? 0 : 1], *x[d[0] ? 1 : 0], *x[2], n); r.valid()) {
+                        result = std::move(r);
+                        return true;
+                    }
+                }
+                if (!shared || p->table->size * 8 > n) d[2] = false;     // interleaving K records has to pay for itself
             }
             // the same array in a fused AND an unfused slot (g * g): the unfused use materialises it anyway
             for (int k = 0; k < arity; ++k)
                 for (int j = 0; j < arity; ++j)
                     if (!d[k] && d[j] && x[k]->m_buf == x[j]->m_buf) d[j] = false;
             if (!d[0] && !d[1] && !d[2]) return false;
-            if (arity == 3 && d[2] && (d[0] || d[1])) {
-                if (HIPArray r = defer_pair_fma_(op, *x[d[0] ? 0 : 1], *x[d[0] ? 1 : 0], *x[2], n); r.valid()) {
-                    result = std::move(r);
-                    return true;
-                }
-            }
             ek_gathered g[3];
             ek_operand o[3];
             const ek_gathered *pg[3] = { nullptr, nullptr, nullptr };

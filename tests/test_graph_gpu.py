@@ -46,12 +46,14 @@ def test_cfg3b_step_graph_replay(ek, capi, n, K):
     g = ek.hip_graph_end()
     try:
         per_step = ek.hip_graph_launch_count(g)
-        assert per_step >= 8 and ek.hip_launch_count() - launches0 == per_step
+        assert per_step >= 6 and ek.hip_launch_count() - launches0 == per_step
         t = cfg3b_truth(hA, hB, hx, hidx)
         for _ in range(3):
             ek.hip_graph_launch(g)
             y, gA, gB = out["y"].numpy(), out["gA"].numpy(), out["gB"].numpy()
-            assert bits_equal(y, eager[0])                              # hsum is run-to-run deterministic
+            # (the bucket-ordered forward sums in the order its partition happened to produce: class D, not run-to-run
+            # reproducible -- ENOKI_HIP_DETERMINISTIC=1 is the reproducible mode)
+            assert abs(float(y[0]) - t["y"]) <= t["y_bound"] and abs(float(y[0]) - float(eager[0][0])) <= 2 * t["y_bound"]
             assert np.all(np.abs(gA - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(gB - t["gB"]) <= t["gB_bound"])
         # new contents in the SAME buffers: the graph reads the new inputs
         hA2, hx2 = rng.uniform(-1, 1, K).astype(np.float32), rng.uniform(-1, 1, n).astype(np.float32)
