@@ -296,6 +296,58 @@ __device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, fl
     }
 }
 
+// N independent updates per lane: all N bins are CLAIMED first (N exchanges in flight -- one LDS round trip instead of N
+// dependent ones, which is what bounds the one-at-a-time version), then every claim that succeeded is added to and
+// released; the few that met a lock (another lane's, or this lane's own claim of the same bin in an earlier slot) go
+// through the one-at-a-time path afterwards.  Nobody spins while holding a lock, so there is no circular wait.
+template <int N>
+__device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, const uint32_t (&l)[N], const float (&v0)[N],
+                                                   const float (&v1)[N]) {
+    unsigned long long old[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) old[j] = atomicExch(table + l[j], kLockedPair);
+    unsigned pending = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (old[j] != kLockedPair)
+            __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        else
+            pending |= 1u << j;
+    }
+    if (__any(pending != 0)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) lds_add_pair(table + l[j], v0[j], v1[j], (pending >> j) & 1u);
+    }
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], const T (&v)[N]) {
+    if constexpr (std::is_same_v<T, float>) {
+        unsigned *t = reinterpret_cast<unsigned *>(table);
+        unsigned old[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) old[j] = atomicExch(t + l[j], kLockedBits);
+        unsigned pending = 0;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (old[j] != kLockedBits) {
+                unsigned bits = __float_as_uint(__uint_as_float(old[j]) + v[j]);
+                if (bits == kLockedBits) bits = 0x7FC00000u;
+                __hip_atomic_store(t + l[j], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                pending |= 1u << j;
+            }
+        }
+        if (__any(pending != 0)) {
+#pragma unroll
+            for (int j = 0; j < N; ++j) lds_add<true>(table + l[j], v[j], ((pending >> j) & 1u) != 0);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < N; ++j) lds_add<true>(table + l[j], v[j], true);
+    }
+}
+
 // The streaming part.  Map >= 0: every stream that is a function of u applies THIS op (compile time; evaluated once per
 // element however many streams share it -- the usual pair cos(u), x * cos(u)); Map < 0: per-stream ops chosen at run time.
 template <typename T, int C, int V, int Map>
@@ -343,10 +395,33 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
         }
     };
     auto apply = [&](const Step &s) {
+        // the values of all 4 V elements first, then ONE batch of LDS updates per table (pair)
+        constexpr int NB = 4 * V;
+        uint32_t l[NB];
+        T v[C][NB];
 #pragma unroll
-        for (int h = 0; h < V; ++h)
+        for (int h = 0; h < V; ++h) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) one(s.pi[h].v[j], need_u ? s.pu[h][j] : T(0), need_x ? s.px[h][j] : T(0), true);
+            for (int j = 0; j < 4; ++j) {
+                const int k = h * 4 + j;
+                const T u = need_u ? s.pu[h][j] : T(0), x = need_x ? s.px[h][j] : T(0);
+                l[k] = (uint32_t) s.pi[h].v[j] & (Bins - 1);
+                T m = T(0);
+                if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    if constexpr (Map >= 0) v[c][k] = ((st.from_u >> c) & 1u) ? m : st.imm[c];
+                    else v[c][k] = ((st.from_u >> c) & 1u) ? unary_fused<T>(st.map_op[c], u) : st.imm[c];
+                    if ((st.weighted >> c) & 1u) v[c][k] = dev::safe_mul(x, v[c][k]);
+                }
+            }
+        }
+        if constexpr (Paired) {
+            lds_add_pair_batch<NB>(reinterpret_cast<unsigned long long *>(acc), l, v[0], v[C - 1]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) lds_add_batch<T, NB>(acc + c * Bins, l, v[c]);
+        }
     };
     size_t base = head_end;
     if (base + kStep <= end) {
