@@ -57,7 +57,8 @@ DESCRIPTION["cfg5"] = ("synthetic 3-bounce path tracer inside a textured unit sp
                        "texture (K = 1 Mi), cosine-weighted bounce; loss = hsum(radiance); backward() scatter_adds the "
                        "texture gradient; 16 Mi paths per GPU; report only")
 # kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
-PMC_SYMBOL = {"gather_pair_fmadd": "k_map_gathered<GTernary<0", "gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
+PMC_SYMBOL = {"bucket_accumulate": "k_bucket_accumulate", "bucket_partition": "k_bin_partition", "bucket_pair_fma_reduce": "k_bucket_pair_forward",
+              "bucket_count": "k_bin_count", "gather_pair_fmadd": "k_map_gathered<GTernary<0", "gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
               "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",
               "safe_mul": "k_map2<BinaryOp<13", "hsum": "k_reduce_stage1", "sin": "k_map1<UnaryOp<10", "exp": "k_map1<UnaryOp<12"}
 
@@ -77,15 +78,28 @@ def parse():
     return ap.parse_args()
 
 
+PMC_FILE = os.path.join("profiles", "rocprof_pmc_r03.txt")
+
+
+def kernels_sha16():
+    """fingerprint of the device code (every source that goes into libenoki-hip.so): the PMC summary under profiles/ is
+    stamped with it by tools/rocprof_summary.py, and a summary taken from other kernels is refused"""
+    from enoki_amd import _build
+    return _build.kernels_sha16()
+
+
 def pmc_traffic(kernel):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC summary (separate --pmc passes,
-    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/rocprof_summary.py), or None"""
-    path = os.path.join(ROOT, "profiles", "rocprof_pmc_r02.txt")
+    """(HBM bytes per launch of `kernel`, provenance) from the committed rocprofv3 PMC summary (separate --pmc passes,
+    FETCH_SIZE x2 gfx950 correction + WRITE_SIZE; tools/rocprof_summary.py).  The summary names the kernel sources it was
+    measured on (`# kernels_sha16`); when they are not the sources of THIS tree the number is not reported."""
+    path = os.path.join(ROOT, PMC_FILE)
     sym = PMC_SYMBOL.get(kernel)
     if not sym or not os.path.exists(path):
-        return None
-    best = None
+        return None, f"no PMC summary for kernel '{kernel}' ({PMC_FILE})"
+    stamp, best = None, None
     for line in open(path):
+        if line.startswith("# kernels_sha16:"):
+            stamp = line.split(":", 1)[1].strip()
         if line.startswith(sym):
             f = line.split()
             try:
@@ -94,7 +108,13 @@ def pmc_traffic(kernel):
                 continue
             if best is None or grid > best[0]:
                 best = (grid, (rd + wr) * 1e6)
-    return int(best[1]) if best else None
+    here = kernels_sha16()
+    if stamp != here:
+        return None, f"{PMC_FILE} was measured on kernel sources {stamp}, this tree is {here}: refused"
+    if not best:
+        return None, f"{PMC_FILE} has no line for {sym}"
+    return int(best[1]), (f"{PMC_FILE} (kernels_sha16 {stamp}): separate rocprofv3 --pmc passes over the same command, "
+                          "2 x FETCH_SIZE + WRITE_SIZE per launch")
 
 
 def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024):
@@ -376,8 +396,21 @@ class Bench:
         units = N_RAYS_PER_GPU * self.world if workload.startswith("cfg4") else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
         gelem_s = units / (ms_per_step * 1e-3) / 1e9
 
+        eager_ms = ms_per_step
         if graph is not None:
             ek.hip_graph_destroy(graph)
+            # the same K steps driven from python (tape walk, allocator, one launch call per kernel), same timing protocol
+            step()
+            if packer:
+                packer.wait_all()
+            ekd.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                step()
+            if packer:
+                packer.wait_all()
+            torch.cuda.synchronize(); ekd.barrier()
+            eager_ms = ekd.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
         # per-kernel timing of the same step (run eagerly): one HIP event per launch on the library stream
         ek.hip_profile_begin()
         for _ in range(profile_steps):
@@ -403,12 +436,10 @@ class Bench:
             dom = kernels[0]
             achieved = dom["bytes_per_launch"] / dom["avg_ms"] / 1e6      # GB/s
             whole = total_bytes_step / (ms_per_step * 1e-3) / 1e9
+            traffic, traffic_source = pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else (None, "PMC summaries are taken at 64 Mi elements per GPU")
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
                         "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
-                        "traffic": pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else None,
-                        "traffic_source": "profiles/rocprof_pmc_r02.txt (separate rocprofv3 --pmc passes, same command; 2 x FETCH_SIZE + WRITE_SIZE. "
-                                          "For the pair gather the read side is L2-miss traffic of random 8-byte lookups -- 64-byte fabric "
-                                          "requests mostly served by the Infinity Cache -- for which the x2 streaming correction is not calibrated)",
+                        "traffic": traffic, "traffic_source": traffic_source,
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
                                        "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload.startswith("cfg4") else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
@@ -420,7 +451,7 @@ class Bench:
             y_val = float(out["reduced"][0].item())
         outputs = {k: out[k].numpy() for k in ("gA", "gB", "ga", "gb") if k in out} if self.world == 1 and workload == self.args.workload else {}
         outputs["y"] = y_val
-        return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "result_y": y_val,
+        return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "eager_ms_per_step": round(eager_ms, 4), "result_y": y_val,
                 "roofline": roofline, "collectives_per_step": 1 if packer else 0, "outputs": outputs, "replay": replay}
 
 
@@ -536,8 +567,14 @@ def check_parity(workload, N, gpu, ref, kind):
 
 
 def _cpu_shard_worker(job):
-    """one index-range shard of the workload on one host core (spawned process: no torch, no HIP)"""
-    workload, kind, begin, count = job
+    """one index-range shard of the workload on one host core (spawned process: no torch, no HIP), pinned to that core;
+    inputs are generated (= touched) before the first run, one untimed warm-up run faults the checker's own buffers in,
+    then the MEDIAN of three timed runs counts"""
+    workload, kind, begin, count, core = job
+    try:
+        os.sched_setaffinity(0, {core})
+    except Exception:
+        pass
     import oracle_lib as ol
     from conftest import hash_u32, uniform_pm1
     chk = ol.ref() if kind == "reference" else ol.port()
@@ -550,26 +587,37 @@ def _cpu_shard_worker(job):
     if workload == "cfg3b":
         A, B = uniform_pm1(K_TABLE, 6), uniform_pm1(K_TABLE, 7)
         idx = (hash_u32(i, 4) % np.uint32(K_TABLE)).astype(np.uint32)
-        return chk.cfg3b(A, B, x, idx)[-1]
-    if workload == "cfg3a":
-        return chk.cfg3a(u(1), x, u(3))[-1]
-    return chk.cfg2(u(1), x, u(3))[-1]
+        run = lambda: chk.cfg3b(A, B, x, idx)[-1]
+    elif workload == "cfg3a":
+        a, b = u(1), u(3)
+        run = lambda: chk.cfg3a(a, x, b)[-1]
+    else:
+        a, b = u(1), u(3)
+        run = lambda: chk.cfg2(a, x, b)[-1]
+    run()
+    return sorted(run() for _ in range(3))[1]
 
 
 def cpu_all_cores(workload, n, kind):
     """OUR index-range split of the reference's single-threaded CPU path over the host cores (Enoki itself has no
-    threading): P processes, each runs the checker on its own n/P shard; rate = n / slowest shard (incl. nothing
-    but the timed region of each shard).  Clearly not a number of the reference."""
+    threading): P pinned processes, each runs the checker on its own n/P shard (warm-up + median of 3); rate = n / slowest
+    shard.  Clearly not a number of the reference."""
     import concurrent.futures
     import multiprocessing
-    procs = max(1, min(64, (os.cpu_count() or 2) // 2))
+    try:
+        cores = sorted(os.sched_getaffinity(0))
+    except Exception:
+        cores = list(range(os.cpu_count() or 2))
+    procs = max(1, min(64, len(cores) // 2))
+    cores = cores[::max(1, len(cores) // procs)][:procs]       # spread over the sockets / SMT pairs the affinity mask offers
     per = n // procs
-    jobs = [(workload, kind, r * per, per) for r in range(procs)]
+    jobs = [(workload, kind, r * per, per, cores[r]) for r in range(procs)]
     try:
         with concurrent.futures.ProcessPoolExecutor(procs, mp_context=multiprocessing.get_context("spawn")) as ex:
             times = list(ex.map(_cpu_shard_worker, jobs, timeout=240))
         return {"value": round(per * procs / max(times) / 1e9, 4), "unit": "Gelem/s", "cores": procs,
-                "note": "our index-range split of the reference's CPU path over host cores; not a reference number"}
+                "note": "our index-range split of the reference's CPU path over pinned host cores (warm-up, median of 3 per shard, "
+                        "slowest shard counts); not a reference number"}
     except Exception as e:          # never let the side measurement break the bench line
         return {"value": None, "cores": procs, "note": f"all-cores measurement failed: {type(e).__name__}: {e}"}
 
@@ -595,6 +643,8 @@ def main():
                            "dominant_kernel": r["roofline"]["kernel"] if r["roofline"] else None,
                            "dominant_kernel_frac": r["roofline"]["frac"] if r["roofline"] else None,
                            "workload": DESCRIPTION[w]}
+                if w == "cfg5":
+                    also[w]["parity"] = "no oracle (synthetic workload, not in the reference): gradient checked against finite differences only (tests/test_cfg5_gpu.py)"
     cpu, parity = None, None
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         cpu, ref_out = cpu_baseline(args.workload, b.N)
@@ -606,7 +656,7 @@ def main():
         line = {
             "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "higher_is_better": True,
+            "ms_per_step": main_res["ms_per_step"], "eager_ms_per_step": main_res["eager_ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}",

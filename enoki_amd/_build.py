@@ -34,6 +34,20 @@ LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "sc
 PROBE_SOURCES = ["probe.hip", "probe_rt.cpp"]
 
 
+def kernels_sha16():
+    """fingerprint of the device code: every source and header that goes into libenoki-hip.so, in a fixed order"""
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".cpp")) and not f.startswith("probe"))
+    dev = os.path.join(ROOT, "include", "enoki", "device")
+    files += sorted(os.path.join(dev, f) for f in os.listdir(dev) if f.endswith(".h"))
+    files.append(os.path.join(ROOT, "include", "enoki_hip.h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def _newer(target, deps):
     if not os.path.exists(target):
         return True

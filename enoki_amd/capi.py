@@ -461,9 +461,10 @@ class Bucketed:
         return bool(lib.ek_hip_bucketed_applicable(NP2EK[np.dtype(dtype)], NP2EK[np.dtype(index_dtype)], ctypes.c_size_t(table_size),
                                                    ctypes.c_size_t(n)))
 
-    def reduce(self, op, map_op=None, keep=True):
+    def reduce(self, op, map_op=None, keep=True, keep_op=None):
         out = Buf(self.dtype, 1)
-        check(lib.ek_hip_bucketed_reduce(self.handle, REDUCE[op], UNARY[map_op or "copy"], ctypes.c_void_p(out.ptr), int(keep)))
+        check(lib.ek_hip_bucketed_reduce(self.handle, REDUCE[op], UNARY[map_op or "copy"], ctypes.c_void_p(out.ptr), int(keep),
+                                         UNARY[keep_op or "copy"]))
         return out
 
     def scatter_add(self, targets, streams):

@@ -91,7 +91,10 @@ __device__ __forceinline__ bool bucket_piece(const uint32_t *__restrict__ bucket
 // The streaming part, specialised for the unary op that is applied to u before the reduction (Map, compile time: the
 // kernel switches ONCE, outside the loops -- a runtime switch per element would inline nine transcendental bodies into an
 // eight-fold unrolled loop and blow the instruction cache).
-template <typename T, int ROp, int V, int Map>
+// KeepPartner (Map = sin or cos only): what is kept in bucket order is not u but the OTHER half of sincos(u) -- one sincos
+// evaluation yields the reduced half and the kept half (the cos(u) that the adjoint of sin needs), like the stand-alone
+// sincos kernel fills both halves of a linked pair.
+template <typename T, int ROp, int V, int Map, bool KeepPartner = false>
 __device__ __forceinline__ void bucket_forward_stream(const PairRec<T> *__restrict__ rec, T (&acc)[4], T *__restrict__ u_out,
                                                       const uint16_t *__restrict__ pair_idx, const T *__restrict__ x_b,
                                                       size_t begin, size_t end) {
@@ -100,8 +103,16 @@ __device__ __forceinline__ void bucket_forward_stream(const PairRec<T> *__restri
     auto one = [&](uint32_t l, T x, int slot) -> T {
         const PairRec<T> r = rec[l & (Bins - 1)];
         const T u = fma_t(r.a, x, r.c);
-        if constexpr (ROp != EK_REDUCE_NONE) acc[slot] = R::combine(acc[slot], UnaryOp<Map, T>::apply(u));
-        return u;
+        if constexpr (KeepPartner) {
+            static_assert(Map == EK_SIN || Map == EK_COS);
+            T sn, cs;
+            SinCosOp::apply(u, sn, cs);
+            acc[slot] = R::combine(acc[slot], Map == EK_SIN ? sn : cs);
+            return Map == EK_SIN ? cs : sn;
+        } else {
+            if constexpr (ROp != EK_REDUCE_NONE) acc[slot] = R::combine(acc[slot], UnaryOp<Map, T>::apply(u));
+            return u;
+        }
     };
     // a piece starts anywhere: up to 3 leading elements go one per lane, then every lane moves 4-element vectors
     const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
@@ -178,7 +189,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
                                                                         const T *__restrict__ x_b,
                                                                         const uint32_t *__restrict__ bucket_base,
                                                                         const uint32_t *__restrict__ piece_prefix, int n_buckets,
-                                                                        int map_op) {
+                                                                        int map_op, int keep_partner) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
     __shared__ T wave_part[kBucketWaves];
@@ -209,6 +220,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
 #define EK_FWD_CASE(OP) case OP: bucket_forward_stream<T, ROp, V, OP>(rec, acc, u_out, pair_idx, x_b, begin, end); break;
     if constexpr (ROp == EK_REDUCE_NONE) {
         bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end);
+    } else if (keep_partner && map_op == EK_SIN) {
+        bucket_forward_stream<T, ROp, V, EK_SIN, true>(rec, acc, u_out, pair_idx, x_b, begin, end);
+    } else if (keep_partner && map_op == EK_COS) {
+        bucket_forward_stream<T, ROp, V, EK_COS, true>(rec, acc, u_out, pair_idx, x_b, begin, end);
     } else {
         switch (map_op) {
             EK_FWD_CASE(EK_NEG) EK_FWD_CASE(EK_ABS) EK_FWD_CASE(EK_SQRT) EK_FWD_CASE(EK_RCP) EK_FWD_CASE(EK_RSQRT)
@@ -304,9 +319,10 @@ template <int N>
 __device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, const uint32_t (&l)[N], const float (&v0)[N],
                                                    const float (&v1)[N]) {
     unsigned long long old[N];
+    unsigned pending = 0;
+    // round 1: every slot
 #pragma unroll
     for (int j = 0; j < N; ++j) old[j] = atomicExch(table + l[j], kLockedPair);
-    unsigned pending = 0;
 #pragma unroll
     for (int j = 0; j < N; ++j) {
         if (old[j] != kLockedPair)
@@ -314,9 +330,26 @@ __device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, co
         else
             pending |= 1u << j;
     }
+    // With 64 N claims in flight per wave and 16 Ki bins a few claims per batch meet a lock (64 N = 512: ~3 % of them), so
+    // "somebody in the wave is pending" is the rule, not the exception.  Round 2 retries exactly those slots, again all in
+    // flight together -- their locks were released by the stores above -- and leaves only true repeat offenders (hot
+    // bins) to the one-at-a-time path with its wave-level combining.
     if (__any(pending != 0)) {
 #pragma unroll
-        for (int j = 0; j < N; ++j) lds_add_pair(table + l[j], v0[j], v1[j], (pending >> j) & 1u);
+        for (int j = 0; j < N; ++j)
+            if ((pending >> j) & 1u) old[j] = atomicExch(table + l[j], kLockedPair);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if (((pending >> j) & 1u) && old[j] != kLockedPair) {
+                __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pending &= ~(1u << j);
+            }
+        }
+        if (__any(pending != 0)) {
+#pragma unroll
+            for (int j = 0; j < N; ++j)
+                if (__any((pending >> j) & 1u)) lds_add_pair(table + l[j], v0[j], v1[j], (pending >> j) & 1u);
+        }
     }
 }
 
@@ -325,22 +358,34 @@ __device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], 
     if constexpr (std::is_same_v<T, float>) {
         unsigned *t = reinterpret_cast<unsigned *>(table);
         unsigned old[N];
+        unsigned pending = 0;
+        auto sum = [](unsigned o, float x) {
+            unsigned bits = __float_as_uint(__uint_as_float(o) + x);
+            return bits == kLockedBits ? 0x7FC00000u : bits;
+        };
 #pragma unroll
         for (int j = 0; j < N; ++j) old[j] = atomicExch(t + l[j], kLockedBits);
-        unsigned pending = 0;
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            if (old[j] != kLockedBits) {
-                unsigned bits = __float_as_uint(__uint_as_float(old[j]) + v[j]);
-                if (bits == kLockedBits) bits = 0x7FC00000u;
-                __hip_atomic_store(t + l[j], bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            } else {
-                pending |= 1u << j;
-            }
+            if (old[j] != kLockedBits) __hip_atomic_store(t + l[j], sum(old[j], v[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            else pending |= 1u << j;
         }
         if (__any(pending != 0)) {
 #pragma unroll
-            for (int j = 0; j < N; ++j) lds_add<true>(table + l[j], v[j], ((pending >> j) & 1u) != 0);
+            for (int j = 0; j < N; ++j)
+                if ((pending >> j) & 1u) old[j] = atomicExch(t + l[j], kLockedBits);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                if (((pending >> j) & 1u) && old[j] != kLockedBits) {
+                    __hip_atomic_store(t + l[j], sum(old[j], v[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    pending &= ~(1u << j);
+                }
+            }
+            if (__any(pending != 0)) {
+#pragma unroll
+                for (int j = 0; j < N; ++j)
+                    if (__any((pending >> j) & 1u)) lds_add<true>(table + l[j], v[j], ((pending >> j) & 1u) != 0);
+            }
         }
     } else {
 #pragma unroll
@@ -502,9 +547,12 @@ struct Bucketed {
     void *x_b = nullptr;           // x in bucket order
     void *u_b = nullptr;           // u in bucket order (allocated by the first consumer that keeps it)
     bool has_u = false;
+    void *m_b = nullptr;           // m_op(u) in bucket order: the kept half of a sincos pair (see ek_hip_bucketed_reduce)
+    int m_op = EK_COPY;
+    bool has_m = false;
 
     ~Bucketed() {
-        for (void *p : { meta, pair_idx, x_b, u_b })
+        for (void *p : { meta, pair_idx, x_b, u_b, m_b })
             if (p) ek_hip_free(p);
     }
 };
@@ -575,25 +623,30 @@ static int bucketed_create(Bucketed *b, const T *x, const I *index) {
 }
 
 template <typename T, int ROp>
-static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep) {
+static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep, int keep_op = EK_COPY) {
     Context &c = ctx();
     constexpr int Bins = bins_of<T>;
     const size_t lds = (size_t) Bins * sizeof(PairRec<T>);
     if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp>, lds)) return rc;
-    if (keep && !b->u_b)
-        if (int rc = ek_hip_malloc(b->n * sizeof(T), &b->u_b)) return rc;
+    // keep the OTHER half of a sincos pair instead of u: only when it is exactly that (sin reduced, cos kept or vice versa)
+    const bool partner = keep && ROp != EK_REDUCE_NONE &&
+                         ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN));
+    void **kept = partner ? &b->m_b : &b->u_b;
+    if (keep && !*kept)
+        if (int rc = ek_hip_malloc(b->n * sizeof(T), kept)) return rc;
     const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
 #define EK_FWD(VV)                                                                                                          \
     hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,           \
-                       (T *) b->reduce_partials, keep ? (T *) b->u_b : (T *) nullptr, (const T *) b->table_a,                   \
+                       (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,                    \
                        (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,                   \
                        (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, \
-                       map_op)
+                       map_op, partner ? 1 : 0)
     EK_FWD(2);
 #undef EK_FWD
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
-    if (keep) b->has_u = true;
+    if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
+    else if (keep) b->has_u = true;
     if constexpr (ROp != EK_REDUCE_NONE) {
         hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out,
                            (const T *) b->reduce_partials, b->max_pieces);
@@ -603,24 +656,25 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
 }
 
 template <typename T>
-static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bool keep) {
+static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bool keep, int keep_op) {
     RoctxRange range("enoki-hip: bucket-ordered gather + fma + reduction");
+    if (b->has_m && map_op == b->m_op) return ek_hip_reduce(reduce_op, b->type, out, b->m_b, b->n);   // the kept half itself
     if (b->has_u) {
         // u already exists in bucket order: an ordinary reduction over it
         if (map_op == EK_COPY) return ek_hip_reduce(reduce_op, b->type, out, b->u_b, b->n);
         return ek_hip_reduce_map(reduce_op, map_op, b->type, out, b->u_b, b->n);
     }
     switch (reduce_op) {
-        case EK_HSUM: return bucketed_forward_launch<T, EK_HSUM>(b, out, map_op, keep);
-        case EK_HPROD: return bucketed_forward_launch<T, EK_HPROD>(b, out, map_op, keep);
-        case EK_HMIN: return bucketed_forward_launch<T, EK_HMIN>(b, out, map_op, keep);
-        case EK_HMAX: return bucketed_forward_launch<T, EK_HMAX>(b, out, map_op, keep);
+        case EK_HSUM: return bucketed_forward_launch<T, EK_HSUM>(b, out, map_op, keep, keep_op);
+        case EK_HPROD: return bucketed_forward_launch<T, EK_HPROD>(b, out, map_op, keep, keep_op);
+        case EK_HMIN: return bucketed_forward_launch<T, EK_HMIN>(b, out, map_op, keep, keep_op);
+        case EK_HMAX: return bucketed_forward_launch<T, EK_HMAX>(b, out, map_op, keep, keep_op);
         default: return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): unknown op %d", reduce_op);
     }
 }
 
 template <typename T, int C>
-static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams<T, C> &st) {
+static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams<T, C> &st, const void *u_src) {
     Context &c = ctx();
     constexpr int Bins = bins_of<T>;
     const size_t lds = (size_t) C * Bins * sizeof(T);
@@ -629,7 +683,7 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
     if (int rc = partials.alloc((size_t) C * b->max_pieces * Bins * sizeof(T))) return rc;
 #define EK_ACC(VV)                                                                                                          \
     hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,               \
-                       (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) b->u_b, (const T *) b->x_b,              \
+                       (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) u_src, (const T *) b->x_b,               \
                        (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st)
     EK_ACC(2);
 #undef EK_ACC
@@ -649,10 +703,16 @@ template <typename T>
 static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                 const uint64_t *imm_bits, const int *weighted) {
     RoctxRange range("enoki-hip: bucket-ordered scatter_add");
-    bool need_u = false;
-    for (int s = 0; s < count; ++s) need_u = need_u || from_u[s];
-    if (need_u && !b->has_u)
+    bool need_u = false, all_kept = b->has_m;
+    for (int s = 0; s < count; ++s) {
+        need_u = need_u || from_u[s];
+        if (from_u[s]) all_kept = all_kept && (map_ops ? map_ops[s] : (int) EK_COPY) == b->m_op;
+    }
+    // every stream that reads u wants exactly the half of sincos(u) that the forward kept: stream it as is
+    const bool use_kept = need_u && all_kept;
+    if (need_u && !use_kept && !b->has_u)
         if (int rc = bucketed_forward_launch<T, EK_REDUCE_NONE>(b, nullptr, EK_COPY, true)) return rc;
+    const void *u_src = use_kept ? b->m_b : b->u_b;
     // two tables per launch: their LDS tables fill the 128 KiB a workgroup may use
     for (int s0 = 0; s0 < count; s0 += 2) {
         const int C = std::min(2, count - s0);
@@ -660,19 +720,19 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
         if (C == 2) {
             BucketStreams<T, 2> st{};
             for (int s = 0; s < 2; ++s) {
-                st.map_op[s] = map_ops ? map_ops[s0 + s] : (int) EK_COPY;
+                st.map_op[s] = (map_ops && !use_kept) ? map_ops[s0 + s] : (int) EK_COPY;
                 memcpy(&st.imm[s], &imm_bits[s0 + s], sizeof(T));
                 st.from_u |= (from_u[s0 + s] ? 1u : 0u) << s;
                 st.weighted |= (weighted[s0 + s] ? 1u : 0u) << s;
             }
-            if (int rc = bucketed_accumulate<T, 2>(b, tb, st)) return rc;
+            if (int rc = bucketed_accumulate<T, 2>(b, tb, st, u_src)) return rc;
         } else {
             BucketStreams<T, 1> st{};
-            st.map_op[0] = map_ops ? map_ops[s0] : (int) EK_COPY;
+            st.map_op[0] = (map_ops && !use_kept) ? map_ops[s0] : (int) EK_COPY;
             memcpy(&st.imm[0], &imm_bits[s0], sizeof(T));
             st.from_u = from_u[s0] ? 1u : 0u;
             st.weighted = weighted[s0] ? 1u : 0u;
-            if (int rc = bucketed_accumulate<T, 1>(b, tb, st)) return rc;
+            if (int rc = bucketed_accumulate<T, 1>(b, tb, st, u_src)) return rc;
         }
     }
     return EK_OK;
@@ -717,13 +777,13 @@ int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *ta
     return EK_OK;
 }
 
-int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values) {
+int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values, int keep_op) {
     if (int rc = ensure_init()) return rc;
     if (!b || !out) return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): null pointer");
     if (map_op != EK_COPY && !unary_fusable(map_op))
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_reduce(): op %d cannot be applied on load", map_op);
-    if (b->type == EK_F32) return bucketed_reduce<float>(b, reduce_op, map_op, out, keep_values != 0);
-    return bucketed_reduce<double>(b, reduce_op, map_op, out, keep_values != 0);
+    if (b->type == EK_F32) return bucketed_reduce<float>(b, reduce_op, map_op, out, keep_values != 0, keep_op);
+    return bucketed_reduce<double>(b, reduce_op, map_op, out, keep_values != 0, keep_op);
 }
 
 int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,

@@ -756,7 +756,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
 
     /// Horizontal reduction over map_op(u) of an unevaluated kind-2 node `u` in bucket order; false: not covered (the caller
     /// evaluates u in element order).  `held_by_consumer`: references on u that belong to the array being reduced.
-    static bool reduce_bucketed_(detail::HIPBuffer *u, int op, int map_op, void *out, uint32_t held_by_consumer) {
+    static bool reduce_bucketed_(detail::HIPBuffer *u, int op, int map_op, void *out, uint32_t held_by_consumer, int keep_op = EK_COPY) {
         if constexpr (!IsFloat) {
             return false;
         } else {
@@ -764,7 +764,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if (!b) return false;
             // somebody else can still ask for u (the cos(u) of the derivative, a user handle): keep it in bucket order
             const int keep = u->ref_count > held_by_consumer ? 1 : 0;
-            int rc = ek_hip_bucketed_reduce(b, op, map_op, out, keep);
+            int rc = ek_hip_bucketed_reduce(b, op, map_op, out, keep, keep_op);
             if (rc == EK_ERR_UNSUPPORTED) return false;
             detail::hip_check(rc, "HIPArray (bucket-ordered reduction)");
             return true;
@@ -1327,8 +1327,14 @@ private:
                 const auto *d = m_buf->deferred;
                 detail::HIPBuffer *src = d->table;
                 // map(u) with u an unevaluated fma of gathers: gathers, fma, map and reduction bucket by bucket
-                if (src->deferred && src->deferred->kind == 2 && reduce_bucketed_(src, op, d->index_type, r.m_buf->ptr, 1))
-                    return r;
+                if (src->deferred && src->deferred->kind == 2) {
+                    // the other half of an unevaluated sincos pair is what will be asked for next (the derivative): keep THAT
+                    // in bucket order rather than u
+                    int keep_op = EK_COPY;
+                    if (d->partner && d->partner->deferred && d->partner->deferred->kind == 1 && d->partner->deferred->table == src)
+                        keep_op = d->partner->deferred->index_type;
+                    if (reduce_bucketed_(src, op, d->index_type, r.m_buf->ptr, 1, keep_op)) return r;
+                }
                 if (src->deferred) src->force();
                 detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, src->ptr, n), what);
                 return r;

@@ -237,7 +237,9 @@ EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_
  *                 EK_ERR_UNSUPPORTED for shapes the path does not cover (ask ek_hip_bucketed_applicable first): tables of
  *                 one bucket or of more than 256, fewer than 256 Ki lookups, deterministic mode, non-fp types.
  *   reduce        out[0] = reduce_op over map_op(u)  (map_op: EK_COPY or an op ek_hip_reduce_map accepts); keep_values != 0
- *                 also keeps u in bucket order for later calls (4 B/elt more).
+ *                 also keeps u in bucket order for later calls (4 B/elt more) -- or, when {map_op, keep_op} = {EK_SIN, EK_COS},
+ *                 the OTHER half of sincos(u): one sincos per element yields the reduced and the kept half, and a later
+ *                 scatter_add of that half (the cos(u) of d/du sin(u)) streams it as is.  keep_op = EK_COPY: keep u.
  *   scatter_add   bases[c][index[i]] += (weighted[c] ? safe_mul(x[i], v_c[i]) : v_c[i]),  v_c = from_u[c] ? map_ops[c](u) :
  *                 the scalar imm_bits[c];  count 1..4 tables of table_size entries.
  * Values of u are bit-identical to the element-order kernels; reductions and sums differ by the ORDER of their fp
@@ -246,7 +248,7 @@ typedef struct ek_hip_bucketed ek_hip_bucketed;
 EK_API int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n);
 EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c,
                                        size_t table_size, const void *x, const void *index, size_t n, ek_hip_bucketed **out);
-EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values);
+EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values, int keep_op);
 EK_API int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                        const uint64_t *imm_bits, const int *weighted);
 EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);

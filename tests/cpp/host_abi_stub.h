@@ -258,7 +258,7 @@ int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *a,
     *out = b;
     return EK_OK;
 }
-int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int keep) {
+int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int keep, int /* keep_op: a hint, u is kept */) {
     ++g_bucketed_reduces;
     float *u = (float *) malloc(b->n * sizeof(float));
     for (size_t i = 0; i < b->n; ++i) u[i] = b->u ? b->u[i] : bucketed_u(b, i);

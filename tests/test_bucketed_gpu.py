@@ -118,9 +118,22 @@ def test_scatter_add_cos_pair_within_class_d(capi, dtype):
     cu = capi.unary("cos", u).numpy().astype(np.float64)
     ii = idx.astype(np.int64)
     cnt = np.bincount(ii, minlength=K)
-    for forward_first in (True, False):
+    for forward_first in (True, False, "partner"):
         b = capi.Bucketed("fmadd", dA, dx, dC, di)
-        if forward_first:
+        if forward_first == "partner":
+            # the forward keeps cos(u) -- the other half of the sincos it evaluates -- instead of u
+            y = float(b.reduce("hsum", "sin", keep=True, keep_op="cos").numpy()[0])
+            s64 = capi.unary("sin", u).numpy().astype(np.float64)
+            assert abs(y - s64.sum()) <= EPS[dtype] * depth(n) * np.abs(s64).sum()
+            # a stream that wants another function of u afterwards: u is rebuilt in bucket order
+            t = up(capi, np.zeros(K, dtype))
+            b.scatter_add([t], [("sin", 0, False)])
+            ref = np.bincount(ii, weights=s64, minlength=K)
+            assert (np.abs(t.numpy().astype(np.float64) - ref) <= EPS[dtype] * cnt * np.bincount(ii, weights=np.abs(s64), minlength=K) + 1e-300).all()
+            # ... and the kept half reduced directly
+            c1 = float(b.reduce("hsum", "cos").numpy()[0])
+            assert abs(c1 - cu.sum()) <= EPS[dtype] * (n // (1 << 20) + 40) * np.abs(cu).sum()
+        elif forward_first:
             b.reduce("hsum", "sin", keep=True)
         gA, gC = up(capi, np.zeros(K, dtype)), up(capi, np.zeros(K, dtype))
         b.scatter_add([gC, gA], [("cos", 0, False), ("cos", 0, True)])

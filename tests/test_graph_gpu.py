@@ -76,7 +76,9 @@ def test_cfg3b_step_graph_replay(ek, capi, n, K):
     g2 = ek.hip_graph_end()
     ek.hip_graph_destroy(g2)
     step()
-    assert bits_equal(out["y"].numpy(), ek.hsum(ek.sin(ek.fmadd(ek.gather(A0, idx), x, ek.gather(B0, idx)))).numpy())
+    # two bucket-ordered evaluations of the same sum: same terms, an order that depends on the partition (class D)
+    again = ek.hsum(ek.sin(ek.fmadd(ek.gather(A0, idx), x, ek.gather(B0, idx)))).numpy()
+    assert abs(float(out["y"].numpy()[0]) - t2["y"]) <= t2["y_bound"] and abs(float(again[0]) - t2["y"]) <= t2["y_bound"]
 
 
 def test_host_waits_are_refused_inside_a_capture(ek):

@@ -20,7 +20,7 @@ out = {}
 
 def bucketed():
     b = capi.Bucketed("fmadd", A, x, B, idx)
-    out["y"] = b.reduce("hsum", "sin", keep=True)
+    out["y"] = b.reduce("hsum", "sin", keep=True, keep_op="cos")      # what DiffArray::sin_ leads to: sincos, cos kept for the adjoint
     gA, gB = capi.fill(np.float32, 0, K), capi.fill(np.float32, 0, K)
     b.scatter_add([gB, gA], [("cos", 0, False), ("cos", 0, True)])
     out["gA"], out["gB"] = gA, gB

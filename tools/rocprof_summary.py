@@ -42,6 +42,10 @@ def pmc(dirs):
                 a = agg.setdefault((short(name), grid), {})
                 s = a.setdefault(counter, [0, 0.0])
                 s[0] += 1; s[1] += value
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from enoki_amd import _build
+    print(f"# kernels_sha16: {_build.kernels_sha16()}")
     print("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes); per launch averages; large grids only")
     print("# hbm_read = 2 * FETCH_SIZE KiB (gfx950 correction), hbm_write = WRITE_SIZE KiB")
     print(f"{'kernel':112s} {'grid':>10s} {'launches':>8s} {'read_MB':>10s} {'write_MB':>10s}")
