@@ -95,6 +95,45 @@ def ulp_diff(a, b):
     return np.abs(ia - ib)
 
 
+# ---- class C: functions that go through rcp() / rsqrt() ------------------------------------------------------------
+# The reference's own rows do not agree on them: the AVX2 row approximates reciprocals (rcpps + one Newton step,
+# array_avx.h:324-395) but fuses its polynomial cores; the scalar `none` row divides exactly (array_fallbacks.h:23-101) but its
+# generic packets never fuse (array_static.h:433-446).  The device divides exactly AND fuses -- exactly what an FMA machine
+# does with a correctly rounded division.  What is asserted (tests/golden/classc_scalar.npz, made from both rows):
+#   * rcp, rsqrt, division: BIT-EXACT against the scalar row;
+#   * everything built on them: no further from EITHER row than the two rows are from each other, and within the listed
+#     number of ulp (the worst case observed over the fixture; the share of differing elements is in DESIGN section 5).
+CLASS_C_EXACT = ["rcp", "rsqrt"]
+#                op: (max ulp vs scalar row, max ulp vs AVX2 row, max ulp between the two rows of the reference)
+CLASS_C_BAND = {"tan": (2, 2, 3), "cot": (2, 2, 3), "sinh": (3, 3, 3), "cosh": (2, 3, 3), "tanh": (2, 4, 4),
+                "erf": (2, 2, 2), "erfc": (8, 4, 8), "i0e": (5, 4, 5)}
+
+
+def class_c_fixture():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "classc_scalar.npz"))
+
+
+def class_c_check(op, got, z):
+    """`got` = op(x) of the implementation under test on the fixture's inputs (see make_golden.py for the argument)"""
+    s, a = z[f"scalar_{op}"], z[f"avx2_{op}"]
+    if op in CLASS_C_EXACT:
+        assert bits_equal(got, s), op
+        return
+    ok = np.isfinite(got) & np.isfinite(s) & np.isfinite(a) & (np.abs(got) > 1e-30)
+    assert ok.mean() > 0.9, op
+    # outside `ok` (overflow, underflow to denormals / zero, NaN): same class of result as the scalar row
+    assert np.array_equal(np.isnan(got), np.isnan(s)) and np.array_equal(np.isinf(got), np.isinf(s)), op
+    ds, da, dr = ulp_diff(got[ok], s[ok]).max(), ulp_diff(got[ok], a[ok]).max(), ulp_diff(s[ok], a[ok]).max()
+    bs, ba, br = CLASS_C_BAND[op]
+    assert dr == br, (op, "the fixture's own rows", dr)
+    assert ds <= bs and da <= ba and ds <= dr and da <= dr, (op, ds, da, dr)
+
+
+def class_c_arg(op, z):
+    return np.abs(z["x"]) + np.float32(1e-3) if op == "rsqrt" else z["x"]
+
+
 def hsum_depth(n):
     """longest chain of fp additions behind one output of the library's hsum (csrc/reduce.hip): 2^20 lane accumulators in
     stage 1, each summing ceil(n / 2^20) entries in sequence, then the wave / workgroup trees and stage 2"""
@@ -116,12 +155,27 @@ def cfg3b_truth(A, B, x, idx):
     cnt = np.bincount(ii, minlength=K)
     sum_abs = float(np.abs(s).sum())
     out = {"y": float(s.sum()), "y_bound": eps * (hsum_depth(n) * sum_abs + 4 * n), "cnt": cnt,
+           "y_stat_bound": stat_sum_bound(s, hsum_depth(n)),
            # the reference adds lane-wise: 8 (AVX2) accumulators of n / 8 entries each, then a tree (dynamic.h:632-650)
            "y_bound_reference": eps * ((n // 8 + 4) * sum_abs + 4 * n)}
     for name, terms in (("gA", c * x64), ("gB", c)):
         out[name] = np.bincount(ii, weights=terms, minlength=K)
         out[name + "_bound"] = eps * (cnt * np.bincount(ii, weights=np.abs(terms), minlength=K) + 4 * cnt)
     return out
+
+
+def stat_sum_bound(terms64, depth, sigmas=5.0):
+    """What the error of an f32 sum of these terms looks like when roundings behave like independent noise (they do): for
+    sequential chains of `depth` additions followed by a balanced tree, sigma^2 ~= u^2 (depth / 6 + 8) sum t^2 from the
+    zero-mean part of the partial sums (chains: u^2 r^2 k / 3 per addition; tree: u^2 r^2 n / 3 per level, ~23 levels), another
+    u^2 * 4 sum t^2 for the rounding of the f32 terms themselves, plus the drift when the terms have a mean m: 0.8 u |sum t|
+    from the top of the tree and u |m| depth sqrt(n) / 3 from the chains.  Returns `sigmas` standard deviations -- for
+    BASELINE config 3b at 64 Mi elements 7e-3, against 1.2e-3 observed and a worst-case bound of 188."""
+    t = np.asarray(terms64, np.float64)
+    u, n, total = 2.0 ** -24, t.size, float(t.sum())
+    sigma = u * np.sqrt((depth / 6.0 + 12.0) * float((t * t).sum()))
+    drift = u * (0.8 * abs(total) + abs(total) / max(n, 1) * depth * np.sqrt(n) / 3.0)
+    return sigmas * (sigma + drift)
 
 
 def hsum_bound(terms64, per_term_ulps=4):

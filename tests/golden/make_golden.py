@@ -45,6 +45,32 @@ if tape_lib.ref512_available():
                 out[f"g{i}"] = gi
         np.savez_compressed(os.path.join(HERE, f"tape_scatter_twice_{name}.npz"), **out)
 
+# ---- class C against the reference's SCALAR row (oracle/Makefile refscalar: rcp = 1 / a, rsqrt = 1 / sqrt(a)) -----------
+# rcp / rsqrt / div: what the device must reproduce bit for bit.  tan ... i0e: the second anchor beside the AVX2 row (the two
+# rows of the reference differ from each other: unfused vs fused polynomial cores, exact vs approximate reciprocals).
+CLASS_C_OPS = ["rcp", "rsqrt", "tan", "cot", "sinh", "cosh", "tanh", "erf", "erfc", "i0e"]
+CLASS_C_PROGRAMS = ["div_rcp_rsqrt", "sw_trig", "sw_hyp", "sw_sum", "sw_cbrt_pow"]
+if tape_lib.refscalar_available():
+    S = oracle_lib.ref_scalar()
+    xs = f32_inputs(8192, seed=211, scale=4.0)
+    xs = np.concatenate([xs, np.linspace(-12, 12, 4096, dtype=np.float32), uniform_pm1(4096, 5)])
+    cc = {"x": xs, "y": np.roll(xs, 7) + np.float32(0.25)}
+    for op in CLASS_C_OPS:
+        arg = np.abs(xs) + np.float32(1e-3) if op == "rsqrt" else xs
+        cc[f"scalar_{op}"] = S.unary(op, arg)
+        cc[f"avx2_{op}"] = R.unary(op, arg)
+    cc["scalar_div"] = S.binary("div", cc["x"], cc["y"])
+    cc["avx2_div"] = R.binary("div", cc["x"], cc["y"])
+    np.savez_compressed(os.path.join(HERE, "classc_scalar.npz"), **cc)
+    progs = tape_lib.suite()
+    for name in CLASS_C_PROGRAMS:
+        v, g = tape_lib.run(tape_lib.refscalar_fn(), progs[name])
+        out = {"value": v, "n_grads": np.array(len(g))}
+        for i, gi in enumerate(g):
+            if gi is not None:
+                out[f"g{i}"] = gi
+        np.savez_compressed(os.path.join(HERE, f"tape_scalar_{name}.npz"), **out)
+
 # ---- elementwise ops on a fixed input set (incl. specials) -------------------------------------------
 n = 4096
 a = f32_inputs(n, seed=101, scale=20.0); b = f32_inputs(n, seed=102, scale=20.0)[::-1].copy(); c = f32_inputs(n, seed=103)

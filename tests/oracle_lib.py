@@ -31,7 +31,8 @@ class Checker:
     def __init__(self, lib, prefix, kind):
         self.lib, self.prefix, self.kind = lib, prefix, kind
         for name in ("cfg1", "cfg2", "cfg3a", "cfg3b"):
-            getattr(lib, prefix + name).restype = ctypes.c_float
+            if hasattr(lib, prefix + name):          # the scalar flavour (ref_scalar_driver.cpp) has the elementwise entry points only
+                getattr(lib, prefix + name).restype = ctypes.c_float
 
     def _f(self, name):
         return getattr(self.lib, self.prefix + name)
@@ -238,3 +239,17 @@ def ref():
             _build("ref")
         _cache["ref"] = Checker(ctypes.CDLL(path), "ref_", "reference")
     return _cache["ref"]
+
+
+def ref_scalar():
+    """the reference's SCALAR path (its `none` row, oracle/Makefile refscalar): generic packets, rcp() = 1 / a, rsqrt() =
+    1 / sqrt(a), fmadd() = a * b + c in two roundings -- what rcp / rsqrt / division of the device are pinned to bit for bit,
+    and the second anchor (beside the AVX2 row) of the functions built on them"""
+    if "refscalar" not in _cache:
+        path = os.path.join(ORACLE_DIR, "_ref", "libenoki_refscalar.so")
+        if not os.path.exists(path):
+            if not os.path.isdir("/root/reference"):
+                raise FileNotFoundError(path)
+            _build("refscalar")
+        _cache["refscalar"] = Checker(ctypes.CDLL(path), "ref_", "refscalar")
+    return _cache["refscalar"]

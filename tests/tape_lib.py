@@ -100,6 +100,17 @@ def ref512_fn():
     return _libs["ref512"].ref_tape_program
 
 
+def refscalar_available():
+    return os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libenoki_refscalar.so"))
+
+
+def refscalar_fn():
+    """ref_tape_program of the reference's SCALAR row (oracle/Makefile refscalar): rcp / rsqrt / division exact"""
+    if "refscalar" not in _libs:
+        _libs["refscalar"] = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libenoki_refscalar.so"))
+    return _libs["refscalar"].ref_tape_program
+
+
 def host_lib():
     if "host" not in _libs:
         _libs["host"] = ctypes.CDLL(os.path.join(HERE, "cpp", "libtape_host.so"))

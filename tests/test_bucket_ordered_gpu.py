@@ -66,7 +66,6 @@ def test_bucket_ordered_semantics(ek, capi):
     u_ref = eager_u(ek, A, B, x, idx)
     dA, dB, dx, di = ek.Float32(A), ek.Float32(B), ek.Float32(x), ek.UInt32(idx)
     make = lambda: ek.fmadd(ek.gather(dA, di), dx, ek.gather(dB, di))
-    s64 = np.sin(u_ref.astype(np.float64))
     t = cfg3b_truth(A, B, x, idx)
 
     # consumed by a reduction through a unary map: bucket order, no element-order kernel
@@ -74,7 +73,7 @@ def test_bucket_ordered_semantics(ek, capi):
     assert "bucket_pair_fma_reduce" in ks and "bucket_partition" in ks and not any(k.startswith("gather") for k in ks), ks
     assert abs(float(y.numpy()[0]) - t["y"]) <= t["y_bound"]
     # statistically far inside the worst case: chains of <= 64 additions, then trees
-    assert abs(float(y.numpy()[0]) - s64.sum()) <= 2.0 ** -24 * (8 * np.sqrt(64 * (s64 ** 2).sum()) + 4 * abs(s64.sum()))
+    assert abs(float(y.numpy()[0]) - t["y"]) <= t["y_stat_bound"]
     # order-independent reductions are bit-exact
     assert bits_equal(ek.hmax(make()).numpy(), np.array([u_ref.max()]))
     assert bits_equal(ek.hmin(ek.abs(make())).numpy(), np.array([np.abs(u_ref).min()]))

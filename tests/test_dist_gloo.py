@@ -61,11 +61,14 @@ def test_sharded_cfg3b_allreduce_matches_unsharded(tmp_path):
     N, K = 200003, 4096
     x = uniform_pm1(N, 2); idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)
     A, B = uniform_pm1(K, 6), uniform_pm1(K, 7)
+    from conftest import cfg3b_truth
     y, gA, gB, _ = oracle_lib.port().cfg3b(A, B, x, idx)
-    assert abs(float(z["y"][0]) - y) <= N * 2.0 ** -23 * N
-    cnt = np.bincount(idx, minlength=K) + 1
-    assert np.all(np.abs(z["gA"] - gA) <= cnt * cnt * 2.0 ** -24)
-    assert np.all(np.abs(z["gB"] - gB) <= cnt * cnt * 2.0 ** -24)
+    t = cfg3b_truth(A, B, x, idx)
+    # class D against float64: the shards are summed by the CPU checker (8 lane-wise accumulators each), then added
+    assert abs(float(z["y"][0]) - t["y"]) <= t["y_bound_reference"] and abs(float(z["y"][0]) - y) <= 2 * t["y_bound_reference"]
+    for name, got, whole in (("gA", z["gA"], gA), ("gB", z["gB"], gB)):
+        assert np.all(np.abs(got - t[name]) <= t[name + "_bound"]), name           # cnt * sum|terms| * 2^-24 per bin
+        assert np.all(np.abs(got - whole) <= 2 * t[name + "_bound"]), name
     assert z["tmax"][0] == 2.0
 
 

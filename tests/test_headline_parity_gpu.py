@@ -52,6 +52,7 @@ def test_cfg3b_headline_default_mode(ek, cfg3b_case):
     y, gA, gB = _run_cfg3b(ek, cfg3b_case)
     ry, rgA, rgB = cfg3b_case["ref"]
     assert abs(y - t["y"]) <= t["y_bound"], (y, t["y"])
+    assert abs(y - t["y"]) <= t["y_stat_bound"], (y, t["y"], t["y_stat_bound"])   # 5 sigma of independent roundings: ~6x today's error
     assert abs(y - t["y"]) <= abs(ry - t["y"]) + 1e-3          # and no worse than the reference's own lane-wise sum
     for g, arr, ref in (("gA", gA, rgA), ("gB", gB, rgB)):
         err = np.abs(arr - t[g])

@@ -46,6 +46,19 @@ def test_second_wave_unary_bit_exact(capi, oracle, op, scale):
     assert bits_equal(capi.unary(op, up(capi, a)).numpy(), oracle.unary(op, a)), op
 
 
+def test_class_c_kernels_vs_both_rows_of_the_reference(capi):
+    """The kernels that go through rcp() / rsqrt() against the REFERENCE (not against our restatement): rcp, rsqrt, division
+    bit-exact against its scalar row (1 / a, array_fallbacks.h:23-101); tan, cot, sinh, cosh, tanh, erf, erfc, i0e no further
+    from either of its rows than the rows are from each other, within the ulp counts listed in conftest.CLASS_C_BAND
+    (fixture: tests/golden/classc_scalar.npz, made by make_golden.py from oracle/_ref/libenoki_refscalar.so + libenoki_ref.so)."""
+    from conftest import CLASS_C_BAND, CLASS_C_EXACT, class_c_arg, class_c_check, class_c_fixture
+    z = class_c_fixture()
+    for op in CLASS_C_EXACT + list(CLASS_C_BAND):
+        class_c_check(op, capi.unary(op, up(capi, class_c_arg(op, z))).numpy(), z)
+    got = capi.binary("div", up(capi, z["x"]), up(capi, z["y"])).numpy()
+    assert bits_equal(got, z["scalar_div"])
+
+
 @pytest.mark.parametrize("op", ["atan2", "pow", "fmod", "ldexp"])
 def test_second_wave_binary_bit_exact(capi, oracle, op):
     for scale in (1.0, 40.0):

@@ -301,3 +301,25 @@ def test_golden_memory_reduce_configs():
         I = (hash_u32(np.arange(nn, dtype=np.uint64), 4) % np.uint32(Kc)).astype(np.uint32)
         y, gA, gB, _ = P.cfg3b(TA, TB, X, I)
         assert np.float32(y) == c[f"cfg3b_{nn}_y"][0] and bits_equal(gA, c[f"cfg3b_{nn}_gA"]) and bits_equal(gB, c[f"cfg3b_{nn}_gB"])
+
+
+def test_class_c_pinned_to_the_scalar_row_and_between_the_rows():
+    """rcp / rsqrt / division of the oracle: bit-exact against the reference's SCALAR row (oracle/Makefile refscalar: rcp =
+    1 / a); tan ... i0e: no further from either row of the reference than the rows are from each other (conftest.py,
+    CLASS_C_BAND).  From the committed fixture, and live against oracle/_ref/libenoki_refscalar.so where it exists."""
+    from conftest import CLASS_C_BAND, CLASS_C_EXACT, class_c_arg, class_c_check, class_c_fixture
+    import oracle_lib as ol
+    z = class_c_fixture()
+    P = ol.port()
+    for op in CLASS_C_EXACT + list(CLASS_C_BAND):
+        class_c_check(op, P.unary(op, class_c_arg(op, z)), z)
+    assert bits_equal(P.binary("div", z["x"], z["y"]), z["scalar_div"]) and bits_equal(z["scalar_div"], z["avx2_div"])
+    try:
+        S = ol.ref_scalar()
+    except (FileNotFoundError, OSError):
+        return
+    for op in CLASS_C_EXACT + list(CLASS_C_BAND):               # the fixture is what the live build produces
+        assert bits_equal(S.unary(op, class_c_arg(op, z)), z[f"scalar_{op}"]), op
+    a = f32_inputs(100003, seed=77, scale=50.0)
+    assert bits_equal(P.unary("rcp", a), S.unary("rcp", a))
+    assert bits_equal(P.unary("rsqrt", np.abs(a)), S.unary("rsqrt", np.abs(a)))

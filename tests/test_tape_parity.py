@@ -62,9 +62,45 @@ def test_golden_fixtures_match_host_tape(name):
         assert bits_equal(z[f"g{i}"], g) if exact else np.allclose(z[f"g{i}"], g, rtol=3e-6, atol=3e-6)
 
 
-def _order_bound(prog, n_terms_hint=None):
-    n = max(a.size for a, _ in prog.inputs)
-    return n * 2.0 ** -23
+CLASS_C_PROGRAMS = ["div_rcp_rsqrt", "sw_trig", "sw_hyp", "sw_sum", "sw_cbrt_pow"]
+
+
+def _band(name, what, got, scalar_row, avx2_row):
+    """`got` is no further (in ulp, over the finite entries) from either row of the reference than the rows are from each
+    other.  (Composite outputs cancel -- sums of several function values -- so the distances can be large in ulp for BOTH
+    rows; the band is what is meaningful, see conftest.py on class C.)"""
+    from conftest import ulp_diff
+    g, s, a = (np.asarray(v, np.float32).ravel() for v in (got, scalar_row, avx2_row))
+    ok = np.isfinite(g) & np.isfinite(s) & np.isfinite(a) & (np.abs(g) > 1e-30) & (np.abs(s) > 1e-30) & (np.abs(a) > 1e-30)
+    ds, da, dr = ulp_diff(g[ok], s[ok]).max(), ulp_diff(g[ok], a[ok]).max(), ulp_diff(s[ok], a[ok]).max()
+    assert ds <= dr and da <= dr, (name, what, int(ds), int(da), int(dr))
+
+
+def _class_c_program(name, run_fn, value_is_order_dependent):
+    prog = tl.suite()[name]
+    zs = np.load(os.path.join(GOLDEN, f"tape_scalar_{name}.npz"))      # the reference's scalar row (oracle/Makefile refscalar)
+    za = np.load(os.path.join(GOLDEN, f"tape_{name}.npz"))             # its AVX2 row
+    v, g = tl.run(run_fn, prog)
+    if not value_is_order_dependent:
+        _band(name, "value", v, zs["value"], za["value"])
+    for i, gi in enumerate(g):
+        if gi is not None:
+            _band(name, f"g{i}", gi, zs[f"g{i}"], za[f"g{i}"])
+    if name == "div_rcp_rsqrt":
+        # weights made of division, rcp and rsqrt only: the scalar row's bits
+        assert bits_equal(g[0], zs["g0"]) and bits_equal(g[1], zs["g1"])
+
+
+@pytest.mark.parametrize("name", CLASS_C_PROGRAMS)
+def test_host_tape_class_c_programs_between_the_reference_rows(name):
+    """the five tape programs whose values / edge weights go through rcp() or rsqrt(), against BOTH rows of the reference"""
+    _class_c_program(name, tl.host_lib().host_tape_program, value_is_order_dependent=False)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", CLASS_C_PROGRAMS)
+def test_hip_tape_class_c_programs_between_the_reference_rows(name):
+    _class_c_program(name, tl.hip_lib().hip_tape_program, value_is_order_dependent=name in tl.ORDER_DEPENDENT_ON_GPU)
 
 
 @pytest.mark.gpu
@@ -96,17 +132,20 @@ def test_hip_tape_matches_reference(name):
         for a, b in zip(rg, gg):
             assert (a is None and b is None) or bits_equal(a, b), name
         return
-    # programs containing horizontal reductions / fp scatter_add: the primal reduction and every gradient that
-    # passed through a reduction depend on summation order (class D).  Bound: n * 2^-23 relative to the sum of
-    # magnitudes, evaluated per output.
-    scale = max(float(np.abs(rv).max()), 1.0)
+    # programs containing horizontal reductions / fp scatter_add: the primal reduction and every gradient that passed through
+    # a reduction depend on the summation order (class D).  Two orders of the same n <= 1000 terms differ by a few ulp AT THE
+    # SCALE of what is summed: the output's own magnitude when the terms have a sign, sqrt(n) entries of input magnitude when
+    # they cancel.  16 of those ulps; the errors observed on the MI355X (tools/probe_tape_errors.py) are 0 .. 4.6 of them.
     n = max(a.size for a, _ in prog.inputs)
-    assert np.all(np.abs(gv - rv) <= n * 2.0 ** -23 * max(scale, float(np.sum(np.abs(prog.inputs[0][0]))))), name
+    unit = 2.0 ** -24 * np.sqrt(n) * max(float(np.abs(a).max()) for a, _ in prog.inputs)
+
+    def tol(ref):
+        return 16 * (2.0 ** -24 * float(np.abs(ref).max()) + unit)
+    assert np.all(np.abs(gv - rv) <= tol(rv)), (name, float(np.abs(gv - rv).max()), tol(rv))
     for a, b in zip(rg, gg):
         if a is None:
             continue
-        tol = n * 2.0 ** -22 * max(float(np.abs(a).max()), 1.0)
-        assert np.all(np.abs(a - b) <= tol), (name, float(np.abs(a - b).max()), tol)
+        assert np.all(np.abs(a - b) <= tol(a)), (name, float(np.abs(a - b).max()), tol(a))
 
 
 @pytest.mark.gpu
@@ -118,7 +157,11 @@ def test_hip_cfg3a_gradients_bit_exact_elementwise():
         pytest.skip("needs the reference build for n = 100003")
     gv, gg = tl.run(tl.hip_lib().hip_tape_program, prog)
     assert bits_equal(rg[0], gg[0]) and bits_equal(rg[2], gg[2])
-    assert abs(float(gv[0]) - float(rv[0])) <= 100003 * 2.0 ** -23 * 100003
+    from conftest import hsum_bound, hsum_depth, stat_sum_bound
+    (a, _), (x, _), (b, _) = prog.inputs
+    s64 = np.sin(a.astype(np.float64) * x + b)
+    assert abs(float(gv[0]) - s64.sum()) <= hsum_bound(s64)                                   # worst case of our order
+    assert abs(float(gv[0]) - s64.sum()) <= stat_sum_bound(s64, hsum_depth(s64.size))         # 5 sigma
 
 
 SEEDS = list(range(24))
