@@ -38,7 +38,7 @@ EXPORTS = [
     "ek_hip_last_error", "ek_hip_malloc", "ek_hip_free", "ek_hip_malloc_trim", "ek_hip_host_malloc",
     "ek_hip_host_free", "ek_hip_mem_get_info", "ek_hip_memcpy_to_device", "ek_hip_memcpy_to_host",
     "ek_hip_memcpy_device", "ek_hip_memset", "ek_hip_whos", "ek_hip_set_log_level", "ek_hip_log_level",
-    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_gather_multi_sized", "ek_hip_gather_multi_plan", "ek_hip_scatter_add_multi", "ek_hip_concat",
+    "ek_hip_launch_count", "ek_hip_set_tuning", "ek_hip_profile_begin", "ek_hip_profile_end", "ek_hip_unary", "ek_hip_binary", "ek_hip_ternary", "ek_hip_sincos", "ek_hip_sincosh", "ek_hip_pcg32_next", "ek_hip_gather_multi", "ek_hip_gather_multi_sized", "ek_hip_gather_multi_plan", "ek_hip_scatter_add_multi", "ek_hip_concat", "ek_hip_concat_rows",
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
@@ -467,15 +467,17 @@ class Bucketed:
                                          UNARY[keep_op or "copy"]))
         return out
 
-    def scatter_add(self, targets, streams):
-        """streams[c] = (map_op name | None for a constant, constant value, weighted by x?)"""
+    def scatter_add(self, targets, streams, fresh=None):
+        """streams[c] = (map_op name | None for a constant, constant value, weighted by x?); fresh[c]: table c holds no data
+        yet, its sums are written instead of added"""
         count = len(targets)
         bases = (ctypes.c_void_p * count)(*[t.ptr for t in targets])
         from_u = (ctypes.c_int * count)(*[0 if s[0] is None else 1 for s in streams])
         ops = (ctypes.c_int * count)(*[UNARY[s[0] or "copy"] for s in streams])
         imm = (ctypes.c_uint64 * count)(*[_imm_bits(s[1], self.dtype) for s in streams])
         wt = (ctypes.c_int * count)(*[int(bool(s[2])) for s in streams])
-        check(lib.ek_hip_bucketed_scatter_add(self.handle, count, bases, from_u, ops, imm, wt))
+        fr = (ctypes.c_int * count)(*[int(bool(f)) for f in fresh]) if fresh is not None else None
+        check(lib.ek_hip_bucketed_scatter_add(self.handle, count, bases, from_u, ops, imm, wt, fr))
 
     def destroy(self):
         if self.handle:

@@ -43,6 +43,20 @@ __global__ __launch_bounds__(256) void k_reverse(T *__restrict__ out, const T *_
 constexpr int kConcatMax = 8;
 struct ConcatArgs { const void *src[kConcatMax]; size_t end[kConcatMax]; };
 
+// out[r][end[k-1] + j] = src_k[r * c_k + j]: every source seen as [rows, c_k], concatenated along the columns (a.end = column
+// boundaries within one output row of `row` entries)
+template <typename T> __global__ __launch_bounds__(256) void k_concat_rows(T *__restrict__ out, ConcatArgs a, size_t row, size_t total) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const size_t r = i / row, col = i - r * row;
+    const void *src = a.src[0];
+    size_t begin = 0, width = a.end[0];
+#pragma unroll
+    for (int k = 0; k < kConcatMax - 1; ++k)
+        if (col >= a.end[k]) { src = a.src[k + 1]; begin = a.end[k]; width = a.end[k + 1] - a.end[k]; }
+    out[i] = static_cast<const T *>(src)[r * width + (col - begin)];
+}
+
 template <typename T> __global__ __launch_bounds__(256) void k_concat(T *__restrict__ out, ConcatArgs a, size_t total) {
     const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -419,6 +433,35 @@ int ek_hip_reverse(int type, void *out, const void *in, size_t n) {
         default: return fail(EK_ERR_INVALID, "ek_hip_reverse(): unknown type %d", type);
     }
     EK_LAUNCH_CHECK("reverse", n, 2 * n * type_size(type));
+    return EK_OK;
+}
+
+int ek_hip_concat_rows(int type, void *out, size_t rows, int count, const void *const *srcs, const size_t *sizes) {
+    if (int rc = ensure_init()) return rc;
+    if (count < 1 || count > kConcatMax) return fail(EK_ERR_INVALID, "ek_hip_concat_rows(): 1 to %d arrays expected, got %d", kConcatMax, count);
+    if (!out || !srcs || !sizes || rows == 0) return fail(EK_ERR_INVALID, "ek_hip_concat_rows(): null pointer / no rows");
+    ConcatArgs a;
+    size_t row = 0;
+    for (int i = 0; i < kConcatMax; ++i) {
+        a.src[i] = nullptr;
+        a.end[i] = row;
+        if (i < count) {
+            if (!srcs[i] || sizes[i] % rows) return fail(EK_ERR_INVALID, "ek_hip_concat_rows(): array %d: null or not a multiple of %zu rows", i, rows);
+            a.src[i] = srcs[i];
+            row += sizes[i] / rows;
+            a.end[i] = row;
+        }
+    }
+    if (row == 0) return EK_OK;
+    Context &c = ctx();
+    const size_t total = rows * row;
+    unsigned grid = (unsigned) ((total + 255) / 256);
+    switch (type_size(type)) {
+        case 4: hipLaunchKernelGGL((k_concat_rows<uint32_t>), dim3(grid), dim3(256), 0, c.stream, (uint32_t *) out, a, row, total); break;
+        case 8: hipLaunchKernelGGL((k_concat_rows<uint64_t>), dim3(grid), dim3(256), 0, c.stream, (uint64_t *) out, a, row, total); break;
+        default: return fail(EK_ERR_INVALID, "ek_hip_concat_rows(): 4- and 8-byte types only");
+    }
+    EK_LAUNCH_CHECK("concat_rows", total, 2 * total * type_size(type));
     return EK_OK;
 }
 

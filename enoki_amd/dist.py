@@ -4,7 +4,9 @@ Partition: rank r of P owns elements [r*N/P, (r+1)*N/P) of EVERY size-N array, s
 selects and casts are local.  Size-1 arrays and small gather tables (size K) are replicated.  The only exchange
 steps of the hot path are
     * horizontal reductions: local block reduction, then an all-reduce of ONE element;
-    * gradients of replicated tables: local scatter_add into a K-buffer, then an all-reduce of K elements.
+    * gradients of replicated tables: local scatter_add into a K-buffer, then an all-reduce of K elements -- or, when the
+      consumer of the gradient works on the slice it owns (`gradient(table, scattered=True)`), a REDUCE-SCATTER: rank r
+      receives bins [r K / P, (r + 1) K / P), half the bytes on the wire and no K-sized work replicated afterwards.
 Both run as RCCL all-reduces over xGMI through torch.distributed (backend "nccl" IS RCCL on ROCm); `gloo` is
 used by the CPU tests.  To keep the number of collectives per backward() at ONE, callers pack every pending
 reduction into a flat buffer with `Packer`.
@@ -163,6 +165,9 @@ class Handle:
     """A contribution to an Exchange: after flush() `tensor()` is the REDUCED value (a view of the staging buffer, valid
     until the buffer rotates back: `depth` flushes later)"""
 
+    scattered = False        # reduce-scattered: tensor() is the slice of the reduction that this rank owns
+    owned = None             # (begin, end) of that slice in the full table
+
     def __init__(self):
         self._slot, self._work = None, None
 
@@ -201,6 +206,19 @@ class Exchange:
         self._pending.append((h, _to_tensor(value, self.device, dtype), op))
         return h
 
+    def add_scattered(self, value, op="sum", dtype=None):
+        """A K-element contribution whose REDUCED value is only needed where it is owned: after flush() the handle's
+        tensor() is the slice [r * c, (r + 1) * c) of the reduction, c = ceil(K / P), on rank r (`Handle.owned` = its range
+        in the table).  All scattered contributions of one (dtype, reduction) share ONE reduce-scatter, which moves half
+        the bytes of the all-reduce they would otherwise ride on -- and nothing K-sized is replicated afterwards: what
+        each rank does with the gradient (an optimiser step on its slice, a norm) scales with 1 / P."""
+        if op not in _TORCH_OPS:
+            raise ValueError(f"unknown reduction '{op}'")
+        h = Handle()
+        h.scattered = True
+        self._pending.append((h, _to_tensor(value, self.device, dtype), op))
+        return h
+
     def flush(self, async_op=True):
         plan = Plan(self, self._pending, async_op)
         self._pending = []
@@ -236,15 +254,80 @@ class Exchange:
                     entry["work"][i] = None
 
 
+def _world():
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
+def _rank():
+    return dist.get_rank() if dist.is_initialized() else 0
+
+
 class Plan:
     def __init__(self, exchange, items, async_op):
         self.ex, self.async_op = exchange, async_op
-        self.groups = {}
+        self.groups, self.scattered = {}, {}
         for h, t, op in items:
-            self.groups.setdefault((t.dtype, op), []).append((h, t))
+            (self.scattered if h.scattered else self.groups).setdefault((t.dtype, op), []).append((h, t))
+
+    def _run_scattered(self):
+        """ONE reduce-scatter per (dtype, reduction): the staging buffer is laid out rank-major, row r = the chunks that
+        rank r owns of every part ([P, sum of chunks]); padded where K is not a multiple of P"""
+        ex, P, r = self.ex, _world(), _rank()
+        for (dtype, op), parts in self.scattered.items():
+            chunks = [-(-t.numel() // P) for _, t in parts]
+            row = sum(chunks)
+            entry, i = ex._buffer((dtype, op, "scatter"), P * row + row, dtype)
+            flat = entry["bufs"][i]
+            send, recv = flat[:P * row].view(P, row), flat[P * row:]
+            fast = False
+            if flat.is_cuda and dtype == torch.float32 and len(parts) <= 8 and \
+                    all(t.is_cuda and t.is_contiguous() and t.numel() == P * c for (_, t), c in zip(parts, chunks)):
+                from enoki_amd import hip as _ek
+                if _ek.hip_stream() == torch.cuda.current_stream().cuda_stream:
+                    _ek.hip_concat_rows_f32(flat.data_ptr(), P, [(t.data_ptr(), t.numel()) for _, t in parts])   # one launch
+                    fast = True
+            offset = 0
+            for (h, t), c in zip(parts, chunks):
+                k = t.numel()
+                if fast:
+                    pass
+                elif k == P * c:
+                    send[:, offset:offset + c].copy_(t.view(P, c), non_blocking=True)
+                else:                                    # ragged last chunk: zero padding (the identity of a sum)
+                    if op != "sum":
+                        raise ValueError("scattered reductions other than 'sum' need a table size that is a multiple of the world size")
+                    send[:, offset:offset + c].zero_()
+                    full = k // c
+                    if full:
+                        send[:full, offset:offset + c].copy_(t[:full * c].view(full, c), non_blocking=True)
+                    if k > full * c:
+                        send[full, offset:offset + k - full * c].copy_(t[full * c:], non_blocking=True)
+                h._slot = recv[offset:offset + min(c, max(0, k - r * c))]
+                h.owned = (min(r * c, k), min((r + 1) * c, k))
+                offset += c
+            work = None
+            if dist.is_initialized() and P > 1 and dist.get_backend() != "gloo":
+                work = dist.reduce_scatter_tensor(recv, flat[:P * row], op=_TORCH_OPS[op], async_op=self.async_op)
+            elif dist.is_initialized() and P > 1:
+                # gloo (the CPU tests) has no reduce-scatter: all-reduce the staging buffer, keep the owned row
+                work = dist.all_reduce(flat[:P * row], op=_TORCH_OPS[op], async_op=False)
+                recv.copy_(send[r])
+                work = None
+            else:
+                recv.copy_(send[0], non_blocking=True)
+            if dist.is_initialized():
+                ex.collectives += 1
+            if not self.async_op:
+                if work is not None:
+                    work.wait()
+                work = None
+            entry["work"][i] = work
+            for h, _ in parts:
+                h._work = work
 
     def run(self):
         ex = self.ex
+        self._run_scattered()
         for (dtype, op), parts in self.groups.items():
             total = sum(t.numel() for _, t in parts)
             entry, i = ex._buffer((dtype, op), total, dtype)
@@ -328,13 +411,30 @@ class Sharded:
         return _Predicate(self.exchange.add(int(self.ek.count(mask)), "sum", torch.int64),
                           lambda c, n=(self.n_total if size is None else size): c == n)
 
-    def gradient(self, table):
-        """gradient of a REPLICATED table: the local scatter_add result, summed over the ranks"""
-        return self.exchange.add(self.ek.gradient(table), "sum")
+    def gradient(self, table, scattered=False):
+        """gradient of a REPLICATED table: the local scatter_add result, summed over the ranks.  scattered=True: every rank
+        receives only the bins it owns ([r K / P, (r + 1) K / P), Handle.owned) through a reduce-scatter -- half the bytes
+        of the all-reduce, and no K-sized work is replicated after the exchange; gather_scattered() rebuilds the full array
+        where somebody needs it."""
+        g = self.ek.gradient(table)
+        return self.exchange.add_scattered(g, "sum") if scattered else self.exchange.add(g, "sum")
 
-    def reduce(self, array, op="sum"):
+    def reduce(self, array, op="sum", scattered=False):
         """an already computed local partial (e.g. kept from a captured step graph)"""
-        return self.exchange.add(array, op)
+        return self.exchange.add_scattered(array, op) if scattered else self.exchange.add(array, op)
+
+    def gather_scattered(self, handle, size):
+        """the full reduced table from its scattered slices (an all-gather; only for callers that need all of it)"""
+        own = handle.tensor()
+        if self.world == 1:
+            return own[:size].clone()
+        c = -(-size // self.world)
+        padded = torch.zeros(c, device=own.device, dtype=own.dtype)
+        padded[:own.numel()] = own
+        out = torch.empty(self.world * c, device=own.device, dtype=own.dtype)
+        dist.all_gather_into_tensor(out, padded) if dist.get_backend() != "gloo" else \
+            dist.all_gather(list(out.view(self.world, c).unbind(0)), padded)
+        return out[:size]
 
     def flush(self, async_op=True):
         return self.exchange.flush(async_op)

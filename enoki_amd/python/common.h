@@ -790,5 +790,12 @@ inline void bind_runtime(py::module_ &m) {
         for (const auto &p : parts) { srcs.push_back((const void *) p.first); sizes.push_back(p.second); }
         detail::hip_check(ek_hip_concat(EK_F32, (void *) out, (int) parts.size(), srcs.data(), sizes.data()), "hip_concat_f32");
     }, "out"_a, "parts"_a, "out = parts[0] | parts[1] | ... ((device pointer, element count) pairs of float32 arrays), one launch");
+    m.def("hip_concat_rows_f32", [](uintptr_t out, size_t rows, const std::vector<std::pair<uintptr_t, size_t>> &parts) {
+        std::vector<const void *> srcs;
+        std::vector<size_t> sizes;
+        for (const auto &p : parts) { srcs.push_back((const void *) p.first); sizes.push_back(p.second); }
+        detail::hip_check(ek_hip_concat_rows(EK_F32, (void *) out, rows, (int) parts.size(), srcs.data(), sizes.data()), "hip_concat_rows_f32");
+    }, "out"_a, "rows"_a, "parts"_a, "out[r] = parts[0][r] | parts[1][r] | ... with every part seen as [rows, size / rows]: the staging "
+       "layout of a reduce-scatter, one launch");
     m.def("hip_set_tuning", [](const char *k, int v) { detail::hip_check(ek_hip_set_tuning(k, v), "hip_set_tuning"); });
 }

@@ -59,7 +59,7 @@ namespace detail {
             int type, index_type;              // map: index_type holds the unary op
             size_t elem_size;
             bool consumed;                     // a fused consumer has read it once: the next access materialises (gathers)
-            int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below)
+            int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below), 3: zeros (no sources)
             HIPBuffer *partner = nullptr;      // map: the other half of an unevaluated sincos pair (not owning)
             // kind 2:  u = op(table[index], arg0, table2[index])  with op of the fma family -- the parameter lookup
             // `fmadd(gather(A, idx), x, gather(B, idx))`.  Left unevaluated one step longer than its gathers: when the
@@ -192,11 +192,34 @@ namespace detail {
             return d->bucketed;
         }
 
+        /// kind 3: zero<HIPArray>(n) that nobody has looked at yet.  The gradient buffers of the backward sweep start their life
+        /// like this (autodiff.cpp:332-338 zero-fills them); a bucket-ordered scatter_add that takes one as its target WRITES
+        /// its sums instead of adding them to a memset buffer (adopt_uninitialized()), everybody else gets the memset.
+        void force_zeros() {
+            void *p = nullptr;
+            const size_t bytes = (size ? size : 1) * deferred->elem_size;
+            hip_check(ek_hip_malloc(bytes, &p), "HIPArray (zeros)");
+            if (ek_hip_memset(p, 0, bytes) != EK_OK) {
+                ek_hip_free(p);
+                hip_raise("HIPArray (zeros)");
+            }
+            ptr = p;
+            drop_deferred();
+        }
+        /// Storage without contents for a pending zeros node whose only consumer is about to overwrite every entry
+        void adopt_uninitialized() {
+            void *p = nullptr;
+            hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (zeros)");
+            ptr = p;
+            drop_deferred();
+        }
+
         /// Execute the deferred gather / map
         void force() {
             if (!deferred) return;
             if (deferred->kind == 1) { force_map(); return; }
             if (deferred->kind == 2) { force_pair(); return; }
+            if (deferred->kind == 3) { force_zeros(); return; }
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (deferred gather)");
             ek_gathered g = gathered();
@@ -570,6 +593,20 @@ template <typename Value_> struct HIPArray : ArrayTag {
 
     static HIPArray zero_(size_t size) {
         if (size == 1) return HIPArray(Value(0));
+        if constexpr (IsFloat) {
+            // left unevaluated (kind 3, see detail::HIPBuffer::force_zeros): the usual fate of a zero array in the backward
+            // sweep is to become the target of ONE scatter_add, which can then write instead of accumulate
+            const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_min_size_;
+            if (detail::hip_defer_gather_flag() && size >= least) {
+                auto *d = new typename detail::HIPBuffer::Deferred{ nullptr, nullptr, nullptr, Type, 0, sizeof(Value), false, 3, nullptr };
+                HIPArray r;
+                r.m_buf = new detail::HIPBuffer();
+                r.m_buf->size = size;
+                r.m_buf->deferred = d;
+                r.m_buf->pending_link();
+                return r;
+            }
+        }
         HIPArray r = empty_(size);
         if (size) detail::hip_check(ek_hip_memset(r.m_buf->ptr, 0, size * sizeof(Value)), "zero_");
         return r;
@@ -691,6 +728,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
     bool deferred_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 0 && !m_buf->deferred->consumed; }
     /// An unevaluated unary map (see detail::HIPBuffer)
     bool mapped_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 1; }
+    /// zero<HIPArray>(n) that has not been looked at yet (kind 3)
+    bool zeroed_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 3; }
     /// An unevaluated fma over a gathered pair (kind 2, see detail::HIPBuffer)
     bool paired_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 2; }
 
@@ -951,16 +990,31 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if (weighted[c] && (weights[c]->m_is_imm || weights[c]->m_buf != d->arg0)) return false;
             if (targets[c]->size() != d->table->size) return false;
         }
-        // writers first: a target that aliases one of u's sources evaluates u (and drops its partition) right here
+        // writers first: a target that aliases one of u's sources evaluates u (and drops its partition) right here.  A target
+        // that is a pending zeros node held by nobody else (the fresh gradient buffer of the sweep) is not memset: the fold
+        // WRITES its sums there.
         void *bases[4];
-        for (size_t c = 0; c < count; ++c) targets[c]->make_unique();
+        int fresh[4];
+        for (size_t c = 0; c < count; ++c) {
+            fresh[c] = targets[c]->zeroed_() && targets[c]->m_buf->ref_count == 1 ? 1 : 0;
+            for (size_t t = 0; t < c; ++t) fresh[c] = fresh[c] && targets[t]->m_buf != targets[c]->m_buf;
+            if (!fresh[c]) targets[c]->make_unique();
+        }
         if (!u->deferred) return false;
         ek_hip_bucketed *b = u->bucketed();
         if (!b) return false;
-        for (size_t c = 0; c < count; ++c) bases[c] = targets[c]->data();
-        int rc = ek_hip_bucketed_scatter_add(b, (int) count, bases, from_u, ops, imm, weighted);
-        if (rc == EK_ERR_UNSUPPORTED) return false;
-        detail::hip_check(rc, "scatter_add_multi_ (bucket order)");
+        for (size_t c = 0; c < count; ++c) {
+            if (fresh[c]) targets[c]->m_buf->adopt_uninitialized();
+            bases[c] = targets[c]->m_buf->ptr;
+        }
+        int rc = ek_hip_bucketed_scatter_add(b, (int) count, bases, from_u, ops, imm, weighted, fresh);
+        if (rc != EK_OK) {
+            // not covered after all: the adopted targets become what they promised to be before anybody else adds to them
+            for (size_t c = 0; c < count; ++c)
+                if (fresh[c]) detail::hip_check(ek_hip_memset(bases[c], 0, targets[c]->m_buf->size * sizeof(Value)), "scatter_add_multi_");
+            if (rc == EK_ERR_UNSUPPORTED) return false;
+            detail::hip_check(rc, "scatter_add_multi_ (bucket order)");
+        }
         return true;
     }
 

@@ -183,6 +183,10 @@ EK_API int ek_hip_reverse(int type, void *out, const void *in, size_t n);
 /* out = srcs[0] | srcs[1] | ... (sizes in elements, count <= 8) in ONE launch: the staging step of the packed all-reduce
  * (scalar loss + K-element gradients -> one flat buffer), where three small copies would cost three launches */
 EK_API int ek_hip_concat(int type, void *out, int count, const void *const *srcs, const size_t *sizes);
+/* The staging step of a REDUCE-SCATTER over `rows` ranks: every source (sizes[k] a multiple of `rows`) is seen as [rows, c_k]
+ * and the sources are concatenated along the columns -- out[r] = srcs[0][r] | srcs[1][r] | ..., i.e. row r holds the chunks of
+ * all tables that rank r will own -- in ONE launch (count <= 8, 4- and 8-byte types). */
+EK_API int ek_hip_concat_rows(int type, void *out, size_t rows, int count, const void *const *srcs, const size_t *sizes);
 
 /* ---------------------------------------------------------------------------------------------
  *  Indexed memory ops (cuda.h:845-905).  `index_type` in {EK_I32, EK_U32, EK_I64, EK_U64};
@@ -241,7 +245,9 @@ EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_
  *                 the OTHER half of sincos(u): one sincos per element yields the reduced and the kept half, and a later
  *                 scatter_add of that half (the cos(u) of d/du sin(u)) streams it as is.  keep_op = EK_COPY: keep u.
  *   scatter_add   bases[c][index[i]] += (weighted[c] ? safe_mul(x[i], v_c[i]) : v_c[i]),  v_c = from_u[c] ? map_ops[c](u) :
- *                 the scalar imm_bits[c];  count 1..4 tables of table_size entries.
+ *                 the scalar imm_bits[c];  count 1..4 tables of table_size entries.  fresh (may be NULL): fresh[c] != 0 says
+ *                 that table c holds no data yet -- a gradient buffer that would otherwise be zero-filled first: its sums are
+ *                 WRITTEN (bases[c][k] = sum), saving the fill and the read of the old contents.
  * Values of u are bit-identical to the element-order kernels; reductions and sums differ by the ORDER of their fp
  * additions only (unspecified, like ek_hip_reduce / ek_hip_scatter_add mode 0). */
 typedef struct ek_hip_bucketed ek_hip_bucketed;
@@ -250,7 +256,7 @@ EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const v
                                        size_t table_size, const void *x, const void *index, size_t n, ek_hip_bucketed **out);
 EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values, int keep_op);
 EK_API int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
-                                       const uint64_t *imm_bits, const int *weighted);
+                                       const uint64_t *imm_bits, const int *weighted, const int *fresh);
 EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
 EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
                           const ek_operand *index, const ek_operand *mask, size_t n);

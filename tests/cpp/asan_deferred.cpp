@@ -152,9 +152,23 @@ static void directed() {
         CHECK(same(host(a), hs) && same(host(sc.second), hc));
     }
 
+    // --- zeros stay unevaluated until somebody looks (kind 3) ---
+    {
+        F z = zero<F>(N);
+        CHECK(z.zeroed_());
+        F z2 = z;                                      // a second handle: no longer a candidate for "write instead of add"
+        CHECK(z.coeff(17) == 0.f && !z.zeroed_() && !z2.zeroed_());
+        F w = zero<F>(N) + x;                          // consumed by an ordinary op: memset first
+        CHECK(same(host(w), hx));
+        F t = zero<F>(N);
+        scatter_add(t, x, idx);                        // target of an element-order scatter_add
+        CHECK(same(host(t), hx));
+        { F dead = zero<F>(N); }
+    }
+
     // --- fma over a gathered pair (kind 2): bucket-ordered consumers, and every way of asking for element order ---
     {
-        const size_t K = 1024;
+        const size_t K = 4096;
         F A = input(K, 1.f), C = input(K, 0.5f);
         U gi = (arange<U>(N) * U(2654435761u)) & U((uint32_t) K - 1u);
         std::vector<float> hA = host(A), hC = host(C);
@@ -177,8 +191,19 @@ static void directed() {
         F ga = zero<F>(K), gc = zero<F>(K);
         F *targets[2] = { &gc, &ga };
         const F *values[2] = { &cu, &cu }, *weights[2] = { nullptr, &x };
+        long fr0 = g_fresh_targets;
+        CHECK(ga.zeroed_() && gc.zeroed_());
         F::scatter_add_multi_(2, targets, values, weights, gi, M(true));
         CHECK(g_bucketed_scatters == s0 + 1 && g_fused_calls == f0 && cu.mapped_());
+        CHECK(g_fresh_targets == fr0 + 2 && !ga.zeroed_());            // both gradient buffers were written, not memset + added to
+        {   // a zeros target that somebody else also holds is an ordinary (memset) target
+            F shared = zero<F>(K), alias = shared, other2 = zero<F>(K);
+            F *t2[2] = { &other2, &shared };
+            long fr1 = g_fresh_targets;
+            F::scatter_add_multi_(2, t2, values, weights, gi, M(true));
+            CHECK(g_fresh_targets == fr1 + 1 && alias.coeff(0) == 0.f);
+            CHECK(same(host(shared), host(ga)) && same(host(other2), host(gc)));
+        }
         std::vector<float> ea(K, 0.f), ec(K, 0.f);
         for (size_t i = 0; i < N; ++i) {
             float c = std::cos(hu[i]);

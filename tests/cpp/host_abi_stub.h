@@ -271,10 +271,15 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int k
     if (keep && !b->u) b->u = u; else free(u);
     return EK_OK;
 }
+static long g_fresh_targets = 0;
 int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
-                                const uint64_t *imm, const int *weighted) {
+                                const uint64_t *imm, const int *weighted, const int *fresh) {
     ++g_bucketed_scatters;
-    for (int c = 0; c < count; ++c)
+    for (int c = 0; c < count; ++c) {
+        if (fresh && fresh[c]) {           // the table holds no data yet (malloc'd garbage here): its sums are written
+            ++g_fresh_targets;
+            for (size_t k = 0; k < b->table_size; ++k) ((float *) bases[c])[k] = 0.f;
+        }
         for (size_t i = 0; i < b->n; ++i) {
             float v;
             if (from_u[c]) v = unary_f(ops ? ops[c] : (int) EK_COPY, b->u ? b->u[i] : bucketed_u(b, i));
@@ -282,6 +287,7 @@ int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *base
             if (weighted[c]) v = (b->x[i] == 0.f || v == 0.f) ? 0.f : b->x[i] * v;
             ((float *) bases[c])[b->idx[i]] += v;
         }
+    }
     return EK_OK;
 }
 int ek_hip_bucketed_destroy(ek_hip_bucketed *b) {

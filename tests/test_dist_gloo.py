@@ -189,3 +189,87 @@ def test_library_level_sharding_cfg3b_and_cfg4(tmp_path):
     assert P.lib.orc_cfg4(p_(gx), p_(gy), p_(perm), p_(mask), ctypes.c_size_t(n4), p_(img), ctypes.byref(hc)) == 0
     assert int(z["hits"][0]) == hc.value and z["hmax"][0] == img.max() and z["hmin"][0] == img.min()
     assert bool(z["anyhit"][0]) and not bool(z["allhit"][0])
+
+
+WORKER_SCATTERED = r'''
+import os, sys
+import numpy as np
+sys.path.insert(0, os.environ["EK_ROOT"]); sys.path.insert(0, os.path.join(os.environ["EK_ROOT"], "tests"))
+import torch, torch.distributed as dist
+from enoki_amd import dist as ekd
+import oracle_lib
+from conftest import hash_u32, uniform_pm1
+
+P = oracle_lib.port()
+
+
+class HostArrays:
+    hsum = staticmethod(lambda x: np.array([P.reduce("hsum", x)], x.dtype))
+    detach = staticmethod(lambda x: x)
+    gradient = staticmethod(lambda t: t.grad)
+
+
+class Table:
+    def __init__(self, values): self.values, self.grad = values, None
+
+
+rank, local_rank, world = ekd.init("gloo")
+N, K = 200003, int(os.environ["EK_K"])                     # K = 4099: not a multiple of the world size (ragged last slice)
+sh = ekd.Sharded(HostArrays, N, device="cpu")
+x = np.ascontiguousarray(uniform_pm1(N, 2)[sh.begin:sh.end])
+idx = np.ascontiguousarray((hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)[sh.begin:sh.end])
+A, B = Table(uniform_pm1(K, 6)), Table(uniform_pm1(K, 7))
+yl, A.grad, B.grad, _ = P.cfg3b(A.values, B.values, x, idx)
+y = sh.reduce(np.array([yl], np.float32))
+gA, gB = sh.gradient(A, scattered=True), sh.gradient(B, scattered=True)
+before = sh.exchange.collectives
+plan = sh.flush()
+# the loss rides on a 1-element all-reduce, BOTH tables on one reduce-scatter
+assert sh.exchange.collectives - before == 2, sh.exchange.collectives - before
+c = -(-K // world)
+assert gA.owned == (min(rank * c, K), min((rank + 1) * c, K)) and gA.tensor().numel() == gA.owned[1] - gA.owned[0]
+first = (gA.tensor().numpy().copy(), gB.tensor().numpy().copy())
+plan.run()                                                 # replay on the same sources (step-graph path)
+assert np.array_equal(gA.tensor().numpy(), first[0]) and np.array_equal(gB.tensor().numpy(), first[1])
+fullA = sh.gather_scattered(gA, K).numpy()
+fullB = sh.gather_scattered(gB, K).numpy()
+assert np.array_equal(fullA[gA.owned[0]:gA.owned[1]], first[0])
+ekd.barrier()
+np.savez(os.environ["EK_OUT"] + f".{rank}.npz", y=y.tensor().numpy(), gA=first[0], gB=first[1], lo=np.array([gA.owned[0]]),
+         fullA=fullA, fullB=fullB)
+dist.destroy_process_group()
+'''
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("world,K", [(2, 4096), (4, 4096), (4, 4099), (3, 4099)])
+def test_reduce_scattered_table_gradients_equal_the_unsharded_oracle(tmp_path, world, K):
+    """gradient(table, scattered=True): rank r ends up with bins [r c, (r + 1) c) of the global gradient (c = ceil(K / P)),
+    one reduce-scatter for both tables; the slices of all ranks concatenate to the unsharded result, and the all-gather of
+    gather_scattered() reproduces it on every rank"""
+    out = tmp_path / "out"
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER_SCATTERED)
+    env = dict(os.environ, EK_ROOT=ROOT, EK_OUT=str(out), EK_K=str(K), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29550 + world + K % 7))
+    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world)))
+             for r in range(world)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import cfg3b_truth, hash_u32, uniform_pm1
+    N = 200003
+    x = uniform_pm1(N, 2); idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)
+    t = cfg3b_truth(uniform_pm1(K, 6), uniform_pm1(K, 7), x, idx)
+    gA, gB = np.zeros(K, np.float32), np.zeros(K, np.float32)
+    covered = 0
+    for r in range(world):
+        z = np.load(str(out) + f".{r}.npz")
+        lo = int(z["lo"][0])
+        gA[lo:lo + z["gA"].size] = z["gA"]; gB[lo:lo + z["gB"].size] = z["gB"]
+        covered += z["gA"].size
+        assert abs(float(z["y"][0]) - t["y"]) <= t["y_bound_reference"]
+        assert np.all(np.abs(z["fullA"] - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(z["fullB"] - t["gB"]) <= t["gB_bound"])
+    assert covered == K
+    assert np.all(np.abs(gA - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(gB - t["gB"]) <= t["gB_bound"])

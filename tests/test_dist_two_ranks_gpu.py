@@ -36,9 +36,29 @@ def test_two_ranks_match_one(workload):
     n = 1 << 22
     one = run_bench(workload, n, 1, 29611)
     two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613)
-    assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2 and two["config"]["collectives_per_step"] == 1
-    assert abs(one["result_y"] - two["result_y"]) <= n * 2.0 ** -23 * max(abs(one["result_y"]), 1.0) * 4
+    # cfg3b: the loss on a 1-element all-reduce + ONE reduce-scatter for both gradient tables; cfg3a: the loss only
+    assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2
+    assert two["config"]["collectives_per_step"] == (2 if workload == "cfg3b" else 1)
+    truth, bound = truth_y(workload, n)
+    assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound, (one["result_y"], two["result_y"], truth, bound)
     assert two["value"] > 0 and two["scaling"] == "strong"
+
+
+def truth_y(workload, n):
+    """float64 value of the bench's loss on its synthetic inputs (seeds of SURVEY 8d) and 5 sigma of independent f32 roundings
+    for summation orders of our depth (conftest.stat_sum_bound; two shards of half the depth are covered by it)"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import hash_u32, hsum_depth, stat_sum_bound, uniform_pm1
+    x = uniform_pm1(n, 2).astype(np.float64)
+    if workload == "cfg3b":
+        K = 1 << 20
+        idx = (hash_u32(np.arange(n, dtype=np.uint64), 4) % np.uint32(K)).astype(np.int64)
+        u = uniform_pm1(K, 6).astype(np.float64)[idx] * x + uniform_pm1(K, 7).astype(np.float64)[idx]
+    else:
+        u = uniform_pm1(n, 1).astype(np.float64) * x + uniform_pm1(n, 3).astype(np.float64)
+    s = np.sin(u)
+    return float(s.sum()), stat_sum_bound(s, hsum_depth(n) + 64)
 
 
 def _gpu_count():
@@ -61,5 +81,6 @@ def test_two_gpus_rccl():
     out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     two = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 1
-    assert abs(one["result_y"] - two["result_y"]) <= n * 2.0 ** -23 * max(abs(one["result_y"]), 1.0) * 4
+    assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 2
+    truth, bound = truth_y("cfg3b", n)
+    assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound
