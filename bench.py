@@ -221,9 +221,9 @@ class Bench:
                     if reuse and out.get("plan") is not None:
                         out["plan"].run()
                     else:
-                        # the loss on a 1-element all-reduce; the table gradients REDUCE-SCATTERED: rank r receives bins
-                        # [r K / P, (r + 1) K / P) of both tables in one collective (half the bytes of an all-reduce, and
-                        # nothing K-sized is replicated after the exchange); --allreduce-grads: every rank gets all of it
+                        # the table gradients REDUCE-SCATTERED: rank r receives bins [r K / P, (r + 1) K / P) of both tables in
+                        # one collective (half the bytes of an all-reduce, nothing K-sized is replicated after the exchange)
+                        # and the loss rides in an extra column of it; --allreduce-grads: every rank gets all of it
                         scat = not self.args.allreduce_grads
                         out["reduced"] = [self.sh.reduce(out["y"]), self.sh.reduce(out["gA"], scattered=scat),
                                           self.sh.reduce(out["gB"], scattered=scat)]
@@ -403,7 +403,7 @@ class Bench:
         elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
         ms_per_step = elapsed / steps * 1e3
         units = N_RAYS_PER_GPU * self.world if workload.startswith("cfg4") else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
-        gelem_s = units / (ms_per_step * 1e-3) / 1e9
+        graph_ms = ms_per_step if graph is not None else None
 
         eager_ms = ms_per_step
         if graph is not None:
@@ -420,6 +420,12 @@ class Bench:
                 packer.wait_all()
             torch.cuda.synchronize(); ekd.barrier()
             eager_ms = ekd.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
+            # Both are K timed steps of the same kernels under the same protocol; a hipGraph replay saves the host work but
+            # pays its own launch cost, and which of the two wins depends on the step length and the box.  `value` is the
+            # faster one; both times are in the line.
+            if eager_ms < ms_per_step:
+                ms_per_step, replay = eager_ms, "eager (python-driven steps; the hipGraph replay of the same step was slower: see graph_ms_per_step)"
+        gelem_s = units / (ms_per_step * 1e-3) / 1e9
         # per-kernel timing of the same step (run eagerly): one HIP event per launch on the library stream
         ek.hip_profile_begin()
         for _ in range(profile_steps):
@@ -460,7 +466,8 @@ class Bench:
             y_val = float(out["reduced"][0].item())
         outputs = {k: out[k].numpy() for k in ("gA", "gB", "ga", "gb") if k in out} if self.world == 1 and workload == self.args.workload else {}
         outputs["y"] = y_val
-        return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "eager_ms_per_step": round(eager_ms, 4), "result_y": y_val,
+        return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "eager_ms_per_step": round(eager_ms, 4),
+                "graph_ms_per_step": round(graph_ms, 4) if graph_ms is not None else None, "result_y": y_val,
                 "roofline": roofline, "collectives_per_step": coll_per_step,
                 "outputs": outputs, "replay": replay}
 
@@ -668,7 +675,8 @@ def main():
         line = {
             "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "eager_ms_per_step": main_res["eager_ms_per_step"], "higher_is_better": True,
+            "ms_per_step": main_res["ms_per_step"], "eager_ms_per_step": main_res["eager_ms_per_step"],
+            "graph_ms_per_step": main_res["graph_ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}",
@@ -678,7 +686,7 @@ def main():
                        "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"],
                        "gradient_exchange": (None if not b.ekd.active() or args.workload != "cfg3b" else
                                              "all-reduce (every rank holds all K bins)" if args.allreduce_grads else
-                                             "reduce-scatter (rank r holds bins [r K / P, (r + 1) K / P) of both tables) + 1-element all-reduce for the loss"),
+                                             "ONE reduce-scatter per step: rank r receives bins [r K / P, (r + 1) K / P) of both tables, the loss rides in an extra column"),
                        "step_replay": main_res["replay"]},
             "result_y": main_res["result_y"], "parity_checked": bool(parity and parity["parity_checked"]), "parity": parity,
             "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,

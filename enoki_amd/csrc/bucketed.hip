@@ -643,7 +643,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
                        (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,                   \
                        (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, \
                        map_op, partner ? 1 : 0)
-    EK_FWD(2);
+    EK_FWD(2);          // two 4-element vectors per lane and step (one: 6 % slower, four: 13 % slower, same box)
 #undef EK_FWD
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void k_reverse(T *__restrict__ out, const T *_
 
 // ---- concat ------------------------------------------------------------------------------------
 constexpr int kConcatMax = 8;
-struct ConcatArgs { const void *src[kConcatMax]; size_t end[kConcatMax]; };
+struct ConcatArgs { const void *src[kConcatMax]; size_t end[kConcatMax]; unsigned bcast = 0; /* bit k: source k is ONE entry copied to every row (k_concat_rows) */ };
 
 // out[r][end[k-1] + j] = src_k[r * c_k + j]: every source seen as [rows, c_k], concatenated along the columns (a.end = column
 // boundaries within one output row of `row` entries)
@@ -51,10 +51,11 @@ template <typename T> __global__ __launch_bounds__(256) void k_concat_rows(T *__
     const size_t r = i / row, col = i - r * row;
     const void *src = a.src[0];
     size_t begin = 0, width = a.end[0];
+    unsigned bc = a.bcast & 1u;
 #pragma unroll
     for (int k = 0; k < kConcatMax - 1; ++k)
-        if (col >= a.end[k]) { src = a.src[k + 1]; begin = a.end[k]; width = a.end[k + 1] - a.end[k]; }
-    out[i] = static_cast<const T *>(src)[r * width + (col - begin)];
+        if (col >= a.end[k]) { src = a.src[k + 1]; begin = a.end[k]; width = a.end[k + 1] - a.end[k]; bc = (a.bcast >> (k + 1)) & 1u; }
+    out[i] = static_cast<const T *>(src)[bc ? 0 : r * width + (col - begin)];
 }
 
 template <typename T> __global__ __launch_bounds__(256) void k_concat(T *__restrict__ out, ConcatArgs a, size_t total) {
@@ -446,9 +447,11 @@ int ek_hip_concat_rows(int type, void *out, size_t rows, int count, const void *
         a.src[i] = nullptr;
         a.end[i] = row;
         if (i < count) {
-            if (!srcs[i] || sizes[i] % rows) return fail(EK_ERR_INVALID, "ek_hip_concat_rows(): array %d: null or not a multiple of %zu rows", i, rows);
+            if (!srcs[i] || (sizes[i] != 1 && sizes[i] % rows))
+                return fail(EK_ERR_INVALID, "ek_hip_concat_rows(): array %d: null, or neither one entry nor a multiple of %zu rows", i, rows);
             a.src[i] = srcs[i];
-            row += sizes[i] / rows;
+            if (sizes[i] == 1) { a.bcast |= 1u << i; row += 1; }      // one entry: the same value in every row
+            else row += sizes[i] / rows;
             a.end[i] = row;
         }
     }

@@ -165,6 +165,7 @@ class Handle:
     """A contribution to an Exchange: after flush() `tensor()` is the REDUCED value (a view of the staging buffer, valid
     until the buffer rotates back: `depth` flushes later)"""
 
+    rider = False            # a 1-element sum that travels in an extra column of a reduce-scatter (Plan)
     scattered = False        # reduce-scattered: tensor() is the slice of the reduction that this rank owns
     owned = None             # (begin, end) of that slice in the full table
 
@@ -268,20 +269,33 @@ class Plan:
         self.groups, self.scattered = {}, {}
         for h, t, op in items:
             (self.scattered if h.scattered else self.groups).setdefault((t.dtype, op), []).append((h, t))
+        # 1-element sums (the loss) RIDE on the reduce-scatter of their (dtype, "sum") group instead of paying a collective of
+        # their own: the value goes into one extra column of EVERY row, so every rank receives sum_r(value_r) there
+        for key, parts in self.scattered.items():
+            if key[1] != "sum" or key not in self.groups:
+                continue
+            riders = [(h, t) for h, t in self.groups[key] if t.numel() == 1]
+            if riders and len(parts) + len(riders) <= 8:
+                for h, _ in riders:
+                    h.rider = True
+                parts.extend(riders)
+                self.groups[key] = [(h, t) for h, t in self.groups[key] if t.numel() != 1]
+                if not self.groups[key]:
+                    del self.groups[key]
 
     def _run_scattered(self):
         """ONE reduce-scatter per (dtype, reduction): the staging buffer is laid out rank-major, row r = the chunks that
         rank r owns of every part ([P, sum of chunks]); padded where K is not a multiple of P"""
         ex, P, r = self.ex, _world(), _rank()
         for (dtype, op), parts in self.scattered.items():
-            chunks = [-(-t.numel() // P) for _, t in parts]
+            chunks = [1 if h.rider else -(-t.numel() // P) for h, t in parts]
             row = sum(chunks)
             entry, i = ex._buffer((dtype, op, "scatter"), P * row + row, dtype)
             flat = entry["bufs"][i]
             send, recv = flat[:P * row].view(P, row), flat[P * row:]
             fast = False
             if flat.is_cuda and dtype == torch.float32 and len(parts) <= 8 and \
-                    all(t.is_cuda and t.is_contiguous() and t.numel() == P * c for (_, t), c in zip(parts, chunks)):
+                    all(t.is_cuda and t.is_contiguous() and (h.rider or t.numel() == P * c) for (h, t), c in zip(parts, chunks)):
                 from enoki_amd import hip as _ek
                 if _ek.hip_stream() == torch.cuda.current_stream().cuda_stream:
                     _ek.hip_concat_rows_f32(flat.data_ptr(), P, [(t.data_ptr(), t.numel()) for _, t in parts])   # one launch
@@ -289,6 +303,12 @@ class Plan:
             offset = 0
             for (h, t), c in zip(parts, chunks):
                 k = t.numel()
+                if h.rider:
+                    if not fast:
+                        send[:, offset] = t[0]
+                    h._slot = recv[offset:offset + 1]
+                    offset += 1
+                    continue
                 if fast:
                     pass
                 elif k == P * c:

@@ -185,7 +185,9 @@ EK_API int ek_hip_reverse(int type, void *out, const void *in, size_t n);
 EK_API int ek_hip_concat(int type, void *out, int count, const void *const *srcs, const size_t *sizes);
 /* The staging step of a REDUCE-SCATTER over `rows` ranks: every source (sizes[k] a multiple of `rows`) is seen as [rows, c_k]
  * and the sources are concatenated along the columns -- out[r] = srcs[0][r] | srcs[1][r] | ..., i.e. row r holds the chunks of
- * all tables that rank r will own -- in ONE launch (count <= 8, 4- and 8-byte types). */
+ * all tables that rank r will own -- in ONE launch (count <= 8, 4- and 8-byte types).  A source of ONE entry is copied into
+ * every row: a scalar partial sum (the loss) rides on the same reduce-scatter -- every rank then receives sum_r(loss_r) in
+ * that column -- instead of on a collective of its own. */
 EK_API int ek_hip_concat_rows(int type, void *out, size_t rows, int count, const void *const *srcs, const size_t *sizes);
 
 /* ---------------------------------------------------------------------------------------------

@@ -36,9 +36,9 @@ def test_two_ranks_match_one(workload):
     n = 1 << 22
     one = run_bench(workload, n, 1, 29611)
     two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613)
-    # cfg3b: the loss on a 1-element all-reduce + ONE reduce-scatter for both gradient tables; cfg3a: the loss only
+    # cfg3b: ONE reduce-scatter for both gradient tables with the loss riding in an extra column; cfg3a: the loss only
     assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2
-    assert two["config"]["collectives_per_step"] == (2 if workload == "cfg3b" else 1)
+    assert two["config"]["collectives_per_step"] == 1
     truth, bound = truth_y(workload, n)
     assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound, (one["result_y"], two["result_y"], truth, bound)
     assert two["value"] > 0 and two["scaling"] == "strong"
@@ -81,6 +81,6 @@ def test_two_gpus_rccl():
     out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     two = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
-    assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 2
+    assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 1
     truth, bound = truth_y("cfg3b", n)
     assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound
