@@ -49,6 +49,10 @@ DESCRIPTION = {
     "cfg4_packed": "cfg4's fused kernel over a pixel grid stored as packed {x, y} records: ONE 8-byte lookup per ray "
                    "instead of two 4-byte ones (examples/sphere_fused.cpp sphere_fused_packed_device), bit-identical image",
     "cfg4_unfused": "the same program on Array<HIPArray<float>,3> op by op (~40 eager kernels), bit-identical image",
+    "cfg4_bucketed": "cfg4 executed per PIXEL instead of per ray (enoki::vectorize_through, examples/sphere_fused.cpp "
+                     "sphere_through_device): gather and scatter share the permutation and the kernels depend on the gathered pixel only, "
+                     "so the rays are partitioned by pixel bucket once and every bucket streams its grid slice in and its image slice "
+                     "out in order; bit-identical image and hit count",
 }
 N_RAYS_PER_GPU = 1 << 25
 N_PATHS_PER_GPU = 1 << 24
@@ -68,7 +72,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5"])
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5"])
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
@@ -264,7 +268,7 @@ class Bench:
                     out["reduced"] = [self.sh.reduce(out["y"]), self.sh.reduce(g)]
                     self.sh.flush()
                 out["grad"] = g
-        elif workload in ("cfg4", "cfg4_packed", "cfg4_unfused"):
+        elif workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed"):
             torch = self.torch
             nr = N_RAYS_PER_GPU                                    # weak: every rank traces its own 32 Mi rays
             res = int(round(nr ** 0.5)); res -= res % 2
@@ -292,7 +296,11 @@ class Bench:
                 # (examples/sphere_fused.cpp); 18 B per ray instead of ~318
                 image = F.full(-1.0, nr)
                 P = ctypes.c_void_p
-                if grid_xy is not None:
+                if workload == "cfg4_bucketed":
+                    # per PIXEL instead of per ray: rays grouped by pixel bucket once, grid / image slices streamed in order
+                    rc = fused_lib.sphere_through_device(P(grid.x.data_ptr()), P(grid.y.data_ptr()), P(perm.data_ptr()), P(mask.data_ptr()),
+                                                         ctypes.c_size_t(nr), P(image.data_ptr()), ctypes.byref(hits_c))
+                elif grid_xy is not None:
                     rc = fused_lib.sphere_fused_packed_device(P(grid_xy.data_ptr()), P(perm.data_ptr()), P(mask.data_ptr()),
                                                               ctypes.c_size_t(nr), P(image.data_ptr()), ctypes.byref(hits_c))
                 else:
@@ -497,7 +505,7 @@ def cpu_baseline(workload, N):
         def fn():
             ref_out["y"], ref_out["ga"], ref_out["gb"], t = chk.cfg3a(a, x, b)
             return t
-    elif workload in ("cfg4", "cfg4_packed", "cfg4_unfused"):
+    elif workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed"):
         import ctypes
         n = 1 << 22                                   # bounded sample: 4 Mi rays of the same program
         res = 2048
@@ -653,7 +661,7 @@ def main():
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
     if b.world == 1 and not args.no_also:
-        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5"):
+        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5"):
             if w != args.workload:
                 r = b.run(w, max(5, args.steps // 2), 2, 3)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
@@ -677,11 +685,11 @@ def main():
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "eager_ms_per_step": main_res["eager_ms_per_step"],
             "graph_ms_per_step": main_res["graph_ms_per_step"], "higher_is_better": True,
-            "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg5") else "strong", "vs_baseline": None,
+            "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}",
                        "elements_total": (N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU) * b.world
-                       if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg5") else b.N,
+                       if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5") else b.N,
                        "elements_per_gpu": N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU if args.workload == "cfg5" else b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
                        "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"],
                        "gradient_exchange": (None if not b.ekd.active() or args.workload != "cfg3b" else

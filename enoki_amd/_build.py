@@ -157,7 +157,7 @@ def build_checkers(force=False, verbose=True):
     oracle = os.path.join(ROOT, "oracle")
     _run(["make", "-C", oracle, "port"])
     if os.path.isdir("/root/reference"):
-        _run(["make", "-C", oracle, "ref", "ref512"])
+        _run(["make", "-C", oracle, "ref", "ref512", "refscalar"])
     tcpp = os.path.join(ROOT, "tests", "cpp")
     inc = f"-I{os.path.join(ROOT, 'include')}"
     host = os.path.join(tcpp, "libtape_host.so")

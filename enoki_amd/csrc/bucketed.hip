@@ -741,11 +741,59 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
     return EK_OK;
 }
 
+// ---- partition of an index array alone (ek_hip_index_partition_*) ------------------------------------------------------
+struct IndexPartition {
+    ek_hip_index_partition_info info{};
+    void *meta = nullptr, *local = nullptr;
+    ~IndexPartition() {
+        for (void *p : { meta, local })
+            if (p) ek_hip_free(p);
+    }
+};
+
+template <typename I, int Shift>
+static int index_partition_run(IndexPartition *ip, const I *index, const Arg<uint8_t> &mask, size_t n, int n_buckets) {
+    RoctxRange range("enoki-hip: index partition");
+    Context &c = ctx();
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+    const int vec_ok = aligned16(index) && arg_aligned(mask);
+    int rep_shift = 0;
+    while ((n_buckets << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
+    const size_t count_entries = (size_t) n_buckets * blocks;
+    if (int rc = ek_hip_malloc((count_entries + 2 * kMaxBuckets + 2) * sizeof(uint32_t), &ip->meta)) return rc;
+    if (int rc = ek_hip_malloc((n ? n : 1) * sizeof(uint32_t), &ip->local)) return rc;
+    uint32_t *counts = (uint32_t *) ip->meta, *row_total = counts + count_entries, *bucket_base = row_total + kMaxBuckets;
+    hipLaunchKernelGGL((k_bin_count<I, Shift>), dim3(blocks), dim3(kThreads), 0, c.stream, counts, index, mask, n, chunk, n_buckets,
+                       rep_shift, vec_ok);
+    EK_LAUNCH_CHECK("index_partition_count", n, n * sizeof(I) + arg_bytes(mask, n));
+    hipLaunchKernelGGL(k_bin_scan_rows, dim3(n_buckets), dim3(1024), 0, c.stream, counts, row_total, blocks);
+    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr,
+                       (const uint32_t *) row_total, n_buckets, 0u);
+    EK_LAUNCH_CHECK("index_partition_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
+    BinStreams<uint32_t, 1> st{};
+    st.value[0] = Arg<uint32_t>{ nullptr, 0u, 0u };
+    st.weight[0] = Arg<uint32_t>{ nullptr, 1u, 0u };
+    st.pair_val[0] = nullptr;
+    st.value_op[0] = EK_COPY;
+    hipLaunchKernelGGL((k_bin_partition<uint32_t, I, Shift, uint32_t, 1, false, true>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                       (uint32_t *) ip->local, st, (const uint32_t *) counts, (const uint32_t *) bucket_base, index, mask, n, chunk,
+                       n_buckets, 0, vec_ok);
+    EK_LAUNCH_CHECK("index_partition", n, n * (sizeof(I) + sizeof(uint32_t)) + arg_bytes(mask, n));
+    ip->info.bucket_base = bucket_base;
+    ip->info.local = (const uint32_t *) ip->local;
+    return EK_OK;
+}
+
 } // namespace ek
 
 using namespace ek;
 
 struct ek_hip_bucketed : ek::Bucketed { };
+struct ek_hip_index_partition : ek::IndexPartition { };
 
 extern "C" {
 
@@ -805,6 +853,51 @@ int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *base
 
 int ek_hip_bucketed_destroy(ek_hip_bucketed *b) {
     delete b;
+    return EK_OK;
+}
+
+int ek_hip_index_partition_create(int index_type, const void *index, const ek_operand *mask, size_t n, size_t range,
+                                  ek_hip_index_partition **out) {
+    if (int rc = ensure_init()) return rc;
+    if (!out || !index || !mask) return fail(EK_ERR_INVALID, "ek_hip_index_partition_create(): null pointer");
+    *out = nullptr;
+    if (index_type != EK_U32 && index_type != EK_I32)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_index_partition_create(): 32-bit index arrays only");
+    if (n == 0 || n >= ((size_t) 1 << 32) || range == 0 || range > ((size_t) kMaxBuckets << 19))
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_index_partition_create(): %zu indices into %zu entries is out of range", n, range);
+    Arg<uint8_t> m;
+    if (int rc = make_arg<uint8_t>(mask, n, m, "ek_hip_index_partition_create")) return rc;
+    // the smallest bucket size of {4 Ki, 16 Ki, 128 Ki, 512 Ki} entries that covers the range with <= 256 buckets
+    static const int shifts[] = { 12, 14, 17, 19 };
+    int shift = 19;
+    for (int sft : shifts)
+        if (((range + ((size_t) 1 << sft) - 1) >> sft) <= (size_t) kMaxBuckets) { shift = sft; break; }
+    ek_hip_index_partition *ip = new ek_hip_index_partition();
+    ip->info.shift = shift;
+    ip->info.n_buckets = (int) ((range + ((size_t) 1 << shift) - 1) >> shift);
+    ip->info.n = n;
+    ip->info.range = range;
+    int rc;
+    const uint32_t *idx = (const uint32_t *) index;          // valid int32 indices are non-negative: same bits as uint32
+    switch (shift) {
+        case 12: rc = index_partition_run<uint32_t, 12>(ip, idx, m, n, ip->info.n_buckets); break;
+        case 14: rc = index_partition_run<uint32_t, 14>(ip, idx, m, n, ip->info.n_buckets); break;
+        case 17: rc = index_partition_run<uint32_t, 17>(ip, idx, m, n, ip->info.n_buckets); break;
+        default: rc = index_partition_run<uint32_t, 19>(ip, idx, m, n, ip->info.n_buckets); break;
+    }
+    if (rc != EK_OK) { delete ip; return rc; }
+    *out = ip;
+    return EK_OK;
+}
+
+int ek_hip_index_partition_get(const ek_hip_index_partition *p, ek_hip_index_partition_info *info) {
+    if (!p || !info) return fail(EK_ERR_INVALID, "ek_hip_index_partition_get(): null pointer");
+    *info = p->info;
+    return EK_OK;
+}
+
+int ek_hip_index_partition_destroy(ek_hip_index_partition *p) {
+    delete p;
     return EK_OK;
 }
 

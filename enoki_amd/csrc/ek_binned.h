@@ -214,7 +214,8 @@ static __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__res
 }
 
 // ---- 3. partition ----------------------------------------------------------------------------------
-template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t, int C = 1, bool Mapped = false>
+// NoValues: partition of the INDICES alone (ek_hip_index_partition_*): no value stream is read, staged or written.
+template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t, int C = 1, bool Mapped = false, bool NoValues = false>
 __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_bin_partition(OutIdx *__restrict__ pair_idx, BinStreams<T, C> st,
                                                             const uint32_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ bucket_base,
@@ -225,7 +226,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
     __shared__ uint32_t tile_off[kMaxBuckets];     // exclusive prefix of tile_hist
     const uint32_t rep = threadIdx.x & ((1u << rep_shift) - 1u);
     __shared__ uint32_t stage_idx[kTile];
-    __shared__ T stage_val[kTile];
+    __shared__ T stage_val[NoValues ? 1 : kTile];
 
     for (int b = threadIdx.x; b < kMaxBuckets; b += kThreads) {
         cursor[b] = b < n_buckets ? bucket_base[b] + offsets[(size_t) b * gridDim.x + blockIdx.x] : 0u;
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
 #pragma unroll
             for (int k = 0; k < kPerThread; ++k) on |= (flag[k] ? 1u : 0u) << k;
         }
-        load_stream(full, 0, base, val);
+        if constexpr (!NoValues) load_stream(full, 0, base, val);
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
             rank[k] = ((on >> k) & 1u) ? atomicAdd(&tile_hist[((ix[k] >> Shift) << rep_shift) | rep], 1u) : 0u;
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
                 uint32_t p = tile_off[((ix[k] >> Shift) << rep_shift) | rep] + rank[k];
                 rank[k] = p;
                 stage_idx[p] = ix[k];
-                stage_val[p] = val[k];
+                if constexpr (!NoValues) stage_val[p] = val[k];
             }
         }
         __syncthreads();
@@ -322,7 +323,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
             uint32_t key = stage_idx[j], b = key >> Shift;
             uint32_t g = cursor[b] + (j - tile_off[b << rep_shift]);
             pair_idx[g] = (OutIdx) (key & ((1u << Shift) - 1u));   // the bucket is implied by the position
-            st.pair_val[0][g] = stage_val[j];
+            if constexpr (!NoValues) st.pair_val[0][g] = stage_val[j];
         }
         // further streams reuse the sorted positions: restage the values, same output addresses
 #pragma unroll

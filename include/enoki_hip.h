@@ -260,6 +260,25 @@ EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op,
 EK_API int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                        const uint64_t *imm_bits, const int *weighted, const int *fresh);
 EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
+/* Partition of an INDEX array by bucket of the range it points into: the active entries (mask) of `index` are grouped by
+ * bucket = index >> shift and stored as bucket-local indices (index & ((1 << shift) - 1)), bucket b at local[bucket_base[b] ..
+ * bucket_base[b + 1]).  shift is the smallest of {12, 14, 17, 19} with <= 256 buckets for `range` entries (range <= 128 Mi).
+ * This is what a program needs whose gather and scatter go through the SAME index array and whose body depends on the
+ * gathered values only (tests/sphere.cpp:58-83 behind a pixel permutation): it can then run per TARGET entry, bucket by
+ * bucket, with coalesced reads of the source slice and coalesced writes of the target slice instead of two random accesses
+ * per element (enoki/vectorize_indexed.h builds that kernel from a user functor).  count + scan + partition: 5 + 9 B per
+ * entry with a mask array.  The pointers in the info struct are DEVICE pointers owned by the object. */
+typedef struct ek_hip_index_partition ek_hip_index_partition;
+typedef struct {
+    int shift, n_buckets;
+    size_t n, range;
+    const uint32_t *bucket_base;      /* n_buckets + 1 entries; bucket_base[n_buckets] = number of active entries */
+    const uint32_t *local;            /* bucket-local indices in bucket order */
+} ek_hip_index_partition_info;
+EK_API int ek_hip_index_partition_create(int index_type, const void *index, const ek_operand *mask, size_t n, size_t range,
+                                         ek_hip_index_partition **out);
+EK_API int ek_hip_index_partition_get(const ek_hip_index_partition *p, ek_hip_index_partition_info *info);
+EK_API int ek_hip_index_partition_destroy(ek_hip_index_partition *p);
 EK_API int ek_hip_scatter(int type, int index_type, void *base, const ek_operand *value,
                           const ek_operand *index, const ek_operand *mask, size_t n);
 /* mode 0: fastest -- LDS-binned accumulation for large inputs (needs `base_size`), hardware atomics otherwise;

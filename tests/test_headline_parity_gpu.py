@@ -110,3 +110,6 @@ def test_cfg4_headline_image_bit_exact():
     # ... and over packed {x, y} records (one 8-byte lookup per ray)
     fi, fh = run(fused.sphere_fused_packed, *args)
     assert fh == ph and np.array_equal(fi.view(np.uint32), pi.view(np.uint32))
+    # ... and executed per pixel, bucket by bucket (enoki::vectorize_through: 256 buckets of 128 Ki pixels at this size)
+    fi, fh = run(fused.sphere_through, *args)
+    assert fh == ph and np.array_equal(fi.view(np.uint32), pi.view(np.uint32))

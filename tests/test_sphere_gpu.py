@@ -68,10 +68,12 @@ def test_hip_cfg4_bit_exact(res):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("res", [8, 64, 257, 1024])
-@pytest.mark.parametrize("entry", ["sphere_fused", "sphere_fused_packed"])
+@pytest.mark.parametrize("entry", ["sphere_fused", "sphere_fused_packed", "sphere_through"])
 def test_hip_cfg4_fused_bit_exact(res, entry):
     """the same program as ONE kernel through enoki::vectorize() (examples/sphere_fused.cpp): bit-identical image, with
-    the pixel grid as two planes or as packed {x, y} records (ONE 8-byte lookup per ray, array.h gather_packed)"""
+    the pixel grid as two planes or as packed {x, y} records (ONE 8-byte lookup per ray, array.h gather_packed); and
+    executed per PIXEL, bucket by bucket (enoki::vectorize_through, enoki/vectorize_indexed.h: rays grouped by pixel bucket
+    once, grid slices read and image slices written in order)"""
     lib = ctypes.CDLL(os.path.join(HERE, "..", "examples", "libsphere_fused.so"))
     args = scene(res, seed=res + 1)
     gi, gh = run(getattr(lib, entry), *args)
@@ -111,3 +113,22 @@ def test_fused_math_matches_kernels(is_double):
     for n in (1, 1000, (1 << 20) + 3):
         bad = lib.vectorize_math_check(is_double, ctypes.c_size_t(n), report, ctypes.c_size_t(len(report)))
         assert bad == 0, (n, report.value.decode())
+
+
+@pytest.mark.gpu
+def test_vectorize_through_with_duplicate_and_sparse_indices():
+    """vectorize_through() does not need a permutation: an index array with duplicates and holes gives the image and the
+    count(hit & mask) of the element-order program (every duplicate computes the same value; the count is per ELEMENT)"""
+    lib = ctypes.CDLL(os.path.join(HERE, "..", "examples", "libsphere_fused.so"))
+    for res, seed in ((64, 3), (300, 4), (1200, 5)):
+        gx, gy, perm, mask = scene(res, seed=seed)
+        n = perm.size
+        rng = np.random.default_rng(seed)
+        idx = rng.integers(0, n, n).astype(np.uint32)              # duplicates, and pixels nobody points at
+        idx[: n // 7] = idx[n // 7: 2 * (n // 7)][: n // 7]
+        gi, gh = run(lib.sphere_through, gx, gy, idx, mask)
+        fi, fh = run(lib.sphere_fused, gx, gy, idx, mask)          # the per-element fused kernel: same semantics
+        assert gh == fh and np.array_equal(gi.view(np.uint32), fi.view(np.uint32)), res
+        none = np.zeros(n, np.uint8)                                # nothing active: the image is untouched, no hits
+        gi, gh = run(lib.sphere_through, gx, gy, idx, none)
+        assert gh == 0 and np.all(gi == -1.0)
