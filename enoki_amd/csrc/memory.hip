@@ -39,6 +39,18 @@ __global__ __launch_bounds__(256) void k_reverse(T *__restrict__ out, const T *_
         out[i] = in[n - 1 - i];
 }
 
+// out[i] = mask[i] && address[i] ? *(T *) (address[i] + byte_offset) : 0 -- a data member read out of instance memory through a
+// pointer array (ENOKI_CALL_SUPPORT_GETTER, array_call.h:269-283: gather<Return, 1>(nullptr, self + offset, mask))
+template <typename T>
+__global__ __launch_bounds__(256) void k_gather_address(T *__restrict__ out, Arg<uint64_t> address, int64_t byte_offset, Arg<uint8_t> mask,
+                                                        size_t n) {
+    const size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t a = address.vec ? address.ptr[i] : arg_scalar(address);
+    const bool on = (mask.vec ? mask.ptr[i] : arg_scalar(mask)) != 0 && a != 0;
+    out[i] = on ? *reinterpret_cast<const T *>(a + (uint64_t) byte_offset) : T(0);
+}
+
 // ---- concat ------------------------------------------------------------------------------------
 constexpr int kConcatMax = 8;
 struct ConcatArgs { const void *src[kConcatMax]; size_t end[kConcatMax]; unsigned bcast = 0; /* bit k: source k is ONE entry copied to every row (k_concat_rows) */ };
@@ -517,6 +529,26 @@ int ek_hip_gather(int type, int index_type, void *out, const void *base, const e
         case 8: EK_INDEX_SWITCH(index_type, (gather_launch<uint64_t, I>(out, base, index, mask, n)), "ek_hip_gather()")
         default: return fail(EK_ERR_INVALID, "ek_hip_gather(): unknown type %d", type);
     }
+}
+
+int ek_hip_gather_address(int type, void *out, const ek_operand *address, int64_t byte_offset, const ek_operand *mask, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out || !address) return fail(EK_ERR_INVALID, "ek_hip_gather_address(): null pointer");
+    Arg<uint64_t> aa;
+    Arg<uint8_t> mm;
+    if (int rc = make_arg<uint64_t>(address, n, aa, "ek_hip_gather_address")) return rc;
+    if (int rc = make_arg<uint8_t>(mask, n, mm, "ek_hip_gather_address")) return rc;
+    Context &c = ctx();
+    const unsigned grid = (unsigned) ((n + 255) / 256);
+    switch (type_size(type)) {
+        case 1: hipLaunchKernelGGL((k_gather_address<uint8_t>), dim3(grid), dim3(256), 0, c.stream, (uint8_t *) out, aa, byte_offset, mm, n); break;
+        case 4: hipLaunchKernelGGL((k_gather_address<uint32_t>), dim3(grid), dim3(256), 0, c.stream, (uint32_t *) out, aa, byte_offset, mm, n); break;
+        case 8: hipLaunchKernelGGL((k_gather_address<uint64_t>), dim3(grid), dim3(256), 0, c.stream, (uint64_t *) out, aa, byte_offset, mm, n); break;
+        default: return fail(EK_ERR_INVALID, "ek_hip_gather_address(): unknown type %d", type);
+    }
+    EK_LAUNCH_CHECK("gather_address", n, arg_bytes(aa, n) + arg_bytes(mm, n) + 2 * n * type_size(type));
+    return EK_OK;
 }
 
 int ek_hip_gather_multi(int type, int index_type, int count, void *const *outs, const void *const *bases,

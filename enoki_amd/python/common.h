@@ -776,6 +776,10 @@ inline void bind_runtime(py::module_ &m) {
           "large gathers from small tables stay deferred until consumed (fused into the consuming add/sub/mul/fma)");
     m.def("hip_set_defer", [](bool v) { hip_set_defer(v); }, "deferred evaluation of gathers and fusable unary ops on / off");
     m.def("hip_defer", []() { return hip_defer(); });
+    m.def("hip_set_scatter_aliasing", [](bool v) { hip_set_scatter_aliasing(v); },
+          "True: scatter / scatter_add write IN PLACE through shared handles, like copies of a CUDAArray that alias one variable "
+          "(cuda.h:224-226); False (default): copy on write");
+    m.def("hip_scatter_aliasing", []() { return hip_scatter_aliasing(); });
     m.def("hip_defer_gather", []() { return hip_defer_gather(); });
     m.def("hip_profile_begin", []() { detail::hip_check(ek_hip_profile_begin(), "hip_profile_begin"); });
     m.def("hip_profile_end", []() {

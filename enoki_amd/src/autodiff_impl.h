@@ -582,7 +582,17 @@ template <typename Value> void Tape<Value>::forward(Index index, bool free_graph
     d->simplification_enabled = saved;
 }
 
+namespace detail {
+    /// Brackets a sweep for backends that want to know (HIPArray: scatters inside a sweep always copy on write)
+    template <typename Value, typename = void> struct SweepScope { };
+    template <typename Value> struct SweepScope<Value, std::void_t<decltype(Value::sweep_scope_(true))>> {
+        SweepScope() { Value::sweep_scope_(true); }
+        ~SweepScope() { Value::sweep_scope_(false); }
+    };
+}
+
 template <typename Value> void Tape<Value>::backward(bool free_graph) {
+    detail::SweepScope<Value> sweep_scope;
     std::vector<Index> order = d->scheduled;
     d->clear_schedule();
     d->pending.clear();             // (left over only if an earlier sweep threw)
@@ -683,6 +693,7 @@ template <typename Value> void Tape<Value>::backward(bool free_graph) {
 }
 
 template <typename Value> void Tape<Value>::forward(bool free_graph) {
+    detail::SweepScope<Value> sweep_scope;
     std::vector<Index> order = d->scheduled;
     d->clear_schedule();
 

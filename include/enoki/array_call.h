@@ -24,8 +24,9 @@
     lanes in ascending order within a group.  The partition is cached in the array (copies share it), like
     cuda.h:816-842.
 
-    ENOKI_CALL_SUPPORT_GETTER (array_call.h:269-283) is provided for scalar data members: the reference gathers
-    the field out of managed instance memory on the device, here it is read on the host once per instance.
+    ENOKI_CALL_SUPPORT_GETTER (array_call.h:269-283) is provided for scalar data members: gathered out of instance memory
+    on the device when the class declares ENOKI_PINNED_OPERATOR_NEW (pinned instances, like the reference), read on the
+    host once per instance otherwise.
 */
 #pragma once
 
@@ -290,12 +291,45 @@ namespace detail {
                 return Base::dispatch(invoke, true, packed, std::make_index_sequence<sizeof...(Args)>()); \
         }
 
-/// `ptrs->name()`: per-lane value of a scalar data member of the instances (array_call.h:269-283).  The reference
-/// gathers the field straight out of managed instance memory; instances live in ordinary host memory here, so the
-/// field is read on the host once per distinct instance and scattered to that instance's lanes (null -> 0).
+/// Instances that the GPU can read: classes that declare ENOKI_PINNED_OPERATOR_NEW(Type) allocate themselves in pinned host
+/// memory (ek_hip_host_malloc; the reference's macro of the same name uses cuda_host_malloc, array_macro.h:361-395) and are
+/// marked, so that ENOKI_CALL_SUPPORT_GETTER reads their data members ON THE DEVICE.  As in the reference, instances of such
+/// a class must then live on the heap (`new`): a stack object is ordinary host memory.
+#define ENOKI_PINNED_OPERATOR_NEW(Type)                                                           \
+    static constexpr bool enoki_pinned_instances_ = true;                                         \
+    void *operator new(size_t size) { return enoki::detail::pinned_new(size); }                   \
+    void *operator new(size_t size, std::align_val_t) { return enoki::detail::pinned_new(size); } \
+    void *operator new[](size_t size) { return enoki::detail::pinned_new(size); }                 \
+    void *operator new[](size_t size, std::align_val_t) { return enoki::detail::pinned_new(size); } \
+    void operator delete(void *ptr) { ek_hip_host_free(ptr); }                                    \
+    void operator delete(void *ptr, std::align_val_t) { ek_hip_host_free(ptr); }                  \
+    void operator delete[](void *ptr) { ek_hip_host_free(ptr); }                                  \
+    void operator delete[](void *ptr, std::align_val_t) { ek_hip_host_free(ptr); }
+
+namespace detail {
+    inline void *pinned_new(size_t size) {
+        void *p = nullptr;
+        if (ek_hip_host_malloc(size, &p) != EK_OK) throw std::bad_alloc();
+        return p;
+    }
+    template <typename T, typename = void> struct is_pinned_class : std::false_type { };
+    template <typename T> struct is_pinned_class<T, std::enable_if_t<T::enoki_pinned_instances_>> : std::true_type { };
+}
+
+/// `ptrs->name()`: per-lane value of a scalar data member of the instances (array_call.h:269-283).  Like the reference, the
+/// field is gathered straight out of instance memory ON THE DEVICE (ek_hip_gather_address: one kernel, whatever the number of
+/// instances) when the class allocates its instances where the GPU can read them (ENOKI_PINNED_OPERATOR_NEW above); instances
+/// in ordinary host memory are read on the host once per distinct instance and scattered to that instance's lanes.
+/// Null pointers and masked lanes give 0 either way.
 #define ENOKI_CALL_SUPPORT_GETTER_TYPE(name, field, type)                                         \
     HIPArray<type> name(Mask mask = Mask(true)) const {                                           \
         using Return = HIPArray<type>;                                                            \
+        using FieldType_ = std::decay_t<decltype(std::declval<Class>().field)>;                   \
+        if constexpr (enoki::detail::is_pinned_class<Class>::value && std::is_arithmetic_v<FieldType_> && \
+                      !std::is_same_v<FieldType_, bool>) {                                        \
+            const ptrdiff_t offset_ = (ptrdiff_t) (uintptr_t) &(((Class *) nullptr)->field);      \
+            return Return(HIPArray<FieldType_>::gather_address_(self.bits(), offset_, mask));     \
+        }                                                                                         \
         mask = mask.and_(self.neq_(Storage(nullptr)));                                            \
         const auto &groups = self.partition_();                                                   \
         if (groups.size() == 1 && groups[0].first != nullptr)                                     \

@@ -79,13 +79,20 @@ namespace detail {
         /// capture must not receive its storage from the graph's private pool (it would dangle once the graph is destroyed).
         /// (The head lives in libenoki-hip.so, ek_hip_binding_slot(): this header is compiled into several shared objects --
         /// the two python modules, the tape library, user code -- that hand buffers to each other.)
-        struct Shared { HIPBuffer *pending = nullptr; bool defer = true; };
+        struct Shared {
+            HIPBuffer *pending = nullptr;
+            bool defer = true;
+            bool scatter_alias = false;      // hip_set_scatter_aliasing(): user-level scatters write in place through shared handles
+            int sweeps = 0;                  // > 0 while a Tape sweep runs (its buffers are shared as VALUES: always copy on write)
+        };
         static Shared &shared() {
             void **slot = ek_hip_binding_slot();
             if (!*slot) {
                 Shared *s = new Shared();             // once per process, never freed
                 const char *e = getenv("ENOKI_HIP_DEFER"), *g = getenv("ENOKI_HIP_DEFER_GATHER");
                 s->defer = !((e && e[0] == '0') || (g && g[0] == '0'));
+                const char *al = getenv("ENOKI_HIP_SCATTER_ALIASING");
+                s->scatter_alias = al && al[0] == '1';
                 *slot = s;
             }
             return *static_cast<Shared *>(*slot);
@@ -683,6 +690,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
         detail::hip_check(ek_hip_scatter_add(Type, Index::Type, ptr, target_size, &ov, &oi, &om, n, 0), "scatter_add_");
     }
 
+    /// out[i] = mask[i] && address[i] ? *(Value *) (address[i] + byte_offset) : 0 (ENOKI_CALL_SUPPORT_GETTER on the device)
+    static HIPArray gather_address_(const HIPArray<uint64_t> &address, ptrdiff_t byte_offset, const MaskType &mask) {
+        address.require_valid("gather_address_"); mask.require_valid("gather_address_");
+        size_t n = broadcast_size(address.size(), mask.size());
+        HIPArray r = empty_(n);
+        ek_operand oa = address.operand(), om = mask.operand();
+        detail::hip_check(ek_hip_gather_address(Type, r.m_buf->ptr, &oa, (int64_t) byte_offset, &om, n), "gather_address_");
+        return r;
+    }
+
     /// gather/scatter with an array as source/target (array_struct.h:9-123); a source of size 1 is
     /// a broadcast (array_struct.h:19-22)
     template <bool IsPermute, typename Index>
@@ -872,15 +889,33 @@ template <typename Value_> struct HIPArray : ArrayTag {
         }
     }
 
+    /// What a user-level scatter / scatter_add does with a target that other handles share.  Default: copy on write -- arrays
+    /// are values, the other handles keep the old contents.  With hip_set_scatter_aliasing(true) (ENOKI_HIP_SCATTER_ALIASING=1):
+    /// write IN PLACE, every handle observes the scatter -- what copies of a CUDAArray do, which alias one JIT variable
+    /// (cuda.h:224-226; cuda_var_mark_dirty).  Unevaluated nodes that read the buffer are evaluated first either way (they
+    /// were created before the write), and the Tape's own sweeps always copy on write (they share buffers as values).
+    void make_writable_() {
+        auto &sh = detail::HIPBuffer::shared();
+        if (sh.scatter_alias && sh.sweeps == 0 && m_buf && !m_is_imm) {
+            m_buf->force_readers();
+            m_buf->drop_host_mirror();
+            ptr_();
+        } else {
+            make_unique();
+        }
+    }
+    /// Tape sweeps bracket themselves with this (autodiff_impl.h): inside, scatters copy on write whatever the mode
+    static void sweep_scope_(bool enter) { detail::HIPBuffer::shared().sweeps += enter ? 1 : -1; }
+
     template <bool IsPermute, typename Index>
     static void scatter_array_(HIPArray &target, const HIPArray &value, const Index &index, const MaskType &mask) {
-        target.make_unique();
+        target.make_writable_();
         value.template scatter_<sizeof(Value)>(target.data(), detach(index), mask);
     }
 
     template <bool IsPermute, typename Index>
     static void scatter_add_array_(HIPArray &target, const HIPArray &value, const Index &index, const MaskType &mask) {
-        target.make_unique();
+        target.make_writable_();
         value.template scatter_add_<sizeof(Value)>(target.data(), detach(index), mask, target.size());
     }
 
@@ -1452,6 +1487,9 @@ inline std::string hip_whos() {
 inline void hip_set_defer(bool value) { detail::hip_defer_gather_flag() = value; }
 inline bool hip_defer() { return detail::hip_defer_gather_flag(); }
 inline void hip_set_defer_gather(bool value) { hip_set_defer(value); }
+/// Shared-handle scatter semantics of the reference's CUDAArray (see HIPArray::make_writable_): off by default
+inline void hip_set_scatter_aliasing(bool value) { detail::HIPBuffer::shared().scatter_alias = value; }
+inline bool hip_scatter_aliasing() { return detail::HIPBuffer::shared().scatter_alias; }
 inline bool hip_defer_gather() { return hip_defer(); }
 
 template <typename T> inline void set_label(const HIPArray<T> &, const char *) { }

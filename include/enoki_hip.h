@@ -196,6 +196,11 @@ EK_API int ek_hip_concat_rows(int type, void *out, size_t rows, int count, const
  * ------------------------------------------------------------------------------------------- */
 EK_API int ek_hip_gather(int type, int index_type, void *out, const void *base,
                          const ek_operand *index, const ek_operand *mask, size_t n);
+/* out[i] = mask[i] && address[i] ? *(type *) (address[i] + byte_offset) : 0: a data member read out of INSTANCE memory through an
+ * array of 64-bit object addresses -- what ENOKI_CALL_SUPPORT_GETTER does on the device (array_call.h:269-283:
+ * gather<Return, 1>(nullptr, self + offset, mask) from managed instance memory).  The addresses must be readable by the GPU
+ * (ek_hip_host_malloc / ENOKI_PINNED_OPERATOR_NEW, like the reference's pinned instances, array_macro.h:361). */
+EK_API int ek_hip_gather_address(int type, void *out, const ek_operand *address, int64_t byte_offset, const ek_operand *mask, size_t n);
 /* Gather of a structure-of-arrays value: `count` (2..4) tables of the same element type share ONE index / mask array
  * (gather<Array<HIPArray<T>, N>>(...), array_struct.h:9-40 calls gather_ once per component).  outs[c][i] =
  * mask[i] ? bases[c][index[i]] : 0.  4- and 8-byte element types. */

@@ -245,6 +245,60 @@ int hip_getter_test(const uint8_t *which, const uint8_t *mask_, size_t n, float 
     }
 }
 
+// ---- getters on the device: instances in pinned host memory (ENOKI_PINNED_OPERATOR_NEW) ---------------------------------
+struct Light {
+    ENOKI_PINNED_OPERATOR_NEW(Light)
+    virtual ~Light() = default;
+    virtual float id() const = 0;
+    float power = 0.f;
+    double tag_value = 0.0;
+    uint32_t samples = 0;
+};
+struct Spot : Light { float id() const override { return 1.f; } float cone = 0.5f; };
+struct Area : Light { float id() const override { return 2.f; } double area = 2.0; char pad[24]; };
+
+ENOKI_CALL_SUPPORT_BEGIN(Light)
+ENOKI_CALL_SUPPORT_METHOD(id)
+ENOKI_CALL_SUPPORT_GETTER(power, power)
+ENOKI_CALL_SUPPORT_GETTER(samples, samples)
+ENOKI_CALL_SUPPORT_GETTER_TYPE(tag, tag_value, float)
+ENOKI_CALL_SUPPORT_END(Light)
+
+/// which[i] selects one of `instances` heap-allocated lights (odd: Spot, even: Area; 0xFFFFFFFF: null).  Outputs per lane;
+/// launches[0] = kernel launches of the three getters together (device path: one gather each, + one cast for the double
+/// field -- whatever the number of instances).
+extern "C" __attribute__((visibility("default")))
+int hip_getter_device_test(const uint32_t *which, const uint8_t *mask_, size_t n, uint32_t instances, float *out_power,
+                           float *out_tag_masked, uint32_t *out_samples, uint64_t *launches) {
+    try {
+        std::vector<std::unique_ptr<Light>> lights;
+        for (uint32_t k = 0; k < instances; ++k) {
+            if (k & 1) lights.emplace_back(new Spot()); else lights.emplace_back(new Area());
+            lights.back()->power = 0.5f * (float) k + 1.f;
+            lights.back()->tag_value = 1000.0 - (double) k;
+            lights.back()->samples = 7u * k + 3u;
+        }
+        std::vector<Light *> host(n);
+        for (size_t i = 0; i < n; ++i) host[i] = which[i] < instances ? lights[which[i]].get() : nullptr;
+        using LightPtrC = HIPArray<Light *>;
+        LightPtrC ptrs = LightPtrC::copy(host.data(), n);
+        MaskC mask = MaskC::copy(mask_, n);
+        const uint64_t l0 = ek_hip_launch_count();
+        FloatC power = ptrs->power();
+        FloatC tag = ptrs->tag(mask);
+        HIPArray<uint32_t> samples = ptrs->samples();
+        launches[0] = ek_hip_launch_count() - l0;
+        to_host(power, out_power, n);
+        to_host(tag, out_tag_masked, n);
+        auto hs = samples.to_host();
+        memcpy(out_samples, hs.data(), n * sizeof(uint32_t));
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "hip_getter_device_test: %s\n", e.what());
+        return -3;
+    }
+}
+
 // ---- partition() with many instances ---------------------------------------------------------------------------------
 // `which[i]` selects one of `instances` objects (or none: which[i] == 0xFFFFFFFF -> null pointer).  Returns, per group in
 // partition order, the instance number (0xFFFFFFFF for null) and the group size; `perm_out` receives the concatenated

@@ -155,6 +155,29 @@ def test_call_support_getters():
     assert np.array_equal(lanes, np.select([which == 0, which == 1, which == 2], [11, 22, 33], 0).astype(np.uint64))
 
 
+@pytest.mark.parametrize("instances", [1, 3, 5000])
+def test_call_support_getters_on_the_device(instances):
+    """instances of a class with ENOKI_PINNED_OPERATOR_NEW live where the GPU can read them: the getter is ONE gather out of
+    instance memory (ek_hip_gather_address; array_call.h:269-283 does the same from managed memory) however many instances
+    there are -- no partition, no host read per instance"""
+    lib = ctypes.CDLL(os.path.join(HERE, "cpp", "libcall_hip.so"))
+    n = 200003
+    rng = np.random.default_rng(instances)
+    which = rng.integers(0, instances + 1, n).astype(np.uint32)
+    which[which == instances] = 0xFFFFFFFF
+    mask = (np.arange(n) % 3 != 0).astype(np.uint8)
+    power = np.empty(n, np.float32); tag = np.empty(n, np.float32); samples = np.empty(n, np.uint32); launches = np.zeros(1, np.uint64)
+    p = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+    assert lib.hip_getter_device_test(p(which), p(mask), ctypes.c_size_t(n), ctypes.c_uint32(instances), p(power), p(tag), p(samples),
+                                      p(launches)) == 0
+    live = which != 0xFFFFFFFF
+    k = np.where(live, which, 0).astype(np.float64)
+    assert np.array_equal(power, np.where(live, 0.5 * k + 1.0, 0.0).astype(np.float32))
+    assert np.array_equal(tag, np.where(live & (mask != 0), 1000.0 - k, 0.0).astype(np.float32))
+    assert np.array_equal(samples, np.where(live, 7 * k + 3, 0).astype(np.uint32))
+    assert int(launches[0]) <= 5, launches          # three gathers + the double -> float cast (+ a mask and): not per instance
+
+
 @pytest.mark.parametrize("instances", [1, 3, 1000, 70000])
 def test_partition_scales_with_instances(instances):
     """partition() = dense 32-bit keys + ONE stable radix sort + run starts (like cuda_partition, horiz.cu:35-122): groups

@@ -548,3 +548,40 @@ def test_binary_search(ekc, ek):
         last = mod.UInt32(np.array([999], np.uint32))
         found = mod.binary_search(0, 1000, lambda i: mod.gather(T, mod.min(i, last)) < Nd)
         assert np.array_equal(found.numpy(), np.searchsorted(table, needles, side="left").astype(np.uint32))
+
+
+def test_scatter_aliasing_is_opt_in():
+    """copies of an array share a buffer.  Default: scatter copies on write, the other handle keeps the old values; with
+    hip_set_scatter_aliasing(True) every handle observes the scatter, like copies of a CUDAArray that alias one variable
+    (cuda.h:224-226) -- and a backward() sweep is not affected by the mode"""
+    import enoki_amd.hip as ek
+    import enoki_amd.hip_autodiff as ad
+    ek.hip_init(0)
+    n = 100003
+    base = np.arange(n, dtype=np.float32)
+    idx = ek.UInt32(np.arange(0, n, 7, dtype=np.uint32))
+    vals = ek.Float32(np.full(idx.numpy().size, -1.0, np.float32))
+    a = ek.Float32(base); b = ek.Float32(a)
+    ek.scatter(a, vals, idx)
+    assert np.array_equal(b.numpy(), base) and np.all(a.numpy()[::7] == -1.0)
+    assert not ek.hip_scatter_aliasing()
+    ek.hip_set_scatter_aliasing(True)
+    try:
+        a = ek.Float32(base); b = ek.Float32(a)
+        pending = ek.sin(a)                                   # created BEFORE the write: sees the old contents
+        ek.scatter(a, vals, idx)
+        assert np.array_equal(b.numpy(), a.numpy()) and np.all(b.numpy()[::7] == -1.0)
+        assert np.array_equal(pending.numpy(), ek.sin(ek.Float32(base)).numpy())
+        ek.scatter_add(b, vals, idx)
+        assert np.all(a.numpy()[::7] == -2.0)
+        # the tape shares buffers as VALUES: its sweeps copy on write whatever the mode
+        K, m = 1 << 16, 1 << 19
+        rng = np.random.default_rng(3)
+        A = rng.integers(-3, 4, K).astype(np.float32); x = rng.integers(-2, 3, m).astype(np.float32)
+        ii = rng.integers(0, K, m).astype(np.uint32)
+        dA = ad.Float32(A); ad.set_requires_gradient(dA)
+        y = ad.hsum(ad.gather(dA, ad.UInt32(ii)) * ad.Float32(x))
+        ad.backward(y)
+        assert np.array_equal(ad.gradient(dA).numpy(), np.bincount(ii, weights=x.astype(np.float64), minlength=K).astype(np.float32))
+    finally:
+        ek.hip_set_scatter_aliasing(False)
