@@ -278,16 +278,18 @@ constexpr unsigned long long kLockedPair = 0xFFC00001FFC00001ull;
 
 __device__ __forceinline__ unsigned long long pair_sum(unsigned long long old, float v0, float v1) {
     const float s0 = __uint_as_float((unsigned) old) + v0, s1 = __uint_as_float((unsigned) (old >> 32)) + v1;
-    unsigned long long bits = (unsigned long long) __float_as_uint(s0) | ((unsigned long long) __float_as_uint(s1) << 32);
-    if (bits == kLockedPair) bits = 0x7FC000007FC00000ull;          // never publish the lock pattern
-    return bits;
+    // a pair is LOCKED iff its low word carries the lock pattern (a NaN payload no sum produces): one compare per test, and
+    // the pattern is never published as a value
+    unsigned lo = __float_as_uint(s0);
+    if (lo == kLockedBits) lo = 0x7FC00000u;
+    return (unsigned long long) lo | ((unsigned long long) __float_as_uint(s1) << 32);
 }
 
 __device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, float v1, bool active) {
     bool pending = active;
     if (pending) {
         const unsigned long long old = atomicExch(p, kLockedPair);
-        if (old != kLockedPair) {
+        if ((unsigned) old != kLockedBits) {
             __hip_atomic_store(p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             pending = false;
         }
@@ -304,7 +306,7 @@ __device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, fl
         for (int d = 32; d >= 1; d >>= 1) { t0 += __shfl_xor(t0, d); t1 += __shfl_xor(t1, d); }
         if (lane == leader) {
             unsigned long long old;
-            do { old = atomicExch(p, kLockedPair); } while (old == kLockedPair);
+            do { old = atomicExch(p, kLockedPair); } while ((unsigned) old == kLockedBits);
             __hip_atomic_store(p, pair_sum(old, t0, t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
         pending = pending && !grouped;
@@ -325,7 +327,7 @@ __device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, co
     for (int j = 0; j < N; ++j) old[j] = atomicExch(table + l[j], kLockedPair);
 #pragma unroll
     for (int j = 0; j < N; ++j) {
-        if (old[j] != kLockedPair)
+        if ((unsigned) old[j] != kLockedBits)
             __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         else
             pending |= 1u << j;
@@ -340,7 +342,7 @@ __device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, co
             if ((pending >> j) & 1u) old[j] = atomicExch(table + l[j], kLockedPair);
 #pragma unroll
         for (int j = 0; j < N; ++j) {
-            if (((pending >> j) & 1u) && old[j] != kLockedPair) {
+            if (((pending >> j) & 1u) && (unsigned) old[j] != kLockedBits) {
                 __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                 pending &= ~(1u << j);
             }
@@ -395,24 +397,35 @@ __device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], 
 
 // The streaming part.  Map >= 0: every stream that is a function of u applies THIS op (compile time; evaluated once per
 // element however many streams share it -- the usual pair cos(u), x * cos(u)); Map < 0: per-stream ops chosen at run time.
-template <typename T, int C, int V, int Map>
+// Spec = 1: the adjoint of a gathered pair as the tape issues it -- two streams, both the (kept / mapped) function of u, the
+// SECOND one weighted by x: known at compile time, no per-element selects on the stream description.
+template <typename T, int C, int V, int Map, int Spec = 0>
 __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, const BucketStreams<T, C> &st,
                                                          const uint16_t *__restrict__ pair_idx, const T *__restrict__ u_b,
                                                          const T *__restrict__ x_b, size_t begin, size_t end) {
     constexpr int Bins = bins_of<T>;
     constexpr bool Paired = C == 2 && sizeof(T) == 4;
-    const bool need_u = st.from_u != 0, need_x = st.weighted != 0;
+    static_assert(Spec == 0 || (C == 2 && Map >= 0));
+    const bool need_u = Spec == 1 || st.from_u != 0, need_x = Spec == 1 || st.weighted != 0;
+    auto values = [&](T u, T x, T (&v)[C]) {
+        T m = T(0);
+        if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
+        if constexpr (Spec == 1) {
+            v[0] = m;
+            v[C - 1] = dev::safe_mul(x, m);
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                if constexpr (Map >= 0) v[c] = ((st.from_u >> c) & 1u) ? m : st.imm[c];
+                else v[c] = ((st.from_u >> c) & 1u) ? unary_fused<T>(st.map_op[c], u) : st.imm[c];
+                if ((st.weighted >> c) & 1u) v[c] = dev::safe_mul(x, v[c]);
+            }
+        }
+    };
     // every lane of a wave passes through the lock (its retry loop is wave-uniform): inactive lanes add nothing
     auto one = [&](uint32_t l, T u, T x, bool on) {
         T v[C];
-        T m = T(0);
-        if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-            if constexpr (Map >= 0) v[c] = ((st.from_u >> c) & 1u) ? m : st.imm[c];
-            else v[c] = ((st.from_u >> c) & 1u) ? unary_fused<T>(st.map_op[c], u) : st.imm[c];
-            if ((st.weighted >> c) & 1u) v[c] = dev::safe_mul(x, v[c]);
-        }
+        values(u, x, v);
         if constexpr (Paired) {
             lds_add_pair(reinterpret_cast<unsigned long long *>(acc) + (l & (Bins - 1)), v[0], v[C - 1], on);
         } else {
@@ -451,14 +464,10 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
                 const int k = h * 4 + j;
                 const T u = need_u ? s.pu[h][j] : T(0), x = need_x ? s.px[h][j] : T(0);
                 l[k] = (uint32_t) s.pi[h].v[j] & (Bins - 1);
-                T m = T(0);
-                if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
+                T vk[C];
+                values(u, x, vk);
 #pragma unroll
-                for (int c = 0; c < C; ++c) {
-                    if constexpr (Map >= 0) v[c][k] = ((st.from_u >> c) & 1u) ? m : st.imm[c];
-                    else v[c][k] = ((st.from_u >> c) & 1u) ? unary_fused<T>(st.map_op[c], u) : st.imm[c];
-                    if ((st.weighted >> c) & 1u) v[c][k] = dev::safe_mul(x, v[c][k]);
-                }
+                for (int c = 0; c < C; ++c) v[c][k] = vk[c];
             }
         }
         if constexpr (Paired) {
@@ -514,7 +523,21 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
         else uniform = uniform && st.map_op[c] == op;
     }
 #define EK_ACC_CASE(OP) case OP: bucket_accumulate_stream<T, C, V, OP>(acc, st, pair_idx, u_b, x_b, begin, end); break;
-    if (uniform) {
+#define EK_ACC_SPEC(OP) case OP: bucket_accumulate_stream<T, C, V, OP, 1>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+    bool done = false;
+    if constexpr (C == 2) {
+        if (uniform && st.from_u == 3u && st.weighted == 2u) {         // (host side: the weighted stream is put second)
+            done = true;
+            switch (op) {
+                EK_ACC_SPEC(EK_NEG) EK_ACC_SPEC(EK_ABS) EK_ACC_SPEC(EK_SQRT) EK_ACC_SPEC(EK_RCP) EK_ACC_SPEC(EK_RSQRT)
+                EK_ACC_SPEC(EK_SIN) EK_ACC_SPEC(EK_COS) EK_ACC_SPEC(EK_EXP) EK_ACC_SPEC(EK_LOG)
+                default: bucket_accumulate_stream<T, C, V, EK_COPY, 1>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+            }
+        }
+    }
+#undef EK_ACC_SPEC
+    if (done) {
+    } else if (uniform) {
         switch (op) {
             EK_ACC_CASE(EK_NEG) EK_ACC_CASE(EK_ABS) EK_ACC_CASE(EK_SQRT) EK_ACC_CASE(EK_RCP) EK_ACC_CASE(EK_RSQRT)
             EK_ACC_CASE(EK_SIN) EK_ACC_CASE(EK_COS) EK_ACC_CASE(EK_EXP) EK_ACC_CASE(EK_LOG)
@@ -721,13 +744,19 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
         T *tb[2] = { (T *) bases[s0], C == 2 ? (T *) bases[s0 + 1] : nullptr };
         if (C == 2) {
             BucketStreams<T, 2> st{};
+            // the weighted stream second (the tape queues the adjoints of the addend and of the factor in either order): the
+            // kernel has a compile-time form for { f(u), x * f(u) }
+            const bool swap = weighted[s0] && !weighted[s0 + 1];
+            if (swap) std::swap(tb[0], tb[1]);
             for (int s = 0; s < 2; ++s) {
-                st.map_op[s] = (map_ops && !use_kept) ? map_ops[s0 + s] : (int) EK_COPY;
-                memcpy(&st.imm[s], &imm_bits[s0 + s], sizeof(T));
-                st.from_u |= (from_u[s0 + s] ? 1u : 0u) << s;
-                st.weighted |= (weighted[s0 + s] ? 1u : 0u) << s;
+                const int src = s0 + (swap ? 1 - s : s);
+                st.map_op[s] = (map_ops && !use_kept) ? map_ops[src] : (int) EK_COPY;
+                memcpy(&st.imm[s], &imm_bits[src], sizeof(T));
+                st.from_u |= (from_u[src] ? 1u : 0u) << s;
+                st.weighted |= (weighted[src] ? 1u : 0u) << s;
             }
-            const unsigned fr = fresh ? ((fresh[s0] ? 1u : 0u) | (fresh[s0 + 1] ? 2u : 0u)) : 0u;
+            const int f0 = swap ? s0 + 1 : s0, f1 = swap ? s0 : s0 + 1;
+            const unsigned fr = fresh ? ((fresh[f0] ? 1u : 0u) | (fresh[f1] ? 2u : 0u)) : 0u;
             if (int rc = bucketed_accumulate<T, 2>(b, tb, st, u_src, fr)) return rc;
         } else {
             BucketStreams<T, 1> st{};
