@@ -640,6 +640,8 @@ static int bucketed_create(Bucketed *b, const T *x, const I *index) {
     st.pair_val[0] = (T *) b->x_b;
     st.weighted = 0u;
     st.value_op[0] = EK_COPY;
+    // (histogram replicas for the tile ranking, as in the count kernel: measured, no difference -- 0.2006 / 0.2014 / 0.2021 ms
+    // for 1 / 2 / 4 replicas on one box; the ranking is not what bounds this kernel)
     hipLaunchKernelGGL((k_bin_partition<T, I, Shift, uint16_t, 1>), dim3(blocks), dim3(kThreads), 0, c.stream,
                        (uint16_t *) b->pair_idx, st, (const uint32_t *) counts, (const uint32_t *) b->bucket_base, index, mask, n,
                        chunk, n_buckets, 0, vec_ok);

@@ -285,6 +285,9 @@ int ek_hip_malloc(size_t bytes, void **out) {
         hipError_t e = hipMalloc(&ptr, cls);
         if (e != hipSuccess) {
             (void) hipGetLastError();
+            // trimming needs the stream drained -- which cannot be done (and would invalidate the capture) while a step graph is
+            // being captured: fail cleanly instead
+            if (int busy = refuse_while_capturing("ek_hip_malloc(): out of device memory, and trimming the cache")) return busy;
             hipError_t e2 = hipStreamSynchronize(ctx().stream);
             if (e2 == hipSuccess) e2 = a.trim_locked();
             if (e2 == hipSuccess) e = hipMalloc(&ptr, cls);
@@ -521,6 +524,9 @@ uint64_t ek_hip_graph_launch_count(const ek_hip_graph *g) { return g ? g->launch
 
 int ek_hip_graph_destroy(ek_hip_graph *g) {
     if (!g) return EK_OK;
+    // a replay of this graph may still be running: wait for it -- unless ANOTHER graph is being captured on the stream right
+    // now, where a synchronisation would invalidate that capture
+    if (int busy = refuse_while_capturing("ek_hip_graph_destroy()")) return busy;
     if (ctx().initialized) (void) hipStreamSynchronize(ctx().stream);
     if (g->exec) (void) hipGraphExecDestroy(g->exec);
     if (g->graph) (void) hipGraphDestroy(g->graph);

@@ -164,7 +164,7 @@ private:
         for (size_t g = 0; g < starts.size(); ++g) {
             const size_t begin = starts[g], end = g + 1 < starts.size() ? starts[g + 1] : n;
             const uint64_t p = start_keys[g] == 0 ? 0 : lowest + ((uint64_t) (start_keys[g] - 1) << 3);
-            result.emplace_back((Value) (uintptr_t) p, UInt32::map((void *) (m_partition_lanes.data() + begin), end - begin));
+            result.emplace_back((Value) (uintptr_t) p, UInt32::view_(m_partition_lanes, begin, end - begin));   // shares ownership
         }
         return true;
     }

@@ -113,6 +113,7 @@ namespace detail {
         static void force_all_pending() {
             while (pending_head()) pending_head()->force();
         }
+        HIPBuffer *view_of = nullptr;          // a window into another buffer (HIPArray::view_): holds a reference on it
         void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
         bool exported = false;                 // an external zero-copy view (torch, __cuda_array_interface__) may exist
 
@@ -272,6 +273,7 @@ namespace detail {
             if (deferred) drop_deferred();
             drop_host_mirror();
             if (owned && ptr) ek_hip_free(ptr);
+            unref(view_of);
         }
     };
 
@@ -646,6 +648,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
         r.m_buf->ptr = ptr;
         r.m_buf->size = size;
         r.m_buf->owned = dealloc;
+        return r;
+    }
+
+    /// A read-only window [begin, begin + size) into `parent` that shares ownership of the parent's storage: it stays valid for
+    /// as long as any window (or the parent) is alive.  (The groups that partition() hands out are such windows into ONE sorted
+    /// lane array: a group copied out of the partition may outlive the pointer array it came from.)
+    static HIPArray view_(const HIPArray &parent, size_t begin, size_t size) {
+        HIPArray r = map((void *) (parent.data() + begin), size, false);
+        r.m_buf->view_of = parent.m_buf;
+        parent.m_buf->ref_count++;
         return r;
     }
 

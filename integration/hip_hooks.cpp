@@ -44,6 +44,14 @@ std::shared_ptr<Buffer> make(size_t size, size_t elem) {
 }
 ek_operand op(const std::shared_ptr<Buffer> &b) { return ek_operand{ b->get(), 0, b->size }; }
 size_t bsize(size_t a, size_t b) { return a == 1 ? b : a; }
+/// The fragments below are the float32 spellings of safe_mul / safe_fmadd (autodiff.cpp:1191-1221) and are executed by float32
+/// kernels on 4-byte buffers: any other element type is refused loudly instead of being reinterpreted.
+void require_f32(EnokiType type, const char *fragment) {
+    if (type != EnokiType::Float32 && type != EnokiType::Bool)
+        throw std::runtime_error(std::string("enoki-hip integration: trace fragment \"") + fragment +
+                                 "\" on a non-float32 array is not provided (Tape<double> is not wired through the integration layer)");
+}
+
 [[noreturn]] void unknown(const char *fragment) {
     throw std::runtime_error(std::string("integration/hip_hooks.cpp: trace fragment not provided by the eager backend: ") + fragment);
 }
@@ -76,13 +84,15 @@ bool tests_factors_of(const std::shared_ptr<Buffer> &mask, const std::shared_ptr
 }
 } // namespace
 
-uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1) {
+uint32_t cuda_trace_append(EnokiType type, const char *fragment, uint32_t i1) {
+    require_f32(type, fragment);
     if (strcmp(fragment, "setp.eq.f32 $r1, $r2, 0.0") != 0) unknown(fragment);
     auto v = Handles::get().find(i1);
     return Handles::get().park(recipe(1, v->size, v, nullptr));                  // (v == 0), not evaluated yet
 }
 
-uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_t i2) {
+uint32_t cuda_trace_append(EnokiType type, const char *fragment, uint32_t i1, uint32_t i2) {
+    require_f32(type, fragment);
     auto x = Handles::get().find(i1), y = Handles::get().find(i2);
     if (strcmp(fragment, "setp.eq.or.f32 $r1, $r2, 0.0, $r3") == 0) {          // (x == 0) | y
         const size_t n = bsize(x->size, y->size);
@@ -110,7 +120,8 @@ uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_
     unknown(fragment);
 }
 
-uint32_t cuda_trace_append(EnokiType, const char *fragment, uint32_t i1, uint32_t i2, uint32_t i3) {
+uint32_t cuda_trace_append(EnokiType type, const char *fragment, uint32_t i1, uint32_t i2, uint32_t i3) {
+    require_f32(type, fragment);
     if (strcmp(fragment, "selp.$t1 $r1, $r2, $r3, $r4") != 0) unknown(fragment);   // m ? x : y
     auto x = Handles::get().find(i1), y = Handles::get().find(i2), m = Handles::get().find(i3);
     const size_t n = bsize(bsize(x->size, y->size), m->size);
