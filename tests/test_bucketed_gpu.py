@@ -178,3 +178,57 @@ def test_skewed_indices(capi):
         b.scatter_add([g], [("copy", 0, True)])
         want = np.bincount(idx.astype(np.int64), weights=(x * u).astype(np.float64), minlength=K)
         assert np.array_equal(g.numpy().astype(np.float64), want)
+
+
+class _PartInfo(__import__("ctypes").Structure):
+    import ctypes as _c
+    _fields_ = [("shift", _c.c_int), ("n_buckets", _c.c_int), ("n", _c.c_size_t), ("range", _c.c_size_t),
+                ("bucket_base", _c.c_void_p), ("local", _c.c_void_p)]
+
+
+@pytest.mark.parametrize("range_,shift", [(3000, 12), (1 << 20, 12), ((1 << 20) + 1, 14), (1 << 22, 14), ((1 << 22) + 5, 17),
+                                           (1 << 25, 17), ((1 << 25) + 1, 19)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_index_partition(capi, range_, shift, masked):
+    """ek_hip_index_partition_*: the active entries of an index array grouped by bucket of the range (what
+    enoki::vectorize_through runs on): every bucket holds exactly the bucket-local indices of its active entries (as a multiset:
+    the order inside a bucket is unspecified), bucket_base is their exclusive prefix, the shift is the smallest of {12, 14, 17,
+    19} with at most 256 buckets"""
+    import ctypes
+    n = 300007
+    rng = np.random.default_rng(range_ % 1000 + masked)
+    idx = rng.integers(0, range_, n).astype(np.uint32)
+    idx[: n // 10] = idx[n // 10: 2 * (n // 10)]                   # duplicates
+    mask = (rng.integers(0, 4, n) != 0).astype(np.uint8) if masked else None
+    di = up(capi, idx)
+    dm = up(capi, mask) if masked else None
+    om = capi.operand(dm if masked else True, np.uint8)
+    h = ctypes.c_void_p()
+    capi.check(capi.lib.ek_hip_index_partition_create(capi.U32, ctypes.c_void_p(di.ptr), ctypes.byref(om), ctypes.c_size_t(n),
+                                                      ctypes.c_size_t(range_), ctypes.byref(h)))
+    info = _PartInfo()
+    capi.check(capi.lib.ek_hip_index_partition_get(h, ctypes.byref(info)))
+    assert info.shift == shift and info.n_buckets == -(-range_ // (1 << shift)) and info.n == n and info.range == range_
+    base = capi.Buf(np.uint32, info.n_buckets + 1, own=False, ptr=info.bucket_base).numpy()
+    active = idx[mask != 0] if masked else idx
+    assert base[0] == 0 and base[-1] == active.size
+    local = capi.Buf(np.uint32, max(int(base[-1]), 1), own=False, ptr=info.local).numpy()[: int(base[-1])]
+    counts = np.bincount(active >> shift, minlength=info.n_buckets)
+    assert np.array_equal(np.diff(base.astype(np.int64)), counts)
+    # bucket by bucket: the same multiset of local indices
+    order = np.argsort(active >> shift, kind="stable")
+    want = (active[order] & ((1 << shift) - 1)).astype(np.uint32)
+    for b in np.flatnonzero(counts)[:: max(1, info.n_buckets // 16)]:
+        lo, hi = int(base[b]), int(base[b + 1])
+        assert np.array_equal(np.sort(local[lo:hi]), np.sort(want[lo:hi])), b
+    capi.check(capi.lib.ek_hip_index_partition_destroy(h))
+
+
+def test_index_partition_rejects_what_it_does_not_cover(capi):
+    import ctypes
+    di = up(capi, np.zeros(16, np.uint32))
+    om = capi.operand(True, np.uint8)
+    h = ctypes.c_void_p()
+    for args in ((capi.U64, 16, 100), (capi.U32, 0, 100), (capi.U32, 16, 0), (capi.U32, 16, (256 << 19) + 1)):
+        assert capi.lib.ek_hip_index_partition_create(args[0], ctypes.c_void_p(di.ptr), ctypes.byref(om), ctypes.c_size_t(args[1]),
+                                                      ctypes.c_size_t(args[2]), ctypes.byref(h)) != 0
