@@ -294,16 +294,20 @@ class Bench:
             def step_fused():
                 # the same program as ONE kernel: enoki::vectorize() over the reference's templated kernels
                 # (examples/sphere_fused.cpp); 18 B per ray instead of ~318
-                image = F.full(-1.0, nr)
                 P = ctypes.c_void_p
                 if workload == "cfg4_bucketed":
-                    # per PIXEL instead of per ray: rays grouped by pixel bucket once, grid / image slices streamed in order
-                    rc = fused_lib.sphere_through_device(P(grid.x.data_ptr()), P(grid.y.data_ptr()), P(perm.data_ptr()), P(mask.data_ptr()),
-                                                         ctypes.c_size_t(nr), P(image.data_ptr()), ctypes.byref(hits_c))
+                    # per PIXEL instead of per ray: rays grouped by pixel bucket once, grid / image slices streamed in order;
+                    # `image = full(-1)` happens in the same pass (every pixel is written: vectorize_through_fill)
+                    image = F.empty(nr)
+                    rc = fused_lib.sphere_through_fill_device(P(grid.x.data_ptr()), P(grid.y.data_ptr()), P(perm.data_ptr()),
+                                                              P(mask.data_ptr()), ctypes.c_size_t(nr), ctypes.c_float(-1.0),
+                                                              P(image.data_ptr()), ctypes.byref(hits_c))
                 elif grid_xy is not None:
+                    image = F.full(-1.0, nr)
                     rc = fused_lib.sphere_fused_packed_device(P(grid_xy.data_ptr()), P(perm.data_ptr()), P(mask.data_ptr()),
                                                               ctypes.c_size_t(nr), P(image.data_ptr()), ctypes.byref(hits_c))
                 else:
+                    image = F.full(-1.0, nr)
                     rc = fused_lib.sphere_fused_device(P(grid.x.data_ptr()), P(grid.y.data_ptr()), P(perm.data_ptr()), P(mask.data_ptr()),
                                                        ctypes.c_size_t(nr), P(image.data_ptr()), ctypes.byref(hits_c))
                 assert rc == 0

@@ -170,9 +170,11 @@ class Handle:
     owned = None             # (begin, end) of that slice in the full table
 
     def __init__(self):
-        self._slot, self._work = None, None
+        self._slot, self._work, self._host = None, None, None
 
     def tensor(self):
+        if self._host is not None and self._slot is None:
+            self._slot = _to_tensor(self._host[0], self._host[1], self._host[2])
         if self._slot is None:
             raise RuntimeError("Exchange.flush() has not been called for this contribution")
         if self._work is not None:
@@ -181,6 +183,8 @@ class Handle:
         return self._slot
 
     def item(self):
+        if self._host is not None:
+            return self._host[0]
         return self.tensor()[0].item()
 
 
@@ -204,6 +208,10 @@ class Exchange:
         if op not in _TORCH_OPS:
             raise ValueError(f"unknown reduction '{op}'")
         h = Handle()
+        if isinstance(value, (bool, int, float)) and not (dist.is_initialized() and dist.get_world_size() > 1):
+            # a host scalar with nobody to exchange it with: it is its own reduction (no device round trip)
+            h._host = (value, self.device, dtype)
+            return h
         self._pending.append((h, _to_tensor(value, self.device, dtype), op))
         return h
 

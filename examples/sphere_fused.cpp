@@ -158,6 +158,17 @@ int sphere_fused(const float *gx, const float *gy, const uint32_t *perm_, const 
 /// permutation and the three kernels depend on the gathered pixel position only, so the rays are grouped by pixel bucket once
 /// (ek_hip_index_partition_*) and every bucket's slice of the grid is read, and of the image written, IN ORDER: ~28 B per ray of
 /// streaming traffic instead of two (packed: one and a half) 64-byte random accesses.  Same image, same hit count, bit for bit.
+static auto through_body() {
+    return [](auto &&px, auto &&py) {
+        using Vector2fP = Array<FloatP, 2>;
+        using MaskP = mask_t<FloatP>;
+        MaskP hit;
+        auto pos = intersect_rays(make_rays(Vector2fP(px, py)), hit);
+        FloatP shade = shade_hits(pos);
+        return std::pair<FloatP, MaskP>(shade, hit);
+    };
+}
+
 extern "C" __attribute__((visibility("default")))
 int sphere_through_device(const float *gx, const float *gy, const uint32_t *perm_, const uint8_t *mask_, size_t n, float *image,
                           uint64_t *hit_count) {
@@ -165,20 +176,31 @@ int sphere_through_device(const float *gx, const float *gy, const uint32_t *perm
         UInt32C perm = UInt32C::map((void *) perm_, n);
         MaskC mask = MaskC::map((void *) mask_, n);
         FloatC x = FloatC::map((void *) gx, n), y = FloatC::map((void *) gy, n), img = FloatC::map((void *) image, n);
-        size_t hits = vectorize_through(
-            [](auto &&px, auto &&py) {
-                using Vector2fP = Array<FloatP, 2>;
-                using MaskP = mask_t<FloatP>;
-                MaskP hit;
-                auto pos = intersect_rays(make_rays(Vector2fP(px, py)), hit);
-                FloatP shade = shade_hits(pos);
-                return std::pair<FloatP, MaskP>(shade, hit);
-            },
-            (const UInt32C &) perm, (const MaskC &) mask, img, (const FloatC &) x, (const FloatC &) y);
+        size_t hits = vectorize_through(through_body(), (const UInt32C &) perm, (const MaskC &) mask, img, (const FloatC &) x,
+                                        (const FloatC &) y);
         if (hit_count) *hit_count = hits;
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "sphere_through_device: %s\n", e.what());
+        return -3;
+    }
+}
+
+/// `image = full(background); scatter(image, shade, perm, hit)` of sphere.cpp:66-83 in the same pass (vectorize_through_fill):
+/// `image` need not be initialised, every pixel is written.
+extern "C" __attribute__((visibility("default")))
+int sphere_through_fill_device(const float *gx, const float *gy, const uint32_t *perm_, const uint8_t *mask_, size_t n,
+                               float background, float *image, uint64_t *hit_count) {
+    try {
+        UInt32C perm = UInt32C::map((void *) perm_, n);
+        MaskC mask = MaskC::map((void *) mask_, n);
+        FloatC x = FloatC::map((void *) gx, n), y = FloatC::map((void *) gy, n), img = FloatC::map((void *) image, n);
+        size_t hits = vectorize_through_fill(through_body(), (const UInt32C &) perm, (const MaskC &) mask, background, img,
+                                             (const FloatC &) x, (const FloatC &) y);
+        if (hit_count) *hit_count = hits;
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "sphere_through_fill_device: %s\n", e.what());
         return -3;
     }
 }
@@ -198,6 +220,26 @@ int sphere_through(const float *gx, const float *gy, const uint32_t *perm_, cons
         return 0;
     } catch (const std::exception &e) {
         fprintf(stderr, "sphere_through: %s\n", e.what());
+        return -3;
+    }
+}
+
+/// Host-pointer wrapper of the fill variant: `image` is an output only
+extern "C" __attribute__((visibility("default")))
+int sphere_through_fill(const float *gx, const float *gy, const uint32_t *perm_, const uint8_t *mask_, size_t n, float background,
+                        float *image, uint64_t *hit_count) {
+    try {
+        FloatC dgx = FloatC::copy(gx, n), dgy = FloatC::copy(gy, n), img = empty<FloatC>(n);
+        UInt32C perm = UInt32C::copy(perm_, n);
+        MaskC mask = MaskC::copy(mask_, n);
+        int rc = sphere_through_fill_device(dgx.data(), dgy.data(), perm.data(), (const uint8_t *) mask.data(), n, background, img.data(),
+                                            hit_count);
+        if (rc) return rc;
+        auto host = img.to_host();
+        memcpy(image, host.data(), n * sizeof(float));
+        return 0;
+    } catch (const std::exception &e) {
+        fprintf(stderr, "sphere_through_fill: %s\n", e.what());
         return -3;
     }
 }

@@ -883,6 +883,28 @@ inline void store(void *mem, const T &value, const Mask &mask = true) { store_un
 //  reference's generic static array: hsum = ((c0 + c1) + c2) ..., dot = fmadd(a2, b2, fmadd(a1, b1,
 //  a0 * b0)) (array_static.h:948-960).
 // ---------------------------------------------------------------------------------------------
+namespace detail {
+    /// Component storage of Array<Value, Size>.  bool components copy ONE BY ONE: the implicit copy of a struct of bools is
+    /// a byte copy, and the gfx950 code generator does not forward the 1-bit store of a comparison result to the byte load
+    /// of such a copy -- every mask of a vectorize() kernel then made a round trip through scratch memory (a store, a load
+    /// and an s_waitcnt vmcnt(0) that also waited for every load in flight).
+    template <typename Value, size_t Size> struct ArrayStorage {
+        Value v[Size];
+        Value &operator[](size_t i) { return v[i]; }
+        const Value &operator[](size_t i) const { return v[i]; }
+    };
+    template <size_t Size> struct ArrayStorage<bool, Size> {
+        bool v[Size];
+        ArrayStorage() = default;
+        template <typename... Args, std::enable_if_t<sizeof...(Args) == Size && (std::is_same_v<Args, bool> && ...), int> = 0>
+        ArrayStorage(Args... args) : v{ args... } { }
+        ArrayStorage(const ArrayStorage &o) { for (size_t i = 0; i < Size; ++i) v[i] = o.v[i]; }
+        ArrayStorage &operator=(const ArrayStorage &o) { for (size_t i = 0; i < Size; ++i) v[i] = o.v[i]; return *this; }
+        bool &operator[](size_t i) { return v[i]; }
+        const bool &operator[](size_t i) const { return v[i]; }
+    };
+}
+
 /// (the default size 1 is the one-element packet that vectorize() instantiates kernels on: one slice per GPU lane)
 template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     using Value = Value_;
@@ -1054,7 +1076,7 @@ template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
         if constexpr (detail::has_gather_multi<Value, Index>::value &&
                       (is_diff_array_v<Value> ? !IsPermute : !is_diff_array_v<Index>)) {
             // device components sharing one index array: one kernel instead of Size
-            if (Value::template gather_multi_<Size>(source.m_data, r.m_data, index, detail::as<mask_t<Value>>(mask)))
+            if (Value::template gather_multi_<Size>(source.m_data.v, r.m_data.v, index, detail::as<mask_t<Value>>(mask)))
                 return r;
         }
         for (size_t i = 0; i < Size; ++i) r.m_data[i] = gather<Value, 0, true, IsPermute>(source.m_data[i], index, mask);
@@ -1085,7 +1107,7 @@ template <typename Value_, size_t Size_ = 1> struct Array : ArrayTag {
     }
 
 private:
-    Value m_data[Size_];
+    detail::ArrayStorage<Value_, Size_> m_data;
 };
 
 namespace detail {

@@ -16,13 +16,21 @@
       1. ek_hip_index_partition_create() groups the active entries of `index` by bucket of 4 Ki .. 512 Ki target entries
          (count + scan + partition: 14 B per entry, all streaming);
       2. ONE workgroup per bucket (k_vectorize_through below)
-           a. marks, in an LDS bitmap, the target entries that at least one active element points at   4 B per element
-           b. walks its slice of the target range IN ORDER: coalesced loads of the sources at the marked entries, f, coalesced
-              stores of the value where `hit`, and a second bitmap of the entries that were hit   sources + 4 B per target entry
-           c. counts the active elements whose entry was hit (what count(hit & mask) returns)          4 B per element (L2)
+           a. counts, in one LDS byte per target entry, the active elements that point at it             4 B per element
+           b. walks its slice of the target range IN ORDER: coalesced loads of the sources at the entries somebody points
+              at, f, coalesced stores of the value where `hit`; count(hit & mask) is the sum of the bytes of the entries
+              that were hit                                                                sources + 4 B per target entry
+         (buckets of 512 Ki entries do not fit the LDS as bytes: two bitmaps instead, marked / hit, and a second pass over
+         the bucket's list that counts the elements whose entry was hit; the same after a byte counter overflowed)
+      3. the workgroup that finishes last publishes the count to pinned host memory: the host synchronises the stream and
+         reads it -- no memset launch, no device -> host copy.
+
+    vectorize_through_fill(f, index, mask, fill_value, target, sources...) is `target = full(fill_value); vectorize_through(...)`
+    in one pass: step 2b writes EVERY entry (the fill value where nobody hit) with full-width stores.
 
     Results are identical to the element-order program: every element that points at entry j computes f(sources[j]) -- the same
-    value, so which of several duplicates writes last does not matter -- and an entry nobody points at is not touched.
+    value, so which of several duplicates writes last does not matter -- and an entry nobody points at is not touched (Fill:
+    holds the fill value).
 
     Requirements as for enoki/vectorize.h (hipcc translation unit, this header or vectorize.h first, user templates between
     ENOKI_DEVICE_CODE_BEGIN / END).  `f` takes one one-element packet per source and returns std::pair<Packet, mask_t<Packet>>.
@@ -30,6 +38,7 @@
 #pragma once
 
 #include <enoki/vectorize.h>
+#include <mutex>
 
 namespace enoki {
 
@@ -42,23 +51,52 @@ namespace detail {
         return f(Packet(v[Is])...);
     }
 
-    // LDS: two bitmaps of 2^shift bits (marked / hit); 1024 threads; one workgroup per bucket.  Every loop keeps several
-    // loads per lane in flight (8 list entries; 2 x 4 consecutive target entries per source): with one load per lane and
-    // iteration the kernel would be bound by memory latency, not bandwidth.
-    template <typename Func, size_t N>
+    /// What one call leaves behind for the host: {count(hit & mask), "a multiplicity counter overflowed"}.  `state` lives in
+    /// device memory and cleans up after itself (the workgroup that finishes last publishes the totals to the pinned host
+    /// slot and zeroes the state), so a call costs no memset launch and no device -> host copy: the host synchronises the
+    /// stream and reads two words of pinned memory.
+    struct ThroughState { unsigned long long total; unsigned int done, overflow; };
+
+    struct ThroughScratch {
+        std::mutex mutex;                       // held for the duration of a call (launch .. readback)
+        ThroughState *state = nullptr;          // device
+        volatile unsigned long long *host = nullptr;   // pinned: [0] = total, [1] = overflow
+    };
+    inline ThroughScratch &through_scratch() { static ThroughScratch s; return s; }
+
+    // One workgroup of 1024 threads per bucket of 2^shift target entries.  Every loop keeps several loads per lane in flight
+    // (16 list entries; 4 x 4 consecutive target entries per source): with one load per lane and iteration the kernel would
+    // be bound by memory latency, not bandwidth.
+    //
+    //   Counters (shift <= 17): LDS holds one BYTE per target entry, the number of active elements that point at it -- an entry
+    //     is marked when its byte is not zero, and count(hit & mask) is the sum of the bytes of the entries that were hit, so
+    //     the bucket's list is read ONCE.  A 256th duplicate of one entry would carry into its neighbour: the workgroup
+    //     notices (the atomic returns the old word), raises `overflow` and gives up, and the host repeats the call with
+    //     bitmaps (every store of the first attempt is repeated with the same value).
+    //   Bitmaps (any shift): two bitmaps of 2^shift bits (marked / hit), and a second pass over the list that counts the
+    //     elements whose entry was hit.
+    //   Fill: EVERY entry of the target is written -- f's value where an active element hit, `fill_value` elsewhere -- which
+    //     is `target = full(fill_value); scatter(target, ...)` without the separate pass over the target, and with full-width
+    //     stores instead of masked ones.
+    template <typename Func, size_t N, bool Fill, bool Counters>
     __global__ __launch_bounds__(1024) void k_vectorize_through(Func f, float *__restrict__ target, ThroughSources<N> src, size_t range,
-                                                                int shift, int vec_ok, const uint32_t *__restrict__ bucket_base,
-                                                                const uint32_t *__restrict__ local,
-                                                                unsigned long long *__restrict__ hit_count) {
-        extern __shared__ uint32_t through_bits[];
+                                                                int shift, int vec_ok, float fill_value,
+                                                                const uint32_t *__restrict__ bucket_base,
+                                                                const uint32_t *__restrict__ local, ThroughState *__restrict__ state,
+                                                                volatile unsigned long long *__restrict__ host) {
+        extern __shared__ uint32_t through_lds[];
         typedef float __attribute__((ext_vector_type(4))) float4v;
-        const uint32_t words = 1u << (shift - 5);
-        uint32_t *marked = through_bits, *hit = through_bits + words;
-        for (uint32_t w = threadIdx.x; w < 2 * words; w += 1024) through_bits[w] = 0u;
+        __shared__ unsigned wave_count[16];
+        __shared__ unsigned gave_up;
+        // Counters: 2^shift bytes;  bitmaps: 2 x 2^shift bits
+        const uint32_t words = Counters ? 1u << (shift - 2) : 2u << (shift - 5);
+        uint32_t *marked = through_lds, *hit = through_lds + (1u << (shift - 5));
+        for (uint32_t w = threadIdx.x; w < words; w += 1024) through_lds[w] = 0u;
+        if (threadIdx.x == 0) gave_up = 0u;
         __syncthreads();
         const uint32_t begin = bucket_base[blockIdx.x], end = bucket_base[blockIdx.x + 1];
         constexpr int U = 16;
-        // (a) which target entries does an active element point at?
+        // (a) which target entries does an active element point at (Counters: how many of them)?
         for (uint32_t base = begin; base < end; base += U * 1024) {
             uint32_t l[U];
 #pragma unroll
@@ -67,92 +105,223 @@ namespace detail {
                 l[k] = i < end ? __builtin_nontemporal_load(local + i) : ~0u;
             }
 #pragma unroll
-            for (int k = 0; k < U; ++k)
-                if (l[k] != ~0u) atomicOr(&marked[l[k] >> 5], 1u << (l[k] & 31u));
+            for (int k = 0; k < U; ++k) {
+                if (l[k] == ~0u) continue;
+                if constexpr (Counters) {
+                    const uint32_t sh = (l[k] & 3u) * 8u;
+                    const uint32_t old = atomicAdd(&through_lds[l[k] >> 2], 1u << sh);
+                    if (((old >> sh) & 255u) == 255u) gave_up = 1u;
+                } else {
+                    atomicOr(&marked[l[k] >> 5], 1u << (l[k] & 31u));
+                }
+            }
         }
         __syncthreads();
-        // (b) the bucket's slice of the target range, in order
-        const size_t first = (size_t) blockIdx.x << shift;
-        const uint32_t entries = (uint32_t) (range - first < ((size_t) 1 << shift) ? range - first : ((size_t) 1 << shift));
-        auto one = [&](uint32_t l, const float (&v)[N]) {
-            auto r = through_eval(f, v, std::make_index_sequence<N>());
-            if (r.second.coeff(0)) {
-                target[first + l] = r.first.coeff(0);
-                atomicOr(&hit[l >> 5], 1u << (l & 31u));
-            }
-        };
-        if (vec_ok) {
-            constexpr int V = 4;
-            for (uint32_t base = 0; base < entries; base += V * 4096) {
-                float4v v[V][N];
-                uint32_t lv[V], bits[V];
-#pragma unroll
-                for (int h = 0; h < V; ++h) {
-                    lv[h] = base + h * 4096 + threadIdx.x * 4;
-                    bits[h] = lv[h] + 4 <= entries ? (marked[lv[h] >> 5] >> (lv[h] & 31u)) & 15u : 0u;
-                    if (bits[h]) {
-#pragma unroll
-                        for (size_t s = 0; s < N; ++s)
-                            v[h][s] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(src.ptr[s] + first + lv[h]));
-                    }
-                }
-#pragma unroll
-                for (int h = 0; h < V; ++h) {
-                    if (!bits[h]) continue;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!((bits[h] >> j) & 1u)) continue;
-                        float in[N];
-#pragma unroll
-                        for (size_t s = 0; s < N; ++s) in[s] = v[h][s][j];
-                        one(lv[h] + j, in);
-                    }
-                }
-            }
-            // ragged end of the range (fewer than 4 entries left for a lane)
-            const uint32_t tail = entries & ~3u;
-            if (threadIdx.x < entries - tail) {
-                const uint32_t l = tail + threadIdx.x;
-                if ((marked[l >> 5] >> (l & 31u)) & 1u) {
+        unsigned count = 0;
+        const bool abandon = Counters && gave_up;
+        if (!abandon) {
+            // (b) the bucket's slice of the target range, in order
+            const size_t first = (size_t) blockIdx.x << shift;
+            const uint32_t entries = (uint32_t) (range - first < ((size_t) 1 << shift) ? range - first : ((size_t) 1 << shift));
+            // multiplicity of entry l (bitmaps: 0 / 1)
+            auto mult = [&](uint32_t l) -> uint32_t {
+                if constexpr (Counters) return (through_lds[l >> 2] >> ((l & 3u) * 8u)) & 255u;
+                else return (marked[l >> 5] >> (l & 31u)) & 1u;
+            };
+            // f at one marked entry; returns whether it hit
+            auto one = [&](uint32_t l, uint32_t m, const float (&v)[N], float &value) -> bool {
+                auto r = through_eval(f, v, std::make_index_sequence<N>());
+                if (!r.second.coeff(0)) return false;
+                value = r.first.coeff(0);
+                if constexpr (Counters) count += m;
+                else atomicOr(&hit[l >> 5], 1u << (l & 31u));
+                return true;
+            };
+            auto scalar_entry = [&](uint32_t l) {
+                const uint32_t m = mult(l);
+                float value = fill_value;
+                bool write = Fill;
+                if (m) {
                     float in[N];
 #pragma unroll
                     for (size_t s = 0; s < N; ++s) in[s] = src.ptr[s][first + l];
-                    one(l, in);
+                    write |= one(l, m, in, value);
+                }
+                if (write) target[first + l] = value;
+            };
+            if (vec_ok) {
+                // four groups of 4 consecutive entries per lane and step; the loads of step i + 1 are requested before
+                // the arithmetic of step i starts (two register sets), so f runs in the shadow of the memory system
+                constexpr int V = 4;
+                constexpr uint32_t kStep = V * 4096;
+                struct Set {
+                    float4v v[V][N];
+                    uint32_t lv[V], bits[V];          // Counters: the four multiplicity bytes;  bitmaps: four bits
+                };
+                auto load_set = [&](uint32_t base, Set &q) {
+#pragma unroll
+                    for (int h = 0; h < V; ++h) {
+                        q.lv[h] = base + h * 4096 + threadIdx.x * 4;
+                        q.bits[h] = 0u;
+                        if (q.lv[h] + 4 <= entries) {
+                            if constexpr (Counters) q.bits[h] = through_lds[q.lv[h] >> 2];
+                            else q.bits[h] = (marked[q.lv[h] >> 5] >> (q.lv[h] & 31u)) & 15u;
+                        }
+                        if (q.bits[h]) {
+#pragma unroll
+                            for (size_t s = 0; s < N; ++s)
+                                q.v[h][s] = __builtin_nontemporal_load(reinterpret_cast<const float4v *>(src.ptr[s] + first + q.lv[h]));
+                        }
+                    }
+                };
+                auto compute_set = [&](Set &q) {
+#pragma unroll
+                    for (int h = 0; h < V; ++h) {
+                        if (q.lv[h] + 4 > entries) continue;
+                        float4v out = { fill_value, fill_value, fill_value, fill_value };
+                        if (q.bits[h]) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const uint32_t m = Counters ? (q.bits[h] >> (8 * j)) & 255u : (q.bits[h] >> j) & 1u;
+                                if (!m) continue;
+                                float in[N], value;
+#pragma unroll
+                                for (size_t s = 0; s < N; ++s) in[s] = q.v[h][s][j];
+                                if (one(q.lv[h] + j, m, in, value)) {
+                                    if constexpr (Fill) out[j] = value;
+                                    else target[first + q.lv[h] + j] = value;
+                                }
+                            }
+                        }
+                        if constexpr (Fill) __builtin_nontemporal_store(out, reinterpret_cast<float4v *>(target + first + q.lv[h]));
+                    }
+                };
+                Set qa, qb;
+                if (entries) load_set(0, qa);
+                for (uint32_t base = 0; base < entries; base += 2 * kStep) {
+                    const bool second = base + kStep < entries;
+                    if (second) load_set(base + kStep, qb);
+                    compute_set(qa);
+                    if (second) {
+                        if (base + 2 * kStep < entries) load_set(base + 2 * kStep, qa);
+                        compute_set(qb);
+                    }
+                }
+                // ragged end of the range (fewer than 4 entries left for a lane)
+                const uint32_t tail = entries & ~3u;
+                if (threadIdx.x < entries - tail) scalar_entry(tail + threadIdx.x);
+            } else {
+                for (uint32_t l = threadIdx.x; l < entries; l += 1024) scalar_entry(l);
+            }
+            if constexpr (!Counters) {
+                __syncthreads();
+                // (c) count(hit & mask): the active elements whose entry was hit
+                for (uint32_t base = begin; base < end; base += U * 1024) {
+                    uint32_t l[U];
+#pragma unroll
+                    for (int k = 0; k < U; ++k) {
+                        const uint32_t i = base + k * 1024 + threadIdx.x;
+                        l[k] = i < end ? local[i] : ~0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < U; ++k)
+                        if (l[k] != ~0u) count += (hit[l[k] >> 5] >> (l[k] & 31u)) & 1u;
                 }
             }
-        } else {
-            for (uint32_t l = threadIdx.x; l < entries; l += 1024) {
-                if (!((marked[l >> 5] >> (l & 31u)) & 1u)) continue;
-                float in[N];
-#pragma unroll
-                for (size_t s = 0; s < N; ++s) in[s] = src.ptr[s][first + l];
-                one(l, in);
-            }
-        }
-        __syncthreads();
-        // (c) count(hit & mask): the active elements whose entry was hit
-        unsigned count = 0;
-        for (uint32_t base = begin; base < end; base += U * 1024) {
-            uint32_t l[U];
-#pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = base + k * 1024 + threadIdx.x;
-                l[k] = i < end ? local[i] : ~0u;
-            }
-#pragma unroll
-            for (int k = 0; k < U; ++k)
-                if (l[k] != ~0u) count += (hit[l[k] >> 5] >> (l[k] & 31u)) & 1u;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) count += __shfl_down(count, d, 64);
-        __shared__ unsigned wave_count[16];
         if ((threadIdx.x & 63) == 0) wave_count[threadIdx.x >> 6] = count;
         __syncthreads();
         if (threadIdx.x == 0) {
             unsigned long long total = 0;
             for (int w = 0; w < 16; ++w) total += wave_count[w];
-            if (total) atomicAdd(hit_count, total);
+            if (total) atomicAdd(&state->total, total);
+            if (abandon) atomicOr(&state->overflow, 1u);
+            __threadfence();
+            if (atomicAdd(&state->done, 1u) == gridDim.x - 1) {
+                // last one out: publish, and leave the state as the next call expects it
+                __threadfence();
+                host[0] = atomicExch(&state->total, 0ull);
+                host[1] = atomicExch(&state->overflow, 0u);
+                atomicExch(&state->done, 0u);
+                __threadfence_system();
+            }
         }
+    }
+
+    template <bool Fill, typename Func, typename... Sources>
+    size_t vectorize_through_impl(Func f, const HIPArray<uint32_t> &index, const HIPArray<bool> &mask, float fill_value,
+                                  HIPArray<float> &target, const Sources &... sources) {
+        static_assert((std::is_same_v<Sources, HIPArray<float>> && ...), "vectorize_through(): float32 source arrays expected");
+        constexpr size_t N = sizeof...(Sources);
+        static_assert(N >= 1, "vectorize_through(): at least one source array");
+        const char *what = "vectorize_through";
+        const size_t n = index.size();
+        size_t sizes[N] = { sources.size()... };
+        const size_t range = Fill ? sizes[0] : target.size();
+        for (size_t s = 0; s < N; ++s)
+            if (sizes[s] != range)
+                throw std::runtime_error("vectorize_through(): the sources and the target must have the same length");
+        if (mask.size() != n && mask.size() != 1)
+            throw std::runtime_error("vectorize_through(): the mask and the index array must have the same length");
+        if (Fill) {
+            if (range == 0) { target = HIPArray<float>(); return 0; }
+            if (n == 0) { target = HIPArray<float>::full_(fill_value, range); return 0; }
+            // a target of the right length is overwritten in place (a mapped image, say); anything else is replaced
+            if (target.size() == range) target.make_unique();
+            else target = HIPArray<float>::empty_(range);
+        } else {
+            if (n == 0 || range == 0) return 0;
+            target.make_unique();
+        }
+        ek_operand om = mask.operand();
+        ek_hip_index_partition *part = nullptr;
+        hip_check(ek_hip_index_partition_create(HIPArray<uint32_t>::Type, index.data(), &om, n, range, &part), what);
+        ek_hip_index_partition_info info;
+        ek_hip_index_partition_get(part, &info);
+        float *out = target.data();
+        ThroughSources<N> src{ { sources.data()... } };
+        int vec_ok = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
+        for (size_t s = 0; s < N; ++s) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(src.ptr[s]) & 15u) == 0;
+
+        ThroughScratch &scratch = through_scratch();
+        std::lock_guard<std::mutex> guard(scratch.mutex);
+        int rc = 0;
+        if (!scratch.state) {
+            void *state = nullptr, *host = nullptr;
+            rc = ek_hip_malloc(sizeof(ThroughState), &state);
+            if (!rc) rc = ek_hip_memset(state, 0, sizeof(ThroughState));
+            if (!rc) rc = ek_hip_host_malloc(2 * sizeof(unsigned long long), &host);
+            if (rc) {
+                if (state) ek_hip_free(state);
+                ek_hip_index_partition_destroy(part);
+                hip_check(rc, what);
+            }
+            scratch.state = (ThroughState *) state;
+            scratch.host = (volatile unsigned long long *) host;
+        }
+        hipStream_t stream = (hipStream_t) ek_hip_stream();
+        unsigned long long hits = 0;
+        // byte counters where the bucket's entries fit the LDS as bytes; bitmaps otherwise, and after a counter overflowed
+        for (int attempt = info.shift <= 17 ? 0 : 1; attempt < 2; ++attempt) {
+            const bool counters = attempt == 0;
+            const size_t lds = counters ? (size_t) 1 << info.shift : (size_t) 2 << (info.shift - 3);
+            auto kernel = counters ? k_vectorize_through<Func, N, Fill, true> : k_vectorize_through<Func, N, Fill, false>;
+            if (lds > 65536)
+                (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+            hipLaunchKernelGGL(kernel, dim3((unsigned) info.n_buckets), dim3(1024), lds, stream, f, out, src, range, info.shift, vec_ok,
+                               fill_value, info.bucket_base, info.local, scratch.state, scratch.host);
+            // algorithmic bytes: the bucket lists once (bitmaps: twice), the sources once, the target once
+            rc = ek_hip_note_launch("vectorize_through", n, (counters ? 4 : 8) * n + (N + 1) * 4 * range);
+            if (!rc) rc = ek_hip_sync();
+            if (rc) break;
+            hits = scratch.host[0];
+            if (!scratch.host[1]) break;          // no counter overflowed
+        }
+        ek_hip_index_partition_destroy(part);
+        hip_check(rc, what);
+        return (size_t) hits;
     }
 }
 
@@ -161,40 +330,15 @@ namespace detail {
 template <typename Func, typename... Sources>
 size_t vectorize_through(Func f, const HIPArray<uint32_t> &index, const HIPArray<bool> &mask, HIPArray<float> &target,
                          const Sources &... sources) {
-    static_assert((std::is_same_v<Sources, HIPArray<float>> && ...), "vectorize_through(): float32 source arrays expected");
-    constexpr size_t N = sizeof...(Sources);
-    static_assert(N >= 1, "vectorize_through(): at least one source array");
-    const size_t n = index.size(), range = target.size();
-    if (((sources.size() != range) || ...))
-        throw std::runtime_error("vectorize_through(): the sources and the target must have the same length");
-    if (n == 0 || range == 0) return 0;
-    ek_operand om = mask.operand();
-    ek_hip_index_partition *part = nullptr;
-    detail::hip_check(ek_hip_index_partition_create(HIPArray<uint32_t>::Type, index.data(), &om, n, range, &part), "vectorize_through");
-    ek_hip_index_partition_info info;
-    ek_hip_index_partition_get(part, &info);
-    target.make_unique();
-    float *out = target.data();
-    detail::ThroughSources<N> src{ { sources.data()... } };
-    int vec_ok = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
-    for (size_t s = 0; s < N; ++s) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(src.ptr[s]) & 15u) == 0;
-    void *counter = nullptr;
-    detail::hip_check(ek_hip_malloc(sizeof(unsigned long long), &counter), "vectorize_through");
-    detail::hip_check(ek_hip_memset(counter, 0, sizeof(unsigned long long)), "vectorize_through");
-    hipStream_t stream = (hipStream_t) ek_hip_stream();
-    const size_t lds = (size_t) 2 << (info.shift - 3);
-    auto kernel = detail::k_vectorize_through<Func, N>;
-    if (lds > 65536) (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    hipLaunchKernelGGL(kernel, dim3((unsigned) info.n_buckets), dim3(1024), lds, stream, f, out, src, range, info.shift, vec_ok,
-                       info.bucket_base, info.local, (unsigned long long *) counter);
-    // algorithmic bytes: the bucket lists twice, the sources and the target once
-    detail::hip_check(ek_hip_note_launch("vectorize_through", n, 8 * n + (N + 1) * 4 * range), "vectorize_through");
-    unsigned long long hits = 0;
-    int rc = ek_hip_memcpy_to_host(&hits, counter, sizeof(hits));       // synchronises
-    ek_hip_free(counter);
-    ek_hip_index_partition_destroy(part);
-    detail::hip_check(rc, "vectorize_through");
-    return (size_t) hits;
+    return detail::vectorize_through_impl<false>(f, index, mask, 0.f, target, sources...);
+}
+
+/// `target = full(fill_value, range); vectorize_through(f, index, mask, target, sources...)` in one pass: the target is
+/// (re)allocated with the length of the sources and EVERY entry is written.
+template <typename Func, typename... Sources>
+size_t vectorize_through_fill(Func f, const HIPArray<uint32_t> &index, const HIPArray<bool> &mask, float fill_value,
+                              HIPArray<float> &target, const Sources &... sources) {
+    return detail::vectorize_through_impl<true>(f, index, mask, fill_value, target, sources...);
 }
 
 } // namespace enoki

@@ -36,6 +36,15 @@ def run(fn, gx, gy, perm, mask):
     return img, hc.value
 
 
+def fill_entry(lib):
+    """sphere_through_fill(): `image = full(-1)` happens inside the call, the image passed in is an output only -- hand it
+    garbage to prove that"""
+    def fn(gx, gy, perm, mask, n, img, hc):
+        ctypes.memset(img, 0x5a, n.value * 4)
+        return lib.sphere_through_fill(gx, gy, perm, mask, n, ctypes.c_float(-1.0), img, hc)
+    return fn
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="oracle/_ref was not built")
 @pytest.mark.parametrize("res", [8, 64, 257])
 def test_oracle_cfg4_matches_reference_build(res):
@@ -68,7 +77,7 @@ def test_hip_cfg4_bit_exact(res):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("res", [8, 64, 257, 1024])
-@pytest.mark.parametrize("entry", ["sphere_fused", "sphere_fused_packed", "sphere_through"])
+@pytest.mark.parametrize("entry", ["sphere_fused", "sphere_fused_packed", "sphere_through", "sphere_through_fill"])
 def test_hip_cfg4_fused_bit_exact(res, entry):
     """the same program as ONE kernel through enoki::vectorize() (examples/sphere_fused.cpp): bit-identical image, with
     the pixel grid as two planes or as packed {x, y} records (ONE 8-byte lookup per ray, array.h gather_packed); and
@@ -76,7 +85,7 @@ def test_hip_cfg4_fused_bit_exact(res, entry):
     once, grid slices read and image slices written in order)"""
     lib = ctypes.CDLL(os.path.join(HERE, "..", "examples", "libsphere_fused.so"))
     args = scene(res, seed=res + 1)
-    gi, gh = run(getattr(lib, entry), *args)
+    gi, gh = run(fill_entry(lib) if entry == "sphere_through_fill" else getattr(lib, entry), *args)
     pi, ph = run(ol.port().lib.orc_cfg4, *args)
     assert gh == ph and np.array_equal(gi.view(np.uint32), pi.view(np.uint32))
     assert gh > 0 and gi.max() > 100
@@ -126,9 +135,18 @@ def test_vectorize_through_with_duplicate_and_sparse_indices():
         rng = np.random.default_rng(seed)
         idx = rng.integers(0, n, n).astype(np.uint32)              # duplicates, and pixels nobody points at
         idx[: n // 7] = idx[n // 7: 2 * (n // 7)][: n // 7]
-        gi, gh = run(lib.sphere_through, gx, gy, idx, mask)
         fi, fh = run(lib.sphere_fused, gx, gy, idx, mask)          # the per-element fused kernel: same semantics
-        assert gh == fh and np.array_equal(gi.view(np.uint32), fi.view(np.uint32)), res
-        none = np.zeros(n, np.uint8)                                # nothing active: the image is untouched, no hits
-        gi, gh = run(lib.sphere_through, gx, gy, idx, none)
-        assert gh == 0 and np.all(gi == -1.0)
+        for entry in (lib.sphere_through, fill_entry(lib)):
+            gi, gh = run(entry, gx, gy, idx, mask)
+            assert gh == fh and np.array_equal(gi.view(np.uint32), fi.view(np.uint32)), res
+            none = np.zeros(n, np.uint8)                            # nothing active: the image is untouched, no hits
+            gi, gh = run(entry, gx, gy, idx, none)
+            assert gh == 0 and np.all(gi == -1.0)
+        # more than 255 elements on one pixel: the byte counters of a bucket overflow and the call falls back to bitmaps
+        for dup in (255, 256, 1000, n):
+            heavy = idx.copy()
+            heavy[:dup] = heavy[0] = np.uint32(n // 2 + res // 2)   # a pixel the sphere covers
+            fi, fh = run(lib.sphere_fused, gx, gy, heavy, mask)
+            for entry in (lib.sphere_through, fill_entry(lib)):
+                gi, gh = run(entry, gx, gy, heavy, mask)
+                assert gh == fh and np.array_equal(gi.view(np.uint32), fi.view(np.uint32)), (res, dup)
