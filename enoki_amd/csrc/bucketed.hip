@@ -654,7 +654,10 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     Context &c = ctx();
     constexpr int Bins = bins_of<T>;
     const size_t lds = (size_t) Bins * sizeof(PairRec<T>);
-    if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp>, lds)) return rc;
+    // vectors per lane and step.  float: two (one: 6 % slower, four: 13 % slower, same box); double: one -- with two the
+    // kernel needs more than the 128 registers a 1024-thread workgroup leaves a lane (12 spilled; the adjoint: 250)
+    constexpr int VV = sizeof(T) == 8 ? 1 : 2;
+    if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp, VV>, lds)) return rc;
     // keep the OTHER half of a sincos pair instead of u: only when it is exactly that (sin reduced, cos kept or vice versa)
     const bool partner = keep && ROp != EK_REDUCE_NONE &&
                          ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN));
@@ -662,14 +665,11 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     if (keep && !*kept)
         if (int rc = ek_hip_malloc(b->n * sizeof(T), kept)) return rc;
     const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
-#define EK_FWD(VV)                                                                                                          \
-    hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,           \
-                       (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,                    \
-                       (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,                   \
-                       (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, \
-                       map_op, partner ? 1 : 0)
-    EK_FWD(2);          // two 4-element vectors per lane and step (one: 6 % slower, four: 13 % slower, same box)
-#undef EK_FWD
+    hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
+                       (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
+                       (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,
+                       (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets,
+                       map_op, partner ? 1 : 0);
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
     if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
@@ -705,15 +705,13 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
     Context &c = ctx();
     constexpr int Bins = bins_of<T>;
     const size_t lds = (size_t) C * Bins * sizeof(T);
-    if (int rc = allow_big_lds(k_bucket_accumulate<T, C>, lds)) return rc;
+    constexpr int VV = sizeof(T) == 8 ? 1 : 2;          // as in the forward kernel
+    if (int rc = allow_big_lds(k_bucket_accumulate<T, C, VV>, lds)) return rc;
     Scratch partials;
     if (int rc = partials.alloc((size_t) C * b->max_pieces * Bins * sizeof(T))) return rc;
-#define EK_ACC(VV)                                                                                                          \
-    hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,               \
-                       (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) u_src, (const T *) b->x_b,               \
-                       (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st)
-    EK_ACC(2);
-#undef EK_ACC
+    hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
+                       (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) u_src, (const T *) b->x_b,
+                       (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st);
     EK_LAUNCH_CHECK("bucket_accumulate", (size_t) C * b->n,
                     b->n * (sizeof(uint16_t) + (st.from_u ? sizeof(T) : 0) + (st.weighted ? sizeof(T) : 0)) +
                     (size_t) C * b->max_pieces * Bins * sizeof(T));

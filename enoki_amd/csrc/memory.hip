@@ -201,10 +201,11 @@ __global__ __launch_bounds__(256) void k_gather_records(TablePtrs<T, C> t, const
     Pack<T, R> got[N];
 #pragma unroll
     for (int k = 0; k < N; ++k) {
-        Pack<T, R> zero;
+        // (not `on ? rec[...] : zero`: a select between two records is a select between two ADDRESSES, and the zero record
+        // then lives in scratch memory)
 #pragma unroll
-        for (int c = 0; c < R; ++c) zero.v[c] = T(0);
-        got[k] = (pm.v[k] && e + k < n) ? rec[index_offset(pi.v[k])] : zero;
+        for (int c = 0; c < R; ++c) got[k].v[c] = T(0);
+        if (pm.v[k] && e + k < n) got[k] = rec[index_offset(pi.v[k])];
     }
 #pragma unroll
     for (int c = 0; c < C; ++c) {
