@@ -43,7 +43,7 @@ EXPORTS = [
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
     "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
-    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add",
+    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add",
     "ek_hip_bucketed_destroy", "ek_hip_index_partition_create", "ek_hip_index_partition_get", "ek_hip_index_partition_destroy", "ek_hip_gather_address",
 ]
 
@@ -448,12 +448,14 @@ class Bucketed:
     """u = op(A[index], x, C[index]) kept in bucket order (ek_hip_bucketed_*): reductions over map(u) and the adjoint
     scatter_add of the two gathers without a lookup that leaves the CU.  Keeps A, C alive; x and index may be dropped."""
 
-    def __init__(self, op, A, x, C, index):
+    HINT_ADJOINT = 1
+
+    def __init__(self, op, A, x, C, index, hints=0):
         self.A, self.C, self.dtype, self.K = A, C, A.dtype, A.n
         h = ctypes.c_void_p()
-        check(lib.ek_hip_bucketed_pair_create(A.ek, index.ek, TERNARY[op], ctypes.c_void_p(A.ptr), ctypes.c_void_p(C.ptr),
-                                              ctypes.c_size_t(A.n), ctypes.c_void_p(x.ptr), ctypes.c_void_p(index.ptr),
-                                              ctypes.c_size_t(index.n), ctypes.byref(h)))
+        check(lib.ek_hip_bucketed_pair_create_hinted(A.ek, index.ek, TERNARY[op], ctypes.c_void_p(A.ptr), ctypes.c_void_p(C.ptr),
+                                                     ctypes.c_size_t(A.n), ctypes.c_void_p(x.ptr), ctypes.c_void_p(index.ptr),
+                                                     ctypes.c_size_t(index.n), ctypes.c_uint(hints), ctypes.byref(h)))
         self.handle = h
 
     @staticmethod

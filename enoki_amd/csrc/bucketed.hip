@@ -97,11 +97,10 @@ __device__ __forceinline__ bool bucket_piece(const uint32_t *__restrict__ bucket
 template <typename T, int ROp, int V, int Map, bool KeepPartner = false>
 __device__ __forceinline__ void bucket_forward_stream(const PairRec<T> *__restrict__ rec, T (&acc)[4], T *__restrict__ u_out,
                                                       const uint16_t *__restrict__ pair_idx, const T *__restrict__ x_b,
-                                                      size_t begin, size_t end) {
+                                                      size_t begin, size_t end, uint32_t lmask) {
     using R = BucketReducer<ROp, T>;
-    constexpr int Bins = bins_of<T>;
     auto one = [&](uint32_t l, T x, int slot) -> T {
-        const PairRec<T> r = rec[l & (Bins - 1)];
+        const PairRec<T> r = rec[l & lmask];
         const T u = fma_t(r.a, x, r.c);
         if constexpr (KeepPartner) {
             static_assert(Map == EK_SIN || Map == EK_COS);
@@ -189,12 +188,13 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
                                                                         const T *__restrict__ x_b,
                                                                         const uint32_t *__restrict__ bucket_base,
                                                                         const uint32_t *__restrict__ piece_prefix, int n_buckets,
-                                                                        int map_op, int keep_partner) {
+                                                                        int map_op, int keep_partner, int shift) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
     __shared__ T wave_part[kBucketWaves];
     using R = BucketReducer<ROp, T>;
-    constexpr int Bins = bins_of<T>;
+    const int Bins = 1 << shift;
+    const uint32_t lmask = (uint32_t) Bins - 1u;
     int bucket;
     size_t begin, end;
     if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) {
@@ -217,18 +217,18 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
     T acc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) acc[k] = R::identity();
-#define EK_FWD_CASE(OP) case OP: bucket_forward_stream<T, ROp, V, OP>(rec, acc, u_out, pair_idx, x_b, begin, end); break;
+#define EK_FWD_CASE(OP) case OP: bucket_forward_stream<T, ROp, V, OP>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask); break;
     if constexpr (ROp == EK_REDUCE_NONE) {
-        bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end);
+        bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask);
     } else if (keep_partner && map_op == EK_SIN) {
-        bucket_forward_stream<T, ROp, V, EK_SIN, true>(rec, acc, u_out, pair_idx, x_b, begin, end);
+        bucket_forward_stream<T, ROp, V, EK_SIN, true>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask);
     } else if (keep_partner && map_op == EK_COS) {
-        bucket_forward_stream<T, ROp, V, EK_COS, true>(rec, acc, u_out, pair_idx, x_b, begin, end);
+        bucket_forward_stream<T, ROp, V, EK_COS, true>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask);
     } else {
         switch (map_op) {
             EK_FWD_CASE(EK_NEG) EK_FWD_CASE(EK_ABS) EK_FWD_CASE(EK_SQRT) EK_FWD_CASE(EK_RCP) EK_FWD_CASE(EK_RSQRT)
             EK_FWD_CASE(EK_SIN) EK_FWD_CASE(EK_COS) EK_FWD_CASE(EK_EXP) EK_FWD_CASE(EK_LOG)
-            default: bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end); break;
+            default: bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask); break;
         }
     }
 #undef EK_FWD_CASE
@@ -402,8 +402,7 @@ __device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], 
 template <typename T, int C, int V, int Map, int Spec = 0>
 __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, const BucketStreams<T, C> &st,
                                                          const uint16_t *__restrict__ pair_idx, const T *__restrict__ u_b,
-                                                         const T *__restrict__ x_b, size_t begin, size_t end) {
-    constexpr int Bins = bins_of<T>;
+                                                         const T *__restrict__ x_b, size_t begin, size_t end, int Bins) {
     constexpr bool Paired = C == 2 && sizeof(T) == 4;
     static_assert(Spec == 0 || (C == 2 && Map >= 0));
     const bool need_u = Spec == 1 || st.from_u != 0, need_x = Spec == 1 || st.weighted != 0;
@@ -502,10 +501,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
                                                                       const T *__restrict__ u_b, const T *__restrict__ x_b,
                                                                       const uint32_t *__restrict__ bucket_base,
                                                                       const uint32_t *__restrict__ piece_prefix, int n_buckets,
-                                                                      BucketStreams<T, C> st) {
+                                                                      BucketStreams<T, C> st, int shift) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T *acc = reinterpret_cast<T *>(lds_raw);                 // C tables of Bins entries; two f32 tables: Bins {t0, t1} pairs
-    constexpr int Bins = bins_of<T>;
+    const int Bins = 1 << shift;
     constexpr bool Paired = C == 2 && sizeof(T) == 4;
     int bucket;
     size_t begin, end;
@@ -522,8 +521,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
         if (first) { op = st.map_op[c]; first = false; }
         else uniform = uniform && st.map_op[c] == op;
     }
-#define EK_ACC_CASE(OP) case OP: bucket_accumulate_stream<T, C, V, OP>(acc, st, pair_idx, u_b, x_b, begin, end); break;
-#define EK_ACC_SPEC(OP) case OP: bucket_accumulate_stream<T, C, V, OP, 1>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+#define EK_ACC_CASE(OP) case OP: bucket_accumulate_stream<T, C, V, OP>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
+#define EK_ACC_SPEC(OP) case OP: bucket_accumulate_stream<T, C, V, OP, 1>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
     bool done = false;
     if constexpr (C == 2) {
         if (uniform && st.from_u == 3u && st.weighted == 2u) {         // (host side: the weighted stream is put second)
@@ -531,7 +530,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
             switch (op) {
                 EK_ACC_SPEC(EK_NEG) EK_ACC_SPEC(EK_ABS) EK_ACC_SPEC(EK_SQRT) EK_ACC_SPEC(EK_RCP) EK_ACC_SPEC(EK_RSQRT)
                 EK_ACC_SPEC(EK_SIN) EK_ACC_SPEC(EK_COS) EK_ACC_SPEC(EK_EXP) EK_ACC_SPEC(EK_LOG)
-                default: bucket_accumulate_stream<T, C, V, EK_COPY, 1>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+                default: bucket_accumulate_stream<T, C, V, EK_COPY, 1>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
             }
         }
     }
@@ -541,10 +540,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
         switch (op) {
             EK_ACC_CASE(EK_NEG) EK_ACC_CASE(EK_ABS) EK_ACC_CASE(EK_SQRT) EK_ACC_CASE(EK_RCP) EK_ACC_CASE(EK_RSQRT)
             EK_ACC_CASE(EK_SIN) EK_ACC_CASE(EK_COS) EK_ACC_CASE(EK_EXP) EK_ACC_CASE(EK_LOG)
-            default: bucket_accumulate_stream<T, C, V, EK_COPY>(acc, st, pair_idx, u_b, x_b, begin, end); break;
+            default: bucket_accumulate_stream<T, C, V, EK_COPY>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
         }
     } else {
-        bucket_accumulate_stream<T, C, V, -1>(acc, st, pair_idx, u_b, x_b, begin, end);
+        bucket_accumulate_stream<T, C, V, -1>(acc, st, pair_idx, u_b, x_b, begin, end, Bins);
     }
 #undef EK_ACC_CASE
     __syncthreads();
@@ -553,6 +552,148 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
     for (int c = 0; c < C; ++c) {
         T *out = partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
         for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? acc[2 * j + c] : acc[c * Bins + j];
+    }
+}
+
+// ---- 2 + 3 in one pass: the reduction of a sincos half AND the adjoint of the gathers --------------------------------
+// y = hsum(sin(u)) is linear in its seed: whatever gradient g the tape later sends down, the tables receive
+// g * sum(cos(u)) and g * sum(x cos(u)) per entry.  When the reduction is asked to KEEP the other half of sincos(u) -- the
+// sign that a derivative will be asked for -- the sums are formed right here, while u, its sincos and the bucket's table
+// slice are at hand: the LDS holds the {A, C} slice AND the two gradient tables of a half-size bucket (2 x 64 KiB), the kept
+// half is never written (4 B/elt) or read back (4 B/elt), (l16, x_b) is streamed once instead of twice, and the adjoint's
+// LDS round trips overlap the forward's arithmetic.  The tape's scatter_add of exactly these streams then only folds the
+// partial tables (ek_hip_bucketed_scatter_add); anything else it asks for takes the ordinary kernels.
+template <typename T, int V, int Map>
+__device__ __forceinline__ void bucket_early_stream(const PairRec<T> *__restrict__ rec, T *__restrict__ tables, T (&acc)[4],
+                                                    const uint16_t *__restrict__ pair_idx, const T *__restrict__ x_b, size_t begin,
+                                                    size_t end, int Bins) {
+    static_assert(Map == EK_SIN || Map == EK_COS);
+    constexpr bool Paired = sizeof(T) == 4;
+    const uint32_t lmask = (uint32_t) Bins - 1u;
+    // reduced half into `sum`, kept half m and x * m out
+    auto values = [&](uint32_t l, T x, T &sum, T &v0, T &v1) {
+        const PairRec<T> r = rec[l];
+        const T u = fma_t(r.a, x, r.c);
+        T sn, cs;
+        SinCosOp::apply(u, sn, cs);
+        sum = Map == EK_SIN ? sn : cs;
+        v0 = Map == EK_SIN ? cs : sn;
+        v1 = dev::safe_mul(x, v0);
+    };
+    auto one = [&](size_t i, bool on) {
+        const uint32_t l = on ? (uint32_t) pair_idx[i] & lmask : 0u;
+        T sum, v0, v1;
+        values(l, on ? x_b[i] : T(0), sum, v0, v1);
+        if (on) acc[0] += sum;
+        if constexpr (Paired) {
+            lds_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
+        } else {
+            lds_add<true>(&tables[l], v0, on);
+            lds_add<true>(&tables[Bins + l], v1, on);
+        }
+    };
+    const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
+    one(begin + threadIdx.x, begin + threadIdx.x < head_end);
+    constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;
+    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
+    auto fetch = [&](Step &s, size_t at) {
+#pragma unroll
+        for (int h = 0; h < V; ++h) {
+            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
+            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
+            load4<T, true>(x_b + e, s.px[h]);
+        }
+    };
+    auto apply = [&](const Step &s) {
+        constexpr int NB = 4 * V;
+        uint32_t l[NB];
+        T v0[NB], v1[NB];
+#pragma unroll
+        for (int h = 0; h < V; ++h) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int k = h * 4 + j;
+                l[k] = (uint32_t) s.pi[h].v[j] & lmask;
+                T sum;
+                values(l[k], s.px[h][j], sum, v0[k], v1[k]);
+                acc[j] += sum;
+            }
+        }
+        if constexpr (Paired) {
+            lds_add_pair_batch<NB>(reinterpret_cast<unsigned long long *>(tables), l, v0, v1);
+        } else {
+            lds_add_batch<T, NB>(tables, l, v0);
+            lds_add_batch<T, NB>(tables + Bins, l, v1);
+        }
+    };
+    size_t base = head_end;
+    if (base + kStep <= end) {
+        Step cur, next;
+        fetch(cur, base);
+        for (; base + 2 * kStep <= end; base += kStep) {
+            fetch(next, base + kStep);
+            apply(cur);
+            cur = next;
+        }
+        apply(cur);
+        base += kStep;
+    }
+    for (; base < end; base += kBucketThreads) one(base + threadIdx.x, base + threadIdx.x < end);
+}
+
+template <typename T, int V = 2>
+__global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
+                                                                                const T *__restrict__ table_a,
+                                                                                const T *__restrict__ table_c, size_t table_size,
+                                                                                int flip_a, int flip_c,
+                                                                                const uint16_t *__restrict__ pair_idx,
+                                                                                const T *__restrict__ x_b,
+                                                                                const uint32_t *__restrict__ bucket_base,
+                                                                                const uint32_t *__restrict__ piece_prefix,
+                                                                                int n_buckets, int map_op, int shift) {
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    const int Bins = 1 << shift;
+    PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
+    T *tables = reinterpret_cast<T *>(rec + Bins);          // f32: Bins {t0, t1} pairs under one lock;  f64: two tables
+    __shared__ T wave_part[kBucketWaves];
+    constexpr bool Paired = sizeof(T) == 4;
+    int bucket;
+    size_t begin, end;
+    if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) {
+        if (threadIdx.x == 0) partials[blockIdx.x] = T(0);
+        return;
+    }
+    const size_t first = (size_t) bucket * Bins;
+    for (int j = threadIdx.x; j < Bins; j += kBucketThreads) {
+        const size_t k = first + j;
+        T a = k < table_size ? table_a[k] : T(0), c = k < table_size ? table_c[k] : T(0);
+        if (flip_a) a = -a;
+        if (flip_c) c = -c;
+        rec[j] = PairRec<T>{ a, c };
+        tables[2 * j] = T(0);
+        tables[2 * j + 1] = T(0);
+    }
+    __syncthreads();
+    T acc[4] = { T(0), T(0), T(0), T(0) };
+    if (map_op == EK_SIN) bucket_early_stream<T, V, EK_SIN>(rec, tables, acc, pair_idx, x_b, begin, end, Bins);
+    else bucket_early_stream<T, V, EK_COS>(rec, tables, acc, pair_idx, x_b, begin, end, Bins);
+    T v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) wave_part[wave] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : T(0);
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
+        if (threadIdx.x == 0) partials[blockIdx.x] = v;
+    }
+    // table c (0: sum of the kept half, 1: sum of x * kept half) of this piece at table_partials + (c * gridDim.x + piece) * Bins
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        T *out = table_partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
+        for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? tables[2 * j + c] : tables[c * Bins + j];
     }
 }
 
@@ -573,9 +714,14 @@ struct Bucketed {
     void *m_b = nullptr;           // m_op(u) in bucket order: the kept half of a sincos pair (see ek_hip_bucketed_reduce)
     int m_op = EK_COPY;
     bool has_m = false;
+    int shift = 0;                 // buckets of 2^shift table entries: bin_shift_of<T>, or one less (EK_BUCKETED_HINT_ADJOINT)
+    void *early = nullptr;         // k_bucket_pair_forward_adjoint: per piece, sums of early_op(u) and of x * early_op(u) per entry
+    int early_op = EK_COPY;
+    bool has_early = false;
 
+    size_t bins() const { return (size_t) 1 << shift; }
     ~Bucketed() {
-        for (void *p : { meta, pair_idx, x_b, u_b, m_b })
+        for (void *p : { meta, pair_idx, x_b, u_b, m_b, early })
             if (p) ek_hip_free(p);
     }
 };
@@ -593,11 +739,12 @@ template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
     return EK_OK;
 }
 
-template <typename T, typename I>
+template <typename T, typename I, int Shift>
 static int bucketed_create(Bucketed *b, const T *x, const I *index) {
     RoctxRange range("enoki-hip: bucket partition");
     Context &c = ctx();
-    constexpr int Bins = bins_of<T>, Shift = bin_shift_of<T>;
+    constexpr int Bins = 1 << Shift;
+    b->shift = Shift;
     const size_t n = b->n;
     const int n_buckets = b->n_buckets = (int) ((b->table_size + Bins - 1) / Bins);
 
@@ -652,8 +799,8 @@ static int bucketed_create(Bucketed *b, const T *x, const I *index) {
 template <typename T, int ROp>
 static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep, int keep_op = EK_COPY) {
     Context &c = ctx();
-    constexpr int Bins = bins_of<T>;
-    const size_t lds = (size_t) Bins * sizeof(PairRec<T>);
+    const size_t Bins = b->bins();
+    const size_t lds = Bins * sizeof(PairRec<T>);
     // vectors per lane and step.  float: two (one: 6 % slower, four: 13 % slower, same box); double: one -- with two the
     // kernel needs more than the 128 registers a 1024-thread workgroup leaves a lane (12 spilled; the adjoint: 250)
     constexpr int VV = sizeof(T) == 8 ? 1 : 2;
@@ -669,7 +816,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
                        (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
                        (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,
                        (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets,
-                       map_op, partner ? 1 : 0);
+                       map_op, partner ? 1 : 0, b->shift);
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
     if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
@@ -682,9 +829,38 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     return EK_OK;
 }
 
+/// hsum of one half of sincos(u) with the adjoint of the gathers formed in the same pass (k_bucket_pair_forward_adjoint)
+template <typename T>
+static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, int keep_op) {
+    Context &c = ctx();
+    const size_t Bins = b->bins();
+    const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
+    constexpr int VV = sizeof(T) == 8 ? 1 : 2;
+    if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV>, lds)) return rc;
+    if (!b->early)
+        if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
+    const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
+    hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
+                       (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
+                       flip_a, flip_c, (const uint16_t *) b->pair_idx, (const T *) b->x_b, (const uint32_t *) b->bucket_base,
+                       (const uint32_t *) b->piece_prefix, b->n_buckets, map_op, b->shift);
+    EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
+                    b->n * (sizeof(uint16_t) + sizeof(T)) + 2 * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
+    b->has_early = true;
+    b->early_op = keep_op;
+    hipLaunchKernelGGL((k_bucket_reduce_final<T, EK_HSUM>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
+                       b->max_pieces);
+    EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    return EK_OK;
+}
+
 template <typename T>
 static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bool keep, int keep_op) {
     RoctxRange range("enoki-hip: bucket-ordered gather + fma + reduction");
+    // a plan with half-size buckets was made for this: the sum of one half of sincos(u) whose other half is to be kept
+    if (b->shift < bin_shift_of<T> && reduce_op == EK_HSUM && keep && !b->has_u && !b->has_m && !b->has_early &&
+        ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN)))
+        return bucketed_forward_adjoint_launch<T>(b, out, map_op, keep_op);
     if (b->has_m && map_op == b->m_op) return ek_hip_reduce(reduce_op, b->type, out, b->m_b, b->n);   // the kept half itself
     if (b->has_u) {
         // u already exists in bucket order: an ordinary reduction over it
@@ -703,7 +879,7 @@ static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bo
 template <typename T, int C>
 static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams<T, C> &st, const void *u_src, unsigned fresh) {
     Context &c = ctx();
-    constexpr int Bins = bins_of<T>;
+    const size_t Bins = b->bins();
     const size_t lds = (size_t) C * Bins * sizeof(T);
     constexpr int VV = sizeof(T) == 8 ? 1 : 2;          // as in the forward kernel
     if (int rc = allow_big_lds(k_bucket_accumulate<T, C, VV>, lds)) return rc;
@@ -711,14 +887,15 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
     if (int rc = partials.alloc((size_t) C * b->max_pieces * Bins * sizeof(T))) return rc;
     hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
                        (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) u_src, (const T *) b->x_b,
-                       (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st);
+                       (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st, b->shift);
     EK_LAUNCH_CHECK("bucket_accumulate", (size_t) C * b->n,
                     b->n * (sizeof(uint16_t) + (st.from_u ? sizeof(T) : 0) + (st.weighted ? sizeof(T) : 0)) +
                     (size_t) C * b->max_pieces * Bins * sizeof(T));
     FoldTargets<T, C> targets;
     for (int s = 0; s < C; ++s) targets.table[s] = bases[s];
     hipLaunchKernelGGL((k_bin_fold_pieces<T, C>), dim3((unsigned) ((b->table_size + 255) / 256), C), dim3(256), 0, c.stream, targets,
-                       (const T *) partials.ptr, (const uint32_t *) b->piece_prefix, b->table_size, (size_t) b->max_pieces * Bins, fresh);
+                       (const T *) partials.ptr, (const uint32_t *) b->piece_prefix, b->table_size, (size_t) b->max_pieces * Bins, fresh,
+                       b->shift);
     EK_LAUNCH_CHECK("scatter_add_fold", (size_t) C * b->table_size,
                     (size_t) C * ((size_t) b->max_pieces * Bins * sizeof(T) + 2 * b->table_size * sizeof(T)));
     return EK_OK;
@@ -728,6 +905,37 @@ template <typename T>
 static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                 const uint64_t *imm_bits, const int *weighted, const int *fresh) {
     RoctxRange range("enoki-hip: bucket-ordered scatter_add");
+    if (b->has_early && count >= 1 && count <= 2) {
+        // exactly the streams that the forward pass summed already -- early_op(u), and x * early_op(u)?  Fold them.
+        bool match = true;
+        for (int s = 0; s < count; ++s)
+            match = match && from_u[s] && (map_ops ? map_ops[s] : (int) EK_COPY) == b->early_op;
+        if (count == 2) match = match && (weighted[0] != 0) != (weighted[1] != 0);
+        if (match) {
+            Context &c = ctx();
+            const size_t stride = (size_t) b->max_pieces * b->bins();
+            const unsigned grid = (unsigned) ((b->table_size + 255) / 256);
+            if (count == 2) {
+                // partial table 0: unweighted, 1: weighted
+                const int s_plain = weighted[0] ? 1 : 0, s_weighted = 1 - s_plain;
+                FoldTargets<T, 2> targets;
+                targets.table[0] = (T *) bases[s_plain];
+                targets.table[1] = (T *) bases[s_weighted];
+                const unsigned fr = fresh ? ((fresh[s_plain] ? 1u : 0u) | (fresh[s_weighted] ? 2u : 0u)) : 0u;
+                hipLaunchKernelGGL((k_bin_fold_pieces<T, 2>), dim3(grid, 2), dim3(256), 0, c.stream, targets, (const T *) b->early,
+                                   (const uint32_t *) b->piece_prefix, b->table_size, stride, fr, b->shift);
+            } else {
+                FoldTargets<T, 1> targets;
+                targets.table[0] = (T *) bases[0];
+                hipLaunchKernelGGL((k_bin_fold_pieces<T, 1>), dim3(grid, 1), dim3(256), 0, c.stream, targets,
+                                   (const T *) b->early + (weighted[0] ? stride : 0), (const uint32_t *) b->piece_prefix,
+                                   b->table_size, stride, (fresh && fresh[0]) ? 1u : 0u, b->shift);
+            }
+            EK_LAUNCH_CHECK("scatter_add_fold", (size_t) count * b->table_size,
+                            (size_t) count * (stride * sizeof(T) + 2 * b->table_size * sizeof(T)));
+            return EK_OK;
+        }
+    }
     bool need_u = false, all_kept = b->has_m;
     for (int s = 0; s < count; ++s) {
         need_u = need_u || from_u[s];
@@ -836,6 +1044,11 @@ int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size
 
 int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
                                 const void *x, const void *index, size_t n, ek_hip_bucketed **out) {
+    return ek_hip_bucketed_pair_create_hinted(type, index_type, op, table_a, table_c, table_size, x, index, n, 0u, out);
+}
+
+int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
+                                       const void *x, const void *index, size_t n, unsigned hints, ek_hip_bucketed **out) {
     if (int rc = ensure_init()) return rc;
     if (!out || !table_a || !table_c || !x || !index) return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): null pointer");
     *out = nullptr;
@@ -850,8 +1063,17 @@ int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *ta
     b->table_a = table_a; b->table_c = table_c;
     int rc;
     // valid int32 indices are non-negative: same bits as uint32
-    if (type == EK_F32) rc = bucketed_create<float, uint32_t>(b, (const float *) x, (const uint32_t *) index);
-    else rc = bucketed_create<double, uint32_t>(b, (const double *) x, (const uint32_t *) index);
+    // EK_BUCKETED_HINT_ADJOINT: buckets of half the size, so that a bucket's table slice AND its two gradient tables fit the LDS
+    // together (k_bucket_pair_forward_adjoint) -- when the table still fits kMaxBuckets of those
+    const size_t bins = type == EK_F64 ? (size_t) bins_of<double> : (size_t) bins_of<float>;
+    const bool half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint && table_size <= (size_t) kMaxBuckets * (bins / 2);
+    if (type == EK_F32) {
+        if (half) rc = bucketed_create<float, uint32_t, bin_shift_of<float> - 1>(b, (const float *) x, (const uint32_t *) index);
+        else rc = bucketed_create<float, uint32_t, bin_shift_of<float>>(b, (const float *) x, (const uint32_t *) index);
+    } else {
+        if (half) rc = bucketed_create<double, uint32_t, bin_shift_of<double> - 1>(b, (const double *) x, (const uint32_t *) index);
+        else rc = bucketed_create<double, uint32_t, bin_shift_of<double>>(b, (const double *) x, (const uint32_t *) index);
+    }
     if (rc != EK_OK) { delete b; return rc; }
     *out = b;
     return EK_OK;

@@ -638,16 +638,17 @@ template <typename T, int C> struct FoldTargets { T *table[C]; };
 template <typename T, int C>
 __global__ __launch_bounds__(256) void k_bin_fold_pieces(FoldTargets<T, C> targets, const T *__restrict__ partials,
                                                          const uint32_t *__restrict__ piece_prefix, size_t table_size,
-                                                         size_t partial_stride, unsigned fresh = 0u) {
+                                                         size_t partial_stride, unsigned fresh = 0u,
+                                                         int shift = bin_shift_of<T>) {
     size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
     if (k >= table_size) return;
     using U = wrap_t<T>;
     T *__restrict__ target = targets.table[blockIdx.y];
     partials += (size_t) blockIdx.y * partial_stride;
-    const uint32_t b = (uint32_t) (k >> bin_shift_of<T>), local = (uint32_t) (k & (bins_of<T> - 1));
+    const uint32_t b = (uint32_t) (k >> shift), local = (uint32_t) (k & (((size_t) 1 << shift) - 1));
     T s = ((fresh >> blockIdx.y) & 1u) ? T(0) : target[k];       // fresh: the table holds no data yet, its sums are written
     for (uint32_t p = piece_prefix[b]; p < piece_prefix[b + 1]; ++p)
-        s = (T) ((U) s + (U) partials[(size_t) p * bins_of<T> + local]);
+        s = (T) ((U) s + (U) partials[((size_t) p << shift) + local]);
     target[k] = s;
 }
 

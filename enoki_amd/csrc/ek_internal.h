@@ -31,6 +31,7 @@ struct Tuning {
     int deterministic = 0;        // 1: fp scatter_add always takes the bit-reproducible sorted path (ENOKI_HIP_DETERMINISTIC)
     int gather_records = 1;       // struct gathers through staged {x, y, ..} records: 1 by size, 2 always, 0 never
     int bucket_ordered = 1;       // gather -> fma -> {reduction, scatter_add} chains in bucket order (bucketed.hip); 0: element order only
+    int early_adjoint = 1;        // EK_BUCKETED_HINT_ADJOINT is honoured (half-size buckets, adjoint sums formed in the forward pass)
 };
 
 struct Context {

@@ -189,11 +189,11 @@ namespace detail {
         }
 
         /// The bucket partition of a kind-2 node (built on first use); nullptr when the library does not cover the shape
-        ek_hip_bucketed *bucketed() {
+        ek_hip_bucketed *bucketed(unsigned hints = 0) {
             Deferred *d = deferred;
             if (!d->bucketed) {
-                int rc = ek_hip_bucketed_pair_create(d->type, d->index_type, d->op, d->table->ptr, d->table2->ptr, d->table->size,
-                                                     d->arg0->ptr, d->index->ptr, size, &d->bucketed);
+                int rc = ek_hip_bucketed_pair_create_hinted(d->type, d->index_type, d->op, d->table->ptr, d->table2->ptr, d->table->size,
+                                                            d->arg0->ptr, d->index->ptr, size, hints, &d->bucketed);
                 if (rc == EK_ERR_UNSUPPORTED) return nullptr;
                 hip_check(rc, "HIPArray (bucket partition)");
             }
@@ -828,7 +828,10 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if constexpr (!IsFloat) {
             return false;
         } else {
-            ek_hip_bucketed *b = u->bucketed();
+            // the sum of one half of an unevaluated sincos pair whose other half is still held: the shape of a derivative that
+            // the tape will ask for (see ek_hip_bucketed_pair_create_hinted)
+            const bool adjoint_expected = op == EK_HSUM && ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN));
+            ek_hip_bucketed *b = u->bucketed(adjoint_expected ? (unsigned) EK_BUCKETED_HINT_ADJOINT : 0u);
             if (!b) return false;
             // somebody else can still ask for u (the cos(u) of the derivative, a user handle): keep it in bucket order
             const int keep = u->ref_count > held_by_consumer ? 1 : 0;

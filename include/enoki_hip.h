@@ -145,7 +145,7 @@ EK_API int ek_hip_graph_end(ek_hip_graph **out);
 EK_API int ek_hip_graph_launch(ek_hip_graph *graph);
 EK_API uint64_t ek_hip_graph_launch_count(const ek_hip_graph *graph);   /* kernel launches inside one replay */
 EK_API int ek_hip_graph_destroy(ek_hip_graph *graph);
-EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic", "gather_records", "bucket_ordered" */
+EK_API int ek_hip_set_tuning(const char *key, int value);   /* "reduce_blocks_per_cu", "scatter_add_binned", "deterministic", "gather_records", "bucket_ordered", "early_adjoint" */
 /* Per-kernel timing: between begin and end one HIP event is recorded on the library stream after every
    launch.  ek_hip_profile_end() synchronizes and returns a malloc'd JSON array (caller free()s) of
    {"kernel", "launches", "total_ms", "bytes", "elements"}; `bytes` are the ALGORITHMIC bytes of the
@@ -255,12 +255,24 @@ EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_
  *                 the scalar imm_bits[c];  count 1..4 tables of table_size entries.  fresh (may be NULL): fresh[c] != 0 says
  *                 that table c holds no data yet -- a gradient buffer that would otherwise be zero-filled first: its sums are
  *                 WRITTEN (bases[c][k] = sum), saving the fill and the read of the old contents.
+ *   create_hinted hints = EK_BUCKETED_HINT_ADJOINT: the caller expects `reduce(EK_HSUM, sin | cos, keep the other half)` followed
+ *                 by the scatter_add of that half and of x times that half -- y = hsum(sin(u)) recorded on a tape whose gathers
+ *                 need gradients (autodiff.cpp:899-918 gather, :1191-1199 the edge product).  Because that adjoint is linear in
+ *                 its seed, the partition is then made with buckets of HALF the size, the reduce call forms both sums in the
+ *                 same pass over (l16, x) -- table slice and gradient tables share the LDS; the kept half is neither written nor
+ *                 read back -- and the scatter_add call only folds the per-piece tables.  Any other sequence of calls on a
+ *                 hinted object works as on an unhinted one.  Ignored for tables beyond 256 half-size buckets and when
+ *                 ek_hip_set_tuning("early_adjoint", 0).
  * Values of u are bit-identical to the element-order kernels; reductions and sums differ by the ORDER of their fp
  * additions only (unspecified, like ek_hip_reduce / ek_hip_scatter_add mode 0). */
 typedef struct ek_hip_bucketed ek_hip_bucketed;
+enum { EK_BUCKETED_HINT_ADJOINT = 1 };
 EK_API int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n);
 EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c,
                                        size_t table_size, const void *x, const void *index, size_t n, ek_hip_bucketed **out);
+EK_API int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *table_a, const void *table_c,
+                                              size_t table_size, const void *x, const void *index, size_t n, unsigned hints,
+                                              ek_hip_bucketed **out);
 EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values, int keep_op);
 EK_API int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                        const uint64_t *imm_bits, const int *weighted, const int *fresh);

@@ -258,6 +258,11 @@ int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *a,
     *out = b;
     return EK_OK;
 }
+int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *a, const void *c, size_t table_size, const void *x,
+                                       const void *index, size_t n, unsigned /* hints: this stand-in works in element order */,
+                                       ek_hip_bucketed **out) {
+    return ek_hip_bucketed_pair_create(type, index_type, op, a, c, table_size, x, index, n, out);
+}
 int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int keep, int /* keep_op: a hint, u is kept */) {
     ++g_bucketed_reduces;
     float *u = (float *) malloc(b->n * sizeof(float));

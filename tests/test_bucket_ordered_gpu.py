@@ -143,9 +143,32 @@ def test_backward_reuses_the_partition(ad):
         return ad.detach(y).numpy(), ad.gradient(dA).numpy(), ad.gradient(dB).numpy()
 
     (y, gA, gB), ks = kernels(ad, lambda: step(A, B, x, idx))
-    # ONE count / scan / partition per step, in the forward; the adjoint only accumulates and folds
-    assert ks.get("bucket_partition") == 1 and ks.get("bucket_count") == 1 and ks.get("bucket_accumulate") == 1, ks
-    assert not any(k in ks for k in ("scatter_add_partition", "scatter_add_count", "gather_pair_fmadd", "sincos", "hsum_map")), ks
+    # ONE count / scan / partition per step, in the forward; hsum(sin(u)) with cos(u) still held by the tape is the shape of a
+    # derivative: the sums of cos(u) and x cos(u) per table entry are formed in the SAME pass (EK_BUCKETED_HINT_ADJOINT) and
+    # the backward sweep only folds them
+    assert ks.get("bucket_partition") == 1 and ks.get("bucket_count") == 1 and ks.get("bucket_pair_fma_reduce_adjoint") == 1, ks
+    assert ks.get("scatter_add_fold") == 1, ks
+    assert not any(k in ks for k in ("scatter_add_partition", "scatter_add_count", "gather_pair_fmadd", "sincos", "hsum_map",
+                                     "bucket_accumulate", "bucket_pair_fma_reduce")), ks
+    # a seed other than 1 is not what was summed (0.5 * cos(u) is an evaluated array): the ordinary scatter_add, same values
+    def step_scaled():
+        dA, dB = ad.Float32(A), ad.Float32(B)
+        ad.set_requires_gradient(dA); ad.set_requires_gradient(dB)
+        di = ad.UInt32(idx)
+        y = ad.hsum(ad.sin(ad.fmadd(ad.gather(dA, di), ad.Float32(x), ad.gather(dB, di)))) * ad.Float32(0.5)
+        ad.backward(y)
+        return ad.gradient(dA).numpy(), ad.gradient(dB).numpy()
+    (hA, hB), ks2 = kernels(ad, step_scaled)
+    assert ks2.get("bucket_partition") == 1, ks2
+    assert np.all(np.abs(hA - 0.5 * t["gA"]) <= t["gA_bound"]) and np.all(np.abs(hB - 0.5 * t["gB"]) <= t["gB_bound"])
+    # switched off: forward and adjoint are two passes again
+    ad.hip_set_tuning("early_adjoint", 0)
+    try:
+        (y0, gA0, gB0), ks0 = kernels(ad, lambda: step(A, B, x, idx))
+        assert ks0.get("bucket_accumulate") == 1 and ks0.get("bucket_pair_fma_reduce") == 1, ks0
+        assert np.all(np.abs(gA0 - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(gB0 - t["gB"]) <= t["gB_bound"])
+    finally:
+        ad.hip_set_tuning("early_adjoint", 1)
     assert abs(float(y[0]) - t["y"]) <= t["y_bound"]
     assert np.all(np.abs(gA - t["gA"]) <= t["gA_bound"]) and np.all(np.abs(gB - t["gB"]) <= t["gB_bound"])
     # integer-valued data: sin / cos are not exact, so take the exact part -- y = hsum(u), grads x and 1 -- via a linear loss

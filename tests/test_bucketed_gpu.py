@@ -146,6 +146,94 @@ def test_scatter_add_cos_pair_within_class_d(capi, dtype):
             assert (err <= bound).all(), (forward_first, float((err / bound).max()))
 
 
+def launches(capi, fn):
+    capi.profile_begin()
+    fn()
+    return {k["kernel"]: k["launches"] for k in capi.profile_end() if k["launches"]}
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("op", ["fmadd", "fnmsub"])
+@pytest.mark.parametrize("half", ["sin", "cos"])
+def test_hinted_plan_forms_the_adjoint_in_the_forward_pass(capi, dtype, op, half):
+    """EK_BUCKETED_HINT_ADJOINT: reduce(hsum, sin, keep cos) sums cos(u) and x cos(u) per table entry in the same pass (half-size
+    buckets: table slice and gradient tables share the LDS); the scatter_add of exactly those streams only folds.  Same
+    multisets as the unhinted object, so the same class-D bounds; fresh targets are written, others added to."""
+    other = "cos" if half == "sin" else "sin"
+    K, n = (1 << 16) + 1, (1 << 20) + 17
+    A, C, x, idx = make(dtype, n, K, seed=21)
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    u = element_order_u(capi, op, dA, dx, dC, di)
+    red = capi.unary(half, u).numpy().astype(np.float64)
+    kept = capi.unary(other, u).numpy().astype(np.float64)
+    ii = idx.astype(np.int64)
+    cnt = np.bincount(ii, minlength=K)
+    b = capi.Bucketed(op, dA, dx, dC, di, hints=capi.Bucketed.HINT_ADJOINT)
+    ks = launches(capi, lambda: b.reduce("hsum", half, keep=True, keep_op=other))
+    assert ks.get("bucket_pair_fma_reduce_adjoint") == 1 and "bucket_pair_fma_reduce" not in ks, ks
+    b2 = capi.Bucketed(op, dA, dx, dC, di, hints=capi.Bucketed.HINT_ADJOINT)
+    y = float(b2.reduce("hsum", half, keep=True, keep_op=other).numpy()[0])
+    assert abs(y - red.sum()) <= EPS[dtype] * depth(n) * np.abs(red).sum()
+    for b_, order, fresh in ((b, (False, True), (1, 0)), (b2, (True, False), (0, 0))):
+        # targets: one "fresh" (garbage that must be overwritten), one holding 1.0 (added to);  both orders of the two streams
+        T = [up(capi, np.full(K, 7.0 if f else 1.0, dtype)) for f in fresh]
+        ks = launches(capi, lambda: b_.scatter_add(T, [(other, 0, w) for w in order], fresh=list(fresh)))
+        assert ks == {"scatter_add_fold": 1}, ks
+        for t, w, f in zip(T, order, fresh):
+            terms = (kept * x.astype(np.float64) if w else kept).astype(dtype).astype(np.float64)
+            ref = (0.0 if f else 1.0) + np.bincount(ii, weights=terms, minlength=K)
+            bound = EPS[dtype] * ((cnt + 1) * (1.0 + np.bincount(ii, weights=np.abs(terms), minlength=K))) + 1e-300
+            err = np.abs(t.numpy().astype(np.float64) - ref)
+            assert (err <= bound).all(), (w, f, float((err / bound).max()))
+    # one stream only, and a second fold of the same sums
+    t = up(capi, np.zeros(K, dtype))
+    b.scatter_add([t], [(other, 0, True)])
+    b.scatter_add([t], [(other, 0, True)])
+    terms = (kept * x.astype(np.float64)).astype(dtype).astype(np.float64)
+    ref = 2.0 * np.bincount(ii, weights=terms, minlength=K)
+    assert (np.abs(t.numpy().astype(np.float64) - ref) <= 2 * EPS[dtype] * (cnt + 1) * np.bincount(ii, weights=np.abs(terms), minlength=K) + 1e-300).all()
+    # anything else on the same object: the ordinary kernels (u is rebuilt in bucket order)
+    t = up(capi, np.zeros(K, dtype))
+    ks = launches(capi, lambda: b.scatter_add([t], [(half, 0, False)]))
+    assert ks.get("bucket_accumulate") == 1, ks
+    ref = np.bincount(ii, weights=red, minlength=K)
+    assert (np.abs(t.numpy().astype(np.float64) - ref) <= EPS[dtype] * cnt * np.bincount(ii, weights=np.abs(red), minlength=K) + 1e-300).all()
+    um = u.numpy()
+    assert bits_equal(np.array([b.reduce("hmax", None).numpy()[0]]), np.array([um.max()]))
+    b.destroy(); b2.destroy()
+
+
+def test_hinted_plan_integer_data_is_exact_and_hint_can_be_ignored(capi):
+    """A = C = 0: every u is 0, the kept half cos(0) is exactly 1, and the sums are exact counts / exact sums of the
+    integer-valued x -- any order of additions gives the same bits"""
+    K, n = (1 << 16) + 3, (1 << 19) + 5
+    rng = np.random.default_rng(2)
+    A = np.zeros(K, np.float32); x = rng.integers(-2, 3, n).astype(np.float32)
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    dA, dx, di = up(capi, A), up(capi, x), up(capi, idx)
+    for tuning in (1, 0):
+        capi.set_tuning("early_adjoint", tuning)
+        try:
+            b = capi.Bucketed("fmadd", dA, dx, dA, di, hints=capi.Bucketed.HINT_ADJOINT)
+            ks = launches(capi, lambda: b.reduce("hsum", "sin", keep=True, keep_op="cos"))
+            assert ("bucket_pair_fma_reduce_adjoint" in ks) == bool(tuning), ks
+            g1, gx = up(capi, np.zeros(K, np.float32)), up(capi, np.zeros(K, np.float32))
+            b.scatter_add([g1, gx], [("cos", 0, False), ("cos", 0, True)])
+            assert np.array_equal(g1.numpy(), np.bincount(idx, minlength=K).astype(np.float32))
+            assert np.array_equal(gx.numpy(), np.bincount(idx, weights=x.astype(np.float64), minlength=K).astype(np.float32))
+            b.destroy()
+        finally:
+            capi.set_tuning("early_adjoint", 1)
+    # tables beyond 256 half-size buckets: the hint is ignored, the object works as before
+    K2 = (200 << 14) + 5
+    A2 = up(capi, np.zeros(K2, np.float32))
+    i2 = up(capi, rng.integers(0, K2, n).astype(np.uint32))
+    b = capi.Bucketed("fmadd", A2, dx, A2, i2, hints=capi.Bucketed.HINT_ADJOINT)
+    ks = launches(capi, lambda: b.reduce("hsum", "sin", keep=True, keep_op="cos"))
+    assert "bucket_pair_fma_reduce" in ks and "bucket_pair_fma_reduce_adjoint" not in ks, ks
+    b.destroy()
+
+
 def test_not_applicable_shapes_are_refused(capi):
     assert not capi.Bucketed.applicable(np.float32, np.uint32, 1 << 14, 1 << 20)        # one bucket
     assert not capi.Bucketed.applicable(np.float32, np.uint32, (256 << 14) + 1, 1 << 20)  # more than 256 buckets

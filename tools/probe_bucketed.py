@@ -18,13 +18,19 @@ idx = capi.Buf.from_numpy(rng.integers(0, K, n).astype(np.uint32))
 out = {}
 
 
-def bucketed():
-    b = capi.Bucketed("fmadd", A, x, B, idx)
+def bucketed(hints=0, key=""):
+    b = capi.Bucketed("fmadd", A, x, B, idx, hints=hints)
     out["y"] = b.reduce("hsum", "sin", keep=True, keep_op="cos")      # what DiffArray::sin_ leads to: sincos, cos kept for the adjoint
     gA, gB = capi.fill(np.float32, 0, K), capi.fill(np.float32, 0, K)
     b.scatter_add([gB, gA], [("cos", 0, False), ("cos", 0, True)])
-    out["gA"], out["gB"] = gA, gB
+    out["gA" + key], out["gB" + key] = gA, gB
+    if key:
+        out["y" + key] = out["y"]
     b.destroy()
+
+
+def early():
+    bucketed(capi.Bucketed.HINT_ADJOINT, "_early")
 
 
 def element_order():
@@ -36,7 +42,7 @@ def element_order():
 
 
 print(f"# tools/probe_bucketed.py on 1 x MI355X: n = 2^{logn}, K = 2^{logk}, pieces per CU = {os.environ.get('ENOKI_HIP_BUCKET_PIECES_PER_CU', '1')}")
-for name, fn in (("bucket order", bucketed), ("element order", element_order)):
+for name, fn in (("early adjoint", early), ("bucket order", bucketed), ("element order", element_order)):
     for _ in range(3):
         fn()
     capi.sync()
@@ -53,6 +59,10 @@ y, ye = float(out["y"].numpy()[0]), float(out["y_e"].numpy()[0])
 dA = np.abs(out["gA"].numpy().astype(np.float64) - out["gA_e"].numpy()).max()
 dB = np.abs(out["gB"].numpy().astype(np.float64) - out["gB_e"].numpy()).max()
 print(f"y bucket {y!r}  element {ye!r}  |diff| {abs(y - ye):.3e};  max |gA diff| {dA:.3e}  max |gB diff| {dB:.3e}")
+yl = float(out["y_early"].numpy()[0])
+dA = np.abs(out["gA_early"].numpy().astype(np.float64) - out["gA_e"].numpy()).max()
+dB = np.abs(out["gB_early"].numpy().astype(np.float64) - out["gB_e"].numpy()).max()
+print(f"y early  {yl!r}  |diff| {abs(yl - ye):.3e};  max |gA diff| {dA:.3e}  max |gB diff| {dB:.3e}")
 
 # the adjoint alone on a kept partition: what the value streams cost
 b = capi.Bucketed("fmadd", A, x, B, idx)
