@@ -617,11 +617,19 @@ __device__ __forceinline__ void bucket_early_stream(const PairRec<T> *__restrict
                 T sum;
                 values(l[k], s.px[h][j], sum, v0[k], v1[k]);
                 acc[j] += sum;
+                if constexpr (Paired) {
+                    // One claim at a time, right behind its element (lds_add_pair_batch<1>: claim, add, release, batched
+                    // retry): the round trip runs in the shadow of the next element's sincos and of the other waves, and
+                    // a lock is held for the shortest possible time.  Measured on 64 Mi lookups into 1 Mi entries, same
+                    // box: 0.199 ms with 8 claims per lane in flight (the stand-alone adjoint's batches), 0.165 with 4,
+                    // 0.149 with 2, 0.146 with 1 after all four elements, 0.135 with 1 right behind each element.
+                    const uint32_t ls[1] = { l[k] };
+                    const T a0[1] = { v0[k] }, a1[1] = { v1[k] };
+                    lds_add_pair_batch<1>(reinterpret_cast<unsigned long long *>(tables), ls, a0, a1);
+                }
             }
         }
-        if constexpr (Paired) {
-            lds_add_pair_batch<NB>(reinterpret_cast<unsigned long long *>(tables), l, v0, v1);
-        } else {
+        if constexpr (!Paired) {
             lds_add_batch<T, NB>(tables, l, v0);
             lds_add_batch<T, NB>(tables + Bins, l, v1);
         }
@@ -641,7 +649,7 @@ __device__ __forceinline__ void bucket_early_stream(const PairRec<T> *__restrict
     for (; base < end; base += kBucketThreads) one(base + threadIdx.x, base + threadIdx.x < end);
 }
 
-template <typename T, int V = 2>
+template <typename T, int V = 1>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
                                                                                 const T *__restrict__ table_a,
                                                                                 const T *__restrict__ table_c, size_t table_size,
@@ -835,7 +843,7 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
     Context &c = ctx();
     const size_t Bins = b->bins();
     const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
-    constexpr int VV = sizeof(T) == 8 ? 1 : 2;
+    constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.199 ms against 0.166, same box)
     if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV>, lds)) return rc;
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
