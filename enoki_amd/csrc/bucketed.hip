@@ -314,9 +314,11 @@ __device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, fl
 }
 
 // N independent updates per lane: all N bins are CLAIMED first (N exchanges in flight -- one LDS round trip instead of N
-// dependent ones, which is what bounds the one-at-a-time version), then every claim that succeeded is added to and
-// released; the few that met a lock (another lane's, or this lane's own claim of the same bin in an earlier slot) go
-// through the one-at-a-time path afterwards.  Nobody spins while holding a lock, so there is no circular wait.
+// dependent ones), then every claim that succeeded is added to and released; the few that met a lock (another lane's, or
+// this lane's own claim of the same bin in an earlier slot) are retried together, and what is still locked then goes through
+// the one-at-a-time path with wave-level combining.  Nobody spins while holding a lock, so there is no circular wait.
+// The kernels below call it with N = 1 (see bucket_accumulate_stream for the measurement that retired N = 4 / 8); what they
+// keep from it is the cheap retry round before the wave-combining loop.
 template <int N>
 __device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, const uint32_t (&l)[N], const float (&v0)[N],
                                                    const float (&v1)[N]) {
@@ -452,7 +454,8 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
         }
     };
     auto apply = [&](const Step &s) {
-        // the values of all 4 V elements first, then ONE batch of LDS updates per table (pair)
+        // the values of all 4 V elements; two f32 tables: each element's pair is added right away, otherwise one batch of LDS
+        // updates per table afterwards
         constexpr int NB = 4 * V;
         uint32_t l[NB];
         T v[C][NB];
@@ -467,11 +470,19 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
                 values(u, x, vk);
 #pragma unroll
                 for (int c = 0; c < C; ++c) v[c][k] = vk[c];
+                if constexpr (Paired) {
+                    // one claim right behind its element (claim, add, release, batched retry).  Claiming all 4 V bins of
+                    // a step first -- one LDS round trip instead of 4 V dependent ones -- was measured again once the
+                    // kernels took the bucket size at run time and lost: 0.185 vs 0.152 ms for {cos(u), x cos(u)}, 0.138
+                    // vs 0.108 ms for {1, x}, equal for the rest (same box, 64 Mi elements): a lock held across a batch
+                    // is met by the other 15 waves more often than its round trip costs.
+                    const uint32_t ls[1] = { l[k] };
+                    const T a0[1] = { vk[0] }, a1[1] = { vk[C - 1] };
+                    lds_add_pair_batch<1>(reinterpret_cast<unsigned long long *>(acc), ls, a0, a1);
+                }
             }
         }
-        if constexpr (Paired) {
-            lds_add_pair_batch<NB>(reinterpret_cast<unsigned long long *>(acc), l, v[0], v[C - 1]);
-        } else {
+        if constexpr (!Paired) {
 #pragma unroll
             for (int c = 0; c < C; ++c) lds_add_batch<T, NB>(acc + c * Bins, l, v[c]);
         }
