@@ -268,6 +268,30 @@ def test_skewed_indices(capi):
         assert np.array_equal(g.numpy().astype(np.float64), want)
 
 
+@pytest.mark.parametrize("hinted", [False, True])
+def test_skewed_indices_cos_pair_is_exact(capi, hinted):
+    """hot bins under the pair lock, with the sincos arithmetic between the claims (both the early adjoint and the stand-alone
+    adjoint): A = C = 0, so u = 0, cos(u) = 1 exactly, and the sums are exact counts / exact sums of the integer-valued x --
+    every lost or doubled update would show"""
+    K, n = 1 << 17, (1 << 20) + 5
+    rng = np.random.default_rng(4)
+    Z = up(capi, np.zeros(K, np.float32))
+    x = rng.integers(-2, 3, n).astype(np.float32)
+    dx = up(capi, x)
+    for idx in (np.full(n, 70001, np.uint32), (rng.integers(0, 100, n) + 5 * 8192).astype(np.uint32),
+                np.where(rng.integers(0, 2, n) == 0, 3, rng.integers(0, K, n)).astype(np.uint32),
+                (rng.integers(0, 2, n) * 8191 + 8192 * 3).astype(np.uint32)):
+        di = up(capi, idx)
+        b = capi.Bucketed("fmadd", Z, dx, Z, di, hints=capi.Bucketed.HINT_ADJOINT if hinted else 0)
+        y = float(b.reduce("hsum", "sin", keep=True, keep_op="cos").numpy()[0])
+        assert y == 0.0
+        g1, gx = up(capi, np.zeros(K, np.float32)), up(capi, np.zeros(K, np.float32))
+        b.scatter_add([gx, g1], [("cos", 0, True), ("cos", 0, False)])
+        assert np.array_equal(g1.numpy().astype(np.float64), np.bincount(idx, minlength=K).astype(np.float64))
+        assert np.array_equal(gx.numpy().astype(np.float64), np.bincount(idx, weights=x.astype(np.float64), minlength=K))
+        b.destroy()
+
+
 class _PartInfo(__import__("ctypes").Structure):
     import ctypes as _c
     _fields_ = [("shift", _c.c_int), ("n_buckets", _c.c_int), ("n", _c.c_size_t), ("range", _c.c_size_t),
