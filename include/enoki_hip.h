@@ -254,7 +254,9 @@ EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_
  *   scatter_add   bases[c][index[i]] += (weighted[c] ? safe_mul(x[i], v_c[i]) : v_c[i]),  v_c = from_u[c] ? map_ops[c](u) :
  *                 the scalar imm_bits[c];  count 1..4 tables of table_size entries.  fresh (may be NULL): fresh[c] != 0 says
  *                 that table c holds no data yet -- a gradient buffer that would otherwise be zero-filled first: its sums are
- *                 WRITTEN (bases[c][k] = sum), saving the fill and the read of the old contents.
+ *                 WRITTEN (bases[c][k] = sum), saving the fill and the read of the old contents.  The tables must be
+ *                 distinct buffers (Tape::flush_pending never queues two scatters into one node's gradient, and
+ *                 HIPArray::scatter_add_multi_ un-shares copy-on-write handles before it calls this).
  *   create_hinted hints = EK_BUCKETED_HINT_ADJOINT: the caller expects `reduce(EK_HSUM, sin | cos, keep the other half)` followed
  *                 by the scatter_add of that half and of x times that half -- y = hsum(sin(u)) recorded on a tape whose gathers
  *                 need gradients (autodiff.cpp:899-918 gather, :1191-1199 the edge product).  Because that adjoint is linear in
