@@ -235,3 +235,27 @@ def test_bucket_ordered_step_graph(ad, capi):
             assert bits_equal(out["e"].numpy(), ad.exp(ad.Float32(y) * ad.Float32(hx)).numpy())
     finally:
         ad.hip_graph_destroy(g)
+
+
+def test_x_needs_a_gradient_too(ad):
+    """x on the tape as well: its adjoint cos(u) * A[idx] is an ELEMENT-order product, so the held cos(u) and u are evaluated in
+    element order after the bucket-ordered forward pass (whose gradient sums are dropped with the partition): three gradients,
+    all within their class-D bounds; and once more with x the only differentiated input"""
+    A, B, x, idx = data(seed=11)
+    t = cfg3b_truth(A, B, x, idx)
+    ii = idx.astype(np.int64)
+    u = A.astype(np.float64)[ii] * x + B.astype(np.float64)[ii]
+    gx_ref = np.cos(u) * A.astype(np.float64)[ii]
+    for tables in (True, False):
+        dA, dB, dx = ad.Float32(A), ad.Float32(B), ad.Float32(x)
+        if tables:
+            ad.set_requires_gradient(dA); ad.set_requires_gradient(dB)
+        ad.set_requires_gradient(dx)
+        di = ad.UInt32(idx)
+        y = ad.hsum(ad.sin(ad.fmadd(ad.gather(dA, di), dx, ad.gather(dB, di))))
+        ad.backward(y)
+        assert abs(float(ad.detach(y).numpy()[0]) - t["y"]) <= t["y_bound"]
+        assert np.all(np.abs(ad.gradient(dx).numpy() - gx_ref) <= 8 * 2.0 ** -24 * (1.0 + np.abs(gx_ref)))
+        if tables:
+            assert np.all(np.abs(ad.gradient(dA).numpy() - t["gA"]) <= t["gA_bound"])
+            assert np.all(np.abs(ad.gradient(dB).numpy() - t["gB"]) <= t["gB_bound"])
