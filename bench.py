@@ -61,7 +61,7 @@ DESCRIPTION["cfg5"] = ("synthetic 3-bounce path tracer inside a textured unit sp
                        "texture (K = 1 Mi), cosine-weighted bounce; loss = hsum(radiance); backward() scatter_adds the "
                        "texture gradient; 16 Mi paths per GPU; report only")
 # kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
-PMC_SYMBOL = {"bucket_accumulate": "k_bucket_accumulate", "bucket_partition": "k_bin_partition", "bucket_pair_fma_reduce": "k_bucket_pair_forward<",
+PMC_SYMBOL = {"bucket_accumulate": "k_bucket_accumulate", "bucket_partition": "k_page_partition", "bucket_directory": "k_page_directory", "bucket_pair_fma_reduce": "k_bucket_pair_forward<",
               "bucket_pair_fma_reduce_adjoint": "k_bucket_pair_forward_adjoint",
               "bucket_count": "k_bin_count", "gather_pair_fmadd": "k_map_gathered<GTernary<0", "gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
               "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",

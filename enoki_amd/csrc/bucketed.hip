@@ -26,6 +26,7 @@
 // for u; reductions and gradients differ from the element-order path only by the order of their fp additions (parity
 // class D, like every reduction / scatter_add of this library).  Deterministic mode never comes here.
 #include "ek_binned.h"
+#include "ek_paged.h"
 
 #include <limits>
 
@@ -71,20 +72,128 @@ template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c) {
     if constexpr (sizeof(T) == 4) return __builtin_fmaf(a, b, c); else return __builtin_fma(a, b, c);
 }
 
-// piece `blockIdx.x` -> its bucket and its range of the bucket-ordered lists (the same cut as k_bin_accumulate)
-__device__ __forceinline__ bool bucket_piece(const uint32_t *__restrict__ bucket_base, const uint32_t *__restrict__ piece_prefix,
-                                             int n_buckets, int &bucket, size_t &begin, size_t &end) {
+// ---- where a bucket's elements are ----------------------------------------------------------------------------------
+// Two layouts of the bucket-ordered lists (l16, x_b and what is kept next to them):
+//   contiguous  (PS = 0; count / scan / partition of ek_binned.h -- 8-byte element types): bucket b owns positions
+//               [base[b], base[b + 1]), a piece is a sub-range that starts anywhere
+//   paged       (PS = 5 | 6; the single-pass partition of ek_paged.h -- 4-byte element types): bucket b owns the pages
+//               glist_full[base[b] .. base[b + 1]) (2^PS elements each, complete) and glist_part[base_part[b] .. base_part[b + 1])
+//               (page << 6 | count - 1); a piece is a range of both lists
+struct BucketLists {
+    const uint32_t *base, *piece_prefix;
+    const uint32_t *base_part, *glist_full, *glist_part;
+    int n_buckets;
+};
+
+struct PieceRange {
+    size_t begin, end;               // contiguous
+    uint32_t f0, f1, p0, p1;         // paged
+};
+
+// piece `blockIdx.x` -> its bucket and its share of the bucket's elements (the same cut as k_bin_accumulate)
+template <int PS>
+__device__ __forceinline__ bool bucket_piece(const BucketLists &bl, int &bucket, PieceRange &r) {
     __shared__ int s_bucket;
-    if (blockIdx.x >= piece_prefix[n_buckets]) return false;
+    const int n_buckets = bl.n_buckets;
+    if (blockIdx.x >= bl.piece_prefix[n_buckets]) return false;
     for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
-        if (piece_prefix[b] <= blockIdx.x && blockIdx.x < piece_prefix[b + 1]) s_bucket = b;
+        if (bl.piece_prefix[b] <= blockIdx.x && blockIdx.x < bl.piece_prefix[b + 1]) s_bucket = b;
     __syncthreads();
     bucket = s_bucket;
-    const size_t lo = bucket_base[bucket], hi = bucket_base[bucket + 1], q = blockIdx.x - piece_prefix[bucket];
-    const size_t pieces = piece_prefix[bucket + 1] - piece_prefix[bucket], per = (hi - lo + pieces - 1) / pieces;
-    begin = lo + q * per < hi ? lo + q * per : hi;
-    end = begin + per < hi ? begin + per : hi;
+    const size_t q = blockIdx.x - bl.piece_prefix[bucket], pieces = bl.piece_prefix[bucket + 1] - bl.piece_prefix[bucket];
+    auto cut = [&](size_t lo, size_t hi, size_t &b0, size_t &b1) {
+        const size_t per = (hi - lo + pieces - 1) / pieces;
+        b0 = lo + q * per < hi ? lo + q * per : hi;
+        b1 = b0 + per < hi ? b0 + per : hi;
+    };
+    r = PieceRange{};
+    if constexpr (PS == 0) {
+        cut(bl.base[bucket], bl.base[bucket + 1], r.begin, r.end);
+    } else {
+        size_t a, b;
+        cut(bl.base[bucket], bl.base[bucket + 1], a, b);
+        r.f0 = (uint32_t) a; r.f1 = (uint32_t) b;
+        cut(bl.base_part[bucket], bl.base_part[bucket + 1], a, b);
+        r.p0 = (uint32_t) a; r.p1 = (uint32_t) b;
+    }
     return true;
+}
+
+// Walks a piece.  Body:
+//   struct Step                                what a lane holds of V vectors of four consecutive elements
+//   fetch(Step &, int h, size_t pos)           requests vector h at element position pos (16-byte aligned)
+//   apply(const Step &)                        consumes the V vectors
+//   one(size_t pos, bool on, int slot)         one element; EVERY lane of a wave calls it together (on = false: no element)
+// Contiguous: up to 3 leading elements one per lane, then vectors with the loads of step i + 1 requested before step i is
+// consumed, then the tail one element per lane.  Paged: 2^PS / 4 lanes share a page, four elements each -- the same 8- and
+// 16-byte vector loads; the pages' numbers are requested two steps ahead; what does not fill a step of the whole workgroup
+// (the last complete pages, the partially filled ones) goes element by element under a lane predicate.
+template <int PS, int V, typename Body>
+__device__ __forceinline__ void walk_piece(const BucketLists &bl, const PieceRange &r, Body &body) {
+    using Step = typename Body::Step;
+    if constexpr (PS == 0) {
+        const size_t begin = r.begin, end = r.end;
+        const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
+        body.one(begin + threadIdx.x, begin + threadIdx.x < head_end, 0);
+        constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;
+        size_t base = head_end;
+        if (base + kStep <= end) {
+            Step cur, next;
+#pragma unroll
+            for (int h = 0; h < V; ++h) body.fetch(cur, h, base + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4);
+            for (; base + 2 * kStep <= end; base += kStep) {
+#pragma unroll
+                for (int h = 0; h < V; ++h) body.fetch(next, h, base + kStep + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4);
+                body.apply(cur);
+                cur = next;
+            }
+            body.apply(cur);
+            base += kStep;
+        }
+        for (; base < end; base += kBucketThreads) body.one(base + threadIdx.x, base + threadIdx.x < end, 0);
+    } else {
+        constexpr uint32_t LX = (1u << PS) / 4, G = kBucketThreads / LX;        // lanes per page, pages per vector of the workgroup
+        const uint32_t g = threadIdx.x / LX, i = threadIdx.x % LX;
+        const uint32_t nfull = r.f1 - r.f0, steps = nfull / (G * V);
+        auto at = [&](uint32_t page) { return ((size_t) page << PS) + 4 * i; };
+        if (steps) {
+            const uint32_t *list = bl.glist_full + r.f0 + g;
+            uint32_t e1[V], e2[V];
+            Step cur, next;
+#pragma unroll
+            for (int h = 0; h < V; ++h) e1[h] = list[h * G];
+#pragma unroll
+            for (int h = 0; h < V; ++h) body.fetch(cur, h, at(e1[h]));
+#pragma unroll
+            for (int h = 0; h < V; ++h) e1[h] = steps > 1 ? list[(V + h) * G] : 0u;
+            for (uint32_t s = 0; s + 1 < steps; ++s) {
+#pragma unroll
+                for (int h = 0; h < V; ++h) e2[h] = s + 2 < steps ? list[((s + 2) * V + h) * G] : 0u;
+#pragma unroll
+                for (int h = 0; h < V; ++h) body.fetch(next, h, at(e1[h]));
+                body.apply(cur);
+                cur = next;
+#pragma unroll
+                for (int h = 0; h < V; ++h) e1[h] = e2[h];
+            }
+            body.apply(cur);
+        }
+        // wave-uniform trip counts: the lock protocol inside one() wants every lane of a wave to come along
+        const uint32_t done = steps * G * V, rest = nfull - done;
+        for (uint32_t r0 = 0; r0 < rest; r0 += G) {
+            const bool valid = r0 + g < rest;
+            const uint32_t page = valid ? bl.glist_full[r.f0 + done + r0 + g] : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) body.one(at(page) + j, valid, j);
+        }
+        const uint32_t nparts = r.p1 - r.p0;
+        for (uint32_t r0 = 0; r0 < nparts; r0 += G) {
+            const bool valid = r0 + g < nparts;
+            const uint32_t e = valid ? bl.glist_part[r.p0 + r0 + g] : 0u, count = valid ? (e & 63u) + 1u : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) body.one(at(e >> 6) + j, 4 * i + j < count, j);
+        }
+    }
 }
 
 // ---- 2. forward ------------------------------------------------------------------------------------
@@ -94,14 +203,27 @@ __device__ __forceinline__ bool bucket_piece(const uint32_t *__restrict__ bucket
 // KeepPartner (Map = sin or cos only): what is kept in bucket order is not u but the OTHER half of sincos(u) -- one sincos
 // evaluation yields the reduced half and the kept half (the cos(u) that the adjoint of sin needs), like the stand-alone
 // sincos kernel fills both halves of a linked pair.
-template <typename T, int ROp, int V, int Map, bool KeepPartner = false>
-__device__ __forceinline__ void bucket_forward_stream(const PairRec<T> *__restrict__ rec, T (&acc)[4], T *__restrict__ u_out,
-                                                      const uint16_t *__restrict__ pair_idx, const T *__restrict__ x_b,
-                                                      size_t begin, size_t end, uint32_t lmask) {
+// FromKept: u is not formed from the table slice but read back from what an earlier pass kept (the lists have holes in the
+// paged layout, so such a reduction walks the pages too).
+template <typename T, int ROp, int V, int Map, bool KeepPartner, bool FromKept>
+struct ForwardBody {
     using R = BucketReducer<ROp, T>;
-    auto one = [&](uint32_t l, T x, int slot) -> T {
-        const PairRec<T> r = rec[l & lmask];
-        const T u = fma_t(r.a, x, r.c);
+    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; size_t pos[V]; };
+    const PairRec<T> *rec;
+    T *u_out;
+    const uint16_t *pair_idx;
+    const T *x_b, *kept;
+    uint32_t lmask;
+    T acc[4];
+
+    __device__ __forceinline__ T elem(uint32_t l, T x, int slot) {
+        T u;
+        if constexpr (FromKept) {
+            u = x;
+        } else {
+            const PairRec<T> r = rec[l & lmask];
+            u = fma_t(r.a, x, r.c);
+        }
         if constexpr (KeepPartner) {
             static_assert(Map == EK_SIN || Map == EK_COS);
             T sn, cs;
@@ -112,83 +234,54 @@ __device__ __forceinline__ void bucket_forward_stream(const PairRec<T> *__restri
             if constexpr (ROp != EK_REDUCE_NONE) acc[slot] = R::combine(acc[slot], UnaryOp<Map, T>::apply(u));
             return u;
         }
-    };
-    // a piece starts anywhere: up to 3 leading elements go one per lane, then every lane moves 4-element vectors
-    const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
-    {
-        const size_t i = begin + threadIdx.x;
-        if (i < head_end) {
-            const T u = one(pair_idx[i], x_b[i], 0);
-            if (u_out) u_out[i] = u;
+    }
+    __device__ __forceinline__ void fetch(Step &s, int h, size_t pos) {
+        s.pos[h] = pos;
+        if constexpr (FromKept) {
+            load4<T, true>(kept + pos, s.px[h]);
+        } else {
+            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + pos);
+            load4<T, true>(x_b + pos, s.px[h]);
         }
     }
-    constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;      // V vectors of 4 per lane and step
-    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
-    auto fetch = [&](Step &s, size_t at) {
+    __device__ __forceinline__ void apply(const Step &s) {
 #pragma unroll
         for (int h = 0; h < V; ++h) {
-            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
-            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
-            load4<T, true>(x_b + e, s.px[h]);
-        }
-    };
-    auto apply = [&](const Step &s, size_t at) {
-#pragma unroll
-        for (int h = 0; h < V; ++h) {
-            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
             T u[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) u[j] = one(s.pi[h].v[j], s.px[h][j], j);
+            for (int j = 0; j < 4; ++j) u[j] = elem(FromKept ? 0u : (uint32_t) s.pi[h].v[j], s.px[h][j], j);
             if (u_out) {
                 if constexpr (sizeof(T) == 4) {
                     Pack<T, 4> po;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) po.v[j] = u[j];
-                    pack_store<T, 4, true>(u_out + e, po);
+                    pack_store<T, 4, true>(u_out + s.pos[h], po);
                 } else {
                     Pack<T, 2> p0, p1;
                     p0.v[0] = u[0]; p0.v[1] = u[1]; p1.v[0] = u[2]; p1.v[1] = u[3];
-                    pack_store<T, 2, true>(u_out + e, p0);
-                    pack_store<T, 2, true>(u_out + e + 2, p1);
+                    pack_store<T, 2, true>(u_out + s.pos[h], p0);
+                    pack_store<T, 2, true>(u_out + s.pos[h] + 2, p1);
                 }
             }
         }
-    };
-    size_t base = head_end;
-    if (base + kStep <= end) {
-        Step cur, next;
-        fetch(cur, base);
-        for (; base + 2 * kStep <= end; base += kStep) {
-            fetch(next, base + kStep);
-            apply(cur, base);
-            cur = next;
-        }
-        apply(cur, base);
-        base += kStep;
     }
-    for (; base < end; base += (size_t) 4 * kBucketThreads) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const size_t i = base + (size_t) k * kBucketThreads + threadIdx.x;
-            if (i < end) {
-                const T u = one(__builtin_nontemporal_load(pair_idx + i), __builtin_nontemporal_load(x_b + i), k);
-                if (u_out) u_out[i] = u;
-            }
+    __device__ __forceinline__ void one(size_t pos, bool on, int slot) {
+        if (on) {
+            const T u = FromKept ? elem(0u, kept[pos], slot) : elem(pair_idx[pos], x_b[pos], slot);
+            if (u_out) u_out[pos] = u;
         }
     }
-}
+};
 
 // flip_a / flip_c: the fma family differs by the signs of its first and third operand (fmsub: -c, fnmadd: -a, fnmsub:
 // both); the signs are applied ONCE to the staged table entries -- exact -- and the inner loop is always one fma.
-template <typename T, int ROp, int V = 2>
+template <typename T, int ROp, int V, int PS, bool FromKept = false>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__restrict__ partials, T *__restrict__ u_out,
                                                                         const T *__restrict__ table_a, const T *__restrict__ table_c,
                                                                         size_t table_size, int flip_a, int flip_c,
                                                                         const uint16_t *__restrict__ pair_idx,
-                                                                        const T *__restrict__ x_b,
-                                                                        const uint32_t *__restrict__ bucket_base,
-                                                                        const uint32_t *__restrict__ piece_prefix, int n_buckets,
-                                                                        int map_op, int keep_partner, int shift) {
+                                                                        const T *__restrict__ x_b, const T *__restrict__ kept,
+                                                                        BucketLists bl, int map_op, int keep_partner, int shift) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
     __shared__ T wave_part[kBucketWaves];
@@ -196,12 +289,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
     const int Bins = 1 << shift;
     const uint32_t lmask = (uint32_t) Bins - 1u;
     int bucket;
-    size_t begin, end;
-    if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) {
+    PieceRange range;
+    if (!bucket_piece<PS>(bl, bucket, range)) {
         if (ROp != EK_REDUCE_NONE && threadIdx.x == 0) partials[blockIdx.x] = R::identity();
         return;
     }
-    {
+    if constexpr (!FromKept) {
         // the bucket's slice of both tables, interleaved: every element then costs ONE ds_read_b64 (b128 for doubles)
         const size_t first = (size_t) bucket * Bins;
         for (int j = threadIdx.x; j < Bins; j += kBucketThreads) {
@@ -211,29 +304,34 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
             if (flip_c) c = -c;
             rec[j] = PairRec<T>{ a, c };
         }
+        __syncthreads();
     }
-    __syncthreads();
 
-    T acc[4];
+    T result = R::identity();
+    auto run = [&](auto body) {
+        body.rec = rec; body.u_out = u_out; body.pair_idx = pair_idx; body.x_b = x_b; body.kept = kept; body.lmask = lmask;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) acc[k] = R::identity();
-#define EK_FWD_CASE(OP) case OP: bucket_forward_stream<T, ROp, V, OP>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask); break;
+        for (int k = 0; k < 4; ++k) body.acc[k] = R::identity();
+        walk_piece<PS, V>(bl, range, body);
+        result = R::combine(R::combine(body.acc[0], body.acc[1]), R::combine(body.acc[2], body.acc[3]));
+    };
+#define EK_FWD_CASE(OP) case OP: run(ForwardBody<T, ROp, V, OP, false, FromKept>{}); break;
     if constexpr (ROp == EK_REDUCE_NONE) {
-        bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask);
-    } else if (keep_partner && map_op == EK_SIN) {
-        bucket_forward_stream<T, ROp, V, EK_SIN, true>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask);
-    } else if (keep_partner && map_op == EK_COS) {
-        bucket_forward_stream<T, ROp, V, EK_COS, true>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask);
+        run(ForwardBody<T, ROp, V, EK_COPY, false, FromKept>{});
+    } else if (!FromKept && keep_partner && map_op == EK_SIN) {
+        run(ForwardBody<T, ROp, V, EK_SIN, true, false>{});
+    } else if (!FromKept && keep_partner && map_op == EK_COS) {
+        run(ForwardBody<T, ROp, V, EK_COS, true, false>{});
     } else {
         switch (map_op) {
             EK_FWD_CASE(EK_NEG) EK_FWD_CASE(EK_ABS) EK_FWD_CASE(EK_SQRT) EK_FWD_CASE(EK_RCP) EK_FWD_CASE(EK_RSQRT)
             EK_FWD_CASE(EK_SIN) EK_FWD_CASE(EK_COS) EK_FWD_CASE(EK_EXP) EK_FWD_CASE(EK_LOG)
-            default: bucket_forward_stream<T, ROp, V, EK_COPY>(rec, acc, u_out, pair_idx, x_b, begin, end, lmask); break;
+            default: run(ForwardBody<T, ROp, V, EK_COPY, false, FromKept>{}); break;
         }
     }
 #undef EK_FWD_CASE
     if constexpr (ROp != EK_REDUCE_NONE) {
-        T v = R::combine(R::combine(acc[0], acc[1]), R::combine(acc[2], acc[3]));
+        T v = result;
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -269,7 +367,6 @@ template <typename T, int C> struct BucketStreams {
     T imm[C];
     unsigned from_u, weighted;
 };
-
 // Two f32 tables share ONE lock per bin: the LDS holds {table 0, table 1} pairs and a bin pair is claimed by a 64-bit
 // exchange (ds_wrxchg_rtn_b64), updated and released by one 64-bit store -- half the LDS atomics and half the dependent
 // round trips of two independent 32-bit locks.  Same protocol as lds_add (ek_binned.h), see there for why the retry loop
@@ -401,14 +498,19 @@ __device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], 
 // element however many streams share it -- the usual pair cos(u), x * cos(u)); Map < 0: per-stream ops chosen at run time.
 // Spec = 1: the adjoint of a gathered pair as the tape issues it -- two streams, both the (kept / mapped) function of u, the
 // SECOND one weighted by x: known at compile time, no per-element selects on the stream description.
-template <typename T, int C, int V, int Map, int Spec = 0>
-__device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, const BucketStreams<T, C> &st,
-                                                         const uint16_t *__restrict__ pair_idx, const T *__restrict__ u_b,
-                                                         const T *__restrict__ x_b, size_t begin, size_t end, int Bins) {
-    constexpr bool Paired = C == 2 && sizeof(T) == 4;
+template <typename T, int C, int V, int Map, int Spec>
+struct AccumulateBody {
+    static constexpr bool Paired = C == 2 && sizeof(T) == 4;
     static_assert(Spec == 0 || (C == 2 && Map >= 0));
-    const bool need_u = Spec == 1 || st.from_u != 0, need_x = Spec == 1 || st.weighted != 0;
-    auto values = [&](T u, T x, T (&v)[C]) {
+    struct Step { Pack<uint16_t, 4> pi[V]; T pu[V][4], px[V][4]; };
+    T *acc;
+    BucketStreams<T, C> st;
+    const uint16_t *pair_idx;
+    const T *u_b, *x_b;
+    int Bins;
+    bool need_u, need_x;
+
+    __device__ __forceinline__ void values(T u, T x, T (&v)[C]) const {
         T m = T(0);
         if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
         if constexpr (Spec == 1) {
@@ -422,9 +524,11 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
                 if ((st.weighted >> c) & 1u) v[c] = dev::safe_mul(x, v[c]);
             }
         }
-    };
+    }
     // every lane of a wave passes through the lock (its retry loop is wave-uniform): inactive lanes add nothing
-    auto one = [&](uint32_t l, T u, T x, bool on) {
+    __device__ __forceinline__ void one(size_t pos, bool on, int) {
+        const uint32_t l = on ? (uint32_t) pair_idx[pos] : 0u;
+        const T u = (on && need_u) ? u_b[pos] : T(0), x = (on && need_x) ? x_b[pos] : T(0);
         T v[C];
         values(u, x, v);
         if constexpr (Paired) {
@@ -433,27 +537,13 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
 #pragma unroll
             for (int c = 0; c < C; ++c) lds_add<true>(&acc[c * Bins + (l & (Bins - 1))], v[c], on);
         }
-    };
-
-    const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
-    {
-        const size_t i = begin + threadIdx.x;
-        const bool on = i < head_end;
-        one(on ? (uint32_t) pair_idx[i] : 0u, (on && need_u) ? u_b[i] : T(0), (on && need_x) ? x_b[i] : T(0), on);
     }
-    // V vectors of 4 per lane, array and step; the loads of step i + 1 are issued before the LDS updates of step i
-    constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;
-    struct Step { Pack<uint16_t, 4> pi[V]; T pu[V][4], px[V][4]; };
-    auto fetch = [&](Step &s, size_t at) {
-#pragma unroll
-        for (int h = 0; h < V; ++h) {
-            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
-            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
-            if (need_u) load4<T, true>(u_b + e, s.pu[h]);
-            if (need_x) load4<T, true>(x_b + e, s.px[h]);
-        }
-    };
-    auto apply = [&](const Step &s) {
+    __device__ __forceinline__ void fetch(Step &s, int h, size_t pos) {
+        s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + pos);
+        if (need_u) load4<T, true>(u_b + pos, s.pu[h]);
+        if (need_x) load4<T, true>(x_b + pos, s.px[h]);
+    }
+    __device__ __forceinline__ void apply(const Step &s) {
         // the values of all 4 V elements; two f32 tables: each element's pair is added right away, otherwise one batch of LDS
         // updates per table afterwards
         constexpr int NB = 4 * V;
@@ -486,40 +576,21 @@ __device__ __forceinline__ void bucket_accumulate_stream(T *__restrict__ acc, co
 #pragma unroll
             for (int c = 0; c < C; ++c) lds_add_batch<T, NB>(acc + c * Bins, l, v[c]);
         }
-    };
-    size_t base = head_end;
-    if (base + kStep <= end) {
-        Step cur, next;
-        fetch(cur, base);
-        for (; base + 2 * kStep <= end; base += kStep) {
-            fetch(next, base + kStep);
-            apply(cur);
-            cur = next;
-        }
-        apply(cur);
-        base += kStep;
     }
-    for (; base < end; base += kBucketThreads) {
-        const size_t i = base + threadIdx.x;
-        const bool on = i < end;
-        one(on ? (uint32_t) pair_idx[i] : 0u, (on && need_u) ? u_b[i] : T(0), (on && need_x) ? x_b[i] : T(0), on);
-    }
-}
+};
 
-template <typename T, int C, int V = 2>
+template <typename T, int C, int V, int PS>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restrict__ partials,
                                                                       const uint16_t *__restrict__ pair_idx,
                                                                       const T *__restrict__ u_b, const T *__restrict__ x_b,
-                                                                      const uint32_t *__restrict__ bucket_base,
-                                                                      const uint32_t *__restrict__ piece_prefix, int n_buckets,
-                                                                      BucketStreams<T, C> st, int shift) {
+                                                                      BucketLists bl, BucketStreams<T, C> st, int shift) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     T *acc = reinterpret_cast<T *>(lds_raw);                 // C tables of Bins entries; two f32 tables: Bins {t0, t1} pairs
     const int Bins = 1 << shift;
     constexpr bool Paired = C == 2 && sizeof(T) == 4;
     int bucket;
-    size_t begin, end;
-    if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) return;
+    PieceRange range;
+    if (!bucket_piece<PS>(bl, bucket, range)) return;
     for (int j = threadIdx.x; j < C * Bins; j += kBucketThreads) acc[j] = T(0);
     __syncthreads();
 
@@ -532,8 +603,14 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
         if (first) { op = st.map_op[c]; first = false; }
         else uniform = uniform && st.map_op[c] == op;
     }
-#define EK_ACC_CASE(OP) case OP: bucket_accumulate_stream<T, C, V, OP>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
-#define EK_ACC_SPEC(OP) case OP: bucket_accumulate_stream<T, C, V, OP, 1>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
+    auto run = [&](auto body, bool spec) {
+        body.acc = acc; body.st = st; body.pair_idx = pair_idx; body.u_b = u_b; body.x_b = x_b; body.Bins = Bins;
+        body.need_u = spec || st.from_u != 0;
+        body.need_x = spec || st.weighted != 0;
+        walk_piece<PS, V>(bl, range, body);
+    };
+#define EK_ACC_CASE(OP) case OP: run(AccumulateBody<T, C, V, OP, 0>{}, false); break;
+#define EK_ACC_SPEC(OP) case OP: run(AccumulateBody<T, C, V, OP, 1>{}, true); break;
     bool done = false;
     if constexpr (C == 2) {
         if (uniform && st.from_u == 3u && st.weighted == 2u) {         // (host side: the weighted stream is put second)
@@ -541,7 +618,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
             switch (op) {
                 EK_ACC_SPEC(EK_NEG) EK_ACC_SPEC(EK_ABS) EK_ACC_SPEC(EK_SQRT) EK_ACC_SPEC(EK_RCP) EK_ACC_SPEC(EK_RSQRT)
                 EK_ACC_SPEC(EK_SIN) EK_ACC_SPEC(EK_COS) EK_ACC_SPEC(EK_EXP) EK_ACC_SPEC(EK_LOG)
-                default: bucket_accumulate_stream<T, C, V, EK_COPY, 1>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
+                default: run(AccumulateBody<T, C, V, EK_COPY, 1>{}, true); break;
             }
         }
     }
@@ -551,10 +628,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
         switch (op) {
             EK_ACC_CASE(EK_NEG) EK_ACC_CASE(EK_ABS) EK_ACC_CASE(EK_SQRT) EK_ACC_CASE(EK_RCP) EK_ACC_CASE(EK_RSQRT)
             EK_ACC_CASE(EK_SIN) EK_ACC_CASE(EK_COS) EK_ACC_CASE(EK_EXP) EK_ACC_CASE(EK_LOG)
-            default: bucket_accumulate_stream<T, C, V, EK_COPY>(acc, st, pair_idx, u_b, x_b, begin, end, Bins); break;
+            default: run(AccumulateBody<T, C, V, EK_COPY, 0>{}, false); break;
         }
     } else {
-        bucket_accumulate_stream<T, C, V, -1>(acc, st, pair_idx, u_b, x_b, begin, end, Bins);
+        run(AccumulateBody<T, C, V, -1, 0>{}, false);
     }
 #undef EK_ACC_CASE
     __syncthreads();
@@ -566,56 +643,67 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
     }
 }
 
-// ---- 2 + 3 in one pass: the reduction of a sincos half AND the adjoint of the gathers --------------------------------
-// y = hsum(sin(u)) is linear in its seed: whatever gradient g the tape later sends down, the tables receive
-// g * sum(cos(u)) and g * sum(x cos(u)) per entry.  When the reduction is asked to KEEP the other half of sincos(u) -- the
-// sign that a derivative will be asked for -- the sums are formed right here, while u, its sincos and the bucket's table
-// slice are at hand: the LDS holds the {A, C} slice AND the two gradient tables of a half-size bucket (2 x 64 KiB), the kept
-// half is never written (4 B/elt) or read back (4 B/elt), (l16, x_b) is streamed once instead of twice, and the adjoint's
-// LDS round trips overlap the forward's arithmetic.  The tape's scatter_add of exactly these streams then only folds the
-// partial tables (ek_hip_bucketed_scatter_add); anything else it asks for takes the ordinary kernels.
-template <typename T, int V, int Map>
-__device__ __forceinline__ void bucket_early_stream(const PairRec<T> *__restrict__ rec, T *__restrict__ tables, T (&acc)[4],
-                                                    const uint16_t *__restrict__ pair_idx, const T *__restrict__ x_b, size_t begin,
-                                                    size_t end, int Bins) {
-    static_assert(Map == EK_SIN || Map == EK_COS);
-    constexpr bool Paired = sizeof(T) == 4;
-    const uint32_t lmask = (uint32_t) Bins - 1u;
-    // reduced half into `sum`, kept half m and x * m out
-    auto values = [&](uint32_t l, T x, T &sum, T &v0, T &v1) {
+// ---- 2 + 3 in one pass: the reduction of f(u) AND the adjoint of the gathers ------------------------------------------
+// y = hsum(f(u)) is linear in its seed: whatever gradient g the tape later sends down, the tables receive g * sum(f'(u)) and
+// g * sum(x f'(u)) per entry.  When the reduction is asked to KEEP the function of u that the derivative will be made of --
+// the other half of a sincos pair for sin / cos, the value itself for exp, rcp(u) for log, ... -- the sums are formed right
+// here, while u, the two function values and the bucket's table slice are at hand: the LDS holds the {A, C} slice AND the two
+// gradient tables of a half-size bucket (2 x 64 KiB), the kept function is never written (4 B/elt) or read back (4 B/elt),
+// (l16, x_b) is streamed once instead of twice, and the adjoint's LDS round trips overlap the forward's arithmetic.  The
+// tape's scatter_add of exactly these streams then only folds the partial tables (ek_hip_bucketed_scatter_add, with the seed
+// as a factor); anything else it asks for takes the ordinary kernels.
+template <int Map, int Keep, typename T> struct EarlyPair {
+    // reduced value and kept function of one u
+    static __device__ __forceinline__ void apply(T u, T &val, T &kept) {
+        if constexpr ((Map == EK_SIN && Keep == EK_COS) || (Map == EK_COS && Keep == EK_SIN)) {
+            T sn, cs;
+            SinCosOp::apply(u, sn, cs);
+            val = Map == EK_SIN ? sn : cs;
+            kept = Map == EK_SIN ? cs : sn;
+        } else if constexpr (Map == Keep) {
+            val = kept = UnaryOp<Map, T>::apply(u);
+        } else {
+            val = UnaryOp<Map, T>::apply(u);
+            kept = UnaryOp<Keep, T>::apply(u);
+        }
+    }
+};
+
+template <typename T, int V, int Map, int Keep>
+struct EarlyBody {
+    static constexpr bool Paired = sizeof(T) == 4;
+    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
+    const PairRec<T> *rec;
+    T *tables;
+    const uint16_t *pair_idx;
+    const T *x_b;
+    int Bins;
+    uint32_t lmask;
+    T acc[4];
+
+    // reduced value into `sum`, kept function m and x * m out
+    __device__ __forceinline__ void values(uint32_t l, T x, T &sum, T &v0, T &v1) const {
         const PairRec<T> r = rec[l];
-        const T u = fma_t(r.a, x, r.c);
-        T sn, cs;
-        SinCosOp::apply(u, sn, cs);
-        sum = Map == EK_SIN ? sn : cs;
-        v0 = Map == EK_SIN ? cs : sn;
+        EarlyPair<Map, Keep, T>::apply(fma_t(r.a, x, r.c), sum, v0);
         v1 = dev::safe_mul(x, v0);
-    };
-    auto one = [&](size_t i, bool on) {
-        const uint32_t l = on ? (uint32_t) pair_idx[i] & lmask : 0u;
+    }
+    __device__ __forceinline__ void one(size_t pos, bool on, int slot) {
+        const uint32_t l = on ? (uint32_t) pair_idx[pos] & lmask : 0u;
         T sum, v0, v1;
-        values(l, on ? x_b[i] : T(0), sum, v0, v1);
-        if (on) acc[0] += sum;
+        values(l, on ? x_b[pos] : T(0), sum, v0, v1);
+        if (on) acc[slot] += sum;
         if constexpr (Paired) {
             lds_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
         } else {
             lds_add<true>(&tables[l], v0, on);
             lds_add<true>(&tables[Bins + l], v1, on);
         }
-    };
-    const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
-    one(begin + threadIdx.x, begin + threadIdx.x < head_end);
-    constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;
-    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
-    auto fetch = [&](Step &s, size_t at) {
-#pragma unroll
-        for (int h = 0; h < V; ++h) {
-            const size_t e = at + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4;
-            s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + e);
-            load4<T, true>(x_b + e, s.px[h]);
-        }
-    };
-    auto apply = [&](const Step &s) {
+    }
+    __device__ __forceinline__ void fetch(Step &s, int h, size_t pos) {
+        s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + pos);
+        load4<T, true>(x_b + pos, s.px[h]);
+    }
+    __device__ __forceinline__ void apply(const Step &s) {
         constexpr int NB = 4 * V;
         uint32_t l[NB];
         T v0[NB], v1[NB];
@@ -644,32 +732,25 @@ __device__ __forceinline__ void bucket_early_stream(const PairRec<T> *__restrict
             lds_add_batch<T, NB>(tables, l, v0);
             lds_add_batch<T, NB>(tables + Bins, l, v1);
         }
-    };
-    size_t base = head_end;
-    if (base + kStep <= end) {
-        Step cur, next;
-        fetch(cur, base);
-        for (; base + 2 * kStep <= end; base += kStep) {
-            fetch(next, base + kStep);
-            apply(cur);
-            cur = next;
-        }
-        apply(cur);
-        base += kStep;
     }
-    for (; base < end; base += kBucketThreads) one(base + threadIdx.x, base + threadIdx.x < end);
+};
+
+/// which {reduced op, kept op} pairs the forward + adjoint kernel is built for
+__host__ __device__ constexpr bool early_pair_supported(int map_op, int keep_op) {
+    if ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN)) return true;
+    if (map_op == EK_LOG && keep_op == EK_RCP) return true;
+    return map_op == keep_op && (map_op == EK_SIN || map_op == EK_COS || map_op == EK_EXP || map_op == EK_SQRT || map_op == EK_RCP ||
+                                 map_op == EK_RSQRT || map_op == EK_LOG || map_op == EK_ABS || map_op == EK_NEG);
 }
 
-template <typename T, int V = 1>
+template <typename T, int V, int PS>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
                                                                                 const T *__restrict__ table_a,
                                                                                 const T *__restrict__ table_c, size_t table_size,
                                                                                 int flip_a, int flip_c,
                                                                                 const uint16_t *__restrict__ pair_idx,
-                                                                                const T *__restrict__ x_b,
-                                                                                const uint32_t *__restrict__ bucket_base,
-                                                                                const uint32_t *__restrict__ piece_prefix,
-                                                                                int n_buckets, int map_op, int shift) {
+                                                                                const T *__restrict__ x_b, BucketLists bl,
+                                                                                int map_op, int keep_op, int shift) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int Bins = 1 << shift;
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
@@ -677,8 +758,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     __shared__ T wave_part[kBucketWaves];
     constexpr bool Paired = sizeof(T) == 4;
     int bucket;
-    size_t begin, end;
-    if (!bucket_piece(bucket_base, piece_prefix, n_buckets, bucket, begin, end)) {
+    PieceRange range;
+    if (!bucket_piece<PS>(bl, bucket, range)) {
         if (threadIdx.x == 0) partials[blockIdx.x] = T(0);
         return;
     }
@@ -693,10 +774,21 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         tables[2 * j + 1] = T(0);
     }
     __syncthreads();
-    T acc[4] = { T(0), T(0), T(0), T(0) };
-    if (map_op == EK_SIN) bucket_early_stream<T, V, EK_SIN>(rec, tables, acc, pair_idx, x_b, begin, end, Bins);
-    else bucket_early_stream<T, V, EK_COS>(rec, tables, acc, pair_idx, x_b, begin, end, Bins);
-    T v = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    T v = T(0);
+    auto run = [&](auto body) {
+        body.rec = rec; body.tables = tables; body.pair_idx = pair_idx; body.x_b = x_b; body.Bins = Bins;
+        body.lmask = (uint32_t) Bins - 1u;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) body.acc[k] = T(0);
+        walk_piece<PS, V>(bl, range, body);
+        v = (body.acc[0] + body.acc[1]) + (body.acc[2] + body.acc[3]);
+    };
+#define EK_EARLY_CASE(M, K) else if (map_op == M && keep_op == K) run(EarlyBody<T, V, M, K>{});
+    if (map_op == EK_SIN && keep_op == EK_COS) run(EarlyBody<T, V, EK_SIN, EK_COS>{});
+    EK_EARLY_CASE(EK_COS, EK_SIN) EK_EARLY_CASE(EK_LOG, EK_RCP) EK_EARLY_CASE(EK_SIN, EK_SIN) EK_EARLY_CASE(EK_COS, EK_COS)
+    EK_EARLY_CASE(EK_EXP, EK_EXP) EK_EARLY_CASE(EK_SQRT, EK_SQRT) EK_EARLY_CASE(EK_RCP, EK_RCP) EK_EARLY_CASE(EK_RSQRT, EK_RSQRT)
+    EK_EARLY_CASE(EK_LOG, EK_LOG) EK_EARLY_CASE(EK_ABS, EK_ABS) EK_EARLY_CASE(EK_NEG, EK_NEG)
+#undef EK_EARLY_CASE
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -708,7 +800,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         for (int d = 8; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
         if (threadIdx.x == 0) partials[blockIdx.x] = v;
     }
-    // table c (0: sum of the kept half, 1: sum of x * kept half) of this piece at table_partials + (c * gridDim.x + piece) * Bins
+    // table c (0: sum of the kept function, 1: sum of x * kept function) of this piece at table_partials + (c * gridDim.x + piece) * Bins
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
         T *out = table_partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
@@ -737,10 +829,17 @@ struct Bucketed {
     void *early = nullptr;         // k_bucket_pair_forward_adjoint: per piece, sums of early_op(u) and of x * early_op(u) per entry
     int early_op = EK_COPY;
     bool has_early = false;
+    // paged lists (ek_paged.h; 4-byte element types): page_shift = 5 | 6, pair_idx / x_b / u_b / m_b hold `positions` elements
+    // (whole pages, the workgroups' unused slots in between), bucket_base counts complete pages
+    int page_shift = 0;
+    size_t positions = 0;
+    void *page_lists = nullptr;    // glist_full[page slots] | glist_part[W * n_buckets]
+    uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
 
     size_t bins() const { return (size_t) 1 << shift; }
+    BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
     ~Bucketed() {
-        for (void *p : { meta, pair_idx, x_b, u_b, m_b, early })
+        for (void *p : { meta, pair_idx, x_b, u_b, m_b, early, page_lists })
             if (p) ek_hip_free(p);
     }
 };
@@ -766,6 +865,7 @@ static int bucketed_create(Bucketed *b, const T *x, const I *index) {
     b->shift = Shift;
     const size_t n = b->n;
     const int n_buckets = b->n_buckets = (int) ((b->table_size + Bins - 1) / Bins);
+    b->positions = n;
 
     unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
     if (blocks == 0) blocks = 1;
@@ -815,6 +915,76 @@ static int bucketed_create(Bucketed *b, const T *x, const I *index) {
     return EK_OK;
 }
 
+/// The same object from the single-pass paged partition (ek_paged.h): 4-byte element types, n <= 2^30.  One streaming pass
+/// over (index, x) + the page directory: no count pass, no scans.
+template <typename I>
+static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, const Arg<uint8_t> &mask, int shift) {
+    RoctxRange range("enoki-hip: bucket partition (pages)");
+    Context &c = ctx();
+    b->shift = shift;
+    const size_t n = b->n;
+    const int n_buckets = b->n_buckets = (int) ((b->table_size + ((size_t) 1 << shift) - 1) >> shift);
+    const PagedPlan p = paged_plan(n, n_buckets, c.num_cu);
+    if (p.W > 1024) return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): %u workgroups", p.W);
+    b->page_shift = p.page_shift;
+    b->positions = p.page_slots << p.page_shift;
+    const uint32_t target_pieces = (uint32_t) bucket_target_pieces(n, n_buckets);
+    b->max_pieces = target_pieces + (unsigned) n_buckets;
+    // meta: gtotal[2][256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
+    const size_t meta_words = 2 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
+    if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(float) + 16, &b->meta)) return rc;
+    if (int rc = ek_hip_malloc(b->positions * sizeof(uint16_t), &b->pair_idx)) return rc;
+    if (int rc = ek_hip_malloc(b->positions * sizeof(float), &b->x_b)) return rc;
+    const size_t part_entries = (size_t) p.W * n_buckets;
+    if (int rc = ek_hip_malloc((p.page_slots + part_entries + 1) * sizeof(uint32_t), &b->page_lists)) return rc;
+    b->glist_full = (uint32_t *) b->page_lists;
+    b->glist_part = b->glist_full + p.page_slots;
+    uint32_t *gtotal = (uint32_t *) b->meta;
+    b->bucket_base = gtotal + 2 * kMaxBuckets;
+    b->base_part = b->bucket_base + kMaxBuckets + 1;
+    b->piece_prefix = b->base_part + kMaxBuckets + 1;
+    b->reduce_partials = (void *) (((uintptr_t) (gtotal + meta_words) + 15) & ~(uintptr_t) 15);
+    // what only the two kernels below need: the workgroups' own page lists and counts
+    Scratch work;
+    if (int rc = work.alloc((2 * p.page_slots + 3 * part_entries) * sizeof(uint32_t))) return rc;
+    PagedOut<float> out;
+    out.lp = (uint16_t *) b->pair_idx;
+    out.xp = (float *) b->x_b;
+    out.wdir = (uint32_t *) work.ptr;
+    out.wlist = out.wdir + p.page_slots;
+    out.cnt_full = out.wlist + p.page_slots;
+    out.loff = out.cnt_full + part_entries;
+    out.part = out.loff + part_entries;
+    out.gtotal = gtotal;
+    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 2 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
+    auto launch = [&](auto kernel) -> int {
+        if (int rc = allow_big_lds(kernel, p.lds)) return rc;
+        hipLaunchKernelGGL(kernel, dim3(p.W), dim3(kPgThreads), p.lds, c.stream, out, index, mask, x, n, p.chunk, n_buckets, shift,
+                           p.cap, p.slots, vec_ok);
+        return EK_OK;
+    };
+    int rc;
+    if (p.page_shift == 6) rc = mask.vec ? launch(k_page_partition<float, I, 6, true>) : launch(k_page_partition<float, I, 6, false>);
+    else rc = mask.vec ? launch(k_page_partition<float, I, 5, true>) : launch(k_page_partition<float, I, 5, false>);
+    if (rc) return rc;
+    EK_LAUNCH_CHECK("bucket_partition", n, n * (sizeof(I) + sizeof(float)) + arg_bytes(mask, n) + n * (sizeof(uint16_t) + sizeof(float)));
+    hipLaunchKernelGGL(k_page_directory, dim3(n_buckets), dim3(1024), 0, c.stream, b->glist_full, b->glist_part, b->bucket_base,
+                       b->base_part, b->piece_prefix, (const uint32_t *) gtotal, (const uint32_t *) out.cnt_full,
+                       (const uint32_t *) out.loff, (const uint32_t *) out.part, (const uint32_t *) out.wlist, p.W, p.slots, n_buckets,
+                       target_pieces);
+    EK_LAUNCH_CHECK("bucket_directory", p.page_slots, 2 * p.page_slots * sizeof(uint32_t));
+    return EK_OK;
+}
+
+// kernel variants by list layout: contiguous for 8-byte element types, pages of 32 / 64 elements for 4-byte ones
+#define EK_BY_LAYOUT(b, call)                                                                                  \
+    do {                                                                                                       \
+        if constexpr (sizeof(T) == 8) { constexpr int PS = 0; call; }                                          \
+        else if ((b)->page_shift == 6) { constexpr int PS = 6; call; }                                         \
+        else { constexpr int PS = 5; call; }                                                                   \
+    } while (0)
+
 template <typename T, int ROp>
 static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep, int keep_op = EK_COPY) {
     Context &c = ctx();
@@ -823,19 +993,20 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     // vectors per lane and step.  float: two (one: 6 % slower, four: 13 % slower, same box); double: one -- with two the
     // kernel needs more than the 128 registers a 1024-thread workgroup leaves a lane (12 spilled; the adjoint: 250)
     constexpr int VV = sizeof(T) == 8 ? 1 : 2;
-    if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp, VV>, lds)) return rc;
     // keep the OTHER half of a sincos pair instead of u: only when it is exactly that (sin reduced, cos kept or vice versa)
     const bool partner = keep && ROp != EK_REDUCE_NONE &&
                          ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN));
     void **kept = partner ? &b->m_b : &b->u_b;
     if (keep && !*kept)
-        if (int rc = ek_hip_malloc(b->n * sizeof(T), kept)) return rc;
+        if (int rc = ek_hip_malloc(b->positions * sizeof(T), kept)) return rc;
     const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
-    hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
-                       (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
-                       (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,
-                       (const T *) b->x_b, (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets,
-                       map_op, partner ? 1 : 0, b->shift);
+    EK_BY_LAYOUT(b, {
+        if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp, VV, PS>, lds)) return rc;
+        hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
+                           (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
+                           (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,
+                           (const T *) b->x_b, (const T *) nullptr, b->lists(), map_op, partner ? 1 : 0, b->shift);
+    });
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
     if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
@@ -848,21 +1019,55 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     return EK_OK;
 }
 
-/// hsum of one half of sincos(u) with the adjoint of the gathers formed in the same pass (k_bucket_pair_forward_adjoint)
+/// reduce_op over map_op(values) of what an earlier pass kept in list order (u, or the kept half of a sincos pair)
+template <typename T, int ROp>
+static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const void *values) {
+    Context &c = ctx();
+    constexpr int VV = sizeof(T) == 8 ? 1 : 2;
+    EK_BY_LAYOUT(b, {
+        hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV, PS, true>), dim3(b->max_pieces), dim3(kBucketThreads), 0, c.stream,
+                           (T *) b->reduce_partials, (T *) nullptr, (const T *) nullptr, (const T *) nullptr, b->table_size, 0, 0,
+                           (const uint16_t *) b->pair_idx, (const T *) b->x_b, (const T *) values, b->lists(), map_op, 0, b->shift);
+    });
+    EK_LAUNCH_CHECK("bucket_reduce_kept", b->n, b->n * sizeof(T));
+    hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
+                       b->max_pieces);
+    EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    return EK_OK;
+}
+
+template <typename T>
+static int bucketed_reduce_kept(Bucketed *b, int reduce_op, int map_op, void *out, const void *values) {
+    if (b->page_shift == 0) {          // contiguous lists have no holes: an ordinary reduction
+        if (map_op == EK_COPY) return ek_hip_reduce(reduce_op, b->type, out, values, b->n);
+        return ek_hip_reduce_map(reduce_op, map_op, b->type, out, values, b->n);
+    }
+    switch (reduce_op) {
+        case EK_HSUM: return bucketed_reduce_kept_launch<T, EK_HSUM>(b, out, map_op, values);
+        case EK_HPROD: return bucketed_reduce_kept_launch<T, EK_HPROD>(b, out, map_op, values);
+        case EK_HMIN: return bucketed_reduce_kept_launch<T, EK_HMIN>(b, out, map_op, values);
+        case EK_HMAX: return bucketed_reduce_kept_launch<T, EK_HMAX>(b, out, map_op, values);
+        default: return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): unknown op %d", reduce_op);
+    }
+}
+
+/// hsum of map_op(u) with the adjoint of the gathers -- the sums of keep_op(u) and x * keep_op(u) per entry -- formed in the
+/// same pass (k_bucket_pair_forward_adjoint)
 template <typename T>
 static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, int keep_op) {
     Context &c = ctx();
     const size_t Bins = b->bins();
     const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
     constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.199 ms against 0.166, same box)
-    if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV>, lds)) return rc;
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
     const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
-    hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
-                       (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
-                       flip_a, flip_c, (const uint16_t *) b->pair_idx, (const T *) b->x_b, (const uint32_t *) b->bucket_base,
-                       (const uint32_t *) b->piece_prefix, b->n_buckets, map_op, b->shift);
+    EK_BY_LAYOUT(b, {
+        if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV, PS>, lds)) return rc;
+        hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
+                           (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
+                           flip_a, flip_c, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift);
+    });
     EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T)) + 2 * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
     b->has_early = true;
@@ -878,14 +1083,10 @@ static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bo
     RoctxRange range("enoki-hip: bucket-ordered gather + fma + reduction");
     // a plan with half-size buckets was made for this: the sum of one half of sincos(u) whose other half is to be kept
     if (b->shift < bin_shift_of<T> && reduce_op == EK_HSUM && keep && !b->has_u && !b->has_m && !b->has_early &&
-        ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN)))
+        early_pair_supported(map_op, keep_op))
         return bucketed_forward_adjoint_launch<T>(b, out, map_op, keep_op);
-    if (b->has_m && map_op == b->m_op) return ek_hip_reduce(reduce_op, b->type, out, b->m_b, b->n);   // the kept half itself
-    if (b->has_u) {
-        // u already exists in bucket order: an ordinary reduction over it
-        if (map_op == EK_COPY) return ek_hip_reduce(reduce_op, b->type, out, b->u_b, b->n);
-        return ek_hip_reduce_map(reduce_op, map_op, b->type, out, b->u_b, b->n);
-    }
+    if (b->has_m && map_op == b->m_op) return bucketed_reduce_kept<T>(b, reduce_op, EK_COPY, out, b->m_b);   // the kept half itself
+    if (b->has_u) return bucketed_reduce_kept<T>(b, reduce_op, map_op, out, b->u_b);      // u already exists in list order
     switch (reduce_op) {
         case EK_HSUM: return bucketed_forward_launch<T, EK_HSUM>(b, out, map_op, keep, keep_op);
         case EK_HPROD: return bucketed_forward_launch<T, EK_HPROD>(b, out, map_op, keep, keep_op);
@@ -901,12 +1102,14 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
     const size_t Bins = b->bins();
     const size_t lds = (size_t) C * Bins * sizeof(T);
     constexpr int VV = sizeof(T) == 8 ? 1 : 2;          // as in the forward kernel
-    if (int rc = allow_big_lds(k_bucket_accumulate<T, C, VV>, lds)) return rc;
     Scratch partials;
     if (int rc = partials.alloc((size_t) C * b->max_pieces * Bins * sizeof(T))) return rc;
-    hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
-                       (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) u_src, (const T *) b->x_b,
-                       (const uint32_t *) b->bucket_base, (const uint32_t *) b->piece_prefix, b->n_buckets, st, b->shift);
+    EK_BY_LAYOUT(b, {
+        if (int rc = allow_big_lds(k_bucket_accumulate<T, C, VV, PS>, lds)) return rc;
+        hipLaunchKernelGGL((k_bucket_accumulate<T, C, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
+                           (T *) partials.ptr, (const uint16_t *) b->pair_idx, (const T *) u_src, (const T *) b->x_b, b->lists(), st,
+                           b->shift);
+    });
     EK_LAUNCH_CHECK("bucket_accumulate", (size_t) C * b->n,
                     b->n * (sizeof(uint16_t) + (st.from_u ? sizeof(T) : 0) + (st.weighted ? sizeof(T) : 0)) +
                     (size_t) C * b->max_pieces * Bins * sizeof(T));
@@ -1058,7 +1261,9 @@ int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size
     if (index_type != EK_U32 && index_type != EK_I32) return 0;
     if (ctx().tuning.deterministic || !ctx().tuning.bucket_ordered) return 0;
     const size_t bins = type == EK_F64 ? (size_t) bins_of<double> : (size_t) bins_of<float>;
-    return n >= ((size_t) 1 << 18) && n < ((size_t) 1 << 32) && table_size > bins && table_size <= (size_t) kMaxBuckets * bins;
+    // (4-byte types go through pages whose numbers are packed with an element count: 2^30 elements at most)
+    return n >= ((size_t) 1 << 18) && n < ((size_t) 1 << (type == EK_F64 ? 32 : 30)) && table_size > bins &&
+           table_size <= (size_t) kMaxBuckets * bins;
 }
 
 int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
@@ -1087,8 +1292,8 @@ int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const v
     const size_t bins = type == EK_F64 ? (size_t) bins_of<double> : (size_t) bins_of<float>;
     const bool half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint && table_size <= (size_t) kMaxBuckets * (bins / 2);
     if (type == EK_F32) {
-        if (half) rc = bucketed_create<float, uint32_t, bin_shift_of<float> - 1>(b, (const float *) x, (const uint32_t *) index);
-        else rc = bucketed_create<float, uint32_t, bin_shift_of<float>>(b, (const float *) x, (const uint32_t *) index);
+        const Arg<uint8_t> all{ nullptr, 1, 0u };
+        rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, all, bin_shift_of<float> - (half ? 1 : 0));
     } else {
         if (half) rc = bucketed_create<double, uint32_t, bin_shift_of<double> - 1>(b, (const double *) x, (const uint32_t *) index);
         else rc = bucketed_create<double, uint32_t, bin_shift_of<double>>(b, (const double *) x, (const uint32_t *) index);

@@ -1,0 +1,467 @@
+// Single-pass bucket partition into PAGES (round 4).
+//
+// What it replaces: k_bin_count + k_bin_scan_rows + k_bin_scan_buckets + k_bin_partition (ek_binned.h) on the bucket-ordered
+// path -- the role of the reference's sort + run-length partition (src/cuda/horiz.cu:35-122), done in ONE streaming pass.
+//
+// Why pages.  A partition whose output is one contiguous run per bucket has to know every bucket's size before the first
+// element is written: a count pass over the indices (4 B/elt) and two scans.  And a workgroup that writes its share of a
+// bucket's run appends ~64 elements per tile at an arbitrary alignment: partially written cache lines, 2-byte stores,
+// 1.19x write amplification (profiles/rocprof_pmc_r03.txt) -- the write-out was 56 % of the kernel.
+// Here the output of a bucket is a LIST OF PAGES instead: a page is 64 elements (32 when the table has more than 128
+// buckets) = one full 128-byte line of 16-bit bucket-local indices + two full lines of values, written exactly once by 16-byte
+// stores.  Every workgroup owns a contiguous range of page slots and hands them out itself, so no offset depends on another
+// workgroup: no count pass, no scan, no look-back, no global atomics in the loop.
+//
+//   k_page_partition   one 1024-thread workgroup per CU walks its chunk of (index, x) in tiles of 4096 elements.  Per bucket the
+//                      LDS holds a circular buffer of `cap` elements (16 Ki elements over all buckets = 96 KiB); an element
+//                      takes its slot with ONE returning LDS atomic on a {origin, fill} word, complete pages leave as 16-byte
+//                      vectors.  A tile that brings a bucket more than its buffer holds (skewed indices) takes further rounds
+//                      of the same three phases.  What is left at the end of the chunk leaves as one partially filled page per
+//                      bucket.  The workgroup finally lists its pages bucket by bucket (wlist) -- the order is that of the
+//                      input, nothing depends on timing.                               idx 4 + x 4 read, 6 written per element
+//   k_page_directory   one workgroup per bucket gathers the workgroups' lists into the bucket's page list (full pages first,
+//                      partially filled ones with their element count behind) and cuts the bucket into pieces for the
+//                      consumers.                                                                        ~8 B per PAGE
+//
+// Consumers (bucketed.hip) walk page lists: 16 lanes take a page, four elements each -- the same 8- and 16-byte vector loads
+// as over a contiguous run.
+#pragma once
+#include "ek_binned.h"
+
+namespace ek {
+
+constexpr int kPgThreads = 1024;
+constexpr int kPgTile = 4 * kPgThreads;
+constexpr int kPgLdsElems = 16384;             // elements staged per workgroup, all buckets together (128 KiB of 8-byte records)
+constexpr uint32_t kNoPage = 0xFFFFFFFFu;
+
+template <typename T> struct PagedOut {
+    uint16_t *lp;          // pages of bucket-local indices
+    T *xp;                 // pages of values, same positions
+    uint32_t *wdir;        // [W][slots]  page slot -> (sequence number within its bucket) << 8 | bucket
+    uint32_t *wlist;       // [W][slots]  the workgroup's full pages, bucket by bucket, in input order
+    uint32_t *cnt_full;    // [n_buckets][W]  full pages of the workgroup per bucket
+    uint32_t *loff;        // [n_buckets][W]  where they start in wlist[w]
+    uint32_t *part;        // [n_buckets][W]  page << 6 | (count - 1) of the partially filled page, or kNoPage
+    uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
+#ifdef EK_PG_TIMING
+    unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
+#endif
+};
+
+#ifdef EK_PG_TIMING
+#define EK_PG_T(k) do { const unsigned long long now_ = __builtin_readcyclecounter(); tacc[k] += now_ - tlast; tlast = now_; } while (0)
+#else
+#define EK_PG_T(k) do { } while (0)
+#endif
+
+using PgV4 = __attribute__((ext_vector_type(4))) uint32_t;
+using PgV2 = __attribute__((ext_vector_type(2))) uint32_t;
+
+template <typename T, typename I, int PS, bool HasMask>
+__global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, const I *__restrict__ index, Arg<uint8_t> mask,
+                                                               const T *__restrict__ x, size_t n, size_t chunk, int n_buckets,
+                                                               int shift, uint32_t cap, uint32_t slots, int vec_ok) {
+    static_assert(sizeof(T) == 4, "pages carry 4-byte values");
+    constexpr uint32_t Page = 1u << PS;
+    extern __shared__ __align__(16) unsigned char lds_raw[];
+    unsigned long long *rec = reinterpret_cast<unsigned long long *>(lds_raw);                                // [n_buckets][cap] of {value bits, local index}
+    __shared__ uint32_t cnt[kMaxBuckets];      // origin << 16 | fill of the bucket's circular buffer
+    __shared__ uint32_t npg[kMaxBuckets];      // full pages written so far per bucket
+    __shared__ uint32_t dbase[kMaxBuckets];    // overflowing bucket: first of its directly written pages (slot within the round)
+    __shared__ uint32_t dtail[kMaxBuckets];    //                     fill from which its elements stay in the LDS
+    __shared__ uint32_t jobs[1024];            // page slots of this round: page in the buffer << 8 | bucket (kNoPage: written directly)
+    __shared__ uint32_t s_pages, s_jobs, s_over;
+
+    const uint32_t W = gridDim.x, w = blockIdx.x;
+#ifdef EK_PG_TIMING
+    const unsigned long long t_start = wall_clock64();
+#endif
+    const size_t begin = (size_t) w * chunk < n ? (size_t) w * chunk : n, end = begin + chunk < n ? begin + chunk : n;
+    const size_t wbase = (size_t) w * slots;                     // first page slot of this workgroup
+    const uint32_t lowmask = (1u << shift) - 1u, cap_pages = cap >> PS, cap_shift = 31u - (uint32_t) __builtin_clz(cap);
+    const uint32_t spare = (uint32_t) n_buckets << cap_shift;         // one record behind the buffers
+    for (int b = threadIdx.x; b < kMaxBuckets; b += kPgThreads) { cnt[b] = 0; npg[b] = 0; }
+    if (threadIdx.x == 0) { s_pages = 0; s_jobs = 0; s_over = 0; }
+    __syncthreads();
+
+    const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
+    // a tile as it arrives: nothing is decoded before the tile is placed, so that two tiles of loads stay in flight
+    struct Raw { I pi[4]; PgV4 xv; uint32_t m; };
+    struct Tile { uint32_t ix[4], xv[4], on; };          // xv: the values' bits
+    auto load_raw = [&](size_t base, Raw &r) {
+        const size_t e = base + (size_t) threadIdx.x * 4;
+        load4<I, true>(index + e, r.pi);
+        r.xv = __builtin_nontemporal_load(reinterpret_cast<const PgV4 *>(x + e));
+        if constexpr (HasMask) r.m = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(mask.ptr + e));
+        else r.m = 0;
+    };
+    auto decode = [&](const Raw &r, Tile &t) {
+        t.on = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t.ix[j] = (uint32_t) r.pi[j];
+            t.xv[j] = r.xv[j];
+            if constexpr (HasMask) t.on |= (((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u) << j;
+        }
+        if constexpr (!HasMask) t.on = sm ? 0xFu : 0u;
+    };
+    auto load_ragged = [&](size_t base, Tile &t) {
+        const size_t e = base + (size_t) threadIdx.x * 4;
+        t.on = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            t.ix[j] = 0; t.xv[j] = 0;
+            if (e + j < end) {
+                t.ix[j] = (uint32_t) index[e + j];
+                t.xv[j] = __builtin_bit_cast(uint32_t, x[e + j]);
+                t.on |= ((mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u) << j;
+            }
+        }
+    };
+
+    // the pages in slots [ps0, ps0 + njobs) leave the LDS: one page per group of lanes, four elements per lane (16 bytes of
+    // values, 8 bytes of indices)
+    auto write_out = [&](uint32_t ps0, uint32_t njobs) {
+        constexpr int LX = (int) (Page / 4);
+        const uint32_t g = threadIdx.x / LX, i = threadIdx.x % LX;
+        for (uint32_t j = g; j < njobs; j += kPgThreads / LX) {
+            const uint32_t jb = jobs[j];
+            if (jb == kNoPage) continue;
+            const uint32_t src = ((jb & 0xFFu) << cap_shift) + ((jb >> 8) << PS) + 4 * i;
+            const size_t at = ((wbase + ps0 + j) << PS) + 4 * i;
+            const PgV4 r01 = *reinterpret_cast<const PgV4 *>(rec + src), r23 = *reinterpret_cast<const PgV4 *>(rec + src + 2);
+            const PgV4 vx = { r01[0], r01[2], r23[0], r23[2] };
+            const PgV2 vl = { r01[1] | (r01[3] << 16), r23[1] | (r23[3] << 16) };
+            *reinterpret_cast<PgV4 *>(out.xp + at) = vx;
+            *reinterpret_cast<PgV2 *>(out.lp + at) = vl;
+        }
+    };
+
+    uint32_t ps0 = 0;
+#ifdef EK_PG_TIMING
+    unsigned long long tacc[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, tlast = __builtin_readcyclecounter();
+#endif
+    // One round of two barriers per tile.  An element takes a fill number of its bucket's buffer with ONE returning LDS atomic
+    // and is staged at origin + fill; the element that takes the last fill of a page announces the page (slot, job, directory
+    // entry) on the spot -- no serial bookkeeping.  After the barrier the announced pages leave as 16-byte vectors and their
+    // announcers move the buckets' {origin, fill} words on.
+    // A tile that brings a bucket more than its buffer holds (skewed indices) sets a flag; such a tile takes one more barrier:
+    // the bucket's elements beyond the buffer are complete pages + a rest, the pages get slots like any other and their
+    // elements go STRAIGHT to global memory (4- and 2-byte stores, as the contiguous-run partition writes all of its output),
+    // the rest is staged once the buffer has been written out.
+    auto process = [&](const Tile &t) {
+        uint32_t old[4], pending = 0, done = 0;
+        EK_PG_T(0);                       // waiting for the tile's loads + decode
+#pragma unroll
+        for (int k = 0; k < 4; ++k) old[k] = ((t.on >> k) & 1u) ? atomicAdd(&cnt[t.ix[k] >> shift], 1u) : 0u;
+        // staged without a branch: an element that found its bucket's buffer full (or is masked out) writes to a spare record
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
+            const bool on = (t.on >> k) & 1u, ok = on && fill < cap;
+            rec[ok ? ((b << cap_shift) | pos) : spare] = (unsigned long long) t.xv[k] | ((unsigned long long) (t.ix[k] & lowmask) << 32);
+            pending |= (on && !ok) ? 1u << k : 0u;
+            done |= (ok && ((fill + 1u) & (Page - 1u)) == 0u) ? 1u << k : 0u;
+        }
+        if (pending) s_over = 1u;
+        if (done) {
+            // the elements that took the last fill of a page announce it: ONE slot request per lane, all reads in flight together
+            const uint32_t first = atomicAdd(&s_pages, (uint32_t) __popc(done));
+            uint32_t seq[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) seq[k] = ((done >> k) & 1u) ? npg[t.ix[k] >> shift] : 0u;
+            uint32_t ps = first;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((done >> k) & 1u) {
+                    const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
+                    jobs[ps - ps0] = b | ((pos >> PS) << 8);
+                    out.wdir[wbase + ps] = ((seq[k] + (fill >> PS)) << 8) | b;
+                    ++ps;
+                }
+            }
+        }
+        EK_PG_T(1);                       // placement
+        __syncthreads();
+        EK_PG_T(2);                       // barrier 1
+        const bool over = s_over != 0u;
+        if (over) {
+            if ((int) threadIdx.x < n_buckets) {
+                const uint32_t b = threadIdx.x, c = cnt[b], f = c & 0xFFFFu;
+                if (f > cap) {
+                    const uint32_t nd = (f >> PS) - cap_pages, p = nd ? atomicAdd(&s_pages, nd) : ps0, seq0 = npg[b] + cap_pages;
+                    for (uint32_t q = 0; q < nd; ++q) {
+                        jobs[p - ps0 + q] = kNoPage;
+                        out.wdir[wbase + p + q] = ((seq0 + q) << 8) | b;
+                    }
+                    dbase[b] = p - ps0;
+                    dtail[b] = (f >> PS) << PS;
+                }
+            }
+            __syncthreads();
+        }
+        EK_PG_T(3);
+        const uint32_t ps1 = s_pages;
+        write_out(ps0, ps1 - ps0);
+        if (!over) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((done >> k) & 1u) {
+                    const uint32_t b = t.ix[k] >> shift;
+                    atomicAdd(&cnt[b], (Page << 16) - Page);          // origin + Page, fill - Page
+                    atomicAdd(&npg[b], 1u);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((pending >> k) & 1u) {
+                    const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu;
+                    if (fill < dtail[b]) {
+                        const size_t at = ((wbase + ps0 + dbase[b]) << PS) + (fill - cap);
+                        reinterpret_cast<uint32_t *>(out.xp)[at] = t.xv[k];
+                        out.lp[at] = (uint16_t) (t.ix[k] & lowmask);
+                        pending &= ~(1u << k);
+                    } else {
+                        old[k] = (old[k] & 0xFFFF0000u) | (fill - dtail[b]);     // its place in the emptied buffer
+                    }
+                }
+            }
+            if ((int) threadIdx.x < n_buckets) {
+                const uint32_t b = threadIdx.x, c = cnt[b], f = c & 0xFFFFu, org = c >> 16, np = f >> PS;
+                if (f > cap) cnt[b] = (org << 16) | (f & (Page - 1u));
+                else cnt[b] = (((org + (np << PS)) & 0xFFFFu) << 16) | (f & (Page - 1u));
+                npg[b] += np;
+            }
+            if (threadIdx.x == 0) s_over = 0u;
+        }
+        ps0 = ps1;
+        EK_PG_T(5);                       // write-out
+        __syncthreads();
+        EK_PG_T(6);                       // barrier 2
+        if (pending) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                if ((pending >> k) & 1u) {
+                    const uint32_t b = t.ix[k] >> shift;
+                    const uint32_t slot = (b << cap_shift) | (((old[k] >> 16) + (old[k] & 0xFFFFu)) & (cap - 1u));
+                    rec[slot] = (unsigned long long) t.xv[k] | ((unsigned long long) (t.ix[k] & lowmask) << 32);
+                }
+            }
+        }
+    };
+
+#ifdef EK_PG_TIMING
+    const unsigned long long t_loop = wall_clock64();
+#endif
+    // whole tiles of 16-byte aligned operands: two tiles of loads in flight ahead of the one that is being placed.  The two
+    // register sets alternate (a rotation by moves would have to wait for the loads it moves).
+    size_t base = begin;
+    const size_t ntiles = vec_ok ? (end - begin) / kPgTile : 0;
+    if (ntiles > 0) {
+        Raw buf0, buf1;
+        load_raw(begin, buf0);
+        if (ntiles > 1) load_raw(begin + kPgTile, buf1);
+        for (size_t i = 0; i < ntiles; i += 2) {
+            {
+                Tile t;
+                decode(buf0, t);
+                if (i + 2 < ntiles) load_raw(begin + (i + 2) * kPgTile, buf0);
+                process(t);
+            }
+            if (i + 1 < ntiles) {
+                Tile t;
+                decode(buf1, t);
+                if (i + 3 < ntiles) load_raw(begin + (i + 3) * kPgTile, buf1);
+                process(t);
+            }
+        }
+        base = begin + ntiles * kPgTile;
+    }
+    for (; base < end; base += kPgTile) {
+        Tile t;
+        load_ragged(base, t);
+        process(t);
+    }
+
+#ifdef EK_PG_TIMING
+    if ((threadIdx.x & 63) == 0 && threadIdx.x < 128)
+        for (int k = 0; k < 8; ++k) out.dbg[((size_t) w * 2 + (threadIdx.x >> 6)) * 8 + k] = tacc[k];
+    if (threadIdx.x == 0) { out.dbg[(size_t) W * 16 + w * 4 + 0] = t_start; out.dbg[(size_t) W * 16 + w * 4 + 1] = t_loop; out.dbg[(size_t) W * 16 + w * 4 + 2] = wall_clock64(); }
+#endif
+    // what is left: one partially filled page per bucket; the workgroup's page lists
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        uint32_t fl[4], org[4], full[4], tot = 0, ftot = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = 4 * l + j;
+            fl[j] = org[j] = full[j] = 0;
+            if (b < n_buckets) {
+                const uint32_t c = cnt[b];
+                org[j] = c >> 16;
+                fl[j] = c & 0xFFFFu;
+                full[j] = npg[b];
+            }
+            tot += fl[j] ? 1u : 0u;
+            ftot += full[j];
+        }
+        uint32_t incl = tot, fincl = ftot;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = __shfl_up(incl, d, 64), fup = __shfl_up(fincl, d, 64);
+            if (l >= d) { incl += up; fincl += fup; }
+        }
+        uint32_t p = incl - tot, lo = fincl - ftot;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int b = 4 * l + j;
+            if (b < n_buckets) {
+                uint32_t entry = kNoPage;
+                if (fl[j]) {
+                    jobs[p] = (uint32_t) b | (((org[j] >> PS) & (cap_pages - 1u)) << 8);
+                    entry = (uint32_t) ((wbase + ps0 + p) << 6) | (fl[j] - 1u);
+                    ++p;
+                    atomicAdd(&out.gtotal[kMaxBuckets + b], 1u);
+                }
+                out.part[(size_t) b * W + w] = entry;
+                out.cnt_full[(size_t) b * W + w] = full[j];
+                out.loff[(size_t) b * W + w] = lo;
+                if (full[j]) atomicAdd(&out.gtotal[b], full[j]);
+                cnt[b] = lo;                                    // from here on: where the bucket's pages start in wlist[w]
+                lo += full[j];
+            }
+        }
+        if (l == 63) s_jobs = incl;
+    }
+    // wdir was written by wave 0 of this workgroup: its stores have to be done, and it is read back past the L1
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const uint32_t nfull = ps0;
+    write_out(ps0, s_jobs);
+    for (uint32_t s0 = threadIdx.x; s0 < nfull; s0 += 4 * kPgThreads) {
+        uint32_t d[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t s = s0 + u * kPgThreads;
+            d[u] = s < nfull ? __hip_atomic_load(out.wdir + wbase + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t s = s0 + u * kPgThreads;
+            if (s < nfull) out.wlist[wbase + cnt[d[u] & 0xFFu] + (d[u] >> 8)] = (uint32_t) (wbase + s);
+        }
+    }
+#ifdef EK_PG_TIMING
+    if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + w * 4 + 3] = wall_clock64();
+#endif
+}
+
+// 1024 threads: inclusive scan of one value per thread (wave shuffles + 16 wave totals)
+__device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot /* [17] */, uint32_t &total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    uint32_t incl = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += up;
+    }
+    __syncthreads();                      // the previous scan's totals have been read
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0, all = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t tk = wave_tot[k];
+        before += k < wave ? tk : 0u;
+        all += tk;
+    }
+    total = all;
+    return incl + before;
+}
+
+// One workgroup per bucket: the bucket's page list = the workgroups' lists one after the other (full pages), then the
+// partially filled pages; bucket bases of both lists; pieces for the consumers (as k_bin_scan_buckets: a share of
+// `target_pieces` in proportion to the bucket's population, at least one when it is not empty).
+static __global__ __launch_bounds__(1024) void k_page_directory(uint32_t *__restrict__ glist_full, uint32_t *__restrict__ glist_part,
+                                                                uint32_t *__restrict__ base_full, uint32_t *__restrict__ base_part,
+                                                                uint32_t *__restrict__ piece_prefix,
+                                                                const uint32_t *__restrict__ gtotal, const uint32_t *__restrict__ cnt_full,
+                                                                const uint32_t *__restrict__ loff, const uint32_t *__restrict__ part,
+                                                                const uint32_t *__restrict__ wlist, uint32_t W, uint32_t slots,
+                                                                int n_buckets, uint32_t target_pieces) {
+    __shared__ uint32_t wave_tot[17];
+    __shared__ uint32_t row[1025], lrow[1024];
+    __shared__ uint32_t s_fb, s_pb, s_f;
+    const int t = threadIdx.x, b = blockIdx.x;
+    const uint32_t f = t < n_buckets ? gtotal[t] : 0u, p = t < n_buckets ? gtotal[kMaxBuckets + t] : 0u;
+    const uint32_t wq = t, c = wq < W ? cnt_full[(size_t) b * W + wq] : 0u;
+    const uint32_t entry = wq < W ? part[(size_t) b * W + wq] : kNoPage;
+    if (wq < W) lrow[wq] = (uint32_t) ((size_t) wq * slots) + loff[(size_t) b * W + wq];
+    uint32_t total_f, total_p, total_q, total_c, total_h;
+    const uint32_t fi = pg_block_scan(f, wave_tot, total_f), pi = pg_block_scan(p, wave_tot, total_p);
+    const uint64_t pop = (uint64_t) f + p, total = (uint64_t) total_f + total_p;
+    uint32_t pieces = 0;
+    if (t < n_buckets && pop > 0 && target_pieces > 0) {
+        pieces = (uint32_t) ((pop * target_pieces + total / 2) / total);
+        if (pieces == 0) pieces = 1;
+    }
+    const uint32_t qi = pg_block_scan(pieces, wave_tot, total_q);
+    if (t == b) {
+        base_full[b] = fi - f; base_part[b] = pi - p; piece_prefix[b] = qi - pieces;
+        s_fb = fi - f; s_pb = pi - p; s_f = f;
+        if (b == n_buckets - 1) { base_full[n_buckets] = total_f; base_part[n_buckets] = total_p; piece_prefix[n_buckets] = total_q; }
+    }
+    // row b of cnt_full: exclusive prefix over the workgroups (W <= 1024)
+    const uint32_t ci = pg_block_scan(c, wave_tot, total_c);
+    if (wq < W) row[wq] = ci - c;
+    if (t == 0) row[W] = total_c;
+    const uint32_t has = entry != kNoPage ? 1u : 0u, hi = pg_block_scan(has, wave_tot, total_h);
+    __syncthreads();
+    const uint32_t fb = s_fb, pb = s_pb, F = s_f;
+    if (has) glist_part[pb + hi - 1u] = entry;
+    for (uint32_t e0 = t; e0 < F; e0 += 4 * 1024) {
+        uint32_t src[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t e = e0 + u * 1024;
+            uint32_t lo = 0, hi2 = W;                         // last w with row[w] <= e
+            while (hi2 - lo > 1) {
+                const uint32_t mid = (lo + hi2) / 2;
+                if (row[mid] <= e) lo = mid; else hi2 = mid;
+            }
+            src[u] = e < F ? __builtin_nontemporal_load(wlist + lrow[lo] + (e - row[lo])) : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (e0 + u * 1024 < F) glist_full[fb + e0 + u * 1024] = src[u];
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+struct PagedPlan {
+    int page_shift = 6;
+    uint32_t cap = 0, W = 0, slots = 0;
+    size_t chunk = 0, page_slots = 0;          // page_slots: W * slots (positions = page_slots << page_shift)
+    size_t lds = 0;
+};
+
+/// geometry of the paged partition of n elements into n_buckets buckets (4-byte values)
+static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu) {
+    PagedPlan p;
+    p.page_shift = n_buckets > 128 ? 5 : 6;
+    int nb2 = 2;
+    while (nb2 < n_buckets) nb2 <<= 1;
+    p.cap = (uint32_t) (kPgLdsElems / nb2);
+    const size_t tiles = (n + kPgTile - 1) / kPgTile;
+    p.W = (uint32_t) std::max<size_t>(1, std::min<size_t>((size_t) num_cu, tiles));
+    p.chunk = ((tiles + p.W - 1) / p.W) * kPgTile;
+    p.W = (uint32_t) std::max<size_t>(1, (n + p.chunk - 1) / p.chunk);
+    p.slots = (uint32_t) ((p.chunk >> p.page_shift) + (size_t) n_buckets);
+    p.page_slots = (size_t) p.W * p.slots;
+    p.lds = ((size_t) n_buckets * p.cap + 2) * 8;
+    return p;
+}
+
+} // namespace ek

@@ -504,3 +504,65 @@ extern "C" EK_API int ek_hip_probe_gather_pair_sliced(int slices, float *o0, con
     EK_LAUNCH_CHECK("probe_gather_pair_sliced", n, 0);
     return EK_OK;
 }
+
+// ---- single-pass paged partition (ek_paged.h): validation + timing outside the product path ---------------------------
+#define EK_PG_TIMING 1
+#include "ek_paged.h"
+
+// geometry[0..7] <- page_shift, cap, W, slots, chunk, page_slots, lds bytes, n_buckets
+extern "C" EK_API int ek_hip_probe_page_plan(size_t n, size_t table_size, int shift, uint64_t *geometry) {
+    if (int rc = ek::ensure_init()) return rc;
+    const int n_buckets = (int) ((table_size + ((size_t) 1 << shift) - 1) >> shift);
+    const ek::PagedPlan p = ek::paged_plan(n, n_buckets, ek::ctx().num_cu);
+    geometry[0] = p.page_shift; geometry[1] = p.cap; geometry[2] = p.W; geometry[3] = p.slots; geometry[4] = p.chunk;
+    geometry[5] = p.page_slots; geometry[6] = p.lds; geometry[7] = (uint64_t) n_buckets;
+    return EK_OK;
+}
+
+// meta: uint32 words laid out as  gtotal[512] | base_full[257] | base_part[257] | piece_prefix[257] | cnt_full[nb*W] | loff[nb*W] | part[nb*W]
+extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const void *index, const float *x, const uint8_t *mask,
+                                                  size_t n, size_t table_size, int shift, uint32_t target_pieces, uint16_t *lp,
+                                                  float *xp, uint32_t *wdir, uint32_t *wlist, uint32_t *glist_full,
+                                                  uint32_t *glist_part, uint32_t *meta, int directory, unsigned long long *dbg) {
+    using namespace ek;
+    if (int rc = ensure_init()) return rc;
+    Context &c = ctx();
+    const int n_buckets = (int) ((table_size + ((size_t) 1 << shift) - 1) >> shift);
+    if (n_buckets > kMaxBuckets) return fail(EK_ERR_INVALID, "too many buckets");
+    const PagedPlan p = paged_plan(n, n_buckets, c.num_cu);
+    PagedOut<float> out;
+    out.lp = lp; out.xp = xp; out.wdir = wdir; out.wlist = wlist;
+    out.gtotal = meta;
+    out.dbg = dbg;
+    uint32_t *base_full = meta + 2 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1, *piece_prefix = base_part + kMaxBuckets + 1;
+    out.cnt_full = piece_prefix + kMaxBuckets + 1;
+    out.loff = out.cnt_full + (size_t) n_buckets * p.W;
+    out.part = out.loff + (size_t) n_buckets * p.W;
+    EK_HIP_CHECK(hipMemsetAsync(meta, 0, 2 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    const Arg<uint8_t> m{ mask, 1, mask ? 1u : 0u };
+    const int vec_ok = aligned16(index) && aligned16(x) && (!mask || aligned16(mask));
+#define EK_PP_LAUNCH(I, PS, HM)                                                                                                        \
+    {                                                                                                                                  \
+        EK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_page_partition<float, I, PS, HM>),                          \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int) p.lds));                                   \
+        hipLaunchKernelGGL((k_page_partition<float, I, PS, HM>), dim3(p.W), dim3(kPgThreads), p.lds, c.stream, out, (const I *) index,  \
+                           m, x, n, p.chunk, n_buckets, shift, p.cap, p.slots, vec_ok);                                               \
+    }
+    (void) nts;
+    if (index64) {
+        if (p.page_shift == 6) { if (mask) EK_PP_LAUNCH(uint64_t, 6, true) else EK_PP_LAUNCH(uint64_t, 6, false) }
+        else { if (mask) EK_PP_LAUNCH(uint64_t, 5, true) else EK_PP_LAUNCH(uint64_t, 5, false) }
+    } else {
+        if (p.page_shift == 6) { if (mask) EK_PP_LAUNCH(uint32_t, 6, true) else EK_PP_LAUNCH(uint32_t, 6, false) }
+        else { if (mask) EK_PP_LAUNCH(uint32_t, 5, true) else EK_PP_LAUNCH(uint32_t, 5, false) }
+    }
+#undef EK_PP_LAUNCH
+    EK_LAUNCH_CHECK("probe_page_partition", n, n * 14);
+    if (directory) {
+        hipLaunchKernelGGL(k_page_directory, dim3(n_buckets), dim3(1024), 0, c.stream, glist_full, glist_part, base_full, base_part,
+                           piece_prefix, (const uint32_t *) out.gtotal, (const uint32_t *) out.cnt_full, (const uint32_t *) out.loff,
+                           (const uint32_t *) out.part, (const uint32_t *) wlist, p.W, p.slots, n_buckets, target_pieces);
+        EK_LAUNCH_CHECK("probe_page_directory", (size_t) n_buckets, 0);
+    }
+    return EK_OK;
+}

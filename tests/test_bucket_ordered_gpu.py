@@ -146,7 +146,8 @@ def test_backward_reuses_the_partition(ad):
     # ONE count / scan / partition per step, in the forward; hsum(sin(u)) with cos(u) still held by the tape is the shape of a
     # derivative: the sums of cos(u) and x cos(u) per table entry are formed in the SAME pass (EK_BUCKETED_HINT_ADJOINT) and
     # the backward sweep only folds them
-    assert ks.get("bucket_partition") == 1 and ks.get("bucket_count") == 1 and ks.get("bucket_pair_fma_reduce_adjoint") == 1, ks
+    assert ks.get("bucket_partition") == 1 and ks.get("bucket_directory") == 1 and ks.get("bucket_pair_fma_reduce_adjoint") == 1, ks
+    assert "bucket_count" not in ks and "bucket_scan" not in ks, ks          # single-pass partition (round 4): no count pass, no scans
     assert ks.get("scatter_add_fold") == 1, ks
     assert not any(k in ks for k in ("scatter_add_partition", "scatter_add_count", "gather_pair_fmadd", "sincos", "hsum_map",
                                      "bucket_accumulate", "bucket_pair_fma_reduce")), ks

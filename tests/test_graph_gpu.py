@@ -46,7 +46,7 @@ def test_cfg3b_step_graph_replay(ek, capi, n, K):
     g = ek.hip_graph_end()
     try:
         per_step = ek.hip_graph_launch_count(g)
-        assert per_step >= 6 and ek.hip_launch_count() - launches0 == per_step
+        assert per_step >= 4 and ek.hip_launch_count() - launches0 == per_step       # (round 4: single-pass partition, fewer launches)
         t = cfg3b_truth(hA, hB, hx, hidx)
         for _ in range(3):
             ek.hip_graph_launch(g)
