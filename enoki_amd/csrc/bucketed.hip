@@ -969,7 +969,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     else rc = mask.vec ? launch(k_page_partition<float, I, 5, true>) : launch(k_page_partition<float, I, 5, false>);
     if (rc) return rc;
     EK_LAUNCH_CHECK("bucket_partition", n, n * (sizeof(I) + sizeof(float)) + arg_bytes(mask, n) + n * (sizeof(uint16_t) + sizeof(float)));
-    hipLaunchKernelGGL(k_page_directory, dim3(n_buckets), dim3(1024), 0, c.stream, b->glist_full, b->glist_part, b->bucket_base,
+    hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, b->glist_full, b->glist_part, b->bucket_base,
                        b->base_part, b->piece_prefix, (const uint32_t *) gtotal, (const uint32_t *) out.cnt_full,
                        (const uint32_t *) out.loff, (const uint32_t *) out.part, (const uint32_t *) out.wlist, p.W, p.slots, n_buckets,
                        target_pieces);

@@ -335,11 +335,20 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         }
         if (l == 63) s_jobs = incl;
     }
+#ifdef EK_PG_TIMING
+    if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 0] = wall_clock64();
+#endif
     // wdir was written by wave 0 of this workgroup: its stores have to be done, and it is read back past the L1
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef EK_PG_TIMING
+    if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 1] = wall_clock64();
+#endif
     const uint32_t nfull = ps0;
     write_out(ps0, s_jobs);
+#ifdef EK_PG_TIMING
+    if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 2] = wall_clock64();
+#endif
     for (uint32_t s0 = threadIdx.x; s0 < nfull; s0 += 4 * kPgThreads) {
         uint32_t d[4];
 #pragma unroll
@@ -358,8 +367,8 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
 #endif
 }
 
-// 1024 threads: inclusive scan of one value per thread (wave shuffles + 16 wave totals)
-__device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot /* [17] */, uint32_t &total) {
+// inclusive scan of one value per thread over a workgroup of 256 threads (wave shuffles + 4 wave totals)
+__device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot /* [4] */, uint32_t &total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     uint32_t incl = v;
 #pragma unroll
@@ -372,7 +381,7 @@ __device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot
     __syncthreads();
     uint32_t before = 0, all = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < 4; ++k) {
         const uint32_t tk = wave_tot[k];
         before += k < wave ? tk : 0u;
         all += tk;
@@ -381,24 +390,32 @@ __device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot
     return incl + before;
 }
 
-// One workgroup per bucket: the bucket's page list = the workgroups' lists one after the other (full pages), then the
-// partially filled pages; bucket bases of both lists; pieces for the consumers (as k_bin_scan_buckets: a share of
-// `target_pieces` in proportion to the bucket's population, at least one when it is not empty).
-static __global__ __launch_bounds__(1024) void k_page_directory(uint32_t *__restrict__ glist_full, uint32_t *__restrict__ glist_part,
-                                                                uint32_t *__restrict__ base_full, uint32_t *__restrict__ base_part,
-                                                                uint32_t *__restrict__ piece_prefix,
-                                                                const uint32_t *__restrict__ gtotal, const uint32_t *__restrict__ cnt_full,
-                                                                const uint32_t *__restrict__ loff, const uint32_t *__restrict__ part,
-                                                                const uint32_t *__restrict__ wlist, uint32_t W, uint32_t slots,
-                                                                int n_buckets, uint32_t target_pieces) {
-    __shared__ uint32_t wave_tot[17];
+constexpr int kPgDirSlices = 4;
+
+// The bucket's page list = the workgroups' lists one after the other (full pages), then the partially filled pages; bucket
+// bases of both lists; pieces for the consumers (as k_bin_scan_buckets: a share of `target_pieces` in proportion to the
+// bucket's population, at least one when it is not empty).  Grid: (bucket, slice of the bucket's list).
+static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restrict__ glist_full, uint32_t *__restrict__ glist_part,
+                                                               uint32_t *__restrict__ base_full, uint32_t *__restrict__ base_part,
+                                                               uint32_t *__restrict__ piece_prefix,
+                                                               const uint32_t *__restrict__ gtotal, const uint32_t *__restrict__ cnt_full,
+                                                               const uint32_t *__restrict__ loff, const uint32_t *__restrict__ part,
+                                                               const uint32_t *__restrict__ wlist, uint32_t W, uint32_t slots,
+                                                               int n_buckets, uint32_t target_pieces) {
+    __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t row[1025], lrow[1024];
     __shared__ uint32_t s_fb, s_pb, s_f;
-    const int t = threadIdx.x, b = blockIdx.x;
+    const int t = threadIdx.x, b = blockIdx.x, slice = blockIdx.y;
+    // everything this workgroup reads from global memory, requested up front
     const uint32_t f = t < n_buckets ? gtotal[t] : 0u, p = t < n_buckets ? gtotal[kMaxBuckets + t] : 0u;
-    const uint32_t wq = t, c = wq < W ? cnt_full[(size_t) b * W + wq] : 0u;
-    const uint32_t entry = wq < W ? part[(size_t) b * W + wq] : kNoPage;
-    if (wq < W) lrow[wq] = (uint32_t) ((size_t) wq * slots) + loff[(size_t) b * W + wq];
+    uint32_t c[4], ent[4], lo[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t wq = 4 * t + k;
+        c[k] = wq < W ? cnt_full[(size_t) b * W + wq] : 0u;
+        lo[k] = wq < W ? loff[(size_t) b * W + wq] : 0u;
+        ent[k] = (wq < W && slice == 0) ? part[(size_t) b * W + wq] : kNoPage;
+    }
     uint32_t total_f, total_p, total_q, total_c, total_h;
     const uint32_t fi = pg_block_scan(f, wave_tot, total_f), pi = pg_block_scan(p, wave_tot, total_p);
     const uint64_t pop = (uint64_t) f + p, total = (uint64_t) total_f + total_p;
@@ -409,33 +426,48 @@ static __global__ __launch_bounds__(1024) void k_page_directory(uint32_t *__rest
     }
     const uint32_t qi = pg_block_scan(pieces, wave_tot, total_q);
     if (t == b) {
-        base_full[b] = fi - f; base_part[b] = pi - p; piece_prefix[b] = qi - pieces;
         s_fb = fi - f; s_pb = pi - p; s_f = f;
-        if (b == n_buckets - 1) { base_full[n_buckets] = total_f; base_part[n_buckets] = total_p; piece_prefix[n_buckets] = total_q; }
+        if (slice == 0) {
+            base_full[b] = fi - f; base_part[b] = pi - p; piece_prefix[b] = qi - pieces;
+            if (b == n_buckets - 1) { base_full[n_buckets] = total_f; base_part[n_buckets] = total_p; piece_prefix[n_buckets] = total_q; }
+        }
     }
-    // row b of cnt_full: exclusive prefix over the workgroups (W <= 1024)
-    const uint32_t ci = pg_block_scan(c, wave_tot, total_c);
-    if (wq < W) row[wq] = ci - c;
+    // row b of cnt_full: exclusive prefix over the workgroups (four per thread)
+    const uint32_t csum = c[0] + c[1] + c[2] + c[3], ci = pg_block_scan(csum, wave_tot, total_c);
+    uint32_t run = ci - csum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const uint32_t wq = 4 * t + k;
+        if (wq < W) { row[wq] = run; lrow[wq] = (uint32_t) ((size_t) wq * slots) + lo[k]; }
+        run += c[k];
+    }
     if (t == 0) row[W] = total_c;
-    const uint32_t has = entry != kNoPage ? 1u : 0u, hi = pg_block_scan(has, wave_tot, total_h);
+    const uint32_t hsum = (ent[0] != kNoPage) + (ent[1] != kNoPage) + (ent[2] != kNoPage) + (ent[3] != kNoPage);
+    const uint32_t hi = pg_block_scan(hsum, wave_tot, total_h);
     __syncthreads();
     const uint32_t fb = s_fb, pb = s_pb, F = s_f;
-    if (has) glist_part[pb + hi - 1u] = entry;
-    for (uint32_t e0 = t; e0 < F; e0 += 4 * 1024) {
+    if (slice == 0) {
+        uint32_t at = pb + hi - hsum;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (ent[k] != kNoPage) glist_part[at++] = ent[k];
+    }
+    const uint32_t e_begin = (uint32_t) ((uint64_t) F * slice / kPgDirSlices), e_end = (uint32_t) ((uint64_t) F * (slice + 1) / kPgDirSlices);
+    for (uint32_t e0 = e_begin + t; e0 < e_end; e0 += 4 * 256) {
         uint32_t src[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint32_t e = e0 + u * 1024;
-            uint32_t lo = 0, hi2 = W;                         // last w with row[w] <= e
-            while (hi2 - lo > 1) {
-                const uint32_t mid = (lo + hi2) / 2;
-                if (row[mid] <= e) lo = mid; else hi2 = mid;
+            const uint32_t e = e0 + u * 256;
+            uint32_t lo2 = 0, hi2 = W;                         // last w with row[w] <= e
+            while (hi2 - lo2 > 1) {
+                const uint32_t mid = (lo2 + hi2) / 2;
+                if (row[mid] <= e) lo2 = mid; else hi2 = mid;
             }
-            src[u] = e < F ? __builtin_nontemporal_load(wlist + lrow[lo] + (e - row[lo])) : 0u;
+            src[u] = e < e_end ? __builtin_nontemporal_load(wlist + lrow[lo2] + (e - row[lo2])) : 0u;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (e0 + u * 1024 < F) glist_full[fb + e0 + u * 1024] = src[u];
+            if (e0 + u * 256 < e_end) glist_full[fb + e0 + u * 256] = src[u];
     }
 }
 

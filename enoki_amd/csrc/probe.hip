@@ -506,7 +506,7 @@ extern "C" EK_API int ek_hip_probe_gather_pair_sliced(int slices, float *o0, con
 }
 
 // ---- single-pass paged partition (ek_paged.h): validation + timing outside the product path ---------------------------
-#define EK_PG_TIMING 1
+// (-DEK_PG_TIMING: per-phase cycle counters and wall-clock stamps of k_page_partition, read by tools/probe_paged.py)
 #include "ek_paged.h"
 
 // geometry[0..7] <- page_shift, cap, W, slots, chunk, page_slots, lds bytes, n_buckets
@@ -533,7 +533,11 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     PagedOut<float> out;
     out.lp = lp; out.xp = xp; out.wdir = wdir; out.wlist = wlist;
     out.gtotal = meta;
+#ifdef EK_PG_TIMING
     out.dbg = dbg;
+#else
+    (void) dbg;
+#endif
     uint32_t *base_full = meta + 2 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1, *piece_prefix = base_part + kMaxBuckets + 1;
     out.cnt_full = piece_prefix + kMaxBuckets + 1;
     out.loff = out.cnt_full + (size_t) n_buckets * p.W;
@@ -559,7 +563,7 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
 #undef EK_PP_LAUNCH
     EK_LAUNCH_CHECK("probe_page_partition", n, n * 14);
     if (directory) {
-        hipLaunchKernelGGL(k_page_directory, dim3(n_buckets), dim3(1024), 0, c.stream, glist_full, glist_part, base_full, base_part,
+        hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, glist_full, glist_part, base_full, base_part,
                            piece_prefix, (const uint32_t *) out.gtotal, (const uint32_t *) out.cnt_full, (const uint32_t *) out.loff,
                            (const uint32_t *) out.part, (const uint32_t *) wlist, p.W, p.slots, n_buckets, target_pieces);
         EK_LAUNCH_CHECK("probe_page_directory", (size_t) n_buckets, 0);

@@ -33,7 +33,7 @@ class Run:
         self.gpart = capi.Buf(np.uint32, self.W * self.nb + 1)
         self.meta = capi.Buf(np.uint32, 512 + 3 * 257 + 3 * self.nb * self.W)
         self.tp = target_pieces
-        self.dbg = capi.Buf(np.uint64, self.W * 20)
+        self.dbg = capi.Buf(np.uint64, self.W * 24)
 
     def launch(self, nts=0, directory=1):
         pcheck(pl.ek_hip_probe_page_partition(nts, int(self.idx64), P(self.idx.ptr), P(self.x.ptr), P(self.mask.ptr if self.mask else None),
@@ -118,17 +118,20 @@ if mode in ("time", "all"):
             print(f"paged partition nts={nts} directory={d}: {ms:7.4f} ms  {n * 14 / ms / 1e9:6.3f} TB/s")
     ok, nf, npart, npieces = r.verify(idx_h, x_h)
     print("verify at 64 Mi:", "ok" if ok else "MISMATCH", nf, npart, npieces)
-    r.launch(0, 0); capi.sync()
-    draw = r.dbg.numpy()
-    d = draw[:r.W * 16].reshape(r.W, 2, 8).astype(np.float64)
-    ts = draw[r.W * 16:].reshape(r.W, 4).astype(np.int64)
-    t0 = ts[:, 0].min()
-    us = lambda v: (v - t0) / 100.0
-    print(f'  wall clock (100 MHz), us from the first start: starts {us(ts[:,0]).min():.1f}..{us(ts[:,0]).max():.1f}, loop begins {us(ts[:,1]).min():.1f}..{us(ts[:,1]).max():.1f}, loop ends {us(ts[:,2]).min():.1f}..{np.median(us(ts[:,2])):.1f}..{us(ts[:,2]).max():.1f}, ends {us(ts[:,3]).min():.1f}..{np.median(us(ts[:,3])):.1f}..{us(ts[:,3]).max():.1f}; epilogue median {np.median(ts[:,3]-ts[:,2])/100.0:.1f} max {(ts[:,3]-ts[:,2]).max()/100.0:.1f}')
-    names = ["wait loads", "placement", "barrier 1", "overflow", "-", "write-out", "barrier 2", "-"]
-    tiles = r.chunk // 4096
-    for wv in (0, 1):
-        print(f"  wave {wv}: cycles per tile (mean over workgroups; 100 MHz counter?) " + ", ".join(f"{names[k]} {d[:, wv, k].mean() / tiles:7.1f}" for k in range(7)) + f"  total {d[:, wv, :7].sum(axis=1).mean() / tiles:8.1f}")
+    if os.environ.get("EK_PG_TIMING"):                 # probe library built with -DEK_PG_TIMING
+        r.launch(0, 0); capi.sync()
+        draw = r.dbg.numpy()
+        d = draw[:r.W * 16].reshape(r.W, 2, 8).astype(np.float64)
+        ts = draw[r.W * 16:r.W * 20].reshape(r.W, 4).astype(np.int64)
+        te = draw[r.W * 20:].reshape(r.W, 4).astype(np.int64)
+        print(f"  epilogue (us, median): bookkeeping {np.median(te[:,0]-ts[:,2])/100:.1f}, wait stores + barrier {np.median(te[:,1]-te[:,0])/100:.1f}, partial pages {np.median(te[:,2]-te[:,1])/100:.1f}, lists {np.median(ts[:,3]-te[:,2])/100:.1f}")
+        t0 = ts[:, 0].min()
+        us = lambda v: (v - t0) / 100.0
+        print(f"  wall clock (100 MHz), us from the first start: starts {us(ts[:,0]).min():.1f}..{us(ts[:,0]).max():.1f}, loop begins {us(ts[:,1]).min():.1f}..{us(ts[:,1]).max():.1f}, loop ends {us(ts[:,2]).min():.1f}..{np.median(us(ts[:,2])):.1f}..{us(ts[:,2]).max():.1f}, ends {us(ts[:,3]).min():.1f}..{np.median(us(ts[:,3])):.1f}..{us(ts[:,3]).max():.1f}")
+        names = ["wait loads", "placement", "barrier 1", "overflow", "-", "write-out", "barrier 2", "-"]
+        tiles = r.chunk // 4096
+        for wv in (0, 1):
+            print(f"  wave {wv}: core cycles per tile (mean over workgroups) " + ", ".join(f"{names[k]} {d[:, wv, k].mean() / tiles:7.1f}" for k in range(7)) + f"  total {d[:, wv, :7].sum(axis=1).mean() / tiles:8.1f}")
     for name, gen in (("zipf(1.3)", lambda: (np.minimum(rng.zipf(1.3, n), K) - 1).astype(np.uint32)), ("one index", lambda: np.full(n, 777, np.uint32))):
         r2 = Run(gen(), x_h, K, 13)
         f = lambda: r2.launch(0, 1)
