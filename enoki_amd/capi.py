@@ -43,7 +43,7 @@ EXPORTS = [
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
     "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
-    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add",
+    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_pair_create_masked", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add", "ek_hip_bucketed_scatter_add_scaled", "ek_hip_bucketed_early_pair",
     "ek_hip_bucketed_destroy", "ek_hip_index_partition_create", "ek_hip_index_partition_get", "ek_hip_index_partition_destroy", "ek_hip_gather_address",
 ]
 
@@ -450,11 +450,12 @@ class Bucketed:
 
     HINT_ADJOINT = 1
 
-    def __init__(self, op, A, x, C, index, hints=0):
+    def __init__(self, op, A, x, C, index, hints=0, mask=None):
         self.A, self.C, self.dtype, self.K = A, C, A.dtype, A.n
         h = ctypes.c_void_p()
-        check(lib.ek_hip_bucketed_pair_create_hinted(A.ek, index.ek, TERNARY[op], ctypes.c_void_p(A.ptr), ctypes.c_void_p(C.ptr),
+        check(lib.ek_hip_bucketed_pair_create_masked(A.ek, index.ek, TERNARY[op], ctypes.c_void_p(A.ptr), ctypes.c_void_p(C.ptr),
                                                      ctypes.c_size_t(A.n), ctypes.c_void_p(x.ptr), ctypes.c_void_p(index.ptr),
+                                                     ctypes.c_void_p(mask.ptr if mask is not None else None),
                                                      ctypes.c_size_t(index.n), ctypes.c_uint(hints), ctypes.byref(h)))
         self.handle = h
 
@@ -469,9 +470,9 @@ class Bucketed:
                                          UNARY[keep_op or "copy"]))
         return out
 
-    def scatter_add(self, targets, streams, fresh=None):
+    def scatter_add(self, targets, streams, fresh=None, scales=None):
         """streams[c] = (map_op name | None for a constant, constant value, weighted by x?); fresh[c]: table c holds no data
-        yet, its sums are written instead of added"""
+        yet, its sums are written instead of added; scales[c]: host scalar factor on stream c"""
         count = len(targets)
         bases = (ctypes.c_void_p * count)(*[t.ptr for t in targets])
         from_u = (ctypes.c_int * count)(*[0 if s[0] is None else 1 for s in streams])
@@ -479,7 +480,11 @@ class Bucketed:
         imm = (ctypes.c_uint64 * count)(*[_imm_bits(s[1], self.dtype) for s in streams])
         wt = (ctypes.c_int * count)(*[int(bool(s[2])) for s in streams])
         fr = (ctypes.c_int * count)(*[int(bool(f)) for f in fresh]) if fresh is not None else None
-        check(lib.ek_hip_bucketed_scatter_add(self.handle, count, bases, from_u, ops, imm, wt, fr))
+        if scales is not None:
+            sc = (ctypes.c_uint64 * count)(*[_imm_bits(v, self.dtype) for v in scales])
+            check(lib.ek_hip_bucketed_scatter_add_scaled(self.handle, count, bases, from_u, ops, imm, wt, fr, sc))
+        else:
+            check(lib.ek_hip_bucketed_scatter_add(self.handle, count, bases, from_u, ops, imm, wt, fr))
 
     def destroy(self):
         if self.handle:

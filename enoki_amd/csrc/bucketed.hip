@@ -346,8 +346,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
     }
 }
 
+// `active` (may be null): number of elements in the lists.  The other n - active lanes were masked out of both gathers: their
+// u is fma(0, x, 0) = 0 and they contribute map_op(0) to the reduction, whatever their x (a non-finite x would make the
+// element-order evaluation produce 0 * inf = NaN there: documented deviation).
 template <typename T, int ROp>
-__global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out, const T *__restrict__ partials, unsigned count) {
+__global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out, const T *__restrict__ partials, unsigned count,
+                                                             const uint32_t *__restrict__ active, size_t n, int map_op) {
     using R = BucketReducer<ROp, T>;
     __shared__ T wave_part[4];
     T v = R::identity();
@@ -356,7 +360,23 @@ __global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out
     for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
     if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = R::combine(R::combine(wave_part[0], wave_part[1]), R::combine(wave_part[2], wave_part[3]));
+    if (threadIdx.x == 0) {
+        T r = R::combine(R::combine(wave_part[0], wave_part[1]), R::combine(wave_part[2], wave_part[3]));
+        const size_t masked = active ? n - (size_t) active[0] : 0;
+        if (masked) {
+            const T f0 = unary_fused<T>(map_op, T(0));
+            if constexpr (ROp == EK_HSUM) {
+                r = r + (T) masked * f0;
+            } else if constexpr (ROp == EK_HPROD) {
+                T p = T(1), base = f0;
+                for (size_t e = masked; e; e >>= 1) { if (e & 1) p = p * base; base = base * base; }
+                r = r * p;
+            } else {
+                r = R::combine(r, f0);
+            }
+        }
+        out[0] = r;
+    }
 }
 
 // ---- 3. adjoint ------------------------------------------------------------------------------------
@@ -365,6 +385,7 @@ __global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out
 template <typename T, int C> struct BucketStreams {
     int map_op[C];
     T imm[C];
+    T scale[C];           // host scalar factor on the stream's value (before the weight)
     unsigned from_u, weighted;
 };
 // Two f32 tables share ONE lock per bin: the LDS holds {table 0, table 1} pairs and a bin pair is claimed by a 64-bit
@@ -514,13 +535,14 @@ struct AccumulateBody {
         T m = T(0);
         if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
         if constexpr (Spec == 1) {
-            v[0] = m;
-            v[C - 1] = dev::safe_mul(x, m);
+            v[0] = m * st.scale[0];
+            v[C - 1] = dev::safe_mul(x, m * st.scale[C - 1]);
         } else {
 #pragma unroll
             for (int c = 0; c < C; ++c) {
                 if constexpr (Map >= 0) v[c] = ((st.from_u >> c) & 1u) ? m : st.imm[c];
                 else v[c] = ((st.from_u >> c) & 1u) ? unary_fused<T>(st.map_op[c], u) : st.imm[c];
+                v[c] = v[c] * st.scale[c];
                 if ((st.weighted >> c) & 1u) v[c] = dev::safe_mul(x, v[c]);
             }
         }
@@ -835,6 +857,7 @@ struct Bucketed {
     size_t positions = 0;
     void *page_lists = nullptr;    // glist_full[page slots] | glist_part[W * n_buckets]
     uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
+    const uint32_t *active = nullptr;      // device: number of elements in the lists (null: all n -- no mask)
 
     size_t bins() const { return (size_t) 1 << shift; }
     BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
@@ -930,8 +953,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->positions = p.page_slots << p.page_shift;
     const uint32_t target_pieces = (uint32_t) bucket_target_pieces(n, n_buckets);
     b->max_pieces = target_pieces + (unsigned) n_buckets;
-    // meta: gtotal[2][256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
-    const size_t meta_words = 2 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
+    // meta: gtotal[3][256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
+    const size_t meta_words = 3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
     if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(float) + 16, &b->meta)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(uint16_t), &b->pair_idx)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(float), &b->x_b)) return rc;
@@ -940,7 +963,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->glist_full = (uint32_t *) b->page_lists;
     b->glist_part = b->glist_full + p.page_slots;
     uint32_t *gtotal = (uint32_t *) b->meta;
-    b->bucket_base = gtotal + 2 * kMaxBuckets;
+    b->bucket_base = gtotal + 3 * kMaxBuckets;
+    if (mask.vec) b->active = gtotal + 2 * kMaxBuckets;
     b->base_part = b->bucket_base + kMaxBuckets + 1;
     b->piece_prefix = b->base_part + kMaxBuckets + 1;
     b->reduce_partials = (void *) (((uintptr_t) (gtotal + meta_words) + 15) & ~(uintptr_t) 15);
@@ -956,7 +980,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.loff = out.cnt_full + part_entries;
     out.part = out.loff + part_entries;
     out.gtotal = gtotal;
-    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 2 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
         if (int rc = allow_big_lds(kernel, p.lds)) return rc;
@@ -1013,7 +1037,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     else if (keep) b->has_u = true;
     if constexpr (ROp != EK_REDUCE_NONE) {
         hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out,
-                           (const T *) b->reduce_partials, b->max_pieces);
+                           (const T *) b->reduce_partials, b->max_pieces, b->active, b->n, map_op);
         EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
     }
     return EK_OK;
@@ -1021,7 +1045,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
 
 /// reduce_op over map_op(values) of what an earlier pass kept in list order (u, or the kept half of a sincos pair)
 template <typename T, int ROp>
-static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const void *values) {
+static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const void *values, int zero_op) {
     Context &c = ctx();
     constexpr int VV = sizeof(T) == 8 ? 1 : 2;
     EK_BY_LAYOUT(b, {
@@ -1031,22 +1055,23 @@ static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const
     });
     EK_LAUNCH_CHECK("bucket_reduce_kept", b->n, b->n * sizeof(T));
     hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                       b->max_pieces);
+                       b->max_pieces, b->active, b->n, zero_op);
     EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
     return EK_OK;
 }
 
 template <typename T>
-static int bucketed_reduce_kept(Bucketed *b, int reduce_op, int map_op, void *out, const void *values) {
+static int bucketed_reduce_kept(Bucketed *b, int reduce_op, int map_op, void *out, const void *values, int zero_op) {
+    // zero_op: what the masked-out lanes (u = 0) contribute, as a function of 0
     if (b->page_shift == 0) {          // contiguous lists have no holes: an ordinary reduction
         if (map_op == EK_COPY) return ek_hip_reduce(reduce_op, b->type, out, values, b->n);
         return ek_hip_reduce_map(reduce_op, map_op, b->type, out, values, b->n);
     }
     switch (reduce_op) {
-        case EK_HSUM: return bucketed_reduce_kept_launch<T, EK_HSUM>(b, out, map_op, values);
-        case EK_HPROD: return bucketed_reduce_kept_launch<T, EK_HPROD>(b, out, map_op, values);
-        case EK_HMIN: return bucketed_reduce_kept_launch<T, EK_HMIN>(b, out, map_op, values);
-        case EK_HMAX: return bucketed_reduce_kept_launch<T, EK_HMAX>(b, out, map_op, values);
+        case EK_HSUM: return bucketed_reduce_kept_launch<T, EK_HSUM>(b, out, map_op, values, zero_op);
+        case EK_HPROD: return bucketed_reduce_kept_launch<T, EK_HPROD>(b, out, map_op, values, zero_op);
+        case EK_HMIN: return bucketed_reduce_kept_launch<T, EK_HMIN>(b, out, map_op, values, zero_op);
+        case EK_HMAX: return bucketed_reduce_kept_launch<T, EK_HMAX>(b, out, map_op, values, zero_op);
         default: return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): unknown op %d", reduce_op);
     }
 }
@@ -1073,7 +1098,7 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
     b->has_early = true;
     b->early_op = keep_op;
     hipLaunchKernelGGL((k_bucket_reduce_final<T, EK_HSUM>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                       b->max_pieces);
+                       b->max_pieces, b->active, b->n, map_op);
     EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
     return EK_OK;
 }
@@ -1085,8 +1110,8 @@ static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bo
     if (b->shift < bin_shift_of<T> && reduce_op == EK_HSUM && keep && !b->has_u && !b->has_m && !b->has_early &&
         early_pair_supported(map_op, keep_op))
         return bucketed_forward_adjoint_launch<T>(b, out, map_op, keep_op);
-    if (b->has_m && map_op == b->m_op) return bucketed_reduce_kept<T>(b, reduce_op, EK_COPY, out, b->m_b);   // the kept half itself
-    if (b->has_u) return bucketed_reduce_kept<T>(b, reduce_op, map_op, out, b->u_b);      // u already exists in list order
+    if (b->has_m && map_op == b->m_op) return bucketed_reduce_kept<T>(b, reduce_op, EK_COPY, out, b->m_b, b->m_op);   // the kept half itself
+    if (b->has_u) return bucketed_reduce_kept<T>(b, reduce_op, map_op, out, b->u_b, map_op);      // u already exists in list order
     switch (reduce_op) {
         case EK_HSUM: return bucketed_forward_launch<T, EK_HSUM>(b, out, map_op, keep, keep_op);
         case EK_HPROD: return bucketed_forward_launch<T, EK_HPROD>(b, out, map_op, keep, keep_op);
@@ -1114,7 +1139,7 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
                     b->n * (sizeof(uint16_t) + (st.from_u ? sizeof(T) : 0) + (st.weighted ? sizeof(T) : 0)) +
                     (size_t) C * b->max_pieces * Bins * sizeof(T));
     FoldTargets<T, C> targets;
-    for (int s = 0; s < C; ++s) targets.table[s] = bases[s];
+    for (int s = 0; s < C; ++s) { targets.table[s] = bases[s]; targets.scale[s] = T(1); }
     hipLaunchKernelGGL((k_bin_fold_pieces<T, C>), dim3((unsigned) ((b->table_size + 255) / 256), C), dim3(256), 0, c.stream, targets,
                        (const T *) partials.ptr, (const uint32_t *) b->piece_prefix, b->table_size, (size_t) b->max_pieces * Bins, fresh,
                        b->shift);
@@ -1125,8 +1150,11 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
 
 template <typename T>
 static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
-                                const uint64_t *imm_bits, const int *weighted, const int *fresh) {
+                                const uint64_t *imm_bits, const int *weighted, const int *fresh, const uint64_t *scale_bits) {
     RoctxRange range("enoki-hip: bucket-ordered scatter_add");
+    T scale[4] = { T(1), T(1), T(1), T(1) };
+    if (scale_bits)
+        for (int s = 0; s < count; ++s) memcpy(&scale[s], &scale_bits[s], sizeof(T));
     if (b->has_early && count >= 1 && count <= 2) {
         // exactly the streams that the forward pass summed already -- early_op(u), and x * early_op(u)?  Fold them.
         bool match = true;
@@ -1143,12 +1171,15 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
                 FoldTargets<T, 2> targets;
                 targets.table[0] = (T *) bases[s_plain];
                 targets.table[1] = (T *) bases[s_weighted];
+                targets.scale[0] = scale[s_plain];
+                targets.scale[1] = scale[s_weighted];
                 const unsigned fr = fresh ? ((fresh[s_plain] ? 1u : 0u) | (fresh[s_weighted] ? 2u : 0u)) : 0u;
                 hipLaunchKernelGGL((k_bin_fold_pieces<T, 2>), dim3(grid, 2), dim3(256), 0, c.stream, targets, (const T *) b->early,
                                    (const uint32_t *) b->piece_prefix, b->table_size, stride, fr, b->shift);
             } else {
                 FoldTargets<T, 1> targets;
                 targets.table[0] = (T *) bases[0];
+                targets.scale[0] = scale[0];
                 hipLaunchKernelGGL((k_bin_fold_pieces<T, 1>), dim3(grid, 1), dim3(256), 0, c.stream, targets,
                                    (const T *) b->early + (weighted[0] ? stride : 0), (const uint32_t *) b->piece_prefix,
                                    b->table_size, stride, (fresh && fresh[0]) ? 1u : 0u, b->shift);
@@ -1182,6 +1213,7 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
                 const int src = s0 + (swap ? 1 - s : s);
                 st.map_op[s] = (map_ops && !use_kept) ? map_ops[src] : (int) EK_COPY;
                 memcpy(&st.imm[s], &imm_bits[src], sizeof(T));
+                st.scale[s] = scale[src];
                 st.from_u |= (from_u[src] ? 1u : 0u) << s;
                 st.weighted |= (weighted[src] ? 1u : 0u) << s;
             }
@@ -1192,6 +1224,7 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
             BucketStreams<T, 1> st{};
             st.map_op[0] = (map_ops && !use_kept) ? map_ops[s0] : (int) EK_COPY;
             memcpy(&st.imm[0], &imm_bits[s0], sizeof(T));
+            st.scale[0] = scale[s0];
             st.from_u = from_u[s0] ? 1u : 0u;
             st.weighted = weighted[s0] ? 1u : 0u;
             if (int rc = bucketed_accumulate<T, 1>(b, tb, st, u_src, (fresh && fresh[s0]) ? 1u : 0u)) return rc;
@@ -1273,6 +1306,12 @@ int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *ta
 
 int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
                                        const void *x, const void *index, size_t n, unsigned hints, ek_hip_bucketed **out) {
+    return ek_hip_bucketed_pair_create_masked(type, index_type, op, table_a, table_c, table_size, x, index, nullptr, n, hints, out);
+}
+
+int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
+                                       const void *x, const void *index, const uint8_t *mask, size_t n, unsigned hints,
+                                       ek_hip_bucketed **out) {
     if (int rc = ensure_init()) return rc;
     if (!out || !table_a || !table_c || !x || !index) return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): null pointer");
     *out = nullptr;
@@ -1292,8 +1331,10 @@ int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const v
     const size_t bins = type == EK_F64 ? (size_t) bins_of<double> : (size_t) bins_of<float>;
     const bool half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint && table_size <= (size_t) kMaxBuckets * (bins / 2);
     if (type == EK_F32) {
-        const Arg<uint8_t> all{ nullptr, 1, 0u };
-        rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, all, bin_shift_of<float> - (half ? 1 : 0));
+        const Arg<uint8_t> m{ mask, 1, mask ? 1u : 0u };
+        rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (half ? 1 : 0));
+    } else if (mask) {
+        rc = fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create_masked(): masks with 4-byte element types only");
     } else {
         if (half) rc = bucketed_create<double, uint32_t, bin_shift_of<double> - 1>(b, (const double *) x, (const uint32_t *) index);
         else rc = bucketed_create<double, uint32_t, bin_shift_of<double>>(b, (const double *) x, (const uint32_t *) index);
@@ -1314,6 +1355,13 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *
 
 int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                 const uint64_t *imm_bits, const int *weighted, const int *fresh) {
+    return ek_hip_bucketed_scatter_add_scaled(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh, nullptr);
+}
+
+int ek_hip_bucketed_early_pair(int map_op, int keep_op) { return early_pair_supported(map_op, keep_op) ? 1 : 0; }
+
+int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
+                                       const uint64_t *imm_bits, const int *weighted, const int *fresh, const uint64_t *scale_bits) {
     if (int rc = ensure_init()) return rc;
     if (!b || !bases || !from_u || !imm_bits || !weighted || count < 1 || count > 4)
         return fail(EK_ERR_INVALID, "ek_hip_bucketed_scatter_add(): bad arguments");
@@ -1322,8 +1370,8 @@ int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *base
         if (from_u[s] && map_ops && map_ops[s] != EK_COPY && !unary_fusable(map_ops[s]))
             return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_scatter_add(): op %d cannot be applied on load", map_ops[s]);
     }
-    if (b->type == EK_F32) return bucketed_scatter_add<float>(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh);
-    return bucketed_scatter_add<double>(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh);
+    if (b->type == EK_F32) return bucketed_scatter_add<float>(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh, scale_bits);
+    return bucketed_scatter_add<double>(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh, scale_bits);
 }
 
 int ek_hip_bucketed_destroy(ek_hip_bucketed *b) {

@@ -633,7 +633,7 @@ __global__ __launch_bounds__(256) void k_bin_fold_groups(T *__restrict__ out, co
 }
 
 // binned path: bin k of bucket b sums the partials of the bucket's pieces; blockIdx.y = value stream (table)
-template <typename T, int C> struct FoldTargets { T *table[C]; };
+template <typename T, int C> struct FoldTargets { T *table[C]; T scale[C]; };     // scale: factor on the folded sum
 
 template <typename T, int C>
 __global__ __launch_bounds__(256) void k_bin_fold_pieces(FoldTargets<T, C> targets, const T *__restrict__ partials,
@@ -647,9 +647,14 @@ __global__ __launch_bounds__(256) void k_bin_fold_pieces(FoldTargets<T, C> targe
     partials += (size_t) blockIdx.y * partial_stride;
     const uint32_t b = (uint32_t) (k >> shift), local = (uint32_t) (k & (((size_t) 1 << shift) - 1));
     T s = ((fresh >> blockIdx.y) & 1u) ? T(0) : target[k];       // fresh: the table holds no data yet, its sums are written
+    U sum = U(0);
     for (uint32_t p = piece_prefix[b]; p < piece_prefix[b + 1]; ++p)
-        s = (T) ((U) s + (U) partials[((size_t) p << shift) + local]);
-    target[k] = s;
+        sum = (U) (sum + (U) partials[((size_t) p << shift) + local]);
+    if constexpr (std::is_floating_point_v<T>) {
+        const T f = targets.scale[blockIdx.y];
+        if (f != T(1)) sum = sum * f;
+    }
+    target[k] = (T) ((U) s + sum);
 }
 
 struct Scratch {

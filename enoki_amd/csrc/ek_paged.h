@@ -43,7 +43,7 @@ template <typename T> struct PagedOut {
     uint32_t *cnt_full;    // [n_buckets][W]  full pages of the workgroup per bucket
     uint32_t *loff;        // [n_buckets][W]  where they start in wlist[w]
     uint32_t *part;        // [n_buckets][W]  page << 6 | (count - 1) of the partially filled page, or kNoPage
-    uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
+    uint32_t *gtotal;      // [3][kMaxBuckets]  full / partially filled pages per bucket over all workgroups; [2][0]: active elements (zeroed by the host)
 #ifdef EK_PG_TIMING
     unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
 #endif
@@ -334,6 +334,13 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             }
         }
         if (l == 63) s_jobs = incl;
+        // elements this workgroup kept (masked-out entries are dropped): complete pages + what is left
+        uint32_t kept = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) kept += (full[j] << PS) + fl[j];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d, 64);
+        if (l == 0 && kept) atomicAdd(&out.gtotal[2 * kMaxBuckets], kept);
     }
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 0] = wall_clock64();

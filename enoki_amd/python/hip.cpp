@@ -50,6 +50,7 @@ PYBIND11_MODULE(hip, m) {
     bind_memory<FloatC, UInt32C>(m); bind_memory<FloatC, Int32C>(m);
     bind_memory<Int32C, UInt32C>(m); bind_memory<UInt32C, UInt32C>(m);
     bind_memory<DoubleC, UInt32C>(m);
+    bind_memory<FloatC, UInt64C>(m); bind_memory<FloatC, Int64C>(m);      // 64-bit index arrays (narrowed once, enoki/hip.h)
 
     // PCG32 (src/python/random.h:9-80, cuda_pcg32.cpp)
     using RNG = PCG32<FloatC>;

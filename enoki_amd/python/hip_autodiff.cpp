@@ -54,4 +54,5 @@ PYBIND11_MODULE(hip_autodiff, m) {
     bind_memory<FloatD, UInt32D>(m); bind_memory<FloatD, Int32D>(m);
     bind_memory<UInt32D, UInt32D>(m); bind_memory<Int32D, UInt32D>(m);
     bind_memory<DoubleD, UInt32D>(m);
+    bind_memory<FloatD, UInt64D>(m); bind_memory<FloatD, Int64D>(m);      // 64-bit index arrays (narrowed once, enoki/hip.h)
 }

@@ -61,6 +61,11 @@ namespace detail {
             bool consumed;                     // a fused consumer has read it once: the next access materialises (gathers)
             int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below), 3: zeros (no sources)
             HIPBuffer *partner = nullptr;      // map: the other half of an unevaluated sincos pair (not owning)
+            // map: the node is  scale * op(source)  -- the product of an unevaluated map with a host scalar stays a map
+            // (HIPArray::scaled_map_: the -sin(u) that d/du cos(u) records, the c * cos(u) that backward(c * y) sends down),
+            // so that its consumers still see WHICH function of the source it is.  Bits of the element type.
+            uint64_t scale_bits = 0;
+            bool scaled = false;
             // kind 2:  u = op(table[index], arg0, table2[index])  with op of the fma family -- the parameter lookup
             // `fmadd(gather(A, idx), x, gather(B, idx))`.  Left unevaluated one step longer than its gathers: when the
             // consumer does not care about the element order (a horizontal reduction, possibly through a deferred unary map;
@@ -114,6 +119,12 @@ namespace detail {
             while (pending_head()) pending_head()->force();
         }
         HIPBuffer *view_of = nullptr;          // a window into another buffer (HIPArray::view_): holds a reference on it
+        // A 64-bit integer array that was narrowed to 32 bits keeps the result for as long as its contents cannot change (owning):
+        // the gather, the tape's offset array (autodiff.h `Offset(index)`) and the adjoint scatter_add of ONE 64-bit index array then
+        // all see the same 32-bit buffer -- the index array is narrowed once, and the bucket-ordered path recognises it.
+        HIPBuffer *narrowed = nullptr;
+        int narrowed_type = 0;
+        void drop_narrowed() { if (narrowed) { HIPBuffer *n = narrowed; narrowed = nullptr; unref(n); } }
         void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
         bool exported = false;                 // an external zero-copy view (torch, __cuda_array_interface__) may exist
 
@@ -155,6 +166,18 @@ namespace detail {
                 if (q) ek_hip_free(q);
                 hip_raise("HIPArray (deferred map)");
             }
+            // a scaled node: the product with its host scalar, in place (the same two roundings as op, then mul, run eagerly)
+            auto scale_in_place = [&](HIPBuffer *b2, void *at) {
+                if (!b2->deferred->scaled) return;
+                ek_operand self{ at, 0, size }, factor{ nullptr, b2->deferred->scale_bits, 1 };
+                if (ek_hip_binary(EK_MUL, d->type, at, &self, &factor, size) != EK_OK) {
+                    ek_hip_free(p);
+                    if (q) ek_hip_free(q);
+                    hip_raise("HIPArray (deferred map)");
+                }
+            };
+            scale_in_place(this, p);
+            if (other) scale_in_place(other, q);
             ptr = p;
             if (other) {
                 other->ptr = q;
@@ -173,7 +196,7 @@ namespace detail {
             ga.table_size = d->table->size;
             ga.index = ek_operand{ d->index->ptr, 0, d->index->size };
             ga.index_type = d->index_type;
-            ga.mask = ek_operand{ nullptr, 1, 1 };
+            ga.mask = d->mask ? ek_operand{ d->mask->ptr, 0, d->mask->size } : ek_operand{ nullptr, 1, 1 };
             gc = ga;
             gc.table = d->table2->ptr;
             gc.table_size = d->table2->size;
@@ -192,8 +215,9 @@ namespace detail {
         ek_hip_bucketed *bucketed(unsigned hints = 0) {
             Deferred *d = deferred;
             if (!d->bucketed) {
-                int rc = ek_hip_bucketed_pair_create_hinted(d->type, d->index_type, d->op, d->table->ptr, d->table2->ptr, d->table->size,
-                                                            d->arg0->ptr, d->index->ptr, size, hints, &d->bucketed);
+                int rc = ek_hip_bucketed_pair_create_masked(d->type, d->index_type, d->op, d->table->ptr, d->table2->ptr, d->table->size,
+                                                            d->arg0->ptr, d->index->ptr, d->mask ? (const uint8_t *) d->mask->ptr : nullptr,
+                                                            size, hints, &d->bucketed);
                 if (rc == EK_ERR_UNSUPPORTED) return nullptr;
                 hip_check(rc, "HIPArray (bucket partition)");
             }
@@ -243,6 +267,7 @@ namespace detail {
         /// Deferred gathers that read this buffer must run before its contents change
         void force_readers() {
             while (!readers.empty()) readers.back()->force();
+            drop_narrowed();                   // (called whenever the contents may change)
         }
 
         void drop_deferred() {
@@ -271,6 +296,7 @@ namespace detail {
 
         ~HIPBuffer() {
             if (deferred) drop_deferred();
+            drop_narrowed();
             drop_host_mirror();
             if (owned && ptr) ek_hip_free(ptr);
             unref(view_of);
@@ -283,6 +309,10 @@ namespace detail {
     /// ENOKI_HIP_DEFER_GATHER=0), or hip_set_defer(false) / hip_set_defer_gather(false).  One switch per process, whichever
     /// shared object asks.
     inline bool &hip_defer_gather_flag() { return HIPBuffer::shared().defer; }
+    inline bool hip_strict_safe_mul() {
+        static const bool strict = [] { const char *e = getenv("ENOKI_HIP_STRICT_SAFE_MUL"); return e && *e == '1'; }();
+        return strict;
+    }
 
     /// Smallest array whose fusable unary results / gathers are left unevaluated (defaults 64 Ki / 4096 elements: below
     /// that a kernel launch costs more than the bytes it moves).  ENOKI_HIP_DEFER_MIN=<n> overrides both -- the test
@@ -392,9 +422,26 @@ template <typename Value_> struct HIPArray : ArrayTag {
             m_is_imm = true;
         } else if (v.m_buf) {
             size_t n = v.size();
+            // 64-bit integers narrowed to 32 bits: kept on the source (detail::HIPBuffer::narrowed)
+            constexpr bool Narrowing = std::is_integral_v<T> && sizeof(T) == 8 && std::is_integral_v<Value> && sizeof(Value) == 4 && !IsMask;
+            if constexpr (Narrowing) {
+                if (v.m_buf->narrowed && v.m_buf->narrowed_type == Type && !v.m_buf->narrowed->exported) {
+                    m_buf = v.m_buf->narrowed;
+                    m_buf->ref_count++;
+                    return;
+                }
+            }
             allocate(n);
             ek_operand oa = v.operand();
             detail::hip_check(ek_hip_cast(HIPArray<T>::Type, Type, m_buf->ptr, &oa, n), "HIPArray(cast)");
+            if constexpr (Narrowing) {
+                if (n >= 4096 && v.m_buf->owned && !v.m_buf->exported && !v.m_buf->deferred) {
+                    v.m_buf->drop_narrowed();
+                    v.m_buf->narrowed = m_buf;
+                    v.m_buf->narrowed_type = Type;
+                    m_buf->ref_count++;
+                }
+            }
         }
     }
 
@@ -720,6 +767,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if constexpr (IsFloat && (Index::Type == EK_U32 || Index::Type == EK_I32)) {
             if (HIPArray r = defer_gather_(source, detach(index), mask); r.valid()) return r;
         }
+        if constexpr (IsFloat && (Index::Type == EK_U64 || Index::Type == EK_I64)) {
+            // a table has fewer than 2^32 entries: valid 64-bit indices are narrowed ONCE (the result stays on the index array)
+            // and take the 32-bit paths -- deferral, bucket order -- like the tape's own offset arrays
+            const auto &ix = detach(index);
+            if (source.size() <= ((size_t) 1 << 32) && !ix.m_is_imm && ix.m_buf && ix.m_buf->size >= 4096) {
+                HIPArray<uint32_t> narrow(ix);
+                if (HIPArray r = defer_gather_(source, narrow, mask); r.valid()) return r;
+                return gather_<sizeof(Value)>(source.data(), narrow, mask);
+            }
+        }
         return gather_<sizeof(Value)>(source.data(), detach(index), mask);
     }
 
@@ -788,6 +845,42 @@ template <typename Value_> struct HIPArray : ArrayTag {
         return r;
     }
 
+    /// factor * (this unevaluated map) as another unevaluated map of the same source (detail::HIPBuffer::Deferred::scale_bits).
+    /// Invalid array when the product would not have the bits of the eager evaluation: two inexact factors in a row
+    /// ((f c1) c2 rounds twice, f (c1 c2) once), a factor that is not finite, deferral switched off.
+    HIPArray scaled_map_(Value factor) const {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const auto *d = m_buf->deferred;
+            if (!detail::hip_defer_gather_flag() || !(factor == factor) || factor - factor != Value(0)) return r;
+            Value scale = factor;
+            if (d->scaled) {
+                Value old;
+                memcpy(&old, &d->scale_bits, sizeof(Value));
+                if (old != Value(1) && old != Value(-1) && factor != Value(1) && factor != Value(-1)) return r;
+                scale = old * factor;                 // exact: one of the two is +-1
+            }
+            detail::HIPBuffer *src = d->table;
+            auto *nd = new typename detail::HIPBuffer::Deferred{ src, nullptr, nullptr, Type, d->index_type, sizeof(Value), false, 1, nullptr };
+            nd->scaled = true;
+            nd->scale_bits = imm_bits(scale);
+            src->ref_count++;
+            r.m_buf = new detail::HIPBuffer();
+            r.m_buf->size = m_buf->size;
+            r.m_buf->deferred = nd;
+            r.m_buf->pending_link();
+            src->readers.push_back(r.m_buf);
+        }
+        return r;
+    }
+    Value map_scale_() const {
+        Value v = Value(1);
+        if constexpr (IsFloat) {
+            if (mapped_() && m_buf->deferred->scaled) memcpy(&v, &m_buf->deferred->scale_bits, sizeof(Value));
+        }
+        return v;
+    }
+
     /// op(gather(A, idx), x, gather(C, idx)) (fma family, shared index array, no mask, x an array) stays unevaluated as a
     /// kind-2 node when the library's bucket-ordered path covers the shape (see detail::HIPBuffer::Deferred); returns an
     /// invalid array otherwise.  The two gathers are marked as consumed, exactly as if the fused kernel had run.
@@ -795,11 +888,13 @@ template <typename Value_> struct HIPArray : ArrayTag {
         HIPArray r;
         if constexpr (IsFloat) {
             const auto *p = ga.m_buf->deferred, *q = gc.m_buf->deferred;
-            if (!detail::hip_defer_gather_flag() || p->mask || q->mask || x.m_is_imm || !x.m_buf || x.m_buf->size != n ||
+            // (both gathers under the SAME mask array -- or none: masked-out lanes are dropped by the partition)
+            if (!detail::hip_defer_gather_flag() || p->mask != q->mask || x.m_is_imm || !x.m_buf || x.m_buf->size != n ||
                 !x.m_buf->owned || x.m_buf->exported || x.m_buf->deferred)
                 return r;
+            if (p->mask && sizeof(Value) != 4) return r;
             if (!ek_hip_bucketed_applicable(Type, p->index_type, p->table->size, n)) return r;
-            auto *d = new typename detail::HIPBuffer::Deferred{ p->table, p->index, nullptr, Type, p->index_type, sizeof(Value),
+            auto *d = new typename detail::HIPBuffer::Deferred{ p->table, p->index, p->mask, Type, p->index_type, sizeof(Value),
                                                                 false, 2, nullptr };
             d->table2 = q->table;
             d->arg0 = x.m_buf;
@@ -808,9 +903,10 @@ template <typename Value_> struct HIPArray : ArrayTag {
             r.m_buf->size = n;
             r.m_buf->deferred = d;
             r.m_buf->pending_link();
-            detail::HIPBuffer *seen[4] = { nullptr, nullptr, nullptr, nullptr };
+            detail::HIPBuffer *seen[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
             int k = 0;
-            for (detail::HIPBuffer *src : { d->table, d->index, d->table2, d->arg0 }) {
+            for (detail::HIPBuffer *src : { d->table, d->index, d->table2, d->arg0, d->mask }) {
+                if (!src) continue;
                 src->ref_count++;
                 bool dup = false;
                 for (int j = 0; j < k; ++j) dup = dup || seen[j] == src;
@@ -830,7 +926,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         } else {
             // the sum of one half of an unevaluated sincos pair whose other half is still held: the shape of a derivative that
             // the tape will ask for (see ek_hip_bucketed_pair_create_hinted)
-            const bool adjoint_expected = op == EK_HSUM && ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN));
+            const bool adjoint_expected = op == EK_HSUM && keep_op != EK_COPY && ek_hip_bucketed_early_pair(map_op, keep_op);
             ek_hip_bucketed *b = u->bucketed(adjoint_expected ? (unsigned) EK_BUCKETED_HINT_ADJOINT : 0u);
             if (!b) return false;
             // somebody else can still ask for u (the cos(u) of the derivative, a user handle): keep it in bucket order
@@ -962,7 +1058,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if constexpr (IsFloat) {
                 // an unevaluated unary result (the cos(u) of d/du sin(u), ...) is applied while the stream is loaded --
                 // unless a target is its own source buffer
-                if (values[c]->mapped_()) {
+                if (values[c]->mapped_() && !values[c]->m_buf->deferred->scaled) {
                     const auto *d = values[c]->m_buf->deferred;
                     in_place = true;
                     for (size_t t = 0; t < count; ++t) {
@@ -1007,14 +1103,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
     template <typename Index>
     static bool scatter_add_bucketed_(size_t count, HIPArray *const *targets, const HIPArray *const *values,
                                       const HIPArray *const *weights, const Index &index, const MaskType &mask) {
-        if (!(mask.m_is_imm && mask.m_imm) || !index.m_buf || index.m_is_imm) return false;
+        if ((mask.m_is_imm && !mask.m_imm) || !index.m_buf || index.m_is_imm) return false;
+        detail::HIPBuffer *mask_buf = mask.m_is_imm ? nullptr : mask.m_buf;      // must be u's own mask (checked below)
         detail::HIPBuffer *u = nullptr;
         int from_u[4], ops[4], weighted[4];
-        uint64_t imm[4];
+        uint64_t imm[4], scale[4];
         for (size_t c = 0; c < count; ++c) {
             const HIPArray &v = *values[c];
             detail::HIPBuffer *src = nullptr;
             from_u[c] = 1; ops[c] = EK_COPY; imm[c] = 0;
+            scale[c] = imm_bits(v.map_scale_());
             if (v.mapped_()) { src = v.m_buf->deferred->table; ops[c] = v.m_buf->deferred->index_type; }
             else if (v.paired_()) src = v.m_buf;
             else if (v.m_is_imm) { from_u[c] = 0; imm[c] = imm_bits(v.m_imm); }
@@ -1035,7 +1133,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if (!u) return false;
         }
         const auto *d = u->deferred;
-        if (d->index != index.m_buf || d->index_type != Index::Type || u->size != index.m_buf->size) return false;
+        if (d->index != index.m_buf || d->index_type != Index::Type || u->size != index.m_buf->size || d->mask != mask_buf) return false;
         for (size_t c = 0; c < count; ++c) {
             if (weighted[c] && (weights[c]->m_is_imm || weights[c]->m_buf != d->arg0)) return false;
             if (targets[c]->size() != d->table->size) return false;
@@ -1057,7 +1155,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if (fresh[c]) targets[c]->m_buf->adopt_uninitialized();
             bases[c] = targets[c]->m_buf->ptr;
         }
-        int rc = ek_hip_bucketed_scatter_add(b, (int) count, bases, from_u, ops, imm, weighted, fresh);
+        int rc = ek_hip_bucketed_scatter_add_scaled(b, (int) count, bases, from_u, ops, imm, weighted, fresh, scale);
         if (rc != EK_OK) {
             // not covered after all: the adopted targets become what they promised to be before anybody else adds to them
             for (size_t c = 0; c < count; ++c)
@@ -1320,6 +1418,8 @@ private:
             }
         }
         if constexpr (IsFloat) {
+            if (op == EK_NEG && mapped_())
+                if (HIPArray r = scaled_map_(Value(-1)); r.valid()) return r;
             if (map_fusable_(op) && can_defer_map_()) return defer_map_(op);
         }
         size_t n = size();
@@ -1387,6 +1487,16 @@ private:
             Value r;
             if (detail::host_binary<Value>(op, m_imm, b.m_imm, r)) return HIPArray(r);
         }
+        if constexpr (IsFloat) {
+            // an unevaluated map times a host scalar stays an unevaluated map (safe_mul(w, c) with c != 0 is w * c up to the
+            // sign of a zero, like the unit-weight shortcuts of the tape; ENOKI_HIP_STRICT_SAFE_MUL=1 evaluates literally)
+            if (op == EK_MUL || (op == EK_SAFE_MUL && !detail::hip_strict_safe_mul())) {
+                const HIPArray *m = mapped_() && b.m_is_imm ? this : (b.mapped_() && m_is_imm ? &b : nullptr);
+                const HIPArray *c = m == this ? &b : this;
+                if (m && c->m_imm != Value(0))
+                    if (HIPArray r = m->scaled_map_(c->m_imm); r.valid()) return r;
+            }
+        }
         size_t n = broadcast_size(size(), b.size());
         if ((op == EK_ADD || op == EK_SUB || op == EK_MUL) && (deferred_() || b.deferred_())) {
             const HIPArray *x[3] = { this, &b, nullptr };
@@ -1431,17 +1541,31 @@ private:
                 const auto *d = m_buf->deferred;
                 detail::HIPBuffer *src = d->table;
                 // map(u) with u an unevaluated fma of gathers: gathers, fma, map and reduction bucket by bucket
-                if (src->deferred && src->deferred->kind == 2) {
-                    // the other half of an unevaluated sincos pair is what will be asked for next (the derivative): keep THAT
-                    // in bucket order rather than u
-                    int keep_op = EK_COPY;
-                    if (d->partner && d->partner->deferred && d->partner->deferred->kind == 1 && d->partner->deferred->table == src)
-                        keep_op = d->partner->deferred->index_type;
-                    if (reduce_bucketed_(src, op, d->index_type, r.m_buf->ptr, 1, keep_op)) return r;
+                // scale * f(u): sums are linear -- reduce f(u) as usual, scale the result (the order of the roundings is that of
+                // a reduction anyway); other reductions of a scaled map see the evaluated array
+                const bool scaled = d->scaled;
+                if (!scaled || op == EK_HSUM) {
+                    auto finish = [&]() -> HIPArray { return scaled ? r.binary(EK_MUL, HIPArray(map_scale_()), what) : r; };
+                    if (src->deferred && src->deferred->kind == 2) {
+                        // Which function of u will be asked for next?  Another unevaluated map of the same u that somebody holds
+                        // is the derivative's factor (the cos(u) next to sin(u), -sin(u) next to cos(u), rcp(u) next to log(u));
+                        // a map that is itself held elsewhere is its own (exp).  THAT is kept in bucket order rather than u --
+                        // or, for y = hsum(f(u)), summed per table entry on the spot (ek_hip_bucketed_pair_create_hinted).
+                        int keep_op = EK_COPY, others = 0;
+                        for (detail::HIPBuffer *rd : src->readers)
+                            if (rd != m_buf && rd->deferred && rd->deferred->kind == 1 && rd->deferred->table == src) {
+                                keep_op = rd->deferred->index_type;
+                                ++others;
+                            }
+                        if (others == 0 && m_buf->ref_count > 1) keep_op = d->index_type;
+                        else if (others != 1) keep_op = EK_COPY;
+                        // (a value that somebody else holds as well will be asked for again: u counts as held, too)
+                        if (reduce_bucketed_(src, op, d->index_type, r.m_buf->ptr, m_buf->ref_count > 1 ? 0 : 1, keep_op)) return finish();
+                    }
+                    if (src->deferred) src->force();
+                    detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, src->ptr, n), what);
+                    return finish();
                 }
-                if (src->deferred) src->force();
-                detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, src->ptr, n), what);
-                return r;
             }
             if (paired_() && reduce_bucketed_(m_buf, op, EK_COPY, r.m_buf->ptr, 1)) return r;
         }

@@ -275,9 +275,25 @@ EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const v
 EK_API int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *table_a, const void *table_c,
                                               size_t table_size, const void *x, const void *index, size_t n, unsigned hints,
                                               ek_hip_bucketed **out);
+/* Both gathers under ONE mask array (cuda.h:845-864: masked-out lanes gather 0): inactive entries are dropped by the partition --
+ * their u = fma(0, x, 0) = 0 enters a reduction as map_op(0), added in the final step, and they scatter nothing.  (Where the
+ * element-order evaluation would produce 0 * inf = NaN for a non-finite x under a cleared mask bit, this path still says 0.)
+ * mask: n bytes or NULL; 4-byte element types only. */
+EK_API int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const void *table_a, const void *table_c,
+                                              size_t table_size, const void *x, const void *index, const uint8_t *mask, size_t n,
+                                              unsigned hints, ek_hip_bucketed **out);
 EK_API int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *out, int keep_values, int keep_op);
 EK_API int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                        const uint64_t *imm_bits, const int *weighted, const int *fresh);
+/* scatter_add with a host scalar factor per stream: v_c = scale_c * (from_u[c] ? map_ops[c](u) : imm_c) -- what the tape sends
+ * down for backward(c * y), for the -sin(u) of d/du cos(u), ...: the product of an unevaluated function of u with a host scalar
+ * (enoki/hip.h: HIPArray::scaled_map_).  scale_bits = NULL: all ones.  Sums that the reduce call of a hinted object formed
+ * early are folded with the factor. */
+EK_API int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
+                                              const uint64_t *imm_bits, const int *weighted, const int *fresh, const uint64_t *scale_bits);
+/* != 0: a hinted object sums keep_op(u) and x * keep_op(u) per table entry inside reduce(EK_HSUM, map_op, keep, keep_op):
+ * {sin, cos}, {cos, sin}, {log, rcp} and {f, f} for f in neg abs sqrt rcp rsqrt sin cos exp log */
+EK_API int ek_hip_bucketed_early_pair(int map_op, int keep_op);
 EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
 /* Partition of an INDEX array by bucket of the range it points into: the active entries (mask) of `index` are grouped by
  * bucket = index >> shift and stored as bucket-local indices (index & ((1 << shift) - 1)), bucket b at local[bucket_base[b] ..

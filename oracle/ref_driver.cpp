@@ -479,6 +479,43 @@ float ref_cfg3b(const float *A_, const float *B_, size_t k, const float *x_, con
     return y.value_().coeff(0);
 }
 
+/* The neighbours of cfg3b that bench.py times next to it (round 4): y = seed * hsum(f(fmadd(gather(A, idx, mask), x,
+   gather(B, idx, mask)))) with f = sin (0) | cos (1) | exp (2) | log(.)^2-free: plain log (3), a 32- or 64-bit index array and an
+   optional mask; backward() of the scaled loss. */
+float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float *x_, const void *idx_, int idx64,
+                        const uint8_t *mask_, size_t n, int func, float seed, float *grad_A, float *grad_B, double *seconds) {
+    FloatD::set_log_level_(0);
+    FloatD A = FloatX::copy(A_, k), B = FloatX::copy(B_, k), x = FloatX::copy(x_, n);
+    using UInt64X = DynamicArray<Packet<uint64_t, Packet<float>::Size>>;
+    using UInt64D = DiffArray<UInt64X>;
+    mask_t<FloatD> mask = true;
+    if (mask_) {
+        mask_t<FloatX> m;
+        set_slices(m, n);
+        for (size_t i = 0; i < n; ++i) m.coeff(i) = mask_[i] != 0;
+        mask = mask_t<FloatD>(m);
+    }
+    set_requires_gradient(A);
+    set_requires_gradient(B);
+    double t0 = now();
+    FloatD a, b;
+    if (idx64) {
+        UInt64D idx = UInt64X::copy(idx_, n);
+        a = gather<FloatD>(A, idx, mask); b = gather<FloatD>(B, idx, mask);
+    } else {
+        UInt32D idx = UInt32X::copy(idx_, n);
+        a = gather<FloatD>(A, idx, mask); b = gather<FloatD>(B, idx, mask);
+    }
+    FloatD u = fmadd(a, x, b);
+    FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : log(u));
+    FloatD z = seed == 1.f ? y : y * seed;
+    backward(z);
+    if (seconds) *seconds = now() - t0;
+    if (grad_A) store(gradient(A), grad_A, k);
+    if (grad_B) store(gradient(B), grad_B, k);
+    return z.value_().coeff(0);
+}
+
 /* Generic little tape programs used by the tape parity tests: see tests/test_tape_parity.py.
    prog: a sequence of (opcode, arg0, arg1, arg2) int32 quadruples acting on a register file of
    FloatD values.  Registers [0, n_in) are preloaded from `inputs` (each of length sizes[i]) and

@@ -164,6 +164,27 @@ def cfg3b_truth(A, B, x, idx):
     return out
 
 
+def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
+    """cfg3b_truth for the neighbours that bench.py times next to the headline: y = seed * hsum(f(u)), f = sin | cos | exp,
+    masked-out lanes gather 0 (u = 0, no gradient).  Same class-D bounds, scaled by |seed| and by the size of f and f'."""
+    eps = 2.0 ** -24
+    K, n = A.size, x.size
+    ii = idx.astype(np.int64)
+    on = np.ones(n, bool) if mask is None else np.asarray(mask, bool)
+    x64 = x.astype(np.float64)
+    u = np.where(on, A.astype(np.float64)[ii] * x64 + B.astype(np.float64)[ii], 0.0)
+    f, df = {"sin": (np.sin, np.cos), "cos": (np.cos, lambda v: -np.sin(v)), "exp": (np.exp, np.exp)}[func]
+    s, c = f(u) * seed, df(u) * seed
+    big = max(1.0, float(np.abs(s).max()), float(np.abs(c).max()))          # |f|, |f'| <= e^2 for exp on |u| <= 2
+    cnt = np.bincount(ii[on], minlength=K)
+    out = {"y": float(s.sum()), "y_bound": eps * (hsum_depth(n) * float(np.abs(s).sum()) + 8 * big * n), "cnt": cnt,
+           "y_stat_bound": stat_sum_bound(s, hsum_depth(n)) + 4 * eps * abs(float(s.sum()))}
+    for name, terms in (("gA", c * x64), ("gB", c)):
+        out[name] = np.bincount(ii[on], weights=terms[on], minlength=K)
+        out[name + "_bound"] = eps * (cnt * np.bincount(ii[on], weights=np.abs(terms[on]), minlength=K) + 8 * big * cnt)
+    return out
+
+
 def stat_sum_bound(terms64, depth, sigmas=5.0):
     """What the error of an f32 sum of these terms looks like when roundings behave like independent noise (they do): for
     sequential chains of `depth` additions followed by a balanced tree, sigma^2 ~= u^2 (depth / 6 + 8) sum t^2 from the

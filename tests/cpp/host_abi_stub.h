@@ -236,9 +236,11 @@ struct ek_hip_bucketed {
     float *x;
     uint32_t *idx;
     float *u;
+    uint8_t *mask = nullptr;       // null: every lane is active
 };
 static long g_bucketed_live = 0, g_bucketed_reduces = 0, g_bucketed_scatters = 0;
 static float bucketed_u(const ek_hip_bucketed *b, size_t i) {
+    if (b->mask && !b->mask[i]) return 0.f;                // masked-out lanes gather 0 (the device path drops them: u = 0)
     float a = b->a[b->idx[i]], c = b->c[b->idx[i]];
     if (b->op == EK_FNMADD || b->op == EK_FNMSUB) a = -a;
     if (b->op == EK_FMSUB || b->op == EK_FNMSUB) c = -c;
@@ -263,6 +265,12 @@ int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const v
                                        ek_hip_bucketed **out) {
     return ek_hip_bucketed_pair_create(type, index_type, op, a, c, table_size, x, index, n, out);
 }
+int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const void *a, const void *c, size_t table_size, const void *x,
+                                       const void *index, const uint8_t *mask, size_t n, unsigned, ek_hip_bucketed **out) {
+    int rc = ek_hip_bucketed_pair_create(type, index_type, op, a, c, table_size, x, index, n, out);
+    if (rc == EK_OK && mask) { (*out)->mask = (uint8_t *) malloc(n); memcpy((*out)->mask, mask, n); }
+    return rc;
+}
 int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int keep, int /* keep_op: a hint, u is kept */) {
     ++g_bucketed_reduces;
     float *u = (float *) malloc(b->n * sizeof(float));
@@ -277,8 +285,12 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int k
     return EK_OK;
 }
 static long g_fresh_targets = 0;
-int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
-                                const uint64_t *imm, const int *weighted, const int *fresh) {
+int ek_hip_bucketed_early_pair(int map_op, int keep_op) {
+    return (map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN) || (map_op == EK_LOG && keep_op == EK_RCP) ||
+           map_op == keep_op;
+}
+int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
+                                       const uint64_t *imm, const int *weighted, const int *fresh, const uint64_t *scale) {
     ++g_bucketed_scatters;
     for (int c = 0; c < count; ++c) {
         if (fresh && fresh[c]) {           // the table holds no data yet (malloc'd garbage here): its sums are written
@@ -286,17 +298,23 @@ int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *base
             for (size_t k = 0; k < b->table_size; ++k) ((float *) bases[c])[k] = 0.f;
         }
         for (size_t i = 0; i < b->n; ++i) {
+            if (b->mask && !b->mask[i]) continue;
             float v;
             if (from_u[c]) v = unary_f(ops ? ops[c] : (int) EK_COPY, b->u ? b->u[i] : bucketed_u(b, i));
             else { uint32_t bits = (uint32_t) imm[c]; memcpy(&v, &bits, 4); }
+            if (scale) { uint32_t bits = (uint32_t) scale[c]; float f; memcpy(&f, &bits, 4); v = v * f; }
             if (weighted[c]) v = (b->x[i] == 0.f || v == 0.f) ? 0.f : b->x[i] * v;
             ((float *) bases[c])[b->idx[i]] += v;
         }
     }
     return EK_OK;
 }
+int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
+                                const uint64_t *imm, const int *weighted, const int *fresh) {
+    return ek_hip_bucketed_scatter_add_scaled(b, count, bases, from_u, ops, imm, weighted, fresh, nullptr);
+}
 int ek_hip_bucketed_destroy(ek_hip_bucketed *b) {
-    if (b) { free(b->x); free(b->idx); free(b->u); delete b; --g_bucketed_live; }
+    if (b) { free(b->x); free(b->idx); free(b->u); free(b->mask); delete b; --g_bucketed_live; }
     return EK_OK;
 }
 int ek_hip_scatter(int, int, void *base, const ek_operand *v, const ek_operand *index, const ek_operand *mask, size_t n) {

@@ -1,0 +1,95 @@
+"""The neighbours of the headline step (BASELINE configs[2]): the same gather -> fma -> f -> hsum -> backward() chain with another
+f, a scaled loss, masked gathers, 64-bit index arrays.  Each must (a) agree with the reference build (oracle/_ref) and the float64
+evaluation inside the class-D bounds and (b) stay on the bucket-ordered path -- one partition, no element-order gather, no
+second count / partition in the backward sweep."""
+import json
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from conftest import cfg3b_variant_truth, hash_u32, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+N, K = 1 << 22, 1 << 20
+
+
+@pytest.fixture(scope="module")
+def ad():
+    import enoki_amd.hip_autodiff as m
+    m.hip_init(0)
+    return m
+
+
+@pytest.fixture(scope="module")
+def ref():
+    try:
+        return ol.ref()
+    except Exception:
+        pytest.skip("oracle/_ref is not built")
+
+
+@pytest.fixture(scope="module")
+def data():
+    A, B, x = uniform_pm1(K, 6), uniform_pm1(K, 7), uniform_pm1(N, 2)
+    idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)
+    mask = (hash_u32(np.arange(N, dtype=np.uint64), 5) & 3) != 0             # 75 % active
+    return A, B, x, idx, mask
+
+
+def kernels(m, fn):
+    m.hip_profile_begin()
+    out = fn()
+    prof = json.loads(m.hip_profile_end())
+    return out, {k["kernel"]: k["launches"] for k in prof if k["launches"]}
+
+
+def run(ad, A, B, x, idx, mask=None, func="sin", seed=1.0, idx64=False):
+    dA, dB = ad.Float32(A), ad.Float32(B)
+    ad.set_requires_gradient(dA); ad.set_requires_gradient(dB)
+    di = ad.UInt64(idx.astype(np.uint64)) if idx64 else ad.UInt32(idx)
+    xd = ad.Float32(x)
+    if mask is not None:
+        dm = ad.Mask(mask)
+        a, b = ad.gather(dA, di, dm), ad.gather(dB, di, dm)
+    else:
+        a, b = ad.gather(dA, di), ad.gather(dB, di)
+    y = ad.hsum(getattr(ad, func)(ad.fmadd(a, xd, b)))
+    z = y if seed == 1.0 else y * seed
+    ad.backward(z)
+    return float(ad.detach(z).numpy()[0]), ad.gradient(dA).numpy(), ad.gradient(dB).numpy()
+
+
+CASES = {
+    "sin": dict(),
+    "cos": dict(func="cos"),
+    "exp": dict(func="exp"),
+    "seed3": dict(seed=3.0),
+    "exp_negative_seed": dict(func="exp", seed=-0.5),
+    "masked": dict(masked=True),
+    "i64": dict(idx64=True),
+    "masked_exp_i64_seed": dict(func="exp", masked=True, idx64=True, seed=2.0),
+}
+# what the step may launch when it stays in bucket order: ONE partition in the forward pass, the adjoint formed there as well
+EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed"}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_neighbour_matches_the_reference_and_stays_in_bucket_order(ad, ref, data, name):
+    A, B, x, idx, mask = data
+    kw = dict(CASES[name])
+    m = mask if kw.pop("masked", False) else None
+    idx64 = kw.pop("idx64", False)
+    (y, gA, gB), ks = kernels(ad, lambda: run(ad, A, B, x, idx, mask=m, idx64=idx64, **kw))
+    t = cfg3b_variant_truth(A, B, x, idx, mask=m, **kw)
+    ry, rgA, rgB, _ = ref.cfg3b_variant(A, B, x, idx.astype(np.uint64) if idx64 else idx, mask=m, **kw)
+    assert abs(y - t["y"]) <= t["y_bound"] and abs(y - t["y"]) <= t["y_stat_bound"], (y, t["y"], t["y_stat_bound"])
+    assert abs(y - ry) <= t["y_bound"] + abs(ry - t["y"])
+    for g, arr, r in (("gA", gA, rgA), ("gB", gB, rgB)):
+        err = np.abs(arr - t[g])
+        assert np.all(err <= t[g + "_bound"]), (name, g, float((err / np.maximum(t[g + "_bound"], 1e-30)).max()))
+        assert np.all(np.abs(arr - r) <= 2 * t[g + "_bound"]), (name, g)
+    assert ks.get("bucket_partition") == 1, (name, ks)
+    assert not any(k in ks for k in ("gather_pair_fmadd", "gather", "scatter_add_partition", "scatter_add_count", "hsum_map")), (name, ks)
+    if name in EARLY:
+        assert ks.get("bucket_pair_fma_reduce_adjoint") == 1 and "bucket_accumulate" not in ks, (name, ks)
