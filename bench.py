@@ -54,6 +54,15 @@ DESCRIPTION = {
                      "so the rays are partitioned by pixel bucket once and every bucket streams its grid slice in and its image slice "
                      "out in order; bit-identical image and hit count",
 }
+# the neighbours of the headline step (same chain, one thing changed): what a caller meets one step off the benchmark's exact
+# expression.  Parity of each against the reference build at 64 Mi elements: tests/test_headline_parity_gpu.py.
+CFG3B_VARIANTS = {
+    "cfg3b_cos": dict(func="cos"), "cfg3b_exp": dict(func="exp"), "cfg3b_seed3": dict(seed=3.0), "cfg3b_masked": dict(masked=True),
+    "cfg3b_i64": dict(idx64=True), "cfg3b_K2Mi": dict(K=1 << 21), "cfg3b_K4Mi": dict(K=1 << 22), "cfg3b_K16Mi": dict(K=1 << 24),
+}
+for _w, _v in CFG3B_VARIANTS.items():
+    DESCRIPTION[_w] = ("cfg3b with " + ", ".join(f"{k}={v}" for k, v in _v.items()) +
+                       " (y = seed * hsum(func(fmadd(gather(A, idx, mask), x, gather(B, idx, mask)))), backward(); 75 % mask of SURVEY 8d)")
 N_RAYS_PER_GPU = 1 << 25
 N_PATHS_PER_GPU = 1 << 24
 DESCRIPTION["cfg5"] = ("synthetic 3-bounce path tracer inside a textured unit sphere (SURVEY 8d cfg5, not in the reference): "
@@ -73,7 +82,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5"])
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5"] + list(CFG3B_VARIANTS))
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
@@ -124,19 +133,23 @@ def pmc_traffic(kernel):
                           "2 x FETCH_SIZE + WRITE_SIZE per launch")
 
 
-def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024):
-    """cfg5: `n` light paths inside the unit sphere whose inner surface carries the albedo texture `tex`
-    (differentiable, width x width texels over (phi, theta)).  Geometry and sampling use plain arrays (enoki.hip),
-    only the texture lookups are on the tape, so backward() is one scatter_add per bounce into grad(tex).
-    Sampling: PCG32 streams first_lane .. first_lane + n (enoki/random.h); sphere intersection as in the
-    reference's tests/sphere.cpp:67-78; concentric disk mapping as in tests/autodiff.cpp:468-491."""
+def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024, record=None):
+    """cfg5 op by op: examples/path_trace.h (the ONE source of the program: the reference-side oracle `ref_cfg5` instantiates that
+    template on the reference's arrays, the fused kernel on one-element packets) spelled with the python bindings, operation for
+    operation in the same order -- only parity class A operations decide where a path goes (no normalize / rcp / rsqrt), so all
+    three visit the same texels.  Geometry and sampling use plain arrays (enoki.hip); only the texture lookups are on the tape, so
+    backward() is one scatter_add per bounce into grad(tex)."""
     import math
     F, U32, U64, V3 = ekc.Float32, ekc.UInt32, ekc.UInt64, ekc.Vector3f
+    pi = float(np.float32(math.pi))
+    f32 = lambda v: float(np.float32(v))
+    def unit(v):                      # component by component: exact divisions (vector / value goes through rcp in the reference)
+        l = ekc.sqrt(ekc.dot(v, v))
+        return V3(v.x / l, v.y / l, v.z / l)
     rng = ekc.PCG32(U64(seed), U64.arange(n) + U64(first_lane))
-    # primary directions: uniform on the sphere; origin: a fixed point inside
     z = F(1.0) - F(2.0) * rng.next_float32()
     r = ekc.sqrt(ekc.max(F(0.0), F(1.0) - z * z))
-    phi = F(2.0 * math.pi) * rng.next_float32()
+    phi = F(f32(2.0 * np.float32(pi))) * rng.next_float32()
     s_, c_ = ekc.sincos(phi)
     d = V3(r * c_, r * s_, z)
     o = V3(F(0.1), F(0.2), F(-0.1))
@@ -146,12 +159,14 @@ def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024):
         b = ekc.dot(o, d)
         c = ekc.dot(o, o) - F(1.0)
         t = ekc.sqrt(ekc.max(F(0.0), b * b - c)) - b                       # far root: we are inside the sphere
-        p = ekc.normalize(o + d * t)
-        theta = ekc.acos(ekc.clamp(p.z, F(-1.0), F(1.0)))
+        p = unit(o + d * t)
+        theta = ekc.acos(ekc.min(ekc.max(p.z, F(-1.0)), F(1.0)))
         ph = ekc.atan2(p.y, p.x)
-        uu = ekc.fmadd(ph, F(0.5 / math.pi), F(0.5)); vv = theta * F(1.0 / math.pi)
+        uu = ekc.fmadd(ph, F(f32(np.float32(0.5) / np.float32(pi))), F(0.5)); vv = theta * F(f32(np.float32(1.0) / np.float32(pi)))
         ix = ekc.min(U32(uu * F(float(width))), U32(width - 1)); iy = ekc.min(U32(vv * F(float(width))), U32(width - 1))
         texel = iy * U32(width) + ix
+        if record is not None:
+            record.append(texel)
         albedo = ek.gather(tex, ek.UInt32(texel))                          # the only differentiable operation
         radiance = radiance + throughput * albedo * ek.Float32(0.1)        # the surface emits a little of its colour
         throughput = throughput * albedo
@@ -161,7 +176,8 @@ def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024):
         swap = ekc.abs(r1) < ekc.abs(r2)
         rad = ekc.select(swap, r2, r1)
         ratio = ekc.select(swap, r1, r2) / ekc.select(rad == F(0.0), F(1.0), rad)
-        ang = ekc.select(swap, F(0.5 * math.pi) - F(0.25 * math.pi) * ratio, F(0.25 * math.pi) * ratio)
+        half_pi, quarter_pi = f32(np.float32(0.5) * np.float32(pi)), f32(np.float32(0.25) * np.float32(pi))
+        ang = ekc.select(swap, F(half_pi) - F(quarter_pi) * ratio, F(quarter_pi) * ratio)
         sn, cs = ekc.sincos(ang)
         dx = rad * cs; dy = rad * sn
         dz = ekc.sqrt(ekc.max(F(0.0), F(1.0) - dx * dx - dy * dy))
@@ -171,7 +187,7 @@ def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024):
         bb = nrm.x * nrm.y * a
         sx = V3(F(1.0) + sign * nrm.x * nrm.x * a, sign * bb, F(-1.0) * sign * nrm.x)
         ty = V3(bb, sign + nrm.y * nrm.y * a, F(-1.0) * nrm.y)
-        d = ekc.normalize(sx * dx + ty * dy + nrm * dz)
+        d = unit(sx * dx + ty * dy + nrm * dz)
         o = p + nrm * F(1e-3)
     radiance = radiance + throughput                                        # leftover energy reaches a white environment
     return ek.hsum(radiance)
@@ -204,17 +220,28 @@ class Bench:
         n, begin = self.n, self.begin
         x = synth.uniform_pm1(begin, n, 2)
         out = {}
-        if workload == "cfg3b":
-            A0 = synth.uniform_pm1(0, K_TABLE, 6); B0 = synth.uniform_pm1(0, K_TABLE, 7)
-            idx = ek.UInt32(synth.index_mod(begin, n, 4, K_TABLE))
+        if workload == "cfg3b" or workload in CFG3B_VARIANTS:
+            var = CFG3B_VARIANTS.get(workload, {})
+            kt = var.get("K", K_TABLE)
+            A0 = synth.uniform_pm1(0, kt, 6); B0 = synth.uniform_pm1(0, kt, 7)
+            idx = ek.UInt32(synth.index_mod(begin, n, 4, kt))
+            if var.get("idx64"):
+                idx = ek.UInt64(idx)
+            mask = ek.Mask((synth.hash_u32(begin, n, 5) & ekc.UInt32(3)) != ekc.UInt32(0)) if var.get("masked") else None
+            func, seed = getattr(ek, var.get("func", "sin")), var.get("seed", 1.0)
             xd = ek.Float32(x)
             packer = self.sh if ekd.active() else None
 
             def compute():
                 A = ek.Float32(A0); B = ek.Float32(B0)
                 ek.set_requires_gradient(A); ek.set_requires_gradient(B)
-                a = ek.gather(A, idx); b = ek.gather(B, idx)
-                y = ek.hsum(ek.sin(ek.fmadd(a, xd, b)))
+                if mask is not None:
+                    a = ek.gather(A, idx, mask); b = ek.gather(B, idx, mask)
+                else:
+                    a = ek.gather(A, idx); b = ek.gather(B, idx)
+                y = ek.hsum(func(ek.fmadd(a, xd, b)))
+                if seed != 1.0:
+                    y = y * seed
                 ek.backward(y)
                 out["y"] = ek.detach(y)
                 out["gA"], out["gB"] = ek.gradient(A), ek.gradient(B)
@@ -351,7 +378,7 @@ class Bench:
                         out["reduced"] = [self.sh.reduce(out["y"])]
                         out["plan"] = self.sh.flush()
         ek.hip_sync()
-        if workload in ("cfg3b", "cfg3a", "cfg2"):
+        if workload in ("cfg3b", "cfg3a", "cfg2") or workload in CFG3B_VARIANTS:
             def step():
                 compute()
                 exchange()
@@ -666,7 +693,7 @@ def main():
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
     if b.world == 1 and not args.no_also:
-        for w in ("cfg3a", "cfg2", "cfg3b", "cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5"):
+        for w in ("cfg3a", "cfg2", "cfg3b") + tuple(CFG3B_VARIANTS) + ("cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5"):
             if w != args.workload:
                 r = b.run(w, max(5, args.steps // 2), 2, 3)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
@@ -675,6 +702,8 @@ def main():
                            "dominant_kernel": r["roofline"]["kernel"] if r["roofline"] else None,
                            "dominant_kernel_frac": r["roofline"]["frac"] if r["roofline"] else None,
                            "workload": DESCRIPTION[w]}
+                if w in CFG3B_VARIANTS:
+                    also[w]["parity"] = "against the reference build and float64 at 64 Mi elements: tests/test_headline_parity_gpu.py::test_cfg3b_neighbours_at_the_headline_size"
                 if w == "cfg5":
                     also[w]["parity"] = "no oracle (synthetic workload, not in the reference): gradient checked against finite differences only (tests/test_cfg5_gpu.py)"
     cpu, parity = None, None

@@ -36,6 +36,7 @@
 #include <string>
 #include <vector>
 
+#include "../examples/path_trace.h"
 using namespace enoki;
 
 namespace {
@@ -514,6 +515,83 @@ float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float 
     if (grad_A) store(gradient(A), grad_A, k);
     if (grad_B) store(gradient(B), grad_B, k);
     return z.value_().coeff(0);
+}
+
+/* cfg5 (BASELINE configs[4], synthetic): the templated path tracer of examples/path_trace.h on the reference's own arrays.
+   loss = hsum(radiance over n paths), backward() -> grad_tex (K = width * width texels). */
+float ref_cfg5(const float *tex_, size_t k, size_t n, uint64_t seed, uint64_t first_lane, int bounces, uint32_t width,
+               float *grad_tex, double *seconds) {
+    FloatD::set_log_level_(0);
+    using UInt64X = DynamicArray<Packet<uint64_t, Packet<float>::Size>>;
+    FloatD tex = FloatX::copy(tex_, k);
+    set_requires_gradient(tex);
+    double t0 = now();
+    PCG32<FloatX> rng(UInt64X(seed), arange<UInt64X>(n) + UInt64X(first_lane));
+    auto lookup = [&](const UInt32X &texel) { return gather<FloatD>(tex, UInt32D(texel)); };
+    FloatD radiance = cfg5::path_trace<FloatD, FloatX>(rng, lookup, bounces, width);
+    FloatD y = hsum(radiance);
+    backward(y);
+    if (seconds) *seconds = now() - t0;
+    if (grad_tex) store(gradient(tex), grad_tex, k);
+    return y.value_().coeff(0);
+}
+
+/* the texels that the paths of ref_cfg5 look up, bounce by bounce (n entries per bounce) */
+int ref_cfg5_texels(size_t n, uint64_t seed, uint64_t first_lane, int bounces, uint32_t width, uint32_t *out) {
+    using UInt64X = DynamicArray<Packet<uint64_t, Packet<float>::Size>>;
+    PCG32<FloatX> rng(UInt64X(seed), arange<UInt64X>(n) + UInt64X(first_lane));
+    int k = 0;
+    auto lookup = [&](const UInt32X &texel) { store(texel, out + (size_t) (k++) * n, n); return FloatX(.5f); };
+    FloatX radiance = cfg5::path_trace<FloatX, FloatX>(rng, lookup, bounces, width);
+    (void) radiance;
+    return 0;
+}
+
+/* first-bounce quantities of ref_cfg5, one row of n floats each (debugging aid of tools/debug_cfg5.py): z r phi s c b cc t px py pz
+   theta ph uu vv texel r1 r2 */
+int ref_cfg5_trace(size_t n, uint64_t seed, uint64_t first_lane, uint32_t width, float *out) {
+    using UInt64X = DynamicArray<Packet<uint64_t, Packet<float>::Size>>;
+    using Vector3 = Array<FloatX, 3>;
+    const float pi = 3.14159265358979323846f;
+    PCG32<FloatX> rng(UInt64X(seed), arange<UInt64X>(n) + UInt64X(first_lane));
+    FloatX z = 1.f - 2.f * rng.next_float32();
+    FloatX r = sqrt(max(FloatX(0.f), 1.f - z * z));
+    FloatX phi = (2.f * pi) * rng.next_float32();
+    auto [s_, c_] = sincos(phi);
+    Vector3 d(r * c_, r * s_, z), o(FloatX(.1f), FloatX(.2f), FloatX(-.1f));
+    FloatX b = dot(o, d), c = dot(o, o) - 1.f;
+    FloatX t = sqrt(max(FloatX(0.f), b * b - c)) - b;
+    Vector3 v = o + d * t;
+    FloatX l = sqrt(dot(v, v));
+    Vector3 p(v.x() / l, v.y() / l, v.z() / l);
+    FloatX theta = acos(min(max(p.z(), FloatX(-1.f)), FloatX(1.f)));
+    FloatX ph = atan2(p.y(), p.x());
+    FloatX uu = fmadd(ph, FloatX(.5f / pi), FloatX(.5f)), vv = theta * (1.f / pi);
+    UInt32X ix = min(UInt32X(uu * float(width)), UInt32X(width - 1)), iy = min(UInt32X(vv * float(width)), UInt32X(width - 1));
+    FloatX texel = FloatX(iy * width + ix);
+    FloatX r1 = 2.f * rng.next_float32() - 1.f, r2 = 2.f * rng.next_float32() - 1.f;
+    Vector3 nrm = p * FloatX(-1.f);
+    auto swap = abs(r1) < abs(r2);
+    FloatX rad = select(swap, r2, r1);
+    FloatX ratio = select(swap, r1, r2) / select(eq(rad, FloatX(0.f)), FloatX(1.f), rad);
+    FloatX ang = select(swap, (.5f * pi) - (.25f * pi) * ratio, (.25f * pi) * ratio);
+    auto [sn, cs] = sincos(ang);
+    FloatX dx = rad * cs, dy = rad * sn;
+    FloatX dz = sqrt(max(FloatX(0.f), 1.f - dx * dx - dy * dy));
+    FloatX sign = copysign(FloatX(1.f), nrm.z());
+    FloatX a = FloatX(-1.f) / (sign + nrm.z());
+    FloatX bb = nrm.x() * nrm.y() * a;
+    Vector3 sx(1.f + sign * nrm.x() * nrm.x() * a, sign * bb, FloatX(-1.f) * sign * nrm.x());
+    Vector3 ty(bb, sign + nrm.y() * nrm.y() * a, FloatX(-1.f) * nrm.y());
+    Vector3 w = sx * dx + ty * dy + nrm * dz;
+    FloatX wl = sqrt(dot(w, w));
+    Vector3 d2(w.x() / wl, w.y() / wl, w.z() / wl);
+    Vector3 o2 = p + nrm * FloatX(1e-3f);
+    const FloatX *rows[] = { &z, &r, &phi, &s_, &c_, &b, &c, &t, &p.x(), &p.y(), &p.z(), &theta, &ph, &uu, &vv, &texel, &r1, &r2,
+                             &rad, &ratio, &ang, &sn, &cs, &dx, &dy, &dz, &sign, &a, &bb, &sx.x(), &sx.y(), &sx.z(), &ty.x(), &ty.y(),
+                             &ty.z(), &w.x(), &w.y(), &w.z(), &d2.x(), &d2.y(), &d2.z(), &o2.x(), &o2.y(), &o2.z() };
+    for (size_t q = 0; q < sizeof(rows) / sizeof(rows[0]); ++q) store(*rows[q], out + q * n, n);
+    return 0;
 }
 
 /* Generic little tape programs used by the tape parity tests: see tests/test_tape_parity.py.

@@ -151,6 +151,17 @@ class Checker:
               ctypes.c_float(seed), _p(gA), _p(gB), ctypes.byref(sec))
         return y, gA, gB, sec.value
 
+    def cfg5(self, tex, n, seed, first_lane=0, bounces=3, width=1024):
+        """reference build only: the templated path tracer of examples/path_trace.h on the reference's arrays
+        (oracle/ref_driver.cpp:ref_cfg5) -> loss, grad_tex, seconds"""
+        tex = np.ascontiguousarray(tex, np.float32)
+        g = np.empty_like(tex); sec = ctypes.c_double()
+        f = self._f("cfg5")
+        f.restype = ctypes.c_float
+        y = f(_p(tex), ctypes.c_size_t(tex.size), ctypes.c_size_t(n), ctypes.c_uint64(seed), ctypes.c_uint64(first_lane),
+              ctypes.c_int(bounces), ctypes.c_uint32(width), _p(g), ctypes.byref(sec))
+        return y, g, sec.value
+
     def pcg32(self, initstate, initseq, steps, mask, bound, delta):
         """the PCG32 draw script of oracle/ref_driver.cpp:ref_pcg32 -> dict of outputs"""
         initseq = np.ascontiguousarray(initseq, np.uint64); mask = np.ascontiguousarray(mask, np.uint8); n = initseq.size

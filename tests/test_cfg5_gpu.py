@@ -45,3 +45,35 @@ def test_path_tracer_gradient_matches_finite_differences():
     assert abs(fd - an) <= 2e-2 * max(abs(an), 1.0), (fd, an)
     # texels that no path visits receive no gradient; most texels of a 64 x 64 texture are visited by 65536 x 3 hits
     assert (g > 0).mean() > 0.9
+
+
+def test_path_tracer_matches_the_reference_build():
+    """BASELINE configs[4] against its oracle: examples/path_trace.h instantiated on the reference's own arrays
+    (oracle/ref_driver.cpp:ref_cfg5, unmodified reference headers) and the same program spelled with the python bindings visit the
+    same texels (only class A operations decide where a path goes), so loss and texture gradient differ by the order of fp
+    additions only: class D."""
+    import enoki_amd.hip as ekc
+    import enoki_amd.hip_autodiff as ek
+    import oracle_lib as ol
+    from bench import path_trace
+    from conftest import stat_sum_bound, hsum_depth
+    try:
+        ref = ol.ref()
+    except Exception:
+        pytest.skip("oracle/_ref is not built")
+    n, width = 1 << 20, 1024
+    K = width * width
+    tex_np = (np.random.default_rng(3).uniform(0.2, 0.8, K)).astype(np.float32)
+    ry, rg, _ = ref.cfg5(tex_np, n, seed=42, first_lane=7, bounces=3, width=width)
+    tex = ek.Float32(ekc.Float32(tex_np))
+    ek.set_requires_gradient(tex)
+    y = path_trace(ek, ekc, tex, n, seed=42, first_lane=7, bounces=3, width=width)
+    ek.backward(y)
+    yv, g = float(ek.detach(y).numpy()[0]), ek.gradient(tex).numpy()
+    eps = 2.0 ** -24
+    # every path carries between 0.2^3 and 0.72: the loss is a sum of n positive terms
+    assert abs(yv - ry) <= eps * (hsum_depth(n) + n // 8 + 8) * max(abs(ry), abs(yv)), (yv, ry)
+    # per texel: a handful of positive terms each (3 n hits over K texels); the same texels are hit on both sides
+    assert np.array_equal(g == 0, rg == 0)
+    hits = np.maximum(np.ceil(np.maximum(g, rg) / (0.1 * 0.2 * 0.2)), 1.0)          # no term is smaller than 0.1 * 0.2^2
+    assert np.all(np.abs(g - rg) <= eps * (hits + 4) * np.maximum(g, rg)), float(np.abs(g - rg).max())

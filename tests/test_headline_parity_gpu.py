@@ -113,3 +113,42 @@ def test_cfg4_headline_image_bit_exact():
     # ... and executed per pixel, bucket by bucket (enoki::vectorize_through: 256 buckets of 128 Ki pixels at this size)
     fi, fh = run(fused.sphere_through, *args)
     assert fh == ph and np.array_equal(fi.view(np.uint32), pi.view(np.uint32))
+
+
+NEIGHBOURS = {"cos": dict(func="cos"), "exp": dict(func="exp"), "seed3": dict(seed=3.0), "masked": dict(masked=True),
+              "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22)}
+
+
+@pytest.mark.parametrize("name", list(NEIGHBOURS))
+def test_cfg3b_neighbours_at_the_headline_size(ek, checker, name):
+    """bench.py's `also` entries cfg3b_<name>: the headline chain with one thing changed, 64 Mi elements, against the reference
+    build (oracle/_ref, ref_cfg3b_variant) and the float64 evaluation, inside the class-D bounds"""
+    from conftest import cfg3b_variant_truth
+    if not hasattr(checker, "cfg3b_variant") or checker.kind != "reference":
+        pytest.skip("needs oracle/_ref")
+    kw = dict(NEIGHBOURS[name])
+    Kt = kw.pop("K", K)
+    masked, idx64 = kw.pop("masked", False), kw.pop("idx64", False)
+    A, B, x = uniform_pm1(Kt, 6), uniform_pm1(Kt, 7), uniform_pm1(N, 2)
+    idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(Kt)).astype(np.uint32)
+    mask = ((hash_u32(np.arange(N, dtype=np.uint64), 5) & 3) != 0) if masked else None
+    dA, dB = ek.Float32(A), ek.Float32(B)
+    ek.set_requires_gradient(dA); ek.set_requires_gradient(dB)
+    di = ek.UInt64(idx.astype(np.uint64)) if idx64 else ek.UInt32(idx)
+    if mask is not None:
+        dm = ek.Mask(mask)
+        a, b = ek.gather(dA, di, dm), ek.gather(dB, di, dm)
+    else:
+        a, b = ek.gather(dA, di), ek.gather(dB, di)
+    y = ek.hsum(getattr(ek, kw.get("func", "sin"))(ek.fmadd(a, ek.Float32(x), b)))
+    z = y * kw["seed"] if "seed" in kw else y
+    ek.backward(z)
+    yv, gA, gB = float(ek.detach(z).numpy()[0]), ek.gradient(dA).numpy(), ek.gradient(dB).numpy()
+    t = cfg3b_variant_truth(A, B, x, idx, mask=mask, **kw)
+    ry, rgA, rgB, _ = checker.cfg3b_variant(A, B, x, idx.astype(np.uint64) if idx64 else idx, mask=mask, **kw)
+    assert abs(yv - t["y"]) <= t["y_bound"] and abs(yv - t["y"]) <= t["y_stat_bound"], (name, yv, t["y"], t["y_stat_bound"])
+    assert abs(yv - t["y"]) <= abs(ry - t["y"]) + t["y_stat_bound"]           # no worse than the reference's own lane-wise sum
+    for g, arr, ref in (("gA", gA, rgA), ("gB", gB, rgB)):
+        err = np.abs(arr - t[g])
+        assert np.all(err <= t[g + "_bound"]), (name, g, float((err / np.maximum(t[g + "_bound"], 1e-30)).max()))
+        assert np.all(np.abs(arr - ref) <= 2 * t[g + "_bound"]), (name, g)
