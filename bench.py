@@ -65,10 +65,13 @@ for _w, _v in CFG3B_VARIANTS.items():
                        " (y = seed * hsum(func(fmadd(gather(A, idx, mask), x, gather(B, idx, mask)))), backward(); 75 % mask of SURVEY 8d)")
 N_RAYS_PER_GPU = 1 << 25
 N_PATHS_PER_GPU = 1 << 24
+DESCRIPTION["cfg5_unfused"] = "cfg5 spelled op by op with the python bindings (every operation one kernel, three gather nodes on the tape)"
+DESCRIPTION["cfg5_cpp"] = "cfg5: the template of examples/path_trace.h on DiffArray<HIPArray<float>>, op by op"
 DESCRIPTION["cfg5"] = ("synthetic 3-bounce path tracer inside a textured unit sphere (SURVEY 8d cfg5, not in the reference): "
                        "PCG32 sampling, sphere intersection, (theta, phi) -> texel, differentiable gather of the albedo "
                        "texture (K = 1 Mi), cosine-weighted bounce; loss = hsum(radiance); backward() scatter_adds the "
-                       "texture gradient; 16 Mi paths per GPU; report only")
+                       "texture gradient; 16 Mi paths per GPU; ONE fused kernel per evaluation (examples/path_trace.cpp: the template "
+                       "of examples/path_trace.h on one-element packets with forward-mode duals), one tape node, one scatter_add")
 # kernel name reported by the library -> kernel symbol prefix in the rocprofv3 PMC summary (profiles/)
 PMC_SYMBOL = {"bucket_accumulate": "k_bucket_accumulate", "bucket_partition": "k_page_partition", "bucket_directory": "k_page_directory", "bucket_pair_fma_reduce": "k_bucket_pair_forward<",
               "bucket_pair_fma_reduce_adjoint": "k_bucket_pair_forward_adjoint",
@@ -82,7 +85,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5"] + list(CFG3B_VARIANTS))
+    ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5", "cfg5_unfused", "cfg5_cpp"] + list(CFG3B_VARIANTS))
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
@@ -280,7 +283,29 @@ class Bench:
                     else:
                         out["reduced"] = [self.sh.reduce(out["y"])]
                         out["plan"] = self.sh.flush()
-        elif workload == "cfg5":
+        elif workload in ("cfg5", "cfg5_cpp"):
+            # the templated program of examples/path_trace.h through examples/libpath_trace.so: cfg5 = ONE fused kernel per
+            # evaluation (one-element packets + forward-mode duals, one tape node, one scatter_add in backward()); cfg5_cpp = the
+            # same template on DiffArray<HIPArray<float>>, every operation one kernel
+            import ctypes
+            n5 = N_PATHS_PER_GPU
+            tex0 = ekc.fmadd(synth.uniform_pm1(0, K_TABLE, 8), ekc.Float32(0.3), ekc.Float32(0.5))    # albedo in [0.2, 0.8)
+            packer = self.sh if ekd.active() else None
+            lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "examples", "libpath_trace.so"))
+            fn = lib.path_trace_fused_device if workload == "cfg5" else lib.path_trace_device
+            loss_buf, grad_buf = ekc.Float32.empty(1), ekc.Float32.empty(K_TABLE)
+            P = ctypes.c_void_p
+
+            def step():
+                rc = fn(P(tex0.data_ptr()), ctypes.c_size_t(K_TABLE), ctypes.c_size_t(n5), ctypes.c_uint64(0x853c49e6748fea9b + self.rank),
+                        ctypes.c_uint64(self.rank * n5), 3, ctypes.c_uint32(1024), P(loss_buf.data_ptr()), P(grad_buf.data_ptr()))
+                if rc != 0:
+                    raise RuntimeError(f"path_trace: rc = {rc}")
+                out["y"], out["grad"] = loss_buf, grad_buf
+                if packer:
+                    out["reduced"] = [self.sh.reduce(ek.Float32(loss_buf)), self.sh.reduce(ek.Float32(grad_buf))]
+                    self.sh.flush()
+        elif workload == "cfg5_unfused":
             n5 = N_PATHS_PER_GPU
             tex0 = ekc.fmadd(synth.uniform_pm1(0, K_TABLE, 8), ekc.Float32(0.3), ekc.Float32(0.5))    # albedo in [0.2, 0.8)
             packer = self.sh if ekd.active() else None
@@ -442,7 +467,7 @@ class Bench:
         torch.cuda.synchronize(); ekd.barrier()
         elapsed = ekd.max_over_ranks(time.perf_counter() - t0)
         ms_per_step = elapsed / steps * 1e3
-        units = N_RAYS_PER_GPU * self.world if workload.startswith("cfg4") else N_PATHS_PER_GPU * self.world if workload == "cfg5" else self.N
+        units = N_RAYS_PER_GPU * self.world if workload.startswith("cfg4") else N_PATHS_PER_GPU * self.world if workload.startswith("cfg5") else self.N
         graph_ms = ms_per_step if graph is not None else None
 
         eager_ms = ms_per_step
@@ -496,7 +521,7 @@ class Bench:
                         "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
                         "traffic": traffic, "traffic_source": traffic_source,
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
-                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload.startswith("cfg4") else N_PATHS_PER_GPU if workload == "cfg5" else self.n, 1), 2),
+                                       "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload.startswith("cfg4") else N_PATHS_PER_GPU if workload.startswith("cfg5") else self.n, 1), 2),
                                        "achieved_GBs": round(whole, 1), "frac": round(whole / (HBM_PEAK_TBS * 1000), 4)},
                         "kernels": kernels}
         if roofline and workload == self.args.workload:
@@ -693,7 +718,7 @@ def main():
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
     also = {}
     if b.world == 1 and not args.no_also:
-        for w in ("cfg3a", "cfg2", "cfg3b") + tuple(CFG3B_VARIANTS) + ("cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5"):
+        for w in ("cfg3a", "cfg2", "cfg3b") + tuple(CFG3B_VARIANTS) + ("cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5", "cfg5_unfused"):
             if w != args.workload:
                 r = b.run(w, max(5, args.steps // 2), 2, 3)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
@@ -704,8 +729,10 @@ def main():
                            "workload": DESCRIPTION[w]}
                 if w in CFG3B_VARIANTS:
                     also[w]["parity"] = "against the reference build and float64 at 64 Mi elements: tests/test_headline_parity_gpu.py::test_cfg3b_neighbours_at_the_headline_size"
-                if w == "cfg5":
-                    also[w]["parity"] = "no oracle (synthetic workload, not in the reference): gradient checked against finite differences only (tests/test_cfg5_gpu.py)"
+                if w.startswith("cfg5"):
+                    also[w]["unit"] = "G paths/s"
+                    also[w]["parity"] = ("against examples/path_trace.h instantiated on the reference's arrays (oracle/_ref: ref_cfg5), 1 Mi paths, "
+                                         "loss and texture gradient inside the class-D bounds: tests/test_cfg5_gpu.py")
     cpu, parity = None, None
     if b.rank == 0 and b.world == 1 and not args.no_cpu_baseline:
         cpu, ref_out = cpu_baseline(args.workload, b.N)

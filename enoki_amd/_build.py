@@ -302,15 +302,16 @@ def build_examples(force=False, verbose=True):
     """user-level programs that go through hipcc because they use enoki::vectorize() (compile-time fusion)"""
     ex = os.path.join(ROOT, "examples")
     out = []
-    for name in ("sphere_fused",):
+    for name in ("sphere_fused", "path_trace"):
         src = os.path.join(ex, name + ".cpp")
         lib = os.path.join(ex, f"lib{name}.so")
         if not os.path.exists(src):
             continue
-        if force or _newer(lib, [src, os.path.join(HERE, "libenoki-hip.so")] + _headers()):
+        extra = [os.path.join(ex, "path_trace.h"), os.path.join(HERE, "libenoki-hip-autodiff.so")] if name == "path_trace" else []
+        if force or _newer(lib, [src, os.path.join(HERE, "libenoki-hip.so")] + extra + _headers()):
             _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-                                     f"-I{os.path.join(ROOT, 'include')}", src, "-o", lib, f"-L{HERE}", "-lenoki-hip",
-                                     "-Wl,-rpath,$ORIGIN/../enoki_amd"])
+                                     f"-I{os.path.join(ROOT, 'include')}", src, "-o", lib, f"-L{HERE}"] +
+                 (["-lenoki-hip-autodiff"] if name == "path_trace" else []) + ["-lenoki-hip", "-Wl,-rpath,$ORIGIN/../enoki_amd"])
             if verbose:
                 print(f"[enoki_amd] built {os.path.relpath(lib, ROOT)}")
         out.append(lib)

@@ -482,6 +482,26 @@ template <typename Value> auto Tape<Value>::append_reverse(Index source) -> Inde
     return target;
 }
 
+template <typename Value>
+auto Tape<Value>::append_custom(Index source, size_t size, const char *label, std::function<Value(const Value &)> backward) -> Index {
+    if (source == 0) return 0;
+    struct Custom : Special {
+        std::function<Value(const Value &)> bwd;
+        void forward(Detail *, Index, const Edge &) const override {
+            throw std::runtime_error("autodiff: forward-mode traversal through a custom node is not available");
+        }
+        void backward(Detail *detail, Index target, const Edge &edge) const override {
+            Detail::accumulate(detail->node(edge.source).grad, bwd(detail->node(target).grad));
+        }
+    };
+    Custom *c = new Custom();
+    c->bwd = std::move(backward);
+    Index target = append_node(size, label);
+    d->node(target).edges.emplace_back(source, c);
+    inc_ref_int(source, target);
+    return target;
+}
+
 template <typename Value> auto Tape<Value>::append_psum(Index source) -> Index {
     if (source == 0) return 0;
     struct PrefixSum : Special {

@@ -13,14 +13,15 @@
 //   Float   the differentiable value type (the texture's entries, throughput, radiance)
 //   FloatC  its plain counterpart (geometry and sampling do not depend on the texture)
 //   Tex     how a texel is looked up:  Float tex(const UInt32C &texel)
+//   Bounces compile time: the loop is unrolled, so a fused kernel can keep one derivative slot per lookup in registers
 #pragma once
 #include <cstddef>
 #include <cstdint>
 
 namespace cfg5 {
 
-template <typename Float, typename FloatC, typename RNG, typename Tex>
-Float path_trace(RNG &rng, const Tex &tex, int bounces, uint32_t width) {
+template <int Bounces, typename Float, typename FloatC, typename RNG, typename Tex>
+Float path_trace(RNG &rng, Tex &&tex, uint32_t width) {
     using namespace enoki;
     using UInt32C = uint32_array_t<FloatC>;
     using Vector3 = Array<FloatC, 3>;
@@ -30,19 +31,20 @@ Float path_trace(RNG &rng, const Tex &tex, int bounces, uint32_t width) {
 
     // primary directions: uniform on the sphere; origin: a fixed point inside
     FloatC z = 1.f - 2.f * rng.next_float32();
-    FloatC r = sqrt(max(FloatC(0.f), 1.f - z * z));
+    FloatC r = sqrt(enoki::max(FloatC(0.f), 1.f - z * z));
     FloatC phi = (2.f * pi) * rng.next_float32();
     auto [s_, c_] = sincos(phi);
     Vector3 d(r * c_, r * s_, z), o(FloatC(.1f), FloatC(.2f), FloatC(-.1f));
     Float throughput(1.f), radiance(0.f);
-    for (int k = 0; k < bounces; ++k) {
+#pragma unroll
+    for (int k = 0; k < Bounces; ++k) {
         FloatC b = dot(o, d), c = dot(o, o) - 1.f;
-        FloatC t = sqrt(max(FloatC(0.f), b * b - c)) - b;                      // far root: we are inside the sphere
+        FloatC t = sqrt(enoki::max(FloatC(0.f), b * b - c)) - b;                      // far root: we are inside the sphere
         Vector3 p = unit(o + d * t);
-        FloatC theta = acos(min(max(p.z(), FloatC(-1.f)), FloatC(1.f)));
+        FloatC theta = acos(enoki::min(enoki::max(p.z(), FloatC(-1.f)), FloatC(1.f)));
         FloatC ph = atan2(p.y(), p.x());
         FloatC uu = fmadd(ph, FloatC(.5f / pi), FloatC(.5f)), vv = theta * (1.f / pi);
-        UInt32C ix = min(UInt32C(uu * float(width)), UInt32C(width - 1)), iy = min(UInt32C(vv * float(width)), UInt32C(width - 1));
+        UInt32C ix = enoki::min(UInt32C(uu * float(width)), UInt32C(width - 1)), iy = enoki::min(UInt32C(vv * float(width)), UInt32C(width - 1));
         Float albedo = tex(iy * width + ix);                                   // the only differentiable operation
         radiance = radiance + throughput * albedo * .1f;                       // the surface emits a little of its colour
         throughput = throughput * albedo;
@@ -55,7 +57,7 @@ Float path_trace(RNG &rng, const Tex &tex, int bounces, uint32_t width) {
         FloatC ang = select(swap, (.5f * pi) - (.25f * pi) * ratio, (.25f * pi) * ratio);
         auto [sn, cs] = sincos(ang);
         FloatC dx = rad * cs, dy = rad * sn;
-        FloatC dz = sqrt(max(FloatC(0.f), 1.f - dx * dx - dy * dy));
+        FloatC dz = sqrt(enoki::max(FloatC(0.f), 1.f - dx * dx - dy * dy));
         // orthonormal frame around nrm (Duff et al. 2017)
         FloatC sign = copysign(FloatC(1.f), nrm.z());
         FloatC a = FloatC(-1.f) / (sign + nrm.z());

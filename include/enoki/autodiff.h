@@ -22,6 +22,7 @@
     of src/autodiff/autodiff.cpp:1223-1241).
 */
 #pragma once
+#include <functional>
 
 #include <enoki/array.h>
 
@@ -118,6 +119,10 @@ template <typename Type> struct Tape {
     Index append_gather(const Offset &offset, const Mask &mask);
     void append_scatter(Index source, const Offset &offset, const Mask &mask, bool scatter_add);
     Index append_psum(Index source);
+    /// A node of `size` entries whose adjoint w.r.t. `source` is supplied by the caller: backward(grad of the node) returns the
+    /// contribution to grad(source).  (How a fused kernel that computed the node's value AND what its adjoint needs in one pass --
+    /// enoki::vectorize-style -- enters the tape: examples/path_trace.cpp.)
+    Index append_custom(Index source, size_t size, const char *label, std::function<Type(const Type &)> backward);
     Index append_reverse(Index source);
     void set_scatter_gather_operand(Index *index, size_t size, bool permute);
 
@@ -783,6 +788,15 @@ template <typename Type_> struct DiffArray : ArrayTag {
     static std::string whos_() { return tape()->whos(); }
     static void inc_ref_ext_(Index index) { if constexpr (Enabled) tape()->inc_ref_ext(index); }
     static void dec_ref_ext_(Index index) { if constexpr (Enabled) tape()->dec_ref_ext(index); }
+
+    /// value = f(source) computed outside the tape, with `backward` as its adjoint (Tape::append_custom)
+    static DiffArray custom_(const DiffArray &source, Type &&value, const char *label, std::function<Type(const Type &)> backward) {
+        Index idx = 0;
+        if constexpr (Enabled) {
+            if (source.m_index) idx = tape()->append_custom(source.m_index, slices(value), label, std::move(backward));
+        }
+        return create(idx, std::move(value));
+    }
 
     static DiffArray create(Index index, Type &&value) {
         DiffArray result(std::move(value));

@@ -528,7 +528,10 @@ float ref_cfg5(const float *tex_, size_t k, size_t n, uint64_t seed, uint64_t fi
     double t0 = now();
     PCG32<FloatX> rng(UInt64X(seed), arange<UInt64X>(n) + UInt64X(first_lane));
     auto lookup = [&](const UInt32X &texel) { return gather<FloatD>(tex, UInt32D(texel)); };
-    FloatD radiance = cfg5::path_trace<FloatD, FloatX>(rng, lookup, bounces, width);
+    FloatD radiance = bounces == 1 ? cfg5::path_trace<1, FloatD, FloatX>(rng, lookup, width)
+                    : bounces == 2 ? cfg5::path_trace<2, FloatD, FloatX>(rng, lookup, width)
+                                   : cfg5::path_trace<3, FloatD, FloatX>(rng, lookup, width);
+    if (bounces < 1 || bounces > 3) return 0.f / 0.f;
     FloatD y = hsum(radiance);
     backward(y);
     if (seconds) *seconds = now() - t0;
@@ -542,7 +545,9 @@ int ref_cfg5_texels(size_t n, uint64_t seed, uint64_t first_lane, int bounces, u
     PCG32<FloatX> rng(UInt64X(seed), arange<UInt64X>(n) + UInt64X(first_lane));
     int k = 0;
     auto lookup = [&](const UInt32X &texel) { store(texel, out + (size_t) (k++) * n, n); return FloatX(.5f); };
-    FloatX radiance = cfg5::path_trace<FloatX, FloatX>(rng, lookup, bounces, width);
+    FloatX radiance = bounces == 1 ? cfg5::path_trace<1, FloatX, FloatX>(rng, lookup, width)
+                    : bounces == 2 ? cfg5::path_trace<2, FloatX, FloatX>(rng, lookup, width)
+                                   : cfg5::path_trace<3, FloatX, FloatX>(rng, lookup, width);
     (void) radiance;
     return 0;
 }

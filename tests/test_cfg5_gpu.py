@@ -77,3 +77,36 @@ def test_path_tracer_matches_the_reference_build():
     assert np.array_equal(g == 0, rg == 0)
     hits = np.maximum(np.ceil(np.maximum(g, rg) / (0.1 * 0.2 * 0.2)), 1.0)          # no term is smaller than 0.1 * 0.2^2
     assert np.all(np.abs(g - rg) <= eps * (hits + 4) * np.maximum(g, rg)), float(np.abs(g - rg).max())
+
+
+@pytest.mark.parametrize("entry", ["path_trace_fused_device", "path_trace_device"])
+def test_cpp_path_tracers_match_the_reference_build(entry):
+    """examples/libpath_trace.so: the template of examples/path_trace.h (a) on one-element packets inside ONE kernel, with
+    forward-mode duals for the three texture lookups, one tape node and one scatter_add in backward(); (b) on
+    DiffArray<HIPArray<float>> op by op -- both against the same template on the reference's arrays (ref_cfg5)."""
+    import ctypes
+    import enoki_amd.hip as ekc
+    import oracle_lib as ol
+    from conftest import hsum_depth
+    try:
+        ref = ol.ref()
+    except Exception:
+        pytest.skip("oracle/_ref is not built")
+    ekc.hip_init(0)
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "libpath_trace.so"))
+    n, width = 1 << 20, 1024
+    K = width * width
+    tex_np = (np.random.default_rng(3).uniform(0.2, 0.8, K)).astype(np.float32)
+    ry, rg, _ = ref.cfg5(tex_np, n, seed=42, first_lane=7, bounces=3, width=width)
+    tex, loss, grad = ekc.Float32(tex_np), ekc.Float32.empty(1), ekc.Float32.empty(K)
+    P = ctypes.c_void_p
+    rc = getattr(lib, entry)(P(tex.data_ptr()), ctypes.c_size_t(K), ctypes.c_size_t(n), ctypes.c_uint64(42), ctypes.c_uint64(7), 3,
+                             ctypes.c_uint32(width), P(loss.data_ptr()), P(grad.data_ptr()))
+    assert rc == 0
+    yv, g = float(loss.numpy()[0]), grad.numpy()
+    eps = 2.0 ** -24
+    assert abs(yv - ry) <= eps * (hsum_depth(n) + n // 8 + 8) * max(abs(ry), abs(yv)), (yv, ry)
+    assert np.array_equal(g == 0, rg == 0)                                    # the same texels are hit
+    hits = np.maximum(np.ceil(np.maximum(g, rg) / (0.1 * 0.2 * 0.2)), 1.0)
+    # (the dual numbers of the fused kernel form each derivative in another association than the tape's products: a few ulp per term)
+    assert np.all(np.abs(g - rg) <= eps * (4 * hits + 8) * np.maximum(g, rg)), float((np.abs(g - rg) / np.maximum(g, 1e-30)).max())
