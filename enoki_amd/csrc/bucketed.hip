@@ -858,7 +858,11 @@ struct Bucketed {
     void *page_lists = nullptr;    // glist_full[page slots] | glist_part[W * n_buckets]
     uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
     const uint32_t *active = nullptr;      // device: number of elements in the lists (null: all n -- no mask)
+    uint32_t win_lo = 0, win_span = 0;     // a slice of a large table: only indices in [win_lo, win_lo + win_span) (ek_hip_bucketed::slices)
+    bool correct_masked = true;            // the final reduction adds the masked-out lanes' map_op(0) terms (slices: their owner does)
 
+    bool has_mask = false;
+    const uint32_t *masked_ptr() const { return has_mask && correct_masked ? active : nullptr; }
     size_t bins() const { return (size_t) 1 << shift; }
     BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
     ~Bucketed() {
@@ -964,7 +968,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->glist_part = b->glist_full + p.page_slots;
     uint32_t *gtotal = (uint32_t *) b->meta;
     b->bucket_base = gtotal + 3 * kMaxBuckets;
-    if (mask.vec) b->active = gtotal + 2 * kMaxBuckets;
+    b->active = gtotal + 2 * kMaxBuckets;
+    b->has_mask = mask.vec != 0;
     b->base_part = b->bucket_base + kMaxBuckets + 1;
     b->piece_prefix = b->base_part + kMaxBuckets + 1;
     b->reduce_partials = (void *) (((uintptr_t) (gtotal + meta_words) + 15) & ~(uintptr_t) 15);
@@ -980,6 +985,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.loff = out.cnt_full + part_entries;
     out.part = out.loff + part_entries;
     out.gtotal = gtotal;
+    out.active = gtotal + 2 * kMaxBuckets;
+    out.lo = b->win_lo; out.span = b->win_span;
     EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
@@ -1037,7 +1044,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     else if (keep) b->has_u = true;
     if constexpr (ROp != EK_REDUCE_NONE) {
         hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out,
-                           (const T *) b->reduce_partials, b->max_pieces, b->active, b->n, map_op);
+                           (const T *) b->reduce_partials, b->max_pieces, b->masked_ptr(), b->n, map_op);
         EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
     }
     return EK_OK;
@@ -1055,7 +1062,7 @@ static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const
     });
     EK_LAUNCH_CHECK("bucket_reduce_kept", b->n, b->n * sizeof(T));
     hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                       b->max_pieces, b->active, b->n, zero_op);
+                       b->max_pieces, b->masked_ptr(), b->n, zero_op);
     EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
     return EK_OK;
 }
@@ -1098,7 +1105,7 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
     b->has_early = true;
     b->early_op = keep_op;
     hipLaunchKernelGGL((k_bucket_reduce_final<T, EK_HSUM>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                       b->max_pieces, b->active, b->n, map_op);
+                       b->max_pieces, b->masked_ptr(), b->n, map_op);
     EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
     return EK_OK;
 }
@@ -1284,7 +1291,41 @@ static int index_partition_run(IndexPartition *ip, const I *index, const Arg<uin
 
 using namespace ek;
 
-struct ek_hip_bucketed : ek::Bucketed { };
+// A table beyond 256 buckets is cut into SLICES of 256 buckets: one object per slice, each made by a pass over (index, x) that
+// keeps the indices of its slice (PagedOut::lo / span) -- S passes of 8 B/elt instead of one, still without a lookup that
+// leaves the CU.  Reductions combine the slices' results (and add the masked-out lanes' terms once), the scatter_add of slice s
+// goes to entries [s span, (s + 1) span) of its tables.
+struct ek_hip_bucketed : ek::Bucketed {
+    std::vector<ek_hip_bucketed *> slices;
+    size_t slice_span = 0;
+    ~ek_hip_bucketed() { for (ek_hip_bucketed *s : slices) delete s; }
+};
+constexpr int kMaxSlices = 64;
+struct SliceCounts { const uint32_t *active[kMaxSlices]; };
+
+template <typename T, int ROp>
+__global__ __launch_bounds__(64) void k_slices_combine(T *__restrict__ out, const T *__restrict__ partial, int slices, SliceCounts counts,
+                                                       size_t n, int map_op) {
+    using R = ek::BucketReducer<ROp, T>;
+    if (threadIdx.x != 0) return;
+    T r = R::identity();
+    size_t kept = 0;
+    for (int s = 0; s < slices; ++s) { r = R::combine(r, partial[s]); kept += counts.active[s][0]; }
+    const size_t masked = n - kept;
+    if (masked) {
+        const T f0 = ek::unary_fused<T>(map_op, T(0));
+        if constexpr (ROp == EK_HSUM) {
+            r = r + (T) masked * f0;
+        } else if constexpr (ROp == EK_HPROD) {
+            T p = T(1), base = f0;
+            for (size_t e = masked; e; e >>= 1) { if (e & 1) p = p * base; base = base * base; }
+            r = r * p;
+        } else {
+            r = R::combine(r, f0);
+        }
+    }
+    out[0] = r;
+}
 struct ek_hip_index_partition : ek::IndexPartition { };
 
 extern "C" {
@@ -1294,9 +1335,10 @@ int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size
     if (index_type != EK_U32 && index_type != EK_I32) return 0;
     if (ctx().tuning.deterministic || !ctx().tuning.bucket_ordered) return 0;
     const size_t bins = type == EK_F64 ? (size_t) bins_of<double> : (size_t) bins_of<float>;
-    // (4-byte types go through pages whose numbers are packed with an element count: 2^30 elements at most)
+    // (4-byte types go through pages whose numbers are packed with an element count: 2^30 elements at most; their tables may
+    // have up to kMaxSlices slices of 256 half-size buckets)
     return n >= ((size_t) 1 << 18) && n < ((size_t) 1 << (type == EK_F64 ? 32 : 30)) && table_size > bins &&
-           table_size <= (size_t) kMaxBuckets * bins;
+           table_size <= (size_t) kMaxBuckets * bins * (type == EK_F64 ? 1 : kMaxSlices / 2);
 }
 
 int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c, size_t table_size,
@@ -1332,7 +1374,27 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
     const bool half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint && table_size <= (size_t) kMaxBuckets * (bins / 2);
     if (type == EK_F32) {
         const Arg<uint8_t> m{ mask, 1, mask ? 1u : 0u };
-        rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (half ? 1 : 0));
+        const bool want_half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint;
+        const size_t sel_bins = want_half ? bins / 2 : bins, span = (size_t) kMaxBuckets * sel_bins;
+        if (table_size > span) {
+            const int S = (int) ((table_size + span - 1) / span);
+            b->slice_span = span;
+            rc = EK_OK;
+            for (int sl = 0; sl < S && rc == EK_OK; ++sl) {
+                ek_hip_bucketed *sub = new ek_hip_bucketed();
+                b->slices.push_back(sub);
+                sub->type = type; sub->index_type = index_type; sub->op = op; sub->n = n;
+                sub->table_size = std::min(span, table_size - (size_t) sl * span);
+                sub->table_a = (const float *) table_a + (size_t) sl * span;
+                sub->table_c = (const float *) table_c + (size_t) sl * span;
+                sub->win_lo = (uint32_t) ((size_t) sl * span);
+                sub->win_span = (uint32_t) sub->table_size;
+                sub->correct_masked = false;
+                rc = bucketed_create_paged<uint32_t>(sub, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (want_half ? 1 : 0));
+            }
+        } else {
+            rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (half ? 1 : 0));
+        }
     } else if (mask) {
         rc = fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create_masked(): masks with 4-byte element types only");
     } else {
@@ -1349,6 +1411,28 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *
     if (!b || !out) return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): null pointer");
     if (map_op != EK_COPY && !unary_fusable(map_op))
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_reduce(): op %d cannot be applied on load", map_op);
+    if (!b->slices.empty()) {
+        const int S = (int) b->slices.size();
+        Scratch partial;
+        if (int rc = partial.alloc((size_t) S * sizeof(float))) return rc;
+        SliceCounts counts{};
+        for (int sl = 0; sl < S; ++sl) {
+            if (int rc = bucketed_reduce<float>(b->slices[sl], reduce_op, map_op, (float *) partial.ptr + sl, keep_values != 0, keep_op)) return rc;
+            counts.active[sl] = b->slices[sl]->active;
+        }
+        Context &c = ctx();
+#define EK_COMBINE(OP) hipLaunchKernelGGL((k_slices_combine<float, OP>), dim3(1), dim3(64), 0, c.stream, (float *) out, (const float *) partial.ptr, S, counts, b->n, map_op)
+        switch (reduce_op) {
+            case EK_HSUM: EK_COMBINE(EK_HSUM); break;
+            case EK_HPROD: EK_COMBINE(EK_HPROD); break;
+            case EK_HMIN: EK_COMBINE(EK_HMIN); break;
+            case EK_HMAX: EK_COMBINE(EK_HMAX); break;
+            default: return fail(EK_ERR_INVALID, "ek_hip_bucketed_reduce(): unknown op %d", reduce_op);
+        }
+#undef EK_COMBINE
+        EK_LAUNCH_CHECK("reduce_stage2", (size_t) S, (size_t) S * sizeof(float));
+        return EK_OK;
+    }
     if (b->type == EK_F32) return bucketed_reduce<float>(b, reduce_op, map_op, out, keep_values != 0, keep_op);
     return bucketed_reduce<double>(b, reduce_op, map_op, out, keep_values != 0, keep_op);
 }
@@ -1369,6 +1453,14 @@ int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *cons
         if (!bases[s]) return fail(EK_ERR_INVALID, "ek_hip_bucketed_scatter_add(): null table");
         if (from_u[s] && map_ops && map_ops[s] != EK_COPY && !unary_fusable(map_ops[s]))
             return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_scatter_add(): op %d cannot be applied on load", map_ops[s]);
+    }
+    if (!b->slices.empty()) {
+        for (size_t sl = 0; sl < b->slices.size(); ++sl) {
+            void *sb[4];
+            for (int s = 0; s < count; ++s) sb[s] = (float *) bases[s] + sl * b->slice_span;
+            if (int rc = bucketed_scatter_add<float>(b->slices[sl], count, sb, from_u, map_ops, imm_bits, weighted, fresh, scale_bits)) return rc;
+        }
+        return EK_OK;
     }
     if (b->type == EK_F32) return bucketed_scatter_add<float>(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh, scale_bits);
     return bucketed_scatter_add<double>(b, count, bases, from_u, map_ops, imm_bits, weighted, fresh, scale_bits);

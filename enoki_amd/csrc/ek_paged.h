@@ -43,7 +43,9 @@ template <typename T> struct PagedOut {
     uint32_t *cnt_full;    // [n_buckets][W]  full pages of the workgroup per bucket
     uint32_t *loff;        // [n_buckets][W]  where they start in wlist[w]
     uint32_t *part;        // [n_buckets][W]  page << 6 | (count - 1) of the partially filled page, or kNoPage
-    uint32_t *gtotal;      // [3][kMaxBuckets]  full / partially filled pages per bucket over all workgroups; [2][0]: active elements (zeroed by the host)
+    uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
+    uint32_t *active;      // number of elements kept (zeroed by the host)
+    uint32_t lo, span;     // only indices in [lo, lo + span) are kept (a slice of a large table), rebased to lo; span = 0: all
 #ifdef EK_PG_TIMING
     unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
 #endif
@@ -96,6 +98,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         if constexpr (HasMask) r.m = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(mask.ptr + e));
         else r.m = 0;
     };
+    const uint32_t win_lo = out.lo, win_span = out.span;
     auto decode = [&](const Raw &r, Tile &t) {
         t.on = 0;
 #pragma unroll
@@ -105,6 +108,13 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             if constexpr (HasMask) t.on |= (((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u) << j;
         }
         if constexpr (!HasMask) t.on = sm ? 0xFu : 0u;
+        if (win_span) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                t.ix[j] -= win_lo;
+                if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
+            }
+        }
     };
     auto load_ragged = [&](size_t base, Tile &t) {
         const size_t e = base + (size_t) threadIdx.x * 4;
@@ -116,6 +126,10 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
                 t.ix[j] = (uint32_t) index[e + j];
                 t.xv[j] = __builtin_bit_cast(uint32_t, x[e + j]);
                 t.on |= ((mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u) << j;
+                if (win_span) {
+                    t.ix[j] -= win_lo;
+                    if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
+                }
             }
         }
     };
@@ -340,7 +354,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         for (int j = 0; j < 4; ++j) kept += (full[j] << PS) + fl[j];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d, 64);
-        if (l == 0 && kept) atomicAdd(&out.gtotal[2 * kMaxBuckets], kept);
+        if (l == 0 && kept) atomicAdd(out.active, kept);
     }
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 0] = wall_clock64();

@@ -533,16 +533,18 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     PagedOut<float> out;
     out.lp = lp; out.xp = xp; out.wdir = wdir; out.wlist = wlist;
     out.gtotal = meta;
+    out.active = meta + 2 * kMaxBuckets;
+    out.lo = 0; out.span = 0;
 #ifdef EK_PG_TIMING
     out.dbg = dbg;
 #else
     (void) dbg;
 #endif
-    uint32_t *base_full = meta + 2 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1, *piece_prefix = base_part + kMaxBuckets + 1;
+    uint32_t *base_full = meta + 3 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1, *piece_prefix = base_part + kMaxBuckets + 1;
     out.cnt_full = piece_prefix + kMaxBuckets + 1;
     out.loff = out.cnt_full + (size_t) n_buckets * p.W;
     out.part = out.loff + (size_t) n_buckets * p.W;
-    EK_HIP_CHECK(hipMemsetAsync(meta, 0, 2 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    EK_HIP_CHECK(hipMemsetAsync(meta, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
     const Arg<uint8_t> m{ mask, 1, mask ? 1u : 0u };
     const int vec_ok = aligned16(index) && aligned16(x) && (!mask || aligned16(mask));
 #define EK_PP_LAUNCH(I, PS, HM)                                                                                                        \

@@ -781,7 +781,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
     }
 
     /// Large gathers from small tables are deferred (see detail::HIPBuffer); returns an invalid array when this one is not
-    static constexpr size_t defer_min_size_ = 4096, defer_max_table_bytes_ = (size_t) 16 << 20;
+    static constexpr size_t defer_min_size_ = 4096, defer_max_table_bytes_ = (size_t) 512 << 20;
     template <typename Index>
     static HIPArray defer_gather_(const HIPArray &source, const Index &index, const MaskType &mask) {
         HIPArray r;

@@ -149,7 +149,11 @@ def test_scatter_add_cos_pair_within_class_d(capi, dtype):
 def launches(capi, fn):
     capi.profile_begin()
     fn()
-    return {k["kernel"]: k["launches"] for k in capi.profile_end() if k["launches"]}
+    out = {}
+    for k in capi.profile_end():
+        if k["launches"]:
+            out[k["kernel"]] = out.get(k["kernel"], 0) + k["launches"]
+    return out
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
@@ -224,19 +228,21 @@ def test_hinted_plan_integer_data_is_exact_and_hint_can_be_ignored(capi):
             b.destroy()
         finally:
             capi.set_tuning("early_adjoint", 1)
-    # tables beyond 256 half-size buckets: the hint is ignored, the object works as before
+    # tables beyond 256 half-size buckets (round 4): cut into slices of 256 half-size buckets, one partition pass per slice,
+    # the early adjoint in every slice
     K2 = (200 << 14) + 5
     A2 = up(capi, np.zeros(K2, np.float32))
     i2 = up(capi, rng.integers(0, K2, n).astype(np.uint32))
     b = capi.Bucketed("fmadd", A2, dx, A2, i2, hints=capi.Bucketed.HINT_ADJOINT)
     ks = launches(capi, lambda: b.reduce("hsum", "sin", keep=True, keep_op="cos"))
-    assert "bucket_pair_fma_reduce" in ks and "bucket_pair_fma_reduce_adjoint" not in ks, ks
+    assert ks.get("bucket_pair_fma_reduce_adjoint") == 2 and "bucket_pair_fma_reduce" not in ks, ks
     b.destroy()
 
 
 def test_not_applicable_shapes_are_refused(capi):
     assert not capi.Bucketed.applicable(np.float32, np.uint32, 1 << 14, 1 << 20)        # one bucket
-    assert not capi.Bucketed.applicable(np.float32, np.uint32, (256 << 14) + 1, 1 << 20)  # more than 256 buckets
+    assert capi.Bucketed.applicable(np.float32, np.uint32, (256 << 14) + 1, 1 << 20)      # more than 256 buckets: slices (f32)
+    assert not capi.Bucketed.applicable(np.float64, np.uint32, (256 << 13) + 1, 1 << 20)  # more than 256 buckets
     assert not capi.Bucketed.applicable(np.float32, np.uint32, 1 << 20, 1 << 17)        # too few lookups
     assert not capi.Bucketed.applicable(np.int32, np.uint32, 1 << 20, 1 << 20)
     capi.set_tuning("deterministic", 1)
@@ -247,6 +253,31 @@ def test_not_applicable_shapes_are_refused(capi):
             capi.Bucketed("fmadd", A, x, A, i)
     finally:
         capi.set_tuning("deterministic", 0)
+
+
+@pytest.mark.parametrize("hinted", [False, True])
+def test_tables_beyond_256_buckets_are_sliced(capi, hinted):
+    """K = 5 Mi + 3 entries: 2 slices of 4 Mi unhinted / 3 slices of 2 Mi hinted; integer data -> exact sums, so the sliced object
+    must agree EXACTLY with numpy, masked-out lanes included (their u = 0 enters the reduction as cos(0) = 1)"""
+    K, n = (5 << 20) + 3, (1 << 20) + 77
+    rng = np.random.default_rng(5)
+    A = rng.integers(-3, 4, K).astype(np.float32); C = rng.integers(-3, 4, K).astype(np.float32)
+    x = rng.integers(-2, 3, n).astype(np.float32)
+    idx = rng.integers(0, K, n).astype(np.uint32)
+    mask = rng.integers(0, 4, n) != 0
+    dA, dC, dx, di, dm = up(capi, A), up(capi, C), up(capi, x), up(capi, idx), up(capi, mask.astype(np.uint8))
+    b = capi.Bucketed("fmadd", dA, dx, dC, di, hints=capi.Bucketed.HINT_ADJOINT if hinted else 0, mask=dm)
+    u = np.where(mask, A[idx] * x + C[idx], 0).astype(np.float32)
+    # f = abs keeps integers: y = sum |u|; kept function for the adjoint: abs(u) as well ({f, f} pair)
+    y = float(b.reduce("hsum", "abs", keep=True, keep_op="abs").numpy()[0])
+    assert y == float(np.abs(u).astype(np.float64).sum())
+    gA, gC = capi.fill(np.float32, 0, K), capi.fill(np.float32, 0, K)
+    b.scatter_add([gC, gA], [("abs", 0, False), ("abs", 0, True)])
+    eA = np.bincount(idx[mask], weights=(np.abs(u) * x)[mask], minlength=K).astype(np.float32)
+    eC = np.bincount(idx[mask], weights=np.abs(u)[mask], minlength=K).astype(np.float32)
+    assert np.array_equal(gA.numpy(), eA) and np.array_equal(gC.numpy(), eC)
+    assert float(b.reduce("hmax", "neg", keep=False).numpy()[0]) == float((-u).max())
+    b.destroy()
 
 
 def test_skewed_indices(capi):

@@ -31,7 +31,7 @@ class Run:
         self.wlist = capi.Buf(np.uint32, self.page_slots)
         self.gfull = capi.Buf(np.uint32, self.page_slots)
         self.gpart = capi.Buf(np.uint32, self.W * self.nb + 1)
-        self.meta = capi.Buf(np.uint32, 512 + 3 * 257 + 3 * self.nb * self.W)
+        self.meta = capi.Buf(np.uint32, 768 + 3 * 257 + 3 * self.nb * self.W)
         self.tp = target_pieces
         self.dbg = capi.Buf(np.uint64, self.W * 24)
 
@@ -46,7 +46,7 @@ class Run:
         page = 1 << self.ps
         lp, xp = self.lp.numpy(), self.xp.numpy()
         gfull, gpart, meta = self.gfull.numpy(), self.gpart.numpy(), self.meta.numpy()
-        bf, bp, pp = meta[512:512 + 257], meta[512 + 257:512 + 514], meta[512 + 514:512 + 771]
+        bf, bp, pp = meta[768:768 + 257], meta[768 + 257:768 + 514], meta[768 + 514:768 + 771]
         nb = self.nb
         on = np.ones(self.n, bool) if mask_h is None else mask_h.astype(bool)
         keys_in = idx_h[on].astype(np.uint64)
