@@ -83,21 +83,25 @@ PMC_SYMBOL = {"bucket_accumulate": "k_bucket_accumulate", "bucket_partition": "k
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    # defaults: a timed region of about one second (0.34 ms per headline step), long enough for an outside sampler to see a busy GPU
+    ap.add_argument("--steps", type=int, default=3000)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5", "cfg5_unfused", "cfg5_cpp"] + list(CFG3B_VARIANTS))
     ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--deterministic", action="store_true", help="bit-reproducible fp scatter_add (sorted path)")
-    ap.add_argument("--eager", action="store_true", help="time python-driven eager steps instead of step-graph replays")
+    ap.add_argument("--eager", action="store_true", help="(default since round 4; kept for old command lines)")
+    ap.add_argument("--dump-gradients", default=None, metavar="DIR", help="cfg3b: every rank saves what it holds of the table gradients after the exchange (owned slices when reduce-scattered) as DIR/grad_rank<r>.npz -- for the multi-rank parity tests")
+    ap.add_argument("--graph", action="store_true", help="ALSO time the K steps as replays of a captured step graph (graph_ms_per_step); `value` stays the python-driven protocol")
     ap.add_argument("--allreduce-grads", action="store_true",
                     help="multi-GPU: all-reduce the table gradients (every rank ends up with all K bins) instead of reduce-scattering them")
     return ap.parse_args()
 
 
-PMC_FILE = os.path.join("profiles", "rocprof_pmc_r03.txt")
+PMC_FILE = os.path.join("profiles", "rocprof_pmc_r04.txt")
+KSTATS_FILE = os.path.join("profiles", "rocprof_kernel_stats_r04.txt")
 
 
 def kernels_sha16():
@@ -134,6 +138,32 @@ def pmc_traffic(kernel):
         return None, f"{PMC_FILE} has no line for {sym}"
     return int(best[1]), (f"{PMC_FILE} (kernels_sha16 {stamp}): separate rocprofv3 --pmc passes over the same command, "
                           "2 x FETCH_SIZE + WRITE_SIZE per launch")
+
+
+def rocprof_avg_us(kernel):
+    """average duration of `kernel` in the committed rocprofv3 --kernel-trace --stats summary (no launch gaps), when that
+    summary was taken on THIS tree's kernel sources"""
+    path = os.path.join(ROOT, KSTATS_FILE)
+    sym = PMC_SYMBOL.get(kernel)
+    if not sym or not os.path.exists(path):
+        return None, f"no kernel-trace summary for '{kernel}' ({KSTATS_FILE})"
+    stamp, best = None, None
+    for line in open(path):
+        if line.startswith("# kernels_sha16:"):
+            stamp = line.split(":", 1)[1].strip()
+        if line.startswith(sym):
+            f = line.split()
+            try:
+                calls, total, avg = int(f[-4]), float(f[-3]), float(f[-2])
+            except ValueError:
+                continue
+            if best is None or total > best[0]:
+                best = (total, avg)
+    if stamp != kernels_sha16():
+        return None, f"{KSTATS_FILE} was measured on kernel sources {stamp}, this tree is {kernels_sha16()}: refused"
+    if not best:
+        return None, f"{KSTATS_FILE} has no line for {sym}"
+    return best[1], f"{KSTATS_FILE} (kernels_sha16 {stamp})"
 
 
 def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024, record=None):
@@ -421,18 +451,27 @@ class Bench:
         gbs = 8.0 * n / ms / 1e6
         return {"kernel": "floor, 64 Mi f32 (8 B/elt)", "GB/s": round(gbs, 1), "frac_of_peak": round(gbs / (HBM_PEAK_TBS * 1000), 4)}
 
-    def run(self, workload, steps, warmup, profile_steps):
+    def run(self, workload, steps, warmup, profile_steps, max_seconds=None):
         torch, ek, ekd = self.torch, self.ek, self.ekd
         step, packer, out, compute, exchange = self.make_step(workload)
         for _ in range(warmup):
             step()
         if packer:
             packer.wait_all()
-        # The timed steps replay a step graph: the launches of ONE forward + backward() captured on the library stream
+        if max_seconds is not None:
+            # secondary workloads: as many steps as fit the time budget (at least 5), from the duration of two more steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(); step()
+            if packer:
+                packer.wait_all()
+            torch.cuda.synchronize()
+            steps = max(5, min(steps, int(max_seconds / max((time.perf_counter() - t0) / 2, 1e-6))))
+        # (--graph) The timed steps replay a step graph: the launches of ONE forward + backward() captured on the library stream
         # (ek_hip_graph_*), so a step costs no host work (tape walk, allocator, ~12 launch calls).  The collective stays
         # outside the graph.  Workloads that read back to the host inside the step (cfg4: count) run eagerly.
-        graph, replay = None, "eager"
-        if compute is not None and not self.args.eager:
+        graph, replay = None, "eager (python-driven steps: tape walk, allocator, one launch call per kernel)"
+        if compute is not None and self.args.graph:
             try:
                 ek.hip_sync()
                 ek.hip_graph_begin()
@@ -485,11 +524,9 @@ class Bench:
                 packer.wait_all()
             torch.cuda.synchronize(); ekd.barrier()
             eager_ms = ekd.max_over_ranks(time.perf_counter() - t0) / steps * 1e3
-            # Both are K timed steps of the same kernels under the same protocol; a hipGraph replay saves the host work but
-            # pays its own launch cost, and which of the two wins depends on the step length and the box.  `value` is the
-            # faster one; both times are in the line.
-            if eager_ms < ms_per_step:
-                ms_per_step, replay = eager_ms, "eager (python-driven steps; the hipGraph replay of the same step was slower: see graph_ms_per_step)"
+            # `value` is ALWAYS the python-driven protocol (what a caller of the library gets); the replay time is reported next to it
+            ms_per_step = eager_ms
+            replay = "eager (python-driven steps: tape walk, allocator, one launch call per kernel); graph_ms_per_step is the hipGraph replay of the same step"
         gelem_s = units / (ms_per_step * 1e-3) / 1e9
         # per-kernel timing of the same step (run eagerly): one HIP event per launch on the library stream
         ek.hip_profile_begin()
@@ -517,8 +554,16 @@ class Bench:
             achieved = dom["bytes_per_launch"] / dom["avg_ms"] / 1e6      # GB/s
             whole = total_bytes_step / (ms_per_step * 1e-3) / 1e9
             traffic, traffic_source = pmc_traffic(dom["kernel"]) if self.n == (1 << 26) else (None, "PMC summaries are taken at 64 Mi elements per GPU")
+            rp_us, rp_src = rocprof_avg_us(dom["kernel"]) if self.n == (1 << 26) else (None, "kernel-trace summaries are taken at 64 Mi elements per GPU")
+            frac_live = achieved / (HBM_PEAK_TBS * 1000)
+            frac_rocprof = dom["bytes_per_launch"] / (rp_us * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1000) if rp_us else None
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(achieved / (HBM_PEAK_TBS * 1000), 4),
+                        "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(frac_live, 4),
+                        # frac / frac_live: from HIP-event deltas of this run (they include the gap to the previous launch);
+                        # frac_rocprof: the same algorithmic bytes over the kernel's average duration in the committed rocprofv3
+                        # kernel trace of this tree (no gaps)
+                        "frac_live": round(frac_live, 4), "frac_rocprof": round(frac_rocprof, 4) if frac_rocprof else None,
+                        "rocprof_avg_us": rp_us, "rocprof_source": rp_src,
                         "traffic": traffic, "traffic_source": traffic_source,
                         "whole_step": {"algorithmic_bytes": int(total_bytes_step),
                                        "bytes_per_elt": round(total_bytes_step / max(N_RAYS_PER_GPU if workload.startswith("cfg4") else N_PATHS_PER_GPU if workload.startswith("cfg5") else self.n, 1), 2),
@@ -529,6 +574,16 @@ class Bench:
         y_val = float(out["y"].numpy()[0])
         if packer and out.get("reduced"):
             y_val = float(out["reduced"][0].item())
+        if self.args.dump_gradients and workload == "cfg3b" and workload == self.args.workload:
+            os.makedirs(self.args.dump_gradients, exist_ok=True)
+            if packer and out.get("reduced") and len(out["reduced"]) == 3:
+                hA, hB = out["reduced"][1], out["reduced"][2]
+                owned = hA.owned if hA.scattered else (0, K_TABLE)
+                np.savez(os.path.join(self.args.dump_gradients, f"grad_rank{self.rank}.npz"), gA=hA.tensor().cpu().numpy(),
+                         gB=hB.tensor().cpu().numpy(), begin=owned[0], end=owned[1])
+            else:
+                np.savez(os.path.join(self.args.dump_gradients, f"grad_rank{self.rank}.npz"), gA=out["gA"].numpy(), gB=out["gB"].numpy(),
+                         begin=0, end=K_TABLE)
         outputs = {k: out[k].numpy() for k in ("gA", "gB", "ga", "gb") if k in out} if self.world == 1 and workload == self.args.workload else {}
         outputs["y"] = y_val
         return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "eager_ms_per_step": round(eager_ms, 4),
@@ -720,7 +775,7 @@ def main():
     if b.world == 1 and not args.no_also:
         for w in ("cfg3a", "cfg2", "cfg3b") + tuple(CFG3B_VARIANTS) + ("cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5", "cfg5_unfused"):
             if w != args.workload:
-                r = b.run(w, max(5, args.steps // 2), 2, 3)
+                r = b.run(w, args.steps // 2, 2, 3, max_seconds=1.0)
                 also[w] = {"value": r["value"], "unit": "Gelem/s", "ms_per_step": r["ms_per_step"],
                            "whole_step_frac_of_hbm_peak": r["roofline"]["whole_step"]["frac"] if r["roofline"] else None,
                            "bytes_per_elt": r["roofline"]["whole_step"]["bytes_per_elt"] if r["roofline"] else None,
@@ -744,7 +799,7 @@ def main():
         line = {
             "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "eager_ms_per_step": main_res["eager_ms_per_step"],
+            "ms_per_step": main_res["ms_per_step"], "value_source": "eager", "eager_ms_per_step": main_res["eager_ms_per_step"],
             "graph_ms_per_step": main_res["graph_ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",

@@ -431,6 +431,29 @@ __device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, fl
     }
 }
 
+// One update per lane, the form the streaming loops use: claim, add, release; the lanes that met a lock (another wave's, or a
+// lane of this wave with the same bin) retry together once, what is still locked then takes the combining path above.  The
+// "did anybody meet a lock" tests are wave ballots consumed by scalar branches (no vector instruction spent on them).
+__device__ __forceinline__ void lds_add_pair_one(unsigned long long *table, uint32_t l, float v0, float v1) {
+    unsigned long long *p = table + l;
+    const unsigned long long old = atomicExch(p, kLockedPair);
+    unsigned lo = (unsigned) old;
+    asm volatile("" : "+v"(lo));                       // (keeps the lock test a 32-bit compare of the low word)
+    const unsigned long long met = __builtin_amdgcn_uicmp(lo, kLockedBits, 32 /* == */);     // lanes that met a lock
+    if (lo != kLockedBits) __hip_atomic_store(p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (met) {
+        bool pending = lo == kLockedBits;
+        if (pending) {
+            const unsigned long long again = atomicExch(p, kLockedPair);
+            if ((unsigned) again != kLockedBits) {
+                __hip_atomic_store(p, pair_sum(again, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                pending = false;
+            }
+        }
+        if (__builtin_amdgcn_ballot_w64(pending)) lds_add_pair(p, v0, v1, pending);
+    }
+}
+
 // N independent updates per lane: all N bins are CLAIMED first (N exchanges in flight -- one LDS round trip instead of N
 // dependent ones), then every claim that succeeded is added to and released; the few that met a lock (another lane's, or
 // this lane's own claim of the same bin in an earlier slot) are retried together, and what is still locked then goes through
@@ -588,9 +611,7 @@ struct AccumulateBody {
                     // kernels took the bucket size at run time and lost: 0.185 vs 0.152 ms for {cos(u), x cos(u)}, 0.138
                     // vs 0.108 ms for {1, x}, equal for the rest (same box, 64 Mi elements): a lock held across a batch
                     // is met by the other 15 waves more often than its round trip costs.
-                    const uint32_t ls[1] = { l[k] };
-                    const T a0[1] = { vk[0] }, a1[1] = { vk[C - 1] };
-                    lds_add_pair_batch<1>(reinterpret_cast<unsigned long long *>(acc), ls, a0, a1);
+                    lds_add_pair_one(reinterpret_cast<unsigned long long *>(acc), l[k], vk[0], vk[C - 1]);
                 }
             }
         }
@@ -744,9 +765,7 @@ struct EarlyBody {
                     // a lock is held for the shortest possible time.  Measured on 64 Mi lookups into 1 Mi entries, same
                     // box: 0.199 ms with 8 claims per lane in flight (the stand-alone adjoint's batches), 0.165 with 4,
                     // 0.149 with 2, 0.146 with 1 after all four elements, 0.135 with 1 right behind each element.
-                    const uint32_t ls[1] = { l[k] };
-                    const T a0[1] = { v0[k] }, a1[1] = { v1[k] };
-                    lds_add_pair_batch<1>(reinterpret_cast<unsigned long long *>(tables), ls, a0, a1);
+                    lds_add_pair_one(reinterpret_cast<unsigned long long *>(tables), l[k], v0[k], v1[k]);
                 }
             }
         }
@@ -986,7 +1005,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.part = out.loff + part_entries;
     out.gtotal = gtotal;
     out.active = gtotal + 2 * kMaxBuckets;
-    out.lo = b->win_lo; out.span = b->win_span;
+    out.lo = b->win_lo; out.span = b->win_span ? b->win_span : (uint32_t) std::min<size_t>(b->table_size, 0xFFFFFFFFu);
     EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {

@@ -45,7 +45,7 @@ template <typename T> struct PagedOut {
     uint32_t *part;        // [n_buckets][W]  page << 6 | (count - 1) of the partially filled page, or kNoPage
     uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
     uint32_t *active;      // number of elements kept (zeroed by the host)
-    uint32_t lo, span;     // only indices in [lo, lo + span) are kept (a slice of a large table), rebased to lo; span = 0: all
+    uint32_t lo, span;     // only indices in [lo, lo + span) are kept, rebased to lo: the table (lo = 0, span = its size) or a slice of it
 #ifdef EK_PG_TIMING
     unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
 #endif
@@ -108,12 +108,12 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             if constexpr (HasMask) t.on |= (((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u) << j;
         }
         if constexpr (!HasMask) t.on = sm ? 0xFu : 0u;
-        if (win_span) {
+        // indices outside the table (or outside this slice of it) are dropped like masked-out lanes: an out-of-range index must
+        // not reach another bucket's counters (what it gathers / scatters is unspecified anyway, cuda.h:845-905)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                t.ix[j] -= win_lo;
-                if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
-            }
+        for (int j = 0; j < 4; ++j) {
+            t.ix[j] -= win_lo;
+            if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
         }
     };
     auto load_ragged = [&](size_t base, Tile &t) {
@@ -126,10 +126,8 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
                 t.ix[j] = (uint32_t) index[e + j];
                 t.xv[j] = __builtin_bit_cast(uint32_t, x[e + j]);
                 t.on |= ((mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u) << j;
-                if (win_span) {
-                    t.ix[j] -= win_lo;
-                    if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
-                }
+                t.ix[j] -= win_lo;
+                if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
             }
         }
     };

@@ -534,7 +534,7 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     out.lp = lp; out.xp = xp; out.wdir = wdir; out.wlist = wlist;
     out.gtotal = meta;
     out.active = meta + 2 * kMaxBuckets;
-    out.lo = 0; out.span = 0;
+    out.lo = 0; out.span = (uint32_t) std::min<size_t>(table_size, 0xFFFFFFFFu);
 #ifdef EK_PG_TIMING
     out.dbg = dbg;
 #else

@@ -326,7 +326,8 @@ namespace detail {
         using Return = HIPArray<type>;                                                            \
         using FieldType_ = std::decay_t<decltype(std::declval<Class>().field)>;                   \
         if constexpr (enoki::detail::is_pinned_class<Class>::value && std::is_arithmetic_v<FieldType_> && \
-                      !std::is_same_v<FieldType_, bool>) {                                        \
+                      !std::is_same_v<FieldType_, bool> &&                                        \
+                      (sizeof(FieldType_) == 1 || sizeof(FieldType_) == 4 || sizeof(FieldType_) == 8)) { /* what the kernel reads */ \
             const ptrdiff_t offset_ = (ptrdiff_t) (uintptr_t) &(((Class *) nullptr)->field);      \
             return Return(HIPArray<FieldType_>::gather_address_(self.bits(), offset_, mask));     \
         }                                                                                         \

@@ -282,6 +282,13 @@ namespace detail {
         ek_hip_index_partition_get(part, &info);
         float *out = target.data();
         ThroughSources<N> src{ { sources.data()... } };
+        // the kernel reads the sources while it writes the target (and may run twice: the byte-counter overflow retry): in-place
+        // use would apply f to entries that the first attempt already replaced
+        for (size_t s = 0; s < N; ++s)
+            if ((const void *) src.ptr[s] == (const void *) out) {
+                ek_hip_index_partition_destroy(part);
+                throw std::runtime_error(std::string(what) + ": the target must not be one of the sources");
+            }
         int vec_ok = (reinterpret_cast<uintptr_t>(out) & 15u) == 0;
         for (size_t s = 0; s < N; ++s) vec_ok = vec_ok && (reinterpret_cast<uintptr_t>(src.ptr[s]) & 15u) == 0;
 

@@ -13,9 +13,11 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(workload, n, ranks, port):
+def run_bench(workload, n, ranks, port, dump=None):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--n", str(n),
            "--workload", workload, "--no-cpu-baseline", "--no-also", "--profile-steps", "1"]
+    if dump:
+        cmd += ["--dump-gradients", dump]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ENOKI_DIST_BACKEND="gloo")
     if ranks == 1:
         out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=300)
@@ -32,16 +34,39 @@ def run_bench(workload, n, ranks, port):
 
 
 @pytest.mark.parametrize("workload", ["cfg3b", "cfg3a"])
-def test_two_ranks_match_one(workload):
+def test_two_ranks_match_one(workload, tmp_path):
     n = 1 << 22
-    one = run_bench(workload, n, 1, 29611)
-    two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613)
+    one = run_bench(workload, n, 1, 29611, dump=str(tmp_path / "one"))
+    two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613, dump=str(tmp_path / "two"))
+    if workload == "cfg3b":
+        check_scattered_gradients(n, tmp_path)
     # cfg3b: ONE reduce-scatter for both gradient tables with the loss riding in an extra column; cfg3a: the loss only
     assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2
     assert two["config"]["collectives_per_step"] == 1
     truth, bound = truth_y(workload, n)
     assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound, (one["result_y"], two["result_y"], truth, bound)
     assert two["value"] > 0 and two["scaling"] == "strong"
+
+
+def check_scattered_gradients(n, tmp_path):
+    """the REDUCE-SCATTERED table gradients on the device: rank r holds bins [r K / 2, (r + 1) K / 2) of the sum over both shards;
+    the owned slices, concatenated, are the single-process gradients -- both inside the per-bin class-D bound of the float64 sums"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import cfg3b_truth, hash_u32, uniform_pm1
+    K = 1 << 20
+    A, B, x = uniform_pm1(K, 6), uniform_pm1(K, 7), uniform_pm1(n, 2)
+    idx = (hash_u32(np.arange(n, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)
+    t = cfg3b_truth(A, B, x, idx)
+    single = np.load(tmp_path / "one" / "grad_rank0.npz")
+    parts = sorted((np.load(tmp_path / "two" / f"grad_rank{r}.npz") for r in range(2)), key=lambda z: int(z["begin"]))
+    assert int(parts[0]["begin"]) == 0 and int(parts[0]["end"]) == int(parts[1]["begin"]) and int(parts[1]["end"]) == K
+    for g in ("gA", "gB"):
+        whole = np.concatenate([p[g][: int(p["end"]) - int(p["begin"])] for p in parts])
+        assert whole.shape == (K,)
+        # two shards: every bin is the sum of two partial sums of at most cnt terms each
+        assert np.all(np.abs(whole - t[g]) <= t[g + "_bound"] + 2.0 ** -24 * np.abs(t[g])), g
+        assert np.all(np.abs(single[g] - t[g]) <= t[g + "_bound"]), g
 
 
 def truth_y(workload, n):

@@ -1,0 +1,26 @@
+# rocprofv3 evidence for round 4 (run on the GPU box: bash tools/profile_r04.sh); summaries land in gpurun_out/ and are copied to
+# profiles/*_r04.txt.  Counter passes are separate runs (no tracing domains besides the kernel trace).
+R=$GRAFT_REPO_ROOT
+cd /tmp && export TMPDIR=/tmp
+B="python $R/bench.py --no-cpu-baseline --no-also --steps 5 --warmup 2 --profile-steps 2"
+timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- $B > /tmp/kt.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch -- $B > /tmp/f.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_write -- $B > /tmp/w.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_LDS SQ_INSTS_VALU -d /tmp/prof_sqa -- $B > /tmp/c.log 2>&1
+timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY -d /tmp/prof_sqb -- $B > /tmp/d.log 2>&1
+# cfg4 per pixel in bucket order and the fused cfg5: kernel trace + HBM traffic
+for w in cfg4_bucketed cfg5; do
+  W="python $R/bench.py --workload $w --no-cpu-baseline --no-also --steps 5 --warmup 2 --profile-steps 2"
+  timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_$w -- $W > /tmp/kt_$w.log 2>&1
+  timeout 300 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch_$w -- $W > /tmp/f_$w.log 2>&1
+  timeout 300 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_write_$w -- $W > /tmp/w_$w.log 2>&1
+done
+cd $R
+python tools/rocprof_summary.py kernels /tmp/prof_kt > gpurun_out/rocprof_kernel_stats_r04.txt
+python tools/rocprof_summary.py pmc /tmp/prof_fetch /tmp/prof_write > gpurun_out/rocprof_pmc_r04.txt
+python tools/rocprof_summary.py raw /tmp/prof_sqa /tmp/prof_sqb > gpurun_out/rocprof_sq_r04.txt
+for w in cfg4_bucketed cfg5; do
+  python tools/rocprof_summary.py kernels /tmp/prof_kt_$w > gpurun_out/rocprof_kernel_stats_${w}_r04.txt
+  python tools/rocprof_summary.py pmc /tmp/prof_fetch_$w /tmp/prof_write_$w > gpurun_out/rocprof_pmc_${w}_r04.txt
+done
+head -14 gpurun_out/rocprof_kernel_stats_r04.txt

@@ -8,6 +8,7 @@ coalesced streaming read, so the read side is doubled before comparing with byte
 as is (uncalibrated).  Both counters are in KiB."""
 import glob
 import re
+import os
 import sqlite3
 import sys
 
@@ -23,6 +24,9 @@ def short(name):
 
 
 def kernels(d):
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from enoki_amd import _build
+    print(f"# kernels_sha16: {_build.kernels_sha16()}")
     for f in dbs(d):
         cur = sqlite3.connect(f).cursor()
         print(f"# rocprofv3 --kernel-trace --stats  ({f})")
