@@ -243,10 +243,14 @@ EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_
  * every bucket's {A, C} slice is then served from LDS (no lookup leaves the CU: element-order lookups into tables beyond
  * the 4 MiB L2 of an XCD run at 0.25 of the HBM roofline), and the adjoint reuses the partition instead of counting,
  * scanning and partitioning again.
- *   create        count / scan / partition; `table_a`, `table_c` (`table_size` entries each), are read by later calls:
+ *   create        the partition -- 4-byte element types: ONE streaming pass into pages (csrc/ek_paged.h: full-line pages per bucket,
+ *                 no count pass, no scans) + the page directory; 8-byte types: count / scan / partition into contiguous runs;
+ *                 4-byte tables beyond 256 buckets are cut into slices of 256 buckets, one filtered pass per slice.
+ *                 `table_a`, `table_c` (`table_size` entries each), are read by later calls:
  *                 the caller keeps them alive and unchanged for the lifetime of the object.  x and index: n-element arrays.
  *                 EK_ERR_UNSUPPORTED for shapes the path does not cover (ask ek_hip_bucketed_applicable first): tables of
- *                 one bucket or of more than 256, fewer than 256 Ki lookups, deterministic mode, non-fp types.
+ *                 one bucket, 8-byte tables of more than 256 buckets, 4-byte tables of more than 32 x 256, fewer than 256 Ki or
+ *                 (4-byte types) 2^30 or more lookups, deterministic mode, non-fp types.  Indices outside the table are dropped.
  *   reduce        out[0] = reduce_op over map_op(u)  (map_op: EK_COPY or an op ek_hip_reduce_map accepts); keep_values != 0
  *                 also keeps u in bucket order for later calls (4 B/elt more) -- or, when {map_op, keep_op} = {EK_SIN, EK_COS},
  *                 the OTHER half of sincos(u): one sincos per element yields the reduced and the kept half, and a later
