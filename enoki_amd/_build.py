@@ -73,7 +73,9 @@ def _run(cmd):
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if force or _newer(obj, [src] + _headers()):
-        cmd = [HIPCC] + DEVICE + COMMON + (["-x", "hip"] if src.endswith(".cpp") and "csrc" in src else []) + ["-c", src, "-o", obj]
+        # ENOKI_PROBE_DEFINES="-DEK_PG_TIMING" builds the measurement library (probe.hip only) with instrumentation
+        extra = os.environ.get("ENOKI_PROBE_DEFINES", "").split() if os.path.basename(src).startswith("probe") else []
+        cmd = [HIPCC] + DEVICE + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") and "csrc" in src else []) + ["-c", src, "-o", obj]
         _run(cmd)
     return obj
 

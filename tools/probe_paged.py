@@ -128,6 +128,10 @@ if mode in ("time", "all"):
         t0 = ts[:, 0].min()
         us = lambda v: (v - t0) / 100.0
         print(f"  wall clock (100 MHz), us from the first start: starts {us(ts[:,0]).min():.1f}..{us(ts[:,0]).max():.1f}, loop begins {us(ts[:,1]).min():.1f}..{us(ts[:,1]).max():.1f}, loop ends {us(ts[:,2]).min():.1f}..{np.median(us(ts[:,2])):.1f}..{us(ts[:,2]).max():.1f}, ends {us(ts[:,3]).min():.1f}..{np.median(us(ts[:,3])):.1f}..{us(ts[:,3]).max():.1f}")
+        ends = us(ts[:, 2])
+        print("  loop end by XCD (block % 8), us: " + ", ".join(f"{x}: {np.median(ends[x::8]):.1f} (max {ends[x::8].max():.1f})" for x in range(8)))
+        order = np.argsort(ends)
+        print("  slowest blocks:", [(int(b), round(float(ends[b]), 1)) for b in order[-12:]])
         names = ["wait loads", "placement", "barrier 1", "overflow", "-", "write-out", "barrier 2", "-"]
         tiles = r.chunk // 4096
         for wv in (0, 1):
