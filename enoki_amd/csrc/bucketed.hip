@@ -961,6 +961,57 @@ static int bucketed_create(Bucketed *b, const T *x, const I *index) {
     return EK_OK;
 }
 
+/// A table of three or more slices: (index, x) are first split by SLICE into contiguous runs -- the count / scan / partition
+/// kernels of ek_binned.h with 32-bit slice-local indices -- so that every slice's page partition reads only its own elements
+/// (20 B/elt once instead of 8 B/elt per slice).  The slice populations come back to the host (which sizes the per-slice work).
+struct CoarseSplit {
+    void *idx = nullptr, *x = nullptr, *meta = nullptr;      // slice-local indices and x in slice order; counts / bases
+    std::vector<uint32_t> base;                              // host copy of bucket_base[0 .. S]
+    ~CoarseSplit() {
+        for (void *p : { idx, x, meta })
+            if (p) ek_hip_free(p);
+    }
+};
+
+template <int Shift>
+static int coarse_split(CoarseSplit &cs, const float *x, const uint32_t *index, const Arg<uint8_t> &mask, size_t n, int S) {
+    RoctxRange range("enoki-hip: slice partition");
+    Context &c = ctx();
+    unsigned blocks = (unsigned) std::min<size_t>((size_t) c.num_cu * 4, (n + kTile - 1) / kTile);
+    if (blocks == 0) blocks = 1;
+    size_t chunk = (n + blocks - 1) / blocks;
+    chunk = (chunk + kTile - 1) / kTile * kTile;
+    blocks = (unsigned) ((n + chunk - 1) / chunk);
+    const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
+    int rep_shift = 0;
+    while ((S << (rep_shift + 1)) <= kMaxBuckets && rep_shift < 4) ++rep_shift;
+    const size_t count_entries = (size_t) S * blocks;
+    if (int rc = ek_hip_malloc((count_entries + 2 * kMaxBuckets + 2) * sizeof(uint32_t), &cs.meta)) return rc;
+    if (int rc = ek_hip_malloc(n * sizeof(uint32_t), &cs.idx)) return rc;
+    if (int rc = ek_hip_malloc(n * sizeof(float), &cs.x)) return rc;
+    uint32_t *counts = (uint32_t *) cs.meta, *row_total = counts + count_entries, *bucket_base = row_total + kMaxBuckets;
+    hipLaunchKernelGGL((k_bin_count<uint32_t, Shift>), dim3(blocks), dim3(kThreads), 0, c.stream, counts, index, mask, n, chunk, S,
+                       rep_shift, vec_ok);
+    EK_LAUNCH_CHECK("bucket_slice_count", n, n * sizeof(uint32_t) + arg_bytes(mask, n));
+    hipLaunchKernelGGL(k_bin_scan_rows, dim3(S), dim3(1024), 0, c.stream, counts, row_total, blocks);
+    hipLaunchKernelGGL(k_bin_scan_buckets, dim3(1), dim3(256), 0, c.stream, bucket_base, (uint32_t *) nullptr, (const uint32_t *) row_total, S, 0u);
+    EK_LAUNCH_CHECK("bucket_slice_scan", count_entries, 2 * count_entries * sizeof(uint32_t));
+    BinStreams<float, 1> st;
+    st.value[0] = Arg<float>{ x, 0.f, 1u };
+    st.weight[0] = Arg<float>{ nullptr, 1.f, 0u };
+    st.pair_val[0] = (float *) cs.x;
+    st.weighted = 0u;
+    st.value_op[0] = EK_COPY;
+    hipLaunchKernelGGL((k_bin_partition<float, uint32_t, Shift, uint32_t, 1>), dim3(blocks), dim3(kThreads), 0, c.stream,
+                       (uint32_t *) cs.idx, st, (const uint32_t *) counts, (const uint32_t *) bucket_base, index, mask, n, chunk, S, 0,
+                       vec_ok);
+    EK_LAUNCH_CHECK("bucket_slice_partition", n, n * 16 + arg_bytes(mask, n));
+    cs.base.resize(S + 1);
+    EK_HIP_CHECK(hipMemcpyAsync(cs.base.data(), bucket_base, (S + 1) * sizeof(uint32_t), hipMemcpyDeviceToHost, c.stream));
+    EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+    return EK_OK;
+}
+
 /// The same object from the single-pass paged partition (ek_paged.h): 4-byte element types, n <= 2^30.  One streaming pass
 /// over (index, x) + the page directory: no count pass, no scans.
 template <typename I>
@@ -1317,6 +1368,8 @@ using namespace ek;
 struct ek_hip_bucketed : ek::Bucketed {
     std::vector<ek_hip_bucketed *> slices;
     size_t slice_span = 0;
+    bool slices_split = false;       // the slices hold disjoint parts of the input (CoarseSplit) instead of filtered views of all of it
+    bool empty_slice = false;        // a slice that received no element
     ~ek_hip_bucketed() { for (ek_hip_bucketed *s : slices) delete s; }
 };
 constexpr int kMaxSlices = 64;
@@ -1399,18 +1452,41 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
             const int S = (int) ((table_size + span - 1) / span);
             b->slice_span = span;
             rc = EK_OK;
+            // two slices: each reads all of (index, x) and keeps its own; three or more: split by slice first (needs the slice
+            // populations on the host, which a captured step cannot wait for)
+            CoarseSplit cs;
+            const bool split = S >= 3;
+            if (split) {
+                rc = refuse_while_capturing("ek_hip_bucketed_pair_create(): a table of three or more slices (slice populations are read back)");
+                if (rc == EK_OK)
+                    rc = want_half ? coarse_split<bin_shift_of<float> - 1 + 8>(cs, (const float *) x, (const uint32_t *) index, m, n, S)
+                                   : coarse_split<bin_shift_of<float> + 8>(cs, (const float *) x, (const uint32_t *) index, m, n, S);
+            }
+            const Arg<uint8_t> all{ nullptr, 1, 0u };
             for (int sl = 0; sl < S && rc == EK_OK; ++sl) {
                 ek_hip_bucketed *sub = new ek_hip_bucketed();
                 b->slices.push_back(sub);
-                sub->type = type; sub->index_type = index_type; sub->op = op; sub->n = n;
+                sub->type = type; sub->index_type = index_type; sub->op = op;
                 sub->table_size = std::min(span, table_size - (size_t) sl * span);
                 sub->table_a = (const float *) table_a + (size_t) sl * span;
                 sub->table_c = (const float *) table_c + (size_t) sl * span;
-                sub->win_lo = (uint32_t) ((size_t) sl * span);
-                sub->win_span = (uint32_t) sub->table_size;
                 sub->correct_masked = false;
-                rc = bucketed_create_paged<uint32_t>(sub, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (want_half ? 1 : 0));
+                if (split) {
+                    // the slice's own elements, indices already local to the slice
+                    sub->n = cs.base[sl + 1] - cs.base[sl];
+                    sub->win_lo = 0;
+                    sub->win_span = (uint32_t) sub->table_size;
+                    if (sub->n == 0) { sub->empty_slice = true; continue; }
+                    rc = bucketed_create_paged<uint32_t>(sub, (const float *) cs.x + cs.base[sl], (const uint32_t *) cs.idx + cs.base[sl], all,
+                                                         bin_shift_of<float> - (want_half ? 1 : 0));
+                } else {
+                    sub->n = n;
+                    sub->win_lo = (uint32_t) ((size_t) sl * span);
+                    sub->win_span = (uint32_t) sub->table_size;
+                    rc = bucketed_create_paged<uint32_t>(sub, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (want_half ? 1 : 0));
+                }
             }
+            b->slices_split = split;
         } else {
             rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (half ? 1 : 0));
         }
@@ -1431,13 +1507,14 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *
     if (map_op != EK_COPY && !unary_fusable(map_op))
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_reduce(): op %d cannot be applied on load", map_op);
     if (!b->slices.empty()) {
-        const int S = (int) b->slices.size();
         Scratch partial;
-        if (int rc = partial.alloc((size_t) S * sizeof(float))) return rc;
+        if (int rc = partial.alloc(b->slices.size() * sizeof(float))) return rc;
         SliceCounts counts{};
-        for (int sl = 0; sl < S; ++sl) {
-            if (int rc = bucketed_reduce<float>(b->slices[sl], reduce_op, map_op, (float *) partial.ptr + sl, keep_values != 0, keep_op)) return rc;
-            counts.active[sl] = b->slices[sl]->active;
+        int S = 0;                                     // slices that hold elements
+        for (ek_hip_bucketed *sub : b->slices) {
+            if (sub->empty_slice) continue;
+            if (int rc = bucketed_reduce<float>(sub, reduce_op, map_op, (float *) partial.ptr + S, keep_values != 0, keep_op)) return rc;
+            counts.active[S++] = sub->active;
         }
         Context &c = ctx();
 #define EK_COMBINE(OP) hipLaunchKernelGGL((k_slices_combine<float, OP>), dim3(1), dim3(64), 0, c.stream, (float *) out, (const float *) partial.ptr, S, counts, b->n, map_op)
@@ -1477,6 +1554,12 @@ int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *cons
         for (size_t sl = 0; sl < b->slices.size(); ++sl) {
             void *sb[4];
             for (int s = 0; s < count; ++s) sb[s] = (float *) bases[s] + sl * b->slice_span;
+            if (b->slices[sl]->empty_slice) {          // nothing to add; a fresh table still has to hold zeros there
+                for (int s = 0; s < count; ++s)
+                    if (fresh && fresh[s])
+                        EK_HIP_CHECK(hipMemsetAsync(sb[s], 0, b->slices[sl]->table_size * sizeof(float), ctx().stream));
+                continue;
+            }
             if (int rc = bucketed_scatter_add<float>(b->slices[sl], count, sb, from_u, map_ops, imm_bits, weighted, fresh, scale_bits)) return rc;
         }
         return EK_OK;

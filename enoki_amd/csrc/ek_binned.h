@@ -120,9 +120,10 @@ __global__ __launch_bounds__(kThreads) void k_bin_count(uint32_t *__restrict__ c
         uint32_t ix[kPerThread];
         bool on[kPerThread];
         load_tile<false>(index, mask, sm, Arg<uint32_t>{ nullptr, 0u, 0u }, 0u, base, end, vec_ok, ix, on, (uint32_t *) nullptr);
+        // (an index beyond the table is dropped like a masked-out lane: it must not reach another bucket's counter)
 #pragma unroll
         for (int k = 0; k < kPerThread; ++k)
-            if (on[k]) atomicAdd(&hist[((ix[k] >> Shift) << rep_shift) | rep], 1u);
+            if (on[k] && (ix[k] >> Shift) < (uint32_t) n_buckets) atomicAdd(&hist[((ix[k] >> Shift) << rep_shift) | rep], 1u);
     }
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += kThreads) {
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) v
             bool flag[kPerThread];
             load_tile<false, Full>(index, mask, sm, Arg<T>{ nullptr, T(0), 0u }, T(0), base, end, vec_ok, ix, flag, (T *) nullptr);
 #pragma unroll
-            for (int k = 0; k < kPerThread; ++k) on |= (flag[k] ? 1u : 0u) << k;
+            for (int k = 0; k < kPerThread; ++k) on |= ((flag[k] && (ix[k] >> Shift) < (uint32_t) n_buckets) ? 1u : 0u) << k;
         }
         if constexpr (!NoValues) load_stream(full, 0, base, val);
 #pragma unroll

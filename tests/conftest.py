@@ -8,8 +8,20 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def pytest_collection_modifyitems(config, items):
+    """the `extras` suites run only when asked for by name: they are neither part of the GPU gate (-m gpu) nor runnable on CPU"""
+    if "extras" in (config.getoption("-m") or ""):
+        return
+    skip = pytest.mark.skip(reason="support-library device test outside SURVEY section 8: run with -m extras on a GPU box")
+    for item in items:
+        if "extras" in item.keywords:
+            item.add_marker(skip)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "extras: device tests of the support library OUTSIDE the hot-path contract of SURVEY section 8 "
+                                       "(complex, matrix, morton, sh, special); need a GPU, run with `-m extras`")
     # torch ships its own HIP runtime; when both runtimes live in one process torch's must initialise first
     # (bench.py does the same), otherwise torch later reports "No HIP GPUs are available".
     if "gpu" in (config.getoption("-m") or "") and "not gpu" not in (config.getoption("-m") or ""):

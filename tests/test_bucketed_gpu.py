@@ -280,6 +280,29 @@ def test_tables_beyond_256_buckets_are_sliced(capi, hinted):
     b.destroy()
 
 
+def test_slices_with_no_elements_and_out_of_range_indices(capi):
+    """five hinted slices (K = 9 Mi: split by slice first), every index in slices 0 and 3: the other slices are empty -- their part of
+    a fresh gradient table must still hold zeros -- and indices beyond the table are dropped like masked-out lanes"""
+    K, n = 9 << 20, (1 << 19) + 11
+    rng = np.random.default_rng(6)
+    A = rng.integers(-3, 4, K).astype(np.float32); C = rng.integers(-3, 4, K).astype(np.float32)
+    x = rng.integers(-2, 3, n).astype(np.float32)
+    idx = np.where(rng.integers(0, 2, n) == 0, rng.integers(0, 2 << 20, n), rng.integers(6 << 20, 8 << 20, n)).astype(np.uint32)
+    idx[::1000] = K + 5                                   # out of range
+    ok = idx < K
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    b = capi.Bucketed("fmadd", dA, dx, dC, di, hints=capi.Bucketed.HINT_ADJOINT)
+    u = np.where(ok, A[np.minimum(idx, K - 1)] * x + C[np.minimum(idx, K - 1)], 0).astype(np.float32)
+    y = float(b.reduce("hsum", "abs", keep=True, keep_op="abs").numpy()[0])
+    assert y == float(np.abs(u).astype(np.float64).sum())
+    gA, gC = capi.Buf(np.float32, K), capi.Buf(np.float32, K)          # uninitialised: fresh tables are WRITTEN
+    b.scatter_add([gC, gA], [("abs", 0, False), ("abs", 0, True)], fresh=[1, 1])
+    eA = np.bincount(idx[ok], weights=(np.abs(u) * x)[ok], minlength=K).astype(np.float32)
+    eC = np.bincount(idx[ok], weights=np.abs(u)[ok], minlength=K).astype(np.float32)
+    assert np.array_equal(gA.numpy(), eA) and np.array_equal(gC.numpy(), eC)
+    b.destroy()
+
+
 def test_skewed_indices(capi):
     """all lookups in one bucket / one bin: the exchange lock's wave-combining path and the piece split stay correct"""
     K, n = 1 << 18, (1 << 19) + 5

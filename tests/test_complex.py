@@ -29,7 +29,7 @@ def test_restated_product_order(oracle):
     assert bits_equal(np.sqrt(sq), out[ABSARG][0])
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 @pytest.mark.parametrize("mod", ["hip", "hip_autodiff"])
 def test_complex_ops_match_reference(mod):
     import importlib
@@ -56,7 +56,7 @@ def test_complex_ops_match_reference(mod):
     assert bits_equal(num(ek.conj(a).imag), -z["a"][1]) and bits_equal(num((a * ek.Float32(2.0)).real), z["a"][0] * np.float32(2))
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_complex_gradient():
     """d/d re |z|^2 = 2 re through the complex product z * conj(z)"""
     import enoki_amd.hip_autodiff as ek
@@ -85,7 +85,7 @@ def test_complex_more_golden_is_sane():
         assert np.abs(g[sel] - f(a[sel])).max() < 5e-6, MORE[k]
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_complex_more_matches_reference():
     """sinh ... atanh of Complex2f against the reference build (tests/golden/complex_more.npz): the same compositions of
     log / sqrt / sincos / sincosh; class C where rcp() or a division enters"""

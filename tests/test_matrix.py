@@ -45,7 +45,7 @@ def ulp_diff(x, y):
     return np.abs(xi - yi).max()
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 @pytest.mark.parametrize("mod", ["hip", "hip_autodiff"])
 @pytest.mark.parametrize("N", [2, 3, 4])
 def test_matrix_ops_match_reference(mod, N):
@@ -89,7 +89,7 @@ def test_matrix_ops_match_reference(mod, N):
     assert bits_equal(num(s[1, 0]), g["a"][N] * np.float32(2))
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_matrix_gradient():
     """d/dv hsum(M v) = column sums of M^T: the tape sees the fmadd chain like any other program"""
     import enoki_amd.hip_autodiff as ek
@@ -137,7 +137,7 @@ def test_transform_host_matches_golden():
         assert np.allclose(clip / w, want, atol=1e-4)
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_transform_device_matches_golden():
     import enoki_amd.hip as ek
     z = np.load(os.path.join(GOLDEN, "transform.npz"))
@@ -173,7 +173,7 @@ def test_polar_decomposition_host_properties():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_transform_decompose_device():
     """device arrays: compose(decompose(A)) = A and A * compose_inverse = I; Q of the polar decomposition against scipy"""
     import enoki_amd.hip as ek

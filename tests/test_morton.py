@@ -20,7 +20,7 @@ def test_host_scalars_match_the_definition():
     assert out.returncode == 0, out.stdout + out.stderr
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 @pytest.mark.parametrize("dim", [2, 3])
 def test_device_arrays(dim):
     import enoki_amd.hip as ek

@@ -30,7 +30,7 @@ def test_host_scalars_match_scipy_and_the_reference():
     assert np.abs(mine - z["out"]).max() < 4e-6
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_device_arrays_match_the_reference():
     import enoki_amd.hip as ek
     ek.hip_init(0)

@@ -56,7 +56,7 @@ def test_against_libm(oracle):
     assert np.allclose(oracle.unary("erf", oracle.unary("erfinv", u)), u, rtol=1e-5, atol=1e-6)
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_kernels_bit_exact_vs_oracle_and_golden(capi, oracle):
     from test_kernels_gpu import up
     z = np.load(os.path.join(GOLDEN, "special.npz"))
@@ -70,7 +70,7 @@ def test_kernels_bit_exact_vs_oracle_and_golden(capi, oracle):
             assert same(oracle.unary(op, x), fn(op, x)), (op, dt)
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 @pytest.mark.parametrize("mod", ["hip", "hip_autodiff"])
 def test_python_surface_and_composition(mod, oracle):
     """enoki_amd.hip.*: the fused kernels; enoki_amd.hip_autodiff.*: the generic composition over DiffArray ops -- the same
@@ -86,7 +86,7 @@ def test_python_surface_and_composition(mod, oracle):
             assert same(oracle.unary(op, x), r), (mod, op, dt)
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_gradients_through_the_composition():
     import enoki_amd.hip_autodiff as ek
     x = np.linspace(-2.5, 2.5, 1001).astype(np.float32)
@@ -140,7 +140,7 @@ def test_ellint_host_packets_match_golden():
     assert np.abs(want[6] - sp.elliprf(phi * phi, 1.5 - k * k, 1 + np.abs(nu))).max() < 1e-14
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_ellint_device_matches_golden():
     """HIPArray composition (one kernel per operation, device sincos = the reference's algorithm): ALL ten functions are
     bit-exact against the reference build in float64; float32 is class C (rcp)"""
@@ -161,7 +161,7 @@ def test_ellint_device_matches_golden():
                 assert rel.max() <= 1e-6, (name, rel.max())
 
 
-@pytest.mark.gpu
+@pytest.mark.extras
 def test_ellint_gradient():
     """DiffArray differentiates through the duplication rounds: dF/dphi = 1 / sqrt(1 - k^2 sin^2 phi),
     dE/dphi = sqrt(1 - k^2 sin^2 phi)"""
