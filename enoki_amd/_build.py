@@ -29,7 +29,7 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", 
           "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
 DEVICE = [f"--offload-arch={ARCH}"]
 
-LIB_SOURCES = ["runtime.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "gathered.hip", "scan.hip", "bucketed.hip"]
+LIB_SOURCES = ["runtime.cpp", "dist.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "gathered.hip", "scan.hip", "bucketed.hip"]
 # measurement scaffolding (tools/probe_*.py): its own library on top of the public C ABI, never loaded by the product
 PROBE_SOURCES = ["probe.hip", "probe_rt.cpp"]
 

@@ -1,0 +1,171 @@
+// Index-range sharding for callers WITHOUT python / torch: one process per GPU, RCCL collectives on the library stream.
+//
+// The reference has no multi-device layer; BASELINE's north star asks for arrays sharded over the 8 GPUs of a node
+// with horizontal results and table gradients finished by RCCL over xGMI.  enoki_amd/dist.py does that on top of
+// torch.distributed; this file is the same exchange step at the C ABI: rank 0 makes a unique id, the caller ships its 128 bytes
+// to the other ranks (a file, MPI, an environment variable -- bootstrap is the caller's business, as with ncclGetUniqueId), every
+// rank calls ek_hip_dist_init, and the collectives run on the stream that the kernels run on (ordered with them, no host wait).
+// librccl.so is loaded on first use: the library has no link-time dependency on it, and a world of ONE rank never loads it.
+#include "ek_internal.h"
+
+#include <dlfcn.h>
+
+namespace ek {
+
+struct Id128 { char bytes[128]; };            // ncclUniqueId (passed by value)
+
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*get_unique_id)(void *) = nullptr;
+    int (*comm_init_rank)(void **, int, Id128, int) = nullptr;
+    int (*all_reduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*reduce_scatter)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*all_gather)(const void *, void *, size_t, int, void *, hipStream_t) = nullptr;
+    int (*comm_destroy)(void *) = nullptr;
+    const char *(*error_string)(int) = nullptr;
+};
+} // namespace
+
+static Rccl g_rccl;
+static void *g_comm = nullptr;
+static int g_rank = 0, g_world = 1;
+
+static int load_rccl() {
+    if (g_rccl.lib) return EK_OK;
+    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist: librccl.so cannot be loaded (%s)", dlerror());
+    Rccl r;
+    r.lib = lib;
+    r.get_unique_id = (decltype(r.get_unique_id)) dlsym(lib, "ncclGetUniqueId");
+    r.comm_init_rank = (decltype(r.comm_init_rank)) dlsym(lib, "ncclCommInitRank");
+    r.all_reduce = (decltype(r.all_reduce)) dlsym(lib, "ncclAllReduce");
+    r.reduce_scatter = (decltype(r.reduce_scatter)) dlsym(lib, "ncclReduceScatter");
+    r.all_gather = (decltype(r.all_gather)) dlsym(lib, "ncclAllGather");
+    r.comm_destroy = (decltype(r.comm_destroy)) dlsym(lib, "ncclCommDestroy");
+    r.error_string = (decltype(r.error_string)) dlsym(lib, "ncclGetErrorString");
+    if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.reduce_scatter || !r.all_gather || !r.comm_destroy)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist: librccl.so lacks an entry point");
+    g_rccl = r;
+    return EK_OK;
+}
+
+static int nccl_fail(int rc, const char *what) {
+    return fail(EK_ERR_HIP, "%s failed: %s", what, g_rccl.error_string ? g_rccl.error_string(rc) : "RCCL error");
+}
+
+static int nccl_type(int type) {
+    switch (type) {
+        case EK_BOOL: return 1;       // ncclUint8
+        case EK_I32: return 2;
+        case EK_U32: return 3;
+        case EK_I64: return 4;
+        case EK_U64: return 5;
+        case EK_F32: return 7;
+        case EK_F64: return 8;
+        default: return -1;
+    }
+}
+
+static int nccl_op(int reduce_op) {
+    switch (reduce_op) {
+        case EK_HSUM: return 0;       // ncclSum
+        case EK_HPROD: return 1;
+        case EK_HMAX: return 2;
+        case EK_HMIN: return 3;
+        default: return -1;
+    }
+}
+
+} // namespace ek
+
+using namespace ek;
+
+extern "C" {
+
+int ek_hip_dist_unique_id(void *id128) {
+    if (int rc = ensure_init()) return rc;
+    if (!id128) return fail(EK_ERR_INVALID, "ek_hip_dist_unique_id(): null pointer");
+    if (int rc = load_rccl()) return rc;
+    if (int rc = g_rccl.get_unique_id(id128)) return nccl_fail(rc, "ncclGetUniqueId");
+    return EK_OK;
+}
+
+int ek_hip_dist_init(int rank, int world, const void *id128) {
+    if (int rc = ensure_init()) return rc;
+    if (world < 1 || rank < 0 || rank >= world) return fail(EK_ERR_INVALID, "ek_hip_dist_init(): rank %d of %d", rank, world);
+    if (g_comm) return fail(EK_ERR_INVALID, "ek_hip_dist_init(): already initialised (ek_hip_dist_finalize first)");
+    g_rank = rank;
+    g_world = world;
+    if (world == 1 && !id128) return EK_OK;                  // a world of one: every collective is local
+    if (!id128) return fail(EK_ERR_INVALID, "ek_hip_dist_init(): null unique id");
+    if (int rc = load_rccl()) return rc;
+    Id128 id;
+    memcpy(&id, id128, sizeof(id));
+    if (int rc = g_rccl.comm_init_rank(&g_comm, world, id, rank)) { g_rank = 0; g_world = 1; return nccl_fail(rc, "ncclCommInitRank"); }
+    return EK_OK;
+}
+
+int ek_hip_dist_world(int *rank, int *world) {
+    if (rank) *rank = g_rank;
+    if (world) *world = g_world;
+    return EK_OK;
+}
+
+int ek_hip_dist_shard_range(size_t n, int rank, int world, size_t *begin, size_t *end) {
+    if (world < 1 || rank < 0 || rank >= world || !begin || !end) return fail(EK_ERR_INVALID, "ek_hip_dist_shard_range(): bad arguments");
+    // rank r owns [r n / P, (r + 1) n / P): the same partition for every size-n array, so vertical operations stay local
+    *begin = (size_t) ((unsigned __int128) n * (unsigned) rank / (unsigned) world);
+    *end = (size_t) ((unsigned __int128) n * (unsigned) (rank + 1) / (unsigned) world);
+    return EK_OK;
+}
+
+int ek_hip_dist_all_reduce(int type, int reduce_op, void *buf, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    const int t = nccl_type(type), op = nccl_op(reduce_op);
+    if (!buf || t < 0 || op < 0) return fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): bad arguments");
+    if (!g_comm) return g_world == 1 ? EK_OK : fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): ek_hip_dist_init has not been called");
+    if (int rc = g_rccl.all_reduce(buf, buf, n, t, op, g_comm, ctx().stream)) return nccl_fail(rc, "ncclAllReduce");
+    note_launch("dist_all_reduce", n, 2 * n * type_size(type));
+    return EK_OK;
+}
+
+int ek_hip_dist_reduce_scatter(int type, int reduce_op, void *recv, const void *send, size_t recv_count) {
+    if (int rc = ensure_init()) return rc;
+    const int t = nccl_type(type), op = nccl_op(reduce_op);
+    if (!recv || !send || t < 0 || op < 0) return fail(EK_ERR_INVALID, "ek_hip_dist_reduce_scatter(): bad arguments");
+    if (!g_comm) {
+        if (g_world != 1) return fail(EK_ERR_INVALID, "ek_hip_dist_reduce_scatter(): ek_hip_dist_init has not been called");
+        return recv == send ? EK_OK : ek_hip_memcpy_device(recv, send, recv_count * type_size(type));
+    }
+    if (int rc = g_rccl.reduce_scatter(send, recv, recv_count, t, op, g_comm, ctx().stream)) return nccl_fail(rc, "ncclReduceScatter");
+    note_launch("dist_reduce_scatter", recv_count * g_world, (size_t) (g_world + 1) * recv_count * type_size(type));
+    return EK_OK;
+}
+
+int ek_hip_dist_all_gather(int type, void *recv, const void *send, size_t send_count) {
+    if (int rc = ensure_init()) return rc;
+    const int t = nccl_type(type);
+    if (!recv || !send || t < 0) return fail(EK_ERR_INVALID, "ek_hip_dist_all_gather(): bad arguments");
+    if (!g_comm) {
+        if (g_world != 1) return fail(EK_ERR_INVALID, "ek_hip_dist_all_gather(): ek_hip_dist_init has not been called");
+        return recv == send ? EK_OK : ek_hip_memcpy_device(recv, send, send_count * type_size(type));
+    }
+    if (int rc = g_rccl.all_gather(send, recv, send_count, t, g_comm, ctx().stream)) return nccl_fail(rc, "ncclAllGather");
+    note_launch("dist_all_gather", send_count * g_world, (size_t) (g_world + 1) * send_count * type_size(type));
+    return EK_OK;
+}
+
+int ek_hip_dist_finalize(void) {
+    if (g_comm) {
+        (void) hipStreamSynchronize(ctx().stream);
+        g_rccl.comm_destroy(g_comm);
+        g_comm = nullptr;
+    }
+    g_rank = 0;
+    g_world = 1;
+    return EK_OK;
+}
+
+} // extern "C"

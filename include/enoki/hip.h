@@ -1590,6 +1590,29 @@ private:
 inline void hip_eval() { }
 inline void hip_sync() { detail::hip_check(ek_hip_sync(), "hip_sync"); }
 
+/// Sharding across the GPUs of a node from C++, one process per GPU (ek_hip_dist_*, include/enoki_hip.h: RCCL on the library
+/// stream).  `hip_dist_unique_id` on rank 0, ship the 128 bytes, `hip_dist_init` everywhere; arrays are index-range shards
+/// (`hip_dist_shard_range`), tables and scalars replicated, so vertical operations are local and only horizontal results
+/// (`hsum_all`, ...) and the gradients of replicated tables (`all_reduce_`) cross ranks.
+inline void hip_dist_unique_id(void *id128) { detail::hip_check(ek_hip_dist_unique_id(id128), "hip_dist_unique_id"); }
+inline void hip_dist_init(int rank, int world, const void *id128) { detail::hip_check(ek_hip_dist_init(rank, world, id128), "hip_dist_init"); }
+inline void hip_dist_finalize() { detail::hip_check(ek_hip_dist_finalize(), "hip_dist_finalize"); }
+inline std::pair<size_t, size_t> hip_dist_shard_range(size_t n, int rank, int world) {
+    size_t b = 0, e = 0;
+    detail::hip_check(ek_hip_dist_shard_range(n, rank, world, &b, &e), "hip_dist_shard_range");
+    return { b, e };
+}
+/// sum / product / min / max over all ranks, entry by entry (reduce_op: EK_HSUM ...): the replicated result
+template <typename T> HIPArray<T> all_reduce_(const HIPArray<T> &x, int reduce_op = EK_HSUM) {
+    HIPArray<T> r = x;
+    if (r.size() == 0) return r;
+    r.make_unique();
+    detail::hip_check(ek_hip_dist_all_reduce(HIPArray<T>::Type, reduce_op, r.data(), r.size()), "all_reduce_");
+    return r;
+}
+/// hsum over the shards of all ranks (local two-stage reduction, then a 1-element all-reduce)
+template <typename T> HIPArray<T> hsum_all(const HIPArray<T> &shard) { return all_reduce_(hsum(shard), EK_HSUM); }
+
 /// Step graphs (ek_hip_graph_*, include/enoki_hip.h).  Use these wrappers rather than the C entry points: arrays that are still
 /// unevaluated when a capture starts (deferred gathers / unary results) are evaluated first, so that none of them receives
 /// its storage from the graph's private pool.

@@ -299,6 +299,25 @@ EK_API int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, voi
  * {sin, cos}, {cos, sin}, {log, rcp} and {f, f} for f in neg abs sqrt rcp rsqrt sin cos exp log */
 EK_API int ek_hip_bucketed_early_pair(int map_op, int keep_op);
 EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
+/* ---- multi-GPU without python / torch (csrc/dist.cpp) -------------------------------------------------------------------------
+ * One process per GPU.  Index-range sharding: rank r owns [r n / P, (r + 1) n / P) of EVERY size-n array (ek_hip_dist_shard_range),
+ * so all vertical operations are local; size-1 arrays and gather tables are replicated.  The exchange steps -- a horizontal result,
+ * the gradient of a replicated table -- are RCCL collectives on the library stream, ordered with the kernels (no host wait):
+ *   rank 0: ek_hip_dist_unique_id(id);  ship the 128 bytes to the other ranks;  every rank: ek_hip_dist_init(rank, world, id)
+ *   y = hsum over all shards:   ek_hip_reduce(EK_HSUM, ...local shard...) then ek_hip_dist_all_reduce(type, EK_HSUM, y, 1)
+ *   table gradients:            ek_hip_dist_all_reduce(type, EK_HSUM, g, K), or ek_hip_dist_reduce_scatter (rank r receives bins
+ *                               [r c, (r + 1) c) of the sum; send holds world * c entries) + ek_hip_dist_all_gather when needed
+ * reduce_op: EK_HSUM | EK_HPROD | EK_HMIN | EK_HMAX.  world == 1 with a NULL id needs no RCCL at all (collectives are local).
+ * librccl.so is loaded on first use (no link-time dependency).  The reference has no counterpart; python callers use
+ * enoki_amd.dist (torch.distributed) for the same exchange. */
+EK_API int ek_hip_dist_unique_id(void *id128);
+EK_API int ek_hip_dist_init(int rank, int world, const void *id128);
+EK_API int ek_hip_dist_world(int *rank, int *world);
+EK_API int ek_hip_dist_shard_range(size_t n, int rank, int world, size_t *begin, size_t *end);
+EK_API int ek_hip_dist_all_reduce(int type, int reduce_op, void *buf, size_t n);
+EK_API int ek_hip_dist_reduce_scatter(int type, int reduce_op, void *recv, const void *send, size_t recv_count);
+EK_API int ek_hip_dist_all_gather(int type, void *recv, const void *send, size_t send_count);
+EK_API int ek_hip_dist_finalize(void);
 /* Partition of an INDEX array by bucket of the range it points into: the active entries (mask) of `index` are grouped by
  * bucket = index >> shift and stored as bucket-local indices (index & ((1 << shift) - 1)), bucket b at local[bucket_base[b] ..
  * bucket_base[b + 1]).  shift is the smallest of {12, 14, 17, 19} with <= 256 buckets for `range` entries (range <= 128 Mi).

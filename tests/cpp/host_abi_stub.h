@@ -285,6 +285,11 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int op, int map, void *out, int k
     return EK_OK;
 }
 static long g_fresh_targets = 0;
+int ek_hip_dist_unique_id(void *) { return EK_OK; }
+int ek_hip_dist_init(int, int, const void *) { return EK_OK; }
+int ek_hip_dist_finalize(void) { return EK_OK; }
+int ek_hip_dist_shard_range(size_t n, int rank, int world, size_t *b, size_t *e) { *b = n * rank / world; *e = n * (rank + 1) / world; return EK_OK; }
+int ek_hip_dist_all_reduce(int, int, void *, size_t) { return EK_OK; }
 int ek_hip_bucketed_early_pair(int map_op, int keep_op) {
     return (map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN) || (map_op == EK_LOG && keep_op == EK_RCP) ||
            map_op == keep_op;

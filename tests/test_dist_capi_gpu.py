@@ -1,0 +1,104 @@
+"""The C-ABI exchange step (ek_hip_dist_*, csrc/dist.cpp): RCCL on the library stream for callers without python / torch.
+One GPU: a world of one rank through a REAL communicator (ncclCommInitRank with nranks = 1) and through the RCCL-free path;
+two GPUs: two processes, the unique id shipped through a file (skipped on a 1-GPU box)."""
+import ctypes
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SZ = ctypes.c_size_t
+
+
+def test_shard_ranges_partition_every_length():
+    """CPU part: the index ranges of all ranks tile [0, n) exactly (the same partition for every size-n array)"""
+    from enoki_amd import capi
+    for n in (0, 1, 7, 1 << 20, (1 << 26) + 3):
+        for world in (1, 2, 3, 8):
+            edges = []
+            for r in range(world):
+                b, e = SZ(), SZ()
+                assert capi.lib.ek_hip_dist_shard_range(SZ(n), r, world, ctypes.byref(b), ctypes.byref(e)) == 0
+                edges.append((b.value, e.value))
+            assert edges[0][0] == 0 and edges[-1][1] == n and all(edges[i][1] == edges[i + 1][0] for i in range(world - 1))
+            assert max(e - b for b, e in edges) - min(e - b for b, e in edges) <= 1
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_rccl", [False, True])
+def test_world_of_one(with_rccl):
+    from enoki_amd import capi
+    capi.init()
+    lib = capi.lib
+    ident = (ctypes.c_char * 128)()
+    if with_rccl:
+        capi.check(lib.ek_hip_dist_unique_id(ident))
+    capi.check(lib.ek_hip_dist_init(0, 1, ident if with_rccl else None))
+    try:
+        a = np.arange(1000, dtype=np.float32)
+        buf = capi.Buf.from_numpy(a)
+        capi.check(lib.ek_hip_dist_all_reduce(buf.ek, 0, ctypes.c_void_p(buf.ptr), SZ(buf.n)))
+        out = capi.Buf(np.float32, 1000)
+        capi.check(lib.ek_hip_dist_reduce_scatter(buf.ek, 0, ctypes.c_void_p(out.ptr), ctypes.c_void_p(buf.ptr), SZ(1000)))
+        gathered = capi.Buf(np.float32, 1000)
+        capi.check(lib.ek_hip_dist_all_gather(buf.ek, ctypes.c_void_p(gathered.ptr), ctypes.c_void_p(out.ptr), SZ(1000)))
+        capi.sync()
+        assert np.array_equal(buf.numpy(), a) and np.array_equal(out.numpy(), a) and np.array_equal(gathered.numpy(), a)
+        r, w = ctypes.c_int(), ctypes.c_int()
+        lib.ek_hip_dist_world(ctypes.byref(r), ctypes.byref(w))
+        assert (r.value, w.value) == (0, 1)
+    finally:
+        capi.check(lib.ek_hip_dist_finalize())
+
+
+WORKER = r"""
+import ctypes, os, sys, time
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+rank, world, path = int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+os.environ["HIP_VISIBLE_DEVICES"] = str(rank)
+from enoki_amd import capi
+capi.init(); lib = capi.lib; SZ = ctypes.c_size_t
+ident = (ctypes.c_char * 128)()
+if rank == 0:
+    capi.check(lib.ek_hip_dist_unique_id(ident)); open(path + ".tmp", "wb").write(bytes(ident)); os.rename(path + ".tmp", path)
+else:
+    while not os.path.exists(path): time.sleep(0.05)
+    ident.raw = open(path, "rb").read()
+capi.check(lib.ek_hip_dist_init(rank, world, ident))
+K = 1 << 20
+g = capi.Buf.from_numpy(np.full(K, float(rank + 1), np.float32))
+capi.check(lib.ek_hip_dist_all_reduce(g.ek, 0, ctypes.c_void_p(g.ptr), SZ(K)))
+own = capi.Buf(np.float32, K // world)
+src = capi.Buf.from_numpy(np.arange(K, dtype=np.float32) * (rank + 1))
+capi.check(lib.ek_hip_dist_reduce_scatter(src.ek, 0, ctypes.c_void_p(own.ptr), ctypes.c_void_p(src.ptr), SZ(K // world)))
+capi.sync()
+tot = world * (world + 1) / 2
+assert np.all(g.numpy() == tot)
+c = K // world
+assert np.array_equal(own.numpy(), np.arange(rank * c, (rank + 1) * c, dtype=np.float32) * tot)
+capi.check(lib.ek_hip_dist_finalize())
+print("ok", rank)
+"""
+
+
+def _gpu_count():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_gpu_count() < 2, reason="needs two GPUs")
+def test_two_gpus_through_the_c_abi(tmp_path):
+    path = str(tmp_path / "rccl_id")
+    procs = [subprocess.Popen([sys.executable, "-c", WORKER, ROOT, str(r), "2", path], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+             for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    for p, (so, se) in zip(procs, outs):
+        assert p.returncode == 0 and "ok" in so, se[-2000:]
