@@ -454,6 +454,41 @@ __device__ __forceinline__ void lds_add_pair_one(unsigned long long *table, uint
     }
 }
 
+// The same update WITHOUT a branch: claim, add, release -- a lane that met a lock stores its (meaningless) sum to a dummy slot
+// and reports the update as still to be made.  A step's updates then form one basic block (the compiler overlaps an exchange's
+// round trip with the next element's arithmetic), and what met a lock is retried once per step, all slots in flight together
+// (lds_add_pair_retry).
+__device__ __forceinline__ bool lds_try_add_pair(unsigned long long *table, unsigned long long *dummy, uint32_t l, float v0, float v1) {
+    unsigned long long *p = table + l;
+    const unsigned long long old = atomicExch(p, kLockedPair);
+    const bool met = (unsigned) old == kLockedBits;
+    __hip_atomic_store(met ? dummy : p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return met;
+}
+
+// the slots of `pending` once more, their exchanges in flight together (the locks they met have been released long since); what
+// is locked even then -- hot bins, or two slots of one lane with the same bin -- goes one slot at a time with wave combining
+template <int N>
+__device__ __forceinline__ void lds_add_pair_retry(unsigned long long *table, const uint32_t (&l)[N], const float (&v0)[N],
+                                                   const float (&v1)[N], unsigned pending) {
+    unsigned long long old[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j)
+        if ((pending >> j) & 1u) old[j] = atomicExch(table + l[j], kLockedPair);
+#pragma unroll
+    for (int j = 0; j < N; ++j) {
+        if (((pending >> j) & 1u) && (unsigned) old[j] != kLockedBits) {
+            __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            pending &= ~(1u << j);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(pending != 0)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j)
+            if (__builtin_amdgcn_ballot_w64((pending >> j) & 1u)) lds_add_pair(table + l[j], v0[j], v1[j], (pending >> j) & 1u);
+    }
+}
+
 // N independent updates per lane: all N bins are CLAIMED first (N exchanges in flight -- one LDS round trip instead of N
 // dependent ones), then every claim that succeeded is added to and released; the few that met a lock (another lane's, or
 // this lane's own claim of the same bin in an earlier slot) are retried together, and what is still locked then goes through
@@ -718,6 +753,7 @@ struct EarlyBody {
     struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
     const PairRec<T> *rec;
     T *tables;
+    unsigned long long *dummy;
     const uint16_t *pair_idx;
     const T *x_b;
     int Bins;
@@ -750,24 +786,41 @@ struct EarlyBody {
         constexpr int NB = 4 * V;
         uint32_t l[NB];
         T v0[NB], v1[NB];
+        if constexpr (Paired) {
+            // f32: the step's table records first (four independent reads), then element by element: value and kept function,
+            // ONE claim -- add -- release without a branch (lds_try_add_pair), and what met a lock retried once per step, all
+            // slots in flight (lds_add_pair_retry).  A lock is held for one LDS round trip.  Measured on 64 Mi lookups into
+            // 1 Mi entries, same box, us per launch: 8 claims per lane in flight 199, 4: 165, 2: 149, one claim behind each
+            // element with its own retry round 143-147, this form 137-143; the next element's arithmetic pinned under the
+            // exchange's round trip (a longer hold) 147-149; sincos / exp in packed-fp32 instructions (v_pk_fma_f32: two
+            // passes on gfx950's SIMD-32) 150-153 against 147-150.  With the claims removed the kernel takes 100, with the
+            // arithmetic removed 124, with both 80-87 (profiles/probe_early_r04.txt).
+            unsigned long long *tb = reinterpret_cast<unsigned long long *>(tables);
+            PairRec<T> r[NB];
 #pragma unroll
-        for (int h = 0; h < V; ++h) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = h * 4 + j;
-                l[k] = (uint32_t) s.pi[h].v[j] & lmask;
-                T sum;
-                values(l[k], s.px[h][j], sum, v0[k], v1[k]);
-                acc[j] += sum;
-                if constexpr (Paired) {
-                    // One claim at a time, right behind its element (lds_add_pair_batch<1>: claim, add, release, batched
-                    // retry): the round trip runs in the shadow of the next element's sincos and of the other waves, and
-                    // a lock is held for the shortest possible time.  Measured on 64 Mi lookups into 1 Mi entries, same
-                    // box: 0.199 ms with 8 claims per lane in flight (the stand-alone adjoint's batches), 0.165 with 4,
-                    // 0.149 with 2, 0.146 with 1 after all four elements, 0.135 with 1 right behind each element.
-                    lds_add_pair_one(reinterpret_cast<unsigned long long *>(tables), l[k], v0[k], v1[k]);
-                }
+            for (int k = 0; k < NB; ++k) {
+                l[k] = (uint32_t) s.pi[k / 4].v[k % 4] & lmask;
+                r[k] = rec[l[k]];
             }
+            unsigned pending = 0;
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const T x = s.px[k / 4][k % 4];
+                T sum;
+                EarlyPair<Map, Keep, T>::apply(fma_t(r[k].a, x, r[k].c), sum, v0[k]);
+                v1[k] = dev::safe_mul(x, v0[k]);
+                acc[k % 4] += sum;
+                pending |= lds_try_add_pair(tb, dummy, l[k], v0[k], v1[k]) ? 1u << k : 0u;
+            }
+            if (__builtin_amdgcn_ballot_w64(pending != 0)) lds_add_pair_retry<NB>(tb, l, v0, v1, pending);
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < NB; ++k) {
+            l[k] = (uint32_t) s.pi[k / 4].v[k % 4] & lmask;
+            T sum;
+            values(l[k], s.px[k / 4][k % 4], sum, v0[k], v1[k]);
+            acc[k % 4] += sum;
         }
         if constexpr (!Paired) {
             lds_add_batch<T, NB>(tables, l, v0);
@@ -797,6 +850,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
     T *tables = reinterpret_cast<T *>(rec + Bins);          // f32: Bins {t0, t1} pairs under one lock;  f64: two tables
     __shared__ T wave_part[kBucketWaves];
+    __shared__ unsigned long long s_dummy;
     constexpr bool Paired = sizeof(T) == 4;
     int bucket;
     PieceRange range;
@@ -818,7 +872,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     T v = T(0);
     auto run = [&](auto body) {
         body.rec = rec; body.tables = tables; body.pair_idx = pair_idx; body.x_b = x_b; body.Bins = Bins;
-        body.lmask = (uint32_t) Bins - 1u;
+        body.lmask = (uint32_t) Bins - 1u; body.dummy = &s_dummy;
 #pragma unroll
         for (int k = 0; k < 4; ++k) body.acc[k] = T(0);
         walk_piece<PS, V>(bl, range, body);
@@ -1160,7 +1214,7 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
     Context &c = ctx();
     const size_t Bins = b->bins();
     const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
-    constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.199 ms against 0.166, same box)
+    constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.151 ms against 0.143, same box)
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
     const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
