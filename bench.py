@@ -59,6 +59,7 @@ DESCRIPTION = {
 CFG3B_VARIANTS = {
     "cfg3b_cos": dict(func="cos"), "cfg3b_exp": dict(func="exp"), "cfg3b_seed3": dict(seed=3.0), "cfg3b_masked": dict(masked=True),
     "cfg3b_i64": dict(idx64=True), "cfg3b_K2Mi": dict(K=1 << 21), "cfg3b_K4Mi": dict(K=1 << 22), "cfg3b_K16Mi": dict(K=1 << 24),
+    "cfg3b_sqrt": dict(func="sqrt", shift=3.0),          # (B + 3: u > 0; the derivative's factor .5 / sqrt(u) is a function of u)
 }
 for _w, _v in CFG3B_VARIANTS.items():
     DESCRIPTION[_w] = ("cfg3b with " + ", ".join(f"{k}={v}" for k, v in _v.items()) +
@@ -257,6 +258,8 @@ class Bench:
             var = CFG3B_VARIANTS.get(workload, {})
             kt = var.get("K", K_TABLE)
             A0 = synth.uniform_pm1(0, kt, 6); B0 = synth.uniform_pm1(0, kt, 7)
+            if var.get("shift"):
+                B0 = B0 + ekc.Float32(float(var["shift"]))
             idx = ek.UInt32(synth.index_mod(begin, n, 4, kt))
             if var.get("idx64"):
                 idx = ek.UInt64(idx)

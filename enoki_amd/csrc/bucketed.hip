@@ -833,6 +833,7 @@ struct EarlyBody {
 __host__ __device__ constexpr bool early_pair_supported(int map_op, int keep_op) {
     if ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN)) return true;
     if (map_op == EK_LOG && keep_op == EK_RCP) return true;
+    if (map_op == EK_SQRT && keep_op == EK_RSQRT) return true;
     return map_op == keep_op && (map_op == EK_SIN || map_op == EK_COS || map_op == EK_EXP || map_op == EK_SQRT || map_op == EK_RCP ||
                                  map_op == EK_RSQRT || map_op == EK_LOG || map_op == EK_ABS || map_op == EK_NEG);
 }
@@ -880,7 +881,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     };
 #define EK_EARLY_CASE(M, K) else if (map_op == M && keep_op == K) run(EarlyBody<T, V, M, K>{});
     if (map_op == EK_SIN && keep_op == EK_COS) run(EarlyBody<T, V, EK_SIN, EK_COS>{});
-    EK_EARLY_CASE(EK_COS, EK_SIN) EK_EARLY_CASE(EK_LOG, EK_RCP) EK_EARLY_CASE(EK_SIN, EK_SIN) EK_EARLY_CASE(EK_COS, EK_COS)
+    EK_EARLY_CASE(EK_COS, EK_SIN) EK_EARLY_CASE(EK_LOG, EK_RCP) EK_EARLY_CASE(EK_SQRT, EK_RSQRT) EK_EARLY_CASE(EK_SIN, EK_SIN) EK_EARLY_CASE(EK_COS, EK_COS)
     EK_EARLY_CASE(EK_EXP, EK_EXP) EK_EARLY_CASE(EK_SQRT, EK_SQRT) EK_EARLY_CASE(EK_RCP, EK_RCP) EK_EARLY_CASE(EK_RSQRT, EK_RSQRT)
     EK_EARLY_CASE(EK_LOG, EK_LOG) EK_EARLY_CASE(EK_ABS, EK_ABS) EK_EARLY_CASE(EK_NEG, EK_NEG)
 #undef EK_EARLY_CASE
@@ -1500,7 +1501,11 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
     const bool half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint && table_size <= (size_t) kMaxBuckets * (bins / 2);
     if (type == EK_F32) {
         const Arg<uint8_t> m{ mask, 1, mask ? 1u : 0u };
-        const bool want_half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint;
+        // half-size buckets (early adjoint) while the table needs at most two slices of them; beyond that the per-slice costs
+        // (a partition launch, table slices staged and folded per piece) weigh more than the second pass over the lists: full-size
+        // buckets halve the number of slices (K = 16 Mi, 64 Mi lookups, same box: 8 slices 53.8, 4 slices 57.0 Gelem/s)
+        const bool want_half = (hints & EK_BUCKETED_HINT_ADJOINT) && ctx().tuning.early_adjoint &&
+                               table_size <= (size_t) 2 * kMaxBuckets * (bins / 2);
         const size_t sel_bins = want_half ? bins / 2 : bins, span = (size_t) kMaxBuckets * sel_bins;
         if (table_size > span) {
             const int S = (int) ((table_size + span - 1) / span);

@@ -216,11 +216,11 @@ static __global__ __launch_bounds__(256) void k_bin_scan_buckets(uint32_t *__res
 
 // ---- 3. partition ----------------------------------------------------------------------------------
 // NoValues: partition of the INDICES alone (ek_hip_index_partition_*): no value stream is read, staged or written.
-#ifndef EK_BIN_PARTITION_WAVES
-#define EK_BIN_PARTITION_WAVES(C, Mapped) 4
-#endif
+// amdgpu_waves_per_eu(4) = 128 registers: two workgroups per CU.  The forms with two or three mapped value streams spill under
+// it (up to 68 registers, 148 B of scratch per lane) -- measured against a build that lets them have 155 registers (no scratch,
+// one workgroup per CU): 0.355 ms against 0.40-0.41 ms per 64 Mi elements, same box.  The spills stay.
 template <typename T, typename I, int Shift = kBinShift, typename OutIdx = uint16_t, int C = 1, bool Mapped = false, bool NoValues = false>
-__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(EK_BIN_PARTITION_WAVES(C, Mapped)))) void k_bin_partition(OutIdx *__restrict__ pair_idx, BinStreams<T, C> st,
+__global__ __launch_bounds__(kThreads) __attribute__((amdgpu_waves_per_eu(4))) void k_bin_partition(OutIdx *__restrict__ pair_idx, BinStreams<T, C> st,
                                                             const uint32_t *__restrict__ offsets,
                                                             const uint32_t *__restrict__ bucket_base,
                                                             const I *__restrict__ index, Arg<uint8_t> mask, size_t n,

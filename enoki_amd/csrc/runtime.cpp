@@ -215,6 +215,17 @@ int ek_hip_init(int device) {
     EK_HIP_CHECK(hipStreamCreateWithFlags(&c.stream, hipStreamNonBlocking));
     c.owns_stream = true;
     c.initialized = true;
+    // A process that returns from main() with kernels still in flight lets the HIP runtime tear its queues down underneath
+    // them (seen once as an abort in an HSA completion thread after a test binary had printed its last result).  Registered
+    // after the runtime's own exit handlers, so it runs before them; a stream the caller supplied is the caller's to drain.
+    static bool exit_hook = false;
+    if (!exit_hook) {
+        exit_hook = true;
+        atexit([]() {
+            Context &x = ctx();
+            if (x.initialized && x.owns_stream && x.stream) (void) hipStreamSynchronize(x.stream);
+        });
+    }
     if (const char *lv = getenv("ENOKI_HIP_LOG")) c.log_level = (uint32_t) atoi(lv);
     if (const char *dv = getenv("ENOKI_HIP_DETERMINISTIC")) c.tuning.deterministic = atoi(dv) != 0;
     if (const char *bo = getenv("ENOKI_HIP_BUCKET_ORDERED")) c.tuning.bucket_ordered = atoi(bo) != 0;

@@ -19,6 +19,7 @@
 #include <enoki/array.h>
 #include <enoki_hip.h>
 
+#include <cmath>
 #include <cstdlib>
 #include <initializer_list>
 #include <vector>
@@ -873,6 +874,34 @@ template <typename Value_> struct HIPArray : ArrayTag {
         }
         return r;
     }
+    /// c / sqrt(u) with sqrt(u) (this) an unevaluated map and c a power of two -- the weight `.5f / result` that d/du sqrt(u)
+    /// records (autodiff.h:353-364) -- as the unevaluated map c * rsqrt(u) of the same source: rsqrt is 1 / sqrt(u) with both
+    /// operations correctly rounded, and scaling by a power of two commutes with the rounding of the division (no result of
+    /// 1 / sqrt(u) is near the denormal range), so the bits are those of the eager division.  The derivative of sqrt then is
+    /// a function of u the bucket-ordered consumers can form themselves (early pair {sqrt, rsqrt}).
+    HIPArray rsqrt_of_sqrt_map_(Value numerator) const {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const auto *d = m_buf->deferred;
+            int exponent = 0;
+            if (!detail::hip_defer_gather_flag() || d->index_type != EK_SQRT || d->scaled || !(numerator == numerator) ||
+                numerator - numerator != Value(0) || numerator == Value(0))
+                return r;
+            const Value mant = std::frexp(numerator, &exponent);
+            if ((mant != Value(0.5) && mant != Value(-0.5)) || exponent < -32 || exponent > 32) return r;
+            detail::HIPBuffer *src = d->table;
+            auto *nd = new typename detail::HIPBuffer::Deferred{ src, nullptr, nullptr, Type, EK_RSQRT, sizeof(Value), false, 1, nullptr };
+            nd->scaled = numerator != Value(1);
+            nd->scale_bits = imm_bits(numerator);
+            src->ref_count++;
+            r.m_buf = new detail::HIPBuffer();
+            r.m_buf->size = m_buf->size;
+            r.m_buf->deferred = nd;
+            r.m_buf->pending_link();
+            src->readers.push_back(r.m_buf);
+        }
+        return r;
+    }
     Value map_scale_() const {
         Value v = Value(1);
         if constexpr (IsFloat) {
@@ -1496,6 +1525,9 @@ private:
                 if (m && c->m_imm != Value(0))
                     if (HIPArray r = m->scaled_map_(c->m_imm); r.valid()) return r;
             }
+            // a power of two over an unevaluated sqrt(u) is an unevaluated multiple of rsqrt(u) (the derivative's factor of sqrt)
+            if (op == EK_DIV && m_is_imm && b.mapped_())
+                if (HIPArray r = b.rsqrt_of_sqrt_map_(m_imm); r.valid()) return r;
         }
         size_t n = broadcast_size(size(), b.size());
         if ((op == EK_ADD || op == EK_SUB || op == EK_MUL) && (deferred_() || b.deferred_())) {

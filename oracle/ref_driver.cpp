@@ -481,8 +481,8 @@ float ref_cfg3b(const float *A_, const float *B_, size_t k, const float *x_, con
 }
 
 /* The neighbours of cfg3b that bench.py times next to it (round 4): y = seed * hsum(f(fmadd(gather(A, idx, mask), x,
-   gather(B, idx, mask)))) with f = sin (0) | cos (1) | exp (2) | log(.)^2-free: plain log (3), a 32- or 64-bit index array and an
-   optional mask; backward() of the scaled loss. */
+   gather(B, idx, mask)))) with f = sin (0) | cos (1) | exp (2) | log (3) | sqrt (4), a 32- or 64-bit index array and an optional
+   mask; backward() of the scaled loss. */
 float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float *x_, const void *idx_, int idx64,
                         const uint8_t *mask_, size_t n, int func, float seed, float *grad_A, float *grad_B, double *seconds) {
     FloatD::set_log_level_(0);
@@ -508,7 +508,7 @@ float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float 
         a = gather<FloatD>(A, idx, mask); b = gather<FloatD>(B, idx, mask);
     }
     FloatD u = fmadd(a, x, b);
-    FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : log(u));
+    FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : func == 3 ? log(u) : sqrt(u));
     FloatD z = seed == 1.f ? y : y * seed;
     backward(z);
     if (seconds) *seconds = now() - t0;

@@ -177,7 +177,7 @@ def cfg3b_truth(A, B, x, idx):
 
 
 def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
-    """cfg3b_truth for the neighbours that bench.py times next to the headline: y = seed * hsum(f(u)), f = sin | cos | exp,
+    """cfg3b_truth for the neighbours that bench.py times next to the headline: y = seed * hsum(f(u)), f = sin | cos | exp | log | sqrt,
     masked-out lanes gather 0 (u = 0, no gradient).  Same class-D bounds, scaled by |seed| and by the size of f and f'."""
     eps = 2.0 ** -24
     K, n = A.size, x.size
@@ -185,7 +185,11 @@ def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
     on = np.ones(n, bool) if mask is None else np.asarray(mask, bool)
     x64 = x.astype(np.float64)
     u = np.where(on, A.astype(np.float64)[ii] * x64 + B.astype(np.float64)[ii], 0.0)
-    f, df = {"sin": (np.sin, np.cos), "cos": (np.cos, lambda v: -np.sin(v)), "exp": (np.exp, np.exp)}[func]
+    with np.errstate(all="ignore"):         # (log / sqrt want positive u: the tests that use them shift the addend table)
+        safe = np.where(on, u, 1.0)
+    f, df = {"sin": (np.sin, np.cos), "cos": (np.cos, lambda v: -np.sin(v)), "exp": (np.exp, np.exp),
+             "log": (lambda v: np.where(on, np.log(safe), 0.0), lambda v: np.where(on, 1.0 / safe, 0.0)),
+             "sqrt": (lambda v: np.where(on, np.sqrt(safe), 0.0), lambda v: np.where(on, 0.5 / np.sqrt(safe), 0.0))}[func]
     s, c = f(u) * seed, df(u) * seed
     big = max(1.0, float(np.abs(s).max()), float(np.abs(c).max()))          # |f|, |f'| <= e^2 for exp on |u| <= 2
     cnt = np.bincount(ii[on], minlength=K)

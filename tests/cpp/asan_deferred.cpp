@@ -328,7 +328,7 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
         static const int maps[] = { EK_NEG, EK_ABS, EK_SIN, EK_COS, EK_EXP };
         auto pick = [&]() -> F & { return pool[rng() % pool.size()]; };
         for (int step = 0; step < 60; ++step) {
-            const int what = rng() % 13;
+            const int what = rng() % 14;
             if (getenv("TRACE")) fprintf(stderr, "seed %u step %d op %d\n", seed, step, what);
             switch (what) {
                 case 0: {   // unary map
@@ -373,6 +373,17 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
                     break;
                 }
                 case 10: { pick() = pick(); break; }                     // handle copy
+                case 13: {  // sqrt and its derivative's factor .5 / sqrt(v): an unevaluated multiple of rsqrt(v) when deferred
+                    F v = abs(pick()) + F(1.f);
+                    F r = sqrt(v);
+                    F w = F(0.5f) / r, w2 = F(3.f) / r;                  // (3 is no power of two: an ordinary division)
+                    seen.push_back({ hsum(r).coeff(0), hsum(w).coeff(0) });
+                    seen.push_back(host(w));
+                    seen.push_back(host(w2));
+                    if (rng() & 1) pick() = w * F(2.f);
+                    if (rng() & 1) pick() = r;
+                    break;
+                }
                 case 11: {  // adjoint-style multi scatter with (possibly) mapped values
                     F v = cos(pick());
                     F ta = zero<F>(K), tb = zero<F>(K);

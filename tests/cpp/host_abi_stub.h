@@ -292,7 +292,7 @@ int ek_hip_dist_shard_range(size_t n, int rank, int world, size_t *b, size_t *e)
 int ek_hip_dist_all_reduce(int, int, void *, size_t) { return EK_OK; }
 int ek_hip_bucketed_early_pair(int map_op, int keep_op) {
     return (map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN) || (map_op == EK_LOG && keep_op == EK_RCP) ||
-           map_op == keep_op;
+           (map_op == EK_SQRT && keep_op == EK_RSQRT) || map_op == keep_op;
 }
 int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
                                        const uint64_t *imm, const int *weighted, const int *fresh, const uint64_t *scale) {

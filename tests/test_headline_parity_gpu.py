@@ -116,7 +116,7 @@ def test_cfg4_headline_image_bit_exact():
 
 
 NEIGHBOURS = {"cos": dict(func="cos"), "exp": dict(func="exp"), "seed3": dict(seed=3.0), "masked": dict(masked=True),
-              "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22)}
+              "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22), "sqrt": dict(func="sqrt", shift=3.0)}
 
 
 @pytest.mark.parametrize("name", list(NEIGHBOURS))
@@ -130,6 +130,7 @@ def test_cfg3b_neighbours_at_the_headline_size(ek, checker, name):
     Kt = kw.pop("K", K)
     masked, idx64 = kw.pop("masked", False), kw.pop("idx64", False)
     A, B, x = uniform_pm1(Kt, 6), uniform_pm1(Kt, 7), uniform_pm1(N, 2)
+    B = (B + np.float32(kw.pop("shift", 0.0))).astype(np.float32)          # (sqrt: u = a x + b > 0)
     idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(Kt)).astype(np.uint32)
     mask = ((hash_u32(np.arange(N, dtype=np.uint64), 5) & 3) != 0) if masked else None
     dA, dB = ek.Float32(A), ek.Float32(B)

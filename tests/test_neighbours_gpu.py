@@ -69,9 +69,13 @@ CASES = {
     "masked": dict(masked=True),
     "i64": dict(idx64=True),
     "masked_exp_i64_seed": dict(func="exp", masked=True, idx64=True, seed=2.0),
+    # u > 0 (the addend table shifted by 3): the derivative's factor is another function of u -- rcp(u) next to log(u), and
+    # .5 / sqrt(u) = .5 rsqrt(u) next to sqrt(u) (autodiff.h:353-364) -- which the forward pass sums per table entry
+    "log": dict(func="log", shift=3.0),
+    "sqrt": dict(func="sqrt", shift=3.0),
 }
 # what the step may launch when it stays in bucket order: ONE partition in the forward pass, the adjoint formed there as well
-EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed"}
+EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt"}
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -80,6 +84,7 @@ def test_neighbour_matches_the_reference_and_stays_in_bucket_order(ad, ref, data
     kw = dict(CASES[name])
     m = mask if kw.pop("masked", False) else None
     idx64 = kw.pop("idx64", False)
+    B = (B + np.float32(kw.pop("shift", 0.0))).astype(np.float32)
     (y, gA, gB), ks = kernels(ad, lambda: run(ad, A, B, x, idx, mask=m, idx64=idx64, **kw))
     t = cfg3b_variant_truth(A, B, x, idx, mask=m, **kw)
     ry, rgA, rgB, _ = ref.cfg3b_variant(A, B, x, idx.astype(np.uint64) if idx64 else idx, mask=m, **kw)
