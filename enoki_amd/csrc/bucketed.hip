@@ -34,6 +34,36 @@ namespace ek {
 
 template <typename T> struct alignas(2 * sizeof(T)) PairRec { T a, c; };
 
+// The bucket's slice of both tables as interleaved {a, c} records in the LDS (every element then costs ONE ds_read_b64; b128 for
+// doubles), and -- ZeroTables -- the two gradient tables behind them cleared.  A thread requests all of its entries before it
+// uses the first: the loop used to wait for each pair of loads (Bins / 1024 = 8 or 16 dependent round trips per piece, 6-10 us
+// of every launch).  Entries beyond the table read its last entry and count as zero.
+template <typename T, bool ZeroTables>
+__device__ __forceinline__ void stage_pair_slice(PairRec<T> *rec, T *tables, const T *__restrict__ table_a, const T *__restrict__ table_c,
+                                                 size_t first, size_t table_size, int Bins, int flip_a, int flip_c) {
+    constexpr int U = 8;
+    const size_t last = table_size - 1;
+    for (int j0 = threadIdx.x; j0 < Bins; j0 += U * (int) blockDim.x) {
+        T a[U], c[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const size_t k = first + (size_t) (j0 + u * (int) blockDim.x);
+            const size_t kc = k < last ? k : last;
+            a[u] = table_a[kc];
+            c[u] = table_c[kc];
+            if (k > last) { a[u] = T(0); c[u] = T(0); }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int j = j0 + u * (int) blockDim.x;
+            if (j < Bins) {
+                rec[j] = PairRec<T>{ flip_a ? -a[u] : a[u], flip_c ? -c[u] : c[u] };
+                if constexpr (ZeroTables) { tables[2 * j] = T(0); tables[2 * j + 1] = T(0); }
+            }
+        }
+    }
+}
+
 constexpr int kBucketThreads = 1024;        // one workgroup per CU: the {A, C} slice / two gradient tables fill 128 KiB of LDS
 constexpr int kBucketWaves = kBucketThreads / 64;
 enum { EK_REDUCE_NONE = EK_REDUCE_COUNT };   // forward kernel without a reduction: only keeps u in bucket order
@@ -295,15 +325,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
         return;
     }
     if constexpr (!FromKept) {
-        // the bucket's slice of both tables, interleaved: every element then costs ONE ds_read_b64 (b128 for doubles)
-        const size_t first = (size_t) bucket * Bins;
-        for (int j = threadIdx.x; j < Bins; j += kBucketThreads) {
-            const size_t k = first + j;
-            T a = k < table_size ? table_a[k] : T(0), c = k < table_size ? table_c[k] : T(0);
-            if (flip_a) a = -a;
-            if (flip_c) c = -c;
-            rec[j] = PairRec<T>{ a, c };
-        }
+        stage_pair_slice<T, false>(rec, nullptr, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
         __syncthreads();
     }
 
@@ -859,16 +881,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         if (threadIdx.x == 0) partials[blockIdx.x] = T(0);
         return;
     }
-    const size_t first = (size_t) bucket * Bins;
-    for (int j = threadIdx.x; j < Bins; j += kBucketThreads) {
-        const size_t k = first + j;
-        T a = k < table_size ? table_a[k] : T(0), c = k < table_size ? table_c[k] : T(0);
-        if (flip_a) a = -a;
-        if (flip_c) c = -c;
-        rec[j] = PairRec<T>{ a, c };
-        tables[2 * j] = T(0);
-        tables[2 * j + 1] = T(0);
-    }
+    stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
     __syncthreads();
     T v = T(0);
     auto run = [&](auto body) {
