@@ -1,6 +1,8 @@
-"""Bucket-ordered gather -> fma -> {reduction, scatter_add} (ek_hip_bucketed_*, csrc/bucketed.hip) through the C ABI.
+"""Bucket-ordered gather -> fma -> {reduction, scatter_add} (ek_hip_bucketed_*, csrc/bucketed.hip) through the C ABI, checked against
+the library's OWN element-order kernels and float64 numpy -- not against oracle/ directly (the whole step is compared with the
+reference build at 64 Mi elements in test_headline_parity_gpu.py, test_neighbours_gpu.py and inside bench.py).
 
-Oracle: the element-order kernels of the same library give u = fma(A[idx], x, C[idx]) bit for bit (class A, pinned against
+Yardstick: the element-order kernels of the same library give u = fma(A[idx], x, C[idx]) bit for bit (class A, pinned against
 the reference build in test_gathered_gpu.py / test_kernels_gpu.py); the bucket-ordered path must
   * reduce exactly the multiset { map(u_i) } -- checked against the float64 sum of the f32 terms with the class-D bound of
     OUR summation depth, and a statistical sqrt(n) bound ten times tighter than the worst case,
