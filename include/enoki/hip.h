@@ -858,8 +858,13 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if (d->scaled) {
                 Value old;
                 memcpy(&old, &d->scale_bits, sizeof(Value));
-                if (old != Value(1) && old != Value(-1) && factor != Value(1) && factor != Value(-1)) return r;
-                scale = old * factor;                 // exact: one of the two is +-1
+                // (c1 f) c2 == f (c1 c2) bit for bit when one of the factors is +-1 -- or, for rsqrt (whose values stay
+                // clear of the denormal range), when the first one is a power of two: the .5 rsqrt(u) that d/du sqrt(u) records
+                // times the seed of backward(c y)
+                int e2 = 0;
+                const bool pow2 = d->index_type == EK_RSQRT && std::fabs(std::frexp(old, &e2)) == Value(0.5) && e2 >= -32 && e2 <= 32;
+                if (old != Value(1) && old != Value(-1) && factor != Value(1) && factor != Value(-1) && !pow2) return r;
+                scale = old * factor;                 // exact
             }
             detail::HIPBuffer *src = d->table;
             auto *nd = new typename detail::HIPBuffer::Deferred{ src, nullptr, nullptr, Type, d->index_type, sizeof(Value), false, 1, nullptr };

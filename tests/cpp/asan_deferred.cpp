@@ -381,6 +381,7 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
                     seen.push_back(host(w));
                     seen.push_back(host(w2));
                     if (rng() & 1) pick() = w * F(2.f);
+                    if (rng() & 1) seen.push_back(host(w * F(3.f)));          // .5 rsqrt times a seed: still a map (1.5 rsqrt)
                     if (rng() & 1) pick() = r;
                     break;
                 }

@@ -73,9 +73,10 @@ CASES = {
     # .5 / sqrt(u) = .5 rsqrt(u) next to sqrt(u) (autodiff.h:353-364) -- which the forward pass sums per table entry
     "log": dict(func="log", shift=3.0),
     "sqrt": dict(func="sqrt", shift=3.0),
+    "sqrt_seed3": dict(func="sqrt", shift=3.0, seed=3.0),
 }
 # what the step may launch when it stays in bucket order: ONE partition in the forward pass, the adjoint formed there as well
-EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt"}
+EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt", "sqrt_seed3"}
 
 
 @pytest.mark.parametrize("name", list(CASES))
