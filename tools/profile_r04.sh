@@ -29,3 +29,16 @@ for w in cfg4_bucketed cfg5; do
   python tools/rocprof_summary.py pmc /tmp/prof_fetch_$w /tmp/prof_write_$w > gpurun_out/rocprof_pmc_${w}_r04.txt
 done
 head -14 gpurun_out/rocprof_kernel_stats_r04.txt
+# the two bandwidth-bound reference points (BASELINE configs[1] and the leaf-only tape): kernel trace + HBM traffic
+cd /tmp
+for w in cfg3a cfg2; do
+  W="python $R/bench.py --workload $w --no-cpu-baseline --no-also --steps 5 --warmup 2 --profile-steps 2"
+  timeout 200 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt_$w -- $W > /tmp/kt_$w.log 2>&1
+  timeout 200 rocprofv3 --pmc FETCH_SIZE -d /tmp/prof_fetch_$w -- $W > /tmp/f_$w.log 2>&1
+  timeout 200 rocprofv3 --pmc WRITE_SIZE -d /tmp/prof_write_$w -- $W > /tmp/w_$w.log 2>&1
+done
+cd $R
+for w in cfg3a cfg2; do
+  python tools/rocprof_summary.py kernels /tmp/prof_kt_$w > gpurun_out/rocprof_kernel_stats_${w}_r04.txt
+  python tools/rocprof_summary.py pmc /tmp/prof_fetch_$w /tmp/prof_write_$w > gpurun_out/rocprof_pmc_${w}_r04.txt
+done
