@@ -24,7 +24,8 @@ EK2NP = {BOOL: np.uint8, I32: np.int32, U32: np.uint32, I64: np.int64, U64: np.u
 UNARY = {n: i for i, n in enumerate(
     ["neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
      "popcnt", "lzcnt", "tzcnt", "sign", "copy", "tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh",
-     "acosh", "atanh", "cbrt", "erf", "erfc", "erfinv", "i0e", "dawson", "erfi", "lgamma", "tgamma"])}
+     "acosh", "atanh", "cbrt", "erf", "erfc", "erfinv", "i0e", "dawson", "erfi", "lgamma", "tgamma", "rcp_sqr", "rsqrt_sqr",
+     "rsqrt_cube"])}
 BINARY = {n: i for i, n in enumerate(
     ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
      "atan2", "pow", "fmod", "ldexp"])}

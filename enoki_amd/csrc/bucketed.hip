@@ -348,6 +348,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
         switch (map_op) {
             EK_FWD_CASE(EK_NEG) EK_FWD_CASE(EK_ABS) EK_FWD_CASE(EK_SQRT) EK_FWD_CASE(EK_RCP) EK_FWD_CASE(EK_RSQRT)
             EK_FWD_CASE(EK_SIN) EK_FWD_CASE(EK_COS) EK_FWD_CASE(EK_EXP) EK_FWD_CASE(EK_LOG)
+            EK_FWD_CASE(EK_RCP_SQR) EK_FWD_CASE(EK_RSQRT_SQR) EK_FWD_CASE(EK_RSQRT_CUBE)
             default: run(ForwardBody<T, ROp, V, EK_COPY, false, FromKept>{}); break;
         }
     }
@@ -718,6 +719,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
             switch (op) {
                 EK_ACC_SPEC(EK_NEG) EK_ACC_SPEC(EK_ABS) EK_ACC_SPEC(EK_SQRT) EK_ACC_SPEC(EK_RCP) EK_ACC_SPEC(EK_RSQRT)
                 EK_ACC_SPEC(EK_SIN) EK_ACC_SPEC(EK_COS) EK_ACC_SPEC(EK_EXP) EK_ACC_SPEC(EK_LOG)
+                EK_ACC_SPEC(EK_RCP_SQR) EK_ACC_SPEC(EK_RSQRT_CUBE)
                 default: run(AccumulateBody<T, C, V, EK_COPY, 1>{}, true); break;
             }
         }
@@ -728,6 +730,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
         switch (op) {
             EK_ACC_CASE(EK_NEG) EK_ACC_CASE(EK_ABS) EK_ACC_CASE(EK_SQRT) EK_ACC_CASE(EK_RCP) EK_ACC_CASE(EK_RSQRT)
             EK_ACC_CASE(EK_SIN) EK_ACC_CASE(EK_COS) EK_ACC_CASE(EK_EXP) EK_ACC_CASE(EK_LOG)
+            EK_ACC_CASE(EK_RCP_SQR) EK_ACC_CASE(EK_RSQRT_CUBE)
             default: run(AccumulateBody<T, C, V, EK_COPY, 0>{}, false); break;
         }
     } else {
@@ -856,6 +859,8 @@ __host__ __device__ constexpr bool early_pair_supported(int map_op, int keep_op)
     if ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN)) return true;
     if (map_op == EK_LOG && keep_op == EK_RCP) return true;
     if (map_op == EK_SQRT && keep_op == EK_RSQRT) return true;
+    if (map_op == EK_RCP && keep_op == EK_RCP_SQR) return true;
+    if (map_op == EK_RSQRT && keep_op == EK_RSQRT_CUBE) return true;
     return map_op == keep_op && (map_op == EK_SIN || map_op == EK_COS || map_op == EK_EXP || map_op == EK_SQRT || map_op == EK_RCP ||
                                  map_op == EK_RSQRT || map_op == EK_LOG || map_op == EK_ABS || map_op == EK_NEG);
 }
@@ -894,7 +899,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     };
 #define EK_EARLY_CASE(M, K) else if (map_op == M && keep_op == K) run(EarlyBody<T, V, M, K>{});
     if (map_op == EK_SIN && keep_op == EK_COS) run(EarlyBody<T, V, EK_SIN, EK_COS>{});
-    EK_EARLY_CASE(EK_COS, EK_SIN) EK_EARLY_CASE(EK_LOG, EK_RCP) EK_EARLY_CASE(EK_SQRT, EK_RSQRT) EK_EARLY_CASE(EK_SIN, EK_SIN) EK_EARLY_CASE(EK_COS, EK_COS)
+    EK_EARLY_CASE(EK_COS, EK_SIN) EK_EARLY_CASE(EK_LOG, EK_RCP) EK_EARLY_CASE(EK_SQRT, EK_RSQRT) EK_EARLY_CASE(EK_RCP, EK_RCP_SQR)
+    EK_EARLY_CASE(EK_RSQRT, EK_RSQRT_CUBE) EK_EARLY_CASE(EK_SIN, EK_SIN) EK_EARLY_CASE(EK_COS, EK_COS)
     EK_EARLY_CASE(EK_EXP, EK_EXP) EK_EARLY_CASE(EK_SQRT, EK_SQRT) EK_EARLY_CASE(EK_RCP, EK_RCP) EK_EARLY_CASE(EK_RSQRT, EK_RSQRT)
     EK_EARLY_CASE(EK_LOG, EK_LOG) EK_EARLY_CASE(EK_ABS, EK_ABS) EK_EARLY_CASE(EK_NEG, EK_NEG)
 #undef EK_EARLY_CASE

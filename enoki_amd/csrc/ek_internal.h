@@ -159,6 +159,7 @@ int refuse_while_capturing(const char *what);
 constexpr inline bool unary_fusable(int op) {
     switch (op) {
         case EK_NEG: case EK_ABS: case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
+        case EK_RCP_SQR: case EK_RSQRT_SQR: case EK_RSQRT_CUBE:
             return true;
         default: return false;
     }

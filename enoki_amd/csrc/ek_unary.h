@@ -33,7 +33,7 @@ template <int Op, typename T> constexpr bool unary_supported() {
         case EK_NEG: case EK_ABS: return !is_mask<T>;
         case EK_NOT: return !is_fp<T>;
         case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_FLOOR: case EK_CEIL: case EK_ROUND: case EK_TRUNC:
-        case EK_SIGN: return is_fp<T>;
+        case EK_SIGN: case EK_RCP_SQR: case EK_RSQRT_SQR: case EK_RSQRT_CUBE: return is_fp<T>;
         case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
         case EK_TAN: case EK_COT: case EK_ASIN: case EK_ACOS: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_TANH:
         case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return is_fp<T>;
@@ -67,6 +67,14 @@ template <int Op, typename T> struct UnaryOp {
             return T(1) / x;
         } else if constexpr (Op == EK_RSQRT) {
             if constexpr (sizeof(T) == 4) return 1.0f / __builtin_sqrtf(x); else return 1.0 / __builtin_sqrt(x);
+        } else if constexpr (Op == EK_RCP_SQR) {
+            const T r = T(1) / x;
+            return r * r;
+        } else if constexpr (Op == EK_RSQRT_SQR || Op == EK_RSQRT_CUBE) {
+            T r;
+            if constexpr (sizeof(T) == 4) r = 1.0f / __builtin_sqrtf(x); else r = 1.0 / __builtin_sqrt(x);
+            const T r2 = r * r;
+            if constexpr (Op == EK_RSQRT_SQR) return r2; else return r * r2;
         } else if constexpr (Op == EK_FLOOR) {
             if constexpr (sizeof(T) == 4) return __builtin_floorf(x); else return __builtin_floor(x);
         } else if constexpr (Op == EK_CEIL) {
@@ -159,6 +167,9 @@ template <typename T> __device__ __forceinline__ T unary_fused(int op, T x) {
         case EK_COS: return UnaryOp<EK_COS, T>::apply(x);
         case EK_EXP: return UnaryOp<EK_EXP, T>::apply(x);
         case EK_LOG: return UnaryOp<EK_LOG, T>::apply(x);
+        case EK_RCP_SQR: return UnaryOp<EK_RCP_SQR, T>::apply(x);
+        case EK_RSQRT_SQR: return UnaryOp<EK_RSQRT_SQR, T>::apply(x);
+        case EK_RSQRT_CUBE: return UnaryOp<EK_RSQRT_CUBE, T>::apply(x);
         default: return x;
     }
 }

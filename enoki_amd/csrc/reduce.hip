@@ -226,6 +226,9 @@ template <int Op, typename T> int reduce_map_select(int map, void *out, const vo
         case EK_COS: return reduce_map_typed<Op, EK_COS, T>(out, in, n);
         case EK_EXP: return reduce_map_typed<Op, EK_EXP, T>(out, in, n);
         case EK_LOG: return reduce_map_typed<Op, EK_LOG, T>(out, in, n);
+        case EK_RCP_SQR: return reduce_map_typed<Op, EK_RCP_SQR, T>(out, in, n);
+        case EK_RSQRT_SQR: return reduce_map_typed<Op, EK_RSQRT_SQR, T>(out, in, n);
+        case EK_RSQRT_CUBE: return reduce_map_typed<Op, EK_RSQRT_CUBE, T>(out, in, n);
         default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): op %d cannot be applied on load", map);
     }
 }

@@ -825,7 +825,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
     static constexpr size_t defer_map_min_size_ = (size_t) 1 << 16;
     static constexpr bool map_fusable_(int op) {
         return op == EK_NEG || op == EK_ABS || op == EK_SQRT || op == EK_RCP || op == EK_RSQRT || op == EK_SIN ||
-               op == EK_COS || op == EK_EXP || op == EK_LOG;
+               op == EK_COS || op == EK_EXP || op == EK_LOG || op == EK_RCP_SQR || op == EK_RSQRT_SQR || op == EK_RSQRT_CUBE;
     }
     bool can_defer_map_() const {
         const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_map_min_size_;
@@ -901,6 +901,33 @@ template <typename Value_> struct HIPArray : ArrayTag {
             src->ref_count++;
             r.m_buf = new detail::HIPBuffer();
             r.m_buf->size = m_buf->size;
+            r.m_buf->deferred = nd;
+            r.m_buf->pending_link();
+            src->readers.push_back(r.m_buf);
+        }
+        return r;
+    }
+    /// The products that the derivatives of rcp and rsqrt are made of (autodiff.h:381-403: -sqr(result), -.5 result sqr(result)),
+    /// taken of UNEVALUATED maps of one source: rcp(u) rcp(u), rsqrt(u) rsqrt(u), rsqrt(u) (rsqrt(u) rsqrt(u)) stay unevaluated as
+    /// ONE map of u each (EK_RCP_SQR, EK_RSQRT_SQR, EK_RSQRT_CUBE: the same roundings as the eager products), so that the
+    /// weight remains a function of u the bucket-ordered consumers can form themselves.  Invalid array: not such a product.
+    static HIPArray product_of_maps_(const HIPArray &a, const HIPArray &b) {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            if (!detail::hip_defer_gather_flag() || !a.mapped_() || !b.mapped_()) return r;
+            const auto *da = a.m_buf->deferred, *db = b.m_buf->deferred;
+            if (da->table != db->table || da->scaled || db->scaled) return r;
+            const int oa = da->index_type, ob = db->index_type;
+            int op = -1;
+            if (a.m_buf == b.m_buf && oa == EK_RCP) op = EK_RCP_SQR;
+            else if (a.m_buf == b.m_buf && oa == EK_RSQRT) op = EK_RSQRT_SQR;
+            else if ((oa == EK_RSQRT && ob == EK_RSQRT_SQR) || (oa == EK_RSQRT_SQR && ob == EK_RSQRT)) op = EK_RSQRT_CUBE;
+            if (op < 0) return r;
+            detail::HIPBuffer *src = da->table;
+            auto *nd = new typename detail::HIPBuffer::Deferred{ src, nullptr, nullptr, Type, op, sizeof(Value), false, 1, nullptr };
+            src->ref_count++;
+            r.m_buf = new detail::HIPBuffer();
+            r.m_buf->size = a.m_buf->size;
             r.m_buf->deferred = nd;
             r.m_buf->pending_link();
             src->readers.push_back(r.m_buf);
@@ -1530,6 +1557,8 @@ private:
                 if (m && c->m_imm != Value(0))
                     if (HIPArray r = m->scaled_map_(c->m_imm); r.valid()) return r;
             }
+            if (op == EK_MUL && mapped_() && b.mapped_())
+                if (HIPArray r = product_of_maps_(*this, b); r.valid()) return r;
             // a power of two over an unevaluated sqrt(u) is an unevaluated multiple of rsqrt(u) (the derivative's factor of sqrt)
             if (op == EK_DIV && m_is_imm && b.mapped_())
                 if (HIPArray r = b.rsqrt_of_sqrt_map_(m_imm); r.valid()) return r;

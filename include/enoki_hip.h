@@ -59,6 +59,10 @@ typedef enum {
     EK_TAN, EK_COT, EK_ASIN, EK_ACOS, EK_ATAN, EK_SINH, EK_COSH, EK_TANH, EK_ASINH, EK_ACOSH, EK_ATANH,
     EK_CBRT,
     EK_ERF, EK_ERFC, EK_ERFINV, EK_I0E, EK_DAWSON, EK_ERFI, EK_LGAMMA, EK_TGAMMA,   /* special.h:56-312, f32 and f64 */
+    /* what the derivatives of rcp and rsqrt are made of, as ONE function of the argument each (autodiff.h:381-403: -sqr(result),
+     * -.5 result^3 with result = rcp(x) / rsqrt(x)): r r with r = 1 / x;  r r and r (r r) with r = 1 / sqrt(x) -- the roundings of
+     * the eager products, so that a consumer which applies an op while it loads can form them from x */
+    EK_RCP_SQR, EK_RSQRT_SQR, EK_RSQRT_CUBE,
     EK_UNARY_COUNT
 } ek_unary_op;
 

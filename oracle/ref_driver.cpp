@@ -481,7 +481,7 @@ float ref_cfg3b(const float *A_, const float *B_, size_t k, const float *x_, con
 }
 
 /* The neighbours of cfg3b that bench.py times next to it (round 4): y = seed * hsum(f(fmadd(gather(A, idx, mask), x,
-   gather(B, idx, mask)))) with f = sin (0) | cos (1) | exp (2) | log (3) | sqrt (4), a 32- or 64-bit index array and an optional
+   gather(B, idx, mask)))) with f = sin (0) | cos (1) | exp (2) | log (3) | sqrt (4) | rcp (5) | rsqrt (6), a 32- or 64-bit index array and an optional
    mask; backward() of the scaled loss. */
 float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float *x_, const void *idx_, int idx64,
                         const uint8_t *mask_, size_t n, int func, float seed, float *grad_A, float *grad_B, double *seconds) {
@@ -508,7 +508,7 @@ float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float 
         a = gather<FloatD>(A, idx, mask); b = gather<FloatD>(B, idx, mask);
     }
     FloatD u = fmadd(a, x, b);
-    FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : func == 3 ? log(u) : sqrt(u));
+    FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : func == 3 ? log(u) : func == 4 ? sqrt(u) : func == 5 ? rcp(u) : rsqrt(u));
     FloatD z = seed == 1.f ? y : y * seed;
     backward(z);
     if (seconds) *seconds = now() - t0;

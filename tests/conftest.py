@@ -189,7 +189,9 @@ def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
         safe = np.where(on, u, 1.0)
     f, df = {"sin": (np.sin, np.cos), "cos": (np.cos, lambda v: -np.sin(v)), "exp": (np.exp, np.exp),
              "log": (lambda v: np.where(on, np.log(safe), 0.0), lambda v: np.where(on, 1.0 / safe, 0.0)),
-             "sqrt": (lambda v: np.where(on, np.sqrt(safe), 0.0), lambda v: np.where(on, 0.5 / np.sqrt(safe), 0.0))}[func]
+             "sqrt": (lambda v: np.where(on, np.sqrt(safe), 0.0), lambda v: np.where(on, 0.5 / np.sqrt(safe), 0.0)),
+             "rcp": (lambda v: np.where(on, 1.0 / safe, 0.0), lambda v: np.where(on, -1.0 / (safe * safe), 0.0)),
+             "rsqrt": (lambda v: np.where(on, safe ** -0.5, 0.0), lambda v: np.where(on, -0.5 * safe ** -1.5, 0.0))}[func]
     s, c = f(u) * seed, df(u) * seed
     big = max(1.0, float(np.abs(s).max()), float(np.abs(c).max()))          # |f|, |f'| <= e^2 for exp on |u| <= 2
     cnt = np.bincount(ii[on], minlength=K)

@@ -383,6 +383,14 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
                     if (rng() & 1) pick() = w * F(2.f);
                     if (rng() & 1) seen.push_back(host(w * F(3.f)));          // .5 rsqrt times a seed: still a map (1.5 rsqrt)
                     if (rng() & 1) pick() = r;
+                    // the weights of rcp and rsqrt (autodiff.h:381-403): products of unevaluated maps of one source
+                    F q = rcp(v), wq = -sqr(q);
+                    F s = rsqrt(v), s2 = sqr(s), w3 = F(-0.5f) * (s * s2);
+                    seen.push_back({ hsum(q).coeff(0), hsum(s).coeff(0) });
+                    seen.push_back(host(wq));
+                    seen.push_back(host(w3));
+                    if (rng() & 1) seen.push_back(host(s2));
+                    if (rng() & 1) pick() = q * s;                       // maps of one source, but no derivative's product
                     break;
                 }
                 case 11: {  // adjoint-style multi scatter with (possibly) mapped values

@@ -38,6 +38,9 @@ static float unary_f(int op, float x) {
         case EK_SQRT: return std::sqrt(x);
         case EK_RCP: return 1.0f / x;
         case EK_RSQRT: return 1.0f / std::sqrt(x);
+        case EK_RCP_SQR: { volatile float r = 1.0f / x; return r * r; }
+        case EK_RSQRT_SQR: { volatile float r = 1.0f / std::sqrt(x); return r * r; }
+        case EK_RSQRT_CUBE: { volatile float r = 1.0f / std::sqrt(x); volatile float r2 = r * r; return r * r2; }
         case EK_SIN: return std::sin(x);
         case EK_COS: return std::cos(x);
         case EK_EXP: return std::exp(x);
@@ -292,7 +295,8 @@ int ek_hip_dist_shard_range(size_t n, int rank, int world, size_t *b, size_t *e)
 int ek_hip_dist_all_reduce(int, int, void *, size_t) { return EK_OK; }
 int ek_hip_bucketed_early_pair(int map_op, int keep_op) {
     return (map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN) || (map_op == EK_LOG && keep_op == EK_RCP) ||
-           (map_op == EK_SQRT && keep_op == EK_RSQRT) || map_op == keep_op;
+           (map_op == EK_SQRT && keep_op == EK_RSQRT) || (map_op == EK_RCP && keep_op == EK_RCP_SQR) ||
+           (map_op == EK_RSQRT && keep_op == EK_RSQRT_CUBE) || map_op == keep_op;
 }
 int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *ops,
                                        const uint64_t *imm, const int *weighted, const int *fresh, const uint64_t *scale) {

@@ -147,7 +147,7 @@ class Checker:
         f.restype = ctypes.c_float
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
         y = f(_p(A), _p(B), ctypes.c_size_t(A.size), _p(x), _p(idx), ctypes.c_int(int(idx.dtype.itemsize == 8)),
-              _p(m) if m is not None else None, ctypes.c_size_t(x.size), ctypes.c_int({"sin": 0, "cos": 1, "exp": 2, "log": 3, "sqrt": 4}[func]),
+              _p(m) if m is not None else None, ctypes.c_size_t(x.size), ctypes.c_int({"sin": 0, "cos": 1, "exp": 2, "log": 3, "sqrt": 4, "rcp": 5, "rsqrt": 6}[func]),
               ctypes.c_float(seed), _p(gA), _p(gB), ctypes.byref(sec))
         return y, gA, gB, sec.value
 

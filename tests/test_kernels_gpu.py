@@ -133,6 +133,25 @@ def test_sincos_bit_exact(capi, oracle):
         assert bits_equal(s.numpy(), es) and bits_equal(c.numpy(), ec)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_derivative_products_bit_exact(capi, dtype):
+    """EK_RCP_SQR / EK_RSQRT_SQR / EK_RSQRT_CUBE -- what the derivatives of rcp and rsqrt are made of (autodiff.h:381-403) as one op
+    each -- have the bits of the eager products of the library's own rcp / rsqrt (IEEE division, correctly rounded sqrt)"""
+    rng = np.random.default_rng(11)
+    a = np.concatenate([rng.uniform(0.01, 100.0, 100003), [0.0, np.inf, 1.0, 4.0, 1e-30, 1e30]]).astype(dtype)
+    d = up(capi, a)
+    r = capi.unary("rcp", d).numpy(); s = capi.unary("rsqrt", d).numpy()
+    with np.errstate(all="ignore"):
+        assert bits_equal(capi.unary("rcp_sqr", d).numpy(), r * r)
+        assert bits_equal(capi.unary("rsqrt_sqr", d).numpy(), s * s)
+        assert bits_equal(capi.unary("rsqrt_cube", d).numpy(), s * (s * s))
+    # and applied on load by a reduction (ek_hip_reduce_map): inside the class-D bound of the mapped terms
+    b = a[:100003]
+    t = (1.0 / b.astype(np.float64)) ** 2
+    got = float(capi.reduce_map("hsum", "rcp_sqr", up(capi, b)).numpy()[0])
+    assert abs(got - t.sum()) <= (2.0 ** -24 if dtype == np.float32 else 2.0 ** -53) * 64 * np.abs(t).sum()
+
+
 @pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "min", "max", "safe_mul"])
 def test_binary_f32_bit_exact(capi, oracle, op):
     a = f32_inputs(100003, seed=1, scale=10.0)

@@ -74,9 +74,12 @@ CASES = {
     "log": dict(func="log", shift=3.0),
     "sqrt": dict(func="sqrt", shift=3.0),
     "sqrt_seed3": dict(func="sqrt", shift=3.0, seed=3.0),
+    # -sqr(rcp(u)) and -.5 rsqrt(u)^3 (autodiff.h:381-403): products of unevaluated maps stay ONE map of u each
+    "rcp": dict(func="rcp", shift=3.0),
+    "rsqrt": dict(func="rsqrt", shift=3.0),
 }
 # what the step may launch when it stays in bucket order: ONE partition in the forward pass, the adjoint formed there as well
-EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt", "sqrt_seed3"}
+EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt", "sqrt_seed3", "rcp", "rsqrt"}
 
 
 @pytest.mark.parametrize("name", list(CASES))
