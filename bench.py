@@ -60,6 +60,7 @@ CFG3B_VARIANTS = {
     "cfg3b_cos": dict(func="cos"), "cfg3b_exp": dict(func="exp"), "cfg3b_seed3": dict(seed=3.0), "cfg3b_masked": dict(masked=True),
     "cfg3b_i64": dict(idx64=True), "cfg3b_K2Mi": dict(K=1 << 21), "cfg3b_K4Mi": dict(K=1 << 22), "cfg3b_K16Mi": dict(K=1 << 24),
     "cfg3b_sqrt": dict(func="sqrt", shift=3.0),          # (B + 3: u > 0; the derivative's factor .5 / sqrt(u) is a function of u)
+    "cfg3b_rcp": dict(func="rcp", shift=3.0),            # (the derivative's factor -sqr(rcp(u)) as ONE map of u)
 }
 for _w, _v in CFG3B_VARIANTS.items():
     DESCRIPTION[_w] = ("cfg3b with " + ", ".join(f"{k}={v}" for k, v in _v.items()) +

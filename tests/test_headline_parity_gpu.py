@@ -116,7 +116,8 @@ def test_cfg4_headline_image_bit_exact():
 
 
 NEIGHBOURS = {"cos": dict(func="cos"), "exp": dict(func="exp"), "seed3": dict(seed=3.0), "masked": dict(masked=True),
-              "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22), "sqrt": dict(func="sqrt", shift=3.0)}
+              "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22), "sqrt": dict(func="sqrt", shift=3.0),
+              "rcp": dict(func="rcp", shift=3.0)}
 
 
 @pytest.mark.parametrize("name", list(NEIGHBOURS))
