@@ -93,6 +93,24 @@ static void directed() {
         F st = sin(input(N, 1.f));                    // never looked at: node and source are released with the handle
     }
 
+    // --- the factors of the derivatives of sqrt / rcp / rsqrt stay ONE unevaluated map of the source each (autodiff.h:353-403) ---
+    {
+        F v = abs(input(N, 3.f)) + F(1.f);
+        std::vector<float> hv = host(v), want(N);
+        u0 = g_unary_calls;
+        F r = sqrt(v), w = F(0.5f) / r;               // .5 / sqrt(v): an unevaluated multiple of rsqrt(v)
+        F q = rcp(v), wq = -sqr(q);                   // -(1 / v)^2
+        F t = rsqrt(v), t2 = sqr(t), w3 = F(-0.5f) * (t * t2);
+        CHECK(g_unary_calls == u0);                   // nothing ran
+        for (size_t i = 0; i < N; ++i) want[i] = 0.5f / std::sqrt(hv[i]);
+        CHECK(same(host(w), want));
+        for (size_t i = 0; i < N; ++i) { volatile float a = 1.0f / hv[i]; want[i] = -(a * a); }
+        CHECK(same(host(wq), want));
+        for (size_t i = 0; i < N; ++i) { volatile float a = 1.0f / std::sqrt(hv[i]), a2 = a * a; want[i] = -0.5f * (a * a2); }
+        CHECK(same(host(w3), want));
+        CHECK(g_unary_calls == u0 + 3);               // ONE kernel per weight: neither sqrt / rcp / rsqrt nor the products ran
+    }
+
     // --- sincos pairs: every order of touching / dropping the halves ---
     for (int order = 0; order < 6; ++order) {
         long c0 = g_sincos_calls, un0 = g_unary_calls;
