@@ -98,12 +98,18 @@ def parse():
     ap.add_argument("--dump-gradients", default=None, metavar="DIR", help="cfg3b: every rank saves what it holds of the table gradients after the exchange (owned slices when reduce-scattered) as DIR/grad_rank<r>.npz -- for the multi-rank parity tests")
     ap.add_argument("--graph", action="store_true", help="ALSO time the K steps as replays of a captured step graph (graph_ms_per_step); `value` stays the python-driven protocol")
     ap.add_argument("--allreduce-grads", action="store_true",
-                    help="multi-GPU: all-reduce the table gradients (every rank ends up with all K bins) instead of reduce-scattering them")
+                    help="(default since round 5: what BASELINE.json's north_star names) multi-GPU: all-reduce the table gradients, every rank ends up with all K bins")
+    ap.add_argument("--reduce-scatter-grads", action="store_true",
+                    help="multi-GPU: reduce-scatter the table gradients instead (rank r receives bins [r K / P, (r + 1) K / P): half the bytes, "
+                         "for callers that update the slice they own)")
+    ap.add_argument("--pre-warm-s", type=float, default=0.6,
+                    help="seconds of the headline step run BEFORE the --warmup steps (clocks and caches in the state of a long run; "
+                         "reported as pre_warm_s, outside the timed region)")
     return ap.parse_args()
 
 
-PMC_FILE = os.path.join("profiles", "rocprof_pmc_r04.txt")
-KSTATS_FILE = os.path.join("profiles", "rocprof_kernel_stats_r04.txt")
+PMC_FILE = os.path.join("profiles", "rocprof_pmc_r05.txt")
+KSTATS_FILE = os.path.join("profiles", "rocprof_kernel_stats_r05.txt")
 
 
 def kernels_sha16():
@@ -166,6 +172,37 @@ def rocprof_avg_us(kernel):
     if not best:
         return None, f"{KSTATS_FILE} has no line for {sym}"
     return best[1], f"{KSTATS_FILE} (kernels_sha16 {stamp})"
+
+
+def rocprof_step_sum_us():
+    """sum over the kernels of one headline step of their average duration in the committed rocprofv3 kernel trace (same stamp
+    rule as rocprof_avg_us); every library kernel of the step is launched once per step"""
+    path = os.path.join(ROOT, KSTATS_FILE)
+    if not os.path.exists(path):
+        return None
+    stamp, total = None, 0.0
+    for line in open(path):
+        if line.startswith("# kernels_sha16:"):
+            stamp = line.split(":", 1)[1].strip()
+        if line.startswith("# step_sum_us:"):
+            total = float(line.split(":", 1)[1])
+    return total if stamp == kernels_sha16() and total > 0 else None
+
+
+def trace_check(ms_per_step, live_sum_ms, headline):
+    """Does the per-kernel evidence add up to the claimed step?  sum(kernels) <= step <= 1.1 x sum, for the live event deltas of
+    this run and -- on the headline at 64 Mi elements -- for the committed rocprofv3 trace (tools/profile_r05.sh takes it after
+    the same pre-warm)."""
+    rep = {"ms_per_step": round(ms_per_step, 4), "sum_live_kernel_ms": round(live_sum_ms, 4),
+           "step_over_live_sum": round(ms_per_step / live_sum_ms, 3) if live_sum_ms > 0 else None}
+    rp = rocprof_step_sum_us() if headline else None
+    if rp:
+        rep["sum_rocprof_kernel_ms"] = round(rp * 1e-3, 4)
+        rep["step_over_rocprof_sum"] = round(ms_per_step / (rp * 1e-3), 3)
+        rep["ok"] = bool(0.97 * rp * 1e-3 <= ms_per_step <= 1.1 * rp * 1e-3)
+        if not rep["ok"]:
+            print(f"[bench] trace check: step {ms_per_step:.4f} ms against {rp * 1e-3:.4f} ms of traced kernels ({KSTATS_FILE})", file=sys.stderr)
+    return rep
 
 
 def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024, record=None):
@@ -236,8 +273,10 @@ class Bench:
         from enoki_amd import dist as ekd, synth
         self.torch, self.ekc, self.ek, self.ekd, self.synth, self.args = torch, ekc, ek, ekd, synth, args
         self.rank, self.local_rank, self.world = ekd.init()
-        if self.world != args.gpus and self.rank == 0:
-            print(f"[bench] warning: --gpus {args.gpus} but WORLD_SIZE={self.world}", file=sys.stderr)
+        if self.world != args.gpus:
+            # never print a line whose n_gpus is not what was asked for (main() re-launches itself as --gpus ranks when it is
+            # started without a launcher, so this is a launcher that was given another --nproc-per-node)
+            raise SystemExit(f"[bench] --gpus {args.gpus} but the process group has WORLD_SIZE={self.world}: refusing to measure")
         torch.cuda.set_device(self.local_rank)          # torch's HIP runtime initialises first
         ek.hip_init(self.local_rank)
         ekd.adopt_torch_stream(ek)                        # kernels + RCCL ordered by one stream
@@ -248,6 +287,18 @@ class Bench:
         self.begin, self.end = ekd.shard_range(self.N, self.rank, self.world)
         self.n = self.end - self.begin
         self.sh = ekd.Sharded(ek, self.N, device=self.dev)     # horizontal results of the shards -> ONE all-reduce per step
+
+    def group_world(self):
+        """ranks the process group actually has (what the collectives run over), not what the command line says"""
+        import torch.distributed as dist
+        return dist.get_world_size() if dist.is_initialized() else 1
+
+    def backend(self):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            return "none (single process)"
+        be = dist.get_backend()
+        return "nccl (RCCL over xGMI)" if be == "nccl" else f"{be} ({self.world} ranks on {self.torch.cuda.device_count()} visible GPU(s))"
 
     def make_step(self, workload):
         """returns (step_fn, packer, out_dict); inputs are generated on the device (seeds of SURVEY.md 8d)"""
@@ -290,10 +341,11 @@ class Bench:
                     if reuse and out.get("plan") is not None:
                         out["plan"].run()
                     else:
-                        # the table gradients REDUCE-SCATTERED: rank r receives bins [r K / P, (r + 1) K / P) of both tables in
-                        # one collective (half the bytes of an all-reduce, nothing K-sized is replicated after the exchange)
-                        # and the loss rides in an extra column of it; --allreduce-grads: every rank gets all of it
-                        scat = not self.args.allreduce_grads
+                        # default: ONE all-reduce finishes the loss and both gradient tables on every rank (north_star: "hsum and
+                        # grad accumulation finished by RCCL all-reduce").  --reduce-scatter-grads: rank r receives bins
+                        # [r K / P, (r + 1) K / P) of both tables in one collective (half the bytes, nothing K-sized replicated
+                        # after the exchange) and the loss rides in an extra column of it
+                        scat = self.args.reduce_scatter_grads
                         out["reduced"] = [self.sh.reduce(out["y"]), self.sh.reduce(out["gA"], scattered=scat),
                                           self.sh.reduce(out["gB"], scattered=scat)]
                         out["plan"] = self.sh.flush()
@@ -455,9 +507,24 @@ class Bench:
         gbs = 8.0 * n / ms / 1e6
         return {"kernel": "floor, 64 Mi f32 (8 B/elt)", "GB/s": round(gbs, 1), "frac_of_peak": round(gbs / (HBM_PEAK_TBS * 1000), 4)}
 
-    def run(self, workload, steps, warmup, profile_steps, max_seconds=None):
+    def run(self, workload, steps, warmup, profile_steps, max_seconds=None, pre_warm_s=0.0):
         torch, ek, ekd = self.torch, self.ek, self.ekd
         step, packer, out, compute, exchange = self.make_step(workload)
+        self.pre_warm_s = 0.0
+        if pre_warm_s > 0:
+            # The driver times 20 steps (7 ms) of a process that has just started: memory clocks, the allocator's pools and
+            # the instruction caches are those of an idle GPU, and the same kernels ran 12 % faster one workload later in the
+            # same process (round 4).  The headline step runs for `pre_warm_s` seconds first -- outside the timed region,
+            # reported -- so that the timed steps are those of a long run; --warmup / --steps stay exactly as given.
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < pre_warm_s:
+                for _ in range(20):
+                    step()
+                if packer:
+                    packer.wait_all()
+                torch.cuda.synchronize()
+            self.pre_warm_s = round(time.perf_counter() - t0, 3)
         for _ in range(warmup):
             step()
         if packer:
@@ -590,6 +657,12 @@ class Bench:
                          begin=0, end=K_TABLE)
         outputs = {k: out[k].numpy() for k in ("gA", "gB", "ga", "gb") if k in out} if self.world == 1 and workload == self.args.workload else {}
         outputs["y"] = y_val
+        if roofline:
+            # the per-kernel times and the step they are said to add up to, taken in the SAME state of the device: kernels on
+            # one in-order stream do not overlap, so sum(live event deltas, which include the launch gaps) ~ the step; the
+            # committed rocprofv3 trace (no gaps) must not exceed it
+            live_sum = sum(k["total_ms"] for k in prof) / profile_steps
+            roofline["trace_check"] = trace_check(ms_per_step, live_sum, self.n == (1 << 26) and workload == "cfg3b")
         return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "eager_ms_per_step": round(eager_ms, 4),
                 "graph_ms_per_step": round(graph_ms, 4) if graph_ms is not None else None, "result_y": y_val,
                 "roofline": roofline, "collectives_per_step": coll_per_step,
@@ -765,16 +838,39 @@ def cpu_all_cores(workload, n, kind):
         return {"value": None, "cores": procs, "note": f"all-cores measurement failed: {type(e).__name__}: {e}"}
 
 
+def relaunch_as_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks of this very command line (torch.distributed.run, one rank per
+    GPU, rendezvous on 127.0.0.1) and hand their exit code back.  Fewer than N visible GPUs: the ranks share them and the
+    collectives go through gloo (RCCL refuses two ranks on one device) -- the line then says so (`config.backend`)."""
+    import socket
+    import subprocess
+    import torch
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    if torch.cuda.device_count() < args.gpus:
+        env.setdefault("ENOKI_DIST_BACKEND", "gloo")
+        print(f"[bench] --gpus {args.gpus} on {torch.cuda.device_count()} visible GPU(s): ranks share devices, collectives through gloo",
+              file=sys.stderr)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
     launched = "RANK" in os.environ or int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if args.gpus > 1 and not launched:
+        sys.exit(relaunch_as_ranks(args))
     if launched:
         # A multi-process run must never sit in a collective forever (a rank that died, a rendezvous that never
         # completes): after 15 minutes every rank dumps its python stack and exits non-zero instead of hanging.
         import faulthandler
         faulthandler.dump_traceback_later(900, exit=True)
     b = Bench(args)
-    main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps)
+    main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps, pre_warm_s=args.pre_warm_s)
+    pre_warm_s = b.pre_warm_s
     also = {}
     if b.world == 1 and not args.no_also:
         for w in ("cfg3a", "cfg2", "cfg3b") + tuple(CFG3B_VARIANTS) + ("cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5", "cfg5_unfused"):
@@ -803,7 +899,7 @@ def main():
         line = {
             "metric": "Gelem/s + %HBM-roofline, 64M-elt DiffArray backward(), 1/2/4/8 MI355X",
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": main_res["ms_per_step"], "value_source": "eager", "eager_ms_per_step": main_res["eager_ms_per_step"],
+            "ms_per_step": main_res["ms_per_step"], "pre_warm_s": pre_warm_s, "value_source": "eager", "eager_ms_per_step": main_res["eager_ms_per_step"],
             "graph_ms_per_step": main_res["graph_ms_per_step"], "higher_is_better": True,
             "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5") else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -811,9 +907,10 @@ def main():
                        "elements_total": (N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU) * b.world
                        if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5") else b.N,
                        "elements_per_gpu": N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU if args.workload == "cfg5" else b.n, "table_size": K_TABLE if args.workload == "cfg3b" else None,
-                       "sharding": f"index-range x{b.world}", "collectives_per_step": main_res["collectives_per_step"],
+                       "sharding": f"index-range x{b.world}", "world_size": b.group_world(), "backend": b.backend(),
+                       "collectives_per_step": main_res["collectives_per_step"],
                        "gradient_exchange": (None if not b.ekd.active() or args.workload != "cfg3b" else
-                                             "all-reduce (every rank holds all K bins)" if args.allreduce_grads else
+                                             "ONE all-reduce per step: the loss and both gradient tables, every rank holds all K bins" if not args.reduce_scatter_grads else
                                              "ONE reduce-scatter per step: rank r receives bins [r K / P, (r + 1) K / P) of both tables, the loss rides in an extra column"),
                        "step_replay": main_res["replay"]},
             "result_y": main_res["result_y"], "parity_checked": bool(parity and parity["parity_checked"]), "parity": parity,

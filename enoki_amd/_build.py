@@ -184,7 +184,7 @@ def build_checkers(force=False, verbose=True):
               f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     compat = os.path.join(tcpp, "compat_names_hip.bin")
     if force or _newer(compat, [os.path.join(tcpp, "compat_names_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", inc, os.path.join(tcpp, "compat_names_hip.cpp"), "-o", compat,
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-DENOKI_HIP_DYNAMIC_IS_DEVICE=1", inc, os.path.join(tcpp, "compat_names_hip.cpp"), "-o", compat,
               f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     call = os.path.join(tcpp, "libcall_hip.so")
     if force or _newer(call, [os.path.join(tcpp, "call_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):

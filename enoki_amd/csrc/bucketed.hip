@@ -83,6 +83,15 @@ template <int Op, typename T> struct BucketReducer {
     }
 };
 
+/// where the last workgroup of a reducing launch puts the result (bucket_finish); ticket == nullptr: a separate launch does it
+template <typename T> struct BucketFinish {
+    uint32_t *ticket;
+    T *out;
+    const uint32_t *active;
+    size_t n;
+    int zero_op;             // what a dropped lane (u = 0) contributes, as a function of 0
+};
+
 template <typename T> __device__ __forceinline__ T bucket_shfl_down(T v, int delta) {
     if constexpr (sizeof(T) == 8) {
         uint64_t u;
@@ -226,6 +235,74 @@ __device__ __forceinline__ void walk_piece(const BucketLists &bl, const PieceRan
     }
 }
 
+// `active` (may be null): [0] number of elements in the lists, [1] != 0 when a lane whose mask bit is clear carries a non-finite x.
+// The other n - active[0] lanes were dropped by the partition -- masked out of both gathers, or pointing outside the table (the
+// reference leaves that case unspecified, cuda.h:845-905; here it counts as masked out).  Their u is fma(0, x, 0): 0 for a finite
+// x, so they contribute map_op(0) to the reduction; NaN for an infinite or NaN x -- then the reference's result is NaN
+// (dynamic.h:632-650 sums every lane) and so is this one (hsum, hprod; hmin / hmax skip NaNs here as everywhere: DESIGN section 5).
+template <typename T, int ROp>
+__device__ __forceinline__ T bucket_dropped_lanes(T r, size_t masked, bool nonfinite, int map_op) {
+    using R = BucketReducer<ROp, T>;
+    if (masked) {
+        const T f0 = unary_fused<T>(map_op, T(0));
+        if constexpr (ROp == EK_HSUM) {
+            r = r + (T) masked * f0;
+        } else if constexpr (ROp == EK_HPROD) {
+            T p = T(1), base = f0;
+            for (size_t e = masked; e; e >>= 1) { if (e & 1) p = p * base; base = base * base; }
+            r = r * p;
+        } else {
+            r = R::combine(r, f0);
+        }
+    }
+    if (nonfinite) r = R::combine(r, std::numeric_limits<T>::quiet_NaN());
+    return r;
+}
+
+// The reduction over the pieces' partial results, finished by the LAST workgroup to arrive instead of a launch of its own
+// (k_bucket_reduce_final: 4.5 us + a launch gap per step; a quarter of what an 8 Mi-element shard step spends outside its two
+// big kernels).  Every workgroup publishes its partial and takes a ticket; the one that draws the last ticket reads all
+// partials (agent-scope loads: they were written on other XCDs), adds what the dropped lanes contribute and resets the ticket
+// for the next launch -- launches on one object are ordered by the stream.  `ticket` == nullptr: the host launches
+// k_bucket_reduce_final (objects whose meta block is not zero-filled: 8-byte element types).
+template <typename T, int ROp>
+__device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *__restrict__ partials, uint32_t *__restrict__ ticket,
+                                              T *__restrict__ out, const uint32_t *__restrict__ active, size_t n, int map_op,
+                                              T *wave_part /* [kBucketWaves] shared */) {
+    using R = BucketReducer<ROp, T>;
+    using Bits = std::conditional_t<sizeof(T) == 4, uint32_t, unsigned long long>;
+    __shared__ uint32_t s_last;
+    if (threadIdx.x == 0) {
+        Bits b;
+        __builtin_memcpy(&b, &block_result, sizeof(T));
+        __hip_atomic_store(reinterpret_cast<Bits *>(partials) + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = ticket && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    T v = R::identity();
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
+        const Bits b = __hip_atomic_load(reinterpret_cast<const Bits *>(partials) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        T p;
+        __builtin_memcpy(&p, &b, sizeof(T));
+        v = R::combine(v, p);
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
+    __syncthreads();                                  // (wave_part may still hold this workgroup's own wave results)
+    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        v = threadIdx.x < blockDim.x / 64 ? wave_part[threadIdx.x] : R::identity();
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
+        if (threadIdx.x == 0) {
+            out[0] = bucket_dropped_lanes<T, ROp>(v, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 // ---- 2. forward ------------------------------------------------------------------------------------
 // The streaming part, specialised for the unary op that is applied to u before the reduction (Map, compile time: the
 // kernel switches ONCE, outside the loops -- a runtime switch per element would inline nine transcendental bodies into an
@@ -311,7 +388,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
                                                                         size_t table_size, int flip_a, int flip_c,
                                                                         const uint16_t *__restrict__ pair_idx,
                                                                         const T *__restrict__ x_b, const T *__restrict__ kept,
-                                                                        BucketLists bl, int map_op, int keep_partner, int shift) {
+                                                                        BucketLists bl, int map_op, int keep_partner, int shift,
+                                                                        BucketFinish<T> fin) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
     __shared__ T wave_part[kBucketWaves];
@@ -320,8 +398,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
     const uint32_t lmask = (uint32_t) Bins - 1u;
     int bucket;
     PieceRange range;
-    if (!bucket_piece<PS>(bl, bucket, range)) {
-        if (ROp != EK_REDUCE_NONE && threadIdx.x == 0) partials[blockIdx.x] = R::identity();
+    const bool live = bucket_piece<PS>(bl, bucket, range);        // (workgroup-uniform; a launch has a few more workgroups than pieces)
+    if (!live) {
+        if constexpr (ROp != EK_REDUCE_NONE) bucket_finish<T, ROp>(R::identity(), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
         return;
     }
     if constexpr (!FromKept) {
@@ -364,14 +443,11 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
             v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : R::identity();
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
-            if (threadIdx.x == 0) partials[blockIdx.x] = v;
         }
+        bucket_finish<T, ROp>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
     }
 }
 
-// `active` (may be null): number of elements in the lists.  The other n - active lanes were masked out of both gathers: their
-// u is fma(0, x, 0) = 0 and they contribute map_op(0) to the reduction, whatever their x (a non-finite x would make the
-// element-order evaluation produce 0 * inf = NaN there: documented deviation).
 template <typename T, int ROp>
 __global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out, const T *__restrict__ partials, unsigned count,
                                                              const uint32_t *__restrict__ active, size_t n, int map_op) {
@@ -385,20 +461,7 @@ __global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out
     __syncthreads();
     if (threadIdx.x == 0) {
         T r = R::combine(R::combine(wave_part[0], wave_part[1]), R::combine(wave_part[2], wave_part[3]));
-        const size_t masked = active ? n - (size_t) active[0] : 0;
-        if (masked) {
-            const T f0 = unary_fused<T>(map_op, T(0));
-            if constexpr (ROp == EK_HSUM) {
-                r = r + (T) masked * f0;
-            } else if constexpr (ROp == EK_HPROD) {
-                T p = T(1), base = f0;
-                for (size_t e = masked; e; e >>= 1) { if (e & 1) p = p * base; base = base * base; }
-                r = r * p;
-            } else {
-                r = R::combine(r, f0);
-            }
-        }
-        out[0] = r;
+        out[0] = bucket_dropped_lanes<T, ROp>(r, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
     }
 }
 
@@ -719,19 +782,23 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
             switch (op) {
                 EK_ACC_SPEC(EK_NEG) EK_ACC_SPEC(EK_ABS) EK_ACC_SPEC(EK_SQRT) EK_ACC_SPEC(EK_RCP) EK_ACC_SPEC(EK_RSQRT)
                 EK_ACC_SPEC(EK_SIN) EK_ACC_SPEC(EK_COS) EK_ACC_SPEC(EK_EXP) EK_ACC_SPEC(EK_LOG)
-                EK_ACC_SPEC(EK_RCP_SQR) EK_ACC_SPEC(EK_RSQRT_CUBE)
-                default: run(AccumulateBody<T, C, V, EK_COPY, 1>{}, true); break;
+                EK_ACC_SPEC(EK_RCP_SQR) EK_ACC_SPEC(EK_RSQRT_SQR) EK_ACC_SPEC(EK_RSQRT_CUBE)
+                case EK_COPY: run(AccumulateBody<T, C, V, EK_COPY, 1>{}, true); break;
+                default: done = false; break;       // an op without a compile-time body: the per-stream run-time form below
             }
         }
     }
 #undef EK_ACC_SPEC
     if (done) {
     } else if (uniform) {
+        // (an op that unary_fusable() accepts but that has no case here must never fall into the EK_COPY body -- it would scatter u
+        // instead of op(u): it takes the run-time form, which evaluates unary_fused(op, u) per stream)
         switch (op) {
             EK_ACC_CASE(EK_NEG) EK_ACC_CASE(EK_ABS) EK_ACC_CASE(EK_SQRT) EK_ACC_CASE(EK_RCP) EK_ACC_CASE(EK_RSQRT)
             EK_ACC_CASE(EK_SIN) EK_ACC_CASE(EK_COS) EK_ACC_CASE(EK_EXP) EK_ACC_CASE(EK_LOG)
-            EK_ACC_CASE(EK_RCP_SQR) EK_ACC_CASE(EK_RSQRT_CUBE)
-            default: run(AccumulateBody<T, C, V, EK_COPY, 0>{}, false); break;
+            EK_ACC_CASE(EK_RCP_SQR) EK_ACC_CASE(EK_RSQRT_SQR) EK_ACC_CASE(EK_RSQRT_CUBE)
+            case EK_COPY: run(AccumulateBody<T, C, V, EK_COPY, 0>{}, false); break;
+            default: run(AccumulateBody<T, C, V, -1, 0>{}, false); break;
         }
     } else {
         run(AccumulateBody<T, C, V, -1, 0>{}, false);
@@ -872,7 +939,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
                                                                                 int flip_a, int flip_c,
                                                                                 const uint16_t *__restrict__ pair_idx,
                                                                                 const T *__restrict__ x_b, BucketLists bl,
-                                                                                int map_op, int keep_op, int shift) {
+                                                                                int map_op, int keep_op, int shift, BucketFinish<T> fin) {
     extern __shared__ __align__(16) unsigned char lds_raw[];
     const int Bins = 1 << shift;
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
@@ -883,7 +950,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     int bucket;
     PieceRange range;
     if (!bucket_piece<PS>(bl, bucket, range)) {
-        if (threadIdx.x == 0) partials[blockIdx.x] = T(0);
+        bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
         return;
     }
     stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
@@ -913,7 +980,6 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : T(0);
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
-        if (threadIdx.x == 0) partials[blockIdx.x] = v;
     }
     // table c (0: sum of the kept function, 1: sum of x * kept function) of this piece at table_partials + (c * gridDim.x + piece) * Bins
 #pragma unroll
@@ -921,6 +987,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         T *out = table_partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
         for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? tables[2 * j + c] : tables[c * Bins + j];
     }
+    bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -950,12 +1017,18 @@ struct Bucketed {
     size_t positions = 0;
     void *page_lists = nullptr;    // glist_full[page slots] | glist_part[W * n_buckets]
     uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
-    const uint32_t *active = nullptr;      // device: number of elements in the lists (null: all n -- no mask)
+    const uint32_t *active = nullptr;      // device: [0] number of elements in the lists, [1] non-finite x under a cleared mask bit (null: contiguous lists)
+    uint32_t *ticket = nullptr;            // device, zero between launches: the last workgroup of a reducing launch finishes the reduction (bucket_finish)
     uint32_t win_lo = 0, win_span = 0;     // a slice of a large table: only indices in [win_lo, win_lo + win_span) (ek_hip_bucketed::slices)
     bool correct_masked = true;            // the final reduction adds the masked-out lanes' map_op(0) terms (slices: their owner does)
 
     bool has_mask = false;
-    const uint32_t *masked_ptr() const { return has_mask && correct_masked ? active : nullptr; }
+    // (with or without a mask array: lanes whose index points outside the table are dropped by the partition too, and count like
+    //  masked-out ones -- one rule for a single object and for the slices of a large table)
+    const uint32_t *masked_ptr() const { return correct_masked ? active : nullptr; }
+    template <typename T> BucketFinish<T> finish(void *out, int zero_op) const {
+        return BucketFinish<T>{ ticket, (T *) out, masked_ptr(), n, zero_op };
+    }
     size_t bins() const { return (size_t) 1 << shift; }
     BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
     ~Bucketed() {
@@ -1113,6 +1186,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     uint32_t *gtotal = (uint32_t *) b->meta;
     b->bucket_base = gtotal + 3 * kMaxBuckets;
     b->active = gtotal + 2 * kMaxBuckets;
+    b->ticket = gtotal + 2 * kMaxBuckets + 2;              // (zeroed by the memset below, reset by whoever draws the last ticket)
     b->has_mask = mask.vec != 0;
     b->base_part = b->bucket_base + kMaxBuckets + 1;
     b->piece_prefix = b->base_part + kMaxBuckets + 1;
@@ -1180,16 +1254,19 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
         hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
                            (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
                            (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,
-                           (const T *) b->x_b, (const T *) nullptr, b->lists(), map_op, partner ? 1 : 0, b->shift);
+                           (const T *) b->x_b, (const T *) nullptr, b->lists(), map_op, partner ? 1 : 0, b->shift,
+                           b->template finish<T>(out, map_op));
     });
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
     if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
     else if (keep) b->has_u = true;
     if constexpr (ROp != EK_REDUCE_NONE) {
-        hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out,
-                           (const T *) b->reduce_partials, b->max_pieces, b->masked_ptr(), b->n, map_op);
-        EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+        if (!b->ticket) {
+            hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out,
+                               (const T *) b->reduce_partials, b->max_pieces, b->masked_ptr(), b->n, map_op);
+            EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+        }
     }
     return EK_OK;
 }
@@ -1202,12 +1279,15 @@ static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const
     EK_BY_LAYOUT(b, {
         hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV, PS, true>), dim3(b->max_pieces), dim3(kBucketThreads), 0, c.stream,
                            (T *) b->reduce_partials, (T *) nullptr, (const T *) nullptr, (const T *) nullptr, b->table_size, 0, 0,
-                           (const uint16_t *) b->pair_idx, (const T *) b->x_b, (const T *) values, b->lists(), map_op, 0, b->shift);
+                           (const uint16_t *) b->pair_idx, (const T *) b->x_b, (const T *) values, b->lists(), map_op, 0, b->shift,
+                           b->template finish<T>(out, zero_op));
     });
     EK_LAUNCH_CHECK("bucket_reduce_kept", b->n, b->n * sizeof(T));
-    hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                       b->max_pieces, b->masked_ptr(), b->n, zero_op);
-    EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    if (!b->ticket) {
+        hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
+                           b->max_pieces, b->masked_ptr(), b->n, zero_op);
+        EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    }
     return EK_OK;
 }
 
@@ -1242,15 +1322,18 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
         if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV, PS>, lds)) return rc;
         hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
                            (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
-                           flip_a, flip_c, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift);
+                           flip_a, flip_c, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift,
+                           b->template finish<T>(out, map_op));
     });
     EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T)) + 2 * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
     b->has_early = true;
     b->early_op = keep_op;
-    hipLaunchKernelGGL((k_bucket_reduce_final<T, EK_HSUM>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                       b->max_pieces, b->masked_ptr(), b->n, map_op);
-    EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    if (!b->ticket) {
+        hipLaunchKernelGGL((k_bucket_reduce_final<T, EK_HSUM>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
+                           b->max_pieces, b->masked_ptr(), b->n, map_op);
+        EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
+    }
     return EK_OK;
 }
 
@@ -1447,7 +1530,7 @@ struct ek_hip_bucketed : ek::Bucketed {
     ~ek_hip_bucketed() { for (ek_hip_bucketed *s : slices) delete s; }
 };
 constexpr int kMaxSlices = 64;
-struct SliceCounts { const uint32_t *active[kMaxSlices]; };
+struct SliceCounts { const uint32_t *active[kMaxSlices]; const uint32_t *flag; };
 
 template <typename T, int ROp>
 __global__ __launch_bounds__(64) void k_slices_combine(T *__restrict__ out, const T *__restrict__ partial, int slices, SliceCounts counts,
@@ -1456,21 +1539,19 @@ __global__ __launch_bounds__(64) void k_slices_combine(T *__restrict__ out, cons
     if (threadIdx.x != 0) return;
     T r = R::identity();
     size_t kept = 0;
-    for (int s = 0; s < slices; ++s) { r = R::combine(r, partial[s]); kept += counts.active[s][0]; }
-    const size_t masked = n - kept;
-    if (masked) {
-        const T f0 = ek::unary_fused<T>(map_op, T(0));
-        if constexpr (ROp == EK_HSUM) {
-            r = r + (T) masked * f0;
-        } else if constexpr (ROp == EK_HPROD) {
-            T p = T(1), base = f0;
-            for (size_t e = masked; e; e >>= 1) { if (e & 1) p = p * base; base = base * base; }
-            r = r * p;
-        } else {
-            r = R::combine(r, f0);
-        }
-    }
-    out[0] = r;
+    bool nonfinite = counts.flag && counts.flag[0];
+    for (int s = 0; s < slices; ++s) { r = R::combine(r, partial[s]); kept += counts.active[s][0]; nonfinite = nonfinite || counts.active[s][1]; }
+    out[0] = ek::bucket_dropped_lanes<T, ROp>(r, n - kept, nonfinite, map_op);
+}
+
+// (tables of three or more slices under a mask: the split by slice drops the masked-out lanes before any page partition sees
+// them, so their x is looked at here -- 5 B/elt of a shape that already pays 20 B/elt for the split)
+__global__ __launch_bounds__(256) void k_masked_nonfinite(uint32_t *__restrict__ flag, const uint32_t *__restrict__ xbits,
+                                                          const uint8_t *__restrict__ mask, size_t n) {
+    bool bad = false;
+    for (size_t i = (size_t) blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t) gridDim.x * 256)
+        bad = bad || (!mask[i] && (xbits[i] & 0x7F800000u) == 0x7F800000u);
+    if (bad) atomicOr(flag, 1u);
 }
 struct ek_hip_index_partition : ek::IndexPartition { };
 
@@ -1540,6 +1621,16 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
                     rc = want_half ? coarse_split<bin_shift_of<float> - 1 + 8>(cs, (const float *) x, (const uint32_t *) index, m, n, S)
                                    : coarse_split<bin_shift_of<float> + 8>(cs, (const float *) x, (const uint32_t *) index, m, n, S);
             }
+            if (split && rc == EK_OK && mask) {
+                // the split drops the masked-out lanes: whether one of them carried a non-finite x is found out here
+                rc = ek_hip_malloc(16, &b->meta);
+                if (rc == EK_OK) {
+                    EK_HIP_CHECK(hipMemsetAsync(b->meta, 0, 16, ctx().stream));
+                    const unsigned grid = (unsigned) std::min<size_t>((n + 255) / 256, (size_t) ctx().num_cu * 8);
+                    hipLaunchKernelGGL(k_masked_nonfinite, dim3(grid), dim3(256), 0, ctx().stream, (uint32_t *) b->meta, (const uint32_t *) x, mask, n);
+                    EK_LAUNCH_CHECK("bucket_masked_nonfinite", n, n * 5);
+                }
+            }
             const Arg<uint8_t> all{ nullptr, 1, 0u };
             for (int sl = 0; sl < S && rc == EK_OK; ++sl) {
                 ek_hip_bucketed *sub = new ek_hip_bucketed();
@@ -1594,6 +1685,7 @@ int ek_hip_bucketed_reduce(ek_hip_bucketed *b, int reduce_op, int map_op, void *
             if (int rc = bucketed_reduce<float>(sub, reduce_op, map_op, (float *) partial.ptr + S, keep_values != 0, keep_op)) return rc;
             counts.active[S++] = sub->active;
         }
+        counts.flag = (const uint32_t *) b->meta;          // (tables of three or more slices under a mask; null otherwise)
         Context &c = ctx();
 #define EK_COMBINE(OP) hipLaunchKernelGGL((k_slices_combine<float, OP>), dim3(1), dim3(64), 0, c.stream, (float *) out, (const float *) partial.ptr, S, counts, b->n, map_op)
         switch (reduce_op) {

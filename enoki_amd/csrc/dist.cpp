@@ -9,6 +9,10 @@
 #include "ek_internal.h"
 
 #include <dlfcn.h>
+#include <link.h>
+
+#include <cstring>
+#include <string>
 
 namespace ek {
 
@@ -31,10 +35,37 @@ static Rccl g_rccl;
 static void *g_comm = nullptr;
 static int g_rank = 0, g_world = 1;
 
+// ONE copy of RCCL per process.  A python caller has torch's own librccl.so mapped already (torch/lib/librccl.so, soname
+// librccl.so.1, the copy `torch.distributed` talks to); mapping /opt/rocm/lib/librccl.so next to it would give the process two
+// RCCL runtimes with separate bootstrap state.  So: (1) ENOKI_HIP_RCCL_PATH when set, (2) whatever copy is ALREADY mapped --
+// found by soname without loading anything, then by walking the mapped objects --, (3) only then the loader's search path.
+static int find_mapped_rccl(struct dl_phdr_info *info, size_t, void *out) {
+    const char *name = info->dlpi_name;
+    if (!name || !*name) return 0;
+    const char *base = strrchr(name, '/');
+    base = base ? base + 1 : name;
+    if (strncmp(base, "librccl.so", 10) != 0) return 0;
+    *static_cast<std::string *>(out) = name;
+    return 1;
+}
+
+static std::string g_rccl_path = "(not loaded)";
+
 static int load_rccl() {
     if (g_rccl.lib) return EK_OK;
-    void *lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+    void *lib = nullptr;
+    if (const char *e = getenv("ENOKI_HIP_RCCL_PATH")) {
+        lib = dlopen(e, RTLD_NOW | RTLD_GLOBAL);
+        if (!lib) return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist: ENOKI_HIP_RCCL_PATH=%s cannot be loaded (%s)", e, dlerror());
+    }
+    if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+    if (!lib) {
+        std::string mapped;
+        dl_iterate_phdr(find_mapped_rccl, &mapped);
+        if (!mapped.empty()) lib = dlopen(mapped.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    }
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+    if (!lib) lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
     if (!lib) return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist: librccl.so cannot be loaded (%s)", dlerror());
     Rccl r;
     r.lib = lib;
@@ -48,6 +79,8 @@ static int load_rccl() {
     if (!r.get_unique_id || !r.comm_init_rank || !r.all_reduce || !r.reduce_scatter || !r.all_gather || !r.comm_destroy)
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist: librccl.so lacks an entry point");
     g_rccl = r;
+    Dl_info where;
+    if (dladdr((void *) r.all_reduce, &where) && where.dli_fname) g_rccl_path = where.dli_fname;
     return EK_OK;
 }
 
@@ -101,6 +134,8 @@ int ek_hip_dist_init(int rank, int world, const void *id128) {
     if (world == 1 && !id128) return EK_OK;                  // a world of one: every collective is local
     if (!id128) return fail(EK_ERR_INVALID, "ek_hip_dist_init(): null unique id");
     if (int rc = load_rccl()) return rc;
+    // the communicator belongs to the device of the library's context, whatever device the calling thread has current
+    EK_HIP_CHECK(hipSetDevice(ctx().device));
     Id128 id;
     memcpy(&id, id128, sizeof(id));
     if (int rc = g_rccl.comm_init_rank(&g_comm, world, id, rank)) { g_rank = 0; g_world = 1; return nccl_fail(rc, "ncclCommInitRank"); }
@@ -124,8 +159,10 @@ int ek_hip_dist_shard_range(size_t n, int rank, int world, size_t *begin, size_t
 int ek_hip_dist_all_reduce(int type, int reduce_op, void *buf, size_t n) {
     if (int rc = ensure_init()) return rc;
     const int t = nccl_type(type), op = nccl_op(reduce_op);
-    if (!buf || t < 0 || op < 0) return fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): bad arguments");
+    if (t < 0 || op < 0 || (!buf && n)) return fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): bad arguments");
     if (!g_comm) return g_world == 1 ? EK_OK : fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): ek_hip_dist_init has not been called");
+    if (n == 0) return EK_OK;
+    if (int rc = refuse_while_capturing("ek_hip_dist_all_reduce(): RCCL collectives are not recorded into step graphs")) return rc;
     if (int rc = g_rccl.all_reduce(buf, buf, n, t, op, g_comm, ctx().stream)) return nccl_fail(rc, "ncclAllReduce");
     note_launch("dist_all_reduce", n, 2 * n * type_size(type));
     return EK_OK;
@@ -137,8 +174,10 @@ int ek_hip_dist_reduce_scatter(int type, int reduce_op, void *recv, const void *
     if (!recv || !send || t < 0 || op < 0) return fail(EK_ERR_INVALID, "ek_hip_dist_reduce_scatter(): bad arguments");
     if (!g_comm) {
         if (g_world != 1) return fail(EK_ERR_INVALID, "ek_hip_dist_reduce_scatter(): ek_hip_dist_init has not been called");
-        return recv == send ? EK_OK : ek_hip_memcpy_device(recv, send, recv_count * type_size(type));
+        return (recv == send || recv_count == 0) ? EK_OK : ek_hip_memcpy_device(recv, send, recv_count * type_size(type));
     }
+    if (recv_count == 0) return EK_OK;
+    if (int rc = refuse_while_capturing("ek_hip_dist_reduce_scatter(): RCCL collectives are not recorded into step graphs")) return rc;
     if (int rc = g_rccl.reduce_scatter(send, recv, recv_count, t, op, g_comm, ctx().stream)) return nccl_fail(rc, "ncclReduceScatter");
     note_launch("dist_reduce_scatter", recv_count * g_world, (size_t) (g_world + 1) * recv_count * type_size(type));
     return EK_OK;
@@ -150,12 +189,16 @@ int ek_hip_dist_all_gather(int type, void *recv, const void *send, size_t send_c
     if (!recv || !send || t < 0) return fail(EK_ERR_INVALID, "ek_hip_dist_all_gather(): bad arguments");
     if (!g_comm) {
         if (g_world != 1) return fail(EK_ERR_INVALID, "ek_hip_dist_all_gather(): ek_hip_dist_init has not been called");
-        return recv == send ? EK_OK : ek_hip_memcpy_device(recv, send, send_count * type_size(type));
+        return (recv == send || send_count == 0) ? EK_OK : ek_hip_memcpy_device(recv, send, send_count * type_size(type));
     }
+    if (send_count == 0) return EK_OK;
+    if (int rc = refuse_while_capturing("ek_hip_dist_all_gather(): RCCL collectives are not recorded into step graphs")) return rc;
     if (int rc = g_rccl.all_gather(send, recv, send_count, t, g_comm, ctx().stream)) return nccl_fail(rc, "ncclAllGather");
     note_launch("dist_all_gather", send_count * g_world, (size_t) (g_world + 1) * send_count * type_size(type));
     return EK_OK;
 }
+
+const char *ek_hip_dist_rccl_path(void) { return g_rccl_path.c_str(); }
 
 int ek_hip_dist_finalize(void) {
     if (g_comm) {

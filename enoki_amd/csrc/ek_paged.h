@@ -44,7 +44,7 @@ template <typename T> struct PagedOut {
     uint32_t *loff;        // [n_buckets][W]  where they start in wlist[w]
     uint32_t *part;        // [n_buckets][W]  page << 6 | (count - 1) of the partially filled page, or kNoPage
     uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
-    uint32_t *active;      // number of elements kept (zeroed by the host)
+    uint32_t *active;      // [0] number of elements kept, [1] != 0: a lane whose mask bit is clear carries a non-finite x (zeroed by the host)
     uint32_t lo, span;     // only indices in [lo, lo + span) are kept, rebased to lo: the table (lo = 0, span = its size) or a slice of it
 #ifdef EK_PG_TIMING
     unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
@@ -99,13 +99,21 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         else r.m = 0;
     };
     const uint32_t win_lo = out.lo, win_span = out.span;
+    // A lane whose mask bit is clear gathers 0 from both tables (cuda.h:845-864): its u is fma(0, x, 0) -- 0 for a finite x, NaN
+    // for an infinite or NaN x, and the reference's reduction then is NaN (dynamic.h:632-650).  The lane is dropped here; that
+    // it would have produced a NaN is remembered (one compare per masked-out lane) and applied by the final reduction.
+    uint32_t nonfinite_masked = 0;
     auto decode = [&](const Raw &r, Tile &t) {
         t.on = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t.ix[j] = (uint32_t) r.pi[j];
             t.xv[j] = r.xv[j];
-            if constexpr (HasMask) t.on |= (((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u) << j;
+            if constexpr (HasMask) {
+                const uint32_t on = ((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u;
+                t.on |= on << j;
+                nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[j] & 0x7F800000u) == 0x7F800000u);
+            }
         }
         if constexpr (!HasMask) t.on = sm ? 0xFu : 0u;
         // indices outside the table (or outside this slice of it) are dropped like masked-out lanes: an out-of-range index must
@@ -125,7 +133,9 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             if (e + j < end) {
                 t.ix[j] = (uint32_t) index[e + j];
                 t.xv[j] = __builtin_bit_cast(uint32_t, x[e + j]);
-                t.on |= ((mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u) << j;
+                const uint32_t on = (mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u;
+                t.on |= on << j;
+                if constexpr (HasMask) nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[j] & 0x7F800000u) == 0x7F800000u);
                 t.ix[j] -= win_lo;
                 if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
             }
@@ -302,6 +312,9 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         for (int k = 0; k < 8; ++k) out.dbg[((size_t) w * 2 + (threadIdx.x >> 6)) * 8 + k] = tacc[k];
     if (threadIdx.x == 0) { out.dbg[(size_t) W * 16 + w * 4 + 0] = t_start; out.dbg[(size_t) W * 16 + w * 4 + 1] = t_loop; out.dbg[(size_t) W * 16 + w * 4 + 2] = wall_clock64(); }
 #endif
+    if constexpr (HasMask) {
+        if (nonfinite_masked) atomicOr(out.active + 1, 1u);
+    }
     // what is left: one partially filled page per bucket; the workgroup's page lists
     if (threadIdx.x < 64) {
         const int l = threadIdx.x;

@@ -673,7 +673,11 @@ __device__ __forceinline__ double pow_f64(double x, double y) { return exp_f64(l
 template <typename T> __device__ __forceinline__ T safe_mul(T w, T g) {
     return (w == T(0) || g == T(0)) ? T(0) : w * g;
 }
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && (defined(__gfx900__) || defined(__gfx906__) || defined(__gfx908__) || defined(__gfx90a__) || \
+                                       defined(__gfx940__) || defined(__gfx941__) || defined(__gfx942__) || defined(__gfx950__))
+// (GFX9 only: the mnemonic does not exist on gfx10+, where user kernels that include this header through enoki::vectorize get the
+// generic template above.  Denormal operands follow the kernel's fp32 denormal mode exactly like the plain multiplication of the
+// generic form does -- the library builds with denormals on; tests/test_kernels_gpu.py covers denormal operands.)
 // float: v_mul_legacy_f32 IS this function -- (+-0) * anything = +0, an IEEE multiplication otherwise -- in one instruction
 // instead of two compares, a multiplication and a select (bit-exact against the literal form: tests/test_kernels_gpu.py)
 template <> __device__ __forceinline__ float safe_mul<float>(float w, float g) {

@@ -125,7 +125,11 @@ namespace detail {
         // all see the same 32-bit buffer -- the index array is narrowed once, and the bucket-ordered path recognises it.
         HIPBuffer *narrowed = nullptr;
         int narrowed_type = 0;
-        void drop_narrowed() { if (narrowed) { HIPBuffer *n = narrowed; narrowed = nullptr; unref(n); } }
+        HIPBuffer *narrowed_of = nullptr;      // this buffer IS some source's cache entry (not owning; cleared when the entry goes)
+        void drop_narrowed() { if (narrowed) { HIPBuffer *n = narrowed; narrowed = nullptr; n->narrowed_of = nullptr; unref(n); } }
+        /// A cache entry that is about to be written through one of its own handles (non-const data(), an in-place scatter) or
+        /// exported stops being a cache entry: the source narrows again next time
+        void leave_narrowed_cache() { if (narrowed_of) narrowed_of->drop_narrowed(); }
         void *host_mirror = nullptr;           // begin() / end(): read-only host copy, dropped when the buffer may change
         bool exported = false;                 // an external zero-copy view (torch, __cuda_array_interface__) may exist
 
@@ -426,7 +430,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             // 64-bit integers narrowed to 32 bits: kept on the source (detail::HIPBuffer::narrowed)
             constexpr bool Narrowing = std::is_integral_v<T> && sizeof(T) == 8 && std::is_integral_v<Value> && sizeof(Value) == 4 && !IsMask;
             if constexpr (Narrowing) {
-                if (v.m_buf->narrowed && v.m_buf->narrowed_type == Type && !v.m_buf->narrowed->exported) {
+                if (v.m_buf->narrowed && v.m_buf->narrowed_type == Type && !v.m_buf->narrowed->exported && !v.m_buf->exported) {
                     m_buf = v.m_buf->narrowed;
                     m_buf->ref_count++;
                     return;
@@ -440,6 +444,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
                     v.m_buf->drop_narrowed();
                     v.m_buf->narrowed = m_buf;
                     v.m_buf->narrowed_type = Type;
+                    m_buf->narrowed_of = v.m_buf;
                     m_buf->ref_count++;
                 }
             }
@@ -1070,6 +1075,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         auto &sh = detail::HIPBuffer::shared();
         if (sh.scatter_alias && sh.sweeps == 0 && m_buf && !m_is_imm) {
             m_buf->force_readers();
+            m_buf->leave_narrowed_cache();
             m_buf->drop_host_mirror();
             ptr_();
         } else {
@@ -1228,7 +1234,13 @@ template <typename Value_> struct HIPArray : ArrayTag {
     }
 
     /// An external consumer received this buffer's address (see make_unique())
-    void mark_exported_() const { if (m_buf) m_buf->exported = true; }
+    void mark_exported_() const {
+        if (!m_buf) return;
+        m_buf->exported = true;
+        // an external view may write: neither a narrowed copy OF this buffer nor this buffer AS somebody's narrowed copy stays valid
+        m_buf->drop_narrowed();
+        m_buf->leave_narrowed_cache();
+    }
 
     /// Same device buffer (or the same host-known scalar)?  Lets the tape recognise gathers that share an index array.
     bool same_storage_(const HIPArray &o) const {
@@ -1299,6 +1311,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         materialize();
         if (!m_buf) return nullptr;
         m_buf->force_readers();                // the caller may write through the pointer
+        m_buf->leave_narrowed_cache();
         m_buf->drop_host_mirror();
         return (Value *) ptr_();
     }
@@ -1418,6 +1431,8 @@ template <typename Value_> struct HIPArray : ArrayTag {
         materialize();
         if (!m_buf) return;
         m_buf->force_readers();                // deferred gathers from this array see its contents before the write
+        m_buf->leave_narrowed_cache();         // (a cache entry holds a reference of its own: without this the copy below would
+                                               //  always be taken, with it a sole user handle writes in place)
         m_buf->drop_host_mirror();
         if (m_buf->ref_count > 1) {
             // copy on write.  An exported buffer is parked (one reference is never given back): the external view keeps

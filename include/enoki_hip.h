@@ -283,9 +283,13 @@ EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const v
 EK_API int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *table_a, const void *table_c,
                                               size_t table_size, const void *x, const void *index, size_t n, unsigned hints,
                                               ek_hip_bucketed **out);
-/* Both gathers under ONE mask array (cuda.h:845-864: masked-out lanes gather 0): inactive entries are dropped by the partition --
- * their u = fma(0, x, 0) = 0 enters a reduction as map_op(0), added in the final step, and they scatter nothing.  (Where the
- * element-order evaluation would produce 0 * inf = NaN for a non-finite x under a cleared mask bit, this path still says 0.)
+/* Both gathers under ONE mask array (cuda.h:845-864: masked-out lanes gather 0): inactive entries are dropped by the partition,
+ * and what they would have contributed is added by the final step of a reduction: u = fma(0, x, 0) is 0 for a finite x (the lane
+ * enters as map_op(0)) and NaN for an infinite or NaN x -- hsum / hprod then are NaN, exactly as the reference's lane-by-lane
+ * evaluation (dynamic.h:632-650) and this library's element-order kernels say.  Dropped lanes scatter nothing.
+ * ONE rule for every dropped lane: an index outside [0, table_size) -- unspecified in the reference (cuda.h:845-905) -- is
+ * treated like a cleared mask bit with a finite x (u = 0, contributes map_op(0), scatters nothing), for a single object and for
+ * the slices of a large table alike.
  * mask: n bytes or NULL; 4-byte element types only. */
 EK_API int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const void *table_a, const void *table_c,
                                               size_t table_size, const void *x, const void *index, const uint8_t *mask, size_t n,
@@ -312,8 +316,11 @@ EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
  *   table gradients:            ek_hip_dist_all_reduce(type, EK_HSUM, g, K), or ek_hip_dist_reduce_scatter (rank r receives bins
  *                               [r c, (r + 1) c) of the sum; send holds world * c entries) + ek_hip_dist_all_gather when needed
  * reduce_op: EK_HSUM | EK_HPROD | EK_HMIN | EK_HMAX.  world == 1 with a NULL id needs no RCCL at all (collectives are local).
- * librccl.so is loaded on first use (no link-time dependency).  The reference has no counterpart; python callers use
- * enoki_amd.dist (torch.distributed) for the same exchange. */
+ * librccl.so is loaded on first use (no link-time dependency) and ONE copy per process: ENOKI_HIP_RCCL_PATH when set, else the copy
+ * that is already mapped (a python caller has torch's own librccl.so: the collectives of torch.distributed and these then share
+ * one RCCL runtime), else the loader's search path; ek_hip_dist_rccl_path() says which file it was.  The collectives refuse to run
+ * while a step graph is being captured (EK_ERR_UNSUPPORTED, the capture stays valid) and are no-ops for n == 0.  The reference
+ * has no counterpart; python callers use enoki_amd.dist (torch.distributed) for the same exchange. */
 EK_API int ek_hip_dist_unique_id(void *id128);
 EK_API int ek_hip_dist_init(int rank, int world, const void *id128);
 EK_API int ek_hip_dist_world(int *rank, int *world);
@@ -322,6 +329,7 @@ EK_API int ek_hip_dist_all_reduce(int type, int reduce_op, void *buf, size_t n);
 EK_API int ek_hip_dist_reduce_scatter(int type, int reduce_op, void *recv, const void *send, size_t recv_count);
 EK_API int ek_hip_dist_all_gather(int type, void *recv, const void *send, size_t send_count);
 EK_API int ek_hip_dist_finalize(void);
+EK_API const char *ek_hip_dist_rccl_path(void);
 /* Partition of an INDEX array by bucket of the range it points into: the active entries (mask) of `index` are grouped by
  * bucket = index >> shift and stored as bucket-local indices (index & ((1 << shift) - 1)), bucket b at local[bucket_base[b] ..
  * bucket_base[b + 1]).  shift is the smallest of {12, 14, 17, 19} with <= 256 buckets for `range` entries (range <= 128 Mi).

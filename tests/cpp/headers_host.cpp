@@ -19,7 +19,7 @@ namespace mine { enoki::HIPArray<float> *make(); void take(const enoki::Array<en
 #include <enoki/array_round.h>
 #include <enoki/array_math.h>
 #include <enoki/cuda.h>
-#include <enoki/dynamic.h>
+#include <enoki/dynamic.h>      // (without ENOKI_HIP_DYNAMIC_IS_DEVICE: the name exists, using it is a compile error -- tests/test_half.py)
 #include <enoki/autodiff.h>
 #include <enoki/matrix.h>
 #include <enoki/complex.h>

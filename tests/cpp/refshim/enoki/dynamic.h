@@ -3,6 +3,10 @@
 // plus the throwing assert() of the shim.
 #pragma once
 
+// the retargeted build asks for the substitution explicitly (include/enoki/dynamic.h: opt-in)
+#ifndef ENOKI_HIP_DYNAMIC_IS_DEVICE
+#  define ENOKI_HIP_DYNAMIC_IS_DEVICE 1
+#endif
 #include_next <enoki/dynamic.h>
 
 #include <iostream>

@@ -148,6 +148,51 @@ def test_scatter_add_cos_pair_within_class_d(capi, dtype):
             assert (err <= bound).all(), (forward_first, float((err / bound).max()))
 
 
+FUSABLE = ["neg", "abs", "sqrt", "rcp", "rsqrt", "sin", "cos", "exp", "log", "rcp_sqr", "rsqrt_sqr", "rsqrt_cube"]
+
+
+@pytest.mark.parametrize("mop", FUSABLE)
+def test_scatter_add_applies_every_fusable_op(capi, mop):
+    """Every op that unary_fusable() accepts, as the value stream of a bucket-ordered scatter_add in each of the kernel's forms:
+    the compile-time pair { f(u), x f(u) } (Spec), a uniform pair with both streams unweighted, one stream alone, and a pair of
+    DIFFERENT ops (run-time form).  (Round 4 shipped a switch that sent rsqrt_sqr to the copy body: the streams scattered u
+    instead of rsqrt(u)^2.)  u = A x + C with C in [2, 4): every op is finite and well away from its singularities."""
+    dtype = np.float32
+    K, n = (1 << 16) + 1, (1 << 19) + 17
+    A, C, x, idx = make(dtype, n, K, seed=31)
+    A = (A * np.float32(0.5)).astype(dtype); C = (C + np.float32(3.0)).astype(dtype)
+    dA, dC, dx, di = up(capi, A), up(capi, C), up(capi, x), up(capi, idx)
+    u = element_order_u(capi, "fmadd", dA, dx, dC, di)
+    fu = capi.unary(mop, u).numpy().astype(np.float64)
+    other = "cos" if mop != "cos" else "sin"
+    gu = capi.unary(other, u).numpy().astype(np.float64)
+    ii = idx.astype(np.int64)
+    cnt = np.bincount(ii, minlength=K)
+    x64 = x.astype(np.float64)
+
+    def check(got, terms, what):
+        tr = terms.astype(dtype).astype(np.float64)
+        ref = np.bincount(ii, weights=tr, minlength=K)
+        bound = EPS[dtype] * (cnt * np.bincount(ii, weights=np.abs(tr), minlength=K)) + 1e-300
+        err = np.abs(got.numpy().astype(np.float64) - ref)
+        assert (err <= bound).all(), (mop, what, float((err / bound).max()))
+
+    b = capi.Bucketed("fmadd", dA, dx, dC, di)
+    t0, t1 = up(capi, np.zeros(K, dtype)), up(capi, np.zeros(K, dtype))
+    b.scatter_add([t0, t1], [(mop, 0, False), (mop, 0, True)])                    # Spec: { f(u), x f(u) }
+    check(t0, fu, "spec plain"); check(t1, fu * x64, "spec weighted")
+    t0, t1 = up(capi, np.zeros(K, dtype)), up(capi, np.zeros(K, dtype))
+    b.scatter_add([t0, t1], [(mop, 0, False), (mop, 0, False)])                   # uniform, both unweighted
+    check(t0, fu, "uniform 0"); check(t1, fu, "uniform 1")
+    t0 = up(capi, np.zeros(K, dtype))
+    b.scatter_add([t0], [(mop, 0, True)])                                          # one stream
+    check(t0, fu * x64, "single weighted")
+    t0, t1 = up(capi, np.zeros(K, dtype)), up(capi, np.zeros(K, dtype))
+    b.scatter_add([t0, t1], [(mop, 0, False), (other, 0, True)])                  # two different ops: run-time form
+    check(t0, fu, "mixed 0"); check(t1, gu * x64, "mixed 1")
+    b.destroy()
+
+
 def launches(capi, fn):
     capi.profile_begin()
     fn()

@@ -110,3 +110,37 @@ def test_cpp_path_tracers_match_the_reference_build(entry):
     hits = np.maximum(np.ceil(np.maximum(g, rg) / (0.1 * 0.2 * 0.2)), 1.0)
     # (the dual numbers of the fused kernel form each derivative in another association than the tape's products: a few ulp per term)
     assert np.all(np.abs(g - rg) <= eps * (4 * hits + 8) * np.maximum(g, rg)), float((np.abs(g - rg) / np.maximum(g, 1e-30)).max())
+
+
+def test_fused_path_tracer_at_the_bench_size_matches_the_reference_build():
+    """The size bench.py quotes (16 Mi paths per GPU, its seed, K = 1 Mi): loss and texture gradient of the ONE fused kernel against
+    examples/path_trace.h instantiated on the reference's arrays (ref_cfg5: ~12 s and ~6 GB of host memory).  Same bounds as at
+    1 Mi paths; per texel ~48 hits instead of 3."""
+    import ctypes
+    import enoki_amd.hip as ekc
+    import oracle_lib as ol
+    from conftest import hsum_depth
+    try:
+        ref = ol.ref()
+    except Exception:
+        pytest.skip("oracle/_ref is not built")
+    ekc.hip_init(0)
+    from enoki_amd import synth
+    import bench
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "libpath_trace.so"))
+    n, width, K, seed = bench.N_PATHS_PER_GPU, 1024, bench.K_TABLE, 0x853c49e6748fea9b
+    assert n == 1 << 24 and K == width * width
+    tex = ekc.fmadd(synth.uniform_pm1(0, K, 8), ekc.Float32(0.3), ekc.Float32(0.5))        # bench.py's texture: albedo in [0.2, 0.8)
+    tex_np = tex.numpy()
+    ry, rg, _ = ref.cfg5(tex_np, n, seed=seed, first_lane=0, bounces=3, width=width)
+    loss, grad = ekc.Float32.empty(1), ekc.Float32.empty(K)
+    P = ctypes.c_void_p
+    rc = lib.path_trace_fused_device(P(tex.data_ptr()), ctypes.c_size_t(K), ctypes.c_size_t(n), ctypes.c_uint64(seed), ctypes.c_uint64(0), 3,
+                                     ctypes.c_uint32(width), P(loss.data_ptr()), P(grad.data_ptr()))
+    assert rc == 0
+    yv, g = float(loss.numpy()[0]), grad.numpy()
+    eps = 2.0 ** -24
+    assert abs(yv - ry) <= eps * (hsum_depth(n) + n // 8 + 8) * max(abs(ry), abs(yv)), (yv, ry)
+    assert np.array_equal(g == 0, rg == 0)                                    # the same texels are hit
+    hits = np.maximum(np.ceil(np.maximum(g, rg) / (0.1 * 0.2 * 0.2)), 1.0)
+    assert np.all(np.abs(g - rg) <= eps * (4 * hits + 8) * np.maximum(g, rg)), float((np.abs(g - rg) / np.maximum(g, 1e-30)).max())

@@ -54,6 +54,47 @@ def test_world_of_one(with_rccl):
         capi.check(lib.ek_hip_dist_finalize())
 
 
+@pytest.mark.gpu
+def test_one_rccl_copy_per_process():
+    """csrc/dist.cpp loads RCCL at run time.  In a python process torch has its own librccl.so mapped (the copy torch.distributed
+    talks to): the C-ABI exchange must reuse THAT copy instead of mapping /opt/rocm/lib/librccl.so next to it -- two RCCL runtimes
+    in one process have separate bootstrap state.  Checked in a fresh interpreter: torch first, then a 1-rank communicator
+    through the C ABI; exactly one librccl object may be mapped, and it is the one ek_hip_dist_rccl_path() names."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import ctypes, os, sys
+sys.path.insert(0, sys.argv[1])
+import torch
+torch.cuda.init()
+from enoki_amd import capi
+capi.init()
+lib = capi.lib
+lib.ek_hip_dist_rccl_path.restype = ctypes.c_char_p
+ident = (ctypes.c_char * 128)()
+capi.check(lib.ek_hip_dist_unique_id(ident))
+capi.check(lib.ek_hip_dist_init(0, 1, ident))
+import numpy as np
+buf = capi.Buf.from_numpy(np.arange(64, dtype=np.float32))
+capi.check(lib.ek_hip_dist_all_reduce(buf.ek, 0, ctypes.c_void_p(buf.ptr), ctypes.c_size_t(64)))
+capi.check(lib.ek_hip_dist_all_reduce(buf.ek, 0, None, ctypes.c_size_t(0)))        # n == 0: a no-op, not an error
+capi.sync()
+assert np.array_equal(buf.numpy(), np.arange(64, dtype=np.float32))
+capi.check(lib.ek_hip_dist_finalize())
+mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
+print("RCCL", lib.ek_hip_dist_rccl_path().decode(), "|", ";".join(mapped))
+'''
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("RCCL ")][-1]
+    used, mapped = line[5:].split(" | ")
+    mapped = [m for m in mapped.split(";") if m]
+    assert len(mapped) == 1, f"more than one RCCL copy mapped: {mapped}"
+    assert os.path.realpath(used) == os.path.realpath(mapped[0]), (used, mapped)
+    assert os.sep + "torch" + os.sep in os.path.realpath(used), f"expected torch's own copy, got {used}"
+
+
 WORKER = r"""
 import ctypes, os, sys, time
 import numpy as np

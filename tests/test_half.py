@@ -28,3 +28,21 @@ def test_every_reference_header_name_is_includable(tmp_path):
     out = subprocess.run(["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", "-c", os.path.join(HERE, "cpp", "headers_host.cpp"),
                           "-o", str(tmp_path / "headers_host.o")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
+
+
+def test_dynamic_array_alias_is_opt_in(tmp_path):
+    """include/enoki/dynamic.h: the reference's DynamicArray<Packet<T>> is a HOST array (reference dynamic.h:54-60).  Using the name
+    without -DENOKI_HIP_DYNAMIC_IS_DEVICE must stop the compilation with an explanation; with it the name is HIPArray<T>."""
+    root = os.path.dirname(HERE)
+    src = tmp_path / "dyn.cpp"
+    src.write_text("#include <enoki/dynamic.h>\n"
+                   "using FloatX = enoki::DynamicArray<enoki::Packet<float, 8>>;\n"
+                   "#if defined(ENOKI_HIP_DYNAMIC_IS_DEVICE)\n"
+                   "static_assert(std::is_same_v<FloatX, enoki::HIPArray<float>>);\n"
+                   "#endif\n"
+                   "size_t f() { return sizeof(FloatX); }\n")
+    cmd = ["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", "-fsyntax-only", str(src)]
+    off = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert off.returncode != 0 and "ENOKI_HIP_DYNAMIC_IS_DEVICE" in off.stderr and "HOST array" in off.stderr, off.stderr[-2000:]
+    on = subprocess.run(cmd + ["-DENOKI_HIP_DYNAMIC_IS_DEVICE=1"], capture_output=True, text=True, timeout=600)
+    assert on.returncode == 0, on.stderr[-2000:]

@@ -171,9 +171,15 @@ def test_denormals_are_not_flushed(capi, oracle):
     """the CPU reference does not set FTZ/DAZ (array_intrin.h:167-194); neither may the kernels"""
     a = np.array([1e-39, 2e-39, -3e-40, 1.17549435e-38, 1e-45] * 13, np.float32)
     b = np.array([0.5, 1.0, 2.0, 0.25, 1.0] * 13, np.float32)
-    for op in ["add", "mul", "sub"]:
-        got = capi.binary(op, up(capi, a), up(capi, b if op == "mul" else a)).numpy()
-        assert bits_equal(got, oracle.binary(op, a, b if op == "mul" else a)), op
+    for op in ["add", "mul", "sub", "safe_mul"]:
+        # (safe_mul is ONE v_mul_legacy_f32 on the device: denormal operands and results must behave like the literal
+        # compare-and-multiply form of the reference, autodiff.cpp:1191-1199)
+        second = b if op in ("mul", "safe_mul") else a
+        got = capi.binary(op, up(capi, a), up(capi, second)).numpy()
+        assert bits_equal(got, oracle.binary(op, a, second)), op
+    z = np.array([0.0, -0.0, 1e-45, -1e-45, 1e-39] * 13, np.float32)             # zeros and denormals against denormals / inf
+    w = np.array([1e-45, np.inf, 1e-45, 0.5, np.inf] * 13, np.float32)
+    assert bits_equal(capi.binary("safe_mul", up(capi, z), up(capi, w)).numpy(), oracle.binary("safe_mul", z, w))
     got = capi.ternary("fmadd", up(capi, a), up(capi, b), up(capi, a)).numpy()
     assert bits_equal(got, oracle.ternary("fmadd", a, b, a))
     assert np.any((got != 0) & (np.abs(got) < 1.17549435e-38))     # denormal results survive

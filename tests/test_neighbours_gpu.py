@@ -102,3 +102,37 @@ def test_neighbour_matches_the_reference_and_stays_in_bucket_order(ad, ref, data
     assert not any(k in ks for k in ("gather_pair_fmadd", "gather", "scatter_add_partition", "scatter_add_count", "hsum_map")), (name, ks)
     if name in EARLY:
         assert ks.get("bucket_pair_fma_reduce_adjoint") == 1 and "bucket_accumulate" not in ks, (name, ks)
+
+
+@pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
+@pytest.mark.parametrize("order", ["bucket", "element"])
+def test_masked_out_lane_with_non_finite_x_is_nan_like_the_reference(ad, ref, data, bad, order):
+    """A lane whose mask bit is clear gathers 0 from both tables (cuda.h:845-864): u = fma(0, x, 0), and for an infinite or NaN x
+    that is NaN -- the reference's lane-by-lane hsum (dynamic.h:632-650) then is NaN.  The bucket-ordered path DROPS masked-out
+    lanes in the partition; it must say NaN all the same (round 4 said f(0)), while the gradients -- the masked scatter_add drops
+    the lane (cuda.h:892-905) -- are those of the finite lanes.  Checked against the reference build on the same inputs, in
+    bucket order and in element order (ENOKI_HIP tuning bucket_ordered = 0)."""
+    A, B, x, idx, mask = data
+    x = x.copy()
+    off = np.flatnonzero(~mask)
+    x[off[off.size // 3]] = bad
+    ry, rgA, rgB, _ = ref.cfg3b_variant(A, B, x, idx, mask=mask)
+    assert np.isnan(ry), "the reference itself: masked-out lane, non-finite x -> NaN"
+    if order == "element":
+        ad.hip_set_tuning("bucket_ordered", 0)
+    try:
+        (y, gA, gB), ks = kernels(ad, lambda: run(ad, A, B, x, idx, mask=mask))
+    finally:
+        ad.hip_set_tuning("bucket_ordered", 1)
+    assert np.isnan(y), (order, y)
+    if order == "bucket":
+        assert ks.get("bucket_partition") == 1 and "gather_pair_fmadd" not in ks, ks
+    xf = x.copy(); xf[~mask] = 0.0            # what the masked-out lanes hold does not reach the gradients
+    t = cfg3b_variant_truth(A, B, xf, idx, mask=mask)
+    for g, arr, r in (("gA", gA, rgA), ("gB", gB, rgB)):
+        assert np.all(np.isfinite(arr)) and np.all(np.isfinite(r)), g
+        assert np.all(np.abs(arr - t[g]) <= t[g + "_bound"]), (order, g)
+        assert np.all(np.abs(arr - r) <= 2 * t[g + "_bound"]), (order, g)
+    # a finite x under every cleared mask bit: the masked-out lanes enter as f(0) = 0, the result is finite again
+    (y2, _, _), _ = kernels(ad, lambda: run(ad, A, B, xf, idx, mask=mask))
+    assert np.isfinite(y2) and abs(y2 - t["y"]) <= t["y_stat_bound"]
