@@ -42,7 +42,7 @@ K_TABLE = 1 << 20
 DESCRIPTION = {
     "cfg3b": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)), a=gather(A,idx), b=gather(B,idx), K=1Mi; backward() with scatter_add grads",
     "cfg3a": "DiffArray<HIPArray<float>> y=hsum(sin(a*x+b)); backward(), a,b leaves of size N",
-    "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b))))",
+    "cfg2": "HIPArray<float> hsum(sin(exp(fmadd(a,x,b)))): ONE pass over a, x, b (the fma and both maps stay unevaluated until the reduction consumes the chain, ek_hip_reduce_chain)",
     "cfg4": "ray-sphere (tests/sphere.cpp:58-83): masked gather of a 16384^2-style pixel grid through a random "
             "permutation, make_rays/intersect_rays/shade_hits, masked scatter, count(hit); 32 Mi rays per GPU; ONE fused "
             "kernel through enoki::vectorize() (examples/sphere_fused.cpp)",
@@ -61,10 +61,14 @@ CFG3B_VARIANTS = {
     "cfg3b_i64": dict(idx64=True), "cfg3b_K2Mi": dict(K=1 << 21), "cfg3b_K4Mi": dict(K=1 << 22), "cfg3b_K16Mi": dict(K=1 << 24),
     "cfg3b_sqrt": dict(func="sqrt", shift=3.0),          # (B + 3: u > 0; the derivative's factor .5 / sqrt(u) is a function of u)
     "cfg3b_rcp": dict(func="rcp", shift=3.0),            # (the derivative's factor -sqr(rcp(u)) as ONE map of u)
+    # u written with OPERATORS, the literal spelling of BASELINE.json configs[2] (`y=hsum(sin(a*x+b))`): a product and a sum with a
+    # rounding each -- the same bucket-ordered step (round 4: 48 Gelem/s in element order)
+    "cfg3b_operators": dict(spelling="a*x+b"),
+    "cfg3b_operators_sub": dict(spelling="b-a*x", func="cos"),
 }
 for _w, _v in CFG3B_VARIANTS.items():
     DESCRIPTION[_w] = ("cfg3b with " + ", ".join(f"{k}={v}" for k, v in _v.items()) +
-                       " (y = seed * hsum(func(fmadd(gather(A, idx, mask), x, gather(B, idx, mask)))), backward(); 75 % mask of SURVEY 8d)")
+                       " (y = seed * hsum(func(fmadd(gather(A, idx, mask), x, gather(B, idx, mask)))), backward(); 75 % mask of SURVEY 8d; spelling: u written with operators)")
 N_RAYS_PER_GPU = 1 << 25
 N_PATHS_PER_GPU = 1 << 24
 DESCRIPTION["cfg5_unfused"] = "cfg5 spelled op by op with the python bindings (every operation one kernel, three gather nodes on the tape)"
@@ -79,7 +83,8 @@ PMC_SYMBOL = {"bucket_accumulate": "k_bucket_accumulate", "bucket_partition": "k
               "bucket_pair_fma_reduce_adjoint": "k_bucket_pair_forward_adjoint",
               "bucket_count": "k_bin_count", "gather_pair_fmadd": "k_map_gathered<GTernary<0", "gather": "k_gather", "scatter_add_partition": "k_bin_partition", "scatter_add_accumulate": "k_bin_accumulate",
               "scatter_add_count": "k_bin_count", "fmadd": "k_map3<TernaryOp<0", "sincos": "k_map1x2<SinCosOp",
-              "safe_mul": "k_map2<BinaryOp<13", "hsum": "k_reduce_stage1", "sin": "k_map1<UnaryOp<10", "exp": "k_map1<UnaryOp<12"}
+              "safe_mul": "k_map2<BinaryOp<13", "hsum": "k_reduce_stage1", "sin": "k_map1<UnaryOp<10", "exp": "k_map1<UnaryOp<12",
+              "reduce_chain": "k_chain_reduce", "map_chain": "k_chain_map"}
 
 
 def parse():
@@ -327,7 +332,9 @@ class Bench:
                     a = ek.gather(A, idx, mask); b = ek.gather(B, idx, mask)
                 else:
                     a = ek.gather(A, idx); b = ek.gather(B, idx)
-                y = ek.hsum(func(ek.fmadd(a, xd, b)))
+                sp = var.get("spelling", "fmadd")
+                u = ek.fmadd(a, xd, b) if sp == "fmadd" else a * xd + b if sp == "a*x+b" else b - a * xd
+                y = ek.hsum(func(u))
                 if seed != 1.0:
                     y = y * seed
                 ek.backward(y)

@@ -29,7 +29,7 @@ UNARY = {n: i for i, n in enumerate(
 BINARY = {n: i for i, n in enumerate(
     ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
      "atan2", "pow", "fmod", "ldexp"])}
-TERNARY = {n: i for i, n in enumerate(["fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd"])}
+TERNARY = {n: i for i, n in enumerate(["fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd", "muladd", "mulsub", "nmuladd"])}
 COMPARE = {n: i for i, n in enumerate(["eq", "neq", "lt", "le", "gt", "ge"])}
 REDUCE = {n: i for i, n in enumerate(["hsum", "hprod", "hmin", "hmax"])}
 MASK_REDUCE = {n: i for i, n in enumerate(["all", "any", "count"])}
@@ -43,7 +43,7 @@ EXPORTS = [
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
-    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
+    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_reduce_chain", "ek_hip_map_chain", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
     "ek_hip_dist_unique_id", "ek_hip_dist_init", "ek_hip_dist_world", "ek_hip_dist_shard_range", "ek_hip_dist_all_reduce",
     "ek_hip_dist_reduce_scatter", "ek_hip_dist_all_gather", "ek_hip_dist_finalize", "ek_hip_dist_rccl_path",
     "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_pair_create_masked", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add", "ek_hip_bucketed_scatter_add_scaled", "ek_hip_bucketed_early_pair",
@@ -391,6 +391,42 @@ def scatter_add_multi(targets, values, index, mask=True, weights=None, n=None, m
     check(lib.ek_hip_scatter_add_multi(targets[0].ek, index.ek, count, bases, ctypes.c_size_t(targets[0].n), vals,
                                        wts if weights is not None else None, ctypes.byref(oi), ctypes.byref(om),
                                        ctypes.c_size_t(n), mode))
+
+
+class Chain(ctypes.Structure):
+    """ek_chain: base(src[0 .. arity)) under n_maps unary ops, evaluated in one pass (ek_hip_reduce_chain / ek_hip_map_chain)"""
+    _fields_ = [("arity", ctypes.c_int), ("base_op", ctypes.c_int), ("src", Operand * 3), ("n_maps", ctypes.c_int),
+                ("map_ops", ctypes.c_int * 3)]
+
+
+def _chain(base, srcs, maps):
+    dt = _dtype(*srcs); n = _n(*srcs)
+    ch = Chain()
+    ch.arity = len(srcs)
+    ch.base_op = 0 if len(srcs) == 1 else (BINARY if len(srcs) == 2 else TERNARY)[base]
+    for k, x in enumerate(srcs):
+        ch.src[k] = operand(x, dt)
+    ch.n_maps = len(maps)
+    for k, m in enumerate(maps):
+        ch.map_ops[k] = UNARY[m]
+    return ch, dt, n
+
+
+def reduce_chain(op, base, srcs, maps):
+    """op over maps[-1](.. maps[0](base(*srcs))) in ONE pass over the operands (ek_hip_reduce_chain); base: None for one source,
+    "add" | "sub" | "mul" for two, the fma family / "muladd" | "mulsub" | "nmuladd" for three"""
+    ch, dt, n = _chain(base, srcs, maps)
+    out = Buf(dt, 1)
+    check(lib.ek_hip_reduce_chain(REDUCE[op], NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(ch), ctypes.c_size_t(n)))
+    return out
+
+
+def map_chain(base, srcs, maps):
+    """the same chain written out (ek_hip_map_chain)"""
+    ch, dt, n = _chain(base, srcs, maps)
+    out = Buf(dt, n)
+    check(lib.ek_hip_map_chain(NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(ch), ctypes.c_size_t(n)))
+    return out
 
 
 def reduce_map(op, map_op, a):

@@ -110,6 +110,14 @@ template <typename T> __device__ __forceinline__ T bucket_shfl_down(T v, int del
 template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c) {
     if constexpr (sizeof(T) == 4) return __builtin_fmaf(a, b, c); else return __builtin_fma(a, b, c);
 }
+// u of one element: fma(a, x, c), or -- `a * x + c` written with operators, EK_MULADD / EK_MULSUB / EK_NMULADD -- the product and
+// the sum with a rounding each (this translation unit is built with -ffp-contract=off).  `two` is uniform over the launch: both
+// forms are two or three vector instructions next to the ~50 of the function that follows, so it is a select, not a kernel.
+template <typename T> __device__ __forceinline__ T pair_value(T a, T x, T c, int two) {
+    const T p = a * x;
+    const T s = p + c, f = fma_t(a, x, c);
+    return two ? s : f;
+}
 
 // ---- where a bucket's elements are ----------------------------------------------------------------------------------
 // Two layouts of the bucket-ordered lists (l16, x_b and what is kept next to them):
@@ -321,6 +329,7 @@ struct ForwardBody {
     const uint16_t *pair_idx;
     const T *x_b, *kept;
     uint32_t lmask;
+    int two;                 // != 0: u = a * x + c with a rounding each (EK_MULADD family) instead of one fma
     T acc[4];
 
     __device__ __forceinline__ T elem(uint32_t l, T x, int slot) {
@@ -329,7 +338,7 @@ struct ForwardBody {
             u = x;
         } else {
             const PairRec<T> r = rec[l & lmask];
-            u = fma_t(r.a, x, r.c);
+            u = pair_value(r.a, x, r.c, two);
         }
         if constexpr (KeepPartner) {
             static_assert(Map == EK_SIN || Map == EK_COS);
@@ -385,7 +394,7 @@ struct ForwardBody {
 template <typename T, int ROp, int V, int PS, bool FromKept = false>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__restrict__ partials, T *__restrict__ u_out,
                                                                         const T *__restrict__ table_a, const T *__restrict__ table_c,
-                                                                        size_t table_size, int flip_a, int flip_c,
+                                                                        size_t table_size, int flip_a, int flip_c, int two,
                                                                         const uint16_t *__restrict__ pair_idx,
                                                                         const T *__restrict__ x_b, const T *__restrict__ kept,
                                                                         BucketLists bl, int map_op, int keep_partner, int shift,
@@ -410,7 +419,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
 
     T result = R::identity();
     auto run = [&](auto body) {
-        body.rec = rec; body.u_out = u_out; body.pair_idx = pair_idx; body.x_b = x_b; body.kept = kept; body.lmask = lmask;
+        body.rec = rec; body.u_out = u_out; body.pair_idx = pair_idx; body.x_b = x_b; body.kept = kept; body.lmask = lmask; body.two = two;
 #pragma unroll
         for (int k = 0; k < 4; ++k) body.acc[k] = R::identity();
         walk_piece<PS, V>(bl, range, body);
@@ -550,6 +559,49 @@ __device__ __forceinline__ bool lds_try_add_pair(unsigned long long *table, unsi
     const bool met = (unsigned) old == kLockedBits;
     __hip_atomic_store(met ? dummy : p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return met;
+}
+
+// ---- the same sums WITHOUT locks: compare-and-swap on the {t0, t1} pair ------------------------------------------------------
+// (EK_EARLY_CAS builds; measured against the exchange locks in profiles/probe_early_r05.txt.)  A lock is held for an LDS round
+// trip, and every claim that another wave meets in that time costs the other wave a retry round -- which is why more claims in
+// flight per lane made the lock protocol slower (199 / 165 / 149 / 143 us for 8 / 4 / 2 / 1, round 4).  A compare-and-swap holds
+// nothing: a lane reads the pairs of ALL its elements of a step together with their table records (the reads' round trip
+// overlaps the arithmetic), then issues all its swaps together; a swap fails only if somebody changed that entry in between, and
+// then only that slot goes again with the value the failed swap returned.  Two dependent LDS round trips per step instead of
+// one per element.
+__device__ __forceinline__ unsigned long long pair_sum_plain(unsigned long long old, float v0, float v1) {
+    return (unsigned long long) __float_as_uint(__uint_as_float((unsigned) old) + v0) |
+           ((unsigned long long) __float_as_uint(__uint_as_float((unsigned) (old >> 32)) + v1) << 32);
+}
+
+__device__ __forceinline__ void lds_cas_add_pair(unsigned long long *p, float v0, float v1, bool on) {
+    if (!on) return;
+    unsigned long long old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), assumed;
+    do {
+        assumed = old;
+        old = atomicCAS(p, assumed, pair_sum_plain(assumed, v0, v1));
+    } while (old != assumed);
+}
+
+template <int N>
+__device__ __forceinline__ void lds_cas_add_pair_batch(unsigned long long *table, const uint32_t (&l)[N], unsigned long long (&old)[N],
+                                                       const float (&v0)[N], const float (&v1)[N]) {
+    unsigned long long got[N];
+#pragma unroll
+    for (int j = 0; j < N; ++j) got[j] = atomicCAS(table + l[j], old[j], pair_sum_plain(old[j], v0[j], v1[j]));
+    unsigned pending = 0;
+#pragma unroll
+    for (int j = 0; j < N; ++j) pending |= got[j] != old[j] ? 1u << j : 0u;
+    while (__builtin_amdgcn_ballot_w64(pending != 0)) {
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            if ((pending >> j) & 1u) {
+                old[j] = got[j];
+                got[j] = atomicCAS(table + l[j], old[j], pair_sum_plain(old[j], v0[j], v1[j]));
+                if (got[j] == old[j]) pending &= ~(1u << j);
+            }
+        }
+    }
 }
 
 // the slots of `pending` once more, their exchanges in flight together (the locks they met have been released long since); what
@@ -850,12 +902,13 @@ struct EarlyBody {
     const T *x_b;
     int Bins;
     uint32_t lmask;
+    int two;                 // see pair_value()
     T acc[4];
 
     // reduced value into `sum`, kept function m and x * m out
     __device__ __forceinline__ void values(uint32_t l, T x, T &sum, T &v0, T &v1) const {
         const PairRec<T> r = rec[l];
-        EarlyPair<Map, Keep, T>::apply(fma_t(r.a, x, r.c), sum, v0);
+        EarlyPair<Map, Keep, T>::apply(pair_value(r.a, x, r.c, two), sum, v0);
         v1 = dev::safe_mul(x, v0);
     }
     __device__ __forceinline__ void one(size_t pos, bool on, int slot) {
@@ -864,7 +917,11 @@ struct EarlyBody {
         values(l, on ? x_b[pos] : T(0), sum, v0, v1);
         if (on) acc[slot] += sum;
         if constexpr (Paired) {
+#ifdef EK_EARLY_CAS
+            lds_cas_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
+#else
             lds_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
+#endif
         } else {
             lds_add<true>(&tables[l], v0, on);
             lds_add<true>(&tables[Bins + l], v1, on);
@@ -894,12 +951,27 @@ struct EarlyBody {
                 l[k] = (uint32_t) s.pi[k / 4].v[k % 4] & lmask;
                 r[k] = rec[l[k]];
             }
+#ifdef EK_EARLY_CAS
+            unsigned long long old[NB];
+#pragma unroll
+            for (int k = 0; k < NB; ++k) old[k] = __hip_atomic_load(tb + l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                const T x = s.px[k / 4][k % 4];
+                T sum;
+                EarlyPair<Map, Keep, T>::apply(pair_value(r[k].a, x, r[k].c, two), sum, v0[k]);
+                v1[k] = dev::safe_mul(x, v0[k]);
+                acc[k % 4] += sum;
+            }
+            lds_cas_add_pair_batch<NB>(tb, l, old, v0, v1);
+            return;
+#endif
             unsigned pending = 0;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
                 const T x = s.px[k / 4][k % 4];
                 T sum;
-                EarlyPair<Map, Keep, T>::apply(fma_t(r[k].a, x, r[k].c), sum, v0[k]);
+                EarlyPair<Map, Keep, T>::apply(pair_value(r[k].a, x, r[k].c, two), sum, v0[k]);
                 v1[k] = dev::safe_mul(x, v0[k]);
                 acc[k % 4] += sum;
                 pending |= lds_try_add_pair(tb, dummy, l[k], v0[k], v1[k]) ? 1u << k : 0u;
@@ -936,7 +1008,7 @@ template <typename T, int V, int PS>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
                                                                                 const T *__restrict__ table_a,
                                                                                 const T *__restrict__ table_c, size_t table_size,
-                                                                                int flip_a, int flip_c,
+                                                                                int flip_a, int flip_c, int two,
                                                                                 const uint16_t *__restrict__ pair_idx,
                                                                                 const T *__restrict__ x_b, BucketLists bl,
                                                                                 int map_op, int keep_op, int shift, BucketFinish<T> fin) {
@@ -958,7 +1030,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     T v = T(0);
     auto run = [&](auto body) {
         body.rec = rec; body.tables = tables; body.pair_idx = pair_idx; body.x_b = x_b; body.Bins = Bins;
-        body.lmask = (uint32_t) Bins - 1u; body.dummy = &s_dummy;
+        body.lmask = (uint32_t) Bins - 1u; body.dummy = &s_dummy; body.two = two;
 #pragma unroll
         for (int k = 0; k < 4; ++k) body.acc[k] = T(0);
         walk_piece<PS, V>(bl, range, body);
@@ -1029,6 +1101,10 @@ struct Bucketed {
     template <typename T> BucketFinish<T> finish(void *out, int zero_op) const {
         return BucketFinish<T>{ ticket, (T *) out, masked_ptr(), n, zero_op };
     }
+    // signs applied ONCE to the staged table entries (exact): fmsub / mulsub: -c;  fnmadd / nmuladd (c - a x = (-a) x + c): -a;  fnmsub: both
+    int flip_a() const { return op == EK_FNMADD || op == EK_FNMSUB || op == EK_NMULADD; }
+    int flip_c() const { return op == EK_FMSUB || op == EK_FNMSUB || op == EK_MULSUB; }
+    int two_roundings() const { return op == EK_MULADD || op == EK_MULSUB || op == EK_NMULADD; }
     size_t bins() const { return (size_t) 1 << shift; }
     BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
     ~Bucketed() {
@@ -1248,12 +1324,12 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     void **kept = partner ? &b->m_b : &b->u_b;
     if (keep && !*kept)
         if (int rc = ek_hip_malloc(b->positions * sizeof(T), kept)) return rc;
-    const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
+    const int flip_a = b->flip_a(), flip_c = b->flip_c(), two = b->two_roundings();
     EK_BY_LAYOUT(b, {
         if (int rc = allow_big_lds(k_bucket_pair_forward<T, ROp, VV, PS>, lds)) return rc;
         hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
                            (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
-                           (const T *) b->table_c, b->table_size, flip_a, flip_c, (const uint16_t *) b->pair_idx,
+                           (const T *) b->table_c, b->table_size, flip_a, flip_c, two, (const uint16_t *) b->pair_idx,
                            (const T *) b->x_b, (const T *) nullptr, b->lists(), map_op, partner ? 1 : 0, b->shift,
                            b->template finish<T>(out, map_op));
     });
@@ -1278,7 +1354,7 @@ static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const
     constexpr int VV = sizeof(T) == 8 ? 1 : 2;
     EK_BY_LAYOUT(b, {
         hipLaunchKernelGGL((k_bucket_pair_forward<T, ROp, VV, PS, true>), dim3(b->max_pieces), dim3(kBucketThreads), 0, c.stream,
-                           (T *) b->reduce_partials, (T *) nullptr, (const T *) nullptr, (const T *) nullptr, b->table_size, 0, 0,
+                           (T *) b->reduce_partials, (T *) nullptr, (const T *) nullptr, (const T *) nullptr, b->table_size, 0, 0, 0,
                            (const uint16_t *) b->pair_idx, (const T *) b->x_b, (const T *) values, b->lists(), map_op, 0, b->shift,
                            b->template finish<T>(out, zero_op));
     });
@@ -1314,15 +1390,19 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
     Context &c = ctx();
     const size_t Bins = b->bins();
     const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
+#ifdef EK_EARLY_VV
+    constexpr int VV = EK_EARLY_VV;
+#else
     constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.151 ms against 0.143, same box)
+#endif
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
-    const int flip_a = b->op == EK_FNMADD || b->op == EK_FNMSUB, flip_c = b->op == EK_FMSUB || b->op == EK_FNMSUB;
+    const int flip_a = b->flip_a(), flip_c = b->flip_c(), two = b->two_roundings();
     EK_BY_LAYOUT(b, {
         if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV, PS>, lds)) return rc;
         hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
                            (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
-                           flip_a, flip_c, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift,
+                           flip_a, flip_c, two, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift,
                            b->template finish<T>(out, map_op));
     });
     EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
@@ -1584,8 +1664,8 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
     if (int rc = ensure_init()) return rc;
     if (!out || !table_a || !table_c || !x || !index) return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): null pointer");
     *out = nullptr;
-    if (op != EK_FMADD && op != EK_FMSUB && op != EK_FNMADD && op != EK_FNMSUB)
-        return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): op %d is not of the fma family", op);
+    if (op != EK_FMADD && op != EK_FMSUB && op != EK_FNMADD && op != EK_FNMSUB && op != EK_MULADD && op != EK_MULSUB && op != EK_NMULADD)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): op %d is neither of the fma family nor a product-then-sum", op);
     if (!ek_hip_bucketed_applicable(type, index_type, table_size, n))
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): shape not covered (type %d, %zu lookups into %zu entries%s)",
                     type, n, table_size, ctx().tuning.deterministic ? ", deterministic mode" : "");

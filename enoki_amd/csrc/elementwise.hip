@@ -21,7 +21,7 @@ static const char *const unary_names[EK_UNARY_COUNT] = {
 static const char *const binary_names[EK_BINARY_COUNT] = {
     "add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
     "atan2", "pow", "fmod", "ldexp" };
-static const char *const ternary_names[EK_TERNARY_COUNT] = { "fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd" };
+static const char *const ternary_names[EK_TERNARY_COUNT] = { "fmadd", "fmsub", "fnmadd", "fnmsub", "safe_fmadd", "muladd", "mulsub", "nmuladd" };
 
 
 struct SinCoshOp {
@@ -160,6 +160,10 @@ template <int Op, typename T> struct TernaryOp {
             else if constexpr (Op == EK_FMSUB) return fma_(x, y, -z);
             else if constexpr (Op == EK_FNMADD) return fma_(-x, y, z);
             else if constexpr (Op == EK_FNMSUB) return fma_(-x, y, -z);
+            // two roundings (the translation unit is built with -ffp-contract=off: a product and a sum never fuse)
+            else if constexpr (Op == EK_MULADD) return x * y + z;
+            else if constexpr (Op == EK_MULSUB) return x * y - z;
+            else if constexpr (Op == EK_NMULADD) return z - x * y;
             else return dev::safe_fmadd(x, y, z);
         } else {
             // integer mad.lo (cuda.h:387-394)
@@ -174,7 +178,7 @@ template <int Op, typename T> struct TernaryOp {
 
 template <int Op, typename T>
 int ternary_launch(void *out, const ek_operand *a, const ek_operand *b, const ek_operand *c, size_t n) {
-    if constexpr (is_mask<T> || (Op == EK_SAFE_FMADD && !is_fp<T>)) {
+    if constexpr (is_mask<T> || ((Op == EK_SAFE_FMADD || Op == EK_MULADD || Op == EK_MULSUB || Op == EK_NMULADD) && !is_fp<T>)) {
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_ternary(): op %d is not defined for this type", Op);
     } else {
         Arg<T> aa, bb, cc;
@@ -191,6 +195,7 @@ int ternary_dispatch(int op, void *out, const ek_operand *a, const ek_operand *b
     switch (op) {
         EK_TERNARY_CASE(EK_FMADD) EK_TERNARY_CASE(EK_FMSUB) EK_TERNARY_CASE(EK_FNMADD)
         EK_TERNARY_CASE(EK_FNMSUB) EK_TERNARY_CASE(EK_SAFE_FMADD)
+        EK_TERNARY_CASE(EK_MULADD) EK_TERNARY_CASE(EK_MULSUB) EK_TERNARY_CASE(EK_NMULADD)
         default: return fail(EK_ERR_INVALID, "ek_hip_ternary(): unknown op %d", op);
     }
 }

@@ -44,6 +44,10 @@ template <int Op, typename T> struct GTernary {
         if constexpr (Op == EK_FMADD) return fma_(x, y, z);
         else if constexpr (Op == EK_FMSUB) return fma_(x, y, -z);
         else if constexpr (Op == EK_FNMADD) return fma_(-x, y, z);
+        // the operator spellings: a product and a sum with a rounding each (-ffp-contract=off: never fused)
+        else if constexpr (Op == EK_MULADD) return x * y + z;
+        else if constexpr (Op == EK_MULSUB) return x * y - z;
+        else if constexpr (Op == EK_NMULADD) return z - x * y;
         else return fma_(-x, y, -z);
     }
 };
@@ -179,8 +183,11 @@ int map_gathered(int arity, int op, void *out, const ek_operand *const *o, const
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_gathered(): binary op %d cannot consume a gather", op);
     }
     if (arity != 3) return fail(EK_ERR_INVALID, "ek_hip_map_gathered(): arity must be 2 or 3");
-    if (op != EK_FMADD && op != EK_FMSUB && op != EK_FNMADD && op != EK_FNMSUB)
+    const bool two_roundings = op == EK_MULADD || op == EK_MULSUB || op == EK_NMULADD;
+    if (op != EK_FMADD && op != EK_FMSUB && op != EK_FNMADD && op != EK_FNMSUB && !two_roundings)
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_gathered(): ternary op %d cannot consume a gather", op);
+    if (two_roundings && !(g[2] && (g[0] || g[1])))
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_gathered(): op %d takes a gathered factor AND a gathered addend", op);
     const ek_operand *oa = o[0], *ob = o[1];
     const ek_gathered *g0 = g[0], *g1 = g[1], *g2 = g[2];
     if (g0 && g1) return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_gathered(): both factors of the product are gathered");
@@ -226,10 +233,13 @@ int map_gathered(int arity, int op, void *out, const ek_operand *const *o, const
            : slot == G_SLOT_C ? launch_gathered<GTernary<OP, T>, T, 3, G_SLOT_C>("gather_" NAME, outp, n, ga, s0, s1)         \
                               : launch_gathered<GTernary<OP, T>, T, 3, G_SLOT_PAIR>("gather_pair_" NAME, outp, n, ga, s0, s1); \
         break;
+#define EK_G3_PAIR(OP, NAME) case OP: rc = launch_gathered<GTernary<OP, T>, T, 3, G_SLOT_PAIR>("gather_pair_" NAME, outp, n, ga, s0, s1); break;
     switch (op) {
         EK_G3(EK_FMADD, "fmadd") EK_G3(EK_FMSUB, "fmsub") EK_G3(EK_FNMADD, "fnmadd") EK_G3(EK_FNMSUB, "fnmsub")
+        EK_G3_PAIR(EK_MULADD, "muladd") EK_G3_PAIR(EK_MULSUB, "mulsub") EK_G3_PAIR(EK_NMULADD, "nmuladd")
         default: break;
     }
+#undef EK_G3_PAIR
 #undef EK_G3
     if (pair_table) ek_hip_free(pair_table);     // stream-ordered reuse: the kernel above is already enqueued
     return rc;

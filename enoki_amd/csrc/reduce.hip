@@ -243,6 +243,169 @@ template <typename T> int reduce_map_dispatch(int op, int map, void *out, const 
     }
 }
 
+// ---- chains: base(src0, src1, src2) under up to three unary maps, applied while the operands are loaded -------------------
+// What the reference's JIT does with hsum(sin(exp(fmadd(a, x, b)))) -- BASELINE configs[1] -- is ONE kernel that reads a, x, b and
+// writes a partial sum per block (src/cuda/jit.cu:1066-1217 assemble, :1418-1508 eval): 12 B/elt.  Run op by op the same
+// expression moves 36 B/elt, with the reduction applying its last map on load 28.  HIPArray leaves the fma AND the maps on top
+// of it unevaluated (include/enoki/hip.h, kind 4 / kind 1 nodes); the reduction that finally consumes the chain gets it as a
+// DESCRIPTOR -- a base op over at most three operands and at most three unary op codes -- not as a kernel per combination:
+// a lane holds one 16-byte vector of every operand, and each stage is a wave-uniform switch AROUND the loop over the
+// vector's elements, so every op body exists once per kernel and the switch costs a scalar branch per stage and vector.
+// Same functors as the one-op kernels (UnaryOp / TernaryOp bodies): the values are bit-identical to the op-by-op evaluation.
+enum { CH_COPY = 0, CH_ADD, CH_SUB, CH_MUL, CH_TERNARY };     // + ek_ternary_op
+
+template <typename T> struct ChainArgs {
+    Arg<T> src[3];
+    int base, n_maps;
+    int map_ops[3];
+};
+
+template <typename T, int E>
+__device__ __forceinline__ void chain_apply(T (&r)[E], const T (&b)[E], const T (&c)[E], const ChainArgs<T> &ch) {
+    auto fma_ = [](T x, T y, T z) -> T {
+        if constexpr (sizeof(T) == 4) return __builtin_fmaf(x, y, z); else return __builtin_fma(x, y, z);
+    };
+#define EK_CH_BASE(CODE, EXPR) case CODE: _Pragma("unroll") for (int e = 0; e < E; ++e) r[e] = (EXPR); break;
+    switch (ch.base) {
+        EK_CH_BASE(CH_ADD, r[e] + b[e]) EK_CH_BASE(CH_SUB, r[e] - b[e]) EK_CH_BASE(CH_MUL, r[e] * b[e])
+        EK_CH_BASE(CH_TERNARY + EK_FMADD, fma_(r[e], b[e], c[e])) EK_CH_BASE(CH_TERNARY + EK_FMSUB, fma_(r[e], b[e], -c[e]))
+        EK_CH_BASE(CH_TERNARY + EK_FNMADD, fma_(-r[e], b[e], c[e])) EK_CH_BASE(CH_TERNARY + EK_FNMSUB, fma_(-r[e], b[e], -c[e]))
+        EK_CH_BASE(CH_TERNARY + EK_MULADD, r[e] * b[e] + c[e]) EK_CH_BASE(CH_TERNARY + EK_MULSUB, r[e] * b[e] - c[e])
+        EK_CH_BASE(CH_TERNARY + EK_NMULADD, c[e] - r[e] * b[e])
+        default: break;                                                     // CH_COPY
+    }
+#undef EK_CH_BASE
+#define EK_CH_MAP(OP) case OP: _Pragma("unroll") for (int e = 0; e < E; ++e) r[e] = UnaryOp<OP, T>::apply(r[e]); break;
+    for (int s = 0; s < ch.n_maps; ++s) {
+        switch (ch.map_ops[s]) {
+            EK_CH_MAP(EK_NEG) EK_CH_MAP(EK_ABS) EK_CH_MAP(EK_SQRT) EK_CH_MAP(EK_RCP) EK_CH_MAP(EK_RSQRT) EK_CH_MAP(EK_SIN)
+            EK_CH_MAP(EK_COS) EK_CH_MAP(EK_EXP) EK_CH_MAP(EK_LOG) EK_CH_MAP(EK_RCP_SQR) EK_CH_MAP(EK_RSQRT_SQR) EK_CH_MAP(EK_RSQRT_CUBE)
+            default: break;
+        }
+    }
+#undef EK_CH_MAP
+}
+
+template <typename T, int N>
+__device__ __forceinline__ void chain_load(const ChainArgs<T> &ch, const T (&s)[3], size_t e, size_t n, bool fast, T (&r)[N], T (&b)[N], T (&c)[N]) {
+    const Pack<T, N> p0 = arg_load<T, N, true>(ch.src[0], s[0], e, n, fast), p1 = arg_load<T, N, true>(ch.src[1], s[1], e, n, fast),
+                     p2 = arg_load<T, N, true>(ch.src[2], s[2], e, n, fast);
+#pragma unroll
+    for (int i = 0; i < N; ++i) { r[i] = p0.v[i]; b[i] = p1.v[i]; c[i] = p2.v[i]; }
+}
+
+template <typename R, typename T>
+__global__ __launch_bounds__(256) void k_chain_reduce(T *__restrict__ partials, size_t n, int vec_ok, ChainArgs<T> ch) {
+    constexpr int N = 16 / sizeof(T);
+    T s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = ch.src[k].vec ? T(0) : arg_scalar(ch.src[k]);
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256, nvec = (n + N - 1) / N;
+    T acc[N];
+#pragma unroll
+    for (int i = 0; i < N; ++i) acc[i] = R::identity();
+    for (size_t v = gid; v < nvec; v += total) {
+        const size_t e = v * N;
+        const bool whole = e + N <= n;
+        T r[N], b[N], c[N];
+        chain_load<T, N>(ch, s, e, n, vec_ok && whole, r, b, c);
+        chain_apply<T, N>(r, b, c, ch);
+#pragma unroll
+        for (int i = 0; i < N; ++i)
+            if (whole || e + i < n) acc[i] = R::combine(acc[i], r[i]);
+    }
+    T v = acc[0];
+#pragma unroll
+    for (int i = 1; i < N; ++i) v = R::combine(v, acc[i]);
+    v = block_reduce<R>(v);
+    if (threadIdx.x == 0) partials[blockIdx.x] = v;
+}
+
+// the same chain written out (what forcing an unevaluated chain costs: one pass instead of one per op)
+template <typename T>
+__global__ __launch_bounds__(256) void k_chain_map(T *__restrict__ out, size_t n, int vec_ok, ChainArgs<T> ch) {
+    constexpr int N = 16 / sizeof(T);
+    T s[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) s[k] = ch.src[k].vec ? T(0) : arg_scalar(ch.src[k]);
+    const size_t e = lane_elem<N, 1>(0);
+    if (e >= n) return;
+    const bool fast = vec_ok && e + N <= n;
+    T r[N], b[N], c[N];
+    chain_load<T, N>(ch, s, e, n, fast, r, b, c);
+    chain_apply<T, N>(r, b, c, ch);
+    Pack<T, N> po;
+#pragma unroll
+    for (int i = 0; i < N; ++i) po.v[i] = r[i];
+    out_store<T, N, true>(out, po, e, n, fast);
+}
+
+template <typename T> int chain_args(const ek_chain *chain, size_t n, ChainArgs<T> &ch, size_t &bytes, int &aligned, const char *what) {
+    if (!chain) return fail(EK_ERR_INVALID, "%s: null chain", what);
+    if (chain->arity < 1 || chain->arity > 3 || chain->n_maps < 0 || chain->n_maps > 3)
+        return fail(EK_ERR_INVALID, "%s: arity %d with %d maps", what, chain->arity, chain->n_maps);
+    const int op = chain->base_op;
+    if (chain->arity == 1) ch.base = CH_COPY;
+    else if (chain->arity == 2 && (op == EK_ADD || op == EK_SUB || op == EK_MUL)) ch.base = op == EK_ADD ? CH_ADD : op == EK_SUB ? CH_SUB : CH_MUL;
+    else if (chain->arity == 3 && (op == EK_FMADD || op == EK_FMSUB || op == EK_FNMADD || op == EK_FNMSUB || op == EK_MULADD ||
+                                   op == EK_MULSUB || op == EK_NMULADD)) ch.base = CH_TERNARY + op;
+    else return fail(EK_ERR_UNSUPPORTED, "%s: base op %d of arity %d cannot head a chain", what, op, chain->arity);
+    bytes = 0;
+    aligned = 1;
+    for (int k = 0; k < 3; ++k) {
+        ch.src[k] = Arg<T>{ nullptr, T(0), 0u };
+        if (k >= chain->arity) continue;
+        if (int rc = make_arg<T>(&chain->src[k], n, ch.src[k], what)) return rc;
+        bool dup = false;
+        for (int j = 0; j < k; ++j) dup = dup || (ch.src[j].vec && ch.src[k].vec && ch.src[j].ptr == ch.src[k].ptr);
+        if (!dup) bytes += arg_bytes(ch.src[k], n);
+        aligned = aligned && arg_aligned(ch.src[k]);
+    }
+    ch.n_maps = chain->n_maps;
+    for (int k = 0; k < 3; ++k) {
+        ch.map_ops[k] = k < chain->n_maps ? chain->map_ops[k] : (int) EK_COPY;
+        if (k < chain->n_maps && !unary_fusable(ch.map_ops[k]))
+            return fail(EK_ERR_UNSUPPORTED, "%s: op %d cannot be applied on load", what, ch.map_ops[k]);
+    }
+    return EK_OK;
+}
+
+template <typename T> int chain_reduce(int op, void *out, const ek_chain *chain, size_t n) {
+    ChainArgs<T> ch;
+    size_t bytes;
+    int aligned;
+    if (int rc = chain_args<T>(chain, n, ch, bytes, aligned, "ek_hip_reduce_chain()")) return rc;
+    RoctxRange range("enoki-hip: horizontal reduction of a chain");
+    Context &c = ctx();
+    constexpr int N = 16 / sizeof(T);
+    // transcendental stages make the pass VALU-bound: as many resident waves as the registers allow, every lane a few vectors
+    unsigned grid = stream_grid((n / N + 3) / 4 + 1, 2 * c.tuning.reduce_blocks_per_cu);
+    if (grid > 2048) grid = 2048;
+    void *scratch = nullptr;
+    if (int rc = reduce_scratch((size_t) grid * sizeof(T), &scratch)) return rc;
+#define EK_CHAIN_REDUCE(OP) case OP: hipLaunchKernelGGL((k_chain_reduce<Reducer<OP, T>, T>), dim3(grid), dim3(256), 0, c.stream, (T *) scratch, n, aligned, ch); \
+                                     EK_LAUNCH_CHECK("reduce_chain", n, bytes); \
+                                     hipLaunchKernelGGL((k_reduce_stage2<Reducer<OP, T>, T>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) scratch, grid); break;
+    switch (op) {
+        EK_CHAIN_REDUCE(EK_HSUM) EK_CHAIN_REDUCE(EK_HPROD) EK_CHAIN_REDUCE(EK_HMIN) EK_CHAIN_REDUCE(EK_HMAX)
+        default: return fail(EK_ERR_INVALID, "ek_hip_reduce_chain(): unknown op %d", op);
+    }
+#undef EK_CHAIN_REDUCE
+    EK_LAUNCH_CHECK("reduce_stage2", (size_t) grid, (size_t) grid * sizeof(T) + sizeof(T));
+    return EK_OK;
+}
+
+template <typename T> int chain_map(void *out, const ek_chain *chain, size_t n) {
+    ChainArgs<T> ch;
+    size_t bytes;
+    int aligned;
+    if (int rc = chain_args<T>(chain, n, ch, bytes, aligned, "ek_hip_map_chain()")) return rc;
+    constexpr int N = 16 / sizeof(T);
+    hipLaunchKernelGGL((k_chain_map<T>), dim3(oneshot_grid<N, 1>(n)), dim3(256), 0, ctx().stream, (T *) out, n, aligned && aligned16(out), ch);
+    EK_LAUNCH_CHECK("map_chain", n, bytes + n * sizeof(T));
+    return EK_OK;
+}
+
 // Identities of EMPTY inputs follow the CPU reference literally (dynamic.h:633, 651, 669, 687):
 // hsum -> 0, hprod -> 1, hmin -> numeric_limits::max(), hmax -> numeric_limits::min() (which is the
 // smallest positive normal for floating point types -- a reference quirk we keep).
@@ -359,6 +522,28 @@ int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n) {
         case EK_F32: return reduce_dispatch<float>(op, out, in, n);
         case EK_F64: return reduce_dispatch<double>(op, out, in, n);
         default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce(): unsupported type %d", type);
+    }
+}
+
+int ek_hip_reduce_chain(int reduce_op, int type, void *out, const ek_chain *chain, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_reduce_chain(): null pointer");
+    if (n == 0) return fail(EK_ERR_INVALID, "ek_hip_reduce_chain(): empty input");
+    switch (type) {
+        case EK_F32: return chain_reduce<float>(reduce_op, out, chain, n);
+        case EK_F64: return chain_reduce<double>(reduce_op, out, chain, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_chain(): floating point types only");
+    }
+}
+
+int ek_hip_map_chain(int type, void *out, const ek_chain *chain, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    if (!out) return fail(EK_ERR_INVALID, "ek_hip_map_chain(): null pointer");
+    switch (type) {
+        case EK_F32: return chain_map<float>(out, chain, n);
+        case EK_F64: return chain_map<double>(out, chain, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_chain(): floating point types only");
     }
 }
 

@@ -145,6 +145,9 @@ template <typename Array> py::class_<Array> bind_array(py::module_ &m, const cha
           return out;
       })
       .def("data_ptr", [](Array &a) { return (uintptr_t) a.data(); }, "raw device pointer")
+      .def("explain", [](const Array &a) { return detach(a).explain_(); },
+           "what state the array is in (evaluated / which kind of unevaluated node) and what its consumers can still fuse -- "
+           "does not evaluate anything; hip_set_log_level(2) additionally prints a line whenever an expression leaves bucket order")
       .def_property_readonly("__cuda_array_interface__", [](Array &a) {
           // consumed by torch.as_tensor(obj, device='cuda') on ROCm builds: zero-copy view.  The consumer keeps the python
           // OBJECT alive, not the buffer: the buffer is marked as exported so that a later copy-on-write (a scatter into

@@ -33,6 +33,11 @@ namespace detail {
     inline void hip_check(int rc, const char *what) {
         if (rc != EK_OK) hip_raise(what);
     }
+    /// ENOKI_HIP_LOG >= 2 (hip_set_log_level): one line whenever an expression that could have run in bucket order does not --
+    /// which shape was expected and what was found instead (`explain()` of an array says what state it is in)
+    inline void hip_note_element_order(const char *what, const char *why) {
+        if (ek_hip_log_level() >= 2) fprintf(stderr, "enoki-hip: [bucket order] %s: %s\n", what, why);
+    }
 
     /// Reference-counted device allocation
     ///
@@ -60,7 +65,8 @@ namespace detail {
             int type, index_type;              // map: index_type holds the unary op
             size_t elem_size;
             bool consumed;                     // a fused consumer has read it once: the next access materialises (gathers)
-            int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below), 3: zeros (no sources)
+            int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below), 3: zeros (no sources),
+                                               // 4: arithmetic over evaluated operands, 5: gather * array (both below)
             HIPBuffer *partner = nullptr;      // map: the other half of an unevaluated sincos pair (not owning)
             // map: the node is  scale * op(source)  -- the product of an unevaluated map with a host scalar stays a map
             // (HIPArray::scaled_map_: the -sin(u) that d/du cos(u) records, the c * cos(u) that backward(c * y) sends down),
@@ -76,6 +82,21 @@ namespace detail {
             HIPBuffer *table2 = nullptr, *arg0 = nullptr;      // references held
             int op = 0;
             ek_hip_bucketed *bucketed = nullptr;               // the partition of (index, arg0) by table bucket, once built
+            // kind 4:  op(operand 0, operand 1[, operand 2])  over EVALUATED arrays / host scalars that has not run yet -- the fma
+            // family, a product, and the product-then-sum forms EK_MULADD / EK_MULSUB / EK_NMULADD that `a * x + b` written with
+            // operators becomes.  Operand k is the buffer in table / arg0 / table2 (references held) or the immediate imm[k].
+            // The reference fuses every vertical op between two evaluation points into one kernel (jit.cu:1066-1217,
+            // :1418-1508); here a horizontal reduction that finds such a node under (up to three) unevaluated unary maps reads
+            // the operands once and writes nothing (ek_hip_reduce_chain; `hsum(sin(exp(fmadd(a, x, b))))`, BASELINE configs[1]:
+            // 12 B/elt instead of 28), and any other access runs the plain kernel -- same bits either way.
+            // kind 5:  table[index] * arg0  -- the product `gather(A, idx) * x` of the operator spelling `gather(A, idx) * x +
+            // gather(B, idx)`, left unevaluated for ONE step: the sum that adds a gather through the same index array turns it
+            // into a kind-2 node (op EK_MULADD / EK_MULSUB / EK_NMULADD: a product and a sum with a rounding each, bucket order
+            // possible); any other access runs the kernel that consumes the gather in place, as the eager product did.
+            int arity = 0;
+            uint64_t imm[3] = { 0, 0, 0 };
+            bool is_imm[3] = { false, false, false };
+            HIPBuffer *operand_buf(int k) const { return k == 0 ? table : k == 1 ? arg0 : table2; }
         };
         Deferred *deferred = nullptr;
         std::vector<HIPBuffer *> readers;      // deferred nodes whose table / source is THIS buffer (not owning)
@@ -150,8 +171,30 @@ namespace detail {
         /// Execute a deferred unary map; a sincos pair is evaluated by one kernel
         void force_map() {
             Deferred *d = deferred;
-            if (d->table->deferred) d->table->force();          // a source that is an unevaluated fma of gathers runs first
             const size_t bytes = (size ? size : 1) * d->elem_size;
+            if (d->table->deferred && (d->table->deferred->kind == 1 || d->table->deferred->kind == 4) &&
+                !(d->partner && d->partner->deferred)) {
+                // maps over maps over an unevaluated arithmetic node: what only this chain wants is evaluated in ONE pass
+                ek_chain ch;
+                build_chain(ch);
+                if (ch.n_maps > 1 || ch.arity > 1) {
+                    void *p = nullptr;
+                    hip_check(ek_hip_malloc(bytes, &p), "HIPArray (deferred chain)");
+                    int rc = ek_hip_map_chain(d->type, p, &ch, size);
+                    if (rc == EK_OK && d->scaled) {
+                        ek_operand self{ p, 0, size }, factor{ nullptr, d->scale_bits, 1 };
+                        rc = ek_hip_binary(EK_MUL, d->type, p, &self, &factor, size);
+                    }
+                    if (rc != EK_OK) {
+                        ek_hip_free(p);
+                        hip_raise("HIPArray (deferred chain)");
+                    }
+                    ptr = p;
+                    drop_deferred();
+                    return;
+                }
+            }
+            if (d->table->deferred) d->table->force();          // a source that is an unevaluated fma of gathers runs first
             ek_operand src{ d->table->ptr, 0, d->table->size };
             HIPBuffer *other = d->partner && d->partner->deferred ? d->partner : nullptr;
             void *p = nullptr, *q = nullptr;
@@ -194,6 +237,10 @@ namespace detail {
         /// Element-order evaluation of a deferred fma over a gathered pair: one kernel, gathers consumed in place
         void force_pair() {
             Deferred *d = deferred;
+            hip_note_element_order("fma of two gathers through one index array",
+                                   "evaluated in ELEMENT order -- its consumer is not a horizontal reduction (directly or through one "
+                                   "fusable unary op) nor the adjoint scatter_add of its gathers, or a source is about to be written, or a "
+                                   "step graph is being captured, or deterministic mode is on");
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * d->elem_size, &p), "HIPArray (deferred fma of gathers)");
             ek_gathered ga, gc;
@@ -229,6 +276,79 @@ namespace detail {
             return d->bucketed;
         }
 
+        /// kind 4: run the deferred arithmetic op
+        void force_arith() {
+            Deferred *d = deferred;
+            void *p = nullptr;
+            hip_check(ek_hip_malloc((size ? size : 1) * d->elem_size, &p), "HIPArray (deferred arithmetic)");
+            ek_operand o[3];
+            for (int k = 0; k < d->arity; ++k) {
+                HIPBuffer *b = d->operand_buf(k);
+                o[k] = d->is_imm[k] ? ek_operand{ nullptr, d->imm[k], 1 } : ek_operand{ b->ptr, 0, b->size };
+            }
+            int rc = d->arity == 3 ? ek_hip_ternary(d->op, d->type, p, &o[0], &o[1], &o[2], size)
+                                   : ek_hip_binary(d->op, d->type, p, &o[0], &o[1], size);
+            if (rc != EK_OK) {
+                ek_hip_free(p);
+                hip_raise("HIPArray (deferred arithmetic)");
+            }
+            ptr = p;
+            drop_deferred();
+        }
+
+        /// kind 5: the product of a gather with an array, the gather consumed in place (element order)
+        void force_gathered_product() {
+            Deferred *d = deferred;
+            void *p = nullptr;
+            hip_check(ek_hip_malloc((size ? size : 1) * d->elem_size, &p), "HIPArray (deferred product of a gather)");
+            ek_gathered g = gathered();
+            ek_operand x{ d->arg0->ptr, 0, d->arg0->size };
+            const ek_gathered *pg[3] = { &g, nullptr, nullptr };
+            const ek_operand *po[3] = { nullptr, &x, nullptr };
+            if (ek_hip_map_gathered(2, EK_MUL, d->type, p, po, pg, size) != EK_OK) {
+                ek_hip_free(p);
+                hip_raise("HIPArray (deferred product of a gather)");
+            }
+            ptr = p;
+            drop_deferred();
+        }
+
+        /// Only the chain above holds / reads this unevaluated node: it can be recomputed inside the consumer instead of written
+        bool absorbable_() const { return deferred && ref_count == 1 && readers.size() == 1; }
+
+        /// The chain that ends in this kind-1 node, as a descriptor for ek_hip_reduce_chain / ek_hip_map_chain: unevaluated maps
+        /// below it that nobody else wants (unscaled, no live sincos partner) are absorbed, then an unevaluated arithmetic node
+        /// (kind 4) that nobody else wants becomes the base; whatever cannot be absorbed is evaluated here and is the base.  The
+        /// scale / partner of THIS node are its caller's business.
+        void build_chain(ek_chain &ch) {
+            int ops[3], n = 0;
+            ops[n++] = deferred->index_type;
+            HIPBuffer *src = deferred->table;
+            while (n < 3 && src->absorbable_() && src->deferred->kind == 1 && !src->deferred->scaled &&
+                   !(src->deferred->partner && src->deferred->partner->deferred)) {
+                ops[n++] = src->deferred->index_type;
+                src = src->deferred->table;
+            }
+            ch.n_maps = n;
+            for (int k = 0; k < 3; ++k) ch.map_ops[k] = k < n ? ops[n - 1 - k] : (int) EK_COPY;        // first applied first
+            if (src->absorbable_() && src->deferred->kind == 4) {
+                const Deferred *a = src->deferred;
+                ch.arity = a->arity;
+                ch.base_op = a->op;
+                for (int k = 0; k < 3; ++k) {
+                    HIPBuffer *b = k < a->arity ? a->operand_buf(k) : nullptr;
+                    ch.src[k] = k >= a->arity ? ek_operand{ nullptr, 0, 0 }
+                              : a->is_imm[k]  ? ek_operand{ nullptr, a->imm[k], 1 } : ek_operand{ b->ptr, 0, b->size };
+                }
+            } else {
+                if (src->deferred) src->force();
+                ch.arity = 1;
+                ch.base_op = EK_COPY;
+                ch.src[0] = ek_operand{ src->ptr, 0, src->size };
+                ch.src[1] = ch.src[2] = ek_operand{ nullptr, 0, 0 };
+            }
+        }
+
         /// kind 3: zero<HIPArray>(n) that nobody has looked at yet.  The gradient buffers of the backward sweep start their life
         /// like this (autodiff.cpp:332-338 zero-fills them); a bucket-ordered scatter_add that takes one as its target WRITES
         /// its sums instead of adding them to a memset buffer (adopt_uninitialized()), everybody else gets the memset.
@@ -257,6 +377,8 @@ namespace detail {
             if (deferred->kind == 1) { force_map(); return; }
             if (deferred->kind == 2) { force_pair(); return; }
             if (deferred->kind == 3) { force_zeros(); return; }
+            if (deferred->kind == 4) { force_arith(); return; }
+            if (deferred->kind == 5) { force_gathered_product(); return; }
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (deferred gather)");
             ek_gathered g = gathered();
@@ -825,6 +947,120 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// An unevaluated fma over a gathered pair (kind 2, see detail::HIPBuffer)
     bool paired_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 2; }
 
+    /// gather(A, idx) * x that has not run yet (kind 5, see detail::HIPBuffer)
+    bool gathered_product_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 5; }
+
+    /// g * x with g an unevaluated gather and x an evaluated array of the same length: left unevaluated (kind 5) when a sum with
+    /// another gather through the same index array could still take the whole expression in bucket order.  Invalid array: not
+    /// that shape -- the caller consumes the gather in place right away.
+    static HIPArray defer_gathered_product_(const HIPArray &g, const HIPArray &x, size_t n) {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const auto *p = g.m_buf->deferred;
+            if (!detail::hip_defer_gather_flag() || x.m_is_imm || !x.m_buf || x.m_buf->size != n || !x.m_buf->owned ||
+                x.m_buf->exported || x.m_buf->deferred || g.m_buf->size != n)
+                return r;
+            if (p->mask && sizeof(Value) != 4) return r;
+            if (!ek_hip_bucketed_applicable(Type, p->index_type, p->table->size, n)) return r;
+            auto *d = new typename detail::HIPBuffer::Deferred{ p->table, p->index, p->mask, Type, p->index_type, sizeof(Value),
+                                                                false, 5, nullptr };
+            d->arg0 = x.m_buf;
+            r.m_buf = new detail::HIPBuffer();
+            r.m_buf->size = n;
+            r.m_buf->deferred = d;
+            r.m_buf->pending_link();
+            detail::HIPBuffer *seen[4] = { nullptr, nullptr, nullptr, nullptr };
+            int k = 0;
+            for (detail::HIPBuffer *src : { d->table, d->index, d->arg0, d->mask }) {
+                if (!src) continue;
+                src->ref_count++;
+                bool dup = false;
+                for (int j = 0; j < k; ++j) dup = dup || seen[j] == src;
+                if (!dup) { src->readers.push_back(r.m_buf); seen[k++] = src; }
+            }
+            g.m_buf->deferred->consumed = true;
+        }
+        return r;
+    }
+
+    /// (this = gather(A, idx) * x, unevaluated)  +/-  gc = gather(C, idx)  through the same index / mask array and equally sized
+    /// tables:  the kind-2 node of the whole expression with a product-then-sum op.  form: EK_MULADD (p + gc), EK_MULSUB (p - gc),
+    /// EK_NMULADD (gc - p).  Invalid array: not that shape.
+    HIPArray gathered_product_plus_(int form, const HIPArray &gc, size_t n) const {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const auto *p = m_buf->deferred, *q = gc.m_buf->deferred;
+            if (p->index != q->index || p->mask != q->mask || p->index_type != q->index_type || p->table->size != q->table->size ||
+                m_buf->size != n || gc.m_buf->size != n)
+                return r;
+            HIPArray x;
+            x.m_buf = p->arg0;
+            x.m_buf->ref_count++;
+            r = defer_pair_fma_(form, *this, x, gc, n);
+        }
+        return r;
+    }
+
+    /// An unevaluated arithmetic op over evaluated operands (kind 4, see detail::HIPBuffer)
+    bool arith_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 4; }
+
+    /// op(x[0], .., x[arity - 1]) left unevaluated (kind 4): every operand a host scalar or an evaluated, owned array of n elements
+    /// that no external view can write.  Invalid array: not such a shape -- the caller runs the kernel.
+    static HIPArray defer_arith_(int arity, int op, const HIPArray *const *x, size_t n) {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_map_min_size_;
+            if (!detail::hip_defer_gather_flag() || n < least || n < 2) return r;
+            bool any_array = false;
+            for (int k = 0; k < arity; ++k) {
+                if (x[k]->m_is_imm) continue;
+                const detail::HIPBuffer *b = x[k]->m_buf;
+                if (!b || b->size != n || !b->owned || b->exported || b->deferred) return r;
+                any_array = true;
+            }
+            if (!any_array) return r;
+            auto *d = new typename detail::HIPBuffer::Deferred{ nullptr, nullptr, nullptr, Type, 0, sizeof(Value), false, 4, nullptr };
+            d->arity = arity;
+            d->op = op;
+            r.m_buf = new detail::HIPBuffer();
+            r.m_buf->size = n;
+            r.m_buf->deferred = d;
+            r.m_buf->pending_link();
+            for (int k = 0; k < arity; ++k) {
+                if (x[k]->m_is_imm) { d->is_imm[k] = true; d->imm[k] = imm_bits(x[k]->m_imm); continue; }
+                detail::HIPBuffer *b = x[k]->m_buf;
+                (k == 0 ? d->table : k == 1 ? d->arg0 : d->table2) = b;
+                b->ref_count++;
+                bool dup = false;
+                for (int j = 0; j < k; ++j) dup = dup || (!x[j]->m_is_imm && x[j]->m_buf == b);
+                if (!dup) b->readers.push_back(r.m_buf);
+            }
+        }
+        return r;
+    }
+
+    /// this (an unevaluated PRODUCT p * q, kind 4) plus / minus `other`, or `other` minus it, as ONE unevaluated node
+    /// (EK_MULADD / EK_MULSUB / EK_NMULADD: the same two roundings) -- `a * x + b` written with operators.  The product node
+    /// itself stays as it is (whoever else holds it can still evaluate it).  Invalid array: not that shape.
+    HIPArray product_plus_(int form, const HIPArray &other, size_t n) const {
+        HIPArray r;
+        if constexpr (IsFloat) {
+            const auto *d = m_buf->deferred;
+            if (d->op != EK_MUL || d->arity != 2 || m_buf->size != n) return r;
+            HIPArray p, q;
+            auto operand_of = [&](int k) {
+                HIPArray a;
+                if (d->is_imm[k]) { Value v; memcpy(&v, &d->imm[k], sizeof(Value)); a = HIPArray(v); }
+                else { a.m_buf = d->operand_buf(k); a.m_buf->ref_count++; }
+                return a;
+            };
+            p = operand_of(0); q = operand_of(1);
+            const HIPArray *x[3] = { &p, &q, &other };
+            r = defer_arith_(3, form, x, n);
+        }
+        return r;
+    }
+
     /// Unary ops whose result is left unevaluated until its first consumer: the ones ek_hip_reduce_map /
     /// ek_hip_scatter_add_multi_map can apply on load.  Small arrays are evaluated right away (nothing to win).
     static constexpr size_t defer_map_min_size_ = (size_t) 1 << 16;
@@ -838,8 +1074,16 @@ template <typename Value_> struct HIPArray : ArrayTag {
                m_buf->size >= least && m_buf->size > 1;
     }
     HIPArray defer_map_(int op) const {
-        if (!paired_()) ptr_();                              // a source that is a deferred gather / map runs first; an fma of
-                                                             // gathers stays: its consumer may want it in bucket order
+        // A source that is a deferred gather runs first.  An fma of gathers stays (its consumer may want it in bucket order), and
+        // so do an unevaluated arithmetic node and up to two levels of unevaluated maps: a reduction that consumes the chain
+        // applies all of it while it loads the operands (detail::HIPBuffer::build_chain).
+        bool keep = paired_() || arith_();
+        if (mapped_()) {
+            int depth = 1;
+            for (const detail::HIPBuffer *b = m_buf->deferred->table; b->deferred && b->deferred->kind == 1; b = b->deferred->table) ++depth;
+            keep = depth <= 2;
+        }
+        if (!keep) ptr_();
         auto *d = new typename detail::HIPBuffer::Deferred{ m_buf, nullptr, nullptr, Type, op, sizeof(Value), false, 1, nullptr };
         m_buf->ref_count++;
         HIPArray r;
@@ -955,11 +1199,18 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if constexpr (IsFloat) {
             const auto *p = ga.m_buf->deferred, *q = gc.m_buf->deferred;
             // (both gathers under the SAME mask array -- or none: masked-out lanes are dropped by the partition)
-            if (!detail::hip_defer_gather_flag() || p->mask != q->mask || x.m_is_imm || !x.m_buf || x.m_buf->size != n ||
-                !x.m_buf->owned || x.m_buf->exported || x.m_buf->deferred)
+            const char *shape = "fma(gather(A, idx), x, gather(B, idx))";
+            if (!detail::hip_defer_gather_flag()) return r;
+            if (p->mask != q->mask) { detail::hip_note_element_order(shape, "the two gathers use different mask arrays"); return r; }
+            if (x.m_is_imm || !x.m_buf || x.m_buf->size != n) { detail::hip_note_element_order(shape, "x is a scalar / of another length"); return r; }
+            if (!x.m_buf->owned || x.m_buf->exported) { detail::hip_note_element_order(shape, "x is a view of foreign memory or has a zero-copy export (an external writer could change it)"); return r; }
+            if (x.m_buf->deferred) { detail::hip_note_element_order(shape, "x is itself unevaluated"); return r; }
+            if (p->mask && sizeof(Value) != 4) { detail::hip_note_element_order(shape, "masked gathers of 8-byte elements"); return r; }
+            if (!ek_hip_bucketed_applicable(Type, p->index_type, p->table->size, n)) {
+                detail::hip_note_element_order(shape, "the library does not cover the shape (fewer than 2^18 lookups, a table within one bucket or beyond "
+                                                      "64 slices, deterministic mode, ENOKI_HIP_BUCKET_ORDERED=0)");
                 return r;
-            if (p->mask && sizeof(Value) != 4) return r;
-            if (!ek_hip_bucketed_applicable(Type, p->index_type, p->table->size, n)) return r;
+            }
             auto *d = new typename detail::HIPBuffer::Deferred{ p->table, p->index, p->mask, Type, p->index_type, sizeof(Value),
                                                                 false, 2, nullptr };
             d->table2 = q->table;
@@ -1236,6 +1487,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// An external consumer received this buffer's address (see make_unique())
     void mark_exported_() const {
         if (!m_buf) return;
+        m_buf->force_readers();                // unevaluated nodes that read this buffer must see it as it is NOW
         m_buf->exported = true;
         // an external view may write: neither a narrowed copy OF this buffer nor this buffer AS somebody's narrowed copy stays valid
         m_buf->drop_narrowed();
@@ -1299,6 +1551,34 @@ template <typename Value_> struct HIPArray : ArrayTag {
     size_t size() const { return m_is_imm ? 1 : (m_buf ? m_buf->size : 0); }
     size_t slices_() const { return size(); }
     bool empty() const { return size() == 0; }
+
+    /// What state the array is in and what its consumers can still do with it (python: hip_explain(array))
+    std::string explain_() const {
+        if (m_is_imm) return "host scalar (passed to kernels as an argument)";
+        if (!m_buf) return "uninitialized";
+        const std::string n = std::to_string(m_buf->size) + " elements";
+        if (!m_buf->deferred) return "evaluated array, " + n + (m_buf->exported ? ", exported zero-copy" : "") + (m_buf->owned ? "" : ", foreign memory");
+        const auto *d = m_buf->deferred;
+        switch (d->kind) {
+            case 0: return "unevaluated gather from a table of " + std::to_string(d->table->size) + " entries, " + n +
+                           (d->consumed ? " (a fused consumer has read it: the next access runs the gather kernel)"
+                                        : ": add / sub / mul / fma consume it in place; fma (or `g * x + g2`) with a second gather through the SAME index "
+                                          "array stays unevaluated for bucket order");
+            case 1: return std::string("unevaluated unary op ") + std::to_string(d->index_type) + (d->scaled ? " times a host scalar" : "") + ", " + n +
+                           ": reductions and scatter_add value streams apply it while loading; source " +
+                           (d->table->deferred ? "unevaluated (kind " + std::to_string(d->table->deferred->kind) + ")" : "evaluated");
+            case 2: return "unevaluated " + std::string(d->op >= EK_MULADD ? "product-then-sum" : "fma") + " of two gathers through one index array (K = " +
+                           std::to_string(d->table->size) + ", " + n + "): BUCKET ORDER possible -- a horizontal reduction (directly or through one fusable "
+                           "unary op) and the adjoint scatter_add of the gathers stay in bucket order; any other access evaluates it in element order" +
+                           (d->bucketed ? "; partition built" : "");
+            case 3: return "zeros that nobody has looked at, " + n;
+            case 4: return "unevaluated arithmetic op " + std::to_string(d->op) + " of arity " + std::to_string(d->arity) + " over evaluated operands, " + n +
+                           ": a reduction (through up to three fusable unary ops) reads the operands once; any other access runs the kernel";
+            case 5: return "unevaluated gather * array, " + n + ": `+ gather(B, idx)` through the same index array makes it a bucket-ordered "
+                           "product-then-sum; any other access consumes the gather in place (element order)";
+            default: return "unevaluated (kind " + std::to_string(d->kind) + ")";
+        }
+    }
 
     /// True when the array is a host-known scalar equal to `v` (lets callers skip `x * 1` style passes)
     bool is_literal_(Value v) const { return m_is_imm && m_imm == v; }
@@ -1532,6 +1812,7 @@ private:
                         return true;
                     }
                 }
+                if (!shared) detail::hip_note_element_order("fma(gather(A, i), x, gather(B, j))", "the gathers do not share index array, mask and table size");
                 if (!shared || p->table->size * 8 > n) d[2] = false;     // interleaving K records has to pay for itself
             }
             // the same array in a fused AND an unfused slot (g * g): the unfused use materialises it anyway
@@ -1579,10 +1860,37 @@ private:
                 if (HIPArray r = b.rsqrt_of_sqrt_map_(m_imm); r.valid()) return r;
         }
         size_t n = broadcast_size(size(), b.size());
+        if constexpr (IsFloat) {
+            // `gather(A, idx) * x + gather(B, idx)` written with operators (BASELINE.json spells config 3b `a*x+b`): the product
+            // waits one step (kind 5), the sum with the second gather makes the kind-2 node that bucket order can take
+            if (op == EK_MUL && deferred_() != b.deferred_()) {
+                const HIPArray &g = deferred_() ? *this : b, &x = deferred_() ? b : *this;
+                if (HIPArray r = defer_gathered_product_(g, x, n); r.valid()) return r;
+            }
+            if ((op == EK_ADD || op == EK_SUB) && ((gathered_product_() && b.deferred_()) || (b.gathered_product_() && deferred_()))) {
+                HIPArray r = gathered_product_() ? gathered_product_plus_(op == EK_ADD ? EK_MULADD : EK_MULSUB, b, n)
+                                                 : b.gathered_product_plus_(op == EK_ADD ? EK_MULADD : EK_NMULADD, *this, n);
+                if (r.valid()) return r;
+            }
+        }
         if ((op == EK_ADD || op == EK_SUB || op == EK_MUL) && (deferred_() || b.deferred_())) {
             const HIPArray *x[3] = { this, &b, nullptr };
             HIPArray r;
             if (map_gathered_(2, op, x, n, r, what)) return r;
+        }
+        if constexpr (IsFloat) {
+            // `a * x + b` written with operators: the product stays unevaluated (kind 4), the sum that consumes it becomes the
+            // product-then-sum node -- two roundings, like the eager kernels, in one pass whenever a reduction consumes it
+            if ((op == EK_ADD || op == EK_SUB) && (arith_() || b.arith_())) {
+                HIPArray r;
+                if (arith_() && !b.arith_()) r = product_plus_(op == EK_ADD ? EK_MULADD : EK_MULSUB, b, n);
+                else if (b.arith_() && !arith_()) r = b.product_plus_(op == EK_ADD ? EK_MULADD : EK_NMULADD, *this, n);
+                if (r.valid()) return r;
+            }
+            if (op == EK_MUL && !mapped_() && !b.mapped_()) {
+                const HIPArray *x[3] = { this, &b, nullptr };
+                if (HIPArray r = defer_arith_(2, EK_MUL, x, n); r.valid()) return r;
+            }
         }
         HIPArray r = empty_(n);
         ek_operand oa = operand(), ob = b.operand();
@@ -1597,6 +1905,12 @@ private:
             const HIPArray *x[3] = { this, &b, &c };
             HIPArray g;
             if (map_gathered_(3, op, x, n, g, what)) return g;
+        }
+        if constexpr (IsFloat) {
+            if (op == EK_FMADD || op == EK_FMSUB || op == EK_FNMADD || op == EK_FNMSUB) {
+                const HIPArray *x[3] = { this, &b, &c };
+                if (HIPArray r = defer_arith_(3, op, x, n); r.valid()) return r;
+            }
         }
         HIPArray r = empty_(n);
         ek_operand oa = operand(), ob = b.operand(), oc = c.operand();
@@ -1643,12 +1957,35 @@ private:
                         // (a value that somebody else holds as well will be asked for again: u counts as held, too)
                         if (reduce_bucketed_(src, op, d->index_type, r.m_buf->ptr, m_buf->ref_count > 1 ? 0 : 1, keep_op)) return finish();
                     }
+                    if (src->deferred && (src->deferred->kind == 1 || src->deferred->kind == 4)) {
+                        // maps over maps over an unevaluated arithmetic node: whatever only this chain wants is applied on load
+                        ek_chain ch;
+                        m_buf->build_chain(ch);
+                        if (ch.n_maps > 1 || ch.arity > 1) {
+                            detail::hip_check(ek_hip_reduce_chain(op, Type, r.m_buf->ptr, &ch, n), what);
+                            return finish();
+                        }
+                    }
                     if (src->deferred) src->force();
                     detail::hip_check(ek_hip_reduce_map(op, d->index_type, Type, r.m_buf->ptr, src->ptr, n), what);
                     return finish();
                 }
             }
             if (paired_() && reduce_bucketed_(m_buf, op, EK_COPY, r.m_buf->ptr, 1)) return r;
+            if (arith_() && m_buf->ref_count == 1 && m_buf->readers.empty()) {
+                // hsum(fmadd(a, x, b)) and the like: the operands are read once, the result of the arithmetic is never written
+                const auto *a = m_buf->deferred;
+                ek_chain ch;
+                ch.arity = a->arity; ch.base_op = a->op; ch.n_maps = 0;
+                for (int k = 0; k < 3; ++k) {
+                    ch.map_ops[k] = EK_COPY;
+                    const detail::HIPBuffer *b = k < a->arity ? a->operand_buf(k) : nullptr;
+                    ch.src[k] = k >= a->arity ? ek_operand{ nullptr, 0, 0 }
+                              : a->is_imm[k]  ? ek_operand{ nullptr, a->imm[k], 1 } : ek_operand{ b->ptr, 0, b->size };
+                }
+                detail::hip_check(ek_hip_reduce_chain(op, Type, r.m_buf->ptr, &ch, n), what);
+                return r;
+            }
         }
         detail::hip_check(ek_hip_reduce(op, Type, r.m_buf->ptr, m_buf ? ptr_() : nullptr, n), what);
         return r;

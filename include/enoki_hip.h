@@ -74,9 +74,13 @@ typedef enum {
     EK_BINARY_COUNT
 } ek_binary_op;
 
-/* Ternary ops.  cuda.h:387-406; safe_fmadd = autodiff.cpp:1207-1221. */
+/* Ternary ops.  cuda.h:387-406; safe_fmadd = autodiff.cpp:1207-1221.
+ * EK_MULADD / EK_MULSUB / EK_NMULADD (floating point): a * b + c, a * b - c, c - a * b written with OPERATORS -- a multiplication
+ * and an addition with a rounding each, what `a*x+b` means in the reference (separate packet operations are never contracted,
+ * SURVEY 8c) -- as ONE pass over the operands.  A caller-visible op only so that a product left unevaluated by HIPArray can be
+ * finished by the addition that consumes it; bit-identical to ek_hip_binary(EK_MUL) followed by EK_ADD / EK_SUB. */
 typedef enum {
-    EK_FMADD = 0, EK_FMSUB, EK_FNMADD, EK_FNMSUB, EK_SAFE_FMADD,
+    EK_FMADD = 0, EK_FMSUB, EK_FNMADD, EK_FNMSUB, EK_SAFE_FMADD, EK_MULADD, EK_MULSUB, EK_NMULADD,
     EK_TERNARY_COUNT
 } ek_ternary_op;
 
@@ -389,6 +393,22 @@ EK_API int ek_hip_scatter_add_multi_map(int type, int index_type, int count, voi
  *  mask reductions return to the host and therefore synchronize (cuda.h:761-794).
  * ------------------------------------------------------------------------------------------- */
 EK_API int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n);
+/* A CHAIN: base(src[0 .. arity)) under n_maps unary ops (map_ops[0] first), evaluated in ONE pass over the operands -- the fused
+ * kernel that the reference's JIT assembles for the vertical ops between two evaluation points (src/cuda/jit.cu:1066-1217,
+ * :1418-1508), here as a descriptor interpreted by a pre-compiled kernel (a wave-uniform switch per stage around the loop over a
+ * lane's 16-byte vector; no kernel per combination).  arity 1: the source itself; arity 2: base_op = EK_ADD | EK_SUB | EK_MUL;
+ * arity 3: the fma family and EK_MULADD / EK_MULSUB / EK_NMULADD.  map_ops: the ops ek_hip_reduce_map accepts.  Operands are
+ * arrays of n elements, arrays of one element or immediates.  Values are bit-identical to the op-by-op evaluation
+ * (ek_hip_ternary, then ek_hip_unary per map); ek_hip_reduce_chain reduces them (order unspecified, like ek_hip_reduce),
+ * ek_hip_map_chain writes them.  hsum(sin(exp(fmadd(a, x, b)))) then moves 12 B/elt instead of 28. */
+typedef struct {
+    int arity, base_op;
+    ek_operand src[3];
+    int n_maps;
+    int map_ops[3];
+} ek_chain;
+EK_API int ek_hip_reduce_chain(int reduce_op, int type, void *out, const ek_chain *chain, size_t n);
+EK_API int ek_hip_map_chain(int type, void *out, const ek_chain *chain, size_t n);
 /* op(map_op(in[0..n))) in ONE pass over `in`: the unary operation is applied while loading (hsum(sin(x)): 4 B/element
  * instead of 12).  map_op: EK_NEG, EK_ABS, EK_SQRT, EK_RCP, EK_RSQRT, EK_SIN, EK_COS, EK_EXP, EK_LOG; floating point
  * types; n >= 1.  Same element values and the same reduction tree as ek_hip_unary followed by ek_hip_reduce (bit-identical

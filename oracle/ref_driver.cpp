@@ -482,7 +482,7 @@ float ref_cfg3b(const float *A_, const float *B_, size_t k, const float *x_, con
 
 /* The neighbours of cfg3b that bench.py times next to it (round 4): y = seed * hsum(f(fmadd(gather(A, idx, mask), x,
    gather(B, idx, mask)))) with f = sin (0) | cos (1) | exp (2) | log (3) | sqrt (4) | rcp (5) | rsqrt (6), a 32- or 64-bit index array and an optional
-   mask; backward() of the scaled loss. */
+   mask; backward() of the scaled loss.  func + 16 * spelling: u written with operators instead of fmadd (see below). */
 float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float *x_, const void *idx_, int idx64,
                         const uint8_t *mask_, size_t n, int func, float seed, float *grad_A, float *grad_B, double *seconds) {
     FloatD::set_log_level_(0);
@@ -507,7 +507,12 @@ float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float 
         UInt32D idx = UInt32X::copy(idx_, n);
         a = gather<FloatD>(A, idx, mask); b = gather<FloatD>(B, idx, mask);
     }
-    FloatD u = fmadd(a, x, b);
+    // how u is written: 0 fmadd(a, x, b) | 1 a * x + b | 2 a * x - b | 3 b - a * x | 4 b + a * x  (operators: a product and a sum
+    // with a rounding each -- separate packet operations are never contracted)
+    const int spelling = func >> 4;
+    func &= 15;
+    FloatD u = spelling == 0 ? fmadd(a, x, b) : spelling == 1 ? FloatD(a * x + b) : spelling == 2 ? FloatD(a * x - b)
+             : spelling == 3 ? FloatD(b - a * x) : FloatD(b + a * x);
     FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : func == 3 ? log(u) : func == 4 ? sqrt(u) : func == 5 ? rcp(u) : rsqrt(u));
     FloatD z = seed == 1.f ? y : y * seed;
     backward(z);

@@ -176,7 +176,7 @@ def cfg3b_truth(A, B, x, idx):
     return out
 
 
-def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
+def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0, spelling="fmadd"):
     """cfg3b_truth for the neighbours that bench.py times next to the headline: y = seed * hsum(f(u)), f = sin | cos | exp | log | sqrt,
     masked-out lanes gather 0 (u = 0, no gradient).  Same class-D bounds, scaled by |seed| and by the size of f and f'."""
     eps = 2.0 ** -24
@@ -184,7 +184,9 @@ def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
     ii = idx.astype(np.int64)
     on = np.ones(n, bool) if mask is None else np.asarray(mask, bool)
     x64 = x.astype(np.float64)
-    u = np.where(on, A.astype(np.float64)[ii] * x64 + B.astype(np.float64)[ii], 0.0)
+    # (the operator spellings differ from fmadd by one more rounding of u, which the bounds below cover: |f'| <= big)
+    sa, sb = {"fmadd": (1, 1), "a*x+b": (1, 1), "b+a*x": (1, 1), "a*x-b": (1, -1), "b-a*x": (-1, 1)}[spelling]
+    u = np.where(on, sa * A.astype(np.float64)[ii] * x64 + sb * B.astype(np.float64)[ii], 0.0)
     with np.errstate(all="ignore"):         # (log / sqrt want positive u: the tests that use them shift the addend table)
         safe = np.where(on, u, 1.0)
     f, df = {"sin": (np.sin, np.cos), "cos": (np.cos, lambda v: -np.sin(v)), "exp": (np.exp, np.exp),
@@ -197,7 +199,7 @@ def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0):
     cnt = np.bincount(ii[on], minlength=K)
     out = {"y": float(s.sum()), "y_bound": eps * (hsum_depth(n) * float(np.abs(s).sum()) + 8 * big * n), "cnt": cnt,
            "y_stat_bound": stat_sum_bound(s, hsum_depth(n)) + 4 * eps * abs(float(s.sum()))}
-    for name, terms in (("gA", c * x64), ("gB", c)):
+    for name, terms in (("gA", sa * c * x64), ("gB", sb * c)):
         out[name] = np.bincount(ii[on], weights=terms[on], minlength=K)
         out[name + "_bound"] = eps * (cnt * np.bincount(ii[on], weights=np.abs(terms[on]), minlength=K) + 8 * big * cnt)
     return out

@@ -9,6 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <vector>
 
 #define STUB_UNSUPPORTED(what, a, b) (fprintf(stderr, "stand-in: %s not provided (%d, %d)\n", what, (int) (a), (int) (b)), abort())
 
@@ -55,6 +56,7 @@ static float unary_f(int op, float x) {
 extern "C" {
 const char *ek_hip_last_error(void) { return g_error; }
 void **ek_hip_binding_slot(void) { static void *slot = nullptr; return &slot; }
+uint32_t ek_hip_log_level(void) { return 0; }
 int ek_hip_malloc(size_t bytes, void **out) {
     *out = malloc(bytes ? bytes : 1);
     g_live[*out] = bytes;
@@ -143,6 +145,9 @@ int ek_hip_ternary(int op, int, void *out, const ek_operand *a, const ek_operand
             case EK_FNMADD: r = std::fma(-x, y, z); break;
             case EK_FNMSUB: r = std::fma(-x, y, -z); break;
             case EK_SAFE_FMADD: ++g_safe_calls; r = (x == 0 || y == 0) ? z : std::fma(x, y, z); break;
+            case EK_MULADD: { volatile float p = x * y; r = p + z; break; }          // a product and a sum, a rounding each
+            case EK_MULSUB: { volatile float p = x * y; r = p - z; break; }
+            case EK_NMULADD: { volatile float p = x * y; r = z - p; break; }
             default: STUB_UNSUPPORTED("ternary", op, 0);
         }
         ((float *) out)[i] = r;
@@ -224,9 +229,10 @@ int ek_hip_map_gathered(int arity, int op, int, void *out, const ek_operand *con
         float x[3] = { 0, 0, 0 };
         for (int k = 0; k < arity; ++k)
             x[k] = g[k] ? (op_m(&g[k]->mask, i) ? ((const float *) g[k]->table)[op_u(&g[k]->index, i)] : 0.f) : op_f(o[k], i);
-        if (arity == 3 && (op == EK_FNMADD || op == EK_FNMSUB)) x[0] = -x[0];
-        if (arity == 3 && (op == EK_FMSUB || op == EK_FNMSUB)) x[2] = -x[2];
-        ((float *) out)[i] = arity == 2 ? binary_f(op, x[0], x[1]) : std::fma(x[0], x[1], x[2]);
+        if (arity == 3 && (op == EK_FNMADD || op == EK_FNMSUB || op == EK_NMULADD)) x[0] = -x[0];
+        if (arity == 3 && (op == EK_FMSUB || op == EK_FNMSUB || op == EK_MULSUB)) x[2] = -x[2];
+        volatile float prod = x[0] * x[1];
+        ((float *) out)[i] = arity == 2 ? binary_f(op, x[0], x[1]) : op >= EK_MULADD ? prod + x[2] : std::fma(x[0], x[1], x[2]);
     }
     return EK_OK;
 }
@@ -245,9 +251,10 @@ static long g_bucketed_live = 0, g_bucketed_reduces = 0, g_bucketed_scatters = 0
 static float bucketed_u(const ek_hip_bucketed *b, size_t i) {
     if (b->mask && !b->mask[i]) return 0.f;                // masked-out lanes gather 0 (the device path drops them: u = 0)
     float a = b->a[b->idx[i]], c = b->c[b->idx[i]];
-    if (b->op == EK_FNMADD || b->op == EK_FNMSUB) a = -a;
-    if (b->op == EK_FMSUB || b->op == EK_FNMSUB) c = -c;
-    return std::fma(a, b->x[i], c);
+    if (b->op == EK_FNMADD || b->op == EK_FNMSUB || b->op == EK_NMULADD) a = -a;
+    if (b->op == EK_FMSUB || b->op == EK_FNMSUB || b->op == EK_MULSUB) c = -c;
+    volatile float prod = a * b->x[i];
+    return b->op >= EK_MULADD ? prod + c : std::fma(a, b->x[i], c);
 }
 int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n) {
     return type == EK_F32 && (index_type == EK_U32 || index_type == EK_I32) && table_size >= 8 && n >= 16;
@@ -359,6 +366,33 @@ static float reduce_f(int op, int map, const float *in, size_t n) {
     return acc;
 }
 int ek_hip_reduce(int op, int, void *out, const void *in, size_t n) { *(float *) out = reduce_f(op, EK_COPY, (const float *) in, n); return EK_OK; }
+// chains (ek_hip_reduce_chain / ek_hip_map_chain): base op over the sources, then the maps -- element by element
+static long g_chain_calls = 0;
+static float chain_value(const ek_chain *ch, size_t i) {
+    float v[3] = { 0, 0, 0 };
+    for (int k = 0; k < ch->arity; ++k) v[k] = op_f(&ch->src[k], i);
+    float r = v[0];
+    if (ch->arity == 2) r = binary_f(ch->base_op, v[0], v[1]);
+    if (ch->arity == 3) {
+        ek_operand a{ nullptr, 0, 1 }, b = a, c = a;
+        memcpy(&a.imm, &v[0], 4); memcpy(&b.imm, &v[1], 4); memcpy(&c.imm, &v[2], 4);
+        ek_hip_ternary(ch->base_op, EK_F32, &r, &a, &b, &c, 1);
+    }
+    for (int k = 0; k < ch->n_maps; ++k) r = unary_f(ch->map_ops[k], r);
+    return r;
+}
+int ek_hip_map_chain(int, void *out, const ek_chain *ch, size_t n) {
+    ++g_chain_calls;
+    for (size_t i = 0; i < n; ++i) ((float *) out)[i] = chain_value(ch, i);
+    return EK_OK;
+}
+int ek_hip_reduce_chain(int op, int, void *out, const ek_chain *ch, size_t n) {
+    ++g_chain_calls;
+    std::vector<float> tmp(n);
+    for (size_t i = 0; i < n; ++i) tmp[i] = chain_value(ch, i);
+    *(float *) out = reduce_f(op, EK_COPY, tmp.data(), n);
+    return EK_OK;
+}
 int ek_hip_reduce_map(int op, int map, int, void *out, const void *in, size_t n) {
     ++g_fused_calls;
     *(float *) out = reduce_f(op, map, (const float *) in, n);

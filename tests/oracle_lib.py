@@ -139,7 +139,9 @@ class Checker:
         return y, gA, gB, sec.value
 
 
-    def cfg3b_variant(self, A, B, x, idx, mask=None, func="sin", seed=1.0):
+    SPELLINGS = {"fmadd": 0, "a*x+b": 1, "a*x-b": 2, "b-a*x": 3, "b+a*x": 4}
+
+    def cfg3b_variant(self, A, B, x, idx, mask=None, func="sin", seed=1.0, spelling="fmadd"):
         """reference build only (oracle/ref_driver.cpp:ref_cfg3b_variant): the neighbours of cfg3b -- f = sin | cos | exp | log | sqrt,
         32- or 64-bit indices, optional mask, backward(seed * y)"""
         gA = np.empty_like(A); gB = np.empty_like(B); sec = ctypes.c_double()
@@ -147,7 +149,8 @@ class Checker:
         f.restype = ctypes.c_float
         m = np.ascontiguousarray(mask, np.uint8) if mask is not None else None
         y = f(_p(A), _p(B), ctypes.c_size_t(A.size), _p(x), _p(idx), ctypes.c_int(int(idx.dtype.itemsize == 8)),
-              _p(m) if m is not None else None, ctypes.c_size_t(x.size), ctypes.c_int({"sin": 0, "cos": 1, "exp": 2, "log": 3, "sqrt": 4, "rcp": 5, "rsqrt": 6}[func]),
+              _p(m) if m is not None else None, ctypes.c_size_t(x.size),
+              ctypes.c_int({"sin": 0, "cos": 1, "exp": 2, "log": 3, "sqrt": 4, "rcp": 5, "rsqrt": 6}[func] + 16 * self.SPELLINGS[spelling]),
               ctypes.c_float(seed), _p(gA), _p(gB), ctypes.byref(sec))
         return y, gA, gB, sec.value
 

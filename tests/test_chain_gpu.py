@@ -1,0 +1,151 @@
+"""Chains: base(src..) under up to three unary maps in ONE pass (ek_hip_reduce_chain / ek_hip_map_chain, csrc/reduce.hip) and the
+HIPArray nodes that feed them (include/enoki/hip.h: kind 4 = an unevaluated fma / product / product-then-sum over evaluated
+operands, kind 1 maps on top of it).  What the reference's JIT does for hsum(sin(exp(fmadd(a, x, b)))) -- BASELINE configs[1] --
+one kernel over a, x, b (src/cuda/jit.cu:1066-1217, :1418-1508).
+
+Yardsticks: the values of a chain are BIT-IDENTICAL to the op-by-op kernels of the same library (which are pinned bit for bit
+against the reference build in test_kernels_gpu.py) and to the CPU oracle; reductions over them are class D (order of fp
+additions) and are held to the float64 sum of the f32 terms; hmin / hmax are order independent: bit for bit."""
+import json
+
+import numpy as np
+import pytest
+
+from conftest import bits_equal, f32_inputs, f64_inputs, uniform_pm1
+
+pytestmark = pytest.mark.gpu
+EPS = {np.float32: 2.0 ** -24, np.float64: 2.0 ** -53}
+
+
+def up(capi, a):
+    return capi.Buf.from_numpy(a)
+
+
+BASES = [("fmadd", 3), ("fmsub", 3), ("fnmadd", 3), ("fnmsub", 3), ("muladd", 3), ("mulsub", 3), ("nmuladd", 3),
+         ("add", 2), ("sub", 2), ("mul", 2), (None, 1)]
+MAPS = [[], ["sin"], ["exp", "sin"], ["abs", "sqrt", "rcp"], ["neg", "exp", "log"], ["cos", "abs", "rsqrt"], ["rcp_sqr"], ["abs", "rsqrt_sqr", "rsqrt_cube"]]
+
+
+def op_by_op(capi, base, srcs, maps):
+    if len(srcs) == 3:
+        if base in ("muladd", "mulsub", "nmuladd"):            # the operator spelling: a product, then a sum
+            p = capi.binary("mul", srcs[0], srcs[1])
+            v = capi.binary("add", p, srcs[2]) if base == "muladd" else capi.binary("sub", p, srcs[2]) if base == "mulsub" else capi.binary("sub", srcs[2], p)
+        else:
+            v = capi.ternary(base, *srcs)
+    elif len(srcs) == 2:
+        v = capi.binary(base, *srcs)
+    else:
+        v = srcs[0]
+    for m in maps:
+        v = capi.unary(m, v)
+    return v
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("base,arity", BASES)
+def test_chain_values_are_the_op_by_op_values(capi, dtype, base, arity):
+    """every base under every map list, a ragged length (vector body + guarded tail), arrays / a one-element array / an immediate"""
+    n = 100003
+    gen = f32_inputs if dtype == np.float32 else f64_inputs
+    arrs = [up(capi, gen(n, seed=3 + k, scale=2.0)) for k in range(3)]
+    one = up(capi, np.array([0.75], dtype))
+    for maps in MAPS:
+        for variant in range(3):
+            srcs = list(arrs[:arity])
+            if variant == 1 and arity >= 2:
+                srcs[1] = 0.625                                  # host scalar
+            if variant == 2 and arity == 3:
+                srcs[2] = one                                    # device scalar
+            if variant and arity == 1:
+                continue
+            want = op_by_op(capi, base, srcs, maps).numpy()
+            got = capi.map_chain(base, srcs, maps).numpy()
+            assert bits_equal(got, want), (base, maps, variant)
+            for rop in ("hmin", "hmax"):
+                r = capi.reduce_chain(rop, base, srcs, maps).numpy()[0]
+                finite = want[~np.isnan(want)]
+                if finite.size:
+                    assert bits_equal(np.array([r]), np.array([finite.min() if rop == "hmin" else finite.max()])), (base, maps, rop)
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chain_sums_are_class_d(capi, dtype):
+    n = (1 << 20) + 77
+    a, x, b = (uniform_pm1(n, s).astype(dtype) for s in (1, 2, 3))
+    da, dx, db = up(capi, a), up(capi, x), up(capi, b)
+    for base, srcs, maps in (("fmadd", [da, dx, db], ["exp", "sin"]), ("muladd", [da, dx, db], ["sin"]), ("fmadd", [da, dx, db], []),
+                             ("mul", [da, dx], ["cos"]), (None, [da], ["abs", "sqrt", "exp"])):
+        terms = op_by_op(capi, base, srcs, maps).numpy().astype(np.float64)
+        got = float(capi.reduce_chain("hsum", base, srcs, maps).numpy()[0])
+        depth = n // (1 << 18) + 40
+        assert abs(got - terms.sum()) <= EPS[dtype] * depth * np.abs(terms).sum(), (base, maps)
+        assert abs(got - terms.sum()) <= EPS[dtype] * (8 * np.sqrt(depth * (terms ** 2).sum()) + 4 * abs(terms.sum())), (base, maps)
+    small = up(capi, (np.abs(a[:4099]) + 0.5).astype(dtype))
+    p64 = float(np.exp(np.log(np.abs(small.numpy().astype(np.float64) * 0.999)).sum()))
+    got = float(capi.reduce_chain("hprod", "mul", [small, 0.999], []).numpy()[0])
+    assert abs(got - p64) <= 4 * 4099 * EPS[dtype] * abs(p64) + 1e-300
+
+
+@pytest.fixture(scope="module")
+def ek():
+    import enoki_amd.hip as m
+    m.hip_init(0)
+    return m
+
+
+def kernels(m, fn):
+    m.hip_profile_begin()
+    out = fn()
+    prof = json.loads(m.hip_profile_end())
+    return out, {k["kernel"]: k["launches"] for k in prof if k["launches"]}
+
+
+def test_cfg2_expression_is_one_pass(ek, oracle):
+    """BASELINE configs[1]: hsum(sin(exp(fmadd(a, x, b)))) on plain arrays -- one chain reduction (+ its second stage), nothing
+    written; the same expression with the operands kept alive afterwards, written with operators, and forced element by element
+    gives the same bits as the oracle's op-by-op evaluation"""
+    n = (1 << 20) + 13
+    a, x, b = uniform_pm1(n, 1), uniform_pm1(n, 2), uniform_pm1(n, 3)
+    da, dx, db = ek.Float32(a), ek.Float32(x), ek.Float32(b)
+    u = oracle.ternary("fmadd", a, x, b)
+    t = oracle.unary("sin", oracle.unary("exp", u)).astype(np.float64)
+    depth = n // (1 << 18) + 40
+    y, ks = kernels(ek, lambda: float(ek.hsum(ek.sin(ek.exp(ek.fmadd(da, dx, db)))).numpy()[0]))
+    assert set(ks) == {"reduce_chain", "reduce_stage2"} and ks["reduce_chain"] == 1, ks
+    assert abs(y - t.sum()) <= 2.0 ** -24 * depth * np.abs(t).sum()
+    # written with operators: a product and a sum, two roundings -- still one pass
+    t2 = oracle.unary("sin", oracle.binary("add", oracle.binary("mul", a, x), b)).astype(np.float64)
+    y2, ks = kernels(ek, lambda: float(ek.hsum(ek.sin(da * dx + db)).numpy()[0]))
+    assert set(ks) == {"reduce_chain", "reduce_stage2"}, ks
+    assert abs(y2 - t2.sum()) <= 2.0 ** -24 * depth * np.abs(t2).sum()
+    y3, ks = kernels(ek, lambda: float(ek.hsum(db - da * dx).numpy()[0]))
+    assert set(ks) == {"reduce_chain", "reduce_stage2"}, ks
+    t3 = oracle.binary("sub", b, oracle.binary("mul", a, x)).astype(np.float64)
+    assert abs(y3 - t3.sum()) <= 2.0 ** -24 * depth * np.abs(t3).sum()
+    # forced: the chain is written by ONE kernel, bit-identical to the oracle's op-by-op values
+    v, ks = kernels(ek, lambda: ek.sin(ek.exp(ek.fmadd(da, dx, db))).numpy())
+    assert ks.get("map_chain") == 1 and not any(k in ks for k in ("fmadd", "exp", "sin")), ks
+    assert bits_equal(v, oracle.unary("sin", oracle.unary("exp", u)))
+    w = (da * dx + db).numpy()
+    assert bits_equal(w, oracle.binary("add", oracle.binary("mul", a, x), b))
+
+
+def test_a_value_somebody_else_holds_is_evaluated_once(ek, oracle):
+    """the chain only absorbs what nobody else wants: u held by the caller is written once and then reused; results are the same"""
+    n = (1 << 18) + 5
+    a, x, b = uniform_pm1(n, 1), uniform_pm1(n, 2), uniform_pm1(n, 3)
+    da, dx, db = ek.Float32(a), ek.Float32(x), ek.Float32(b)
+    u = ek.fmadd(da, dx, db)
+    e = ek.exp(u)
+    y1 = float(ek.hsum(ek.sin(e)).numpy()[0])               # e and u are held: evaluated, sin applied on load
+    y2 = float(ek.hsum(ek.cos(e)).numpy()[0])
+    assert bits_equal(u.numpy(), oracle.ternary("fmadd", a, x, b))
+    assert bits_equal(e.numpy(), oracle.unary("exp", oracle.ternary("fmadd", a, x, b)))
+    t = oracle.unary("exp", oracle.ternary("fmadd", a, x, b))
+    s64, c64 = oracle.unary("sin", t).astype(np.float64), oracle.unary("cos", t).astype(np.float64)
+    assert abs(y1 - s64.sum()) <= 2.0 ** -24 * 48 * np.abs(s64).sum() and abs(y2 - c64.sum()) <= 2.0 ** -24 * 48 * np.abs(c64).sum()
+    # an operand that is overwritten AFTER the node was made: the node sees the old contents (arrays are values)
+    p = da * dx
+    ek.scatter(da, ek.Float32(np.zeros(16, np.float32)), ek.UInt32(np.arange(16, dtype=np.uint32)))
+    assert bits_equal(p.numpy(), oracle.binary("mul", a, x))

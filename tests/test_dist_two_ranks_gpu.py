@@ -13,36 +13,41 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def run_bench(workload, n, ranks, port, dump=None):
+def run_bench(workload, n, ranks, port, dump=None, extra=()):
+    """`python bench.py --gpus <ranks>` exactly as the driver types it for one GPU -- NO launcher, no RANK in the environment: for
+    ranks > 1 bench.py starts its own ranks (torch.distributed.run, rendezvous on 127.0.0.1) and, on a box with fewer GPUs than
+    ranks, routes the collectives through gloo (the line says so).  `port` is unused since round 5 (bench.py picks a free one)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--n", str(n),
-           "--workload", workload, "--no-cpu-baseline", "--no-also", "--profile-steps", "1"]
+           "--workload", workload, "--no-cpu-baseline", "--no-also", "--profile-steps", "1", "--pre-warm-s", "0"] + list(extra)
     if dump:
         cmd += ["--dump-gradients", dump]
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), ENOKI_DIST_BACKEND="gloo")
-    if ranks == 1:
-        out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=300)
-        assert out.returncode == 0, out.stderr[-2000:]
-        return json.loads(out.stdout.strip().splitlines()[-1])
-    procs = [subprocess.Popen(cmd, env=dict(env, RANK=str(r), LOCAL_RANK="0", WORLD_SIZE=str(ranks)), stdout=subprocess.PIPE,
-                              stderr=subprocess.PIPE, text=True) for r in range(ranks)]
-    outs = [p.communicate(timeout=300) for p in procs]
-    for p, (so, se) in zip(procs, outs):
-        assert p.returncode == 0, se[-2000:]
-    line = [l for l in outs[0][0].strip().splitlines() if l.startswith("{")]
-    assert line and not any(l.startswith("{") for l in outs[1][0].splitlines()), "rank 0 alone prints the JSON line"
-    return json.loads(line[-1])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 alone prints the JSON line"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == ranks and line["config"]["world_size"] == ranks, (line["n_gpus"], line["config"].get("world_size"))
+    return line
 
 
 @pytest.mark.parametrize("workload", ["cfg3b", "cfg3a"])
 def test_two_ranks_match_one(workload, tmp_path):
     n = 1 << 22
     one = run_bench(workload, n, 1, 29611, dump=str(tmp_path / "one"))
-    two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613, dump=str(tmp_path / "two"))
+    # cfg3b: ONE reduce-scatter for both gradient tables with the loss riding in an extra column; cfg3a: the loss only
+    two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613, dump=str(tmp_path / "two"),
+                    extra=["--reduce-scatter-grads"] if workload == "cfg3b" else [])
     if workload == "cfg3b":
         check_scattered_gradients(n, tmp_path)
-    # cfg3b: ONE reduce-scatter for both gradient tables with the loss riding in an extra column; cfg3a: the loss only
+        assert "reduce-scatter" in two["config"]["gradient_exchange"]
+        # the record form (north_star: "grad accumulation finished by RCCL all-reduce"): ONE all-reduce, every rank holds all K bins
+        full = run_bench(workload, n, 2, 0, dump=str(tmp_path / "full"))
+        assert "all-reduce" in full["config"]["gradient_exchange"] and full["config"]["collectives_per_step"] == 1
+        check_all_reduced_gradients(n, tmp_path)
     assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2
     assert two["config"]["collectives_per_step"] == 1
+    assert "gloo" in two["config"]["backend"] or "nccl" in two["config"]["backend"]
     truth, bound = truth_y(workload, n)
     assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound, (one["result_y"], two["result_y"], truth, bound)
     assert two["value"] > 0 and two["scaling"] == "strong"
@@ -67,6 +72,22 @@ def check_scattered_gradients(n, tmp_path):
         # two shards: every bin is the sum of two partial sums of at most cnt terms each
         assert np.all(np.abs(whole - t[g]) <= t[g + "_bound"] + 2.0 ** -24 * np.abs(t[g])), g
         assert np.all(np.abs(single[g] - t[g]) <= t[g + "_bound"]), g
+
+
+def check_all_reduced_gradients(n, tmp_path):
+    """default exchange: after ONE all-reduce every rank holds the full gradient tables -- identical on both ranks, inside the
+    per-bin class-D bound of the float64 sums"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import cfg3b_truth, hash_u32, uniform_pm1
+    K = 1 << 20
+    A, B, x = uniform_pm1(K, 6), uniform_pm1(K, 7), uniform_pm1(n, 2)
+    idx = (hash_u32(np.arange(n, dtype=np.uint64), 4) % np.uint32(K)).astype(np.uint32)
+    t = cfg3b_truth(A, B, x, idx)
+    r0, r1 = (np.load(tmp_path / "full" / f"grad_rank{r}.npz") for r in range(2))
+    for g in ("gA", "gB"):
+        assert r0[g].shape == (K,) and np.array_equal(r0[g].view(np.uint32), r1[g].view(np.uint32)), g
+        assert np.all(np.abs(r0[g] - t[g]) <= t[g + "_bound"] + 2.0 ** -24 * np.abs(t[g])), g
 
 
 def truth_y(workload, n):
@@ -100,12 +121,8 @@ def test_two_gpus_rccl():
     way the driver launches it (torch.distributed.run)"""
     n = 1 << 24
     one = run_bench("cfg3b", n, 1, 29621)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29622", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--n", str(n),
-           "--no-cpu-baseline", "--no-also", "--profile-steps", "1"]
-    out = subprocess.run(cmd, env=os.environ.copy(), capture_output=True, text=True, timeout=600)
-    assert out.returncode == 0, out.stderr[-3000:]
-    two = json.loads([l for l in out.stdout.strip().splitlines() if l.startswith("{")][-1])
+    two = run_bench("cfg3b", n, 2, 0)
+    assert "nccl" in two["config"]["backend"], two["config"]["backend"]
     assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 1
     truth, bound = truth_y("cfg3b", n)
     assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound

@@ -91,6 +91,21 @@ def test_cfg2_headline(checker):
     s64 = np.sin(np.exp(a.astype(np.float64) * x + b))
     # sin(exp(u)): the rounding of u (2 ulp absolute) and of exp (1 ulp relative) move the argument of sin by < 24 * 2^-24
     assert abs(y - float(s64.sum())) <= hsum_bound(s64, per_term_ulps=32)
+    # round 5: the expression is ONE pass over a, x, b (the fma and both maps stay unevaluated until the reduction consumes the
+    # chain).  Its terms, written out by the one-kernel form of the same chain, are BIT-IDENTICAL to the CPU oracle's op-by-op
+    # evaluation (class A), and the reduction launched exactly one chain kernel.
+    import json
+    da, dx, db = ekc.Float32(a), ekc.Float32(x), ekc.Float32(b)
+    ekc.hip_profile_begin()
+    y2 = float(ekc.hsum(ekc.sin(ekc.exp(ekc.fmadd(da, dx, db)))).numpy()[0])
+    ks = {k["kernel"]: k["launches"] for k in json.loads(ekc.hip_profile_end()) if k["launches"]}
+    assert ks.get("reduce_chain") == 1 and not any(k in ks for k in ("fmadd", "exp", "sin", "hsum_map")), ks
+    assert y2 == y                                    # (a reduction without atomics: run-to-run reproducible)
+    terms = ekc.sin(ekc.exp(ekc.fmadd(da, dx, db))).numpy()
+    port = ol.port()
+    want = port.unary("sin", port.unary("exp", port.ternary("fmadd", a, x, b)))
+    assert bits_equal(terms, want)
+    assert abs(y - float(terms.astype(np.float64).sum())) <= 2.0 ** -24 * (N // (1 << 19) + 40) * float(np.abs(terms.astype(np.float64)).sum())
 
 
 def test_cfg4_headline_image_bit_exact():
@@ -117,7 +132,9 @@ def test_cfg4_headline_image_bit_exact():
 
 NEIGHBOURS = {"cos": dict(func="cos"), "exp": dict(func="exp"), "seed3": dict(seed=3.0), "masked": dict(masked=True),
               "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22), "sqrt": dict(func="sqrt", shift=3.0),
-              "rcp": dict(func="rcp", shift=3.0)}
+              "rcp": dict(func="rcp", shift=3.0),
+              # `y=hsum(sin(a*x+b))` as BASELINE.json configs[2] spells it: operators, two roundings (bench.py: cfg3b_operators)
+              "operators": dict(spelling="a*x+b")}
 
 
 @pytest.mark.parametrize("name", list(NEIGHBOURS))
@@ -142,7 +159,8 @@ def test_cfg3b_neighbours_at_the_headline_size(ek, checker, name):
         a, b = ek.gather(dA, di, dm), ek.gather(dB, di, dm)
     else:
         a, b = ek.gather(dA, di), ek.gather(dB, di)
-    y = ek.hsum(getattr(ek, kw.get("func", "sin"))(ek.fmadd(a, ek.Float32(x), b)))
+    u = a * ek.Float32(x) + b if kw.get("spelling") == "a*x+b" else ek.fmadd(a, ek.Float32(x), b)
+    y = ek.hsum(getattr(ek, kw.get("func", "sin"))(u))
     z = y * kw["seed"] if "seed" in kw else y
     ek.backward(z)
     yv, gA, gB = float(ek.detach(z).numpy()[0]), ek.gradient(dA).numpy(), ek.gradient(dB).numpy()

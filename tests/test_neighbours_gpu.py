@@ -44,7 +44,7 @@ def kernels(m, fn):
     return out, {k["kernel"]: k["launches"] for k in prof if k["launches"]}
 
 
-def run(ad, A, B, x, idx, mask=None, func="sin", seed=1.0, idx64=False):
+def run(ad, A, B, x, idx, mask=None, func="sin", seed=1.0, idx64=False, spelling="fmadd"):
     dA, dB = ad.Float32(A), ad.Float32(B)
     ad.set_requires_gradient(dA); ad.set_requires_gradient(dB)
     di = ad.UInt64(idx.astype(np.uint64)) if idx64 else ad.UInt32(idx)
@@ -54,7 +54,10 @@ def run(ad, A, B, x, idx, mask=None, func="sin", seed=1.0, idx64=False):
         a, b = ad.gather(dA, di, dm), ad.gather(dB, di, dm)
     else:
         a, b = ad.gather(dA, di), ad.gather(dB, di)
-    y = ad.hsum(getattr(ad, func)(ad.fmadd(a, xd, b)))
+    # BASELINE.json spells config 3b `a*x+b`: operators -- a product and a sum with a rounding each, not one fma
+    u = {"fmadd": lambda: ad.fmadd(a, xd, b), "a*x+b": lambda: a * xd + b, "a*x-b": lambda: a * xd - b, "b-a*x": lambda: b - a * xd,
+         "b+a*x": lambda: b + a * xd}[spelling]()
+    y = ad.hsum(getattr(ad, func)(u))
     z = y if seed == 1.0 else y * seed
     ad.backward(z)
     return float(ad.detach(z).numpy()[0]), ad.gradient(dA).numpy(), ad.gradient(dB).numpy()
@@ -77,9 +80,17 @@ CASES = {
     # -sqr(rcp(u)) and -.5 rsqrt(u)^3 (autodiff.h:381-403): products of unevaluated maps stay ONE map of u each
     "rcp": dict(func="rcp", shift=3.0),
     "rsqrt": dict(func="rsqrt", shift=3.0),
+    # the operator spellings of u (the literal `hsum(sin(a*x+b))` of BASELINE.json configs[2] is the first): two roundings, checked
+    # against the reference build evaluating the SAME spelling
+    "operators": dict(spelling="a*x+b"),
+    "operators_commuted": dict(spelling="b+a*x"),
+    "operators_minus": dict(spelling="a*x-b", func="cos"),
+    "operators_reversed_minus": dict(spelling="b-a*x", func="exp", seed=2.0),
+    "operators_masked_i64": dict(spelling="a*x+b", masked=True, idx64=True),
 }
 # what the step may launch when it stays in bucket order: ONE partition in the forward pass, the adjoint formed there as well
-EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt", "sqrt_seed3", "rcp", "rsqrt"}
+EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt", "sqrt_seed3", "rcp", "rsqrt",
+         "operators", "operators_commuted", "operators_minus", "operators_reversed_minus", "operators_masked_i64"}
 
 
 @pytest.mark.parametrize("name", list(CASES))

@@ -31,8 +31,17 @@ def kernels(d):
         cur = sqlite3.connect(f).cursor()
         print(f"# rocprofv3 --kernel-trace --stats  ({f})")
         print(f"{'kernel':112s} {'calls':>6s} {'total_us':>12s} {'avg_us':>10s} {'%':>7s}")
-        for name, calls, total, avg, pct in cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"):
+        rows = list(cur.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
+        for name, calls, total, avg, pct in rows:
             print(f"{short(name):112s} {calls:6d} {total:12.1f} {avg:10.2f} {pct:7.2f}")
+        # one step of the profiled workload = one launch of the partition kernel (bucket-ordered workloads): every kernel that is
+        # launched at least once per step, summed over ALL its launches and divided by the number of steps -- what the kernels of one
+        # step take back to back on an in-order stream (bench.py compares its ms_per_step with this: trace_check)
+        steps = max((calls for name, calls, *_ in rows if "k_page_partition" in name), default=0)
+        if steps:
+            per_step = sum(total for name, calls, total, *_ in rows if calls >= steps) / steps
+            print(f"# steps: {steps}")
+            print(f"# step_sum_us: {per_step:.2f}")
 
 
 def pmc(dirs):
