@@ -110,7 +110,10 @@ def parse():
     ap.add_argument("--pre-warm-s", type=float, default=0.6,
                     help="seconds of the headline step run BEFORE the --warmup steps (clocks and caches in the state of a long run; "
                          "reported as pre_warm_s, outside the timed region)")
-    return ap.parse_args()
+    # ranks started by relaunch_as_ranks() receive the original command line through the environment: torch.distributed.run parses
+    # its own options with prefix matching, and a script argument like `--n` is ambiguous to it
+    forwarded = os.environ.get("ENOKI_BENCH_ARGV")
+    return ap.parse_args(json.loads(forwarded)) if forwarded is not None else ap.parse_args()
 
 
 PMC_FILE = os.path.join("profiles", "rocprof_pmc_r05.txt")
@@ -860,8 +863,9 @@ def relaunch_as_ranks(args):
         env.setdefault("ENOKI_DIST_BACKEND", "gloo")
         print(f"[bench] --gpus {args.gpus} on {torch.cuda.device_count()} visible GPU(s): ranks share devices, collectives through gloo",
               file=sys.stderr)
+    env["ENOKI_BENCH_ARGV"] = json.dumps(sys.argv[1:])
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+           "--master-port", str(port), os.path.abspath(__file__), "--gpus", str(args.gpus)]
     return subprocess.call(cmd, env=env)
 
 

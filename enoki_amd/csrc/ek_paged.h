@@ -515,6 +515,10 @@ struct PagedPlan {
 static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu) {
     PagedPlan p;
     p.page_shift = n_buckets > 128 ? 5 : 6;
+    // (measurement only: ENOKI_HIP_PAGE_SHIFT=5 halves the pages of a table of <= 128 buckets -- half as many elements in the
+    // partially filled page that every (workgroup, bucket) leaves behind, which small inputs pay for: tools/gpu_call3_r05.sh)
+    static const int forced = [] { const char *e = getenv("ENOKI_HIP_PAGE_SHIFT"); return e ? atoi(e) : 0; }();
+    if (forced == 5) p.page_shift = 5;
     int nb2 = 2;
     while (nb2 < n_buckets) nb2 <<= 1;
     p.cap = (uint32_t) (kPgLdsElems / nb2);

@@ -294,29 +294,53 @@ __device__ __forceinline__ void chain_load(const ChainArgs<T> &ch, const T (&s)[
     for (int i = 0; i < N; ++i) { r[i] = p0.v[i]; b[i] = p1.v[i]; c[i] = p2.v[i]; }
 }
 
+// The reduction TREE is that of k_reduce_stage1 over a plain array, slot for slot (same grid, four vectors per lane and trip, one
+// accumulator per vector slot, the same tail and the same combine order): the result is bit-identical to evaluating the chain
+// op by op and reducing the array -- deferred evaluation never changes a bit (tests/cpp fuzz programs compare exactly that).
 template <typename R, typename T>
 __global__ __launch_bounds__(256) void k_chain_reduce(T *__restrict__ partials, size_t n, int vec_ok, ChainArgs<T> ch) {
-    constexpr int N = 16 / sizeof(T);
+    constexpr int N = 16 / sizeof(T), U = 4, E = N * U;
     T s[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) s[k] = ch.src[k].vec ? T(0) : arg_scalar(ch.src[k]);
-    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256, nvec = (n + N - 1) / N;
-    T acc[N];
+    const size_t gid = (size_t) blockIdx.x * 256 + threadIdx.x, total = (size_t) gridDim.x * 256;
+    T acc[U];
 #pragma unroll
-    for (int i = 0; i < N; ++i) acc[i] = R::identity();
-    for (size_t v = gid; v < nvec; v += total) {
-        const size_t e = v * N;
-        const bool whole = e + N <= n;
-        T r[N], b[N], c[N];
-        chain_load<T, N>(ch, s, e, n, vec_ok && whole, r, b, c);
-        chain_apply<T, N>(r, b, c, ch);
+    for (int k = 0; k < U; ++k) acc[k] = R::identity();
+    size_t done = 0;
+    if (vec_ok) {
+        const size_t nvec = n / N;
+        for (size_t v0 = gid; v0 < nvec; v0 += total * U) {
+            T r[E], b[E], c[E];
 #pragma unroll
-        for (int i = 0; i < N; ++i)
-            if (whole || e + i < n) acc[i] = R::combine(acc[i], r[i]);
+            for (int k = 0; k < U; ++k) {
+                // (a slot beyond the end reads the first vector again: its values are computed and not used)
+                const size_t v = v0 + k * total < nvec ? v0 + k * total : 0;
+                const Pack<T, N> p0 = arg_load<T, N, true>(ch.src[0], s[0], v * N, n, true), p1 = arg_load<T, N, true>(ch.src[1], s[1], v * N, n, true),
+                                 p2 = arg_load<T, N, true>(ch.src[2], s[2], v * N, n, true);
+#pragma unroll
+                for (int i = 0; i < N; ++i) { r[k * N + i] = p0.v[i]; b[k * N + i] = p1.v[i]; c[k * N + i] = p2.v[i]; }
+            }
+            chain_apply<T, E>(r, b, c, ch);
+#pragma unroll
+            for (int k = 0; k < U; ++k) {
+                if (v0 + k * total < nvec) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) acc[k] = R::combine(acc[k], r[k * N + i]);
+                }
+            }
+        }
+        done = nvec * N;
     }
-    T v = acc[0];
-#pragma unroll
-    for (int i = 1; i < N; ++i) v = R::combine(v, acc[i]);
+    for (size_t i = done + gid; i < n; i += total) {
+        T r[1], b[1], c[1];
+        r[0] = ch.src[0].vec ? ch.src[0].ptr[i] : s[0];
+        b[0] = ch.src[1].vec ? ch.src[1].ptr[i] : s[1];
+        c[0] = ch.src[2].vec ? ch.src[2].ptr[i] : s[2];
+        chain_apply<T, 1>(r, b, c, ch);
+        acc[0] = R::combine(acc[0], r[0]);
+    }
+    T v = R::combine(R::combine(acc[0], acc[1]), R::combine(acc[2], acc[3]));
     v = block_reduce<R>(v);
     if (threadIdx.x == 0) partials[blockIdx.x] = v;
 }
@@ -378,8 +402,8 @@ template <typename T> int chain_reduce(int op, void *out, const ek_chain *chain,
     RoctxRange range("enoki-hip: horizontal reduction of a chain");
     Context &c = ctx();
     constexpr int N = 16 / sizeof(T);
-    // transcendental stages make the pass VALU-bound: as many resident waves as the registers allow, every lane a few vectors
-    unsigned grid = stream_grid((n / N + 3) / 4 + 1, 2 * c.tuning.reduce_blocks_per_cu);
+    // the grid of reduce_launch() over a plain array of n elements: same partial sums, same second stage
+    unsigned grid = stream_grid((n / N + 3) / 4 + 1, c.tuning.reduce_blocks_per_cu);
     if (grid > 2048) grid = 2048;
     void *scratch = nullptr;
     if (int rc = reduce_scratch((size_t) grid * sizeof(T), &scratch)) return rc;

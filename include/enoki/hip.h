@@ -363,6 +363,12 @@ namespace detail {
             ptr = p;
             drop_deferred();
         }
+        /// A pending zeros node becomes the owner of a buffer that already holds what its only consumer would have written
+        /// (allocated by ek_hip_malloc: ek_hip_bucketed_take_early)
+        void adopt_pointer(void *p) {
+            ptr = p;
+            drop_deferred();
+        }
         /// Storage without contents for a pending zeros node whose only consumer is about to overwrite every entry
         void adopt_uninitialized() {
             void *p = nullptr;
@@ -1440,6 +1446,15 @@ template <typename Value_> struct HIPArray : ArrayTag {
                 u = src;
             }
             weighted[c] = weights && weights[c] ? 1 : 0;
+            if (weighted[c] && weights[c]->m_is_imm) {
+                // a host-scalar weight (the -1 that `p - gather(B, idx)` records for its subtrahend): the stream's scale takes it
+                // when the product has the bits of safe_mul(w, scale * f(u)) -- one of the two factors is +-1
+                Value sc, w = weights[c]->m_imm;
+                memcpy(&sc, &scale[c], sizeof(Value));
+                if (w == Value(0) || !(w == w) || (sc != Value(1) && sc != Value(-1) && w != Value(1) && w != Value(-1))) return false;
+                scale[c] = imm_bits(sc * w);
+                weighted[c] = 0;
+            }
         }
         if (!u) {
             // only host scalars: the partition still pays when a weight names the x of a pending fma over this index array
@@ -1469,6 +1484,15 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if (!u->deferred) return false;
         ek_hip_bucketed *b = u->bucketed();
         if (!b) return false;
+        if (count == 2 && fresh[0] && fresh[1] && sizeof(Value) == 4) {
+            // both targets are fresh gradient buffers and the forward pass left exactly these sums per table entry: the
+            // gradient arrays take the tables over, no kernel runs
+            void *taken[2] = { nullptr, nullptr };
+            if (ek_hip_bucketed_take_early(b, 2, from_u, ops, weighted, scale, taken) == EK_OK) {
+                for (size_t c = 0; c < 2; ++c) targets[c]->m_buf->adopt_pointer(taken[c]);
+                return true;
+            }
+        }
         for (size_t c = 0; c < count; ++c) {
             if (fresh[c]) targets[c]->m_buf->adopt_uninitialized();
             bases[c] = targets[c]->m_buf->ptr;

@@ -81,9 +81,10 @@ def test_chain_sums_are_class_d(capi, dtype):
         depth = n // (1 << 18) + 40
         assert abs(got - terms.sum()) <= EPS[dtype] * depth * np.abs(terms).sum(), (base, maps)
         assert abs(got - terms.sum()) <= EPS[dtype] * (8 * np.sqrt(depth * (terms ** 2).sum()) + 4 * abs(terms.sum())), (base, maps)
-    small = up(capi, (np.abs(a[:4099]) + 0.5).astype(dtype))
-    p64 = float(np.exp(np.log(np.abs(small.numpy().astype(np.float64) * 0.999)).sum()))
-    got = float(capi.reduce_chain("hprod", "mul", [small, 0.999], []).numpy()[0])
+    small = up(capi, (1.0 + 0.05 * a[:4099]).astype(dtype))            # factors near 1: the product of 4099 of them stays in range
+    sc = float(np.asarray(1.001, dtype))
+    p64 = float(np.exp(np.log(small.numpy().astype(np.float64) * sc).sum()))
+    got = float(capi.reduce_chain("hprod", "mul", [small, sc], []).numpy()[0])
     assert abs(got - p64) <= 4 * 4099 * EPS[dtype] * abs(p64) + 1e-300
 
 

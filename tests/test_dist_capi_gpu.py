@@ -83,12 +83,12 @@ capi.sync()
 assert np.array_equal(buf.numpy(), np.arange(64, dtype=np.float32))
 capi.check(lib.ek_hip_dist_finalize())
 mapped = sorted({l.split()[-1] for l in open("/proc/self/maps") if "librccl" in l})
-print("RCCL", lib.ek_hip_dist_rccl_path().decode(), "|", ";".join(mapped))
+print("EK_RCCL_COPY=" + lib.ek_hip_dist_rccl_path().decode() + " | " + ";".join(mapped))
 '''
     out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
-    line = [l for l in out.stdout.splitlines() if l.startswith("RCCL ")][-1]
-    used, mapped = line[5:].split(" | ")
+    line = [l for l in out.stdout.splitlines() if l.startswith("EK_RCCL_COPY=")][-1]
+    used, mapped = line[len("EK_RCCL_COPY="):].split(" | ")
     mapped = [m for m in mapped.split(";") if m]
     assert len(mapped) == 1, f"more than one RCCL copy mapped: {mapped}"
     assert os.path.realpath(used) == os.path.realpath(mapped[0]), (used, mapped)
