@@ -46,7 +46,7 @@ EXPORTS = [
     "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_reduce_chain", "ek_hip_map_chain", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
     "ek_hip_dist_unique_id", "ek_hip_dist_init", "ek_hip_dist_world", "ek_hip_dist_shard_range", "ek_hip_dist_all_reduce",
     "ek_hip_dist_reduce_scatter", "ek_hip_dist_all_gather", "ek_hip_dist_finalize", "ek_hip_dist_rccl_path",
-    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_pair_create_masked", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add", "ek_hip_bucketed_scatter_add_scaled", "ek_hip_bucketed_early_pair", "ek_hip_bucketed_take_early",
+    "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_pair_create_masked", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add", "ek_hip_bucketed_scatter_add_scaled", "ek_hip_bucketed_early_pair",
     "ek_hip_bucketed_destroy", "ek_hip_index_partition_create", "ek_hip_index_partition_get", "ek_hip_index_partition_destroy", "ek_hip_gather_address",
 ]
 

@@ -90,10 +90,6 @@ template <typename T> struct BucketFinish {
     const uint32_t *active;
     size_t n;
     int zero_op;             // what a dropped lane (u = 0) contributes, as a function of 0
-    // forward + adjoint kernel: the LAST piece of a bucket to finish sums the bucket's per-piece tables into the object's own
-    // K-sized tables (bucket_fold_last_piece); null: the per-piece tables are folded by a launch of their own in backward()
-    uint32_t *bucket_ticket = nullptr;
-    T *folded[2] = { nullptr, nullptr };
 };
 
 template <typename T> __device__ __forceinline__ T bucket_shfl_down(T v, int delta) {
@@ -1008,61 +1004,6 @@ __host__ __device__ constexpr bool early_pair_supported(int map_op, int keep_op)
                                  map_op == EK_RSQRT || map_op == EK_LOG || map_op == EK_ABS || map_op == EK_NEG);
 }
 
-// The per-piece gradient tables of a bucket, summed by the LAST of the bucket's pieces to finish -- instead of k_bin_fold_pieces
-// in backward() (8-13 us + a launch gap per step; an 8 Mi-element shard step spends a tenth of its time there).  Every piece
-// writes its tables as before, fences them to agent scope and takes a ticket of its bucket; the piece that draws the last ticket
-// adds the other pieces' tables (written on other XCDs: read behind an acquire, with agent-scope loads) to its own, which are
-// still in the LDS, in piece order, and writes the bucket's slice of the object's two K-sized tables.  backward() then hands
-// those tables to the gradient arrays as they are (seed 1, fresh targets: ek_hip_bucketed_take_early) or scales / adds them
-// in one small pass.  A bucket of one piece writes its slice directly.
-template <typename T>
-__device__ __forceinline__ void bucket_zero_slices(const BucketFinish<T> &fin, int b0, int b1, int Bins, size_t table_size) {
-    const size_t lo = (size_t) b0 * Bins, hi = (size_t) b1 * Bins < table_size ? (size_t) b1 * Bins : table_size;
-    for (size_t k = lo + threadIdx.x; k < hi; k += kBucketThreads) { fin.folded[0][k] = T(0); fin.folded[1][k] = T(0); }
-}
-
-template <typename T, bool Paired>
-__device__ __forceinline__ void bucket_fold_last_piece(const BucketFinish<T> &fin, const BucketLists &bl, int bucket, const T *tables,
-                                                       const T *table_partials, int Bins, size_t table_size) {
-    if (!fin.folded[0]) return;
-    using Bits = std::conditional_t<sizeof(T) == 4, uint32_t, unsigned long long>;
-    __shared__ uint32_t s_fold;
-    const uint32_t p0 = bl.piece_prefix[bucket], pieces = bl.piece_prefix[bucket + 1] - p0;
-    __threadfence();                                   // this thread's part of the piece's tables: visible at agent scope
-    __syncthreads();
-    if (threadIdx.x == 0)
-        s_fold = pieces == 1 || __hip_atomic_fetch_add(fin.bucket_ticket + bucket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == pieces - 1u;
-    __syncthreads();
-    if (!s_fold) return;
-    if (threadIdx.x == 0 && pieces > 1) __hip_atomic_store(fin.bucket_ticket + bucket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);           // (agent scope: the other pieces' tables as their tickets published them)
-    const size_t first = (size_t) bucket * Bins;
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        for (int j = threadIdx.x; j < Bins && first + j < table_size; j += kBucketThreads) {
-            T sum = T(0);
-            for (uint32_t p = p0; p < p0 + pieces; ++p) {
-                T v;
-                if (p == blockIdx.x) {
-                    v = Paired ? tables[2 * j + c] : tables[c * Bins + j];
-                } else {
-                    const Bits b = __hip_atomic_load(reinterpret_cast<const Bits *>(table_partials + ((size_t) c * gridDim.x + p) * Bins + j),
-                                                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __builtin_memcpy(&v, &b, sizeof(T));
-                }
-                sum += v;
-            }
-            fin.folded[c][first + j] = sum;
-        }
-    }
-    // buckets that received no element have no piece: their slices hold zeros, written by the last piece of the nearest populated
-    // bucket below them (and, for leading empty buckets, of the first populated one)
-    int e0 = bucket + 1, e1 = e0;
-    while (e1 < bl.n_buckets && bl.piece_prefix[e1 + 1] == bl.piece_prefix[e1]) ++e1;
-    bucket_zero_slices(fin, e0, e1, Bins, table_size);
-    if (p0 == 0 && bucket > 0) bucket_zero_slices(fin, 0, bucket, Bins, table_size);
-}
-
 template <typename T, int V, int PS>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
                                                                                 const T *__restrict__ table_a,
@@ -1081,8 +1022,6 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     int bucket;
     PieceRange range;
     if (!bucket_piece<PS>(bl, bucket, range)) {
-        // (no element at all -- every lane masked out: nobody folds, the tables are zero)
-        if (blockIdx.x == 0 && fin.folded[0]) bucket_zero_slices(fin, 0, bl.n_buckets, Bins, table_size);
         bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
         return;
     }
@@ -1120,21 +1059,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         T *out = table_partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
         for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? tables[2 * j + c] : tables[c * Bins + j];
     }
-    bucket_fold_last_piece<T, Paired>(fin, bl, bucket, tables, table_partials, Bins, table_size);
     bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
-}
-
-// target = (fresh ? 0 : target) + scale * folded  -- what is left of the adjoint's scatter_add when the forward pass formed the
-// sums per entry already and the target cannot simply take the table over (a seed other than 1, a target that holds data)
-template <typename T> struct ApplyFolded { T *target[2]; const T *folded[2]; T scale[2]; unsigned fresh; };
-template <typename T>
-__global__ __launch_bounds__(256) void k_apply_folded(ApplyFolded<T> a, size_t table_size) {
-    const size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
-    if (k >= table_size) return;
-    const int c = blockIdx.y;
-    T sum = a.folded[c][k];
-    if (a.scale[c] != T(1)) sum = sum * a.scale[c];
-    a.target[c][k] = ((a.fresh >> c) & 1u) ? T(0) + sum : a.target[c][k] + sum;
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -1166,8 +1091,6 @@ struct Bucketed {
     uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
     const uint32_t *active = nullptr;      // device: [0] number of elements in the lists, [1] non-finite x under a cleared mask bit (null: contiguous lists)
     uint32_t *ticket = nullptr;            // device, zero between launches: the last workgroup of a reducing launch finishes the reduction (bucket_finish)
-    uint32_t *bucket_ticket = nullptr;     // device, [n_buckets], zero between launches: the last piece of a bucket folds its tables
-    void *folded[2] = { nullptr, nullptr };    // the early adjoint's sums per table ENTRY (table_size each): [0] early_op(u), [1] x * early_op(u)
     uint32_t win_lo = 0, win_span = 0;     // a slice of a large table: only indices in [win_lo, win_lo + win_span) (ek_hip_bucketed::slices)
     bool correct_masked = true;            // the final reduction adds the masked-out lanes' map_op(0) terms (slices: their owner does)
 
@@ -1185,7 +1108,7 @@ struct Bucketed {
     size_t bins() const { return (size_t) 1 << shift; }
     BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
     ~Bucketed() {
-        for (void *p : { meta, pair_idx, x_b, u_b, m_b, early, page_lists, folded[0], folded[1] })
+        for (void *p : { meta, pair_idx, x_b, u_b, m_b, early, page_lists })
             if (p) ek_hip_free(p);
     }
 };
@@ -1327,8 +1250,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->positions = p.page_slots << p.page_shift;
     const uint32_t target_pieces = (uint32_t) bucket_target_pieces(n, n_buckets);
     b->max_pieces = target_pieces + (unsigned) n_buckets;
-    // meta: gtotal[3][256] | bucket tickets [256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
-    const size_t meta_words = 4 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
+    // meta: gtotal[3][256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
+    const size_t meta_words = 3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
     if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(float) + 16, &b->meta)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(uint16_t), &b->pair_idx)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(float), &b->x_b)) return rc;
@@ -1337,10 +1260,9 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->glist_full = (uint32_t *) b->page_lists;
     b->glist_part = b->glist_full + p.page_slots;
     uint32_t *gtotal = (uint32_t *) b->meta;
-    b->bucket_base = gtotal + 4 * kMaxBuckets;
+    b->bucket_base = gtotal + 3 * kMaxBuckets;
     b->active = gtotal + 2 * kMaxBuckets;
     b->ticket = gtotal + 2 * kMaxBuckets + 2;              // (zeroed by the memset below, reset by whoever draws the last ticket)
-    b->bucket_ticket = gtotal + 3 * kMaxBuckets;
     b->has_mask = mask.vec != 0;
     b->base_part = b->bucket_base + kMaxBuckets + 1;
     b->piece_prefix = b->base_part + kMaxBuckets + 1;
@@ -1359,7 +1281,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.gtotal = gtotal;
     out.active = gtotal + 2 * kMaxBuckets;
     out.lo = b->win_lo; out.span = b->win_span ? b->win_span : (uint32_t) std::min<size_t>(b->table_size, 0xFFFFFFFFu);
-    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 4 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
         if (int rc = allow_big_lds(kernel, p.lds)) return rc;
@@ -1475,27 +1397,16 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
 #endif
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
-    BucketFinish<T> fin = b->template finish<T>(out, map_op);
-    if (b->bucket_ticket) {
-        // the bucket's last piece sums the per-piece tables into two tables of the object's own (separate allocations: each can be
-        // handed to a gradient array as it is)
-        for (int c = 0; c < 2; ++c) {
-            if (!b->folded[c])
-                if (int rc = ek_hip_malloc(b->table_size * sizeof(T), &b->folded[c])) return rc;
-            fin.folded[c] = (T *) b->folded[c];
-        }
-        fin.bucket_ticket = b->bucket_ticket;
-    }
     const int flip_a = b->flip_a(), flip_c = b->flip_c(), two = b->two_roundings();
     EK_BY_LAYOUT(b, {
         if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV, PS>, lds)) return rc;
         hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
                            (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
-                           flip_a, flip_c, two, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift, fin);
+                           flip_a, flip_c, two, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift,
+                           b->template finish<T>(out, map_op));
     });
     EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
-                    b->n * (sizeof(uint16_t) + sizeof(T)) + 2 * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T) +
-                    (fin.folded[0] ? 2 * b->table_size * sizeof(T) : 0));
+                    b->n * (sizeof(uint16_t) + sizeof(T)) + 2 * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
     b->has_early = true;
     b->early_op = keep_op;
     if (!b->ticket) {
@@ -1564,20 +1475,6 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
         for (int s = 0; s < count; ++s)
             match = match && from_u[s] && (map_ops ? map_ops[s] : (int) EK_COPY) == b->early_op;
         if (count == 2) match = match && (weighted[0] != 0) != (weighted[1] != 0);
-        if (match && b->folded[0] && b->folded[1]) {
-            // the bucket's last piece folded the per-piece tables already: one small pass of scale / add per table
-            Context &c = ctx();
-            ApplyFolded<T> a{};
-            for (int s = 0; s < count; ++s) {
-                a.target[s] = (T *) bases[s];
-                a.folded[s] = (const T *) b->folded[weighted[s] ? 1 : 0];
-                a.scale[s] = scale[s];
-                a.fresh |= (fresh && fresh[s]) ? 1u << s : 0u;
-            }
-            hipLaunchKernelGGL((k_apply_folded<T>), dim3((unsigned) ((b->table_size + 255) / 256), count), dim3(256), 0, c.stream, a, b->table_size);
-            EK_LAUNCH_CHECK("scatter_add_fold", (size_t) count * b->table_size, (size_t) count * 3 * b->table_size * sizeof(T));
-            return EK_OK;
-        }
         if (match) {
             Context &c = ctx();
             const size_t stride = (size_t) b->max_pieces * b->bins();
@@ -1892,26 +1789,6 @@ int ek_hip_bucketed_scatter_add(ek_hip_bucketed *b, int count, void *const *base
 }
 
 int ek_hip_bucketed_early_pair(int map_op, int keep_op) { return early_pair_supported(map_op, keep_op) ? 1 : 0; }
-
-int ek_hip_bucketed_take_early(ek_hip_bucketed *b, int count, const int *from_u, const int *map_ops, const int *weighted,
-                               const uint64_t *scale_bits, void **tables) {
-    if (!b || !from_u || !weighted || !tables || count != 2) return fail(EK_ERR_INVALID, "ek_hip_bucketed_take_early(): bad arguments");
-    // exactly the two streams whose sums per table entry the forward pass left in the object's own tables, unscaled
-    if (!b->slices.empty() || !b->has_early || !b->folded[0] || !b->folded[1] || b->type != EK_F32) return EK_ERR_UNSUPPORTED;
-    const uint32_t one = 0x3F800000u;
-    for (int s = 0; s < 2; ++s) {
-        if (!from_u[s] || (map_ops ? map_ops[s] : (int) EK_COPY) != b->early_op) return EK_ERR_UNSUPPORTED;
-        if (scale_bits && (uint32_t) scale_bits[s] != one) return EK_ERR_UNSUPPORTED;
-    }
-    if ((weighted[0] != 0) == (weighted[1] != 0)) return EK_ERR_UNSUPPORTED;
-    for (int s = 0; s < 2; ++s) {
-        tables[s] = b->folded[weighted[s] ? 1 : 0];
-        b->folded[weighted[s] ? 1 : 0] = nullptr;
-    }
-    b->has_early = false;              // the sums have left: a second request re-evaluates the streams on the lists
-    note_launch("scatter_add_adopt", 0, 0);
-    return EK_OK;
-}
 
 int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                        const uint64_t *imm_bits, const int *weighted, const int *fresh, const uint64_t *scale_bits) {

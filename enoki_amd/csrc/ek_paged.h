@@ -279,6 +279,8 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
 #endif
     // whole tiles of 16-byte aligned operands: two tiles of loads in flight ahead of the one that is being placed.  The two
     // register sets alternate (a rotation by moves would have to wait for the loads it moves).
+    // (Tiles handed out round robin -- at every moment the W workgroups reading W consecutive 16-KiB stretches instead of W
+    // stretches a whole chunk apart -- were measured in round 5: 188-191 us against 185-186, profiles/probe_paged_r05.txt.)
     size_t base = begin;
     const size_t ntiles = vec_ok ? (end - begin) / kPgTile : 0;
     if (ntiles > 0) {
@@ -515,10 +517,6 @@ struct PagedPlan {
 static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu) {
     PagedPlan p;
     p.page_shift = n_buckets > 128 ? 5 : 6;
-    // (measurement only: ENOKI_HIP_PAGE_SHIFT=5 halves the pages of a table of <= 128 buckets -- half as many elements in the
-    // partially filled page that every (workgroup, bucket) leaves behind, which small inputs pay for: tools/gpu_call3_r05.sh)
-    static const int forced = [] { const char *e = getenv("ENOKI_HIP_PAGE_SHIFT"); return e ? atoi(e) : 0; }();
-    if (forced == 5) p.page_shift = 5;
     int nb2 = 2;
     while (nb2 < n_buckets) nb2 <<= 1;
     p.cap = (uint32_t) (kPgLdsElems / nb2);

@@ -363,12 +363,6 @@ namespace detail {
             ptr = p;
             drop_deferred();
         }
-        /// A pending zeros node becomes the owner of a buffer that already holds what its only consumer would have written
-        /// (allocated by ek_hip_malloc: ek_hip_bucketed_take_early)
-        void adopt_pointer(void *p) {
-            ptr = p;
-            drop_deferred();
-        }
         /// Storage without contents for a pending zeros node whose only consumer is about to overwrite every entry
         void adopt_uninitialized() {
             void *p = nullptr;
@@ -1484,15 +1478,6 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if (!u->deferred) return false;
         ek_hip_bucketed *b = u->bucketed();
         if (!b) return false;
-        if (count == 2 && fresh[0] && fresh[1] && sizeof(Value) == 4) {
-            // both targets are fresh gradient buffers and the forward pass left exactly these sums per table entry: the
-            // gradient arrays take the tables over, no kernel runs
-            void *taken[2] = { nullptr, nullptr };
-            if (ek_hip_bucketed_take_early(b, 2, from_u, ops, weighted, scale, taken) == EK_OK) {
-                for (size_t c = 0; c < 2; ++c) targets[c]->m_buf->adopt_pointer(taken[c]);
-                return true;
-            }
-        }
         for (size_t c = 0; c < count; ++c) {
             if (fresh[c]) targets[c]->m_buf->adopt_uninitialized();
             bases[c] = targets[c]->m_buf->ptr;

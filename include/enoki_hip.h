@@ -310,14 +310,6 @@ EK_API int ek_hip_bucketed_scatter_add_scaled(ek_hip_bucketed *b, int count, voi
 /* != 0: a hinted object sums keep_op(u) and x * keep_op(u) per table entry inside reduce(EK_HSUM, map_op, keep, keep_op):
  * {sin, cos}, {cos, sin}, {log, rcp} and {f, f} for f in neg abs sqrt rcp rsqrt sin cos exp log */
 EK_API int ek_hip_bucketed_early_pair(int map_op, int keep_op);
-/* The adjoint without a kernel: when the reduce call of a hinted object formed the sums of keep_op(u) and x * keep_op(u) per table
- * entry (its last piece per bucket folds them into two tables of table_size entries that the object owns), and the scatter_add that
- * backward() is about to issue is exactly { keep_op(u), x * keep_op(u) } with scale 1 into two FRESH tables, the caller may take
- * the tables over instead: tables[s] receives the buffer for stream s (allocated by ek_hip_malloc: the caller now owns it and
- * frees it with ek_hip_free).  EK_ERR_UNSUPPORTED: not that situation -- call ek_hip_bucketed_scatter_add_scaled as before.
- * (The reference accumulates such gradients with atom.global.add into a zero-filled buffer, cuda.h:892-905 / autodiff.cpp:332-338.) */
-EK_API int ek_hip_bucketed_take_early(ek_hip_bucketed *b, int count, const int *from_u, const int *map_ops, const int *weighted,
-                                      const uint64_t *scale_bits, void **tables);
 EK_API int ek_hip_bucketed_destroy(ek_hip_bucketed *b);
 /* ---- multi-GPU without python / torch (csrc/dist.cpp) -------------------------------------------------------------------------
  * One process per GPU.  Index-range sharding: rank r owns [r n / P, (r + 1) n / P) of EVERY size-n array (ek_hip_dist_shard_range),

@@ -381,7 +381,6 @@ static float chain_value(const ek_chain *ch, size_t i) {
     for (int k = 0; k < ch->n_maps; ++k) r = unary_f(ch->map_ops[k], r);
     return r;
 }
-int ek_hip_bucketed_take_early(ek_hip_bucketed *, int, const int *, const int *, const int *, const uint64_t *, void **) { return EK_ERR_UNSUPPORTED; }
 int ek_hip_map_chain(int, void *out, const ek_chain *ch, size_t n) {
     ++g_chain_calls;
     for (size_t i = 0; i < n; ++i) ((float *) out)[i] = chain_value(ch, i);

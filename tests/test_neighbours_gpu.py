@@ -113,10 +113,7 @@ def test_neighbour_matches_the_reference_and_stays_in_bucket_order(ad, ref, data
     assert not any(k in ks for k in ("gather_pair_fmadd", "gather", "scatter_add_partition", "scatter_add_count", "hsum_map")), (name, ks)
     if name in EARLY:
         assert ks.get("bucket_pair_fma_reduce_adjoint") == 1 and "bucket_accumulate" not in ks, (name, ks)
-        # round 5: the bucket's last piece folds the per-piece tables inside the forward kernel; with seed 1 the gradient arrays
-        # take the folded tables over (no kernel in backward()), otherwise one small scale pass
-        if kw.get("seed", 1.0) == 1.0 and kw.get("spelling") not in ("a*x-b", "b-a*x") and kw.get("func", "sin") not in ("cos", "sqrt", "rcp", "rsqrt"):
-            assert ks.get("scatter_add_adopt") == 1 and "scatter_add_fold" not in ks, (name, ks)
+        assert ks.get("scatter_add_fold") == 1, (name, ks)         # backward(): ONE fold of the per-piece tables, nothing else
 
 
 @pytest.mark.parametrize("bad", [np.inf, -np.inf, np.nan])
@@ -155,8 +152,7 @@ def test_masked_out_lane_with_non_finite_x_is_nan_like_the_reference(ad, ref, da
 
 @pytest.mark.parametrize("where", ["middle", "all_masked"])
 def test_buckets_without_elements_have_zero_gradients(ad, ref, data, where):
-    """The forward pass folds the early adjoint per BUCKET (the last piece of a bucket sums the bucket's tables into the object's
-    own K-sized tables, which the gradient arrays then take over without a kernel).  A bucket that receives no element has no
+    """The early adjoint is summed per PIECE of a bucket and folded by backward().  A bucket that receives no element has no
     piece: its slice of both gradients must still be zero -- leading, trailing and interior empty buckets, and the degenerate
     step in which every lane is masked out."""
     A, B, x, idx, mask = data
@@ -175,4 +171,4 @@ def test_buckets_without_elements_have_zero_gradients(ad, ref, data, where):
         untouched = t["cnt"] == 0
         assert untouched.any() and np.array_equal(arr[untouched], np.zeros(int(untouched.sum()), np.float32)), g
     if where == "middle":
-        assert ks.get("bucket_pair_fma_reduce_adjoint") == 1 and "scatter_add_fold" not in ks and ks.get("scatter_add_adopt") == 1, ks
+        assert ks.get("bucket_pair_fma_reduce_adjoint") == 1 and ks.get("scatter_add_fold") == 1, ks
