@@ -65,6 +65,8 @@ CFG3B_VARIANTS = {
     # rounding each -- the same bucket-ordered step (round 4: 48 Gelem/s in element order)
     "cfg3b_operators": dict(spelling="a*x+b"),
     "cfg3b_operators_sub": dict(spelling="b-a*x", func="cos"),
+    # ONE gather times an array (`texture lookup * weight`, the shape of cfg5's albedo lookups): y = hsum(sin(gather(A, idx) * x))
+    "cfg3b_product": dict(spelling="a*x"),
 }
 for _w, _v in CFG3B_VARIANTS.items():
     DESCRIPTION[_w] = ("cfg3b with " + ", ".join(f"{k}={v}" for k, v in _v.items()) +
@@ -336,13 +338,14 @@ class Bench:
                 else:
                     a = ek.gather(A, idx); b = ek.gather(B, idx)
                 sp = var.get("spelling", "fmadd")
-                u = ek.fmadd(a, xd, b) if sp == "fmadd" else a * xd + b if sp == "a*x+b" else b - a * xd
+                u = ek.fmadd(a, xd, b) if sp == "fmadd" else a * xd + b if sp == "a*x+b" else a * xd if sp == "a*x" else b - a * xd
                 y = ek.hsum(func(u))
                 if seed != 1.0:
                     y = y * seed
                 ek.backward(y)
                 out["y"] = ek.detach(y)
-                out["gA"], out["gB"] = ek.gradient(A), ek.gradient(B)
+                out["gA"] = ek.gradient(A)
+                out["gB"] = ek.gradient(B) if sp != "a*x" else out["gA"]        # (the product alone: B does not take part)
 
             def exchange(reuse=False):
                 # library-level sharding (enoki_amd.dist.Sharded): the loss partial and both table gradients are finished by

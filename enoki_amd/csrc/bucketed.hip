@@ -50,7 +50,7 @@ __device__ __forceinline__ void stage_pair_slice(PairRec<T> *rec, T *tables, con
             const size_t k = first + (size_t) (j0 + u * (int) blockDim.x);
             const size_t kc = k < last ? k : last;
             a[u] = table_a[kc];
-            c[u] = table_c[kc];
+            c[u] = table_c ? table_c[kc] : T(-0.0);       // no addend table: u = a x + (-0) = a x, bit for bit (signed zeros included)
             if (k > last) { a[u] = T(0); c[u] = T(0); }
         }
 #pragma unroll
@@ -561,49 +561,6 @@ __device__ __forceinline__ bool lds_try_add_pair(unsigned long long *table, unsi
     return met;
 }
 
-// ---- the same sums WITHOUT locks: compare-and-swap on the {t0, t1} pair ------------------------------------------------------
-// (EK_EARLY_CAS builds; measured against the exchange locks in profiles/probe_early_r05.txt.)  A lock is held for an LDS round
-// trip, and every claim that another wave meets in that time costs the other wave a retry round -- which is why more claims in
-// flight per lane made the lock protocol slower (199 / 165 / 149 / 143 us for 8 / 4 / 2 / 1, round 4).  A compare-and-swap holds
-// nothing: a lane reads the pairs of ALL its elements of a step together with their table records (the reads' round trip
-// overlaps the arithmetic), then issues all its swaps together; a swap fails only if somebody changed that entry in between, and
-// then only that slot goes again with the value the failed swap returned.  Two dependent LDS round trips per step instead of
-// one per element.
-__device__ __forceinline__ unsigned long long pair_sum_plain(unsigned long long old, float v0, float v1) {
-    return (unsigned long long) __float_as_uint(__uint_as_float((unsigned) old) + v0) |
-           ((unsigned long long) __float_as_uint(__uint_as_float((unsigned) (old >> 32)) + v1) << 32);
-}
-
-__device__ __forceinline__ void lds_cas_add_pair(unsigned long long *p, float v0, float v1, bool on) {
-    if (!on) return;
-    unsigned long long old = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP), assumed;
-    do {
-        assumed = old;
-        old = atomicCAS(p, assumed, pair_sum_plain(assumed, v0, v1));
-    } while (old != assumed);
-}
-
-template <int N>
-__device__ __forceinline__ void lds_cas_add_pair_batch(unsigned long long *table, const uint32_t (&l)[N], unsigned long long (&old)[N],
-                                                       const float (&v0)[N], const float (&v1)[N]) {
-    unsigned long long got[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j) got[j] = atomicCAS(table + l[j], old[j], pair_sum_plain(old[j], v0[j], v1[j]));
-    unsigned pending = 0;
-#pragma unroll
-    for (int j = 0; j < N; ++j) pending |= got[j] != old[j] ? 1u << j : 0u;
-    while (__builtin_amdgcn_ballot_w64(pending != 0)) {
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if ((pending >> j) & 1u) {
-                old[j] = got[j];
-                got[j] = atomicCAS(table + l[j], old[j], pair_sum_plain(old[j], v0[j], v1[j]));
-                if (got[j] == old[j]) pending &= ~(1u << j);
-            }
-        }
-    }
-}
-
 // the slots of `pending` once more, their exchanges in flight together (the locks they met have been released long since); what
 // is locked even then -- hot bins, or two slots of one lane with the same bin -- goes one slot at a time with wave combining
 template <int N>
@@ -917,11 +874,7 @@ struct EarlyBody {
         values(l, on ? x_b[pos] : T(0), sum, v0, v1);
         if (on) acc[slot] += sum;
         if constexpr (Paired) {
-#ifdef EK_EARLY_CAS
-            lds_cas_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
-#else
             lds_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
-#endif
         } else {
             lds_add<true>(&tables[l], v0, on);
             lds_add<true>(&tables[Bins + l], v1, on);
@@ -943,7 +896,10 @@ struct EarlyBody {
             // element with its own retry round 143-147, this form 137-143; the next element's arithmetic pinned under the
             // exchange's round trip (a longer hold) 147-149; sincos / exp in packed-fp32 instructions (v_pk_fma_f32: two
             // passes on gfx950's SIMD-32) 150-153 against 147-150.  With the claims removed the kernel takes 100, with the
-            // arithmetic removed 124, with both 80-87 (profiles/probe_early_r04.txt).
+            // arithmetic removed 124, with both 80-87 (profiles/probe_early_r04.txt).  Round 5: a LOCK-FREE form -- the pairs of
+            // all four elements read up front, four compare-and-swaps in flight, two dependent LDS round trips per step instead of
+            // five -- is 11 % SLOWER (171 against 154 us): it moves 40 B per element through the LDS instead of 32, and that, not
+            // the latency of the claim -- add -- release chain, is what bounds the adjoint part (profiles/probe_early_r05.txt).
             unsigned long long *tb = reinterpret_cast<unsigned long long *>(tables);
             PairRec<T> r[NB];
 #pragma unroll
@@ -951,21 +907,6 @@ struct EarlyBody {
                 l[k] = (uint32_t) s.pi[k / 4].v[k % 4] & lmask;
                 r[k] = rec[l[k]];
             }
-#ifdef EK_EARLY_CAS
-            unsigned long long old[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) old[k] = __hip_atomic_load(tb + l[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const T x = s.px[k / 4][k % 4];
-                T sum;
-                EarlyPair<Map, Keep, T>::apply(pair_value(r[k].a, x, r[k].c, two), sum, v0[k]);
-                v1[k] = dev::safe_mul(x, v0[k]);
-                acc[k % 4] += sum;
-            }
-            lds_cas_add_pair_batch<NB>(tb, l, old, v0, v1);
-            return;
-#endif
             unsigned pending = 0;
 #pragma unroll
             for (int k = 0; k < NB; ++k) {
@@ -1334,7 +1275,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
                            b->template finish<T>(out, map_op));
     });
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
-                    b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + 2 * b->table_size * sizeof(T));
+                    b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + (b->table_c ? 2 : 1) * b->table_size * sizeof(T));
     if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
     else if (keep) b->has_u = true;
     if constexpr (ROp != EK_REDUCE_NONE) {
@@ -1390,11 +1331,7 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
     Context &c = ctx();
     const size_t Bins = b->bins();
     const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
-#ifdef EK_EARLY_VV
-    constexpr int VV = EK_EARLY_VV;
-#else
     constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.151 ms against 0.143, same box)
-#endif
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
     const int flip_a = b->flip_a(), flip_c = b->flip_c(), two = b->two_roundings();
@@ -1406,7 +1343,7 @@ static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, i
                            b->template finish<T>(out, map_op));
     });
     EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
-                    b->n * (sizeof(uint16_t) + sizeof(T)) + 2 * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
+                    b->n * (sizeof(uint16_t) + sizeof(T)) + (b->table_c ? 2 : 1) * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
     b->has_early = true;
     b->early_op = keep_op;
     if (!b->ticket) {
@@ -1662,7 +1599,9 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
                                        const void *x, const void *index, const uint8_t *mask, size_t n, unsigned hints,
                                        ek_hip_bucketed **out) {
     if (int rc = ensure_init()) return rc;
-    if (!out || !table_a || !table_c || !x || !index) return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): null pointer");
+    if (!out || !table_a || !x || !index) return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): null pointer");
+    if (!table_c && op != EK_MULADD)
+        return fail(EK_ERR_INVALID, "ek_hip_bucketed_pair_create(): a NULL addend table (the product gather(A, idx) * x alone) goes with EK_MULADD");
     *out = nullptr;
     if (op != EK_FMADD && op != EK_FMSUB && op != EK_FNMADD && op != EK_FNMSUB && op != EK_MULADD && op != EK_MULSUB && op != EK_NMULADD)
         return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): op %d is neither of the fma family nor a product-then-sum", op);
@@ -1718,7 +1657,7 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
                 sub->type = type; sub->index_type = index_type; sub->op = op;
                 sub->table_size = std::min(span, table_size - (size_t) sl * span);
                 sub->table_a = (const float *) table_a + (size_t) sl * span;
-                sub->table_c = (const float *) table_c + (size_t) sl * span;
+                sub->table_c = table_c ? (const float *) table_c + (size_t) sl * span : nullptr;
                 sub->correct_masked = false;
                 if (split) {
                     // the slice's own elements, indices already local to the slice

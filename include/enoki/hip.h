@@ -66,7 +66,7 @@ namespace detail {
             size_t elem_size;
             bool consumed;                     // a fused consumer has read it once: the next access materialises (gathers)
             int kind = 0;                      // 0: gather, 1: unary map, 2: fma of a gathered pair (below), 3: zeros (no sources),
-                                               // 4: arithmetic over evaluated operands, 5: gather * array (both below)
+                                               // 4: arithmetic over evaluated operands (below)
             HIPBuffer *partner = nullptr;      // map: the other half of an unevaluated sincos pair (not owning)
             // map: the node is  scale * op(source)  -- the product of an unevaluated map with a host scalar stays a map
             // (HIPArray::scaled_map_: the -sin(u) that d/du cos(u) records, the c * cos(u) that backward(c * y) sends down),
@@ -89,10 +89,11 @@ namespace detail {
             // :1418-1508); here a horizontal reduction that finds such a node under (up to three) unevaluated unary maps reads
             // the operands once and writes nothing (ek_hip_reduce_chain; `hsum(sin(exp(fmadd(a, x, b))))`, BASELINE configs[1]:
             // 12 B/elt instead of 28), and any other access runs the plain kernel -- same bits either way.
-            // kind 5:  table[index] * arg0  -- the product `gather(A, idx) * x` of the operator spelling `gather(A, idx) * x +
-            // gather(B, idx)`, left unevaluated for ONE step: the sum that adds a gather through the same index array turns it
-            // into a kind-2 node (op EK_MULADD / EK_MULSUB / EK_NMULADD: a product and a sum with a rounding each, bucket order
-            // possible); any other access runs the kernel that consumes the gather in place, as the eager product did.
+            // kind 2 WITHOUT an addend (table2 == nullptr, op == EK_MULADD):  table[index] * arg0  -- the product `gather(A, idx) * x`.
+            // A sum that adds a gather through the same index array turns it into the full kind-2 node (op EK_MULADD / EK_MULSUB /
+            // EK_NMULADD: `gather(A, idx) * x + gather(B, idx)` written with operators, a product and a sum with a rounding each); a
+            // horizontal reduction (through one fusable unary op) and the adjoint scatter_add of the ONE gather take it in bucket order
+            // as it is; any other access runs the kernel that consumes the gather in place, as the eager product did.
             int arity = 0;
             uint64_t imm[3] = { 0, 0, 0 };
             bool is_imm[3] = { false, false, false };
@@ -241,6 +242,7 @@ namespace detail {
                                    "evaluated in ELEMENT order -- its consumer is not a horizontal reduction (directly or through one "
                                    "fusable unary op) nor the adjoint scatter_add of its gathers, or a source is about to be written, or a "
                                    "step graph is being captured, or deterministic mode is on");
+            if (!d->table2) { force_gathered_product(); return; }
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * d->elem_size, &p), "HIPArray (deferred fma of gathers)");
             ek_gathered ga, gc;
@@ -267,7 +269,7 @@ namespace detail {
         ek_hip_bucketed *bucketed(unsigned hints = 0) {
             Deferred *d = deferred;
             if (!d->bucketed) {
-                int rc = ek_hip_bucketed_pair_create_masked(d->type, d->index_type, d->op, d->table->ptr, d->table2->ptr, d->table->size,
+                int rc = ek_hip_bucketed_pair_create_masked(d->type, d->index_type, d->op, d->table->ptr, d->table2 ? d->table2->ptr : nullptr, d->table->size,
                                                             d->arg0->ptr, d->index->ptr, d->mask ? (const uint8_t *) d->mask->ptr : nullptr,
                                                             size, hints, &d->bucketed);
                 if (rc == EK_ERR_UNSUPPORTED) return nullptr;
@@ -296,7 +298,7 @@ namespace detail {
             drop_deferred();
         }
 
-        /// kind 5: the product of a gather with an array, the gather consumed in place (element order)
+        /// kind 2 without an addend: the product of a gather with an array, the gather consumed in place (element order)
         void force_gathered_product() {
             Deferred *d = deferred;
             void *p = nullptr;
@@ -378,7 +380,6 @@ namespace detail {
             if (deferred->kind == 2) { force_pair(); return; }
             if (deferred->kind == 3) { force_zeros(); return; }
             if (deferred->kind == 4) { force_arith(); return; }
-            if (deferred->kind == 5) { force_gathered_product(); return; }
             void *p = nullptr;
             hip_check(ek_hip_malloc((size ? size : 1) * deferred->elem_size, &p), "HIPArray (deferred gather)");
             ek_gathered g = gathered();
@@ -947,12 +948,12 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// An unevaluated fma over a gathered pair (kind 2, see detail::HIPBuffer)
     bool paired_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 2; }
 
-    /// gather(A, idx) * x that has not run yet (kind 5, see detail::HIPBuffer)
-    bool gathered_product_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 5; }
+    /// gather(A, idx) * x that has not run yet (kind 2 without an addend table, see detail::HIPBuffer)
+    bool gathered_product_() const { return m_buf && m_buf->deferred && m_buf->deferred->kind == 2 && !m_buf->deferred->table2; }
 
-    /// g * x with g an unevaluated gather and x an evaluated array of the same length: left unevaluated (kind 5) when a sum with
-    /// another gather through the same index array could still take the whole expression in bucket order.  Invalid array: not
-    /// that shape -- the caller consumes the gather in place right away.
+    /// g * x with g an unevaluated gather and x an evaluated array of the same length: left unevaluated (kind 2 without an addend)
+    /// when the library's bucket-ordered path covers the shape.  Invalid array: not that shape -- the caller consumes the gather
+    /// in place right away.
     static HIPArray defer_gathered_product_(const HIPArray &g, const HIPArray &x, size_t n) {
         HIPArray r;
         if constexpr (IsFloat) {
@@ -963,8 +964,9 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if (p->mask && sizeof(Value) != 4) return r;
             if (!ek_hip_bucketed_applicable(Type, p->index_type, p->table->size, n)) return r;
             auto *d = new typename detail::HIPBuffer::Deferred{ p->table, p->index, p->mask, Type, p->index_type, sizeof(Value),
-                                                                false, 5, nullptr };
+                                                                false, 2, nullptr };
             d->arg0 = x.m_buf;
+            d->op = EK_MULADD;
             r.m_buf = new detail::HIPBuffer();
             r.m_buf->size = n;
             r.m_buf->deferred = d;
@@ -1576,15 +1578,13 @@ template <typename Value_> struct HIPArray : ArrayTag {
             case 1: return std::string("unevaluated unary op ") + std::to_string(d->index_type) + (d->scaled ? " times a host scalar" : "") + ", " + n +
                            ": reductions and scatter_add value streams apply it while loading; source " +
                            (d->table->deferred ? "unevaluated (kind " + std::to_string(d->table->deferred->kind) + ")" : "evaluated");
-            case 2: return "unevaluated " + std::string(d->op >= EK_MULADD ? "product-then-sum" : "fma") + " of two gathers through one index array (K = " +
+            case 2: return "unevaluated " + std::string(!d->table2 ? "product of a gather with an array" : d->op >= EK_MULADD ? "product-then-sum of two gathers through one index array" : "fma of two gathers through one index array") + " (K = " +
                            std::to_string(d->table->size) + ", " + n + "): BUCKET ORDER possible -- a horizontal reduction (directly or through one fusable "
                            "unary op) and the adjoint scatter_add of the gathers stay in bucket order; any other access evaluates it in element order" +
                            (d->bucketed ? "; partition built" : "");
             case 3: return "zeros that nobody has looked at, " + n;
             case 4: return "unevaluated arithmetic op " + std::to_string(d->op) + " of arity " + std::to_string(d->arity) + " over evaluated operands, " + n +
                            ": a reduction (through up to three fusable unary ops) reads the operands once; any other access runs the kernel";
-            case 5: return "unevaluated gather * array, " + n + ": `+ gather(B, idx)` through the same index array makes it a bucket-ordered "
-                           "product-then-sum; any other access consumes the gather in place (element order)";
             default: return "unevaluated (kind " + std::to_string(d->kind) + ")";
         }
     }
@@ -1871,7 +1871,7 @@ private:
         size_t n = broadcast_size(size(), b.size());
         if constexpr (IsFloat) {
             // `gather(A, idx) * x + gather(B, idx)` written with operators (BASELINE.json spells config 3b `a*x+b`): the product
-            // waits one step (kind 5), the sum with the second gather makes the kind-2 node that bucket order can take
+            // stays unevaluated (kind 2 without an addend), the sum with the second gather makes the node of the whole expression
             if (op == EK_MUL && deferred_() != b.deferred_()) {
                 const HIPArray &g = deferred_() ? *this : b, &x = deferred_() ? b : *this;
                 if (HIPArray r = defer_gathered_product_(g, x, n); r.valid()) return r;

@@ -287,7 +287,9 @@ EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const v
 EK_API int ek_hip_bucketed_pair_create_hinted(int type, int index_type, int op, const void *table_a, const void *table_c,
                                               size_t table_size, const void *x, const void *index, size_t n, unsigned hints,
                                               ek_hip_bucketed **out);
-/* Both gathers under ONE mask array (cuda.h:845-864: masked-out lanes gather 0): inactive entries are dropped by the partition,
+/* table_c == NULL with op == EK_MULADD: the product  u = gather(A, idx) * x  alone (no addend table; u = a x + (-0) = a x bit for
+ * bit) -- reductions and the adjoint scatter_add of the ONE gather (the stream x * f'(u)) run in bucket order like the pair's.
+ * Both gathers under ONE mask array (cuda.h:845-864: masked-out lanes gather 0): inactive entries are dropped by the partition,
  * and what they would have contributed is added by the final step of a reduction: u = fma(0, x, 0) is 0 for a finite x (the lane
  * enters as map_op(0)) and NaN for an infinite or NaN x -- hsum / hprod then are NaN, exactly as the reference's lane-by-lane
  * evaluation (dynamic.h:632-650) and this library's element-order kernels say.  Dropped lanes scatter nothing.

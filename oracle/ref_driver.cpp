@@ -511,14 +511,18 @@ float ref_cfg3b_variant(const float *A_, const float *B_, size_t k, const float 
     // with a rounding each -- separate packet operations are never contracted)
     const int spelling = func >> 4;
     func &= 15;
+    //                         5 a * x  (the product of ONE gather with an array; B is not used, its gradient is reported as zero)
     FloatD u = spelling == 0 ? fmadd(a, x, b) : spelling == 1 ? FloatD(a * x + b) : spelling == 2 ? FloatD(a * x - b)
-             : spelling == 3 ? FloatD(b - a * x) : FloatD(b + a * x);
+             : spelling == 3 ? FloatD(b - a * x) : spelling == 4 ? FloatD(b + a * x) : FloatD(a * x);
     FloatD y = hsum(func == 0 ? sin(u) : func == 1 ? cos(u) : func == 2 ? exp(u) : func == 3 ? log(u) : func == 4 ? sqrt(u) : func == 5 ? rcp(u) : rsqrt(u));
     FloatD z = seed == 1.f ? y : y * seed;
     backward(z);
     if (seconds) *seconds = now() - t0;
     if (grad_A) store(gradient(A), grad_A, k);
-    if (grad_B) store(gradient(B), grad_B, k);
+    if (grad_B) {
+        if (spelling == 5) memset(grad_B, 0, k * sizeof(float));
+        else store(gradient(B), grad_B, k);
+    }
     return z.value_().coeff(0);
 }
 

@@ -185,7 +185,7 @@ def cfg3b_variant_truth(A, B, x, idx, mask=None, func="sin", seed=1.0, spelling=
     on = np.ones(n, bool) if mask is None else np.asarray(mask, bool)
     x64 = x.astype(np.float64)
     # (the operator spellings differ from fmadd by one more rounding of u, which the bounds below cover: |f'| <= big)
-    sa, sb = {"fmadd": (1, 1), "a*x+b": (1, 1), "b+a*x": (1, 1), "a*x-b": (1, -1), "b-a*x": (-1, 1)}[spelling]
+    sa, sb = {"fmadd": (1, 1), "a*x+b": (1, 1), "b+a*x": (1, 1), "a*x-b": (1, -1), "b-a*x": (-1, 1), "a*x": (1, 0)}[spelling]
     u = np.where(on, sa * A.astype(np.float64)[ii] * x64 + sb * B.astype(np.float64)[ii], 0.0)
     with np.errstate(all="ignore"):         # (log / sqrt want positive u: the tests that use them shift the addend table)
         safe = np.where(on, u, 1.0)

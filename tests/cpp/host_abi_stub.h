@@ -250,7 +250,7 @@ struct ek_hip_bucketed {
 static long g_bucketed_live = 0, g_bucketed_reduces = 0, g_bucketed_scatters = 0;
 static float bucketed_u(const ek_hip_bucketed *b, size_t i) {
     if (b->mask && !b->mask[i]) return 0.f;                // masked-out lanes gather 0 (the device path drops them: u = 0)
-    float a = b->a[b->idx[i]], c = b->c[b->idx[i]];
+    float a = b->a[b->idx[i]], c = b->c ? b->c[b->idx[i]] : -0.0f;        // no addend table: the product alone
     if (b->op == EK_FNMADD || b->op == EK_FNMSUB || b->op == EK_NMULADD) a = -a;
     if (b->op == EK_FMSUB || b->op == EK_FNMSUB || b->op == EK_MULSUB) c = -c;
     volatile float prod = a * b->x[i];

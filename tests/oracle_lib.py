@@ -139,7 +139,7 @@ class Checker:
         return y, gA, gB, sec.value
 
 
-    SPELLINGS = {"fmadd": 0, "a*x+b": 1, "a*x-b": 2, "b-a*x": 3, "b+a*x": 4}
+    SPELLINGS = {"fmadd": 0, "a*x+b": 1, "a*x-b": 2, "b-a*x": 3, "b+a*x": 4, "a*x": 5}
 
     def cfg3b_variant(self, A, B, x, idx, mask=None, func="sin", seed=1.0, spelling="fmadd"):
         """reference build only (oracle/ref_driver.cpp:ref_cfg3b_variant): the neighbours of cfg3b -- f = sin | cos | exp | log | sqrt,

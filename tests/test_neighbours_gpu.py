@@ -56,11 +56,12 @@ def run(ad, A, B, x, idx, mask=None, func="sin", seed=1.0, idx64=False, spelling
         a, b = ad.gather(dA, di), ad.gather(dB, di)
     # BASELINE.json spells config 3b `a*x+b`: operators -- a product and a sum with a rounding each, not one fma
     u = {"fmadd": lambda: ad.fmadd(a, xd, b), "a*x+b": lambda: a * xd + b, "a*x-b": lambda: a * xd - b, "b-a*x": lambda: b - a * xd,
-         "b+a*x": lambda: b + a * xd}[spelling]()
+         "b+a*x": lambda: b + a * xd, "a*x": lambda: a * xd}[spelling]()
     y = ad.hsum(getattr(ad, func)(u))
     z = y if seed == 1.0 else y * seed
     ad.backward(z)
-    return float(ad.detach(z).numpy()[0]), ad.gradient(dA).numpy(), ad.gradient(dB).numpy()
+    gB = np.zeros(B.size, np.float32) if spelling == "a*x" else ad.gradient(dB).numpy()       # (B does not take part)
+    return float(ad.detach(z).numpy()[0]), ad.gradient(dA).numpy(), gB
 
 
 CASES = {
@@ -87,10 +88,13 @@ CASES = {
     "operators_minus": dict(spelling="a*x-b", func="cos"),
     "operators_reversed_minus": dict(spelling="b-a*x", func="exp", seed=2.0),
     "operators_masked_i64": dict(spelling="a*x+b", masked=True, idx64=True),
+    # ONE gather times an array (`texture lookup * weight`): the product alone stays in bucket order, the adjoint is one stream
+    "product": dict(spelling="a*x"),
+    "product_exp_masked_seed": dict(spelling="a*x", func="exp", masked=True, seed=-1.5),
 }
 # what the step may launch when it stays in bucket order: ONE partition in the forward pass, the adjoint formed there as well
 EARLY = {"sin", "cos", "exp", "seed3", "exp_negative_seed", "masked", "i64", "masked_exp_i64_seed", "log", "sqrt", "sqrt_seed3", "rcp", "rsqrt",
-         "operators", "operators_commuted", "operators_minus", "operators_reversed_minus", "operators_masked_i64"}
+         "operators", "operators_commuted", "operators_minus", "operators_reversed_minus", "operators_masked_i64", "product", "product_exp_masked_seed"}
 
 
 @pytest.mark.parametrize("name", list(CASES))
