@@ -639,26 +639,73 @@ __global__ __launch_bounds__(256) void k_bin_fold_groups(T *__restrict__ out, co
 // binned path: bin k of bucket b sums the partials of the bucket's pieces; blockIdx.y = value stream (table)
 template <typename T, int C> struct FoldTargets { T *table[C]; T scale[C]; };     // scale: factor on the folded sum
 
+// Four consecutive entries per lane (one 16-byte access per piece and per target for 4-byte types): a bucket is a multiple of four
+// entries, so the four share their bucket and its pieces.  (One entry per lane: 7.9 us for two 1 Mi-entry tables of two pieces each,
+// a latency-bound trickle of 4-byte loads.)
+constexpr int kFoldPerLane = 4;
+inline unsigned fold_grid(size_t table_size) { return (unsigned) ((table_size + 256 * kFoldPerLane - 1) / (256 * kFoldPerLane)); }
+
 template <typename T, int C>
 __global__ __launch_bounds__(256) void k_bin_fold_pieces(FoldTargets<T, C> targets, const T *__restrict__ partials,
                                                          const uint32_t *__restrict__ piece_prefix, size_t table_size,
                                                          size_t partial_stride, unsigned fresh = 0u,
                                                          int shift = bin_shift_of<T>) {
-    size_t k = (size_t) blockIdx.x * 256 + threadIdx.x;
-    if (k >= table_size) return;
+    const size_t k0 = ((size_t) blockIdx.x * 256 + threadIdx.x) * kFoldPerLane;
+    if (k0 >= table_size) return;
     using U = wrap_t<T>;
     T *__restrict__ target = targets.table[blockIdx.y];
     partials += (size_t) blockIdx.y * partial_stride;
-    const uint32_t b = (uint32_t) (k >> shift), local = (uint32_t) (k & (((size_t) 1 << shift) - 1));
-    T s = ((fresh >> blockIdx.y) & 1u) ? T(0) : target[k];       // fresh: the table holds no data yet, its sums are written
-    U sum = U(0);
-    for (uint32_t p = piece_prefix[b]; p < piece_prefix[b + 1]; ++p)
-        sum = (U) (sum + (U) partials[((size_t) p << shift) + local]);
-    if constexpr (std::is_floating_point_v<T>) {
-        const T f = targets.scale[blockIdx.y];
-        if (f != T(1)) sum = sum * f;
+    const uint32_t b = (uint32_t) (k0 >> shift), local = (uint32_t) (k0 & (((size_t) 1 << shift) - 1));
+    const bool is_fresh = (fresh >> blockIdx.y) & 1u;       // fresh: the table holds no data yet, its sums are written
+    const uint32_t p0 = piece_prefix[b], p1 = piece_prefix[b + 1];
+    U sum[kFoldPerLane];
+    T old[kFoldPerLane];
+#pragma unroll
+    for (int j = 0; j < kFoldPerLane; ++j) { sum[j] = U(0); old[j] = T(0); }
+    const bool vec = sizeof(T) == 4 && k0 + kFoldPerLane <= table_size && ((reinterpret_cast<uintptr_t>(target + k0) | reinterpret_cast<uintptr_t>(partials)) & 15u) == 0;
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            if (!is_fresh) {
+                const Pack<T, 4> t = pack_load<T, 4, false>(target + k0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) old[j] = t.v[j];
+            }
+            for (uint32_t p = p0; p < p1; ++p) {
+                const Pack<T, 4> v = pack_load<T, 4, true>(partials + ((size_t) p << shift) + local);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum[j] = (U) (sum[j] + (U) v.v[j]);
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kFoldPerLane; ++j) {
+            if (k0 + j >= table_size) continue;
+            if (!is_fresh) old[j] = target[k0 + j];
+            for (uint32_t p = p0; p < p1; ++p) sum[j] = (U) (sum[j] + (U) partials[((size_t) p << shift) + local + j]);
+        }
     }
-    target[k] = (T) ((U) s + sum);
+    T out[kFoldPerLane];
+#pragma unroll
+    for (int j = 0; j < kFoldPerLane; ++j) {
+        U v = sum[j];
+        if constexpr (std::is_floating_point_v<T>) {
+            const T f = targets.scale[blockIdx.y];
+            if (f != T(1)) v = v * f;
+        }
+        out[j] = (T) ((U) old[j] + v);
+    }
+    if (vec) {
+        if constexpr (sizeof(T) == 4) {
+            Pack<T, 4> o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o.v[j] = out[j];
+            pack_store<T, 4, false>(target + k0, o);
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < kFoldPerLane; ++j)
+            if (k0 + j < table_size) target[k0 + j] = out[j];
+    }
 }
 
 struct Scratch {

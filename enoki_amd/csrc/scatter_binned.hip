@@ -165,7 +165,7 @@ int scatter_add_binned_multi(T *const *bases, size_t table_size, const Arg<T> *v
                     (size_t) C * (n * (sizeof(uint16_t) + sizeof(T)) + (size_t) max_pieces * Bins * sizeof(T)));
     FoldTargets<T, C> targets;
     for (int s = 0; s < C; ++s) { targets.table[s] = bases[s]; targets.scale[s] = T(1); }
-    hipLaunchKernelGGL((k_bin_fold_pieces<T, C>), dim3((unsigned) ((table_size + 255) / 256), C), dim3(256), 0, c.stream, targets,
+    hipLaunchKernelGGL((k_bin_fold_pieces<T, C>), dim3(fold_grid(table_size), C), dim3(256), 0, c.stream, targets,
                        (const T *) partials.ptr, (const uint32_t *) piece_prefix, table_size, (size_t) max_pieces * Bins);
     EK_LAUNCH_CHECK("scatter_add_fold", (size_t) C * table_size,
                     (size_t) C * ((size_t) max_pieces * Bins * sizeof(T) + 2 * table_size * sizeof(T)));
