@@ -41,7 +41,8 @@ for r in range(rounds):
     idx = indices(kind, K, n).astype(np.uint32)
     ii = idx.astype(np.int64)
     cnt = np.bincount(ii, minlength=K)
-    op = ("fmadd", "fmsub", "fnmadd", "fnmsub")[r % 4]
+    # (round 5: the product-then-sum forms of `a * x + b` written with operators ride along)
+    op = ("fmadd", "fmsub", "fnmadd", "fnmsub", "muladd", "mulsub", "nmuladd")[r % 7]
     half, other = (("sin", "cos"), ("cos", "sin"))[(r // 2) % 2]
     di = up(idx)
     # ---- exact part
