@@ -529,14 +529,22 @@ class Bench:
             # the instruction caches are those of an idle GPU, and the same kernels ran 12 % faster one workload later in the
             # same process (round 4).  The headline step runs for `pre_warm_s` seconds first -- outside the timed region,
             # reported -- so that the timed steps are those of a long run; --warmup / --steps stay exactly as given.
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            while time.perf_counter() - t0 < pre_warm_s:
-                for _ in range(20):
+            # (the step contains the exchange: every rank must run the SAME number of steps -- the count is derived from a timed
+            # batch whose duration all ranks agree on, never from a rank's own clock inside the loop)
+            def batch(k):
+                ekd.barrier(); torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(k):
                     step()
                 if packer:
                     packer.wait_all()
                 torch.cuda.synchronize()
+                return ekd.max_over_ranks(time.perf_counter() - t)
+            t0 = time.perf_counter()
+            t20 = batch(20)
+            more = int(min(max(0.0, pre_warm_s - t20) / max(t20 / 20, 1e-6), 100000))
+            if more > 0:
+                batch(more)
             self.pre_warm_s = round(time.perf_counter() - t0, 3)
         for _ in range(warmup):
             step()

@@ -18,7 +18,7 @@ def run_bench(workload, n, ranks, port, dump=None, extra=()):
     ranks > 1 bench.py starts its own ranks (torch.distributed.run, rendezvous on 127.0.0.1) and, on a box with fewer GPUs than
     ranks, routes the collectives through gloo (the line says so).  `port` is unused since round 5 (bench.py picks a free one)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ranks), "--steps", "3", "--warmup", "1", "--n", str(n),
-           "--workload", workload, "--no-cpu-baseline", "--no-also", "--profile-steps", "1", "--pre-warm-s", "0"] + list(extra)
+           "--workload", workload, "--no-cpu-baseline", "--no-also", "--profile-steps", "1", "--pre-warm-s", "0.05"] + list(extra)
     if dump:
         cmd += ["--dump-gradients", dump]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
