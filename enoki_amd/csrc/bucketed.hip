@@ -90,6 +90,7 @@ template <typename T> struct BucketFinish {
     const uint32_t *active;
     size_t n;
     int zero_op;             // what a dropped lane (u = 0) contributes, as a function of 0
+    uint32_t *counters = nullptr;   // the object's block of partition counters (gtotal): cleared by the last workgroup for the block's next user
 };
 
 template <typename T> __device__ __forceinline__ T bucket_shfl_down(T v, int delta) {
@@ -276,7 +277,7 @@ __device__ __forceinline__ T bucket_dropped_lanes(T r, size_t masked, bool nonfi
 template <typename T, int ROp>
 __device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *__restrict__ partials, uint32_t *__restrict__ ticket,
                                               T *__restrict__ out, const uint32_t *__restrict__ active, size_t n, int map_op,
-                                              T *wave_part /* [kBucketWaves] shared */) {
+                                              T *wave_part /* [kBucketWaves] shared */, uint32_t *__restrict__ counters = nullptr) {
     using R = BucketReducer<ROp, T>;
     using Bits = std::conditional_t<sizeof(T) == 4, uint32_t, unsigned long long>;
     __shared__ uint32_t s_last;
@@ -288,6 +289,11 @@ __device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *
     }
     __syncthreads();
     if (!s_last) return;
+    // (the partition's page totals and accumulators have been consumed by the directory launch: cleared here, the block of counters
+    // can go to the next object without a fill -- MetaRing)
+    if (counters) {
+        for (unsigned k = threadIdx.x; k < 2u * kMaxBuckets + 2u; k += blockDim.x) counters[k] = 0u;
+    }
     T v = R::identity();
     for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
         const Bits b = __hip_atomic_load(reinterpret_cast<const Bits *>(partials) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -409,7 +415,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
     PieceRange range;
     const bool live = bucket_piece<PS>(bl, bucket, range);        // (workgroup-uniform; a launch has a few more workgroups than pieces)
     if (!live) {
-        if constexpr (ROp != EK_REDUCE_NONE) bucket_finish<T, ROp>(R::identity(), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
+        if constexpr (ROp != EK_REDUCE_NONE) bucket_finish<T, ROp>(R::identity(), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
         return;
     }
     if constexpr (!FromKept) {
@@ -453,7 +459,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
 #pragma unroll
             for (int d = 8; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
         }
-        bucket_finish<T, ROp>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
+        bucket_finish<T, ROp>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
     }
 }
 
@@ -963,7 +969,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     int bucket;
     PieceRange range;
     if (!bucket_piece<PS>(bl, bucket, range)) {
-        bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
+        bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
         return;
     }
     stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
@@ -1000,7 +1006,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         T *out = table_partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
         for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? tables[2 * j + c] : tables[c * Bins + j];
     }
-    bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part);
+    bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
 }
 
 // ---- host side -------------------------------------------------------------------------------------
@@ -1032,6 +1038,8 @@ struct Bucketed {
     uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
     const uint32_t *active = nullptr;      // device: [0] number of elements in the lists, [1] non-finite x under a cleared mask bit (null: contiguous lists)
     uint32_t *ticket = nullptr;            // device, zero between launches: the last workgroup of a reducing launch finishes the reduction (bucket_finish)
+    int meta_slot = -1;                    // >= 0: `meta` is a block of the context's ring (meta_ring()), not an allocation of its own
+    bool meta_clean = false;               // a reducing launch ran: its last workgroup left the counters of the block zeroed
     uint32_t win_lo = 0, win_span = 0;     // a slice of a large table: only indices in [win_lo, win_lo + win_span) (ek_hip_bucketed::slices)
     bool correct_masked = true;            // the final reduction adds the masked-out lanes' map_op(0) terms (slices: their owner does)
 
@@ -1039,8 +1047,11 @@ struct Bucketed {
     // (with or without a mask array: lanes whose index points outside the table are dropped by the partition too, and count like
     //  masked-out ones -- one rule for a single object and for the slices of a large table)
     const uint32_t *masked_ptr() const { return correct_masked ? active : nullptr; }
-    template <typename T> BucketFinish<T> finish(void *out, int zero_op) const {
-        return BucketFinish<T>{ ticket, (T *) out, masked_ptr(), n, zero_op };
+    template <typename T> BucketFinish<T> finish(void *out, int zero_op, bool reducing = true) {
+        // (a ring block under a launch that reduces: its last workgroup clears the partition's counters -- from then on the block is clean)
+        BucketFinish<T> f{ ticket, (T *) out, masked_ptr(), n, zero_op };
+        if (reducing && meta_slot >= 0 && ticket) { f.counters = (uint32_t *) meta; meta_clean = true; }
+        return f;
     }
     // signs applied ONCE to the staged table entries (exact): fmsub / mulsub: -c;  fnmadd / nmuladd (c - a x = (-a) x + c): -a;  fnmsub: both
     int flip_a() const { return op == EK_FNMADD || op == EK_FNMSUB || op == EK_NMULADD; }
@@ -1048,11 +1059,33 @@ struct Bucketed {
     int two_roundings() const { return op == EK_MULADD || op == EK_MULSUB || op == EK_NMULADD; }
     size_t bins() const { return (size_t) 1 << shift; }
     BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
-    ~Bucketed() {
-        for (void *p : { meta, pair_idx, x_b, u_b, m_b, early, page_lists })
-            if (p) ek_hip_free(p);
-    }
+    ~Bucketed();
 };
+
+// Counter blocks of the paged objects, kept by the context and handed from object to object: the first reducing launch of an object
+// leaves its block's counters zeroed (bucket_finish: the last workgroup clears what the directory launch has consumed), so the next
+// object that takes the block needs no fill -- the 768-word memset in front of every partition was 4.5 us of a 100 us shard step.
+// Four blocks cover a tape that keeps a few objects alive; whoever finds none free (the slices of a large table, a captured step,
+// whose blocks must come from the graph's own pool) allocates and fills as before.
+struct MetaRing {
+    static constexpr int kBlocks = 4;
+    static constexpr size_t kPartials = 2048;                   // reduce partials a block has room for (max_pieces)
+    void *block[kBlocks] = {};
+    bool busy[kBlocks] = {}, clean[kBlocks] = {};
+    static size_t bytes() { return (3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1) * sizeof(uint32_t) + kPartials * sizeof(float) + 16; }
+};
+static MetaRing &meta_ring() { static MetaRing *r = new MetaRing(); return *r; }
+
+Bucketed::~Bucketed() {
+    if (meta_slot >= 0) {
+        MetaRing &r = meta_ring();
+        r.busy[meta_slot] = false;
+        r.clean[meta_slot] = meta_clean;
+        meta = nullptr;
+    }
+    for (void *p : { meta, pair_idx, x_b, u_b, m_b, early, page_lists })
+        if (p) ek_hip_free(p);
+}
 
 static size_t bucket_target_pieces(size_t n, int n_buckets) {
     Context &c = ctx();
@@ -1193,7 +1226,25 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->max_pieces = target_pieces + (unsigned) n_buckets;
     // meta: gtotal[3][256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
     const size_t meta_words = 3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
-    if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(float) + 16, &b->meta)) return rc;
+    // the counter block: one of the context's ring when one is free (then usually without a fill, see MetaRing), else an allocation
+    bool filled = false;
+    static const bool use_ring = [] { const char *e = getenv("ENOKI_HIP_META_RING"); return !e || atoi(e) != 0; }();
+    if (use_ring && b->max_pieces <= MetaRing::kPartials && refuse_while_capturing_quiet() == EK_OK) {
+        MetaRing &r = meta_ring();
+        for (int k = 0; k < MetaRing::kBlocks && b->meta_slot < 0; ++k) {
+            if (r.busy[k]) continue;
+            if (!r.block[k]) {
+                if (ek_hip_malloc(MetaRing::bytes(), &r.block[k]) != EK_OK) break;
+                r.clean[k] = false;
+            }
+            r.busy[k] = true;
+            b->meta_slot = k;
+            b->meta = r.block[k];
+            filled = r.clean[k];
+        }
+    }
+    if (b->meta_slot < 0)
+        if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(float) + 16, &b->meta)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(uint16_t), &b->pair_idx)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(float), &b->x_b)) return rc;
     const size_t part_entries = (size_t) p.W * n_buckets;
@@ -1202,8 +1253,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->glist_part = b->glist_full + p.page_slots;
     uint32_t *gtotal = (uint32_t *) b->meta;
     b->bucket_base = gtotal + 3 * kMaxBuckets;
-    b->active = gtotal + 2 * kMaxBuckets;
-    b->ticket = gtotal + 2 * kMaxBuckets + 2;              // (zeroed by the memset below, reset by whoever draws the last ticket)
+    b->active = gtotal + 2 * kMaxBuckets + kPgMetaResult;        // (written by the directory launch from the partition's accumulators)
+    b->ticket = gtotal + 2 * kMaxBuckets + kPgMetaFinishTicket;  // (zero between launches: reset by whoever draws the last ticket)
     b->has_mask = mask.vec != 0;
     b->base_part = b->bucket_base + kMaxBuckets + 1;
     b->piece_prefix = b->base_part + kMaxBuckets + 1;
@@ -1220,10 +1271,12 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.loff = out.cnt_full + part_entries;
     out.part = out.loff + part_entries;
     out.gtotal = gtotal;
-    out.active = gtotal + 2 * kMaxBuckets;
+    out.active = gtotal + 2 * kMaxBuckets + kPgMetaAccum;
     out.lo = b->win_lo; out.span = b->win_span ? b->win_span : (uint32_t) std::min<size_t>(b->table_size, 0xFFFFFFFFu);
-    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
-    note_launch("bucket_meta_clear", 3 * kMaxBuckets, 3 * kMaxBuckets * sizeof(uint32_t));   // (so that a profiled run does not bill the fill, and the host's gap in front of it, to the partition)
+    if (!filled) {
+        EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
+        note_launch("bucket_meta_clear", 3 * kMaxBuckets, 3 * kMaxBuckets * sizeof(uint32_t));   // (its own mark: a profiled run must not bill the fill to the partition)
+    }
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
         if (int rc = allow_big_lds(kernel, p.lds)) return rc;
@@ -1237,7 +1290,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     if (rc) return rc;
     EK_LAUNCH_CHECK("bucket_partition", n, n * (sizeof(I) + sizeof(float)) + arg_bytes(mask, n) + n * (sizeof(uint16_t) + sizeof(float)));
     hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, b->glist_full, b->glist_part, b->bucket_base,
-                       b->base_part, b->piece_prefix, (const uint32_t *) gtotal, (const uint32_t *) out.cnt_full,
+                       b->base_part, b->piece_prefix, gtotal, (const uint32_t *) out.cnt_full,
                        (const uint32_t *) out.loff, (const uint32_t *) out.part, (const uint32_t *) out.wlist, p.W, p.slots, n_buckets,
                        target_pieces);
     EK_LAUNCH_CHECK("bucket_directory", p.page_slots, 2 * p.page_slots * sizeof(uint32_t));
@@ -1273,7 +1326,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
                            (T *) b->reduce_partials, keep ? (T *) *kept : (T *) nullptr, (const T *) b->table_a,
                            (const T *) b->table_c, b->table_size, flip_a, flip_c, two, (const uint16_t *) b->pair_idx,
                            (const T *) b->x_b, (const T *) nullptr, b->lists(), map_op, partner ? 1 : 0, b->shift,
-                           b->template finish<T>(out, map_op));
+                           b->template finish<T>(out, map_op, ROp != EK_REDUCE_NONE));
     });
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + (b->table_c ? 2 : 1) * b->table_size * sizeof(T));

@@ -154,6 +154,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
 // device -- a read-back, a synchronisation -- cannot be recorded and would invalidate the capture.  Such entry points call
 // this first and fail cleanly (the capture stays valid, the caller ends it and runs the step eagerly).
 int refuse_while_capturing(const char *what);
+int refuse_while_capturing_quiet();        // EK_OK when no capture is in progress; sets no error message
 
 // The unary ops that a consumer may apply on load (HIPArray defers exactly these: include/enoki/hip.h)
 constexpr inline bool unary_fusable(int op) {

@@ -425,6 +425,8 @@ __device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot
 }
 
 constexpr int kPgDirSlices = 4;
+// words of the third row of the counter block (gtotal[2][.]): what the partition accumulates, the tickets, what the consumers read
+enum { kPgMetaAccum = 0 /* [2] */, kPgMetaFinishTicket = 2, kPgMetaResult = 4 /* [2] */ };
 
 // The bucket's page list = the workgroups' lists one after the other (full pages), then the partially filled pages; bucket
 // bases of both lists; pieces for the consumers (as k_bin_scan_buckets: a share of `target_pieces` in proportion to the
@@ -432,7 +434,7 @@ constexpr int kPgDirSlices = 4;
 static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restrict__ glist_full, uint32_t *__restrict__ glist_part,
                                                                uint32_t *__restrict__ base_full, uint32_t *__restrict__ base_part,
                                                                uint32_t *__restrict__ piece_prefix,
-                                                               const uint32_t *__restrict__ gtotal, const uint32_t *__restrict__ cnt_full,
+                                                               uint32_t *__restrict__ gtotal, const uint32_t *__restrict__ cnt_full,
                                                                const uint32_t *__restrict__ loff, const uint32_t *__restrict__ part,
                                                                const uint32_t *__restrict__ wlist, uint32_t W, uint32_t slots,
                                                                int n_buckets, uint32_t target_pieces) {
@@ -503,7 +505,13 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
         for (int u = 0; u < 4; ++u)
             if (e0 + u * 256 < e_end) glist_full[fb + e0 + u * 256] = src[u];
     }
+    // what the partition accumulated (elements kept, "non-finite x under a cleared mask bit") goes to where the consumers read it;
+    // the accumulators and the page totals are cleared by the last workgroup of the first reducing launch (bucket_finish), after
+    // which the block can serve the next object without a fill (csrc/bucketed.hip: MetaRing)
+    if (b == 0 && slice == 0 && t < 2) gtotal[2 * kMaxBuckets + kPgMetaResult + t] = gtotal[2 * kMaxBuckets + kPgMetaAccum + t];
 }
+
+
 
 // ---- host side -------------------------------------------------------------------------------------
 struct PagedPlan {

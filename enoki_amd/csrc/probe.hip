@@ -566,7 +566,7 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     EK_LAUNCH_CHECK("probe_page_partition", n, n * 14);
     if (directory) {
         hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, glist_full, glist_part, base_full, base_part,
-                           piece_prefix, (const uint32_t *) out.gtotal, (const uint32_t *) out.cnt_full, (const uint32_t *) out.loff,
+                           piece_prefix, out.gtotal, (const uint32_t *) out.cnt_full, (const uint32_t *) out.loff,
                            (const uint32_t *) out.part, (const uint32_t *) wlist, p.W, p.slots, n_buckets, target_pieces);
         EK_LAUNCH_CHECK("probe_page_directory", (size_t) n_buckets, 0);
     }

@@ -453,6 +453,8 @@ struct ek_hip_graph {
 static ek_hip_graph *g_capturing = nullptr;
 
 } // extern "C"
+int ek::refuse_while_capturing_quiet() { return g_capturing ? EK_ERR_UNSUPPORTED : EK_OK; }
+
 int ek::refuse_while_capturing(const char *what) {
     if (!g_capturing) return EK_OK;
     return fail(EK_ERR_INVALID, "%s: the host would have to wait for the device, which cannot be part of a captured step graph "

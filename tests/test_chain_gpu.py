@@ -150,3 +150,39 @@ def test_a_value_somebody_else_holds_is_evaluated_once(ek, oracle):
     p = da * dx
     ek.scatter(da, ek.Float32(np.zeros(16, np.float32)), ek.UInt32(np.arange(16, dtype=np.uint32)))
     assert bits_equal(p.numpy(), oracle.binary("mul", a, x))
+
+
+def test_explain_and_the_bucket_order_log(ek, capfd):
+    """array.explain() names the state of an array without evaluating it; hip_set_log_level(2) prints one line when an expression that
+    could have run in bucket order is evaluated in element order, and why"""
+    import enoki_amd.hip_autodiff as ad
+    n, K = 1 << 19, 1 << 16
+    rng = np.random.default_rng(5)
+    A, B = ek.Float32(uniform_pm1(K, 1)), ek.Float32(uniform_pm1(K, 2))
+    x = ek.Float32(uniform_pm1(n, 3))
+    idx = ek.UInt32(rng.integers(0, K, n).astype(np.uint32))
+    launches = ek.hip_launch_count()
+    g = ek.gather(A, idx)
+    assert "unevaluated gather" in g.explain()
+    p = g * x
+    assert "product of a gather" in p.explain() and "BUCKET ORDER possible" in p.explain()
+    u = p + ek.gather(B, idx)
+    assert "product-then-sum of two gathers" in u.explain()
+    s = ek.sin(u)
+    assert "unevaluated unary op" in s.explain() and "kind 2" in s.explain()
+    f = ek.fmadd(x, x, x)
+    assert "unevaluated arithmetic op" in f.explain()
+    assert ek.hip_launch_count() == launches, "explain() must not evaluate anything"
+    assert "evaluated array" in x.explain() and "host scalar" in ek.Float32(1.5).explain()
+    # an elementwise consumer of the node: element order, and the log says so
+    ek.hip_set_log_level(2)
+    try:
+        capfd.readouterr()
+        v = (u * ek.Float32(2.0)).numpy()
+        err = capfd.readouterr().err
+    finally:
+        ek.hip_set_log_level(0)
+    assert "[bucket order]" in err and "ELEMENT order" in err, err
+    assert "evaluated array" in u.explain()
+    want = (uniform_pm1(K, 1)[idx.numpy()] * uniform_pm1(n, 3) + uniform_pm1(K, 2)[idx.numpy()]) * np.float32(2.0)
+    assert bits_equal(v, want.astype(np.float32))
