@@ -488,6 +488,7 @@ template <typename T, int C> struct BucketStreams {
     T imm[C];
     T scale[C];           // host scalar factor on the stream's value (before the weight)
     unsigned from_u, weighted;
+    unsigned plain_x = 0;  // C == 1: the stream is x itself (scatter_add_paged)
 };
 // Two f32 tables share ONE lock per bin: the LDS holds {table 0, table 1} pairs and a bin pair is claimed by a 64-bit
 // exchange (ds_wrxchg_rtn_b64), updated and released by one 64-bit store -- half the LDS atomics and half the dependent
@@ -678,10 +679,12 @@ __device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], 
 // element however many streams share it -- the usual pair cos(u), x * cos(u)); Map < 0: per-stream ops chosen at run time.
 // Spec = 1: the adjoint of a gathered pair as the tape issues it -- two streams, both the (kept / mapped) function of u, the
 // SECOND one weighted by x: known at compile time, no per-element selects on the stream description.
+// Spec = 2: ONE stream that is the partitioned value x itself -- a plain scatter_add(value, index) whose (index, value) pairs went
+// through the page partition (scatter_add_paged below).
 template <typename T, int C, int V, int Map, int Spec>
 struct AccumulateBody {
     static constexpr bool Paired = C == 2 && sizeof(T) == 4;
-    static_assert(Spec == 0 || (C == 2 && Map >= 0));
+    static_assert(Spec == 0 || (Spec == 1 && C == 2 && Map >= 0) || (Spec == 2 && C == 1));
     struct Step { Pack<uint16_t, 4> pi[V]; T pu[V][4], px[V][4]; };
     T *acc;
     BucketStreams<T, C> st;
@@ -693,7 +696,9 @@ struct AccumulateBody {
     __device__ __forceinline__ void values(T u, T x, T (&v)[C]) const {
         T m = T(0);
         if constexpr (Map >= 0) m = UnaryOp<Map, T>::apply(u);
-        if constexpr (Spec == 1) {
+        if constexpr (Spec == 2) {
+            v[0] = x;
+        } else if constexpr (Spec == 1) {
             v[0] = m * st.scale[0];
             v[C - 1] = dev::safe_mul(x, m * st.scale[C - 1]);
         } else {
@@ -791,6 +796,15 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
 #define EK_ACC_CASE(OP) case OP: run(AccumulateBody<T, C, V, OP, 0>{}, false); break;
 #define EK_ACC_SPEC(OP) case OP: run(AccumulateBody<T, C, V, OP, 1>{}, true); break;
     bool done = false;
+    if constexpr (C == 1) {
+        if (st.plain_x) {
+            auto body = AccumulateBody<T, C, V, EK_COPY, 2>{};
+            body.acc = acc; body.st = st; body.pair_idx = pair_idx; body.u_b = u_b; body.x_b = x_b; body.Bins = Bins;
+            body.need_u = false; body.need_x = true;
+            walk_piece<PS, V>(bl, range, body);
+            done = true;
+        }
+    }
     if constexpr (C == 2) {
         if (uniform && st.from_u == 3u && st.weighted == 2u) {         // (host side: the weighted stream is put second)
             done = true;
@@ -1075,6 +1089,13 @@ struct MetaRing {
     static size_t bytes() { return (3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1) * sizeof(uint32_t) + kPartials * sizeof(float) + 16; }
 };
 static MetaRing &meta_ring() { static MetaRing *r = new MetaRing(); return *r; }
+
+void release_meta_ring() {
+    MetaRing &r = meta_ring();
+    for (int k = 0; k < MetaRing::kBlocks; ++k) {
+        if (r.block[k] && !r.busy[k]) { ek_hip_free(r.block[k]); r.block[k] = nullptr; r.clean[k] = false; }
+    }
+}
 
 Bucketed::~Bucketed() {
     if (meta_slot >= 0) {
@@ -1536,6 +1557,34 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
         }
     }
     return EK_OK;
+}
+
+// ---- plain scatter_add(value, index, mask) through the page partition ------------------------------------------------------
+// The LDS-binned scatter_add of scatter_binned.hip reads the indices twice and needs two scans before it can place a pair
+// (count 5 + partition 15 + accumulate 6 B per pair, five launches).  The single-pass page partition of the bucket-ordered path
+// does the same job for ONE f32 value stream in 14 + 6 B and three launches + the fold: the (index, value) pairs are partitioned
+// into pages by bucket of 16 Ki table entries, every piece of a bucket adds its values into an LDS table under the exchange
+// lock, the per-piece tables are folded into the target.  Same sums up to the order of the additions (class D, like the binned
+// path); out-of-range indices and masked-out pairs are dropped.
+int scatter_add_paged(float *base, size_t table_size, const float *value, const uint32_t *index, const Arg<uint8_t> &mask, size_t n) {
+    RoctxRange range("enoki-hip: scatter_add (paged)");
+    ek::Bucketed obj;
+    obj.type = EK_F32; obj.index_type = EK_U32; obj.op = EK_FMADD;
+    obj.n = n; obj.table_size = table_size;
+    if (int rc = bucketed_create_paged<uint32_t>(&obj, value, index, mask, bin_shift_of<float>)) return rc;
+    BucketStreams<float, 1> st{};
+    st.map_op[0] = EK_COPY; st.imm[0] = 0.f; st.scale[0] = 1.f;
+    st.from_u = 0u; st.weighted = 1u; st.plain_x = 1u;
+    float *bases[1] = { base };
+    return bucketed_accumulate<float, 1>(&obj, bases, st, nullptr, 0u);
+}
+
+bool scatter_add_paged_applicable(size_t table_size, size_t n) {
+    // (from 32 buckets on: with a handful of buckets every element of a tile meets the same few LDS counters -- 64 Mi adds into
+    // 64 Ki bins: 0.51 ms paged against 0.36 ms binned, 256 Ki bins: equal, 1 Mi: 0.28 against 0.33, 4 Mi: 0.31 against 0.39;
+    // profiles/probe_scatter_paged_r05.txt)
+    return ctx().tuning.bucket_ordered && !ctx().tuning.deterministic && n >= ((size_t) 1 << 18) && n < ((size_t) 1 << 30) &&
+           table_size >= (size_t) 32 * bins_of<float> && table_size <= (size_t) kMaxBuckets * bins_of<float>;
 }
 
 // ---- partition of an index array alone (ek_hip_index_partition_*) ------------------------------------------------------

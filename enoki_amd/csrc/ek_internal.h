@@ -155,6 +155,7 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
 // this first and fail cleanly (the capture stays valid, the caller ends it and runs the step eagerly).
 int refuse_while_capturing(const char *what);
 int refuse_while_capturing_quiet();        // EK_OK when no capture is in progress; sets no error message
+void release_meta_ring();                  // bucketed.hip: the context's counter blocks go back to the allocator (device switch)
 
 // The unary ops that a consumer may apply on load (HIPArray defers exactly these: include/enoki/hip.h)
 constexpr inline bool unary_fusable(int op) {
@@ -165,6 +166,10 @@ constexpr inline bool unary_fusable(int op) {
         default: return false;
     }
 }
+
+// one f32 value stream through the single-pass page partition (bucketed.hip): 20 B per pair instead of 26
+bool scatter_add_paged_applicable(size_t table_size, size_t n);
+int scatter_add_paged(float *base, size_t table_size, const float *value, const uint32_t *index, const Arg<uint8_t> &mask, size_t n);
 
 bool scatter_add_binned_multi_applicable(size_t table_size, size_t n, bool index_is_array, size_t elem_size = 4);
 template <typename T, typename I, int C>

@@ -191,6 +191,7 @@ int ek_hip_init(int device) {
         // keyed by size only, so the cache (and the reduction scratch, which lives in it) is released on the old device
         // first; arrays that are still alive would dangle, so the switch is refused while any exist.
         EK_HIP_CHECK(hipStreamSynchronize(c.stream));
+        release_meta_ring();
         if (c.reduce_scratch) {
             ek_hip_free(c.reduce_scratch);
             c.reduce_scratch = nullptr;

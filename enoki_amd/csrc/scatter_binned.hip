@@ -37,6 +37,12 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     constexpr int Bins = bins_of<T>;
     if (table_size > (size_t) kMaxBuckets * Bins)
         return scatter_add_binned_large<T, I>(base, table_size, value, index, mask, n);
+    if constexpr (std::is_same_v<T, float>) {
+        // one pass over (index, value) instead of count + scans + partition (valid int32 indices are non-negative: same bits as uint32)
+        static const bool paged = [] { const char *e = getenv("ENOKI_HIP_SCATTER_PAGED"); return !e || atoi(e) != 0; }();
+        if (paged && value.vec && index.vec && scatter_add_paged_applicable(table_size, n))
+            return scatter_add_paged(base, table_size, value.ptr, reinterpret_cast<const uint32_t *>(index.ptr), mask, n);
+    }
     Context &c = ctx();
     const int n_buckets = (int) ((table_size + Bins - 1) / Bins);
     const size_t lds_bytes = (size_t) Bins * sizeof(T);
