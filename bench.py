@@ -541,10 +541,12 @@ class Bench:
                 torch.cuda.synchronize()
                 return ekd.max_over_ranks(time.perf_counter() - t)
             t0 = time.perf_counter()
-            t20 = batch(20)
-            more = int(min(max(0.0, pre_warm_s - t20) / max(t20 / 20, 1e-6), 100000))
-            if more > 0:
-                batch(more)
+            done = batch(20)                         # (the first steps of a process are slow: kernels load, pools fill)
+            per_step, rounds = done / 20, 0
+            while done < pre_warm_s and rounds < 8:
+                k = int(min(max(1.0, (pre_warm_s - done) / max(per_step, 1e-6)), 100000))
+                t = batch(k)
+                done, per_step, rounds = done + t, t / k, rounds + 1
             self.pre_warm_s = round(time.perf_counter() - t0, 3)
         for _ in range(warmup):
             step()
