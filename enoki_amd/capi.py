@@ -43,7 +43,7 @@ EXPORTS = [
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
-    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_reduce_chain", "ek_hip_map_chain", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
+    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_reduce_chain", "ek_hip_map_chain", "ek_hip_map_chain_product", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
     "ek_hip_dist_unique_id", "ek_hip_dist_init", "ek_hip_dist_world", "ek_hip_dist_shard_range", "ek_hip_dist_all_reduce",
     "ek_hip_dist_reduce_scatter", "ek_hip_dist_all_gather", "ek_hip_dist_finalize", "ek_hip_dist_rccl_path",
     "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_pair_create_masked", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add", "ek_hip_bucketed_scatter_add_scaled", "ek_hip_bucketed_early_pair",
@@ -427,6 +427,19 @@ def map_chain(base, srcs, maps):
     out = Buf(dt, n)
     check(lib.ek_hip_map_chain(NP2EK[dt], ctypes.c_void_p(out.ptr), ctypes.byref(ch), ctypes.c_size_t(n)))
     return out
+
+
+def map_chain_product(base, srcs, maps, scale=None, w=None, op2="mul", first=True):
+    """(chain * scale, op2(w, chain * scale)) in one pass (ek_hip_map_chain_product); first=False: only the product is written"""
+    ch, dt, n = _chain(base, srcs, maps)
+    out = Buf(dt, n) if first else None
+    out2 = Buf(dt, n) if w is not None else None
+    sc = operand(dt.type(scale), dt) if scale is not None else None
+    wo = operand(w, dt) if w is not None else None
+    check(lib.ek_hip_map_chain_product(NP2EK[dt], ctypes.c_void_p(out.ptr if out else None), ctypes.c_void_p(out2.ptr if out2 else None),
+                                       ctypes.byref(ch), ctypes.byref(sc) if sc is not None else None, BINARY[op2],
+                                       ctypes.byref(wo) if wo is not None else None, ctypes.c_size_t(n)))
+    return out, out2
 
 
 def reduce_map(op, map_op, a):

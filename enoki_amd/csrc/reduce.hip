@@ -345,23 +345,84 @@ __global__ __launch_bounds__(256) void k_chain_reduce(T *__restrict__ partials, 
     if (threadIdx.x == 0) partials[blockIdx.x] = v;
 }
 
-// the same chain written out (what forcing an unevaluated chain costs: one pass instead of one per op)
-template <typename T>
-__global__ __launch_bounds__(256) void k_chain_map(T *__restrict__ out, size_t n, int vec_ok, ChainArgs<T> ch) {
-    constexpr int N = 16 / sizeof(T);
+// the same chain written out (what forcing an unevaluated chain costs: one pass instead of one per op).  Tail: the optional factor
+// of a scaled map (one more rounding, as the eager product has) and the optional SECOND output  out2 = w (safe-)times out  -- the
+// step of Tape::backward() at u = fmadd(a, x, b) under sin: grad_b = cos(u) and grad_a = x cos(u) are two results of one pass
+// over a, x, b (20 B/elt) instead of cos written, re-read and multiplied (24 after a stored u, 28 after a recomputed one).
+struct ChainTail {
+    int scaled, product;            // product: 0 none, 1 w * out, 2 safe_mul(w, out)
+};
+
+#ifndef EK_CHAIN_TAIL_VECTORS
+#define EK_CHAIN_TAIL_VECTORS 1              // 16-byte vectors per lane of the kernel with a tail (A/B switch)
+#endif
+#ifndef EK_CHAIN_TAIL_NT
+#define EK_CHAIN_TAIL_NT 1                   // nontemporal stores of its outputs
+#endif
+
+template <typename T, bool Tail>
+__global__ __launch_bounds__(256) void k_chain_map(T *__restrict__ out, size_t n, int vec_ok, ChainArgs<T> ch, ChainTail tail, T scale,
+                                                    const T *__restrict__ w, T *__restrict__ out2) {
+    constexpr int N = 16 / sizeof(T), U = Tail ? EK_CHAIN_TAIL_VECTORS : 1;
+    constexpr bool NT = Tail ? EK_CHAIN_TAIL_NT != 0 : true;
     T s[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) s[k] = ch.src[k].vec ? T(0) : arg_scalar(ch.src[k]);
-    const size_t e = lane_elem<N, 1>(0);
-    if (e >= n) return;
-    const bool fast = vec_ok && e + N <= n;
-    T r[N], b[N], c[N];
-    chain_load<T, N>(ch, s, e, n, fast, r, b, c);
-    chain_apply<T, N>(r, b, c, ch);
-    Pack<T, N> po;
+    size_t e[U];
+    bool fast[U];
+    T r[U * N], b[U * N], c[U * N];
 #pragma unroll
-    for (int i = 0; i < N; ++i) po.v[i] = r[i];
-    out_store<T, N, true>(out, po, e, n, fast);
+    for (int u = 0; u < U; ++u) {
+        e[u] = lane_elem<N, U>(u);
+        fast[u] = vec_ok && e[u] + N <= n;
+        if (e[u] >= n) {                                   // (only the last vectors of the grid: computed on zeros, not stored)
+#pragma unroll
+            for (int i = 0; i < N; ++i) r[u * N + i] = b[u * N + i] = c[u * N + i] = T(0);
+            continue;
+        }
+        const Pack<T, N> p0 = arg_load<T, N, true>(ch.src[0], s[0], e[u], n, fast[u]), p1 = arg_load<T, N, true>(ch.src[1], s[1], e[u], n, fast[u]),
+                         p2 = arg_load<T, N, true>(ch.src[2], s[2], e[u], n, fast[u]);
+#pragma unroll
+        for (int i = 0; i < N; ++i) { r[u * N + i] = p0.v[i]; b[u * N + i] = p1.v[i]; c[u * N + i] = p2.v[i]; }
+    }
+    if (e[0] >= n) return;
+    Pack<T, N> pw[U];
+    if constexpr (Tail) {
+        if (tail.product) {
+            const Arg<T> wa{ w, T(0), 1u };
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (e[u] < n) pw[u] = arg_load<T, N, true>(wa, T(0), e[u], n, fast[u]);
+        }
+    }
+    chain_apply<T, U * N>(r, b, c, ch);
+    if constexpr (Tail) {
+        if (tail.scaled) {
+#pragma unroll
+            for (int i = 0; i < U * N; ++i) r[i] = r[i] * scale;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (e[u] >= n) continue;
+        Pack<T, N> po;
+#pragma unroll
+        for (int i = 0; i < N; ++i) po.v[i] = r[u * N + i];
+        if (!Tail || out) out_store<T, N, NT>(out, po, e[u], n, fast[u]);
+        if constexpr (Tail) {
+            if (tail.product) {
+                Pack<T, N> pp;
+                if (tail.product == 2) {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) pp.v[i] = dev::safe_mul(pw[u].v[i], r[u * N + i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < N; ++i) pp.v[i] = pw[u].v[i] * r[u * N + i];
+                }
+                out_store<T, N, NT>(out2, pp, e[u], n, fast[u]);
+            }
+        }
+    }
 }
 
 template <typename T> int chain_args(const ek_chain *chain, size_t n, ChainArgs<T> &ch, size_t &bytes, int &aligned, const char *what) {
@@ -425,8 +486,42 @@ template <typename T> int chain_map(void *out, const ek_chain *chain, size_t n) 
     int aligned;
     if (int rc = chain_args<T>(chain, n, ch, bytes, aligned, "ek_hip_map_chain()")) return rc;
     constexpr int N = 16 / sizeof(T);
-    hipLaunchKernelGGL((k_chain_map<T>), dim3(oneshot_grid<N, 1>(n)), dim3(256), 0, ctx().stream, (T *) out, n, aligned && aligned16(out), ch);
+    hipLaunchKernelGGL((k_chain_map<T, false>), dim3(oneshot_grid<N, 1>(n)), dim3(256), 0, ctx().stream, (T *) out, n, aligned && aligned16(out), ch,
+                       ChainTail{ 0, 0 }, T(1), (const T *) nullptr, (T *) nullptr);
     EK_LAUNCH_CHECK("map_chain", n, bytes + n * sizeof(T));
+    return EK_OK;
+}
+
+template <typename T> int chain_map_product(void *out, void *out2, const ek_chain *chain, const ek_operand *scale, int op2, const ek_operand *w, size_t n) {
+    const char *what = "ek_hip_map_chain_product()";
+    ChainArgs<T> ch;
+    size_t bytes;
+    int aligned;
+    if (int rc = chain_args<T>(chain, n, ch, bytes, aligned, what)) return rc;
+    ChainTail tail{ 0, 0 };
+    T factor = T(1);
+    if (!out && !out2) return fail(EK_ERR_INVALID, "%s: null pointer", what);
+    if (scale) {
+        if (scale->ptr) return fail(EK_ERR_INVALID, "%s: the factor is an immediate", what);
+        memcpy(&factor, &scale->imm, sizeof(T));
+        tail.scaled = 1;
+    }
+    const T *wp = nullptr;
+    if (out2) {
+        if (op2 != EK_MUL && op2 != EK_SAFE_MUL) return fail(EK_ERR_UNSUPPORTED, "%s: second output through op %d", what, op2);
+        if (!w || !w->ptr || w->size != n) return fail(EK_ERR_INVALID, "%s: the other factor is an array of n elements", what);
+        wp = (const T *) w->ptr;
+        tail.product = op2 == EK_SAFE_MUL ? 2 : 1;
+        aligned = aligned && aligned16(wp) && aligned16(out2);
+        bool dup = false;                                   // (the factor usually IS one of the chain's operands: x of fmadd(a, x, b))
+        for (int k = 0; k < 3; ++k) dup = dup || (ch.src[k].vec && ch.src[k].ptr == wp);
+        bytes += (dup ? 1 : 2) * n * sizeof(T);
+    }
+    if (out) { aligned = aligned && aligned16(out); bytes += n * sizeof(T); }
+    constexpr int N = 16 / sizeof(T);
+    hipLaunchKernelGGL((k_chain_map<T, true>), dim3(oneshot_grid<N, EK_CHAIN_TAIL_VECTORS>(n)), dim3(256), 0, ctx().stream, (T *) out, n, aligned, ch, tail,
+                       factor, wp, (T *) out2);
+    EK_LAUNCH_CHECK("map_chain_product", n, bytes);
     return EK_OK;
 }
 
@@ -568,6 +663,16 @@ int ek_hip_map_chain(int type, void *out, const ek_chain *chain, size_t n) {
         case EK_F32: return chain_map<float>(out, chain, n);
         case EK_F64: return chain_map<double>(out, chain, n);
         default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_chain(): floating point types only");
+    }
+}
+
+int ek_hip_map_chain_product(int type, void *out, void *out2, const ek_chain *chain, const ek_operand *scale, int op2, const ek_operand *w, size_t n) {
+    if (int rc = ensure_init()) return rc;
+    if (n == 0) return EK_OK;
+    switch (type) {
+        case EK_F32: return chain_map_product<float>(out, out2, chain, scale, op2, w, n);
+        case EK_F64: return chain_map_product<double>(out, out2, chain, scale, op2, w, n);
+        default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_map_chain_product(): floating point types only");
     }
 }
 

@@ -181,11 +181,9 @@ namespace detail {
                 if (ch.n_maps > 1 || ch.arity > 1) {
                     void *p = nullptr;
                     hip_check(ek_hip_malloc(bytes, &p), "HIPArray (deferred chain)");
-                    int rc = ek_hip_map_chain(d->type, p, &ch, size);
-                    if (rc == EK_OK && d->scaled) {
-                        ek_operand self{ p, 0, size }, factor{ nullptr, d->scale_bits, 1 };
-                        rc = ek_hip_binary(EK_MUL, d->type, p, &self, &factor, size);
-                    }
+                    ek_operand factor{ nullptr, d->scale_bits, 1 };           // (a scaled node: one more rounding, inside the pass)
+                    int rc = d->scaled ? ek_hip_map_chain_product(d->type, p, nullptr, &ch, &factor, EK_MUL, nullptr, size)
+                                       : ek_hip_map_chain(d->type, p, &ch, size);
                     if (rc != EK_OK) {
                         ek_hip_free(p);
                         hip_raise("HIPArray (deferred chain)");
@@ -232,6 +230,25 @@ namespace detail {
                 other->ptr = q;
                 other->drop_deferred();
             }
+            drop_deferred();
+        }
+
+        /// A deferred unary map whose first consumer is a product with an evaluated array `w` -- safe_mul(edge weight, gradient)
+        /// of the backward sweep, with the gradient still the unevaluated cos(u) -- is evaluated TOGETHER with that product: one
+        /// pass over the chain's operands writes both (ek_hip_map_chain_product); the caller owns `product` (size elements).
+        /// Precondition: no unevaluated sincos partner (that pair has a kernel of its own).
+        void force_map_product(const HIPBuffer *w, int op2, void *product) {
+            Deferred *d = deferred;
+            ek_chain ch;
+            build_chain(ch);
+            void *p = nullptr;
+            hip_check(ek_hip_malloc((size ? size : 1) * d->elem_size, &p), "HIPArray (deferred map and its product)");
+            ek_operand factor{ nullptr, d->scale_bits, 1 }, other{ w->ptr, 0, w->size };
+            if (ek_hip_map_chain_product(d->type, p, product, &ch, d->scaled ? &factor : nullptr, op2, &other, size) != EK_OK) {
+                ek_hip_free(p);
+                hip_raise("HIPArray (deferred map and its product)");
+            }
+            ptr = p;
             drop_deferred();
         }
 
@@ -317,23 +334,34 @@ namespace detail {
 
         /// Only the chain above holds / reads this unevaluated node: it can be recomputed inside the consumer instead of written
         bool absorbable_() const { return deferred && ref_count == 1 && readers.size() == 1; }
+        /// An unevaluated arithmetic node that only `reader` and ONE more unevaluated map hold -- the sin(u) / cos(u) that
+        /// differentiating sin records next to each other.  A reduction of the one reads u's operands (12 B/elt for an fma)
+        /// instead of writing u for the other (16 + 4): no worse whatever the sibling does later, and better when the
+        /// sibling in turn finds itself alone (hsum(sin(fmadd(a, x, b))) followed by backward(): cfg3a, 40 -> 32 B/elt).
+        bool only_sibling_maps_(const HIPBuffer *reader) const {
+            if (!deferred || deferred->kind != 4 || readers.size() != 2 || ref_count != 2) return false;
+            for (const HIPBuffer *rd : readers)
+                if (rd != reader && !(rd->deferred && rd->deferred->kind == 1 && rd->deferred->table == this)) return false;
+            return readers[0] == reader || readers[1] == reader;
+        }
 
         /// The chain that ends in this kind-1 node, as a descriptor for ek_hip_reduce_chain / ek_hip_map_chain: unevaluated maps
         /// below it that nobody else wants (unscaled, no live sincos partner) are absorbed, then an unevaluated arithmetic node
         /// (kind 4) that nobody else wants becomes the base; whatever cannot be absorbed is evaluated here and is the base.  The
         /// scale / partner of THIS node are its caller's business.
-        void build_chain(ek_chain &ch) {
+        void build_chain(ek_chain &ch, bool peek = false) {
             int ops[3], n = 0;
             ops[n++] = deferred->index_type;
-            HIPBuffer *src = deferred->table;
+            HIPBuffer *src = deferred->table, *below = this;        // below: the node of the chain that reads src
             while (n < 3 && src->absorbable_() && src->deferred->kind == 1 && !src->deferred->scaled &&
                    !(src->deferred->partner && src->deferred->partner->deferred)) {
                 ops[n++] = src->deferred->index_type;
+                below = src;
                 src = src->deferred->table;
             }
             ch.n_maps = n;
             for (int k = 0; k < 3; ++k) ch.map_ops[k] = k < n ? ops[n - 1 - k] : (int) EK_COPY;        // first applied first
-            if (src->absorbable_() && src->deferred->kind == 4) {
+            if ((src->absorbable_() || (peek && src->only_sibling_maps_(below))) && src->deferred->kind == 4) {
                 const Deferred *a = src->deferred;
                 ch.arity = a->arity;
                 ch.base_op = a->op;
@@ -1105,6 +1133,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         if constexpr (IsFloat) {
             const auto *d = m_buf->deferred;
             if (!detail::hip_defer_gather_flag() || !(factor == factor) || factor - factor != Value(0)) return r;
+            if (factor == Value(1)) return *this;          // the same function of the same source: the same node (x * 1 is x)
             Value scale = factor;
             if (d->scaled) {
                 Value old;
@@ -1870,6 +1899,18 @@ private:
         }
         size_t n = broadcast_size(size(), b.size());
         if constexpr (IsFloat) {
+            // an unevaluated map times an evaluated array (the sweep's safe_mul(x, grad_u) with grad_u = cos(u) still pending):
+            // the map and the product are the two outputs of one pass over the chain's operands
+            if ((op == EK_MUL || op == EK_SAFE_MUL) && mapped_() != b.mapped_()) {
+                const HIPArray &m = mapped_() ? *this : b, &w = mapped_() ? b : *this;
+                const auto *d = m.m_buf->deferred;
+                if (!w.m_is_imm && w.m_buf && !w.m_buf->deferred && w.m_buf->size == m.m_buf->size && n == m.m_buf->size && n > 1 &&
+                    !(d->partner && d->partner->deferred)) {
+                    HIPArray r = empty_(n);
+                    m.m_buf->force_map_product(w.m_buf, op, r.m_buf->ptr);
+                    return r;
+                }
+            }
             // `gather(A, idx) * x + gather(B, idx)` written with operators (BASELINE.json spells config 3b `a*x+b`): the product
             // stays unevaluated (kind 2 without an addend), the sum with the second gather makes the node of the whole expression
             if (op == EK_MUL && deferred_() != b.deferred_()) {
@@ -1969,7 +2010,7 @@ private:
                     if (src->deferred && (src->deferred->kind == 1 || src->deferred->kind == 4)) {
                         // maps over maps over an unevaluated arithmetic node: whatever only this chain wants is applied on load
                         ek_chain ch;
-                        m_buf->build_chain(ch);
+                        m_buf->build_chain(ch, /* peek = */ true);
                         if (ch.n_maps > 1 || ch.arity > 1) {
                             detail::hip_check(ek_hip_reduce_chain(op, Type, r.m_buf->ptr, &ch, n), what);
                             return finish();

@@ -411,6 +411,15 @@ typedef struct {
 } ek_chain;
 EK_API int ek_hip_reduce_chain(int reduce_op, int type, void *out, const ek_chain *chain, size_t n);
 EK_API int ek_hip_map_chain(int type, void *out, const ek_chain *chain, size_t n);
+/* ek_hip_map_chain with a tail -- a factor and a second output:
+ *     out[i]  = chain(i) * scale           scale: an immediate (ptr == NULL), or NULL for none; one more rounding, like the eager product
+ *     out2[i] = op2(w[i], out[i])          op2 = EK_MUL | EK_SAFE_MUL, w an array of n elements
+ * Either of out / out2 may be NULL (not both; out2 == NULL: op2 and w are ignored).  This is what the sweep of Tape::backward()
+ * asks for at u = fmadd(a, x, b) under y = hsum(sin(u)) (src/autodiff/autodiff.cpp:838-988: grad_b = 1 * grad_u,
+ * grad_a = x * grad_u with grad_u = cos(u)): a, x, b are read once and both gradients written, 20 B/elt, where the op-by-op
+ * evaluation writes cos(u), re-reads it and multiplies (24 B/elt after a stored u).  Bits as op by op. */
+EK_API int ek_hip_map_chain_product(int type, void *out, void *out2, const ek_chain *chain, const ek_operand *scale, int op2,
+                                    const ek_operand *w, size_t n);
 /* op(map_op(in[0..n))) in ONE pass over `in`: the unary operation is applied while loading (hsum(sin(x)): 4 B/element
  * instead of 12).  map_op: EK_NEG, EK_ABS, EK_SQRT, EK_RCP, EK_RSQRT, EK_SIN, EK_COS, EK_EXP, EK_LOG; floating point
  * types; n >= 1.  Same element values and the same reduction tree as ek_hip_unary followed by ek_hip_reduce (bit-identical

@@ -352,7 +352,7 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
         static const int maps[] = { EK_NEG, EK_ABS, EK_SIN, EK_COS, EK_EXP };
         auto pick = [&]() -> F & { return pool[rng() % pool.size()]; };
         for (int step = 0; step < 60; ++step) {
-            const int what = rng() % 19;
+            const int what = rng() % 20;
             if (getenv("TRACE")) fprintf(stderr, "seed %u step %d op %d\n", seed, step, what);
             switch (what) {
                 case 0: {   // unary map
@@ -410,6 +410,16 @@ static std::vector<std::vector<float>> run_program(uint32_t seed, bool defer) {
                 }
                 case 16: { F r = gather<F>(tables[0], idx) * pick() + gather<F>(tables[1], idx); if (rng() & 1) seen.push_back({ hsum(cos(r)).coeff(0) }); pick() = r; break; }
                 case 17: { F p = gather<F>(tables[1], idx) * pick(); F r = rng() & 1 ? p - gather<F>(tables[0], idx) : gather<F>(tables[0], idx) - p; pick() = r; break; }
+                case 19: {  // an unevaluated map times an array: the map and the product are two outputs of one pass
+                    F u = fmadd(pick(), pick(), pick());
+                    F c = rng() & 1 ? cos(u) : -sin(exp(u * F(0.125f)));
+                    F &w = pick();
+                    F p = rng() & 1 ? c * w : w * c;
+                    if (rng() & 1) seen.push_back(host(p));
+                    if (rng() & 1) pick() = c;
+                    pick() = p;
+                    break;
+                }
                 case 18: { F p = pick() * gather<F>(tables[0], idx); if (rng() & 1) seen.push_back({ hsum(p).coeff(0) }); else pick() = p; break; }
                 case 13: {  // sqrt and its derivative's factor .5 / sqrt(v): an unevaluated multiple of rsqrt(v) when deferred
                     F v = abs(pick()) + F(1.f);
@@ -468,7 +478,8 @@ int main() {
     }
     hip_set_defer(true);
     CHECK(fused_total > 100 && g_bucketed_reduces > 20 && g_bucketed_scatters > 10);      // the deferred paths were really taken
-    CHECK(g_chain_calls > 10);                                                              // ... chains among them
+    CHECK(g_chain_calls > 10);                                                            // ... chains among them,
+    CHECK(g_chain_product_calls > 5);                                                     // and maps evaluated together with a product
     printf("asan_deferred: directed scenarios + 40 fuzzed programs agree with eager evaluation (%ld fused consumer launches), no block left allocated\n",
            fused_total);
     return 0;

@@ -104,6 +104,7 @@ int ek_hip_sincos(int, void *s, void *c, const ek_operand *a, size_t n) {
     return EK_OK;
 }
 static long g_safe_calls = 0;               // elements that went through EK_SAFE_MUL / EK_SAFE_FMADD
+static long g_array_launches = 0;           // ek_hip_unary / binary / ternary calls over more than one element
 static float binary_f(int op, float a, float b) {
     switch (op) {
         case EK_ADD: return a + b;
@@ -117,6 +118,7 @@ static float binary_f(int op, float a, float b) {
     }
 }
 int ek_hip_binary(int op, int type, void *out, const ek_operand *a, const ek_operand *b, size_t n) {
+    g_array_launches += n > 1;
     if (type == EK_BOOL) {
         for (size_t i = 0; i < n; ++i) {
             bool x = op_m(a, i), y = op_m(b, i);
@@ -136,6 +138,7 @@ int ek_hip_binary(int op, int type, void *out, const ek_operand *a, const ek_ope
     return EK_OK;
 }
 int ek_hip_ternary(int op, int, void *out, const ek_operand *a, const ek_operand *b, const ek_operand *c, size_t n) {
+    g_array_launches += n > 1;
     for (size_t i = 0; i < n; ++i) {
         const float x = op_f(a, i), y = op_f(b, i), z = op_f(c, i);
         float r;
@@ -384,6 +387,20 @@ static float chain_value(const ek_chain *ch, size_t i) {
 int ek_hip_map_chain(int, void *out, const ek_chain *ch, size_t n) {
     ++g_chain_calls;
     for (size_t i = 0; i < n; ++i) ((float *) out)[i] = chain_value(ch, i);
+    return EK_OK;
+}
+static long g_chain_product_calls = 0;
+int ek_hip_map_chain_product(int, void *out, void *out2, const ek_chain *ch, const ek_operand *scale, int op2, const ek_operand *w, size_t n) {
+    ++g_chain_calls;
+    if (out2) ++g_chain_product_calls;
+    float factor = 1.f;
+    if (scale) memcpy(&factor, &scale->imm, 4);
+    for (size_t i = 0; i < n; ++i) {
+        float v = chain_value(ch, i);
+        if (scale) v = binary_f(EK_MUL, v, factor);
+        if (out) ((float *) out)[i] = v;
+        if (out2) ((float *) out2)[i] = binary_f(op2, op_f(w, i), v);
+    }
     return EK_OK;
 }
 int ek_hip_reduce_chain(int op, int, void *out, const ek_chain *ch, size_t n) {

@@ -88,6 +88,37 @@ def test_chain_sums_are_class_d(capi, dtype):
     assert abs(got - p64) <= 4 * 4099 * EPS[dtype] * abs(p64) + 1e-300
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_chain_with_a_factor_and_a_second_output(capi, dtype):
+    """ek_hip_map_chain_product: (chain * scale, op2(w, chain * scale)) -- bit for bit the op-by-op kernels, for both products, with
+    zeros in w against infinities / NaNs in the chain (safe_mul's point), a ragged length, either output alone"""
+    n = 70001
+    gen = f32_inputs if dtype == np.float32 else f64_inputs
+    arrs = [up(capi, gen(n, seed=11 + k, scale=2.0)) for k in range(3)]
+    wn = gen(n, seed=17, scale=2.0)
+    wn[::5] = 0.0
+    wn[1::7] = -0.0
+    w = up(capi, wn)
+    for base, arity in (("fmadd", 3), ("nmuladd", 3), ("mul", 2), (None, 1)):
+        for maps in ([], ["cos"], ["exp", "sin"], ["log"], ["neg", "rcp", "sqrt"]):
+            if not maps and arity == 1:
+                continue
+            srcs = list(arrs[:arity])
+            for scale in (None, -1.0, 0.375):
+                v = op_by_op(capi, base, srcs, maps)
+                if scale is not None:
+                    v = capi.binary("mul", v, dtype(scale))
+                for op2 in ("mul", "safe_mul"):
+                    want2 = capi.binary(op2, w, v).numpy()
+                    got, got2 = capi.map_chain_product(base, srcs, maps, scale=scale, w=w, op2=op2)
+                    assert bits_equal(got.numpy(), v.numpy()), (base, maps, scale)
+                    assert bits_equal(got2.numpy(), want2), (base, maps, scale, op2)
+                _, only2 = capi.map_chain_product(base, srcs, maps, scale=scale, w=w, op2="safe_mul", first=False)
+                assert bits_equal(only2.numpy(), capi.binary("safe_mul", w, v).numpy()), (base, maps, scale)
+                only, none = capi.map_chain_product(base, srcs, maps, scale=scale)
+                assert none is None and bits_equal(only.numpy(), v.numpy()), (base, maps, scale)
+
+
 @pytest.fixture(scope="module")
 def ek():
     import enoki_amd.hip as m
@@ -186,3 +217,34 @@ def test_explain_and_the_bucket_order_log(ek, capfd):
     assert "evaluated array" in u.explain()
     want = (uniform_pm1(K, 1)[idx.numpy()] * uniform_pm1(n, 3) + uniform_pm1(K, 2)[idx.numpy()]) * np.float32(2.0)
     assert bits_equal(v, want.astype(np.float32))
+
+
+def test_cfg3a_is_a_reduction_and_one_backward_pass(ek, oracle):
+    """BASELINE configs[2] with leaf arrays: y = hsum(sin(fmadd(a, x, b))), backward().  Forward: one chain reduction over a, x, b
+    (u is wanted by the sin and by the cos that differentiating sin records, by nobody else: never written).  Backward: grad_b =
+    cos(u) and grad_a = safe_mul(x, cos(u)) are the two outputs of ONE pass over a, x, b: 32 B/elt for the step.  Gradients are
+    vertical ops: bit for bit the oracle's (class A)."""
+    import enoki_amd.hip_autodiff as ad
+    n = (1 << 20) + 29
+    a, x, b = uniform_pm1(n, 1), uniform_pm1(n, 2), uniform_pm1(n, 3)
+    x[::9] = 0.0
+    xd = ad.Float32(x)
+
+    def step():
+        da, db = ad.Float32(a), ad.Float32(b)
+        ad.set_requires_gradient(da); ad.set_requires_gradient(db)
+        y = ad.hsum(ad.sin(ad.fmadd(da, xd, db)))
+        ad.backward(y)
+        return float(ad.detach(y).numpy()[0]), ad.gradient(da), ad.gradient(db)
+
+    step()
+    (y, ga, gb), ks = kernels(ek, lambda: step())
+    ga, gb = ga.numpy(), gb.numpy()
+    big = {k: v for k, v in ks.items() if k not in ("reduce_stage2", "copy", "memcpy", "fill")}
+    assert big == {"reduce_chain": 1, "map_chain_product": 1}, ks
+    u = oracle.ternary("fmadd", a, x, b)
+    c = oracle.unary("cos", u)
+    assert bits_equal(gb, c)
+    assert bits_equal(ga, oracle.binary("safe_mul", x, c))
+    t = oracle.unary("sin", u).astype(np.float64)
+    assert abs(y - t.sum()) <= 2.0 ** -24 * (n // (1 << 18) + 40) * np.abs(t).sum()
