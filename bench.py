@@ -17,9 +17,11 @@ One "step" = one pass of the hot path over one batch of synthetic input that is 
 configurations of BASELINE.md section 4 are measured in the same run and reported under "also" (same timing
 method), because the three have separate pass lines.
 
-Multi-GPU (one process per GPU, launched by torch.distributed.run): the N-element arrays are index-range
-sharded (STRONG scaling: N total is fixed), the K-element tables are replicated; per step ONE asynchronous
-RCCL all-reduce finishes y and the table gradients (enoki_amd/dist.py) and overlaps the next step's kernels.
+Multi-GPU (one process per GPU; `python bench.py --gpus N` starts its own ranks): the arrays are index-range
+sharded, the K-element tables are replicated; per step ONE asynchronous RCCL all-reduce finishes y and the table
+gradients (enoki_amd/dist.py).  Default --scaling weak: every GPU owns --n (64 Mi) elements of an array of
+N x --n -- the per-GPU size the metric is quoted on, as configs[3] / [4] give theirs per GPU; `value` = all
+elements of all ranks / max-over-ranks time.  --scaling strong: --n elements in total, --n / N per GPU.
 
 The JSON line carries, besides the contract fields, `roofline` for the dominant kernel (live per-launch timing
 with HIP events on the library stream, ek_hip_profile_*) and `cpu_baseline` (the reference build oracle/_ref, or
@@ -96,7 +98,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5", "cfg5_unfused", "cfg5_cpp"] + list(CFG3B_VARIANTS))
-    ap.add_argument("--n", type=int, default=1 << 26, help="TOTAL elements (sharded across the GPUs)")
+    ap.add_argument("--n", type=int, default=1 << 26, help="elements PER GPU (--scaling weak, the default) or in total (--scaling strong)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="cfg2 / cfg3a / cfg3b on N > 1 GPUs.  weak (default): every GPU owns an index range of --n elements of an "
+                         "array of N x --n -- the per-GPU size the metric is quoted on, like the per-GPU sizes of configs[3] and [4]; "
+                         "strong: --n elements in total, --n / N per GPU (DESIGN.md section 7 for what each can give)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -293,7 +299,8 @@ class Bench:
         if args.deterministic:
             ek.hip_set_tuning("deterministic", 1)
         self.dev = torch.device("cuda", self.local_rank)
-        self.N = args.n
+        self.weak = args.scaling == "weak" or args.workload.startswith(("cfg4", "cfg5"))
+        self.N = args.n * self.world if args.scaling == "weak" else args.n       # (cfg4 / cfg5 size their own per-GPU work)
         self.begin, self.end = ekd.shard_range(self.N, self.rank, self.world)
         self.n = self.end - self.begin
         self.sh = ekd.Sharded(ek, self.N, device=self.dev)     # horizontal results of the shards -> ONE all-reduce per step
@@ -925,7 +932,7 @@ def main():
             "value": main_res["value"], "unit": "Gelem/s", "n_gpus": b.world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": main_res["ms_per_step"], "pre_warm_s": pre_warm_s, "value_source": "eager", "eager_ms_per_step": main_res["eager_ms_per_step"],
             "graph_ms_per_step": main_res["graph_ms_per_step"], "higher_is_better": True,
-            "scaling": "weak" if args.workload in ("cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5") else "strong", "vs_baseline": None,
+            "scaling": "weak" if b.weak else "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{args.workload}: {DESCRIPTION[args.workload]}",
                        "elements_total": (N_RAYS_PER_GPU if args.workload.startswith("cfg4") else N_PATHS_PER_GPU) * b.world

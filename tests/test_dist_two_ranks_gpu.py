@@ -35,14 +35,15 @@ def run_bench(workload, n, ranks, port, dump=None, extra=()):
 def test_two_ranks_match_one(workload, tmp_path):
     n = 1 << 22
     one = run_bench(workload, n, 1, 29611, dump=str(tmp_path / "one"))
+    # (--scaling strong: the SAME n elements on two ranks, so that the single process is the yardstick)
     # cfg3b: ONE reduce-scatter for both gradient tables with the loss riding in an extra column; cfg3a: the loss only
     two = run_bench(workload, n, 2, 29612 if workload == "cfg3b" else 29613, dump=str(tmp_path / "two"),
-                    extra=["--reduce-scatter-grads"] if workload == "cfg3b" else [])
+                    extra=["--scaling", "strong"] + (["--reduce-scatter-grads"] if workload == "cfg3b" else []))
     if workload == "cfg3b":
         check_scattered_gradients(n, tmp_path)
         assert "reduce-scatter" in two["config"]["gradient_exchange"]
         # the record form (north_star: "grad accumulation finished by RCCL all-reduce"): ONE all-reduce, every rank holds all K bins
-        full = run_bench(workload, n, 2, 0, dump=str(tmp_path / "full"))
+        full = run_bench(workload, n, 2, 0, dump=str(tmp_path / "full"), extra=["--scaling", "strong"])
         assert "all-reduce" in full["config"]["gradient_exchange"] and full["config"]["collectives_per_step"] == 1
         check_all_reduced_gradients(n, tmp_path)
     assert two["n_gpus"] == 2 and two["config"]["elements_per_gpu"] == n // 2
@@ -51,6 +52,19 @@ def test_two_ranks_match_one(workload, tmp_path):
     truth, bound = truth_y(workload, n)
     assert abs(one["result_y"] - truth) <= bound and abs(two["result_y"] - truth) <= bound, (one["result_y"], two["result_y"], truth, bound)
     assert two["value"] > 0 and two["scaling"] == "strong"
+
+
+def test_default_is_weak_scaling():
+    """`python bench.py --gpus 2` without further options: every rank owns --n elements of an array of 2 x --n (the per-GPU size of
+    the metric), the line says so, and the loss is that of the 2n-element problem"""
+    n = 1 << 21
+    two = run_bench("cfg3b", n, 2, 0)
+    assert two["scaling"] == "weak" and two["config"]["elements_per_gpu"] == n and two["config"]["elements_total"] == 2 * n
+    assert two["config"]["collectives_per_step"] == 1
+    truth, bound = truth_y("cfg3b", 2 * n)
+    assert abs(two["result_y"] - truth) <= bound, (two["result_y"], truth, bound)
+    one = run_bench("cfg3b", n, 1, 0)
+    assert one["scaling"] == "weak" and one["config"]["elements_total"] == n
 
 
 def check_scattered_gradients(n, tmp_path):
@@ -121,7 +135,7 @@ def test_two_gpus_rccl():
     way the driver launches it (torch.distributed.run)"""
     n = 1 << 24
     one = run_bench("cfg3b", n, 1, 29621)
-    two = run_bench("cfg3b", n, 2, 0)
+    two = run_bench("cfg3b", n, 2, 0, extra=["--scaling", "strong"])
     assert "nccl" in two["config"]["backend"], two["config"]["backend"]
     assert two["n_gpus"] == 2 and two["config"]["collectives_per_step"] == 1
     truth, bound = truth_y("cfg3b", n)
