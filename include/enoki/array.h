@@ -210,9 +210,27 @@ using enable_if_array_any_t = enable_if_t<(is_array_v<T1> || is_array_v<T2>) &&
 //  Operator / function routing
 // ---------------------------------------------------------------------------------------------
 
+namespace detail {
+    /// Array types that can let go of their storage handle (HIPArray, DiffArray over it): `release_expiring_()`
+    template <typename T, typename = void> struct has_release_expiring : std::false_type { };
+    template <typename T> struct has_release_expiring<T, std::void_t<decltype(std::declval<T &>().release_expiring_())>> : std::true_type { };
+}
+
+/// The second overload takes an EXPIRING array (a temporary, std::move(x)): once the result exists the argument lets go of its
+/// handle instead of keeping it until the end of the full expression.  A C++ caller writes hsum(sin(exp(fmadd(a, x, b)))) in one
+/// expression; HIPArray leaves such values unevaluated and the consumer of a chain absorbs what NOBODY ELSE holds
+/// (hip.h, detail::HIPBuffer::build_chain) -- a temporary that lives on to the semicolon would count as somebody else and
+/// every link would be written out (python callers never see this: their temporaries die call by call).
 #define ENOKI_HIP_ROUTE_UNARY(name, member)                                                       \
     template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto name(const T &a) {          \
         return a.member##_();                                                                     \
+    }                                                                                             \
+    template <typename T, enable_if_t<!std::is_reference_v<T> && !std::is_const_v<T> && is_array_v<T> && \
+                                      detail::has_release_expiring<T>::value> = 0>                \
+    inline auto name(T &&a) {                                                                     \
+        auto result = a.member##_();                                                              \
+        a.release_expiring_();                                                                    \
+        return result;                                                                            \
     }
 
 #define ENOKI_HIP_ROUTE_BINARY(name, member)                                                      \

@@ -206,6 +206,12 @@ template <typename Type_> struct DiffArray : ArrayTag {
 
     DiffArray(DiffArray &&a) noexcept : m_value(std::move(a.m_value)), m_index(a.m_index) { a.m_index = 0; }
 
+    /// An expiring variable (the temporary argument of a routed unary function, array.h) lets go of its VALUE early; the tape
+    /// index stays until the destructor runs
+    void release_expiring_() {
+        if constexpr (detail::has_release_expiring<Type>::value) m_value.release_expiring_();
+    }
+
     DiffArray(const Type &value) : m_value(value) { }
     DiffArray(Type &&value) : m_value(std::move(value)) { }
 

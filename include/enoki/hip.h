@@ -1794,6 +1794,10 @@ private:
         if (m_buf && --m_buf->ref_count == 0) delete m_buf;
         m_buf = nullptr;
     }
+public:
+    /// An expiring array (the temporary argument of a routed unary function, array.h) lets go of its buffer early
+    void release_expiring_() { release(); }
+private:
 
     void materialize() const {
         if (!m_is_imm) return;

@@ -332,6 +332,29 @@ static void directed() {
         std::vector<float> hv = host(v), ho = host(other);
         for (size_t i = 0; i < N; i += 101) CHECK(hv[i] == hx[i] + hc[i] && ho[i] == hc[i]);
     }
+
+    // --- BASELINE configs[1] as a C++ caller writes it, ONE expression: the temporaries between the calls let go of their handles
+    //     as soon as the next function has its result (array.h, expiring arguments), so the reduction absorbs the whole chain ---
+    {
+        F a = input(N, 1.f), b = input(N, 0.5f), xx = input(N, 0.25f);
+        const long c0 = g_chain_calls, l0 = g_array_launches, u1 = g_unary_calls, f0 = g_fused_calls;
+        float y = hsum(sin(exp(fmadd(a, xx, b)))).coeff(0);
+        CHECK(g_chain_calls == c0 + 1 && g_array_launches == l0 && g_unary_calls == u1 && g_fused_calls == f0);
+        float y2 = hsum(sin(exp(a * xx + b))).coeff(0);                 // the operator spelling: a product and a sum, still one pass
+        CHECK(g_chain_calls == c0 + 2 && g_array_launches == l0 && g_unary_calls == u1);
+        std::vector<float> ha = host(a), hb = host(b), hxx = host(xx);
+        float e1 = 0.f, e2 = 0.f;
+        for (size_t i = 0; i < N; ++i) {
+            e1 += std::sin(std::exp(std::fma(ha[i], hxx[i], hb[i])));
+            volatile float p = ha[i] * hxx[i];
+            e2 += std::sin(std::exp(p + hb[i]));
+        }
+        CHECK(y == e1 && y2 == e2);
+        // a NAMED intermediate is not expiring: it is evaluated once and keeps its value
+        F u = fmadd(a, xx, b);
+        float y3 = hsum(sin(exp(u))).coeff(0);
+        CHECK(y3 == e1 && u.valid() && u.coeff(7) == std::fma(ha[7], hxx[7], hb[7]));
+    }
 }
 
 // ------------------------------------------------------------------------------------------------------------------

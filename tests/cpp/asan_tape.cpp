@@ -103,7 +103,9 @@ static std::vector<std::vector<Real>> run_program(uint32_t seed, bool defer) {
 /// its only holders), and the sweep's grad_b = cos(u), grad_a = safe_mul(x, cos(u)) are the two outputs of ONE pass.
 static void directed_cfg3a() {
     std::vector<std::vector<Real>> res[2];
-    for (int defer = 1; defer >= 0; --defer) {
+    for (int pass = 3; pass >= 0; --pass) {
+        const int defer = pass & 1;
+        const bool one_expression = pass >= 2;
         hip_set_defer(defer != 0);
         const size_t n = 5000;
         const long c0 = g_chain_calls, p0 = g_chain_product_calls, a0 = g_array_launches, u0 = g_unary_calls, s0 = g_sincos_calls;
@@ -114,10 +116,13 @@ static void directed_cfg3a() {
             (void) detach(a).data(); (void) detach(b).data();
             set_requires_gradient(a); set_requires_gradient(b);
             const long a1 = g_array_launches, u1 = g_unary_calls;
-            // (statement by statement, as a python caller's temporaries die: in ONE C++ expression the temporary that holds u lives
-            // until the end of the statement, u counts as wanted by somebody else and is written -- 36 B/elt instead of 32)
+            // statement by statement, as a python caller's temporaries die -- or in ONE C++ expression: the routed unary functions
+            // take an expiring argument's handle away as soon as their result exists (array.h), so the temporary that holds u
+            // does not count as somebody who still wants it
             D y;
-            {
+            if (one_expression) {
+                y = hsum(sin(fmadd(a, D(x), b)));
+            } else {
                 D s;
                 { D u = fmadd(a, D(x), b); s = sin(u); }
                 y = hsum(s);
@@ -136,6 +141,13 @@ static void directed_cfg3a() {
     }
     for (size_t i = 0; i < 3; ++i) CHECK(same(res[0][i], res[1][i]));
     hip_set_defer(true);
+    // a named variable is not expiring: the function leaves it alone; std::move() hands it over
+    D keep = D(linspace<F>(0.f, 1.f, 5000));
+    D s1 = sin(keep);
+    CHECK(detach(keep).valid() && detach(keep).size() == 5000);
+    D s2 = sin(std::move(keep));
+    CHECK(!detach(keep).valid());
+    CHECK(same(host(detach(s1)), host(detach(s2))));
 }
 #endif
 
@@ -150,6 +162,40 @@ int main() {
     if (ek_hip_init(-1) != EK_OK) { fprintf(stderr, "%s\n", ek_hip_last_error()); return 2; }
     ek_hip_set_tuning("deterministic", 1);         // fp scatter_add in element order: comparable bit for bit
     uint64_t launches_with = 0, launches_without = 0;
+    {
+        // ONE C++ expression launches what the statement-by-statement form launches (expiring temporaries let go of their
+        // handles, array.h): BASELINE configs[1] is a chain reduction + its second stage, configs[2] on leaf arrays the same
+        // forward pass and one backward pass with two outputs
+        const size_t n = 1 << 18;
+        F a = linspace<F>(-1.f, 1.f, n), x = sin(linspace<F>(0.f, 40.f, n)), b = cos(linspace<F>(0.f, 9.f, n));
+        (void) a.data(); (void) x.data(); (void) b.data();
+        uint64_t l0 = ek_hip_launch_count();
+        F y = hsum(sin(exp(fmadd(a, x, b))));
+        CHECK(ek_hip_launch_count() - l0 == 2);
+        uint64_t counts[2];
+        std::vector<Real> grads[2];
+        for (int one_expression = 0; one_expression < 2; ++one_expression) {
+            D da = D(a), db = D(b);
+            set_requires_gradient(da); set_requires_gradient(db);
+            l0 = ek_hip_launch_count();
+            D yd;
+            if (one_expression) {
+                yd = hsum(sin(fmadd(da, D(x), db)));
+            } else {
+                D s;
+                { D u = fmadd(da, D(x), db); s = sin(u); }
+                yd = hsum(s);
+            }
+            CHECK(ek_hip_launch_count() - l0 == 2);
+            backward(yd);
+            F ga = gradient(da), gb = gradient(db);
+            (void) ga.data(); (void) gb.data();
+            counts[one_expression] = ek_hip_launch_count() - l0;
+            grads[one_expression] = host(ga);
+        }
+        CHECK(counts[0] == counts[1]);
+        CHECK(same(grads[0], grads[1]));
+    }
 #endif
 #if defined(EK_FUZZ_DEVICE)
     const uint32_t programs = 400;                 // 0.01 s each on the device
