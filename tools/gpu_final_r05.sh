@@ -1,7 +1,8 @@
 # round 5: the suites, smoke, the driver's bench protocol, then ALL the rocprofv3 evidence (tools/profile_r05.sh) on the same box
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/pytest_final.log 2>&1; tail -4 gpurun_out/pytest_final.log | head -3
+# (SKIP_SUITE=1: the suite has just run on this very tree in a call of its own)
+[ "$SKIP_SUITE" = 1 ] || { timeout 1500 python -m pytest tests -m gpu -q --timeout 900 > gpurun_out/pytest_final.log 2>&1; tail -4 gpurun_out/pytest_final.log | head -3; }
 timeout 120 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
 bash tools/profile_r05.sh 2>&1 | tail -22
 # the bench line LAST: it finds the stamped summaries of this very tree under profiles/ only after they are copied there by hand, so
