@@ -21,7 +21,7 @@ def timed(fn, reps=30):
     for _ in range(reps):
         fn()
     prof = json.loads(ek.hip_profile_end())
-    return {k["kernel"]: round(k["avg_ms"] * 1e3, 1) for k in prof if k["launches"] >= reps and k["avg_ms"] > 0.02}
+    return {k["kernel"]: round(k["total_ms"] / k["launches"] * 1e3, 1) for k in prof if k["launches"] >= reps and k["total_ms"] / k["launches"] > 0.02}
 
 
 for rnd in range(2):
