@@ -248,3 +248,34 @@ def test_cfg3a_is_a_reduction_and_one_backward_pass(ek, oracle):
     assert bits_equal(ga, oracle.binary("safe_mul", x, c))
     t = oracle.unary("sin", u).astype(np.float64)
     assert abs(y - t.sum()) <= 2.0 ** -24 * (n // (1 << 18) + 40) * np.abs(t).sum()
+
+
+@pytest.mark.parametrize("fn", ["cos", "exp", "log_abs"])
+def test_other_maps_over_leaf_arrays_are_two_passes_too(ek, oracle, fn):
+    """the same two passes for the other differentiable maps whose derivative is a fusable map of u: cos (weight -sin(u): a scaled
+    sibling), exp (the weight IS the result), log (weight rcp(u)); gradients bit for bit"""
+    import enoki_amd.hip_autodiff as ad
+    n = (1 << 19) + 3
+    a, x, b = uniform_pm1(n, 4), uniform_pm1(n, 5), uniform_pm1(n, 6)
+    if fn == "log_abs":
+        b = (b + np.float32(3.0)).astype(np.float32)              # u in [1, 5]
+    xd = ad.Float32(x)
+    f = {"cos": ad.cos, "exp": ad.exp, "log_abs": ad.log}[fn]
+
+    def step():
+        da, db = ad.Float32(a), ad.Float32(b)
+        ad.set_requires_gradient(da); ad.set_requires_gradient(db)
+        y = ad.hsum(f(ad.fmadd(da, xd, db)))
+        ad.backward(y)
+        return ad.gradient(da), ad.gradient(db)
+
+    step()
+    (ga, gb), ks = kernels(ek, lambda: step())
+    ga, gb = ga.numpy(), gb.numpy()
+    big = {k: v for k, v in ks.items() if k not in ("reduce_stage2", "copy", "memcpy", "fill")}
+    assert big == {"reduce_chain": 1, "map_chain_product": 1}, (fn, ks)
+    u = oracle.ternary("fmadd", a, x, b)
+    w = {"cos": lambda: oracle.unary("neg", oracle.unary("sin", u)), "exp": lambda: oracle.unary("exp", u),
+         "log_abs": lambda: oracle.unary("rcp", u)}[fn]()
+    assert bits_equal(gb, w), fn
+    assert bits_equal(ga, oracle.binary("safe_mul", x, w)), fn
