@@ -106,7 +106,7 @@ if mode in ("check", "all"):
                 print("    the elements in list order differ between two runs")
 
 if mode in ("time", "all"):
-    n, K = 1 << 26, 1 << 20
+    n, K = int(os.environ.get("PROBE_N", 1 << 26)), 1 << 20
     idx_h = rng.integers(0, K, n).astype(np.uint32)
     x_h = rng.uniform(-1, 1, n).astype(np.float32)
     print(f"# timing: {n >> 20} Mi elements, K = {K >> 20} Mi, 128 buckets of 8 Ki; 14 B/elt")
@@ -117,7 +117,7 @@ if mode in ("time", "all"):
             ms = statistics.median(hiprt.time_region(st, f, iters=10, warmup=2) for _ in range(5))
             print(f"paged partition nts={nts} directory={d}: {ms:7.4f} ms  {n * 14 / ms / 1e9:6.3f} TB/s")
     ok, nf, npart, npieces = r.verify(idx_h, x_h)
-    print("verify at 64 Mi:", "ok" if ok else "MISMATCH", nf, npart, npieces)
+    print(f"verify at {n >> 20} Mi:", "ok" if ok else "MISMATCH", nf, npart, npieces)
     if os.environ.get("EK_PG_TIMING"):                 # probe library built with -DEK_PG_TIMING
         r.launch(0, 0); capi.sync()
         draw = r.dbg.numpy()
