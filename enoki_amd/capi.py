@@ -43,7 +43,7 @@ EXPORTS = [
     "ek_hip_compare", "ek_hip_select", "ek_hip_cast", "ek_hip_fill", "ek_hip_arange", "ek_hip_linspace",
     "ek_hip_reverse", "ek_hip_gather", "ek_hip_scatter", "ek_hip_scatter_add", "ek_hip_reduce",
     "ek_hip_hsum_safe_mul", "ek_hip_mask_reduce", "ek_hip_psum", "ek_hip_map_gathered", "ek_hip_note_launch", "ek_hip_graph_begin", "ek_hip_graph_end", "ek_hip_graph_launch",
-    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_reduce_chain", "ek_hip_map_chain", "ek_hip_map_chain_product", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
+    "ek_hip_graph_launch_count", "ek_hip_graph_destroy", "ek_hip_sort_pairs", "ek_hip_reduce_map", "ek_hip_reduce_chain", "ek_hip_map_chain", "ek_hip_map_chain_product", "ek_hip_partition_class_state", "ek_hip_scatter_add_multi_map", "ek_hip_binding_slot",
     "ek_hip_dist_unique_id", "ek_hip_dist_init", "ek_hip_dist_world", "ek_hip_dist_shard_range", "ek_hip_dist_all_reduce",
     "ek_hip_dist_reduce_scatter", "ek_hip_dist_all_gather", "ek_hip_dist_finalize", "ek_hip_dist_rccl_path",
     "ek_hip_bucketed_applicable", "ek_hip_bucketed_pair_create", "ek_hip_bucketed_pair_create_hinted", "ek_hip_bucketed_pair_create_masked", "ek_hip_bucketed_reduce", "ek_hip_bucketed_scatter_add", "ek_hip_bucketed_scatter_add_scaled", "ek_hip_bucketed_early_pair",

@@ -1090,7 +1090,63 @@ struct MetaRing {
 };
 static MetaRing &meta_ring() { static MetaRing *r = new MetaRing(); return *r; }
 
+// The class weights of the page partition (ek_paged.h: kPgClasses) and the workgroups' loop stamps: one small device block per
+// context, weights initialised to 1.  ENOKI_HIP_XCD_BALANCE=0 (tuning "xcd_balance") deals equal chunks as before.
+struct ClassState {
+    void *block = nullptr;             // uint32: weights[kPgClasses] | "the weights are being dealt" | - | stamps[1024] from word kPgClassStamps
+    uint32_t *weights() { return (uint32_t *) block; }
+    uint32_t *stamps() { return (uint32_t *) block + kPgClassStamps; }
+};
+static ClassState &class_state() { static ClassState *s = new ClassState(); return *s; }
+static uint32_t *class_weights_or_null() {
+    ClassState &s = class_state();
+    if (!s.block) {
+        if (refuse_while_capturing_quiet() != EK_OK) return nullptr;            // (a copy from the host is not part of a step graph)
+        if (ek_hip_malloc((kPgClassStamps + 1024) * sizeof(uint32_t), &s.block) != EK_OK) { s.block = nullptr; return nullptr; }
+        static const uint32_t ones[kPgClasses] = { kPgWeightOne, kPgWeightOne, kPgWeightOne, kPgWeightOne,
+                                                   kPgWeightOne, kPgWeightOne, kPgWeightOne, kPgWeightOne };
+        if (hipMemsetAsync(s.block, 0, (kPgClassStamps + 1024) * sizeof(uint32_t), ctx().stream) != hipSuccess ||
+            hipMemcpyAsync(s.block, ones, sizeof(ones), hipMemcpyHostToDevice, ctx().stream) != hipSuccess) {
+            ek_hip_free(s.block);
+            s.block = nullptr;
+            return nullptr;
+        }
+    }
+    return s.weights();
+}
+
+} // namespace ek
+
+/* diagnostics: the weights of the page partition's workgroup classes and the mean loop duration per class of the last stamped
+   launch (100 MHz ticks); synchronises.  weights8 / ticks8: 8 entries each, zeros when no launch has used the weights yet. */
+extern "C" EK_API int ek_hip_partition_class_state(uint32_t *weights8, uint32_t *ticks8, uint32_t *dealt) {
+    using namespace ek;
+    if (int rc = ensure_init()) return rc;
+    if (!weights8 || !ticks8) return fail(EK_ERR_INVALID, "ek_hip_partition_class_state(): null pointer");
+    for (int k = 0; k < kPgClasses; ++k) weights8[k] = ticks8[k] = 0;
+    if (dealt) *dealt = 0;
+    ClassState &s = class_state();
+    if (!s.block) return EK_OK;
+    if (int busy = refuse_while_capturing("ek_hip_partition_class_state()")) return busy;
+    std::vector<uint32_t> host(kPgClassStamps + 1024);
+    EK_HIP_CHECK(hipMemcpyAsync(host.data(), s.block, host.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx().stream));
+    EK_HIP_CHECK(hipStreamSynchronize(ctx().stream));
+    const unsigned W = (unsigned) ctx().num_cu < 1024u ? (unsigned) ctx().num_cu : 1024u;
+    for (int k = 0; k < kPgClasses; ++k) {
+        weights8[k] = host[k];
+        uint64_t sum = 0, cnt = 0;
+        for (unsigned w = k; w < W; w += kPgClasses) { sum += host[kPgClassStamps + w]; ++cnt; }
+        ticks8[k] = cnt ? (uint32_t) (sum / cnt) : 0u;
+    }
+    if (dealt) *dealt = host[kPgClasses];
+    return EK_OK;
+}
+
+namespace ek {
+
 void release_meta_ring() {
+    ClassState &cs = class_state();
+    if (cs.block) { ek_hip_free(cs.block); cs.block = nullptr; }
     MetaRing &r = meta_ring();
     for (int k = 0; k < MetaRing::kBlocks; ++k) {
         if (r.block[k] && !r.busy[k]) { ek_hip_free(r.block[k]); r.block[k] = nullptr; r.clean[k] = false; }
@@ -1239,7 +1295,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->shift = shift;
     const size_t n = b->n;
     const int n_buckets = b->n_buckets = (int) ((b->table_size + ((size_t) 1 << shift) - 1) >> shift);
-    const PagedPlan p = paged_plan(n, n_buckets, c.num_cu);
+    const PagedPlan p = paged_plan(n, n_buckets, c.num_cu, c.tuning.xcd_balance != 0);
     if (p.W > 1024) return fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create(): %u workgroups", p.W);
     b->page_shift = p.page_shift;
     b->positions = p.page_slots << p.page_shift;
@@ -1294,6 +1350,17 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.gtotal = gtotal;
     out.active = gtotal + 2 * kMaxBuckets + kPgMetaAccum;
     out.lo = b->win_lo; out.span = b->win_span ? b->win_span : (uint32_t) std::min<size_t>(b->table_size, 0xFFFFFFFFu);
+    // tiles dealt to the classes w % 8 by the weights the previous launches fed back (ek_paged.h); a launch of at least 32 tiles per
+    // workgroup stamps its loops and lets the directory launch update the weights
+    // (ENOKI_HIP_XCD_BALANCE=2: the slots are provisioned and the loops stamped, but the chunks stay equal -- what
+    // ek_hip_partition_class_state() then reports is the imbalance itself)
+    uint32_t *class_block = p.balanced ? class_weights_or_null() : nullptr;
+    out.class_w = c.tuning.xcd_balance == 1 ? class_block : nullptr;
+    const bool stamped = class_block && n >= (size_t) 32 * kPgTile * p.W && p.W <= 1024;
+    const bool feedback = stamped && out.class_w;
+    out.class_stamp = stamped ? class_state().stamps() : nullptr;
+    static const uint32_t band = [] { const char *e = getenv("ENOKI_HIP_XCD_BAND"); return e ? (uint32_t) atoi(e) : kPgWeightBand; }();
+    out.class_band = band;
     if (!filled) {
         EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
         note_launch("bucket_meta_clear", 3 * kMaxBuckets, 3 * kMaxBuckets * sizeof(uint32_t));   // (its own mark: a profiled run must not bill the fill to the partition)
@@ -1313,7 +1380,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, b->glist_full, b->glist_part, b->bucket_base,
                        b->base_part, b->piece_prefix, gtotal, (const uint32_t *) out.cnt_full,
                        (const uint32_t *) out.loff, (const uint32_t *) out.part, (const uint32_t *) out.wlist, p.W, p.slots, n_buckets,
-                       target_pieces);
+                       target_pieces, feedback ? class_state().weights() : (uint32_t *) nullptr, (const uint32_t *) out.class_stamp, band);
     EK_LAUNCH_CHECK("bucket_directory", p.page_slots, 2 * p.page_slots * sizeof(uint32_t));
     return EK_OK;
 }

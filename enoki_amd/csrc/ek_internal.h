@@ -32,6 +32,8 @@ struct Tuning {
     int gather_records = 1;       // struct gathers through staged {x, y, ..} records: 1 by size, 2 always, 0 never
     int bucket_ordered = 1;       // gather -> fma -> {reduction, scatter_add} chains in bucket order (bucketed.hip); 0: element order only
     int early_adjoint = 1;        // EK_BUCKETED_HINT_ADJOINT is honoured (half-size buckets, adjoint sums formed in the forward pass)
+    int xcd_balance = 0;          // 1: the page partition deals its tiles to the workgroup classes w % 8 by fed-back weights (ek_paged.h);
+                                  // 2: equal chunks, but the classes' loop durations are recorded (ek_hip_partition_class_state)
 };
 
 struct Context {

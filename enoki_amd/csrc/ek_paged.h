@@ -34,6 +34,14 @@ constexpr int kPgThreads = 1024;
 constexpr int kPgTile = 4 * kPgThreads;
 constexpr int kPgLdsElems = 16384;             // elements staged per workgroup, all buckets together (128 KiB of 8-byte records)
 constexpr uint32_t kNoPage = 0xFFFFFFFFu;
+// Workgroup w is dispatched to XCD w % 8, and on every box seen so far one XCD runs the same streaming work ~9 % slower than the
+// other seven (profiles/probe_paged_phases_r05.txt): with equal chunks the kernel ends when that XCD ends.  The eight CLASSES
+// w % 8 therefore get shares of the tiles in proportion to WEIGHTS (Q16, 65536 = 1) that live on the device and are fed back by
+// the directory launch from the loop durations the workgroups stamp -- no host round trip, no assumption about which XCD (or
+// whether any) is the slow one: equal durations leave the weights where they are.  OPT-IN (tuning "xcd_balance", default 0): on the
+// boxes it could be measured on it changed nothing (profiles/probe_xcd_balance_r05.txt), see DESIGN.md section 9 item 2.
+constexpr int kPgClasses = 8, kPgClassStamps = 16;      // class block: weights[8] | dealt flag | - | stamps[W] from word 16
+constexpr uint32_t kPgWeightOne = 65536u, kPgWeightMin = 57672u /* 0.88 */, kPgWeightMax = 73400u /* 1.12 */, kPgWeightBand = 2621u /* 0.04 */;
 
 template <typename T> struct PagedOut {
     uint16_t *lp;          // pages of bucket-local indices
@@ -46,6 +54,9 @@ template <typename T> struct PagedOut {
     uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
     uint32_t *active;      // [0] number of elements kept, [1] != 0: a lane whose mask bit is clear carries a non-finite x (zeroed by the host)
     uint32_t lo, span;     // only indices in [lo, lo + span) are kept, rebased to lo: the table (lo = 0, span = its size) or a slice of it
+    const uint32_t *class_w;   // [kPgClasses] weights of the classes w % 8 (nullptr: equal chunks, `chunk` elements each)
+    uint32_t *class_stamp;     // [W] loop duration of every workgroup in 100 MHz ticks (nullptr: not recorded)
+    uint32_t class_band;       // weights that all stay within this distance of 1 (Q16) count as equal
 #ifdef EK_PG_TIMING
     unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
 #endif
@@ -79,7 +90,28 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
 #ifdef EK_PG_TIMING
     const unsigned long long t_start = wall_clock64();
 #endif
-    const size_t begin = (size_t) w * chunk < n ? (size_t) w * chunk : n, end = begin + chunk < n ? begin + chunk : n;
+    size_t begin = (size_t) w * chunk < n ? (size_t) w * chunk : n, end = begin + chunk < n ? begin + chunk : n;
+    if (out.class_w) {
+        // the tiles of the whole input, dealt to the classes by weight and equally to a class's workgroups (W is a multiple of 8)
+        const uint64_t NT = (n + kPgTile - 1) / kPgTile, per = W / kPgClasses, cls = w % kPgClasses, r = w / kPgClasses;
+        uint64_t before = 0, mine = 0, all = 0;
+#pragma unroll
+        for (int k = 0; k < kPgClasses; ++k) {
+            const uint64_t wk = out.class_w[k];
+            all += wk;
+            before += (uint64_t) k < cls ? wk : 0u;
+            mine = (uint64_t) k == cls ? wk : mine;
+        }
+        // (class_w[kPgClasses]: the weights are being dealt -- set by the feedback once a class is more than the band away from 1
+        // and cleared when all are back within half of it; the launch-to-launch scatter of a balanced box stays below and the
+        // chunks stay equal, as without weights)
+        if (out.class_w[kPgClasses]) {
+            const uint64_t t0 = NT * before / all, t1 = NT * (before + mine) / all, tx = t1 - t0;
+            const uint64_t b0 = (t0 + tx * r / per) * kPgTile, b1 = (t0 + tx * (r + 1) / per) * kPgTile;
+            begin = b0 < n ? (size_t) b0 : n;
+            end = b1 < n ? (size_t) b1 : n;
+        }
+    }
     const size_t wbase = (size_t) w * slots;                     // first page slot of this workgroup
     const uint32_t lowmask = (1u << shift) - 1u, cap_pages = cap >> PS, cap_shift = 31u - (uint32_t) __builtin_clz(cap);
     const uint32_t spare = (uint32_t) n_buckets << cap_shift;         // one record behind the buffers
@@ -277,6 +309,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
 #ifdef EK_PG_TIMING
     const unsigned long long t_loop = wall_clock64();
 #endif
+    const unsigned long long stamp0 = out.class_stamp ? wall_clock64() : 0ull;
     // whole tiles of 16-byte aligned operands: two tiles of loads in flight ahead of the one that is being placed.  The two
     // register sets alternate (a rotation by moves would have to wait for the loads it moves).
     // (Tiles handed out round robin -- at every moment the W workgroups reading W consecutive 16-KiB stretches instead of W
@@ -308,6 +341,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         load_ragged(base, t);
         process(t);
     }
+    if (out.class_stamp && threadIdx.x == 0) out.class_stamp[w] = (uint32_t) (wall_clock64() - stamp0);
 
 #ifdef EK_PG_TIMING
     if ((threadIdx.x & 63) == 0 && threadIdx.x < 128)
@@ -437,7 +471,9 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
                                                                uint32_t *__restrict__ gtotal, const uint32_t *__restrict__ cnt_full,
                                                                const uint32_t *__restrict__ loff, const uint32_t *__restrict__ part,
                                                                const uint32_t *__restrict__ wlist, uint32_t W, uint32_t slots,
-                                                               int n_buckets, uint32_t target_pieces) {
+                                                               int n_buckets, uint32_t target_pieces,
+                                                               uint32_t *__restrict__ class_w, const uint32_t *__restrict__ class_stamp,
+                                                               uint32_t class_band) {
     __shared__ uint32_t wave_tot[4];
     __shared__ uint32_t row[1025], lrow[1024];
     __shared__ uint32_t s_fb, s_pb, s_f;
@@ -509,6 +545,34 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
     // the accumulators and the page totals are cleared by the last workgroup of the first reducing launch (bucket_finish), after
     // which the block can serve the next object without a fill (csrc/bucketed.hip: MetaRing)
     if (b == 0 && slice == 0 && t < 2) gtotal[2 * kMaxBuckets + kPgMetaResult + t] = gtotal[2 * kMaxBuckets + kPgMetaAccum + t];
+    // Feedback for the next partition launch (class_w != nullptr only after a launch long enough to say something): a class's speed
+    // is its share of the tiles over the mean loop duration of its workgroups; the new weight moves an eighth of the way towards
+    // the share that would have made the durations equal, within [0.88, 1.12].  Equal durations are a fixed point; the class means
+    // of a balanced box scatter by ~2 % from launch to launch, which at this gain leaves the weights within ~0.5 % of 1 (simulated:
+    // +0.6 % on the kernel where there is nothing to balance, 1.095 -> 1.02 of the balanced time where one class is 9.5 % slow).
+    if (class_w && b == 0 && slice == 1 && t < 64) {
+        float dur = 0.f, cnt = 0.f;                                     // lane t: class t % 8, every eighth of its workgroups
+        for (uint32_t w = (uint32_t) t; w < W; w += 64) { dur += (float) class_stamp[w]; cnt += 1.f; }
+#pragma unroll
+        for (int d = kPgClasses; d < 64; d <<= 1) { dur += __shfl_xor(dur, d, 64); cnt += __shfl_xor(cnt, d, 64); }
+        const float old_w = t < kPgClasses ? (float) class_w[t] : (float) kPgWeightOne;
+        const bool was_dealt = class_w[kPgClasses] != 0u;
+        const float dealt = was_dealt ? old_w : (float) kPgWeightOne;                           // the shares the launch really used
+        const float speed = (t < kPgClasses && dur > 0.f) ? dealt * cnt / dur : 0.f;
+        float sum = speed, least = t < kPgClasses ? speed : 1.f;
+#pragma unroll
+        for (int d = 1; d < kPgClasses; d <<= 1) { sum += __shfl_xor(sum, d, 64); least = fminf(least, __shfl_xor(least, d, 64)); }
+        if (t < kPgClasses && least > 0.f) {
+            const float target = speed / (sum / kPgClasses) * (float) kPgWeightOne;
+            const float next = fminf(fmaxf(0.875f * old_w + 0.125f * target, (float) kPgWeightMin), (float) kPgWeightMax);
+            class_w[t] = (uint32_t) (next + 0.5f);
+            // hysteresis: dealt from the band on, equal again below half of it
+            float far = fabsf(next - (float) kPgWeightOne);
+#pragma unroll
+            for (int d = 1; d < kPgClasses; d <<= 1) far = fmaxf(far, __shfl_xor(far, d, 64));
+            if (t == 0) class_w[kPgClasses] = (far > (float) class_band || (was_dealt && far > 0.5f * (float) class_band)) ? 1u : 0u;
+        }
+    }
 }
 
 
@@ -519,10 +583,11 @@ struct PagedPlan {
     uint32_t cap = 0, W = 0, slots = 0;
     size_t chunk = 0, page_slots = 0;          // page_slots: W * slots (positions = page_slots << page_shift)
     size_t lds = 0;
+    bool balanced = false;                     // the launch may deal its tiles by class weights (slots are provisioned for it)
 };
 
 /// geometry of the paged partition of n elements into n_buckets buckets (4-byte values)
-static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu) {
+static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu, bool weighted = false) {
     PagedPlan p;
     p.page_shift = n_buckets > 128 ? 5 : 6;
     int nb2 = 2;
@@ -533,6 +598,14 @@ static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu) {
     p.chunk = ((tiles + p.W - 1) / p.W) * kPgTile;
     p.W = (uint32_t) std::max<size_t>(1, (n + p.chunk - 1) / p.chunk);
     p.slots = (uint32_t) ((p.chunk >> p.page_shift) + (size_t) n_buckets);
+    // weighted classes (k_page_partition): a workgroup of the class with the largest possible share takes up to
+    // max / (7 min + max) of the tiles instead of 1 / 8 (+ a tile of rounding)
+    p.balanced = weighted && p.W >= 64 && p.W % kPgClasses == 0 && tiles >= (size_t) 4 * p.W;
+    if (p.balanced) {
+        const double share = (double) kPgWeightMax / (7.0 * kPgWeightMin + kPgWeightMax);
+        const size_t most = (size_t) ((double) tiles * share / (p.W / kPgClasses)) + 2;
+        p.slots = (uint32_t) (((most * kPgTile) >> p.page_shift) + (size_t) n_buckets);
+    }
     p.page_slots = (size_t) p.W * p.slots;
     p.lds = ((size_t) n_buckets * p.cap + 2) * 8;
     return p;

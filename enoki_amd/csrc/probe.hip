@@ -535,6 +535,7 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     out.gtotal = meta;
     out.active = meta + 2 * kMaxBuckets;
     out.lo = 0; out.span = (uint32_t) std::min<size_t>(table_size, 0xFFFFFFFFu);
+    out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = 0;             // (equal chunks: the probe measures the kernel, not the balancing)
 #ifdef EK_PG_TIMING
     out.dbg = dbg;
 #else
@@ -567,7 +568,8 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     if (directory) {
         hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, glist_full, glist_part, base_full, base_part,
                            piece_prefix, out.gtotal, (const uint32_t *) out.cnt_full, (const uint32_t *) out.loff,
-                           (const uint32_t *) out.part, (const uint32_t *) wlist, p.W, p.slots, n_buckets, target_pieces);
+                           (const uint32_t *) out.part, (const uint32_t *) wlist, p.W, p.slots, n_buckets, target_pieces,
+                           (uint32_t *) nullptr, (const uint32_t *) nullptr, 0u);
         EK_LAUNCH_CHECK("probe_page_directory", (size_t) n_buckets, 0);
     }
     return EK_OK;

@@ -231,6 +231,7 @@ int ek_hip_init(int device) {
     if (const char *dv = getenv("ENOKI_HIP_DETERMINISTIC")) c.tuning.deterministic = atoi(dv) != 0;
     if (const char *bo = getenv("ENOKI_HIP_BUCKET_ORDERED")) c.tuning.bucket_ordered = atoi(bo) != 0;
     if (const char *ea = getenv("ENOKI_HIP_EARLY_ADJOINT")) c.tuning.early_adjoint = atoi(ea) != 0;
+    if (const char *xb = getenv("ENOKI_HIP_XCD_BALANCE")) c.tuning.xcd_balance = atoi(xb) == 2 ? 2 : atoi(xb) != 0;
     if (const char *gr = getenv("ENOKI_HIP_GATHER_RECORDS")) { int v = atoi(gr); if (v >= 0 && v <= 2) c.tuning.gather_records = v; }
     if (c.log_level >= 1)
         fprintf(stderr, "enoki-hip: device %d (%s, %d CUs, %.1f GiB)\n", device, prop.name, c.num_cu,
@@ -617,6 +618,7 @@ int ek_hip_set_tuning(const char *key, int value) {
     else if (!strcmp(key, "gather_records") && value >= 0 && value <= 2) t.gather_records = value;
     else if (!strcmp(key, "bucket_ordered") && (value == 0 || value == 1)) t.bucket_ordered = value;
     else if (!strcmp(key, "early_adjoint") && (value == 0 || value == 1)) t.early_adjoint = value;
+    else if (!strcmp(key, "xcd_balance") && value >= 0 && value <= 2) t.xcd_balance = value;
     else return fail(EK_ERR_INVALID, "ek_hip_set_tuning(): unknown key/value %s=%d", key, value);
     return EK_OK;
 }

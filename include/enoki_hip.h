@@ -394,6 +394,14 @@ EK_API int ek_hip_scatter_add_multi_map(int type, int index_type, int count, voi
  *  Horizontal ops.  Results of ek_hip_reduce* stay on the device (`out` = 1 element, async);
  *  mask reductions return to the host and therefore synchronize (cuda.h:761-794).
  * ------------------------------------------------------------------------------------------- */
+/* Diagnostics of the bucket partition's load balancing.  The single-pass page partition runs one workgroup per compute unit and
+ * deals the input to the eight workgroup CLASSES w % 8 (the XCD a workgroup is dispatched to) in proportion to weights that the
+ * library feeds back on the device from the classes' loop durations (OPT-IN: tuning "xcd_balance" / ENOKI_HIP_XCD_BALANCE = 1; 2 records
+ * the durations of equal chunks without dealing by them; 0, the default, does neither and this call reports zeros; Q16: 65536 =
+ * an equal share).  weights8 / ticks8 receive the current weights and the mean loop duration per class of the last stamped launch
+ * in 100 MHz ticks (zeros before the first), *dealt (may be NULL) whether the weights are currently applied -- they are once a class
+ * is more than 4 % away from an equal share, until all are back within 2 %; the call synchronises. */
+EK_API int ek_hip_partition_class_state(uint32_t *weights8, uint32_t *ticks8, uint32_t *dealt);
 EK_API int ek_hip_reduce(int op, int type, void *out, const void *in, size_t n);
 /* A CHAIN: base(src[0 .. arity)) under n_maps unary ops (map_ops[0] first), evaluated in ONE pass over the operands -- the fused
  * kernel that the reference's JIT assembles for the vertical ops between two evaluation points (src/cuda/jit.cu:1066-1217,

@@ -60,6 +60,27 @@ def test_cfg3b_headline_default_mode(ek, cfg3b_case):
         assert np.all(np.abs(arr - ref) <= 2 * t[g + "_bound"]), g
 
 
+def test_cfg3b_headline_with_class_weights(ek, cfg3b_case):
+    """the opt-in load balancing of the page partition (tuning "xcd_balance" 1: tiles dealt to the workgroup classes w % 8 by weights
+    fed back on the device) changes which workgroup partitions which elements and nothing else: the same bounds hold while the
+    weights move, and ek_hip_partition_class_state reports weights inside [0.88, 1.12] and a loop duration per class"""
+    import enoki_amd.hip as raw
+    lib = ctypes.CDLL(os.path.join(os.path.dirname(raw.__file__), "libenoki-hip.so"))
+    t = cfg3b_case["truth"]
+    ek.hip_set_tuning("xcd_balance", 1)
+    try:
+        for _ in range(12):
+            y, gA, gB = _run_cfg3b(ek, cfg3b_case)
+        w, ticks, dealt = (ctypes.c_uint32 * 8)(), (ctypes.c_uint32 * 8)(), ctypes.c_uint32()
+        assert lib.ek_hip_partition_class_state(w, ticks, ctypes.byref(dealt)) == 0
+    finally:
+        ek.hip_set_tuning("xcd_balance", 0)
+    assert all(57672 <= v <= 73400 for v in w) and all(v > 0 for v in ticks), (list(w), list(ticks))
+    assert abs(y - t["y"]) <= t["y_bound"] and abs(y - t["y"]) <= t["y_stat_bound"], (y, t["y"])
+    for g, arr in (("gA", gA), ("gB", gB)):
+        assert np.all(np.abs(arr - t[g]) <= t[g + "_bound"]), g
+
+
 def test_cfg3b_headline_deterministic_mode_is_bit_exact(ek, cfg3b_case):
     """mode 1 reproduces the CPU element order: gradients BIT-IDENTICAL to the reference at 64 Mi / K = 1 Mi"""
     ek.hip_set_tuning("deterministic", 1)
