@@ -1367,8 +1367,19 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     }
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
-        if (int rc = allow_big_lds(kernel, p.lds)) return rc;
-        hipLaunchKernelGGL(kernel, dim3(p.W), dim3(kPgThreads), p.lds, c.stream, out, index, mask, x, n, p.chunk, n_buckets, shift,
+        // the workgroup's own page directory in the LDS behind the records when it fits next to them and the kernel's static
+        // arrays (160 KiB per workgroup on gfx950: inputs up to ~64 Mi elements); ENOKI_HIP_WDIR_LDS=0: through global memory
+        static const bool want = [] { const char *e = getenv("ENOKI_HIP_WDIR_LDS"); return !e || atoi(e) != 0; }();
+        size_t lds = p.lds;
+        out.wdir_lds = 0;
+        hipFuncAttributes attr;
+        if (want && hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess &&
+            attr.sharedSizeBytes + p.lds + (size_t) p.slots * sizeof(uint32_t) <= (size_t) 160 * 1024) {
+            lds += (size_t) p.slots * sizeof(uint32_t);
+            out.wdir_lds = 1;
+        }
+        if (int rc = allow_big_lds(kernel, lds)) return rc;
+        hipLaunchKernelGGL(kernel, dim3(p.W), dim3(kPgThreads), lds, c.stream, out, index, mask, x, n, p.chunk, n_buckets, shift,
                            p.cap, p.slots, vec_ok);
         return EK_OK;
     };

@@ -57,6 +57,7 @@ template <typename T> struct PagedOut {
     const uint32_t *class_w;   // [kPgClasses] weights of the classes w % 8 (nullptr: equal chunks, `chunk` elements each)
     uint32_t *class_stamp;     // [W] loop duration of every workgroup in 100 MHz ticks (nullptr: not recorded)
     uint32_t class_band;       // weights that all stay within this distance of 1 (Q16) count as equal
+    uint32_t wdir_lds;         // != 0: the workgroup's wdir entries live in the LDS behind the records (>= slots words) instead of out.wdir
 #ifdef EK_PG_TIMING
     unsigned long long *dbg;   // [W][2][8] cycles per phase of waves 0 and 1 (measurement builds only)
 #endif
@@ -115,6 +116,11 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     const size_t wbase = (size_t) w * slots;                     // first page slot of this workgroup
     const uint32_t lowmask = (1u << shift) - 1u, cap_pages = cap >> PS, cap_shift = 31u - (uint32_t) __builtin_clz(cap);
     const uint32_t spare = (uint32_t) n_buckets << cap_shift;         // one record behind the buffers
+    // The workgroup's own page directory (slot -> sequence number << 8 | bucket) is written while pages are announced and read
+    // once, by the lists phase at the end.  Through global memory that read has to wait for ALL of the workgroup's stores (the
+    // counter that orders them is in-order: 8-12 us at the end of every workgroup, profiles/probe_paged_phases_r05.txt); when
+    // the entries fit the LDS behind the records (inputs up to ~64 Mi elements) they stay there and nobody waits.
+    uint32_t *wd = reinterpret_cast<uint32_t *>(rec + spare + 2);
     for (int b = threadIdx.x; b < kMaxBuckets; b += kPgThreads) { cnt[b] = 0; npg[b] = 0; }
     if (threadIdx.x == 0) { s_pages = 0; s_jobs = 0; s_over = 0; }
     __syncthreads();
@@ -231,7 +237,8 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
                 if ((done >> k) & 1u) {
                     const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
                     jobs[ps - ps0] = b | ((pos >> PS) << 8);
-                    out.wdir[wbase + ps] = ((seq[k] + (fill >> PS)) << 8) | b;
+                    const uint32_t entry = ((seq[k] + (fill >> PS)) << 8) | b;
+                    if (out.wdir_lds) wd[ps] = entry; else out.wdir[wbase + ps] = entry;
                     ++ps;
                 }
             }
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
                     const uint32_t nd = (f >> PS) - cap_pages, p = nd ? atomicAdd(&s_pages, nd) : ps0, seq0 = npg[b] + cap_pages;
                     for (uint32_t q = 0; q < nd; ++q) {
                         jobs[p - ps0 + q] = kNoPage;
-                        out.wdir[wbase + p + q] = ((seq0 + q) << 8) | b;
+                        if (out.wdir_lds) wd[p + q] = ((seq0 + q) << 8) | b; else out.wdir[wbase + p + q] = ((seq0 + q) << 8) | b;
                     }
                     dbase[b] = p - ps0;
                     dtail[b] = (f >> PS) << PS;
@@ -406,8 +413,8 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 0] = wall_clock64();
 #endif
-    // wdir was written by wave 0 of this workgroup: its stores have to be done, and it is read back past the L1
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // wdir in global memory was written by this workgroup: its stores have to be done, and it is read back past the L1
+    if (!out.wdir_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 1] = wall_clock64();
@@ -422,7 +429,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const uint32_t s = s0 + u * kPgThreads;
-            d[u] = s < nfull ? __hip_atomic_load(out.wdir + wbase + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+            d[u] = s >= nfull ? 0u : out.wdir_lds ? wd[s] : __hip_atomic_load(out.wdir + wbase + s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {

@@ -535,7 +535,7 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     out.gtotal = meta;
     out.active = meta + 2 * kMaxBuckets;
     out.lo = 0; out.span = (uint32_t) std::min<size_t>(table_size, 0xFFFFFFFFu);
-    out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = 0;             // (equal chunks: the probe measures the kernel, not the balancing)
+    out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = 0; out.wdir_lds = 0;             // (equal chunks: the probe measures the kernel, not the balancing)
 #ifdef EK_PG_TIMING
     out.dbg = dbg;
 #else
