@@ -31,7 +31,7 @@ DEVICE = [f"--offload-arch={ARCH}"]
 
 LIB_SOURCES = ["runtime.cpp", "dist.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "gathered.hip", "scan.hip", "bucketed.hip"]
 # measurement scaffolding (tools/probe_*.py): its own library on top of the public C ABI, never loaded by the product
-PROBE_SOURCES = ["probe.hip", "probe_rt.cpp"]
+PROBE_SOURCES = ["probe.hip", "probe_lds64.hip", "probe_rt.cpp"]
 
 
 def kernels_sha16():
