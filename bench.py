@@ -19,9 +19,10 @@ method), because the three have separate pass lines.
 
 Multi-GPU (one process per GPU; `python bench.py --gpus N` starts its own ranks): the arrays are index-range
 sharded, the K-element tables are replicated; per step ONE asynchronous RCCL all-reduce finishes y and the table
-gradients (enoki_amd/dist.py).  Default --scaling weak: every GPU owns --n (64 Mi) elements of an array of
-N x --n -- the per-GPU size the metric is quoted on, as configs[3] / [4] give theirs per GPU; `value` = all
-elements of all ranks / max-over-ranks time.  --scaling strong: --n elements in total, --n / N per GPU.
+gradients (enoki_amd/dist.py).  Default --scaling strong -- what BASELINE.json's metric, `north_star` and BASELINE.md
+section 4 state: --n (64 Mi) elements IN TOTAL, --n / N per GPU; `value` = --n / max-over-ranks time.  The same run then
+also measures the weak form (every GPU owns --n elements of an array of N x --n) and carries it as the labelled
+sub-record `weak` of the same line (--no-weak skips it; --scaling weak makes it the `value` as in round 5).
 
 The JSON line carries, besides the contract fields, `roofline` for the dominant kernel (live per-launch timing
 with HIP events on the library stream, ek_hip_profile_*) and `cpu_baseline` (the reference build oracle/_ref, or
@@ -98,11 +99,12 @@ def parse():
     ap.add_argument("--steps", type=int, default=3000)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", default="cfg3b", choices=["cfg3b", "cfg3a", "cfg2", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg4_bucketed", "cfg5", "cfg5_unfused", "cfg5_cpp"] + list(CFG3B_VARIANTS))
-    ap.add_argument("--n", type=int, default=1 << 26, help="elements PER GPU (--scaling weak, the default) or in total (--scaling strong)")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="cfg2 / cfg3a / cfg3b on N > 1 GPUs.  weak (default): every GPU owns an index range of --n elements of an "
-                         "array of N x --n -- the per-GPU size the metric is quoted on, like the per-GPU sizes of configs[3] and [4]; "
-                         "strong: --n elements in total, --n / N per GPU (DESIGN.md section 7 for what each can give)")
+    ap.add_argument("--n", type=int, default=1 << 26, help="elements IN TOTAL (--scaling strong, the default: what BASELINE.md section 4 and north_star state) or per GPU (--scaling weak)")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1 GPUs: skip the weak-scaling sub-record (`weak` in the line)")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="cfg2 / cfg3a / cfg3b on N > 1 GPUs.  strong (default, the contract's configuration): --n elements in total, "
+                         "--n / N per GPU; weak: every GPU owns an index range of --n elements of an array of N x --n "
+                         "(DESIGN.md section 7 for what each can give).  With strong, the weak measurement rides along as `weak`.")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-also", action="store_true", help="skip the secondary workloads on one GPU")
     ap.add_argument("--profile-steps", type=int, default=5)
@@ -282,7 +284,7 @@ def path_trace(ek, ekc, tex, n, seed, first_lane=0, bounces=3, width=1024, recor
 
 
 class Bench:
-    def __init__(self, args):
+    def __init__(self, args, scaling=None):
         import torch
         import enoki_amd.hip as ekc
         import enoki_amd.hip_autodiff as ek
@@ -299,8 +301,9 @@ class Bench:
         if args.deterministic:
             ek.hip_set_tuning("deterministic", 1)
         self.dev = torch.device("cuda", self.local_rank)
-        self.weak = args.scaling == "weak" or args.workload.startswith(("cfg4", "cfg5"))
-        self.N = args.n * self.world if args.scaling == "weak" else args.n       # (cfg4 / cfg5 size their own per-GPU work)
+        scaling = scaling or args.scaling
+        self.weak = scaling == "weak" or args.workload.startswith(("cfg4", "cfg5"))
+        self.N = args.n * self.world if scaling == "weak" else args.n       # (cfg4 / cfg5 size their own per-GPU work)
         self.begin, self.end = ekd.shard_range(self.N, self.rank, self.world)
         self.n = self.end - self.begin
         self.sh = ekd.Sharded(ek, self.N, device=self.dev)     # horizontal results of the shards -> ONE all-reduce per step
@@ -902,6 +905,16 @@ def main():
     b = Bench(args)
     main_res = b.run(args.workload, args.steps, args.warmup, args.profile_steps, pre_warm_s=args.pre_warm_s)
     pre_warm_s = b.pre_warm_s
+    # N > 1 under the contract's (strong) mode: the weak measurement of the SAME run as a labelled sub-record -- every rank takes
+    # part (collectives), rank 0 reports
+    weak = None
+    if b.world > 1 and not b.weak and not args.no_weak:
+        bw = Bench(args, scaling="weak")
+        rw = bw.run(args.workload, args.steps, args.warmup, 0, pre_warm_s=min(args.pre_warm_s, 0.3))
+        weak = {"scaling": "weak", "value": rw["value"], "unit": "Gelem/s", "ms_per_step": rw["ms_per_step"],
+                "elements_per_gpu": bw.n, "elements_total": bw.N,
+                "note": "every GPU owns --n elements of an array of N x --n; all elements of all ranks / max-over-ranks time; same kernels, same exchange"}
+        del bw
     also = {}
     if b.world == 1 and not args.no_also:
         for w in ("cfg3a", "cfg2", "cfg3b") + tuple(CFG3B_VARIANTS) + ("cfg4_bucketed", "cfg4", "cfg4_packed", "cfg4_unfused", "cfg5", "cfg5_unfused"):
@@ -945,7 +958,7 @@ def main():
                                              "ONE reduce-scatter per step: rank r receives bins [r K / P, (r + 1) K / P) of both tables, the loss rides in an extra column"),
                        "step_replay": main_res["replay"]},
             "result_y": main_res["result_y"], "parity_checked": bool(parity and parity["parity_checked"]), "parity": parity,
-            "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None,
+            "roofline": main_res["roofline"], "cpu_baseline": cpu, "also": also or None, "weak": weak,
         }
         print(json.dumps(line), flush=True)
     if b.ekd.active():

@@ -29,9 +29,9 @@ COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-math-errno", 
           "-Wall", "-Wno-unused-function", f"-I{os.path.join(ROOT, 'include')}"]
 DEVICE = [f"--offload-arch={ARCH}"]
 
-LIB_SOURCES = ["runtime.cpp", "dist.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "gathered.hip", "scan.hip", "bucketed.hip"]
+LIB_SOURCES = ["runtime.cpp", "dist.cpp", "elementwise.hip", "memory.hip", "reduce.hip", "scatter_binned.hip", "random.hip", "gathered.hip", "scan.hip", "bucketed.hip", "bucketed_early.hip"]
 # measurement scaffolding (tools/probe_*.py): its own library on top of the public C ABI, never loaded by the product
-PROBE_SOURCES = ["probe.hip", "probe_lds64.hip", "probe_rt.cpp"]
+PROBE_SOURCES = ["probe.hip", "probe_lds64.hip", "probe_valu.hip", "probe_rt.cpp"]
 
 
 def kernels_sha16():
@@ -184,7 +184,7 @@ def build_checkers(force=False, verbose=True):
               f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     compat = os.path.join(tcpp, "compat_names_hip.bin")
     if force or _newer(compat, [os.path.join(tcpp, "compat_names_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):
-        _run(["g++", "-O2", "-std=c++17", "-Wall", "-DENOKI_HIP_DYNAMIC_IS_DEVICE=1", inc, os.path.join(tcpp, "compat_names_hip.cpp"), "-o", compat,
+        _run(["g++", "-O2", "-std=c++17", "-Wall", "-DENOKI_HIP_DYNAMIC_IS_DEVICE=1", inc, f"-I{os.path.join(ROOT, 'compat')}", os.path.join(tcpp, "compat_names_hip.cpp"), "-o", compat,
               f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     call = os.path.join(tcpp, "libcall_hip.so")
     if force or _newer(call, [os.path.join(tcpp, "call_hip.cpp"), os.path.join(HERE, "libenoki-hip-autodiff.so")] + _headers()):
@@ -252,7 +252,7 @@ def build_checkers(force=False, verbose=True):
             shim_files = [os.path.join(base, f) for base, _, files in os.walk(shim) for f in files]
             if force or _newer(exe, [src, os.path.join(ref_tests, source), os.path.join(HERE, "libenoki-hip-autodiff.so")] + shim_files + _headers()):
                 # -I- : the reference's `#include "test.h"` must find the shim, not the file next to the test source
-                _run(["g++", "-O1", "-std=c++17", "-iquote", shim, "-iquote", "/usr/include/c++/11/pstl", "-I-", f"-I{shim}", inc,
+                _run(["g++", "-O1", "-std=c++17", "-iquote", shim, "-iquote", "/usr/include/c++/11/pstl", "-I-", f"-I{shim}", inc, f"-I{os.path.join(ROOT, 'compat')}",
                       "-DENOKI_AUTODIFF=1", f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, source)}"', src, "-o", exe,
                       f"-L{HERE}", "-lenoki-hip-autodiff", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
         # the reference's own HEADERS (router, math, struct support) driving this backend through integration/enoki/hip.h, with
@@ -293,7 +293,7 @@ def build_checkers(force=False, verbose=True):
         shim_files = [os.path.join(base, f) for base, _, files in os.walk(shim) for f in files]
         if force or _newer(exe, [src, os.path.join(ref_tests, "sphere.cpp"), os.path.join(ref_tests, "ray.h"),
                                  os.path.join(HERE, "libenoki-hip.so")] + shim_files + _headers()):
-            _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{shim}", inc,
+            _run([HIPCC] + DEVICE + ["-x", "hip", "-O2", "-std=c++17", "-ffp-contract=off", f"-I{shim}", inc, f"-I{os.path.join(ROOT, 'compat')}",
                                      f'-DREFERENCE_TEST_FILE="{os.path.join(ref_tests, "sphere.cpp")}"', src, "-o", exe,
                                      f"-L{HERE}", "-lenoki-hip", "-Wl,-rpath,$ORIGIN/../../enoki_amd"])
     if verbose:

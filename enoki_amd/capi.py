@@ -501,6 +501,7 @@ class Bucketed:
     scatter_add of the two gathers without a lookup that leaves the CU.  Keeps A, C alive; x and index may be dropped."""
 
     HINT_ADJOINT = 1
+    HINT_BOUNDED = 2
 
     def __init__(self, op, A, x, C, index, hints=0, mask=None):
         self.A, self.C, self.dtype, self.K = A, C, A.dtype, A.n

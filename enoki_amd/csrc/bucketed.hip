@@ -25,297 +25,9 @@
 // (data(), an elementwise consumer, another index array) takes the element-order kernels (gathered.hip) -- same bits
 // for u; reductions and gradients differ from the element-order path only by the order of their fp additions (parity
 // class D, like every reduction / scatter_add of this library).  Deterministic mode never comes here.
-#include "ek_binned.h"
-#include "ek_paged.h"
-
-#include <limits>
+#include "ek_bucketed.h"
 
 namespace ek {
-
-template <typename T> struct alignas(2 * sizeof(T)) PairRec { T a, c; };
-
-// The bucket's slice of both tables as interleaved {a, c} records in the LDS (every element then costs ONE ds_read_b64; b128 for
-// doubles), and -- ZeroTables -- the two gradient tables behind them cleared.  A thread requests all of its entries before it
-// uses the first: the loop used to wait for each pair of loads (Bins / 1024 = 8 or 16 dependent round trips per piece, 6-10 us
-// of every launch).  Entries beyond the table read its last entry and count as zero.
-template <typename T, bool ZeroTables>
-__device__ __forceinline__ void stage_pair_slice(PairRec<T> *rec, T *tables, const T *__restrict__ table_a, const T *__restrict__ table_c,
-                                                 size_t first, size_t table_size, int Bins, int flip_a, int flip_c) {
-    constexpr int U = 8;
-    const size_t last = table_size - 1;
-    for (int j0 = threadIdx.x; j0 < Bins; j0 += U * (int) blockDim.x) {
-        T a[U], c[U];
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const size_t k = first + (size_t) (j0 + u * (int) blockDim.x);
-            const size_t kc = k < last ? k : last;
-            a[u] = table_a[kc];
-            c[u] = table_c ? table_c[kc] : T(-0.0);       // no addend table: u = a x + (-0) = a x, bit for bit (signed zeros included)
-            if (k > last) { a[u] = T(0); c[u] = T(0); }
-        }
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int j = j0 + u * (int) blockDim.x;
-            if (j < Bins) {
-                rec[j] = PairRec<T>{ flip_a ? -a[u] : a[u], flip_c ? -c[u] : c[u] };
-                if constexpr (ZeroTables) { tables[2 * j] = T(0); tables[2 * j + 1] = T(0); }
-            }
-        }
-    }
-}
-
-constexpr int kBucketThreads = 1024;        // one workgroup per CU: the {A, C} slice / two gradient tables fill 128 KiB of LDS
-constexpr int kBucketWaves = kBucketThreads / 64;
-enum { EK_REDUCE_NONE = EK_REDUCE_COUNT };   // forward kernel without a reduction: only keeps u in bucket order
-
-template <int Op, typename T> struct BucketReducer {
-    static __device__ __host__ __forceinline__ T identity() {
-        if constexpr (Op == EK_HSUM || Op == EK_REDUCE_NONE) return T(0);
-        else if constexpr (Op == EK_HPROD) return T(1);
-        else return std::numeric_limits<T>::quiet_NaN();           // minNum / maxNum (reduce.hip)
-    }
-    static __device__ __forceinline__ T combine(T acc, T v) {
-        if constexpr (Op == EK_HSUM) return acc + v;
-        else if constexpr (Op == EK_HPROD) return acc * v;
-        else if constexpr (Op == EK_HMIN) { if constexpr (sizeof(T) == 4) return __builtin_fminf(acc, v); else return __builtin_fmin(acc, v); }
-        else if constexpr (Op == EK_HMAX) { if constexpr (sizeof(T) == 4) return __builtin_fmaxf(acc, v); else return __builtin_fmax(acc, v); }
-        else return acc;
-    }
-};
-
-/// where the last workgroup of a reducing launch puts the result (bucket_finish); ticket == nullptr: a separate launch does it
-template <typename T> struct BucketFinish {
-    uint32_t *ticket;
-    T *out;
-    const uint32_t *active;
-    size_t n;
-    int zero_op;             // what a dropped lane (u = 0) contributes, as a function of 0
-    uint32_t *counters = nullptr;   // the object's block of partition counters (gtotal): cleared by the last workgroup for the block's next user
-};
-
-template <typename T> __device__ __forceinline__ T bucket_shfl_down(T v, int delta) {
-    if constexpr (sizeof(T) == 8) {
-        uint64_t u;
-        __builtin_memcpy(&u, &v, 8);
-        uint32_t lo = (uint32_t) u, hi = (uint32_t) (u >> 32);
-        lo = __shfl_down(lo, delta, 64);
-        hi = __shfl_down(hi, delta, 64);
-        u = ((uint64_t) hi << 32) | lo;
-        __builtin_memcpy(&v, &u, 8);
-        return v;
-    } else {
-        return __shfl_down(v, delta, 64);
-    }
-}
-
-template <typename T> __device__ __forceinline__ T fma_t(T a, T b, T c) {
-    if constexpr (sizeof(T) == 4) return __builtin_fmaf(a, b, c); else return __builtin_fma(a, b, c);
-}
-// u of one element: fma(a, x, c), or -- `a * x + c` written with operators, EK_MULADD / EK_MULSUB / EK_NMULADD -- the product and
-// the sum with a rounding each (this translation unit is built with -ffp-contract=off).  `two` is uniform over the launch: both
-// forms are two or three vector instructions next to the ~50 of the function that follows, so it is a select, not a kernel.
-template <typename T> __device__ __forceinline__ T pair_value(T a, T x, T c, int two) {
-    const T p = a * x;
-    const T s = p + c, f = fma_t(a, x, c);
-    return two ? s : f;
-}
-
-// ---- where a bucket's elements are ----------------------------------------------------------------------------------
-// Two layouts of the bucket-ordered lists (l16, x_b and what is kept next to them):
-//   contiguous  (PS = 0; count / scan / partition of ek_binned.h -- 8-byte element types): bucket b owns positions
-//               [base[b], base[b + 1]), a piece is a sub-range that starts anywhere
-//   paged       (PS = 5 | 6; the single-pass partition of ek_paged.h -- 4-byte element types): bucket b owns the pages
-//               glist_full[base[b] .. base[b + 1]) (2^PS elements each, complete) and glist_part[base_part[b] .. base_part[b + 1])
-//               (page << 6 | count - 1); a piece is a range of both lists
-struct BucketLists {
-    const uint32_t *base, *piece_prefix;
-    const uint32_t *base_part, *glist_full, *glist_part;
-    int n_buckets;
-};
-
-struct PieceRange {
-    size_t begin, end;               // contiguous
-    uint32_t f0, f1, p0, p1;         // paged
-};
-
-// piece `blockIdx.x` -> its bucket and its share of the bucket's elements (the same cut as k_bin_accumulate)
-template <int PS>
-__device__ __forceinline__ bool bucket_piece(const BucketLists &bl, int &bucket, PieceRange &r) {
-    __shared__ int s_bucket;
-    const int n_buckets = bl.n_buckets;
-    if (blockIdx.x >= bl.piece_prefix[n_buckets]) return false;
-    for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
-        if (bl.piece_prefix[b] <= blockIdx.x && blockIdx.x < bl.piece_prefix[b + 1]) s_bucket = b;
-    __syncthreads();
-    bucket = s_bucket;
-    const size_t q = blockIdx.x - bl.piece_prefix[bucket], pieces = bl.piece_prefix[bucket + 1] - bl.piece_prefix[bucket];
-    auto cut = [&](size_t lo, size_t hi, size_t &b0, size_t &b1) {
-        const size_t per = (hi - lo + pieces - 1) / pieces;
-        b0 = lo + q * per < hi ? lo + q * per : hi;
-        b1 = b0 + per < hi ? b0 + per : hi;
-    };
-    r = PieceRange{};
-    if constexpr (PS == 0) {
-        cut(bl.base[bucket], bl.base[bucket + 1], r.begin, r.end);
-    } else {
-        size_t a, b;
-        cut(bl.base[bucket], bl.base[bucket + 1], a, b);
-        r.f0 = (uint32_t) a; r.f1 = (uint32_t) b;
-        cut(bl.base_part[bucket], bl.base_part[bucket + 1], a, b);
-        r.p0 = (uint32_t) a; r.p1 = (uint32_t) b;
-    }
-    return true;
-}
-
-// Walks a piece.  Body:
-//   struct Step                                what a lane holds of V vectors of four consecutive elements
-//   fetch(Step &, int h, size_t pos)           requests vector h at element position pos (16-byte aligned)
-//   apply(const Step &)                        consumes the V vectors
-//   one(size_t pos, bool on, int slot)         one element; EVERY lane of a wave calls it together (on = false: no element)
-// Contiguous: up to 3 leading elements one per lane, then vectors with the loads of step i + 1 requested before step i is
-// consumed, then the tail one element per lane.  Paged: 2^PS / 4 lanes share a page, four elements each -- the same 8- and
-// 16-byte vector loads; the pages' numbers are requested two steps ahead; what does not fill a step of the whole workgroup
-// (the last complete pages, the partially filled ones) goes element by element under a lane predicate.
-template <int PS, int V, typename Body>
-__device__ __forceinline__ void walk_piece(const BucketLists &bl, const PieceRange &r, Body &body) {
-    using Step = typename Body::Step;
-    if constexpr (PS == 0) {
-        const size_t begin = r.begin, end = r.end;
-        const size_t head_end = ((begin + 3) & ~(size_t) 3) < end ? ((begin + 3) & ~(size_t) 3) : end;
-        body.one(begin + threadIdx.x, begin + threadIdx.x < head_end, 0);
-        constexpr size_t kStep = (size_t) 4 * V * kBucketThreads;
-        size_t base = head_end;
-        if (base + kStep <= end) {
-            Step cur, next;
-#pragma unroll
-            for (int h = 0; h < V; ++h) body.fetch(cur, h, base + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4);
-            for (; base + 2 * kStep <= end; base += kStep) {
-#pragma unroll
-                for (int h = 0; h < V; ++h) body.fetch(next, h, base + kStep + (size_t) h * (kStep / V) + (size_t) threadIdx.x * 4);
-                body.apply(cur);
-                cur = next;
-            }
-            body.apply(cur);
-            base += kStep;
-        }
-        for (; base < end; base += kBucketThreads) body.one(base + threadIdx.x, base + threadIdx.x < end, 0);
-    } else {
-        constexpr uint32_t LX = (1u << PS) / 4, G = kBucketThreads / LX;        // lanes per page, pages per vector of the workgroup
-        const uint32_t g = threadIdx.x / LX, i = threadIdx.x % LX;
-        const uint32_t nfull = r.f1 - r.f0, steps = nfull / (G * V);
-        auto at = [&](uint32_t page) { return ((size_t) page << PS) + 4 * i; };
-        if (steps) {
-            const uint32_t *list = bl.glist_full + r.f0 + g;
-            uint32_t e1[V], e2[V];
-            Step cur, next;
-#pragma unroll
-            for (int h = 0; h < V; ++h) e1[h] = list[h * G];
-#pragma unroll
-            for (int h = 0; h < V; ++h) body.fetch(cur, h, at(e1[h]));
-#pragma unroll
-            for (int h = 0; h < V; ++h) e1[h] = steps > 1 ? list[(V + h) * G] : 0u;
-            for (uint32_t s = 0; s + 1 < steps; ++s) {
-#pragma unroll
-                for (int h = 0; h < V; ++h) e2[h] = s + 2 < steps ? list[((s + 2) * V + h) * G] : 0u;
-#pragma unroll
-                for (int h = 0; h < V; ++h) body.fetch(next, h, at(e1[h]));
-                body.apply(cur);
-                cur = next;
-#pragma unroll
-                for (int h = 0; h < V; ++h) e1[h] = e2[h];
-            }
-            body.apply(cur);
-        }
-        // wave-uniform trip counts: the lock protocol inside one() wants every lane of a wave to come along
-        const uint32_t done = steps * G * V, rest = nfull - done;
-        for (uint32_t r0 = 0; r0 < rest; r0 += G) {
-            const bool valid = r0 + g < rest;
-            const uint32_t page = valid ? bl.glist_full[r.f0 + done + r0 + g] : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) body.one(at(page) + j, valid, j);
-        }
-        const uint32_t nparts = r.p1 - r.p0;
-        for (uint32_t r0 = 0; r0 < nparts; r0 += G) {
-            const bool valid = r0 + g < nparts;
-            const uint32_t e = valid ? bl.glist_part[r.p0 + r0 + g] : 0u, count = valid ? (e & 63u) + 1u : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) body.one(at(e >> 6) + j, 4 * i + j < count, j);
-        }
-    }
-}
-
-// `active` (may be null): [0] number of elements in the lists, [1] != 0 when a lane whose mask bit is clear carries a non-finite x.
-// The other n - active[0] lanes were dropped by the partition -- masked out of both gathers, or pointing outside the table (the
-// reference leaves that case unspecified, cuda.h:845-905; here it counts as masked out).  Their u is fma(0, x, 0): 0 for a finite
-// x, so they contribute map_op(0) to the reduction; NaN for an infinite or NaN x -- then the reference's result is NaN
-// (dynamic.h:632-650 sums every lane) and so is this one (hsum, hprod; hmin / hmax skip NaNs here as everywhere: DESIGN section 5).
-template <typename T, int ROp>
-__device__ __forceinline__ T bucket_dropped_lanes(T r, size_t masked, bool nonfinite, int map_op) {
-    using R = BucketReducer<ROp, T>;
-    if (masked) {
-        const T f0 = unary_fused<T>(map_op, T(0));
-        if constexpr (ROp == EK_HSUM) {
-            r = r + (T) masked * f0;
-        } else if constexpr (ROp == EK_HPROD) {
-            T p = T(1), base = f0;
-            for (size_t e = masked; e; e >>= 1) { if (e & 1) p = p * base; base = base * base; }
-            r = r * p;
-        } else {
-            r = R::combine(r, f0);
-        }
-    }
-    if (nonfinite) r = R::combine(r, std::numeric_limits<T>::quiet_NaN());
-    return r;
-}
-
-// The reduction over the pieces' partial results, finished by the LAST workgroup to arrive instead of a launch of its own
-// (k_bucket_reduce_final: 4.5 us + a launch gap per step; a quarter of what an 8 Mi-element shard step spends outside its two
-// big kernels).  Every workgroup publishes its partial and takes a ticket; the one that draws the last ticket reads all
-// partials (agent-scope loads: they were written on other XCDs), adds what the dropped lanes contribute and resets the ticket
-// for the next launch -- launches on one object are ordered by the stream.  `ticket` == nullptr: the host launches
-// k_bucket_reduce_final (objects whose meta block is not zero-filled: 8-byte element types).
-template <typename T, int ROp>
-__device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *__restrict__ partials, uint32_t *__restrict__ ticket,
-                                              T *__restrict__ out, const uint32_t *__restrict__ active, size_t n, int map_op,
-                                              T *wave_part /* [kBucketWaves] shared */, uint32_t *__restrict__ counters = nullptr) {
-    using R = BucketReducer<ROp, T>;
-    using Bits = std::conditional_t<sizeof(T) == 4, uint32_t, unsigned long long>;
-    __shared__ uint32_t s_last;
-    if (threadIdx.x == 0) {
-        Bits b;
-        __builtin_memcpy(&b, &block_result, sizeof(T));
-        __hip_atomic_store(reinterpret_cast<Bits *>(partials) + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    // (the partition's page totals and accumulators have been consumed by the directory launch: cleared here, the block of counters
-    // can go to the next object without a fill -- MetaRing)
-    if (counters) {
-        for (unsigned k = threadIdx.x; k < 2u * kMaxBuckets + 2u; k += blockDim.x) counters[k] = 0u;
-    }
-    T v = R::identity();
-    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
-        const Bits b = __hip_atomic_load(reinterpret_cast<const Bits *>(partials) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        T p;
-        __builtin_memcpy(&p, &b, sizeof(T));
-        v = R::combine(v, p);
-    }
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
-    __syncthreads();                                  // (wave_part may still hold this workgroup's own wave results)
-    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        v = threadIdx.x < blockDim.x / 64 ? wave_part[threadIdx.x] : R::identity();
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
-        if (threadIdx.x == 0) {
-            out[0] = bucket_dropped_lanes<T, ROp>(v, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-}
 
 // ---- 2. forward ------------------------------------------------------------------------------------
 // The streaming part, specialised for the unary op that is applied to u before the reduction (Map, compile time: the
@@ -463,22 +175,6 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward(T *__res
     }
 }
 
-template <typename T, int ROp>
-__global__ __launch_bounds__(256) void k_bucket_reduce_final(T *__restrict__ out, const T *__restrict__ partials, unsigned count,
-                                                             const uint32_t *__restrict__ active, size_t n, int map_op) {
-    using R = BucketReducer<ROp, T>;
-    __shared__ T wave_part[4];
-    T v = R::identity();
-    for (unsigned i = threadIdx.x; i < count; i += 256) v = R::combine(v, partials[i]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
-    if ((threadIdx.x & 63) == 0) wave_part[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        T r = R::combine(R::combine(wave_part[0], wave_part[1]), R::combine(wave_part[2], wave_part[3]));
-        out[0] = bucket_dropped_lanes<T, ROp>(r, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
-    }
-}
 
 // ---- 3. adjoint ------------------------------------------------------------------------------------
 // Value stream c of the scatter_add:  v_c = from_u(c) ? map_c(u) : imm_c,  times x with safe_mul semantics when weighted(c)
@@ -490,191 +186,6 @@ template <typename T, int C> struct BucketStreams {
     unsigned from_u, weighted;
     unsigned plain_x = 0;  // C == 1: the stream is x itself (scatter_add_paged)
 };
-// Two f32 tables share ONE lock per bin: the LDS holds {table 0, table 1} pairs and a bin pair is claimed by a 64-bit
-// exchange (ds_wrxchg_rtn_b64), updated and released by one 64-bit store -- half the LDS atomics and half the dependent
-// round trips of two independent 32-bit locks.  Same protocol as lds_add (ek_binned.h), see there for why the retry loop
-// is wave-uniform.
-constexpr unsigned long long kLockedPair = 0xFFC00001FFC00001ull;
-
-__device__ __forceinline__ unsigned long long pair_sum(unsigned long long old, float v0, float v1) {
-    const float s0 = __uint_as_float((unsigned) old) + v0, s1 = __uint_as_float((unsigned) (old >> 32)) + v1;
-    // a pair is LOCKED iff its low word carries the lock pattern (a NaN payload no sum produces): one compare per test, and
-    // the pattern is never published as a value
-    unsigned lo = __float_as_uint(s0);
-    if (lo == kLockedBits) lo = 0x7FC00000u;
-    return (unsigned long long) lo | ((unsigned long long) __float_as_uint(s1) << 32);
-}
-
-__device__ __forceinline__ void lds_add_pair(unsigned long long *p, float v0, float v1, bool active) {
-    bool pending = active;
-    if (pending) {
-        const unsigned long long old = atomicExch(p, kLockedPair);
-        if ((unsigned) old != kLockedBits) {
-            __hip_atomic_store(p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pending = false;
-        }
-    }
-    const unsigned key = (unsigned) (uintptr_t) p;
-    const int lane = threadIdx.x & 63;
-    while (__any(pending)) {
-        const unsigned long long pend = __ballot(pending);
-        const int leader = __ffsll((long long) pend) - 1;
-        const unsigned leader_key = __shfl(key, leader);
-        const bool grouped = pending && key == leader_key;
-        float t0 = grouped ? v0 : 0.0f, t1 = grouped ? v1 : 0.0f;
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { t0 += __shfl_xor(t0, d); t1 += __shfl_xor(t1, d); }
-        if (lane == leader) {
-            unsigned long long old;
-            do { old = atomicExch(p, kLockedPair); } while ((unsigned) old == kLockedBits);
-            __hip_atomic_store(p, pair_sum(old, t0, t1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
-        pending = pending && !grouped;
-    }
-}
-
-// One update per lane, the form the streaming loops use: claim, add, release; the lanes that met a lock (another wave's, or a
-// lane of this wave with the same bin) retry together once, what is still locked then takes the combining path above.  The
-// "did anybody meet a lock" tests are wave ballots consumed by scalar branches (no vector instruction spent on them).
-__device__ __forceinline__ void lds_add_pair_one(unsigned long long *table, uint32_t l, float v0, float v1) {
-    unsigned long long *p = table + l;
-    const unsigned long long old = atomicExch(p, kLockedPair);
-    unsigned lo = (unsigned) old;
-    asm volatile("" : "+v"(lo));                       // (keeps the lock test a 32-bit compare of the low word)
-    const unsigned long long met = __builtin_amdgcn_uicmp(lo, kLockedBits, 32 /* == */);     // lanes that met a lock
-    if (lo != kLockedBits) __hip_atomic_store(p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (met) {
-        bool pending = lo == kLockedBits;
-        if (pending) {
-            const unsigned long long again = atomicExch(p, kLockedPair);
-            if ((unsigned) again != kLockedBits) {
-                __hip_atomic_store(p, pair_sum(again, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pending = false;
-            }
-        }
-        if (__builtin_amdgcn_ballot_w64(pending)) lds_add_pair(p, v0, v1, pending);
-    }
-}
-
-// The same update WITHOUT a branch: claim, add, release -- a lane that met a lock stores its (meaningless) sum to a dummy slot
-// and reports the update as still to be made.  A step's updates then form one basic block (the compiler overlaps an exchange's
-// round trip with the next element's arithmetic), and what met a lock is retried once per step, all slots in flight together
-// (lds_add_pair_retry).
-__device__ __forceinline__ bool lds_try_add_pair(unsigned long long *table, unsigned long long *dummy, uint32_t l, float v0, float v1) {
-    unsigned long long *p = table + l;
-    const unsigned long long old = atomicExch(p, kLockedPair);
-    const bool met = (unsigned) old == kLockedBits;
-    __hip_atomic_store(met ? dummy : p, pair_sum(old, v0, v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return met;
-}
-
-// the slots of `pending` once more, their exchanges in flight together (the locks they met have been released long since); what
-// is locked even then -- hot bins, or two slots of one lane with the same bin -- goes one slot at a time with wave combining
-template <int N>
-__device__ __forceinline__ void lds_add_pair_retry(unsigned long long *table, const uint32_t (&l)[N], const float (&v0)[N],
-                                                   const float (&v1)[N], unsigned pending) {
-    unsigned long long old[N];
-#pragma unroll
-    for (int j = 0; j < N; ++j)
-        if ((pending >> j) & 1u) old[j] = atomicExch(table + l[j], kLockedPair);
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        if (((pending >> j) & 1u) && (unsigned) old[j] != kLockedBits) {
-            __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            pending &= ~(1u << j);
-        }
-    }
-    if (__builtin_amdgcn_ballot_w64(pending != 0)) {
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if (__builtin_amdgcn_ballot_w64((pending >> j) & 1u)) lds_add_pair(table + l[j], v0[j], v1[j], (pending >> j) & 1u);
-    }
-}
-
-// N independent updates per lane: all N bins are CLAIMED first (N exchanges in flight -- one LDS round trip instead of N
-// dependent ones), then every claim that succeeded is added to and released; the few that met a lock (another lane's, or
-// this lane's own claim of the same bin in an earlier slot) are retried together, and what is still locked then goes through
-// the one-at-a-time path with wave-level combining.  Nobody spins while holding a lock, so there is no circular wait.
-// The kernels below call it with N = 1 (see bucket_accumulate_stream for the measurement that retired N = 4 / 8); what they
-// keep from it is the cheap retry round before the wave-combining loop.
-template <int N>
-__device__ __forceinline__ void lds_add_pair_batch(unsigned long long *table, const uint32_t (&l)[N], const float (&v0)[N],
-                                                   const float (&v1)[N]) {
-    unsigned long long old[N];
-    unsigned pending = 0;
-    // round 1: every slot
-#pragma unroll
-    for (int j = 0; j < N; ++j) old[j] = atomicExch(table + l[j], kLockedPair);
-#pragma unroll
-    for (int j = 0; j < N; ++j) {
-        if ((unsigned) old[j] != kLockedBits)
-            __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        else
-            pending |= 1u << j;
-    }
-    // With 64 N claims in flight per wave and 16 Ki bins a few claims per batch meet a lock (64 N = 512: ~3 % of them), so
-    // "somebody in the wave is pending" is the rule, not the exception.  Round 2 retries exactly those slots, again all in
-    // flight together -- their locks were released by the stores above -- and leaves only true repeat offenders (hot
-    // bins) to the one-at-a-time path with its wave-level combining.
-    if (__any(pending != 0)) {
-#pragma unroll
-        for (int j = 0; j < N; ++j)
-            if ((pending >> j) & 1u) old[j] = atomicExch(table + l[j], kLockedPair);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (((pending >> j) & 1u) && (unsigned) old[j] != kLockedBits) {
-                __hip_atomic_store(table + l[j], pair_sum(old[j], v0[j], v1[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                pending &= ~(1u << j);
-            }
-        }
-        if (__any(pending != 0)) {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                if (__any((pending >> j) & 1u)) lds_add_pair(table + l[j], v0[j], v1[j], (pending >> j) & 1u);
-        }
-    }
-}
-
-template <typename T, int N>
-__device__ __forceinline__ void lds_add_batch(T *table, const uint32_t (&l)[N], const T (&v)[N]) {
-    if constexpr (std::is_same_v<T, float>) {
-        unsigned *t = reinterpret_cast<unsigned *>(table);
-        unsigned old[N];
-        unsigned pending = 0;
-        auto sum = [](unsigned o, float x) {
-            unsigned bits = __float_as_uint(__uint_as_float(o) + x);
-            return bits == kLockedBits ? 0x7FC00000u : bits;
-        };
-#pragma unroll
-        for (int j = 0; j < N; ++j) old[j] = atomicExch(t + l[j], kLockedBits);
-#pragma unroll
-        for (int j = 0; j < N; ++j) {
-            if (old[j] != kLockedBits) __hip_atomic_store(t + l[j], sum(old[j], v[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            else pending |= 1u << j;
-        }
-        if (__any(pending != 0)) {
-#pragma unroll
-            for (int j = 0; j < N; ++j)
-                if ((pending >> j) & 1u) old[j] = atomicExch(t + l[j], kLockedBits);
-#pragma unroll
-            for (int j = 0; j < N; ++j) {
-                if (((pending >> j) & 1u) && old[j] != kLockedBits) {
-                    __hip_atomic_store(t + l[j], sum(old[j], v[j]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                    pending &= ~(1u << j);
-                }
-            }
-            if (__any(pending != 0)) {
-#pragma unroll
-                for (int j = 0; j < N; ++j)
-                    if (__any((pending >> j) & 1u)) lds_add<true>(table + l[j], v[j], ((pending >> j) & 1u) != 0);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int j = 0; j < N; ++j) lds_add<true>(table + l[j], v[j], true);
-    }
-}
-
 // The streaming part.  Map >= 0: every stream that is a function of u applies THIS op (compile time; evaluated once per
 // element however many streams share it -- the usual pair cos(u), x * cos(u)); Map < 0: per-stream ops chosen at run time.
 // Spec = 1: the adjoint of a gathered pair as the tape issues it -- two streams, both the (kept / mapped) function of u, the
@@ -842,240 +353,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_accumulate(T *__restr
     }
 }
 
-// ---- 2 + 3 in one pass: the reduction of f(u) AND the adjoint of the gathers ------------------------------------------
-// y = hsum(f(u)) is linear in its seed: whatever gradient g the tape later sends down, the tables receive g * sum(f'(u)) and
-// g * sum(x f'(u)) per entry.  When the reduction is asked to KEEP the function of u that the derivative will be made of --
-// the other half of a sincos pair for sin / cos, the value itself for exp, rcp(u) for log, ... -- the sums are formed right
-// here, while u, the two function values and the bucket's table slice are at hand: the LDS holds the {A, C} slice AND the two
-// gradient tables of a half-size bucket (2 x 64 KiB), the kept function is never written (4 B/elt) or read back (4 B/elt),
-// (l16, x_b) is streamed once instead of twice, and the adjoint's LDS round trips overlap the forward's arithmetic.  The
-// tape's scatter_add of exactly these streams then only folds the partial tables (ek_hip_bucketed_scatter_add, with the seed
-// as a factor); anything else it asks for takes the ordinary kernels.
-template <int Map, int Keep, typename T> struct EarlyPair {
-    // reduced value and kept function of one u
-    static __device__ __forceinline__ void apply(T u, T &val, T &kept) {
-        if constexpr ((Map == EK_SIN && Keep == EK_COS) || (Map == EK_COS && Keep == EK_SIN)) {
-            T sn, cs;
-            SinCosOp::apply(u, sn, cs);
-            val = Map == EK_SIN ? sn : cs;
-            kept = Map == EK_SIN ? cs : sn;
-        } else if constexpr (Map == Keep) {
-            val = kept = UnaryOp<Map, T>::apply(u);
-        } else {
-            val = UnaryOp<Map, T>::apply(u);
-            kept = UnaryOp<Keep, T>::apply(u);
-        }
-    }
-};
-
-template <typename T, int V, int Map, int Keep>
-struct EarlyBody {
-    static constexpr bool Paired = sizeof(T) == 4;
-    struct Step { Pack<uint16_t, 4> pi[V]; T px[V][4]; };
-    const PairRec<T> *rec;
-    T *tables;
-    unsigned long long *dummy;
-    const uint16_t *pair_idx;
-    const T *x_b;
-    int Bins;
-    uint32_t lmask;
-    int two;                 // see pair_value()
-    T acc[4];
-
-    // reduced value into `sum`, kept function m and x * m out
-    __device__ __forceinline__ void values(uint32_t l, T x, T &sum, T &v0, T &v1) const {
-        const PairRec<T> r = rec[l];
-        EarlyPair<Map, Keep, T>::apply(pair_value(r.a, x, r.c, two), sum, v0);
-        v1 = dev::safe_mul(x, v0);
-    }
-    __device__ __forceinline__ void one(size_t pos, bool on, int slot) {
-        const uint32_t l = on ? (uint32_t) pair_idx[pos] & lmask : 0u;
-        T sum, v0, v1;
-        values(l, on ? x_b[pos] : T(0), sum, v0, v1);
-        if (on) acc[slot] += sum;
-        if constexpr (Paired) {
-            lds_add_pair(reinterpret_cast<unsigned long long *>(tables) + l, v0, v1, on);
-        } else {
-            lds_add<true>(&tables[l], v0, on);
-            lds_add<true>(&tables[Bins + l], v1, on);
-        }
-    }
-    __device__ __forceinline__ void fetch(Step &s, int h, size_t pos) {
-        s.pi[h] = pack_load<uint16_t, 4, true>(pair_idx + pos);
-        load4<T, true>(x_b + pos, s.px[h]);
-    }
-    __device__ __forceinline__ void apply(const Step &s) {
-        constexpr int NB = 4 * V;
-        uint32_t l[NB];
-        T v0[NB], v1[NB];
-        if constexpr (Paired) {
-            // f32: the step's table records first (four independent reads), then element by element: value and kept function,
-            // ONE claim -- add -- release without a branch (lds_try_add_pair), and what met a lock retried once per step, all
-            // slots in flight (lds_add_pair_retry).  A lock is held for one LDS round trip.  Measured on 64 Mi lookups into
-            // 1 Mi entries, same box, us per launch: 8 claims per lane in flight 199, 4: 165, 2: 149, one claim behind each
-            // element with its own retry round 143-147, this form 137-143; the next element's arithmetic pinned under the
-            // exchange's round trip (a longer hold) 147-149; sincos / exp in packed-fp32 instructions (v_pk_fma_f32: two
-            // passes on gfx950's SIMD-32) 150-153 against 147-150.  With the claims removed the kernel takes 100, with the
-            // arithmetic removed 124, with both 80-87 (profiles/probe_early_r04.txt).  Round 5: a LOCK-FREE form -- the pairs of
-            // all four elements read up front, four compare-and-swaps in flight, two dependent LDS round trips per step instead of
-            // five -- is 11 % SLOWER (171 against 154 us): it moves 40 B per element through the LDS instead of 32, and that, not
-            // the latency of the claim -- add -- release chain, is what bounds the adjoint part (profiles/probe_early_r05.txt).
-            unsigned long long *tb = reinterpret_cast<unsigned long long *>(tables);
-            PairRec<T> r[NB];
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                l[k] = (uint32_t) s.pi[k / 4].v[k % 4] & lmask;
-                r[k] = rec[l[k]];
-            }
-            unsigned pending = 0;
-#pragma unroll
-            for (int k = 0; k < NB; ++k) {
-                const T x = s.px[k / 4][k % 4];
-                T sum;
-                EarlyPair<Map, Keep, T>::apply(pair_value(r[k].a, x, r[k].c, two), sum, v0[k]);
-                v1[k] = dev::safe_mul(x, v0[k]);
-                acc[k % 4] += sum;
-                pending |= lds_try_add_pair(tb, dummy, l[k], v0[k], v1[k]) ? 1u << k : 0u;
-            }
-            if (__builtin_amdgcn_ballot_w64(pending != 0)) lds_add_pair_retry<NB>(tb, l, v0, v1, pending);
-            return;
-        }
-#pragma unroll
-        for (int k = 0; k < NB; ++k) {
-            l[k] = (uint32_t) s.pi[k / 4].v[k % 4] & lmask;
-            T sum;
-            values(l[k], s.px[k / 4][k % 4], sum, v0[k], v1[k]);
-            acc[k % 4] += sum;
-        }
-        if constexpr (!Paired) {
-            lds_add_batch<T, NB>(tables, l, v0);
-            lds_add_batch<T, NB>(tables + Bins, l, v1);
-        }
-    }
-};
-
-/// which {reduced op, kept op} pairs the forward + adjoint kernel is built for
-__host__ __device__ constexpr bool early_pair_supported(int map_op, int keep_op) {
-    if ((map_op == EK_SIN && keep_op == EK_COS) || (map_op == EK_COS && keep_op == EK_SIN)) return true;
-    if (map_op == EK_LOG && keep_op == EK_RCP) return true;
-    if (map_op == EK_SQRT && keep_op == EK_RSQRT) return true;
-    if (map_op == EK_RCP && keep_op == EK_RCP_SQR) return true;
-    if (map_op == EK_RSQRT && keep_op == EK_RSQRT_CUBE) return true;
-    return map_op == keep_op && (map_op == EK_SIN || map_op == EK_COS || map_op == EK_EXP || map_op == EK_SQRT || map_op == EK_RCP ||
-                                 map_op == EK_RSQRT || map_op == EK_LOG || map_op == EK_ABS || map_op == EK_NEG);
-}
-
-template <typename T, int V, int PS>
-__global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
-                                                                                const T *__restrict__ table_a,
-                                                                                const T *__restrict__ table_c, size_t table_size,
-                                                                                int flip_a, int flip_c, int two,
-                                                                                const uint16_t *__restrict__ pair_idx,
-                                                                                const T *__restrict__ x_b, BucketLists bl,
-                                                                                int map_op, int keep_op, int shift, BucketFinish<T> fin) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
-    const int Bins = 1 << shift;
-    PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
-    T *tables = reinterpret_cast<T *>(rec + Bins);          // f32: Bins {t0, t1} pairs under one lock;  f64: two tables
-    __shared__ T wave_part[kBucketWaves];
-    __shared__ unsigned long long s_dummy;
-    constexpr bool Paired = sizeof(T) == 4;
-    int bucket;
-    PieceRange range;
-    if (!bucket_piece<PS>(bl, bucket, range)) {
-        bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
-        return;
-    }
-    stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
-    __syncthreads();
-    T v = T(0);
-    auto run = [&](auto body) {
-        body.rec = rec; body.tables = tables; body.pair_idx = pair_idx; body.x_b = x_b; body.Bins = Bins;
-        body.lmask = (uint32_t) Bins - 1u; body.dummy = &s_dummy; body.two = two;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) body.acc[k] = T(0);
-        walk_piece<PS, V>(bl, range, body);
-        v = (body.acc[0] + body.acc[1]) + (body.acc[2] + body.acc[3]);
-    };
-#define EK_EARLY_CASE(M, K) else if (map_op == M && keep_op == K) run(EarlyBody<T, V, M, K>{});
-    if (map_op == EK_SIN && keep_op == EK_COS) run(EarlyBody<T, V, EK_SIN, EK_COS>{});
-    EK_EARLY_CASE(EK_COS, EK_SIN) EK_EARLY_CASE(EK_LOG, EK_RCP) EK_EARLY_CASE(EK_SQRT, EK_RSQRT) EK_EARLY_CASE(EK_RCP, EK_RCP_SQR)
-    EK_EARLY_CASE(EK_RSQRT, EK_RSQRT_CUBE) EK_EARLY_CASE(EK_SIN, EK_SIN) EK_EARLY_CASE(EK_COS, EK_COS)
-    EK_EARLY_CASE(EK_EXP, EK_EXP) EK_EARLY_CASE(EK_SQRT, EK_SQRT) EK_EARLY_CASE(EK_RCP, EK_RCP) EK_EARLY_CASE(EK_RSQRT, EK_RSQRT)
-    EK_EARLY_CASE(EK_LOG, EK_LOG) EK_EARLY_CASE(EK_ABS, EK_ABS) EK_EARLY_CASE(EK_NEG, EK_NEG)
-#undef EK_EARLY_CASE
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (lane == 0) wave_part[wave] = v;
-    __syncthreads();
-    if (threadIdx.x < 64) {
-        v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : T(0);
-#pragma unroll
-        for (int d = 8; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
-    }
-    // table c (0: sum of the kept function, 1: sum of x * kept function) of this piece at table_partials + (c * gridDim.x + piece) * Bins
-#pragma unroll
-    for (int c = 0; c < 2; ++c) {
-        T *out = table_partials + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
-        for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out[j] = Paired ? tables[2 * j + c] : tables[c * Bins + j];
-    }
-    bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
-}
-
 // ---- host side -------------------------------------------------------------------------------------
-struct Bucketed {
-    int type = 0, index_type = 0, op = 0;
-    size_t n = 0, table_size = 0;
-    const void *table_a = nullptr, *table_c = nullptr;    // not owned: the caller keeps the tables alive and unchanged
-    int n_buckets = 0;
-    unsigned max_pieces = 0;
-    void *meta = nullptr;          // counts[n_buckets][blocks] | row_total | bucket_base | piece_prefix | reduce partials
-    uint32_t *bucket_base = nullptr, *piece_prefix = nullptr;
-    void *reduce_partials = nullptr;
-    void *pair_idx = nullptr;      // uint16_t[n]: index within the bucket, bucket order
-    void *x_b = nullptr;           // x in bucket order
-    void *u_b = nullptr;           // u in bucket order (allocated by the first consumer that keeps it)
-    bool has_u = false;
-    void *m_b = nullptr;           // m_op(u) in bucket order: the kept half of a sincos pair (see ek_hip_bucketed_reduce)
-    int m_op = EK_COPY;
-    bool has_m = false;
-    int shift = 0;                 // buckets of 2^shift table entries: bin_shift_of<T>, or one less (EK_BUCKETED_HINT_ADJOINT)
-    void *early = nullptr;         // k_bucket_pair_forward_adjoint: per piece, sums of early_op(u) and of x * early_op(u) per entry
-    int early_op = EK_COPY;
-    bool has_early = false;
-    // paged lists (ek_paged.h; 4-byte element types): page_shift = 5 | 6, pair_idx / x_b / u_b / m_b hold `positions` elements
-    // (whole pages, the workgroups' unused slots in between), bucket_base counts complete pages
-    int page_shift = 0;
-    size_t positions = 0;
-    void *page_lists = nullptr;    // glist_full[page slots] | glist_part[W * n_buckets]
-    uint32_t *glist_full = nullptr, *glist_part = nullptr, *base_part = nullptr;
-    const uint32_t *active = nullptr;      // device: [0] number of elements in the lists, [1] non-finite x under a cleared mask bit (null: contiguous lists)
-    uint32_t *ticket = nullptr;            // device, zero between launches: the last workgroup of a reducing launch finishes the reduction (bucket_finish)
-    int meta_slot = -1;                    // >= 0: `meta` is a block of the context's ring (meta_ring()), not an allocation of its own
-    bool meta_clean = false;               // a reducing launch ran: its last workgroup left the counters of the block zeroed
-    uint32_t win_lo = 0, win_span = 0;     // a slice of a large table: only indices in [win_lo, win_lo + win_span) (ek_hip_bucketed::slices)
-    bool correct_masked = true;            // the final reduction adds the masked-out lanes' map_op(0) terms (slices: their owner does)
-
-    bool has_mask = false;
-    // (with or without a mask array: lanes whose index points outside the table are dropped by the partition too, and count like
-    //  masked-out ones -- one rule for a single object and for the slices of a large table)
-    const uint32_t *masked_ptr() const { return correct_masked ? active : nullptr; }
-    template <typename T> BucketFinish<T> finish(void *out, int zero_op, bool reducing = true) {
-        // (a ring block under a launch that reduces: its last workgroup clears the partition's counters -- from then on the block is clean)
-        BucketFinish<T> f{ ticket, (T *) out, masked_ptr(), n, zero_op };
-        if (reducing && meta_slot >= 0 && ticket) { f.counters = (uint32_t *) meta; meta_clean = true; }
-        return f;
-    }
-    // signs applied ONCE to the staged table entries (exact): fmsub / mulsub: -c;  fnmadd / nmuladd (c - a x = (-a) x + c): -a;  fnmsub: both
-    int flip_a() const { return op == EK_FNMADD || op == EK_FNMSUB || op == EK_NMULADD; }
-    int flip_c() const { return op == EK_FMSUB || op == EK_FNMSUB || op == EK_MULSUB; }
-    int two_roundings() const { return op == EK_MULADD || op == EK_MULSUB || op == EK_NMULADD; }
-    size_t bins() const { return (size_t) 1 << shift; }
-    BucketLists lists() const { return BucketLists{ bucket_base, piece_prefix, base_part, glist_full, glist_part, n_buckets }; }
-    ~Bucketed();
-};
-
 // Counter blocks of the paged objects, kept by the context and handed from object to object: the first reducing launch of an object
 // leaves its block's counters zeroed (bucket_finish: the last workgroup clears what the directory launch has consumed), so the next
 // object that takes the block needs no fill -- the 768-word memset in front of every partition was 4.5 us of a 100 us shard step.
@@ -1171,11 +449,6 @@ static size_t bucket_target_pieces(size_t n, int n_buckets) {
     return std::max<size_t>(std::min<size_t>((size_t) std::max(per_cu, 1) * (size_t) c.num_cu, n / piece_elems), (size_t) n_buckets);
 }
 
-template <typename K> static int allow_big_lds(K kernel, size_t bytes) {
-    // beyond 64 KiB of dynamic LDS a kernel has to opt in
-    EK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
-    return EK_OK;
-}
 
 template <typename T, typename I, int Shift>
 static int bucketed_create(Bucketed *b, const T *x, const I *index) {
@@ -1396,13 +669,6 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     return EK_OK;
 }
 
-// kernel variants by list layout: contiguous for 8-byte element types, pages of 32 / 64 elements for 4-byte ones
-#define EK_BY_LAYOUT(b, call)                                                                                  \
-    do {                                                                                                       \
-        if constexpr (sizeof(T) == 8) { constexpr int PS = 0; call; }                                          \
-        else if ((b)->page_shift == 6) { constexpr int PS = 6; call; }                                         \
-        else { constexpr int PS = 5; call; }                                                                   \
-    } while (0)
 
 template <typename T, int ROp>
 static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep, int keep_op = EK_COPY) {
@@ -1429,6 +695,7 @@ static int bucketed_forward_launch(Bucketed *b, void *out, int map_op, bool keep
     });
     EK_LAUNCH_CHECK(ROp == EK_REDUCE_NONE ? "bucket_pair_fma" : "bucket_pair_fma_reduce", b->n,
                     b->n * (sizeof(uint16_t) + sizeof(T) + (keep ? sizeof(T) : 0)) + (b->table_c ? 2 : 1) * b->table_size * sizeof(T));
+    b->launched_reducing();
     if (keep && partner) { b->has_m = true; b->m_op = keep_op; }
     else if (keep) b->has_u = true;
     if constexpr (ROp != EK_REDUCE_NONE) {
@@ -1453,6 +720,7 @@ static int bucketed_reduce_kept_launch(Bucketed *b, void *out, int map_op, const
                            b->template finish<T>(out, zero_op));
     });
     EK_LAUNCH_CHECK("bucket_reduce_kept", b->n, b->n * sizeof(T));
+    b->launched_reducing();
     if (!b->ticket) {
         hipLaunchKernelGGL((k_bucket_reduce_final<T, ROp>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
                            b->max_pieces, b->masked_ptr(), b->n, zero_op);
@@ -1479,33 +747,6 @@ static int bucketed_reduce_kept(Bucketed *b, int reduce_op, int map_op, void *ou
 
 /// hsum of map_op(u) with the adjoint of the gathers -- the sums of keep_op(u) and x * keep_op(u) per entry -- formed in the
 /// same pass (k_bucket_pair_forward_adjoint)
-template <typename T>
-static int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, int keep_op) {
-    Context &c = ctx();
-    const size_t Bins = b->bins();
-    const size_t lds = Bins * (sizeof(PairRec<T>) + 2 * sizeof(T));
-    constexpr int VV = 1;            // one 4-element vector per lane and step (two: 0.151 ms against 0.143, same box)
-    if (!b->early)
-        if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * sizeof(T), &b->early)) return rc;
-    const int flip_a = b->flip_a(), flip_c = b->flip_c(), two = b->two_roundings();
-    EK_BY_LAYOUT(b, {
-        if (int rc = allow_big_lds(k_bucket_pair_forward_adjoint<T, VV, PS>, lds)) return rc;
-        hipLaunchKernelGGL((k_bucket_pair_forward_adjoint<T, VV, PS>), dim3(b->max_pieces), dim3(kBucketThreads), lds, c.stream,
-                           (T *) b->reduce_partials, (T *) b->early, (const T *) b->table_a, (const T *) b->table_c, b->table_size,
-                           flip_a, flip_c, two, (const uint16_t *) b->pair_idx, (const T *) b->x_b, b->lists(), map_op, keep_op, b->shift,
-                           b->template finish<T>(out, map_op));
-    });
-    EK_LAUNCH_CHECK("bucket_pair_fma_reduce_adjoint", b->n,
-                    b->n * (sizeof(uint16_t) + sizeof(T)) + (b->table_c ? 2 : 1) * b->table_size * sizeof(T) + (size_t) 2 * b->max_pieces * Bins * sizeof(T));
-    b->has_early = true;
-    b->early_op = keep_op;
-    if (!b->ticket) {
-        hipLaunchKernelGGL((k_bucket_reduce_final<T, EK_HSUM>), dim3(1), dim3(256), 0, c.stream, (T *) out, (const T *) b->reduce_partials,
-                           b->max_pieces, b->masked_ptr(), b->n, map_op);
-        EK_LAUNCH_CHECK("reduce_stage2", (size_t) b->max_pieces, (size_t) b->max_pieces * sizeof(T) + sizeof(T));
-    }
-    return EK_OK;
-}
 
 template <typename T>
 static int bucketed_reduce(Bucketed *b, int reduce_op, int map_op, void *out, bool keep, int keep_op) {
@@ -1552,6 +793,69 @@ static int bucketed_accumulate(Bucketed *b, T *const *bases, const BucketStreams
     return EK_OK;
 }
 
+
+// The per-piece tables of the fixed-point forward + adjoint kernel (bucketed_early.hip) into the gradient tables: 64-bit sums of
+// all pieces of a bucket are added as INTEGERS (order-free: the result does not depend on which piece an element went to, nor on
+// anything else that varies from run to run), converted once, scaled back by the power of two they were scaled up with, times the
+// caller's factor.  A piece that ran under locks (piece_mode 1: max |x| not finite, or a NaN term) left floats, which are added on top.
+template <int C>
+__global__ __launch_bounds__(256) void k_fold_fixed_pieces(FoldTargets<float, C> targets, const long long *__restrict__ partials,
+                                                           const uint32_t *__restrict__ piece_mode, const uint32_t *__restrict__ piece_prefix,
+                                                           size_t table_size, size_t partial_stride, unsigned fresh, int shift,
+                                                           const uint32_t *__restrict__ xmax_bits, int S0, int first_table) {
+    const size_t k0 = ((size_t) blockIdx.x * 256 + threadIdx.x) * kFoldPerLane;
+    if (k0 >= table_size) return;
+    const int c = first_table + (int) blockIdx.y;                 // 0: the plain sums, 1: the x-weighted sums
+    float *__restrict__ target = targets.table[blockIdx.y];
+    partials += (size_t) c * partial_stride;
+    const uint32_t b = (uint32_t) (k0 >> shift), local = (uint32_t) (k0 & (((size_t) 1 << shift) - 1));
+    const bool is_fresh = (fresh >> blockIdx.y) & 1u;
+    const uint32_t p0 = piece_prefix[b], p1 = piece_prefix[b + 1];
+    // (128 bits: a piece's sums stay below 2^62 by the choice of the scale, a skewed bucket of many pieces may not)
+    unsigned long long ilo[kFoldPerLane];
+    long long ihi[kFoldPerLane];
+    float fsum[kFoldPerLane], old[kFoldPerLane];
+#pragma unroll
+    for (int j = 0; j < kFoldPerLane; ++j) { ilo[j] = 0; ihi[j] = 0; fsum[j] = 0.f; old[j] = 0.f; }
+    const int lim = (int) (table_size - k0 < (size_t) kFoldPerLane ? table_size - k0 : (size_t) kFoldPerLane);
+    if (!is_fresh) {
+#pragma unroll
+        for (int j = 0; j < kFoldPerLane; ++j) if (j < lim) old[j] = target[k0 + j];
+    }
+    const uint32_t xm = xmax_bits[0];
+    for (uint32_t p = p0; p < p1; ++p) {
+        // (mode and sums requested together: the 64-bit words of a slot can be read whatever the piece wrote into it)
+        const long long *slot = partials + ((size_t) p << shift);
+        const uint32_t mode = piece_mode[p];
+        long long v[kFoldPerLane];
+#pragma unroll
+        for (int j = 0; j < kFoldPerLane; ++j) v[j] = j < lim ? __builtin_nontemporal_load(slot + local + j) : 0ll;
+        if (mode == 0u) {
+#pragma unroll
+            for (int j = 0; j < kFoldPerLane; ++j) {
+                const unsigned long long before = ilo[j];
+                ilo[j] += (unsigned long long) v[j];
+                ihi[j] += (v[j] >> 63) + (ilo[j] < before ? 1 : 0);
+            }
+        } else {
+            const float *slotf = reinterpret_cast<const float *>(slot);
+#pragma unroll
+            for (int j = 0; j < kFoldPerLane; ++j) if (j < lim) fsum[j] += slotf[local + j];
+        }
+    }
+    const float back = fixed_scale(S0, xm, c == 1).back, f = targets.scale[blockIdx.y];
+#pragma unroll
+    for (int j = 0; j < kFoldPerLane; ++j) {
+        if (j >= lim) continue;
+        // (one conversion of the exact integer: the same integer gives the same float whatever the pieces were)
+        const bool narrow = ihi[j] == ((long long) ilo[j] >> 63);
+        float v = narrow ? (float) (long long) ilo[j] : (float) ((double) ihi[j] * 18446744073709551616.0 + (double) ilo[j]);
+        v = v * back + fsum[j];
+        if (f != 1.f) v = v * f;
+        target[k0 + j] = old[j] + v;
+    }
+}
+
 template <typename T>
 static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, const int *from_u, const int *map_ops,
                                 const uint64_t *imm_bits, const int *weighted, const int *fresh, const uint64_t *scale_bits) {
@@ -1569,6 +873,33 @@ static int bucketed_scatter_add(Bucketed *b, int count, void *const *bases, cons
             Context &c = ctx();
             const size_t stride = (size_t) b->max_pieces * b->bins();
             const unsigned grid = fold_grid(b->table_size);
+            if constexpr (std::is_same_v<T, float>) {
+                if (b->early_fixed) {
+                    const uint32_t *xmax = b->active + (kPgMetaResultXmax - kPgMetaResult);
+                    if (count == 2) {
+                        const int s_plain = weighted[0] ? 1 : 0, s_weighted = 1 - s_plain;
+                        FoldTargets<float, 2> targets;
+                        targets.table[0] = (float *) bases[s_plain];
+                        targets.table[1] = (float *) bases[s_weighted];
+                        targets.scale[0] = scale[s_plain];
+                        targets.scale[1] = scale[s_weighted];
+                        const unsigned fr = fresh ? ((fresh[s_plain] ? 1u : 0u) | (fresh[s_weighted] ? 2u : 0u)) : 0u;
+                        hipLaunchKernelGGL((k_fold_fixed_pieces<2>), dim3(grid, 2), dim3(256), 0, c.stream, targets, (const long long *) b->early,
+                                           (const uint32_t *) b->early_modes, (const uint32_t *) b->piece_prefix, b->table_size, stride, fr, b->shift,
+                                           xmax, b->early_S0, 0);
+                    } else {
+                        FoldTargets<float, 1> targets;
+                        targets.table[0] = (float *) bases[0];
+                        targets.scale[0] = scale[0];
+                        hipLaunchKernelGGL((k_fold_fixed_pieces<1>), dim3(grid, 1), dim3(256), 0, c.stream, targets, (const long long *) b->early,
+                                           (const uint32_t *) b->early_modes, (const uint32_t *) b->piece_prefix, b->table_size, stride,
+                                           (fresh && fresh[0]) ? 1u : 0u, b->shift, xmax, b->early_S0, weighted[0] ? 1 : 0);
+                    }
+                    EK_LAUNCH_CHECK("scatter_add_fold", (size_t) count * b->table_size,
+                                    (size_t) count * (stride * sizeof(long long) + 2 * b->table_size * sizeof(T)));
+                    return EK_OK;
+                }
+            }
             if (count == 2) {
                 // partial table 0: unweighted, 1: weighted
                 const int s_plain = weighted[0] ? 1 : 0, s_weighted = 1 - s_plain;
@@ -1753,6 +1084,7 @@ __global__ __launch_bounds__(256) void k_masked_nonfinite(uint32_t *__restrict__
 }
 struct ek_hip_index_partition : ek::IndexPartition { };
 
+
 extern "C" {
 
 int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n) {
@@ -1857,7 +1189,12 @@ int ek_hip_bucketed_pair_create_masked(int type, int index_type, int op, const v
             }
             b->slices_split = split;
         } else {
-            rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - (half ? 1 : 0));
+            // EK_BUCKETED_HINT_BOUNDED on top of the adjoint hint: buckets of a QUARTER of the size (4 Ki entries), whose records and two planes
+            // of 64-bit fixed-point sums fit the LDS (bucketed_early.hip) -- while the table is within kMaxBuckets of those
+            const bool quarter = half && (hints & EK_BUCKETED_HINT_BOUNDED) && early_fixed_enabled() &&
+                                 table_size <= (size_t) kMaxBuckets * (bins / 4);
+            const int down = half ? (quarter ? 2 : 1) : 0;
+            rc = bucketed_create_paged<uint32_t>(b, (const float *) x, (const uint32_t *) index, m, bin_shift_of<float> - down);
         }
     } else if (mask) {
         rc = fail(EK_ERR_UNSUPPORTED, "ek_hip_bucketed_pair_create_masked(): masks with 4-byte element types only");

@@ -162,7 +162,8 @@ int ek_hip_dist_all_reduce(int type, int reduce_op, void *buf, size_t n) {
     if (t < 0 || op < 0 || (!buf && n)) return fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): bad arguments");
     if (!g_comm) return g_world == 1 ? EK_OK : fail(EK_ERR_INVALID, "ek_hip_dist_all_reduce(): ek_hip_dist_init has not been called");
     if (n == 0) return EK_OK;
-    if (int rc = refuse_while_capturing("ek_hip_dist_all_reduce(): RCCL collectives are not recorded into step graphs")) return rc;
+    if (refuse_while_capturing_quiet() != EK_OK)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist_all_reduce(): RCCL collectives are not recorded into step graphs (end the capture and run this step eagerly)");
     if (int rc = g_rccl.all_reduce(buf, buf, n, t, op, g_comm, ctx().stream)) return nccl_fail(rc, "ncclAllReduce");
     note_launch("dist_all_reduce", n, 2 * n * type_size(type));
     return EK_OK;
@@ -177,7 +178,8 @@ int ek_hip_dist_reduce_scatter(int type, int reduce_op, void *recv, const void *
         return (recv == send || recv_count == 0) ? EK_OK : ek_hip_memcpy_device(recv, send, recv_count * type_size(type));
     }
     if (recv_count == 0) return EK_OK;
-    if (int rc = refuse_while_capturing("ek_hip_dist_reduce_scatter(): RCCL collectives are not recorded into step graphs")) return rc;
+    if (refuse_while_capturing_quiet() != EK_OK)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist_reduce_scatter(): RCCL collectives are not recorded into step graphs (end the capture and run this step eagerly)");
     if (int rc = g_rccl.reduce_scatter(send, recv, recv_count, t, op, g_comm, ctx().stream)) return nccl_fail(rc, "ncclReduceScatter");
     note_launch("dist_reduce_scatter", recv_count * g_world, (size_t) (g_world + 1) * recv_count * type_size(type));
     return EK_OK;
@@ -192,7 +194,8 @@ int ek_hip_dist_all_gather(int type, void *recv, const void *send, size_t send_c
         return (recv == send || send_count == 0) ? EK_OK : ek_hip_memcpy_device(recv, send, send_count * type_size(type));
     }
     if (send_count == 0) return EK_OK;
-    if (int rc = refuse_while_capturing("ek_hip_dist_all_gather(): RCCL collectives are not recorded into step graphs")) return rc;
+    if (refuse_while_capturing_quiet() != EK_OK)
+        return fail(EK_ERR_UNSUPPORTED, "ek_hip_dist_all_gather(): RCCL collectives are not recorded into step graphs (end the capture and run this step eagerly)");
     if (int rc = g_rccl.all_gather(send, recv, send_count, t, g_comm, ctx().stream)) return nccl_fail(rc, "ncclAllGather");
     note_launch("dist_all_gather", send_count * g_world, (size_t) (g_world + 1) * send_count * type_size(type));
     return EK_OK;

@@ -34,6 +34,8 @@ constexpr int kPgThreads = 1024;
 constexpr int kPgTile = 4 * kPgThreads;
 constexpr int kPgLdsElems = 16384;             // elements staged per workgroup, all buckets together (128 KiB of 8-byte records)
 constexpr uint32_t kNoPage = 0xFFFFFFFFu;
+// words of the third row of the counter block (gtotal[2][.]): what the partition accumulates, the tickets, what the consumers read
+enum { kPgMetaAccum = 0 /* [2] */, kPgMetaFinishTicket = 2, kPgMetaAccumXmax = 3, kPgMetaResult = 4 /* [2] */, kPgMetaResultXmax = 6 };
 // Workgroup w is dispatched to XCD w % 8, and on every box seen so far one XCD runs the same streaming work ~9 % slower than the
 // other seven (profiles/probe_paged_phases_r05.txt): with equal chunks the kernel ends when that XCD ends.  The eight CLASSES
 // w % 8 therefore get shares of the tiles in proportion to WEIGHTS (Q16, 65536 = 1) that live on the device and are fed back by
@@ -141,12 +143,17 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // for an infinite or NaN x, and the reference's reduction then is NaN (dynamic.h:632-650).  The lane is dropped here; that
     // it would have produced a NaN is remembered (one compare per masked-out lane) and applied by the final reduction.
     uint32_t nonfinite_masked = 0;
+    // max |x| over the chunk, as bits (|x| as an integer is monotonic; a NaN or an infinity comes out on top): what bounds the terms
+    // x f'(u) of the adjoint sums when they are formed in fixed point (bucketed_early.hip).  Dropped lanes are included -- the
+    // bound only gets more careful.
+    uint32_t xmax_bits = 0;
     auto decode = [&](const Raw &r, Tile &t) {
         t.on = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             t.ix[j] = (uint32_t) r.pi[j];
             t.xv[j] = r.xv[j];
+            xmax_bits = max(xmax_bits, t.xv[j] & 0x7FFFFFFFu);
             if constexpr (HasMask) {
                 const uint32_t on = ((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u;
                 t.on |= on << j;
@@ -171,6 +178,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             if (e + j < end) {
                 t.ix[j] = (uint32_t) index[e + j];
                 t.xv[j] = __builtin_bit_cast(uint32_t, x[e + j]);
+                xmax_bits = max(xmax_bits, t.xv[j] & 0x7FFFFFFFu);
                 const uint32_t on = (mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u;
                 t.on |= on << j;
                 if constexpr (HasMask) nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[j] & 0x7F800000u) == 0x7F800000u);
@@ -225,21 +233,35 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             done |= (ok && ((fill + 1u) & (Page - 1u)) == 0u) ? 1u << k : 0u;
         }
         if (pending) s_over = 1u;
-        if (done) {
-            // the elements that took the last fill of a page announce it: ONE slot request per lane, all reads in flight together
-            const uint32_t first = atomicAdd(&s_pages, (uint32_t) __popc(done));
-            uint32_t seq[4];
+        // The elements that took the last fill of a page announce it.  ONE slot request per WAVE (round 6): every announcing lane
+        // used to add to s_pages itself -- 64 (128 with 32-element pages) returning atomics on ONE LDS address per tile, which the
+        // LDS serves one after the other (~5 cycles each: the whole difference between 64- and 32-element pages,
+        // profiles/probe_paged_r06.txt).  Now the wave counts its pages with ballots, lane 0 requests the range and every
+        // announcing lane finds its slots by its rank among the wave's announcements.
+        const unsigned long long dm0 = __builtin_amdgcn_ballot_w64((done & 1u) != 0), dm1 = __builtin_amdgcn_ballot_w64((done & 2u) != 0),
+                                 dm2 = __builtin_amdgcn_ballot_w64((done & 4u) != 0), dm3 = __builtin_amdgcn_ballot_w64((done & 8u) != 0);
+        if (dm0 | dm1 | dm2 | dm3) {
+            const uint32_t c0 = (uint32_t) __builtin_popcountll(dm0), c1 = (uint32_t) __builtin_popcountll(dm1),
+                           c2 = (uint32_t) __builtin_popcountll(dm2), c3 = (uint32_t) __builtin_popcountll(dm3);
+            uint32_t wave_first = 0;
+            if ((threadIdx.x & 63) == 0) wave_first = atomicAdd(&s_pages, c0 + c1 + c2 + c3);
+            wave_first = (uint32_t) __builtin_amdgcn_readfirstlane((int) wave_first);
+            if (done) {
+                // rank of this lane's announcements: slot k of every lane before slot k + 1 of any (the order inside a wave is immaterial)
+                auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); };
+                const uint32_t rank[4] = { below(dm0), c0 + below(dm1), c0 + c1 + below(dm2), c0 + c1 + c2 + below(dm3) };
+                uint32_t seq[4];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) seq[k] = ((done >> k) & 1u) ? npg[t.ix[k] >> shift] : 0u;
-            uint32_t ps = first;
+                for (int k = 0; k < 4; ++k) seq[k] = ((done >> k) & 1u) ? npg[t.ix[k] >> shift] : 0u;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if ((done >> k) & 1u) {
-                    const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
-                    jobs[ps - ps0] = b | ((pos >> PS) << 8);
-                    const uint32_t entry = ((seq[k] + (fill >> PS)) << 8) | b;
-                    if (out.wdir_lds) wd[ps] = entry; else out.wdir[wbase + ps] = entry;
-                    ++ps;
+                for (int k = 0; k < 4; ++k) {
+                    if ((done >> k) & 1u) {
+                        const uint32_t ps = wave_first + rank[k];
+                        const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
+                        jobs[ps - ps0] = b | ((pos >> PS) << 8);
+                        const uint32_t entry = ((seq[k] + (fill >> PS)) << 8) | b;
+                        if (out.wdir_lds) wd[ps] = entry; else out.wdir[wbase + ps] = entry;
+                    }
                 }
             }
         }
@@ -358,6 +380,13 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     if constexpr (HasMask) {
         if (nonfinite_masked) atomicOr(out.active + 1, 1u);
     }
+    {
+        // (per wave into the LDS word that announced the overflow rounds -- free by now --, ONE global atomic per workgroup behind the
+        //  barrier below: 4096 atomics on one address cost 30 us of every launch)
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) xmax_bits = max(xmax_bits, (uint32_t) __shfl_xor((int) xmax_bits, d, 64));
+        if ((threadIdx.x & 63) == 0 && xmax_bits) atomicMax(&s_over, xmax_bits);
+    }
     // what is left: one partially filled page per bucket; the workgroup's page lists
     if (threadIdx.x < 64) {
         const int l = threadIdx.x;
@@ -416,6 +445,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // wdir in global memory was written by this workgroup: its stores have to be done, and it is read back past the L1
     if (!out.wdir_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (threadIdx.x == 0 && s_over) atomicMax(out.active + kPgMetaAccumXmax, s_over);
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 1] = wall_clock64();
 #endif
@@ -466,8 +496,6 @@ __device__ __forceinline__ uint32_t pg_block_scan(uint32_t v, uint32_t *wave_tot
 }
 
 constexpr int kPgDirSlices = 4;
-// words of the third row of the counter block (gtotal[2][.]): what the partition accumulates, the tickets, what the consumers read
-enum { kPgMetaAccum = 0 /* [2] */, kPgMetaFinishTicket = 2, kPgMetaResult = 4 /* [2] */ };
 
 // The bucket's page list = the workgroups' lists one after the other (full pages), then the partially filled pages; bucket
 // bases of both lists; pieces for the consumers (as k_bin_scan_buckets: a share of `target_pieces` in proportion to the
@@ -552,6 +580,7 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
     // the accumulators and the page totals are cleared by the last workgroup of the first reducing launch (bucket_finish), after
     // which the block can serve the next object without a fill (csrc/bucketed.hip: MetaRing)
     if (b == 0 && slice == 0 && t < 2) gtotal[2 * kMaxBuckets + kPgMetaResult + t] = gtotal[2 * kMaxBuckets + kPgMetaAccum + t];
+    if (b == 0 && slice == 0 && t == 2) gtotal[2 * kMaxBuckets + kPgMetaResultXmax] = gtotal[2 * kMaxBuckets + kPgMetaAccumXmax];
     // Feedback for the next partition launch (class_w != nullptr only after a launch long enough to say something): a class's speed
     // is its share of the tiles over the mean loop duration of its workgroups; the new weight moves an eighth of the way towards
     // the share that would have made the durations equal, within [0.88, 1.12].  Equal durations are a fixed point; the class means
@@ -596,7 +625,8 @@ struct PagedPlan {
 /// geometry of the paged partition of n elements into n_buckets buckets (4-byte values)
 static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu, bool weighted = false) {
     PagedPlan p;
-    p.page_shift = n_buckets > 128 ? 5 : 6;
+    static const int force_ps = [] { const char *e = getenv("ENOKI_HIP_PAGE_SHIFT"); return e ? atoi(e) : 0; }();     // EXPERIMENT
+    p.page_shift = n_buckets > 128 ? 5 : (force_ps == 5 ? 5 : 6);
     int nb2 = 2;
     while (nb2 < n_buckets) nb2 <<= 1;
     p.cap = (uint32_t) (kPgLdsElems / nb2);

@@ -1,0 +1,100 @@
+// VALU issue-rate probe, round 6: cycles per wave64 instruction per SIMD for the instruction classes of the bucket kernels'
+// inner loops (is `65 vector instructions per element` 130 or 260 cycles of a SIMD?).  One workgroup of 1024 threads per CU
+// (4 waves per SIMD, as k_bucket_pair_forward_adjoint runs), `iters` x 64 instructions of ONE class per wave in 8 independent
+// dependency chains; s_memtime around the loop, summed over the waves.
+#include "ek_internal.h"
+#include <hip/hip_runtime.h>
+
+namespace ek {
+
+#define EK_REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
+
+template <int Variant>
+__global__ __launch_bounds__(1024) void k_probe_valu(unsigned long long *__restrict__ out, int iters, float seed) {
+    float f[8]; unsigned u[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { f[j] = seed + (float) (threadIdx.x + j); u[j] = threadIdx.x * 8u + (unsigned) j; }
+    const float c1 = seed * 0.5f, c2 = seed + 1.0f;
+    const unsigned m = (unsigned) seed | 0x55u;
+    unsigned long long smask = __builtin_amdgcn_ballot_w64((threadIdx.x & 3) != 0), smask2 = 0;
+    const unsigned smask_lo = (unsigned) smask;
+    if (Variant == 7 || Variant == 36) asm volatile("s_mov_b64 vcc, %0" :: "s"(smask) : "vcc");
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) {
+#define EK_ONE(j) \
+            if constexpr (Variant == 0) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j]) : "v"(c1), "v"(c2)); \
+            else if constexpr (Variant == 1) asm volatile("v_add_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 2) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 3) asm volatile("v_add_u32 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 4) asm volatile("v_and_b32 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 5) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 6) asm volatile("v_lshlrev_b32 %0, 1, %0" : "+v"(u[j])); \
+            else if constexpr (Variant == 7) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 8) asm volatile("v_cmp_lt_f32 vcc, %0, %1" :: "v"(f[j]), "v"(c1) : "vcc"); \
+            else if constexpr (Variant == 9) asm volatile("v_cvt_i32_f32 %0, %1" : "=v"(u[j]) : "v"(f[j])); \
+            else if constexpr (Variant == 10) asm volatile("v_cvt_f32_i32 %0, %1" : "=v"(f[j]) : "v"(u[j])); \
+            else if constexpr (Variant == 11) asm volatile("v_mov_b32 %0, %1" : "=v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 12) asm volatile("v_lshl_add_u32 %0, %0, 3, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 13) asm volatile("v_mul_lo_u32 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 14) asm volatile("v_mul_u32_u24 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 15) asm volatile("v_bfe_u32 %0, %0, 3, 13" : "+v"(u[j])); \
+            else if constexpr (Variant == 16) asm volatile("v_and_or_b32 %0, %0, %1, %2" : "+v"(u[j]) : "v"(m), "v"(u[(j + 1) & 7])); \
+            else if constexpr (Variant == 17) asm volatile("v_max_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 18) asm volatile("v_rcp_f32 %0, %0" : "+v"(f[j])); \
+            else if constexpr (Variant == 19) asm volatile("v_pk_fma_f32 %0, %0, %1, %1" : "+v"(*reinterpret_cast<unsigned long long *>(&u[j & 6])) : "v"(*reinterpret_cast<const unsigned long long *>(&f[j & 6]))); \
+            else if constexpr (Variant == 20) asm volatile("v_bfi_b32 %0, %1, %0, %2" : "+v"(u[j]) : "v"(m), "v"(u[(j + 1) & 7])); \
+            else if constexpr (Variant == 21) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 22) asm volatile("v_cmp_eq_u32 vcc, %0, %1" :: "v"(u[j]), "v"(m) : "vcc"); \
+            else if constexpr (Variant == 23) asm volatile("v_mad_u32_u24 %0, %0, %1, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 24) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(u[j]) : "v"(m), "s"(smask)); \
+            else if constexpr (Variant == 25) asm volatile("v_cmp_lt_f32_e64 %0, %1, %2" : "=s"(smask2) : "v"(f[j]), "v"(c1)); \
+            else if constexpr (Variant == 26) asm volatile("v_cmp_lt_f32_e64 %0, %2, %3\n\tv_cndmask_b32_e64 %1, %1, %4, %0" : "=&s"(smask2), "+v"(u[j]) : "v"(f[j]), "v"(c1), "v"(m)); \
+            else if constexpr (Variant == 27) asm volatile("v_or_b32 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 28) asm volatile("v_sub_u32 %0, %0, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 29) asm volatile("v_lshrrev_b32 %0, 3, %0" : "+v"(u[j])); \
+            else if constexpr (Variant == 30) asm volatile("v_min_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 31) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(f[j]) : "v"(c1), "v"(c2)); \
+            else if constexpr (Variant == 32) asm volatile("v_add3_u32 %0, %0, %1, %1" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 33) asm volatile("v_fma_f32 %0, |%0|, -%1, %2" : "+v"(f[j]) : "v"(c1), "v"(c2)); \
+            else if constexpr (Variant == 34) asm volatile("v_and_b32 %0, 0x7fffffff, %0" : "+v"(u[j])); \
+            else if constexpr (Variant == 35) asm volatile("v_mul_f32 %0, 0x3fa2f983, %0" : "+v"(f[j])); \
+            else if constexpr (Variant == 36) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(u[j]) : "v"(m) : ); \
+            else if constexpr (Variant == 37) asm volatile("v_trunc_f32 %0, %0" : "+v"(f[j])); \
+            else if constexpr (Variant == 38) asm volatile("v_rndne_f32 %0, %0" : "+v"(f[j])); \
+            else if constexpr (Variant == 39) asm volatile("v_lshlrev_b64 %0, 3, %0" : "+v"(*reinterpret_cast<unsigned long long *>(&u[j & 6]))); \
+            else if constexpr (Variant == 40) asm volatile("v_cmp_eq_f32 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc" :: "v"(f[j]), "v"(c1), "v"(u[j]), "v"(m) : "vcc"); \
+            else if constexpr (Variant == 41) asm volatile("v_xor_b32 %0, 0x80000000, %0" : "+v"(u[j])); \
+            else if constexpr (Variant == 42) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(u[j])); \
+            else if constexpr (Variant == 43) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "s"(smask_lo));
+            EK_REP8(EK_ONE)
+#undef EK_ONE
+        }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    float fs = 0; unsigned us = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { fs += f[j]; us += u[j]; }
+    if ((threadIdx.x & 63) == 0) atomicAdd(out, t1 - t0);
+    if ((fs == 12345.678f && us == 0xdeadbeefu) || smask2 == 0x123456789ull) out[1] = 1;
+}
+
+} // namespace ek
+
+using namespace ek;
+
+extern "C" EK_API int ek_hip_probe_valu(int variant, int blocks, int iters, unsigned long long *out) {
+    if (int rc = ensure_init()) return rc;
+    Context &cx = ctx();
+#define EK_VV(V) case V: hipLaunchKernelGGL((k_probe_valu<V>), dim3(blocks), dim3(1024), 0, cx.stream, out, iters, 1.5f); break;
+    switch (variant) {
+        EK_VV(0) EK_VV(1) EK_VV(2) EK_VV(3) EK_VV(4) EK_VV(5) EK_VV(6) EK_VV(7) EK_VV(8) EK_VV(9) EK_VV(10) EK_VV(11) EK_VV(12) EK_VV(13)
+        EK_VV(14) EK_VV(15) EK_VV(16) EK_VV(17) EK_VV(18) EK_VV(19) EK_VV(20) EK_VV(21) EK_VV(22) EK_VV(23) EK_VV(24) EK_VV(25) EK_VV(26) EK_VV(27)
+        EK_VV(28) EK_VV(29) EK_VV(30) EK_VV(31) EK_VV(32) EK_VV(33) EK_VV(34) EK_VV(35) EK_VV(36) EK_VV(37) EK_VV(38) EK_VV(39) EK_VV(40) EK_VV(41) EK_VV(42) EK_VV(43)
+        default: return EK_ERR_INVALID;
+    }
+#undef EK_VV
+    EK_LAUNCH_CHECK("probe_valu", (size_t) blocks * 1024 * iters * 64, 0);
+    return EK_OK;
+}

@@ -40,8 +40,13 @@ int scatter_add_binned(T *base, size_t table_size, const Arg<T> &value, const Ar
     if constexpr (std::is_same_v<T, float>) {
         // one pass over (index, value) instead of count + scans + partition (valid int32 indices are non-negative: same bits as uint32)
         static const bool paged = [] { const char *e = getenv("ENOKI_HIP_SCATTER_PAGED"); return !e || atoi(e) != 0; }();
-        if (paged && value.vec && index.vec && scatter_add_paged_applicable(table_size, n))
-            return scatter_add_paged(base, table_size, value.ptr, reinterpret_cast<const uint32_t *>(index.ptr), mask, n);
+        if (paged && value.vec && index.vec && scatter_add_paged_applicable(table_size, n)) {
+            // (what the page partition cannot take -- a shape its plan refuses, no memory for its ~6 n bytes of lists --
+            //  is not a failure of scatter_add: the count / scan / partition path below handled every such call before)
+            const int rc = scatter_add_paged(base, table_size, value.ptr, reinterpret_cast<const uint32_t *>(index.ptr), mask, n);
+            if (rc != EK_ERR_UNSUPPORTED && rc != EK_ERR_OOM) return rc;
+            (void) hipGetLastError();
+        }
     }
     Context &c = ctx();
     const int n_buckets = (int) ((table_size + Bins - 1) / Bins);

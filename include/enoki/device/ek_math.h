@@ -23,6 +23,18 @@ __device__ __forceinline__ int32_t cvtt_i32(float a) {
     return (a > -2147483904.0f && a < 2147483648.0f) ? (int32_t) a : (int32_t) 0x80000000;
 }
 
+// The same for an argument that is never negative (|x| * 4/pi), where the quantity that is USED is (j + 1) & ~1: the native
+// conversion saturates at 0x7fffffff, and (0x7fffffff + 1) & ~1 = 0x80000000 = (0x80000000 + 1) & ~1 -- the octant index of an
+// out-of-range argument comes out the same without the two compares and the select of cvtt_i32 (12 of the ~110 issue cycles of a
+// sincos on gfx950: compares and selects are 4-cycle instructions, profiles/probe_valu_r06.txt).  A NaN converts to 0 instead of
+// 0x80000000: bits 1 and 2 of the octant index (the quadrant swap, the two sign flips) are clear either way, and the NaN reaches
+// the result through the reduction and the polynomials whatever j is -- same bits (tests/test_kernels_gpu.py: specials).
+__device__ __forceinline__ int32_t cvt_sat_i32(float a) {
+    int32_t r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(a));
+    return r;
+}
+
 // Joint sine/cosine, float branch of detail::sincos_approx (array_math.h:261-367):
 // octant index j = (trunc(|x| * 4/pi) + 1) & ~1, three-term Cody-Waite reduction written with
 // plain operators (:320-323, separately rounded), degree-2 polynomials in z = y^2 (:334-340),
@@ -31,7 +43,7 @@ __device__ __forceinline__ int32_t cvtt_i32(float a) {
 template <bool Sin, bool Cos>
 __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) {
     float xa = __builtin_fabsf(x);
-    int32_t j = cvtt_i32(xa * 1.2732395447351626862f);
+    int32_t j = cvt_sat_i32(xa * 1.2732395447351626862f);
     j = (int32_t) (((uint32_t) j + 1u) & ~1u);
     float y = (float) j;
 
@@ -44,7 +56,10 @@ __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) 
     y = t;
 
     float z = y * y;
-    if (xa == __builtin_inff()) z = u2f(0xffffffffu);   // z |= eq(xa, inf)  (:331)
+    // z |= eq(xa, inf)  (:331) -- a branch that no wave takes on finite data instead of a select per element
+    if (__builtin_expect(__builtin_amdgcn_ballot_w64(xa == __builtin_inff()) != 0, 0)) {
+        if (xa == __builtin_inff()) z = u2f(0xffffffffu);
+    }
 
     float z2 = z * z;
     float s = __builtin_fmaf(z2, -1.9515295891e-4f, __builtin_fmaf(z, 8.3321608736e-3f, -1.6666654611e-1f)) * z;
@@ -74,7 +89,9 @@ __device__ __forceinline__ float exp_f32(float x) {
                              __builtin_fmaf(x4, __builtin_fmaf(xr, 1.9875691500e-4f, 1.3981999507e-3f),
                                             __builtin_fmaf(xr, 1.6666665459e-1f, 5.0000001201e-1f)));
     z = __builtin_fmaf(z, xr * xr, xr + 1.0f);
-    int32_t ni = cvtt_i32(n);
+    // (saturating conversion: wherever n leaves the int32 range the overflow / underflow select below discards r, and a NaN gives
+    //  (0 + 0x7f) << 23 = 1.0 = (0x80000000 + 0x7f) << 23 -- same bits as the cvttps2dq convention without its compares)
+    int32_t ni = cvt_sat_i32(n);
     float r = z * u2f(((uint32_t) ni + 0x7fu) << 23);
     return overflow ? __builtin_inff() : (underflow ? 0.0f : r);
 }

@@ -1275,7 +1275,9 @@ template <typename Value_> struct HIPArray : ArrayTag {
             // the sum of one half of an unevaluated sincos pair whose other half is still held: the shape of a derivative that
             // the tape will ask for (see ek_hip_bucketed_pair_create_hinted)
             const bool adjoint_expected = op == EK_HSUM && keep_op != EK_COPY && ek_hip_bucketed_early_pair(map_op, keep_op);
-            ek_hip_bucketed *b = u->bucketed(adjoint_expected ? (unsigned) EK_BUCKETED_HINT_ADJOINT : 0u);
+            // (sin / cos: both functions bounded by 1 -- the adjoint sums can then be formed in 64-bit fixed point, see enoki_hip.h)
+            const bool bounded = (map_op == EK_SIN || map_op == EK_COS) && (keep_op == EK_SIN || keep_op == EK_COS);
+            ek_hip_bucketed *b = u->bucketed(adjoint_expected ? (unsigned) EK_BUCKETED_HINT_ADJOINT | (bounded ? (unsigned) EK_BUCKETED_HINT_BOUNDED : 0u) : 0u);
             if (!b) return false;
             // somebody else can still ask for u (the cos(u) of the derivative, a user handle): keep it in bucket order
             const int keep = u->ref_count > held_by_consumer ? 1 : 0;

@@ -277,10 +277,19 @@ EK_API int ek_hip_map_gathered(int arity, int op, int type, void *out, const ek_
  *                 read back -- and the scatter_add call only folds the per-piece tables.  Any other sequence of calls on a
  *                 hinted object works as on an unhinted one.  Ignored for tables beyond 256 half-size buckets and when
  *                 ek_hip_set_tuning("early_adjoint", 0).
+ *                 hints |= EK_BUCKETED_HINT_BOUNDED (round 6): the pair of functions is bounded by 1 (sin / cos).  The partition is
+ *                 then made with buckets of a QUARTER of the size and the two sums per table entry are formed in 64-bit FIXED
+ *                 POINT by non-returning LDS atomics (scale from the bound 1, from max |x| -- which the partition records -- and
+ *                 from n, so that no sum can leave 63 bits): no locks, and sums that do not depend on the order of the additions --
+ *                 the gradients are BIT-IDENTICAL from run to run (the reference's scatter_add is fixed-order: dynamic.h:517-534).
+ *                 A term of 24 significant bits is exact from 2^-13 of its bound upwards; below that its error is < 2^-37 of the
+ *                 bound at 64 Mi elements.  Not finite max |x|, or a NaN term (non-finite table entries, an overflowing u): the
+ *                 pieces concerned run under the exchange locks as without the hint.  Ignored beyond 256 quarter-size buckets
+ *                 (K > 1 Mi entries) and under ENOKI_HIP_EARLY_SUMS=locks.
  * Values of u are bit-identical to the element-order kernels; reductions and sums differ by the ORDER of their fp
  * additions only (unspecified, like ek_hip_reduce / ek_hip_scatter_add mode 0). */
 typedef struct ek_hip_bucketed ek_hip_bucketed;
-enum { EK_BUCKETED_HINT_ADJOINT = 1 };
+enum { EK_BUCKETED_HINT_ADJOINT = 1, EK_BUCKETED_HINT_BOUNDED = 2 };
 EK_API int ek_hip_bucketed_applicable(int type, int index_type, size_t table_size, size_t n);
 EK_API int ek_hip_bucketed_pair_create(int type, int index_type, int op, const void *table_a, const void *table_c,
                                        size_t table_size, const void *x, const void *index, size_t n, ek_hip_bucketed **out);

@@ -1,6 +1,6 @@
 // A program written with the reference's names -- <enoki/cuda.h>, CUDAArray<float>, DiffArray<CUDAArray<float>>, cuda_eval(),
 // <enoki/dynamic.h>, DynamicArray<Packet<float>> -- compiled against this repository's headers without an edit
-// (include/enoki/cuda.h, include/enoki/dynamic.h).  Run by tests/test_reference_sources_gpu.py.
+// (compat/enoki/cuda.h, compat/enoki/dynamic.h: the opt-in include root, -I compat).  Run by tests/test_reference_sources_gpu.py.
 #include <enoki/cuda.h>
 #include <enoki/dynamic.h>
 #include <enoki/autodiff.h>

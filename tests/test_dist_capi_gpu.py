@@ -55,6 +55,38 @@ def test_world_of_one(with_rccl):
 
 
 @pytest.mark.gpu
+def test_collective_under_capture_is_unsupported_and_the_capture_stays_valid():
+    """include/enoki_hip.h: the RCCL collectives refuse to be recorded into a step graph with EK_ERR_UNSUPPORTED -- the code a caller
+    treats as `end the capture, run this step eagerly` -- not with a hard EK_ERR_INVALID"""
+    from enoki_amd import capi
+    capi.init()
+    lib = capi.lib
+    ident = (ctypes.c_char * 128)()
+    capi.check(lib.ek_hip_dist_unique_id(ident))
+    capi.check(lib.ek_hip_dist_init(0, 1, ident))            # (a real communicator: without one a world of one is a no-op, capture or not)
+    try:
+        a = np.arange(4096, dtype=np.float32)
+        buf = capi.Buf.from_numpy(a)
+        out = capi.Buf(np.float32, 4096)
+        capi.check(lib.ek_hip_graph_begin())
+        try:
+            rc = lib.ek_hip_dist_all_reduce(buf.ek, 0, ctypes.c_void_p(buf.ptr), SZ(buf.n))
+            assert rc == -2, f"EK_ERR_UNSUPPORTED expected under capture, got {rc}"
+            assert lib.ek_hip_dist_reduce_scatter(buf.ek, 0, ctypes.c_void_p(out.ptr), ctypes.c_void_p(buf.ptr), SZ(4096)) == -2
+            assert lib.ek_hip_dist_all_gather(buf.ek, ctypes.c_void_p(out.ptr), ctypes.c_void_p(buf.ptr), SZ(4096)) == -2
+        finally:
+            g = ctypes.c_void_p()
+            capi.check(lib.ek_hip_graph_end(ctypes.byref(g)))          # the capture itself is intact
+        if g.value:
+            capi.check(lib.ek_hip_graph_destroy(g))
+        capi.check(lib.ek_hip_dist_all_reduce(buf.ek, 0, ctypes.c_void_p(buf.ptr), SZ(buf.n)))        # and eagerly it runs
+        capi.sync()
+        assert np.array_equal(buf.numpy(), a)
+    finally:
+        capi.check(lib.ek_hip_dist_finalize())
+
+
+@pytest.mark.gpu
 def test_one_rccl_copy_per_process():
     """csrc/dist.cpp loads RCCL at run time.  In a python process torch has its own librccl.so mapped (the copy torch.distributed
     talks to): the C-ABI exchange must reuse THAT copy instead of mapping /opt/rocm/lib/librccl.so next to it -- two RCCL runtimes

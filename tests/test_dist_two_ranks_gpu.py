@@ -54,17 +54,24 @@ def test_two_ranks_match_one(workload, tmp_path):
     assert two["value"] > 0 and two["scaling"] == "strong"
 
 
-def test_default_is_weak_scaling():
-    """`python bench.py --gpus 2` without further options: every rank owns --n elements of an array of 2 x --n (the per-GPU size of
-    the metric), the line says so, and the loss is that of the 2n-element problem"""
+def test_default_is_the_contracts_strong_scaling_with_the_weak_result_alongside():
+    """`python bench.py --gpus 2` without further options measures what BASELINE.md section 4 / north_star state -- --n elements IN
+    TOTAL, n / 2 per rank, `"scaling": "strong"` -- and carries the weak measurement of the same run (every rank owns --n elements of
+    an array of 2 x --n) as the labelled sub-record `weak`; `--scaling weak` makes that the `value` (round 5's default)"""
     n = 1 << 21
     two = run_bench("cfg3b", n, 2, 0)
-    assert two["scaling"] == "weak" and two["config"]["elements_per_gpu"] == n and two["config"]["elements_total"] == 2 * n
+    assert two["scaling"] == "strong" and two["config"]["elements_per_gpu"] == n // 2 and two["config"]["elements_total"] == n
     assert two["config"]["collectives_per_step"] == 1
-    truth, bound = truth_y("cfg3b", 2 * n)
+    truth, bound = truth_y("cfg3b", n)
     assert abs(two["result_y"] - truth) <= bound, (two["result_y"], truth, bound)
+    w = two["weak"]
+    assert w["scaling"] == "weak" and w["elements_per_gpu"] == n and w["elements_total"] == 2 * n and w["value"] > 0
     one = run_bench("cfg3b", n, 1, 0)
-    assert one["scaling"] == "weak" and one["config"]["elements_total"] == n
+    assert one["scaling"] == "strong" and one["config"]["elements_total"] == n and one["weak"] is None
+    weak = run_bench("cfg3b", n, 2, 0, extra=["--scaling", "weak"])
+    assert weak["scaling"] == "weak" and weak["config"]["elements_per_gpu"] == n and weak["config"]["elements_total"] == 2 * n
+    truth2, bound2 = truth_y("cfg3b", 2 * n)
+    assert abs(weak["result_y"] - truth2) <= bound2, (weak["result_y"], truth2, bound2)
 
 
 def check_scattered_gradients(n, tmp_path):

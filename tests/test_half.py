@@ -25,13 +25,13 @@ def test_every_reference_header_name_is_includable(tmp_path):
     """<enoki/fwd.h>, <enoki/array_traits.h>, <enoki/array_router.h>, ... <enoki/array_math.h> and the type headers in one
     translation unit (tests/cpp/headers_host.cpp): compile-only"""
     root = os.path.dirname(HERE)
-    out = subprocess.run(["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", "-c", os.path.join(HERE, "cpp", "headers_host.cpp"),
+    out = subprocess.run(["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", f"-I{os.path.join(root, 'compat')}", "-c", os.path.join(HERE, "cpp", "headers_host.cpp"),
                           "-o", str(tmp_path / "headers_host.o")], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
 
 
 def test_dynamic_array_alias_is_opt_in(tmp_path):
-    """include/enoki/dynamic.h: the reference's DynamicArray<Packet<T>> is a HOST array (reference dynamic.h:54-60).  Using the name
+    """compat/enoki/dynamic.h (opt-in include root): the reference's DynamicArray<Packet<T>> is a HOST array (reference dynamic.h:54-60).  Using the name
     without -DENOKI_HIP_DYNAMIC_IS_DEVICE must stop the compilation with an explanation; with it the name is HIPArray<T>."""
     root = os.path.dirname(HERE)
     src = tmp_path / "dyn.cpp"
@@ -41,7 +41,7 @@ def test_dynamic_array_alias_is_opt_in(tmp_path):
                    "static_assert(std::is_same_v<FloatX, enoki::HIPArray<float>>);\n"
                    "#endif\n"
                    "size_t f() { return sizeof(FloatX); }\n")
-    cmd = ["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", "-fsyntax-only", str(src)]
+    cmd = ["g++", "-std=c++17", f"-I{os.path.join(root, 'include')}", f"-I{os.path.join(root, 'compat')}", "-fsyntax-only", str(src)]
     off = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert off.returncode != 0 and "ENOKI_HIP_DYNAMIC_IS_DEVICE" in off.stderr and "HOST array" in off.stderr, off.stderr[-2000:]
     on = subprocess.run(cmd + ["-DENOKI_HIP_DYNAMIC_IS_DEVICE=1"], capture_output=True, text=True, timeout=600)

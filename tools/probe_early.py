@@ -10,6 +10,8 @@ logn = int(sys.argv[1]) if len(sys.argv) > 1 else 26
 logk = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 label = sys.argv[3] if len(sys.argv) > 3 else ""
 n, K = 1 << logn, 1 << logk
+# PROBE_HINTS=1: the adjoint hint alone (half-size buckets, exchange locks); default 3: + bounded (quarter-size buckets, fixed point)
+HINTS = int(os.environ.get("PROBE_HINTS", capi.Bucketed.HINT_ADJOINT | capi.Bucketed.HINT_BOUNDED))
 rng = np.random.default_rng(0)
 A = capi.Buf.from_numpy(rng.uniform(-1, 1, K).astype(np.float32))
 B = capi.Buf.from_numpy(rng.uniform(-1, 1, K).astype(np.float32))
@@ -18,7 +20,7 @@ idx = capi.Buf.from_numpy(rng.integers(0, K, n).astype(np.uint32))
 
 
 def step():
-    b = capi.Bucketed("fmadd", A, x, B, idx, hints=capi.Bucketed.HINT_ADJOINT)
+    b = capi.Bucketed("fmadd", A, x, B, idx, hints=HINTS)
     y = b.reduce("hsum", "sin", keep=True, keep_op="cos")
     gA, gB = capi.fill(np.float32, 0, K), capi.fill(np.float32, 0, K)
     b.scatter_add([gB, gA], [("cos", 0, False), ("cos", 0, True)])

@@ -110,7 +110,9 @@ if mode in ("time", "all"):
     idx_h = rng.integers(0, K, n).astype(np.uint32)
     x_h = rng.uniform(-1, 1, n).astype(np.float32)
     print(f"# timing: {n >> 20} Mi elements, K = {K >> 20} Mi, 128 buckets of 8 Ki; 14 B/elt")
-    r = Run(idx_h, x_h, K, 13)
+    shift_t = int(os.environ.get("PROBE_SHIFT", 13))          # 13: 128 buckets of 8 Ki entries (64-element pages); 12: 256 buckets of 4 Ki (32-element pages)
+    r = Run(idx_h, x_h, K, shift_t)
+    print(f"# shift {shift_t}: {r.nb} buckets, pages of {1 << r.ps} elements, cap {r.cap}, {r.slots} page slots per workgroup")
     for nts in (0, 0):
         for d in (0, 1):
             f = lambda: r.launch(nts, d)
@@ -137,6 +139,7 @@ if mode in ("time", "all"):
         for wv in (0, 1):
             print(f"  wave {wv}: core cycles per tile (mean over workgroups) " + ", ".join(f"{names[k]} {d[:, wv, k].mean() / tiles:7.1f}" for k in range(7)) + f"  total {d[:, wv, :7].sum(axis=1).mean() / tiles:8.1f}")
     for name, gen in (("zipf(1.3)", lambda: (np.minimum(rng.zipf(1.3, n), K) - 1).astype(np.uint32)), ("one index", lambda: np.full(n, 777, np.uint32))):
+        if os.environ.get("PROBE_SKIP_SKEW"): break
         r2 = Run(gen(), x_h, K, 13)
         f = lambda: r2.launch(0, 1)
         ms = statistics.median(hiprt.time_region(st, f, iters=5, warmup=1) for _ in range(3))
