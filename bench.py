@@ -678,7 +678,7 @@ class Bench:
         y_val = float(out["y"].numpy()[0])
         if packer and out.get("reduced"):
             y_val = float(out["reduced"][0].item())
-        if self.args.dump_gradients and workload == "cfg3b" and workload == self.args.workload:
+        if self.args.dump_gradients and workload == "cfg3b" and workload == self.args.workload and not getattr(self, "side_record", False):
             os.makedirs(self.args.dump_gradients, exist_ok=True)
             if packer and out.get("reduced") and len(out["reduced"]) == 3:
                 hA, hB = out["reduced"][1], out["reduced"][2]
@@ -910,7 +910,8 @@ def main():
     weak = None
     if b.world > 1 and not b.weak and not args.no_weak:
         bw = Bench(args, scaling="weak")
-        rw = bw.run(args.workload, args.steps, args.warmup, 0, pre_warm_s=min(args.pre_warm_s, 0.3))
+        bw.side_record = True               # (no gradient dump: --dump-gradients is about the record's problem)
+        rw = bw.run(args.workload, args.steps, args.warmup, 1, pre_warm_s=min(args.pre_warm_s, 0.3))
         weak = {"scaling": "weak", "value": rw["value"], "unit": "Gelem/s", "ms_per_step": rw["ms_per_step"],
                 "elements_per_gpu": bw.n, "elements_total": bw.N,
                 "note": "every GPU owns --n elements of an array of N x --n; all elements of all ranks / max-over-ranks time; same kernels, same exchange"}

@@ -823,6 +823,12 @@ __global__ __launch_bounds__(256) void k_fold_fixed_pieces(FoldTargets<float, C>
         for (int j = 0; j < kFoldPerLane; ++j) if (j < lim) old[j] = target[k0 + j];
     }
     const uint32_t xm = xmax_bits[0];
+    if (p1 - p0 == 1u) {
+        // a bucket that is one piece wrote floats whatever it ran under (bucketed_early.hip): no mode to wait for, a quarter of the bytes
+        const float *slotf = reinterpret_cast<const float *>(partials + ((size_t) p0 << shift));
+#pragma unroll
+        for (int j = 0; j < kFoldPerLane; ++j) if (j < lim) fsum[j] = __builtin_nontemporal_load(slotf + local + j);
+    } else
     for (uint32_t p = p0; p < p1; ++p) {
         // (mode and sums requested together: the 64-bit words of a slot can be read whatever the piece wrote into it)
         const long long *slot = partials + ((size_t) p << shift);

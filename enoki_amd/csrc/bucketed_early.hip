@@ -357,7 +357,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     // (|u| >= 1.8e19: its reduced argument squared overflows, array_math.h:331-340) -- decided from max |a|, max |c| of the staged
     // slice and max |x|, once per piece, not per element; or the piece is larger than the scale allows for.  Such pieces run under
     // the exchange locks like every piece of round 5; piece_mode tells the fold which kind of table a piece wrote.
-    [[maybe_unused]] bool locks = !Fixed;
+    [[maybe_unused]] bool locks = !Fixed, single = false;
     [[maybe_unused]] FixedScale fixed0{}, fixed1{};
     if constexpr (Fixed) {
         const uint32_t xm = (uint32_t) __builtin_amdgcn_readfirstlane((int) xmax_bits[0]);
@@ -377,7 +377,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         const float ubound = __uint_as_float(am) * __uint_as_float(xm) + __uint_as_float(cm);
         const size_t piece_pages = (size_t) (range.f1 - range.f0) + (range.p1 - range.p0);
         if (am >= 0x7F800000u || cm >= 0x7F800000u || !(ubound < 1.0e18f) || (piece_pages << PS) >> (62 - S0)) locks = true;
-        if (threadIdx.x == 0) piece_mode[blockIdx.x] = locks ? 1u : 0u;
+        // a bucket that is ONE piece (the rule at the headline size: 256 buckets, 256 pieces): its sums are final -- converted here,
+        // exactly as the fold would convert them, and written as floats (half the bytes out and back in; mode 1 like a piece under locks)
+        single = bl.piece_prefix[bucket + 1] - bl.piece_prefix[bucket] == 1u;
+        if (threadIdx.x == 0) piece_mode[blockIdx.x] = (locks || single) ? 1u : 0u;
         if (!locks) {
             fixed0 = fixed_scale(S0, xm, false);
             fixed1 = fixed_scale(S0, xm, true);
@@ -423,7 +426,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         if constexpr (Fixed) {
             // the piece's slot holds Bins 64-bit sums (fixed point), or Bins floats at its start (a piece under locks)
             long long *out64 = reinterpret_cast<long long *>(table_partials) + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
-            if (!locks) {
+            if (!locks && single) {
+                const long long *sums = reinterpret_cast<const long long *>(tables) + (size_t) c * Bins;
+                const float back = c ? fixed1.back : fixed0.back;
+                T *outf = reinterpret_cast<T *>(out64);
+                for (int j = threadIdx.x; j < Bins; j += kBucketThreads) outf[j] = (float) sums[j] * back;
+            } else if (!locks) {
                 const long long *sums = reinterpret_cast<const long long *>(tables) + (size_t) c * Bins;
                 for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out64[j] = sums[j];
             } else {
