@@ -126,8 +126,8 @@ def parse():
     return ap.parse_args(json.loads(forwarded)) if forwarded is not None else ap.parse_args()
 
 
-PMC_FILE = os.path.join("profiles", "rocprof_pmc_r05.txt")
-KSTATS_FILE = os.path.join("profiles", "rocprof_kernel_stats_r05.txt")
+PMC_FILE = os.path.join("profiles", "rocprof_pmc_r06.txt")
+KSTATS_FILE = os.path.join("profiles", "rocprof_kernel_stats_r06.txt")
 
 
 def kernels_sha16():
@@ -207,12 +207,17 @@ def rocprof_step_sum_us():
     return total if stamp == kernels_sha16() and total > 0 else None
 
 
-def trace_check(ms_per_step, live_sum_ms, headline):
+def trace_check(ms_per_step, live_sum_ms, headline, profiled_ms_per_step=None):
     """Does the per-kernel evidence add up to the claimed step?  sum(kernels) <= step <= 1.1 x sum, for the live event deltas of
-    this run and -- on the headline at 64 Mi elements -- for the committed rocprofv3 trace (tools/profile_r05.sh takes it after
+    this run and -- on the headline at 64 Mi elements -- for the committed rocprofv3 trace (tools/profile_r06.sh takes it after
     the same pre-warm)."""
-    rep = {"ms_per_step": round(ms_per_step, 4), "sum_live_kernel_ms": round(live_sum_ms, 4),
-           "step_over_live_sum": round(ms_per_step / live_sum_ms, 3) if live_sum_ms > 0 else None}
+    # step_over_live_sum: the event deltas against the wall time of the very steps they were taken in (recording an event per launch
+    # slows those steps a little: against the unprofiled step the sum used to come out LARGER than what it decomposes);
+    # timed_step_over_live_sum: against the timed (unprofiled) step
+    prof_ms = profiled_ms_per_step if profiled_ms_per_step else ms_per_step
+    rep = {"ms_per_step": round(ms_per_step, 4), "profiled_ms_per_step": round(prof_ms, 4), "sum_live_kernel_ms": round(live_sum_ms, 4),
+           "step_over_live_sum": round(prof_ms / live_sum_ms, 3) if live_sum_ms > 0 else None,
+           "timed_step_over_live_sum": round(ms_per_step / live_sum_ms, 3) if live_sum_ms > 0 else None}
     rp = rocprof_step_sum_us() if headline else None
     if rp:
         rep["sum_rocprof_kernel_ms"] = round(rp * 1e-3, 4)
@@ -633,6 +638,8 @@ class Bench:
             replay = "eager (python-driven steps: tape walk, allocator, one launch call per kernel); graph_ms_per_step is the hipGraph replay of the same step"
         gelem_s = units / (ms_per_step * 1e-3) / 1e9
         # per-kernel timing of the same step (run eagerly): one HIP event per launch on the library stream
+        torch.cuda.synchronize()
+        t_prof = time.perf_counter()
         ek.hip_profile_begin()
         for _ in range(profile_steps):
             step()
@@ -640,6 +647,7 @@ class Bench:
         if packer:
             packer.wait_all()
         torch.cuda.synchronize()
+        profiled_ms_per_step = (time.perf_counter() - t_prof) / max(profile_steps, 1) * 1e3     # (the steps the event deltas below decompose)
         kernels = []
         for k in prof:
             if k["launches"] == 0 or k["elements"] // k["launches"] < 1024:
@@ -661,11 +669,15 @@ class Bench:
             rp_us, rp_src = rocprof_avg_us(dom["kernel"]) if self.n == (1 << 26) else (None, "kernel-trace summaries are taken at 64 Mi elements per GPU")
             frac_live = achieved / (HBM_PEAK_TBS * 1000)
             frac_rocprof = dom["bytes_per_launch"] / (rp_us * 1e-6) / 1e9 / (HBM_PEAK_TBS * 1000) if rp_us else None
+            # frac: the PROFILE-derived figure -- the algorithmic bytes of a launch over the kernel's average duration in the committed
+            # rocprofv3 kernel trace of THIS tree (no gaps; only when the trace's kernels_sha16 stamp equals this tree's) -- and the live
+            # one otherwise; frac_live: from the HIP-event deltas of this run (a delta includes the gap to the previous launch)
+            frac = frac_rocprof if frac_rocprof else frac_live
+            if frac_rocprof:
+                achieved = dom["bytes_per_launch"] / (rp_us * 1e-6) / 1e9
             roofline = {"bound": "hbm", "kernel": dom["kernel"], "achieved": round(achieved, 1),
-                        "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(frac_live, 4),
-                        # frac / frac_live: from HIP-event deltas of this run (they include the gap to the previous launch);
-                        # frac_rocprof: the same algorithmic bytes over the kernel's average duration in the committed rocprofv3
-                        # kernel trace of this tree (no gaps)
+                        "peak": HBM_PEAK_TBS * 1000, "unit": "GB/s", "frac": round(frac, 4),
+                        "frac_source": "rocprofv3 kernel trace of this tree (" + KSTATS_FILE + ")" if frac_rocprof else "live HIP-event deltas (no stamped trace of this tree)",
                         "frac_live": round(frac_live, 4), "frac_rocprof": round(frac_rocprof, 4) if frac_rocprof else None,
                         "rocprof_avg_us": rp_us, "rocprof_source": rp_src,
                         "traffic": traffic, "traffic_source": traffic_source,
@@ -695,7 +707,7 @@ class Bench:
             # one in-order stream do not overlap, so sum(live event deltas, which include the launch gaps) ~ the step; the
             # committed rocprofv3 trace (no gaps) must not exceed it
             live_sum = sum(k["total_ms"] for k in prof) / profile_steps
-            roofline["trace_check"] = trace_check(ms_per_step, live_sum, self.n == (1 << 26) and workload == "cfg3b")
+            roofline["trace_check"] = trace_check(ms_per_step, live_sum, self.n == (1 << 26) and workload == "cfg3b", profiled_ms_per_step)
         return {"value": round(gelem_s, 3), "ms_per_step": round(ms_per_step, 4), "eager_ms_per_step": round(eager_ms, 4),
                 "graph_ms_per_step": round(graph_ms, 4) if graph_ms is not None else None, "result_y": y_val,
                 "roofline": roofline, "collectives_per_step": coll_per_step,

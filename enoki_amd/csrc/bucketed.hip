@@ -1005,12 +1005,78 @@ bool scatter_add_paged_applicable(size_t table_size, size_t n) {
 // ---- partition of an index array alone (ek_hip_index_partition_*) ------------------------------------------------------
 struct IndexPartition {
     ek_hip_index_partition_info info{};
-    void *meta = nullptr, *local = nullptr;
+    void *meta = nullptr, *local = nullptr, *lists = nullptr;
     ~IndexPartition() {
-        for (void *p : { meta, local })
+        for (void *p : { meta, local, lists })
             if (p) ek_hip_free(p);
     }
 };
+
+// The index array alone through the single-pass page partition (k_page_partition<.., IndexOnly>): idx 4 (+ mask 1) read, 4 written per
+// entry, two launches -- instead of count + two scans + partition (idx read twice: 14 B per entry, four launches; 124 us of cfg4's 245 us
+// step at 32 Mi rays).  4-byte records give every one of up to 256 buckets two 64-element pages of LDS.
+static int index_partition_run_paged(IndexPartition *ip, const uint32_t *index, const Arg<uint8_t> &mask, size_t n, int n_buckets, int shift) {
+    RoctxRange range("enoki-hip: index partition (pages)");
+    Context &c = ctx();
+    const PagedPlan p = paged_plan(n, n_buckets, c.num_cu, false, true);
+    if (p.W > 1024) return fail(EK_ERR_UNSUPPORTED, "ek_hip_index_partition_create(): %u workgroups", p.W);
+    const size_t meta_words = 3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
+    if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t), &ip->meta)) return rc;
+    if (int rc = ek_hip_malloc((p.page_slots << p.page_shift) * sizeof(uint32_t), &ip->local)) return rc;
+    const size_t part_entries = (size_t) p.W * n_buckets;
+    if (int rc = ek_hip_malloc((p.page_slots + part_entries + 1) * sizeof(uint32_t), &ip->lists)) return rc;
+    uint32_t *gtotal = (uint32_t *) ip->meta, *base_full = gtotal + 3 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1,
+             *piece_prefix = base_part + kMaxBuckets + 1;
+    uint32_t *glist_full = (uint32_t *) ip->lists, *glist_part = glist_full + p.page_slots;
+    Scratch work;
+    if (int rc = work.alloc((2 * p.page_slots + 3 * part_entries) * sizeof(uint32_t))) return rc;
+    PagedOut<float> out{};
+    out.lp = nullptr;
+    out.xp = (float *) ip->local;
+    out.wdir = (uint32_t *) work.ptr;
+    out.wlist = out.wdir + p.page_slots;
+    out.cnt_full = out.wlist + p.page_slots;
+    out.loff = out.cnt_full + part_entries;
+    out.part = out.loff + part_entries;
+    out.gtotal = gtotal;
+    out.active = gtotal + 2 * kMaxBuckets + kPgMetaAccum;
+    out.lo = 0; out.span = (uint32_t) std::min<size_t>(ip->info.range, 0xFFFFFFFFu);
+    out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = kPgWeightBand;
+    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    note_launch("index_partition_meta_clear", 3 * kMaxBuckets, 3 * kMaxBuckets * sizeof(uint32_t));
+    const int vec_ok = aligned16(index) && arg_aligned(mask);
+    auto launch = [&](auto kernel) -> int {
+        size_t lds = p.lds;
+        out.wdir_lds = 0;
+        hipFuncAttributes attr;
+        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess &&
+            attr.sharedSizeBytes + p.lds + (size_t) p.slots * sizeof(uint32_t) <= (size_t) 160 * 1024) {
+            lds += (size_t) p.slots * sizeof(uint32_t);
+            out.wdir_lds = 1;
+        }
+        if (int rc = allow_big_lds(kernel, lds)) return rc;
+        hipLaunchKernelGGL(kernel, dim3(p.W), dim3(kPgThreads), lds, c.stream, out, index, mask, (const float *) nullptr, n, p.chunk, n_buckets,
+                           shift, p.cap, p.slots, vec_ok);
+        return EK_OK;
+    };
+    int rc;
+    if (p.page_shift == 6) rc = mask.vec ? launch(k_page_partition<float, uint32_t, 6, true, true>) : launch(k_page_partition<float, uint32_t, 6, false, true>);
+    else rc = mask.vec ? launch(k_page_partition<float, uint32_t, 5, true, true>) : launch(k_page_partition<float, uint32_t, 5, false, true>);
+    if (rc) return rc;
+    EK_LAUNCH_CHECK("index_partition", n, n * 2 * sizeof(uint32_t) + arg_bytes(mask, n));
+    hipLaunchKernelGGL(k_page_directory, dim3(n_buckets, kPgDirSlices), dim3(256), 0, c.stream, glist_full, glist_part, base_full,
+                       base_part, piece_prefix, gtotal, (const uint32_t *) out.cnt_full, (const uint32_t *) out.loff,
+                       (const uint32_t *) out.part, (const uint32_t *) out.wlist, p.W, p.slots, n_buckets, 0u,
+                       (uint32_t *) nullptr, (const uint32_t *) nullptr, kPgWeightBand);
+    EK_LAUNCH_CHECK("index_partition_directory", p.page_slots, 2 * p.page_slots * sizeof(uint32_t));
+    ip->info.bucket_base = base_full;
+    ip->info.local = (const uint32_t *) ip->local;
+    ip->info.page_shift = p.page_shift;
+    ip->info.pages_full = glist_full;
+    ip->info.pages_part = glist_part;
+    ip->info.part_base = base_part;
+    return EK_OK;
+}
 
 template <typename I, int Shift>
 static int index_partition_run(IndexPartition *ip, const I *index, const Arg<uint8_t> &mask, size_t n, int n_buckets) {
@@ -1309,6 +1375,16 @@ int ek_hip_index_partition_create(int index_type, const void *index, const ek_op
     ip->info.range = range;
     int rc;
     const uint32_t *idx = (const uint32_t *) index;          // valid int32 indices are non-negative: same bits as uint32
+    // large inputs over many buckets: the single-pass page partition (ENOKI_HIP_INDEX_PAGED=0: count / scan / partition as before)
+    static const bool paged = [] { const char *e = getenv("ENOKI_HIP_INDEX_PAGED"); return !e || atoi(e) != 0; }();
+    if (paged && ctx().tuning.bucket_ordered && n >= ((size_t) 1 << 20) && n < ((size_t) 1 << 30) && ip->info.n_buckets >= 32) {
+        rc = index_partition_run_paged(ip, idx, m, n, ip->info.n_buckets, shift);
+        if (rc == EK_OK) { *out = ip; return EK_OK; }
+        if (rc != EK_ERR_UNSUPPORTED && rc != EK_ERR_OOM) { delete ip; return rc; }
+        (void) hipGetLastError();
+        for (void **q : { &ip->meta, &ip->local, &ip->lists }) { if (*q) ek_hip_free(*q); *q = nullptr; }
+        ip->info.page_shift = 0;
+    }
     switch (shift) {
         case 12: rc = index_partition_run<uint32_t, 12>(ip, idx, m, n, ip->info.n_buckets); break;
         case 14: rc = index_partition_run<uint32_t, 14>(ip, idx, m, n, ip->info.n_buckets); break;

@@ -74,14 +74,18 @@ template <typename T> struct PagedOut {
 using PgV4 = __attribute__((ext_vector_type(4))) uint32_t;
 using PgV2 = __attribute__((ext_vector_type(2))) uint32_t;
 
-template <typename T, typename I, int PS, bool HasMask>
+// IndexOnly (round 6): no value stream -- the pages carry the bucket-local INDEX as a 32-bit word (the value pages' slots), records of
+// 4 bytes (twice the buffer per bucket: 256 buckets keep 64-element pages), nothing is written to the 16-bit pages.  This is the
+// partition of an index array alone (ek_hip_index_partition_*: cfg4's pixel permutation): idx 4 read, 4 written per element.
+template <typename T, typename I, int PS, bool HasMask, bool IndexOnly = false>
 __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, const I *__restrict__ index, Arg<uint8_t> mask,
                                                                const T *__restrict__ x, size_t n, size_t chunk, int n_buckets,
                                                                int shift, uint32_t cap, uint32_t slots, int vec_ok) {
     static_assert(sizeof(T) == 4, "pages carry 4-byte values");
     constexpr uint32_t Page = 1u << PS;
     extern __shared__ __align__(16) unsigned char lds_raw[];
-    unsigned long long *rec = reinterpret_cast<unsigned long long *>(lds_raw);                                // [n_buckets][cap] of {value bits, local index}
+    using Rec = std::conditional_t<IndexOnly, uint32_t, unsigned long long>;
+    Rec *rec = reinterpret_cast<Rec *>(lds_raw);                                // [n_buckets][cap] of {value bits, local index} (IndexOnly: the local index alone)
     __shared__ uint32_t cnt[kMaxBuckets];      // origin << 16 | fill of the bucket's circular buffer
     __shared__ uint32_t npg[kMaxBuckets];      // full pages written so far per bucket
     __shared__ uint32_t dbase[kMaxBuckets];    // overflowing bucket: first of its directly written pages (slot within the round)
@@ -127,14 +131,23 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     if (threadIdx.x == 0) { s_pages = 0; s_jobs = 0; s_over = 0; }
     __syncthreads();
 
+    auto make_rec = [&](uint32_t xv, uint32_t local) -> Rec {
+        if constexpr (IndexOnly) return local; else return (unsigned long long) xv | ((unsigned long long) local << 32);
+    };
     const uint8_t sm = mask.vec ? uint8_t(0) : arg_scalar(mask);
     // a tile as it arrives: nothing is decoded before the tile is placed, so that two tiles of loads stay in flight
+    // IndexOnly places TWO tiles per round (8 elements per lane, 8192 per workgroup): 256 buckets of 128 records take 32 arrivals per
+    // round on average, and the two barriers, the waits in front of them and the page announcements are paid once for twice the
+    // elements (the index partition moves 9 B per element: it is bound by the rounds, not by HBM).  With a value stream a bucket's
+    // buffer is half as deep in elements per bucket and round -- one tile per round as before.
+    constexpr int NT = IndexOnly ? 2 : 1, NE = 4 * NT;
     struct Raw { I pi[4]; PgV4 xv; uint32_t m; };
-    struct Tile { uint32_t ix[4], xv[4], on; };          // xv: the values' bits
+    struct Tile { uint32_t ix[NE], xv[NE], on; };          // xv: the values' bits;  elements 4 s .. 4 s + 3: sub-tile s
     auto load_raw = [&](size_t base, Raw &r) {
         const size_t e = base + (size_t) threadIdx.x * 4;
         load4<I, true>(index + e, r.pi);
-        r.xv = __builtin_nontemporal_load(reinterpret_cast<const PgV4 *>(x + e));
+        if constexpr (!IndexOnly) r.xv = __builtin_nontemporal_load(reinterpret_cast<const PgV4 *>(x + e));
+        else r.xv = PgV4{ 0u, 0u, 0u, 0u };
         if constexpr (HasMask) r.m = __builtin_nontemporal_load(reinterpret_cast<const uint32_t *>(mask.ptr + e));
         else r.m = 0;
     };
@@ -147,43 +160,44 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // x f'(u) of the adjoint sums when they are formed in fixed point (bucketed_early.hip).  Dropped lanes are included -- the
     // bound only gets more careful.
     uint32_t xmax_bits = 0;
-    auto decode = [&](const Raw &r, Tile &t) {
-        t.on = 0;
+    auto decode = [&](const Raw &r, Tile &t, int sub) {
+        const int o = 4 * sub;
+        if (sub == 0) t.on = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t.ix[j] = (uint32_t) r.pi[j];
-            t.xv[j] = r.xv[j];
-            xmax_bits = max(xmax_bits, t.xv[j] & 0x7FFFFFFFu);
+            t.ix[o + j] = (uint32_t) r.pi[j];
+            t.xv[o + j] = r.xv[j];
+            if constexpr (!IndexOnly) xmax_bits = max(xmax_bits, t.xv[o + j] & 0x7FFFFFFFu);
             if constexpr (HasMask) {
                 const uint32_t on = ((r.m >> (8 * j)) & 0xFFu) ? 1u : 0u;
-                t.on |= on << j;
-                nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[j] & 0x7F800000u) == 0x7F800000u);
+                t.on |= on << (o + j);
+                if constexpr (!IndexOnly) nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[o + j] & 0x7F800000u) == 0x7F800000u);
             }
         }
-        if constexpr (!HasMask) t.on = sm ? 0xFu : 0u;
+        if constexpr (!HasMask) t.on |= (sm ? 0xFu : 0u) << o;
         // indices outside the table (or outside this slice of it) are dropped like masked-out lanes: an out-of-range index must
         // not reach another bucket's counters (what it gathers / scatters is unspecified anyway, cuda.h:845-905)
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t.ix[j] -= win_lo;
-            if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
+            t.ix[o + j] -= win_lo;
+            if (t.ix[o + j] >= win_span) { t.on &= ~(1u << (o + j)); t.ix[o + j] = 0; }
         }
     };
-    auto load_ragged = [&](size_t base, Tile &t) {
+    auto load_ragged = [&](size_t base, Tile &t, int sub) {
         const size_t e = base + (size_t) threadIdx.x * 4;
-        t.on = 0;
+        const int o = 4 * sub;
+        if (sub == 0) t.on = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            t.ix[j] = 0; t.xv[j] = 0;
+            t.ix[o + j] = 0; t.xv[o + j] = 0;
             if (e + j < end) {
-                t.ix[j] = (uint32_t) index[e + j];
-                t.xv[j] = __builtin_bit_cast(uint32_t, x[e + j]);
-                xmax_bits = max(xmax_bits, t.xv[j] & 0x7FFFFFFFu);
+                t.ix[o + j] = (uint32_t) index[e + j];
+                if constexpr (!IndexOnly) { t.xv[o + j] = __builtin_bit_cast(uint32_t, x[e + j]); xmax_bits = max(xmax_bits, t.xv[o + j] & 0x7FFFFFFFu); }
                 const uint32_t on = (mask.vec ? mask.ptr[e + j] : sm) ? 1u : 0u;
-                t.on |= on << j;
-                if constexpr (HasMask) nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[j] & 0x7F800000u) == 0x7F800000u);
-                t.ix[j] -= win_lo;
-                if (t.ix[j] >= win_span) { t.on &= ~(1u << j); t.ix[j] = 0; }
+                t.on |= on << (o + j);
+                if constexpr (HasMask && !IndexOnly) nonfinite_masked |= (on ^ 1u) & (uint32_t) ((t.xv[o + j] & 0x7F800000u) == 0x7F800000u);
+                t.ix[o + j] -= win_lo;
+                if (t.ix[o + j] >= win_span) { t.on &= ~(1u << (o + j)); t.ix[o + j] = 0; }
             }
         }
     };
@@ -198,11 +212,15 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             if (jb == kNoPage) continue;
             const uint32_t src = ((jb & 0xFFu) << cap_shift) + ((jb >> 8) << PS) + 4 * i;
             const size_t at = ((wbase + ps0 + j) << PS) + 4 * i;
-            const PgV4 r01 = *reinterpret_cast<const PgV4 *>(rec + src), r23 = *reinterpret_cast<const PgV4 *>(rec + src + 2);
-            const PgV4 vx = { r01[0], r01[2], r23[0], r23[2] };
-            const PgV2 vl = { r01[1] | (r01[3] << 16), r23[1] | (r23[3] << 16) };
-            *reinterpret_cast<PgV4 *>(out.xp + at) = vx;
-            *reinterpret_cast<PgV2 *>(out.lp + at) = vl;
+            if constexpr (IndexOnly) {
+                *reinterpret_cast<PgV4 *>(out.xp + at) = *reinterpret_cast<const PgV4 *>(rec + src);
+            } else {
+                const PgV4 r01 = *reinterpret_cast<const PgV4 *>(rec + src), r23 = *reinterpret_cast<const PgV4 *>(rec + src + 2);
+                const PgV4 vx = { r01[0], r01[2], r23[0], r23[2] };
+                const PgV2 vl = { r01[1] | (r01[3] << 16), r23[1] | (r23[3] << 16) };
+                *reinterpret_cast<PgV4 *>(out.xp + at) = vx;
+                *reinterpret_cast<PgV2 *>(out.lp + at) = vl;
+            }
         }
     };
 
@@ -219,16 +237,16 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // elements go STRAIGHT to global memory (4- and 2-byte stores, as the contiguous-run partition writes all of its output),
     // the rest is staged once the buffer has been written out.
     auto process = [&](const Tile &t) {
-        uint32_t old[4], pending = 0, done = 0;
+        uint32_t old[NE], pending = 0, done = 0;
         EK_PG_T(0);                       // waiting for the tile's loads + decode
 #pragma unroll
-        for (int k = 0; k < 4; ++k) old[k] = ((t.on >> k) & 1u) ? atomicAdd(&cnt[t.ix[k] >> shift], 1u) : 0u;
+        for (int k = 0; k < NE; ++k) old[k] = ((t.on >> k) & 1u) ? atomicAdd(&cnt[t.ix[k] >> shift], 1u) : 0u;
         // staged without a branch: an element that found its bucket's buffer full (or is masked out) writes to a spare record
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < NE; ++k) {
             const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
             const bool on = (t.on >> k) & 1u, ok = on && fill < cap;
-            rec[ok ? ((b << cap_shift) | pos) : spare] = (unsigned long long) t.xv[k] | ((unsigned long long) (t.ix[k] & lowmask) << 32);
+            rec[ok ? ((b << cap_shift) | pos) : spare] = make_rec(t.xv[k], t.ix[k] & lowmask);
             pending |= (on && !ok) ? 1u << k : 0u;
             done |= (ok && ((fill + 1u) & (Page - 1u)) == 0u) ? 1u << k : 0u;
         }
@@ -238,25 +256,28 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         // LDS serves one after the other (~5 cycles each: the whole difference between 64- and 32-element pages,
         // profiles/probe_paged_r06.txt).  Now the wave counts its pages with ballots, lane 0 requests the range and every
         // announcing lane finds its slots by its rank among the wave's announcements.
-        const unsigned long long dm0 = __builtin_amdgcn_ballot_w64((done & 1u) != 0), dm1 = __builtin_amdgcn_ballot_w64((done & 2u) != 0),
-                                 dm2 = __builtin_amdgcn_ballot_w64((done & 4u) != 0), dm3 = __builtin_amdgcn_ballot_w64((done & 8u) != 0);
-        if (dm0 | dm1 | dm2 | dm3) {
-            const uint32_t c0 = (uint32_t) __builtin_popcountll(dm0), c1 = (uint32_t) __builtin_popcountll(dm1),
-                           c2 = (uint32_t) __builtin_popcountll(dm2), c3 = (uint32_t) __builtin_popcountll(dm3);
+        unsigned long long dm[NE];
+        uint32_t before[NE + 1];
+        before[0] = 0;
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            dm[k] = __builtin_amdgcn_ballot_w64(((done >> k) & 1u) != 0);
+            before[k + 1] = before[k] + (uint32_t) __builtin_popcountll(dm[k]);
+        }
+        if (before[NE]) {
             uint32_t wave_first = 0;
-            if ((threadIdx.x & 63) == 0) wave_first = atomicAdd(&s_pages, c0 + c1 + c2 + c3);
+            if ((threadIdx.x & 63) == 0) wave_first = atomicAdd(&s_pages, before[NE]);
             wave_first = (uint32_t) __builtin_amdgcn_readfirstlane((int) wave_first);
             if (done) {
                 // rank of this lane's announcements: slot k of every lane before slot k + 1 of any (the order inside a wave is immaterial)
                 auto below = [](unsigned long long m) { return __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u)); };
-                const uint32_t rank[4] = { below(dm0), c0 + below(dm1), c0 + c1 + below(dm2), c0 + c1 + c2 + below(dm3) };
-                uint32_t seq[4];
+                uint32_t seq[NE];
 #pragma unroll
-                for (int k = 0; k < 4; ++k) seq[k] = ((done >> k) & 1u) ? npg[t.ix[k] >> shift] : 0u;
+                for (int k = 0; k < NE; ++k) seq[k] = ((done >> k) & 1u) ? npg[t.ix[k] >> shift] : 0u;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < NE; ++k) {
                     if ((done >> k) & 1u) {
-                        const uint32_t ps = wave_first + rank[k];
+                        const uint32_t ps = wave_first + before[k] + below(dm[k]);
                         const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu, pos = ((old[k] >> 16) + fill) & (cap - 1u);
                         jobs[ps - ps0] = b | ((pos >> PS) << 8);
                         const uint32_t entry = ((seq[k] + (fill >> PS)) << 8) | b;
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         write_out(ps0, ps1 - ps0);
         if (!over) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NE; ++k) {
                 if ((done >> k) & 1u) {
                     const uint32_t b = t.ix[k] >> shift;
                     atomicAdd(&cnt[b], (Page << 16) - Page);          // origin + Page, fill - Page
@@ -298,13 +319,17 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
             }
         } else {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NE; ++k) {
                 if ((pending >> k) & 1u) {
                     const uint32_t b = t.ix[k] >> shift, fill = old[k] & 0xFFFFu;
                     if (fill < dtail[b]) {
                         const size_t at = ((wbase + ps0 + dbase[b]) << PS) + (fill - cap);
-                        reinterpret_cast<uint32_t *>(out.xp)[at] = t.xv[k];
-                        out.lp[at] = (uint16_t) (t.ix[k] & lowmask);
+                        if constexpr (IndexOnly) {
+                            reinterpret_cast<uint32_t *>(out.xp)[at] = t.ix[k] & lowmask;
+                        } else {
+                            reinterpret_cast<uint32_t *>(out.xp)[at] = t.xv[k];
+                            out.lp[at] = (uint16_t) (t.ix[k] & lowmask);
+                        }
                         pending &= ~(1u << k);
                     } else {
                         old[k] = (old[k] & 0xFFFF0000u) | (fill - dtail[b]);     // its place in the emptied buffer
@@ -325,11 +350,11 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         EK_PG_T(6);                       // barrier 2
         if (pending) {
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
+            for (int k = 0; k < NE; ++k) {
                 if ((pending >> k) & 1u) {
                     const uint32_t b = t.ix[k] >> shift;
                     const uint32_t slot = (b << cap_shift) | (((old[k] >> 16) + (old[k] & 0xFFFFu)) & (cap - 1u));
-                    rec[slot] = (unsigned long long) t.xv[k] | ((unsigned long long) (t.ix[k] & lowmask) << 32);
+                    rec[slot] = make_rec(t.xv[k], t.ix[k] & lowmask);
                 }
             }
         }
@@ -344,30 +369,43 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // (Tiles handed out round robin -- at every moment the W workgroups reading W consecutive 16-KiB stretches instead of W
     // stretches a whole chunk apart -- were measured in round 5: 188-191 us against 185-186, profiles/probe_paged_r05.txt.)
     size_t base = begin;
-    const size_t ntiles = vec_ok ? (end - begin) / kPgTile : 0;
-    if (ntiles > 0) {
-        Raw buf0, buf1;
-        load_raw(begin, buf0);
-        if (ntiles > 1) load_raw(begin + kPgTile, buf1);
-        for (size_t i = 0; i < ntiles; i += 2) {
+    const size_t ntiles = vec_ok ? (end - begin) / kPgTile : 0, ngroups = ntiles / NT;        // rounds of NT whole tiles
+    if (ngroups > 0) {
+        Raw buf0[NT], buf1[NT];
+#pragma unroll
+        for (int sub = 0; sub < NT; ++sub) load_raw(begin + (size_t) sub * kPgTile, buf0[sub]);
+        if (ngroups > 1) {
+#pragma unroll
+            for (int sub = 0; sub < NT; ++sub) load_raw(begin + (size_t) (NT + sub) * kPgTile, buf1[sub]);
+        }
+        for (size_t i = 0; i < ngroups; i += 2) {
             {
                 Tile t;
-                decode(buf0, t);
-                if (i + 2 < ntiles) load_raw(begin + (i + 2) * kPgTile, buf0);
+#pragma unroll
+                for (int sub = 0; sub < NT; ++sub) decode(buf0[sub], t, sub);
+                if (i + 2 < ngroups) {
+#pragma unroll
+                    for (int sub = 0; sub < NT; ++sub) load_raw(begin + ((i + 2) * NT + sub) * kPgTile, buf0[sub]);
+                }
                 process(t);
             }
-            if (i + 1 < ntiles) {
+            if (i + 1 < ngroups) {
                 Tile t;
-                decode(buf1, t);
-                if (i + 3 < ntiles) load_raw(begin + (i + 3) * kPgTile, buf1);
+#pragma unroll
+                for (int sub = 0; sub < NT; ++sub) decode(buf1[sub], t, sub);
+                if (i + 3 < ngroups) {
+#pragma unroll
+                    for (int sub = 0; sub < NT; ++sub) load_raw(begin + ((i + 3) * NT + sub) * kPgTile, buf1[sub]);
+                }
                 process(t);
             }
         }
-        base = begin + ntiles * kPgTile;
+        base = begin + ngroups * NT * kPgTile;
     }
-    for (; base < end; base += kPgTile) {
+    for (; base < end; base += (size_t) NT * kPgTile) {
         Tile t;
-        load_ragged(base, t);
+#pragma unroll
+        for (int sub = 0; sub < NT; ++sub) load_ragged(base + (size_t) sub * kPgTile, t, sub);
         process(t);
     }
     if (out.class_stamp && threadIdx.x == 0) out.class_stamp[w] = (uint32_t) (wall_clock64() - stamp0);
@@ -385,7 +423,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         //  barrier below: 4096 atomics on one address cost 30 us of every launch)
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) xmax_bits = max(xmax_bits, (uint32_t) __shfl_xor((int) xmax_bits, d, 64));
-        if ((threadIdx.x & 63) == 0 && xmax_bits) atomicMax(&s_over, xmax_bits);
+        if (!IndexOnly && (threadIdx.x & 63) == 0 && xmax_bits) atomicMax(&s_over, xmax_bits);
     }
     // what is left: one partially filled page per bucket; the workgroup's page lists
     if (threadIdx.x < 64) {
@@ -445,7 +483,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // wdir in global memory was written by this workgroup: its stores have to be done, and it is read back past the L1
     if (!out.wdir_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (threadIdx.x == 0 && s_over) atomicMax(out.active + kPgMetaAccumXmax, s_over);
+    if (!IndexOnly && threadIdx.x == 0 && s_over) atomicMax(out.active + kPgMetaAccumXmax, s_over);
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 1] = wall_clock64();
 #endif
@@ -623,13 +661,13 @@ struct PagedPlan {
 };
 
 /// geometry of the paged partition of n elements into n_buckets buckets (4-byte values)
-static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu, bool weighted = false) {
+static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu, bool weighted = false, bool index_only = false) {
     PagedPlan p;
-    static const int force_ps = [] { const char *e = getenv("ENOKI_HIP_PAGE_SHIFT"); return e ? atoi(e) : 0; }();     // EXPERIMENT
-    p.page_shift = n_buckets > 128 ? 5 : (force_ps == 5 ? 5 : 6);
+    // (4-byte records: twice as many fit, 256 buckets keep two 64-element pages each)
+    p.page_shift = n_buckets > (index_only ? 256 : 128) ? 5 : 6;
     int nb2 = 2;
     while (nb2 < n_buckets) nb2 <<= 1;
-    p.cap = (uint32_t) (kPgLdsElems / nb2);
+    p.cap = (uint32_t) ((index_only ? 2 * kPgLdsElems : kPgLdsElems) / nb2);
     const size_t tiles = (n + kPgTile - 1) / kPgTile;
     p.W = (uint32_t) std::max<size_t>(1, std::min<size_t>((size_t) num_cu, tiles));
     p.chunk = ((tiles + p.W - 1) / p.W) * kPgTile;
@@ -644,7 +682,7 @@ static inline PagedPlan paged_plan(size_t n, int n_buckets, int num_cu, bool wei
         p.slots = (uint32_t) (((most * kPgTile) >> p.page_shift) + (size_t) n_buckets);
     }
     p.page_slots = (size_t) p.W * p.slots;
-    p.lds = ((size_t) n_buckets * p.cap + 2) * 8;
+    p.lds = ((size_t) n_buckets * p.cap + 2) * (index_only ? 4 : 8);
     return p;
 }
 

@@ -45,6 +45,9 @@ namespace enoki {
 namespace detail {
     template <size_t N> struct ThroughSources { const float *ptr[N]; };
 
+    /// the paged layout of ek_hip_index_partition_info (page_shift == 0: one contiguous run per bucket)
+    struct ThroughPages { int page_shift; const uint32_t *full, *part, *part_base; };
+
     template <typename Func, size_t N, size_t... Is>
     __device__ __forceinline__ auto through_eval(const Func &f, const float (&v)[N], std::index_sequence<Is...>) {
         using Packet = Array<float, 1>;
@@ -83,7 +86,7 @@ namespace detail {
                                                                 int shift, int vec_ok, float fill_value,
                                                                 const uint32_t *__restrict__ bucket_base,
                                                                 const uint32_t *__restrict__ local, ThroughState *__restrict__ state,
-                                                                volatile unsigned long long *__restrict__ host) {
+                                                                volatile unsigned long long *__restrict__ host, ThroughPages pages) {
         extern __shared__ uint32_t through_lds[];
         typedef float __attribute__((ext_vector_type(4))) float4v;
         __shared__ unsigned wave_count[16];
@@ -96,26 +99,59 @@ namespace detail {
         __syncthreads();
         const uint32_t begin = bucket_base[blockIdx.x], end = bucket_base[blockIdx.x + 1];
         constexpr int U = 16;
-        // (a) which target entries does an active element point at (Counters: how many of them)?
-        for (uint32_t base = begin; base < end; base += U * 1024) {
-            uint32_t l[U];
+        // Every bucket-local index of this bucket once, many loads per lane in flight.  Contiguous run: 16 x 4 bytes per lane and
+        // trip.  Pages (round 6, the single-pass partition): 2^page_shift / 4 lanes share a page, one 16-byte vector each, four
+        // pages per group of lanes and trip; the partially filled pages (entry = page << 6 | count - 1) behind them under a
+        // lane predicate.
+        auto for_each_local = [&](auto &&fn) {
+            if (pages.page_shift == 0) {
+                for (uint32_t base = begin; base < end; base += U * 1024) {
+                    uint32_t l[U];
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                const uint32_t i = base + k * 1024 + threadIdx.x;
-                l[k] = i < end ? __builtin_nontemporal_load(local + i) : ~0u;
-            }
+                    for (int k = 0; k < U; ++k) {
+                        const uint32_t i = base + k * 1024 + threadIdx.x;
+                        l[k] = i < end ? __builtin_nontemporal_load(local + i) : ~0u;
+                    }
 #pragma unroll
-            for (int k = 0; k < U; ++k) {
-                if (l[k] == ~0u) continue;
-                if constexpr (Counters) {
-                    const uint32_t sh = (l[k] & 3u) * 8u;
-                    const uint32_t old = atomicAdd(&through_lds[l[k] >> 2], 1u << sh);
-                    if (((old >> sh) & 255u) == 255u) gave_up = 1u;
-                } else {
-                    atomicOr(&marked[l[k] >> 5], 1u << (l[k] & 31u));
+                    for (int k = 0; k < U; ++k)
+                        if (l[k] != ~0u) fn(l[k]);
+                }
+            } else {
+                typedef uint32_t __attribute__((ext_vector_type(4))) uint4v;
+                const uint32_t lx = (1u << pages.page_shift) / 4u, groups = 1024u / lx, g = threadIdx.x / lx, i = threadIdx.x % lx;
+                constexpr int P = 4;
+                for (uint32_t q0 = begin + g; q0 < end; q0 += P * groups) {
+                    uint32_t pg[P];
+                    uint4v v[P];
+#pragma unroll
+                    for (int k = 0; k < P; ++k) pg[k] = q0 + k * groups < end ? __builtin_nontemporal_load(pages.full + q0 + k * groups) : ~0u;
+#pragma unroll
+                    for (int k = 0; k < P; ++k)
+                        if (pg[k] != ~0u) v[k] = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(local + ((size_t) pg[k] << pages.page_shift) + 4u * i));
+#pragma unroll
+                    for (int k = 0; k < P; ++k)
+                        if (pg[k] != ~0u) { fn(v[k][0]); fn(v[k][1]); fn(v[k][2]); fn(v[k][3]); }
+                }
+                const uint32_t pb = pages.part_base[blockIdx.x], pe = pages.part_base[blockIdx.x + 1];
+                for (uint32_t q = pb + g; q < pe; q += groups) {
+                    const uint32_t e = __builtin_nontemporal_load(pages.part + q), cnt = (e & 63u) + 1u;
+                    const uint4v v = __builtin_nontemporal_load(reinterpret_cast<const uint4v *>(local + ((size_t) (e >> 6) << pages.page_shift) + 4u * i));
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (4u * i + j < cnt) fn(v[j]);
                 }
             }
-        }
+        };
+        // (a) which target entries does an active element point at (Counters: how many of them)?
+        for_each_local([&](uint32_t l) {
+            if constexpr (Counters) {
+                const uint32_t sh = (l & 3u) * 8u;
+                const uint32_t old = atomicAdd(&through_lds[l >> 2], 1u << sh);
+                if (((old >> sh) & 255u) == 255u) gave_up = 1u;
+            } else {
+                atomicOr(&marked[l >> 5], 1u << (l & 31u));
+            }
+        });
         __syncthreads();
         unsigned count = 0;
         const bool abandon = Counters && gave_up;
@@ -216,17 +252,7 @@ namespace detail {
             if constexpr (!Counters) {
                 __syncthreads();
                 // (c) count(hit & mask): the active elements whose entry was hit
-                for (uint32_t base = begin; base < end; base += U * 1024) {
-                    uint32_t l[U];
-#pragma unroll
-                    for (int k = 0; k < U; ++k) {
-                        const uint32_t i = base + k * 1024 + threadIdx.x;
-                        l[k] = i < end ? local[i] : ~0u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < U; ++k)
-                        if (l[k] != ~0u) count += (hit[l[k] >> 5] >> (l[k] & 31u)) & 1u;
-                }
+                for_each_local([&](uint32_t l) { count += (hit[l >> 5] >> (l & 31u)) & 1u; });
             }
         }
 #pragma unroll
@@ -318,7 +344,8 @@ namespace detail {
             if (lds > 65536)
                 (void) hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
             hipLaunchKernelGGL(kernel, dim3((unsigned) info.n_buckets), dim3(1024), lds, stream, f, out, src, range, info.shift, vec_ok,
-                               fill_value, info.bucket_base, info.local, scratch.state, scratch.host);
+                               fill_value, info.bucket_base, info.local, scratch.state, scratch.host,
+                               ThroughPages{ info.page_shift, info.pages_full, info.pages_part, info.part_base });
             // algorithmic bytes: the bucket lists once (bitmaps: twice), the sources once, the target once
             rc = ek_hip_note_launch("vectorize_through", n, (counters ? 4 : 8) * n + (N + 1) * 4 * range);
             if (!rc) rc = ek_hip_sync();

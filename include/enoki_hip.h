@@ -359,6 +359,12 @@ typedef struct {
     size_t n, range;
     const uint32_t *bucket_base;      /* n_buckets + 1 entries; bucket_base[n_buckets] = number of active entries */
     const uint32_t *local;            /* bucket-local indices in bucket order */
+    /* round 6 -- page_shift != 0: the PAGED layout (single-pass partition, csrc/ek_paged.h; large inputs).  `local` then holds
+       pages of 2^page_shift bucket-local indices; bucket b owns the complete pages pages_full[bucket_base[b] .. bucket_base[b + 1])
+       and the partially filled ones pages_part[part_base[b] .. part_base[b + 1]) (entry = page << 6 | count - 1).  The order of
+       the elements inside a bucket is unspecified.  page_shift == 0: one contiguous run per bucket as before. */
+    int page_shift;
+    const uint32_t *pages_full, *pages_part, *part_base;
 } ek_hip_index_partition_info;
 EK_API int ek_hip_index_partition_create(int index_type, const void *index, const ek_operand *mask, size_t n, size_t range,
                                          ek_hip_index_partition **out);

@@ -396,7 +396,8 @@ def test_skewed_indices_cos_pair_is_exact(capi, hinted):
 class _PartInfo(__import__("ctypes").Structure):
     import ctypes as _c
     _fields_ = [("shift", _c.c_int), ("n_buckets", _c.c_int), ("n", _c.c_size_t), ("range", _c.c_size_t),
-                ("bucket_base", _c.c_void_p), ("local", _c.c_void_p)]
+                ("bucket_base", _c.c_void_p), ("local", _c.c_void_p),
+                ("page_shift", _c.c_int), ("pages_full", _c.c_void_p), ("pages_part", _c.c_void_p), ("part_base", _c.c_void_p)]
 
 
 @pytest.mark.parametrize("range_,shift", [(3000, 12), (1 << 20, 12), ((1 << 20) + 1, 14), (1 << 22, 14), ((1 << 22) + 5, 17),
@@ -422,6 +423,7 @@ def test_index_partition(capi, range_, shift, masked):
     info = _PartInfo()
     capi.check(capi.lib.ek_hip_index_partition_get(h, ctypes.byref(info)))
     assert info.shift == shift and info.n_buckets == -(-range_ // (1 << shift)) and info.n == n and info.range == range_
+    assert info.page_shift == 0          # (below 2^20 entries: one contiguous run per bucket)
     base = capi.Buf(np.uint32, info.n_buckets + 1, own=False, ptr=info.bucket_base).numpy()
     active = idx[mask != 0] if masked else idx
     assert base[0] == 0 and base[-1] == active.size
@@ -434,6 +436,52 @@ def test_index_partition(capi, range_, shift, masked):
     for b in np.flatnonzero(counts)[:: max(1, info.n_buckets // 16)]:
         lo, hi = int(base[b]), int(base[b + 1])
         assert np.array_equal(np.sort(local[lo:hi]), np.sort(want[lo:hi])), b
+    capi.check(capi.lib.ek_hip_index_partition_destroy(h))
+
+
+@pytest.mark.parametrize("range_,shift", [((1 << 22) + 5, 17), (1 << 25, 17), ((1 << 25) + 1, 19), (1 << 19, 12)])
+@pytest.mark.parametrize("masked", [False, True])
+def test_index_partition_paged(capi, range_, shift, masked):
+    """large inputs over at least 32 buckets go through the single-pass page partition (round 6): `local` holds pages of 2^page_shift
+    bucket-local indices, a bucket owns a list of complete pages and a list of partially filled ones -- together exactly the
+    multiset of its active entries' local indices"""
+    import ctypes
+    n = (1 << 21) + 4321
+    rng = np.random.default_rng(range_ % 1000 + masked)
+    idx = rng.integers(0, range_, n).astype(np.uint32)
+    idx[: n // 10] = idx[n // 10: 2 * (n // 10)]                   # duplicates
+    idx[5] = np.uint32(range_ + 3)                                  # out of range: dropped like a masked-out entry
+    mask = (rng.integers(0, 4, n) != 0).astype(np.uint8) if masked else None
+    di = up(capi, idx)
+    dm = up(capi, mask) if masked else None
+    om = capi.operand(dm if masked else True, np.uint8)
+    h = ctypes.c_void_p()
+    capi.check(capi.lib.ek_hip_index_partition_create(capi.U32, ctypes.c_void_p(di.ptr), ctypes.byref(om), ctypes.c_size_t(n),
+                                                      ctypes.c_size_t(range_), ctypes.byref(h)))
+    info = _PartInfo()
+    capi.check(capi.lib.ek_hip_index_partition_get(h, ctypes.byref(info)))
+    nb = info.n_buckets
+    assert info.shift == shift and nb == -(-range_ // (1 << shift)) and info.page_shift in (5, 6), (info.shift, nb, info.page_shift)
+    page = 1 << info.page_shift
+    base = capi.Buf(np.uint32, nb + 1, own=False, ptr=info.bucket_base).numpy().astype(np.int64)
+    pbase = capi.Buf(np.uint32, nb + 1, own=False, ptr=info.part_base).numpy().astype(np.int64)
+    full = capi.Buf(np.uint32, max(int(base[-1]), 1), own=False, ptr=info.pages_full).numpy()
+    part = capi.Buf(np.uint32, max(int(pbase[-1]), 1), own=False, ptr=info.pages_part).numpy()
+    slots = int(max(full[: int(base[-1])].max(initial=0), (part[: int(pbase[-1])] >> 6).max(initial=0))) + 1
+    local = capi.Buf(np.uint32, slots * page, own=False, ptr=info.local).numpy()
+    keep = (idx < range_) & ((mask != 0) if masked else True)
+    active = idx[keep]
+    counts = np.bincount(active >> shift, minlength=nb)
+    order = np.argsort(active >> shift, kind="stable")
+    want = (active[order] & ((1 << shift) - 1)).astype(np.uint32)
+    starts = np.concatenate([[0], np.cumsum(counts)])
+    for b in range(nb):
+        got = [local[int(pg) * page: int(pg) * page + page] for pg in full[base[b]: base[b + 1]]]
+        got += [local[int(e >> 6) * page: int(e >> 6) * page + int(e & 63) + 1] for e in part[pbase[b]: pbase[b + 1]]]
+        got = np.sort(np.concatenate(got)) if got else np.zeros(0, np.uint32)
+        assert got.size == counts[b], (b, got.size, counts[b])
+        if b % max(1, nb // 24) == 0:
+            assert np.array_equal(got, np.sort(want[starts[b]: starts[b + 1]])), b
     capi.check(capi.lib.ek_hip_index_partition_destroy(h))
 
 
