@@ -25,7 +25,7 @@ UNARY = {n: i for i, n in enumerate(
     ["neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
      "popcnt", "lzcnt", "tzcnt", "sign", "copy", "tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh",
      "acosh", "atanh", "cbrt", "erf", "erfc", "erfinv", "i0e", "dawson", "erfi", "lgamma", "tgamma", "rcp_sqr", "rsqrt_sqr",
-     "rsqrt_cube"])}
+     "rsqrt_cube", "sec_sqr", "sech_sqr", "rcp_1p_sqr"])}
 BINARY = {n: i for i, n in enumerate(
     ["add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
      "atan2", "pow", "fmod", "ldexp"])}

@@ -169,6 +169,16 @@ constexpr inline bool unary_fusable(int op) {
     }
 }
 
+// ... and what a CHAIN may carry on top of those (ek_hip_reduce_chain / ek_hip_map_chain / ek_hip_reduce_map, round 6): the second-wave
+// functions whose derivative is one map of the same argument, and those derivative maps
+constexpr inline bool unary_chainable(int op) {
+    switch (op) {
+        case EK_TAN: case EK_TANH: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_SEC_SQR: case EK_SECH_SQR: case EK_RCP_1P_SQR:
+            return true;
+        default: return unary_fusable(op);
+    }
+}
+
 // one f32 value stream through the single-pass page partition (bucketed.hip): 20 B per pair instead of 26
 bool scatter_add_paged_applicable(size_t table_size, size_t n);
 int scatter_add_paged(float *base, size_t table_size, const float *value, const uint32_t *index, const Arg<uint8_t> &mask, size_t n);

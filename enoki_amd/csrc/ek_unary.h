@@ -33,7 +33,7 @@ template <int Op, typename T> constexpr bool unary_supported() {
         case EK_NEG: case EK_ABS: return !is_mask<T>;
         case EK_NOT: return !is_fp<T>;
         case EK_SQRT: case EK_RCP: case EK_RSQRT: case EK_FLOOR: case EK_CEIL: case EK_ROUND: case EK_TRUNC:
-        case EK_SIGN: case EK_RCP_SQR: case EK_RSQRT_SQR: case EK_RSQRT_CUBE: return is_fp<T>;
+        case EK_SIGN: case EK_RCP_SQR: case EK_RSQRT_SQR: case EK_RSQRT_CUBE: case EK_SEC_SQR: case EK_SECH_SQR: case EK_RCP_1P_SQR: return is_fp<T>;
         case EK_SIN: case EK_COS: case EK_EXP: case EK_LOG:
         case EK_TAN: case EK_COT: case EK_ASIN: case EK_ACOS: case EK_ATAN: case EK_SINH: case EK_COSH: case EK_TANH:
         case EK_ASINH: case EK_ACOSH: case EK_ATANH: case EK_CBRT: return is_fp<T>;
@@ -70,6 +70,14 @@ template <int Op, typename T> struct UnaryOp {
         } else if constexpr (Op == EK_RCP_SQR) {
             const T r = T(1) / x;
             return r * r;
+        } else if constexpr (Op == EK_SEC_SQR) {
+            const T r = T(1) / UnaryOp<EK_COS, T>::apply(x);         // sqr(sec(x)), sec = rcp(cos): d/dx tan (autodiff.h:532-541)
+            return r * r;
+        } else if constexpr (Op == EK_SECH_SQR) {
+            const T r = T(1) / UnaryOp<EK_COSH, T>::apply(x);        // sqr(sech(x)), sech = rcp(cosh): d/dx tanh (autodiff.h:685-696)
+            return r * r;
+        } else if constexpr (Op == EK_RCP_1P_SQR) {
+            return T(1) / (T(1) + x * x);                             // rcp(1 + sqr(x)): d/dx atan (autodiff.h:606-616)
         } else if constexpr (Op == EK_RSQRT_SQR || Op == EK_RSQRT_CUBE) {
             T r;
             if constexpr (sizeof(T) == 4) r = 1.0f / __builtin_sqrtf(x); else r = 1.0 / __builtin_sqrt(x);
@@ -170,7 +178,7 @@ template <typename T> __device__ __forceinline__ T unary_fused(int op, T x) {
         case EK_RCP_SQR: return UnaryOp<EK_RCP_SQR, T>::apply(x);
         case EK_RSQRT_SQR: return UnaryOp<EK_RSQRT_SQR, T>::apply(x);
         case EK_RSQRT_CUBE: return UnaryOp<EK_RSQRT_CUBE, T>::apply(x);
-        default: return x;
+        default: return x;      // (the second-wave maps of unary_chainable() are applied by the chain kernels only: reduce.hip)
     }
 }
 

@@ -17,7 +17,8 @@ namespace ek {
 static const char *const unary_names[EK_UNARY_COUNT] = {
     "neg", "abs", "not", "sqrt", "rcp", "rsqrt", "floor", "ceil", "round", "trunc", "sin", "cos", "exp", "log",
     "popcnt", "lzcnt", "tzcnt", "sign", "copy", "tan", "cot", "asin", "acos", "atan", "sinh", "cosh", "tanh", "asinh",
-    "acosh", "atanh", "cbrt", "erf", "erfc", "erfinv", "i0e", "dawson", "erfi", "lgamma", "tgamma", "rcp_sqr", "rsqrt_sqr", "rsqrt_cube" };
+    "acosh", "atanh", "cbrt", "erf", "erfc", "erfinv", "i0e", "dawson", "erfi", "lgamma", "tgamma", "rcp_sqr", "rsqrt_sqr", "rsqrt_cube",
+    "sec_sqr", "sech_sqr", "rcp_1p_sqr" };
 static const char *const binary_names[EK_BINARY_COUNT] = {
     "add", "sub", "mul", "div", "mod", "min", "max", "mulhi", "and", "or", "xor", "sl", "sr", "safe_mul",
     "atan2", "pow", "fmod", "ldexp" };
@@ -53,6 +54,7 @@ template <typename T> int unary_dispatch(int op, void *out, const ek_operand *a,
         EK_UNARY_CASE(EK_ERF) EK_UNARY_CASE(EK_ERFC) EK_UNARY_CASE(EK_ERFINV) EK_UNARY_CASE(EK_I0E) EK_UNARY_CASE(EK_DAWSON)
         EK_UNARY_CASE(EK_ERFI) EK_UNARY_CASE(EK_LGAMMA) EK_UNARY_CASE(EK_TGAMMA)
         EK_UNARY_CASE(EK_RCP_SQR) EK_UNARY_CASE(EK_RSQRT_SQR) EK_UNARY_CASE(EK_RSQRT_CUBE)
+        EK_UNARY_CASE(EK_SEC_SQR) EK_UNARY_CASE(EK_SECH_SQR) EK_UNARY_CASE(EK_RCP_1P_SQR)
         default: return fail(EK_ERR_INVALID, "ek_hip_unary(): unknown op %d", op);
     }
 }

@@ -229,6 +229,14 @@ template <int Op, typename T> int reduce_map_select(int map, void *out, const vo
         case EK_RCP_SQR: return reduce_map_typed<Op, EK_RCP_SQR, T>(out, in, n);
         case EK_RSQRT_SQR: return reduce_map_typed<Op, EK_RSQRT_SQR, T>(out, in, n);
         case EK_RSQRT_CUBE: return reduce_map_typed<Op, EK_RSQRT_CUBE, T>(out, in, n);
+        case EK_TAN: return reduce_map_typed<Op, EK_TAN, T>(out, in, n);
+        case EK_TANH: return reduce_map_typed<Op, EK_TANH, T>(out, in, n);
+        case EK_ATAN: return reduce_map_typed<Op, EK_ATAN, T>(out, in, n);
+        case EK_SINH: return reduce_map_typed<Op, EK_SINH, T>(out, in, n);
+        case EK_COSH: return reduce_map_typed<Op, EK_COSH, T>(out, in, n);
+        case EK_SEC_SQR: return reduce_map_typed<Op, EK_SEC_SQR, T>(out, in, n);
+        case EK_SECH_SQR: return reduce_map_typed<Op, EK_SECH_SQR, T>(out, in, n);
+        case EK_RCP_1P_SQR: return reduce_map_typed<Op, EK_RCP_1P_SQR, T>(out, in, n);
         default: return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): op %d cannot be applied on load", map);
     }
 }
@@ -280,6 +288,8 @@ __device__ __forceinline__ void chain_apply(T (&r)[E], const T (&b)[E], const T 
         switch (ch.map_ops[s]) {
             EK_CH_MAP(EK_NEG) EK_CH_MAP(EK_ABS) EK_CH_MAP(EK_SQRT) EK_CH_MAP(EK_RCP) EK_CH_MAP(EK_RSQRT) EK_CH_MAP(EK_SIN)
             EK_CH_MAP(EK_COS) EK_CH_MAP(EK_EXP) EK_CH_MAP(EK_LOG) EK_CH_MAP(EK_RCP_SQR) EK_CH_MAP(EK_RSQRT_SQR) EK_CH_MAP(EK_RSQRT_CUBE)
+            EK_CH_MAP(EK_TAN) EK_CH_MAP(EK_TANH) EK_CH_MAP(EK_ATAN) EK_CH_MAP(EK_SINH) EK_CH_MAP(EK_COSH)
+            EK_CH_MAP(EK_SEC_SQR) EK_CH_MAP(EK_SECH_SQR) EK_CH_MAP(EK_RCP_1P_SQR)
             default: break;
         }
     }
@@ -449,7 +459,7 @@ template <typename T> int chain_args(const ek_chain *chain, size_t n, ChainArgs<
     ch.n_maps = chain->n_maps;
     for (int k = 0; k < 3; ++k) {
         ch.map_ops[k] = k < chain->n_maps ? chain->map_ops[k] : (int) EK_COPY;
-        if (k < chain->n_maps && !unary_fusable(ch.map_ops[k]))
+        if (k < chain->n_maps && !unary_chainable(ch.map_ops[k]))
             return fail(EK_ERR_UNSUPPORTED, "%s: op %d cannot be applied on load", what, ch.map_ops[k]);
     }
     return EK_OK;
@@ -680,7 +690,7 @@ int ek_hip_reduce_map(int op, int map_op, int type, void *out, const void *in, s
     if (int rc = ensure_init()) return rc;
     if (!out || !in) return fail(EK_ERR_INVALID, "ek_hip_reduce_map(): null pointer");
     if (n == 0) return fail(EK_ERR_INVALID, "ek_hip_reduce_map(): empty input");
-    if (!unary_fusable(map_op)) return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): op %d cannot be applied on load", map_op);
+    if (!unary_chainable(map_op)) return fail(EK_ERR_UNSUPPORTED, "ek_hip_reduce_map(): op %d cannot be applied on load", map_op);
     switch (type) {
         case EK_F32: return reduce_map_dispatch<float>(op, map_op, out, in, n);
         case EK_F64: return reduce_map_dispatch<double>(op, map_op, out, in, n);

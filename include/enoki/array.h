@@ -332,6 +332,23 @@ template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto csch(const T &
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sech(const T &a) { return rcp(cosh(a)); }
 template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto coth(const T &a) { return rcp(tanh(a)); }
 
+// The derivative weights of tan, tanh and atan as the reference composes them (autodiff.h:532-541, 685-696, 606-616).  An array type
+// that has them as ONE operation of the argument (HIPArray: EK_SEC_SQR, EK_SECH_SQR, EK_RCP_1P_SQR -- same roundings) keeps the
+// weight a single unevaluated map, which a chain or a reduction applies while it loads; every other type composes.
+namespace detail {
+    template <typename T, typename = void> struct has_sec_sqr : std::false_type { };
+    template <typename T> struct has_sec_sqr<T, std::void_t<decltype(std::declval<const T &>().sec_sqr_())>> : std::true_type { };
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sec_sqr(const T &a) {
+    if constexpr (detail::has_sec_sqr<T>::value) return a.sec_sqr_(); else return sqr(sec(a));
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto sech_sqr(const T &a) {
+    if constexpr (detail::has_sec_sqr<T>::value) return a.sech_sqr_(); else return sqr(sech(a));
+}
+template <typename T, enable_if_t<is_array_v<T>> = 0> inline auto rcp_1p_sqr(const T &a) {
+    if constexpr (detail::has_sec_sqr<T>::value) return a.rcp_1p_sqr_(); else return rcp(T(1) + sqr(a));
+}
+
 namespace detail {
     template <typename T, typename = void> struct has_pow : std::false_type { };
     template <typename T> struct has_pow<T, std::void_t<decltype(std::declval<const T &>().pow_(std::declval<const T &>()))>>

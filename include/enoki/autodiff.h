@@ -483,38 +483,60 @@ template <typename Type_> struct DiffArray : ArrayTag {
         return create(idx, std::move(result));                                                       \
     }
 
-    ENOKI_HIP_DIFF_UNARY(tan,   "tan",   tan(m_value),   sqr(sec(m_value)))
+    ENOKI_HIP_DIFF_UNARY(tan,   "tan",   tan(m_value),   sec_sqr(m_value))
     ENOKI_HIP_DIFF_UNARY(cot,   "cot",   cot(m_value),   -sqr(csc(m_value)))
     ENOKI_HIP_DIFF_UNARY(csc,   "csc",   csc(m_value),   -result * cot(m_value))
     ENOKI_HIP_DIFF_UNARY(sec,   "sec",   sec(m_value),   result * tan(m_value))
     ENOKI_HIP_DIFF_UNARY(asin,  "asin",  asin(m_value),  rsqrt(Type(1) - sqr(m_value)))
     ENOKI_HIP_DIFF_UNARY(acos,  "acos",  acos(m_value),  -rsqrt(Type(1) - sqr(m_value)))
-    ENOKI_HIP_DIFF_UNARY(atan,  "atan",  atan(m_value),  rcp(Type(1) + sqr(m_value)))
+    ENOKI_HIP_DIFF_UNARY(atan,  "atan",  atan(m_value),  rcp_1p_sqr(m_value))
     ENOKI_HIP_DIFF_UNARY(csch,  "csch",  csch(m_value),  -result * coth(m_value))
     ENOKI_HIP_DIFF_UNARY(sech,  "sech",  sech(m_value),  -result * tanh(m_value))
-    ENOKI_HIP_DIFF_UNARY(tanh,  "tanh",  tanh(m_value),  sqr(sech(m_value)))
+    ENOKI_HIP_DIFF_UNARY(tanh,  "tanh",  tanh(m_value),  sech_sqr(m_value))
     ENOKI_HIP_DIFF_UNARY(asinh, "asinh", asinh(m_value), rsqrt(Type(1) + sqr(m_value)))
     ENOKI_HIP_DIFF_UNARY(acosh, "acosh", acosh(m_value), rsqrt(sqr(m_value) - Type(1)))
     ENOKI_HIP_DIFF_UNARY(atanh, "atanh", atanh(m_value), rcp(Type(1) - sqr(m_value)))
     ENOKI_HIP_DIFF_UNARY(cbrt,  "cbrt",  cbrt(m_value),  Type(1.f) / (Type(3) * sqr(result)))
 #undef ENOKI_HIP_DIFF_UNARY
 
+    // sinh / cosh (autodiff.h:635-657: value and weight are the two halves of ONE sincosh).  An array type that leaves unary maps
+    // unevaluated (HIPArray) takes the two halves as two maps of the same argument -- the same bits (sinh(x) and cosh(x) are what
+    // sincosh(x) returns, array_math.h:997-1127), but a reduction of the value then reads THROUGH the argument and the weight is
+    // formed by whoever consumes it (a chain, the sweep's product) instead of being written next to the value.
     DiffArray sinh_() const {
-        auto [s, c] = sincosh(m_value);
-        Index idx = 0;
-        if constexpr (Enabled) {
-            if (m_index) idx = tape()->append("sinh", slices(m_value), m_index, c);
+        if constexpr (detail::has_sec_sqr<Type>::value) {
+            Type s = sinh(m_value);
+            Index idx = 0;
+            if constexpr (Enabled) {
+                if (m_index) idx = tape()->append("sinh", slices(m_value), m_index, cosh(m_value));
+            }
+            return create(idx, std::move(s));
+        } else {
+            auto [s, c] = sincosh(m_value);
+            Index idx = 0;
+            if constexpr (Enabled) {
+                if (m_index) idx = tape()->append("sinh", slices(m_value), m_index, c);
+            }
+            return create(idx, std::move(s));
         }
-        return create(idx, std::move(s));
     }
 
     DiffArray cosh_() const {
-        auto [s, c] = sincosh(m_value);
-        Index idx = 0;
-        if constexpr (Enabled) {
-            if (m_index) idx = tape()->append("cosh", slices(m_value), m_index, s);
+        if constexpr (detail::has_sec_sqr<Type>::value) {
+            Type c = cosh(m_value);
+            Index idx = 0;
+            if constexpr (Enabled) {
+                if (m_index) idx = tape()->append("cosh", slices(m_value), m_index, sinh(m_value));
+            }
+            return create(idx, std::move(c));
+        } else {
+            auto [s, c] = sincosh(m_value);
+            Index idx = 0;
+            if constexpr (Enabled) {
+                if (m_index) idx = tape()->append("cosh", slices(m_value), m_index, s);
+            }
+            return create(idx, std::move(c));
         }
-        return create(idx, std::move(c));
     }
 
     std::pair<DiffArray, DiffArray> sincosh_() const {

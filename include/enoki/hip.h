@@ -690,6 +690,10 @@ template <typename Value_> struct HIPArray : ArrayTag {
     HIPArray sinh_() const { return unary(EK_SINH, "sinh_"); }
     HIPArray cosh_() const { return unary(EK_COSH, "cosh_"); }
     HIPArray tanh_() const { return unary(EK_TANH, "tanh_"); }
+    /// the derivative weights of tan, tanh, atan as one op of the argument (same roundings as sqr(sec(x)), sqr(sech(x)), rcp(1 + sqr(x)))
+    HIPArray sec_sqr_() const { return unary(EK_SEC_SQR, "sec_sqr_"); }
+    HIPArray sech_sqr_() const { return unary(EK_SECH_SQR, "sech_sqr_"); }
+    HIPArray rcp_1p_sqr_() const { return unary(EK_RCP_1P_SQR, "rcp_1p_sqr_"); }
     HIPArray asinh_() const { return unary(EK_ASINH, "asinh_"); }
     HIPArray acosh_() const { return unary(EK_ACOSH, "acosh_"); }
     HIPArray atanh_() const { return unary(EK_ATANH, "atanh_"); }
@@ -1094,9 +1098,17 @@ template <typename Value_> struct HIPArray : ArrayTag {
     /// Unary ops whose result is left unevaluated until its first consumer: the ones ek_hip_reduce_map /
     /// ek_hip_scatter_add_multi_map can apply on load.  Small arrays are evaluated right away (nothing to win).
     static constexpr size_t defer_map_min_size_ = (size_t) 1 << 16;
-    static constexpr bool map_fusable_(int op) {
+    /// what EVERY streaming consumer applies on load: reductions, chains, the value streams of scatter_add, the bucket-ordered kernels
+    static constexpr bool map_on_load_(int op) {
         return op == EK_NEG || op == EK_ABS || op == EK_SQRT || op == EK_RCP || op == EK_RSQRT || op == EK_SIN ||
                op == EK_COS || op == EK_EXP || op == EK_LOG || op == EK_RCP_SQR || op == EK_RSQRT_SQR || op == EK_RSQRT_CUBE;
+    }
+    /// ... and what is left unevaluated: those, plus (round 6) the second-wave functions whose derivative is ONE map of the same argument
+    /// -- tan, tanh, atan, sinh, cosh -- and those derivative maps (EK_SEC_SQR, EK_SECH_SQR, EK_RCP_1P_SQR): reductions and chains apply
+    /// them on load (ek_hip_reduce_map / ek_hip_reduce_chain / ek_hip_map_chain), every other consumer evaluates the map first
+    static constexpr bool map_fusable_(int op) {
+        return map_on_load_(op) || op == EK_TAN || op == EK_TANH || op == EK_ATAN || op == EK_SINH || op == EK_COSH ||
+               op == EK_SEC_SQR || op == EK_SECH_SQR || op == EK_RCP_1P_SQR;
     }
     bool can_defer_map_() const {
         const size_t least = detail::hip_defer_min_override() ? detail::hip_defer_min_override() : defer_map_min_size_;
@@ -1274,6 +1286,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
         } else {
             // the sum of one half of an unevaluated sincos pair whose other half is still held: the shape of a derivative that
             // the tape will ask for (see ek_hip_bucketed_pair_create_hinted)
+            if (map_op != EK_COPY && !map_on_load_(map_op)) return false;          // (second-wave maps: element order, before a partition is made for nothing)
             const bool adjoint_expected = op == EK_HSUM && keep_op != EK_COPY && ek_hip_bucketed_early_pair(map_op, keep_op);
             // (sin / cos: both functions bounded by 1 -- the adjoint sums can then be formed in 64-bit fixed point, see enoki_hip.h)
             const bool bounded = (map_op == EK_SIN || map_op == EK_COS) && (keep_op == EK_SIN || keep_op == EK_COS);
@@ -1409,7 +1422,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             if constexpr (IsFloat) {
                 // an unevaluated unary result (the cos(u) of d/du sin(u), ...) is applied while the stream is loaded --
                 // unless a target is its own source buffer
-                if (values[c]->mapped_() && !values[c]->m_buf->deferred->scaled) {
+                if (values[c]->mapped_() && !values[c]->m_buf->deferred->scaled && map_on_load_(values[c]->m_buf->deferred->index_type)) {
                     const auto *d = values[c]->m_buf->deferred;
                     in_place = true;
                     for (size_t t = 0; t < count; ++t) {
@@ -1464,6 +1477,7 @@ template <typename Value_> struct HIPArray : ArrayTag {
             detail::HIPBuffer *src = nullptr;
             from_u[c] = 1; ops[c] = EK_COPY; imm[c] = 0;
             scale[c] = imm_bits(v.map_scale_());
+            if (v.mapped_() && !map_on_load_(v.m_buf->deferred->index_type)) return false;      // (a second-wave map: the bucket-ordered kernels do not carry it)
             if (v.mapped_()) { src = v.m_buf->deferred->table; ops[c] = v.m_buf->deferred->index_type; }
             else if (v.paired_()) src = v.m_buf;
             else if (v.m_is_imm) { from_u[c] = 0; imm[c] = imm_bits(v.m_imm); }

@@ -63,6 +63,10 @@ typedef enum {
      * -.5 result^3 with result = rcp(x) / rsqrt(x)): r r with r = 1 / x;  r r and r (r r) with r = 1 / sqrt(x) -- the roundings of
      * the eager products, so that a consumer which applies an op while it loads can form them from x */
     EK_RCP_SQR, EK_RSQRT_SQR, EK_RSQRT_CUBE,
+    /* round 6: the derivative weights of tan, tanh and atan as ONE function of the argument each, with the roundings of the compositions
+     * the reference records (autodiff.h:532-541 sqr(sec(x)), :685-696 sqr(sech(x)), :606-616 rcp(1 + sqr(x)); sec = rcp(cos),
+     * sech = rcp(cosh), array_math.h:463-464, 1181-1183): r r with r = 1 / cos(x);  r r with r = 1 / cosh(x);  1 / (1 + x x) */
+    EK_SEC_SQR, EK_SECH_SQR, EK_RCP_1P_SQR,
     EK_UNARY_COUNT
 } ek_unary_op;
 

@@ -23,7 +23,9 @@ def up(capi, a):
 
 BASES = [("fmadd", 3), ("fmsub", 3), ("fnmadd", 3), ("fnmsub", 3), ("muladd", 3), ("mulsub", 3), ("nmuladd", 3),
          ("add", 2), ("sub", 2), ("mul", 2), (None, 1)]
-MAPS = [[], ["sin"], ["exp", "sin"], ["abs", "sqrt", "rcp"], ["neg", "exp", "log"], ["cos", "abs", "rsqrt"], ["rcp_sqr"], ["abs", "rsqrt_sqr", "rsqrt_cube"]]
+MAPS = [[], ["sin"], ["exp", "sin"], ["abs", "sqrt", "rcp"], ["neg", "exp", "log"], ["cos", "abs", "rsqrt"], ["rcp_sqr"], ["abs", "rsqrt_sqr", "rsqrt_cube"],
+        # round 6: the second-wave functions whose derivative is one map of the argument, and those derivative maps
+        ["tanh"], ["sech_sqr"], ["tan", "abs"], ["sec_sqr"], ["atan", "sinh"], ["rcp_1p_sqr", "cosh"]]
 
 
 def op_by_op(capi, base, srcs, maps):
@@ -248,6 +250,49 @@ def test_cfg3a_is_a_reduction_and_one_backward_pass(ek, oracle):
     assert bits_equal(ga, oracle.binary("safe_mul", x, c))
     t = oracle.unary("sin", u).astype(np.float64)
     assert abs(y - t.sum()) <= 2.0 ** -24 * (n // (1 << 18) + 40) * np.abs(t).sum()
+
+
+@pytest.mark.parametrize("fn", ["tanh", "tan", "atan", "sinh", "cosh"])
+def test_second_wave_maps_over_leaf_arrays_are_two_passes(ek, oracle, fn):
+    """round 6: tan, tanh, atan, sinh, cosh with gradients stay a chain -- the value is an unevaluated map of u and so is the weight
+    the tape records (EK_SEC_SQR = sqr(sec(u)), EK_SECH_SQR = sqr(sech(u)), EK_RCP_1P_SQR = rcp(1 + sqr(u)), cosh(u), sinh(u): one op
+    of the argument each, with the roundings of the reference's compositions, autodiff.h:532-541, 606-616, 635-657, 685-696), so
+    forward + backward() are two bandwidth kernels; the weights are bit for bit the op-by-op compositions of the library's own
+    kernels (rcp is the exact division: class C against the reference's AVX rows, like every rcp-based weight)"""
+    import enoki_amd.hip_autodiff as ad
+    import enoki_amd.hip as ekc
+    n = (1 << 19) + 3
+    a, x, b = uniform_pm1(n, 4), uniform_pm1(n, 5), uniform_pm1(n, 6)
+    xd = ad.Float32(x)
+    f = {"tanh": ad.tanh, "tan": ad.tan, "atan": ad.atan, "sinh": ad.sinh, "cosh": ad.cosh}[fn]
+
+    def step():
+        da, db = ad.Float32(a), ad.Float32(b)
+        ad.set_requires_gradient(da); ad.set_requires_gradient(db)
+        y = ad.hsum(f(ad.fmadd(da, xd, db)))
+        ad.backward(y)
+        return float(ad.detach(y).numpy()[0]), ad.gradient(da), ad.gradient(db)
+
+    step()
+    (y, ga, gb), ks = kernels(ek, lambda: step())
+    ga, gb = ga.numpy(), gb.numpy()
+    big = {k: v for k, v in ks.items() if k not in ("reduce_stage2", "copy", "memcpy", "fill")}
+    assert big == {"reduce_chain": 1, "map_chain_product": 1}, (fn, ks)
+    # op by op with the library's own kernels (evaluated eagerly on small pieces of the same data: below the deferral threshold)
+    U = ekc.Float32
+    ekc.hip_set_defer(False)
+    try:
+        u = ekc.fmadd(U(a), U(x), U(b))
+        one = U(np.ones(n, np.float32))
+        w = {"tanh": lambda: (lambda r: r * r)(one / ekc.cosh(u)), "tan": lambda: (lambda r: r * r)(one / ekc.cos(u)),
+             "atan": lambda: one / (one + u * u), "sinh": lambda: ekc.cosh(u), "cosh": lambda: ekc.sinh(u)}[fn]()
+        v = {"tanh": ekc.tanh, "tan": ekc.tan, "atan": ekc.atan, "sinh": ekc.sinh, "cosh": ekc.cosh}[fn](u)
+        w_np, v_np = w.numpy(), v.numpy().astype(np.float64)
+    finally:
+        ekc.hip_set_defer(True)
+    assert bits_equal(gb, w_np), fn
+    assert bits_equal(ga, oracle.binary("safe_mul", x, w_np)), fn
+    assert abs(y - v_np.sum()) <= 2.0 ** -24 * (n // (1 << 18) + 40) * np.abs(v_np).sum()
 
 
 @pytest.mark.parametrize("fn", ["cos", "exp", "log_abs"])

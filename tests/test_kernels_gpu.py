@@ -152,6 +152,27 @@ def test_derivative_products_bit_exact(capi, dtype):
     assert abs(got - t.sum()) <= (2.0 ** -24 if dtype == np.float32 else 2.0 ** -53) * 64 * np.abs(t).sum()
 
 
+def test_second_wave_derivative_ops_are_the_compositions(capi):
+    """EK_SEC_SQR / EK_SECH_SQR / EK_RCP_1P_SQR (round 6) -- the derivative weights of tan, tanh and atan as one op of the argument each:
+    bit for bit sqr(rcp(cos(x))), sqr(rcp(cosh(x))), rcp(1 + sqr(x)) evaluated op by op with the library's own kernels (the compositions the
+    reference records, autodiff.h:532-541, 685-696, 606-616), also when a reduction applies them on load"""
+    rng = np.random.default_rng(5)
+    a = np.concatenate([rng.uniform(-4, 4, 1 << 16), [0.0, -0.0, np.inf, -np.inf, np.nan, 1e-30, 88.0, -88.0, 1.5707964]]).astype(np.float32)
+    d = up(capi, a)
+    one = up(capi, np.ones_like(a))
+    sq = lambda r: capi.binary("mul", r, r)
+    want = {"sec_sqr": sq(capi.binary("div", one, capi.unary("cos", d))), "sech_sqr": sq(capi.binary("div", one, capi.unary("cosh", d))),
+            "rcp_1p_sqr": capi.binary("div", one, capi.binary("add", one, sq(d)))}
+    for op, w in want.items():
+        assert bits_equal(capi.unary(op, d).numpy(), w.numpy()), op
+    b = rng.uniform(-1.5, 1.5, (1 << 18) + 11).astype(np.float32)
+    for op in ("sec_sqr", "sech_sqr", "rcp_1p_sqr", "tanh", "tan", "atan", "sinh", "cosh"):
+        got = float(capi.reduce_map("hsum", op, up(capi, b)).numpy()[0])
+        ref = float(capi.reduce("hsum", capi.unary(op, up(capi, b))).numpy()[0])
+        assert got == ref, (op, got, ref)          # the same reduction tree over the same values
+
+
+
 @pytest.mark.parametrize("op", ["add", "sub", "mul", "div", "min", "max", "safe_mul"])
 def test_binary_f32_bit_exact(capi, oracle, op):
     a = f32_inputs(100003, seed=1, scale=10.0)
