@@ -70,6 +70,10 @@ CFG3B_VARIANTS = {
     "cfg3b_operators_sub": dict(spelling="b-a*x", func="cos"),
     # ONE gather times an array (`texture lookup * weight`, the shape of cfg5's albedo lookups): y = hsum(sin(gather(A, idx) * x))
     "cfg3b_product": dict(spelling="a*x"),
+    # SKEWED indices (a textured scene has hot texels): log-uniform over K = 1 Mi -- a magnitude m uniform in 0..19, then an index
+    # uniform in [2^m - 1, 2^(m + 1) - 1): density ~ 1 / k like Zipf(s = 1), integer arithmetic only (host and device generate the same
+    # bits).  Half of the lookups fall into the first 1023 entries, 5 % of them on entry 0.
+    "cfg3b_zipf": dict(zipf=True),
 }
 for _w, _v in CFG3B_VARIANTS.items():
     DESCRIPTION[_w] = ("cfg3b with " + ", ".join(f"{k}={v}" for k, v in _v.items()) +
@@ -338,6 +342,10 @@ class Bench:
             if var.get("shift"):
                 B0 = B0 + ekc.Float32(float(var["shift"]))
             idx = ek.UInt32(synth.index_mod(begin, n, 4, kt))
+            if var.get("zipf"):
+                m = synth.hash_u32(begin, n, 8) % ekc.UInt32(20)
+                lo = (ekc.UInt32(1) << m) - ekc.UInt32(1)
+                idx = ek.UInt32(lo + (synth.hash_u32(begin, n, 9) & lo))
             if var.get("idx64"):
                 idx = ek.UInt64(idx)
             mask = ek.Mask((synth.hash_u32(begin, n, 5) & ekc.UInt32(3)) != ekc.UInt32(0)) if var.get("masked") else None

@@ -364,7 +364,8 @@ struct MetaRing {
     static constexpr size_t kPartials = 2048;                   // reduce partials a block has room for (max_pieces)
     void *block[kBlocks] = {};
     bool busy[kBlocks] = {}, clean[kBlocks] = {};
-    static size_t bytes() { return (3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1) * sizeof(uint32_t) + kPartials * sizeof(float) + 16; }
+    // (16 bytes per piece: a float partial, or -- the fixed-point forward + adjoint kernel -- a 64-bit integer partial and a float one)
+    static size_t bytes() { return (3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1) * sizeof(uint32_t) + kPartials * 16 + 16; }
 };
 static MetaRing &meta_ring() { static MetaRing *r = new MetaRing(); return *r; }
 
@@ -594,7 +595,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
         }
     }
     if (b->meta_slot < 0)
-        if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * sizeof(float) + 16, &b->meta)) return rc;
+        if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t) + (size_t) b->max_pieces * 16 + 16, &b->meta)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(uint16_t), &b->pair_idx)) return rc;
     if (int rc = ek_hip_malloc(b->positions * sizeof(float), &b->x_b)) return rc;
     const size_t part_entries = (size_t) p.W * n_buckets;

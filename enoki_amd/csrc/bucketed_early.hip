@@ -196,7 +196,10 @@ struct EarlyFixed {
     const T *x_b;
     uint32_t lmask;
     FixedScale sc0, sc1;
-    T acc[4];
+    // the reduced value (|sin|, |cos| <= 1) as an INTEGER too: a term becomes trunc(f 2^28) -- four of them fit 32 bits, so a batch
+    // costs one 64-bit addition -- and the sum over the launch is exact in 64 bits: y does not depend on which lane, wave or piece
+    // took which element (the float accumulators of the lock path do).  2^-28 per term is 1/16 of the float's own last bit at 1.
+    long long iacc;
 
     __device__ __forceinline__ void fetch(Step &s, size_t pos) {
         s.pi = pack_load<uint16_t, 4, true>(pair_idx + pos);
@@ -206,6 +209,7 @@ struct EarlyFixed {
     __device__ __forceinline__ void apply(const Step &s, int rem) {
         uint32_t l[4];
         PairRec<T> r[4];
+        int batch = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             l[k] = (uint32_t) s.pi.v[k] & lmask;
@@ -218,16 +222,18 @@ struct EarlyFixed {
             EarlyPair<Map, Keep, T>::apply(pair_value(r[k].a, x, r[k].c, Two), sum, v0);
             const T v1 = dev::safe_mul(x, v0);
             unsigned long long *p0 = s0 + l[k], *p1 = s1 + l[k];
+            const int q = dev::cvt_sat_i32(sum * 268435456.0f);
             if constexpr (Masked) {
                 const bool on = k < rem;
-                acc[k] += on ? sum : T(0);
+                batch += on ? q : 0;
                 p0 = on ? p0 : priv; p1 = on ? p1 : priv;
             } else {
-                acc[k] += sum;
+                batch += q;
             }
             (void) __hip_atomic_fetch_add(p0, to_fixed64(v0, sc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             (void) __hip_atomic_fetch_add(p1, to_fixed64(v1, sc1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        iacc += (long long) batch;
     }
     __device__ __forceinline__ void flush() { }
 };
@@ -280,6 +286,50 @@ __device__ __forceinline__ void walk_pages_dynamic(const BucketLists &bl, const 
     body.flush();
 }
 
+
+/// bucket_finish for the fixed-point kernel: every workgroup publishes an INTEGER partial (units of 2^-28; pieces that ran under locks: 0)
+/// and a float one (pieces under locks; 0 otherwise); the last workgroup adds the integers exactly -- the order cannot matter --,
+/// converts once, and adds the float partials in the order of the pieces.
+__device__ __forceinline__ void bucket_finish_fixed(long long iblock /* thread 0 */, float fblock /* thread 0 */, float *__restrict__ partials,
+                                                    uint32_t *__restrict__ ticket, float *__restrict__ out, const uint32_t *__restrict__ active,
+                                                    size_t n, int map_op, float *wave_part, long long *wave_ipart, uint32_t *__restrict__ counters) {
+    __shared__ uint32_t s_last_fixed;
+    unsigned long long *ipartials = reinterpret_cast<unsigned long long *>(partials);             // [gridDim.x] integers, then [gridDim.x] floats
+    uint32_t *fpartials = reinterpret_cast<uint32_t *>(ipartials + gridDim.x);
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(ipartials + blockIdx.x, (unsigned long long) iblock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(fpartials + blockIdx.x, __float_as_uint(fblock), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last_fixed = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+    }
+    __syncthreads();
+    if (!s_last_fixed) return;
+    if (counters) {
+        for (unsigned k = threadIdx.x; k < 2u * kMaxBuckets + 4u; k += blockDim.x) counters[k] = 0u;
+    }
+    long long iv = 0;
+    float fv = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) {
+        iv += (long long) __hip_atomic_load(ipartials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        fv += __uint_as_float(__hip_atomic_load(fpartials + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { iv += bucket_shfl_down(iv, d); fv += bucket_shfl_down(fv, d); }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { wave_ipart[threadIdx.x >> 6] = iv; wave_part[threadIdx.x >> 6] = fv; }
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        iv = threadIdx.x < blockDim.x / 64 ? wave_ipart[threadIdx.x] : 0ll;
+        fv = threadIdx.x < blockDim.x / 64 ? wave_part[threadIdx.x] : 0.f;
+#pragma unroll
+        for (int d = 8; d >= 1; d >>= 1) { iv += bucket_shfl_down(iv, d); fv += bucket_shfl_down(fv, d); }
+        if (threadIdx.x == 0) {
+            const float r = (float) iv * 3.7252902984619140625e-9f /* 2^-28 */ + fv;
+            out[0] = bucket_dropped_lanes<float, EK_HSUM>(r, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
+            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 template <typename T, int V, int PS, bool Fixed, bool Two>
 __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(T *__restrict__ partials, T *__restrict__ table_partials,
                                                                                 const T *__restrict__ table_a,
@@ -298,6 +348,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     __shared__ unsigned long long s_dummy;
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_guard[2];
+    __shared__ long long wave_ipart[Fixed ? kBucketWaves : 1];
     __shared__ unsigned long long s_priv[Fixed ? kBucketThreads : 1];
     constexpr bool Paired = sizeof(T) == 4;
     int bucket;
@@ -306,7 +357,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
     if (!bucket_piece<PS>(bl, bucket, range)) {
-        bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
+        if constexpr (Fixed) bucket_finish_fixed(0ll, T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
+        else bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
         return;
     }
 #ifdef EK_EARLY_TIMING
@@ -358,6 +410,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     // slice and max |x|, once per piece, not per element; or the piece is larger than the scale allows for.  Such pieces run under
     // the exchange locks like every piece of round 5; piece_mode tells the fold which kind of table a piece wrote.
     [[maybe_unused]] bool locks = !Fixed, single = false;
+    [[maybe_unused]] long long iv = 0;            // Fixed: this lane's share of the reduced value, in units of 2^-28
     [[maybe_unused]] FixedScale fixed0{}, fixed1{};
     if constexpr (Fixed) {
         const uint32_t xm = (uint32_t) __builtin_amdgcn_readfirstlane((int) xmax_bits[0]);
@@ -387,11 +440,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
             auto run_fixed = [&](auto body) {
                 body.rec = rec; body.s0 = reinterpret_cast<unsigned long long *>(tables); body.s1 = body.s0 + Bins; body.priv = &s_priv[Fixed ? threadIdx.x : 0];
                 body.pair_idx = pair_idx; body.x_b = x_b; body.lmask = (uint32_t) Bins - 1u;
-                body.sc0 = fixed0; body.sc1 = fixed1;
-#pragma unroll
-                for (int k = 0; k < 4; ++k) body.acc[k] = T(0);
+                body.sc0 = fixed0; body.sc1 = fixed1; body.iacc = 0;
                 walk_pages_dynamic<PS>(bl, range, body, &s_next);
-                v = (body.acc[0] + body.acc[1]) + (body.acc[2] + body.acc[3]);
+                iv = body.iacc;
             };
             // (launched for the pairs whose functions are bounded by 1 only: bucketed_forward_adjoint_launch)
             if (map_op == EK_SIN && keep_op == EK_COS) run_fixed(EarlyFixed<PS, EK_SIN, EK_COS, Two>{});
@@ -412,12 +463,22 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if constexpr (Fixed) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) iv += bucket_shfl_down(iv, d);
+        if (lane == 0) wave_ipart[wave] = iv;
+    }
     if (lane == 0) wave_part[wave] = v;
     __syncthreads();
     if (threadIdx.x < 64) {
         v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : T(0);
 #pragma unroll
         for (int d = 8; d >= 1; d >>= 1) v += bucket_shfl_down(v, d);
+        if constexpr (Fixed) {
+            iv = threadIdx.x < kBucketWaves ? wave_ipart[threadIdx.x] : 0ll;
+#pragma unroll
+            for (int d = 8; d >= 1; d >>= 1) iv += bucket_shfl_down(iv, d);
+        }
     }
     // table c (0: sum of the kept function, 1: sum of x * kept function) of this piece at table_partials + (c * gridDim.x + piece) * Bins
 #pragma unroll
@@ -451,7 +512,8 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         atomicMax(&g_early_timing[15], t_out - t_entry);
     }
 #endif
-    bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
+    if constexpr (Fixed) bucket_finish_fixed(iv, v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
+    else bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
 }
 
 template <typename T>

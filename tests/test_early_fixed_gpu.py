@@ -111,6 +111,10 @@ def test_fixed_point_sums_are_inside_class_d_and_reproducible(capi, op, half, ma
     for _ in range(3):
         y2, h0, h1, _ = run(capi, op, half, dA, dx, dC, di, K, H, dm)
         assert np.array_equal(g0.view(np.uint32), h0.view(np.uint32)) and np.array_equal(g1.view(np.uint32), h1.view(np.uint32))
+        # ... and so is the reduced value: its terms are summed as integers (units of 2^-28), exactly
+        assert np.float32(y2).view(np.uint32) == np.float32(y).view(np.uint32), (y, y2)
+    # within n * 2^-28 (truncation of each term) + one rounding of the exact sum
+    assert abs(y - red.sum()) <= n * 2.0 ** -28 + 2.0 ** -24 * abs(red.sum()) + 1e-6
 
 
 def test_fixed_point_against_the_lock_protocol_on_the_same_input(capi):

@@ -155,7 +155,9 @@ NEIGHBOURS = {"cos": dict(func="cos"), "exp": dict(func="exp"), "seed3": dict(se
               "i64": dict(idx64=True), "K4Mi": dict(K=1 << 22), "sqrt": dict(func="sqrt", shift=3.0),
               "rcp": dict(func="rcp", shift=3.0),
               # `y=hsum(sin(a*x+b))` as BASELINE.json configs[2] spells it: operators, two roundings (bench.py: cfg3b_operators)
-              "operators": dict(spelling="a*x+b")}
+              "operators": dict(spelling="a*x+b"),
+              # skewed indices (bench.py: cfg3b_zipf): log-uniform over K, 5 % of all lookups on entry 0
+              "zipf": dict(zipf=True)}
 
 
 @pytest.mark.parametrize("name", list(NEIGHBOURS))
@@ -171,6 +173,10 @@ def test_cfg3b_neighbours_at_the_headline_size(ek, checker, name):
     A, B, x = uniform_pm1(Kt, 6), uniform_pm1(Kt, 7), uniform_pm1(N, 2)
     B = (B + np.float32(kw.pop("shift", 0.0))).astype(np.float32)          # (sqrt: u = a x + b > 0)
     idx = (hash_u32(np.arange(N, dtype=np.uint64), 4) % np.uint32(Kt)).astype(np.uint32)
+    if kw.pop("zipf", False):
+        m = (hash_u32(np.arange(N, dtype=np.uint64), 8) % np.uint32(20)).astype(np.uint32)
+        lo = ((np.uint32(1) << m) - np.uint32(1)).astype(np.uint32)
+        idx = (lo + (hash_u32(np.arange(N, dtype=np.uint64), 9) & lo)).astype(np.uint32)
     mask = ((hash_u32(np.arange(N, dtype=np.uint64), 5) & 3) != 0) if masked else None
     dA, dB = ek.Float32(A), ek.Float32(B)
     ek.set_requires_gradient(dA); ek.set_requires_gradient(dB)
