@@ -598,6 +598,24 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
             if (ent[k] != kNoPage) glist_part[at++] = ent[k];
     }
     const uint32_t e_begin = (uint32_t) ((uint64_t) F * slice / kPgDirSlices), e_end = (uint32_t) ((uint64_t) F * (slice + 1) / kPgDirSlices);
+    if (F > 65536u) {
+        // A HOT bucket (skewed indices: hundreds of thousands of pages): the list is copied run by run -- the pages of one partition
+        // workgroup are contiguous in its wlist -- instead of entry by entry with a binary search over the runs per entry (8 dependent
+        // LDS reads each: the directory was 0.83 ms of the 1.6 ms zipf step, profiles/bench_r06.json: also.cfg3b_zipf)
+        for (uint32_t wq = (uint32_t) slice; wq < W; wq += kPgDirSlices) {
+            const uint32_t r0 = row[wq], len = row[wq + 1] - r0;
+            const uint32_t *from = wlist + lrow[wq];
+            uint32_t *to = glist_full + fb + r0;
+            for (uint32_t e0 = t; e0 < len; e0 += 8 * 256) {
+                uint32_t v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = e0 + u * 256 < len ? __builtin_nontemporal_load(from + e0 + u * 256) : 0u;
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (e0 + u * 256 < len) to[e0 + u * 256] = v[u];
+            }
+        }
+    } else
     for (uint32_t e0 = e_begin + t; e0 < e_end; e0 += 4 * 256) {
         uint32_t src[4];
 #pragma unroll

@@ -288,8 +288,10 @@ __device__ __forceinline__ void chain_apply(T (&r)[E], const T (&b)[E], const T 
         switch (ch.map_ops[s]) {
             EK_CH_MAP(EK_NEG) EK_CH_MAP(EK_ABS) EK_CH_MAP(EK_SQRT) EK_CH_MAP(EK_RCP) EK_CH_MAP(EK_RSQRT) EK_CH_MAP(EK_SIN)
             EK_CH_MAP(EK_COS) EK_CH_MAP(EK_EXP) EK_CH_MAP(EK_LOG) EK_CH_MAP(EK_RCP_SQR) EK_CH_MAP(EK_RSQRT_SQR) EK_CH_MAP(EK_RSQRT_CUBE)
+#ifndef EK_CHAIN_FIRST_WAVE_ONLY      /* (measurement builds: what the second-wave cases cost the kernels that do not use them) */
             EK_CH_MAP(EK_TAN) EK_CH_MAP(EK_TANH) EK_CH_MAP(EK_ATAN) EK_CH_MAP(EK_SINH) EK_CH_MAP(EK_COSH)
             EK_CH_MAP(EK_SEC_SQR) EK_CH_MAP(EK_SECH_SQR) EK_CH_MAP(EK_RCP_1P_SQR)
+#endif
             default: break;
         }
     }

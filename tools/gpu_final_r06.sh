@@ -23,3 +23,7 @@ import sys, json
 d = json.loads(sys.stdin.read().strip().splitlines()[-1])
 print('8Mi shard', d['value'], d['ms_per_step'], ' '.join('%s %.1f' % (k['kernel'][:22], k['avg_ms'] * 1e3) for k in d['roofline']['kernels']))
 "
+# round 6 extras: the second-wave chains, the forward + adjoint kernel under locks against fixed point (same box), the SQ counters of both
+timeout 300 python tools/probe_second_wave.py 26 2>&1 | tee gpurun_out/probe_second_wave.txt
+timeout 300 bash tools/ab_early.sh 2>&1 | tee gpurun_out/probe_early.txt
+timeout 300 bash tools/profile_early.sh fixed PROBE_HINTS=3 > /dev/null 2>&1; timeout 300 bash tools/profile_early.sh locks PROBE_HINTS=1 > /dev/null 2>&1
