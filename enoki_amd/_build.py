@@ -70,11 +70,19 @@ def _run(cmd):
     return r.stdout
 
 
+# per-file code generation switches
+#   bucketed_early.hip: the wave-level rewrite of uniform atomics ("atomic optimizer") turns the one-lane page-batch request of
+#   walk_pages_dynamic into a ballot / mbcnt / readfirstlane sequence that WAITS for the returning ds_add on the spot
+#   (s_waitcnt lgkmcnt(0): every LDS add of the previous step) -- without it the value is picked up a step later, for free
+FILE_FLAGS = {"bucketed_early.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
+
+
 def _compile(src, force):
     obj = os.path.join(OBJ, os.path.basename(src) + ".o")
     if force or _newer(obj, [src] + _headers()):
         # ENOKI_PROBE_DEFINES="-DEK_PG_TIMING" builds the measurement library (probe.hip only) with instrumentation
         extra = os.environ.get("ENOKI_PROBE_DEFINES", "").split() if os.path.basename(src).startswith("probe") else []
+        extra = extra + FILE_FLAGS.get(os.path.basename(src), [])
         cmd = [HIPCC] + DEVICE + COMMON + extra + (["-x", "hip"] if src.endswith(".cpp") and "csrc" in src else []) + ["-c", src, "-o", obj]
         _run(cmd)
     return obj

@@ -172,74 +172,111 @@ struct EarlyBody {
 // additions: the default mode becomes bit-reproducible.  A term v becomes round-down(v * 2^S), S from a bound of |v| over the
 // launch and the number of elements (no sum can leave 63 bits); terms of 24 significant bits are exact from 2^-13 of the bound
 // upwards, below that the error is < 2^-S per term -- 2^-37 of the bound at 64 Mi elements.
-__device__ __forceinline__ unsigned long long to_fixed64(float v, const FixedScale &sc) {
-    // t = v 2^S = hf 2^32 + lf with hf = round-to-nearest(t / 2^32) and |lf| <= 2^31: BOTH parts are exact -- t has 24 significant
-    // bits, so below 2^31 it is lf itself, and from 2^31 on its last bit is worth >= 2^8 and lf (a multiple of that, at most 2^31)
-    // fits 24 bits.  (A split with lf in [0, 2^32) is not: a small negative t gives lf = t + 2^32, which a float rounds to a
-    // multiple of 256 -- the first version lost 7 bits of every small negative term that way, tests/test_early_fixed_gpu.py.)
-    const float t = v * sc.up;                                   // exact: a power of two (no over- or underflow by the choice of S)
-    const float hf = __builtin_rintf(v * sc.down);
-    const float lf = __builtin_fmaf(hf, -4294967296.0f, t);
-    const int lo = dev::cvt_sat_i32(lf);                         // (toward zero: the error of a term is below one unit; lf = +2^31, a tie of the split, saturates one unit short)
-    const int hi = (int) hf + (lo >> 31);                        // the low word is added as UNSIGNED: borrow for a negative one
-    return ((unsigned long long) (unsigned) hi << 32) | (unsigned) lo;
+__device__ __forceinline__ unsigned long long to_fixed64(float v, double up) {
+    // t = v 2^S is exact in a double (24 significant bits, any S); d = t + 1.5 * 2^52 rounds it to the nearest integer k (ties to
+    // even; |k| < 2^51 by the choice of S: S0 <= 48) and carries k in its low 52 bits: bits(d) = bits(1.5 * 2^52) + k as 64-bit
+    // integers -- the low word of the constant is zero, so the subtraction is ONE 32-bit add on the high word.  v_cvt_f64_f32 +
+    // v_fma_f64 + v_add_u32 (~9 issue cycles of a SIMD, profiles/probe_valu_r06.txt) against the float form's two multiplies,
+    // v_rndne, fma, two conversions, a shift and an add (~17): the split of t into two exactly representable floats
+    // (hf = rint(t / 2^32), lf = t - hf 2^32) is in git 89107d7.
+    const double d = __builtin_fma((double) v, up, 6755399441055744.0);
+    return __builtin_bit_cast(unsigned long long, d) - 0x4338000000000000ull;
 }
+
+/// bytes of each of the three areas of the fixed-point kernel's LDS: the {a, c} records of a 4 Ki-entry bucket, the plane of the
+/// plain sums, the plane of the x-weighted sums.  Constants whatever Bins is, so that the byte offset 8 l of an entry -- ONE
+/// shift-and-mask of the packed 16-bit indices -- addresses all three through the instructions' immediate offsets (the third
+/// plane lies one byte beyond the 16-bit offset field: one add).  PLANES, not {s0, s1} pairs: with 16-byte entries one
+/// ds_add_u64 instruction touches only every other pair of banks -- measured, SQ_LDS_BANK_CONFLICT 32.7 M against 22.9 M cycles
+/// per launch and the kernel LDS-bound at 77 % (profiles/rocprof_sq_early_pairs_r06.txt).
+constexpr uint32_t kFixedRecBytes = 4096u * 8u;
 
 template <int PS, int Map, int Keep, bool Two>
 struct EarlyFixed {
     using T = float;
     static constexpr uint32_t Page = 1u << PS, LX = Page / 4, PW = 64 / LX;
     struct Step { Pack<uint16_t, 4> pi; T px[4]; };
-    const PairRec<T> *rec;
-    unsigned long long *s0, *s1, *priv;
+    const unsigned char *lds;                // records at lds + 8 l, sums at lds + kFixedRecBytes + 8 l and lds + 2 kFixedRecBytes + 8 l
     const uint16_t *pair_idx;
     const T *x_b;
-    uint32_t lmask;
-    FixedScale sc0, sc1;
+    uint32_t m8;                             // (Bins - 1) << 3, in a VECTOR register (an SGPR operand halves the issue rate of a VOP2, probe_valu)
+    double up0, up1;
     // the reduced value (|sin|, |cos| <= 1) as an INTEGER too: a term becomes trunc(f 2^28) -- four of them fit 32 bits, so a batch
     // costs one 64-bit addition -- and the sum over the launch is exact in 64 bits: y does not depend on which lane, wave or piece
     // took which element (the float accumulators of the lock path do).  2^-28 per term is 1/16 of the float's own last bit at 1.
     long long iacc;
 
     __device__ __forceinline__ void fetch(Step &s, size_t pos) {
+#ifdef EK_FX_DIAG_IDXPAIR
+        // measurement only (wrong data): the two lane groups of a pair read the two halves of ONE 128-byte line of indices
+        const uint32_t lane = threadIdx.x & 63u, even = (lane / (2 * LX)) * 2 * LX + lane % LX;
+        const uint32_t page = (uint32_t) (pos >> PS), pa = (uint32_t) __shfl((int) page, (int) even, 64);
+        const size_t posl = ((size_t) (pa & ~1u) << PS) + (((lane / LX) & 1u) << PS) + (pos & (Page - 1u));
+        s.pi = pack_load<uint16_t, 4, true>(pair_idx + posl);
+#else
         s.pi = pack_load<uint16_t, 4, true>(pair_idx + pos);
+#endif
         load4<T, true>(x_b + pos, s.px);
     }
+    struct Recs { uint32_t a8[4]; PairRec<T> r[4]; };
+    /// the records of a step's four entries: issued ONE STEP AHEAD of the arithmetic that uses them (walk_pages_dynamic) -- behind the
+    /// 8 x 16 non-returning adds the workgroup's other waves keep queued in the LDS, a read takes longer than a step's arithmetic
+    __device__ __forceinline__ void lookup(const Step &s, Recs &o) const {
+        uint32_t w[2];
+        __builtin_memcpy(w, &s.pi, 8);
+        o.a8[0] = (w[0] << 3) & m8; o.a8[1] = (w[0] >> 13) & m8;
+        o.a8[2] = (w[1] << 3) & m8; o.a8[3] = (w[1] >> 13) & m8;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.r[k] = *reinterpret_cast<const PairRec<T> *>(lds + o.a8[k]);
+#ifdef EK_FX_DIAG_NOLOOKUP
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o.r[k] = PairRec<T>{ __uint_as_float(o.a8[k] | 0x3f000000u), T(0.25) };
+#endif
+    }
     template <bool Masked>
-    __device__ __forceinline__ void apply(const Step &s, int rem) {
-        uint32_t l[4];
-        PairRec<T> r[4];
+    __device__ __forceinline__ void apply(const Step &s, const Recs &rc, int rem) {
+        const uint32_t *a8 = rc.a8;
+        const PairRec<T> *r = rc.r;
         int batch = 0;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            l[k] = (uint32_t) s.pi.v[k] & lmask;
-            r[k] = rec[l[k]];
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
             const T x = s.px[k];
-            T sum, v0;
-            EarlyPair<Map, Keep, T>::apply(pair_value(r[k].a, x, r[k].c, Two), sum, v0);
-            const T v1 = dev::safe_mul(x, v0);
-            unsigned long long *p0 = s0 + l[k], *p1 = s1 + l[k];
-            const int q = dev::cvt_sat_i32(sum * 268435456.0f);
+            // (every u of a piece that got here is finite: the piece guard of the kernel -- no fix-up branch per element)
+            const T u = pair_value(r[k].a, x, r[k].c, Two);
+            T sn = T(0), cs = T(0);
+#ifdef EK_FX_DIAG_NOSINCOS
+            sn = u; cs = u * T(0.5);
+#else
+            dev::sincos_f32<Map == EK_SIN || Keep == EK_SIN, Map == EK_COS || Keep == EK_COS, true>(u, sn, cs);
+#endif
+            const T sum = Map == EK_SIN ? sn : cs;
+            T v0 = Keep == EK_SIN ? sn : cs;
+            int q = dev::cvt_sat_i32(sum * 268435456.0f);
             if constexpr (Masked) {
+                // beyond a page's count: the lane adds ZERO to whatever entry its stale index names (in range by the mask) -- no
+                // branch, no private slot; x * 0 = 0 even for a stale infinity (safe_mul is v_mul_legacy_f32)
                 const bool on = k < rem;
-                batch += on ? q : 0;
-                p0 = on ? p0 : priv; p1 = on ? p1 : priv;
-            } else {
-                batch += q;
+                q = on ? q : 0;
+                v0 = on ? v0 : T(0);
             }
-            (void) __hip_atomic_fetch_add(p0, to_fixed64(v0, sc0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            (void) __hip_atomic_fetch_add(p1, to_fixed64(v1, sc1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            batch += q;
+            const T v1 = dev::safe_mul(x, v0);
+            unsigned long long *p = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(lds) + kFixedRecBytes + a8[k]);
+            unsigned long long *p1 = reinterpret_cast<unsigned long long *>(const_cast<unsigned char *>(lds) + 2 * kFixedRecBytes + a8[k]);
+#ifdef EK_FX_DIAG_NOADDS
+            batch += (int) (to_fixed64(v0, up0) >> 20) + (int) (to_fixed64(v1, up1) >> 20) + (int) (size_t) p;
+#else
+            (void) __hip_atomic_fetch_add(p, to_fixed64(v0, up0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            (void) __hip_atomic_fetch_add(p1, to_fixed64(v1, up1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
         }
         iacc += (long long) batch;
     }
     __device__ __forceinline__ void flush() { }
 };
 
-/// batches of a piece's pages handed to the waves from `s_next` (initialised to 3 * kBucketWaves: a wave's first three batches are
-/// wave, wave + 16, wave + 32)
+/// batches of a piece's pages handed to the waves from `s_next` (initialised to 5 * kBucketWaves: a wave's first five batches are
+/// wave, wave + 16, ..., wave + 64)
 template <int PS, typename Body>
 __device__ __forceinline__ void walk_pages_dynamic(const BucketLists &bl, const PieceRange &r, Body &body, uint32_t *s_next) {
     using Step = typename Body::Step;
@@ -264,24 +301,43 @@ __device__ __forceinline__ void walk_pages_dynamic(const BucketLists &bl, const 
         pos = ((size_t) page << PS) + 4u * i;
         rem = (int) count - (int) (4u * i);
     };
-    uint32_t id0 = wave, id1 = wave + kBucketWaves, id2 = wave + 2 * kBucketWaves;
+    // a batch moves through five stages: counter -> list entry -> (l16, x) loads (TWO steps in flight: a step is shorter than the
+    // memory's latency under load) -> record reads -> arithmetic + adds.  The four step buffers, the two record sets and the two
+    // list entries change ROLES from phase to phase instead of being copied: a register move of a value still in flight would
+    // wait for it (s_waitcnt vmcnt(0) at the top of every step is what the rolled form compiles to).
+    uint32_t id0 = wave, id1 = wave + kBucketWaves, id2 = wave + 2 * kBucketWaves, id3 = wave + 3 * kBucketWaves, id4 = wave + 4 * kBucketWaves;
     if (id0 >= nb) return;
-    uint32_t ev0 = entry(id0), ev1 = entry(id1);
-    Step cur, next;
+    uint32_t evA = entry(id0), evB = entry(id1);
+    const uint32_t ev2 = entry(id2);
+    Step st0, st1, st2, st3;
+    typename Body::Recs r0, r1;
     size_t pos;
-    int rem0, rem1;
-    place(id0, ev0, pos, rem0);
-    body.fetch(cur, pos);
+    int rem0, rem1, rem2, rem3 = 0;
+    place(id0, evA, pos, rem0);
+    body.fetch(st0, pos);
+    place(id1, evB, pos, rem1);
+    body.fetch(st1, pos);
+    evB = entry(id3);                                        // (in the order of a phase: the list entry before the data in front of it)
+    place(id2, ev2, pos, rem2);
+    body.fetch(st2, pos);
+    body.lookup(st0, r0);
+    auto phase = [&](const Step &cur, const Step &next, Step &last, const typename Body::Recs &rc, typename Body::Recs &rn, int remc, int &reml,
+                     uint32_t &ev_new, uint32_t ev_old) -> bool {
+        const uint32_t g5 = grab();                          // five batches ahead: the counter
+        ev_new = entry(id4);                                 // four ahead: the list entry
+        place(id3, ev_old, pos, reml);                       // three ahead: the data
+        body.fetch(last, pos);
+        body.lookup(next, rn);                               // one ahead: the records
+        if (__builtin_amdgcn_ballot_w64(remc < 4)) body.template apply<true>(cur, rc, remc);
+        else body.template apply<false>(cur, rc, 4);
+        id0 = id1; id1 = id2; id2 = id3; id3 = id4; id4 = (uint32_t) __builtin_amdgcn_readfirstlane((int) g5);
+        return id0 < nb;
+    };
     while (true) {
-        const uint32_t g3 = grab();                          // three batches ahead: the counter
-        const uint32_t ev2 = entry(id2);                     // two ahead: the list entry
-        place(id1, ev1, pos, rem1);                          // one ahead: the data
-        body.fetch(next, pos);
-        if (__builtin_amdgcn_ballot_w64(rem0 < 4)) body.template apply<true>(cur, rem0);
-        else body.template apply<false>(cur, 4);
-        cur = next; rem0 = rem1; ev1 = ev2;
-        id0 = id1; id1 = id2; id2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) g3);
-        if (id0 >= nb) break;
+        if (!phase(st0, st1, st3, r0, r1, rem0, rem3, evA, evB)) break;
+        if (!phase(st1, st2, st0, r1, r0, rem1, rem0, evB, evA)) break;
+        if (!phase(st2, st3, st1, r0, r1, rem2, rem1, evA, evB)) break;
+        if (!phase(st3, st0, st2, r1, r0, rem3, rem2, evB, evA)) break;
     }
     body.flush();
 }
@@ -340,16 +396,20 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
                                                                                 int map_op, int keep_op, int shift, BucketFinish<T> fin,
                                                                                 const uint32_t *__restrict__ xmax_bits, int S0,
                                                                                 uint32_t *__restrict__ piece_mode) {
-    extern __shared__ __align__(16) unsigned char lds_raw[];
+    extern __shared__ __align__(16) unsigned char lds_dynamic[];
+    // Fixed: a STATIC block (records of 4 Ki entries + 4 Ki pairs of sums, whatever Bins is) -- its address is a constant of the
+    // program, every LDS instruction of the walk carries it in its immediate offset
+    __shared__ __align__(16) unsigned char lds_static[Fixed ? 3 * kFixedRecBytes : 16];
+    unsigned char *lds_raw = Fixed ? lds_static : lds_dynamic;
     const int Bins = 1 << shift;
     PairRec<T> *rec = reinterpret_cast<PairRec<T> *>(lds_raw);
-    T *tables = reinterpret_cast<T *>(rec + Bins);          // f32: Bins {t0, t1} pairs under one lock;  f64: two tables;  Fixed: two planes of 64-bit sums
+    // f32: Bins {t0, t1} pairs under one lock;  f64: two tables;  Fixed: two planes of 64-bit sums (areas of constant size) behind the records
+    T *tables = Fixed ? reinterpret_cast<T *>(lds_raw + kFixedRecBytes) : reinterpret_cast<T *>(rec + Bins);
     __shared__ T wave_part[kBucketWaves];
     __shared__ unsigned long long s_dummy;
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_guard[2];
     __shared__ long long wave_ipart[Fixed ? kBucketWaves : 1];
-    __shared__ unsigned long long s_priv[Fixed ? kBucketThreads : 1];
     constexpr bool Paired = sizeof(T) == 4;
     int bucket;
     PieceRange range;
@@ -366,11 +426,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
 #endif
     stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
     if constexpr (Fixed) {
-        for (int j = threadIdx.x; j < 2 * Bins; j += kBucketThreads) reinterpret_cast<unsigned long long *>(tables)[j] = 0ull;
+        for (int j = threadIdx.x; j < 2 * 4096; j += kBucketThreads) reinterpret_cast<unsigned long long *>(tables)[j] = 0ull;     // both planes, whole areas
     }
     if constexpr (Fixed) {
-        s_priv[threadIdx.x] = 0ull;
-        if (threadIdx.x == 0) { s_next = 3u * kBucketWaves; s_guard[0] = 0u; s_guard[1] = 0u; }
+        if (threadIdx.x == 0) { s_next = 5u * kBucketWaves; s_guard[0] = 0u; s_guard[1] = 0u; }
     }
     __syncthreads();
     T v = T(0);
@@ -438,9 +497,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
             fixed0 = fixed_scale(S0, xm, false);
             fixed1 = fixed_scale(S0, xm, true);
             auto run_fixed = [&](auto body) {
-                body.rec = rec; body.s0 = reinterpret_cast<unsigned long long *>(tables); body.s1 = body.s0 + Bins; body.priv = &s_priv[Fixed ? threadIdx.x : 0];
-                body.pair_idx = pair_idx; body.x_b = x_b; body.lmask = (uint32_t) Bins - 1u;
-                body.sc0 = fixed0; body.sc1 = fixed1; body.iacc = 0;
+                body.lds = lds_raw; body.pair_idx = pair_idx; body.x_b = x_b;
+                asm volatile("v_mov_b32 %0, %1" : "=v"(body.m8) : "s"(((uint32_t) Bins - 1u) << 3));
+                body.up0 = fixed0.upd; body.up1 = fixed1.upd; body.iacc = 0;
                 walk_pages_dynamic<PS>(bl, range, body, &s_next);
                 iv = body.iacc;
             };
@@ -488,12 +547,12 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
             // the piece's slot holds Bins 64-bit sums (fixed point), or Bins floats at its start (a piece under locks)
             long long *out64 = reinterpret_cast<long long *>(table_partials) + ((size_t) c * gridDim.x + blockIdx.x) * Bins;
             if (!locks && single) {
-                const long long *sums = reinterpret_cast<const long long *>(tables) + (size_t) c * Bins;
+                const long long *sums = reinterpret_cast<const long long *>(lds_raw + (c + 1) * kFixedRecBytes);
                 const float back = c ? fixed1.back : fixed0.back;
                 T *outf = reinterpret_cast<T *>(out64);
                 for (int j = threadIdx.x; j < Bins; j += kBucketThreads) outf[j] = (float) sums[j] * back;
             } else if (!locks) {
-                const long long *sums = reinterpret_cast<const long long *>(tables) + (size_t) c * Bins;
+                const long long *sums = reinterpret_cast<const long long *>(lds_raw + (c + 1) * kFixedRecBytes);
                 for (int j = threadIdx.x; j < Bins; j += kBucketThreads) out64[j] = sums[j];
             } else {
                 T *outf = reinterpret_cast<T *>(out64);
@@ -527,7 +586,7 @@ int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, int keep
     // planes of 64-bit sums fit the LDS (24 B per entry: buckets of 4 Ki entries -- EK_BUCKETED_HINT_BOUNDED makes them), and the
     // partition's max |x| at hand.  ENOKI_HIP_EARLY_SUMS=locks: exchange locks for every pair (A/B runs).
     const bool bounded = (map_op == EK_SIN || map_op == EK_COS) && (keep_op == EK_SIN || keep_op == EK_COS);
-    const bool fixed = sizeof(T) == 4 && early_fixed_enabled() && bounded && b->page_shift != 0 && b->active && Bins * 24 <= (size_t) 144 * 1024;
+    const bool fixed = sizeof(T) == 4 && early_fixed_enabled() && bounded && b->page_shift != 0 && b->active && Bins * 8 <= kFixedRecBytes;
     const size_t slot = fixed ? sizeof(long long) : sizeof(T);            // bytes per entry of a piece's partial table
     if (!b->early)
         if (int rc = ek_hip_malloc((size_t) 2 * b->max_pieces * Bins * slot + (fixed ? (size_t) b->max_pieces * sizeof(uint32_t) : 0), &b->early)) return rc;
@@ -548,7 +607,7 @@ int bucketed_forward_adjoint_launch(Bucketed *b, void *out, int map_op, int keep
     if constexpr (sizeof(T) == 8) {
         rc = two ? go(k_bucket_pair_forward_adjoint<T, VV, 0, false, true>) : go(k_bucket_pair_forward_adjoint<T, VV, 0, false, false>);
     } else {
-        if (fixed) lds = Bins * 24;
+        if (fixed) lds = 0;            // (the fixed-point kernels' LDS is static)
 #define EK_GO(PSV) (fixed ? (two ? go(k_bucket_pair_forward_adjoint<T, VV, PSV, true, true>) : go(k_bucket_pair_forward_adjoint<T, VV, PSV, true, false>)) \
                           : (two ? go(k_bucket_pair_forward_adjoint<T, VV, PSV, false, true>) : go(k_bucket_pair_forward_adjoint<T, VV, PSV, false, false>)))
         rc = b->page_shift == 6 ? EK_GO(6) : EK_GO(5);

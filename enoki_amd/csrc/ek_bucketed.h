@@ -120,14 +120,23 @@ struct PieceRange {
 // piece `blockIdx.x` -> its bucket and its share of the bucket's elements (the same cut as k_bin_accumulate)
 template <int PS>
 __device__ __forceinline__ bool bucket_piece(const BucketLists &bl, int &bucket, PieceRange &r) {
-    __shared__ int s_bucket;
+    // ONE round trip to global memory: every thread asks for everything its candidate bucket would need (prefix, bases) at once and
+    // the thread whose bucket holds this piece publishes it -- the search, then the prefix of the bucket found, then its bases were
+    // four dependent round trips, ~2.4 us at the start of every workgroup (profiles/probe_early_phases_r06.txt: "which piece am I")
+    __shared__ uint32_t s_piece[8];
     const int n_buckets = bl.n_buckets;
-    if (blockIdx.x >= bl.piece_prefix[n_buckets]) return false;
-    for (int b = threadIdx.x; b < n_buckets; b += blockDim.x)
-        if (bl.piece_prefix[b] <= blockIdx.x && blockIdx.x < bl.piece_prefix[b + 1]) s_bucket = b;
+    const uint32_t total = bl.piece_prefix[n_buckets];
+    for (int b = threadIdx.x; b < n_buckets; b += blockDim.x) {
+        const uint32_t pp0 = bl.piece_prefix[b], pp1 = bl.piece_prefix[b + 1], lo = bl.base[b], hi = bl.base[b + 1];
+        const uint32_t plo = PS ? bl.base_part[b] : 0u, phi = PS ? bl.base_part[b + 1] : 0u;
+        if (pp0 <= blockIdx.x && blockIdx.x < pp1) {
+            s_piece[0] = (uint32_t) b; s_piece[1] = pp0; s_piece[2] = pp1; s_piece[3] = lo; s_piece[4] = hi; s_piece[5] = plo; s_piece[6] = phi;
+        }
+    }
+    if (blockIdx.x >= total) return false;
     __syncthreads();
-    bucket = s_bucket;
-    const size_t q = blockIdx.x - bl.piece_prefix[bucket], pieces = bl.piece_prefix[bucket + 1] - bl.piece_prefix[bucket];
+    bucket = (int) s_piece[0];
+    const size_t q = blockIdx.x - s_piece[1], pieces = s_piece[2] - s_piece[1];
     auto cut = [&](size_t lo, size_t hi, size_t &b0, size_t &b1) {
         const size_t per = (hi - lo + pieces - 1) / pieces;
         b0 = lo + q * per < hi ? lo + q * per : hi;
@@ -135,12 +144,12 @@ __device__ __forceinline__ bool bucket_piece(const BucketLists &bl, int &bucket,
     };
     r = PieceRange{};
     if constexpr (PS == 0) {
-        cut(bl.base[bucket], bl.base[bucket + 1], r.begin, r.end);
+        cut(s_piece[3], s_piece[4], r.begin, r.end);
     } else {
         size_t a, b;
-        cut(bl.base[bucket], bl.base[bucket + 1], a, b);
+        cut(s_piece[3], s_piece[4], a, b);
         r.f0 = (uint32_t) a; r.f1 = (uint32_t) b;
-        cut(bl.base_part[bucket], bl.base_part[bucket + 1], a, b);
+        cut(s_piece[5], s_piece[6], a, b);
         r.p0 = (uint32_t) a; r.p1 = (uint32_t) b;
     }
     return true;
@@ -523,7 +532,7 @@ __host__ __device__ constexpr bool early_pair_supported(int map_op, int keep_op)
 }
 
 // ---- 64-bit fixed-point adjoint sums (bucketed_early.hip forms them, k_fold_fixed_pieces folds them) ---------------------------
-struct FixedScale { float up /* 2^S */, down /* 2^(S - 32) */, back /* 2^-S */; };
+struct FixedScale { double upd /* 2^S */; float back /* 2^-S */; };
 
 __host__ __device__ inline float pow2f(int e) {                     // 2^e, -126 <= e <= 127
     const uint32_t bits = (uint32_t) (e + 127) << 23;
@@ -545,7 +554,10 @@ __host__ __device__ inline FixedScale fixed_scale(int S0, uint32_t xmax_bits, bo
         if (E < S0 + 1) E = S0 + 1;                                 // (tiny or zero: scaled as if max |x| were 2^(S0 - 126); every factor stays a normal number)
         S = S0 - (E - 126);
     }
-    return FixedScale{ pow2f(S), pow2f(S - 32), pow2f(-S) };
+    const unsigned long long bits = (unsigned long long) (S + 1023) << 52;
+    double up;
+    __builtin_memcpy(&up, &bits, 8);
+    return FixedScale{ up, pow2f(-S) };
 }
 
 /// ENOKI_HIP_EARLY_SUMS=locks: never (exchange locks for every pair, half-size buckets as in round 5)

@@ -11,10 +11,15 @@ namespace ek {
 
 template <int Variant>
 __global__ __launch_bounds__(1024) void k_probe_valu(unsigned long long *__restrict__ out, int iters, float seed) {
-    float f[8]; unsigned u[8];
+    float f[8]; unsigned u[8]; double d[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { f[j] = seed + (float) (threadIdx.x + j); u[j] = threadIdx.x * 8u + (unsigned) j; }
+    for (int j = 0; j < 8; ++j) { f[j] = seed + (float) (threadIdx.x + j); u[j] = threadIdx.x * 8u + (unsigned) j; d[j] = (double) seed + (double) (threadIdx.x + j); }
     const float c1 = seed * 0.5f, c2 = seed + 1.0f;
+    const double dc1 = (double) seed * 0.5, dc2 = (double) seed + 1.0;
+    const float sc1 = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, c1)));
+    double sdc1; { const unsigned long long b = __builtin_bit_cast(unsigned long long, dc1);
+                   const unsigned long long sb = ((unsigned long long) (unsigned) __builtin_amdgcn_readfirstlane((int) (b >> 32)) << 32) | (unsigned) __builtin_amdgcn_readfirstlane((int) b);
+                   sdc1 = __builtin_bit_cast(double, sb); }
     const unsigned m = (unsigned) seed | 0x55u;
     unsigned long long smask = __builtin_amdgcn_ballot_w64((threadIdx.x & 3) != 0), smask2 = 0;
     const unsigned smask_lo = (unsigned) smask;
@@ -67,7 +72,26 @@ __global__ __launch_bounds__(1024) void k_probe_valu(unsigned long long *__restr
             else if constexpr (Variant == 40) asm volatile("v_cmp_eq_f32 vcc, %0, %1\n\tv_cndmask_b32 %2, %2, %3, vcc" :: "v"(f[j]), "v"(c1), "v"(u[j]), "v"(m) : "vcc"); \
             else if constexpr (Variant == 41) asm volatile("v_xor_b32 %0, 0x80000000, %0" : "+v"(u[j])); \
             else if constexpr (Variant == 42) asm volatile("v_bfe_i32 %0, %0, 0, 16" : "+v"(u[j])); \
-            else if constexpr (Variant == 43) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "s"(smask_lo));
+            else if constexpr (Variant == 43) asm volatile("v_and_b32 %0, %1, %0" : "+v"(u[j]) : "s"(smask_lo)); \
+            else if constexpr (Variant == 44) asm volatile("v_cvt_f64_f32 %0, %1" : "=v"(d[j]) : "v"(f[j])); \
+            else if constexpr (Variant == 45) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[j]) : "v"(dc1), "v"(dc2)); \
+            else if constexpr (Variant == 46) asm volatile("v_fma_f64 %0, %0, %1, %2" : "+v"(d[j]) : "s"(sdc1), "v"(dc2)); \
+            else if constexpr (Variant == 47) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[j]) : "v"(dc1)); \
+            else if constexpr (Variant == 48) asm volatile("v_mul_f32_e64 %0, |%0|, %1" : "+v"(f[j]) : "s"(sc1)); \
+            else if constexpr (Variant == 49) asm volatile("v_mul_f32_e64 %0, |%0|, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 50) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(f[j]) : "s"(sc1), "v"(c2)); \
+            else if constexpr (Variant == 51) asm volatile("v_mul_f32 %0, %1, %0" : "+v"(f[j]) : "s"(sc1)); \
+            else if constexpr (Variant == 52) asm volatile("v_ashrrev_i32 %0, 31, %0" : "+v"(u[j])); \
+            else if constexpr (Variant == 53) asm volatile("v_cmp_class_f32 vcc, %0, %1" :: "v"(f[j]), "v"(m) : "vcc"); \
+            else if constexpr (Variant == 54) asm volatile("v_mul_legacy_f32 %0, %0, %1" : "+v"(f[j]) : "v"(c1)); \
+            else if constexpr (Variant == 55) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(u[j]) : "v"(m), "v"(u[(j + 1) & 7])); \
+            else if constexpr (Variant == 56) asm volatile("v_bitop3_b32 %0, %0, %1, %2 bitop3:0x6c" : "+v"(u[j]) : "v"(m), "s"(smask_lo)); \
+            else if constexpr (Variant == 57) asm volatile("v_and_b32_sdwa %0, %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "+v"(u[j]) : "v"(m)); \
+            else if constexpr (Variant == 58) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(*reinterpret_cast<unsigned long long *>(&u[j & 6])) : "v"(*reinterpret_cast<const unsigned long long *>(&f[j & 6]))); \
+            else if constexpr (Variant == 59) asm volatile("v_fmamk_f32 %0, %0, 0x3c08839e, %1" : "+v"(f[j]) : "v"(c2)); \
+            else if constexpr (Variant == 60) asm volatile("v_lshl_add_u64 %0, %0, 2, %1" : "+v"(*reinterpret_cast<unsigned long long *>(&u[j & 6])) : "v"(dc1)); \
+            else if constexpr (Variant == 61) asm volatile("v_add_u32 %0, %1, %0" : "+v"(u[j]) : "s"(smask_lo)); \
+            else if constexpr (Variant == 62) asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(u[j]) : "v"(d[j]));
             EK_REP8(EK_ONE)
 #undef EK_ONE
         }
@@ -75,7 +99,7 @@ __global__ __launch_bounds__(1024) void k_probe_valu(unsigned long long *__restr
     const unsigned long long t1 = __builtin_readcyclecounter();
     float fs = 0; unsigned us = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) { fs += f[j]; us += u[j]; }
+    for (int j = 0; j < 8; ++j) { fs += f[j] + (float) d[j]; us += u[j]; }
     if ((threadIdx.x & 63) == 0) atomicAdd(out, t1 - t0);
     if ((fs == 12345.678f && us == 0xdeadbeefu) || smask2 == 0x123456789ull) out[1] = 1;
 }
@@ -92,6 +116,7 @@ extern "C" EK_API int ek_hip_probe_valu(int variant, int blocks, int iters, unsi
         EK_VV(0) EK_VV(1) EK_VV(2) EK_VV(3) EK_VV(4) EK_VV(5) EK_VV(6) EK_VV(7) EK_VV(8) EK_VV(9) EK_VV(10) EK_VV(11) EK_VV(12) EK_VV(13)
         EK_VV(14) EK_VV(15) EK_VV(16) EK_VV(17) EK_VV(18) EK_VV(19) EK_VV(20) EK_VV(21) EK_VV(22) EK_VV(23) EK_VV(24) EK_VV(25) EK_VV(26) EK_VV(27)
         EK_VV(28) EK_VV(29) EK_VV(30) EK_VV(31) EK_VV(32) EK_VV(33) EK_VV(34) EK_VV(35) EK_VV(36) EK_VV(37) EK_VV(38) EK_VV(39) EK_VV(40) EK_VV(41) EK_VV(42) EK_VV(43)
+        EK_VV(44) EK_VV(45) EK_VV(46) EK_VV(47) EK_VV(48) EK_VV(49) EK_VV(50) EK_VV(51) EK_VV(52) EK_VV(53) EK_VV(54) EK_VV(55) EK_VV(56) EK_VV(57) EK_VV(58) EK_VV(59) EK_VV(60) EK_VV(61) EK_VV(62)
         default: return EK_ERR_INVALID;
     }
 #undef EK_VV

@@ -40,7 +40,8 @@ __device__ __forceinline__ int32_t cvt_sat_i32(float a) {
 // plain operators (:320-323, separately rounded), degree-2 polynomials in z = y^2 (:334-340),
 // s = fma(s, y, y), c = fma(c, z, fma(z, -.5, 1)) (:357-358), quadrant swap and sign fix-up by
 // xor-ing sign bits (:360-366, mulsign = array_router.h:447).
-template <bool Sin, bool Cos>
+// Finite: the caller guarantees a finite x (k_bucket_pair_forward_adjoint's piece guard) -- no fix-up of an infinity.
+template <bool Sin, bool Cos, bool Finite = false>
 __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) {
     float xa = __builtin_fabsf(x);
     int32_t j = cvt_sat_i32(xa * 1.2732395447351626862f);
@@ -57,8 +58,10 @@ __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) 
 
     float z = y * y;
     // z |= eq(xa, inf)  (:331) -- a branch that no wave takes on finite data instead of a select per element
-    if (__builtin_expect(__builtin_amdgcn_ballot_w64(xa == __builtin_inff()) != 0, 0)) {
-        if (xa == __builtin_inff()) z = u2f(0xffffffffu);
+    if constexpr (!Finite) {
+        if (__builtin_expect(__builtin_amdgcn_ballot_w64(xa == __builtin_inff()) != 0, 0)) {
+            if (xa == __builtin_inff()) z = u2f(0xffffffffu);
+        }
     }
 
     float z2 = z * z;
@@ -69,9 +72,16 @@ __device__ __forceinline__ void sincos_f32(float x, float &s_out, float &c_out) 
     s = __builtin_fmaf(s, y, y);
     c = __builtin_fmaf(c, z, __builtin_fmaf(z, -0.5f, 1.0f));
 
-    bool polymask = (j & 2) == 0;
-    if (Sin) s_out = u2f(f2u(polymask ? s : c) ^ (sign_sin & 0x80000000u));
-    if (Cos) c_out = u2f(f2u(polymask ? c : s) ^ (sign_cos & 0x80000000u));
+    // quadrant swap (polymask = (j & 2) == 0 ? s : c) and sign fix-up without the condition register: bit 1 of j spread over a word
+    // selects bit by bit, and x ^ (sign & 0x80000000) is one three-input operation as well -- v_bfe_i32 + 4 x v_bitop3_b32 (~11
+    // issue cycles of a SIMD) against v_and, v_cmp, the wait states of vcc, two v_cndmask and two v_bitop3 with a scalar operand
+    // (~23, profiles/probe_valu_r06.txt).  The sign-bit constant is pinned in a vector register: as a scalar operand it halves
+    // the rate of the instruction.
+    const uint32_t swap = (uint32_t) (((int32_t) ((uint32_t) j << 30)) >> 31);     // all ones: take the other polynomial
+    uint32_t sign_bit;
+    asm("v_mov_b32 %0, 0x80000000" : "=v"(sign_bit));
+    if (Sin) s_out = u2f(__builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(swap, f2u(c), f2u(s), 0xCA), sign_sin, sign_bit, 0x78));
+    if (Cos) c_out = u2f(__builtin_amdgcn_bitop3_b32(__builtin_amdgcn_bitop3_b32(swap, f2u(s), f2u(c), 0xCA), sign_cos, sign_bit, 0x78));
 }
 
 // exp, float branch (array_math.h:711-776): n = floor(fma(log2e, x, .5)); two-step fnmadd range

@@ -15,7 +15,7 @@ name, src, defs = sys.argv[1], sys.argv[2], sys.argv[3:]
 out_dir = os.path.join(ROOT, "build", "variants")
 os.makedirs(out_dir, exist_ok=True)
 obj = os.path.join(out_dir, f"{os.path.basename(src)}-{name}.o")
-subprocess.check_call([b.HIPCC] + b.DEVICE + b.COMMON + defs + ["-c", os.path.join(b.CSRC, src), "-o", obj])
+subprocess.check_call([b.HIPCC] + b.DEVICE + b.COMMON + b.FILE_FLAGS.get(src, []) + defs + ["-c", os.path.join(b.CSRC, src), "-o", obj])
 others = [os.path.join(b.OBJ, s + ".o") for s in b.LIB_SOURCES if s != src]
 lib = os.path.join(out_dir, f"libenoki-hip-{name}.so")
 subprocess.check_call([b.HIPCC] + b.DEVICE + ["-shared", "-fPIC", "-o", lib, obj] + others)

@@ -9,7 +9,7 @@ srcs = sys.argv[1:] or [os.path.join(B.CSRC, s) for s in B.LIB_SOURCES if s.ends
 
 
 def one(src):
-    cmd = [B.HIPCC] + B.DEVICE + B.COMMON + ["--cuda-device-only", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
+    cmd = [B.HIPCC] + B.DEVICE + B.COMMON + B.FILE_FLAGS.get(os.path.basename(src), []) + ["--cuda-device-only", "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"]
     err = subprocess.run(cmd, capture_output=True, text=True).stderr
     rows, cur = [], None
     for line in err.splitlines():
