@@ -646,9 +646,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
         static const bool want = [] { const char *e = getenv("ENOKI_HIP_WDIR_LDS"); return !e || atoi(e) != 0; }();
         size_t lds = p.lds;
         out.wdir_lds = 0;
-        hipFuncAttributes attr;
-        if (want && hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess &&
-            attr.sharedSizeBytes + p.lds + (size_t) p.slots * sizeof(uint32_t) <= (size_t) 160 * 1024) {
+        const size_t fixed_lds = want ? static_lds_of(kernel) : SIZE_MAX;
+        if (fixed_lds != SIZE_MAX && fixed_lds + p.lds + (size_t) p.slots * sizeof(uint32_t) <= (size_t) 160 * 1024) {
             lds += (size_t) p.slots * sizeof(uint32_t);
             out.wdir_lds = 1;
         }
@@ -1043,15 +1042,14 @@ static int index_partition_run_paged(IndexPartition *ip, const uint32_t *index, 
     out.active = gtotal + 2 * kMaxBuckets + kPgMetaAccum;
     out.lo = 0; out.span = (uint32_t) std::min<size_t>(ip->info.range, 0xFFFFFFFFu);
     out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = kPgWeightBand;
-    EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
-    note_launch("index_partition_meta_clear", 3 * kMaxBuckets, 3 * kMaxBuckets * sizeof(uint32_t));
+    // (a kernel of our own: the runtime's memset is a launch with its own barrier packets around it -- the step's widest gap)
+    if (int rc = ek_hip_fill(EK_U32, gtotal, 0, 3 * kMaxBuckets)) return rc;
     const int vec_ok = aligned16(index) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
         size_t lds = p.lds;
         out.wdir_lds = 0;
-        hipFuncAttributes attr;
-        if (hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess &&
-            attr.sharedSizeBytes + p.lds + (size_t) p.slots * sizeof(uint32_t) <= (size_t) 160 * 1024) {
+        const size_t fixed_lds = static_lds_of(kernel);
+        if (fixed_lds != SIZE_MAX && fixed_lds + p.lds + (size_t) p.slots * sizeof(uint32_t) <= (size_t) 160 * 1024) {
             lds += (size_t) p.slots * sizeof(uint32_t);
             out.wdir_lds = 1;
         }

@@ -3,6 +3,8 @@
 // walked, the table slice in the LDS, the exchange locks of the gradient sums, the reduction finished by the last workgroup,
 // and the host-side object.  Split out of bucketed.hip in round 6 so that a change to one kernel family recompiles one unit.
 #pragma once
+#include <mutex>
+#include <unordered_map>
 #include <cstdlib>
 #include <cstring>
 #include "ek_binned.h"
@@ -630,9 +632,28 @@ struct Bucketed {
 };
 
 template <typename K> static inline int allow_big_lds(K kernel, size_t bytes) {
-    // beyond 64 KiB of dynamic LDS a kernel has to opt in
+    // beyond 64 KiB of dynamic LDS a kernel has to opt in -- once per kernel and size (a runtime call per launch otherwise)
+    static std::unordered_map<const void *, size_t> allowed;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    size_t &have = allowed[reinterpret_cast<const void *>(kernel)];
+    if (bytes <= have) return EK_OK;
     EK_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int) bytes));
+    have = bytes;
     return EK_OK;
+}
+
+/// static LDS of a kernel (hipFuncGetAttributes, asked once per kernel); SIZE_MAX when the runtime cannot say
+template <typename K> static inline size_t static_lds_of(K kernel) {
+    static std::unordered_map<const void *, size_t> known;
+    static std::mutex lock;
+    std::lock_guard<std::mutex> guard(lock);
+    auto it = known.find(reinterpret_cast<const void *>(kernel));
+    if (it != known.end()) return it->second;
+    hipFuncAttributes attr;
+    const size_t v = hipFuncGetAttributes(&attr, reinterpret_cast<const void *>(kernel)) == hipSuccess ? (size_t) attr.sharedSizeBytes : SIZE_MAX;
+    known[reinterpret_cast<const void *>(kernel)] = v;
+    return v;
 }
 
 // kernel variants by list layout: contiguous for 8-byte element types, pages of 32 / 64 elements for 4-byte ones
