@@ -365,7 +365,7 @@ struct MetaRing {
     void *block[kBlocks] = {};
     bool busy[kBlocks] = {}, clean[kBlocks] = {};
     // (16 bytes per piece: a float partial, or -- the fixed-point forward + adjoint kernel -- a 64-bit integer partial and a float one)
-    static size_t bytes() { return (3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1) * sizeof(uint32_t) + kPartials * 16 + 16; }
+    static size_t bytes() { return (kPgCounterWords + 3 * (kMaxBuckets + 1) + 1) * sizeof(uint32_t) + kPartials * 16 + 16; }
 };
 static MetaRing &meta_ring() { static MetaRing *r = new MetaRing(); return *r; }
 
@@ -575,8 +575,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->positions = p.page_slots << p.page_shift;
     const uint32_t target_pieces = (uint32_t) bucket_target_pieces(n, n_buckets);
     b->max_pieces = target_pieces + (unsigned) n_buckets;
-    // meta: gtotal[3][256] | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
-    const size_t meta_words = 3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
+    // meta: page totals [kPgReplicas][2][256] + meta row [256] (kPgCounterWords) | base_full[257] | base_part[257] | piece_prefix[257] | reduce partials
+    const size_t meta_words = kPgCounterWords + 3 * (kMaxBuckets + 1) + 1;
     // the counter block: one of the context's ring when one is free (then usually without a fill, see MetaRing), else an allocation
     bool filled = false;
     static const bool use_ring = [] { const char *e = getenv("ENOKI_HIP_META_RING"); return !e || atoi(e) != 0; }();
@@ -603,9 +603,9 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     b->glist_full = (uint32_t *) b->page_lists;
     b->glist_part = b->glist_full + p.page_slots;
     uint32_t *gtotal = (uint32_t *) b->meta;
-    b->bucket_base = gtotal + 3 * kMaxBuckets;
-    b->active = gtotal + 2 * kMaxBuckets + kPgMetaResult;        // (written by the directory launch from the partition's accumulators)
-    b->ticket = gtotal + 2 * kMaxBuckets + kPgMetaFinishTicket;  // (zero between launches: reset by whoever draws the last ticket)
+    b->bucket_base = gtotal + kPgCounterWords;
+    b->active = gtotal + kPgMetaBase + kPgMetaResult;        // (written by the directory launch from the partition's accumulators)
+    b->ticket = gtotal + kPgMetaBase + kPgMetaFinishTicket;  // (zero between launches: reset by whoever draws the last ticket)
     b->has_mask = mask.vec != 0;
     b->base_part = b->bucket_base + kMaxBuckets + 1;
     b->piece_prefix = b->base_part + kMaxBuckets + 1;
@@ -622,7 +622,7 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     out.loff = out.cnt_full + part_entries;
     out.part = out.loff + part_entries;
     out.gtotal = gtotal;
-    out.active = gtotal + 2 * kMaxBuckets + kPgMetaAccum;
+    out.active = gtotal + kPgMetaBase + kPgMetaAccum;
     out.lo = b->win_lo; out.span = b->win_span ? b->win_span : (uint32_t) std::min<size_t>(b->table_size, 0xFFFFFFFFu);
     // tiles dealt to the classes w % 8 by the weights the previous launches fed back (ek_paged.h); a launch of at least 32 tiles per
     // workgroup stamps its loops and lets the directory launch update the weights
@@ -636,8 +636,8 @@ static int bucketed_create_paged(Bucketed *b, const float *x, const I *index, co
     static const uint32_t band = [] { const char *e = getenv("ENOKI_HIP_XCD_BAND"); return e ? (uint32_t) atoi(e) : kPgWeightBand; }();
     out.class_band = band;
     if (!filled) {
-        EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
-        note_launch("bucket_meta_clear", 3 * kMaxBuckets, 3 * kMaxBuckets * sizeof(uint32_t));   // (its own mark: a profiled run must not bill the fill to the partition)
+        EK_HIP_CHECK(hipMemsetAsync(gtotal, 0, kPgCounterWords * sizeof(uint32_t), c.stream));
+        note_launch("bucket_meta_clear", kPgCounterWords, kPgCounterWords * sizeof(uint32_t));   // (its own mark: a profiled run must not bill the fill to the partition)
     }
     const int vec_ok = aligned16(index) && aligned16(x) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
@@ -1020,12 +1020,12 @@ static int index_partition_run_paged(IndexPartition *ip, const uint32_t *index, 
     Context &c = ctx();
     const PagedPlan p = paged_plan(n, n_buckets, c.num_cu, false, true);
     if (p.W > 1024) return fail(EK_ERR_UNSUPPORTED, "ek_hip_index_partition_create(): %u workgroups", p.W);
-    const size_t meta_words = 3 * kMaxBuckets + 3 * (kMaxBuckets + 1) + 1;
+    const size_t meta_words = kPgCounterWords + 3 * (kMaxBuckets + 1) + 1;
     if (int rc = ek_hip_malloc(meta_words * sizeof(uint32_t), &ip->meta)) return rc;
     if (int rc = ek_hip_malloc((p.page_slots << p.page_shift) * sizeof(uint32_t), &ip->local)) return rc;
     const size_t part_entries = (size_t) p.W * n_buckets;
     if (int rc = ek_hip_malloc((p.page_slots + part_entries + 1) * sizeof(uint32_t), &ip->lists)) return rc;
-    uint32_t *gtotal = (uint32_t *) ip->meta, *base_full = gtotal + 3 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1,
+    uint32_t *gtotal = (uint32_t *) ip->meta, *base_full = gtotal + kPgCounterWords, *base_part = base_full + kMaxBuckets + 1,
              *piece_prefix = base_part + kMaxBuckets + 1;
     uint32_t *glist_full = (uint32_t *) ip->lists, *glist_part = glist_full + p.page_slots;
     Scratch work;
@@ -1039,11 +1039,11 @@ static int index_partition_run_paged(IndexPartition *ip, const uint32_t *index, 
     out.loff = out.cnt_full + part_entries;
     out.part = out.loff + part_entries;
     out.gtotal = gtotal;
-    out.active = gtotal + 2 * kMaxBuckets + kPgMetaAccum;
+    out.active = gtotal + kPgMetaBase + kPgMetaAccum;
     out.lo = 0; out.span = (uint32_t) std::min<size_t>(ip->info.range, 0xFFFFFFFFu);
     out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = kPgWeightBand;
     // (a kernel of our own: the runtime's memset is a launch with its own barrier packets around it -- the step's widest gap)
-    if (int rc = ek_hip_fill(EK_U32, gtotal, 0, 3 * kMaxBuckets)) return rc;
+    if (int rc = ek_hip_fill(EK_U32, gtotal, 0, kPgCounterWords)) return rc;
     const int vec_ok = aligned16(index) && arg_aligned(mask);
     auto launch = [&](auto kernel) -> int {
         size_t lds = p.lds;

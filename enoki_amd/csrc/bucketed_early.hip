@@ -360,7 +360,7 @@ __device__ __forceinline__ void bucket_finish_fixed(long long iblock /* thread 0
     __syncthreads();
     if (!s_last_fixed) return;
     if (counters) {
-        for (unsigned k = threadIdx.x; k < 2u * kMaxBuckets + 4u; k += blockDim.x) counters[k] = 0u;
+        for (unsigned k = threadIdx.x; k < kPgTotalsWords + 4u; k += blockDim.x) counters[k] = 0u;
     }
     long long iv = 0;
     float fv = 0.f;

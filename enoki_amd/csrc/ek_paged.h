@@ -34,7 +34,19 @@ constexpr int kPgThreads = 1024;
 constexpr int kPgTile = 4 * kPgThreads;
 constexpr int kPgLdsElems = 16384;             // elements staged per workgroup, all buckets together (128 KiB of 8-byte records)
 constexpr uint32_t kNoPage = 0xFFFFFFFFu;
-// words of the third row of the counter block (gtotal[2][.]): what the partition accumulates, the tickets, what the consumers read
+// The counter block of a partition: kPgReplicas copies of the per-bucket page totals ([replica][full | partially filled][bucket]; a
+// workgroup adds to copy w % kPgReplicas, the directory launch adds the copies up), then the meta row.  ONE copy meant 256 workgroups
+// queueing on every word: device-scope atomics on one address are served one after the other (~40 ns each), and the workgroups wait
+// for their acknowledgements before they may list their pages -- 10-12 us at the end of every workgroup, which an 8 Mi-element shard
+// (all workgroups finishing together) shows in full: partition 49 -> 37 us with 8 copies (profiles/probe_paged_r06.txt, section 6).
+#ifndef EK_PG_REPLICAS
+#define EK_PG_REPLICAS 8            // (measurement builds: -DEK_PG_REPLICAS=1 in EVERY unit that includes this header)
+#endif
+constexpr int kPgReplicas = EK_PG_REPLICAS;
+constexpr uint32_t kPgTotalsWords = (uint32_t) kPgReplicas * 2u * kMaxBuckets;
+constexpr uint32_t kPgMetaBase = kPgTotalsWords;                       // the meta row (kPgMeta* below)
+constexpr uint32_t kPgCounterWords = kPgTotalsWords + kMaxBuckets;     // what is zero when a launch starts
+// words of the meta row of the counter block (gtotal + kPgMetaBase): what the partition accumulates, the tickets, what the consumers read
 enum { kPgMetaAccum = 0 /* [2] */, kPgMetaFinishTicket = 2, kPgMetaAccumXmax = 3, kPgMetaResult = 4 /* [2] */, kPgMetaResultXmax = 6 };
 // Workgroup w is dispatched to XCD w % 8, and on every box seen so far one XCD runs the same streaming work ~9 % slower than the
 // other seven (profiles/probe_paged_phases_r05.txt): with equal chunks the kernel ends when that XCD ends.  The eight CLASSES
@@ -53,7 +65,7 @@ template <typename T> struct PagedOut {
     uint32_t *cnt_full;    // [n_buckets][W]  full pages of the workgroup per bucket
     uint32_t *loff;        // [n_buckets][W]  where they start in wlist[w]
     uint32_t *part;        // [n_buckets][W]  page << 6 | (count - 1) of the partially filled page, or kNoPage
-    uint32_t *gtotal;      // [2][kMaxBuckets]  full / partially filled pages per bucket over all workgroups (zeroed by the host)
+    uint32_t *gtotal;      // [kPgReplicas][2][kMaxBuckets]  full / partially filled pages per bucket over the workgroups of a replica (zero at launch)
     uint32_t *active;      // [0] number of elements kept, [1] != 0: a lane whose mask bit is clear carries a non-finite x (zeroed by the host)
     uint32_t lo, span;     // only indices in [lo, lo + span) are kept, rebased to lo: the table (lo = 0, span = its size) or a slice of it
     const uint32_t *class_w;   // [kPgClasses] weights of the classes w % 8 (nullptr: equal chunks, `chunk` elements each)
@@ -458,12 +470,12 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
                     jobs[p] = (uint32_t) b | (((org[j] >> PS) & (cap_pages - 1u)) << 8);
                     entry = (uint32_t) ((wbase + ps0 + p) << 6) | (fl[j] - 1u);
                     ++p;
-                    atomicAdd(&out.gtotal[kMaxBuckets + b], 1u);
+                    atomicAdd(&out.gtotal[(w % kPgReplicas) * 2u * kMaxBuckets + kMaxBuckets + b], 1u);
                 }
                 out.part[(size_t) b * W + w] = entry;
                 out.cnt_full[(size_t) b * W + w] = full[j];
                 out.loff[(size_t) b * W + w] = lo;
-                if (full[j]) atomicAdd(&out.gtotal[b], full[j]);
+                if (full[j]) atomicAdd(&out.gtotal[(w % kPgReplicas) * 2u * kMaxBuckets + b], full[j]);
                 cnt[b] = lo;                                    // from here on: where the bucket's pages start in wlist[w]
                 lo += full[j];
             }
@@ -552,7 +564,11 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
     __shared__ uint32_t s_fb, s_pb, s_f;
     const int t = threadIdx.x, b = blockIdx.x, slice = blockIdx.y;
     // everything this workgroup reads from global memory, requested up front
-    const uint32_t f = t < n_buckets ? gtotal[t] : 0u, p = t < n_buckets ? gtotal[kMaxBuckets + t] : 0u;
+    uint32_t f = 0, p = 0;
+    if (t < n_buckets) {
+#pragma unroll
+        for (int r = 0; r < kPgReplicas; ++r) { f += gtotal[r * 2 * kMaxBuckets + t]; p += gtotal[r * 2 * kMaxBuckets + kMaxBuckets + t]; }
+    }
     uint32_t c[4], ent[4], lo[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -635,8 +651,8 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
     // what the partition accumulated (elements kept, "non-finite x under a cleared mask bit") goes to where the consumers read it;
     // the accumulators and the page totals are cleared by the last workgroup of the first reducing launch (bucket_finish), after
     // which the block can serve the next object without a fill (csrc/bucketed.hip: MetaRing)
-    if (b == 0 && slice == 0 && t < 2) gtotal[2 * kMaxBuckets + kPgMetaResult + t] = gtotal[2 * kMaxBuckets + kPgMetaAccum + t];
-    if (b == 0 && slice == 0 && t == 2) gtotal[2 * kMaxBuckets + kPgMetaResultXmax] = gtotal[2 * kMaxBuckets + kPgMetaAccumXmax];
+    if (b == 0 && slice == 0 && t < 2) gtotal[kPgMetaBase + kPgMetaResult + t] = gtotal[kPgMetaBase + kPgMetaAccum + t];
+    if (b == 0 && slice == 0 && t == 2) gtotal[kPgMetaBase + kPgMetaResultXmax] = gtotal[kPgMetaBase + kPgMetaAccumXmax];
     // Feedback for the next partition launch (class_w != nullptr only after a launch long enough to say something): a class's speed
     // is its share of the tiles over the mean loop duration of its workgroups; the new weight moves an eighth of the way towards
     // the share that would have made the durations equal, within [0.88, 1.12].  Equal durations are a fixed point; the class means

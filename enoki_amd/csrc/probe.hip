@@ -519,7 +519,7 @@ extern "C" EK_API int ek_hip_probe_page_plan(size_t n, size_t table_size, int sh
     return EK_OK;
 }
 
-// meta: uint32 words laid out as  gtotal[512] | base_full[257] | base_part[257] | piece_prefix[257] | cnt_full[nb*W] | loff[nb*W] | part[nb*W]
+// meta: uint32 words laid out as  counter block [kPgCounterWords = 4352] | base_full[257] | base_part[257] | piece_prefix[257] | cnt_full[nb*W] | loff[nb*W] | part[nb*W]
 extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const void *index, const float *x, const uint8_t *mask,
                                                   size_t n, size_t table_size, int shift, uint32_t target_pieces, uint16_t *lp,
                                                   float *xp, uint32_t *wdir, uint32_t *wlist, uint32_t *glist_full,
@@ -533,7 +533,7 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
     PagedOut<float> out;
     out.lp = lp; out.xp = xp; out.wdir = wdir; out.wlist = wlist;
     out.gtotal = meta;
-    out.active = meta + 2 * kMaxBuckets;
+    out.active = meta + kPgMetaBase;
     out.lo = 0; out.span = (uint32_t) std::min<size_t>(table_size, 0xFFFFFFFFu);
     out.class_w = nullptr; out.class_stamp = nullptr; out.class_band = 0; out.wdir_lds = 0;             // (equal chunks: the probe measures the kernel, not the balancing)
 #ifdef EK_PG_TIMING
@@ -541,11 +541,11 @@ extern "C" EK_API int ek_hip_probe_page_partition(int nts, int index64, const vo
 #else
     (void) dbg;
 #endif
-    uint32_t *base_full = meta + 3 * kMaxBuckets, *base_part = base_full + kMaxBuckets + 1, *piece_prefix = base_part + kMaxBuckets + 1;
+    uint32_t *base_full = meta + kPgCounterWords, *base_part = base_full + kMaxBuckets + 1, *piece_prefix = base_part + kMaxBuckets + 1;
     out.cnt_full = piece_prefix + kMaxBuckets + 1;
     out.loff = out.cnt_full + (size_t) n_buckets * p.W;
     out.part = out.loff + (size_t) n_buckets * p.W;
-    EK_HIP_CHECK(hipMemsetAsync(meta, 0, 3 * kMaxBuckets * sizeof(uint32_t), c.stream));
+    EK_HIP_CHECK(hipMemsetAsync(meta, 0, kPgCounterWords * sizeof(uint32_t), c.stream));
     const Arg<uint8_t> m{ mask, 1, mask ? 1u : 0u };
     const int vec_ok = aligned16(index) && aligned16(x) && (!mask || aligned16(mask));
 #define EK_PP_LAUNCH(I, PS, HM)                                                                                                        \

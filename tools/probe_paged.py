@@ -10,6 +10,9 @@ pl = capi.probe_lib()
 mode = sys.argv[1] if len(sys.argv) > 1 else "all"
 
 
+CB = 8 * 2 * 256 + 256          # words of the counter block (csrc/ek_paged.h: kPgCounterWords)
+
+
 def pcheck(rc):
     if rc != 0:
         raise RuntimeError(pl.ek_hip_probe_last_error().decode())
@@ -31,7 +34,7 @@ class Run:
         self.wlist = capi.Buf(np.uint32, self.page_slots)
         self.gfull = capi.Buf(np.uint32, self.page_slots)
         self.gpart = capi.Buf(np.uint32, self.W * self.nb + 1)
-        self.meta = capi.Buf(np.uint32, 768 + 3 * 257 + 3 * self.nb * self.W)
+        self.meta = capi.Buf(np.uint32, CB + 3 * 257 + 3 * self.nb * self.W)
         self.tp = target_pieces
         self.dbg = capi.Buf(np.uint64, self.W * 24)
 
@@ -46,7 +49,7 @@ class Run:
         page = 1 << self.ps
         lp, xp = self.lp.numpy(), self.xp.numpy()
         gfull, gpart, meta = self.gfull.numpy(), self.gpart.numpy(), self.meta.numpy()
-        bf, bp, pp = meta[768:768 + 257], meta[768 + 257:768 + 514], meta[768 + 514:768 + 771]
+        bf, bp, pp = meta[CB:CB + 257], meta[CB + 257:CB + 514], meta[CB + 514:CB + 771]
         nb = self.nb
         on = np.ones(self.n, bool) if mask_h is None else mask_h.astype(bool)
         keys_in = idx_h[on].astype(np.uint64)
