@@ -34,7 +34,7 @@ template <int Map, int Keep, typename T> struct EarlyPair {
 };
 
 #ifdef EK_EARLY_TIMING
-__device__ unsigned long long g_early_timing[16];
+__device__ unsigned long long g_early_timing[32];       // [16..31]: the fixed-point path per workgroup (thread 0)
 #endif
 
 template <typename T, int V, int Map, int Keep, bool Two>
@@ -355,7 +355,14 @@ __device__ __forceinline__ void bucket_finish_fixed(long long iblock /* thread 0
     if (threadIdx.x == 0) {
         __hip_atomic_store(ipartials + blockIdx.x, (unsigned long long) iblock, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(fpartials + blockIdx.x, __float_as_uint(fblock), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last_fixed = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+#ifdef EK_EARLY_TIMING
+        const unsigned long long t_tk = __builtin_readcyclecounter();
+#endif
+        s_last_fixed = finish_ticket(ticket);             // (relaxed, behind a wait for the stores above: ek_bucketed.h)
+#ifdef EK_EARLY_TIMING
+        const unsigned long long dt_tk = __builtin_readcyclecounter() - t_tk;
+        atomicAdd(&g_early_timing[24], dt_tk); atomicMax(&g_early_timing[25], dt_tk);
+#endif
     }
     __syncthreads();
     if (!s_last_fixed) return;
@@ -381,7 +388,7 @@ __device__ __forceinline__ void bucket_finish_fixed(long long iblock /* thread 0
         if (threadIdx.x == 0) {
             const float r = (float) iv * 3.7252902984619140625e-9f /* 2^-28 */ + fv;
             out[0] = bucket_dropped_lanes<float, EK_HSUM>(r, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            finish_ticket_reset(ticket);
         }
     }
 }
@@ -423,6 +430,10 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     }
 #ifdef EK_EARLY_TIMING
     const unsigned long long t_piece = __builtin_readcyclecounter();
+#endif
+#ifdef EK_EARLY_TIMING
+    unsigned long long fx_t[6] = { 0, 0, 0, 0, 0, 0 };
+    fx_t[0] = __builtin_readcyclecounter();           // piece known
 #endif
     stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
     if constexpr (Fixed) {
@@ -500,7 +511,13 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
                 body.lds = lds_raw; body.pair_idx = pair_idx; body.x_b = x_b;
                 asm volatile("v_mov_b32 %0, %1" : "=v"(body.m8) : "s"(((uint32_t) Bins - 1u) << 3));
                 body.up0 = fixed0.upd; body.up1 = fixed1.upd; body.iacc = 0;
+#ifdef EK_EARLY_TIMING
+                fx_t[1] = __builtin_readcyclecounter();   // slice staged, planes cleared, guards decided
+#endif
                 walk_pages_dynamic<PS>(bl, range, body, &s_next);
+#ifdef EK_EARLY_TIMING
+                fx_t[2] = __builtin_readcyclecounter();   // this wave's walk done
+#endif
                 iv = body.iacc;
             };
             // (launched for the pairs whose functions are bounded by 1 only: bucketed_forward_adjoint_launch)
@@ -529,6 +546,9 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     }
     if (lane == 0) wave_part[wave] = v;
     __syncthreads();
+#ifdef EK_EARLY_TIMING
+    fx_t[3] = __builtin_readcyclecounter();               // every wave's walk done
+#endif
     if (threadIdx.x < 64) {
         v = threadIdx.x < kBucketWaves ? wave_part[threadIdx.x] : T(0);
 #pragma unroll
@@ -571,8 +591,29 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         atomicMax(&g_early_timing[15], t_out - t_entry);
     }
 #endif
+#ifdef EK_EARLY_TIMING
+    if constexpr (Fixed) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        fx_t[4] = __builtin_readcyclecounter();           // tables written
+    }
+#endif
     if constexpr (Fixed) bucket_finish_fixed(iv, v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
     else bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
+#ifdef EK_EARLY_TIMING
+    if constexpr (Fixed) {
+        if (threadIdx.x == 0 && fx_t[1]) {
+            fx_t[5] = __builtin_readcyclecounter();
+            atomicAdd(&g_early_timing[16], fx_t[0] - t_entry);      // which piece am I
+            atomicAdd(&g_early_timing[17], fx_t[1] - fx_t[0]);      // staging, clearing, guards
+            atomicAdd(&g_early_timing[18], fx_t[2] - fx_t[1]);      // wave 0's walk
+            atomicAdd(&g_early_timing[19], fx_t[3] - fx_t[2]);      // waiting for the slowest wave
+            atomicAdd(&g_early_timing[20], fx_t[4] - fx_t[3]);      // tables converted and written
+            atomicAdd(&g_early_timing[21], fx_t[5] - fx_t[4]);      // finish (ticket; the last workgroup: the reduction)
+            atomicAdd(&g_early_timing[22], 1ull);
+            atomicMax(&g_early_timing[23], fx_t[5] - t_entry);
+        }
+    }
+#endif
 }
 
 template <typename T>
@@ -639,8 +680,8 @@ template int bucketed_forward_adjoint_launch<double>(Bucketed *, void *, int, in
 /// measurement builds only: reads and clears the phase counters of k_bucket_pair_forward_adjoint (summed over the waves)
 extern "C" EK_API int ek_hip_debug_early_timing(unsigned long long *out8) {
     (void) hipDeviceSynchronize();
-    (void) hipMemcpyFromSymbol(out8, HIP_SYMBOL(ek::g_early_timing), 16 * sizeof(unsigned long long));
-    unsigned long long zero[16] = {};
+    (void) hipMemcpyFromSymbol(out8, HIP_SYMBOL(ek::g_early_timing), 32 * sizeof(unsigned long long));
+    unsigned long long zero[32] = {};
     (void) hipMemcpyToSymbol(HIP_SYMBOL(ek::g_early_timing), zero, sizeof(zero));
     return EK_OK;
 }

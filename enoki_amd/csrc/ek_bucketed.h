@@ -274,6 +274,26 @@ __device__ __forceinline__ T bucket_dropped_lanes(T r, size_t masked, bool nonfi
 // partials (agent-scope loads: they were written on other XCDs), adds what the dropped lanes contribute and resets the ticket
 // for the next launch -- launches on one object are ordered by the stream.  `ticket` == nullptr: the host launches
 // k_bucket_reduce_final (objects whose meta block is not zero-filled: 8-byte element types).
+/// The finish ticket of a launch, drawn by ONE thread of every workgroup after its partials are in memory; true for the workgroup that
+/// draws the last one.  A RELAXED agent-scope atomic behind a wait for the wave's outstanding stores (the partials are agent-scope
+/// stores, written through to memory; the last workgroup reads them with agent-scope loads): an acquire-release ticket is that wait
+/// PLUS a write-back of the XCD's whole L2 -- the tables of 32 workgroups, which only the next launch reads -- and an invalidate:
+/// 4.5 us per workgroup on average, 14-18 us for the unluckiest one, at the end of every launch; the forward + adjoint kernel went
+/// 107-111 -> 99-100 us at 64 Mi elements, 41.8 -> 35.2 in an 8 Mi shard, same call (profiles/probe_early_fixed_phases_r06.txt).
+/// A two-level ticket (groups of 32 workgroups) on top measured no better: what remains of the wait is the latency of the wave's
+/// own table stores.  -DEK_FINISH_ACQ_REL restores the fenced form for A/B runs.
+__device__ __forceinline__ bool finish_ticket(uint32_t *__restrict__ ticket) {
+#ifdef EK_FINISH_ACQ_REL
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    return __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+#endif
+}
+__device__ __forceinline__ void finish_ticket_reset(uint32_t *__restrict__ ticket) {
+    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <typename T, int ROp>
 __device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *__restrict__ partials, uint32_t *__restrict__ ticket,
                                               T *__restrict__ out, const uint32_t *__restrict__ active, size_t n, int map_op,
@@ -285,7 +305,7 @@ __device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *
         Bits b;
         __builtin_memcpy(&b, &block_result, sizeof(T));
         __hip_atomic_store(reinterpret_cast<Bits *>(partials) + blockIdx.x, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_last = ticket && __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+        s_last = ticket && finish_ticket(ticket);
     }
     __syncthreads();
     if (!s_last) return;
@@ -314,7 +334,7 @@ __device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *
         for (int d = 8; d >= 1; d >>= 1) v = R::combine(v, bucket_shfl_down(v, d));
         if (threadIdx.x == 0) {
             out[0] = bucket_dropped_lanes<T, ROp>(v, active ? n - (size_t) active[0] : 0, active && active[1], map_op);
-            __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            finish_ticket_reset(ticket);
         }
     }
 }
