@@ -1,3 +1,7 @@
+# The tail of k_page_partition alone (tools/probe_paged.py, probe libraries built with -DEK_PG_TIMING): variants are copied from
+# build/variants/probe-<name>.so (ENOKI_PROBE_DEFINES="-DEK_PG_TIMING -DEK_PG_REPLICAS=1" python -c 'from enoki_amd import _build as B; B.build_probe(force=True)',
+# then cp enoki_amd/libenoki-hip-probe.so build/variants/probe-<name>.so).  Round 6 ran base / spread / noactive / both, where spread was a measurement
+# variant of what became kPgReplicas.
 cd $GRAFT_REPO_ROOT
 for v in base spread noactive both base; do
   cp build/variants/probe-$v.so enoki_amd/libenoki-hip-probe.so
