@@ -346,10 +346,10 @@ __device__ __forceinline__ void walk_pages_dynamic(const BucketLists &bl, const 
 /// bucket_finish for the fixed-point kernel: every workgroup publishes an INTEGER partial (units of 2^-28; pieces that ran under locks: 0)
 /// and a float one (pieces under locks; 0 otherwise); the last workgroup adds the integers exactly -- the order cannot matter --,
 /// converts once, and adds the float partials in the order of the pieces.
-__device__ __forceinline__ void bucket_finish_fixed(long long iblock /* thread 0 */, float fblock /* thread 0 */, float *__restrict__ partials,
-                                                    uint32_t *__restrict__ ticket, float *__restrict__ out, const uint32_t *__restrict__ active,
-                                                    size_t n, int map_op, float *wave_part, long long *wave_ipart, uint32_t *__restrict__ counters) {
-    __shared__ uint32_t s_last_fixed;
+/// first half: thread 0 publishes the workgroup's partials and draws the ticket -- BEFORE the workgroup writes its tables, so that the
+/// ticket's round trip (and its wait for the wave's stores, none outstanding yet) runs under the conversion of the tables
+__device__ __forceinline__ void bucket_finish_fixed_begin(long long iblock /* thread 0 */, float fblock /* thread 0 */, float *__restrict__ partials,
+                                                          uint32_t *__restrict__ ticket, uint32_t *s_last_fixed /* shared */) {
     unsigned long long *ipartials = reinterpret_cast<unsigned long long *>(partials);             // [gridDim.x] integers, then [gridDim.x] floats
     uint32_t *fpartials = reinterpret_cast<uint32_t *>(ipartials + gridDim.x);
     if (threadIdx.x == 0) {
@@ -358,14 +358,20 @@ __device__ __forceinline__ void bucket_finish_fixed(long long iblock /* thread 0
 #ifdef EK_EARLY_TIMING
         const unsigned long long t_tk = __builtin_readcyclecounter();
 #endif
-        s_last_fixed = finish_ticket(ticket);             // (relaxed, behind a wait for the stores above: ek_bucketed.h)
+        *s_last_fixed = finish_ticket(ticket) ? 1u : 0u;  // (relaxed, behind a wait for the stores above: ek_bucketed.h)
 #ifdef EK_EARLY_TIMING
         const unsigned long long dt_tk = __builtin_readcyclecounter() - t_tk;
         atomicAdd(&g_early_timing[24], dt_tk); atomicMax(&g_early_timing[25], dt_tk);
 #endif
     }
+}
+__device__ __forceinline__ void bucket_finish_fixed_end(const uint32_t *s_last_fixed /* shared */, float *__restrict__ partials,
+                                                        uint32_t *__restrict__ ticket, float *__restrict__ out, const uint32_t *__restrict__ active,
+                                                        size_t n, int map_op, float *wave_part, long long *wave_ipart, uint32_t *__restrict__ counters) {
+    unsigned long long *ipartials = reinterpret_cast<unsigned long long *>(partials);
+    uint32_t *fpartials = reinterpret_cast<uint32_t *>(ipartials + gridDim.x);
     __syncthreads();
-    if (!s_last_fixed) return;
+    if (!*s_last_fixed) return;
     if (counters) {
         for (unsigned k = threadIdx.x; k < kPgTotalsWords + 4u; k += blockDim.x) counters[k] = 0u;
     }
@@ -417,14 +423,24 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     __shared__ uint32_t s_next;
     __shared__ uint32_t s_guard[2];
     __shared__ long long wave_ipart[Fixed ? kBucketWaves : 1];
+    __shared__ uint32_t s_last_fixed;
     constexpr bool Paired = sizeof(T) == 4;
     int bucket;
     PieceRange range;
 #ifdef EK_EARLY_TIMING
     const unsigned long long t_entry = __builtin_readcyclecounter();
 #endif
+    // (asked for before anything depends on it: a dependent round trip behind the staging barrier otherwise)
+    [[maybe_unused]] uint32_t xm_early = 0;
+    if constexpr (Fixed) {
+        xm_early = xmax_bits[0];
+        if (threadIdx.x == 0) { s_next = 5u * kBucketWaves; s_guard[0] = 0u; s_guard[1] = 0u; }       // (ordered before their users by bucket_piece's barrier)
+    }
     if (!bucket_piece<PS>(bl, bucket, range)) {
-        if constexpr (Fixed) bucket_finish_fixed(0ll, T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
+        if constexpr (Fixed) {
+            bucket_finish_fixed_begin(0ll, T(0), partials, fin.ticket, &s_last_fixed);
+            bucket_finish_fixed_end(&s_last_fixed, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
+        }
         else bucket_finish<T, EK_HSUM>(T(0), partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
         return;
     }
@@ -435,12 +451,17 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     unsigned long long fx_t[6] = { 0, 0, 0, 0, 0, 0 };
     fx_t[0] = __builtin_readcyclecounter();           // piece known
 #endif
-    stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c);
+    [[maybe_unused]] uint32_t slice_max[2] = { 0u, 0u };
+    stage_pair_slice<T, true>(rec, tables, table_a, table_c, (size_t) bucket * Bins, table_size, Bins, flip_a, flip_c, Fixed ? slice_max : nullptr);
     if constexpr (Fixed) {
         for (int j = threadIdx.x; j < 2 * 4096; j += kBucketThreads) reinterpret_cast<unsigned long long *>(tables)[j] = 0ull;     // both planes, whole areas
     }
     if constexpr (Fixed) {
-        if (threadIdx.x == 0) { s_next = 5u * kBucketWaves; s_guard[0] = 0u; s_guard[1] = 0u; }
+        // max |a|, max |c| over the slice, taken from the registers the slice was staged from (one pass, one barrier)
+        uint32_t am = slice_max[0], cm = slice_max[1];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) { am = max(am, (uint32_t) __shfl_xor((int) am, d, 64)); cm = max(cm, (uint32_t) __shfl_xor((int) cm, d, 64)); }
+        if ((threadIdx.x & 63) == 0) { atomicMax(&s_guard[0], am); atomicMax(&s_guard[1], cm); }
     }
     __syncthreads();
     T v = T(0);
@@ -483,26 +504,16 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
     [[maybe_unused]] long long iv = 0;            // Fixed: this lane's share of the reduced value, in units of 2^-28
     [[maybe_unused]] FixedScale fixed0{}, fixed1{};
     if constexpr (Fixed) {
-        const uint32_t xm = (uint32_t) __builtin_amdgcn_readfirstlane((int) xmax_bits[0]);
+        const uint32_t xm = (uint32_t) __builtin_amdgcn_readfirstlane((int) xm_early);
         const uint32_t E = xm >> 23;
         locks = E >= 255u || (E < (uint32_t) S0 + 1u && xm != 0u);
-        // max |a|, max |c| over the slice (as bits: a NaN or an infinity comes out on top)
-        uint32_t am = 0, cm = 0;
-        for (int j = threadIdx.x; j < Bins; j += kBucketThreads) {
-            am = max(am, __float_as_uint(rec[j].a) & 0x7FFFFFFFu);
-            cm = max(cm, __float_as_uint(rec[j].c) & 0x7FFFFFFFu);
-        }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) { am = max(am, (uint32_t) __shfl_xor((int) am, d, 64)); cm = max(cm, (uint32_t) __shfl_xor((int) cm, d, 64)); }
-        if ((threadIdx.x & 63) == 0) { atomicMax(&s_guard[0], am); atomicMax(&s_guard[1], cm); }
-        __syncthreads();
-        am = s_guard[0]; cm = s_guard[1];
+        const uint32_t am = s_guard[0], cm = s_guard[1];         // (max |a|, max |c| over the slice as bits: behind the staging barrier)
         const float ubound = __uint_as_float(am) * __uint_as_float(xm) + __uint_as_float(cm);
         const size_t piece_pages = (size_t) (range.f1 - range.f0) + (range.p1 - range.p0);
         if (am >= 0x7F800000u || cm >= 0x7F800000u || !(ubound < 1.0e18f) || (piece_pages << PS) >> (62 - S0)) locks = true;
         // a bucket that is ONE piece (the rule at the headline size: 256 buckets, 256 pieces): its sums are final -- converted here,
         // exactly as the fold would convert them, and written as floats (half the bytes out and back in; mode 1 like a piece under locks)
-        single = bl.piece_prefix[bucket + 1] - bl.piece_prefix[bucket] == 1u;
+        single = range.pieces == 1u;
         if (threadIdx.x == 0) piece_mode[blockIdx.x] = (locks || single) ? 1u : 0u;
         if (!locks) {
             fixed0 = fixed_scale(S0, xm, false);
@@ -559,6 +570,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
             for (int d = 8; d >= 1; d >>= 1) iv += bucket_shfl_down(iv, d);
         }
     }
+    if constexpr (Fixed) bucket_finish_fixed_begin(iv, v, partials, fin.ticket, &s_last_fixed);
     // table c (0: sum of the kept function, 1: sum of x * kept function) of this piece at table_partials + (c * gridDim.x + piece) * Bins
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
@@ -597,7 +609,7 @@ __global__ __launch_bounds__(kBucketThreads) void k_bucket_pair_forward_adjoint(
         fx_t[4] = __builtin_readcyclecounter();           // tables written
     }
 #endif
-    if constexpr (Fixed) bucket_finish_fixed(iv, v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
+    if constexpr (Fixed) bucket_finish_fixed_end(&s_last_fixed, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, wave_ipart, fin.counters);
     else bucket_finish<T, EK_HSUM>(v, partials, fin.ticket, fin.out, fin.active, fin.n, fin.zero_op, wave_part, fin.counters);
 #ifdef EK_EARLY_TIMING
     if constexpr (Fixed) {

@@ -19,9 +19,10 @@ template <typename T> struct alignas(2 * sizeof(T)) PairRec { T a, c; };
 // doubles), and -- ZeroTables -- the two gradient tables behind them cleared.  A thread requests all of its entries before it
 // uses the first: the loop used to wait for each pair of loads (Bins / 1024 = 8 or 16 dependent round trips per piece, 6-10 us
 // of every launch).  Entries beyond the table read its last entry and count as zero.
+/// max_bits (optional, [2]): max |a|, max |c| over this thread's share of the slice as bit patterns (a NaN or an infinity comes out on top)
 template <typename T, bool ZeroTables>
 __device__ __forceinline__ void stage_pair_slice(PairRec<T> *rec, T *tables, const T *__restrict__ table_a, const T *__restrict__ table_c,
-                                                 size_t first, size_t table_size, int Bins, int flip_a, int flip_c) {
+                                                 size_t first, size_t table_size, int Bins, int flip_a, int flip_c, uint32_t *max_bits = nullptr) {
     constexpr int U = 8;
     const size_t last = table_size - 1;
     for (int j0 = threadIdx.x; j0 < Bins; j0 += U * (int) blockDim.x) {
@@ -39,6 +40,12 @@ __device__ __forceinline__ void stage_pair_slice(PairRec<T> *rec, T *tables, con
             const int j = j0 + u * (int) blockDim.x;
             if (j < Bins) {
                 rec[j] = PairRec<T>{ flip_a ? -a[u] : a[u], flip_c ? -c[u] : c[u] };
+                if constexpr (sizeof(T) == 4) {
+                    if (max_bits) {
+                        max_bits[0] = max(max_bits[0], __float_as_uint((float) a[u]) & 0x7FFFFFFFu);
+                        max_bits[1] = max(max_bits[1], __float_as_uint((float) c[u]) & 0x7FFFFFFFu);
+                    }
+                }
                 if constexpr (ZeroTables) { tables[2 * j] = T(0); tables[2 * j + 1] = T(0); }
             }
         }
@@ -117,6 +124,7 @@ struct BucketLists {
 struct PieceRange {
     size_t begin, end;               // contiguous
     uint32_t f0, f1, p0, p1;         // paged
+    uint32_t pieces;                 // of the bucket this piece belongs to
 };
 
 // piece `blockIdx.x` -> its bucket and its share of the bucket's elements (the same cut as k_bin_accumulate)
@@ -145,6 +153,7 @@ __device__ __forceinline__ bool bucket_piece(const BucketLists &bl, int &bucket,
         b1 = b0 + per < hi ? b0 + per : hi;
     };
     r = PieceRange{};
+    r.pieces = (uint32_t) pieces;
     if constexpr (PS == 0) {
         cut(s_piece[3], s_piece[4], r.begin, r.end);
     } else {

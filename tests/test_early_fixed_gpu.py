@@ -199,3 +199,26 @@ def test_hint_is_ignored_beyond_256_quarter_size_buckets(capi):
     ii = idx.astype(np.int64)
     cnt = np.bincount(ii, minlength=K)
     assert (np.abs(g0.astype(np.float64) - np.bincount(ii, weights=kept, minlength=K)) <= EPS * (cnt + 1) * (cnt + 1)).all()
+
+
+def test_every_launch_reduces_its_own_partials(capi):
+    """The finish ticket of the bucket kernels is a RELAXED agent-scope atomic behind a wait for the wave's stores (csrc/ek_bucketed.h:
+    finish_ticket) -- no release fence.  A stale per-workgroup partial would be invisible wherever one step is repeated (yesterday's
+    partial equals today's), so: new values on every launch, the reduced value against float64 every time, at a size at which all
+    workgroups finish together (tools/stress_finish_ticket.py is the long form: 1200 launches, profiles/stress_finish_ticket_r06.txt)."""
+    rng = np.random.default_rng(11)
+    n, K = 1 << 20, 1 << 20
+    idx_h = rng.integers(0, K, n).astype(np.uint32)
+    di = up(capi, idx_h)
+    for r in range(24):
+        a_h, c_h = rng.uniform(-1, 1, K).astype(np.float32), rng.uniform(-1, 1, K).astype(np.float32)
+        x_h = (rng.uniform(-1, 1, n) * (1 + r % 3)).astype(np.float32)
+        dA, dC, dx = up(capi, a_h), up(capi, c_h), up(capi, x_h)
+        u = a_h[idx_h].astype(np.float64) * x_h + c_h[idx_h]
+        for half, hints in (("sin", capi.Bucketed.HINT_ADJOINT | capi.Bucketed.HINT_BOUNDED), ("exp", capi.Bucketed.HINT_ADJOINT)):
+            b = capi.Bucketed("fmadd", dA, dx, dC, di, hints=hints)
+            y = float(b.reduce("hsum", half, keep=True, keep_op="cos" if half == "sin" else "exp").numpy()[0])
+            b.destroy()
+            terms = np.sin(u) if half == "sin" else np.exp(u)
+            # (a workgroup's share is 1 / 256 of the terms; class D is ~1e-7 of the sum of magnitudes)
+            assert abs(y - float(terms.sum())) <= 2e-6 * float(np.abs(terms).sum()), (r, half, y, float(terms.sum()))
