@@ -374,6 +374,7 @@ __device__ __forceinline__ void bucket_finish_fixed_end(const uint32_t *s_last_f
     if (!*s_last_fixed) return;
     if (counters) {
         for (unsigned k = threadIdx.x; k < kPgTotalsWords + 4u; k += blockDim.x) counters[k] = 0u;
+        for (unsigned k = kPgMetaBase + kPgMetaAccumRep + threadIdx.x; k < kPgMetaBase + kPgMetaAccumRepEnd; k += blockDim.x) counters[k] = 0u;
     }
     long long iv = 0;
     float fv = 0.f;

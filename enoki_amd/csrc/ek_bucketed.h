@@ -324,6 +324,7 @@ __device__ __forceinline__ void bucket_finish(T block_result /* thread 0 */, T *
         // (page totals [2][kMaxBuckets], then the accumulators: elements kept, non-finite flag, the ticket -- stored as 0 again below --,
         //  max |x|)
         for (unsigned k = threadIdx.x; k < kPgTotalsWords + 4u; k += blockDim.x) counters[k] = 0u;
+        for (unsigned k = kPgMetaBase + kPgMetaAccumRep + threadIdx.x; k < kPgMetaBase + kPgMetaAccumRepEnd; k += blockDim.x) counters[k] = 0u;
     }
     T v = R::identity();
     for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) {

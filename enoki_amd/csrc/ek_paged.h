@@ -47,7 +47,10 @@ constexpr uint32_t kPgTotalsWords = (uint32_t) kPgReplicas * 2u * kMaxBuckets;
 constexpr uint32_t kPgMetaBase = kPgTotalsWords;                       // the meta row (kPgMeta* below)
 constexpr uint32_t kPgCounterWords = kPgTotalsWords + kMaxBuckets;     // what is zero when a launch starts
 // words of the meta row of the counter block (gtotal + kPgMetaBase): what the partition accumulates, the tickets, what the consumers read
-enum { kPgMetaAccum = 0 /* [2] */, kPgMetaFinishTicket = 2, kPgMetaAccumXmax = 3, kPgMetaResult = 4 /* [2] */, kPgMetaResultXmax = 6 };
+enum { kPgMetaAccum = 0 /* [2], unused since the accumulators are kept per replica */, kPgMetaFinishTicket = 2, kPgMetaAccumXmax = 3 /* unused */,
+       kPgMetaResult = 4 /* [2] */, kPgMetaResultXmax = 6,
+       kPgMetaAccumRep = 16 /* [kPgReplicas][4]: elements kept, non-finite flag, max |x| bits, - : one set per copy w % kPgReplicas, like the page totals */,
+       kPgMetaAccumRepEnd = kPgMetaAccumRep + 4 * kPgReplicas };
 // Workgroup w is dispatched to XCD w % 8, and on every box seen so far one XCD runs the same streaming work ~9 % slower than the
 // other seven (profiles/probe_paged_phases_r05.txt): with equal chunks the kernel ends when that XCD ends.  The eight CLASSES
 // w % 8 therefore get shares of the tiles in proportion to WEIGHTS (Q16, 65536 = 1) that live on the device and are fed back by
@@ -428,7 +431,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     if (threadIdx.x == 0) { out.dbg[(size_t) W * 16 + w * 4 + 0] = t_start; out.dbg[(size_t) W * 16 + w * 4 + 1] = t_loop; out.dbg[(size_t) W * 16 + w * 4 + 2] = wall_clock64(); }
 #endif
     if constexpr (HasMask) {
-        if (nonfinite_masked) atomicOr(out.active + 1, 1u);
+        if (nonfinite_masked) atomicOr(out.active + (kPgMetaAccumRep - kPgMetaAccum) + 4u * (w % kPgReplicas) + 1u, 1u);
     }
     {
         // (per wave into the LDS word that announced the overflow rounds -- free by now --, ONE global atomic per workgroup behind the
@@ -487,7 +490,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
         for (int j = 0; j < 4; ++j) kept += (full[j] << PS) + fl[j];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) kept += __shfl_xor(kept, d, 64);
-        if (l == 0 && kept) atomicAdd(out.active, kept);
+        if (l == 0 && kept) atomicAdd(out.active + (kPgMetaAccumRep - kPgMetaAccum) + 4u * (w % kPgReplicas), kept);
     }
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 0] = wall_clock64();
@@ -495,7 +498,7 @@ __global__ __launch_bounds__(kPgThreads) void k_page_partition(PagedOut<T> out, 
     // wdir in global memory was written by this workgroup: its stores have to be done, and it is read back past the L1
     if (!out.wdir_lds) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (!IndexOnly && threadIdx.x == 0 && s_over) atomicMax(out.active + kPgMetaAccumXmax, s_over);
+    if (!IndexOnly && threadIdx.x == 0 && s_over) atomicMax(out.active + (kPgMetaAccumRep - kPgMetaAccum) + 4u * (w % kPgReplicas) + 2u, s_over);
 #ifdef EK_PG_TIMING
     if (threadIdx.x == 0) out.dbg[(size_t) W * 16 + W * 4 + w * 4 + 1] = wall_clock64();
 #endif
@@ -651,8 +654,15 @@ static __global__ __launch_bounds__(256) void k_page_directory(uint32_t *__restr
     // what the partition accumulated (elements kept, "non-finite x under a cleared mask bit") goes to where the consumers read it;
     // the accumulators and the page totals are cleared by the last workgroup of the first reducing launch (bucket_finish), after
     // which the block can serve the next object without a fill (csrc/bucketed.hip: MetaRing)
-    if (b == 0 && slice == 0 && t < 2) gtotal[kPgMetaBase + kPgMetaResult + t] = gtotal[kPgMetaBase + kPgMetaAccum + t];
-    if (b == 0 && slice == 0 && t == 2) gtotal[kPgMetaBase + kPgMetaResultXmax] = gtotal[kPgMetaBase + kPgMetaAccumXmax];
+    if (b == 0 && slice == 0 && t < 3) {
+        uint32_t acc = 0;
+#pragma unroll
+        for (int r = 0; r < kPgReplicas; ++r) {
+            const uint32_t v = gtotal[kPgMetaBase + kPgMetaAccumRep + 4 * r + t];
+            acc = t == 2 ? max(acc, v) : acc + v;            // (elements kept: a sum; the flag: any; max |x|: as bits)
+        }
+        gtotal[kPgMetaBase + (t == 2 ? (int) kPgMetaResultXmax : (int) kPgMetaResult + t)] = acc;
+    }
     // Feedback for the next partition launch (class_w != nullptr only after a launch long enough to say something): a class's speed
     // is its share of the tiles over the mean loop duration of its workgroups; the new weight moves an eighth of the way towards
     // the share that would have made the durations equal, within [0.88, 1.12].  Equal durations are a fixed point; the class means
